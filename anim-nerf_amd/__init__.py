@@ -1,0 +1,16 @@
+"""anim_nerf_amd — MI355X-native per-ray rendering path of Anim-NeRF.
+
+Python host classes keep the reference's names and signatures (AnimNeRF, VolumeRenderer, NeRF,
+Embedding, SMPL/create, gen_rays, batched_inference); all per-ray and per-point work runs in
+libanimnerf_hip.so (hand-written HIP for gfx950, C ABI in include/animnerf_hip.h).
+"""
+from . import _lib, ops, synthetic                                   # noqa: F401
+from .anim_nerf import AnimNeRF, batch_transform                      # noqa: F401
+from .body_model import SMPL, create                                  # noqa: F401
+from .nerf import Embedding, NeRF                                     # noqa: F401
+from .rays import gen_ray_directions, gen_rays, get_ray_directions, get_rays   # noqa: F401
+from .render import (batched_inference, render_prepared, shard_range,          # noqa: F401
+                     sigma_grid_inference, system_forward)
+from .volume_rendering import VolumeRenderer                          # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,87 @@
+"""ctypes binding of libanimnerf_hip.so (the C ABI declared in include/animnerf_hip.h).
+
+There is deliberately no fallback: if the library is missing, or a tensor is not on a GPU,
+the calls raise.  The oracle under /oracle is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libanimnerf_hip.so")
+
+ANR_MLP_F32 = 0
+ANR_MLP_BF16 = 1
+ANR_MLP_FLAG_NO_DMA = 0x100
+ANR_MAX_SAMPLES = 256
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipCallFailed(RuntimeError):
+    pass
+
+
+# struct anr_mlp_params { w_trunk[8]; b_trunk[8]; w_sigma; b_sigma; w_final; b_final; w_dir; b_dir; w_rgb; b_rgb; }
+class AnrMlpParams(C.Structure):
+    _fields_ = [
+        ("w_trunk", C.c_void_p * 8), ("b_trunk", C.c_void_p * 8),
+        ("w_sigma", C.c_void_p), ("b_sigma", C.c_void_p),
+        ("w_final", C.c_void_p), ("b_final", C.c_void_p),
+        ("w_dir", C.c_void_p), ("b_dir", C.c_void_p),
+        ("w_rgb", C.c_void_p), ("b_rgb", C.c_void_p),
+    ]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); every symbol include/animnerf_hip.h declares
+SIGNATURES = {
+    "anr_version": (_I, []),
+    "anr_last_error": (C.c_char_p, []),
+    "anr_ray_gen": (_I, [_P, _P, _P, _I, _I, _F, _F, _P, _P]),
+    "anr_rays_to_body": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "anr_ober2cano": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "anr_knn": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),
+    "anr_sample_coarse": (_I, [_P, _I, _P, _P, _L, _I, _P, _P]),
+    "anr_warp_points": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _L, _F, _P, _P, _P, _P, _P]),
+    "anr_points_from_rays": (_I, [_P, _I, _P, _I, _L, _P, _P]),
+    "anr_mlp_pack_bytes": (_L, [_I]),
+    "anr_mlp_pack": (_I, [C.POINTER(AnrMlpParams), _I, _P, _P]),
+    "anr_mlp_forward": (_I, [_P, _I, _P, _L, _P, _P]),
+    "anr_composite": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
+    "anr_sample_fine_merge": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load():
+    """dlopen the library and type every entry point.  Raises HipLibraryMissing if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise HipLibraryMissing(
+                    f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc, gfx950). There is no CPU or PyTorch fallback for the rendering path.")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)        # AttributeError = header/library mismatch
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().anr_last_error()
+        raise HipCallFailed(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,135 @@
+"""`AnimNeRF` — the animatable field, with the reference's constructor, attributes and methods
+(models/anim_nerf.py:41-307) and its per-point work on the HIP library.
+
+Per frame (host, small):   set_body_model -> convert_to_body_model_space -> clac_ober2cano_transform
+Per point  (HIP kernels):  forward(xyz) = warp (exact 4-NN + blend) -> fused encode+MLP -> sigma mask
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .body_model import SMPL, create
+from .nerf import NeRF
+
+
+def batch_transform(P, v, pad_ones=True):
+    """(P @ [v, 1|0])[:3]   (models/anim_nerf.py:31-39)."""
+    out = (P[..., :3, :3] @ v[..., None])[..., 0]
+    return out + P[..., :3, 3] if pad_ones else out
+
+
+class AnimNeRF(nn.Module):
+    def __init__(self, model_path="smplx/models", model_type="smpl", gender="male", freqs_xyz=10, freqs_dir=4,
+                 use_view=False, use_unpose=False, unpose_view=False, k_neigh=4, use_knn=False,
+                 use_deformation=False, deformation_dim=0, apperance_dim=0, use_fine=False, share_fine=False,
+                 dis_threshold=0.2, query_inside=False, body_model_table=None, mlp_mode: Optional[str] = None,
+                 **kwargs):
+        super().__init__()
+        self.freqs_xyz, self.freqs_dir = freqs_xyz, freqs_dir
+        self.use_view, self.use_unpose, self.unpose_view = use_view, use_unpose, unpose_view
+        self.k_neigh, self.use_knn = k_neigh, use_knn
+        self.use_deformation, self.deformation_dim, self.apperance_dim = use_deformation, deformation_dim, apperance_dim
+        self.use_fine, self.share_fine = use_fine, share_fine
+        self.dis_threshold = dis_threshold
+        self.query_inside = query_inside
+        if use_deformation or query_inside:
+            raise NotImplementedError("use_deformation / query_inside are False in every shipped config and broken "
+                                      "in the reference (models/nerf.py:54, models/anim_nerf.py:257)")
+        if k_neigh != 4:
+            raise NotImplementedError("the HIP warp kernel is built for k_neigh = 4 (every shipped config)")
+
+        # `body_model_table` (a dict / SyntheticSMPL in SMPL-pickle layout) replaces the licensed file
+        if body_model_table is not None:
+            self.body_model = SMPL(data_struct=body_model_table, gender=gender)
+        else:
+            self.body_model = create(model_path, model_type, gender=gender)
+        self.weight_std = 0.1
+        self.lbs_dim = self.body_model.lbs_weights.shape[1]
+
+        mk = dict(freqs_xyz=freqs_xyz, freqs_dir=freqs_dir, use_view=use_view, deformation_dim=deformation_dim,
+                  apperance_dim=apperance_dim, mlp_mode=mlp_mode)
+        self.nerf = NeRF(**mk)
+        if use_fine:
+            self.nerf_fine = self.nerf if share_fine else NeRF(**mk)
+
+    # ------------------------------------------------------------------ per-frame state
+    def set_latent_code(self, latent_code):
+        if self.deformation_dim > 0:
+            self.deformation_code = latent_code[:, :self.deformation_dim]
+            if self.apperance_dim > 0:
+                self.apperance_code = latent_code[:, self.deformation_dim:self.deformation_dim + self.apperance_dim]
+        elif self.apperance_dim > 0:
+            self.apperance_code = latent_code[:, :self.apperance_dim]
+
+    def set_body_model(self, body_model_params, body_model_params_template=None):
+        o = self.body_model(**body_model_params, return_verts=True)
+        self.verts = o["vertices"]
+        self.joints = o["joints"][:, :self.lbs_dim]
+        self.verts_transform = o["vertices_transform"]
+        self.joints_transform = o["joints_transform"]
+        self.shape_offsets = o["shape_offsets"]
+        self.pose_offsets = o["pose_offsets"]
+        self.global_transform = o["joints_transform"][:, 0].clone()
+        if body_model_params_template is not None:
+            t = self.body_model(**body_model_params_template, return_verts=True)
+            self.verts_template = t["vertices"]
+            self.joints_template = t["joints"][:, :self.lbs_dim]
+            self.verts_transform_template = t["vertices_transform"]
+            self.joints_transform_template = t["joints_transform"]
+            self.shape_offsets_template = t["shape_offsets"]
+            self.pose_offsets_template = t["pose_offsets"]
+
+    def convert_to_body_model_space(self, rays):
+        """rays[bs,R,>=8] -> rays in the root-joint frame; moves the cached body state too."""
+        g_inv = torch.inverse(self.global_transform)                       # [bs,4,4]; bs tiny
+        new_rays = ops.rays_to_body(g_inv, rays)
+        G = g_inv[:, None]
+        self.verts = batch_transform(G, self.verts)
+        self.joints = batch_transform(G, self.joints)
+        self.global_transform = g_inv @ self.global_transform
+        self.verts_transform = G @ self.verts_transform
+        return new_rays
+
+    def clac_ober2cano_transform(self):
+        self.ober2cano_transform = ops.ober2cano(
+            self.verts_transform, self.verts_transform_template, self.shape_offsets, self.shape_offsets_template,
+            self.pose_offsets, self.pose_offsets_template)
+
+    # ------------------------------------------------------------------ per-point queries
+    def _net(self, use_fine):
+        return self.nerf_fine if use_fine else self.nerf
+
+    def unpose(self, xyz, viewdir=None):
+        """-> xyz_unposed[bs,N,3], viewdir, valid[bs,N,1]   (models/anim_nerf.py:180-192)."""
+        pts = ops.warp_points(self.verts, self.ober2cano_transform, self.body_model.lbs_weights,
+                              self.dis_threshold, xyz=xyz)
+        return pts[..., :3], viewdir, pts[..., 3:4]
+
+    def query_canonical_space(self, xyz, viewdir=None, use_fine=False, only_sigma=False, only_normal=False):
+        net = self._net(use_fine)
+        if only_sigma:
+            return net.get_sigma(xyz, only_sigma=True)
+        if only_normal:
+            return net.get_normal(xyz)
+        return net(xyz, viewdir=viewdir)
+
+    def warped_points(self, *, xyz=None, rays=None, z=None) -> torch.Tensor:
+        """pts[bs*N,4] = (canonical xyz, valid) for explicit points or for samples along rays."""
+        if self.use_unpose:
+            return ops.warp_points(self.verts, self.ober2cano_transform, self.body_model.lbs_weights,
+                                   self.dis_threshold, xyz=xyz, rays=rays, z=z).view(-1, 4)
+        if xyz is not None:
+            flat = xyz.reshape(-1, xyz.shape[-1])[:, :3]
+            return torch.cat([flat, torch.ones_like(flat[:, :1])], -1)
+        return ops.points_from_rays(rays, z)
+
+    def forward(self, xyz, viewdir=None, use_fine=False):
+        """xyz[bs,nv,3] -> rgb[bs,nv,3], sigma[bs,nv,1]; sigma = -1e5 outside dis_threshold."""
+        bs, nv = xyz.shape[:2]
+        pts = self.warped_points(xyz=xyz)
+        out = self._net(use_fine).eval_points(pts).view(bs, nv, 4)
+        return out[..., :3], out[..., 3:4]

@@ -1,0 +1,208 @@
+// Per-ray kernels: alpha compositing (a13) and importance sampling + merge (a14).
+// One 64-lane wavefront owns one ray; transmittance is a wavefront multiplicative scan
+// (DPP/shuffle), reductions are butterfly shuffles.  HBM-bound: 20 B per sample in, 4 out.
+#include "anr_common.h"
+
+#pragma clang fp contract(off)
+
+namespace anr {
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int MAXS = ANR_MAX_SAMPLES / WAVE;    // samples per lane, max
+
+// exclusive multiplicative scan across the wave; returns product of lanes < lane
+__device__ __forceinline__ float wave_excl_prod(float v, int lane) {
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc *= t;
+    }
+    float ex = __shfl_up(inc, 1, 64);
+    return lane == 0 ? 1.0f : ex;
+}
+
+__device__ __forceinline__ float wave_excl_sum(float v, int lane, float* total) {
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    *total = __shfl(inc, 63, 64);
+    float ex = __shfl_up(inc, 1, 64);
+    return lane == 0 ? 0.0f : ex;
+}
+
+// reference: models/volume_rendering.py:122-160
+template <int S>
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_kernel(
+    const float4* __restrict__ rgbs, const float* __restrict__ z, const float* __restrict__ rays, int stride,
+    const float* __restrict__ noise, int64_t R, int K, int white_bkgd, float* __restrict__ weights_out,
+    float* __restrict__ rgb_out, float* __restrict__ depth_out, float* __restrict__ acc_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float4* c = rgbs + r * K;
+    const float* zr = z + r * K;
+
+    float alpha[S], tr[S], zz[S];
+    float4 col[S];
+    float prod = 1.0f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        int k = lane * S + s;
+        alpha[s] = 0.0f; tr[s] = 1.0f; zz[s] = 0.0f; col[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K) {
+            col[s] = c[k];
+            zz[s] = zr[k];
+            float delta = (k + 1 < K) ? (zr[k + 1] - zz[s]) : 1e10f;
+            float sg = col[s].w;
+            if (noise != nullptr) sg = sg + noise[r * K + k];
+            alpha[s] = 1.0f - expf(-delta * fmaxf(sg, 0.0f));
+            tr[s] = prod;                                  // local exclusive product
+            prod = prod * (1.0f - alpha[s] + 1e-10f);
+        }
+    }
+    const float before = wave_excl_prod(prod, lane);
+    float wsum = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dep = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        int k = lane * S + s;
+        if (k < K) {
+            float w = alpha[s] * (before * tr[s]);
+            if (weights_out != nullptr) weights_out[r * K + k] = w;
+            wsum += w; cr += w * col[s].x; cg += w * col[s].y; cb += w * col[s].z; dep += w * zz[s];
+        }
+    }
+    wsum = wave_sum(wsum); cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); dep = wave_sum(dep);
+    if (lane == 0) {
+        if (white_bkgd) {
+            float far = rays[r * stride + 7];
+            dep = dep + (1.0f - wsum) * far;
+            cr = cr + 1.0f - wsum; cg = cg + 1.0f - wsum; cb = cb + 1.0f - wsum;
+        }
+        rgb_out[r * 3 + 0] = cr; rgb_out[r * 3 + 1] = cg; rgb_out[r * 3 + 2] = cb;
+        depth_out[r] = dep;
+        acc_out[r] = wsum;
+    }
+}
+
+// reference: models/volume_rendering.py:59-97 (sample_fine) and :199-207 (cat + sort)
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void sample_fine_merge_kernel(
+    const float* __restrict__ z_coarse, const float* __restrict__ weights, const float* __restrict__ u,
+    int u_per_ray, int64_t R, int Kc, int Kf, float* __restrict__ z_fine_out, float* __restrict__ z_sorted_out) {
+    __shared__ float lds[WAVES_PER_BLOCK][3 * ANR_MAX_SAMPLES];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int64_t r_raw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wv;
+    const bool active = r_raw < R;                        // tail waves compute ray R-1 again, store nothing
+    const int64_t r = active ? r_raw : R - 1;
+    float* zall = lds[wv];                                // [Kc + Kf] : coarse then fine depths
+    float* cdf = lds[wv] + ANR_MAX_SAMPLES;               // [Kc-1]
+    float* bins = lds[wv] + 2 * ANR_MAX_SAMPLES;          // [Kc-1]
+    const float eps = 1e-5f;
+    const int nb = Kc - 1;                                // bins and cdf entries
+    const int np = Kc - 2;                                // pdf entries
+
+    for (int k = lane; k < Kc; k += 64) zall[k] = z_coarse[r * Kc + k];
+    __syncthreads();
+    for (int k = lane; k < nb; k += 64) bins[k] = 0.5f * (zall[k] + zall[k + 1]);
+
+    // pdf over weights[1:-1] + eps; each lane owns a contiguous run of S entries
+    const int S = (np + 63) / 64;
+    float wl[MAXS];
+    float loc = 0.f;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        int i = lane * S + s;
+        wl[s] = (s < S && i < np) ? (weights[r * Kc + 1 + i] + eps) : 0.f;
+        loc += wl[s];
+    }
+    float total;
+    float base = wave_excl_sum(loc, lane, &total);
+    // cdf[0] = 0, cdf[i+1] = sum_{j<=i} pdf_j with pdf_j = w_j / total
+    if (lane == 0) cdf[0] = 0.f;
+    float run = 0.f;
+    {
+        // scan of pdf (not of w): divide first, as the reference does
+        float ploc = 0.f;
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) { wl[s] = wl[s] / total; ploc += wl[s]; }
+        float t2;
+        base = wave_excl_sum(ploc, lane, &t2);
+        run = base;
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            int i = lane * S + s;
+            if (s < S && i < np) { run += wl[s]; cdf[i + 1] = run; }
+        }
+    }
+    __syncthreads();
+
+    for (int j = lane; j < Kf; j += 64) {
+        float uu = u_per_ray ? u[r * Kf + j] : u[j];
+        int lo = 0, hi = nb;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (cdf[mid] <= uu) lo = mid + 1; else hi = mid; }
+        int below = max(lo - 1, 0), above = min(lo, Kc - 2);
+        float c0 = cdf[below], c1 = cdf[above], b0 = bins[below], b1 = bins[above];
+        float den = c1 - c0;
+        if (den < eps) den = 1.0f;
+        float zf = b0 + (uu - c0) / den * (b1 - b0);
+        zall[Kc + j] = zf;
+        if (active && z_fine_out != nullptr) z_fine_out[r * Kf + j] = zf;
+    }
+    __syncthreads();
+
+    // stable rank sort of the Kc+Kf depths (handles unsorted fine samples too)
+    const int K = Kc + Kf;
+    for (int p = lane; p < K; p += 64) {
+        float x = zall[p];
+        int rank = 0;
+        for (int q = 0; q < K; ++q) {
+            float y = zall[q];
+            rank += (y < x || (y == x && q < p)) ? 1 : 0;
+        }
+        if (active) z_sorted_out[r * K + rank] = x;
+    }
+}
+
+}  // namespace anr
+
+using namespace anr;
+
+extern "C" int anr_composite(const float* rgbs, const float* z, const float* rays, int stride, const float* noise,
+                             int64_t R, int K, int white_bkgd, float* weights_out, float* rgb_out,
+                             float* depth_out, float* acc_out, void* stream) {
+    ANR_REQUIRE(rgbs && z && rays && rgb_out && depth_out && acc_out, ANR_E_BADARG, "anr_composite: null pointer");
+    ANR_REQUIRE(R > 0 && K > 0 && stride >= 8, ANR_E_BADARG, "anr_composite: R=%lld K=%d stride=%d", (long long)R, K, stride);
+    ANR_REQUIRE(K <= ANR_MAX_SAMPLES, ANR_E_SHAPE, "anr_composite: K=%d > %d", K, ANR_MAX_SAMPLES);
+    ANR_REQUIRE(((uintptr_t)rgbs & 15) == 0, ANR_E_ALIGN, "anr_composite: rgbs must be 16-B aligned");
+    dim3 grid((unsigned)((R + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), block(WAVE * WAVES_PER_BLOCK);
+    const float4* c = reinterpret_cast<const float4*>(rgbs);
+    hipStream_t st = (hipStream_t)stream;
+    int S = (K + 63) / 64;
+#define ANR_LAUNCH_COMPOSITE(SS)                                                                          \
+    hipLaunchKernelGGL(composite_kernel<SS>, grid, block, 0, st, c, z, rays, stride, noise, R, K, white_bkgd, \
+                       weights_out, rgb_out, depth_out, acc_out)
+    switch (S) {
+        case 1: ANR_LAUNCH_COMPOSITE(1); break;
+        case 2: ANR_LAUNCH_COMPOSITE(2); break;
+        case 3: ANR_LAUNCH_COMPOSITE(3); break;
+        default: ANR_LAUNCH_COMPOSITE(4); break;
+    }
+#undef ANR_LAUNCH_COMPOSITE
+    return check_launch("anr_composite");
+}
+
+extern "C" int anr_sample_fine_merge(const float* z_coarse, const float* weights, const float* u, int u_per_ray,
+                                     int64_t R, int Kc, int Kf, float* z_fine_out, float* z_sorted_out,
+                                     void* stream) {
+    ANR_REQUIRE(z_coarse && weights && u && z_sorted_out, ANR_E_BADARG, "anr_sample_fine_merge: null pointer");
+    ANR_REQUIRE(R > 0 && Kc >= 3 && Kf > 0, ANR_E_BADARG, "anr_sample_fine_merge: R=%lld Kc=%d Kf=%d", (long long)R, Kc, Kf);
+    ANR_REQUIRE(Kc + Kf <= ANR_MAX_SAMPLES, ANR_E_SHAPE, "anr_sample_fine_merge: Kc+Kf=%d > %d", Kc + Kf, ANR_MAX_SAMPLES);
+    dim3 grid((unsigned)((R + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), block(WAVE * WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(sample_fine_merge_kernel, grid, block, 0, (hipStream_t)stream, z_coarse, weights, u,
+                       u_per_ray, R, Kc, Kf, z_fine_out, z_sorted_out);
+    return check_launch("anr_sample_fine_merge");
+}

@@ -1,0 +1,218 @@
+// Per-camera / per-frame / per-ray elementwise kernels (HBM-bound, one pass each):
+//   anr_ray_gen, anr_rays_to_body, anr_ober2cano, anr_sample_coarse, anr_points_from_rays.
+// Floating-point contraction is OFF in this file so that products and sums round exactly like
+// the reference's separate torch ops (z and x = o + z d come out bit-identical).
+#include "anr_common.h"
+#include <stdarg.h>
+
+#pragma clang fp contract(off)
+
+namespace anr {
+
+// ------------------------------------------------------------------ error plumbing
+char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ------------------------------------------------------------------ a1 ray generation
+// reference: datasets/anim_nerf_dataset.py:56-85
+__global__ void ray_gen_kernel(const float* __restrict__ c2w, const float* __restrict__ focal,
+                               const float* __restrict__ center, int H, int W, float near, float far,
+                               float* __restrict__ rays) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)H * W) return;
+    int j = (int)(p / W), i = (int)(p % W);
+    float dx = ((float)i - center[0]) / focal[0];
+    float dy = -((float)j - center[1]) / focal[1];
+    float dz = -1.0f;
+    float n = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx /= n; dy /= n; dz /= n;
+    float o[8];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        o[a] = c2w[a * 4 + 3];
+        o[3 + a] = dx * c2w[a * 4 + 0] + dy * c2w[a * 4 + 1] + dz * c2w[a * 4 + 2];
+    }
+    o[6] = near; o[7] = far;
+    float4* dst = reinterpret_cast<float4*>(rays + p * 8);
+    dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+
+// ------------------------------------------------------------------ a4 rays -> root frame
+// reference: models/anim_nerf.py:128-137
+__global__ void rays_to_body_kernel(const float* __restrict__ ginv, const float* __restrict__ rin,
+                                    float* __restrict__ rout, int R, int stride) {
+    int b = blockIdx.y;
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float* G = ginv + b * 16;
+    const float* s = rin + ((int64_t)b * R + r) * stride;
+    float o[3] = {s[0], s[1], s[2]}, d[3] = {s[3], s[4], s[5]};
+    float on[3], dn[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        on[a] = G[a * 4 + 0] * o[0] + G[a * 4 + 1] * o[1] + G[a * 4 + 2] * o[2] + G[a * 4 + 3];
+        dn[a] = G[a * 4 + 0] * d[0] + G[a * 4 + 1] * d[1] + G[a * 4 + 2] * d[2];
+    }
+    float dist = sqrtf(on[0] * on[0] + on[1] * on[1] + on[2] * on[2]);
+    float near = fmaxf(s[6], dist - 1.0f);
+    float far = fminf(s[7], dist + 1.0f);
+    float4* dst = reinterpret_cast<float4*>(rout + ((int64_t)b * R + r) * 8);
+    dst[0] = make_float4(on[0], on[1], on[2], dn[0]);
+    dst[1] = make_float4(dn[1], dn[2], near, far);
+}
+
+// ------------------------------------------------------------------ a5 observation -> canonical
+// reference: models/anim_nerf.py:147-151.  One thread per vertex; affine closed-form inverse.
+__global__ void ober2cano_kernel(const float* __restrict__ tp, const float* __restrict__ tt,
+                                 const float* __restrict__ so, const float* __restrict__ sot,
+                                 const float* __restrict__ po, const float* __restrict__ pot,
+                                 float* __restrict__ out, int64_t n) {
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    float A[12], B[12];
+    const float4* pa = reinterpret_cast<const float4*>(tp + v * 16);
+    const float4* pb = reinterpret_cast<const float4*>(tt + v * 16);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float4 a = pa[r], b = pb[r];
+        A[r * 4 + 0] = a.x; A[r * 4 + 1] = a.y; A[r * 4 + 2] = a.z; A[r * 4 + 3] = a.w;
+        B[r * 4 + 0] = b.x; B[r * 4 + 1] = b.y; B[r * 4 + 2] = b.z; B[r * 4 + 3] = b.w;
+    }
+    // inverse of the 3x3 block by cofactors
+    float c00 = A[5] * A[10] - A[6] * A[9];
+    float c01 = A[6] * A[8] - A[4] * A[10];
+    float c02 = A[4] * A[9] - A[5] * A[8];
+    float det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+    float id = 1.0f / det;
+    float I[12];
+    I[0] = c00 * id;
+    I[1] = (A[2] * A[9] - A[1] * A[10]) * id;
+    I[2] = (A[1] * A[6] - A[2] * A[5]) * id;
+    I[4] = c01 * id;
+    I[5] = (A[0] * A[10] - A[2] * A[8]) * id;
+    I[6] = (A[2] * A[4] - A[0] * A[6]) * id;
+    I[8] = c02 * id;
+    I[9] = (A[1] * A[8] - A[0] * A[9]) * id;
+    I[10] = (A[0] * A[5] - A[1] * A[4]) * id;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float t = -(I[r * 4 + 0] * A[3] + I[r * 4 + 1] * A[7] + I[r * 4 + 2] * A[11]);
+        t += sot[v * 3 + r] - so[v * 3 + r];
+        t += pot[v * 3 + r] - po[v * 3 + r];
+        I[r * 4 + 3] = t;
+    }
+    float4* dst = reinterpret_cast<float4*>(out + v * 16);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float o0 = B[r * 4 + 0] * I[0] + B[r * 4 + 1] * I[4] + B[r * 4 + 2] * I[8];
+        float o1 = B[r * 4 + 0] * I[1] + B[r * 4 + 1] * I[5] + B[r * 4 + 2] * I[9];
+        float o2 = B[r * 4 + 0] * I[2] + B[r * 4 + 1] * I[6] + B[r * 4 + 2] * I[10];
+        float o3 = B[r * 4 + 0] * I[3] + B[r * 4 + 1] * I[7] + B[r * 4 + 2] * I[11] + B[r * 4 + 3];
+        dst[r] = make_float4(o0, o1, o2, o3);
+    }
+    dst[3] = make_float4(0.f, 0.f, 0.f, 1.f);
+}
+
+// ------------------------------------------------------------------ a6 coarse depths
+// reference: models/volume_rendering.py:29-56
+__global__ void sample_coarse_kernel(const float* __restrict__ rays, int stride,
+                                     const float* __restrict__ steps, const float* __restrict__ t_rand,
+                                     int64_t R, int K, float* __restrict__ z_out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * K) return;
+    int64_t r = idx / K;
+    int k = (int)(idx % K);
+    float near = rays[r * stride + 6], far = rays[r * stride + 7];
+    auto zk = [&](int kk) { float s = steps[kk]; return near * (1.0f - s) + far * s; };
+    float z = zk(k);
+    if (t_rand != nullptr) {
+        float zl = (k > 0) ? zk(k - 1) : z, zu = (k + 1 < K) ? zk(k + 1) : z;
+        float lower = (k > 0) ? 0.5f * (z + zl) : z;
+        float upper = (k + 1 < K) ? 0.5f * (zu + z) : z;
+        z = lower + (upper - lower) * t_rand[idx];
+    }
+    z_out[idx] = z;
+}
+
+// ------------------------------------------------------------------ a7 sample points, no warp
+// reference: models/volume_rendering.py:117, models/anim_nerf.py:296-297
+__global__ void points_from_rays_kernel(const float* __restrict__ rays, int stride,
+                                        const float* __restrict__ z, int K, int64_t n,
+                                        float4* __restrict__ pts) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float* ry = rays + (idx / K) * stride;
+    float zz = z[idx];
+    pts[idx] = make_float4(ry[0] + zz * ry[3], ry[1] + zz * ry[4], ry[2] + zz * ry[5], 1.0f);
+}
+
+}  // namespace anr
+
+using namespace anr;
+
+extern "C" int anr_version(void) { return ANR_VERSION; }
+extern "C" const char* anr_last_error(void) { return err_buf(); }
+
+extern "C" int anr_ray_gen(const float* c2w, const float* focal, const float* center, int H, int W,
+                           float near, float far, float* rays_out, void* stream) {
+    ANR_REQUIRE(c2w && focal && center && rays_out, ANR_E_BADARG, "anr_ray_gen: null pointer");
+    ANR_REQUIRE(H > 0 && W > 0, ANR_E_BADARG, "anr_ray_gen: H=%d W=%d", H, W);
+    ANR_REQUIRE(((uintptr_t)rays_out & 15) == 0, ANR_E_ALIGN, "anr_ray_gen: rays_out must be 16-B aligned");
+    int64_t n = (int64_t)H * W;
+    hipLaunchKernelGGL(ray_gen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       c2w, focal, center, H, W, near, far, rays_out);
+    return check_launch("anr_ray_gen");
+}
+
+extern "C" int anr_rays_to_body(const float* g_inv, const float* rays_in, float* rays_out, int bs, int R,
+                                int stride_in, void* stream) {
+    ANR_REQUIRE(g_inv && rays_in && rays_out, ANR_E_BADARG, "anr_rays_to_body: null pointer");
+    ANR_REQUIRE(bs > 0 && R > 0 && stride_in >= 8, ANR_E_BADARG, "anr_rays_to_body: bs=%d R=%d stride=%d", bs, R, stride_in);
+    ANR_REQUIRE(((uintptr_t)rays_out & 15) == 0, ANR_E_ALIGN, "anr_rays_to_body: rays_out must be 16-B aligned");
+    hipLaunchKernelGGL(rays_to_body_kernel, dim3((R + 255) / 256, bs), dim3(256), 0, (hipStream_t)stream,
+                       g_inv, rays_in, rays_out, R, stride_in);
+    return check_launch("anr_rays_to_body");
+}
+
+extern "C" int anr_ober2cano(const float* t_pose, const float* t_template, const float* shape_off,
+                             const float* shape_off_t, const float* pose_off, const float* pose_off_t,
+                             float* out, int64_t n, void* stream) {
+    ANR_REQUIRE(t_pose && t_template && shape_off && shape_off_t && pose_off && pose_off_t && out,
+                ANR_E_BADARG, "anr_ober2cano: null pointer");
+    ANR_REQUIRE(n > 0, ANR_E_BADARG, "anr_ober2cano: n=%lld", (long long)n);
+    ANR_REQUIRE((((uintptr_t)t_pose | (uintptr_t)t_template | (uintptr_t)out) & 15) == 0, ANR_E_ALIGN,
+                "anr_ober2cano: matrices must be 16-B aligned");
+    hipLaunchKernelGGL(ober2cano_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
+                       t_pose, t_template, shape_off, shape_off_t, pose_off, pose_off_t, out, n);
+    return check_launch("anr_ober2cano");
+}
+
+extern "C" int anr_sample_coarse(const float* rays, int stride, const float* steps, const float* t_rand,
+                                 int64_t R, int K, float* z_out, void* stream) {
+    ANR_REQUIRE(rays && steps && z_out, ANR_E_BADARG, "anr_sample_coarse: null pointer");
+    ANR_REQUIRE(R > 0 && K > 0 && stride >= 8, ANR_E_BADARG, "anr_sample_coarse: R=%lld K=%d stride=%d", (long long)R, K, stride);
+    int64_t n = R * K;
+    hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays, stride, steps, t_rand, R, K, z_out);
+    return check_launch("anr_sample_coarse");
+}
+
+extern "C" int anr_points_from_rays(const float* rays, int ray_stride, const float* z, int K, int64_t n_points,
+                                    float* pts_out, void* stream) {
+    ANR_REQUIRE(rays && z && pts_out, ANR_E_BADARG, "anr_points_from_rays: null pointer");
+    ANR_REQUIRE(n_points > 0 && K > 0 && ray_stride >= 8, ANR_E_BADARG, "anr_points_from_rays: bad sizes");
+    ANR_REQUIRE(((uintptr_t)pts_out & 15) == 0, ANR_E_ALIGN, "anr_points_from_rays: pts_out must be 16-B aligned");
+    hipLaunchKernelGGL(points_from_rays_kernel, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, rays, ray_stride, z, K, n_points, reinterpret_cast<float4*>(pts_out));
+    return check_launch("anr_points_from_rays");
+}

@@ -1,0 +1,439 @@
+// Fused Fourier encoding + 8x256 NeRF MLP (a11 + a12) on CDNA4 matrix cores.
+//
+// Reference: models/embedding.py:22-39, models/nerf.py:129-175 (use_view = False).
+//
+// Shape of the computation.  The GEMMs are evaluated TRANSPOSED: out-features are the MFMA row
+// dimension (A operand = a 32-row weight tile), sample points are the column dimension
+// (B operand = activations), so D^T[feature][point] lands with each lane holding 16 features of
+// ONE point.  With the K index of the next layer's weights permuted to match (done once by
+// anr_mlp_pack), those 16 accumulators ARE the next layer's B fragments: activations never
+// leave registers for the whole 11-GEMM chain, there is no LDS/HBM round trip and no cross-lane
+// shuffle between layers.  Weights stream L2 -> LDS (double-buffered 32-row tiles, LDS-DMA) and are
+// shared by the workgroup's 4 wavefronts; each wavefront owns NT x 32 points.
+//
+//   mode BF16: v_mfma_f32_32x32x16_bf16, NT = 2 (64 points / wave, 256 / workgroup)
+//   mode F32 : v_mfma_f32_32x32x2_f32  , NT = 1 (32 points / wave, 128 / workgroup) — exact fp32
+//              fmaf chains, the parity mode.
+//
+// Slot algebra (h = lane>>5, i = lane&31; "frag" = 16 bytes per lane = 1 KiB per wave):
+//   accumulator reg (g = reg>>2, r = reg&3) of out-tile t  <->  out feature 32t + 8g + 4h + r
+//   BF16 frag b, elem e  <->  hidden feature 16b + 8(e>>2) + 4h + (e&3)   => frags 2t, 2t+1 = regs 0-7, 8-15
+//   F32  frag s, elem e  <->  hidden feature  8s + 4h + e                  => frags 4t..4t+3 = regs 4f..4f+3
+//   encoding panel: slot j in [0,32) (BF16: j = 8b+e, F32: j = 4s+e), half h:
+//       j < 30 : k = j/3, d = j%3 -> h ? cos(2^k x_d) : sin(2^k x_d)   (reference channel 3 + 6k + 3h + d)
+//       j = 30 : h ? x_2 : x_0 ;  j = 31 : h ? <pad, weight 0> : x_1
+//   so the two half-waves run one instruction stream (sin vs cos is a quadrant offset).
+#include "anr_common.h"
+
+namespace anr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MLP_THREADS = 256;
+constexpr int N_TILES_TOTAL = 78;              // 8*8 trunk + 9 (final + sigma) + 4 (dir) + 1 (rgb)
+constexpr int BIAS_BYTES = 10240;              // 78 tiles x 2 halves x 16 floats, padded
+constexpr int FRAG_BYTES = 1024;
+
+template <int MODE> struct Cfg;
+template <> struct Cfg<ANR_MLP_BF16> {
+    using Frag = bf16x8;
+    static constexpr int EPF = 8;    // elements per frag per lane
+    static constexpr int NT = 2;     // 32-point column tiles per wave
+    static constexpr int HF = 16;    // frags per 256 hidden features
+    static constexpr int EF = 4;     // frags of the 64-slot encoding panel
+    static constexpr int DF = 8;     // frags per 128 features (rgb head input)
+};
+template <> struct Cfg<ANR_MLP_F32> {
+    using Frag = f32x4;
+    static constexpr int EPF = 4;
+    static constexpr int NT = 1;
+    static constexpr int HF = 32;
+    static constexpr int EF = 8;
+    static constexpr int DF = 16;
+};
+
+// frags in chunk (= out-tile) c of the flat schedule
+template <class C> __host__ __device__ constexpr int chunk_frags(int c) {
+    return c < 8 ? C::EF : c < 32 ? C::HF : c < 40 ? C::EF + C::HF : c < 77 ? C::HF : c < 78 ? C::DF : 0;
+}
+template <class C> constexpr int total_frags() {
+    return 8 * C::EF + 24 * C::HF + 8 * (C::EF + C::HF) + 24 * C::HF + 9 * C::HF + 4 * C::HF + C::DF;
+}
+template <class C> constexpr int slot_bytes() { return (C::EF + C::HF) * FRAG_BYTES; }
+
+__device__ __forceinline__ void mma(const bf16x8& w, const bf16x8& x, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(const f32x4& w, const f32x4& x, f32x16& acc) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], x[e], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void put(bf16x8& f, int e, float v) { f[e] = (__bf16)v; }
+__device__ __forceinline__ void put(f32x4& f, int e, float v) { f[e] = v; }
+
+// sin(a) for q_off = 0, cos(a) for q_off = 1; Cody-Waite reduction by pi/2 + Cephes minimax polynomials (~1 ulp).
+__device__ __forceinline__ float sin_or_cos(float a, int q_off) {
+    const float n = rintf(a * 0.6366197466850281f);
+    float r = fmaf(-n, 1.5707963705062866f, a);
+    r = fmaf(-n, -4.371138828673793e-08f, r);
+    r = fmaf(-n, -1.7151245100058819e-15f, r);
+    const int q = (int)n + q_off;
+    const float z = r * r;
+    const float s = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float c = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                         fmaf(-0.5f, z, 1.0f));
+    float v = (q & 1) ? c : s;
+    return (q & 2) ? -v : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight staging: chunk = nf frags of 1 KiB; wave w moves pieces w, w+4, ...
+template <bool DMA>
+__device__ __forceinline__ void stage_chunk(const char* __restrict__ g, char* slot, int nf, int wave, int lane) {
+    if constexpr (DMA) {
+        for (int p = wave; p < nf; p += 4) {
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(g + p * FRAG_BYTES + lane * 16),
+                (__attribute__((address_space(3))) void*)(slot + p * FRAG_BYTES), 16, 0, 0);
+        }
+    } else {
+        for (int p = wave; p < nf; p += 4) {
+            uint4 v = *reinterpret_cast<const uint4*>(g + p * FRAG_BYTES + lane * 16);
+            *reinterpret_cast<uint4*>(slot + p * FRAG_BYTES + lane * 16) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int MODE, bool DMA>
+struct Mlp {
+    using C = Cfg<MODE>;
+    using Frag = typename C::Frag;
+    static constexpr int NT = C::NT, EPF = C::EPF, HF = C::HF, EF = C::EF, DF = C::DF;
+    static constexpr int FPT = 16 / EPF;          // next-layer frags produced per out-tile
+    static constexpr int SLOT = slot_bytes<C>();
+
+    // per-wave pipeline state
+    const char* gnext;       // global address of the next chunk to stage
+    char* lds_bias;
+    char* lds_slots;
+    int c;                   // chunk (out-tile) counter
+    int wave, lane, half;
+
+    __device__ __forceinline__ char* slot_of(int cc) { return lds_slots + (cc & 1) * SLOT; }
+
+    // barrier: chunk c has landed and slot (c+1)&1 is free -> stage chunk c+1 -> return slot of chunk c
+    __device__ __forceinline__ const char* advance() {
+        __syncthreads();
+        const int nf_next = chunk_frags<C>(c + 1);
+        stage_chunk<DMA>(gnext, slot_of(c + 1), nf_next, wave, lane);
+        gnext += nf_next * FRAG_BYTES;
+        return slot_of(c);
+    }
+
+    __device__ __forceinline__ void load_bias(f32x16 (&acc)[NT]) {
+        const f32x4* b = reinterpret_cast<const f32x4*>(lds_bias + c * 128 + half * 64);
+        f32x16 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 t = b[q];
+            v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = v;
+    }
+
+    // one out-tile: acc = bias + W_tile . [E (NFE frags), X (NFH frags)]
+    template <int NFE, int NFH, int XF>
+    __device__ __forceinline__ void tile(const Frag (&E)[NT][EF], const Frag (&X)[NT][XF], f32x16 (&acc)[NT]) {
+        const char* slot = advance();
+        load_bias(acc);
+        const Frag* wf = reinterpret_cast<const Frag*>(slot) + lane;
+#pragma unroll
+        for (int f = 0; f < NFE; ++f) {
+            const Frag w = wf[f * 64];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) mma(w, E[n][f], acc[n]);
+        }
+#pragma unroll
+        for (int f = 0; f < NFH; ++f) {
+            const Frag w = wf[(NFE + f) * 64];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) mma(w, X[n][f], acc[n]);
+        }
+        ++c;
+    }
+
+    // a full layer: NTILES out-tiles, activation, results become the next layer's frags
+    template <int NTILES, int NFE, int NFH, bool RELU, int XF, int YF>
+    __device__ __forceinline__ void layer(const Frag (&E)[NT][EF], const Frag (&X)[NT][XF], Frag (&Y)[NT][YF]) {
+#pragma unroll
+        for (int t = 0; t < NTILES; ++t) {
+            f32x16 acc[NT];
+            tile<NFE, NFH, XF>(E, X, acc);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int f = 0; f < FPT; ++f)
+#pragma unroll
+                    for (int e = 0; e < EPF; ++e) {
+                        float v = acc[n][f * EPF + e];
+                        if (RELU) v = fmaxf(v, 0.0f);
+                        put(Y[n][t * FPT + f], e, v);
+                    }
+        }
+    }
+
+    __device__ __forceinline__ void run(const char* __restrict__ pack, const float4* __restrict__ pts, int64_t n_pts,
+                                        float4* __restrict__ out, char* lds) {
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        lane = threadIdx.x & 63;
+        half = lane >> 5;
+        lds_bias = lds;
+        lds_slots = lds + BIAS_BYTES;
+        c = 0;
+
+        // resident bias table + first chunk
+        for (int i = threadIdx.x; i < BIAS_BYTES / 16; i += MLP_THREADS)
+            reinterpret_cast<uint4*>(lds_bias)[i] = reinterpret_cast<const uint4*>(pack)[i];
+        gnext = pack + BIAS_BYTES;
+        stage_chunk<DMA>(gnext, slot_of(0), chunk_frags<C>(0), wave, lane);
+        gnext += chunk_frags<C>(0) * FRAG_BYTES;
+
+        // this wave's points
+        const int64_t wave_base = ((int64_t)blockIdx.x * 4 + wave) * (NT * 32);
+        float4 p[NT];
+        Frag E[NT][EF];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            int64_t idx = wave_base + n * 32 + (lane & 31);
+            p[n] = pts[idx < n_pts ? idx : n_pts - 1];
+            const float xs[3] = {p[n].x, p[n].y, p[n].z};
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                float v;
+                if (j < 30) {
+                    const int k = j / 3, d = j % 3;
+                    v = sin_or_cos(xs[d] * (float)(1 << k), half);
+                } else if (j == 30) {
+                    v = half ? xs[2] : xs[0];
+                } else {
+                    v = half ? 0.0f : xs[1];
+                }
+                put(E[n][j / EPF], j % EPF, v);
+            }
+        }
+
+        Frag X[NT][HF], Y[NT][HF];
+        // layer 1: encoding -> 256
+        layer<8, EF, 0, true, HF, HF>(E, X, Y);
+        // layers 2..8 (layer 5 takes [encoding, hidden])
+#pragma nounroll
+        for (int l = 2; l <= 8; ++l) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int f = 0; f < HF; ++f) X[n][f] = Y[n][f];
+            if (l == 5) layer<8, EF, HF, true, HF, HF>(E, X, Y);
+            else        layer<8, 0, HF, true, HF, HF>(E, X, Y);
+        }
+        // xyz_encoding_final (no activation): Y -> X ; then the sigma row as a 9th tile
+        layer<8, 0, HF, false, HF, HF>(E, Y, X);
+        float sigma[NT];
+        {
+            f32x16 acc[NT];
+            tile<0, HF, HF>(E, Y, acc);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) sigma[n] = acc[n][0];
+        }
+        // dir_encoding: 256 -> 128, relu
+        Frag G[NT][DF];
+        layer<4, 0, HF, true, HF, DF>(E, X, G);
+        // rgb: 128 -> 3, sigmoid
+        {
+            f32x16 acc[NT];
+            tile<0, DF, DF>(E, G, acc);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                int64_t idx = wave_base + n * 32 + (lane & 31);
+                if (half == 0 && idx < n_pts) {
+                    float r = 1.0f / (1.0f + expf(-acc[n][0]));
+                    float g = 1.0f / (1.0f + expf(-acc[n][1]));
+                    float b = 1.0f / (1.0f + expf(-acc[n][2]));
+                    float s = (p[n].w < 1.0f) ? -1e5f : sigma[n];       // models/anim_nerf.py:305
+                    out[idx] = make_float4(r, g, b, s);
+                }
+            }
+        }
+    }
+};
+
+template <int MODE, bool DMA>
+__global__ __launch_bounds__(MLP_THREADS, 1) void mlp_kernel(const char* __restrict__ pack,
+                                                             const float4* __restrict__ pts, int64_t n_pts,
+                                                             float4* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    Mlp<MODE, DMA> m;
+    m.run(pack, pts, n_pts, out, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: one thread per (frag, lane) 16-byte piece; tail threads fill the bias table
+struct PackStage {
+    const float* W; const float* B;
+    int out_dim, in_dim, enc_cols, n_tiles, nf_enc, nf_hid, frag0, tile0;
+};
+struct PackPlan { PackStage s[12]; int n_stages; int total_frags; };
+
+__device__ __forceinline__ int enc_channel(int j, int h) {       // -1 = pad
+    if (j < 30) return 3 + 6 * (j / 3) + 3 * h + (j % 3);
+    if (j == 30) return h ? 2 : 0;
+    return h ? -1 : 1;
+}
+
+template <int MODE>
+__global__ void mlp_pack_kernel(PackPlan plan, char* __restrict__ pack) {
+    using C = Cfg<MODE>;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_pieces = (int64_t)plan.total_frags * 64;
+    if (gid < n_pieces) {
+        const int frag = (int)(gid >> 6), lane = (int)(gid & 63);
+        const int i = lane & 31, h = lane >> 5;
+        int si = 0;
+        while (si + 1 < plan.n_stages && plan.s[si + 1].frag0 <= frag) ++si;
+        const PackStage& st = plan.s[si];
+        const int per_tile = st.nf_enc + st.nf_hid;
+        const int t = (frag - st.frag0) / per_tile, kf = (frag - st.frag0) % per_tile;
+        const int row = 32 * t + i;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < C::EPF; ++e) {
+            int col;
+            if (kf < st.nf_enc) {
+                int ch = enc_channel(C::EPF * kf + e, h);
+                col = (ch >= 0 && ch < st.enc_cols) ? ch : -1;
+            } else {
+                int f = kf - st.nf_enc;
+                int feat = (MODE == ANR_MLP_BF16) ? 16 * f + 8 * (e >> 2) + 4 * h + (e & 3) : 8 * f + 4 * h + e;
+                col = st.enc_cols + feat;
+            }
+            v[e] = (row < st.out_dim && col >= 0 && col < st.in_dim) ? st.W[(int64_t)row * st.in_dim + col] : 0.0f;
+        }
+        char* dst = pack + BIAS_BYTES + (int64_t)frag * FRAG_BYTES + lane * 16;
+        if constexpr (MODE == ANR_MLP_BF16) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+            *reinterpret_cast<bf16x8*>(dst) = o;
+        } else {
+            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    } else {
+        const int64_t bi = gid - n_pieces;                 // float index into the bias table
+        if (bi >= BIAS_BYTES / 4) return;
+        const int T = (int)(bi / 32), h = (int)((bi % 32) / 16), reg = (int)(bi % 16);
+        float val = 0.0f;
+        if (T < N_TILES_TOTAL) {
+            int si = 0;
+            while (si + 1 < plan.n_stages && plan.s[si + 1].tile0 <= T) ++si;
+            const PackStage& st = plan.s[si];
+            const int row = 32 * (T - st.tile0) + 8 * (reg >> 2) + 4 * h + (reg & 3);
+            if (row < st.out_dim) val = st.B[row];
+        }
+        reinterpret_cast<float*>(pack)[bi] = val;
+    }
+}
+
+template <int MODE>
+PackPlan make_plan(const anr_mlp_params* p) {
+    using C = Cfg<MODE>;
+    PackPlan plan{};
+    int frag = 0, tile = 0, n = 0;
+    auto add = [&](const float* W, const float* B, int out_dim, int in_dim, int enc_cols, int n_tiles, int nfe, int nfh) {
+        plan.s[n++] = PackStage{W, B, out_dim, in_dim, enc_cols, n_tiles, nfe, nfh, frag, tile};
+        frag += n_tiles * (nfe + nfh);
+        tile += n_tiles;
+    };
+    add(p->w_trunk[0], p->b_trunk[0], 256, 63, 63, 8, C::EF, 0);
+    for (int l = 1; l < 8; ++l) {
+        if (l == 4) add(p->w_trunk[l], p->b_trunk[l], 256, 319, 63, 8, C::EF, C::HF);
+        else        add(p->w_trunk[l], p->b_trunk[l], 256, 256, 0, 8, 0, C::HF);
+    }
+    add(p->w_final, p->b_final, 256, 256, 0, 8, 0, C::HF);
+    add(p->w_sigma, p->b_sigma, 1, 256, 0, 1, 0, C::HF);
+    add(p->w_dir, p->b_dir, 128, 256, 0, 4, 0, C::HF);
+    add(p->w_rgb, p->b_rgb, 3, 128, 0, 1, 0, C::DF);
+    plan.n_stages = n;
+    plan.total_frags = frag;
+    return plan;
+}
+
+template <int MODE, bool DMA>
+int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStream_t st) {
+    using C = Cfg<MODE>;
+    const int lds = BIAS_BYTES + 2 * slot_bytes<C>();
+    auto kern = mlp_kernel<MODE, DMA>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail((int)e, "anr_mlp_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    const int pts_per_wg = 4 * C::NT * 32;
+    dim3 grid((unsigned)((n + pts_per_wg - 1) / pts_per_wg));
+    hipLaunchKernelGGL(kern, grid, dim3(MLP_THREADS), lds, st, reinterpret_cast<const char*>(pack),
+                       reinterpret_cast<const float4*>(pts), n, reinterpret_cast<float4*>(out));
+    return check_launch("anr_mlp_forward");
+}
+
+}  // namespace anr
+
+using namespace anr;
+
+#define ANR_MLP_FLAG_NO_DMA 0x100
+
+extern "C" int64_t anr_mlp_pack_bytes(int mode) {
+    switch (mode & 0xff) {
+        case ANR_MLP_F32:  return BIAS_BYTES + (int64_t)total_frags<Cfg<ANR_MLP_F32>>() * FRAG_BYTES;
+        case ANR_MLP_BF16: return BIAS_BYTES + (int64_t)total_frags<Cfg<ANR_MLP_BF16>>() * FRAG_BYTES;
+        default: return ANR_E_BADARG;
+    }
+}
+
+extern "C" int anr_mlp_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream) {
+    ANR_REQUIRE(p && pack_out, ANR_E_BADARG, "anr_mlp_pack: null pointer");
+    for (int l = 0; l < 8; ++l)
+        ANR_REQUIRE(p->w_trunk[l] && p->b_trunk[l], ANR_E_BADARG, "anr_mlp_pack: null trunk tensor %d", l);
+    ANR_REQUIRE(p->w_sigma && p->b_sigma && p->w_final && p->b_final && p->w_dir && p->b_dir && p->w_rgb && p->b_rgb,
+                ANR_E_BADARG, "anr_mlp_pack: null head tensor");
+    ANR_REQUIRE(((uintptr_t)pack_out & 15) == 0, ANR_E_ALIGN, "anr_mlp_pack: pack_out must be 16-B aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if ((mode & 0xff) == ANR_MLP_F32) {
+        PackPlan plan = make_plan<ANR_MLP_F32>(p);
+        int64_t n = (int64_t)plan.total_frags * 64 + BIAS_BYTES / 4;
+        hipLaunchKernelGGL(mlp_pack_kernel<ANR_MLP_F32>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, plan, (char*)pack_out);
+    } else if ((mode & 0xff) == ANR_MLP_BF16) {
+        PackPlan plan = make_plan<ANR_MLP_BF16>(p);
+        int64_t n = (int64_t)plan.total_frags * 64 + BIAS_BYTES / 4;
+        hipLaunchKernelGGL(mlp_pack_kernel<ANR_MLP_BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, plan, (char*)pack_out);
+    } else {
+        return fail(ANR_E_BADARG, "anr_mlp_pack: unknown mode %d", mode);
+    }
+    return check_launch("anr_mlp_pack");
+}
+
+extern "C" int anr_mlp_forward(const void* pack, int mode, const float* pts, int64_t n, float* out, void* stream) {
+    ANR_REQUIRE(pack && pts && out, ANR_E_BADARG, "anr_mlp_forward: null pointer");
+    ANR_REQUIRE(n > 0, ANR_E_BADARG, "anr_mlp_forward: n=%lld", (long long)n);
+    ANR_REQUIRE((((uintptr_t)pack | (uintptr_t)pts | (uintptr_t)out) & 15) == 0, ANR_E_ALIGN,
+                "anr_mlp_forward: pack/pts/out must be 16-B aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const bool dma = !(mode & ANR_MLP_FLAG_NO_DMA);
+    switch (mode & 0xff) {
+        case ANR_MLP_F32:
+            return dma ? launch_mlp<ANR_MLP_F32, true>(pack, pts, n, out, st) : launch_mlp<ANR_MLP_F32, false>(pack, pts, n, out, st);
+        case ANR_MLP_BF16:
+            return dma ? launch_mlp<ANR_MLP_BF16, true>(pack, pts, n, out, st) : launch_mlp<ANR_MLP_BF16, false>(pack, pts, n, out, st);
+        default:
+            return fail(ANR_E_BADARG, "anr_mlp_forward: unknown mode %d", mode);
+    }
+}

@@ -1,0 +1,113 @@
+"""`Embedding` and `NeRF` with the reference's constructor arguments and state-dict keys
+(models/embedding.py:5-39, models/nerf.py:60-190), evaluated by the fused HIP MLP kernel.
+
+Layers are created in the reference's order (trunk 1..8, final, dir, sigma, rgb), so
+`torch.manual_seed(s)` followed by construction gives the same random-init weights as the
+reference, and a reference checkpoint loads with `load_state_dict` unchanged.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Embedding(nn.Module):
+    """x -> (x, sin(2^k x), cos(2^k x))_k.  Stand-alone use is not on the hot path (the MLP
+    kernel fuses the encoding); this is the plain tensor-op form of models/embedding.py:22-39."""
+
+    def __init__(self, in_channels: int, N_freqs: int, logscale: bool = True):
+        super().__init__()
+        self.N_freqs = N_freqs
+        self.in_channels = in_channels
+        self.out_channels = in_channels * (2 * N_freqs + 1)
+        self.freq_bands = (2 ** torch.linspace(0, N_freqs - 1, N_freqs) if logscale
+                           else torch.linspace(1, 2 ** (N_freqs - 1), N_freqs))
+
+    def forward(self, x):
+        cols = [x]
+        for f in self.freq_bands.tolist():
+            cols += [torch.sin(f * x), torch.cos(f * x)]
+        return torch.cat(cols, -1)
+
+
+def _default_mode() -> str:
+    return os.environ.get("ANIMNERF_MLP_MODE", "f32")
+
+
+class NeRF(nn.Module):
+    def __init__(self, D=8, W=256, freqs_xyz=10, freqs_dir=4, use_view=True, use_normal=False,
+                 deformation_dim=0, apperance_dim=0, skips=[4], actvn_type="relu", mlp_mode: Optional[str] = None):
+        super().__init__()
+        self.D, self.W = D, W
+        self.freqs_xyz, self.freqs_dir = freqs_xyz, freqs_dir
+        self.deformation_dim, self.apperance_dim = deformation_dim, apperance_dim
+        self.skips = skips
+        self.use_view, self.use_normal = use_view, use_normal
+        self.mlp_mode = mlp_mode or _default_mode()
+
+        self.encoding_xyz = Embedding(3, freqs_xyz)
+        if use_view:
+            self.encoding_dir = Embedding(3, freqs_dir)
+        self.in_channels_xyz = 3 + 6 * freqs_xyz + deformation_dim
+        self.in_channels_dir = apperance_dim + (3 + 6 * freqs_dir if use_view else 0) + (3 if use_normal else 0)
+        if actvn_type != "relu":
+            raise NotImplementedError("the HIP MLP implements actvn_type='relu' (every shipped config)")
+
+        for i in range(D):
+            fan_in = self.in_channels_xyz if i == 0 else W + self.in_channels_xyz if i in skips else W
+            setattr(self, f"xyz_encoding_{i+1}", nn.Sequential(nn.Linear(fan_in, W), nn.ReLU(inplace=True)))
+        self.xyz_encoding_final = nn.Linear(W, W)
+        self.dir_encoding = nn.Sequential(nn.Linear(W + self.in_channels_dir, W // 2), nn.ReLU(True))
+        self.sigma = nn.Linear(W, 1)
+        self.rgb = nn.Sequential(nn.Linear(W // 2, 3), nn.Sigmoid())
+        self._pack_cache = {}
+
+    # -- weight pack (fragment-ordered copy for the kernel), rebuilt when any parameter changes
+    def _hip_supported(self):
+        return (self.D == 8 and self.W == 256 and self.freqs_xyz == 10 and list(self.skips) == [4]
+                and not self.use_view and not self.use_normal and self.deformation_dim == 0
+                and self.apperance_dim == 0)
+
+    def weight_pack(self, mode: Optional[str] = None):
+        if not self._hip_supported():
+            raise NotImplementedError(
+                "HIP MLP covers the shipped configuration: D=8, W=256, freqs_xyz=10, skips=[4], use_view=False, "
+                "no latent codes (configs/**/*.yaml)")
+        mode_id = ops.MLP_MODES[mode or self.mlp_mode]
+        params = {k: v for k, v in self.named_parameters()}
+        key = (mode_id, tuple((p.data_ptr(), p._version) for p in params.values()))
+        hit = self._pack_cache.get(mode_id)
+        if hit is None or hit[0] != key:
+            hit = (key, ops.mlp_pack(params, mode_id))
+            self._pack_cache[mode_id] = hit
+        return hit[1], mode_id
+
+    def eval_points(self, pts: torch.Tensor, mode: Optional[str] = None) -> torch.Tensor:
+        """pts[n,4] = (x,y,z,valid) -> [n,4] = (r,g,b,sigma).  The fused kernel entry."""
+        pack, mode_id = self.weight_pack(mode)
+        return ops.mlp_forward(pack, mode_id, pts)
+
+    def _pack_xyz(self, xyz):
+        flat = xyz.reshape(-1, 3)
+        return torch.cat([flat, torch.ones_like(flat[:, :1])], -1)
+
+    def forward(self, xyz, viewdir=None, deformation_code=None, apperance_code=None):
+        """models/nerf.py:129-153 -> (rgb[...,3], sigma[...,1])."""
+        out = self.eval_points(self._pack_xyz(xyz)).view(*xyz.shape[:-1], 4)
+        return out[..., :3], out[..., 3:4]
+
+    def get_sigma(self, xyz, deformation_code=None, only_sigma=False):
+        """models/nerf.py:155-175.  The 256-wide feature is internal to the fused kernel."""
+        if not only_sigma:
+            raise NotImplementedError("get_sigma(only_sigma=False): xyz_encoding_final is not exported by the fused kernel")
+        out = self.eval_points(self._pack_xyz(xyz)).view(*xyz.shape[:-1], 4)
+        return out[..., 3:4]
+
+    def get_normal(self, xyz, deformation_code=None, delta=0.02):
+        raise NotImplementedError("get_normal (training-only normals regulariser, models/nerf.py:177-190) "
+                                  "is not part of the forward rendering path built so far")

@@ -1,0 +1,218 @@
+"""Tensor-level wrappers around the C ABI: one Python function per `anr_*` entry point.
+
+PyTorch is only plumbing here (device memory, the current HIP stream).  Every function
+requires CUDA(=HIP) float32 tensors and raises otherwise — there is no eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ANR_MLP_BF16, ANR_MLP_F32, ANR_MLP_FLAG_NO_DMA, AnrMlpParams
+
+MLP_MODES = {"f32": ANR_MLP_F32, "fp32": ANR_MLP_F32, "bf16": ANR_MLP_BF16}
+
+
+def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the GPU (the HIP rendering path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+# ---------------------------------------------------------------------------------------------
+
+def ray_gen(c2w: torch.Tensor, H: int, W: int, focal: torch.Tensor, near: float, far: float,
+            center: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """rays[H,W,8] — datasets/anim_nerf_dataset.py:72-85."""
+    lib = _lib.load()
+    c2w = _dev(c2w, "c2w")
+    focal = _dev(focal, "focal")
+    if center is None:
+        center = torch.tensor([W * 0.5, H * 0.5], dtype=torch.float32, device=c2w.device)
+    center = _dev(center, "center")
+    rays = torch.empty(H, W, 8, dtype=torch.float32, device=c2w.device)
+    _lib.check(lib.anr_ray_gen(_ptr(c2w), _ptr(focal), _ptr(center), H, W, float(near), float(far),
+                               _ptr(rays), _stream(rays)), "anr_ray_gen")
+    return rays
+
+
+def rays_to_body(g_inv: torch.Tensor, rays: torch.Tensor) -> torch.Tensor:
+    """models/anim_nerf.py:128-137.  g_inv[bs,4,4], rays[bs,R,>=8] -> [bs,R,8]."""
+    lib = _lib.load()
+    g_inv = _dev(g_inv, "g_inv")
+    rays = _dev(rays, "rays")
+    bs, R, stride = rays.shape
+    out = torch.empty(bs, R, 8, dtype=torch.float32, device=rays.device)
+    _lib.check(lib.anr_rays_to_body(_ptr(g_inv), _ptr(rays), _ptr(out), bs, R, stride, _stream(rays)),
+               "anr_rays_to_body")
+    return out
+
+
+def ober2cano(t_pose, t_template, shape_off, shape_off_t, pose_off, pose_off_t) -> torch.Tensor:
+    """models/anim_nerf.py:147-151.  [bs,V,4,4] x2, [bs,V,3] x4 -> [bs,V,4,4]."""
+    lib = _lib.load()
+    t_pose = _dev(t_pose, "t_pose")
+    t_template = _dev(t_template, "t_template").expand_as(t_pose).contiguous()
+    so, sot = _dev(shape_off, "shape_off"), _dev(shape_off_t, "shape_off_t")
+    po, pot = _dev(pose_off, "pose_off"), _dev(pose_off_t, "pose_off_t")
+    sot = sot.expand_as(so).contiguous()
+    pot = pot.expand_as(po).contiguous()
+    out = torch.empty_like(t_pose)
+    n = t_pose.shape[0] * t_pose.shape[1]
+    _lib.check(lib.anr_ober2cano(_ptr(t_pose), _ptr(t_template), _ptr(so), _ptr(sot), _ptr(po), _ptr(pot),
+                                 _ptr(out), n, _stream(out)), "anr_ober2cano")
+    return out
+
+
+def knn(verts: torch.Tensor, xyz: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Drop-in for knn_cuda.KNN(k=4, transpose_mode=True)(ref, query) — models/anim_nerf.py:159."""
+    lib = _lib.load()
+    verts, xyz = _dev(verts, "verts"), _dev(xyz, "xyz")
+    bs, V, _ = verts.shape
+    N = xyz.shape[1]
+    dist = torch.empty(bs, N, 4, dtype=torch.float32, device=xyz.device)
+    idx = torch.empty(bs, N, 4, dtype=torch.int64, device=xyz.device)
+    _lib.check(lib.anr_knn(_ptr(verts), _ptr(xyz), bs, V, N, _ptr(dist), _ptr(idx), _stream(xyz)), "anr_knn")
+    return dist, idx
+
+
+def sample_coarse(rays: torch.Tensor, steps: torch.Tensor, t_rand: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """models/volume_rendering.py:29-56.  rays[..., >=8] (flattened to R) -> z[R,K]."""
+    lib = _lib.load()
+    rays = _dev(rays, "rays")
+    steps = _dev(steps, "steps")
+    stride = rays.shape[-1]
+    R = rays.numel() // stride
+    K = steps.numel()
+    z = torch.empty(R, K, dtype=torch.float32, device=rays.device)
+    if t_rand is not None:
+        t_rand = _dev(t_rand, "t_rand")
+    _lib.check(lib.anr_sample_coarse(_ptr(rays), stride, _ptr(steps), _ptr(t_rand), R, K, _ptr(z), _stream(z)),
+               "anr_sample_coarse")
+    return z
+
+
+def warp_points(verts, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays=None, z=None, debug=False):
+    """models/anim_nerf.py:153-192.  Either xyz[bs,N,3|4] or (rays[bs,R,>=8], z[bs,R,K]).
+    Returns pts[bs,N,4] = (x_c, y_c, z_c, valid) (+ dist[bs,N,4], idx[bs,N,4] i32, blended[bs,N] if debug)."""
+    lib = _lib.load()
+    verts, o2c, lbs_weights = _dev(verts, "verts"), _dev(o2c, "ober2cano"), _dev(lbs_weights, "lbs_weights")
+    bs, V, _ = verts.shape
+    J = lbs_weights.shape[1]
+    if xyz is not None:
+        xyz = _dev(xyz, "xyz")
+        N, xs = xyz.shape[1], xyz.shape[2]
+        rs, K = 0, 0
+    else:
+        rays, z = _dev(rays, "rays"), _dev(z, "z")
+        K = z.shape[-1]
+        N = z.shape[1] * K
+        rs, xs = rays.shape[-1], 0
+    dev = verts.device
+    pts = torch.empty(bs, N, 4, dtype=torch.float32, device=dev)
+    dist = idx = blended = None
+    if debug:
+        dist = torch.empty(bs, N, 4, dtype=torch.float32, device=dev)
+        idx = torch.empty(bs, N, 4, dtype=torch.int32, device=dev)
+        blended = torch.empty(bs, N, dtype=torch.float32, device=dev)
+    _lib.check(lib.anr_warp_points(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(verts), _ptr(o2c),
+                                   _ptr(lbs_weights), bs, V, J, N, float(dis_threshold), _ptr(pts), _ptr(dist),
+                                   _ptr(idx), _ptr(blended), _stream(pts)), "anr_warp_points")
+    return (pts, dist, idx, blended) if debug else pts
+
+
+def points_from_rays(rays: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    """x = o + z d, valid = 1 (use_unpose=False).  rays[..,R,>=8], z[..,R,K] -> pts[R*K,4]."""
+    lib = _lib.load()
+    rays, z = _dev(rays, "rays"), _dev(z, "z")
+    K = z.shape[-1]
+    n = z.numel()
+    pts = torch.empty(n, 4, dtype=torch.float32, device=z.device)
+    _lib.check(lib.anr_points_from_rays(_ptr(rays), rays.shape[-1], _ptr(z), K, n, _ptr(pts), _stream(pts)),
+               "anr_points_from_rays")
+    return pts
+
+
+def mlp_pack(params: dict, mode: int) -> torch.Tensor:
+    """Pack the 11 weight/bias tensors (reference state-dict keys, PyTorch [out,in] layout) for anr_mlp_forward."""
+    lib = _lib.load()
+    keep = []
+
+    def g(key):
+        t = _dev(params[key].detach(), key)
+        keep.append(t)
+        return t.data_ptr()
+    st = AnrMlpParams()
+    for i in range(8):
+        st.w_trunk[i] = g(f"xyz_encoding_{i+1}.0.weight")
+        st.b_trunk[i] = g(f"xyz_encoding_{i+1}.0.bias")
+    st.w_sigma, st.b_sigma = g("sigma.weight"), g("sigma.bias")
+    st.w_final, st.b_final = g("xyz_encoding_final.weight"), g("xyz_encoding_final.bias")
+    st.w_dir, st.b_dir = g("dir_encoding.0.weight"), g("dir_encoding.0.bias")
+    st.w_rgb, st.b_rgb = g("rgb.0.weight"), g("rgb.0.bias")
+    shapes = [(256, 63)] + [(256, 256)] * 3 + [(256, 319)] + [(256, 256)] * 3
+    for i, shp in enumerate(shapes):
+        if tuple(params[f"xyz_encoding_{i+1}.0.weight"].shape) != shp:
+            raise ValueError(f"xyz_encoding_{i+1}.0.weight: expected {shp}")
+    if tuple(params["dir_encoding.0.weight"].shape) != (128, 256) or tuple(params["rgb.0.weight"].shape) != (3, 128):
+        raise ValueError("head shapes must be dir_encoding [128,256], rgb [3,128] (use_view=False, no latent codes)")
+    nbytes = lib.anr_mlp_pack_bytes(mode & 0xff)
+    pack = torch.empty(nbytes, dtype=torch.uint8, device=keep[0].device)
+    _lib.check(lib.anr_mlp_pack(C.byref(st), mode & 0xff, _ptr(pack), _stream(pack)), "anr_mlp_pack")
+    return pack
+
+
+def mlp_forward(pack: torch.Tensor, mode: int, pts: torch.Tensor) -> torch.Tensor:
+    """pts[n,4] = (x,y,z,valid) -> out[n,4] = (r,g,b,sigma)."""
+    lib = _lib.load()
+    pts = _dev(pts, "pts")
+    n = pts.numel() // 4
+    out = torch.empty(n, 4, dtype=torch.float32, device=pts.device)
+    _lib.check(lib.anr_mlp_forward(_ptr(pack), mode, _ptr(pts), n, _ptr(out), _stream(out)), "anr_mlp_forward")
+    return out
+
+
+def composite(rgbs, z, rays, white_bkgd: bool, noise=None, want_weights: bool = True):
+    """models/volume_rendering.py:131-160.  rgbs[R,K,4], z[R,K], rays[R,>=8]."""
+    lib = _lib.load()
+    rgbs, z, rays = _dev(rgbs, "rgbs"), _dev(z, "z"), _dev(rays, "rays")
+    R, K = z.shape
+    dev = z.device
+    w = torch.empty(R, K, dtype=torch.float32, device=dev) if want_weights else None
+    rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    depth = torch.empty(R, 1, dtype=torch.float32, device=dev)
+    acc = torch.empty(R, 1, dtype=torch.float32, device=dev)
+    if noise is not None:
+        noise = _dev(noise, "noise")
+    _lib.check(lib.anr_composite(_ptr(rgbs), _ptr(z), _ptr(rays), rays.shape[-1], _ptr(noise), R, K,
+                                 1 if white_bkgd else 0, _ptr(w), _ptr(rgb), _ptr(depth), _ptr(acc), _stream(z)),
+               "anr_composite")
+    return w, rgb, depth, acc
+
+
+def sample_fine_merge(z_coarse, weights, u, want_fine: bool = False):
+    """models/volume_rendering.py:59-97,199-207.  z_coarse[R,Kc], weights[R,Kc], u[Kf] or u[R,Kf]."""
+    lib = _lib.load()
+    z_coarse, weights, u = _dev(z_coarse, "z_coarse"), _dev(weights, "weights"), _dev(u, "u")
+    R, Kc = z_coarse.shape
+    Kf = u.shape[-1]
+    per_ray = 1 if u.dim() > 1 else 0
+    dev = z_coarse.device
+    zf = torch.empty(R, Kf, dtype=torch.float32, device=dev) if want_fine else None
+    zs = torch.empty(R, Kc + Kf, dtype=torch.float32, device=dev)
+    _lib.check(lib.anr_sample_fine_merge(_ptr(z_coarse), _ptr(weights), _ptr(u), per_ray, R, Kc, Kf, _ptr(zf),
+                                         _ptr(zs), _stream(zs)), "anr_sample_fine_merge")
+    return (zs, zf) if want_fine else zs

@@ -1,0 +1,72 @@
+"""Frame drivers: the ray-chunk loop the reference repeats in train.py:189-215,
+novel_view.py:78-98, novel_pose.py:43-80 and extract_mesh.py:49-61, plus the one-process-per-GPU
+ray sharding used by bench.py (rays are independent, no collective on the data path).
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .anim_nerf import batch_transform
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) slice of n units owned by `rank`; sizes differ by at most one."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+@torch.no_grad()
+def batched_inference(volume_renderer, anim_nerf, rays, body_model_params, body_model_params_template,
+                      latent_code=None, P=None, chunk=2048) -> Dict[str, torch.Tensor]:
+    """novel_view.py:78-98.  rays[bs,n_rays,8] -> dict of [bs,n_rays,C]."""
+    anim_nerf.set_body_model(body_model_params, body_model_params_template)
+    rays = anim_nerf.convert_to_body_model_space(rays)
+    anim_nerf.clac_ober2cano_transform()
+    if latent_code is not None:
+        anim_nerf.set_latent_code(latent_code)
+    if P is not None:
+        rays = rays.clone()
+        rays[:, :, 0:3] = batch_transform(P, rays[:, :, 0:3], pad_ones=True)
+        rays[:, :, 3:6] = batch_transform(P, rays[:, :, 3:6], pad_ones=False)
+    return render_prepared(volume_renderer, anim_nerf, rays, chunk=chunk, perturb=0.0)
+
+
+@torch.no_grad()
+def render_prepared(volume_renderer, anim_nerf, rays, chunk=2048, perturb=0.0):
+    """The hot loop alone: per-frame state already set on `anim_nerf`, rays already in the body frame."""
+    n_rays = rays.shape[1]
+    pieces = defaultdict(list)
+    for i in range(0, n_rays, chunk):
+        part = volume_renderer(anim_nerf, rays[:, i:i + chunk], perturb=perturb)
+        for k, v in part.items():
+            pieces[k].append(v)
+    return {k: torch.cat(v, 1) for k, v in pieces.items()}
+
+
+@torch.no_grad()
+def system_forward(volume_renderer, anim_nerf, rays, body_model_params, body_model_params_template,
+                   latent_code=None, perturb=1.0, chunk=2048):
+    """AnimNeRFSystem.forward (train.py:189-215): rays[bs,h,w,8] -> dict of [bs,h,w,C]."""
+    bs, h, w = rays.shape[:3]
+    flat = rays.view(bs, h * w, -1)
+    anim_nerf.set_body_model(body_model_params, body_model_params_template)
+    flat = anim_nerf.convert_to_body_model_space(flat)
+    anim_nerf.clac_ober2cano_transform()
+    if latent_code is not None:
+        anim_nerf.set_latent_code(latent_code)
+    out = render_prepared(volume_renderer, anim_nerf, flat, chunk=chunk, perturb=perturb)
+    return {k: v.view(bs, h, w, -1) for k, v in out.items()}
+
+
+@torch.no_grad()
+def sigma_grid_inference(anim_nerf, points, chunk=32 * 32 * 64):
+    """extract_mesh.py:49-61: relu(sigma) of the (fine) field on explicit points[bs,nv,3]."""
+    out = []
+    for i in range(0, points.shape[1], chunk):
+        _, s = anim_nerf(points[:, i:i + chunk], None, use_fine=anim_nerf.use_fine)
+        out.append(torch.relu(s))
+    return torch.cat(out, 1)

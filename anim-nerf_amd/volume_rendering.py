@@ -1,0 +1,91 @@
+"""`VolumeRenderer` with the reference's constructor and `forward(model, rays, perturb, **kw) -> dict`
+(models/volume_rendering.py:7-232), running on the HIP library.
+
+When `model` is this package's AnimNeRF the sample points are never materialised as an xyz
+tensor: depths -> (warp | point-gen) kernel -> fused MLP kernel -> compositing kernel.  Any other
+callable `model(xyz, viewdir, use_fine=...) -> (rgb, sigma)` is served through the same sampling
+and compositing kernels with the points handed to it as the reference does.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class VolumeRenderer(nn.Module):
+    def __init__(self, n_coarse=64, n_fine=0, n_fine_depth=0, share_fine=False, noise_std=1.0, depth_std=0.02,
+                 white_bkgd=True, lindisp=True):
+        super().__init__()
+        self.n_coarse, self.n_fine, self.n_fine_depth = n_coarse, n_fine, n_fine_depth
+        self.share_fine = share_fine
+        self.noise_std, self.depth_std = noise_std, depth_std
+        self.lindisp, self.white_bkgd = lindisp, white_bkgd
+        if not lindisp:
+            raise NotImplementedError("lindisp=False (disparity sampling) is never selected by the reference's callers")
+        if n_fine_depth > 0:
+            raise NotImplementedError("n_fine_depth > 0 (depth-guided samples) is unused: n_depth = 0 in every config")
+        self._tables = {}
+
+    def _table(self, device, kind, n):
+        """linspace tables computed on the host exactly as the reference computes them (bit-identical z)."""
+        key = (str(device), kind, n)
+        t = self._tables.get(key)
+        if t is None:
+            t = torch.linspace(0, 1 - 1.0 / n, n) if kind == "steps" else torch.linspace(0., 1., steps=n)
+            t = t.to(device)
+            self._tables[key] = t
+        return t
+
+    # -- the three stages, usable on their own (and by the tests)
+    def sample_coarse(self, rays, perturb=0.):
+        bs, R = rays.shape[:2]
+        t_rand = None
+        if perturb > 0:
+            t_rand = perturb * torch.rand(bs * R, self.n_coarse, device=rays.device)
+        z = ops.sample_coarse(rays, self._table(rays.device, "steps", self.n_coarse), t_rand)
+        return z.view(bs, R, self.n_coarse)
+
+    def _shade(self, model, rays, z, coarse, perturb, want_weights, **kwargs):
+        bs, R, K = z.shape
+        fused = hasattr(model, "warped_points") and hasattr(model, "_net")
+        if fused:
+            pts = model.warped_points(rays=rays, z=z)
+            out = model._net(not coarse).eval_points(pts)
+        else:
+            xyz = (rays[..., None, :3] + z[..., None] * rays[..., None, 3:6]).reshape(bs, -1, 3)
+            viewdir = rays[..., None, 3:6].expand(-1, -1, K, -1).reshape(bs, -1, 3)
+            rgb, sigma = model(xyz, viewdir, use_fine=not coarse, **kwargs)
+            out = torch.cat([rgb.reshape(-1, 3), sigma.reshape(-1, 1)], -1)
+        noise = None
+        if self.noise_std > 0.0 and perturb > 0:
+            noise = torch.randn(bs * R, K, device=z.device) * self.noise_std
+        w, rgb, depth, acc = ops.composite(out.view(bs * R, K, 4), z.view(bs * R, K), rays.reshape(bs * R, -1),
+                                           self.white_bkgd, noise=noise, want_weights=want_weights)
+        return (w, rgb.view(bs, R, 3), depth.view(bs, R, 1), acc.view(bs, R, 1))
+
+    def sample_fine_sorted(self, z_coarse, weights, perturb=0.):
+        """z_sorted[bs,R,Kc+Kf] = sort(cat(z_coarse, inverse-CDF samples))."""
+        bs, R, Kc = z_coarse.shape
+        if perturb == 0:
+            u = self._table(z_coarse.device, "u", self.n_fine)
+        else:
+            u = torch.rand(bs * R, self.n_fine, device=z_coarse.device)
+        zs = ops.sample_fine_merge(z_coarse.view(bs * R, Kc), weights, u)
+        return zs.view(bs, R, Kc + self.n_fine)
+
+    @torch.no_grad()
+    def forward(self, model, rays, perturb=0., **kwargs):
+        rays = rays if rays.is_contiguous() else rays.contiguous()
+        z_coarse = self.sample_coarse(rays, perturb=perturb)
+        w, rgbs, depths, alphas = self._shade(model, rays, z_coarse, True, perturb, self.n_fine > 0, **kwargs)
+        output = {"rgbs": rgbs, "alphas": alphas, "depths": depths}
+        if self.n_fine > 0:
+            z_all = self.sample_fine_sorted(z_coarse, w, perturb)
+            _, rgbs_f, depths_f, alphas_f = self._shade(model, rays, z_all, False, perturb, False, **kwargs)
+            if self.share_fine:
+                output = {"rgbs": rgbs_f, "alphas": alphas_f, "depths": depths_f}
+            else:
+                output.update({"rgbs_fine": rgbs_f, "alphas_fine": alphas_f, "depths_fine": depths_f})
+        return output

@@ -1,0 +1,155 @@
+/*
+ * animnerf_hip.h — C ABI of libanimnerf_hip.so, the MI355X (gfx950) implementation
+ * of Anim-NeRF's per-ray rendering hot path.
+ *
+ * The reference (JanaldoChen/Anim-NeRF) has no FFI for this path: it sits behind
+ * Python nn.Module methods.  Each entry point below therefore
+ * cites the reference Python lines it replaces.  The only native code the reference
+ * calls on this path is the external KNN_CUDA wheel (`knn_cuda.KNN(k, transpose_mode=True)`,
+ * call site models/anim_nerf.py:82-83,159); `anr_knn` is its drop-in.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the device that owns `stream`
+ *     (`stream` is a hipStream_t passed as void*; NULL = the null stream);
+ *   - the caller allocates every input, output and workspace; the library never
+ *     allocates or frees device memory and keeps no pointer after return;
+ *   - calls only enqueue work (asynchronous w.r.t. the host);
+ *   - return value: 0 = ok, >0 = hipError_t, <0 = ANR_E_* ; anr_last_error() returns a
+ *     thread-local message for the last non-zero return;
+ *   - re-entrant, no global mutable state: safe from several host threads on
+ *     different devices/streams;
+ *   - all floating-point tensors are fp32 unless stated; index tensors are int64
+ *     where the reference returns int64 (KNN), int32 otherwise.
+ */
+#ifndef ANIMNERF_HIP_H
+#define ANIMNERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANR_VERSION 100           /* major*10000 + minor*100 + patch */
+
+#define ANR_E_BADARG   (-1)       /* null pointer / non-positive size */
+#define ANR_E_SHAPE    (-2)       /* unsupported shape (e.g. K > ANR_MAX_SAMPLES) */
+#define ANR_E_ALIGN    (-3)       /* pointer not aligned as documented */
+#define ANR_E_UNSUPP   (-4)       /* feature not built into this library */
+
+#define ANR_MAX_SAMPLES 256       /* samples per ray handled by composite / merge */
+#define ANR_KNN_K       4         /* neighbours (reference configs: k_neigh = 4) */
+
+/* MLP arithmetic modes (anr_mlp_*).  F32 is bit-for-bit an fp32 fmaf chain on the
+ * f32-input MFMA (parity mode, 1e-4 gate); BF16 rounds weights and activations to
+ * bf16 with fp32 accumulation (throughput mode, judged by PSNR). */
+#define ANR_MLP_F32   0
+#define ANR_MLP_BF16  1
+
+int         anr_version(void);
+const char* anr_last_error(void);
+
+/* ---- a1: ray generation --------------------------------------------------------
+ * datasets/anim_nerf_dataset.py:56-85 (gen_ray_directions + gen_rays; the dead twins
+ * utils/ray_utils.py:74-121 are the same with scalar focal, centre (W/2,H/2)).
+ * c2w[12] row-major 3x4; focal[2]; center[2] (all device fp32).
+ * rays_out[H*W*8] = [o(3), d(3), near, far], row-major over (row j, col i). */
+int anr_ray_gen(const float* c2w, const float* focal, const float* center,
+                int H, int W, float near, float far, float* rays_out, void* stream);
+
+/* ---- a4: rays into the root-joint frame -----------------------------------------
+ * models/anim_nerf.py:128-137: o' = Ginv [o,1], d' = Ginv [d,0],
+ * near' = max(near, |o'|-1), far' = min(far, |o'|+1).
+ * g_inv[bs*16] row-major 4x4 (inverse of global_transform); rays_in/out [bs*R*stride]
+ * (stride >= 8 floats; only the first 8 are read/written). */
+int anr_rays_to_body(const float* g_inv, const float* rays_in, float* rays_out,
+                     int bs, int R, int stride_in, void* stream);
+
+/* ---- a5: observation -> canonical per-vertex transform -----------------------------
+ * models/anim_nerf.py:147-151 (clac_ober2cano_transform):
+ *   M = inverse(T_pose); M[:3,3] += (shape_t - shape) + (pose_t - pose); out = T_template @ M.
+ * Matrices are affine (last row 0 0 0 1): the inverse is the closed-form 3x3 adjugate.
+ * t_pose, t_template, out: [n*16] row-major 4x4; offsets: [n*3] each. */
+int anr_ober2cano(const float* t_pose, const float* t_template,
+                  const float* shape_off, const float* shape_off_t,
+                  const float* pose_off, const float* pose_off_t,
+                  float* out, int64_t n, void* stream);
+
+/* ---- a8: exact k=4 nearest SMPL vertices (replaces knn_cuda.KNN) ----------------------
+ * models/anim_nerf.py:157-163.  verts[bs*V*3], xyz[bs*N*3] ->
+ * dist[bs*N*4] (Euclidean, ascending), idx[bs*N*4] (int64, 0-based vertex id). */
+int anr_knn(const float* verts, const float* xyz, int bs, int V, int64_t N,
+            float* dist_out, int64_t* idx_out, void* stream);
+
+/* ---- a6+a7: coarse depths and sample points ------------------------------------------
+ * models/volume_rendering.py:29-46 (lindisp=True branch) and :117:
+ *   z[r,k] = near (1 - s[k]) + far s[k];  if t_rand != NULL the stratified jitter of
+ *   :48-54 is applied with the caller's uniform numbers t_rand[R*K] (already multiplied by `perturb`).
+ * rays[R*stride]; steps[K] = torch.linspace(0, 1-1/K, K) supplied by the caller.
+ * z_out[R*K]. */
+int anr_sample_coarse(const float* rays, int stride, const float* steps, const float* t_rand,
+                      int64_t R, int K, float* z_out, void* stream);
+
+/* ---- a7-a10: points -> canonical space ----------------------------------------------------
+ * models/volume_rendering.py:117 + models/anim_nerf.py:153-192 (get_neighbs, unpose).
+ * Points are either given (xyz != NULL, [bs*N*xyz_stride]) or generated from rays and depths
+ * (xyz == NULL: point n = ray n / K, sample n % K, x = o + z d).
+ * Per body b: verts[b][V*3], ober2cano[b][V*16]; lbs_weights[V*J] shared.
+ * pts_out[bs*N*4] = (x_c, y_c, z_c, valid) with valid = 1.0 iff blended distance < dis_threshold.
+ * Optional debug outputs (may be NULL): dist_out[bs*N*4], idx_out[bs*N*4] (int32), blended_out[bs*N]. */
+int anr_warp_points(const float* xyz, int xyz_stride,
+                    const float* rays, int ray_stride, const float* z, int K,
+                    const float* verts, const float* ober2cano, const float* lbs_weights,
+                    int bs, int V, int J, int64_t N, float dis_threshold,
+                    float* pts_out, float* dist_out, int32_t* idx_out, float* blended_out,
+                    void* stream);
+
+/* Same output layout without the warp (use_unpose=False, models/anim_nerf.py:296-297):
+ * pts_out = (x, y, z, 1). */
+int anr_points_from_rays(const float* rays, int ray_stride, const float* z, int K,
+                         int64_t n_points, float* pts_out, void* stream);
+
+/* ---- a11+a12: Fourier encoding + 8x256 MLP ---------------------------------------------------
+ * models/embedding.py:22-39, models/nerf.py:129-175 (use_view=False, no latent codes).
+ * Weights are handed over pre-packed: anr_mlp_pack_bytes(mode) bytes produced by
+ * anr_mlp_pack() from the module's 11 weight/bias tensors in PyTorch [out,in] layout.
+ * pts[n*4] = (x,y,z,valid) -> out[n*4] = (r,g,b,sigma), sigma = -1e5 where valid < 1
+ * (models/anim_nerf.py:305). */
+int64_t anr_mlp_pack_bytes(int mode);
+
+typedef struct anr_mlp_params {
+    const float* w_trunk[8];  const float* b_trunk[8];   /* xyz_encoding_{1..8}.0: [256,63],[256,256]x3,[256,319],[256,256]x3 */
+    const float* w_sigma;     const float* b_sigma;      /* sigma: [1,256] */
+    const float* w_final;     const float* b_final;      /* xyz_encoding_final: [256,256] */
+    const float* w_dir;       const float* b_dir;        /* dir_encoding.0: [128,256] */
+    const float* w_rgb;       const float* b_rgb;        /* rgb.0: [3,128] */
+} anr_mlp_params;
+
+int anr_mlp_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream);
+
+int anr_mlp_forward(const void* pack, int mode, const float* pts, int64_t n,
+                    float* out, void* stream);
+
+/* ---- a13: alpha compositing ----------------------------------------------------------------------
+ * models/volume_rendering.py:131-160 (far=True, delta_last = 1e10).
+ * rgbs[R*K*4] = (r,g,b,sigma) per sample, z[R*K], rays[R*stride] (far' = rays[..,7]).
+ * noise (may be NULL): added to sigma before the relu (:128-129, caller supplies randn*noise_std).
+ * weights_out[R*K] (may be NULL), rgb_out[R*3], depth_out[R], acc_out[R]. */
+int anr_composite(const float* rgbs, const float* z, const float* rays, int stride,
+                  const float* noise, int64_t R, int K, int white_bkgd,
+                  float* weights_out, float* rgb_out, float* depth_out, float* acc_out,
+                  void* stream);
+
+/* ---- a14: importance sampling + merge ---------------------------------------------------------------
+ * models/volume_rendering.py:59-97 and :199-207: inverse-CDF samples over the Kc-1 mid-points
+ * with weights[1:-1]+1e-5, then sort(cat(z_coarse, z_fine)).
+ * u[Kf] if u_per_ray == 0 (deterministic linspace, shared), else u[R*Kf] (caller's uniforms).
+ * z_fine_out[R*Kf] (may be NULL), z_sorted_out[R*(Kc+Kf)]. */
+int anr_sample_fine_merge(const float* z_coarse, const float* weights, const float* u,
+                          int u_per_ray, int64_t R, int Kc, int Kf,
+                          float* z_fine_out, float* z_sorted_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANIMNERF_HIP_H */

@@ -1,0 +1,120 @@
+"""Pins the CPU oracle (oracle/animnerf_oracle.py) to outputs of the real reference
+(tests/golden/*.npz, produced by tests/golden/make_fixtures.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, net_params, oracle_table, seeded_model, tdict, weights_checksum
+from oracle import animnerf_oracle as orc
+
+from anim_nerf_amd import synthetic as syn
+
+TIGHT = dict(rtol=1e-5, atol=1e-6)
+
+
+def test_table_checksum(smpl_table):
+    assert syn.table_checksum(smpl_table) == str(golden("meta")["table_checksum"])
+
+
+def test_rays():
+    g = golden("rays")
+    rays = orc.make_rays(torch.from_numpy(g["c2w"]), int(g["H"]), int(g["W"]), g["focal"].tolist(),
+                         float(g["near"]), float(g["far"]), g["center"].tolist())
+    torch.testing.assert_close(rays, torch.from_numpy(g["rays"]), rtol=1e-6, atol=1e-7)
+
+
+def test_smpl_and_frame_state(smpl_table):
+    g = golden("frame")
+    tbl = oracle_table(smpl_table)
+    sub = torch.from_numpy(g["sub"])
+    st = orc.frame_state(tbl, tdict(g), {k: torch.from_numpy(v) for k, v in syn.template_pose_params().items()})
+    for key, ref in (("verts", "smpl_verts"), ("verts_transform", "smpl_T"), ("shape_offsets", "smpl_shape_offsets"),
+                     ("pose_offsets", "smpl_pose_offsets"), ("verts_template", "smpl_verts_template"),
+                     ("verts_transform_template", "smpl_T_template")):
+        torch.testing.assert_close(st[key][:, sub], torch.from_numpy(g[ref]), **TIGHT)
+    torch.testing.assert_close(st["joints"], torch.from_numpy(g["smpl_joints"]), **TIGHT)
+    torch.testing.assert_close(st["joints_transform"], torch.from_numpy(g["smpl_A"]), **TIGHT)
+    st2, rays_b = orc.to_root_frame(st, torch.from_numpy(g["rays_world"]))
+    torch.testing.assert_close(rays_b, torch.from_numpy(g["rays_body"]), **TIGHT)
+    torch.testing.assert_close(st2["verts"][:, sub], torch.from_numpy(g["verts_root"]), **TIGHT)
+    torch.testing.assert_close(st2["global_transform"], torch.from_numpy(g["global_transform"]), **TIGHT)
+    o2c = orc.observation_to_canonical(st2)
+    torch.testing.assert_close(o2c[:, sub], torch.from_numpy(g["ober2cano"]), rtol=1e-5, atol=2e-6)
+
+
+def _frame(smpl_table, pose, n_bodies_rays=None):
+    tbl = oracle_table(smpl_table)
+    st = orc.frame_state(tbl, pose, {k: torch.from_numpy(v) for k, v in syn.template_pose_params().items()})
+    return tbl, st
+
+
+def test_warp(smpl_table):
+    g, gf = golden("warp"), golden("frame")
+    tbl, st = _frame(smpl_table, tdict(gf))
+    st, _ = orc.to_root_frame(st, torch.from_numpy(gf["rays_world"]))
+    st["ober2cano"] = orc.observation_to_canonical(st)
+    xyz = torch.from_numpy(g["xyz"])
+    xyz_c, valid, dbg = orc.warp_to_canonical(xyz, st["verts"], tbl["lbs_weights"], st["ober2cano"], 0.2, chunk=1024)
+    torch.testing.assert_close(dbg["dist"], torch.from_numpy(g["knn_dist"]), **TIGHT)
+    assert (dbg["idx"].numpy() == g["knn_idx"]).mean() > 0.9999
+    torch.testing.assert_close(dbg["blended"], torch.from_numpy(g["blended_dist"]), **TIGHT)
+    assert (valid.numpy() == g["valid"]).all()
+    torch.testing.assert_close(xyz_c, torch.from_numpy(g["xyz_c"]), rtol=1e-4, atol=1e-5)
+    # K2: unposing posed vertices lands on the template vertices (up to the 4-neighbour blend), all valid
+    sub = torch.from_numpy(gf["sub"])
+    xv, vv, _ = orc.warp_to_canonical(st["verts"][:, sub], st["verts"], tbl["lbs_weights"], st["ober2cano"], 0.2)
+    torch.testing.assert_close(xv, torch.from_numpy(g["verts_unposed"]), rtol=1e-4, atol=1e-5)
+    assert (xv - st["verts_template"][:, sub]).abs().max() < 0.02
+    assert vv.min() == 1
+
+
+def test_mlp(smpl_table):
+    g, meta = golden("mlp"), golden("meta")
+    m = seeded_model(smpl_table, int(meta["mlp_seed"]), True)
+    assert weights_checksum(m.nerf) == str(meta["w_coarse"]) and weights_checksum(m.nerf_fine) == str(meta["w_fine"])
+    xyz = torch.from_numpy(g["xyz"])
+    torch.testing.assert_close(orc.fourier_encode(xyz[:, :64], 10), torch.from_numpy(g["enc64"]), rtol=0, atol=0)
+    for net, tag in ((m.nerf, "coarse"), (m.nerf_fine, "fine")):
+        rgb, sig = orc.mlp_forward(net_params(net), xyz)
+        torch.testing.assert_close(rgb, torch.from_numpy(g["rgb_" + tag]), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(sig, torch.from_numpy(g["sigma_" + tag]), rtol=1e-5, atol=1e-6)
+
+
+CASES = ["cfg2_nowarp", "cfg2_nowarp_gain", "cfg3_warp_gain", "cfg1_coarse32_warp", "yaml_64_32_warp"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_render_case(smpl_table, case):
+    g = golden("render_" + case)
+    m = seeded_model(smpl_table, g["seed"], g["use_unpose"], g["gain"], g["shift"])
+    assert weights_checksum(m.nerf) == str(g["w_coarse"]) and weights_checksum(m.nerf_fine) == str(g["w_fine"])
+    tbl = oracle_table(smpl_table)
+    templ = {k: torch.from_numpy(v) for k, v in syn.template_pose_params().items()}
+    out = orc.render_frame(tbl, net_params(m.nerf), net_params(m.nerf_fine), torch.from_numpy(g["rays_world"]),
+                           tdict(g), templ, n_coarse=int(g["n_coarse"]), n_fine=int(g["n_fine"]),
+                           use_unpose=bool(g["use_unpose"]), chunk=48, knn_chunk=1024)
+    torch.testing.assert_close(out["_rays_body"], torch.from_numpy(g["rays_body"]), **TIGHT)
+    torch.testing.assert_close(out["_z_coarse"], torch.from_numpy(g["z_coarse"]), rtol=0, atol=0)
+    tol = dict(rtol=1e-4, atol=2e-6)
+    torch.testing.assert_close(out["_weights"], torch.from_numpy(g["weights"]), **tol)
+    keys = ["rgbs", "alphas", "depths"]
+    if int(g["n_fine"]) > 0:
+        torch.testing.assert_close(out["_z_fine"], torch.from_numpy(g["z_fine"]), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(out["_z_sorted"], torch.from_numpy(g["z_sorted"]), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(out["_weights_fine"], torch.from_numpy(g["weights_fine"]), rtol=1e-3, atol=1e-5)
+        keys += ["rgbs_fine", "alphas_fine", "depths_fine"]
+    for k in keys:
+        torch.testing.assert_close(out[k], torch.from_numpy(g[k]), rtol=1e-4, atol=1e-5)
+
+
+def test_invariants_K3_K5_K6_K7():
+    """Closed-form known answers."""
+    rays = torch.tensor([[[0., 0, 0, 0, 0, -1, 2.0, 4.0]]])
+    z = orc.coarse_depths(rays, 8)
+    torch.testing.assert_close(z[0, 0], 2.0 + 2.0 * torch.arange(8) / 8)                       # K7
+    empty = lambda xyz, fine: (torch.full_like(xyz, 0.3), torch.full_like(xyz[..., :1], -1e5))   # K5
+    o = orc.render_rays(empty, rays, 8, 4)
+    assert torch.equal(o["rgbs_fine"], torch.ones(1, 1, 3)) and o["alphas_fine"].item() == 0 and o["depths_fine"].item() == 4.0
+    solid = lambda xyz, fine: (torch.full_like(xyz, 0.3), torch.full_like(xyz[..., :1], 0.01))    # K6
+    o = orc.render_rays(solid, rays, 8, 4)
+    assert abs(o["alphas_fine"].item() - 1.0) < 1e-6
