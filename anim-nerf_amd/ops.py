@@ -15,6 +15,28 @@ from ._lib import ANR_MLP_BF16, ANR_MLP_F32, ANR_MLP_FLAG_NO_DMA, AnrMlpParams
 
 MLP_MODES = {"f32": ANR_MLP_F32, "fp32": ANR_MLP_F32, "bf16": ANR_MLP_BF16}
 
+# When set to a list (bench.py does), every launch appends (name, start_event, end_event, units): HIP events
+# recorded on the stream the kernel is launched on, so elapsed_time() is that kernel's device time.
+KERNEL_TIMING = None
+
+
+class _timed:
+    def __init__(self, name, units):
+        self.name, self.units = name, units
+
+    def __enter__(self):
+        self.on = KERNEL_TIMING is not None
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            KERNEL_TIMING.append((self.name, self.e0, self.e1, self.units))
+        return False
+
 
 def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
@@ -100,8 +122,9 @@ def sample_coarse(rays: torch.Tensor, steps: torch.Tensor, t_rand: Optional[torc
     z = torch.empty(R, K, dtype=torch.float32, device=rays.device)
     if t_rand is not None:
         t_rand = _dev(t_rand, "t_rand")
-    _lib.check(lib.anr_sample_coarse(_ptr(rays), stride, _ptr(steps), _ptr(t_rand), R, K, _ptr(z), _stream(z)),
-               "anr_sample_coarse")
+    with _timed("sample_coarse", R * K):
+        _lib.check(lib.anr_sample_coarse(_ptr(rays), stride, _ptr(steps), _ptr(t_rand), R, K, _ptr(z), _stream(z)),
+                   "anr_sample_coarse")
     return z
 
 
@@ -128,9 +151,10 @@ def warp_points(verts, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
         dist = torch.empty(bs, N, 4, dtype=torch.float32, device=dev)
         idx = torch.empty(bs, N, 4, dtype=torch.int32, device=dev)
         blended = torch.empty(bs, N, dtype=torch.float32, device=dev)
-    _lib.check(lib.anr_warp_points(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(verts), _ptr(o2c),
-                                   _ptr(lbs_weights), bs, V, J, N, float(dis_threshold), _ptr(pts), _ptr(dist),
-                                   _ptr(idx), _ptr(blended), _stream(pts)), "anr_warp_points")
+    with _timed("warp_points", bs * N):
+        _lib.check(lib.anr_warp_points(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(verts), _ptr(o2c),
+                                       _ptr(lbs_weights), bs, V, J, N, float(dis_threshold), _ptr(pts), _ptr(dist),
+                                       _ptr(idx), _ptr(blended), _stream(pts)), "anr_warp_points")
     return (pts, dist, idx, blended) if debug else pts
 
 
@@ -141,8 +165,9 @@ def points_from_rays(rays: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     K = z.shape[-1]
     n = z.numel()
     pts = torch.empty(n, 4, dtype=torch.float32, device=z.device)
-    _lib.check(lib.anr_points_from_rays(_ptr(rays), rays.shape[-1], _ptr(z), K, n, _ptr(pts), _stream(pts)),
-               "anr_points_from_rays")
+    with _timed("points_from_rays", n):
+        _lib.check(lib.anr_points_from_rays(_ptr(rays), rays.shape[-1], _ptr(z), K, n, _ptr(pts), _stream(pts)),
+                   "anr_points_from_rays")
     return pts
 
 
@@ -181,7 +206,8 @@ def mlp_forward(pack: torch.Tensor, mode: int, pts: torch.Tensor) -> torch.Tenso
     pts = _dev(pts, "pts")
     n = pts.numel() // 4
     out = torch.empty(n, 4, dtype=torch.float32, device=pts.device)
-    _lib.check(lib.anr_mlp_forward(_ptr(pack), mode, _ptr(pts), n, _ptr(out), _stream(out)), "anr_mlp_forward")
+    with _timed("mlp_forward", n):
+        _lib.check(lib.anr_mlp_forward(_ptr(pack), mode, _ptr(pts), n, _ptr(out), _stream(out)), "anr_mlp_forward")
     return out
 
 
@@ -197,9 +223,10 @@ def composite(rgbs, z, rays, white_bkgd: bool, noise=None, want_weights: bool = 
     acc = torch.empty(R, 1, dtype=torch.float32, device=dev)
     if noise is not None:
         noise = _dev(noise, "noise")
-    _lib.check(lib.anr_composite(_ptr(rgbs), _ptr(z), _ptr(rays), rays.shape[-1], _ptr(noise), R, K,
-                                 1 if white_bkgd else 0, _ptr(w), _ptr(rgb), _ptr(depth), _ptr(acc), _stream(z)),
-               "anr_composite")
+    with _timed("composite", R * K):
+        _lib.check(lib.anr_composite(_ptr(rgbs), _ptr(z), _ptr(rays), rays.shape[-1], _ptr(noise), R, K,
+                                     1 if white_bkgd else 0, _ptr(w), _ptr(rgb), _ptr(depth), _ptr(acc), _stream(z)),
+                   "anr_composite")
     return w, rgb, depth, acc
 
 
@@ -213,6 +240,7 @@ def sample_fine_merge(z_coarse, weights, u, want_fine: bool = False):
     dev = z_coarse.device
     zf = torch.empty(R, Kf, dtype=torch.float32, device=dev) if want_fine else None
     zs = torch.empty(R, Kc + Kf, dtype=torch.float32, device=dev)
-    _lib.check(lib.anr_sample_fine_merge(_ptr(z_coarse), _ptr(weights), _ptr(u), per_ray, R, Kc, Kf, _ptr(zf),
-                                         _ptr(zs), _stream(zs)), "anr_sample_fine_merge")
+    with _timed("sample_fine_merge", R * (Kc + Kf)):
+        _lib.check(lib.anr_sample_fine_merge(_ptr(z_coarse), _ptr(weights), _ptr(u), per_ray, R, Kc, Kf, _ptr(zf),
+                                             _ptr(zs), _stream(zs)), "anr_sample_fine_merge")
     return (zs, zf) if want_fine else zs

@@ -38,7 +38,8 @@ def tdict(d, prefix="pose_"):
 
 
 def net_params(net):
-    return {k: v.detach() for k, v in net.named_parameters()}
+    """CPU copies of a NeRF module's parameters under the reference's state-dict keys."""
+    return {k: v.detach().cpu() for k, v in net.named_parameters()}
 
 
 def seeded_model(tbl, seed, use_unpose, gain=1.0, shift=(0.0, 0.0), device=None, **kw):

@@ -1,0 +1,314 @@
+"""GPU parity tests: every HIP entry point (through the C ABI, via anim_nerf_amd.ops / the module
+classes) against the CPU oracle on the same seeded inputs and against the reference's golden
+vectors.  Tolerance on rendered RGB / sigma: 1e-4 relative (BASELINE.json north_star), fp32 mode.
+Run with:  python -m pytest tests -m gpu
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, net_params, oracle_table, rel_err, seeded_model, tdict
+from oracle import animnerf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import anim_nerf_amd as ana
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    ana._lib.load()
+    return torch.device("cuda:0")
+
+
+def _templ(device=None):
+    from anim_nerf_amd import synthetic as syn
+    return {k: torch.from_numpy(v).to(device) if device else torch.from_numpy(v) for k, v in syn.template_pose_params().items()}
+
+
+def _to(d, device):
+    return {k: v.to(device) for k, v in d.items()}
+
+
+# ----------------------------------------------------------------------------- a1
+def test_ray_gen(dev):
+    import anim_nerf_amd as ana
+    g = golden("rays")
+    rays = ana.gen_rays(torch.from_numpy(g["c2w"]).to(dev), int(g["H"]), int(g["W"]), g["focal"].tolist(),
+                        float(g["near"]), float(g["far"]), g["center"].tolist())
+    torch.testing.assert_close(rays.cpu(), torch.from_numpy(g["rays"]), rtol=1e-6, atol=1e-6)
+    # full BASELINE size: unit directions, constant origin
+    c2w, focal, cen = ana.synthetic.pinhole_camera(1024, 1024)
+    big = ana.gen_rays(torch.from_numpy(c2w).to(dev), 1024, 1024, focal.tolist(), 0.1, 10.0, cen.tolist())
+    assert big.shape == (1024, 1024, 8)
+    assert (big[..., 3:6].norm(dim=-1) - 1).abs().max() < 1e-6 and big[..., :3].abs().max() == 0
+    ref = orc.make_rays(torch.from_numpy(c2w), 1024, 1024, focal.tolist(), 0.1, 10.0, cen.tolist())
+    torch.testing.assert_close(big.cpu(), ref, rtol=1e-6, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- a2-a5
+def test_frame_state(dev, smpl_table):
+    """set_body_model / convert_to_body_model_space / clac_ober2cano_transform vs the reference's outputs."""
+    g = golden("frame")
+    m = seeded_model(smpl_table, 7, True, device=dev)
+    m.set_body_model(_to(tdict(g), dev), _templ(dev))
+    sub = torch.from_numpy(g["sub"]).to(dev)
+    torch.testing.assert_close(m.verts[:, sub].cpu(), torch.from_numpy(g["smpl_verts"]), rtol=1e-5, atol=5e-6)
+    torch.testing.assert_close(m.verts_transform[:, sub].cpu(), torch.from_numpy(g["smpl_T"]), rtol=1e-5, atol=5e-6)
+    rays_b = m.convert_to_body_model_space(torch.from_numpy(g["rays_world"]).to(dev))
+    torch.testing.assert_close(rays_b.cpu(), torch.from_numpy(g["rays_body"]), rtol=1e-5, atol=5e-6)
+    torch.testing.assert_close(m.verts[:, sub].cpu(), torch.from_numpy(g["verts_root"]), rtol=1e-5, atol=5e-6)
+    m.clac_ober2cano_transform()
+    torch.testing.assert_close(m.ober2cano_transform[:, sub].cpu(), torch.from_numpy(g["ober2cano"]), rtol=1e-4, atol=1e-5)
+    # K1: ober2cano[v] . verts_posed[v] == verts_template[v]; K8: affine last row
+    import anim_nerf_amd as ana
+    back = ana.batch_transform(m.ober2cano_transform, m.verts)
+    assert (back - m.verts_template).abs().max() < 1e-5
+    last = m.ober2cano_transform[..., 3, :]
+    assert torch.equal(last, torch.tensor([0., 0, 0, 1], device=dev).expand_as(last))
+
+
+def _warp_frame(dev, smpl_table):
+    g = golden("frame")
+    m = seeded_model(smpl_table, 7, True, device=dev)
+    m.set_body_model(_to(tdict(g), dev), _templ(dev))
+    m.convert_to_body_model_space(torch.from_numpy(g["rays_world"]).to(dev))
+    m.clac_ober2cano_transform()
+    return m
+
+
+# ----------------------------------------------------------------------------- a8-a10
+def test_knn_matches_reference(dev, smpl_table):
+    import anim_nerf_amd as ana
+    g = golden("warp")
+    m = _warp_frame(dev, smpl_table)
+    xyz = torch.from_numpy(g["xyz"]).to(dev)
+    dist, idx = ana.ops.knn(m.verts, xyz)
+    assert idx.dtype == torch.int64 and dist.shape == (2, xyz.shape[1], 4)
+    d_ref, i_ref = torch.from_numpy(g["knn_dist"]), torch.from_numpy(g["knn_idx"]).long()
+    torch.testing.assert_close(dist.cpu(), d_ref, rtol=1e-5, atol=1e-6)
+    same = (idx.cpu() == i_ref)
+    # index differences are allowed only between (near-)tied distances
+    assert same.float().mean() > 0.999
+    tied = (dist.cpu() - d_ref).abs() <= 1e-6
+    assert (same | tied).all()
+    assert (dist[..., 1:] >= dist[..., :-1]).all()          # ascending
+
+
+def test_warp_matches_reference(dev, smpl_table):
+    import anim_nerf_amd as ana
+    g = golden("warp")
+    m = _warp_frame(dev, smpl_table)
+    xyz = torch.from_numpy(g["xyz"]).to(dev)
+    pts, dist, idx, blended = ana.ops.warp_points(m.verts, m.ober2cano_transform, m.body_model.lbs_weights, 0.2,
+                                                  xyz=xyz, debug=True)
+    b_ref = torch.from_numpy(g["blended_dist"])[..., 0]
+    ok = (blended.cpu() - b_ref).abs() <= 1e-5 + 1e-5 * b_ref.abs()
+    assert ok.float().mean() > 0.998, "blended distance mismatch beyond confidence-threshold flips"
+    v_ref = torch.from_numpy(g["valid"])[..., 0]
+    v_ok = (pts[..., 3].cpu() == v_ref) | ((b_ref - 0.2).abs() < 1e-5)
+    assert v_ok[ok].all()
+    x_ref = torch.from_numpy(g["xyz_c"])
+    err = (pts[..., :3].cpu() - x_ref).abs().max(-1).values
+    assert (err[ok] <= 1e-5 + RTOL * x_ref.abs().max(-1).values[ok]).all()
+    # module API: unpose() and forward()
+    xc, _, valid = m.unpose(xyz)
+    assert torch.equal(xc, pts[..., :3]) and torch.equal(valid[..., 0], pts[..., 3])
+    # K2 on the reference's output for posed vertices
+    sub = torch.from_numpy(golden("frame")["sub"]).to(dev)
+    xv, _, vv = m.unpose(m.verts[:, sub].contiguous())
+    torch.testing.assert_close(xv.cpu(), torch.from_numpy(g["verts_unposed"]), rtol=1e-4, atol=2e-5)
+    assert vv.min() == 1
+
+
+def test_warp_from_rays_equals_explicit_points(dev, smpl_table):
+    import anim_nerf_amd as ana
+    m = _warp_frame(dev, smpl_table)
+    g = golden("frame")
+    rays = torch.from_numpy(g["rays_body"]).to(dev)
+    vr = ana.VolumeRenderer(n_coarse=16)
+    z = vr.sample_coarse(rays)
+    a = ana.ops.warp_points(m.verts, m.ober2cano_transform, m.body_model.lbs_weights, 0.2, rays=rays, z=z)
+    xyz = (rays[..., None, :3] + z[..., None] * rays[..., None, 3:6]).reshape(2, -1, 3)
+    b = ana.ops.warp_points(m.verts, m.ober2cano_transform, m.body_model.lbs_weights, 0.2, xyz=xyz)
+    assert torch.equal(a, b)
+    # against the oracle
+    xc, valid, _ = orc.warp_to_canonical(xyz.cpu(), m.verts.cpu(), m.body_model.lbs_weights.cpu(),
+                                         m.ober2cano_transform.cpu(), 0.2, chunk=1024)
+    assert (a[..., 3].cpu() == valid[..., 0]).float().mean() > 0.999
+    assert ((a[..., :3].cpu() - xc).abs().max(-1).values < 1e-4).float().mean() > 0.998
+
+
+# ----------------------------------------------------------------------------- a11-a12
+@pytest.mark.parametrize("flag", [0, 0x100], ids=["lds_dma", "reg_staged"])
+def test_mlp_fp32_matches_reference(dev, smpl_table, flag):
+    import anim_nerf_amd as ana
+    g, meta = golden("mlp"), golden("meta")
+    m = seeded_model(smpl_table, int(meta["mlp_seed"]), True, device=dev)
+    xyz = torch.from_numpy(g["xyz"]).to(dev)[0]
+    pts = torch.cat([xyz, torch.ones_like(xyz[:, :1])], -1)
+    pts[5, 3] = 0.0                                            # one invalid point -> sigma = -1e5
+    for net, tag in ((m.nerf, "coarse"), (m.nerf_fine, "fine")):
+        pack, mode = net.weight_pack("f32")
+        out = ana.ops.mlp_forward(pack, mode | flag, pts).cpu()
+        rgb_ref, sig_ref = torch.from_numpy(g["rgb_" + tag])[0], torch.from_numpy(g["sigma_" + tag])[0, :, 0]
+        assert out[5, 3] == -1e5
+        keep = torch.arange(len(xyz)) != 5
+        assert rel_err(out[keep, :3], rgb_ref[keep]) < RTOL
+        assert ((out[keep, 3] - sig_ref[keep]).abs() <= RTOL * sig_ref[keep].abs() + 1e-4 * sig_ref.abs().median()).all()
+
+
+def test_mlp_bf16_close_to_fp32_and_tail_sizes(dev, smpl_table):
+    import anim_nerf_amd as ana
+    m = seeded_model(smpl_table, 7, True, device=dev)
+    gen = torch.Generator().manual_seed(9)
+    for n in (1, 31, 129, 1000):                                # ragged sizes: partial waves / partial workgroups
+        xyz = (torch.rand(n, 3, generator=gen) * 2 - 1).to(dev)
+        pts = torch.cat([xyz, torch.ones_like(xyz[:, :1])], -1)
+        f32 = m.nerf.eval_points(pts, "f32")
+        b16 = m.nerf.eval_points(pts, "bf16")
+        rgb_o, sig_o = orc.mlp_forward(net_params(m.nerf), xyz.cpu())
+        assert rel_err(f32[:, :3].cpu(), rgb_o) < RTOL and (f32[:, 3].cpu() - sig_o[:, 0]).abs().max() < 2e-6
+        assert (b16[:, :3] - f32[:, :3]).abs().max() < 2e-2 and (b16[:, 3] - f32[:, 3]).abs().max() < 5e-3
+
+
+def test_animnerf_forward_api(dev, smpl_table):
+    """AnimNeRF.forward(xyz) -> (rgb, sigma) as the mesh-extraction loop calls it (extract_mesh.py:49-61)."""
+    import anim_nerf_amd as ana
+    m = _warp_frame(dev, smpl_table)
+    g = golden("warp")
+    xyz = torch.from_numpy(g["xyz"]).to(dev)[:, :512].contiguous()
+    rgb, sigma = m(xyz, None, use_fine=True)
+    assert rgb.shape == (2, 512, 3) and sigma.shape == (2, 512, 1)
+    tbl = oracle_table(smpl_table)
+    st = dict(verts=m.verts.cpu(), ober2cano=m.ober2cano_transform.cpu())
+    rgb_o, sig_o = orc.field_query(net_params(m.nerf_fine), xyz.cpu(), st, tbl["lbs_weights"], True, 0.2, chunk=512)
+    inval = sig_o[..., 0] == -1e5
+    assert ((sigma[..., 0].cpu() == -1e5) == inval).float().mean() > 0.998
+    both = (~inval) & (sigma[..., 0].cpu() != -1e5)
+    assert rel_err(rgb.cpu()[both], rgb_o[both]) < 5e-4
+    sg = ana.sigma_grid_inference(m, xyz, chunk=200)
+    assert torch.equal(sg, torch.relu(sigma))
+
+
+# ----------------------------------------------------------------------------- a6, a13, a14
+def test_sampling_and_compositing_kernels(dev):
+    import anim_nerf_amd as ana
+    gen = torch.Generator().manual_seed(4)
+    R = 777                                                     # not a multiple of the 4 rays per workgroup
+    rays = torch.zeros(1, R, 8)
+    rays[..., 3:6] = torch.nn.functional.normalize(torch.randn(1, R, 3, generator=gen), dim=-1)
+    rays[..., :3] = torch.randn(1, R, 3, generator=gen)
+    rays[..., 6] = 1.5 + torch.rand(1, R, generator=gen)
+    rays[..., 7] = 3.5 + torch.rand(1, R, generator=gen)
+    for Kc, Kf in ((64, 64), (64, 32), (32, 16), (8, 5), (128, 128)):
+        vr = ana.VolumeRenderer(n_coarse=Kc, n_fine=Kf)
+        z = vr.sample_coarse(rays.to(dev))
+        z_o = orc.coarse_depths(rays, Kc)
+        assert torch.equal(z.cpu(), z_o), "coarse depths must be bit-identical"
+        rgbs = torch.rand(R, Kc, 3, generator=gen)
+        sig = torch.randn(R, Kc, generator=gen) * 20
+        sig[::7] = -1e5                                         # K5: empty rays
+        sig[3::7, -1] = 5.0                                     # K6: opaque tail
+        w_o, c_o, d_o, a_o = orc.composite(rgbs, sig, z_o[0], rays[0, :, 7:8])
+        packed = torch.cat([rgbs, sig[..., None]], -1).to(dev)
+        w, c, d, a = ana.ops.composite(packed, z[0], rays[0].to(dev), True)
+        torch.testing.assert_close(w.cpu(), w_o, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(c.cpu(), c_o, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(d.cpu(), d_o, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(a.cpu(), a_o, rtol=1e-5, atol=1e-6)
+        assert torch.equal(c[::7].cpu(), torch.ones_like(c[::7].cpu())) and a[::7].abs().max() == 0      # K5
+        assert (d[::7, 0].cpu() == rays[0, ::7, 7]).all()
+        # importance sampling + merge
+        zs, zf = ana.ops.sample_fine_merge(z[0], w, vr._table(dev, "u", Kf), want_fine=True)
+        zf_o = orc.fine_depths(z_o[0], w_o, Kf)
+        zs_o, _ = torch.sort(torch.cat([z_o[0], zf_o], -1), -1)
+        torch.testing.assert_close(zf.cpu(), zf_o, rtol=1e-5, atol=2e-5)
+        torch.testing.assert_close(zs.cpu(), zs_o, rtol=1e-5, atol=2e-5)
+        assert (zs[:, 1:] >= zs[:, :-1]).all()                  # sortedness
+        # merge is an exact permutation of its inputs
+        assert torch.equal(torch.sort(torch.cat([z[0], zf], -1), -1).values, zs)
+        # random u (training path): still an exact sort
+        u = torch.rand(R, Kf, generator=gen).to(dev)
+        zs2, zf2 = ana.ops.sample_fine_merge(z[0], w, u, want_fine=True)
+        assert torch.equal(torch.sort(torch.cat([z[0], zf2], -1), -1).values, zs2)
+        torch.testing.assert_close(zf2.cpu(), orc.fine_depths(z_o[0], w_o, Kf, u=u.cpu()), rtol=1e-5, atol=2e-5)
+
+
+# ----------------------------------------------------------------------------- a6-a15 end to end
+CASES = ["cfg2_nowarp", "cfg2_nowarp_gain", "cfg3_warp_gain", "cfg1_coarse32_warp", "yaml_64_32_warp"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_render_matches_reference(dev, smpl_table, case):
+    import anim_nerf_amd as ana
+    g = golden("render_" + case)
+    m = seeded_model(smpl_table, g["seed"], g["use_unpose"], g["gain"], g["shift"], device=dev)
+    vr = ana.VolumeRenderer(n_coarse=int(g["n_coarse"]), n_fine=int(g["n_fine"]), white_bkgd=True)
+    out = ana.batched_inference(vr, m, torch.from_numpy(g["rays_world"]).to(dev), _to(tdict(g), dev), _templ(dev),
+                                chunk=50)
+    keys = ["rgbs", "alphas", "depths"] + (["rgbs_fine", "alphas_fine", "depths_fine"] if int(g["n_fine"]) else [])
+    for k in keys:
+        ref = torch.from_numpy(g[k])
+        got = out[k].cpu()
+        assert got.shape == ref.shape
+        # rays whose samples straddle the validity threshold may flip one sample; allow <1% of rays
+        bad = ((got - ref).abs() > 1e-5 + RTOL * ref.abs()).any(-1)
+        assert bad.float().mean() <= 0.01, (k, bad.float().mean().item(), (got - ref).abs().max().item())
+    # stage-by-stage on the first chunk
+    rays_b = torch.from_numpy(g["rays_body"]).to(dev)
+    m.set_body_model(_to(tdict(g), dev), _templ(dev))
+    m.convert_to_body_model_space(torch.from_numpy(g["rays_world"]).to(dev))
+    m.clac_ober2cano_transform()
+    z = vr.sample_coarse(rays_b)
+    assert torch.equal(z.cpu(), torch.from_numpy(g["z_coarse"]))
+    w, _, _, _ = vr._shade(m, rays_b, z, True, 0.0, True)
+    w_ref = torch.from_numpy(g["weights"])[0]
+    assert (((w.cpu() - w_ref).abs() > 2e-6 + RTOL * w_ref.abs()).any(-1)).float().mean() <= 0.01
+
+
+def test_generic_model_path_equals_fused_path(dev, smpl_table):
+    """VolumeRenderer.forward(model=<any callable>) hands materialised xyz to the model, as the reference does."""
+    import anim_nerf_amd as ana
+    g = golden("render_cfg3_warp_gain")
+    m = seeded_model(smpl_table, g["seed"], True, g["gain"], g["shift"], device=dev)
+    m.set_body_model(_to(tdict(g), dev), _templ(dev))
+    rays = m.convert_to_body_model_space(torch.from_numpy(g["rays_world"]).to(dev))
+    m.clac_ober2cano_transform()
+    vr = ana.VolumeRenderer(n_coarse=64, n_fine=64)
+    fused = vr(m, rays)
+    generic = vr(lambda xyz, viewdir, use_fine=False: m(xyz, viewdir, use_fine=use_fine), rays)
+    for k in fused:
+        torch.testing.assert_close(generic[k], fused[k], rtol=1e-5, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- full BASELINE size
+def test_full_frame_properties(dev, smpl_table):
+    """1024 x 1024, 64 + 64 (BASELINE config 2) through size-independent properties:
+    determinism, chunk invariance, sortedness (inside the kernel tests), alpha range, fp32-vs-bf16 PSNR."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    g = golden("render_cfg2_nowarp_gain")
+    m = seeded_model(smpl_table, g["seed"], False, g["gain"], g["shift"], device=dev, mlp_mode="bf16")
+    H = W = 1024
+    c2w, focal, cen = syn.pinhole_camera(H, W)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), H, W, focal.tolist(), 0.1, 10.0, cen.tolist()).view(1, -1, 8)
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.static_pose_params().items()}
+    vr = ana.VolumeRenderer(n_coarse=64, n_fine=64)
+    a = ana.batched_inference(vr, m, rays, pose, _templ(dev), chunk=1 << 18)
+    b = ana.batched_inference(vr, m, rays, pose, _templ(dev), chunk=1 << 18)
+    c = ana.batched_inference(vr, m, rays, pose, _templ(dev), chunk=100003)
+    for k in a:
+        assert torch.equal(a[k], b[k]), "render must be deterministic"
+        assert torch.equal(a[k], c[k]), "render must not depend on the chunking"
+        assert torch.isfinite(a[k]).all()
+    assert a["alphas_fine"].min() >= 0 and a["alphas_fine"].max() <= 1 + 1e-5
+    assert a["rgbs_fine"].min() >= 0 and a["rgbs_fine"].max() <= 1 + 1e-5
+    # centre 256 x 256 crop in fp32 (parity mode) vs bf16: PSNR
+    idx = (torch.arange(384, 640)[:, None] * W + torch.arange(384, 640)[None]).reshape(-1).to(dev)
+    m.nerf.mlp_mode = m.nerf_fine.mlp_mode = "f32"
+    f = ana.batched_inference(vr, m, rays[:, idx].contiguous(), pose, _templ(dev), chunk=1 << 16)
+    psnr = orc.psnr(a["rgbs_fine"][:, idx].cpu(), f["rgbs_fine"].cpu())
+    assert psnr > 35.0, psnr
