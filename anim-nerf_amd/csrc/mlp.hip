@@ -8,8 +8,8 @@
 // ONE point.  With the K index of the next layer's weights permuted to match (done once by
 // anr_mlp_pack), those 16 accumulators ARE the next layer's B fragments: activations never
 // leave registers for the whole 11-GEMM chain, there is no LDS/HBM round trip and no cross-lane
-// shuffle between layers.  Weights stream L2 -> LDS (double-buffered 32-row tiles, LDS-DMA) and are
-// shared by the workgroup's 4 wavefronts; each wavefront owns NT x 32 points.
+// shuffle between layers.  Weights stream L2 -> LDS (32-row tiles through a 3-slot ring, LDS-DMA) and are
+// shared by the workgroup's 4 wavefronts (3-slot ring); each wavefront owns NT x 32 points.
 //
 //   mode BF16: v_mfma_f32_32x32x16_bf16, NT = 2 (64 points / wave, 256 / workgroup)
 //   mode F32 : v_mfma_f32_32x32x2_f32  , NT = 1 (32 points / wave, 128 / workgroup) — exact fp32
@@ -31,24 +31,33 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int MLP_THREADS = 256;
 constexpr int N_TILES_TOTAL = 78;              // 8*8 trunk + 9 (final + sigma) + 4 (dir) + 1 (rgb)
 constexpr int BIAS_BYTES = 10240;              // 78 tiles x 2 halves x 16 floats, padded
 constexpr int FRAG_BYTES = 1024;
 
+// MODE = arithmetic (ANR_MLP_F32 / ANR_MLP_BF16); VAR = workgroup shape variant
+constexpr int ANR_MLP_BF16_W8 = 2;   // internal: bf16 with 8 waves x 32 points (2 waves per SIMD)
 template <int MODE> struct Cfg;
 template <> struct Cfg<ANR_MLP_BF16> {
     using Frag = bf16x8;
+    static constexpr bool IS_BF16 = true;
     static constexpr int EPF = 8;    // elements per frag per lane
     static constexpr int NT = 2;     // 32-point column tiles per wave
+    static constexpr int WAVES = 4;  // wavefronts per workgroup
     static constexpr int HF = 16;    // frags per 256 hidden features
     static constexpr int EF = 4;     // frags of the 64-slot encoding panel
     static constexpr int DF = 8;     // frags per 128 features (rgb head input)
 };
+template <> struct Cfg<ANR_MLP_BF16_W8> : Cfg<ANR_MLP_BF16> {
+    static constexpr int NT = 1;
+    static constexpr int WAVES = 8;
+};
 template <> struct Cfg<ANR_MLP_F32> {
     using Frag = f32x4;
+    static constexpr bool IS_BF16 = false;
     static constexpr int EPF = 4;
     static constexpr int NT = 1;
+    static constexpr int WAVES = 4;
     static constexpr int HF = 32;
     static constexpr int EF = 8;
     static constexpr int DF = 16;
@@ -74,6 +83,16 @@ __device__ __forceinline__ void mma(const f32x4& w, const f32x4& x, f32x16& acc)
 __device__ __forceinline__ void put(bf16x8& f, int e, float v) { f[e] = (__bf16)v; }
 __device__ __forceinline__ void put(f32x4& f, int e, float v) { f[e] = v; }
 
+// Materialise a fragment in VGPRs HERE: keeps hipcc from carrying a whole layer of un-converted fp32
+// accumulators (8 tiles x 32 registers) and doing the activation/convert pass at the end of the layer.
+__device__ __forceinline__ void pin(bf16x8& f) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 t = __builtin_bit_cast(u32x4, f);
+    asm volatile("" : "+v"(t));
+    f = __builtin_bit_cast(bf16x8, t);
+}
+__device__ __forceinline__ void pin(f32x4& f) { asm volatile("" : "+v"(f)); }
+
 // sin(a) for q_off = 0, cos(a) for q_off = 1; Cody-Waite reduction by pi/2 + Cephes minimax polynomials (~1 ulp).
 __device__ __forceinline__ float sin_or_cos(float a, int q_off) {
     const float n = rintf(a * 0.6366197466850281f);
@@ -91,16 +110,16 @@ __device__ __forceinline__ float sin_or_cos(float a, int q_off) {
 
 // ---------------------------------------------------------------------------------------------
 // weight staging: chunk = nf frags of 1 KiB; wave w moves pieces w, w+4, ...
-template <bool DMA>
+template <bool DMA, int WAVES>
 __device__ __forceinline__ void stage_chunk(const char* __restrict__ g, char* slot, int nf, int wave, int lane) {
     if constexpr (DMA) {
-        for (int p = wave; p < nf; p += 4) {
+        for (int p = wave; p < nf; p += WAVES) {
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(g + p * FRAG_BYTES + lane * 16),
                 (__attribute__((address_space(3))) void*)(slot + p * FRAG_BYTES), 16, 0, 0);
         }
     } else {
-        for (int p = wave; p < nf; p += 4) {
+        for (int p = wave; p < nf; p += WAVES) {
             uint4 v = *reinterpret_cast<const uint4*>(g + p * FRAG_BYTES + lane * 16);
             *reinterpret_cast<uint4*>(slot + p * FRAG_BYTES + lane * 16) = v;
         }
@@ -112,26 +131,32 @@ template <int MODE, bool DMA>
 struct Mlp {
     using C = Cfg<MODE>;
     using Frag = typename C::Frag;
-    static constexpr int NT = C::NT, EPF = C::EPF, HF = C::HF, EF = C::EF, DF = C::DF;
+    static constexpr int NT = C::NT, EPF = C::EPF, HF = C::HF, EF = C::EF, DF = C::DF, WAVES = C::WAVES;
+    static constexpr int THREADS = WAVES * 64;
     static constexpr int FPT = 16 / EPF;          // next-layer frags produced per out-tile
     static constexpr int SLOT = slot_bytes<C>();
 
-    // per-wave pipeline state
-    const char* gnext;       // global address of the next chunk to stage
+    // per-wave pipeline state.  Weight chunks (one 32-row out-tile each) flow through a 3-slot LDS ring:
+    // while tile c is being multiplied, chunk c+1 is already resident (its first fragments are pulled into
+    // registers before tile c ends) and chunk c+2 is in flight on the LDS-DMA engine.
+    const char* gnext;       // global address of the next chunk to stage (chunk c+2)
     char* lds_bias;
-    char* lds_slots;
+    char* slot_cur;          // LDS slot of chunk c
+    char* slot_nxt;          // LDS slot of chunk c+1
+    char* slot_stage;        // LDS slot chunk c+2 is staged into
     int c;                   // chunk (out-tile) counter
     int wave, lane, half;
 
-    __device__ __forceinline__ char* slot_of(int cc) { return lds_slots + (cc & 1) * SLOT; }
-
-    // barrier: chunk c has landed and slot (c+1)&1 is free -> stage chunk c+1 -> return slot of chunk c
-    __device__ __forceinline__ const char* advance() {
+    // barrier: chunk c+1 has landed everywhere and nobody reads chunk c-1 any more -> stage chunk c+2 over it
+    __device__ __forceinline__ void advance() {
         __syncthreads();
-        const int nf_next = chunk_frags<C>(c + 1);
-        stage_chunk<DMA>(gnext, slot_of(c + 1), nf_next, wave, lane);
-        gnext += nf_next * FRAG_BYTES;
-        return slot_of(c);
+        const int nf = chunk_frags<C>(c + 2);
+        stage_chunk<DMA, WAVES>(gnext, slot_stage, nf, wave, lane);
+        gnext += nf * FRAG_BYTES;
+    }
+    __device__ __forceinline__ void rotate() {
+        char* t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_stage; slot_stage = t;
+        ++c;
     }
 
     __device__ __forceinline__ void load_bias(f32x16 (&acc)[NT]) {
@@ -146,34 +171,52 @@ struct Mlp {
         for (int n = 0; n < NT; ++n) acc[n] = v;
     }
 
-    // one out-tile: acc = bias + W_tile . [E (NFE frags), X (NFH frags)]
+    // one out-tile: acc = bias + W_tile . [E (NFE frags), X (NFH frags)].
+    // Weight fragments move LDS -> registers in groups of 4, double-buffered: group j+1 (or the first group of the
+    // NEXT tile, already resident in the ring) is loading while group j feeds the matrix cores.
+    // w0 holds this tile's group 0 on entry and the next tile's group 0 on exit.
     template <int NFE, int NFH, int XF>
-    __device__ __forceinline__ void tile(const Frag (&E)[NT][EF], const Frag (&X)[NT][XF], f32x16 (&acc)[NT]) {
-        const char* slot = advance();
+    __device__ __forceinline__ void tile(const Frag (&E)[NT][EF], const Frag (&X)[NT][XF], f32x16 (&acc)[NT],
+                                         Frag (&w0)[4]) {
+        static_assert((NFE + NFH) % 4 == 0, "fragment groups of 4");
+        constexpr int NG = (NFE + NFH) / 4;
+        advance();
         load_bias(acc);
-        const Frag* wf = reinterpret_cast<const Frag*>(slot) + lane;
+        const Frag* cur = reinterpret_cast<const Frag*>(slot_cur) + lane;
+        const Frag* nxt = reinterpret_cast<const Frag*>(slot_nxt) + lane;
+        Frag wa[4], wb[4];
 #pragma unroll
-        for (int f = 0; f < NFE; ++f) {
-            const Frag w = wf[f * 64];
+        for (int q = 0; q < 4; ++q) wa[q] = w0[q];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) mma(w, E[n][f], acc[n]);
+        for (int j = 0; j < NG; ++j) {
+            Frag (&use)[4] = (j & 1) ? wb : wa;
+            Frag (&ld)[4] = (j & 1) ? wa : wb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ld[q] = (j + 1 < NG) ? cur[((j + 1) * 4 + q) * 64] : nxt[q * 64];
+            __builtin_amdgcn_sched_barrier(0);          // loads of group j+1 are issued before group j's MFMAs
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f = 4 * j + q;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    if (f < NFE) mma(use[q], E[n][f < NFE ? f : 0], acc[n]);
+                    else         mma(use[q], X[n][f >= NFE ? f - NFE : 0], acc[n]);
+                }
+            }
         }
 #pragma unroll
-        for (int f = 0; f < NFH; ++f) {
-            const Frag w = wf[(NFE + f) * 64];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) mma(w, X[n][f], acc[n]);
-        }
-        ++c;
+        for (int q = 0; q < 4; ++q) w0[q] = (NG & 1) ? wb[q] : wa[q];
+        rotate();
     }
 
     // a full layer: NTILES out-tiles, activation, results become the next layer's frags
     template <int NTILES, int NFE, int NFH, bool RELU, int XF, int YF>
-    __device__ __forceinline__ void layer(const Frag (&E)[NT][EF], const Frag (&X)[NT][XF], Frag (&Y)[NT][YF]) {
+    __device__ __forceinline__ void layer(const Frag (&E)[NT][EF], const Frag (&X)[NT][XF], Frag (&Y)[NT][YF],
+                                          Frag (&w0)[4]) {
 #pragma unroll
         for (int t = 0; t < NTILES; ++t) {
             f32x16 acc[NT];
-            tile<NFE, NFH, XF>(E, X, acc);
+            tile<NFE, NFH, XF>(E, X, acc, w0);
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -181,9 +224,13 @@ struct Mlp {
 #pragma unroll
                     for (int e = 0; e < EPF; ++e) {
                         float v = acc[n][f * EPF + e];
-                        if (RELU) v = fmaxf(v, 0.0f);
+                        if (RELU) v = __int_as_float(max(__float_as_int(v), 0));   // relu; one v_max_i32
                         put(Y[n][t * FPT + f], e, v);
                     }
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int f = 0; f < FPT; ++f) pin(Y[n][t * FPT + f]);
         }
     }
 
@@ -193,18 +240,22 @@ struct Mlp {
         lane = threadIdx.x & 63;
         half = lane >> 5;
         lds_bias = lds;
-        lds_slots = lds + BIAS_BYTES;
+        slot_cur = lds + BIAS_BYTES;
+        slot_nxt = slot_cur + SLOT;
+        slot_stage = slot_nxt + SLOT;
         c = 0;
 
-        // resident bias table + first chunk
-        for (int i = threadIdx.x; i < BIAS_BYTES / 16; i += MLP_THREADS)
+        // resident bias table + the first two chunks
+        for (int i = threadIdx.x; i < BIAS_BYTES / 16; i += THREADS)
             reinterpret_cast<uint4*>(lds_bias)[i] = reinterpret_cast<const uint4*>(pack)[i];
         gnext = pack + BIAS_BYTES;
-        stage_chunk<DMA>(gnext, slot_of(0), chunk_frags<C>(0), wave, lane);
+        stage_chunk<DMA, WAVES>(gnext, slot_cur, chunk_frags<C>(0), wave, lane);
         gnext += chunk_frags<C>(0) * FRAG_BYTES;
+        stage_chunk<DMA, WAVES>(gnext, slot_nxt, chunk_frags<C>(1), wave, lane);
+        gnext += chunk_frags<C>(1) * FRAG_BYTES;
 
         // this wave's points
-        const int64_t wave_base = ((int64_t)blockIdx.x * 4 + wave) * (NT * 32);
+        const int64_t wave_base = ((int64_t)blockIdx.x * WAVES + wave) * (NT * 32);
         float4 p[NT];
         Frag E[NT][EF];
 #pragma unroll
@@ -227,9 +278,15 @@ struct Mlp {
             }
         }
 
+        // chunk 0 resident -> first fragment group into registers
+        __syncthreads();
+        Frag w0[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w0[q] = (reinterpret_cast<const Frag*>(slot_cur) + lane)[q * 64];
+
         Frag X[NT][HF], Y[NT][HF];
         // layer 1: encoding -> 256
-        layer<8, EF, 0, true, HF, HF>(E, X, Y);
+        layer<8, EF, 0, true, HF, HF>(E, X, Y, w0);
         // layers 2..8 (layer 5 takes [encoding, hidden])
 #pragma nounroll
         for (int l = 2; l <= 8; ++l) {
@@ -237,25 +294,25 @@ struct Mlp {
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int f = 0; f < HF; ++f) X[n][f] = Y[n][f];
-            if (l == 5) layer<8, EF, HF, true, HF, HF>(E, X, Y);
-            else        layer<8, 0, HF, true, HF, HF>(E, X, Y);
+            if (l == 5) layer<8, EF, HF, true, HF, HF>(E, X, Y, w0);
+            else        layer<8, 0, HF, true, HF, HF>(E, X, Y, w0);
         }
         // xyz_encoding_final (no activation): Y -> X ; then the sigma row as a 9th tile
-        layer<8, 0, HF, false, HF, HF>(E, Y, X);
+        layer<8, 0, HF, false, HF, HF>(E, Y, X, w0);
         float sigma[NT];
         {
             f32x16 acc[NT];
-            tile<0, HF, HF>(E, Y, acc);
+            tile<0, HF, HF>(E, Y, acc, w0);
 #pragma unroll
             for (int n = 0; n < NT; ++n) sigma[n] = acc[n][0];
         }
         // dir_encoding: 256 -> 128, relu
         Frag G[NT][DF];
-        layer<4, 0, HF, true, HF, DF>(E, X, G);
+        layer<4, 0, HF, true, HF, DF>(E, X, G, w0);
         // rgb: 128 -> 3, sigmoid
         {
             f32x16 acc[NT];
-            tile<0, DF, DF>(E, G, acc);
+            tile<0, DF, DF>(E, G, acc, w0);
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 int64_t idx = wave_base + n * 32 + (lane & 31);
@@ -272,7 +329,7 @@ struct Mlp {
 };
 
 template <int MODE, bool DMA>
-__global__ __launch_bounds__(MLP_THREADS, 1) void mlp_kernel(const char* __restrict__ pack,
+__global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void mlp_kernel(const char* __restrict__ pack,
                                                              const float4* __restrict__ pts, int64_t n_pts,
                                                              float4* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -317,13 +374,13 @@ __global__ void mlp_pack_kernel(PackPlan plan, char* __restrict__ pack) {
                 col = (ch >= 0 && ch < st.enc_cols) ? ch : -1;
             } else {
                 int f = kf - st.nf_enc;
-                int feat = (MODE == ANR_MLP_BF16) ? 16 * f + 8 * (e >> 2) + 4 * h + (e & 3) : 8 * f + 4 * h + e;
+                int feat = C::IS_BF16 ? 16 * f + 8 * (e >> 2) + 4 * h + (e & 3) : 8 * f + 4 * h + e;
                 col = st.enc_cols + feat;
             }
             v[e] = (row < st.out_dim && col >= 0 && col < st.in_dim) ? st.W[(int64_t)row * st.in_dim + col] : 0.0f;
         }
         char* dst = pack + BIAS_BYTES + (int64_t)frag * FRAG_BYTES + lane * 16;
-        if constexpr (MODE == ANR_MLP_BF16) {
+        if constexpr (C::IS_BF16) {
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
@@ -374,13 +431,13 @@ PackPlan make_plan(const anr_mlp_params* p) {
 template <int MODE, bool DMA>
 int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStream_t st) {
     using C = Cfg<MODE>;
-    const int lds = BIAS_BYTES + 2 * slot_bytes<C>();
+    const int lds = BIAS_BYTES + 3 * slot_bytes<C>();
     auto kern = mlp_kernel<MODE, DMA>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail((int)e, "anr_mlp_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    const int pts_per_wg = 4 * C::NT * 32;
+    const int pts_per_wg = C::WAVES * C::NT * 32;
     dim3 grid((unsigned)((n + pts_per_wg - 1) / pts_per_wg));
-    hipLaunchKernelGGL(kern, grid, dim3(MLP_THREADS), lds, st, reinterpret_cast<const char*>(pack),
+    hipLaunchKernelGGL(kern, grid, dim3(C::WAVES * 64), lds, st, reinterpret_cast<const char*>(pack),
                        reinterpret_cast<const float4*>(pts), n, reinterpret_cast<float4*>(out));
     return check_launch("anr_mlp_forward");
 }
@@ -389,7 +446,8 @@ int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStr
 
 using namespace anr;
 
-#define ANR_MLP_FLAG_NO_DMA 0x100
+#define ANR_MLP_FLAG_NO_DMA 0x100      /* debug: stage weights through registers instead of the LDS-DMA engine */
+#define ANR_MLP_FLAG_W4     0x200      /* bf16 only: 4 waves x 64 points per workgroup instead of 8 waves x 32 */
 
 extern "C" int64_t anr_mlp_pack_bytes(int mode) {
     switch (mode & 0xff) {
@@ -432,7 +490,9 @@ extern "C" int anr_mlp_forward(const void* pack, int mode, const float* pts, int
         case ANR_MLP_F32:
             return dma ? launch_mlp<ANR_MLP_F32, true>(pack, pts, n, out, st) : launch_mlp<ANR_MLP_F32, false>(pack, pts, n, out, st);
         case ANR_MLP_BF16:
-            return dma ? launch_mlp<ANR_MLP_BF16, true>(pack, pts, n, out, st) : launch_mlp<ANR_MLP_BF16, false>(pack, pts, n, out, st);
+            if (mode & ANR_MLP_FLAG_W4)
+                return dma ? launch_mlp<ANR_MLP_BF16, true>(pack, pts, n, out, st) : launch_mlp<ANR_MLP_BF16, false>(pack, pts, n, out, st);
+            return dma ? launch_mlp<ANR_MLP_BF16_W8, true>(pack, pts, n, out, st) : launch_mlp<ANR_MLP_BF16_W8, false>(pack, pts, n, out, st);
         default:
             return fail(ANR_E_BADARG, "anr_mlp_forward: unknown mode %d", mode);
     }

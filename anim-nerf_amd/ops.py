@@ -13,7 +13,11 @@ import torch
 from . import _lib
 from ._lib import ANR_MLP_BF16, ANR_MLP_F32, ANR_MLP_FLAG_NO_DMA, AnrMlpParams
 
-MLP_MODES = {"f32": ANR_MLP_F32, "fp32": ANR_MLP_F32, "bf16": ANR_MLP_BF16}
+ANR_MLP_FLAG_W4 = 0x200
+MLP_MODES = {"f32": ANR_MLP_F32, "fp32": ANR_MLP_F32, "bf16": ANR_MLP_BF16,
+             # A/B variants of the same arithmetic (bench/diagnostics)
+             "bf16_w4": ANR_MLP_BF16 | ANR_MLP_FLAG_W4, "bf16_nodma": ANR_MLP_BF16 | ANR_MLP_FLAG_NO_DMA,
+             "f32_nodma": ANR_MLP_F32 | ANR_MLP_FLAG_NO_DMA}
 
 # When set to a list (bench.py does), every launch appends (name, start_event, end_event, units): HIP events
 # recorded on the stream the kernel is launched on, so elapsed_time() is that kernel's device time.
