@@ -24,6 +24,7 @@
 //       j = 30 : h ? x_2 : x_0 ;  j = 31 : h ? <pad, weight 0> : x_1
 //   so the two half-waves run one instruction stream (sin vs cos is a quadrant offset).
 #include "anr_common.h"
+#include <utility>
 
 namespace anr {
 
@@ -44,6 +45,7 @@ template <> struct Cfg<ANR_MLP_BF16> {
     static constexpr int EPF = 8;    // elements per frag per lane
     static constexpr int NT = 2;     // 32-point column tiles per wave
     static constexpr int WAVES = 4;  // wavefronts per workgroup
+    static constexpr int TPC = 2;    // out-tiles per staged weight chunk (one workgroup barrier per chunk)
     static constexpr int HF = 16;    // frags per 256 hidden features
     static constexpr int EF = 4;     // frags of the 64-slot encoding panel
     static constexpr int DF = 8;     // frags per 128 features (rgb head input)
@@ -58,19 +60,25 @@ template <> struct Cfg<ANR_MLP_F32> {
     static constexpr int EPF = 4;
     static constexpr int NT = 1;
     static constexpr int WAVES = 4;
+    static constexpr int TPC = 1;
     static constexpr int HF = 32;
     static constexpr int EF = 8;
     static constexpr int DF = 16;
 };
 
-// frags in chunk (= out-tile) c of the flat schedule
+// frags of out-tile t of the flat 78-tile schedule, and of staged chunk c (= TPC consecutive tiles)
+template <class C> __host__ __device__ constexpr int tile_frags(int t) {
+    return t < 8 ? C::EF : t < 32 ? C::HF : t < 40 ? C::EF + C::HF : t < 77 ? C::HF : t < 78 ? C::DF : 0;
+}
 template <class C> __host__ __device__ constexpr int chunk_frags(int c) {
-    return c < 8 ? C::EF : c < 32 ? C::HF : c < 40 ? C::EF + C::HF : c < 77 ? C::HF : c < 78 ? C::DF : 0;
+    int n = 0;
+    for (int i = 0; i < C::TPC; ++i) n += tile_frags<C>(c * C::TPC + i);
+    return n;
 }
 template <class C> constexpr int total_frags() {
     return 8 * C::EF + 24 * C::HF + 8 * (C::EF + C::HF) + 24 * C::HF + 9 * C::HF + 4 * C::HF + C::DF;
 }
-template <class C> constexpr int slot_bytes() { return (C::EF + C::HF) * FRAG_BYTES; }
+template <class C> constexpr int slot_bytes() { return C::TPC * (C::EF + C::HF) * FRAG_BYTES; }
 
 __device__ __forceinline__ void mma(const bf16x8& w, const bf16x8& x, f32x16& acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, acc, 0, 0, 0);
@@ -78,6 +86,16 @@ __device__ __forceinline__ void mma(const bf16x8& w, const bf16x8& x, f32x16& ac
 __device__ __forceinline__ void mma(const f32x4& w, const f32x4& x, f32x16& acc) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], x[e], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 mma_c(const bf16x8& w, const bf16x8& x, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma_c(const f32x4& w, const f32x4& x, const f32x16& c) {
+    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], x[0], c, 0, 0, 0);
+#pragma unroll
+    for (int e = 1; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], x[e], acc, 0, 0, 0);
+    return acc;
 }
 
 __device__ __forceinline__ void put(bf16x8& f, int e, float v) { f[e] = (__bf16)v; }
@@ -127,25 +145,37 @@ __device__ __forceinline__ void stage_chunk(const char* __restrict__ g, char* sl
 }
 
 // ---------------------------------------------------------------------------------------------
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int V> struct IC { static constexpr int value = V; constexpr operator int() const { return V; } };
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 template <int MODE, bool DMA>
 struct Mlp {
     using C = Cfg<MODE>;
     using Frag = typename C::Frag;
-    static constexpr int NT = C::NT, EPF = C::EPF, HF = C::HF, EF = C::EF, DF = C::DF, WAVES = C::WAVES;
+    static constexpr int NT = C::NT, EPF = C::EPF, HF = C::HF, EF = C::EF, DF = C::DF, WAVES = C::WAVES, TPC = C::TPC;
     static constexpr int THREADS = WAVES * 64;
     static constexpr int FPT = 16 / EPF;          // next-layer frags produced per out-tile
     static constexpr int SLOT = slot_bytes<C>();
 
-    // per-wave pipeline state.  Weight chunks (one 32-row out-tile each) flow through a 3-slot LDS ring:
-    // while tile c is being multiplied, chunk c+1 is already resident (its first fragments are pulled into
-    // registers before tile c ends) and chunk c+2 is in flight on the LDS-DMA engine.
+    // Per-wave pipeline state.  Weight chunks (TPC 32-row out-tiles each) flow through a 3-slot LDS ring:
+    // while tile c is being multiplied, chunk c+1 is already resident (its first fragment group and its bias
+    // are pulled into registers before tile c ends) and chunk c+2 is in flight on the LDS-DMA engine.
+    // The activation/convert epilogue of tile c-1 is issued in the shadow of tile c's first MFMAs, so the
+    // matrix pipe never waits for VALU work: accumulators ping-pong between acc[0] and acc[1].
     const char* gnext;       // global address of the next chunk to stage (chunk c+2)
     char* lds_bias;
     char* slot_cur;          // LDS slot of chunk c
     char* slot_nxt;          // LDS slot of chunk c+1
     char* slot_stage;        // LDS slot chunk c+2 is staged into
-    int c;                   // chunk (out-tile) counter
+    int c;                   // chunk counter
     int wave, lane, half;
+    f32x16 acc[2][NT];       // accumulators of tile c (parity c&1) and of tile c-1 (epilogue pending)
+    f32x16 bias_c;           // bias of tile c: C operand of its first MFMA
+    Frag w0[4];              // first fragment group of tile c
 
     // barrier: chunk c+1 has landed everywhere and nobody reads chunk c-1 any more -> stage chunk c+2 over it
     __device__ __forceinline__ void advance() {
@@ -158,80 +188,118 @@ struct Mlp {
         char* t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_stage; slot_stage = t;
         ++c;
     }
-
-    __device__ __forceinline__ void load_bias(f32x16 (&acc)[NT]) {
-        const f32x4* b = reinterpret_cast<const f32x4*>(lds_bias + c * 128 + half * 64);
+    __device__ __forceinline__ f32x16 read_bias(int tile_idx) {
+        const f32x4* b = reinterpret_cast<const f32x4*>(lds_bias + tile_idx * 128 + half * 64);
         f32x16 v;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 t = b[q];
             v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
         }
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[n] = v;
+        return v;
     }
 
-    // one out-tile: acc = bias + W_tile . [E (NFE frags), X (NFH frags)].
-    // Weight fragments move LDS -> registers in groups of 4, double-buffered: group j+1 (or the first group of the
-    // NEXT tile, already resident in the ring) is loading while group j feeds the matrix cores.
-    // w0 holds this tile's group 0 on entry and the next tile's group 0 on exit.
-    template <int NFE, int NFH, int XF>
-    __device__ __forceinline__ void tile(const Frag (&E)[NT][EF], const Frag (&X)[NT][XF], f32x16 (&acc)[NT],
-                                         Frag (&w0)[4]) {
+    // ---- pending epilogues: what is still to be done with the accumulators of the PREVIOUS tile.
+    // part<Q>() handles accumulator registers 4Q..4Q+3 of every column tile (Q = 0..3).
+    struct NoEpi {
+        template <int Q> __device__ __forceinline__ void part() const {}
+    };
+    // activation + conversion into fragments [TB, TB+FPT) of the next layer's input
+    template <bool RELU, int YF, int TB>
+    struct FragEpi {
+        const f32x16 (&a)[NT];
+        Frag (&Y)[NT][YF];
+        template <int Q> __device__ __forceinline__ void part() const {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = a[n][4 * Q + i];
+                    if (RELU) v = __int_as_float(max(__float_as_int(v), 0));       // relu as one v_max_i32
+                    put(Y[n][TB + (4 * Q + i) / EPF], (4 * Q + i) % EPF, v);
+                }
+                if ((4 * Q + 4) % EPF == 0) pin(Y[n][TB + (4 * Q) / EPF]);
+            }
+        }
+    };
+    // sigma head: row 0 of its tile = accumulator register 0 of the lower half-wave
+    struct SigmaEpi {
+        const f32x16 (&a)[NT];
+        float (&sigma)[NT];
+        template <int Q> __device__ __forceinline__ void part() const {
+            if (Q == 0) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) sigma[n] = a[n][0];
+            }
+        }
+    };
+
+    // One out-tile (parity PAR): acc[PAR] = bias + W_tile . [E (NFE frags), X (NFH frags)].
+    // Weight fragments move LDS -> registers in groups of 4, double-buffered: group j+1 (or, in the last group,
+    // the first group and the bias of the NEXT tile, already resident in the ring) loads while group j feeds the
+    // matrix cores; the previous tile's epilogue (`pending`) is spread behind the first four MFMAs.
+    template <int T, int NFE, int NFH, int XF, class Pending>
+    __device__ __forceinline__ void tile(const Frag (&E)[NT][EF], const Frag (&X)[NT][XF], const Pending& pending) {
         static_assert((NFE + NFH) % 4 == 0, "fragment groups of 4");
+        static_assert(NFE + NFH == tile_frags<C>(T), "tile schedule mismatch");
         constexpr int NG = (NFE + NFH) / 4;
-        advance();
-        load_bias(acc);
-        const Frag* cur = reinterpret_cast<const Frag*>(slot_cur) + lane;
-        const Frag* nxt = reinterpret_cast<const Frag*>(slot_nxt) + lane;
+        constexpr int PAR = T & 1;
+        constexpr int POS = T % TPC;                       // position of this tile inside its chunk
+        constexpr int OFF = (POS == 0) ? 0 : tile_frags<C>(T - 1);      // TPC <= 2
+        if constexpr (POS == 0) advance();
+        const Frag* cur = reinterpret_cast<const Frag*>(slot_cur) + OFF * 64 + lane;
+        const Frag* nxt = (POS + 1 < TPC) ? cur + (NFE + NFH) * 64 : reinterpret_cast<const Frag*>(slot_nxt) + lane;
         Frag wa[4], wb[4];
+        f32x16 bias_n;
 #pragma unroll
         for (int q = 0; q < 4; ++q) wa[q] = w0[q];
-#pragma unroll
-        for (int j = 0; j < NG; ++j) {
+        static_for<NG>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
             Frag (&use)[4] = (j & 1) ? wb : wa;
             Frag (&ld)[4] = (j & 1) ? wa : wb;
 #pragma unroll
             for (int q = 0; q < 4; ++q) ld[q] = (j + 1 < NG) ? cur[((j + 1) * 4 + q) * 64] : nxt[q * 64];
-            __builtin_amdgcn_sched_barrier(0);          // loads of group j+1 are issued before group j's MFMAs
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int f = 4 * j + q;
+            if (j + 1 == NG) bias_n = read_bias(T + 1);
+            __builtin_amdgcn_sched_barrier(0);          // the loads above are issued before this group's MFMAs
+            static_for<4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int f = 4 * j + q;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    if (f < NFE) mma(use[q], E[n][f < NFE ? f : 0], acc[n]);
-                    else         mma(use[q], X[n][f >= NFE ? f - NFE : 0], acc[n]);
+                    const Frag& x = (f < NFE) ? E[n][f < NFE ? f : 0] : X[n][f >= NFE ? f - NFE : 0];
+                    if (f == 0) acc[PAR][n] = mma_c(use[q], x, bias_c);
+                    else        mma(use[q], x, acc[PAR][n]);
                 }
-            }
-        }
+                if (j == 0) {
+                    pending.template part<q>();
+                    __builtin_amdgcn_sched_barrier(0);  // keep the epilogue pieces between the MFMAs
+                }
+            });
+        });
 #pragma unroll
         for (int q = 0; q < 4; ++q) w0[q] = (NG & 1) ? wb[q] : wa[q];
-        rotate();
+        bias_c = bias_n;
+        if constexpr (POS + 1 == TPC) rotate();
     }
 
-    // a full layer: NTILES out-tiles, activation, results become the next layer's frags
-    template <int NTILES, int NFE, int NFH, bool RELU, int XF, int YF>
+    // a full layer of NTILES out-tiles starting at global tile index T0; `first` is the epilogue still pending
+    // from the tile before T0.  The epilogue of this layer's LAST tile is left pending for the caller.
+    template <int T0, int NTILES, int NFE, int NFH, bool RELU, int XF, int YF, class Pending>
     __device__ __forceinline__ void layer(const Frag (&E)[NT][EF], const Frag (&X)[NT][XF], Frag (&Y)[NT][YF],
-                                          Frag (&w0)[4]) {
-#pragma unroll
-        for (int t = 0; t < NTILES; ++t) {
-            f32x16 acc[NT];
-            tile<NFE, NFH, XF>(E, X, acc, w0);
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int f = 0; f < FPT; ++f)
-#pragma unroll
-                    for (int e = 0; e < EPF; ++e) {
-                        float v = acc[n][f * EPF + e];
-                        if (RELU) v = __int_as_float(max(__float_as_int(v), 0));   // relu; one v_max_i32
-                        put(Y[n][t * FPT + f], e, v);
-                    }
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int f = 0; f < FPT; ++f) pin(Y[n][t * FPT + f]);
-        }
+                                          const Pending& first) {
+        static_for<NTILES>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int PAR = (T0 + t) & 1;
+            if constexpr (t == 0) {
+                tile<T0 + t, NFE, NFH, XF>(E, X, first);
+            } else {
+                tile<T0 + t, NFE, NFH, XF>(E, X, FragEpi<RELU, YF, (t - 1) * FPT>{acc[PAR ^ 1], Y});
+            }
+        });
+    }
+    template <int T0, int NTILES, bool RELU, int YF>
+    __device__ __forceinline__ auto last_of(Frag (&Y)[NT][YF]) {
+        return FragEpi<RELU, YF, (NTILES - 1) * FPT>{acc[(T0 + NTILES - 1) & 1], Y};
     }
 
     __device__ __forceinline__ void run(const char* __restrict__ pack, const float4* __restrict__ pts, int64_t n_pts,
@@ -254,15 +322,16 @@ struct Mlp {
         stage_chunk<DMA, WAVES>(gnext, slot_nxt, chunk_frags<C>(1), wave, lane);
         gnext += chunk_frags<C>(1) * FRAG_BYTES;
 
-        // this wave's points
+        // this wave's points, Fourier-encoded straight into B fragments
         const int64_t wave_base = ((int64_t)blockIdx.x * WAVES + wave) * (NT * 32);
-        float4 p[NT];
+        float valid[NT];
         Frag E[NT][EF];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             int64_t idx = wave_base + n * 32 + (lane & 31);
-            p[n] = pts[idx < n_pts ? idx : n_pts - 1];
-            const float xs[3] = {p[n].x, p[n].y, p[n].z};
+            const float4 p = pts[idx < n_pts ? idx : n_pts - 1];
+            valid[n] = p.w;
+            const float xs[3] = {p.x, p.y, p.z};
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
                 float v;
@@ -278,51 +347,40 @@ struct Mlp {
             }
         }
 
-        // chunk 0 resident -> first fragment group into registers
+        // chunk 0 resident -> its first fragment group and bias into registers
         __syncthreads();
-        Frag w0[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) w0[q] = (reinterpret_cast<const Frag*>(slot_cur) + lane)[q * 64];
+        bias_c = read_bias(0);
 
-        Frag X[NT][HF], Y[NT][HF];
-        // layer 1: encoding -> 256
-        layer<8, EF, 0, true, HF, HF>(E, X, Y, w0);
-        // layers 2..8 (layer 5 takes [encoding, hidden])
-#pragma nounroll
-        for (int l = 2; l <= 8; ++l) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int f = 0; f < HF; ++f) X[n][f] = Y[n][f];
-            if (l == 5) layer<8, EF, HF, true, HF, HF>(E, X, Y, w0);
-            else        layer<8, 0, HF, true, HF, HF>(E, X, Y, w0);
-        }
-        // xyz_encoding_final (no activation): Y -> X ; then the sigma row as a 9th tile
-        layer<8, 0, HF, false, HF, HF>(E, Y, X, w0);
+        Frag A[NT][HF], B[NT][HF];
         float sigma[NT];
-        {
-            f32x16 acc[NT];
-            tile<0, HF, HF>(E, Y, acc, w0);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) sigma[n] = acc[n][0];
-        }
-        // dir_encoding: 256 -> 128, relu
+        // trunk: 8 layers of 8 tiles, activations ping-pong between A and B (global tile index in <>)
+        layer<0, 8, EF, 0, true, HF, HF>(E, B, A, NoEpi{});                                      // 1: enc -> A
+        layer<8, 8, 0, HF, true, HF, HF>(E, A, B, last_of<0, 8, true>(A));                       // 2: A -> B
+        layer<16, 8, 0, HF, true, HF, HF>(E, B, A, last_of<8, 8, true>(B));                      // 3: B -> A
+        layer<24, 8, 0, HF, true, HF, HF>(E, A, B, last_of<16, 8, true>(A));                     // 4: A -> B
+        layer<32, 8, EF, HF, true, HF, HF>(E, B, A, last_of<24, 8, true>(B));                    // 5: [enc, B] -> A
+        layer<40, 8, 0, HF, true, HF, HF>(E, A, B, last_of<32, 8, true>(A));                     // 6: A -> B
+        layer<48, 8, 0, HF, true, HF, HF>(E, B, A, last_of<40, 8, true>(B));                     // 7: B -> A
+        layer<56, 8, 0, HF, true, HF, HF>(E, A, B, last_of<48, 8, true>(A));                     // 8: A -> B
+        // xyz_encoding_final (no activation): B -> A ; the sigma row is a 9th tile on B
+        layer<64, 8, 0, HF, false, HF, HF>(E, B, A, last_of<56, 8, true>(B));
+        tile<72, 0, HF, HF>(E, B, last_of<64, 8, false>(A));
+        // dir_encoding: A -> G (256 -> 128, relu); rgb: G -> 3, sigmoid
         Frag G[NT][DF];
-        layer<4, 0, HF, true, HF, DF>(E, X, G, w0);
-        // rgb: 128 -> 3, sigmoid
-        {
-            f32x16 acc[NT];
-            tile<0, DF, DF>(E, G, acc, w0);
+        layer<73, 4, 0, HF, true, HF, DF>(E, A, G, SigmaEpi{acc[72 & 1], sigma});
+        tile<77, 0, DF, DF>(E, G, last_of<73, 4, true>(G));
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                int64_t idx = wave_base + n * 32 + (lane & 31);
-                if (half == 0 && idx < n_pts) {
-                    float r = 1.0f / (1.0f + expf(-acc[n][0]));
-                    float g = 1.0f / (1.0f + expf(-acc[n][1]));
-                    float b = 1.0f / (1.0f + expf(-acc[n][2]));
-                    float s = (p[n].w < 1.0f) ? -1e5f : sigma[n];       // models/anim_nerf.py:305
-                    out[idx] = make_float4(r, g, b, s);
-                }
+        for (int n = 0; n < NT; ++n) {
+            int64_t idx = wave_base + n * 32 + (lane & 31);
+            const f32x16& r = acc[77 & 1][n];
+            if (half == 0 && idx < n_pts) {
+                float cr = 1.0f / (1.0f + expf(-r[0]));
+                float cg = 1.0f / (1.0f + expf(-r[1]));
+                float cb = 1.0f / (1.0f + expf(-r[2]));
+                float s = (valid[n] < 1.0f) ? -1e5f : sigma[n];       // models/anim_nerf.py:305
+                out[idx] = make_float4(cr, cg, cb, s);
             }
         }
     }

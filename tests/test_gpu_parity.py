@@ -287,7 +287,11 @@ def test_render_matches_reference(dev, smpl_table, case):
     assert torch.equal(z.cpu(), torch.from_numpy(g["z_coarse"]))
     w, _, _, _ = vr._shade(m, rays_b, z, True, 0.0, True)
     w_ref = torch.from_numpy(g["weights"])[0]
-    assert (((w.cpu() - w_ref).abs() > 2e-6 + RTOL * w_ref.abs()).any(-1)).float().mean() <= (0.05 if bool(g["use_unpose"]) else 0.0)
+    off = (w.cpu() - w_ref).abs() > 2e-6 + RTOL * w_ref.abs()
+    if bool(g["use_unpose"]):       # per-sample weights feel the conditioning more than the per-ray sums do
+        assert off.float().mean() <= 0.01 and (w.cpu() - w_ref).abs().max() < 5e-3
+    else:
+        assert not off.any()
 
 
 def test_generic_model_path_equals_fused_path(dev, smpl_table):
