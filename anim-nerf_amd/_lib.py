@@ -10,7 +10,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libanimnerf_hip.so")
+# ANIMNERF_HIP_LIB points at an alternative build of the SAME library (kernel experiments); never a fallback
+LIB_PATH = os.environ.get("ANIMNERF_HIP_LIB") or os.path.join(_HERE, "libanimnerf_hip.so")
 
 ANR_MLP_F32 = 0
 ANR_MLP_BF16 = 1

@@ -27,16 +27,19 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = False, defines=(), out: str = None) -> str:
+    """Compile every HIP source for gfx950 and link the shared library.  Returns its path.
+    `defines`/`out` build an experiment variant (e.g. timing ablations) next to the product library."""
+    lib_path = out or LIB_PATH
+    if not defines and not out and not force and not _stale():
         return LIB_PATH
     objs = []
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
-             "-Wno-unused-value", "-Wno-pass-failed"]
+             "-Wno-unused-value", "-Wno-pass-failed"] + [f"-D{d}" for d in defines]
+    tag = ("." + "_".join(defines)) if defines else ""
     procs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, src.replace(".hip", tag + ".o"))
         cmd = [_hipcc(), *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -48,12 +51,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, *objs]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    outs = [a[6:] for a in sys.argv[1:] if a.startswith("--out=")]
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, defines=defs, out=outs[0] if outs else None))

@@ -127,15 +127,27 @@ __device__ __forceinline__ float sin_or_cos(float a, int q_off) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight staging: chunk = nf frags of 1 KiB; wave w moves pieces w, w+4, ...
+// weight staging: chunk = nf frags of 1 KiB; wave w moves pieces w, w+WAVES, ...
+//
+// The LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B straight from L2 into LDS at M0 + lane*16) is issued
+// from inline asm on purpose: when hipcc sees the builtin it can no longer prove which ds_reads the DMA may
+// alias and degrades EVERY LDS wait in the kernel to `s_waitcnt lgkmcnt(0)`, which exposes the full LDS latency
+// in front of each group of MFMAs.  Hidden in asm, the fragment reads keep their counted lgkmcnt(N) waits; the
+// DMA's own completion is waited for by hand (`vmcnt(0)` in front of the workgroup barrier, dma_wait()).
+__device__ __forceinline__ void dma16(const char* gsrc_lane, char* lds_dst_uniform) {
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_dst_uniform;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc_lane), "s"(__builtin_amdgcn_readfirstlane(dst))
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <bool DMA, int WAVES>
 __device__ __forceinline__ void stage_chunk(const char* __restrict__ g, char* slot, int nf, int wave, int lane) {
     if constexpr (DMA) {
-        for (int p = wave; p < nf; p += WAVES) {
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(g + p * FRAG_BYTES + lane * 16),
-                (__attribute__((address_space(3))) void*)(slot + p * FRAG_BYTES), 16, 0, 0);
-        }
+        for (int p = wave; p < nf; p += WAVES) dma16(g + p * FRAG_BYTES + lane * 16, slot + p * FRAG_BYTES);
     } else {
         for (int p = wave; p < nf; p += WAVES) {
             uint4 v = *reinterpret_cast<const uint4*>(g + p * FRAG_BYTES + lane * 16);
@@ -179,10 +191,15 @@ struct Mlp {
 
     // barrier: chunk c+1 has landed everywhere and nobody reads chunk c-1 any more -> stage chunk c+2 over it
     __device__ __forceinline__ void advance() {
+#ifndef ANR_ABL_NO_BARRIER
+        if constexpr (DMA) dma_wait();
         __syncthreads();
+#endif
+#ifndef ANR_ABL_NO_STAGE
         const int nf = chunk_frags<C>(c + 2);
         stage_chunk<DMA, WAVES>(gnext, slot_stage, nf, wave, lane);
         gnext += nf * FRAG_BYTES;
+#endif
     }
     __device__ __forceinline__ void rotate() {
         char* t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_stage; slot_stage = t;
@@ -210,6 +227,9 @@ struct Mlp {
         const f32x16 (&a)[NT];
         Frag (&Y)[NT][YF];
         template <int Q> __device__ __forceinline__ void part() const {
+#ifdef ANR_ABL_NO_EPILOGUE
+            if (Q > 0) return;
+#endif
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
 #pragma unroll
@@ -348,6 +368,7 @@ struct Mlp {
         }
 
         // chunk 0 resident -> its first fragment group and bias into registers
+        if constexpr (DMA) dma_wait();
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 4; ++q) w0[q] = (reinterpret_cast<const Frag*>(slot_cur) + lane)[q * 64];

@@ -41,7 +41,10 @@ def parse():
     ap.add_argument("--n-coarse", type=int, default=64)
     ap.add_argument("--n-fine", type=int, default=64)
     ap.add_argument("--chunk", type=int, default=1 << 18, help="rays per renderer call")
-    ap.add_argument("--cpu-rays", type=int, default=3072, help="rays of the same workload timed on the host oracle (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=4096, help="upper bound on the rays timed on the host oracle (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target duration of the host-oracle sample")
+    ap.add_argument("--sigma-gain", type=float, default=3000.0,
+                    help="scale the sigma heads about their median (0 = literal random init, which renders a blank image)")
     ap.add_argument("--no-psnr", action="store_true")
     return ap.parse_args()
 
@@ -68,6 +71,19 @@ def main():
     torch.manual_seed(0)
     model = ana.AnimNeRF(body_model_table=tbl, freqs_dir=0, use_view=False, use_unpose=use_warp, use_knn=True,
                          use_fine=True, mlp_mode=args.mode).eval().to(dev)
+    if args.sigma_gain > 0:
+        # random-init sigma is ~0.017 +- 0.003 (one sign everywhere): every ray renders white or saturates on the far
+        # sample.  Spread it about its median so that compositing, importance sampling and the PSNR mean something.
+        # Same FLOPs, same kernels; only the numbers in the sigma row change.
+        g = torch.Generator().manual_seed(5)
+        probe = (torch.rand(1, 4096, 3, generator=g) * 1.6 - 0.8).to(dev)
+        with torch.no_grad():
+            for net in (model.nerf, model.nerf_fine):
+                net.mlp_mode = "f32"
+                med = net(probe)[1].median().item()
+                net.mlp_mode = args.mode
+                net.sigma.weight.mul_(args.sigma_gain)
+                net.sigma.bias.mul_(args.sigma_gain).add_(-args.sigma_gain * med)
     vr = ana.VolumeRenderer(n_coarse=args.n_coarse, n_fine=args.n_fine, white_bkgd=True)
     H = W = args.hw
     c2w, focal, cen = syn.pinhole_camera(H, W)
@@ -127,8 +143,9 @@ def main():
         "dtype": args.mode,
         "data": "synthetic",
         "config": {
-            "workload": ("BASELINE configs[1]: 1024x1024 render, 64 coarse + 64 fine, random-init 8x256 MLP x2, "
-                         "fixed SMPL pose, no LBS warp" if not use_warp else
+            "workload": ("BASELINE configs[1]: 1024x1024 render, 64 coarse + 64 fine, random-init 8x256 MLP x2"
+                         + (" (sigma rows rescaled about their median)" if args.sigma_gain > 0 else "")
+                         + ", fixed SMPL pose, no LBS warp" if not use_warp else
                          "BASELINE configs[2]: configs[1] + inverse-LBS / exact 4-NN canonical warp (V=6890, animated pose)"),
             "rays_per_step_per_gpu": n_rays, "n_coarse": args.n_coarse, "n_fine": args.n_fine,
             "mlp_evals_per_ray": args.n_coarse + (args.n_coarse + args.n_fine if args.n_fine else 0),
@@ -171,21 +188,27 @@ def cpu_baseline(args, tbl, model, rays, pose_np, use_warp):
     from anim_nerf_amd import synthetic as syn
     from oracle import animnerf_oracle as orc
     import anim_nerf_amd as ana
-    n = args.cpu_rays
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(cores)
     bm = ana.SMPL(data_struct=tbl)
     otbl = dict(v_template=bm.v_template, shapedirs=bm.shapedirs, posedirs=bm.posedirs, J_regressor=bm.J_regressor,
                 parents=bm.parents, lbs_weights=bm.lbs_weights, extra_joints_idxs=bm.vertex_joint_selector.extra_joints_idxs)
     Pc = {k: v.detach().cpu() for k, v in model.nerf.named_parameters()}
     Pf = {k: v.detach().cpu() for k, v in model.nerf_fine.named_parameters()}
-    stride = max(1, rays.shape[1] // n)
-    sample = rays[:, ::stride][:, :n].cpu().contiguous()
     pose = {k: torch.from_numpy(v) for k, v in pose_np.items()}
     templ = {k: torch.from_numpy(v) for k, v in syn.template_pose_params().items()}
     kw = dict(n_coarse=args.n_coarse, n_fine=args.n_fine, use_unpose=use_warp, chunk=512 if not use_warp else 128,
               knn_chunk=2048)
-    orc.render_frame(otbl, Pc, Pf, sample[:, :256], pose, templ, **kw)          # warm-up
+    # warm-up doubles as calibration: size the sample for about --cpu-seconds of work
+    centre = rays.shape[1] // 2
+    probe = rays[:, centre:centre + 64].cpu().contiguous()
+    orc.render_frame(otbl, Pc, Pf, probe[:, :8], pose, templ, **kw)
+    t0 = time.perf_counter()
+    orc.render_frame(otbl, Pc, Pf, probe, pose, templ, **kw)
+    rate = 64 / (time.perf_counter() - t0)
+    n = int(min(args.cpu_rays, max(64, rate * args.cpu_seconds)))
+    stride = max(1, rays.shape[1] // n)
+    sample = rays[:, ::stride][:, :n].cpu().contiguous()
     t0 = time.perf_counter()
     orc.render_frame(otbl, Pc, Pf, sample, pose, templ, **kw)
     dt = time.perf_counter() - t0
