@@ -47,9 +47,11 @@ SIGNATURES = {
     "anr_ray_gen": (_I, [_P, _P, _P, _I, _I, _F, _F, _P, _P]),
     "anr_rays_to_body": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "anr_ober2cano": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "anr_knn_index_bytes": (_L, [_I]),
+    "anr_knn_index_build": (_I, [_P, _P, _I, _I, _P, _P]),
     "anr_knn": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),
     "anr_sample_coarse": (_I, [_P, _I, _P, _P, _L, _I, _P, _P]),
-    "anr_warp_points": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _L, _F, _P, _P, _P, _P, _P]),
+    "anr_warp_points": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _L, _F, _I, _P, _P, _P, _P, _P]),
     "anr_points_from_rays": (_I, [_P, _I, _P, _I, _L, _P, _P]),
     "anr_mlp_pack_bytes": (_L, [_I]),
     "anr_mlp_pack": (_I, [C.POINTER(AnrMlpParams), _I, _P, _P]),

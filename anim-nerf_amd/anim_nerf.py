@@ -49,6 +49,10 @@ class AnimNeRF(nn.Module):
             self.body_model = create(model_path, model_type, gender=gender)
         self.weight_std = 0.1
         self.lbs_dim = self.body_model.lbs_weights.shape[1]
+        # fixed spatial order of the vertices for the per-frame KNN index (not part of the state dict)
+        self.register_buffer("knn_order", ops.morton_order(self.body_model.v_template), persistent=False)
+        self._knn_index = None
+        self.skip_far_samples = True     # renderer only: no neighbour search for provably-invalid samples
 
         mk = dict(freqs_xyz=freqs_xyz, freqs_dir=freqs_dir, use_view=use_view, deformation_dim=deformation_dim,
                   apperance_dim=apperance_dim, mlp_mode=mlp_mode)
@@ -74,6 +78,7 @@ class AnimNeRF(nn.Module):
         self.shape_offsets = o["shape_offsets"]
         self.pose_offsets = o["pose_offsets"]
         self.global_transform = o["joints_transform"][:, 0].clone()
+        self._knn_index = None
         if body_model_params_template is not None:
             t = self.body_model(**body_model_params_template, return_verts=True)
             self.verts_template = t["vertices"]
@@ -89,6 +94,7 @@ class AnimNeRF(nn.Module):
         new_rays = ops.rays_to_body(g_inv, rays)
         G = g_inv[:, None]
         self.verts = batch_transform(G, self.verts)
+        self._knn_index = None
         self.joints = batch_transform(G, self.joints)
         self.global_transform = g_inv @ self.global_transform
         self.verts_transform = G @ self.verts_transform
@@ -103,9 +109,16 @@ class AnimNeRF(nn.Module):
     def _net(self, use_fine):
         return self.nerf_fine if use_fine else self.nerf
 
+    def knn_index(self):
+        """Spatial index over the current posed vertices (rebuilt when set_body_model /
+        convert_to_body_model_space replace them)."""
+        if self._knn_index is None or self._knn_index[0] is not self.verts:
+            self._knn_index = (self.verts, ops.knn_index_build(self.verts, self.knn_order))
+        return self._knn_index[1]
+
     def unpose(self, xyz, viewdir=None):
         """-> xyz_unposed[bs,N,3], viewdir, valid[bs,N,1]   (models/anim_nerf.py:180-192)."""
-        pts = ops.warp_points(self.verts, self.ober2cano_transform, self.body_model.lbs_weights,
+        pts = ops.warp_points(self.knn_index(), self.ober2cano_transform, self.body_model.lbs_weights,
                               self.dis_threshold, xyz=xyz)
         return pts[..., :3], viewdir, pts[..., 3:4]
 
@@ -117,11 +130,14 @@ class AnimNeRF(nn.Module):
             return net.get_normal(xyz)
         return net(xyz, viewdir=viewdir)
 
-    def warped_points(self, *, xyz=None, rays=None, z=None) -> torch.Tensor:
-        """pts[bs*N,4] = (canonical xyz, valid) for explicit points or for samples along rays."""
+    def warped_points(self, *, xyz=None, rays=None, z=None, skip_far=False) -> torch.Tensor:
+        """pts[bs*N,4] = (canonical xyz, valid) for explicit points or for samples along rays.
+        skip_far: provably-invalid samples (farther than dis_threshold from the body's bounding box) skip the
+        neighbour search; only legal where sigma = -1e5 is all that is consumed (the renderer)."""
         if self.use_unpose:
-            return ops.warp_points(self.verts, self.ober2cano_transform, self.body_model.lbs_weights,
-                                   self.dis_threshold, xyz=xyz, rays=rays, z=z).view(-1, 4)
+            return ops.warp_points(self.knn_index(), self.ober2cano_transform, self.body_model.lbs_weights,
+                                   self.dis_threshold, xyz=xyz, rays=rays, z=z,
+                                   skip_far=skip_far and self.skip_far_samples).view(-1, 4)
         if xyz is not None:
             flat = xyz.reshape(-1, xyz.shape[-1])[:, :3]
             return torch.cat([flat, torch.ones_like(flat[:, :1])], -1)

@@ -1,31 +1,110 @@
 // Canonical-space warp: exact 4-nearest-vertex search + blend-weight confidence + blended inverse
 // skinning transform (a7-a10), and the stand-alone KNN entry point that replaces knn_cuda.KNN.
 //
-// Layout.  One workgroup (512 threads = 8 wavefronts) serves one body: the posed vertex table
-// (V x 3 fp32, 82.7 KB at V = 6890) is staged once into LDS as three SoA planes and every lane
-// scans it with wave-uniform (broadcast) ds_read_b128s for PTS points held in registers, so the
-// table is read from HBM/L2 once per workgroup and the V x N distance matrix the CUDA reference
-// materialises in global memory (55 KB per point) never exists.  The per-vertex tables that are
-// only gathered for the four winners (lbs_weights 24 floats, ober2cano 12 floats) stay in L2.
+// The CUDA reference materialises a V x N distance matrix in global memory (55 KB per point) and
+// insertion-sorts its columns.  Here the search is exact but pruned: once per frame
+// `anr_knn_index_build` lays the posed vertices out in a fixed spatial order (clusters of 32, super-
+// clusters of 8 clusters) with their bounding boxes; `anr_warp_points` / `anr_knn` stage that 91 KB
+// index into LDS once per workgroup and every lane walks super-cluster -> cluster -> vertex with
+// wave-uniform (broadcast) LDS reads, skipping whatever cannot beat its current 4th-best distance.
+// A wavefront holds 64 NEIGHBOURING rays at the same sample depth, so its lanes agree on what to skip.
+// The per-vertex tables that are only gathered for the four winners (lbs_weights 24 floats,
+// ober2cano 12 floats) stay in L2.
+//
+// Index layout per body (floats): x[Vp] y[Vp] z[Vp] | cluster boxes NC x 8 | super boxes NS x 8 |
+// body box 8 | order[Vp] (int32: slot -> original vertex id).  Vp = 32 NC, NC = ceil(V/32), NS = ceil(NC/8).
 #include "anr_common.h"
 
 namespace anr {
 
-constexpr int WARP_THREADS = 512;
-constexpr int PTS = 2;                     // points per lane
+constexpr int WARP_THREADS = 1024;
+constexpr int CS = 32;                     // vertices per cluster
+constexpr int SC = 8;                      // clusters per super-cluster
 constexpr int MAX_J = 32;
+constexpr float FAR = 1.0e18f;
 
+struct IndexDims {
+    int V, NC, NS, Vp;
+    __host__ __device__ int box_off() const { return 3 * Vp; }
+    __host__ __device__ int sbox_off() const { return 3 * Vp + 8 * NC; }
+    __host__ __device__ int body_off() const { return 3 * Vp + 8 * NC + 8 * NS; }
+    __host__ __device__ int order_off() const { return 3 * Vp + 8 * NC + 8 * NS + 8; }
+    __host__ __device__ int lds_floats() const { return order_off(); }
+    __host__ __device__ int total_floats() const { return order_off() + Vp; }
+};
+inline IndexDims index_dims(int V) {
+    IndexDims d;
+    d.V = V;
+    d.NC = (V + CS - 1) / CS;
+    d.NS = (d.NC + SC - 1) / SC;
+    d.Vp = d.NC * CS;
+    return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-frame index build: one workgroup per body
+__global__ __launch_bounds__(256) void knn_index_build_kernel(const float* __restrict__ verts,
+                                                              const int32_t* __restrict__ order, IndexDims d,
+                                                              float* __restrict__ index) {
+    const int b = blockIdx.x;
+    const float* v = verts + (int64_t)b * d.V * 3;
+    float* out = index + (int64_t)b * d.total_floats();
+    int32_t* ord_out = reinterpret_cast<int32_t*>(out + d.order_off());
+    __shared__ float cbox[512][6];
+    for (int c = threadIdx.x; c < d.NC; c += blockDim.x) {
+        float lo[3] = {FAR, FAR, FAR}, hi[3] = {-FAR, -FAR, -FAR};
+        for (int i = 0; i < CS; ++i) {
+            const int slot = c * CS + i;
+            float p[3] = {FAR, FAR, FAR};
+            int src = -1;
+            if (slot < d.V) {
+                src = order ? order[slot] : slot;
+                p[0] = v[src * 3 + 0]; p[1] = v[src * 3 + 1]; p[2] = v[src * 3 + 2];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[a]); hi[a] = fmaxf(hi[a], p[a]); }
+            }
+            out[slot] = p[0]; out[d.Vp + slot] = p[1]; out[2 * d.Vp + slot] = p[2];
+            ord_out[slot] = src < 0 ? 0 : src;
+        }
+        float* bx = out + d.box_off() + c * 8;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { bx[a] = lo[a]; bx[4 + a] = hi[a]; cbox[c][a] = lo[a]; cbox[c][3 + a] = hi[a]; }
+        bx[3] = 0.f; bx[7] = 0.f;
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < d.NS; s += blockDim.x) {
+        float lo[3] = {FAR, FAR, FAR}, hi[3] = {-FAR, -FAR, -FAR};
+        for (int c = s * SC; c < min((s + 1) * SC, d.NC); ++c)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], cbox[c][a]); hi[a] = fmaxf(hi[a], cbox[c][3 + a]); }
+        float* bx = out + d.sbox_off() + s * 8;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { bx[a] = lo[a]; bx[4 + a] = hi[a]; }
+        bx[3] = 0.f; bx[7] = 0.f;
+    }
+    if (threadIdx.x == 0) {
+        float lo[3] = {FAR, FAR, FAR}, hi[3] = {-FAR, -FAR, -FAR};
+        for (int c = 0; c < d.NC; ++c)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], cbox[c][a]); hi[a] = fmaxf(hi[a], cbox[c][3 + a]); }
+        float* bx = out + d.body_off();
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { bx[a] = lo[a]; bx[4 + a] = hi[a]; }
+        bx[3] = 0.f; bx[7] = 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 struct Best4 {
     float d[4];
     int i[4];
 };
-
-__device__ __forceinline__ void best_init(Best4& b) {
+// cap2 = squared search radius: only vertices strictly closer than sqrt(cap2) are collected; slots stay -1 otherwise
+__device__ __forceinline__ void best_init(Best4& b, float cap2 = 3.0e38f) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { b.d[k] = 3.0e38f; b.i[k] = 0; }
+    for (int k = 0; k < 4; ++k) { b.d[k] = cap2; b.i[k] = -1; }
 }
-
-// insert (c, v) keeping d ascending; strict < so the lower vertex id wins ties
+// insert (c, v) keeping d ascending; strict < : the first visited vertex wins exact ties
 __device__ __forceinline__ void best_insert(Best4& b, float c, int v) {
     if (c < b.d[3]) {
         b.d[3] = c; b.i[3] = v;
@@ -39,96 +118,226 @@ __device__ __forceinline__ void best_insert(Best4& b, float c, int v) {
     }
 }
 
-// Stage verts[V*3] (AoS) into LDS planes x[Vp], y[Vp], z[Vp]; pad with far-away points.
-__device__ __forceinline__ void stage_verts(const float* __restrict__ verts, int V, int Vp, float* lds) {
-    for (int e = threadIdx.x; e < V * 3; e += blockDim.x) {
-        int v = e / 3, c = e - v * 3;
-        lds[c * Vp + v] = verts[e];
-    }
-    for (int v = V + threadIdx.x; v < Vp; v += blockDim.x) {
-        lds[v] = 1.0e18f; lds[Vp + v] = 1.0e18f; lds[2 * Vp + v] = 1.0e18f;
-    }
-    __syncthreads();
+// squared distance from p to an axis-aligned box (0 inside)
+__device__ __forceinline__ float box_d2(const float* bx, float px, float py, float pz) {
+    const float4 lo = *reinterpret_cast<const float4*>(bx);
+    const float4 hi = *reinterpret_cast<const float4*>(bx + 4);
+    float dx = fmaxf(fmaxf(lo.x - px, px - hi.x), 0.f);
+    float dy = fmaxf(fmaxf(lo.y - py, py - hi.y), 0.f);
+    float dz = fmaxf(fmaxf(lo.z - pz, pz - hi.z), 0.f);
+    return dx * dx + dy * dy + dz * dz;
 }
 
-// brute-force scan of the LDS table for PTS points per lane
-__device__ __forceinline__ void scan_table(const float* lds, int Vp, const float (&px)[PTS], const float (&py)[PTS],
-                                           const float (&pz)[PTS], Best4 (&best)[PTS]) {
-    const float4* X = reinterpret_cast<const float4*>(lds);
-    const float4* Y = reinterpret_cast<const float4*>(lds + Vp);
-    const float4* Z = reinterpret_cast<const float4*>(lds + 2 * Vp);
-    const int n4 = Vp >> 2;
-    for (int q = 0; q < n4; ++q) {
-        float4 vx = X[q], vy = Y[q], vz = Z[q];
+__device__ __forceinline__ void scan_cluster(const float* lds, int Vp, int c, float px, float py, float pz,
+                                             Best4& best) {
+    const float4* X = reinterpret_cast<const float4*>(lds + c * CS);
+    const float4* Y = reinterpret_cast<const float4*>(lds + Vp + c * CS);
+    const float4* Z = reinterpret_cast<const float4*>(lds + 2 * Vp + c * CS);
+#pragma unroll
+    for (int q = 0; q < CS / 4; ++q) {
+        const float4 vx = X[q], vy = Y[q], vz = Z[q];
         const float ax[4] = {vx.x, vx.y, vx.z, vx.w};
         const float ay[4] = {vy.x, vy.y, vy.z, vy.w};
         const float az[4] = {vz.x, vz.y, vz.z, vz.w};
+        float d2[4];
 #pragma unroll
-        for (int p = 0; p < PTS; ++p) {
-            float d2[4];
+        for (int t = 0; t < 4; ++t) {
+            float dx = px - ax[t], dy = py - ay[t], dz = pz - az[t];
+            d2[t] = dx * dx + dy * dy + dz * dz;
+        }
+        float m = fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3]));
+        if (m < best.d[3]) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float dx = px[p] - ax[t], dy = py[p] - ay[t], dz = pz[p] - az[t];
-                d2[t] = dx * dx + dy * dy + dz * dz;
-            }
-            float m = fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3]));
-            if (m < best[p].d[3]) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) best_insert(best[p], d2[t], q * 4 + t);
+            for (int t = 0; t < 4; ++t) best_insert(best, d2[t], c * CS + q * 4 + t);
+        }
+    }
+}
+
+// exact 4 nearest vertices of (px,py,pz); best.i are index SLOTS (map through order[] for vertex ids).
+// Control flow is wave-uniform (ballots); per-lane work is predicated.
+__device__ __forceinline__ void search(const float* lds, const IndexDims& d, float px, float py, float pz, bool active,
+                                       Best4& best) {
+    const float* boxes = lds + d.box_off();
+    const float* sboxes = lds + d.sbox_off();
+    // 1. seed: nearest super-cluster by box distance, nearest cluster inside it -> scan it
+    int seed_s = 0;
+    float seed_v = 3.0e38f;
+    for (int s = 0; s < d.NS; ++s) {
+        float v = box_d2(sboxes + s * 8, px, py, pz);
+        if (v < seed_v) { seed_v = v; seed_s = s; }
+    }
+    int seed_c = seed_s * SC;
+    seed_v = 3.0e38f;
+    for (int j = 0; j < SC; ++j) {
+        // every lane evaluates the j-th cluster of ITS OWN seed super-cluster (per-lane LDS address)
+        int c = min(seed_s * SC + j, d.NC - 1);
+        float v = box_d2(boxes + c * 8, px, py, pz);
+        if (v < seed_v) { seed_v = v; seed_c = c; }
+    }
+    if (!active) seed_c = -1;
+    for (int c = 0; c < d.NC; ++c) {
+        const bool mine = (c == seed_c);
+        if (__any(mine)) {
+            if (mine) scan_cluster(lds, d.Vp, c, px, py, pz, best);
+        }
+    }
+    // 2. every other cluster whose box can still beat the current 4th-best
+    for (int s = 0; s < d.NS; ++s) {
+        const float sv = box_d2(sboxes + s * 8, px, py, pz);
+        if (!__any(active && sv < best.d[3])) continue;
+        const int c_end = min((s + 1) * SC, d.NC);
+        for (int c = s * SC; c < c_end; ++c) {
+            const float v = box_d2(boxes + c * 8, px, py, pz);
+            const bool need = active && (c != seed_c) && (v < best.d[3]);
+            if (__any(need)) {
+                if (need) scan_cluster(lds, d.Vp, c, px, py, pz, best);
             }
         }
     }
+}
+
+__device__ __forceinline__ void stage_index(const float* __restrict__ index, int n_floats, float* lds) {
+    const float4* src = reinterpret_cast<const float4*>(index);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = threadIdx.x; i < n_floats / 4; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
 // reference: models/anim_nerf.py:153-192 (get_neighbs + unpose), volume_rendering.py:117
+// Work item = 64 points handled by one wavefront:
+//   mode RAYS : 64 neighbouring rays at one sample index k; a workgroup owns RAYS_PER_WG rays x all K samples
+//   mode XYZ  : 64 consecutive explicit points; a workgroup owns PTS_PER_WG of them
+// Items are handed out through an LDS counter: empty-space items cost a few instructions, surface items a full
+// search, and a static split would leave most of the workgroup's 16 waves idle behind the slowest one.
+constexpr int RAYS_PER_WG = 256;
+constexpr int PTS_PER_WG = 16384;
+
+template <bool FROM_RAYS>
 __global__ __launch_bounds__(WARP_THREADS) void warp_points_kernel(
     const float* __restrict__ xyz, int xyz_stride, const float* __restrict__ rays, int ray_stride,
-    const float* __restrict__ z, int K, const float* __restrict__ verts, const float* __restrict__ ober2cano,
-    const float* __restrict__ lbs_w, int V, int Vp, int J, int64_t N, float thr, float4* __restrict__ pts_out,
-    float* __restrict__ dist_out, int32_t* __restrict__ idx_out, float* __restrict__ blended_out) {
+    const float* __restrict__ z, int K, const float* __restrict__ index, IndexDims d,
+    const float* __restrict__ ober2cano, const float* __restrict__ lbs_w, int J, int64_t N, float thr, int skip_far,
+    float4* __restrict__ pts_out, float* __restrict__ dist_out, int32_t* __restrict__ idx_out,
+    float* __restrict__ blended_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int next_item;
     const int b = blockIdx.y;
-    stage_verts(verts + (int64_t)b * V * 3, V, Vp, lds);
+    const float* my_index = index + (int64_t)b * d.total_floats();
+    const int32_t* order = reinterpret_cast<const int32_t*>(my_index + d.order_off());
+    const float* O2C = ober2cano + (int64_t)b * d.V * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t R = FROM_RAYS ? N / K : 0;
+    const int n_items = FROM_RAYS ? (RAYS_PER_WG / 64) * K : PTS_PER_WG / 64;
 
-    const int64_t base = (int64_t)blockIdx.x * (WARP_THREADS * PTS);
-    float px[PTS], py[PTS], pz[PTS];
-    int64_t n[PTS];
-    Best4 best[PTS];
-#pragma unroll
-    for (int p = 0; p < PTS; ++p) {
-        n[p] = base + p * WARP_THREADS + threadIdx.x;
-        int64_t nn = n[p] < N ? n[p] : N - 1;
-        if (xyz != nullptr) {
-            const float* s = xyz + ((int64_t)b * N + nn) * xyz_stride;
-            px[p] = s[0]; py[p] = s[1]; pz[p] = s[2];
+    // point of this lane in work item `item`: index n, coordinates, in-range flag
+    auto fetch = [&](int item, int64_t& n, float& px, float& py, float& pz) -> bool {
+        bool active;
+        if (FROM_RAYS) {
+            const int64_t ray = (int64_t)blockIdx.x * RAYS_PER_WG + (item / K) * 64 + lane;
+            const int k = item % K;
+            active = ray < R;
+            n = (active ? ray : 0) * K + k;
+            const float* ry = rays + ((int64_t)b * R + (active ? ray : 0)) * ray_stride;
+            const float zz = z[(int64_t)b * N + n];
+            px = __fadd_rn(ry[0], __fmul_rn(zz, ry[3]));
+            py = __fadd_rn(ry[1], __fmul_rn(zz, ry[4]));
+            pz = __fadd_rn(ry[2], __fmul_rn(zz, ry[5]));
         } else {
-            const float* ry = rays + ((int64_t)b * (N / K) + nn / K) * ray_stride;
-            float zz = z[(int64_t)b * N + nn];
-            px[p] = __fadd_rn(ry[0], __fmul_rn(zz, ry[3]));
-            py[p] = __fadd_rn(ry[1], __fmul_rn(zz, ry[4]));
-            pz[p] = __fadd_rn(ry[2], __fmul_rn(zz, ry[5]));
+            n = (int64_t)blockIdx.x * PTS_PER_WG + item * 64 + lane;
+            active = n < N;
+            if (!active) n = N - 1;
+            const float* s = xyz + ((int64_t)b * N + n) * xyz_stride;
+            px = s[0]; py = s[1]; pz = s[2];
         }
-        best_init(best[p]);
-    }
-    scan_table(lds, Vp, px, py, pz, best);
+        return active;
+    };
 
-    const float* O2C = ober2cano + (int64_t)b * V * 16;
-#pragma unroll
-    for (int p = 0; p < PTS; ++p) {
-        if (n[p] >= N) continue;
+    // Pass 0 (renderer only): a workgroup whose samples are ALL farther than the threshold from the body's
+    // bounding box writes (x, 0) and leaves without staging the 91 KB index — most of the frame is empty space.
+    if (threadIdx.x == 0) next_item = 0;
+    if (skip_far) {
+        const float* gbox = my_index + d.body_off();
+        bool any_near = false;
+        for (int item = wave; item < n_items; item += WARP_THREADS / 64) {
+            int64_t n; float px, py, pz;
+            const bool active = fetch(item, n, px, py, pz);
+            const bool far = box_d2(gbox, px, py, pz) >= thr * thr;
+            if (active && far) pts_out[(int64_t)b * N + n] = make_float4(px, py, pz, 0.0f);
+            any_near |= active && !far;
+        }
+        if (!__syncthreads_or(any_near)) return;
+    }
+    stage_index(my_index, d.lds_floats(), lds);
+    const float* body_box = lds + d.body_off();
+
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(&next_item, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        int64_t n;
+        float px, py, pz;
+        const bool active = fetch(item, n, px, py, pz);
+        const int64_t o = (int64_t)b * N + n;
+        // Points farther than the threshold from the whole body cannot be valid: the blended distance is a convex
+        // combination of neighbour distances, all >= the distance to the body's bounding box.
+        bool far = false;
+        if (skip_far) far = box_d2(body_box, px, py, pz) >= thr * thr;      // already written in pass 0
+        const bool go = active && !far;
+        if (!__any(go)) continue;
+
+        // Renderer mode first searches only inside the validity radius: no vertex there -> the sample is invalid
+        // (blended distance >= nearest distance >= threshold) and needs no neighbours at all; four or more -> those
+        // ARE the exact 4-NN.  Only the thin shell with 1-3 vertices inside the radius repeats the search unbounded.
+        Best4 best;
+        best_init(best, skip_far ? thr * thr * 1.0002f : 3.0e38f);
+        search(lds, d, px, py, pz, go, best);
+        if (skip_far) {
+            const bool none = go && best.i[0] < 0;
+            if (none) pts_out[o] = make_float4(px, py, pz, 0.0f);
+            const bool partial = go && best.i[0] >= 0 && best.i[3] < 0;
+            if (__any(partial)) {
+                Best4 full;
+                best_init(full);
+                search(lds, d, px, py, pz, partial, full);
+                if (partial) best = full;
+            }
+            if (none) continue;
+        }
+        if (!go) continue;
+
         float dist[4], conf[4], w[4];
+        int vid[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dist[k] = sqrtf(best[p].d[k]);
-        // blend-weight confidence against neighbour 0 (anim_nerf.py:165-168)
-        const float* w0 = lbs_w + (int64_t)best[p].i[0] * J;
+        for (int k = 0; k < 4; ++k) { dist[k] = sqrtf(best.d[k]); vid[k] = order[best.i[k]]; }
+        // blend-weight confidence against neighbour 0 (anim_nerf.py:165-168); rows are read as float4 (J % 4 == 0,
+        // 16-B aligned rows): one request per 16 B instead of per float on this uncoalesced gather
         conf[0] = 1.0f;
+        if ((J & 3) == 0) {
+            const float4* r0 = reinterpret_cast<const float4*>(lbs_w + (int64_t)vid[0] * J);
+            float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            const float4* r1 = reinterpret_cast<const float4*>(lbs_w + (int64_t)vid[1] * J);
+            const float4* r2 = reinterpret_cast<const float4*>(lbs_w + (int64_t)vid[2] * J);
+            const float4* r3 = reinterpret_cast<const float4*>(lbs_w + (int64_t)vid[3] * J);
+            for (int q = 0; q < (J >> 2); ++q) {
+                const float4 a = r0[q], b1 = r1[q], b2 = r2[q], b3 = r3[q];
+                s1 += fabsf(b1.x - a.x) + fabsf(b1.y - a.y) + fabsf(b1.z - a.z) + fabsf(b1.w - a.w);
+                s2 += fabsf(b2.x - a.x) + fabsf(b2.y - a.y) + fabsf(b2.z - a.z) + fabsf(b2.w - a.w);
+                s3 += fabsf(b3.x - a.x) + fabsf(b3.y - a.y) + fabsf(b3.z - a.z) + fabsf(b3.w - a.w);
+            }
+            conf[1] = (expf(-s1 / 0.02f) > 0.9f) ? 1.0f : 0.0f;
+            conf[2] = (expf(-s2 / 0.02f) > 0.9f) ? 1.0f : 0.0f;
+            conf[3] = (expf(-s3 / 0.02f) > 0.9f) ? 1.0f : 0.0f;
+        } else {
+            const float* w0 = lbs_w + (int64_t)vid[0] * J;
 #pragma unroll
-        for (int k = 1; k < 4; ++k) {
-            const float* wk = lbs_w + (int64_t)best[p].i[k] * J;
-            float s = 0.f;
-            for (int j = 0; j < J; ++j) s += fabsf(wk[j] - w0[j]);
-            conf[k] = (expf(-s / 0.02f) > 0.9f) ? 1.0f : 0.0f;
+            for (int k = 1; k < 4; ++k) {
+                const float* wk = lbs_w + (int64_t)vid[k] * J;
+                float s = 0.f;
+                for (int j = 0; j < J; ++j) s += fabsf(wk[j] - w0[j]);
+                conf[k] = (expf(-s / 0.02f) > 0.9f) ? 1.0f : 0.0f;
+            }
         }
         float wsum = 0.f;
 #pragma unroll
@@ -140,7 +349,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_points_kernel(
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             w[k] = w[k] / wsum;
-            const float4* M = reinterpret_cast<const float4*>(O2C + (int64_t)best[p].i[k] * 16);
+            const float4* M = reinterpret_cast<const float4*>(O2C + (int64_t)vid[k] * 16);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 float4 m = M[r];
@@ -149,14 +358,13 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_points_kernel(
             }
             db += w[k] * dist[k];
         }
-        float cx = T[0] * px[p] + T[1] * py[p] + T[2] * pz[p] + T[3];
-        float cy = T[4] * px[p] + T[5] * py[p] + T[6] * pz[p] + T[7];
-        float cz = T[8] * px[p] + T[9] * py[p] + T[10] * pz[p] + T[11];
-        const int64_t o = (int64_t)b * N + n[p];
+        float cx = T[0] * px + T[1] * py + T[2] * pz + T[3];
+        float cy = T[4] * px + T[5] * py + T[6] * pz + T[7];
+        float cz = T[8] * px + T[9] * py + T[10] * pz + T[11];
         pts_out[o] = make_float4(cx, cy, cz, db < thr ? 1.0f : 0.0f);
         if (dist_out != nullptr) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { dist_out[o * 4 + k] = dist[k]; idx_out[o * 4 + k] = best[p].i[k]; }
+            for (int k = 0; k < 4; ++k) { dist_out[o * 4 + k] = dist[k]; idx_out[o * 4 + k] = vid[k]; }
             blended_out[o] = db;
         }
     }
@@ -164,39 +372,30 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_points_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // reference: models/anim_nerf.py:157-163 (KNN_CUDA call / in-repo fallback definition)
-__global__ __launch_bounds__(WARP_THREADS) void knn_kernel(const float* __restrict__ verts,
-                                                           const float* __restrict__ xyz, int V, int Vp, int64_t N,
+__global__ __launch_bounds__(WARP_THREADS) void knn_kernel(const float* __restrict__ index, IndexDims d,
+                                                           const float* __restrict__ xyz, int64_t N,
                                                            float* __restrict__ dist_out,
                                                            int64_t* __restrict__ idx_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.y;
-    stage_verts(verts + (int64_t)b * V * 3, V, Vp, lds);
-    const int64_t base = (int64_t)blockIdx.x * (WARP_THREADS * PTS);
-    float px[PTS], py[PTS], pz[PTS];
-    int64_t n[PTS];
-    Best4 best[PTS];
+    const float* my_index = index + (int64_t)b * d.total_floats();
+    stage_index(my_index, d.lds_floats(), lds);
+    const int32_t* order = reinterpret_cast<const int32_t*>(my_index + d.order_off());
+    for (int it = 0; it < 4; ++it) {
+        int64_t n = (int64_t)blockIdx.x * 4096 + it * WARP_THREADS + threadIdx.x;
+        const bool active = n < N;
+        if (!active) n = N - 1;
+        const float* s = xyz + ((int64_t)b * N + n) * 3;
+        const float px = s[0], py = s[1], pz = s[2];
+        if (!__any(active)) continue;
+        Best4 best;
+        best_init(best);
+        search(lds, d, px, py, pz, active, best);
+        if (!active) continue;
+        const int64_t o = ((int64_t)b * N + n) * 4;
 #pragma unroll
-    for (int p = 0; p < PTS; ++p) {
-        n[p] = base + p * WARP_THREADS + threadIdx.x;
-        int64_t nn = n[p] < N ? n[p] : N - 1;
-        const float* s = xyz + ((int64_t)b * N + nn) * 3;
-        px[p] = s[0]; py[p] = s[1]; pz[p] = s[2];
-        best_init(best[p]);
+        for (int k = 0; k < 4; ++k) { dist_out[o + k] = sqrtf(best.d[k]); idx_out[o + k] = order[best.i[k]]; }
     }
-    scan_table(lds, Vp, px, py, pz, best);
-#pragma unroll
-    for (int p = 0; p < PTS; ++p) {
-        if (n[p] >= N) continue;
-        const int64_t o = ((int64_t)b * N + n[p]) * 4;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { dist_out[o + k] = sqrtf(best[p].d[k]); idx_out[o + k] = best[p].i[k]; }
-    }
-}
-
-inline int lds_bytes_for(int V, int* Vp_out) {
-    int Vp = (V + 3) & ~3;
-    *Vp_out = Vp;
-    return Vp * 3 * (int)sizeof(float);
 }
 
 template <typename Kern>
@@ -210,11 +409,28 @@ int allow_big_lds(Kern k, int bytes, const char* who) {
 
 using namespace anr;
 
+extern "C" int64_t anr_knn_index_bytes(int V) {
+    if (V < 4) return ANR_E_BADARG;
+    return (int64_t)index_dims(V).total_floats() * 4;
+}
+
+extern "C" int anr_knn_index_build(const float* verts, const int32_t* order, int bs, int V, void* index_out,
+                                   void* stream) {
+    ANR_REQUIRE(verts && index_out, ANR_E_BADARG, "anr_knn_index_build: null pointer");
+    ANR_REQUIRE(bs > 0 && V >= 4, ANR_E_BADARG, "anr_knn_index_build: bs=%d V=%d", bs, V);
+    ANR_REQUIRE(((uintptr_t)index_out & 15) == 0, ANR_E_ALIGN, "anr_knn_index_build: index_out must be 16-B aligned");
+    IndexDims d = index_dims(V);
+    ANR_REQUIRE(d.NC <= 512, ANR_E_SHAPE, "anr_knn_index_build: V=%d too large (max 16384)", V);
+    hipLaunchKernelGGL(knn_index_build_kernel, dim3(bs), dim3(256), 0, (hipStream_t)stream, verts, order, d,
+                       reinterpret_cast<float*>(index_out));
+    return check_launch("anr_knn_index_build");
+}
+
 extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* rays, int ray_stride, const float* z,
-                               int K, const float* verts, const float* ober2cano, const float* lbs_weights, int bs,
-                               int V, int J, int64_t N, float dis_threshold, float* pts_out, float* dist_out,
-                               int32_t* idx_out, float* blended_out, void* stream) {
-    ANR_REQUIRE(verts && ober2cano && lbs_weights && pts_out, ANR_E_BADARG, "anr_warp_points: null pointer");
+                               int K, const void* knn_index, const float* ober2cano, const float* lbs_weights, int bs,
+                               int V, int J, int64_t N, float dis_threshold, int skip_far, float* pts_out,
+                               float* dist_out, int32_t* idx_out, float* blended_out, void* stream) {
+    ANR_REQUIRE(knn_index && ober2cano && lbs_weights && pts_out, ANR_E_BADARG, "anr_warp_points: null pointer");
     ANR_REQUIRE((xyz != nullptr) || (rays != nullptr && z != nullptr), ANR_E_BADARG,
                 "anr_warp_points: need xyz or (rays, z)");
     ANR_REQUIRE(bs > 0 && V >= 4 && N > 0 && J > 0 && J <= MAX_J, ANR_E_BADARG,
@@ -223,27 +439,41 @@ extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* ra
                 "anr_warp_points: bad stride/K");
     ANR_REQUIRE((dist_out == nullptr) == (idx_out == nullptr) && (dist_out == nullptr) == (blended_out == nullptr),
                 ANR_E_BADARG, "anr_warp_points: debug outputs are all-or-none");
-    ANR_REQUIRE((((uintptr_t)pts_out | (uintptr_t)ober2cano) & 15) == 0, ANR_E_ALIGN,
-                "anr_warp_points: pts_out / ober2cano must be 16-B aligned");
-    int Vp, bytes = lds_bytes_for(V, &Vp);
+    ANR_REQUIRE((((uintptr_t)pts_out | (uintptr_t)ober2cano | (uintptr_t)knn_index) & 15) == 0, ANR_E_ALIGN,
+                "anr_warp_points: pts_out / ober2cano / knn_index must be 16-B aligned");
+    IndexDims d = index_dims(V);
+    const int bytes = d.lds_floats() * 4;
     ANR_REQUIRE(bytes <= 160 * 1024, ANR_E_SHAPE, "anr_warp_points: V=%d needs %d B of LDS (>160 KiB)", V, bytes);
-    if (int rc = allow_big_lds(warp_points_kernel, bytes, "anr_warp_points")) return rc;
-    dim3 grid((unsigned)((N + WARP_THREADS * PTS - 1) / (WARP_THREADS * PTS)), bs);
-    hipLaunchKernelGGL(warp_points_kernel, grid, dim3(WARP_THREADS), bytes, (hipStream_t)stream, xyz, xyz_stride, rays,
-                       ray_stride, z, K, verts, ober2cano, lbs_weights, V, Vp, J, N, dis_threshold,
-                       reinterpret_cast<float4*>(pts_out), dist_out, idx_out, blended_out);
+    hipStream_t st = (hipStream_t)stream;
+    const float* index = reinterpret_cast<const float*>(knn_index);
+    if (xyz == nullptr) {
+        if (int rc = allow_big_lds(warp_points_kernel<true>, bytes, "anr_warp_points")) return rc;
+        const int64_t R = N / K;
+        dim3 grid((unsigned)((R + RAYS_PER_WG - 1) / RAYS_PER_WG), bs);
+        hipLaunchKernelGGL(warp_points_kernel<true>, grid, dim3(WARP_THREADS), bytes, st, xyz, xyz_stride, rays,
+                           ray_stride, z, K, index, d, ober2cano, lbs_weights, J, N, dis_threshold, skip_far,
+                           reinterpret_cast<float4*>(pts_out), dist_out, idx_out, blended_out);
+    } else {
+        if (int rc = allow_big_lds(warp_points_kernel<false>, bytes, "anr_warp_points")) return rc;
+        dim3 grid((unsigned)((N + PTS_PER_WG - 1) / PTS_PER_WG), bs);
+        hipLaunchKernelGGL(warp_points_kernel<false>, grid, dim3(WARP_THREADS), bytes, st, xyz, xyz_stride, rays,
+                           ray_stride, z, K, index, d, ober2cano, lbs_weights, J, N, dis_threshold, skip_far,
+                           reinterpret_cast<float4*>(pts_out), dist_out, idx_out, blended_out);
+    }
     return check_launch("anr_warp_points");
 }
 
-extern "C" int anr_knn(const float* verts, const float* xyz, int bs, int V, int64_t N, float* dist_out,
+extern "C" int anr_knn(const void* knn_index, const float* xyz, int bs, int V, int64_t N, float* dist_out,
                        int64_t* idx_out, void* stream) {
-    ANR_REQUIRE(verts && xyz && dist_out && idx_out, ANR_E_BADARG, "anr_knn: null pointer");
+    ANR_REQUIRE(knn_index && xyz && dist_out && idx_out, ANR_E_BADARG, "anr_knn: null pointer");
     ANR_REQUIRE(bs > 0 && V >= 4 && N > 0, ANR_E_BADARG, "anr_knn: bs=%d V=%d N=%lld", bs, V, (long long)N);
-    int Vp, bytes = lds_bytes_for(V, &Vp);
+    ANR_REQUIRE(((uintptr_t)knn_index & 15) == 0, ANR_E_ALIGN, "anr_knn: knn_index must be 16-B aligned");
+    IndexDims d = index_dims(V);
+    const int bytes = d.lds_floats() * 4;
     ANR_REQUIRE(bytes <= 160 * 1024, ANR_E_SHAPE, "anr_knn: V=%d needs %d B of LDS (>160 KiB)", V, bytes);
     if (int rc = allow_big_lds(knn_kernel, bytes, "anr_knn")) return rc;
-    dim3 grid((unsigned)((N + WARP_THREADS * PTS - 1) / (WARP_THREADS * PTS)), bs);
-    hipLaunchKernelGGL(knn_kernel, grid, dim3(WARP_THREADS), bytes, (hipStream_t)stream, verts, xyz, V, Vp, N, dist_out,
-                       idx_out);
+    dim3 grid((unsigned)((N + 4095) / 4096), bs);
+    hipLaunchKernelGGL(knn_kernel, grid, dim3(WARP_THREADS), bytes, (hipStream_t)stream,
+                       reinterpret_cast<const float*>(knn_index), d, xyz, N, dist_out, idx_out);
     return check_launch("anr_knn");
 }

@@ -103,15 +103,49 @@ def ober2cano(t_pose, t_template, shape_off, shape_off_t, pose_off, pose_off_t) 
     return out
 
 
-def knn(verts: torch.Tensor, xyz: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def morton_order(points: torch.Tensor) -> torch.Tensor:
+    """int32 permutation (slot -> vertex id) that sorts points[V,3] along a 30-bit Morton curve.
+    Host-side, once per model: gives anr_knn_index_build clusters of spatial neighbours."""
+    p = points.detach().float().cpu()
+    lo, hi = p.min(0).values, p.max(0).values
+    q = ((p - lo) / (hi - lo).clamp_min(1e-12) * 1023.0).long().clamp_(0, 1023)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    return torch.argsort(code, stable=True).to(torch.int32)
+
+
+def knn_index_build(verts: torch.Tensor, order: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-frame spatial index of posed vertices verts[bs,V,3] -> uint8[bs, anr_knn_index_bytes(V)]."""
+    lib = _lib.load()
+    verts = _dev(verts, "verts")
+    bs, V, _ = verts.shape
+    if order is not None:
+        order = _dev(order, "order", torch.int32)
+    nbytes = lib.anr_knn_index_bytes(V)
+    index = torch.empty(bs, nbytes, dtype=torch.uint8, device=verts.device)
+    _lib.check(lib.anr_knn_index_build(_ptr(verts), _ptr(order), bs, V, _ptr(index), _stream(index)),
+               "anr_knn_index_build")
+    return index
+
+
+def knn(verts: torch.Tensor, xyz: torch.Tensor, index: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Drop-in for knn_cuda.KNN(k=4, transpose_mode=True)(ref, query) — models/anim_nerf.py:159."""
     lib = _lib.load()
     verts, xyz = _dev(verts, "verts"), _dev(xyz, "xyz")
     bs, V, _ = verts.shape
     N = xyz.shape[1]
+    if index is None:
+        index = knn_index_build(verts, morton_order(verts[0]).to(verts.device))
     dist = torch.empty(bs, N, 4, dtype=torch.float32, device=xyz.device)
     idx = torch.empty(bs, N, 4, dtype=torch.int64, device=xyz.device)
-    _lib.check(lib.anr_knn(_ptr(verts), _ptr(xyz), bs, V, N, _ptr(dist), _ptr(idx), _stream(xyz)), "anr_knn")
+    with _timed("knn", bs * N):
+        _lib.check(lib.anr_knn(_ptr(index), _ptr(xyz), bs, V, N, _ptr(dist), _ptr(idx), _stream(xyz)), "anr_knn")
     return dist, idx
 
 
@@ -132,13 +166,18 @@ def sample_coarse(rays: torch.Tensor, steps: torch.Tensor, t_rand: Optional[torc
     return z
 
 
-def warp_points(verts, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays=None, z=None, debug=False):
+def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays=None, z=None, debug=False,
+                skip_far=False):
     """models/anim_nerf.py:153-192.  Either xyz[bs,N,3|4] or (rays[bs,R,>=8], z[bs,R,K]).
-    Returns pts[bs,N,4] = (x_c, y_c, z_c, valid) (+ dist[bs,N,4], idx[bs,N,4] i32, blended[bs,N] if debug)."""
+    `index` = knn_index_build(posed verts).  Returns pts[bs,N,4] = (x_c, y_c, z_c, valid)
+    (+ dist[bs,N,4], idx[bs,N,4] i32, blended[bs,N] if debug)."""
     lib = _lib.load()
-    verts, o2c, lbs_weights = _dev(verts, "verts"), _dev(o2c, "ober2cano"), _dev(lbs_weights, "lbs_weights")
-    bs, V, _ = verts.shape
+    index = _dev(index, "knn_index", torch.uint8)
+    o2c, lbs_weights = _dev(o2c, "ober2cano"), _dev(lbs_weights, "lbs_weights")
+    bs, V = o2c.shape[0], o2c.shape[1]
     J = lbs_weights.shape[1]
+    if debug and skip_far:
+        raise ValueError("debug outputs need skip_far=False")
     if xyz is not None:
         xyz = _dev(xyz, "xyz")
         N, xs = xyz.shape[1], xyz.shape[2]
@@ -148,7 +187,7 @@ def warp_points(verts, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
         K = z.shape[-1]
         N = z.shape[1] * K
         rs, xs = rays.shape[-1], 0
-    dev = verts.device
+    dev = o2c.device
     pts = torch.empty(bs, N, 4, dtype=torch.float32, device=dev)
     dist = idx = blended = None
     if debug:
@@ -156,9 +195,10 @@ def warp_points(verts, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
         idx = torch.empty(bs, N, 4, dtype=torch.int32, device=dev)
         blended = torch.empty(bs, N, dtype=torch.float32, device=dev)
     with _timed("warp_points", bs * N):
-        _lib.check(lib.anr_warp_points(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(verts), _ptr(o2c),
-                                       _ptr(lbs_weights), bs, V, J, N, float(dis_threshold), _ptr(pts), _ptr(dist),
-                                       _ptr(idx), _ptr(blended), _stream(pts)), "anr_warp_points")
+        _lib.check(lib.anr_warp_points(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(index), _ptr(o2c),
+                                       _ptr(lbs_weights), bs, V, J, N, float(dis_threshold), 1 if skip_far else 0,
+                                       _ptr(pts), _ptr(dist), _ptr(idx), _ptr(blended), _stream(pts)),
+                   "anr_warp_points")
     return (pts, dist, idx, blended) if debug else pts
 
 

@@ -51,7 +51,7 @@ class VolumeRenderer(nn.Module):
         bs, R, K = z.shape
         fused = hasattr(model, "warped_points") and hasattr(model, "_net")
         if fused:
-            pts = model.warped_points(rays=rays, z=z)
+            pts = model.warped_points(rays=rays, z=z, skip_far=True)
             out = model._net(not coarse).eval_points(pts)
         else:
             xyz = (rays[..., None, :3] + z[..., None] * rays[..., None, 3:6]).reshape(bs, -1, 3)

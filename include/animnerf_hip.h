@@ -76,9 +76,16 @@ int anr_ober2cano(const float* t_pose, const float* t_template,
                   float* out, int64_t n, void* stream);
 
 /* ---- a8: exact k=4 nearest SMPL vertices (replaces knn_cuda.KNN) ----------------------
- * models/anim_nerf.py:157-163.  verts[bs*V*3], xyz[bs*N*3] ->
- * dist[bs*N*4] (Euclidean, ascending), idx[bs*N*4] (int64, 0-based vertex id). */
-int anr_knn(const float* verts, const float* xyz, int bs, int V, int64_t N,
+ * models/anim_nerf.py:157-163.  The search is exact but spatially pruned, so it runs against a per-frame
+ * index of the posed vertices instead of the raw table:
+ *   anr_knn_index_build(verts[bs*V*3], order[V] or NULL, ...) -> index_out[bs * anr_knn_index_bytes(V)]
+ * `order` (int32, slot -> vertex id) is any fixed permutation that keeps spatial neighbours together (the host
+ * uses the Morton order of the rest-pose template, computed once per model); NULL = identity (still exact,
+ * just less pruning).  Results do not depend on `order` except in the choice between exactly tied distances.
+ *   anr_knn: xyz[bs*N*3] -> dist[bs*N*4] (Euclidean, ascending), idx[bs*N*4] (int64, 0-based vertex id). */
+int64_t anr_knn_index_bytes(int V);
+int anr_knn_index_build(const float* verts, const int32_t* order, int bs, int V, void* index_out, void* stream);
+int anr_knn(const void* knn_index, const float* xyz, int bs, int V, int64_t N,
             float* dist_out, int64_t* idx_out, void* stream);
 
 /* ---- a6+a7: coarse depths and sample points ------------------------------------------
@@ -94,13 +101,17 @@ int anr_sample_coarse(const float* rays, int stride, const float* steps, const f
  * models/volume_rendering.py:117 + models/anim_nerf.py:153-192 (get_neighbs, unpose).
  * Points are either given (xyz != NULL, [bs*N*xyz_stride]) or generated from rays and depths
  * (xyz == NULL: point n = ray n / K, sample n % K, x = o + z d).
- * Per body b: verts[b][V*3], ober2cano[b][V*16]; lbs_weights[V*J] shared.
+ * Per body b: knn_index[b] (anr_knn_index_build), ober2cano[b][V*16]; lbs_weights[V*J] shared.
  * pts_out[bs*N*4] = (x_c, y_c, z_c, valid) with valid = 1.0 iff blended distance < dis_threshold.
- * Optional debug outputs (may be NULL): dist_out[bs*N*4], idx_out[bs*N*4] (int32), blended_out[bs*N]. */
+ * skip_far != 0: points whose distance to the body's bounding box is >= dis_threshold (hence provably
+ *   invalid: sigma = -1e5, zero compositing weight) get (x, y, z, 0) without a search.  Rendered outputs are
+ *   unchanged; per-point rgb of such points differs from the reference's, so the point-query API passes 0.
+ * Optional debug outputs (may be NULL; need skip_far = 0): dist_out[bs*N*4], idx_out[bs*N*4] (int32),
+ *   blended_out[bs*N]. */
 int anr_warp_points(const float* xyz, int xyz_stride,
                     const float* rays, int ray_stride, const float* z, int K,
-                    const float* verts, const float* ober2cano, const float* lbs_weights,
-                    int bs, int V, int J, int64_t N, float dis_threshold,
+                    const void* knn_index, const float* ober2cano, const float* lbs_weights,
+                    int bs, int V, int J, int64_t N, float dis_threshold, int skip_far,
                     float* pts_out, float* dist_out, int32_t* idx_out, float* blended_out,
                     void* stream);
 

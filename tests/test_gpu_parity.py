@@ -102,7 +102,7 @@ def test_warp_matches_reference(dev, smpl_table):
     g = golden("warp")
     m = _warp_frame(dev, smpl_table)
     xyz = torch.from_numpy(g["xyz"]).to(dev)
-    pts, dist, idx, blended = ana.ops.warp_points(m.verts, m.ober2cano_transform, m.body_model.lbs_weights, 0.2,
+    pts, dist, idx, blended = ana.ops.warp_points(m.knn_index(), m.ober2cano_transform, m.body_model.lbs_weights, 0.2,
                                                   xyz=xyz, debug=True)
     b_ref = torch.from_numpy(g["blended_dist"])[..., 0]
     ok = (blended.cpu() - b_ref).abs() <= 1e-5 + 1e-5 * b_ref.abs()
@@ -130,9 +130,9 @@ def test_warp_from_rays_equals_explicit_points(dev, smpl_table):
     rays = torch.from_numpy(g["rays_body"]).to(dev)
     vr = ana.VolumeRenderer(n_coarse=16)
     z = vr.sample_coarse(rays)
-    a = ana.ops.warp_points(m.verts, m.ober2cano_transform, m.body_model.lbs_weights, 0.2, rays=rays, z=z)
+    a = ana.ops.warp_points(m.knn_index(), m.ober2cano_transform, m.body_model.lbs_weights, 0.2, rays=rays, z=z)
     xyz = (rays[..., None, :3] + z[..., None] * rays[..., None, 3:6]).reshape(2, -1, 3)
-    b = ana.ops.warp_points(m.verts, m.ober2cano_transform, m.body_model.lbs_weights, 0.2, xyz=xyz)
+    b = ana.ops.warp_points(m.knn_index(), m.ober2cano_transform, m.body_model.lbs_weights, 0.2, xyz=xyz)
     # torch may contract o + z*d into an fma (1 ulp); the kernel rounds product and sum separately
     assert (a[..., 3] == b[..., 3]).float().mean() > 0.999
     assert ((a[..., :3] - b[..., :3]).abs().max(-1).values < 2e-5).float().mean() > 0.999
@@ -304,6 +304,12 @@ def test_generic_model_path_equals_fused_path(dev, smpl_table):
     m.clac_ober2cano_transform()
     vr = ana.VolumeRenderer(n_coarse=64, n_fine=64)
     fused = vr(m, rays)
+    # skipping the neighbour search for provably-invalid samples must not change a single bit of the render
+    m.skip_far_samples = False
+    exact_everywhere = vr(m, rays)
+    m.skip_far_samples = True
+    for k in fused:
+        assert torch.equal(fused[k], exact_everywhere[k]), k
     generic = vr(lambda xyz, viewdir, use_fine=False: m(xyz, viewdir, use_fine=use_fine), rays)
     for k in fused:                 # same kernels; only x = o + z d is rounded differently (see conditioning note)
         torch.testing.assert_close(generic[k], fused[k], rtol=2e-3, atol=2e-4)
