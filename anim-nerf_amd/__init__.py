@@ -9,8 +9,8 @@ from .anim_nerf import AnimNeRF, batch_transform                      # noqa: F4
 from .body_model import SMPL, create                                  # noqa: F401
 from .nerf import Embedding, NeRF                                     # noqa: F401
 from .rays import gen_ray_directions, gen_rays, get_ray_directions, get_rays   # noqa: F401
-from .render import (batched_inference, render_prepared, shard_range,          # noqa: F401
-                     sigma_grid_inference, system_forward)
+from .render import (batched_inference, gather_ray_shards, max_over_ranks, render_prepared,   # noqa: F401
+                     shard_range, sigma_grid_inference, system_forward)
 from .volume_rendering import VolumeRenderer                          # noqa: F401
 
 __version__ = "0.1.0"

@@ -70,3 +70,32 @@ def sigma_grid_inference(anim_nerf, points, chunk=32 * 32 * 64):
         _, s = anim_nerf(points[:, i:i + chunk], None, use_fine=anim_nerf.use_fine)
         out.append(torch.relu(s))
     return torch.cat(out, 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# one process per GPU (torch.distributed; backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests)
+
+def max_over_ranks(seconds: float, device=None) -> float:
+    """Slowest rank's time: what a whole-job throughput is divided by.  No-op without a process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
+def gather_ray_shards(local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """Assemble per-rank results for `shard_range(n_total, rank, world)` slices (dim 1) on every rank.
+    Image assembly only — never on the timed data path."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    width = max(shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world))
+    pad = torch.zeros(local.shape[0], width, *local.shape[2:], dtype=local.dtype, device=local.device)
+    pad[:, :local.shape[1]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[:, :shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0]]
+                      for r, p in enumerate(parts)], 1)

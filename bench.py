@@ -112,10 +112,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed = ana.max_over_ranks(elapsed, dev)
 
     # ---- dominant kernel: fused MLP; HIP events were recorded on the launch stream inside the timed region
     per_kernel = {}
