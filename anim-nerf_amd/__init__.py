@@ -10,7 +10,7 @@ from .body_model import SMPL, create                                  # noqa: F4
 from .nerf import Embedding, NeRF                                     # noqa: F401
 from .rays import gen_ray_directions, gen_rays, get_ray_directions, get_rays   # noqa: F401
 from .render import (batched_inference, gather_ray_shards, max_over_ranks, render_prepared,   # noqa: F401
-                     shard_range, sigma_grid_inference, system_forward)
+                     shard_range, sigma_grid, sigma_grid_inference, system_forward)
 from .volume_rendering import VolumeRenderer                          # noqa: F401
 
 __version__ = "0.1.0"

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("ANIMNERF_HIP_LIB") or os.path.join(_HERE, "libanimner
 ANR_MLP_F32 = 0
 ANR_MLP_BF16 = 1
 ANR_MLP_FLAG_NO_DMA = 0x100
+ANR_MLP_FLAG_SIGMA_ONLY = 0x400
 ANR_MAX_SAMPLES = 256
 
 
@@ -56,6 +57,7 @@ SIGNATURES = {
     "anr_mlp_pack_bytes": (_L, [_I]),
     "anr_mlp_pack": (_I, [C.POINTER(AnrMlpParams), _I, _P, _P]),
     "anr_mlp_forward": (_I, [_P, _I, _P, _L, _P, _P]),
+    "anr_grid_points": (_I, [_I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, _L, _L, _P, _P]),
     "anr_composite": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "anr_sample_fine_merge": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P]),
 }

@@ -156,9 +156,39 @@ __global__ void points_from_rays_kernel(const float* __restrict__ rays, int stri
     pts[idx] = make_float4(ry[0] + zz * ry[3], ry[1] + zz * ry[4], ry[2] + zz * ry[5], 1.0f);
 }
 
+// ------------------------------------------------------------------ sigma-grid points (mesh extraction)
+// reference: extract_mesh.py:27-35 (create_grid = np.meshgrid(x, y, z), indexing 'xy') and :152-157 (+ centre)
+__global__ void grid_points_kernel(int N, double x0, double x1, double y0, double y1, double z0, double z1,
+                                   const float* __restrict__ center, int64_t first, int64_t count,
+                                   float4* __restrict__ pts) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int64_t n = first + t;
+    const int k = (int)(n % N), i = (int)((n / N) % N), j = (int)(n / ((int64_t)N * N));
+    // np.linspace: start + arange * step in fp64 (two roundings), last element = stop
+    auto lin = [N](double a, double b, int m) {
+        if (m == N - 1) return b;
+        double step = (b - a) / (double)(N - 1);
+        return __dadd_rn(__dmul_rn((double)m, step), a);
+    };
+    float x = (float)lin(x0, x1, i), y = (float)lin(y0, y1, j), z = (float)lin(z0, z1, k);
+    pts[t] = make_float4(x + center[0], y + center[1], z + center[2], 1.0f);
+}
+
 }  // namespace anr
 
 using namespace anr;
+
+extern "C" int anr_grid_points(int N, double x0, double x1, double y0, double y1, double z0, double z1,
+                               const float* center, int64_t first, int64_t count, float* pts_out, void* stream) {
+    ANR_REQUIRE(center && pts_out, ANR_E_BADARG, "anr_grid_points: null pointer");
+    ANR_REQUIRE(N >= 2 && first >= 0 && count > 0 && first + count <= (int64_t)N * N * N, ANR_E_BADARG,
+                "anr_grid_points: N=%d first=%lld count=%lld", N, (long long)first, (long long)count);
+    ANR_REQUIRE(((uintptr_t)pts_out & 15) == 0, ANR_E_ALIGN, "anr_grid_points: pts_out must be 16-B aligned");
+    hipLaunchKernelGGL(grid_points_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N,
+                       x0, x1, y0, y1, z0, z1, center, first, count, reinterpret_cast<float4*>(pts_out));
+    return check_launch("anr_grid_points");
+}
 
 extern "C" int anr_version(void) { return ANR_VERSION; }
 extern "C" const char* anr_last_error(void) { return err_buf(); }

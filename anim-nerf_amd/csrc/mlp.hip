@@ -32,7 +32,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int N_TILES_TOTAL = 78;              // 8*8 trunk + 9 (final + sigma) + 4 (dir) + 1 (rgb)
+constexpr int N_TILES_TOTAL = 78;              // 8*8 trunk + 1 (sigma) + 8 (final) + 4 (dir) + 1 (rgb)
 constexpr int BIAS_BYTES = 10240;              // 78 tiles x 2 halves x 16 floats, padded
 constexpr int FRAG_BYTES = 1024;
 
@@ -164,7 +164,7 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-template <int MODE, bool DMA>
+template <int MODE, bool DMA, bool SIGMA_ONLY = false>
 struct Mlp {
     using C = Cfg<MODE>;
     using Frag = typename C::Frag;
@@ -172,6 +172,8 @@ struct Mlp {
     static constexpr int THREADS = WAVES * 64;
     static constexpr int FPT = 16 / EPF;          // next-layer frags produced per out-tile
     static constexpr int SLOT = slot_bytes<C>();
+    static constexpr int LAST_TILE = SIGMA_ONLY ? 64 : 77;         // sigma-only stops after the sigma row (tile 64)
+    static constexpr int LAST_CHUNK = LAST_TILE / TPC;
 
     // Per-wave pipeline state.  Weight chunks (TPC 32-row out-tiles each) flow through a 3-slot LDS ring:
     // while tile c is being multiplied, chunk c+1 is already resident (its first fragment group and its bias
@@ -196,9 +198,11 @@ struct Mlp {
         __syncthreads();
 #endif
 #ifndef ANR_ABL_NO_STAGE
-        const int nf = chunk_frags<C>(c + 2);
-        stage_chunk<DMA, WAVES>(gnext, slot_stage, nf, wave, lane);
-        gnext += nf * FRAG_BYTES;
+        if (c + 2 <= LAST_CHUNK) {                     // nothing may be in flight into LDS when the workgroup ends
+            const int nf = chunk_frags<C>(c + 2);
+            stage_chunk<DMA, WAVES>(gnext, slot_stage, nf, wave, lane);
+            gnext += nf * FRAG_BYTES;
+        }
 #endif
     }
     __device__ __forceinline__ void rotate() {
@@ -323,7 +327,7 @@ struct Mlp {
     }
 
     __device__ __forceinline__ void run(const char* __restrict__ pack, const float4* __restrict__ pts, int64_t n_pts,
-                                        float4* __restrict__ out, char* lds) {
+                                        void* __restrict__ out_v, char* lds) {
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         lane = threadIdx.x & 63;
         half = lane >> 5;
@@ -385,34 +389,46 @@ struct Mlp {
         layer<40, 8, 0, HF, true, HF, HF>(E, A, B, last_of<32, 8, true>(A));                     // 6: A -> B
         layer<48, 8, 0, HF, true, HF, HF>(E, B, A, last_of<40, 8, true>(B));                     // 7: B -> A
         layer<56, 8, 0, HF, true, HF, HF>(E, A, B, last_of<48, 8, true>(A));                     // 8: A -> B
-        // xyz_encoding_final (no activation): B -> A ; the sigma row is a 9th tile on B
-        layer<64, 8, 0, HF, false, HF, HF>(E, B, A, last_of<56, 8, true>(B));
-        tile<72, 0, HF, HF>(E, B, last_of<64, 8, false>(A));
-        // dir_encoding: A -> G (256 -> 128, relu); rgb: G -> 3, sigmoid
-        Frag G[NT][DF];
-        layer<73, 4, 0, HF, true, HF, DF>(E, A, G, SigmaEpi{acc[72 & 1], sigma});
-        tile<77, 0, DF, DF>(E, G, last_of<73, 4, true>(G));
+        // sigma row: one tile on h8 (= B).  models/anim_nerf.py:305 masks it where the warp was invalid.
+        tile<64, 0, HF, HF>(E, B, last_of<56, 8, true>(B));
+        if constexpr (SIGMA_ONLY) {
+            float* out = reinterpret_cast<float*>(out_v);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            int64_t idx = wave_base + n * 32 + (lane & 31);
-            const f32x16& r = acc[77 & 1][n];
-            if (half == 0 && idx < n_pts) {
-                float cr = 1.0f / (1.0f + expf(-r[0]));
-                float cg = 1.0f / (1.0f + expf(-r[1]));
-                float cb = 1.0f / (1.0f + expf(-r[2]));
-                float s = (valid[n] < 1.0f) ? -1e5f : sigma[n];       // models/anim_nerf.py:305
-                out[idx] = make_float4(cr, cg, cb, s);
+            for (int n = 0; n < NT; ++n) {
+                int64_t idx = wave_base + n * 32 + (lane & 31);
+                if (half == 0 && idx < n_pts) out[idx] = (valid[n] < 1.0f) ? -1e5f : acc[64 & 1][n][0];
+            }
+            return;
+        } else {
+            float4* out = reinterpret_cast<float4*>(out_v);
+            // xyz_encoding_final (no activation): B -> A
+            layer<65, 8, 0, HF, false, HF, HF>(E, B, A, SigmaEpi{acc[64 & 1], sigma});
+            // dir_encoding: A -> G (256 -> 128, relu); rgb: G -> 3, sigmoid
+            Frag G[NT][DF];
+            layer<73, 4, 0, HF, true, HF, DF>(E, A, G, last_of<65, 8, false>(A));
+            tile<77, 0, DF, DF>(E, G, last_of<73, 4, true>(G));
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                int64_t idx = wave_base + n * 32 + (lane & 31);
+                const f32x16& r = acc[77 & 1][n];
+                if (half == 0 && idx < n_pts) {
+                    float cr = 1.0f / (1.0f + expf(-r[0]));
+                    float cg = 1.0f / (1.0f + expf(-r[1]));
+                    float cb = 1.0f / (1.0f + expf(-r[2]));
+                    float s = (valid[n] < 1.0f) ? -1e5f : sigma[n];       // models/anim_nerf.py:305
+                    out[idx] = make_float4(cr, cg, cb, s);
+                }
             }
         }
     }
 };
 
-template <int MODE, bool DMA>
+template <int MODE, bool DMA, bool SIGMA_ONLY>
 __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void mlp_kernel(const char* __restrict__ pack,
                                                              const float4* __restrict__ pts, int64_t n_pts,
-                                                             float4* __restrict__ out) {
+                                                             void* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    Mlp<MODE, DMA> m;
+    Mlp<MODE, DMA, SIGMA_ONLY> m;
     m.run(pack, pts, n_pts, out, lds);
 }
 
@@ -498,8 +514,8 @@ PackPlan make_plan(const anr_mlp_params* p) {
         if (l == 4) add(p->w_trunk[l], p->b_trunk[l], 256, 319, 63, 8, C::EF, C::HF);
         else        add(p->w_trunk[l], p->b_trunk[l], 256, 256, 0, 8, 0, C::HF);
     }
-    add(p->w_final, p->b_final, 256, 256, 0, 8, 0, C::HF);
-    add(p->w_sigma, p->b_sigma, 1, 256, 0, 1, 0, C::HF);
+    add(p->w_sigma, p->b_sigma, 1, 256, 0, 1, 0, C::HF);          // tile 64: sigma row on h8
+    add(p->w_final, p->b_final, 256, 256, 0, 8, 0, C::HF);        // tiles 65..72
     add(p->w_dir, p->b_dir, 128, 256, 0, 4, 0, C::HF);
     add(p->w_rgb, p->b_rgb, 3, 128, 0, 1, 0, C::DF);
     plan.n_stages = n;
@@ -507,17 +523,17 @@ PackPlan make_plan(const anr_mlp_params* p) {
     return plan;
 }
 
-template <int MODE, bool DMA>
+template <int MODE, bool DMA, bool SIGMA_ONLY = false>
 int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStream_t st) {
     using C = Cfg<MODE>;
     const int lds = BIAS_BYTES + 3 * slot_bytes<C>();
-    auto kern = mlp_kernel<MODE, DMA>;
+    auto kern = mlp_kernel<MODE, DMA, SIGMA_ONLY>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail((int)e, "anr_mlp_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
     const int pts_per_wg = C::WAVES * C::NT * 32;
     dim3 grid((unsigned)((n + pts_per_wg - 1) / pts_per_wg));
     hipLaunchKernelGGL(kern, grid, dim3(C::WAVES * 64), lds, st, reinterpret_cast<const char*>(pack),
-                       reinterpret_cast<const float4*>(pts), n, reinterpret_cast<float4*>(out));
+                       reinterpret_cast<const float4*>(pts), n, reinterpret_cast<void*>(out));
     return check_launch("anr_mlp_forward");
 }
 
@@ -527,6 +543,7 @@ using namespace anr;
 
 #define ANR_MLP_FLAG_NO_DMA 0x100      /* debug: stage weights through registers instead of the LDS-DMA engine */
 #define ANR_MLP_FLAG_W4     0x200      /* bf16 only: 4 waves x 64 points per workgroup instead of 8 waves x 32 */
+/* ANR_MLP_FLAG_SIGMA_ONLY (0x400) is public: include/animnerf_hip.h */
 
 extern "C" int64_t anr_mlp_pack_bytes(int mode) {
     switch (mode & 0xff) {
@@ -565,6 +582,13 @@ extern "C" int anr_mlp_forward(const void* pack, int mode, const float* pts, int
                 "anr_mlp_forward: pack/pts/out must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;
     const bool dma = !(mode & ANR_MLP_FLAG_NO_DMA);
+    if (mode & ANR_MLP_FLAG_SIGMA_ONLY) {              // out = float[n]: sigma only (trunk + sigma row, 83 % of the FLOPs)
+        switch (mode & 0xff) {
+            case ANR_MLP_F32:  return launch_mlp<ANR_MLP_F32, true, true>(pack, pts, n, out, st);
+            case ANR_MLP_BF16: return launch_mlp<ANR_MLP_BF16_W8, true, true>(pack, pts, n, out, st);
+            default: return fail(ANR_E_BADARG, "anr_mlp_forward: unknown mode %d", mode);
+        }
+    }
     switch (mode & 0xff) {
         case ANR_MLP_F32:
             return dma ? launch_mlp<ANR_MLP_F32, true>(pack, pts, n, out, st) : launch_mlp<ANR_MLP_F32, false>(pack, pts, n, out, st);

@@ -87,10 +87,10 @@ class NeRF(nn.Module):
             self._pack_cache[mode_id] = hit
         return hit[1], mode_id
 
-    def eval_points(self, pts: torch.Tensor, mode: Optional[str] = None) -> torch.Tensor:
-        """pts[n,4] = (x,y,z,valid) -> [n,4] = (r,g,b,sigma).  The fused kernel entry."""
+    def eval_points(self, pts: torch.Tensor, mode: Optional[str] = None, sigma_only: bool = False) -> torch.Tensor:
+        """pts[n,4] = (x,y,z,valid) -> [n,4] = (r,g,b,sigma), or sigma[n] (trunk + sigma row only).  The fused kernel entry."""
         pack, mode_id = self.weight_pack(mode)
-        return ops.mlp_forward(pack, mode_id, pts)
+        return ops.mlp_forward(pack, mode_id, pts, sigma_only=sigma_only)
 
     def _pack_xyz(self, xyz):
         flat = xyz.reshape(-1, 3)
@@ -105,8 +105,7 @@ class NeRF(nn.Module):
         """models/nerf.py:155-175.  The 256-wide feature is internal to the fused kernel."""
         if not only_sigma:
             raise NotImplementedError("get_sigma(only_sigma=False): xyz_encoding_final is not exported by the fused kernel")
-        out = self.eval_points(self._pack_xyz(xyz)).view(*xyz.shape[:-1], 4)
-        return out[..., 3:4]
+        return self.eval_points(self._pack_xyz(xyz), sigma_only=True).view(*xyz.shape[:-1], 1)
 
     def get_normal(self, xyz, deformation_code=None, delta=0.02):
         raise NotImplementedError("get_normal (training-only normals regulariser, models/nerf.py:177-190) "

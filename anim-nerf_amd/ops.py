@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ANR_MLP_BF16, ANR_MLP_F32, ANR_MLP_FLAG_NO_DMA, AnrMlpParams
+from ._lib import ANR_MLP_BF16, ANR_MLP_F32, ANR_MLP_FLAG_NO_DMA, ANR_MLP_FLAG_SIGMA_ONLY, AnrMlpParams
 
 ANR_MLP_FLAG_W4 = 0x200
 MLP_MODES = {"f32": ANR_MLP_F32, "fp32": ANR_MLP_F32, "bf16": ANR_MLP_BF16,
@@ -244,15 +244,30 @@ def mlp_pack(params: dict, mode: int) -> torch.Tensor:
     return pack
 
 
-def mlp_forward(pack: torch.Tensor, mode: int, pts: torch.Tensor) -> torch.Tensor:
-    """pts[n,4] = (x,y,z,valid) -> out[n,4] = (r,g,b,sigma)."""
+def mlp_forward(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bool = False) -> torch.Tensor:
+    """pts[n,4] = (x,y,z,valid) -> out[n,4] = (r,g,b,sigma), or sigma[n] if sigma_only."""
     lib = _lib.load()
     pts = _dev(pts, "pts")
     n = pts.numel() // 4
-    out = torch.empty(n, 4, dtype=torch.float32, device=pts.device)
+    if sigma_only:
+        mode = (mode & ~0x300) | ANR_MLP_FLAG_SIGMA_ONLY
+        out = torch.empty(n, dtype=torch.float32, device=pts.device)
+    else:
+        out = torch.empty(n, 4, dtype=torch.float32, device=pts.device)
     with _timed("mlp_forward", n):
         _lib.check(lib.anr_mlp_forward(_ptr(pack), mode, _ptr(pts), n, _ptr(out), _stream(out)), "anr_mlp_forward")
     return out
+
+
+def grid_points(N: int, x_range, y_range, z_range, center: torch.Tensor, first: int, count: int) -> torch.Tensor:
+    """extract_mesh.py:27-35,152-157: slab [first, first+count) of the flattened N^3 grid -> pts[count,4]."""
+    lib = _lib.load()
+    center = _dev(center.reshape(-1), "center")
+    pts = torch.empty(count, 4, dtype=torch.float32, device=center.device)
+    _lib.check(lib.anr_grid_points(N, float(x_range[0]), float(x_range[1]), float(y_range[0]), float(y_range[1]),
+                                   float(z_range[0]), float(z_range[1]), _ptr(center), first, count, _ptr(pts),
+                                   _stream(pts)), "anr_grid_points")
+    return pts
 
 
 def composite(rgbs, z, rays, white_bkgd: bool, noise=None, want_weights: bool = True):

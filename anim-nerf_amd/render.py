@@ -63,6 +63,28 @@ def system_forward(volume_renderer, anim_nerf, rays, body_model_params, body_mod
 
 
 @torch.no_grad()
+def sigma_grid(anim_nerf, N_grid=256, x_range=(-1.2, 1.2), y_range=(-1.2, 1.2), z_range=(-1.2, 1.2),
+               chunk=1 << 22, rank=0, world=1):
+    """extract_mesh.py:152-158 on the fast path: relu(sigma) of the fine (if any) field on this rank's contiguous
+    slab of the N^3 grid around the posed body's bounding-box centre.  Grid points are generated on the device,
+    provably-empty voxels skip the neighbour search, the MLP stops at the sigma row.  Returns (sigma[count], first).
+    Per-frame state (set_body_model / convert_to_body_model_space / clac_ober2cano_transform) must be set."""
+    from . import ops
+    total = N_grid ** 3
+    lo, hi = shard_range(total, rank, world)
+    center = (anim_nerf.verts.max(dim=1)[0] + anim_nerf.verts.min(dim=1)[0]) / 2.     # [1,3]
+    net = anim_nerf._net(anim_nerf.use_fine)
+    out = torch.empty(hi - lo, dtype=torch.float32, device=center.device)
+    for s in range(lo, hi, chunk):
+        n = min(chunk, hi - s)
+        pts = ops.grid_points(N_grid, x_range, y_range, z_range, center[0], s, n)
+        if anim_nerf.use_unpose:
+            pts = anim_nerf.warped_points(xyz=pts.view(1, n, 4), skip_far=True)
+        out[s - lo:s - lo + n] = torch.relu_(net.eval_points(pts, sigma_only=True))
+    return out, lo
+
+
+@torch.no_grad()
 def sigma_grid_inference(anim_nerf, points, chunk=32 * 32 * 64):
     """extract_mesh.py:49-61: relu(sigma) of the (fine) field on explicit points[bs,nv,3]."""
     out = []

@@ -45,6 +45,9 @@ extern "C" {
  * bf16 with fp32 accumulation (throughput mode, judged by PSNR). */
 #define ANR_MLP_F32   0
 #define ANR_MLP_BF16  1
+/* OR-ed into `mode` of anr_mlp_forward: evaluate the trunk and the sigma row only (NeRF.get_sigma(only_sigma=True),
+ * models/nerf.py:155-170; what extract_mesh.py:49-61 keeps); `out` is then float[n]. */
+#define ANR_MLP_FLAG_SIGMA_ONLY 0x400
 
 int         anr_version(void);
 const char* anr_last_error(void);
@@ -140,6 +143,14 @@ int anr_mlp_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream
 
 int anr_mlp_forward(const void* pack, int mode, const float* pts, int64_t n,
                     float* out, void* stream);
+
+/* ---- sigma-grid points for mesh extraction -------------------------------------------------------
+ * extract_mesh.py:27-35 (create_grid: np.meshgrid(x, y, z), 'xy' indexing, fp64 linspace -> fp32) and :152-157
+ * (+ bounding-box centre of the posed vertices).  Flat index n = (j*N + i)*N + k -> (x[i], y[j], z[k]).
+ * Writes points [first, first+count) of the N^3 grid as (x, y, z, 1); center[3] is a device pointer.
+ * A rank of a voxel-sharded job asks for its own [first, first+count) slab. */
+int anr_grid_points(int N, double x0, double x1, double y0, double y1, double z0, double z1,
+                    const float* center, int64_t first, int64_t count, float* pts_out, void* stream);
 
 /* ---- a13: alpha compositing ----------------------------------------------------------------------
  * models/volume_rendering.py:131-160 (far=True, delta_last = 1e10).

@@ -28,8 +28,8 @@ def stages(P, epf):
     for l in range(1, 8):
         W, B = P[f"xyz_encoding_{l+1}.0.weight"], P[f"xyz_encoding_{l+1}.0.bias"]
         s.append((W, B, 256, 319, 63, 8, EF, HF) if l == 4 else (W, B, 256, 256, 0, 8, 0, HF))
-    s.append((P["xyz_encoding_final.weight"], P["xyz_encoding_final.bias"], 256, 256, 0, 8, 0, HF))
     s.append((P["sigma.weight"], P["sigma.bias"], 1, 256, 0, 1, 0, HF))
+    s.append((P["xyz_encoding_final.weight"], P["xyz_encoding_final.bias"], 256, 256, 0, 8, 0, HF))
     s.append((P["dir_encoding.0.weight"], P["dir_encoding.0.bias"], 128, 256, 0, 4, 0, HF))
     s.append((P["rgb.0.weight"], P["rgb.0.bias"], 3, 128, 0, 1, 0, DF))
     return s
@@ -113,10 +113,10 @@ def run(P, xyz, epf):
     Y = layer(8, E, True, HF)
     for l in range(2, 9):
         Y = layer(8, np.concatenate([E, Y]) if l == 5 else Y, True, HF)
-    X = layer(8, Y, False, HF)
     frags, bias = tiles[c[0]]
     c[0] += 1
     sigma = mfma_tile(frags, Y, bias)[:32, 0]
+    X = layer(8, Y, False, HF)
     G = layer(4, X, True, DF)
     frags, bias = tiles[c[0]]
     c[0] += 1

@@ -343,3 +343,32 @@ def test_full_frame_properties(dev, smpl_table):
     f = ana.batched_inference(vr, m, rays[:, idx].contiguous(), pose, _templ(dev), chunk=1 << 16)
     psnr = orc.psnr(a["rgbs_fine"][:, idx].cpu(), f["rgbs_fine"].cpu())
     assert psnr > 35.0, psnr
+
+
+# ----------------------------------------------------------------------------- BASELINE configs[4]: sigma grid
+def test_sigma_grid_matches_reference_loop(dev, smpl_table):
+    """extract_mesh.py:27-35,49-61,152-158: create_grid + centre + chunked AnimNeRF.forward + relu, vs the sharded
+    sigma-only fast path (device grid, no search for provably-empty voxels, MLP stops at the sigma row)."""
+    import anim_nerf_amd as ana
+    m = _warp_frame(dev, smpl_table)
+    m.verts, m.ober2cano_transform = m.verts[:1].contiguous(), m.ober2cano_transform[:1].contiguous()
+    N = 24
+    rng = (-1.2, 1.2)
+    lin = np.linspace(rng[0], rng[1], N)
+    grid = np.stack(np.meshgrid(lin, lin, lin), -1).reshape(-1, 3)               # the reference's create_grid
+    center = (m.verts.max(dim=1)[0] + m.verts.min(dim=1)[0]) / 2.
+    points = torch.from_numpy(grid).unsqueeze(0).float().to(dev) + center
+    ref = ana.sigma_grid_inference(m, points, chunk=5000)[0, :, 0]                  # exact everywhere, full MLP
+    # oracle on a subset (CPU brute force)
+    tbl = oracle_table(smpl_table)
+    sub = torch.arange(0, N ** 3, 7)
+    st = dict(verts=m.verts.cpu(), ober2cano=m.ober2cano_transform.cpu())
+    _, sig_o = orc.field_query(net_params(m.nerf_fine), points[:, sub].cpu(), st, tbl["lbs_weights"], True, 0.2, chunk=512)
+    agree = (torch.relu(sig_o[0, :, 0]) - ref[sub].cpu()).abs() <= 1e-5 + 1e-3 * ref[sub].cpu().abs()
+    assert agree.float().mean() > 0.995
+    parts = [ana.sigma_grid(m, N, rng, rng, rng, chunk=3000, rank=r, world=3) for r in range(3)]
+    assert [p[1] for p in parts] == [ana.shard_range(N ** 3, r, 3)[0] for r in range(3)]
+    fast = torch.cat([p[0] for p in parts])
+    assert fast.shape == ref.shape
+    assert torch.equal(fast, ref), (fast - ref).abs().max()
+    assert (fast > 0).any() and (fast == 0).float().mean() > 0.5                  # a body in mostly empty space
