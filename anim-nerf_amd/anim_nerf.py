@@ -101,6 +101,9 @@ class AnimNeRF(nn.Module):
         return new_rays
 
     def clac_ober2cano_transform(self):
+        if torch.is_grad_enabled() and self.verts_transform.requires_grad:
+            raise NotImplementedError("gradients w.r.t. the SMPL parameters (optim_body_params, pose refinement) are "
+                                      "not built yet: pass detached body_model_params")
         self.ober2cano_transform = ops.ober2cano(
             self.verts_transform, self.verts_transform_template, self.shape_offsets, self.shape_offsets_template,
             self.pose_offsets, self.pose_offsets_template)

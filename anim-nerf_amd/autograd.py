@@ -1,0 +1,103 @@
+"""Autograd bridges for the training path.
+
+Forward runs on the same HIP kernels as inference (`anr_mlp_forward_save` additionally keeps each layer's
+post-activation output, `anr_composite`); backward:
+  * compositing: `anr_composite_backward` (HIP, one wavefront per ray);
+  * MLP: the saved activations are plain row-major [points, features] matrices, and both gradient GEMM families
+    (dX = dY W, dW = dY^T X) are plain library GEMMs (rocBLAS/hipBLASLt through torch.matmul) — 22 per network.
+No gradient flows into the sample points yet (body-pose refinement, `optim_body_params`, is not built).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+PARAM_KEYS = ([k for i in range(1, 9) for k in (f"xyz_encoding_{i}.0.weight", f"xyz_encoding_{i}.0.bias")]
+              + ["sigma.weight", "sigma.bias", "xyz_encoding_final.weight", "xyz_encoding_final.bias",
+                 "dir_encoding.0.weight", "dir_encoding.0.bias", "rgb.0.weight", "rgb.0.bias"])
+
+
+def _encode(xyz: torch.Tensor, n_freqs: int = 10) -> torch.Tensor:
+    cols = [xyz]
+    for k in range(n_freqs):
+        cols += [torch.sin(xyz * float(2 ** k)), torch.cos(xyz * float(2 ** k))]
+    return torch.cat(cols, -1)
+
+
+class MLPFunction(torch.autograd.Function):
+    """out[n,4] = (r,g,b,sigma) (or sigma[n]) = NeRF(pts[n,4]); differentiable w.r.t. the 22 parameter tensors."""
+
+    @staticmethod
+    def forward(ctx, pts, sigma_only, mode_id, *params):
+        pack = ops.mlp_pack(dict(zip(PARAM_KEYS, params)), mode_id)
+        out, act = ops.mlp_forward_save(pack, mode_id, pts, sigma_only)
+        ctx.save_for_backward(pts, out, act, *params)
+        ctx.sigma_only = sigma_only
+        return out
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g):
+        pts, out, act, *params = ctx.saved_tensors
+        P = dict(zip(PARAM_KEYS, params))
+        n = pts.shape[0]
+        H = act[:, :2048].view(n, 8, 256)
+        grads = {}
+        valid = (pts[:, 3] >= 1.0).to(g.dtype)                       # sigma is the constant -1e5 where invalid
+        if ctx.sigma_only:
+            g_sig = g.reshape(n) * valid
+            dh = g_sig[:, None] * P["sigma.weight"]
+        else:
+            g_sig = g[:, 3] * valid
+            rgb = out[:, :3]
+            d_rgb = g[:, :3] * rgb * (1 - rgb)                        # sigmoid'
+            G = act[:, 2304:2432]
+            F = act[:, 2048:2304]
+            grads["rgb.0.weight"] = d_rgb.t() @ G
+            grads["rgb.0.bias"] = d_rgb.sum(0)
+            dG = (d_rgb @ P["rgb.0.weight"]) * (G > 0)
+            grads["dir_encoding.0.weight"] = dG.t() @ F
+            grads["dir_encoding.0.bias"] = dG.sum(0)
+            dF = dG @ P["dir_encoding.0.weight"]
+            grads["xyz_encoding_final.weight"] = dF.t() @ H[:, 7]
+            grads["xyz_encoding_final.bias"] = dF.sum(0)
+            dh = dF @ P["xyz_encoding_final.weight"] + g_sig[:, None] * P["sigma.weight"]
+        grads["sigma.weight"] = (g_sig[None, :] @ H[:, 7])
+        grads["sigma.bias"] = g_sig.sum().reshape(1)
+        enc = _encode(pts[:, :3])
+        for l in range(8, 0, -1):
+            dpre = dh * (H[:, l - 1] > 0)
+            inp = enc if l == 1 else torch.cat([enc, H[:, l - 2]], -1) if l == 5 else H[:, l - 2]
+            grads[f"xyz_encoding_{l}.0.weight"] = dpre.t() @ inp
+            grads[f"xyz_encoding_{l}.0.bias"] = dpre.sum(0)
+            if l > 1:
+                W = P[f"xyz_encoding_{l}.0.weight"]
+                dh = dpre @ (W[:, 63:] if l == 5 else W)
+        out_grads = []
+        for i, k in enumerate(PARAM_KEYS):
+            need = ctx.needs_input_grad[3 + i]
+            out_grads.append(grads.get(k) if need and k in grads else None)
+        return (None, None, None, *out_grads)
+
+
+class CompositeFunction(torch.autograd.Function):
+    """(weights, rgb, depth, acc) = composite(rgbs[R,K,4], z[R,K], rays[R,>=8]); differentiable w.r.t. rgbs."""
+
+    @staticmethod
+    def forward(ctx, rgbs, z, rays, noise, white_bkgd):
+        w, rgb, depth, acc = ops.composite(rgbs, z, rays, white_bkgd, noise=noise, want_weights=True)
+        ctx.save_for_backward(rgbs, z, rays, noise if noise is not None else torch.empty(0, device=z.device))
+        ctx.white = white_bkgd
+        ctx.mark_non_differentiable(w)
+        return w, rgb, depth, acc
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g_w, g_rgb, g_depth, g_acc):
+        rgbs, z, rays, noise = ctx.saved_tensors
+        R = z.shape[0]
+        zero = lambda t, shape: torch.zeros(shape, device=z.device) if t is None else t.contiguous()
+        d = ops.composite_backward(rgbs, z, rays, ctx.white, zero(g_rgb, (R, 3)), zero(g_depth, (R, 1)).reshape(R),
+                                   zero(g_acc, (R, 1)).reshape(R), noise=noise if noise.numel() else None)
+        return d, None, None, None, None

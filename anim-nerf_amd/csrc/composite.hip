@@ -88,6 +88,84 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_kernel(
     }
 }
 
+// inclusive sum over lanes >= this lane (suffix), via shuffles
+__device__ __forceinline__ float wave_suffix_incl_sum(float v, int lane) {
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_down(inc, o, 64);
+        if (lane + o < 64) inc += t;
+    }
+    return inc;
+}
+
+// Backward of composite_kernel (a16, the part autograd differentiates in models/volume_rendering.py:131-160).
+// With G_i = dL/dw_i = g_rgb . c_i + g_depth z_i + g_acc' (+ g_w_i), t_i = 1 - alpha_i + 1e-10:
+//   dL/dc_i = w_i g_rgb ;  dL/dalpha_i = G_i T_i - (sum_{j>i} G_j w_j) / t_i ;
+//   dL/dsigma_i = dL/dalpha_i * delta_i * exp(-delta_i relu(sigma_i)) * [sigma_i > 0].
+// White background folds -sum(g_rgb) - g_depth * far into g_acc'.
+template <int S>
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_backward_kernel(
+    const float4* __restrict__ rgbs, const float* __restrict__ z, const float* __restrict__ rays, int stride,
+    const float* __restrict__ noise, int64_t R, int K, int white_bkgd, const float* __restrict__ g_w,
+    const float* __restrict__ g_rgb, const float* __restrict__ g_depth, const float* __restrict__ g_acc,
+    float4* __restrict__ d_rgbs) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float4* c = rgbs + r * K;
+    const float* zr = z + r * K;
+    const float gr = g_rgb[r * 3 + 0], gg = g_rgb[r * 3 + 1], gb = g_rgb[r * 3 + 2], gd = g_depth[r];
+    float ga = g_acc[r];
+    if (white_bkgd) ga = ga - (gr + gg + gb) - gd * rays[r * stride + 7];
+
+    float alpha[S], tr[S], zz[S], delta[S], sg[S];
+    float4 col[S];
+    float prod = 1.0f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        int k = lane * S + s;
+        alpha[s] = 0.0f; tr[s] = 1.0f; zz[s] = 0.0f; delta[s] = 0.f; sg[s] = 0.f; col[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K) {
+            col[s] = c[k];
+            zz[s] = zr[k];
+            delta[s] = (k + 1 < K) ? (zr[k + 1] - zz[s]) : 1e10f;
+            sg[s] = col[s].w;
+            if (noise != nullptr) sg[s] = sg[s] + noise[r * K + k];
+            alpha[s] = 1.0f - expf(-delta[s] * fmaxf(sg[s], 0.0f));
+            tr[s] = prod;
+            prod = prod * (1.0f - alpha[s] + 1e-10f);
+        }
+    }
+    const float before = wave_excl_prod(prod, lane);
+    // G_i w_i per sample, suffix sums
+    float G[S], w[S], gw_local = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        int k = lane * S + s;
+        w[s] = 0.f; G[s] = 0.f;
+        if (k < K) {
+            tr[s] = before * tr[s];
+            w[s] = alpha[s] * tr[s];
+            G[s] = gr * col[s].x + gg * col[s].y + gb * col[s].z + gd * zz[s] + ga;
+            if (g_w != nullptr) G[s] += g_w[r * K + k];
+            gw_local += G[s] * w[s];
+        }
+    }
+    float after = wave_suffix_incl_sum(gw_local, lane) - gw_local;       // lanes > this lane
+#pragma unroll
+    for (int s = S - 1; s >= 0; --s) {
+        int k = lane * S + s;
+        if (k < K) {
+            const float t = 1.0f - alpha[s] + 1e-10f;
+            const float dalpha = G[s] * tr[s] - after / t;
+            const float dsig = (sg[s] > 0.0f) ? dalpha * delta[s] * expf(-delta[s] * sg[s]) : 0.0f;
+            d_rgbs[r * K + k] = make_float4(w[s] * gr, w[s] * gg, w[s] * gb, dsig);
+            after += G[s] * w[s];
+        }
+    }
+}
+
 // reference: models/volume_rendering.py:59-97 (sample_fine) and :199-207 (cat + sort)
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void sample_fine_merge_kernel(
     const float* __restrict__ z_coarse, const float* __restrict__ weights, const float* __restrict__ u,
@@ -193,6 +271,31 @@ extern "C" int anr_composite(const float* rgbs, const float* z, const float* ray
     }
 #undef ANR_LAUNCH_COMPOSITE
     return check_launch("anr_composite");
+}
+
+extern "C" int anr_composite_backward(const float* rgbs, const float* z, const float* rays, int stride,
+                                      const float* noise, int64_t R, int K, int white_bkgd, const float* g_weights,
+                                      const float* g_rgb, const float* g_depth, const float* g_acc, float* d_rgbs,
+                                      void* stream) {
+    ANR_REQUIRE(rgbs && z && rays && g_rgb && g_depth && g_acc && d_rgbs, ANR_E_BADARG, "anr_composite_backward: null pointer");
+    ANR_REQUIRE(R > 0 && K > 0 && stride >= 8, ANR_E_BADARG, "anr_composite_backward: R=%lld K=%d stride=%d", (long long)R, K, stride);
+    ANR_REQUIRE(K <= ANR_MAX_SAMPLES, ANR_E_SHAPE, "anr_composite_backward: K=%d > %d", K, ANR_MAX_SAMPLES);
+    ANR_REQUIRE((((uintptr_t)rgbs | (uintptr_t)d_rgbs) & 15) == 0, ANR_E_ALIGN, "anr_composite_backward: rgbs/d_rgbs must be 16-B aligned");
+    dim3 grid((unsigned)((R + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), block(WAVE * WAVES_PER_BLOCK);
+    const float4* c = reinterpret_cast<const float4*>(rgbs);
+    float4* d = reinterpret_cast<float4*>(d_rgbs);
+    hipStream_t st = (hipStream_t)stream;
+#define ANR_LAUNCH_CB(SS)                                                                                      \
+    hipLaunchKernelGGL(composite_backward_kernel<SS>, grid, block, 0, st, c, z, rays, stride, noise, R, K, white_bkgd, \
+                       g_weights, g_rgb, g_depth, g_acc, d)
+    switch ((K + 63) / 64) {
+        case 1: ANR_LAUNCH_CB(1); break;
+        case 2: ANR_LAUNCH_CB(2); break;
+        case 3: ANR_LAUNCH_CB(3); break;
+        default: ANR_LAUNCH_CB(4); break;
+    }
+#undef ANR_LAUNCH_CB
+    return check_launch("anr_composite_backward");
 }
 
 extern "C" int anr_sample_fine_merge(const float* z_coarse, const float* weights, const float* u, int u_per_ray,

@@ -1,0 +1,463 @@
+// (header) Fused Fourier encoding + 8x256 NeRF MLP (a11 + a12) on CDNA4 matrix cores.
+//
+// Reference: models/embedding.py:22-39, models/nerf.py:129-175 (use_view = False).
+//
+// Shape of the computation.  The GEMMs are evaluated TRANSPOSED: out-features are the MFMA row
+// dimension (A operand = a 32-row weight tile), sample points are the column dimension
+// (B operand = activations), so D^T[feature][point] lands with each lane holding 16 features of
+// ONE point.  With the K index of the next layer's weights permuted to match (done once by
+// anr_mlp_pack), those 16 accumulators ARE the next layer's B fragments: activations never
+// leave registers for the whole 11-GEMM chain, there is no LDS/HBM round trip and no cross-lane
+// shuffle between layers.  Weights stream L2 -> LDS (32-row tiles through a 3-slot ring, LDS-DMA) and are
+// shared by the workgroup's 4 wavefronts (3-slot ring); each wavefront owns NT x 32 points.
+//
+//   mode BF16: v_mfma_f32_32x32x16_bf16, NT = 2 (64 points / wave, 256 / workgroup)
+//   mode F32 : v_mfma_f32_32x32x2_f32  , NT = 1 (32 points / wave, 128 / workgroup) — exact fp32
+//              fmaf chains, the parity mode.
+//
+// Slot algebra (h = lane>>5, i = lane&31; "frag" = 16 bytes per lane = 1 KiB per wave):
+//   accumulator reg (g = reg>>2, r = reg&3) of out-tile t  <->  out feature 32t + 8g + 4h + r
+//   BF16 frag b, elem e  <->  hidden feature 16b + 8(e>>2) + 4h + (e&3)   => frags 2t, 2t+1 = regs 0-7, 8-15
+//   F32  frag s, elem e  <->  hidden feature  8s + 4h + e                  => frags 4t..4t+3 = regs 4f..4f+3
+//   encoding panel: slot j in [0,32) (BF16: j = 8b+e, F32: j = 4s+e), half h:
+//       j < 30 : k = j/3, d = j%3 -> h ? cos(2^k x_d) : sin(2^k x_d)   (reference channel 3 + 6k + 3h + d)
+//       j = 30 : h ? x_2 : x_0 ;  j = 31 : h ? <pad, weight 0> : x_1
+//   so the two half-waves run one instruction stream (sin vs cos is a quadrant offset).
+#pragma once
+#include "anr_common.h"
+#include <utility>
+
+namespace anr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int N_TILES_TOTAL = 78;              // 8*8 trunk + 1 (sigma) + 8 (final) + 4 (dir) + 1 (rgb)
+constexpr int BIAS_BYTES = 10240;              // 78 tiles x 2 halves x 16 floats, padded
+constexpr int FRAG_BYTES = 1024;
+
+// MODE = arithmetic (ANR_MLP_F32 / ANR_MLP_BF16); VAR = workgroup shape variant
+constexpr int ANR_MLP_BF16_W8 = 2;   // internal: bf16 with 8 waves x 32 points (2 waves per SIMD)
+template <int MODE> struct Cfg;
+template <> struct Cfg<ANR_MLP_BF16> {
+    using Frag = bf16x8;
+    static constexpr bool IS_BF16 = true;
+    static constexpr int EPF = 8;    // elements per frag per lane
+    static constexpr int NT = 2;     // 32-point column tiles per wave
+    static constexpr int WAVES = 4;  // wavefronts per workgroup
+    static constexpr int TPC = 2;    // out-tiles per staged weight chunk (one workgroup barrier per chunk)
+    static constexpr int HF = 16;    // frags per 256 hidden features
+    static constexpr int EF = 4;     // frags of the 64-slot encoding panel
+    static constexpr int DF = 8;     // frags per 128 features (rgb head input)
+};
+template <> struct Cfg<ANR_MLP_BF16_W8> : Cfg<ANR_MLP_BF16> {
+    static constexpr int NT = 1;
+    static constexpr int WAVES = 8;
+};
+template <> struct Cfg<ANR_MLP_F32> {
+    using Frag = f32x4;
+    static constexpr bool IS_BF16 = false;
+    static constexpr int EPF = 4;
+    static constexpr int NT = 1;
+    static constexpr int WAVES = 4;
+    static constexpr int TPC = 1;
+    static constexpr int HF = 32;
+    static constexpr int EF = 8;
+    static constexpr int DF = 16;
+};
+
+// frags of out-tile t of the flat 78-tile schedule, and of staged chunk c (= TPC consecutive tiles)
+template <class C> __host__ __device__ constexpr int tile_frags(int t) {
+    return t < 8 ? C::EF : t < 32 ? C::HF : t < 40 ? C::EF + C::HF : t < 77 ? C::HF : t < 78 ? C::DF : 0;
+}
+template <class C> __host__ __device__ constexpr int chunk_frags(int c) {
+    int n = 0;
+    for (int i = 0; i < C::TPC; ++i) n += tile_frags<C>(c * C::TPC + i);
+    return n;
+}
+template <class C> constexpr int total_frags() {
+    return 8 * C::EF + 24 * C::HF + 8 * (C::EF + C::HF) + 24 * C::HF + 9 * C::HF + 4 * C::HF + C::DF;
+}
+template <class C> constexpr int slot_bytes() { return C::TPC * (C::EF + C::HF) * FRAG_BYTES; }
+
+__device__ __forceinline__ void mma(const bf16x8& w, const bf16x8& x, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(const f32x4& w, const f32x4& x, f32x16& acc) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], x[e], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 mma_c(const bf16x8& w, const bf16x8& x, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma_c(const f32x4& w, const f32x4& x, const f32x16& c) {
+    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], x[0], c, 0, 0, 0);
+#pragma unroll
+    for (int e = 1; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], x[e], acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ void put(bf16x8& f, int e, float v) { f[e] = (__bf16)v; }
+__device__ __forceinline__ void put(f32x4& f, int e, float v) { f[e] = v; }
+
+// Materialise a fragment in VGPRs HERE: keeps hipcc from carrying a whole layer of un-converted fp32
+// accumulators (8 tiles x 32 registers) and doing the activation/convert pass at the end of the layer.
+__device__ __forceinline__ void pin(bf16x8& f) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 t = __builtin_bit_cast(u32x4, f);
+    asm volatile("" : "+v"(t));
+    f = __builtin_bit_cast(bf16x8, t);
+}
+__device__ __forceinline__ void pin(f32x4& f) { asm volatile("" : "+v"(f)); }
+
+// sin(a) for q_off = 0, cos(a) for q_off = 1; Cody-Waite reduction by pi/2 + Cephes minimax polynomials (~1 ulp).
+__device__ __forceinline__ float sin_or_cos(float a, int q_off) {
+    const float n = rintf(a * 0.6366197466850281f);
+    float r = fmaf(-n, 1.5707963705062866f, a);
+    r = fmaf(-n, -4.371138828673793e-08f, r);
+    r = fmaf(-n, -1.7151245100058819e-15f, r);
+    const int q = (int)n + q_off;
+    const float z = r * r;
+    const float s = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float c = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                         fmaf(-0.5f, z, 1.0f));
+    float v = (q & 1) ? c : s;
+    return (q & 2) ? -v : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight staging: chunk = nf frags of 1 KiB; wave w moves pieces w, w+WAVES, ...
+//
+// The LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B straight from L2 into LDS at M0 + lane*16) is issued
+// from inline asm on purpose: when hipcc sees the builtin it can no longer prove which ds_reads the DMA may
+// alias and degrades EVERY LDS wait in the kernel to `s_waitcnt lgkmcnt(0)`, which exposes the full LDS latency
+// in front of each group of MFMAs.  Hidden in asm, the fragment reads keep their counted lgkmcnt(N) waits; the
+// DMA's own completion is waited for by hand (`vmcnt(0)` in front of the workgroup barrier, dma_wait()).
+__device__ __forceinline__ void dma16(const char* gsrc_lane, char* lds_dst_uniform) {
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_dst_uniform;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc_lane), "s"(__builtin_amdgcn_readfirstlane(dst))
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <bool DMA, int WAVES>
+__device__ __forceinline__ void stage_chunk(const char* __restrict__ g, char* slot, int nf, int wave, int lane) {
+    if constexpr (DMA) {
+        for (int p = wave; p < nf; p += WAVES) dma16(g + p * FRAG_BYTES + lane * 16, slot + p * FRAG_BYTES);
+    } else {
+        for (int p = wave; p < nf; p += WAVES) {
+            uint4 v = *reinterpret_cast<const uint4*>(g + p * FRAG_BYTES + lane * 16);
+            *reinterpret_cast<uint4*>(slot + p * FRAG_BYTES + lane * 16) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int V> struct IC { static constexpr int value = V; constexpr operator int() const { return V; } };
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// column of out-tile T's 32 features in a saved-activation row: [h1..h8 (8 x 256) | final (256) | dir hidden (128)]
+constexpr int ACT_COLS = 2432;
+__host__ __device__ constexpr int act_col(int T) { return T < 64 ? 32 * T : T < 73 ? 2048 + 32 * (T - 65) : 2304 + 32 * (T - 73); }
+
+template <int MODE, bool DMA, bool SIGMA_ONLY = false, bool SAVE = false>
+struct Mlp {
+    using C = Cfg<MODE>;
+    using Frag = typename C::Frag;
+    static constexpr int NT = C::NT, EPF = C::EPF, HF = C::HF, EF = C::EF, DF = C::DF, WAVES = C::WAVES, TPC = C::TPC;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int FPT = 16 / EPF;          // next-layer frags produced per out-tile
+    static constexpr int SLOT = slot_bytes<C>();
+    static constexpr int LAST_TILE = SIGMA_ONLY ? 64 : 77;         // sigma-only stops after the sigma row (tile 64)
+    static constexpr int LAST_CHUNK = LAST_TILE / TPC;
+
+    // Per-wave pipeline state.  Weight chunks (TPC 32-row out-tiles each) flow through a 3-slot LDS ring:
+    // while tile c is being multiplied, chunk c+1 is already resident (its first fragment group and its bias
+    // are pulled into registers before tile c ends) and chunk c+2 is in flight on the LDS-DMA engine.
+    // The activation/convert epilogue of tile c-1 is issued in the shadow of tile c's first MFMAs, so the
+    // matrix pipe never waits for VALU work: accumulators ping-pong between acc[0] and acc[1].
+    const char* gnext;       // global address of the next chunk to stage (chunk c+2)
+    char* lds_bias;
+    char* slot_cur;          // LDS slot of chunk c
+    char* slot_nxt;          // LDS slot of chunk c+1
+    char* slot_stage;        // LDS slot chunk c+2 is staged into
+    int c;                   // chunk counter
+    int wave, lane, half;
+    f32x16 acc[2][NT];       // accumulators of tile c (parity c&1) and of tile c-1 (epilogue pending)
+    f32x16 bias_c;           // bias of tile c: C operand of its first MFMA
+    Frag w0[4];              // first fragment group of tile c
+    float* act_row[NT];      // SAVE: this lane's row of saved activations (+ 4*half), or null
+
+    // barrier: chunk c+1 has landed everywhere and nobody reads chunk c-1 any more -> stage chunk c+2 over it
+    __device__ __forceinline__ void advance() {
+#ifndef ANR_ABL_NO_BARRIER
+        if constexpr (DMA) dma_wait();
+        __syncthreads();
+#endif
+#ifndef ANR_ABL_NO_STAGE
+        if (c + 2 <= LAST_CHUNK) {                     // nothing may be in flight into LDS when the workgroup ends
+            const int nf = chunk_frags<C>(c + 2);
+            stage_chunk<DMA, WAVES>(gnext, slot_stage, nf, wave, lane);
+            gnext += nf * FRAG_BYTES;
+        }
+#endif
+    }
+    __device__ __forceinline__ void rotate() {
+        char* t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_stage; slot_stage = t;
+        ++c;
+    }
+    __device__ __forceinline__ f32x16 read_bias(int tile_idx) {
+        const f32x4* b = reinterpret_cast<const f32x4*>(lds_bias + tile_idx * 128 + half * 64);
+        f32x16 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 t = b[q];
+            v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
+        }
+        return v;
+    }
+
+    // ---- pending epilogues: what is still to be done with the accumulators of the PREVIOUS tile.
+    // part<Q>() handles accumulator registers 4Q..4Q+3 of every column tile (Q = 0..3).
+    struct NoEpi {
+        template <int Q> __device__ __forceinline__ void part() const {}
+    };
+    // activation + conversion into fragments [TB, TB+FPT) of the next layer's input
+    // TG = global tile index (selects the column block when activations are saved for the backward pass)
+    template <bool RELU, int YF, int TB, int TG>
+    struct FragEpi {
+        const f32x16 (&a)[NT];
+        Frag (&Y)[NT][YF];
+        float* const (&ar)[NT];
+        template <int Q> __device__ __forceinline__ void part() const {
+#ifdef ANR_ABL_NO_EPILOGUE
+            if (Q > 0) return;
+#endif
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                f32x4 keep;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = a[n][4 * Q + i];
+                    if (RELU) v = __int_as_float(max(__float_as_int(v), 0));       // relu as one v_max_i32
+                    put(Y[n][TB + (4 * Q + i) / EPF], (4 * Q + i) % EPF, v);
+                    keep[i] = v;
+                }
+                if ((4 * Q + 4) % EPF == 0) pin(Y[n][TB + (4 * Q) / EPF]);
+                // features 32t + 8Q + 4h + (0..3) of this lane's point: 16 contiguous bytes of its row
+                if (SAVE && ar[n] != nullptr) *reinterpret_cast<f32x4*>(ar[n] + act_col(TG) + 8 * Q) = keep;
+            }
+        }
+    };
+    // sigma head: row 0 of its tile = accumulator register 0 of the lower half-wave
+    struct SigmaEpi {
+        const f32x16 (&a)[NT];
+        float (&sigma)[NT];
+        template <int Q> __device__ __forceinline__ void part() const {
+            if (Q == 0) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) sigma[n] = a[n][0];
+            }
+        }
+    };
+
+    // One out-tile (parity PAR): acc[PAR] = bias + W_tile . [E (NFE frags), X (NFH frags)].
+    // Weight fragments move LDS -> registers in groups of 4, double-buffered: group j+1 (or, in the last group,
+    // the first group and the bias of the NEXT tile, already resident in the ring) loads while group j feeds the
+    // matrix cores; the previous tile's epilogue (`pending`) is spread behind the first four MFMAs.
+    template <int T, int NFE, int NFH, int XF, class Pending>
+    __device__ __forceinline__ void tile(const Frag (&E)[NT][EF], const Frag (&X)[NT][XF], const Pending& pending) {
+        static_assert((NFE + NFH) % 4 == 0, "fragment groups of 4");
+        static_assert(NFE + NFH == tile_frags<C>(T), "tile schedule mismatch");
+        constexpr int NG = (NFE + NFH) / 4;
+        constexpr int PAR = T & 1;
+        constexpr int POS = T % TPC;                       // position of this tile inside its chunk
+        constexpr int OFF = (POS == 0) ? 0 : tile_frags<C>(T - 1);      // TPC <= 2
+        if constexpr (POS == 0) advance();
+        const Frag* cur = reinterpret_cast<const Frag*>(slot_cur) + OFF * 64 + lane;
+        const Frag* nxt = (POS + 1 < TPC) ? cur + (NFE + NFH) * 64 : reinterpret_cast<const Frag*>(slot_nxt) + lane;
+        Frag wa[4], wb[4];
+        f32x16 bias_n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wa[q] = w0[q];
+        static_for<NG>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            Frag (&use)[4] = (j & 1) ? wb : wa;
+            Frag (&ld)[4] = (j & 1) ? wa : wb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ld[q] = (j + 1 < NG) ? cur[((j + 1) * 4 + q) * 64] : nxt[q * 64];
+            if (j + 1 == NG) bias_n = read_bias(T + 1);
+            __builtin_amdgcn_sched_barrier(0);          // the loads above are issued before this group's MFMAs
+            static_for<4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int f = 4 * j + q;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const Frag& x = (f < NFE) ? E[n][f < NFE ? f : 0] : X[n][f >= NFE ? f - NFE : 0];
+                    if (f == 0) acc[PAR][n] = mma_c(use[q], x, bias_c);
+                    else        mma(use[q], x, acc[PAR][n]);
+                }
+                if (j == 0) {
+                    pending.template part<q>();
+                    __builtin_amdgcn_sched_barrier(0);  // keep the epilogue pieces between the MFMAs
+                }
+            });
+        });
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w0[q] = (NG & 1) ? wb[q] : wa[q];
+        bias_c = bias_n;
+        if constexpr (POS + 1 == TPC) rotate();
+    }
+
+    // a full layer of NTILES out-tiles starting at global tile index T0; `first` is the epilogue still pending
+    // from the tile before T0.  The epilogue of this layer's LAST tile is left pending for the caller.
+    template <int T0, int NTILES, int NFE, int NFH, bool RELU, int XF, int YF, class Pending>
+    __device__ __forceinline__ void layer(const Frag (&E)[NT][EF], const Frag (&X)[NT][XF], Frag (&Y)[NT][YF],
+                                          const Pending& first) {
+        static_for<NTILES>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int PAR = (T0 + t) & 1;
+            if constexpr (t == 0) {
+                tile<T0 + t, NFE, NFH, XF>(E, X, first);
+            } else {
+                tile<T0 + t, NFE, NFH, XF>(E, X, FragEpi<RELU, YF, (t - 1) * FPT, T0 + t - 1>{acc[PAR ^ 1], Y, act_row});
+            }
+        });
+    }
+    template <int T0, int NTILES, bool RELU, int YF>
+    __device__ __forceinline__ auto last_of(Frag (&Y)[NT][YF]) {
+        return FragEpi<RELU, YF, (NTILES - 1) * FPT, T0 + NTILES - 1>{acc[(T0 + NTILES - 1) & 1], Y, act_row};
+    }
+
+    __device__ __forceinline__ void run(const char* __restrict__ pack, const float4* __restrict__ pts, int64_t n_pts,
+                                        void* __restrict__ out_v, float* __restrict__ act, char* lds) {
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        lane = threadIdx.x & 63;
+        half = lane >> 5;
+        lds_bias = lds;
+        slot_cur = lds + BIAS_BYTES;
+        slot_nxt = slot_cur + SLOT;
+        slot_stage = slot_nxt + SLOT;
+        c = 0;
+
+        // resident bias table + the first two chunks
+        for (int i = threadIdx.x; i < BIAS_BYTES / 16; i += THREADS)
+            reinterpret_cast<uint4*>(lds_bias)[i] = reinterpret_cast<const uint4*>(pack)[i];
+        gnext = pack + BIAS_BYTES;
+        stage_chunk<DMA, WAVES>(gnext, slot_cur, chunk_frags<C>(0), wave, lane);
+        gnext += chunk_frags<C>(0) * FRAG_BYTES;
+        stage_chunk<DMA, WAVES>(gnext, slot_nxt, chunk_frags<C>(1), wave, lane);
+        gnext += chunk_frags<C>(1) * FRAG_BYTES;
+
+        // this wave's points, Fourier-encoded straight into B fragments
+        const int64_t wave_base = ((int64_t)blockIdx.x * WAVES + wave) * (NT * 32);
+        float valid[NT];
+        Frag E[NT][EF];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            int64_t idx = wave_base + n * 32 + (lane & 31);
+            const float4 p = pts[idx < n_pts ? idx : n_pts - 1];
+            valid[n] = p.w;
+            act_row[n] = (SAVE && idx < n_pts) ? act + idx * ACT_COLS + 4 * half : nullptr;
+            const float xs[3] = {p.x, p.y, p.z};
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                float v;
+                if (j < 30) {
+                    const int k = j / 3, d = j % 3;
+                    v = sin_or_cos(xs[d] * (float)(1 << k), half);
+                } else if (j == 30) {
+                    v = half ? xs[2] : xs[0];
+                } else {
+                    v = half ? 0.0f : xs[1];
+                }
+                put(E[n][j / EPF], j % EPF, v);
+            }
+        }
+
+        // chunk 0 resident -> its first fragment group and bias into registers
+        if constexpr (DMA) dma_wait();
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w0[q] = (reinterpret_cast<const Frag*>(slot_cur) + lane)[q * 64];
+        bias_c = read_bias(0);
+
+        Frag A[NT][HF], B[NT][HF];
+        float sigma[NT];
+        // trunk: 8 layers of 8 tiles, activations ping-pong between A and B (global tile index in <>)
+        layer<0, 8, EF, 0, true, HF, HF>(E, B, A, NoEpi{});                                      // 1: enc -> A
+        layer<8, 8, 0, HF, true, HF, HF>(E, A, B, last_of<0, 8, true>(A));                       // 2: A -> B
+        layer<16, 8, 0, HF, true, HF, HF>(E, B, A, last_of<8, 8, true>(B));                      // 3: B -> A
+        layer<24, 8, 0, HF, true, HF, HF>(E, A, B, last_of<16, 8, true>(A));                     // 4: A -> B
+        layer<32, 8, EF, HF, true, HF, HF>(E, B, A, last_of<24, 8, true>(B));                    // 5: [enc, B] -> A
+        layer<40, 8, 0, HF, true, HF, HF>(E, A, B, last_of<32, 8, true>(A));                     // 6: A -> B
+        layer<48, 8, 0, HF, true, HF, HF>(E, B, A, last_of<40, 8, true>(B));                     // 7: B -> A
+        layer<56, 8, 0, HF, true, HF, HF>(E, A, B, last_of<48, 8, true>(A));                     // 8: A -> B
+        // sigma row: one tile on h8 (= B).  models/anim_nerf.py:305 masks it where the warp was invalid.
+        tile<64, 0, HF, HF>(E, B, last_of<56, 8, true>(B));
+        if constexpr (SIGMA_ONLY) {
+            float* out = reinterpret_cast<float*>(out_v);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                int64_t idx = wave_base + n * 32 + (lane & 31);
+                if (half == 0 && idx < n_pts) out[idx] = (valid[n] < 1.0f) ? -1e5f : acc[64 & 1][n][0];
+            }
+            return;
+        } else {
+            float4* out = reinterpret_cast<float4*>(out_v);
+            // xyz_encoding_final (no activation): B -> A
+            layer<65, 8, 0, HF, false, HF, HF>(E, B, A, SigmaEpi{acc[64 & 1], sigma});
+            // dir_encoding: A -> G (256 -> 128, relu); rgb: G -> 3, sigmoid
+            Frag G[NT][DF];
+            layer<73, 4, 0, HF, true, HF, DF>(E, A, G, last_of<65, 8, false>(A));
+            tile<77, 0, DF, DF>(E, G, last_of<73, 4, true>(G));
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                int64_t idx = wave_base + n * 32 + (lane & 31);
+                const f32x16& r = acc[77 & 1][n];
+                if (half == 0 && idx < n_pts) {
+                    float cr = 1.0f / (1.0f + expf(-r[0]));
+                    float cg = 1.0f / (1.0f + expf(-r[1]));
+                    float cb = 1.0f / (1.0f + expf(-r[2]));
+                    float s = (valid[n] < 1.0f) ? -1e5f : sigma[n];       // models/anim_nerf.py:305
+                    out[idx] = make_float4(cr, cg, cb, s);
+                }
+            }
+        }
+    }
+};
+
+template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE>
+__global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void mlp_kernel(const char* __restrict__ pack,
+                                                             const float4* __restrict__ pts, int64_t n_pts,
+                                                             void* __restrict__ out, float* __restrict__ act) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    Mlp<MODE, DMA, SIGMA_ONLY, SAVE> m;
+    m.run(pack, pts, n_pts, out, act, lds);
+}
+
+template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE>
+int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStream_t st, float* act) {
+    using C = Cfg<MODE>;
+    const int lds = BIAS_BYTES + 3 * slot_bytes<C>();
+    auto kern = mlp_kernel<MODE, DMA, SIGMA_ONLY, SAVE>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail((int)e, "anr_mlp_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    const int pts_per_wg = C::WAVES * C::NT * 32;
+    dim3 grid((unsigned)((n + pts_per_wg - 1) / pts_per_wg));
+    hipLaunchKernelGGL(kern, grid, dim3(C::WAVES * 64), lds, st, reinterpret_cast<const char*>(pack),
+                       reinterpret_cast<const float4*>(pts), n, reinterpret_cast<void*>(out), act);
+    return check_launch("anr_mlp_forward");
+}
+
+
+}  // namespace anr

@@ -1,0 +1,7 @@
+// explicit instantiations of the fused MLP kernel (see mlp_core.h); split over files so they compile in parallel
+#include "mlp_core.h"
+
+namespace anr {
+template int launch_mlp<ANR_MLP_F32, true, false, true>(const void*, const float*, int64_t, float*, hipStream_t, float*);
+template int launch_mlp<ANR_MLP_F32, true, true, true>(const void*, const float*, int64_t, float*, hipStream_t, float*);
+}  // namespace anr

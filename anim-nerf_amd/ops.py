@@ -289,6 +289,42 @@ def composite(rgbs, z, rays, white_bkgd: bool, noise=None, want_weights: bool = 
     return w, rgb, depth, acc
 
 
+def composite_backward(rgbs, z, rays, white_bkgd: bool, g_rgb, g_depth, g_acc, noise=None, g_weights=None):
+    """Backward of `composite`: -> d_rgbs[R,K,4]."""
+    lib = _lib.load()
+    rgbs, z, rays = _dev(rgbs, "rgbs"), _dev(z, "z"), _dev(rays, "rays")
+    g_rgb, g_depth, g_acc = _dev(g_rgb, "g_rgb"), _dev(g_depth, "g_depth"), _dev(g_acc, "g_acc")
+    R, K = z.shape
+    if noise is not None:
+        noise = _dev(noise, "noise")
+    if g_weights is not None:
+        g_weights = _dev(g_weights, "g_weights")
+    d = torch.empty(R, K, 4, dtype=torch.float32, device=z.device)
+    with _timed("composite_backward", R * K):
+        _lib.check(lib.anr_composite_backward(_ptr(rgbs), _ptr(z), _ptr(rays), rays.shape[-1], _ptr(noise), R, K,
+                                              1 if white_bkgd else 0, _ptr(g_weights), _ptr(g_rgb), _ptr(g_depth),
+                                              _ptr(g_acc), _ptr(d), _stream(d)), "anr_composite_backward")
+    return d
+
+
+def mlp_forward_save(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bool = False):
+    """Training forward: (out, act[n, anr_mlp_act_cols()]) — act keeps every layer's post-activation output."""
+    lib = _lib.load()
+    pts = _dev(pts, "pts")
+    n = pts.numel() // 4
+    mode = mode & 0xff
+    if sigma_only:
+        mode |= ANR_MLP_FLAG_SIGMA_ONLY
+        out = torch.empty(n, dtype=torch.float32, device=pts.device)
+    else:
+        out = torch.empty(n, 4, dtype=torch.float32, device=pts.device)
+    act = torch.empty(n, lib.anr_mlp_act_cols(), dtype=torch.float32, device=pts.device)
+    with _timed("mlp_forward_save", n):
+        _lib.check(lib.anr_mlp_forward_save(_ptr(pack), mode, _ptr(pts), n, _ptr(out), _ptr(act), _stream(out)),
+                   "anr_mlp_forward_save")
+    return out, act
+
+
 def sample_fine_merge(z_coarse, weights, u, want_fine: bool = False):
     """models/volume_rendering.py:59-97,199-207.  z_coarse[R,Kc], weights[R,Kc], u[Kf] or u[R,Kf]."""
     lib = _lib.load()

@@ -35,7 +35,6 @@ def batched_inference(volume_renderer, anim_nerf, rays, body_model_params, body_
     return render_prepared(volume_renderer, anim_nerf, rays, chunk=chunk, perturb=0.0)
 
 
-@torch.no_grad()
 def render_prepared(volume_renderer, anim_nerf, rays, chunk=2048, perturb=0.0):
     """The hot loop alone: per-frame state already set on `anim_nerf`, rays already in the body frame."""
     n_rays = rays.shape[1]
@@ -47,7 +46,6 @@ def render_prepared(volume_renderer, anim_nerf, rays, chunk=2048, perturb=0.0):
     return {k: torch.cat(v, 1) for k, v in pieces.items()}
 
 
-@torch.no_grad()
 def system_forward(volume_renderer, anim_nerf, rays, body_model_params, body_model_params_template,
                    latent_code=None, perturb=1.0, chunk=2048):
     """AnimNeRFSystem.forward (train.py:189-215): rays[bs,h,w,8] -> dict of [bs,h,w,C]."""

@@ -51,7 +51,8 @@ class VolumeRenderer(nn.Module):
         bs, R, K = z.shape
         fused = hasattr(model, "warped_points") and hasattr(model, "_net")
         if fused:
-            pts = model.warped_points(rays=rays, z=z, skip_far=True)
+            with torch.no_grad():
+                pts = model.warped_points(rays=rays, z=z, skip_far=True)
             out = model._net(not coarse).eval_points(pts)
         else:
             xyz = (rays[..., None, :3] + z[..., None] * rays[..., None, 3:6]).reshape(bs, -1, 3)
@@ -61,8 +62,13 @@ class VolumeRenderer(nn.Module):
         noise = None
         if self.noise_std > 0.0 and perturb > 0:
             noise = torch.randn(bs * R, K, device=z.device) * self.noise_std
-        w, rgb, depth, acc = ops.composite(out.view(bs * R, K, 4), z.view(bs * R, K), rays.reshape(bs * R, -1),
-                                           self.white_bkgd, noise=noise, want_weights=want_weights)
+        if out.requires_grad:                                   # training: differentiable compositing
+            from .autograd import CompositeFunction
+            w, rgb, depth, acc = CompositeFunction.apply(out.view(bs * R, K, 4), z.view(bs * R, K),
+                                                         rays.reshape(bs * R, -1), noise, self.white_bkgd)
+        else:
+            w, rgb, depth, acc = ops.composite(out.view(bs * R, K, 4), z.view(bs * R, K), rays.reshape(bs * R, -1),
+                                               self.white_bkgd, noise=noise, want_weights=want_weights)
         return (w, rgb.view(bs, R, 3), depth.view(bs, R, 1), acc.view(bs, R, 1))
 
     def sample_fine_sorted(self, z_coarse, weights, perturb=0.):
@@ -75,14 +81,17 @@ class VolumeRenderer(nn.Module):
         zs = ops.sample_fine_merge(z_coarse.view(bs * R, Kc), weights, u)
         return zs.view(bs, R, Kc + self.n_fine)
 
-    @torch.no_grad()
     def forward(self, model, rays, perturb=0., **kwargs):
-        rays = rays if rays.is_contiguous() else rays.contiguous()
-        z_coarse = self.sample_coarse(rays, perturb=perturb)
+        """Differentiable w.r.t. the MLP weights when autograd is enabled (sampling itself carries no gradient,
+        as in the reference: z_fine is detached, models/volume_rendering.py:200)."""
+        rays = (rays if rays.is_contiguous() else rays.contiguous()).detach()
+        with torch.no_grad():
+            z_coarse = self.sample_coarse(rays, perturb=perturb)
         w, rgbs, depths, alphas = self._shade(model, rays, z_coarse, True, perturb, self.n_fine > 0, **kwargs)
         output = {"rgbs": rgbs, "alphas": alphas, "depths": depths}
         if self.n_fine > 0:
-            z_all = self.sample_fine_sorted(z_coarse, w, perturb)
+            with torch.no_grad():
+                z_all = self.sample_fine_sorted(z_coarse, w.detach(), perturb)
             _, rgbs_f, depths_f, alphas_f = self._shade(model, rays, z_all, False, perturb, False, **kwargs)
             if self.share_fine:
                 output = {"rgbs": rgbs_f, "alphas": alphas_f, "depths": depths_f}

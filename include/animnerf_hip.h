@@ -144,6 +144,14 @@ int anr_mlp_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream
 int anr_mlp_forward(const void* pack, int mode, const float* pts, int64_t n,
                     float* out, void* stream);
 
+/* Training forward: the same kernel, additionally storing each layer's post-activation output for the backward
+ * pass (what autograd keeps alive in the reference, models/nerf.py:163-175): act[n * anr_mlp_act_cols()] fp32,
+ * row = [h1..h8 (8 x 256, post-ReLU) | xyz_encoding_final (256) | dir hidden (128, post-ReLU)]; with
+ * ANR_MLP_FLAG_SIGMA_ONLY only h1..h8 are written. */
+int anr_mlp_act_cols(void);
+int anr_mlp_forward_save(const void* pack, int mode, const float* pts, int64_t n,
+                         float* out, float* act, void* stream);
+
 /* ---- sigma-grid points for mesh extraction -------------------------------------------------------
  * extract_mesh.py:27-35 (create_grid: np.meshgrid(x, y, z), 'xy' indexing, fp64 linspace -> fp32) and :152-157
  * (+ bounding-box centre of the posed vertices).  Flat index n = (j*N + i)*N + k -> (x[i], y[j], z[k]).
@@ -161,6 +169,14 @@ int anr_composite(const float* rgbs, const float* z, const float* rays, int stri
                   const float* noise, int64_t R, int K, int white_bkgd,
                   float* weights_out, float* rgb_out, float* depth_out, float* acc_out,
                   void* stream);
+
+/* ---- a16 (part): backward of anr_composite -------------------------------------------------------------
+ * What autograd differentiates in models/volume_rendering.py:131-160: upstream gradients of the per-ray outputs
+ * g_rgb[R*3], g_depth[R], g_acc[R] (and optionally of the weights, g_weights[R*K] or NULL) ->
+ * d_rgbs[R*K*4] = dL/d(r, g, b, sigma) per sample.  Same inputs as the forward (nothing is kept by the library). */
+int anr_composite_backward(const float* rgbs, const float* z, const float* rays, int stride, const float* noise,
+                           int64_t R, int K, int white_bkgd, const float* g_weights, const float* g_rgb,
+                           const float* g_depth, const float* g_acc, float* d_rgbs, void* stream);
 
 /* ---- a14: importance sampling + merge ---------------------------------------------------------------
  * models/volume_rendering.py:59-97 and :199-207: inverse-CDF samples over the Kc-1 mid-points

@@ -355,7 +355,7 @@ def render_rays(field, rays: Tensor, n_coarse: int, n_fine: int, white_bkgd: boo
     w, col, dep, acc = shade(zc, False)
     out = dict(rgbs=col, alphas=acc, depths=dep, _z_coarse=zc, _weights=w)
     if n_fine > 0:
-        zf = fine_depths(zc, w, n_fine)
+        zf = fine_depths(zc, w.detach(), n_fine).detach()        # volume_rendering.py:200: no gradient through sampling
         zs, _ = torch.sort(torch.cat([zc, zf], -1), dim=-1)
         w2, col2, dep2, acc2 = shade(zs, True)
         out.update(rgbs_fine=col2, alphas_fine=acc2, depths_fine=dep2,

@@ -1,0 +1,141 @@
+"""GPU tests of the training path (a16/a17): gradients of the HIP forward + custom backward against torch autograd
+through the CPU oracle (which restates the reference op for op, so its autograd IS the reference's backward)."""
+import pytest
+import torch
+
+from helpers import golden, net_params, oracle_table, seeded_model, tdict
+from oracle import animnerf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import anim_nerf_amd as ana
+    assert torch.cuda.is_available()
+    ana._lib.load()
+    return torch.device("cuda:0")
+
+
+def _templ(device):
+    from anim_nerf_amd import synthetic as syn
+    return {k: torch.from_numpy(v).to(device) for k, v in syn.template_pose_params().items()}
+
+
+def test_composite_backward_matches_autograd(dev):
+    import anim_nerf_amd as ana
+    from anim_nerf_amd.autograd import CompositeFunction
+    gen = torch.Generator().manual_seed(1)
+    for K in (8, 64, 96, 128):
+        R = 301
+        rays = torch.zeros(R, 8)
+        rays[:, 6], rays[:, 7] = 2.0, 4.0 + torch.rand(R, generator=gen)
+        z = torch.sort(2 + 2 * torch.rand(R, K, generator=gen), -1).values
+        rgbs = torch.rand(R, K, 3, generator=gen)
+        sig = torch.randn(R, K, generator=gen) * 15
+        sig[::5] = -1e5
+        noise = torch.randn(R, K, generator=gen)
+        g_rgb, g_dep, g_acc = torch.randn(R, 3, generator=gen), torch.randn(R, 1, generator=gen), torch.randn(R, 1, generator=gen)
+        # oracle autograd
+        rgbs_o, sig_o = rgbs.clone().requires_grad_(True), sig.clone().requires_grad_(True)
+        _, c, d, a = orc.composite(rgbs_o, sig_o + noise, z, rays[:, 7:8])
+        (c * g_rgb).sum().add((d * g_dep).sum()).add((a * g_acc).sum()).backward()
+        # HIP
+        packed = torch.cat([rgbs, sig[..., None]], -1).to(dev).requires_grad_(True)
+        w, c2, d2, a2 = CompositeFunction.apply(packed, z.to(dev), rays.to(dev), noise.to(dev), True)
+        ((c2 * g_rgb.to(dev)).sum() + (d2 * g_dep.to(dev)).sum() + (a2 * g_acc.to(dev)).sum()).backward()
+        torch.testing.assert_close(packed.grad[..., :3].cpu(), rgbs_o.grad, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(packed.grad[..., 3].cpu(), sig_o.grad, rtol=2e-4, atol=1e-6)
+        assert not w.requires_grad
+
+
+@pytest.mark.parametrize("sigma_only", [False, True])
+def test_mlp_backward_matches_autograd(dev, smpl_table, sigma_only):
+    m = seeded_model(smpl_table, 7, True, gain=50.0, device=dev)
+    net = m.nerf
+    gen = torch.Generator().manual_seed(2)
+    n = 333
+    xyz = torch.rand(n, 3, generator=gen) * 2 - 1
+    pts = torch.cat([xyz, torch.ones(n, 1)], -1)
+    pts[::11, 3] = 0.0                                          # invalid points: sigma is a constant there
+    g = torch.randn(n, 1 if sigma_only else 4, generator=gen)
+    # HIP forward (+ saved activations) and backward
+    out = net.eval_points(pts.to(dev), "f32", sigma_only=sigma_only)
+    assert out.requires_grad
+    (out.reshape(n, -1) * g.to(dev)).sum().backward()
+    # oracle autograd
+    P = {k: v.clone().requires_grad_(True) for k, v in net_params(net).items()}
+    rgb, sig = orc.mlp_forward(P, xyz)
+    sig = torch.where(pts[:, 3:4] < 1, torch.full_like(sig, -1e5), sig)
+    ref_out = sig if sigma_only else torch.cat([rgb, sig], -1)
+    (ref_out * g).sum().backward()
+    for k, p in net.named_parameters():
+        ref = P[k].grad
+        if ref is None:                                         # rgb branch unused in sigma-only mode
+            assert p.grad is None or p.grad.abs().max() == 0, k
+            continue
+        err = (p.grad.cpu() - ref).abs().max().item()
+        assert err <= 2e-4 * ref.abs().max().item() + 1e-6, (k, err, ref.abs().max().item())
+
+
+def test_training_loss_gradients_match_oracle(dev, smpl_table):
+    """One whole training-style forward (2 frames, warp on, coarse + fine, all four loss families) and backward."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    g = golden("render_cfg3_warp_gain")
+    m = seeded_model(smpl_table, g["seed"], True, g["gain"], g["shift"], device=dev)
+    hp = ana.TrainHParams(n_samples=16, n_importance=8, chunk=40)
+    vr = ana.VolumeRenderer(n_coarse=16, n_fine=8)
+    pose_np = syn.animated_pose_params(seed=3, bs=2)
+    pose = {k: torch.from_numpy(v) for k, v in pose_np.items()}
+    templ = {k: torch.from_numpy(v) for k, v in syn.template_pose_params().items()}
+    c2w, focal, cen = syn.pinhole_camera(8, 8)
+    rays = orc.make_rays(torch.from_numpy(c2w), 8, 8, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(2, 1, 1, 1)
+    gen = torch.Generator().manual_seed(4)
+    tgt_rgb, tgt_a = torch.rand(2, 8, 8, 3, generator=gen), (torch.rand(2, 8, 8, 1, generator=gen) > 0.5).float()
+    fg = torch.rand(2, 64, 3, generator=gen) * 0.4 - 0.2
+    bg = torch.rand(2, 64, 3, generator=gen) * 2 - 1
+    # HIP
+    res = ana.system_forward(vr, m, rays.to(dev), {k: v.to(dev) for k, v in pose.items()}, _templ(dev), perturb=0.0,
+                             chunk=hp.chunk)
+    loss, details = ana.compute_loss(m, hp, tgt_rgb.to(dev), tgt_a.to(dev), res, fg.to(dev), bg.to(dev))
+    loss.backward()
+    # oracle
+    tbl = oracle_table(smpl_table)
+    Pc = {k: v.clone().requires_grad_(True) for k, v in net_params(m.nerf).items()}
+    Pf = {k: v.clone().requires_grad_(True) for k, v in net_params(m.nerf_fine).items()}
+    out = orc.render_frame(tbl, Pc, Pf, rays.view(2, 64, 8), pose, templ, n_coarse=16, n_fine=8, use_unpose=True,
+                           chunk=40, knn_chunk=512)
+    F = torch.nn.functional
+    t_rgb, t_a = tgt_rgb.view(2, 64, 3), tgt_a.view(2, 64, 1)
+    ref = (F.mse_loss(out["rgbs"], t_rgb) + F.mse_loss(out["rgbs_fine"], t_rgb)
+           + 0.1 * (F.l1_loss(out["alphas"], t_a) + F.l1_loss(out["alphas_fine"], t_a)))
+    for P in (Pc, Pf):
+        s_fg = orc.mlp_sigma_and_feature(P, fg)[0]
+        s_bg = orc.mlp_sigma_and_feature(P, bg)[0]
+        ref = ref + 0.01 * torch.mean(torch.exp(-2.0 / 16 * torch.relu(s_fg))) \
+                  + 0.01 * torch.mean(1 - torch.exp(-2.0 / 16 * torch.relu(s_bg)))
+    ref.backward()
+    assert out["alphas_fine"].max() > 0.5, "the test scene must not be empty"
+    assert abs(loss.item() - ref.item()) <= 2e-4 * abs(ref.item()), (loss.item(), ref.item())
+    for net, P in ((m.nerf, Pc), (m.nerf_fine, Pf)):
+        num = den = 0.0
+        for k, p in net.named_parameters():
+            num += (p.grad.cpu() - P[k].grad).pow(2).sum().item()
+            den += P[k].grad.pow(2).sum().item()
+        assert den > 0 and (num / den) ** 0.5 < 5e-3, (num / den) ** 0.5     # relative L2 error of the whole gradient
+
+
+def test_adam_steps_reduce_loss(dev, smpl_table):
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    m = seeded_model(smpl_table, 11, False, 300.0, (2.0, 2.0), device=dev)
+    hp = ana.TrainHParams(n_samples=16, n_importance=8, chunk=512, use_unpose=False, lr=1e-3)
+    tr = ana.Trainer(m, ana.VolumeRenderer(n_coarse=16, n_fine=8), hp)
+    c2w, focal, cen = syn.pinhole_camera(16, 16)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), 16, 16, focal.tolist(), 0.1, 10.0, cen.tolist())[None]
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.static_pose_params().items()}
+    tgt = torch.rand(1, 16, 16, 3, generator=torch.Generator().manual_seed(0)).to(dev) * 0.5
+    alp = torch.ones(1, 16, 16, 1, device=dev)
+    losses = [tr.step(rays, tgt, alp, pose, _templ(dev), perturb=0.0)[0].item() for _ in range(25)]
+    assert losses[-1] < 0.7 * losses[0], losses
