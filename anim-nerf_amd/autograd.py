@@ -40,44 +40,64 @@ class MLPFunction(torch.autograd.Function):
     @torch.no_grad()
     def backward(ctx, g):
         pts, out, act, *params = ctx.saved_tensors
-        P = dict(zip(PARAM_KEYS, params))
+        dt = act.dtype                                              # fp32 (parity mode) or bf16 (mixed precision)
+        P = {k: (p if p.dtype == dt else p.to(dt)) for k, p in zip(PARAM_KEYS, params)}
         n = pts.shape[0]
         H = act[:, :2048].view(n, 8, 256)
         grads = {}
+
+        # dW = dY^T X is a [256 x n] x [n x 256] product with n ~ 1e6: the library picks one tile per 64x64 of the
+        # output (16 workgroups on a 256-CU chip), so the reduction dimension is split by hand into S batches
+        # (S x 16 workgroups) and the S partial products are summed.
+        S = 1
+        while S < 128 and n % (2 * S) == 0 and n // (2 * S) >= 256:
+            S *= 2
+
+        def wgrad(dy, x):                                            # accumulated and returned in fp32
+            a = dy.reshape(S, n // S, dy.shape[1]).transpose(1, 2)
+            b = x.reshape(S, n // S, x.shape[1])
+            part = torch.bmm(a, b) if dt == torch.float32 else torch.bmm(a, b, out_dtype=torch.float32)
+            return part.sum(0) if S > 1 else part[0]
+
+        def relu_bwd(dy, h):                                         # dy * (h > 0) in one kernel
+            return torch.ops.aten.threshold_backward(dy, h, 0)
+
         valid = (pts[:, 3] >= 1.0).to(g.dtype)                       # sigma is the constant -1e5 where invalid
         if ctx.sigma_only:
-            g_sig = g.reshape(n) * valid
+            g_sig = (g.reshape(n) * valid).to(dt)
             dh = g_sig[:, None] * P["sigma.weight"]
         else:
-            g_sig = g[:, 3] * valid
+            g_sig = (g[:, 3] * valid).to(dt)
             rgb = out[:, :3]
-            d_rgb = g[:, :3] * rgb * (1 - rgb)                        # sigmoid'
+            d_rgb = (g[:, :3] * rgb * (1 - rgb)).to(dt)               # sigmoid'
             G = act[:, 2304:2432]
             F = act[:, 2048:2304]
-            grads["rgb.0.weight"] = d_rgb.t() @ G
-            grads["rgb.0.bias"] = d_rgb.sum(0)
-            dG = (d_rgb @ P["rgb.0.weight"]) * (G > 0)
-            grads["dir_encoding.0.weight"] = dG.t() @ F
-            grads["dir_encoding.0.bias"] = dG.sum(0)
+            grads["rgb.0.weight"] = wgrad(d_rgb, G)
+            grads["rgb.0.bias"] = d_rgb.sum(0, dtype=torch.float32)
+            dG = relu_bwd(d_rgb @ P["rgb.0.weight"], G)
+            grads["dir_encoding.0.weight"] = wgrad(dG, F)
+            grads["dir_encoding.0.bias"] = dG.sum(0, dtype=torch.float32)
             dF = dG @ P["dir_encoding.0.weight"]
-            grads["xyz_encoding_final.weight"] = dF.t() @ H[:, 7]
-            grads["xyz_encoding_final.bias"] = dF.sum(0)
-            dh = dF @ P["xyz_encoding_final.weight"] + g_sig[:, None] * P["sigma.weight"]
-        grads["sigma.weight"] = (g_sig[None, :] @ H[:, 7])
-        grads["sigma.bias"] = g_sig.sum().reshape(1)
-        enc = _encode(pts[:, :3])
+            grads["xyz_encoding_final.weight"] = wgrad(dF, H[:, 7])
+            grads["xyz_encoding_final.bias"] = dF.sum(0, dtype=torch.float32)
+            dh = torch.addmm(g_sig[:, None] * P["sigma.weight"], dF, P["xyz_encoding_final.weight"])
+        # (a 1-row operand sends the library down a GEMV path that costs ~11 ms of host time: pad to 2 rows)
+        grads["sigma.weight"] = wgrad(torch.stack([g_sig, torch.zeros_like(g_sig)], 1), H[:, 7])[:1]
+        grads["sigma.bias"] = g_sig.sum(dtype=torch.float32).reshape(1)
+        enc = _encode(pts[:, :3]).to(dt)
         for l in range(8, 0, -1):
-            dpre = dh * (H[:, l - 1] > 0)
+            dpre = relu_bwd(dh, H[:, l - 1])
             inp = enc if l == 1 else torch.cat([enc, H[:, l - 2]], -1) if l == 5 else H[:, l - 2]
-            grads[f"xyz_encoding_{l}.0.weight"] = dpre.t() @ inp
-            grads[f"xyz_encoding_{l}.0.bias"] = dpre.sum(0)
+            grads[f"xyz_encoding_{l}.0.weight"] = wgrad(dpre, inp)
+            grads[f"xyz_encoding_{l}.0.bias"] = dpre.sum(0, dtype=torch.float32)
             if l > 1:
                 W = P[f"xyz_encoding_{l}.0.weight"]
                 dh = dpre @ (W[:, 63:] if l == 5 else W)
         out_grads = []
         for i, k in enumerate(PARAM_KEYS):
             need = ctx.needs_input_grad[3 + i]
-            out_grads.append(grads.get(k) if need and k in grads else None)
+            gk = grads.get(k) if need else None
+            out_grads.append(None if gk is None else gk.to(params[i].dtype).reshape(params[i].shape))
         return (None, None, None, *out_grads)
 
 

@@ -147,8 +147,9 @@ extern "C" int anr_mlp_pack(const anr_mlp_params* p, int mode, void* pack_out, v
 
 extern "C" int anr_mlp_act_cols(void) { return ACT_COLS; }
 
-extern "C" int anr_mlp_forward_save(const void* pack, int mode, const float* pts, int64_t n, float* out, float* act,
+extern "C" int anr_mlp_forward_save(const void* pack, int mode, const float* pts, int64_t n, float* out, void* act_v,
                                     void* stream) {
+    float* act = reinterpret_cast<float*>(act_v);
     ANR_REQUIRE(pack && pts && out && act, ANR_E_BADARG, "anr_mlp_forward_save: null pointer");
     ANR_REQUIRE(n > 0, ANR_E_BADARG, "anr_mlp_forward_save: n=%lld", (long long)n);
     ANR_REQUIRE((((uintptr_t)pack | (uintptr_t)pts | (uintptr_t)out | (uintptr_t)act) & 15) == 0, ANR_E_ALIGN,

@@ -25,6 +25,7 @@
 //   so the two half-waves run one instruction stream (sin vs cos is a quadrant offset).
 #pragma once
 #include "anr_common.h"
+#include <type_traits>
 #include <utility>
 
 namespace anr {
@@ -177,6 +178,7 @@ struct Mlp {
     static constexpr int THREADS = WAVES * 64;
     static constexpr int FPT = 16 / EPF;          // next-layer frags produced per out-tile
     static constexpr int SLOT = slot_bytes<C>();
+    using ActT = std::conditional_t<C::IS_BF16, __bf16, float>;    // saved activations: the dtype the next layer consumed
     static constexpr int LAST_TILE = SIGMA_ONLY ? 64 : 77;         // sigma-only stops after the sigma row (tile 64)
     static constexpr int LAST_CHUNK = LAST_TILE / TPC;
 
@@ -195,7 +197,7 @@ struct Mlp {
     f32x16 acc[2][NT];       // accumulators of tile c (parity c&1) and of tile c-1 (epilogue pending)
     f32x16 bias_c;           // bias of tile c: C operand of its first MFMA
     Frag w0[4];              // first fragment group of tile c
-    float* act_row[NT];      // SAVE: this lane's row of saved activations (+ 4*half), or null
+    ActT* act_row[NT];       // SAVE: this lane's row of saved activations (+ 4*half), or null
 
     // barrier: chunk c+1 has landed everywhere and nobody reads chunk c-1 any more -> stage chunk c+2 over it
     __device__ __forceinline__ void advance() {
@@ -237,7 +239,7 @@ struct Mlp {
     struct FragEpi {
         const f32x16 (&a)[NT];
         Frag (&Y)[NT][YF];
-        float* const (&ar)[NT];
+        ActT* const (&ar)[NT];
         template <int Q> __device__ __forceinline__ void part() const {
 #ifdef ANR_ABL_NO_EPILOGUE
             if (Q > 0) return;
@@ -254,7 +256,17 @@ struct Mlp {
                 }
                 if ((4 * Q + 4) % EPF == 0) pin(Y[n][TB + (4 * Q) / EPF]);
                 // features 32t + 8Q + 4h + (0..3) of this lane's point: 16 contiguous bytes of its row
-                if (SAVE && ar[n] != nullptr) *reinterpret_cast<f32x4*>(ar[n] + act_col(TG) + 8 * Q) = keep;
+                if (SAVE && ar[n] != nullptr) {
+                    if constexpr (C::IS_BF16) {
+                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                        bf16x4 k4;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) k4[i] = (__bf16)keep[i];
+                        *reinterpret_cast<bf16x4*>(ar[n] + act_col(TG) + 8 * Q) = k4;
+                    } else {
+                        *reinterpret_cast<f32x4*>(ar[n] + act_col(TG) + 8 * Q) = keep;
+                    }
+                }
             }
         }
     };
@@ -367,7 +379,7 @@ struct Mlp {
             int64_t idx = wave_base + n * 32 + (lane & 31);
             const float4 p = pts[idx < n_pts ? idx : n_pts - 1];
             valid[n] = p.w;
-            act_row[n] = (SAVE && idx < n_pts) ? act + idx * ACT_COLS + 4 * half : nullptr;
+            act_row[n] = (SAVE && idx < n_pts) ? reinterpret_cast<ActT*>(act) + idx * ACT_COLS + 4 * half : nullptr;
             const float xs[3] = {p.x, p.y, p.z};
 #pragma unroll
             for (int j = 0; j < 32; ++j) {

@@ -318,7 +318,8 @@ def mlp_forward_save(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_onl
         out = torch.empty(n, dtype=torch.float32, device=pts.device)
     else:
         out = torch.empty(n, 4, dtype=torch.float32, device=pts.device)
-    act = torch.empty(n, lib.anr_mlp_act_cols(), dtype=torch.float32, device=pts.device)
+    act = torch.empty(n, lib.anr_mlp_act_cols(), device=pts.device,
+                      dtype=torch.bfloat16 if (mode & 0xff) == ANR_MLP_BF16 else torch.float32)
     with _timed("mlp_forward_save", n):
         _lib.check(lib.anr_mlp_forward_save(_ptr(pack), mode, _ptr(pts), n, _ptr(out), _ptr(act), _stream(out)),
                    "anr_mlp_forward_save")

@@ -35,7 +35,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
+                    help="cfg2/cfg3: BASELINE configs[1]/[2] (inference); cfg4: configs[3] training step (64+32, 32x32 rays per frame)")
+    ap.add_argument("--frames-per-gpu", type=int, default=16, help="cfg4: frames (of 1024 rays) per step per GPU")
     ap.add_argument("--mode", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--hw", type=int, default=1024)
     ap.add_argument("--n-coarse", type=int, default=64)
@@ -66,6 +68,8 @@ def main():
     from anim_nerf_amd import ops, synthetic as syn
 
     ana._lib.load()                                   # fails loudly if the HIP library is missing
+    if args.workload == "cfg4":
+        return train_bench(args, rank, local_rank, world, dev)
     use_warp = args.workload == "cfg3"
     tbl = syn.make_smpl_table(0)
     torch.manual_seed(0)
@@ -173,6 +177,71 @@ def main():
             result["psnr_vs_fp32_path_db"] = orc.psnr(out["rgbs_fine"][:, idx].cpu(), ref["rgbs_fine"].cpu())
         if args.cpu_rays > 0:
             result["cpu_baseline"] = cpu_baseline(args, tbl, model, rays, pose_np, use_warp)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def train_bench(args, rank, local_rank, world, dev):
+    """BASELINE configs[3] shape: one optimisation step = `frames_per_gpu` frames x 32x32 rays, 64 coarse + 32 fine,
+    perturb = 1, rgb/alpha/foreground/background losses, backward, ONE flat gradient all-reduce (RCCL), Adam."""
+    import torch.distributed as dist
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import ops, synthetic as syn
+    tbl = syn.make_smpl_table(0)
+    torch.manual_seed(0)
+    model = ana.AnimNeRF(body_model_table=tbl, freqs_dir=0, use_view=False, use_unpose=True, use_knn=True,
+                         use_fine=True, mlp_mode=args.mode).to(dev)
+    hp = ana.TrainHParams(n_samples=64, n_importance=32, chunk=2048)
+    trainer = ana.Trainer(model, ana.VolumeRenderer(n_coarse=64, n_fine=32), hp)
+    F = args.frames_per_gpu
+    c2w, focal, cen = syn.pinhole_camera(32, 32)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), 32, 32, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(F, 1, 1, 1)
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=200 + rank, bs=F).items()}
+    templ = {k: torch.from_numpy(v).to(dev) for k, v in syn.template_pose_params().items()}
+    g = torch.Generator().manual_seed(rank)
+    rgbs = torch.rand(F, 32, 32, 3, generator=g).to(dev)
+    alphas = (torch.rand(F, 32, 32, 1, generator=g) > 0.5).float().to(dev)
+    fg = (torch.rand(F, 128, 3, generator=g) * 0.4 - 0.2).to(dev)
+    bg = (torch.rand(F, 128, 3, generator=g) * 2 - 1).to(dev)
+
+    def step():
+        return trainer.step(rays, rgbs, alphas, pose, templ, fg, bg, perturb=1.0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ops.KERNEL_TIMING = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    barrier()
+    elapsed = ana.max_over_ranks(time.perf_counter() - t0, dev)
+    timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
+    mlp_s = sum(e0.elapsed_time(e1) for n, e0, e1, u in timing if n == "mlp_forward_save") * 1e-3
+    mlp_pts = sum(u for n, e0, e1, u in timing if n == "mlp_forward_save")
+    peak = PEAK_BF16_TFLOPS if args.mode == "bf16" else PEAK_F32_TFLOPS
+    achieved = mlp_pts * MLP_FLOP_PER_POINT / mlp_s / 1e12 if mlp_s else 0.0
+    n_rays = F * 1024
+    result = {
+        "metric": "rays/sec, training step (64+32 samples, 256-wide MLP x2, fwd+bwd+Adam)",
+        "value": n_rays * args.steps * world / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.mode, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3] shape: train step, %d frames x 32x32 rays per GPU, 64 coarse + 32 fine, "
+                               "perturb=1, rgb+alpha+fg/bg losses (no normals term, no pose refinement), "
+                               "flat-gradient all-reduce (4.7 MB) + Adam" % F,
+                   "rays_per_step_per_gpu": n_rays, "grad_floats": sum(p.numel() for p in trainer.params)},
+        "roofline": {"kernel": f"mlp_kernel<{args.mode}, save> (training forward)", "bound": "mfma", "achieved": achieved,
+                     "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None},
+        "final_loss": float(loss),
+    }
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

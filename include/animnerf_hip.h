@@ -145,12 +145,13 @@ int anr_mlp_forward(const void* pack, int mode, const float* pts, int64_t n,
                     float* out, void* stream);
 
 /* Training forward: the same kernel, additionally storing each layer's post-activation output for the backward
- * pass (what autograd keeps alive in the reference, models/nerf.py:163-175): act[n * anr_mlp_act_cols()] fp32,
+ * pass (what autograd keeps alive in the reference, models/nerf.py:163-175): act[n * anr_mlp_act_cols()],
+ * fp32 in mode ANR_MLP_F32 and bf16 in mode ANR_MLP_BF16 (the value the next layer consumed),
  * row = [h1..h8 (8 x 256, post-ReLU) | xyz_encoding_final (256) | dir hidden (128, post-ReLU)]; with
  * ANR_MLP_FLAG_SIGMA_ONLY only h1..h8 are written. */
 int anr_mlp_act_cols(void);
 int anr_mlp_forward_save(const void* pack, int mode, const float* pts, int64_t n,
-                         float* out, float* act, void* stream);
+                         float* out, void* act, void* stream);
 
 /* ---- sigma-grid points for mesh extraction -------------------------------------------------------
  * extract_mesh.py:27-35 (create_grid: np.meshgrid(x, y, z), 'xy' indexing, fp64 linspace -> fp32) and :152-157

@@ -139,3 +139,20 @@ def test_adam_steps_reduce_loss(dev, smpl_table):
     alp = torch.ones(1, 16, 16, 1, device=dev)
     losses = [tr.step(rays, tgt, alp, pose, _templ(dev), perturb=0.0)[0].item() for _ in range(25)]
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_bf16_training_gradients_close_to_fp32(dev, smpl_table):
+    """Mixed precision (bf16 forward, bf16 activations and GEMM inputs, fp32 accumulation): gradient direction is kept."""
+    m = seeded_model(smpl_table, 7, True, gain=50.0, device=dev)
+    gen = torch.Generator().manual_seed(5)
+    n = 4096
+    pts = torch.cat([torch.rand(n, 3, generator=gen) * 2 - 1, torch.ones(n, 1)], -1).to(dev)
+    g = torch.randn(n, 4, generator=gen).to(dev)
+    grads = {}
+    for mode in ("f32", "bf16"):
+        m.nerf.zero_grad(set_to_none=True)
+        (m.nerf.eval_points(pts, mode) * g).sum().backward()
+        grads[mode] = torch.cat([p.grad.reshape(-1) for p in m.nerf.parameters()])
+    cos = torch.nn.functional.cosine_similarity(grads["f32"], grads["bf16"], dim=0).item()
+    assert cos > 0.999, cos
+    assert (grads["bf16"] - grads["f32"]).norm() / grads["f32"].norm() < 0.05
