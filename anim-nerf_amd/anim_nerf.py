@@ -22,6 +22,23 @@ def batch_transform(P, v, pad_ones=True):
     return out + P[..., :3, 3] if pad_ones else out
 
 
+def _ober2cano_autograd(T, T_template, offset_delta):
+    """models/anim_nerf.py:147-151 as differentiable tensor ops (closed-form inverse of the affine T, per frame):
+    out = T_template @ [R^-1 | -R^-1 t + offset_delta]."""
+    R, t = T[..., :3, :3], T[..., :3, 3]
+    c = torch.linalg.cross
+    r0, r1, r2 = R[..., 0, :], R[..., 1, :], R[..., 2, :]
+    adj = torch.stack([c(r1, r2), c(r2, r0), c(r0, r1)], dim=-1)          # columns = cofactor rows -> adjugate
+    det = (r0 * c(r1, r2)).sum(-1)
+    Rinv = adj / det[..., None, None]
+    tinv = -(Rinv @ t[..., None])[..., 0] + offset_delta
+    M = torch.zeros_like(T)
+    M[..., :3, :3] = Rinv
+    M[..., :3, 3] = tinv
+    M[..., 3, 3] = 1
+    return T_template @ M
+
+
 class AnimNeRF(nn.Module):
     def __init__(self, model_path="smplx/models", model_type="smpl", gender="male", freqs_xyz=10, freqs_dir=4,
                  use_view=False, use_unpose=False, unpose_view=False, k_neigh=4, use_knn=False,
@@ -88,10 +105,20 @@ class AnimNeRF(nn.Module):
             self.shape_offsets_template = t["shape_offsets"]
             self.pose_offsets_template = t["pose_offsets"]
 
+    def _pose_grad(self):
+        """True when gradients must reach the SMPL parameters (optim_body_params, train.py:141-144)."""
+        return torch.is_grad_enabled() and self.verts_transform.requires_grad
+
     def convert_to_body_model_space(self, rays):
         """rays[bs,R,>=8] -> rays in the root-joint frame; moves the cached body state too."""
         g_inv = torch.inverse(self.global_transform)                       # [bs,4,4]; bs tiny
-        new_rays = ops.rays_to_body(g_inv, rays)
+        if self._pose_grad():                                              # per-frame, differentiable form of the kernel
+            o = batch_transform(g_inv[:, None], rays[..., 0:3])
+            d = batch_transform(g_inv[:, None], rays[..., 3:6], pad_ones=False)
+            dist = torch.norm(o, dim=-1, keepdim=True)
+            new_rays = torch.cat([o, d, torch.max(rays[..., 6:7], dist - 1.0), torch.min(rays[..., 7:8], dist + 1.0)], -1)
+        else:
+            new_rays = ops.rays_to_body(g_inv, rays)
         G = g_inv[:, None]
         self.verts = batch_transform(G, self.verts)
         self._knn_index = None
@@ -101,9 +128,11 @@ class AnimNeRF(nn.Module):
         return new_rays
 
     def clac_ober2cano_transform(self):
-        if torch.is_grad_enabled() and self.verts_transform.requires_grad:
-            raise NotImplementedError("gradients w.r.t. the SMPL parameters (optim_body_params, pose refinement) are "
-                                      "not built yet: pass detached body_model_params")
+        if self._pose_grad():
+            self.ober2cano_transform = _ober2cano_autograd(
+                self.verts_transform, self.verts_transform_template,
+                (self.shape_offsets_template - self.shape_offsets) + (self.pose_offsets_template - self.pose_offsets))
+            return
         self.ober2cano_transform = ops.ober2cano(
             self.verts_transform, self.verts_transform_template, self.shape_offsets, self.shape_offsets_template,
             self.pose_offsets, self.pose_offsets_template)
@@ -116,7 +145,7 @@ class AnimNeRF(nn.Module):
         """Spatial index over the current posed vertices (rebuilt when set_body_model /
         convert_to_body_model_space replace them)."""
         if self._knn_index is None or self._knn_index[0] is not self.verts:
-            self._knn_index = (self.verts, ops.knn_index_build(self.verts, self.knn_order))
+            self._knn_index = (self.verts, ops.knn_index_build(self.verts.detach(), self.knn_order))
         return self._knn_index[1]
 
     def unpose(self, xyz, viewdir=None):
@@ -138,9 +167,14 @@ class AnimNeRF(nn.Module):
         skip_far: provably-invalid samples (farther than dis_threshold from the body's bounding box) skip the
         neighbour search; only legal where sigma = -1e5 is all that is consumed (the renderer)."""
         if self.use_unpose:
-            return ops.warp_points(self.knn_index(), self.ober2cano_transform, self.body_model.lbs_weights,
-                                   self.dis_threshold, xyz=xyz, rays=rays, z=z,
-                                   skip_far=skip_far and self.skip_far_samples).view(-1, 4)
+            far = skip_far and self.skip_far_samples
+            if xyz is None and torch.is_grad_enabled() and (rays.requires_grad or z.requires_grad
+                                                            or self.ober2cano_transform.requires_grad):
+                from .autograd import WarpFunction               # pose refinement: differentiable warp
+                return WarpFunction.apply(rays, z, self.ober2cano_transform, self.knn_index(),
+                                          self.body_model.lbs_weights, self.dis_threshold, far).view(-1, 4)
+            return ops.warp_points(self.knn_index(), self.ober2cano_transform.detach(), self.body_model.lbs_weights,
+                                   self.dis_threshold, xyz=xyz, rays=rays, z=z, skip_far=far).view(-1, 4)
         if xyz is not None:
             flat = xyz.reshape(-1, xyz.shape[-1])[:, :3]
             return torch.cat([flat, torch.ones_like(flat[:, :1])], -1)

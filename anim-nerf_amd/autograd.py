@@ -5,7 +5,10 @@ post-activation output, `anr_composite`); backward:
   * compositing: `anr_composite_backward` (HIP, one wavefront per ray);
   * MLP: the saved activations are plain row-major [points, features] matrices, and both gradient GEMM families
     (dX = dY W, dW = dY^T X) are plain library GEMMs (rocBLAS/hipBLASLt through torch.matmul) — 22 per network.
-No gradient flows into the sample points yet (body-pose refinement, `optim_body_params`, is not built).
+Pose refinement (`optim_body_params`): dL/dx_c leaves the MLP backward through the encoding, `WarpFunction` routes it
+into the per-vertex observation->canonical transforms (scatter-add over the 4 neighbours, whose weights carry no
+gradient: KNN distances are `no_grad` in the reference, models/anim_nerf.py:158) and into the sample position
+x = o' + z d'; the per-frame chain above that (closed-form inverses, SMPL/LBS) is ordinary torch autograd.
 """
 from __future__ import annotations
 
@@ -31,7 +34,7 @@ class MLPFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, sigma_only, mode_id, *params):
         pack = ops.mlp_pack(dict(zip(PARAM_KEYS, params)), mode_id)
-        out, act = ops.mlp_forward_save(pack, mode_id, pts, sigma_only)
+        out, act = ops.mlp_forward_save(pack, mode_id, pts.detach(), sigma_only)
         ctx.save_for_backward(pts, out, act, *params)
         ctx.sigma_only = sigma_only
         return out
@@ -85,20 +88,35 @@ class MLPFunction(torch.autograd.Function):
         grads["sigma.weight"] = wgrad(torch.stack([g_sig, torch.zeros_like(g_sig)], 1), H[:, 7])[:1]
         grads["sigma.bias"] = g_sig.sum(dtype=torch.float32).reshape(1)
         enc = _encode(pts[:, :3]).to(dt)
+        want_pts = ctx.needs_input_grad[0]
+        d_enc = None
         for l in range(8, 0, -1):
             dpre = relu_bwd(dh, H[:, l - 1])
             inp = enc if l == 1 else torch.cat([enc, H[:, l - 2]], -1) if l == 5 else H[:, l - 2]
             grads[f"xyz_encoding_{l}.0.weight"] = wgrad(dpre, inp)
             grads[f"xyz_encoding_{l}.0.bias"] = dpre.sum(0, dtype=torch.float32)
+            W = P[f"xyz_encoding_{l}.0.weight"]
             if l > 1:
-                W = P[f"xyz_encoding_{l}.0.weight"]
                 dh = dpre @ (W[:, 63:] if l == 5 else W)
+            if want_pts and l in (1, 5):
+                t = (dpre @ W[:, :63]).float()
+                d_enc = t if d_enc is None else d_enc + t
+        d_pts = None
+        if want_pts:                                                # through x -> (x, sin 2^k x, cos 2^k x)
+            x = pts[:, :3]
+            d_x = d_enc[:, :3].clone()
+            e32 = enc.float()
+            for k in range(10):
+                f = float(2 ** k)
+                sin, cos = e32[:, 3 + 6 * k:6 + 6 * k], e32[:, 6 + 6 * k:9 + 6 * k]
+                d_x += f * (cos * d_enc[:, 3 + 6 * k:6 + 6 * k] - sin * d_enc[:, 6 + 6 * k:9 + 6 * k])
+            d_pts = torch.cat([d_x, torch.zeros_like(d_x[:, :1])], 1)
         out_grads = []
         for i, k in enumerate(PARAM_KEYS):
             need = ctx.needs_input_grad[3 + i]
             gk = grads.get(k) if need else None
             out_grads.append(None if gk is None else gk.to(params[i].dtype).reshape(params[i].shape))
-        return (None, None, None, *out_grads)
+        return (d_pts, None, None, *out_grads)
 
 
 class CompositeFunction(torch.autograd.Function):
@@ -118,6 +136,53 @@ class CompositeFunction(torch.autograd.Function):
         rgbs, z, rays, noise = ctx.saved_tensors
         R = z.shape[0]
         zero = lambda t, shape: torch.zeros(shape, device=z.device) if t is None else t.contiguous()
-        d = ops.composite_backward(rgbs, z, rays, ctx.white, zero(g_rgb, (R, 3)), zero(g_depth, (R, 1)).reshape(R),
-                                   zero(g_acc, (R, 1)).reshape(R), noise=noise if noise.numel() else None)
-        return d, None, None, None, None
+        want_geo = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]          # pose refinement: dL/dz, dL/dfar'
+        res = ops.composite_backward(rgbs, z, rays, ctx.white, zero(g_rgb, (R, 3)), zero(g_depth, (R, 1)).reshape(R),
+                                     zero(g_acc, (R, 1)).reshape(R), noise=noise if noise.numel() else None,
+                                     want_dz=want_geo)
+        if not want_geo:
+            return res, None, None, None, None
+        d, dz, dfar = res
+        d_rays = torch.zeros_like(rays)
+        d_rays[:, 7] = dfar
+        return d, dz, d_rays, None, None
+
+
+class WarpFunction(torch.autograd.Function):
+    """pts[bs, R*K, 4] = warp(x = o' + z d') (models/anim_nerf.py:153-192); differentiable w.r.t. the rays in the body
+    frame, the depths and the per-vertex observation->canonical transforms.  Neighbour ids and blend weights are
+    constants of the backward pass (KNN is `no_grad` in the reference)."""
+
+    @staticmethod
+    def forward(ctx, rays, z, o2c, index, lbs_w, thr, skip_far):
+        pts, nidx, nw = ops.warp_points(index, o2c.detach(), lbs_w, thr, rays=rays.detach(), z=z.detach(),
+                                        skip_far=skip_far, neighbours=True)
+        ctx.save_for_backward(rays, z, o2c, nidx, nw)
+        return pts
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, d_pts):
+        rays, z, o2c, nidx, nw = ctx.saved_tensors
+        bs, R, K = z.shape
+        V = o2c.shape[1]
+        N = R * K
+        dxc = d_pts[..., :3]                                                        # [bs,N,3]
+        o, d = rays[..., None, 0:3], rays[..., None, 3:6]
+        xyz = (o + z[..., None] * d).reshape(bs, N, 3)
+        gidx = (nidx.long() + (torch.arange(bs, device=z.device) * V)[:, None, None]).reshape(-1)
+        M = o2c.reshape(bs * V, 16)[gidx].view(bs, N, 4, 16)
+        Tb = (nw[..., None] * M).sum(2)                                             # blended 4x4, row-major
+        Rb = Tb[..., :12].view(bs, N, 3, 4)[..., :3]
+        d_xyz = (Rb.transpose(-1, -2) @ dxc[..., None])[..., 0]
+        # dL/dT_blend[r][c] = dxc[r] * [xyz,1][c]  ->  scatter w_k * that into the neighbours' transforms
+        xyz_h = torch.cat([xyz, torch.ones_like(xyz[..., :1])], -1)
+        dT = (dxc[..., :, None] * xyz_h[..., None, :]).reshape(bs, N, 1, 12)
+        d_o2c = torch.zeros(bs * V, 16, device=z.device)
+        d_o2c[:, :12].index_add_(0, gidx, (nw[..., None] * dT).reshape(-1, 12))
+        d_xyz = d_xyz.view(bs, R, K, 3)
+        d_rays = torch.zeros_like(rays)
+        d_rays[..., 0:3] = d_xyz.sum(2)
+        d_rays[..., 3:6] = (d_xyz * z[..., None]).sum(2)
+        d_z = (d_xyz * d).sum(-1)
+        return d_rays, d_z, d_o2c.view(bs, V, 4, 4), None, None, None, None

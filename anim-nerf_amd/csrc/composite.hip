@@ -109,7 +109,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_backward_ker
     const float4* __restrict__ rgbs, const float* __restrict__ z, const float* __restrict__ rays, int stride,
     const float* __restrict__ noise, int64_t R, int K, int white_bkgd, const float* __restrict__ g_w,
     const float* __restrict__ g_rgb, const float* __restrict__ g_depth, const float* __restrict__ g_acc,
-    float4* __restrict__ d_rgbs) {
+    float4* __restrict__ d_rgbs, float* __restrict__ d_z, float* __restrict__ d_far) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -153,23 +153,46 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_backward_ker
         }
     }
     float after = wave_suffix_incl_sum(gw_local, lane) - gw_local;       // lanes > this lane
+    float ddelta[S];                                                      // dL/d(delta_k)
+    float wsum = 0.f;
 #pragma unroll
     for (int s = S - 1; s >= 0; --s) {
         int k = lane * S + s;
+        ddelta[s] = 0.f;
         if (k < K) {
             const float t = 1.0f - alpha[s] + 1e-10f;
             const float dalpha = G[s] * tr[s] - after / t;
-            const float dsig = (sg[s] > 0.0f) ? dalpha * delta[s] * expf(-delta[s] * sg[s]) : 0.0f;
+            const float e = expf(-delta[s] * fmaxf(sg[s], 0.0f));
+            const float dsig = (sg[s] > 0.0f) ? dalpha * delta[s] * e : 0.0f;
             d_rgbs[r * K + k] = make_float4(w[s] * gr, w[s] * gg, w[s] * gb, dsig);
+            if (k + 1 < K) ddelta[s] = dalpha * fmaxf(sg[s], 0.0f) * e;   // the last delta is the constant 1e10
             after += G[s] * w[s];
+            wsum += w[s];
         }
+    }
+    if (d_z != nullptr) {
+        // z_k enters depth (g_depth w_k), delta_k (minus) and delta_{k-1} (plus)
+        const float prev_lane = __shfl_up(ddelta[S - 1], 1, 64);          // ddelta of sample lane*S - 1
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            int k = lane * S + s;
+            if (k < K) {
+                const float before_d = (s > 0) ? ddelta[s - 1] : (lane > 0 ? prev_lane : 0.0f);
+                d_z[r * K + k] = gd * w[s] - ddelta[s] + before_d;
+            }
+        }
+    }
+    if (d_far != nullptr) {
+        wsum = wave_sum(wsum);
+        if (lane == 0) d_far[r] = white_bkgd ? gd * (1.0f - wsum) : 0.0f;
     }
 }
 
 // reference: models/volume_rendering.py:59-97 (sample_fine) and :199-207 (cat + sort)
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void sample_fine_merge_kernel(
     const float* __restrict__ z_coarse, const float* __restrict__ weights, const float* __restrict__ u,
-    int u_per_ray, int64_t R, int Kc, int Kf, float* __restrict__ z_fine_out, float* __restrict__ z_sorted_out) {
+    int u_per_ray, int64_t R, int Kc, int Kf, float* __restrict__ z_fine_out, float* __restrict__ z_sorted_out,
+    int32_t* __restrict__ perm_out) {
     __shared__ float lds[WAVES_PER_BLOCK][3 * ANR_MAX_SAMPLES];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -241,7 +264,10 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void sample_fine_merge_kern
             float y = zall[q];
             rank += (y < x || (y == x && q < p)) ? 1 : 0;
         }
-        if (active) z_sorted_out[r * K + rank] = x;
+        if (active) {
+            z_sorted_out[r * K + rank] = x;
+            if (perm_out != nullptr) perm_out[r * K + rank] = p;      // z_sorted[rank] = cat(z_coarse, z_fine)[p]
+        }
     }
 }
 
@@ -276,7 +302,7 @@ extern "C" int anr_composite(const float* rgbs, const float* z, const float* ray
 extern "C" int anr_composite_backward(const float* rgbs, const float* z, const float* rays, int stride,
                                       const float* noise, int64_t R, int K, int white_bkgd, const float* g_weights,
                                       const float* g_rgb, const float* g_depth, const float* g_acc, float* d_rgbs,
-                                      void* stream) {
+                                      float* d_z, float* d_far, void* stream) {
     ANR_REQUIRE(rgbs && z && rays && g_rgb && g_depth && g_acc && d_rgbs, ANR_E_BADARG, "anr_composite_backward: null pointer");
     ANR_REQUIRE(R > 0 && K > 0 && stride >= 8, ANR_E_BADARG, "anr_composite_backward: R=%lld K=%d stride=%d", (long long)R, K, stride);
     ANR_REQUIRE(K <= ANR_MAX_SAMPLES, ANR_E_SHAPE, "anr_composite_backward: K=%d > %d", K, ANR_MAX_SAMPLES);
@@ -287,7 +313,7 @@ extern "C" int anr_composite_backward(const float* rgbs, const float* z, const f
     hipStream_t st = (hipStream_t)stream;
 #define ANR_LAUNCH_CB(SS)                                                                                      \
     hipLaunchKernelGGL(composite_backward_kernel<SS>, grid, block, 0, st, c, z, rays, stride, noise, R, K, white_bkgd, \
-                       g_weights, g_rgb, g_depth, g_acc, d)
+                       g_weights, g_rgb, g_depth, g_acc, d, d_z, d_far)
     switch ((K + 63) / 64) {
         case 1: ANR_LAUNCH_CB(1); break;
         case 2: ANR_LAUNCH_CB(2); break;
@@ -300,12 +326,12 @@ extern "C" int anr_composite_backward(const float* rgbs, const float* z, const f
 
 extern "C" int anr_sample_fine_merge(const float* z_coarse, const float* weights, const float* u, int u_per_ray,
                                      int64_t R, int Kc, int Kf, float* z_fine_out, float* z_sorted_out,
-                                     void* stream) {
+                                     int32_t* perm_out, void* stream) {
     ANR_REQUIRE(z_coarse && weights && u && z_sorted_out, ANR_E_BADARG, "anr_sample_fine_merge: null pointer");
     ANR_REQUIRE(R > 0 && Kc >= 3 && Kf > 0, ANR_E_BADARG, "anr_sample_fine_merge: R=%lld Kc=%d Kf=%d", (long long)R, Kc, Kf);
     ANR_REQUIRE(Kc + Kf <= ANR_MAX_SAMPLES, ANR_E_SHAPE, "anr_sample_fine_merge: Kc+Kf=%d > %d", Kc + Kf, ANR_MAX_SAMPLES);
     dim3 grid((unsigned)((R + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), block(WAVE * WAVES_PER_BLOCK);
     hipLaunchKernelGGL(sample_fine_merge_kernel, grid, block, 0, (hipStream_t)stream, z_coarse, weights, u,
-                       u_per_ray, R, Kc, Kf, z_fine_out, z_sorted_out);
+                       u_per_ray, R, Kc, Kf, z_fine_out, z_sorted_out, perm_out);
     return check_launch("anr_sample_fine_merge");
 }

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_points_kernel(
     const float* __restrict__ z, int K, const float* __restrict__ index, IndexDims d,
     const float* __restrict__ ober2cano, const float* __restrict__ lbs_w, int J, int64_t N, float thr, int skip_far,
     float4* __restrict__ pts_out, float* __restrict__ dist_out, int32_t* __restrict__ idx_out,
-    float* __restrict__ blended_out) {
+    float* __restrict__ blended_out, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int next_item;
     const int b = blockIdx.y;
@@ -263,7 +263,13 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_points_kernel(
             int64_t n; float px, py, pz;
             const bool active = fetch(item, n, px, py, pz);
             const bool far = box_d2(gbox, px, py, pz) >= thr * thr;
-            if (active && far) pts_out[(int64_t)b * N + n] = make_float4(px, py, pz, 0.0f);
+            if (active && far) {
+                pts_out[(int64_t)b * N + n] = make_float4(px, py, pz, 0.0f);
+                if (nbr_w != nullptr) {
+                    reinterpret_cast<float4*>(nbr_w)[(int64_t)b * N + n] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    reinterpret_cast<int4*>(nbr_idx)[(int64_t)b * N + n] = make_int4(0, 0, 0, 0);
+                }
+            }
             any_near |= active && !far;
         }
         if (!__syncthreads_or(any_near)) return;
@@ -295,7 +301,13 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_points_kernel(
         search(lds, d, px, py, pz, go, best);
         if (skip_far) {
             const bool none = go && best.i[0] < 0;
-            if (none) pts_out[o] = make_float4(px, py, pz, 0.0f);
+            if (none) {
+                pts_out[o] = make_float4(px, py, pz, 0.0f);
+                if (nbr_w != nullptr) {
+                    reinterpret_cast<float4*>(nbr_w)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(0, 0, 0, 0);
+                }
+            }
             const bool partial = go && best.i[0] >= 0 && best.i[3] < 0;
             if (__any(partial)) {
                 Best4 full;
@@ -362,6 +374,10 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_points_kernel(
         float cy = T[4] * px + T[5] * py + T[6] * pz + T[7];
         float cz = T[8] * px + T[9] * py + T[10] * pz + T[11];
         pts_out[o] = make_float4(cx, cy, cz, db < thr ? 1.0f : 0.0f);
+        if (nbr_w != nullptr) {                  // what the backward pass needs: blend weights and vertex ids
+            reinterpret_cast<float4*>(nbr_w)[o] = make_float4(w[0], w[1], w[2], w[3]);
+            reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(vid[0], vid[1], vid[2], vid[3]);
+        }
         if (dist_out != nullptr) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { dist_out[o * 4 + k] = dist[k]; idx_out[o * 4 + k] = vid[k]; }
@@ -429,7 +445,8 @@ extern "C" int anr_knn_index_build(const float* verts, const int32_t* order, int
 extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* rays, int ray_stride, const float* z,
                                int K, const void* knn_index, const float* ober2cano, const float* lbs_weights, int bs,
                                int V, int J, int64_t N, float dis_threshold, int skip_far, float* pts_out,
-                               float* dist_out, int32_t* idx_out, float* blended_out, void* stream) {
+                               float* dist_out, int32_t* idx_out, float* blended_out, int32_t* nbr_idx_out,
+                               float* nbr_w_out, void* stream) {
     ANR_REQUIRE(knn_index && ober2cano && lbs_weights && pts_out, ANR_E_BADARG, "anr_warp_points: null pointer");
     ANR_REQUIRE((xyz != nullptr) || (rays != nullptr && z != nullptr), ANR_E_BADARG,
                 "anr_warp_points: need xyz or (rays, z)");
@@ -439,6 +456,10 @@ extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* ra
                 "anr_warp_points: bad stride/K");
     ANR_REQUIRE((dist_out == nullptr) == (idx_out == nullptr) && (dist_out == nullptr) == (blended_out == nullptr),
                 ANR_E_BADARG, "anr_warp_points: debug outputs are all-or-none");
+    ANR_REQUIRE((nbr_idx_out == nullptr) == (nbr_w_out == nullptr), ANR_E_BADARG,
+                "anr_warp_points: nbr_idx_out and nbr_w_out go together");
+    ANR_REQUIRE((((uintptr_t)nbr_idx_out | (uintptr_t)nbr_w_out) & 15) == 0, ANR_E_ALIGN,
+                "anr_warp_points: neighbour outputs must be 16-B aligned");
     ANR_REQUIRE((((uintptr_t)pts_out | (uintptr_t)ober2cano | (uintptr_t)knn_index) & 15) == 0, ANR_E_ALIGN,
                 "anr_warp_points: pts_out / ober2cano / knn_index must be 16-B aligned");
     IndexDims d = index_dims(V);
@@ -452,13 +473,13 @@ extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* ra
         dim3 grid((unsigned)((R + RAYS_PER_WG - 1) / RAYS_PER_WG), bs);
         hipLaunchKernelGGL(warp_points_kernel<true>, grid, dim3(WARP_THREADS), bytes, st, xyz, xyz_stride, rays,
                            ray_stride, z, K, index, d, ober2cano, lbs_weights, J, N, dis_threshold, skip_far,
-                           reinterpret_cast<float4*>(pts_out), dist_out, idx_out, blended_out);
+                           reinterpret_cast<float4*>(pts_out), dist_out, idx_out, blended_out, nbr_idx_out, nbr_w_out);
     } else {
         if (int rc = allow_big_lds(warp_points_kernel<false>, bytes, "anr_warp_points")) return rc;
         dim3 grid((unsigned)((N + PTS_PER_WG - 1) / PTS_PER_WG), bs);
         hipLaunchKernelGGL(warp_points_kernel<false>, grid, dim3(WARP_THREADS), bytes, st, xyz, xyz_stride, rays,
                            ray_stride, z, K, index, d, ober2cano, lbs_weights, J, N, dis_threshold, skip_far,
-                           reinterpret_cast<float4*>(pts_out), dist_out, idx_out, blended_out);
+                           reinterpret_cast<float4*>(pts_out), dist_out, idx_out, blended_out, nbr_idx_out, nbr_w_out);
     }
     return check_launch("anr_warp_points");
 }

@@ -89,12 +89,12 @@ class NeRF(nn.Module):
 
     def eval_points(self, pts: torch.Tensor, mode: Optional[str] = None, sigma_only: bool = False) -> torch.Tensor:
         """pts[n,4] = (x,y,z,valid) -> [n,4] = (r,g,b,sigma), or sigma[n] (trunk + sigma row only).  The fused kernel entry."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and (pts.requires_grad or any(p.requires_grad for p in self.parameters())):
             from .autograd import PARAM_KEYS, MLPFunction              # training: keep activations, differentiable
             if not self._hip_supported():
                 raise NotImplementedError("HIP MLP covers the shipped configuration only")
             named = dict(self.named_parameters())
-            return MLPFunction.apply(pts.detach(), sigma_only, ops.MLP_MODES[mode or self.mlp_mode] & 0xff,
+            return MLPFunction.apply(pts, sigma_only, ops.MLP_MODES[mode or self.mlp_mode] & 0xff,
                                      *[named[k] for k in PARAM_KEYS])
         pack, mode_id = self.weight_pack(mode)
         return ops.mlp_forward(pack, mode_id, pts, sigma_only=sigma_only)

@@ -167,7 +167,7 @@ def sample_coarse(rays: torch.Tensor, steps: torch.Tensor, t_rand: Optional[torc
 
 
 def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays=None, z=None, debug=False,
-                skip_far=False):
+                skip_far=False, neighbours=False):
     """models/anim_nerf.py:153-192.  Either xyz[bs,N,3|4] or (rays[bs,R,>=8], z[bs,R,K]).
     `index` = knn_index_build(posed verts).  Returns pts[bs,N,4] = (x_c, y_c, z_c, valid)
     (+ dist[bs,N,4], idx[bs,N,4] i32, blended[bs,N] if debug)."""
@@ -194,11 +194,18 @@ def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
         dist = torch.empty(bs, N, 4, dtype=torch.float32, device=dev)
         idx = torch.empty(bs, N, 4, dtype=torch.int32, device=dev)
         blended = torch.empty(bs, N, dtype=torch.float32, device=dev)
+    nidx = nw = None
+    if neighbours:                       # training: vertex ids + blend weights of the 4 neighbours (zeros where skipped)
+        nidx = torch.empty(bs, N, 4, dtype=torch.int32, device=dev)
+        nw = torch.empty(bs, N, 4, dtype=torch.float32, device=dev)
     with _timed("warp_points", bs * N):
         _lib.check(lib.anr_warp_points(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(index), _ptr(o2c),
                                        _ptr(lbs_weights), bs, V, J, N, float(dis_threshold), 1 if skip_far else 0,
-                                       _ptr(pts), _ptr(dist), _ptr(idx), _ptr(blended), _stream(pts)),
+                                       _ptr(pts), _ptr(dist), _ptr(idx), _ptr(blended), _ptr(nidx), _ptr(nw),
+                                       _stream(pts)),
                    "anr_warp_points")
+    if neighbours:
+        return pts, nidx, nw
     return (pts, dist, idx, blended) if debug else pts
 
 
@@ -289,8 +296,9 @@ def composite(rgbs, z, rays, white_bkgd: bool, noise=None, want_weights: bool = 
     return w, rgb, depth, acc
 
 
-def composite_backward(rgbs, z, rays, white_bkgd: bool, g_rgb, g_depth, g_acc, noise=None, g_weights=None):
-    """Backward of `composite`: -> d_rgbs[R,K,4]."""
+def composite_backward(rgbs, z, rays, white_bkgd: bool, g_rgb, g_depth, g_acc, noise=None, g_weights=None,
+                       want_dz: bool = False):
+    """Backward of `composite`: -> d_rgbs[R,K,4] (and d_z[R,K], d_far[R] if want_dz)."""
     lib = _lib.load()
     rgbs, z, rays = _dev(rgbs, "rgbs"), _dev(z, "z"), _dev(rays, "rays")
     g_rgb, g_depth, g_acc = _dev(g_rgb, "g_rgb"), _dev(g_depth, "g_depth"), _dev(g_acc, "g_acc")
@@ -300,11 +308,14 @@ def composite_backward(rgbs, z, rays, white_bkgd: bool, g_rgb, g_depth, g_acc, n
     if g_weights is not None:
         g_weights = _dev(g_weights, "g_weights")
     d = torch.empty(R, K, 4, dtype=torch.float32, device=z.device)
+    dz = torch.empty(R, K, dtype=torch.float32, device=z.device) if want_dz else None
+    dfar = torch.empty(R, dtype=torch.float32, device=z.device) if want_dz else None
     with _timed("composite_backward", R * K):
         _lib.check(lib.anr_composite_backward(_ptr(rgbs), _ptr(z), _ptr(rays), rays.shape[-1], _ptr(noise), R, K,
                                               1 if white_bkgd else 0, _ptr(g_weights), _ptr(g_rgb), _ptr(g_depth),
-                                              _ptr(g_acc), _ptr(d), _stream(d)), "anr_composite_backward")
-    return d
+                                              _ptr(g_acc), _ptr(d), _ptr(dz), _ptr(dfar), _stream(d)),
+                   "anr_composite_backward")
+    return (d, dz, dfar) if want_dz else d
 
 
 def mlp_forward_save(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bool = False):
@@ -326,7 +337,7 @@ def mlp_forward_save(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_onl
     return out, act
 
 
-def sample_fine_merge(z_coarse, weights, u, want_fine: bool = False):
+def sample_fine_merge(z_coarse, weights, u, want_fine: bool = False, want_perm: bool = False):
     """models/volume_rendering.py:59-97,199-207.  z_coarse[R,Kc], weights[R,Kc], u[Kf] or u[R,Kf]."""
     lib = _lib.load()
     z_coarse, weights, u = _dev(z_coarse, "z_coarse"), _dev(weights, "weights"), _dev(u, "u")
@@ -336,7 +347,10 @@ def sample_fine_merge(z_coarse, weights, u, want_fine: bool = False):
     dev = z_coarse.device
     zf = torch.empty(R, Kf, dtype=torch.float32, device=dev) if want_fine else None
     zs = torch.empty(R, Kc + Kf, dtype=torch.float32, device=dev)
+    perm = torch.empty(R, Kc + Kf, dtype=torch.int32, device=dev) if want_perm else None
     with _timed("sample_fine_merge", R * (Kc + Kf)):
         _lib.check(lib.anr_sample_fine_merge(_ptr(z_coarse), _ptr(weights), _ptr(u), per_ray, R, Kc, Kf, _ptr(zf),
-                                             _ptr(zs), _stream(zs)), "anr_sample_fine_merge")
+                                             _ptr(zs), _ptr(perm), _stream(zs)), "anr_sample_fine_merge")
+    if want_perm:
+        return (zs, zf, perm) if want_fine else (zs, perm)
     return (zs, zf) if want_fine else zs

@@ -5,8 +5,11 @@ losses (train.py:228-286), Adam + the polynomial schedule (utils/__init__.py:33-
 reduction that replaces Lightning's `strategy='dp'` (config.py:77): one process per GPU, one all-reduce of the
 flattened gradient per step (RCCL over xGMI; 2 x 592,388 fp32 = 4.7 MB).
 
-What is not: the normals regulariser (train.py:288-309, second-order autograd through `NeRF.get_normal`) and
-gradients into the SMPL parameters (`optim_body_params`).  Both raise if requested.
+Pose refinement (`optim_body_params`, train.py:141-144,221-222): pass a `BodyModelParams` table; its rows are looked
+up per frame, gradients reach them through the differentiable warp (autograd.WarpFunction) and per-frame chain, and
+they join the optimiser at half the learning rate and the same gradient all-reduce.
+
+What is not: the normals regulariser (train.py:288-309, second-order autograd through `NeRF.get_normal`); it raises.
 """
 from __future__ import annotations
 
@@ -35,6 +38,38 @@ class TrainHParams:
     lambda_normals: float = 0.0          # reference default 0.01; needs second-order autograd (not built)
     max_epochs: int = 30
     poly_exp: float = 0.9
+
+
+class BodyModelParams(nn.Module):
+    """Per-frame learnable SMPL parameters as embedding tables (models/body_model_params.py:5-68, model_type 'smpl'):
+    betas shared by all frames (1 x 10), global_orient / transl / body_pose one row per frame.  Same parameter
+    names as the reference, so its checkpoints load."""
+    DIMS = {"betas": 10, "global_orient": 3, "transl": 3, "body_pose": 69}
+
+    def __init__(self, num_frames, model_type="smpl"):
+        super().__init__()
+        if model_type != "smpl":
+            raise NotImplementedError("only model_type 'smpl' is used by the shipped configs")
+        self.num_frames, self.model_type = num_frames, model_type
+        self.param_names = list(self.DIMS)
+        for name, dim in self.DIMS.items():
+            emb = nn.Embedding(1 if name == "betas" else num_frames, dim)
+            emb.weight.data.zero_()
+            emb.weight.requires_grad = False
+            setattr(self, name, emb)
+
+    def init_parameters(self, param_name, data, requires_grad=False):
+        if param_name == "betas":
+            data = torch.mean(data, dim=0, keepdim=True)
+        emb = getattr(self, param_name)
+        emb.weight.data = data[..., :self.DIMS[param_name]].to(emb.weight.device)
+        emb.weight.requires_grad = requires_grad
+
+    def set_requires_grad(self, param_name, requires_grad=True):
+        getattr(self, param_name).weight.requires_grad = requires_grad
+
+    def forward(self, frame_ids):
+        return {n: getattr(self, n)(torch.zeros_like(frame_ids) if n == "betas" else frame_ids) for n in self.param_names}
 
 
 def compute_loss(anim_nerf, hp: TrainHParams, rgbs, alphas, results, fg_points=None, bg_points=None):
@@ -84,19 +119,29 @@ def allreduce_gradients(params, world: Optional[int] = None):
 class Trainer:
     """optimizer + schedule + step; `step(batch)` mirrors AnimNeRFSystem.training_step (train.py:324-348)."""
 
-    def __init__(self, anim_nerf, volume_renderer, hp: TrainHParams):
+    def __init__(self, anim_nerf, volume_renderer, hp: TrainHParams, body_model_params: Optional[BodyModelParams] = None):
         self.model, self.renderer, self.hp = anim_nerf, volume_renderer, hp
+        self.body_model_params = body_model_params
         for name, p in anim_nerf.named_parameters():          # SMPL member params are unused by the forward
             if name.startswith("body_model."):
                 p.requires_grad_(False)
-        self.params = [p for p in anim_nerf.parameters() if p.requires_grad]
-        self.optimizer = torch.optim.Adam(self.params, lr=hp.lr, eps=1e-8, weight_decay=0)
+        groups = [{"params": [p for p in anim_nerf.parameters() if p.requires_grad], "lr": hp.lr}]
+        if body_model_params is not None:                     # train.py:221-222: half the learning rate
+            bp = [p for p in body_model_params.parameters() if p.requires_grad]
+            if bp:
+                groups.append({"params": bp, "lr": hp.lr * 0.5})
+        self.params = [p for g in groups for p in g["params"]]
+        self.optimizer = torch.optim.Adam(groups, eps=1e-8, weight_decay=0)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(
             self.optimizer, lambda epoch: (1 - epoch / hp.max_epochs) ** hp.poly_exp)
 
     def step(self, rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points=None, bg_points=None,
-             perturb=1.0):
+             perturb=1.0, frame_idx=None):
+        """`body_model_params` is the dict of the batch, or — with a BodyModelParams table and `frame_idx` — replaced
+        by the learnable rows of those frames (train.py:330-331)."""
         self.optimizer.zero_grad(set_to_none=True)
+        if self.body_model_params is not None and frame_idx is not None:
+            body_model_params = self.body_model_params(frame_idx)
         results = system_forward(self.renderer, self.model, rays, body_model_params, body_model_params_template,
                                  perturb=perturb, chunk=self.hp.chunk)
         loss, details = compute_loss(self.model, self.hp, rgbs, alphas, results, fg_points, bg_points)

@@ -44,6 +44,14 @@ class VolumeRenderer(nn.Module):
         t_rand = None
         if perturb > 0:
             t_rand = perturb * torch.rand(bs * R, self.n_coarse, device=rays.device)
+        if torch.is_grad_enabled() and rays.requires_grad:       # pose refinement: near'/far' depend on the root transform
+            s = self._table(rays.device, "steps", self.n_coarse)
+            z = rays[..., 6:7] * (1 - s) + rays[..., 7:8] * s
+            if t_rand is not None:
+                mids = .5 * (z[..., 1:] + z[..., :-1])
+                upper, lower = torch.cat([mids, z[..., -1:]], -1), torch.cat([z[..., :1], mids], -1)
+                z = lower + (upper - lower) * t_rand.view(bs, R, -1)
+            return z
         z = ops.sample_coarse(rays, self._table(rays.device, "steps", self.n_coarse), t_rand)
         return z.view(bs, R, self.n_coarse)
 
@@ -51,8 +59,7 @@ class VolumeRenderer(nn.Module):
         bs, R, K = z.shape
         fused = hasattr(model, "warped_points") and hasattr(model, "_net")
         if fused:
-            with torch.no_grad():
-                pts = model.warped_points(rays=rays, z=z, skip_far=True)
+            pts = model.warped_points(rays=rays, z=z, skip_far=True)
             out = model._net(not coarse).eval_points(pts)
         else:
             xyz = (rays[..., None, :3] + z[..., None] * rays[..., None, 3:6]).reshape(bs, -1, 3)
@@ -78,20 +85,25 @@ class VolumeRenderer(nn.Module):
             u = self._table(z_coarse.device, "u", self.n_fine)
         else:
             u = torch.rand(bs * R, self.n_fine, device=z_coarse.device)
-        zs = ops.sample_fine_merge(z_coarse.view(bs * R, Kc), weights, u)
+        if torch.is_grad_enabled() and z_coarse.requires_grad:
+            # torch.sort routes gradients of the sorted depths back to z_coarse (z_fine is detached, :200)
+            zs, zf, perm = ops.sample_fine_merge(z_coarse.detach().view(bs * R, Kc), weights, u, want_fine=True,
+                                                 want_perm=True)
+            both = torch.cat([z_coarse.view(bs * R, Kc), zf], -1)
+            return torch.gather(both, -1, perm.long()).view(bs, R, Kc + self.n_fine)
+        with torch.no_grad():
+            zs = ops.sample_fine_merge(z_coarse.detach().view(bs * R, Kc), weights, u)
         return zs.view(bs, R, Kc + self.n_fine)
 
     def forward(self, model, rays, perturb=0., **kwargs):
         """Differentiable w.r.t. the MLP weights when autograd is enabled (sampling itself carries no gradient,
         as in the reference: z_fine is detached, models/volume_rendering.py:200)."""
-        rays = (rays if rays.is_contiguous() else rays.contiguous()).detach()
-        with torch.no_grad():
-            z_coarse = self.sample_coarse(rays, perturb=perturb)
+        rays = rays if rays.is_contiguous() else rays.contiguous()
+        z_coarse = self.sample_coarse(rays, perturb=perturb)
         w, rgbs, depths, alphas = self._shade(model, rays, z_coarse, True, perturb, self.n_fine > 0, **kwargs)
         output = {"rgbs": rgbs, "alphas": alphas, "depths": depths}
         if self.n_fine > 0:
-            with torch.no_grad():
-                z_all = self.sample_fine_sorted(z_coarse, w.detach(), perturb)
+            z_all = self.sample_fine_sorted(z_coarse, w.detach(), perturb)
             _, rgbs_f, depths_f, alphas_f = self._shade(model, rays, z_all, False, perturb, False, **kwargs)
             if self.share_fine:
                 output = {"rgbs": rgbs_f, "alphas": alphas_f, "depths": depths_f}

@@ -194,11 +194,16 @@ def train_bench(args, rank, local_rank, world, dev):
     model = ana.AnimNeRF(body_model_table=tbl, freqs_dir=0, use_view=False, use_unpose=True, use_knn=True,
                          use_fine=True, mlp_mode=args.mode).to(dev)
     hp = ana.TrainHParams(n_samples=64, n_importance=32, chunk=2048)
-    trainer = ana.Trainer(model, ana.VolumeRenderer(n_coarse=64, n_fine=32), hp)
     F = args.frames_per_gpu
+    table = ana.BodyModelParams(114).to(dev)                  # 114 training frames (configs/people_snapshot/male-3-casual.yaml)
+    seeded = syn.animated_pose_params(seed=200 + rank, bs=114)
+    for name in table.param_names:                            # optim_body_params: True
+        table.init_parameters(name, torch.from_numpy(seeded[name]).to(dev), requires_grad=True)
+    trainer = ana.Trainer(model, ana.VolumeRenderer(n_coarse=64, n_fine=32), hp, body_model_params=table)
+    frame_idx = torch.arange(F, device=dev) * (114 // F)
     c2w, focal, cen = syn.pinhole_camera(32, 32)
     rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), 32, 32, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(F, 1, 1, 1)
-    pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=200 + rank, bs=F).items()}
+    pose = None                                               # looked up from the table each step
     templ = {k: torch.from_numpy(v).to(dev) for k, v in syn.template_pose_params().items()}
     g = torch.Generator().manual_seed(rank)
     rgbs = torch.rand(F, 32, 32, 3, generator=g).to(dev)
@@ -207,7 +212,7 @@ def train_bench(args, rank, local_rank, world, dev):
     bg = (torch.rand(F, 128, 3, generator=g) * 2 - 1).to(dev)
 
     def step():
-        return trainer.step(rays, rgbs, alphas, pose, templ, fg, bg, perturb=1.0)
+        return trainer.step(rays, rgbs, alphas, pose, templ, fg, bg, perturb=1.0, frame_idx=frame_idx)
 
     def barrier():
         if world > 1:
@@ -235,7 +240,7 @@ def train_bench(args, rank, local_rank, world, dev):
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.mode, "data": "synthetic",
         "config": {"workload": "BASELINE configs[3] shape: train step, %d frames x 32x32 rays per GPU, 64 coarse + 32 fine, "
-                               "perturb=1, rgb+alpha+fg/bg losses (no normals term, no pose refinement), "
+                               "perturb=1, rgb+alpha+fg/bg losses (no normals term), pose refinement on (optim_body_params), "
                                "flat-gradient all-reduce (4.7 MB) + Adam" % F,
                    "rays_per_step_per_gpu": n_rays, "grad_floats": sum(p.numel() for p in trainer.params)},
         "roofline": {"kernel": f"mlp_kernel<{args.mode}, save> (training forward)", "bound": "mfma", "achieved": achieved,

@@ -110,13 +110,16 @@ int anr_sample_coarse(const float* rays, int stride, const float* steps, const f
  *   invalid: sigma = -1e5, zero compositing weight) get (x, y, z, 0) without a search.  Rendered outputs are
  *   unchanged; per-point rgb of such points differs from the reference's, so the point-query API passes 0.
  * Optional debug outputs (may be NULL; need skip_far = 0): dist_out[bs*N*4], idx_out[bs*N*4] (int32),
- *   blended_out[bs*N]. */
+ *   blended_out[bs*N].
+ * Optional training outputs (both or neither): nbr_idx_out[bs*N*4] (int32 vertex ids) and nbr_w_out[bs*N*4]
+ *   (normalised blend weights, anim_nerf.py:169-171; zeros for samples skipped by skip_far) — what the backward
+ *   pass needs to route dL/dx_c into ober2cano and into the sample position. */
 int anr_warp_points(const float* xyz, int xyz_stride,
                     const float* rays, int ray_stride, const float* z, int K,
                     const void* knn_index, const float* ober2cano, const float* lbs_weights,
                     int bs, int V, int J, int64_t N, float dis_threshold, int skip_far,
                     float* pts_out, float* dist_out, int32_t* idx_out, float* blended_out,
-                    void* stream);
+                    int32_t* nbr_idx_out, float* nbr_w_out, void* stream);
 
 /* Same output layout without the warp (use_unpose=False, models/anim_nerf.py:296-297):
  * pts_out = (x, y, z, 1). */
@@ -174,19 +177,23 @@ int anr_composite(const float* rgbs, const float* z, const float* rays, int stri
 /* ---- a16 (part): backward of anr_composite -------------------------------------------------------------
  * What autograd differentiates in models/volume_rendering.py:131-160: upstream gradients of the per-ray outputs
  * g_rgb[R*3], g_depth[R], g_acc[R] (and optionally of the weights, g_weights[R*K] or NULL) ->
- * d_rgbs[R*K*4] = dL/d(r, g, b, sigma) per sample.  Same inputs as the forward (nothing is kept by the library). */
+ * d_rgbs[R*K*4] = dL/d(r, g, b, sigma) per sample; optionally also dL/dz (through the interval lengths and the
+ * depth output) and dL/dfar' (white-background depth term), which pose refinement needs.
+ * Same inputs as the forward (nothing is kept by the library). */
 int anr_composite_backward(const float* rgbs, const float* z, const float* rays, int stride, const float* noise,
                            int64_t R, int K, int white_bkgd, const float* g_weights, const float* g_rgb,
-                           const float* g_depth, const float* g_acc, float* d_rgbs, void* stream);
+                           const float* g_depth, const float* g_acc, float* d_rgbs,
+                           float* d_z /* [R*K] or NULL */, float* d_far /* [R] or NULL */, void* stream);
 
 /* ---- a14: importance sampling + merge ---------------------------------------------------------------
  * models/volume_rendering.py:59-97 and :199-207: inverse-CDF samples over the Kc-1 mid-points
  * with weights[1:-1]+1e-5, then sort(cat(z_coarse, z_fine)).
  * u[Kf] if u_per_ray == 0 (deterministic linspace, shared), else u[R*Kf] (caller's uniforms).
- * z_fine_out[R*Kf] (may be NULL), z_sorted_out[R*(Kc+Kf)]. */
+ * z_fine_out[R*Kf] (may be NULL), z_sorted_out[R*(Kc+Kf)], perm_out[R*(Kc+Kf)] (may be NULL):
+ * z_sorted[s] = cat(z_coarse, z_fine)[perm[s]] — autograd routes gradients of sorted depths back to z_coarse. */
 int anr_sample_fine_merge(const float* z_coarse, const float* weights, const float* u,
                           int u_per_ray, int64_t R, int Kc, int Kf,
-                          float* z_fine_out, float* z_sorted_out, void* stream);
+                          float* z_fine_out, float* z_sorted_out, int32_t* perm_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -228,8 +228,10 @@ def blend_neighbours(dist: Tensor, idx: Tensor, lbs_weights: Tensor, per_vertex_
 def warp_to_canonical(xyz: Tensor, verts: Tensor, lbs_weights: Tensor, ober2cano: Tensor,
                       dis_threshold: float, k: int = 4, chunk: int = 4096):
     """models/anim_nerf.py:180-192 (unpose).  Returns xyz_c[bs,N,3],
-    valid[bs,N,1] (float 0/1), and (dist, idx, blended_dist) for inspection."""
-    dist, idx = knn_bruteforce(verts, xyz, k, chunk)
+    valid[bs,N,1] (float 0/1), and (dist, idx, blended_dist) for inspection.
+    The neighbour search carries no gradient, as on the KNN_CUDA branch every config selects (:157-159)."""
+    with torch.no_grad():
+        dist, idx = knn_bruteforce(verts, xyz, k, chunk)
     db, Tb, _ = blend_neighbours(dist, idx, lbs_weights, ober2cano)
     valid = (db < dis_threshold).float()
     return apply_affine(Tb, xyz, 1.0), valid, dict(dist=dist, idx=idx, blended=db)

@@ -156,3 +156,71 @@ def test_bf16_training_gradients_close_to_fp32(dev, smpl_table):
     cos = torch.nn.functional.cosine_similarity(grads["f32"], grads["bf16"], dim=0).item()
     assert cos > 0.999, cos
     assert (grads["bf16"] - grads["f32"]).norm() / grads["f32"].norm() < 0.05
+
+
+def test_pose_refinement_gradients_match_oracle(dev, smpl_table):
+    """optim_body_params (train.py:141-144): gradients of the rendering loss w.r.t. betas / global_orient / body_pose /
+    transl through warp, sampling, compositing and the per-frame chain, against autograd of the oracle."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    g = golden("render_cfg3_warp_gain")
+    m = seeded_model(smpl_table, g["seed"], True, g["gain"], g["shift"], device=dev)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    vr = ana.VolumeRenderer(n_coarse=16, n_fine=8)
+    pose_np = syn.animated_pose_params(seed=3, bs=2)
+    templ = {k: torch.from_numpy(v) for k, v in syn.template_pose_params().items()}
+    c2w, focal, cen = syn.pinhole_camera(8, 8)
+    rays = orc.make_rays(torch.from_numpy(c2w), 8, 8, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(2, 1, 1, 1)
+    gen = torch.Generator().manual_seed(4)
+    tgt_rgb, tgt_a = torch.rand(2, 8, 8, 3, generator=gen), (torch.rand(2, 8, 8, 1, generator=gen) > 0.5).float()
+    tgt_d = 3 + torch.rand(2, 8, 8, 1, generator=gen)
+    names = ("betas", "global_orient", "body_pose", "transl")
+
+    def loss_of(res, t_rgb, t_a, t_d):
+        F = torch.nn.functional
+        return (F.mse_loss(res["rgbs"], t_rgb) + F.mse_loss(res["rgbs_fine"], t_rgb) + 0.1 * F.l1_loss(res["alphas"], t_a)
+                + 0.1 * F.l1_loss(res["alphas_fine"], t_a) + 0.05 * F.mse_loss(res["depths_fine"], t_d))
+
+    # HIP path
+    pose_g = {k: torch.from_numpy(pose_np[k]).to(dev).requires_grad_(True) for k in names}
+    res = ana.system_forward(vr, m, rays.to(dev), pose_g, _templ(dev), perturb=0.0, chunk=40)
+    loss = loss_of(res, tgt_rgb.to(dev), tgt_a.to(dev), tgt_d.to(dev))
+    loss.backward()
+    # oracle
+    tbl = oracle_table(smpl_table)
+    pose_o = {k: torch.from_numpy(pose_np[k]).clone().requires_grad_(True) for k in names}
+    out = orc.render_frame(tbl, net_params(m.nerf), net_params(m.nerf_fine), rays.view(2, 64, 8), pose_o, templ,
+                           n_coarse=16, n_fine=8, use_unpose=True, chunk=40, knn_chunk=512)
+    ref = loss_of(out, tgt_rgb.view(2, 64, 3), tgt_a.view(2, 64, 1), tgt_d.view(2, 64, 1))
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 5e-4 * abs(ref.item())
+    for k in names:
+        a, b = pose_g[k].grad.cpu(), pose_o[k].grad
+        assert b.abs().max() > 0, k
+        rel = (a - b).norm() / b.norm()
+        assert rel < 0.05, (k, rel.item(), a.flatten()[:4], b.flatten()[:4])
+
+
+def test_trainer_updates_body_params_table(dev, smpl_table):
+    """Trainer + BodyModelParams (optim_body_params): the rows of the frames in the batch move, the others do not."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    g = golden("render_cfg3_warp_gain")
+    m = seeded_model(smpl_table, g["seed"], True, g["gain"], g["shift"], device=dev)
+    table = ana.BodyModelParams(6).to(dev)
+    seeded = syn.animated_pose_params(seed=3, bs=6)
+    for name in table.param_names:
+        table.init_parameters(name, torch.from_numpy(seeded[name]).to(dev), requires_grad=True)
+    before = {n: getattr(table, n).weight.detach().clone() for n in table.param_names}
+    tr = ana.Trainer(m, ana.VolumeRenderer(n_coarse=16, n_fine=8), ana.TrainHParams(n_samples=16, n_importance=8), table)
+    assert len(tr.optimizer.param_groups) == 2 and tr.optimizer.param_groups[1]["lr"] == 0.5 * tr.optimizer.param_groups[0]["lr"]
+    c2w, focal, cen = syn.pinhole_camera(8, 8)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), 8, 8, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(2, 1, 1, 1)
+    frame_idx = torch.tensor([1, 4], device=dev)
+    loss, details = tr.step(rays, torch.rand(2, 8, 8, 3, device=dev), torch.ones(2, 8, 8, 1, device=dev), None,
+                            _templ(dev), perturb=1.0, frame_idx=frame_idx)
+    assert torch.isfinite(loss)
+    moved = (table.body_pose.weight.detach() - before["body_pose"]).abs().sum(1) > 0
+    assert moved.tolist() == [False, True, False, False, True, False]
+    assert (table.betas.weight.detach() - before["betas"]).abs().sum() > 0
