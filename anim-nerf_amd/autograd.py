@@ -164,25 +164,9 @@ class WarpFunction(torch.autograd.Function):
     @torch.no_grad()
     def backward(ctx, d_pts):
         rays, z, o2c, nidx, nw = ctx.saved_tensors
-        bs, R, K = z.shape
-        V = o2c.shape[1]
-        N = R * K
-        dxc = d_pts[..., :3]                                                        # [bs,N,3]
-        o, d = rays[..., None, 0:3], rays[..., None, 3:6]
-        xyz = (o + z[..., None] * d).reshape(bs, N, 3)
-        gidx = (nidx.long() + (torch.arange(bs, device=z.device) * V)[:, None, None]).reshape(-1)
-        M = o2c.reshape(bs * V, 16)[gidx].view(bs, N, 4, 16)
-        Tb = (nw[..., None] * M).sum(2)                                             # blended 4x4, row-major
-        Rb = Tb[..., :12].view(bs, N, 3, 4)[..., :3]
-        d_xyz = (Rb.transpose(-1, -2) @ dxc[..., None])[..., 0]
-        # dL/dT_blend[r][c] = dxc[r] * [xyz,1][c]  ->  scatter w_k * that into the neighbours' transforms
-        xyz_h = torch.cat([xyz, torch.ones_like(xyz[..., :1])], -1)
-        dT = (dxc[..., :, None] * xyz_h[..., None, :]).reshape(bs, N, 1, 12)
-        d_o2c = torch.zeros(bs * V, 16, device=z.device)
-        d_o2c[:, :12].index_add_(0, gidx, (nw[..., None] * dT).reshape(-1, 12))
-        d_xyz = d_xyz.view(bs, R, K, 3)
-        d_rays = torch.zeros_like(rays)
-        d_rays[..., 0:3] = d_xyz.sum(2)
-        d_rays[..., 3:6] = (d_xyz * z[..., None]).sum(2)
-        d_z = (d_xyz * d).sum(-1)
-        return d_rays, d_z, d_o2c.view(bs, V, 4, 4), None, None, None, None
+        d_o2c, d_rays, d_z = ops.warp_backward(d_pts, rays, z, o2c, nidx, nw)
+        if rays.shape[-1] != 8:
+            pad = torch.zeros_like(rays)
+            pad[..., :8] = d_rays
+            d_rays = pad
+        return d_rays, d_z, d_o2c, None, None, None, None

@@ -414,6 +414,61 @@ __global__ __launch_bounds__(WARP_THREADS) void knn_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward of the warp w.r.t. its differentiable inputs (a16, pose refinement): x_c = T_b [x,1], T_b = sum_k w_k M_k,
+// x = o' + z d'.  The neighbour ids and weights are constants (KNN is no_grad in the reference, anim_nerf.py:158).
+//   dM_{v_k}[r][c] += w_k * dxc[r] * [x,1][c]   (atomics: many samples share a vertex)
+//   dx = R_b^T dxc  ->  d o' += dx, d d' += z dx (atomics per ray), dz = dx . d'
+__global__ __launch_bounds__(256) void warp_backward_kernel(
+    const float4* __restrict__ d_pts, const float* __restrict__ rays, int ray_stride, const float* __restrict__ z, int K,
+    const float* __restrict__ ober2cano, const int4* __restrict__ nbr_idx, const float4* __restrict__ nbr_w, int V,
+    int64_t N, float* __restrict__ d_o2c, float* __restrict__ d_rays, float* __restrict__ d_z) {
+    const int b = blockIdx.y;
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int64_t o = (int64_t)b * N + n;
+    const float4 g = d_pts[o];
+    const float4 w4 = nbr_w[o];
+    const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+    const bool live = (w[0] != 0.f || w[1] != 0.f || w[2] != 0.f || w[3] != 0.f) && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
+    float dzv = 0.f;
+    if (live) {
+        const int64_t R = N / K;
+        const int64_t ray = n / K;
+        const float* ry = rays + ((int64_t)b * R + ray) * ray_stride;
+        const float zz = z[o];
+        const float x[4] = {ry[0] + zz * ry[3], ry[1] + zz * ry[4], ry[2] + zz * ry[5], 1.0f};
+        const int4 i4 = nbr_idx[o];
+        const int vid[4] = {i4.x, i4.y, i4.z, i4.w};
+        const float gv[3] = {g.x, g.y, g.z};
+        float Rb[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (w[k] == 0.f) continue;
+            const float* M = ober2cano + ((int64_t)b * V + vid[k]) * 16;
+            float* dM = d_o2c + ((int64_t)b * V + vid[k]) * 16;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Rb[r * 3 + c] += w[k] * M[r * 4 + c];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) atomicAdd(dM + r * 4 + c, w[k] * gv[r] * x[c]);
+            }
+        }
+        float dx[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dx[c] = Rb[c] * gv[0] + Rb[3 + c] * gv[1] + Rb[6 + c] * gv[2];
+        float* dr = d_rays + ((int64_t)b * R + ray) * 8;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            atomicAdd(dr + c, dx[c]);
+            atomicAdd(dr + 3 + c, zz * dx[c]);
+        }
+        dzv = dx[0] * ry[3] + dx[1] * ry[4] + dx[2] * ry[5];
+    }
+    d_z[o] = dzv;
+}
+
 template <typename Kern>
 int allow_big_lds(Kern k, int bytes, const char* who) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -482,6 +537,23 @@ extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* ra
                            reinterpret_cast<float4*>(pts_out), dist_out, idx_out, blended_out, nbr_idx_out, nbr_w_out);
     }
     return check_launch("anr_warp_points");
+}
+
+extern "C" int anr_warp_backward(const float* d_pts, const float* rays, int ray_stride, const float* z, int K,
+                                 const float* ober2cano, const int32_t* nbr_idx, const float* nbr_w, int bs, int V,
+                                 int64_t N, float* d_ober2cano, float* d_rays, float* d_z, void* stream) {
+    ANR_REQUIRE(d_pts && rays && z && ober2cano && nbr_idx && nbr_w && d_ober2cano && d_rays && d_z, ANR_E_BADARG,
+                "anr_warp_backward: null pointer");
+    ANR_REQUIRE(bs > 0 && V > 0 && N > 0 && K > 0 && N % K == 0 && ray_stride >= 8, ANR_E_BADARG,
+                "anr_warp_backward: bs=%d V=%d N=%lld K=%d", bs, V, (long long)N, K);
+    ANR_REQUIRE((((uintptr_t)d_pts | (uintptr_t)nbr_idx | (uintptr_t)nbr_w) & 15) == 0, ANR_E_ALIGN,
+                "anr_warp_backward: d_pts / nbr_idx / nbr_w must be 16-B aligned");
+    dim3 grid((unsigned)((N + 255) / 256), bs);
+    hipLaunchKernelGGL(warp_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(d_pts), rays, ray_stride, z, K, ober2cano,
+                       reinterpret_cast<const int4*>(nbr_idx), reinterpret_cast<const float4*>(nbr_w), V, N,
+                       d_ober2cano, d_rays, d_z);
+    return check_launch("anr_warp_backward");
 }
 
 extern "C" int anr_knn(const void* knn_index, const float* xyz, int bs, int V, int64_t N, float* dist_out,

@@ -114,6 +114,24 @@ class NeRF(nn.Module):
             raise NotImplementedError("get_sigma(only_sigma=False): xyz_encoding_final is not exported by the fused kernel")
         return self.eval_points(self._pack_xyz(xyz), sigma_only=True).view(*xyz.shape[:-1], 1)
 
+    def _sigma_dense(self, xyz):
+        """sigma(xyz) as a chain of library GEMMs under torch autograd — ONLY for get_normal, whose loss needs the
+        gradient of a gradient (second order), which the fused kernel's hand-written backward does not provide."""
+        e = self.encoding_xyz(xyz)
+        h = e
+        for i in range(self.D):
+            if i in self.skips:
+                h = torch.cat([e, h], -1)
+            lin = getattr(self, f"xyz_encoding_{i+1}")[0]
+            h = torch.relu(torch.nn.functional.linear(h, lin.weight, lin.bias))
+        return self.sigma(h)
+
     def get_normal(self, xyz, deformation_code=None, delta=0.02):
-        raise NotImplementedError("get_normal (training-only normals regulariser, models/nerf.py:177-190) "
-                                  "is not part of the forward rendering path built so far")
+        """models/nerf.py:177-190: d alpha / d xyz with create_graph=True (the normals regulariser, train.py:288-309,
+        differentiates it again w.r.t. the weights).  441 k points per step on the template vertices: a small
+        side computation, kept on torch autograd (documented in DESIGN.md section 7)."""
+        with torch.set_grad_enabled(True):
+            xyz = xyz.detach().requires_grad_(True)
+            alpha = 1 - torch.exp(-delta * torch.relu(self._sigma_dense(xyz)))
+            return torch.autograd.grad(alpha, xyz, torch.ones_like(alpha), create_graph=True, retain_graph=True,
+                                       only_inputs=True)[0]

@@ -209,6 +209,23 @@ def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
     return (pts, dist, idx, blended) if debug else pts
 
 
+def warp_backward(d_pts, rays, z, o2c, nbr_idx, nbr_w):
+    """Backward of warp_points(rays=, z=): -> d_o2c[bs,V,4,4], d_rays[bs,R,8], d_z[bs,R,K]."""
+    lib = _lib.load()
+    d_pts, rays, z, o2c = _dev(d_pts, "d_pts"), _dev(rays, "rays"), _dev(z, "z"), _dev(o2c, "ober2cano")
+    nbr_idx, nbr_w = _dev(nbr_idx, "nbr_idx", torch.int32), _dev(nbr_w, "nbr_w")
+    bs, R, K = z.shape
+    V = o2c.shape[1]
+    d_o2c = torch.zeros_like(o2c)
+    d_rays = torch.zeros(bs, R, 8, dtype=torch.float32, device=z.device)
+    d_z = torch.empty_like(z)
+    with _timed("warp_backward", bs * R * K):
+        _lib.check(lib.anr_warp_backward(_ptr(d_pts), _ptr(rays), rays.shape[-1], _ptr(z), K, _ptr(o2c), _ptr(nbr_idx),
+                                         _ptr(nbr_w), bs, V, R * K, _ptr(d_o2c), _ptr(d_rays), _ptr(d_z), _stream(z)),
+                   "anr_warp_backward")
+    return d_o2c, d_rays, d_z
+
+
 def points_from_rays(rays: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     """x = o + z d, valid = 1 (use_unpose=False).  rays[..,R,>=8], z[..,R,K] -> pts[R*K,4]."""
     lib = _lib.load()

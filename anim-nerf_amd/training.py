@@ -9,7 +9,8 @@ Pose refinement (`optim_body_params`, train.py:141-144,221-222): pass a `BodyMod
 up per frame, gradients reach them through the differentiable warp (autograd.WarpFunction) and per-frame chain, and
 they join the optimiser at half the learning rate and the same gradient all-reduce.
 
-What is not: the normals regulariser (train.py:288-309, second-order autograd through `NeRF.get_normal`); it raises.
+The normals regulariser (train.py:288-309) differentiates d alpha/d xyz a second time; that small side computation
+(template vertices only) runs on torch autograd over library GEMMs (`NeRF.get_normal`), not on the fused kernels.
 """
 from __future__ import annotations
 
@@ -35,7 +36,9 @@ class TrainHParams:
     lambda_alphas: float = 0.1
     lambda_foreground: float = 0.01
     lambda_background: float = 0.01
-    lambda_normals: float = 0.0          # reference default 0.01; needs second-order autograd (not built)
+    lambda_normals: float = 0.01         # config.py:60; second-order term, evaluated with torch autograd (nerf.get_normal)
+    epsilon: float = 0.01                # config.py:63
+    dis_threshold: float = 0.2
     max_epochs: int = 30
     poly_exp: float = 0.9
 
@@ -74,8 +77,6 @@ class BodyModelParams(nn.Module):
 
 def compute_loss(anim_nerf, hp: TrainHParams, rgbs, alphas, results, fg_points=None, bg_points=None):
     """train.py:228-286 (rgb MSE, alpha L1, foreground / background sigma priors), coarse and fine."""
-    if hp.lambda_normals != 0:
-        raise NotImplementedError("normals regulariser (train.py:288-309) needs second-order autograd; set lambda_normals=0")
     details: Dict[str, torch.Tensor] = {}
     fine = hp.n_importance > 0 and not hp.share_fine
     loss = details.setdefault("loss_rgb", F.mse_loss(results["rgbs"], rgbs))
@@ -98,6 +99,17 @@ def compute_loss(anim_nerf, hp: TrainHParams, rgbs, alphas, results, fg_points=N
             s = anim_nerf.query_canonical_space(bg_points, use_fine=use_fine, only_sigma=True)
             details["loss_background" + tag] = torch.mean(1 - torch.exp(k * torch.relu(s)))
             loss = loss + hp.lambda_background * details["loss_background" + tag]
+    if hp.lambda_normals != 0:                                  # train.py:288-309
+        pts = anim_nerf.verts_template.detach()
+        pts = pts + torch.randn_like(pts) * hp.dis_threshold * 0.5
+        nbr = pts + torch.randn_like(pts) * hp.epsilon
+        for tag, use_fine in (("", False),) + ((("_fine", True),) if fine else ()):
+            n0 = anim_nerf.query_canonical_space(pts, use_fine=use_fine, only_normal=True)
+            n1 = anim_nerf.query_canonical_space(nbr, use_fine=use_fine, only_normal=True)
+            n0 = n0 / (torch.norm(n0, p=2, dim=-1, keepdim=True) + 1e-5)
+            n1 = n1 / (torch.norm(n1, p=2, dim=-1, keepdim=True) + 1e-5)
+            details["loss_normals" + tag] = F.mse_loss(n0, n1)
+            loss = loss + hp.lambda_normals * details["loss_normals" + tag]
     return loss, details
 
 

@@ -121,6 +121,13 @@ int anr_warp_points(const float* xyz, int xyz_stride,
                     float* pts_out, float* dist_out, int32_t* idx_out, float* blended_out,
                     int32_t* nbr_idx_out, float* nbr_w_out, void* stream);
 
+/* Backward of anr_warp_points (rays mode) for pose refinement (a16): d_pts[bs*N*4] (w component ignored) ->
+ * d_ober2cano[bs*V*16] and d_rays[bs*R*8] (ACCUMULATED with atomics: zero them first), d_z[bs*N] (written).
+ * nbr_idx / nbr_w are the training outputs of the forward. */
+int anr_warp_backward(const float* d_pts, const float* rays, int ray_stride, const float* z, int K,
+                      const float* ober2cano, const int32_t* nbr_idx, const float* nbr_w, int bs, int V, int64_t N,
+                      float* d_ober2cano, float* d_rays, float* d_z, void* stream);
+
 /* Same output layout without the warp (use_unpose=False, models/anim_nerf.py:296-297):
  * pts_out = (x, y, z, 1). */
 int anr_points_from_rays(const float* rays, int ray_stride, const float* z, int K,
