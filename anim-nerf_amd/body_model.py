@@ -5,9 +5,9 @@ smplx/body_models.py:44-387, smplx/lbs.py:152-404): same constructor meaning, sa
 buffer/parameter names (checkpoint compatible), same extra outputs
 (`joints_transform`, `vertices_transform`, `shape_offsets`, `pose_offsets`).
 
-It runs once or twice per frame on a 6890-vertex table (about 7 M MACs); it is expressed
-with torch device ops on whatever device the buffers live on.  The per-POINT work that
-consumes its outputs is in the HIP library.
+It runs once or twice per frame on a 6890-vertex table (about 7 M MACs).  On the GPU without autograd it is three
+HIP launches (`anr_smpl_forward`, csrc/smpl.hip); when gradients must reach the SMPL parameters (pose refinement) or
+on the CPU it is the tensor-op form below, which torch autograd differentiates.
 """
 from __future__ import annotations
 
@@ -147,6 +147,21 @@ class SMPL(nn.Module):
         if betas.shape[0] != B:
             betas = betas.expand(B, -1)
         pose = torch.cat([global_orient, body_pose], 1)
+
+        needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (betas, pose, transl))
+        if self.v_template.is_cuda and not needs_grad:
+            # per-frame fast path: three HIP launches (anr_smpl_forward) instead of ~100 framework kernels
+            from . import ops
+            tr = transl.expand(B, -1) if transl.shape[0] != B else transl
+            verts, Jp, A, T, shape_off, pose_off = ops.smpl_forward(
+                betas.detach(), pose.detach(), tr.detach(), self.v_template, self.shapedirs, self.posedirs,
+                self.J_regressor, self.parents, self.lbs_weights)
+            joints = self.vertex_joint_selector(verts, Jp)
+            return SMPLOutput(vertices=verts if return_verts else None, joints=joints, betas=betas,
+                              global_orient=global_orient, body_pose=body_pose,
+                              full_pose=pose if return_full_pose else None,
+                              joints_transform=A, vertices_transform=T,
+                              shape_offsets=shape_off, pose_offsets=pose_off)
 
         shape_off = torch.einsum("bl,vcl->bvc", betas, self.shapedirs)
         v_shaped = self.v_template + shape_off

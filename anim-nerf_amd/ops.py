@@ -75,6 +75,27 @@ def ray_gen(c2w: torch.Tensor, H: int, W: int, focal: torch.Tensor, near: float,
     return rays
 
 
+def smpl_forward(betas, pose, transl, v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights):
+    """SMPL forward / LBS (smplx/body_models.py:289-387, smplx/lbs.py:152-404) -> verts, joints[bs,J,3], A, T,
+    shape_offsets, pose_offsets.  No autograd: the training path with pose refinement uses the tensor-op form."""
+    lib = _lib.load()
+    betas, pose, transl = _dev(betas, "betas"), _dev(pose, "pose"), _dev(transl, "transl")
+    v_template, shapedirs, posedirs = _dev(v_template, "v_template"), _dev(shapedirs, "shapedirs"), _dev(posedirs, "posedirs")
+    J_regressor, lbs_weights = _dev(J_regressor, "J_regressor"), _dev(lbs_weights, "lbs_weights")
+    parents = _dev(parents, "parents", torch.int64)
+    bs, V, J, NB = pose.shape[0], v_template.shape[0], J_regressor.shape[0], betas.shape[1]
+    dev = pose.device
+    new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+    verts, joints, A, T = new(bs, V, 3), new(bs, J, 3), new(bs, J, 4, 4), new(bs, V, 4, 4)
+    so, po = new(bs, V, 3), new(bs, V, 3)
+    ws1, ws2, ws3 = new(bs, V, 3), new(bs, J, 3), new(bs, 9 * (J - 1))
+    _lib.check(lib.anr_smpl_forward(_ptr(betas), _ptr(pose), _ptr(transl), bs, NB, _ptr(v_template), _ptr(shapedirs),
+                                    _ptr(posedirs), _ptr(J_regressor), _ptr(parents), _ptr(lbs_weights), V, J,
+                                    _ptr(verts), _ptr(joints), _ptr(A), _ptr(T), _ptr(so), _ptr(po), _ptr(ws1), _ptr(ws2),
+                                    _ptr(ws3), _stream(verts)), "anr_smpl_forward")
+    return verts, joints, A, T, so, po
+
+
 def rays_to_body(g_inv: torch.Tensor, rays: torch.Tensor) -> torch.Tensor:
     """models/anim_nerf.py:128-137.  g_inv[bs,4,4], rays[bs,R,>=8] -> [bs,R,8]."""
     lib = _lib.load()

@@ -60,6 +60,20 @@ const char* anr_last_error(void);
 int anr_ray_gen(const float* c2w, const float* focal, const float* center,
                 int H, int W, float near, float far, float* rays_out, void* stream);
 
+/* ---- a2: SMPL forward / linear blend skinning ------------------------------------------------------
+ * smplx/body_models.py:289-387 + smplx/lbs.py:152-404 for model_type 'smpl'.
+ * betas[bs*NB], pose[bs*J*3] (global_orient then body_pose, axis-angle), transl[bs*3];
+ * tables as the reference registers them: v_template[V*3], shapedirs[V*3*NB], posedirs[9(J-1) * 3V] (row-major),
+ * J_regressor[J*V], parents[J] (int64, parents[0] = -1), lbs_weights[V*J].
+ * Outputs: verts[bs*V*3], joints[bs*J*3] (posed, + transl; the 21 extra vertex-joints are a gather the caller does),
+ * A[bs*J*16] and T[bs*V*16] (both with transl added to the translation column, body_models.py:373-374),
+ * shape_off[bs*V*3], pose_off[bs*V*3].  Workspaces: ws_v_shaped[bs*V*3], ws_joints_rest[bs*J*3], ws_feat[bs*9(J-1)]. */
+int anr_smpl_forward(const float* betas, const float* pose, const float* transl, int bs, int NB,
+                     const float* v_template, const float* shapedirs, const float* posedirs,
+                     const float* J_regressor, const int64_t* parents, const float* lbs_weights, int V, int J,
+                     float* verts, float* joints, float* A, float* T, float* shape_off, float* pose_off,
+                     float* ws_v_shaped, float* ws_joints_rest, float* ws_feat, void* stream);
+
 /* ---- a4: rays into the root-joint frame -----------------------------------------
  * models/anim_nerf.py:128-137: o' = Ginv [o,1], d' = Ginv [d,0],
  * near' = max(near, |o'|-1), far' = min(far, |o'|+1).

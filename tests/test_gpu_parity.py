@@ -372,3 +372,24 @@ def test_sigma_grid_matches_reference_loop(dev, smpl_table):
     assert fast.shape == ref.shape
     assert torch.equal(fast, ref), (fast - ref).abs().max()
     assert (fast > 0).any() and (fast == 0).float().mean() > 0.5                  # a body in mostly empty space
+
+
+# ----------------------------------------------------------------------------- a2: SMPL / LBS kernels
+def test_smpl_kernels_match_oracle(dev, smpl_table):
+    """anr_smpl_forward (3 launches) vs the oracle's restatement of smplx/lbs.py, bs = 3, all six outputs."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    bm = ana.SMPL(data_struct=smpl_table).to(dev)
+    pose = {k: torch.from_numpy(v) for k, v in syn.animated_pose_params(seed=9, bs=3, pose_std=0.4).items()}
+    with torch.no_grad():
+        o = bm(**{k: v.to(dev) for k, v in pose.items()})
+    ref = orc.smpl_forward(oracle_table(smpl_table), **pose)
+    for k in ("vertices", "joints", "joints_transform", "vertices_transform", "shape_offsets", "pose_offsets"):
+        assert o[k].shape == ref[k].shape, k
+        torch.testing.assert_close(o[k].cpu(), ref[k], rtol=1e-5, atol=3e-6, msg=lambda m: f"{k}: {m}")
+    # the autograd form (pose refinement) agrees with the kernels
+    g = {k: v.to(dev).requires_grad_(True) for k, v in pose.items()}
+    o2 = bm(**g)
+    assert o2["vertices"].requires_grad
+    torch.testing.assert_close(o2["vertices"].detach(), o["vertices"], rtol=1e-5, atol=3e-6)
+    torch.testing.assert_close(o2["vertices_transform"].detach(), o["vertices_transform"], rtol=1e-5, atol=3e-6)
