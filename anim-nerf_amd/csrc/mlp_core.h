@@ -136,8 +136,7 @@ __device__ __forceinline__ float sin_or_cos(float a, int q_off) {
 // alias and degrades EVERY LDS wait in the kernel to `s_waitcnt lgkmcnt(0)`, which exposes the full LDS latency
 // in front of each group of MFMAs.  Hidden in asm, the fragment reads keep their counted lgkmcnt(N) waits; the
 // DMA's own completion is waited for by hand (`vmcnt(0)` in front of the workgroup barrier, dma_wait()).
-__device__ __forceinline__ void dma16(const char* gsrc_lane, char* lds_dst_uniform) {
-    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_dst_uniform;
+__device__ __forceinline__ void dma16(const char* gsrc_lane, unsigned dst /* LDS byte address, wave-uniform */) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
@@ -146,14 +145,16 @@ __device__ __forceinline__ void dma16(const char* gsrc_lane, char* lds_dst_unifo
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// `slot` = byte offset of the ring slot inside the workgroup's dynamic LDS array `lds`
 template <bool DMA, int WAVES>
-__device__ __forceinline__ void stage_chunk(const char* __restrict__ g, char* slot, int nf, int wave, int lane) {
+__device__ __forceinline__ void stage_chunk(const char* __restrict__ g, char* lds, unsigned slot, int nf, int wave, int lane) {
     if constexpr (DMA) {
-        for (int p = wave; p < nf; p += WAVES) dma16(g + p * FRAG_BYTES + lane * 16, slot + p * FRAG_BYTES);
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + slot;
+        for (int p = wave; p < nf; p += WAVES) dma16(g + p * FRAG_BYTES + lane * 16, base + p * FRAG_BYTES);
     } else {
         for (int p = wave; p < nf; p += WAVES) {
             uint4 v = *reinterpret_cast<const uint4*>(g + p * FRAG_BYTES + lane * 16);
-            *reinterpret_cast<uint4*>(slot + p * FRAG_BYTES + lane * 16) = v;
+            *reinterpret_cast<uint4*>(lds + slot + p * FRAG_BYTES + lane * 16) = v;
         }
     }
 }
@@ -181,6 +182,7 @@ struct Mlp {
     using ActT = std::conditional_t<C::IS_BF16, __bf16, float>;    // saved activations: the dtype the next layer consumed
     static constexpr int LAST_TILE = SIGMA_ONLY ? 64 : 77;         // sigma-only stops after the sigma row (tile 64)
     static constexpr int LAST_CHUNK = LAST_TILE / TPC;
+    static constexpr int NCHUNK = LAST_CHUNK + 1;                  // chunks per pass (the slot pointers rotate at run time)
 
     // Per-wave pipeline state.  Weight chunks (TPC 32-row out-tiles each) flow through a 3-slot LDS ring:
     // while tile c is being multiplied, chunk c+1 is already resident (its first fragment group and its bias
@@ -188,10 +190,13 @@ struct Mlp {
     // The activation/convert epilogue of tile c-1 is issued in the shadow of tile c's first MFMAs, so the
     // matrix pipe never waits for VALU work: accumulators ping-pong between acc[0] and acc[1].
     const char* gnext;       // global address of the next chunk to stage (chunk c+2)
+    const char* gbase;       // first chunk of the pack (the ring wraps to it between point tiles)
+    bool more;               // persistent loop: another point tile follows this one
+    char* lds_base;          // the workgroup's dynamic LDS: [bias table | 3 ring slots]
     char* lds_bias;
-    char* slot_cur;          // LDS slot of chunk c
-    char* slot_nxt;          // LDS slot of chunk c+1
-    char* slot_stage;        // LDS slot chunk c+2 is staged into
+    unsigned slot_cur;       // byte offset (in lds_base) of the slot of chunk c
+    unsigned slot_nxt;       // ... of chunk c+1
+    unsigned slot_stage;     // ... of the slot chunk c+2 is staged into
     int c;                   // chunk counter
     int wave, lane, half;
     f32x16 acc[2][NT];       // accumulators of tile c (parity c&1) and of tile c-1 (epilogue pending)
@@ -206,15 +211,18 @@ struct Mlp {
         __syncthreads();
 #endif
 #ifndef ANR_ABL_NO_STAGE
-        if (c + 2 <= LAST_CHUNK) {                     // nothing may be in flight into LDS when the workgroup ends
-            const int nf = chunk_frags<C>(c + 2);
-            stage_chunk<DMA, WAVES>(gnext, slot_stage, nf, wave, lane);
+        // chunk c+2 of this pass, or — the workgroup is persistent — chunk 0/1 of the NEXT point tile: the weight
+        // stream never drains between tiles.  Nothing may be in flight into LDS when the workgroup ends.
+        if (c + 2 < NCHUNK || more) {
+            if (c + 2 == NCHUNK) gnext = gbase;
+            const int nf = chunk_frags<C>((c + 2) % NCHUNK);
+            stage_chunk<DMA, WAVES>(gnext, lds_base, slot_stage, nf, wave, lane);
             gnext += nf * FRAG_BYTES;
         }
 #endif
     }
     __device__ __forceinline__ void rotate() {
-        char* t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_stage; slot_stage = t;
+        unsigned t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_stage; slot_stage = t;
         ++c;
     }
     __device__ __forceinline__ f32x16 read_bias(int tile_idx) {
@@ -294,9 +302,11 @@ struct Mlp {
         constexpr int PAR = T & 1;
         constexpr int POS = T % TPC;                       // position of this tile inside its chunk
         constexpr int OFF = (POS == 0) ? 0 : tile_frags<C>(T - 1);      // TPC <= 2
+        constexpr bool END = (T == LAST_TILE);             // the next tile is tile 0 of the next point tile
         if constexpr (POS == 0) advance();
-        const Frag* cur = reinterpret_cast<const Frag*>(slot_cur) + OFF * 64 + lane;
-        const Frag* nxt = (POS + 1 < TPC) ? cur + (NFE + NFH) * 64 : reinterpret_cast<const Frag*>(slot_nxt) + lane;
+        const Frag* cur = reinterpret_cast<const Frag*>(lds_base + slot_cur) + OFF * 64 + lane;
+        const Frag* nxt = (POS + 1 < TPC && !END) ? cur + (NFE + NFH) * 64
+                                                  : reinterpret_cast<const Frag*>(lds_base + slot_nxt) + lane;
         Frag wa[4], wb[4];
         f32x16 bias_n;
 #pragma unroll
@@ -307,7 +317,7 @@ struct Mlp {
             Frag (&ld)[4] = (j & 1) ? wa : wb;
 #pragma unroll
             for (int q = 0; q < 4; ++q) ld[q] = (j + 1 < NG) ? cur[((j + 1) * 4 + q) * 64] : nxt[q * 64];
-            if (j + 1 == NG) bias_n = read_bias(T + 1);
+            if (j + 1 == NG) bias_n = read_bias(END ? 0 : T + 1);
             __builtin_amdgcn_sched_barrier(0);          // the loads above are issued before this group's MFMAs
             static_for<4>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
@@ -327,7 +337,7 @@ struct Mlp {
 #pragma unroll
         for (int q = 0; q < 4; ++q) w0[q] = (NG & 1) ? wb[q] : wa[q];
         bias_c = bias_n;
-        if constexpr (POS + 1 == TPC) rotate();
+        if constexpr (POS + 1 == TPC || END) rotate();
     }
 
     // a full layer of NTILES out-tiles starting at global tile index T0; `first` is the epilogue still pending
@@ -355,23 +365,31 @@ struct Mlp {
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         lane = threadIdx.x & 63;
         half = lane >> 5;
+        lds_base = lds;
         lds_bias = lds;
-        slot_cur = lds + BIAS_BYTES;
+        slot_cur = BIAS_BYTES;
         slot_nxt = slot_cur + SLOT;
         slot_stage = slot_nxt + SLOT;
-        c = 0;
+        gbase = pack + BIAS_BYTES;
 
         // resident bias table + the first two chunks
         for (int i = threadIdx.x; i < BIAS_BYTES / 16; i += THREADS)
             reinterpret_cast<uint4*>(lds_bias)[i] = reinterpret_cast<const uint4*>(pack)[i];
-        gnext = pack + BIAS_BYTES;
-        stage_chunk<DMA, WAVES>(gnext, slot_cur, chunk_frags<C>(0), wave, lane);
+        gnext = gbase;
+        stage_chunk<DMA, WAVES>(gnext, lds_base, slot_cur, chunk_frags<C>(0), wave, lane);
         gnext += chunk_frags<C>(0) * FRAG_BYTES;
-        stage_chunk<DMA, WAVES>(gnext, slot_nxt, chunk_frags<C>(1), wave, lane);
+        stage_chunk<DMA, WAVES>(gnext, lds_base, slot_nxt, chunk_frags<C>(1), wave, lane);
         gnext += chunk_frags<C>(1) * FRAG_BYTES;
 
+        // Persistent workgroup: point tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The weight ring, the bias table,
+        // w0 and bias_c carry over from one tile to the next.
+        const int64_t n_tiles = (n_pts + WAVES * NT * 32 - 1) / (WAVES * NT * 32);
+        bool first = true;
+        for (int64_t pt = blockIdx.x; pt < n_tiles; pt += gridDim.x) {
+        more = pt + gridDim.x < n_tiles;
+        c = 0;
         // this wave's points, Fourier-encoded straight into B fragments
-        const int64_t wave_base = ((int64_t)blockIdx.x * WAVES + wave) * (NT * 32);
+        const int64_t wave_base = (pt * WAVES + wave) * (NT * 32);
         float valid[NT];
         Frag E[NT][EF];
 #pragma unroll
@@ -381,27 +399,50 @@ struct Mlp {
             valid[n] = p.w;
             act_row[n] = (SAVE && idx < n_pts) ? reinterpret_cast<ActT*>(act) + idx * ACT_COLS + 4 * half : nullptr;
             const float xs[3] = {p.x, p.y, p.z};
+            if constexpr (C::IS_BF16) {
+                // bf16 mode: exact sin/cos of the base band, then angle doubling (error doubles per octave:
+                // 2^9 * 1e-7 << bf16's 2^-9) — 6 polynomial evaluations instead of 30 per lane
+                float sn[3], cs[3];
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                float v;
-                if (j < 30) {
-                    const int k = j / 3, d = j % 3;
-                    v = sin_or_cos(xs[d] * (float)(1 << k), half);
-                } else if (j == 30) {
-                    v = half ? xs[2] : xs[0];
-                } else {
-                    v = half ? 0.0f : xs[1];
+                for (int d = 0; d < 3; ++d) { sn[d] = sin_or_cos(xs[d], 0); cs[d] = sin_or_cos(xs[d], 1); }
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const int j = 3 * k + d;
+                        put(E[n][j / EPF], j % EPF, half ? cs[d] : sn[d]);
+                        const float s2 = 2.0f * sn[d] * cs[d], c2 = 1.0f - 2.0f * sn[d] * sn[d];
+                        sn[d] = s2; cs[d] = c2;
+                    }
                 }
-                put(E[n][j / EPF], j % EPF, v);
+                put(E[n][30 / EPF], 30 % EPF, half ? xs[2] : xs[0]);
+                put(E[n][31 / EPF], 31 % EPF, half ? 0.0f : xs[1]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    float v;
+                    if (j < 30) {
+                        const int k = j / 3, d = j % 3;
+                        v = sin_or_cos(xs[d] * (float)(1 << k), half);
+                    } else if (j == 30) {
+                        v = half ? xs[2] : xs[0];
+                    } else {
+                        v = half ? 0.0f : xs[1];
+                    }
+                    put(E[n][j / EPF], j % EPF, v);
+                }
             }
         }
 
-        // chunk 0 resident -> its first fragment group and bias into registers
-        if constexpr (DMA) dma_wait();
-        __syncthreads();
+        if (first) {
+            // chunk 0 resident -> its first fragment group and bias into registers
+            if constexpr (DMA) dma_wait();
+            __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) w0[q] = (reinterpret_cast<const Frag*>(slot_cur) + lane)[q * 64];
-        bias_c = read_bias(0);
+            for (int q = 0; q < 4; ++q) w0[q] = (reinterpret_cast<const Frag*>(lds_base + slot_cur) + lane)[q * 64];
+            bias_c = read_bias(0);
+            first = false;
+        }
 
         Frag A[NT][HF], B[NT][HF];
         float sigma[NT];
@@ -423,7 +464,6 @@ struct Mlp {
                 int64_t idx = wave_base + n * 32 + (lane & 31);
                 if (half == 0 && idx < n_pts) out[idx] = (valid[n] < 1.0f) ? -1e5f : acc[64 & 1][n][0];
             }
-            return;
         } else {
             float4* out = reinterpret_cast<float4*>(out_v);
             // xyz_encoding_final (no activation): B -> A
@@ -445,6 +485,7 @@ struct Mlp {
                 }
             }
         }
+        }   // persistent loop over point tiles
     }
 };
 
@@ -465,7 +506,10 @@ int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStr
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail((int)e, "anr_mlp_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
     const int pts_per_wg = C::WAVES * C::NT * 32;
-    dim3 grid((unsigned)((n + pts_per_wg - 1) / pts_per_wg));
+    const int64_t n_tiles = (n + pts_per_wg - 1) / pts_per_wg;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    dim3 grid((unsigned)(n_tiles < cus ? n_tiles : cus));          // one persistent workgroup per CU (LDS-limited)
     hipLaunchKernelGGL(kern, grid, dim3(C::WAVES * 64), lds, st, reinterpret_cast<const char*>(pack),
                        reinterpret_cast<const float4*>(pts), n, reinterpret_cast<void*>(out), act);
     return check_launch("anr_mlp_forward");
