@@ -385,9 +385,21 @@ struct Mlp {
         // w0 and bias_c carry over from one tile to the next.
         const int64_t n_tiles = (n_pts + WAVES * NT * 32 - 1) / (WAVES * NT * 32);
         bool first = true;
+        auto fetch_pts = [&](int64_t tile_idx, float4 (&dst)[NT]) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                int64_t idx = (tile_idx * WAVES + wave) * (NT * 32) + n * 32 + (lane & 31);
+                dst[n] = pts[idx < n_pts ? idx : n_pts - 1];
+            }
+        };
+        float4 p_cur[NT], p_nxt[NT];
+        fetch_pts(blockIdx.x, p_nxt);
         for (int64_t pt = blockIdx.x; pt < n_tiles; pt += gridDim.x) {
         more = pt + gridDim.x < n_tiles;
         c = 0;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) p_cur[n] = p_nxt[n];
+        if (more) fetch_pts(pt + gridDim.x, p_nxt);          // the next tile's points arrive under this tile's MFMAs
         // this wave's points, Fourier-encoded straight into B fragments
         const int64_t wave_base = (pt * WAVES + wave) * (NT * 32);
         float valid[NT];
@@ -395,7 +407,7 @@ struct Mlp {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             int64_t idx = wave_base + n * 32 + (lane & 31);
-            const float4 p = pts[idx < n_pts ? idx : n_pts - 1];
+            const float4 p = p_cur[n];
             valid[n] = p.w;
             act_row[n] = (SAVE && idx < n_pts) ? reinterpret_cast<ActT*>(act) + idx * ACT_COLS + 4 * half : nullptr;
             const float xs[3] = {p.x, p.y, p.z};
