@@ -53,9 +53,9 @@ class AnimNeRF(nn.Module):
         self.use_fine, self.share_fine = use_fine, share_fine
         self.dis_threshold = dis_threshold
         self.query_inside = query_inside
-        if use_deformation or query_inside:
-            raise NotImplementedError("use_deformation / query_inside are False in every shipped config and broken "
-                                      "in the reference (models/nerf.py:54, models/anim_nerf.py:257)")
+        if use_deformation:
+            raise NotImplementedError("use_deformation is False in every shipped config and broken in the reference "
+                                      "(models/nerf.py:54)")
         if k_neigh != 4:
             raise NotImplementedError("the HIP warp kernel is built for k_neigh = 4 (every shipped config)")
 
@@ -70,12 +70,20 @@ class AnimNeRF(nn.Module):
         self.register_buffer("knn_order", ops.morton_order(self.body_model.v_template), persistent=False)
         self._knn_index = None
         self.skip_far_samples = True     # renderer only: no neighbour search for provably-invalid samples
+        # renderer only: the MLP runs on the samples within dis_threshold of the body (the rest is sigma = -1e5 and
+        # composites with weight exactly 0).  `query_inside=True` asks for the same at the forward() level, where it
+        # also zeroes rgb of the other samples (models/anim_nerf.py:245-290).
+        self.skip_invalid_samples = True
 
         mk = dict(freqs_xyz=freqs_xyz, freqs_dir=freqs_dir, use_view=use_view, deformation_dim=deformation_dim,
                   apperance_dim=apperance_dim, mlp_mode=mlp_mode)
         self.nerf = NeRF(**mk)
         if use_fine:
             self.nerf_fine = self.nerf if share_fine else NeRF(**mk)
+
+    @property
+    def evaluate_valid_only(self) -> bool:
+        return bool(self.use_unpose and (self.skip_invalid_samples or self.query_inside))
 
     # ------------------------------------------------------------------ per-frame state
     def set_latent_code(self, latent_code):
@@ -184,5 +192,5 @@ class AnimNeRF(nn.Module):
         """xyz[bs,nv,3] -> rgb[bs,nv,3], sigma[bs,nv,1]; sigma = -1e5 outside dis_threshold."""
         bs, nv = xyz.shape[:2]
         pts = self.warped_points(xyz=xyz)
-        out = self._net(use_fine).eval_points(pts).view(bs, nv, 4)
+        out = self._net(use_fine).eval_points(pts, only_valid=self.use_unpose and self.query_inside).view(bs, nv, 4)
         return out[..., :3], out[..., 3:4]

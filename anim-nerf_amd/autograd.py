@@ -31,18 +31,53 @@ def _encode(xyz: torch.Tensor, n_freqs: int = 10) -> torch.Tensor:
 class MLPFunction(torch.autograd.Function):
     """out[n,4] = (r,g,b,sigma) (or sigma[n]) = NeRF(pts[n,4]); differentiable w.r.t. the 22 parameter tensors."""
 
+    PAD = 4096      # compacted row count is rounded up to this (keeps the split-K weight-gradient GEMMs regular)
+
     @staticmethod
-    def forward(ctx, pts, sigma_only, mode_id, *params):
+    def forward(ctx, pts, sigma_only, mode_id, only_valid, *params):
         pack = ops.mlp_pack(dict(zip(PARAM_KEYS, params)), mode_id)
-        out, act = ops.mlp_forward_save(pack, mode_id, pts.detach(), sigma_only)
-        ctx.save_for_backward(pts, out, act, *params)
+        pts = pts.detach()
+        n = pts.shape[0]
         ctx.sigma_only = sigma_only
-        return out
+        ctx.n_full = n
+        idx = None
+        if only_valid:
+            # samples outside dis_threshold have sigma = -1e5 and composite weight exactly 0: neither their outputs nor
+            # their (exactly zero) gradients are needed.  Forward, saved activations and backward run on the rest.
+            index, count = ops.compact_valid(pts)
+            cnt = int(count.item())                                   # the backward GEMM shapes need it on the host
+            if cnt < n:
+                n_pad = max(-(-cnt // MLPFunction.PAD), 1) * MLPFunction.PAD
+                idx = index[:cnt].long()
+                pts_c = pts.new_zeros(n_pad, 4)                       # padding rows: valid = 0, zero upstream gradient
+                pts_c[:cnt] = pts.index_select(0, idx)
+                pts = pts_c
+        out, act = ops.mlp_forward_save(pack, mode_id, pts, sigma_only)
+        if idx is None:
+            ctx.save_for_backward(pts, out, act, *params)
+            ctx.compacted = False
+            return out
+        ctx.save_for_backward(pts, out, act, idx, *params)
+        ctx.compacted = True
+        full = out.new_zeros((n,) if sigma_only else (n, 4))
+        if sigma_only:
+            full.fill_(-1e5)
+        else:
+            full[:, 3] = -1e5
+        full[idx] = out[:idx.shape[0]]
+        return full
 
     @staticmethod
     @torch.no_grad()
     def backward(ctx, g):
-        pts, out, act, *params = ctx.saved_tensors
+        idx = None
+        if ctx.compacted:
+            pts, out, act, idx, *params = ctx.saved_tensors
+            g_c = g.new_zeros((pts.shape[0],) + tuple(g.shape[1:]))
+            g_c[:idx.shape[0]] = g.index_select(0, idx)
+            g = g_c
+        else:
+            pts, out, act, *params = ctx.saved_tensors
         dt = act.dtype                                              # fp32 (parity mode) or bf16 (mixed precision)
         P = {k: (p if p.dtype == dt else p.to(dt)) for k, p in zip(PARAM_KEYS, params)}
         n = pts.shape[0]
@@ -111,12 +146,16 @@ class MLPFunction(torch.autograd.Function):
                 sin, cos = e32[:, 3 + 6 * k:6 + 6 * k], e32[:, 6 + 6 * k:9 + 6 * k]
                 d_x += f * (cos * d_enc[:, 3 + 6 * k:6 + 6 * k] - sin * d_enc[:, 6 + 6 * k:9 + 6 * k])
             d_pts = torch.cat([d_x, torch.zeros_like(d_x[:, :1])], 1)
+            if idx is not None:
+                full = d_pts.new_zeros(ctx.n_full, 4)
+                full[idx] = d_pts[:idx.shape[0]]
+                d_pts = full
         out_grads = []
         for i, k in enumerate(PARAM_KEYS):
-            need = ctx.needs_input_grad[3 + i]
+            need = ctx.needs_input_grad[4 + i]
             gk = grads.get(k) if need else None
             out_grads.append(None if gk is None else gk.to(params[i].dtype).reshape(params[i].shape))
-        return (d_pts, None, None, *out_grads)
+        return (d_pts, None, None, None, *out_grads)
 
 
 class CompositeFunction(torch.autograd.Function):

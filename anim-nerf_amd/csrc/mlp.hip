@@ -6,7 +6,7 @@ namespace anr {
 
 // instantiated in mlp_inst_*.hip
 #define ANR_MLP_EXTERN(M, D, S, V) \
-    extern template int launch_mlp<M, D, S, V>(const void*, const float*, int64_t, float*, hipStream_t, float*);
+    extern template int launch_mlp<M, D, S, V>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*);
 ANR_MLP_EXTERN(ANR_MLP_F32, true, false, false)  ANR_MLP_EXTERN(ANR_MLP_F32, false, false, false)
 ANR_MLP_EXTERN(ANR_MLP_F32, true, true, false)   ANR_MLP_EXTERN(ANR_MLP_F32, true, false, true)
 ANR_MLP_EXTERN(ANR_MLP_F32, true, true, true)
@@ -149,6 +149,11 @@ extern "C" int anr_mlp_act_cols(void) { return ACT_COLS; }
 
 extern "C" int anr_mlp_forward_save(const void* pack, int mode, const float* pts, int64_t n, float* out, void* act_v,
                                     void* stream) {
+    return anr_mlp_forward_save_indexed(pack, mode, pts, nullptr, nullptr, n, out, act_v, stream);
+}
+
+extern "C" int anr_mlp_forward_save_indexed(const void* pack, int mode, const float* pts, const int32_t* index,
+                                            const int32_t* count, int64_t n, float* out, void* act_v, void* stream) {
     float* act = reinterpret_cast<float*>(act_v);
     ANR_REQUIRE(pack && pts && out && act, ANR_E_BADARG, "anr_mlp_forward_save: null pointer");
     ANR_REQUIRE(n > 0, ANR_E_BADARG, "anr_mlp_forward_save: n=%lld", (long long)n);
@@ -158,17 +163,24 @@ extern "C" int anr_mlp_forward_save(const void* pack, int mode, const float* pts
     const bool so = (mode & ANR_MLP_FLAG_SIGMA_ONLY) != 0;
     switch (mode & 0xff) {
         case ANR_MLP_F32:
-            return so ? launch_mlp<ANR_MLP_F32, true, true, true>(pack, pts, n, out, st, act)
-                      : launch_mlp<ANR_MLP_F32, true, false, true>(pack, pts, n, out, st, act);
+            return so ? launch_mlp<ANR_MLP_F32, true, true, true>(pack, pts, n, out, st, act, index, count)
+                      : launch_mlp<ANR_MLP_F32, true, false, true>(pack, pts, n, out, st, act, index, count);
         case ANR_MLP_BF16:
-            return so ? launch_mlp<ANR_MLP_BF16_W8, true, true, true>(pack, pts, n, out, st, act)
-                      : launch_mlp<ANR_MLP_BF16_W8, true, false, true>(pack, pts, n, out, st, act);
+            return so ? launch_mlp<ANR_MLP_BF16_W8, true, true, true>(pack, pts, n, out, st, act, index, count)
+                      : launch_mlp<ANR_MLP_BF16_W8, true, false, true>(pack, pts, n, out, st, act, index, count);
         default: return fail(ANR_E_BADARG, "anr_mlp_forward_save: unknown mode %d", mode);
     }
 }
 
 extern "C" int anr_mlp_forward(const void* pack, int mode, const float* pts, int64_t n, float* out, void* stream) {
+    return anr_mlp_forward_indexed(pack, mode, pts, nullptr, nullptr, n, out, stream);
+}
+
+extern "C" int anr_mlp_forward_indexed(const void* pack, int mode, const float* pts, const int32_t* index,
+                                       const int32_t* count, int64_t n, float* out, void* stream) {
     ANR_REQUIRE(pack && pts && out, ANR_E_BADARG, "anr_mlp_forward: null pointer");
+    ANR_REQUIRE(index || !count, ANR_E_BADARG, "anr_mlp_forward_indexed: count without index");
+    ANR_REQUIRE(!index || n < (int64_t)1 << 31, ANR_E_BADARG, "anr_mlp_forward_indexed: n=%lld does not fit int32", (long long)n);
     ANR_REQUIRE(n > 0, ANR_E_BADARG, "anr_mlp_forward: n=%lld", (long long)n);
     ANR_REQUIRE((((uintptr_t)pack | (uintptr_t)pts | (uintptr_t)out) & 15) == 0, ANR_E_ALIGN,
                 "anr_mlp_forward: pack/pts/out must be 16-B aligned");
@@ -176,18 +188,18 @@ extern "C" int anr_mlp_forward(const void* pack, int mode, const float* pts, int
     const bool dma = !(mode & ANR_MLP_FLAG_NO_DMA);
     if (mode & ANR_MLP_FLAG_SIGMA_ONLY) {              // out = float[n]: sigma only (trunk + sigma row, 83 % of the FLOPs)
         switch (mode & 0xff) {
-            case ANR_MLP_F32:  return launch_mlp<ANR_MLP_F32, true, true, false>(pack, pts, n, out, st, nullptr);
-            case ANR_MLP_BF16: return launch_mlp<ANR_MLP_BF16_W8, true, true, false>(pack, pts, n, out, st, nullptr);
+            case ANR_MLP_F32:  return launch_mlp<ANR_MLP_F32, true, true, false>(pack, pts, n, out, st, nullptr, index, count);
+            case ANR_MLP_BF16: return launch_mlp<ANR_MLP_BF16_W8, true, true, false>(pack, pts, n, out, st, nullptr, index, count);
             default: return fail(ANR_E_BADARG, "anr_mlp_forward: unknown mode %d", mode);
         }
     }
     switch (mode & 0xff) {
         case ANR_MLP_F32:
-            return dma ? launch_mlp<ANR_MLP_F32, true, false, false>(pack, pts, n, out, st, nullptr) : launch_mlp<ANR_MLP_F32, false, false, false>(pack, pts, n, out, st, nullptr);
+            return dma ? launch_mlp<ANR_MLP_F32, true, false, false>(pack, pts, n, out, st, nullptr, index, count) : launch_mlp<ANR_MLP_F32, false, false, false>(pack, pts, n, out, st, nullptr, index, count);
         case ANR_MLP_BF16:
             if (mode & ANR_MLP_FLAG_W4)
-                return dma ? launch_mlp<ANR_MLP_BF16, true, false, false>(pack, pts, n, out, st, nullptr) : launch_mlp<ANR_MLP_BF16, false, false, false>(pack, pts, n, out, st, nullptr);
-            return dma ? launch_mlp<ANR_MLP_BF16_W8, true, false, false>(pack, pts, n, out, st, nullptr) : launch_mlp<ANR_MLP_BF16_W8, false, false, false>(pack, pts, n, out, st, nullptr);
+                return dma ? launch_mlp<ANR_MLP_BF16, true, false, false>(pack, pts, n, out, st, nullptr, index, count) : launch_mlp<ANR_MLP_BF16, false, false, false>(pack, pts, n, out, st, nullptr, index, count);
+            return dma ? launch_mlp<ANR_MLP_BF16_W8, true, false, false>(pack, pts, n, out, st, nullptr, index, count) : launch_mlp<ANR_MLP_BF16_W8, false, false, false>(pack, pts, n, out, st, nullptr, index, count);
         default:
             return fail(ANR_E_BADARG, "anr_mlp_forward: unknown mode %d", mode);
     }

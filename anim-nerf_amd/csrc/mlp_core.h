@@ -205,9 +205,20 @@ struct Mlp {
     ActT* act_row[NT];       // SAVE: this lane's row of saved activations (+ 4*half), or null
 
     // barrier: chunk c+1 has landed everywhere and nobody reads chunk c-1 any more -> stage chunk c+2 over it
+    static constexpr int MAXP = (TPC * (HF + EF) + WAVES - 1) / WAVES;   // register-staged pieces per wave (DMA off)
+    uint4 sreg[DMA ? 1 : MAXP];
+    unsigned spend_slot; int spend_nf;
     __device__ __forceinline__ void advance() {
 #ifndef ANR_ABL_NO_BARRIER
         if constexpr (DMA) dma_wait();
+        else {
+            // DMA off: the chunk loaded into registers one chunk ago goes to its ring slot now
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i)
+                if (wave + i * WAVES < spend_nf)
+                    *reinterpret_cast<uint4*>(lds_base + spend_slot + (wave + i * WAVES) * FRAG_BYTES + lane * 16) = sreg[i];
+            spend_nf = 0;
+        }
         __syncthreads();
 #endif
 #ifndef ANR_ABL_NO_STAGE
@@ -216,7 +227,14 @@ struct Mlp {
         if (c + 2 < NCHUNK || more) {
             if (c + 2 == NCHUNK) gnext = gbase;
             const int nf = chunk_frags<C>((c + 2) % NCHUNK);
-            stage_chunk<DMA, WAVES>(gnext, lds_base, slot_stage, nf, wave, lane);
+            if constexpr (DMA) stage_chunk<DMA, WAVES>(gnext, lds_base, slot_stage, nf, wave, lane);
+            else {
+#pragma unroll
+                for (int i = 0; i < MAXP; ++i)
+                    if (wave + i * WAVES < nf)
+                        sreg[i] = *reinterpret_cast<const uint4*>(gnext + (wave + i * WAVES) * FRAG_BYTES + lane * 16);
+                spend_slot = slot_stage; spend_nf = nf;
+            }
             gnext += nf * FRAG_BYTES;
         }
 #endif
@@ -360,8 +378,17 @@ struct Mlp {
         return FragEpi<RELU, YF, (NTILES - 1) * FPT, T0 + NTILES - 1>{acc[(T0 + NTILES - 1) & 1], Y, act_row};
     }
 
+    // index/count (both optional): evaluate pts[index[i]] for i < min(n_pts, *count) and write out[index[i]] — the
+    // compacted list of valid samples (anr_compact_valid); saved activations are rows i of the compacted order.
     __device__ __forceinline__ void run(const char* __restrict__ pack, const float4* __restrict__ pts, int64_t n_pts,
-                                        void* __restrict__ out_v, float* __restrict__ act, char* lds) {
+                                        void* __restrict__ out_v, float* __restrict__ act, char* lds,
+                                        const int32_t* __restrict__ index, const int32_t* __restrict__ count) {
+        if (count) {
+            const int64_t cnt = *count;
+            n_pts = cnt < n_pts ? cnt : n_pts;
+        }
+        const int64_t n_tiles = (n_pts + WAVES * NT * 32 - 1) / (WAVES * NT * 32);
+        if ((int64_t)blockIdx.x >= n_tiles) return;       // (before anything is in flight into LDS)
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         lane = threadIdx.x & 63;
         half = lane >> 5;
@@ -376,6 +403,7 @@ struct Mlp {
         for (int i = threadIdx.x; i < BIAS_BYTES / 16; i += THREADS)
             reinterpret_cast<uint4*>(lds_bias)[i] = reinterpret_cast<const uint4*>(pack)[i];
         gnext = gbase;
+        spend_nf = 0; spend_slot = 0;
         stage_chunk<DMA, WAVES>(gnext, lds_base, slot_cur, chunk_frags<C>(0), wave, lane);
         gnext += chunk_frags<C>(0) * FRAG_BYTES;
         stage_chunk<DMA, WAVES>(gnext, lds_base, slot_nxt, chunk_frags<C>(1), wave, lane);
@@ -383,13 +411,20 @@ struct Mlp {
 
         // Persistent workgroup: point tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The weight ring, the bias table,
         // w0 and bias_c carry over from one tile to the next.
-        const int64_t n_tiles = (n_pts + WAVES * NT * 32 - 1) / (WAVES * NT * 32);
         bool first = true;
         auto fetch_pts = [&](int64_t tile_idx, float4 (&dst)[NT]) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 int64_t idx = (tile_idx * WAVES + wave) * (NT * 32) + n * 32 + (lane & 31);
-                dst[n] = pts[idx < n_pts ? idx : n_pts - 1];
+                idx = idx < n_pts ? idx : n_pts - 1;
+                if (index) {
+                    // every listed sample is valid: the w lane carries its position in pts/out instead
+                    const int32_t id = index[idx];
+                    dst[n] = pts[id];
+                    dst[n].w = __int_as_float(id);
+                } else {
+                    dst[n] = pts[idx];
+                }
             }
         };
         float4 p_cur[NT], p_nxt[NT];
@@ -474,7 +509,10 @@ struct Mlp {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 int64_t idx = wave_base + n * 32 + (lane & 31);
-                if (half == 0 && idx < n_pts) out[idx] = (valid[n] < 1.0f) ? -1e5f : acc[64 & 1][n][0];
+                if (half == 0 && idx < n_pts) {
+                    if (index) out[__float_as_int(valid[n])] = acc[64 & 1][n][0];
+                    else out[idx] = (valid[n] < 1.0f) ? -1e5f : acc[64 & 1][n][0];
+                }
             }
         } else {
             float4* out = reinterpret_cast<float4*>(out_v);
@@ -492,8 +530,12 @@ struct Mlp {
                     float cr = 1.0f / (1.0f + expf(-r[0]));
                     float cg = 1.0f / (1.0f + expf(-r[1]));
                     float cb = 1.0f / (1.0f + expf(-r[2]));
-                    float s = (valid[n] < 1.0f) ? -1e5f : sigma[n];       // models/anim_nerf.py:305
-                    out[idx] = make_float4(cr, cg, cb, s);
+                    if (index) {
+                        out[__float_as_int(valid[n])] = make_float4(cr, cg, cb, sigma[n]);
+                    } else {
+                        float s = (valid[n] < 1.0f) ? -1e5f : sigma[n];   // models/anim_nerf.py:305
+                        out[idx] = make_float4(cr, cg, cb, s);
+                    }
                 }
             }
         }
@@ -504,14 +546,17 @@ struct Mlp {
 template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE>
 __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void mlp_kernel(const char* __restrict__ pack,
                                                              const float4* __restrict__ pts, int64_t n_pts,
-                                                             void* __restrict__ out, float* __restrict__ act) {
+                                                             void* __restrict__ out, float* __restrict__ act,
+                                                             const int32_t* __restrict__ index,
+                                                             const int32_t* __restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     Mlp<MODE, DMA, SIGMA_ONLY, SAVE> m;
-    m.run(pack, pts, n_pts, out, act, lds);
+    m.run(pack, pts, n_pts, out, act, lds, index, count);
 }
 
 template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE>
-int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStream_t st, float* act) {
+int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStream_t st, float* act,
+               const int32_t* index = nullptr, const int32_t* count = nullptr) {
     using C = Cfg<MODE>;
     const int lds = BIAS_BYTES + 3 * slot_bytes<C>();
     auto kern = mlp_kernel<MODE, DMA, SIGMA_ONLY, SAVE>;
@@ -523,7 +568,7 @@ int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStr
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     dim3 grid((unsigned)(n_tiles < cus ? n_tiles : cus));          // one persistent workgroup per CU (LDS-limited)
     hipLaunchKernelGGL(kern, grid, dim3(C::WAVES * 64), lds, st, reinterpret_cast<const char*>(pack),
-                       reinterpret_cast<const float4*>(pts), n, reinterpret_cast<void*>(out), act);
+                       reinterpret_cast<const float4*>(pts), n, reinterpret_cast<void*>(out), act, index, count);
     return check_launch("anr_mlp_forward");
 }
 

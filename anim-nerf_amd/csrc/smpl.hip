@@ -10,7 +10,8 @@ constexpr int SMPL_MAX_J = 32;
 
 // ---- 1. shape blend shapes + joint regression partials ------------------------------------------
 // grid (ceil(V/256), bs): shape_off = shapedirs . betas ; v_shaped = v_template + shape_off ;
-// joints[j] += J_regressor[j, v] * v_shaped[v]   (block-reduced, one atomic per block/joint/axis)
+// joint_part[b, block, j] = sum over the block's vertices of J_regressor[j, v] * v_shaped[v]; the chain kernel adds the
+// blocks in a fixed order (no atomics: the frame state must be reproducible bit for bit)
 __global__ __launch_bounds__(256) void smpl_shape_kernel(const float* __restrict__ betas, int NB,
                                                          const float* __restrict__ v_template,
                                                          const float* __restrict__ shapedirs,
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void smpl_shape_kernel(const float* __restrict
         __syncthreads();
         if (threadIdx.x < 3) {
             float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-            if (s != 0.f) atomicAdd(joints_rest + ((int64_t)b * J + j) * 3 + threadIdx.x, s);
+            joints_rest[(((int64_t)b * gridDim.x + blockIdx.x) * J + j) * 3 + threadIdx.x] = s;
         }
         __syncthreads();
     }
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void smpl_shape_kernel(const float* __restrict
 // lbs.py:298-332 (angle = |rv + 1e-8|), :348-404.  Outputs A[J,4,4] (with transl added to its translation column,
 // body_models.py:373), posed joints (+ transl), pose feature (R[1:] - I) flattened [9(J-1)].
 __global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict__ pose, const float* __restrict__ transl,
-                                                        const float* __restrict__ joints_rest,
+                                                        const float* __restrict__ joints_rest, int n_part,
                                                         const int64_t* __restrict__ parents, int J,
                                                         float* __restrict__ A_out, float* __restrict__ joints_out,
                                                         float* __restrict__ feat_out) {
@@ -76,7 +77,11 @@ __global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict_
                 Rm[j][r * 3 + c] = (r == c ? 1.0f : 0.0f) + s * K[r * 3 + c] + c1 * kk;
             }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) Jr[j][c] = joints_rest[((int64_t)b * J + j) * 3 + c];
+        for (int c = 0; c < 3; ++c) {
+            float acc = 0.f;
+            for (int q = 0; q < n_part; ++q) acc += joints_rest[(((int64_t)b * n_part + q) * J + j) * 3 + c];
+            Jr[j][c] = acc;
+        }
         if (j >= 1) {
 #pragma unroll
             for (int e = 0; e < 9; ++e)
@@ -196,12 +201,10 @@ extern "C" int anr_smpl_forward(const float* betas, const float* pose, const flo
     ANR_REQUIRE(bs > 0 && V > 0 && J > 1 && J <= SMPL_MAX_J && NB > 0, ANR_E_BADARG, "anr_smpl_forward: bs=%d V=%d J=%d NB=%d", bs, V, J, NB);
     ANR_REQUIRE(((uintptr_t)T & 15) == 0, ANR_E_ALIGN, "anr_smpl_forward: T must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(ws_joints_rest, 0, sizeof(float) * bs * J * 3, st);
-    if (e != hipSuccess) return fail((int)e, "anr_smpl_forward: memset: %s", hipGetErrorString(e));
     dim3 gv((V + 255) / 256, bs);
     hipLaunchKernelGGL(smpl_shape_kernel, gv, dim3(256), 0, st, betas, NB, v_template, shapedirs, J_regressor, V, J,
                        shape_off, ws_v_shaped, ws_joints_rest);
-    hipLaunchKernelGGL(smpl_chain_kernel, dim3(bs), dim3(64), 0, st, pose, transl, ws_joints_rest, parents, J, A, joints,
+    hipLaunchKernelGGL(smpl_chain_kernel, dim3(bs), dim3(64), 0, st, pose, transl, ws_joints_rest, (int)gv.x, parents, J, A, joints,
                        ws_feat);
     hipLaunchKernelGGL(smpl_skin_kernel, gv, dim3(256), 0, st, ws_feat, 9 * (J - 1), posedirs, lbs_weights, A, transl,
                        ws_v_shaped, V, J, pose_off, T, verts);

@@ -87,17 +87,19 @@ class NeRF(nn.Module):
             self._pack_cache[mode_id] = hit
         return hit[1], mode_id
 
-    def eval_points(self, pts: torch.Tensor, mode: Optional[str] = None, sigma_only: bool = False) -> torch.Tensor:
-        """pts[n,4] = (x,y,z,valid) -> [n,4] = (r,g,b,sigma), or sigma[n] (trunk + sigma row only).  The fused kernel entry."""
+    def eval_points(self, pts: torch.Tensor, mode: Optional[str] = None, sigma_only: bool = False,
+                    only_valid: bool = False) -> torch.Tensor:
+        """pts[n,4] = (x,y,z,valid) -> [n,4] = (r,g,b,sigma), or sigma[n] (trunk + sigma row only).  The fused kernel entry.
+        only_valid: run the network on the samples with valid >= 1 only; the rest get (0,0,0,-1e5)."""
         if torch.is_grad_enabled() and (pts.requires_grad or any(p.requires_grad for p in self.parameters())):
             from .autograd import PARAM_KEYS, MLPFunction              # training: keep activations, differentiable
             if not self._hip_supported():
                 raise NotImplementedError("HIP MLP covers the shipped configuration only")
             named = dict(self.named_parameters())
-            return MLPFunction.apply(pts, sigma_only, ops.MLP_MODES[mode or self.mlp_mode] & 0xff,
+            return MLPFunction.apply(pts, sigma_only, ops.MLP_MODES[mode or self.mlp_mode] & 0xff, only_valid,
                                      *[named[k] for k in PARAM_KEYS])
         pack, mode_id = self.weight_pack(mode)
-        return ops.mlp_forward(pack, mode_id, pts, sigma_only=sigma_only)
+        return ops.mlp_forward(pack, mode_id, pts, sigma_only=sigma_only, only_valid=only_valid)
 
     def _pack_xyz(self, xyz):
         flat = xyz.reshape(-1, 3)

@@ -88,7 +88,7 @@ def smpl_forward(betas, pose, transl, v_template, shapedirs, posedirs, J_regress
     new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
     verts, joints, A, T = new(bs, V, 3), new(bs, J, 3), new(bs, J, 4, 4), new(bs, V, 4, 4)
     so, po = new(bs, V, 3), new(bs, V, 3)
-    ws1, ws2, ws3 = new(bs, V, 3), new(bs, J, 3), new(bs, 9 * (J - 1))
+    ws1, ws2, ws3 = new(bs, V, 3), new(bs, (V + 255) // 256, J, 3), new(bs, 9 * (J - 1))
     _lib.check(lib.anr_smpl_forward(_ptr(betas), _ptr(pose), _ptr(transl), bs, NB, _ptr(v_template), _ptr(shapedirs),
                                     _ptr(posedirs), _ptr(J_regressor), _ptr(parents), _ptr(lbs_weights), V, J,
                                     _ptr(verts), _ptr(joints), _ptr(A), _ptr(T), _ptr(so), _ptr(po), _ptr(ws1), _ptr(ws2),
@@ -289,8 +289,27 @@ def mlp_pack(params: dict, mode: int) -> torch.Tensor:
     return pack
 
 
-def mlp_forward(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bool = False) -> torch.Tensor:
-    """pts[n,4] = (x,y,z,valid) -> out[n,4] = (r,g,b,sigma), or sigma[n] if sigma_only."""
+def compact_valid(pts: torch.Tensor, fill: Optional[torch.Tensor] = None):
+    """-> (index[n] int32, count[1] int32 on the device): positions of the samples with valid >= 1
+    (`inside_inds`, models/anim_nerf.py:253).  fill[n,4] or fill[n]: rows of the other samples := (0,0,0,-1e5) / -1e5."""
+    lib = _lib.load()
+    pts = _dev(pts, "pts")
+    n = pts.numel() // 4
+    index = torch.empty(n, dtype=torch.int32, device=pts.device)
+    count = torch.empty(1, dtype=torch.int32, device=pts.device)
+    cols = 0 if fill is None else (4 if fill.dim() == 2 else 1)
+    with _timed("compact_valid", n):
+        _lib.check(lib.anr_compact_valid(_ptr(pts), n, _ptr(index), _ptr(count), _ptr(fill), cols, _stream(pts)),
+                   "anr_compact_valid")
+    return index, count
+
+
+def mlp_forward(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bool = False,
+                only_valid: bool = False) -> torch.Tensor:
+    """pts[n,4] = (x,y,z,valid) -> out[n,4] = (r,g,b,sigma), or sigma[n] if sigma_only.
+    only_valid: evaluate the samples with valid >= 1 only; the others get (0,0,0,-1e5) as in the reference's
+    query_canonical_space_inside (models/anim_nerf.py:245-290).  Sigma is the same either way; rgb of an invalid
+    sample differs (0 instead of the colour of a point that is never composited)."""
     lib = _lib.load()
     pts = _dev(pts, "pts")
     n = pts.numel() // 4
@@ -299,6 +318,12 @@ def mlp_forward(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bo
         out = torch.empty(n, dtype=torch.float32, device=pts.device)
     else:
         out = torch.empty(n, 4, dtype=torch.float32, device=pts.device)
+    if only_valid:
+        index, count = compact_valid(pts, fill=out)
+        with _timed("mlp_forward", count):                 # units resolved after the timed region (device counter)
+            _lib.check(lib.anr_mlp_forward_indexed(_ptr(pack), mode, _ptr(pts), _ptr(index), _ptr(count), n, _ptr(out),
+                                                   _stream(out)), "anr_mlp_forward_indexed")
+        return out
     with _timed("mlp_forward", n):
         _lib.check(lib.anr_mlp_forward(_ptr(pack), mode, _ptr(pts), n, _ptr(out), _stream(out)), "anr_mlp_forward")
     return out

@@ -60,7 +60,9 @@ class VolumeRenderer(nn.Module):
         fused = hasattr(model, "warped_points") and hasattr(model, "_net")
         if fused:
             pts = model.warped_points(rays=rays, z=z, skip_far=True)
-            out = model._net(not coarse).eval_points(pts)
+            # with the warp on, only samples near the body carry a density: the MLP runs on those (bit-identical
+            # render: the others composite with weight exactly 0)
+            out = model._net(not coarse).eval_points(pts, only_valid=getattr(model, "evaluate_valid_only", False))
         else:
             xyz = (rays[..., None, :3] + z[..., None] * rays[..., None, 3:6]).reshape(bs, -1, 3)
             viewdir = rays[..., None, 3:6].expand(-1, -1, K, -1).reshape(bs, -1, 3)

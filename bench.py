@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--sigma-gain", type=float, default=3000.0,
                     help="scale the sigma heads about their median (0 = literal random init, which renders a blank image)")
     ap.add_argument("--no-psnr", action="store_true")
+    ap.add_argument("--dense", action="store_true",
+                    help="cfg3/cfg4: run the MLP on every sample as the reference does, also on those outside dis_threshold "
+                         "(sigma = -1e5, composite weight 0); default: only on the valid ones — same image, bit for bit")
     return ap.parse_args()
 
 
@@ -88,6 +91,7 @@ def main():
                 net.mlp_mode = args.mode
                 net.sigma.weight.mul_(args.sigma_gain)
                 net.sigma.bias.mul_(args.sigma_gain).add_(-args.sigma_gain * med)
+    model.skip_invalid_samples = not args.dense
     vr = ana.VolumeRenderer(n_coarse=args.n_coarse, n_fine=args.n_fine, white_bkgd=True)
     H = W = args.hw
     c2w, focal, cen = syn.pinhole_camera(H, W)
@@ -123,7 +127,7 @@ def main():
     for name, e0, e1, units in timing:
         d = per_kernel.setdefault(name, [0.0, 0, 0])
         d[0] += e0.elapsed_time(e1) * 1e-3
-        d[1] += units
+        d[1] += int(units)                            # (a device counter where the MLP ran on a compacted list)
         d[2] += 1
     mlp_s, mlp_pts, mlp_launches = per_kernel.get("mlp_forward", [0.0, 0, 0])
     peak = PEAK_BF16_TFLOPS if args.mode == "bf16" else PEAK_F32_TFLOPS
@@ -151,6 +155,10 @@ def main():
             "rays_per_step_per_gpu": n_rays, "n_coarse": args.n_coarse, "n_fine": args.n_fine,
             "mlp_evals_per_ray": args.n_coarse + (args.n_coarse + args.n_fine if args.n_fine else 0),
             "chunk_rays": args.chunk, "sharding": f"{world} independent frames (ray-parallel, no collective)",
+            # warp on: samples farther than dis_threshold from the body are sigma = -1e5 / weight 0 whatever the MLP
+            # says; the MLP runs on the others only (identical image; --dense evaluates all of them like the reference)
+            "mlp_on_valid_samples_only": bool(model.evaluate_valid_only),
+            "mlp_points_per_step": mlp_pts // max(args.steps, 1),
         },
         "roofline": {
             "kernel": f"mlp_kernel<{args.mode}> (fused Fourier encoding + 11 GEMMs)",
@@ -193,6 +201,7 @@ def train_bench(args, rank, local_rank, world, dev):
     torch.manual_seed(0)
     model = ana.AnimNeRF(body_model_table=tbl, freqs_dir=0, use_view=False, use_unpose=True, use_knn=True,
                          use_fine=True, mlp_mode=args.mode).to(dev)
+    model.skip_invalid_samples = not args.dense
     hp = ana.TrainHParams(n_samples=64, n_importance=32, chunk=2048)
     F = args.frames_per_gpu
     table = ana.BodyModelParams(114).to(dev)                  # 114 training frames (configs/people_snapshot/male-3-casual.yaml)
@@ -230,7 +239,7 @@ def train_bench(args, rank, local_rank, world, dev):
     elapsed = ana.max_over_ranks(time.perf_counter() - t0, dev)
     timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
     mlp_s = sum(e0.elapsed_time(e1) for n, e0, e1, u in timing if n == "mlp_forward_save") * 1e-3
-    mlp_pts = sum(u for n, e0, e1, u in timing if n == "mlp_forward_save")
+    mlp_pts = sum(int(u) for n, e0, e1, u in timing if n == "mlp_forward_save")
     peak = PEAK_BF16_TFLOPS if args.mode == "bf16" else PEAK_F32_TFLOPS
     achieved = mlp_pts * MLP_FLOP_PER_POINT / mlp_s / 1e12 if mlp_s else 0.0
     n_rays = F * 1024
@@ -242,6 +251,8 @@ def train_bench(args, rank, local_rank, world, dev):
         "config": {"workload": "BASELINE configs[3] shape: train step, %d frames x 32x32 rays per GPU, 64 coarse + 32 fine, "
                                "perturb=1, rgb+alpha+fg/bg losses (no normals term), pose refinement on (optim_body_params), "
                                "flat-gradient all-reduce (4.7 MB) + Adam" % F,
+                   "mlp_on_valid_samples_only": bool(model.evaluate_valid_only),
+                   "mlp_rows_per_step": mlp_pts // max(args.steps, 1),
                    "rays_per_step_per_gpu": n_rays, "grad_floats": sum(p.numel() for p in trainer.params)},
         "roofline": {"kernel": f"mlp_kernel<{args.mode}, save> (training forward)", "bound": "mfma", "achieved": achieved,
                      "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None},

@@ -67,7 +67,8 @@ int anr_ray_gen(const float* c2w, const float* focal, const float* center,
  * J_regressor[J*V], parents[J] (int64, parents[0] = -1), lbs_weights[V*J].
  * Outputs: verts[bs*V*3], joints[bs*J*3] (posed, + transl; the 21 extra vertex-joints are a gather the caller does),
  * A[bs*J*16] and T[bs*V*16] (both with transl added to the translation column, body_models.py:373-374),
- * shape_off[bs*V*3], pose_off[bs*V*3].  Workspaces: ws_v_shaped[bs*V*3], ws_joints_rest[bs*J*3], ws_feat[bs*9(J-1)]. */
+ * shape_off[bs*V*3], pose_off[bs*V*3].  Workspaces: ws_v_shaped[bs*V*3], ws_joints_rest[bs*ceil(V/256)*J*3]
+ * (per-block partial sums of the joint regression, added in a fixed order: no float atomics), ws_feat[bs*9(J-1)]. */
 int anr_smpl_forward(const float* betas, const float* pose, const float* transl, int bs, int NB,
                      const float* v_template, const float* shapedirs, const float* posedirs,
                      const float* J_regressor, const int64_t* parents, const float* lbs_weights, int V, int J,
@@ -168,6 +169,23 @@ int anr_mlp_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream
 int anr_mlp_forward(const void* pack, int mode, const float* pts, int64_t n,
                     float* out, void* stream);
 
+/* Evaluate the field only where it is consumed.  With use_unpose=True most samples lie farther than dis_threshold
+ * from the body (93 % of the coarse samples on the synthetic frames): their sigma is the constant -1e5
+ * (models/anim_nerf.py:305), compositing gives them weight exactly 0, and their MLP output never reaches a result.
+ * The reference has the same idea as `query_inside` / `inside_inds` (models/anim_nerf.py:245-290: evaluate
+ * xyz[inside_inds], rgb = 0 and sigma = -1e5 elsewhere).
+ *
+ * anr_compact_valid: index_out[0..*count_out) = positions i with pts[4i+3] >= 1 (order preserved inside blocks of
+ * 1024 samples, block order unspecified); *count_out is a DEVICE int32 — no host synchronisation.  fill_out (may be
+ * NULL): rows of the invalid samples are set to (0,0,0,-1e5) (fill_cols = 4) or -1e5 (fill_cols = 1, sigma-only).
+ *
+ * anr_mlp_forward_indexed: for i < min(n, *count) (count may be NULL: all n): out[index[i]] = NeRF(pts[index[i]]);
+ * other rows of out are not touched.  index = NULL is anr_mlp_forward.  n bounds the launch (n < 2^31). */
+int anr_compact_valid(const float* pts, int64_t n, int32_t* index_out, int32_t* count_out,
+                      float* fill_out, int fill_cols, void* stream);
+int anr_mlp_forward_indexed(const void* pack, int mode, const float* pts, const int32_t* index,
+                            const int32_t* count, int64_t n, float* out, void* stream);
+
 /* Training forward: the same kernel, additionally storing each layer's post-activation output for the backward
  * pass (what autograd keeps alive in the reference, models/nerf.py:163-175): act[n * anr_mlp_act_cols()],
  * fp32 in mode ANR_MLP_F32 and bf16 in mode ANR_MLP_BF16 (the value the next layer consumed),
@@ -176,6 +194,9 @@ int anr_mlp_forward(const void* pack, int mode, const float* pts, int64_t n,
 int anr_mlp_act_cols(void);
 int anr_mlp_forward_save(const void* pack, int mode, const float* pts, int64_t n,
                          float* out, void* act, void* stream);
+/* ... on a compacted list (see anr_mlp_forward_indexed): activation row i belongs to sample index[i]. */
+int anr_mlp_forward_save_indexed(const void* pack, int mode, const float* pts, const int32_t* index,
+                                 const int32_t* count, int64_t n, float* out, void* act, void* stream);
 
 /* ---- sigma-grid points for mesh extraction -------------------------------------------------------
  * extract_mesh.py:27-35 (create_grid: np.meshgrid(x, y, z), 'xy' indexing, fp64 linspace -> fp32) and :152-157

@@ -310,9 +310,69 @@ def test_generic_model_path_equals_fused_path(dev, smpl_table):
     m.skip_far_samples = True
     for k in fused:
         assert torch.equal(fused[k], exact_everywhere[k]), k
+    # ... and neither must running the MLP on the valid samples only (the others composite with weight exactly 0)
+    m.skip_invalid_samples = False
+    dense = vr(m, rays)
+    m.skip_invalid_samples = True
+    for k in fused:
+        assert torch.equal(fused[k], dense[k]), k
     generic = vr(lambda xyz, viewdir, use_fine=False: m(xyz, viewdir, use_fine=use_fine), rays)
     for k in fused:                 # same kernels; only x = o + z d is rounded differently (see conditioning note)
         torch.testing.assert_close(generic[k], fused[k], rtol=2e-3, atol=2e-4)
+
+
+def test_compact_valid_and_indexed_mlp(dev, smpl_table):
+    """anr_compact_valid lists exactly the samples with valid >= 1; anr_mlp_forward_indexed gives those the bits the
+    dense kernel gives them and leaves (0,0,0,-1e5) elsewhere (query_canonical_space_inside, models/anim_nerf.py:245-290)."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import ops
+    torch.manual_seed(3)
+    net = ana.NeRF(freqs_dir=0, use_view=False).to(dev)
+    for n, frac in ((1, 1.0), (1, 0.0), (1023, 0.07), (70001, 0.07), (70001, 0.0), (4096, 1.0), (300000, 0.5)):
+        g = torch.Generator().manual_seed(n)
+        xyz = torch.rand(n, 3, generator=g) * 2 - 1
+        valid = (torch.rand(n, 1, generator=g) < frac).float()
+        pts = torch.cat([xyz, valid], 1).to(dev)
+        fill = torch.full((n, 4), 7.0, device=dev)
+        index, count = ops.compact_valid(pts, fill=fill)
+        cnt = int(count.item())
+        want = torch.nonzero(valid[:, 0] >= 1)[:, 0]
+        assert cnt == want.numel()
+        assert torch.equal(index[:cnt].long().sort().values.cpu(), want)
+        inv = (valid[:, 0] < 1).to(dev)
+        assert torch.equal(fill[inv], torch.tensor([0.0, 0.0, 0.0, -1e5], device=dev).expand(int(inv.sum()), 4))
+        assert (fill[~inv] == 7.0).all()
+        for mode in ("f32", "bf16"):
+            pack, mode_id = net.weight_pack(mode)
+            dense = ops.mlp_forward(pack, mode_id, pts)
+            sparse = ops.mlp_forward(pack, mode_id, pts, only_valid=True)
+            assert torch.equal(sparse[~inv], dense[~inv]), (n, frac, mode)
+            assert torch.equal(sparse[inv], fill[inv])
+            assert torch.equal(dense[inv][:, 3], fill[inv][:, 3])
+            s_dense = ops.mlp_forward(pack, mode_id, pts, sigma_only=True)
+            s_sparse = ops.mlp_forward(pack, mode_id, pts, sigma_only=True, only_valid=True)
+            assert torch.equal(s_dense, s_sparse)
+
+
+def test_query_inside(dev, smpl_table):
+    """AnimNeRF(query_inside=True): sigma as query_inside=False, rgb = 0 where the warp is invalid."""
+    g = golden("render_cfg3_warp_gain")
+    outs = []
+    for qi in (False, True):
+        m = seeded_model(smpl_table, g["seed"], True, g["gain"], g["shift"], device=dev)
+        m.query_inside = qi
+        with torch.no_grad():
+            m.set_body_model(_to(tdict(g), dev), _templ(dev))
+            rays = m.convert_to_body_model_space(torch.from_numpy(g["rays_world"]).to(dev))
+            m.clac_ober2cano_transform()
+            z = torch.linspace(2.0, 4.0, 48, device=dev).expand(1, rays.shape[1], 48)
+            xyz = (rays[..., None, :3] + z[..., None] * rays[..., None, 3:6]).reshape(1, -1, 3)
+            outs.append(m(xyz))
+    (rgb0, sig0), (rgb1, sig1) = outs
+    assert torch.equal(sig0, sig1)
+    inv = sig0[..., 0] == -1e5
+    assert 0.02 < (~inv).float().mean() < 0.9
+    assert torch.equal(rgb1[~inv], rgb0[~inv]) and (rgb1[inv] == 0).all()
 
 
 # ----------------------------------------------------------------------------- full BASELINE size
@@ -387,6 +447,12 @@ def test_smpl_kernels_match_oracle(dev, smpl_table):
     for k in ("vertices", "joints", "joints_transform", "vertices_transform", "shape_offsets", "pose_offsets"):
         assert o[k].shape == ref[k].shape, k
         torch.testing.assert_close(o[k].cpu(), ref[k], rtol=1e-5, atol=3e-6, msg=lambda m: f"{k}: {m}")
+    # the frame state is reproducible bit for bit (no float atomics in the joint regression)
+    with torch.no_grad():
+        for _ in range(3):
+            again = bm(**{k: v.to(dev) for k, v in pose.items()})
+            for k in ("vertices", "joints", "joints_transform", "vertices_transform"):
+                assert torch.equal(again[k], o[k]), k
     # the autograd form (pose refinement) agrees with the kernels
     g = {k: v.to(dev).requires_grad_(True) for k, v in pose.items()}
     o2 = bm(**g)

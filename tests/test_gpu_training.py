@@ -49,8 +49,9 @@ def test_composite_backward_matches_autograd(dev):
         assert not w.requires_grad
 
 
+@pytest.mark.parametrize("only_valid", [False, True])
 @pytest.mark.parametrize("sigma_only", [False, True])
-def test_mlp_backward_matches_autograd(dev, smpl_table, sigma_only):
+def test_mlp_backward_matches_autograd(dev, smpl_table, sigma_only, only_valid):
     m = seeded_model(smpl_table, 7, True, gain=50.0, device=dev)
     net = m.nerf
     gen = torch.Generator().manual_seed(2)
@@ -58,10 +59,17 @@ def test_mlp_backward_matches_autograd(dev, smpl_table, sigma_only):
     xyz = torch.rand(n, 3, generator=gen) * 2 - 1
     pts = torch.cat([xyz, torch.ones(n, 1)], -1)
     pts[::11, 3] = 0.0                                          # invalid points: sigma is a constant there
+    if only_valid:
+        pts[100:300, 3] = 0.0
     g = torch.randn(n, 1 if sigma_only else 4, generator=gen)
+    if only_valid:                                              # the renderer's case: an invalid sample has composite
+        g[pts[:, 3] < 1] = 0.0                                  # weight 0, so nothing flows into its colour either
     # HIP forward (+ saved activations) and backward
-    out = net.eval_points(pts.to(dev), "f32", sigma_only=sigma_only)
+    out = net.eval_points(pts.to(dev), "f32", sigma_only=sigma_only, only_valid=only_valid)
     assert out.requires_grad
+    if only_valid:
+        inv = (pts[:, 3] < 1).to(dev)
+        assert (out.reshape(n, -1)[inv][:, -1] == -1e5).all() and (out.reshape(n, -1)[inv][:, :-1] == 0).all()
     (out.reshape(n, -1) * g.to(dev)).sum().backward()
     # oracle autograd
     P = {k: v.clone().requires_grad_(True) for k, v in net_params(net).items()}
