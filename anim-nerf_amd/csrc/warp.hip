@@ -203,6 +203,79 @@ __device__ __forceinline__ void stage_index(const float* __restrict__ index, int
     __syncthreads();
 }
 
+// Blend the four neighbours (models/anim_nerf.py:165-192) and store the canonical point; best.i are index slots.
+__device__ __forceinline__ void blend_and_store(const Best4& best, const int32_t* __restrict__ order,
+                                                const float* __restrict__ lbs_w, int J, const float* __restrict__ O2C,
+                                                float thr, float px, float py, float pz, int64_t o,
+                                                float4* __restrict__ pts_out, float* __restrict__ dist_out,
+                                                int32_t* __restrict__ idx_out, float* __restrict__ blended_out,
+                                                int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w) {
+    float dist[4], conf[4], w[4];
+    int vid[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { dist[k] = sqrtf(best.d[k]); vid[k] = order[best.i[k]]; }
+    // blend-weight confidence against neighbour 0 (anim_nerf.py:165-168); rows are read as float4 (J % 4 == 0,
+    // 16-B aligned rows): one request per 16 B instead of per float on this uncoalesced gather
+    conf[0] = 1.0f;
+    if ((J & 3) == 0) {
+        const float4* r0 = reinterpret_cast<const float4*>(lbs_w + (int64_t)vid[0] * J);
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const float4* r1 = reinterpret_cast<const float4*>(lbs_w + (int64_t)vid[1] * J);
+        const float4* r2 = reinterpret_cast<const float4*>(lbs_w + (int64_t)vid[2] * J);
+        const float4* r3 = reinterpret_cast<const float4*>(lbs_w + (int64_t)vid[3] * J);
+        for (int q = 0; q < (J >> 2); ++q) {
+            const float4 a = r0[q], b1 = r1[q], b2 = r2[q], b3 = r3[q];
+            s1 += fabsf(b1.x - a.x) + fabsf(b1.y - a.y) + fabsf(b1.z - a.z) + fabsf(b1.w - a.w);
+            s2 += fabsf(b2.x - a.x) + fabsf(b2.y - a.y) + fabsf(b2.z - a.z) + fabsf(b2.w - a.w);
+            s3 += fabsf(b3.x - a.x) + fabsf(b3.y - a.y) + fabsf(b3.z - a.z) + fabsf(b3.w - a.w);
+        }
+        conf[1] = (expf(-s1 / 0.02f) > 0.9f) ? 1.0f : 0.0f;
+        conf[2] = (expf(-s2 / 0.02f) > 0.9f) ? 1.0f : 0.0f;
+        conf[3] = (expf(-s3 / 0.02f) > 0.9f) ? 1.0f : 0.0f;
+    } else {
+        const float* w0 = lbs_w + (int64_t)vid[0] * J;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            const float* wk = lbs_w + (int64_t)vid[k] * J;
+            float s = 0.f;
+            for (int j = 0; j < J; ++j) s += fabsf(wk[j] - w0[j]);
+            conf[k] = (expf(-s / 0.02f) > 0.9f) ? 1.0f : 0.0f;
+        }
+    }
+    float wsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { w[k] = expf(-dist[k]) * conf[k]; wsum += w[k]; }
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+    float db = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        w[k] = w[k] / wsum;
+        const float4* M = reinterpret_cast<const float4*>(O2C + (int64_t)vid[k] * 16);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float4 m = M[r];
+            T[r * 4 + 0] += w[k] * m.x; T[r * 4 + 1] += w[k] * m.y;
+            T[r * 4 + 2] += w[k] * m.z; T[r * 4 + 3] += w[k] * m.w;
+        }
+        db += w[k] * dist[k];
+    }
+    float cx = T[0] * px + T[1] * py + T[2] * pz + T[3];
+    float cy = T[4] * px + T[5] * py + T[6] * pz + T[7];
+    float cz = T[8] * px + T[9] * py + T[10] * pz + T[11];
+    pts_out[o] = make_float4(cx, cy, cz, db < thr ? 1.0f : 0.0f);
+    if (nbr_w != nullptr) {                  // what the backward pass needs: blend weights and vertex ids
+        reinterpret_cast<float4*>(nbr_w)[o] = make_float4(w[0], w[1], w[2], w[3]);
+        reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(vid[0], vid[1], vid[2], vid[3]);
+    }
+    if (dist_out != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { dist_out[o * 4 + k] = dist[k]; idx_out[o * 4 + k] = vid[k]; }
+        blended_out[o] = db;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // reference: models/anim_nerf.py:153-192 (get_neighbs + unpose), volume_rendering.py:117
 // Work item = 64 points handled by one wavefront:
@@ -319,70 +392,108 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_points_kernel(
         }
         if (!go) continue;
 
-        float dist[4], conf[4], w[4];
-        int vid[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { dist[k] = sqrtf(best.d[k]); vid[k] = order[best.i[k]]; }
-        // blend-weight confidence against neighbour 0 (anim_nerf.py:165-168); rows are read as float4 (J % 4 == 0,
-        // 16-B aligned rows): one request per 16 B instead of per float on this uncoalesced gather
-        conf[0] = 1.0f;
-        if ((J & 3) == 0) {
-            const float4* r0 = reinterpret_cast<const float4*>(lbs_w + (int64_t)vid[0] * J);
-            float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            const float4* r1 = reinterpret_cast<const float4*>(lbs_w + (int64_t)vid[1] * J);
-            const float4* r2 = reinterpret_cast<const float4*>(lbs_w + (int64_t)vid[2] * J);
-            const float4* r3 = reinterpret_cast<const float4*>(lbs_w + (int64_t)vid[3] * J);
-            for (int q = 0; q < (J >> 2); ++q) {
-                const float4 a = r0[q], b1 = r1[q], b2 = r2[q], b3 = r3[q];
-                s1 += fabsf(b1.x - a.x) + fabsf(b1.y - a.y) + fabsf(b1.z - a.z) + fabsf(b1.w - a.w);
-                s2 += fabsf(b2.x - a.x) + fabsf(b2.y - a.y) + fabsf(b2.z - a.z) + fabsf(b2.w - a.w);
-                s3 += fabsf(b3.x - a.x) + fabsf(b3.y - a.y) + fabsf(b3.z - a.z) + fabsf(b3.w - a.w);
-            }
-            conf[1] = (expf(-s1 / 0.02f) > 0.9f) ? 1.0f : 0.0f;
-            conf[2] = (expf(-s2 / 0.02f) > 0.9f) ? 1.0f : 0.0f;
-            conf[3] = (expf(-s3 / 0.02f) > 0.9f) ? 1.0f : 0.0f;
+        blend_and_store(best, order, lbs_w, J, O2C, thr, px, py, pz, o, pts_out, dist_out, idx_out, blended_out, nbr_idx, nbr_w);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Renderer path in two passes (skip_far with a workspace).  Most samples of a frame are empty space, and the ones
+// near the body sit in a narrow depth band of some of the rays: in a wavefront of 64 neighbouring rays at one sample
+// index only a few lanes have anything to search for.  So:
+//   pass 1 (classify): x = o' + z d' for every sample, (x, 0) written, and the samples within dis_threshold of the
+//           body's bounding box appended to a list (order preserved inside blocks of 1024 samples = runs of
+//           consecutive samples of neighbouring rays);
+//   pass 2 (search):   persistent workgroups with the frame's index staged in LDS walk the list 64 entries per
+//           wavefront — every lane busy, and the 64 points of an item are neighbours in space, which is what the
+//           wave-uniform cluster traversal wants.
+// Workspace per call: int32 ws[bs * N + 2 * bs] = list[bs][N] | count[bs] | cursor[bs].
+template <bool FROM_RAYS>
+__global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
+    const float* __restrict__ xyz, int xyz_stride, const float* __restrict__ rays, int ray_stride,
+    const float* __restrict__ z, int K, const float* __restrict__ index, IndexDims d, int64_t N, float thr,
+    float4* __restrict__ pts_out, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w, int32_t* __restrict__ list,
+    int32_t* __restrict__ count) {
+    __shared__ int wave_cnt[WARP_THREADS / 64];
+    __shared__ int block_base;
+    const int b = blockIdx.y;
+    const float* gbox = index + (int64_t)b * d.total_floats() + d.body_off();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * WARP_THREADS + threadIdx.x;
+    bool near = false;
+    if (n < N) {
+        float px, py, pz;
+        if (FROM_RAYS) {
+            const int64_t R = N / K;
+            const float* ry = rays + ((int64_t)b * R + n / K) * ray_stride;
+            const float zz = z[(int64_t)b * N + n];
+            px = __fadd_rn(ry[0], __fmul_rn(zz, ry[3]));
+            py = __fadd_rn(ry[1], __fmul_rn(zz, ry[4]));
+            pz = __fadd_rn(ry[2], __fmul_rn(zz, ry[5]));
         } else {
-            const float* w0 = lbs_w + (int64_t)vid[0] * J;
-#pragma unroll
-            for (int k = 1; k < 4; ++k) {
-                const float* wk = lbs_w + (int64_t)vid[k] * J;
-                float s = 0.f;
-                for (int j = 0; j < J; ++j) s += fabsf(wk[j] - w0[j]);
-                conf[k] = (expf(-s / 0.02f) > 0.9f) ? 1.0f : 0.0f;
-            }
+            const float* sp = xyz + ((int64_t)b * N + n) * xyz_stride;
+            px = sp[0]; py = sp[1]; pz = sp[2];
         }
-        float wsum = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { w[k] = expf(-dist[k]) * conf[k]; wsum += w[k]; }
-        float T[12];
-#pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = 0.f;
-        float db = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            w[k] = w[k] / wsum;
-            const float4* M = reinterpret_cast<const float4*>(O2C + (int64_t)vid[k] * 16);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                float4 m = M[r];
-                T[r * 4 + 0] += w[k] * m.x; T[r * 4 + 1] += w[k] * m.y;
-                T[r * 4 + 2] += w[k] * m.z; T[r * 4 + 3] += w[k] * m.w;
-            }
-            db += w[k] * dist[k];
+        const int64_t o = (int64_t)b * N + n;
+        pts_out[o] = make_float4(px, py, pz, 0.0f);
+        if (nbr_w != nullptr) {
+            reinterpret_cast<float4*>(nbr_w)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+            reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(0, 0, 0, 0);
         }
-        float cx = T[0] * px + T[1] * py + T[2] * pz + T[3];
-        float cy = T[4] * px + T[5] * py + T[6] * pz + T[7];
-        float cz = T[8] * px + T[9] * py + T[10] * pz + T[11];
-        pts_out[o] = make_float4(cx, cy, cz, db < thr ? 1.0f : 0.0f);
-        if (nbr_w != nullptr) {                  // what the backward pass needs: blend weights and vertex ids
-            reinterpret_cast<float4*>(nbr_w)[o] = make_float4(w[0], w[1], w[2], w[3]);
-            reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(vid[0], vid[1], vid[2], vid[3]);
-        }
-        if (dist_out != nullptr) {
+        // farther than the threshold from the whole body -> cannot be valid (see warp_points_kernel)
+        near = box_d2(gbox, px, py, pz) < thr * thr;
+    }
+    const unsigned long long m = __ballot(near);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { dist_out[o * 4 + k] = dist[k]; idx_out[o * 4 + k] = vid[k]; }
-            blended_out[o] = db;
+        for (int w = 0; w < WARP_THREADS / 64; ++w) { int c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
+        block_base = tot ? atomicAdd(count + b, tot) : 0;
+    }
+    __syncthreads();
+    if (near) list[(int64_t)b * N + block_base + wave_cnt[wave] + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)n;
+}
+
+__global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
+    const float* __restrict__ index, IndexDims d, const float* __restrict__ ober2cano, const float* __restrict__ lbs_w,
+    int J, int64_t N, float thr, float4* __restrict__ pts_out, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w,
+    const int32_t* __restrict__ list, const int32_t* __restrict__ count, int32_t* __restrict__ cursor) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.y;
+    const int cnt = count[b];
+    const int n_items = (cnt + 63) >> 6;
+    if ((int)blockIdx.x * (WARP_THREADS / 64) >= n_items) return;        // nothing left for this workgroup
+    const float* my_index = index + (int64_t)b * d.total_floats();
+    const int32_t* order = reinterpret_cast<const int32_t*>(my_index + d.order_off());
+    const float* O2C = ober2cano + (int64_t)b * d.V * 16;
+    const int32_t* my_list = list + (int64_t)b * N;
+    const int lane = threadIdx.x & 63;
+    stage_index(my_index, d.lds_floats(), lds);
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(cursor + b, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const int i = item * 64 + lane;
+        const bool go = i < cnt;
+        const int64_t o = (int64_t)b * N + my_list[go ? i : cnt - 1];
+        const float4 p = pts_out[o];
+        // search inside the validity radius first: nothing there -> invalid, (x, 0) is already in place; four or
+        // more -> the exact 4-NN; 1-3 -> repeat unbounded (see warp_points_kernel)
+        Best4 best;
+        best_init(best, thr * thr * 1.0002f);
+        search(lds, d, p.x, p.y, p.z, go, best);
+        const bool none = best.i[0] < 0;
+        const bool partial = go && !none && best.i[3] < 0;
+        if (__any(partial)) {
+            Best4 full;
+            best_init(full);
+            search(lds, d, p.x, p.y, p.z, partial, full);
+            if (partial) best = full;
         }
+        if (!go || none) continue;
+        blend_and_store(best, order, lbs_w, J, O2C, thr, p.x, p.y, p.z, o, pts_out, nullptr, nullptr, nullptr, nbr_idx, nbr_w);
     }
 }
 
@@ -501,7 +612,7 @@ extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* ra
                                int K, const void* knn_index, const float* ober2cano, const float* lbs_weights, int bs,
                                int V, int J, int64_t N, float dis_threshold, int skip_far, float* pts_out,
                                float* dist_out, int32_t* idx_out, float* blended_out, int32_t* nbr_idx_out,
-                               float* nbr_w_out, void* stream) {
+                               float* nbr_w_out, int32_t* ws, void* stream) {
     ANR_REQUIRE(knn_index && ober2cano && lbs_weights && pts_out, ANR_E_BADARG, "anr_warp_points: null pointer");
     ANR_REQUIRE((xyz != nullptr) || (rays != nullptr && z != nullptr), ANR_E_BADARG,
                 "anr_warp_points: need xyz or (rays, z)");
@@ -522,6 +633,36 @@ extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* ra
     ANR_REQUIRE(bytes <= 160 * 1024, ANR_E_SHAPE, "anr_warp_points: V=%d needs %d B of LDS (>160 KiB)", V, bytes);
     hipStream_t st = (hipStream_t)stream;
     const float* index = reinterpret_cast<const float*>(knn_index);
+    if (skip_far && ws != nullptr) {
+        // two passes: classify + compact, then search the compacted list (see warp_classify_kernel)
+        ANR_REQUIRE(dist_out == nullptr, ANR_E_BADARG, "anr_warp_points: debug outputs need skip_far = 0");
+        ANR_REQUIRE(N < (int64_t)1 << 31, ANR_E_BADARG, "anr_warp_points: N=%lld does not fit the int32 list", (long long)N);
+        int32_t* list = ws;
+        int32_t* count = ws + (int64_t)bs * N;
+        int32_t* cursor = count + bs;
+        hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t) * 2 * bs, st);
+        if (e != hipSuccess) return fail((int)e, "anr_warp_points: hipMemsetAsync: %s", hipGetErrorString(e));
+        dim3 g1((unsigned)((N + WARP_THREADS - 1) / WARP_THREADS), bs);
+        if (xyz == nullptr)
+            hipLaunchKernelGGL(warp_classify_kernel<true>, g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride, z,
+                               K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
+                               list, count);
+        else
+            hipLaunchKernelGGL(warp_classify_kernel<false>, g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride,
+                               z, K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
+                               list, count);
+        if (int rc = check_launch("anr_warp_points (classify)")) return rc;
+        if (int rc = allow_big_lds(warp_search_kernel, bytes, "anr_warp_points")) return rc;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        int64_t gx = (cus + bs - 1) / bs;                                   // one persistent workgroup per CU in total
+        const int64_t max_wg = (N + 64 * (WARP_THREADS / 64) - 1) / (64 * (WARP_THREADS / 64));
+        if (gx > max_wg) gx = max_wg;
+        hipLaunchKernelGGL(warp_search_kernel, dim3((unsigned)gx, bs), dim3(WARP_THREADS), bytes, st, index, d, ober2cano,
+                           lbs_weights, J, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
+                           list, count, cursor);
+        return check_launch("anr_warp_points (search)");
+    }
     if (xyz == nullptr) {
         if (int rc = allow_big_lds(warp_points_kernel<true>, bytes, "anr_warp_points")) return rc;
         const int64_t R = N / K;

@@ -188,7 +188,7 @@ def sample_coarse(rays: torch.Tensor, steps: torch.Tensor, t_rand: Optional[torc
 
 
 def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays=None, z=None, debug=False,
-                skip_far=False, neighbours=False):
+                skip_far=False, neighbours=False, two_pass=True):
     """models/anim_nerf.py:153-192.  Either xyz[bs,N,3|4] or (rays[bs,R,>=8], z[bs,R,K]).
     `index` = knn_index_build(posed verts).  Returns pts[bs,N,4] = (x_c, y_c, z_c, valid)
     (+ dist[bs,N,4], idx[bs,N,4] i32, blended[bs,N] if debug)."""
@@ -219,10 +219,12 @@ def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
     if neighbours:                       # training: vertex ids + blend weights of the 4 neighbours (zeros where skipped)
         nidx = torch.empty(bs, N, 4, dtype=torch.int32, device=dev)
         nw = torch.empty(bs, N, 4, dtype=torch.float32, device=dev)
+    # renderer mode: classify + compact the samples near the body, then search the compacted list
+    ws = torch.empty(bs * N + 2 * bs, dtype=torch.int32, device=dev) if (skip_far and two_pass) else None
     with _timed("warp_points", bs * N):
         _lib.check(lib.anr_warp_points(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(index), _ptr(o2c),
                                        _ptr(lbs_weights), bs, V, J, N, float(dis_threshold), 1 if skip_far else 0,
-                                       _ptr(pts), _ptr(dist), _ptr(idx), _ptr(blended), _ptr(nidx), _ptr(nw),
+                                       _ptr(pts), _ptr(dist), _ptr(idx), _ptr(blended), _ptr(nidx), _ptr(nw), _ptr(ws),
                                        _stream(pts)),
                    "anr_warp_points")
     if neighbours:

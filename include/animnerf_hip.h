@@ -128,13 +128,17 @@ int anr_sample_coarse(const float* rays, int stride, const float* steps, const f
  *   blended_out[bs*N].
  * Optional training outputs (both or neither): nbr_idx_out[bs*N*4] (int32 vertex ids) and nbr_w_out[bs*N*4]
  *   (normalised blend weights, anim_nerf.py:169-171; zeros for samples skipped by skip_far) — what the backward
- *   pass needs to route dL/dx_c into ober2cano and into the sample position. */
+ *   pass needs to route dL/dx_c into ober2cano and into the sample position.
+ * ws (may be NULL; used with skip_far != 0): int32 workspace of bs*N + 2*bs elements.  With it the call runs in two
+ *   passes — classify every sample against the body's bounding box and compact the near ones into a list, then
+ *   search the list 64 entries per wavefront (all lanes busy, spatially coherent) — instead of one pass in which a
+ *   wavefront of 64 neighbouring rays searches for its few near samples.  Same results bit for bit. */
 int anr_warp_points(const float* xyz, int xyz_stride,
                     const float* rays, int ray_stride, const float* z, int K,
                     const void* knn_index, const float* ober2cano, const float* lbs_weights,
                     int bs, int V, int J, int64_t N, float dis_threshold, int skip_far,
                     float* pts_out, float* dist_out, int32_t* idx_out, float* blended_out,
-                    int32_t* nbr_idx_out, float* nbr_w_out, void* stream);
+                    int32_t* nbr_idx_out, float* nbr_w_out, int32_t* ws, void* stream);
 
 /* Backward of anr_warp_points (rays mode) for pose refinement (a16): d_pts[bs*N*4] (w component ignored) ->
  * d_ober2cano[bs*V*16] and d_rays[bs*R*8] (ACCUMULATED with atomics: zero them first), d_z[bs*N] (written).

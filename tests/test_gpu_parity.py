@@ -143,6 +143,30 @@ def test_warp_from_rays_equals_explicit_points(dev, smpl_table):
     assert ((a[..., :3].cpu() - xc).abs().max(-1).values < 1e-4).float().mean() > 0.998
 
 
+def test_warp_two_pass_equals_one_pass(dev, smpl_table):
+    """Renderer mode (skip_far): classify + compact + search-the-list gives the bits of the one-pass kernel, which on
+    valid samples are the bits of the exact search everywhere; bs = 2, rays and explicit points, neighbour outputs."""
+    import anim_nerf_amd as ana
+    m = _warp_frame(dev, smpl_table)
+    g = golden("frame")
+    rays = torch.from_numpy(g["rays_body"]).to(dev)
+    args = (m.knn_index(), m.ober2cano_transform, m.body_model.lbs_weights, 0.2)
+    for K in (16, 33):
+        z = ana.VolumeRenderer(n_coarse=K).sample_coarse(rays)
+        one = ana.ops.warp_points(*args, rays=rays, z=z, skip_far=True, neighbours=True, two_pass=False)
+        two = ana.ops.warp_points(*args, rays=rays, z=z, skip_far=True, neighbours=True, two_pass=True)
+        for a, b in zip(one, two):
+            assert torch.equal(a, b)
+        exact = ana.ops.warp_points(*args, rays=rays, z=z, skip_far=False)
+        v = exact[..., 3] == 1
+        assert 0.01 < v.float().mean() < 0.9
+        assert torch.equal(two[0][..., 3], exact[..., 3]) and torch.equal(two[0][v], exact[v])
+    xyz = (rays[..., None, :3] + z[..., None] * rays[..., None, 3:6]).reshape(2, -1, 3).contiguous()
+    one = ana.ops.warp_points(*args, xyz=xyz, skip_far=True, two_pass=False)
+    two = ana.ops.warp_points(*args, xyz=xyz, skip_far=True, two_pass=True)
+    assert torch.equal(one, two)
+
+
 # ----------------------------------------------------------------------------- a11-a12
 @pytest.mark.parametrize("flag", [0, 0x100], ids=["lds_dma", "reg_staged"])
 def test_mlp_fp32_matches_reference(dev, smpl_table, flag):
