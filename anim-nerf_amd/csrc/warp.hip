@@ -400,59 +400,197 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_points_kernel(
 // Renderer path in two passes (skip_far with a workspace).  Most samples of a frame are empty space, and the ones
 // near the body sit in a narrow depth band of some of the rays: in a wavefront of 64 neighbouring rays at one sample
 // index only a few lanes have anything to search for.  So:
-//   pass 1 (classify): x = o' + z d' for every sample, (x, 0) written, and the samples within dis_threshold of the
-//           body's bounding box appended to a list (order preserved inside blocks of 1024 samples = runs of
-//           consecutive samples of neighbouring rays);
-//   pass 2 (search):   persistent workgroups with the frame's index staged in LDS walk the list 64 entries per
-//           wavefront — every lane busy, and the 64 points of an item are neighbours in space, which is what the
-//           wave-uniform cluster traversal wants.
-// Workspace per call: int32 ws[bs * N + 2 * bs] = list[bs][N] | count[bs] | cursor[bs].
+//   pass 1 (classify): x = o' + z d' for every sample, (x, 0) written; the samples within dis_threshold of the
+//           body's bounding box are appended to a list together with the id of the grid cell they fall in
+//           (64^3 cells of >= 4 cm over the bounding box), and the cell's counter is bumped;
+//   pass 2 (bin):      exclusive scan of the cell counters, then a counting-sort scatter of the list by cell;
+//   pass 3 (search):   persistent workgroups with the frame's index staged in LDS walk the cell-sorted list 64
+//           entries per wavefront — every lane busy, and the 64 points of an item lie in one or two neighbouring
+//           cells, so the lanes of the wave-uniform cluster traversal all want the same few clusters.
+// The order inside a cell depends on scheduling; every lane's search is independent of its wave-mates, so the
+// results do not.  Workspace: anr_warp_ws_ints(bs, N) int32.
+constexpr int GRID = 64;
+constexpr int NCELL = GRID * GRID * GRID;
+constexpr float MIN_CELL = 0.04f;
+
+struct WarpWs {
+    int32_t *list, *cells, *sorted, *count, *cursor, *cell_count, *cell_start;
+    __host__ static int64_t ints(int bs, int64_t N) { return 3 * (int64_t)bs * N + 2 * bs + 2 * (int64_t)bs * NCELL; }
+    __host__ WarpWs(int32_t* ws, int bs, int64_t N) {
+        list = ws; cells = list + (int64_t)bs * N; sorted = cells + (int64_t)bs * N; count = sorted + (int64_t)bs * N;
+        cursor = count + bs; cell_count = cursor + bs; cell_start = cell_count + (int64_t)bs * NCELL;
+    }
+};
+
+__device__ __forceinline__ int cell_of(const float* gbox, float thr, float px, float py, float pz) {
+    const float ex = gbox[4] - gbox[0], ey = gbox[5] - gbox[1], ez = gbox[6] - gbox[2];
+    const float c = fmaxf(MIN_CELL, (fmaxf(fmaxf(ex, ey), ez) + 2.0f * thr) * (1.0f / GRID));
+    const float inv = 1.0f / c;
+    const int ix = min(max((int)((px - gbox[0] + thr) * inv), 0), GRID - 1);
+    const int iy = min(max((int)((py - gbox[1] + thr) * inv), 0), GRID - 1);
+    const int iz = min(max((int)((pz - gbox[2] + thr) * inv), 0), GRID - 1);
+    return (ix * GRID + iy) * GRID + iz;
+}
+
+// Per-workgroup aggregation of the cell counters: neighbouring rays and consecutive samples fall into the same few
+// cells, and one global atomic per sample on those hot counters costs more than the search it prepares.  A workgroup
+// counts in an LDS hash table (cell -> count) and touches the global counter once per distinct cell.
+constexpr int HN = 2048;                       // hash slots per workgroup
+__device__ __forceinline__ int hash_slot(int* keys, int cell) {
+    unsigned s = ((unsigned)cell * 2654435761u) >> 21;
+#pragma unroll 1
+    for (int t = 0; t < 16; ++t) {
+        const int prev = atomicCAS(&keys[s], -1, cell);
+        if (prev == -1 || prev == cell) return (int)s;
+        s = (s + 1) & (HN - 1);
+    }
+    return -1;                                 // table crowded: the caller falls back to the global counter
+}
+
+constexpr int CLS_ITERS = 8;                   // samples per classify workgroup = 8 x 1024
 template <bool FROM_RAYS>
 __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
     const float* __restrict__ xyz, int xyz_stride, const float* __restrict__ rays, int ray_stride,
     const float* __restrict__ z, int K, const float* __restrict__ index, IndexDims d, int64_t N, float thr,
     float4* __restrict__ pts_out, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w, int32_t* __restrict__ list,
-    int32_t* __restrict__ count) {
+    int32_t* __restrict__ cells, int32_t* __restrict__ count, int32_t* __restrict__ cell_count) {
     __shared__ int wave_cnt[WARP_THREADS / 64];
     __shared__ int block_base;
+    __shared__ int hkeys[HN], hcnt[HN];
     const int b = blockIdx.y;
     const float* gbox = index + (int64_t)b * d.total_floats() + d.body_off();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t n = (int64_t)blockIdx.x * WARP_THREADS + threadIdx.x;
-    bool near = false;
-    if (n < N) {
-        float px, py, pz;
-        if (FROM_RAYS) {
-            const int64_t R = N / K;
-            const float* ry = rays + ((int64_t)b * R + n / K) * ray_stride;
-            const float zz = z[(int64_t)b * N + n];
-            px = __fadd_rn(ry[0], __fmul_rn(zz, ry[3]));
-            py = __fadd_rn(ry[1], __fmul_rn(zz, ry[4]));
-            pz = __fadd_rn(ry[2], __fmul_rn(zz, ry[5]));
-        } else {
-            const float* sp = xyz + ((int64_t)b * N + n) * xyz_stride;
-            px = sp[0]; py = sp[1]; pz = sp[2];
-        }
-        const int64_t o = (int64_t)b * N + n;
-        pts_out[o] = make_float4(px, py, pz, 0.0f);
-        if (nbr_w != nullptr) {
-            reinterpret_cast<float4*>(nbr_w)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
-            reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(0, 0, 0, 0);
-        }
-        // farther than the threshold from the whole body -> cannot be valid (see warp_points_kernel)
-        near = box_d2(gbox, px, py, pz) < thr * thr;
-    }
-    const unsigned long long m = __ballot(near);
-    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    for (int s = threadIdx.x; s < HN; s += WARP_THREADS) { hkeys[s] = -1; hcnt[s] = 0; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int tot = 0;
+    for (int it = 0; it < CLS_ITERS; ++it) {
+        const int64_t n = ((int64_t)blockIdx.x * CLS_ITERS + it) * WARP_THREADS + threadIdx.x;
+        bool near = false;
+        int cell = 0;
+        if (n < N) {
+            float px, py, pz;
+            if (FROM_RAYS) {
+                const int64_t R = N / K;
+                const float* ry = rays + ((int64_t)b * R + n / K) * ray_stride;
+                const float zz = z[(int64_t)b * N + n];
+                px = __fadd_rn(ry[0], __fmul_rn(zz, ry[3]));
+                py = __fadd_rn(ry[1], __fmul_rn(zz, ry[4]));
+                pz = __fadd_rn(ry[2], __fmul_rn(zz, ry[5]));
+            } else {
+                const float* sp = xyz + ((int64_t)b * N + n) * xyz_stride;
+                px = sp[0]; py = sp[1]; pz = sp[2];
+            }
+            const int64_t o = (int64_t)b * N + n;
+            pts_out[o] = make_float4(px, py, pz, 0.0f);
+            if (nbr_w != nullptr) {
+                reinterpret_cast<float4*>(nbr_w)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+                reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(0, 0, 0, 0);
+            }
+            // farther than the threshold from the whole body -> cannot be valid (see warp_points_kernel)
+            near = box_d2(gbox, px, py, pz) < thr * thr;
+            if (near) {
+                cell = cell_of(gbox, thr, px, py, pz);
+                const int slot = hash_slot(hkeys, cell);
+                if (slot >= 0) atomicAdd(&hcnt[slot], 1);
+                else atomicAdd(cell_count + (int64_t)b * NCELL + cell, 1);
+            }
+        }
+        const unsigned long long m = __ballot(near);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
 #pragma unroll
-        for (int w = 0; w < WARP_THREADS / 64; ++w) { int c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
-        block_base = tot ? atomicAdd(count + b, tot) : 0;
+            for (int w = 0; w < WARP_THREADS / 64; ++w) { int c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
+            block_base = tot ? atomicAdd(count + b, tot) : 0;
+        }
+        __syncthreads();
+        if (near) {
+            const int64_t pos = (int64_t)b * N + block_base + wave_cnt[wave] + __popcll(m & ((1ull << lane) - 1ull));
+            list[pos] = (int32_t)n;
+            cells[pos] = cell;
+        }
+        __syncthreads();
     }
+    for (int s = threadIdx.x; s < HN; s += WARP_THREADS)
+        if (hkeys[s] >= 0) atomicAdd(cell_count + (int64_t)b * NCELL + hkeys[s], hcnt[s]);
+}
+
+// one workgroup per body: cell_start = exclusive scan of cell_count; cell_count is zeroed (it becomes the fill counter)
+__global__ __launch_bounds__(1024) void warp_cell_scan_kernel(int32_t* __restrict__ cell_count,
+                                                              int32_t* __restrict__ cell_start) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry;
+    int32_t* cnt = cell_count + (int64_t)blockIdx.x * NCELL;
+    int32_t* start = cell_start + (int64_t)blockIdx.x * NCELL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    if (near) list[(int64_t)b * N + block_base + wave_cnt[wave] + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)n;
+    for (int base = 0; base < NCELL; base += 4096) {
+        // 4 consecutive cells per thread
+        int4 v = reinterpret_cast<const int4*>(cnt + base)[threadIdx.x];
+        reinterpret_cast<int4*>(cnt + base)[threadIdx.x] = make_int4(0, 0, 0, 0);
+        const int mine = v.x + v.y + v.z + v.w;
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int off = carry;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        const int ex = off + incl - mine;
+        reinterpret_cast<int4*>(start + base)[threadIdx.x] = make_int4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = off + incl;
+        __syncthreads();
+    }
+}
+
+// counting-sort scatter of the near list by cell: a workgroup ranks 4096 consecutive list entries per cell in its
+// LDS hash table, reserves one range per distinct cell with a single global atomic, and places the entries
+__global__ __launch_bounds__(WARP_THREADS) void warp_cell_scatter_kernel(const int32_t* __restrict__ list,
+                                                                         const int32_t* __restrict__ cells,
+                                                                         const int32_t* __restrict__ count, int64_t N,
+                                                                         const int32_t* __restrict__ cell_start,
+                                                                         int32_t* __restrict__ cell_fill,
+                                                                         int32_t* __restrict__ sorted) {
+    __shared__ int hkeys[HN], hcnt[HN];
+    const int b = blockIdx.y;
+    const int cnt = count[b];
+    const int32_t* my_cells = cells + (int64_t)b * N;
+    const int32_t* my_list = list + (int64_t)b * N;
+    const int32_t* start = cell_start + (int64_t)b * NCELL;
+    int32_t* fill = cell_fill + (int64_t)b * NCELL;
+    for (int base = blockIdx.x * 4 * WARP_THREADS; base < cnt; base += gridDim.x * 4 * WARP_THREADS) {
+        for (int s = threadIdx.x; s < HN; s += WARP_THREADS) { hkeys[s] = -1; hcnt[s] = 0; }
+        __syncthreads();
+        int cell[4], slot[4], rank[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = base + j * WARP_THREADS + threadIdx.x;
+            slot[j] = -1; rank[j] = 0; cell[j] = 0;
+            if (i < cnt) {
+                cell[j] = my_cells[i];
+                slot[j] = hash_slot(hkeys, cell[j]);
+                if (slot[j] >= 0) rank[j] = atomicAdd(&hcnt[slot[j]], 1);
+            }
+        }
+        __syncthreads();
+        for (int s = threadIdx.x; s < HN; s += WARP_THREADS)
+            if (hkeys[s] >= 0) hcnt[s] = start[hkeys[s]] + atomicAdd(fill + hkeys[s], hcnt[s]);      // count -> base position
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = base + j * WARP_THREADS + threadIdx.x;
+            if (i < cnt) {
+                const int pos = slot[j] >= 0 ? hcnt[slot[j]] + rank[j] : start[cell[j]] + atomicAdd(fill + cell[j], 1);
+                sorted[(int64_t)b * N + pos] = my_list[i];
+            }
+        }
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
@@ -608,6 +746,11 @@ extern "C" int anr_knn_index_build(const float* verts, const int32_t* order, int
     return check_launch("anr_knn_index_build");
 }
 
+extern "C" int64_t anr_warp_ws_ints(int bs, int64_t N) {
+    if (bs <= 0 || N <= 0) return ANR_E_BADARG;
+    return WarpWs::ints(bs, N);
+}
+
 extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* rays, int ray_stride, const float* z,
                                int K, const void* knn_index, const float* ober2cano, const float* lbs_weights, int bs,
                                int V, int J, int64_t N, float dis_threshold, int skip_far, float* pts_out,
@@ -637,21 +780,24 @@ extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* ra
         // two passes: classify + compact, then search the compacted list (see warp_classify_kernel)
         ANR_REQUIRE(dist_out == nullptr, ANR_E_BADARG, "anr_warp_points: debug outputs need skip_far = 0");
         ANR_REQUIRE(N < (int64_t)1 << 31, ANR_E_BADARG, "anr_warp_points: N=%lld does not fit the int32 list", (long long)N);
-        int32_t* list = ws;
-        int32_t* count = ws + (int64_t)bs * N;
-        int32_t* cursor = count + bs;
-        hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t) * 2 * bs, st);
+        WarpWs w(ws, bs, N);
+        hipError_t e = hipMemsetAsync(w.count, 0, sizeof(int32_t) * (2 * bs + (int64_t)bs * NCELL), st);
         if (e != hipSuccess) return fail((int)e, "anr_warp_points: hipMemsetAsync: %s", hipGetErrorString(e));
-        dim3 g1((unsigned)((N + WARP_THREADS - 1) / WARP_THREADS), bs);
+        dim3 g1((unsigned)((N + CLS_ITERS * WARP_THREADS - 1) / (CLS_ITERS * WARP_THREADS)), bs);
         if (xyz == nullptr)
             hipLaunchKernelGGL(warp_classify_kernel<true>, g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride, z,
                                K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                               list, count);
+                               w.list, w.cells, w.count, w.cell_count);
         else
             hipLaunchKernelGGL(warp_classify_kernel<false>, g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride,
                                z, K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                               list, count);
+                               w.list, w.cells, w.count, w.cell_count);
         if (int rc = check_launch("anr_warp_points (classify)")) return rc;
+        hipLaunchKernelGGL(warp_cell_scan_kernel, dim3(bs), dim3(1024), 0, st, w.cell_count, w.cell_start);
+        const int64_t sc_blocks = (N + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
+        hipLaunchKernelGGL(warp_cell_scatter_kernel, dim3((unsigned)(sc_blocks < 1024 ? sc_blocks : 1024), bs), dim3(WARP_THREADS), 0, st,
+                           w.list, w.cells, w.count, N, w.cell_start, w.cell_count, w.sorted);
+        if (int rc = check_launch("anr_warp_points (bin)")) return rc;
         if (int rc = allow_big_lds(warp_search_kernel, bytes, "anr_warp_points")) return rc;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -660,7 +806,7 @@ extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* ra
         if (gx > max_wg) gx = max_wg;
         hipLaunchKernelGGL(warp_search_kernel, dim3((unsigned)gx, bs), dim3(WARP_THREADS), bytes, st, index, d, ober2cano,
                            lbs_weights, J, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                           list, count, cursor);
+                           w.sorted, w.count, w.cursor);
         return check_launch("anr_warp_points (search)");
     }
     if (xyz == nullptr) {

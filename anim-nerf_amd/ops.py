@@ -220,7 +220,8 @@ def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
         nidx = torch.empty(bs, N, 4, dtype=torch.int32, device=dev)
         nw = torch.empty(bs, N, 4, dtype=torch.float32, device=dev)
     # renderer mode: classify + compact the samples near the body, then search the compacted list
-    ws = torch.empty(bs * N + 2 * bs, dtype=torch.int32, device=dev) if (skip_far and two_pass) else None
+    ws = (torch.empty(lib.anr_warp_ws_ints(bs, N), dtype=torch.int32, device=dev)
+          if (skip_far and two_pass) else None)
     with _timed("warp_points", bs * N):
         _lib.check(lib.anr_warp_points(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(index), _ptr(o2c),
                                        _ptr(lbs_weights), bs, V, J, N, float(dis_threshold), 1 if skip_far else 0,

@@ -129,10 +129,12 @@ int anr_sample_coarse(const float* rays, int stride, const float* steps, const f
  * Optional training outputs (both or neither): nbr_idx_out[bs*N*4] (int32 vertex ids) and nbr_w_out[bs*N*4]
  *   (normalised blend weights, anim_nerf.py:169-171; zeros for samples skipped by skip_far) — what the backward
  *   pass needs to route dL/dx_c into ober2cano and into the sample position.
- * ws (may be NULL; used with skip_far != 0): int32 workspace of bs*N + 2*bs elements.  With it the call runs in two
- *   passes — classify every sample against the body's bounding box and compact the near ones into a list, then
- *   search the list 64 entries per wavefront (all lanes busy, spatially coherent) — instead of one pass in which a
- *   wavefront of 64 neighbouring rays searches for its few near samples.  Same results bit for bit. */
+ * ws (may be NULL; used with skip_far != 0): int32 workspace of anr_warp_ws_ints(bs, N) elements.  With it the call
+ *   runs in passes — classify every sample against the body's bounding box and list the near ones, counting-sort
+ *   the list by 64^3 grid cell, then search the sorted list 64 entries per wavefront (all lanes busy, all in one or
+ *   two neighbouring cells) — instead of one pass in which a wavefront of 64 neighbouring rays searches for its few
+ *   near samples.  Same results bit for bit. */
+int64_t anr_warp_ws_ints(int bs, int64_t N);
 int anr_warp_points(const float* xyz, int xyz_stride,
                     const float* rays, int ray_stride, const float* z, int K,
                     const void* knn_index, const float* ober2cano, const float* lbs_weights,
