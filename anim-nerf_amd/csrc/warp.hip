@@ -3,32 +3,38 @@
 //
 // The CUDA reference materialises a V x N distance matrix in global memory (55 KB per point) and
 // insertion-sorts its columns.  Here the search is exact but pruned: once per frame
-// `anr_knn_index_build` lays the posed vertices out in a fixed spatial order (clusters of 32, super-
-// clusters of 8 clusters) with their bounding boxes; `anr_warp_points` / `anr_knn` stage that 91 KB
-// index into LDS once per workgroup and every lane walks super-cluster -> cluster -> vertex with
-// wave-uniform (broadcast) LDS reads, skipping whatever cannot beat its current 4th-best distance.
-// A wavefront holds 64 NEIGHBOURING rays at the same sample depth, so its lanes agree on what to skip.
+// `anr_knn_index_build` lays the posed vertices out in a fixed spatial order as a three-level tree of
+// bounding boxes (clusters of 8 vertices, super-clusters of 8 clusters, tops of 8 super-clusters);
+// `anr_warp_points` / `anr_knn` stage that 114 KB index into LDS once per workgroup and every lane walks
+// top -> super -> cluster -> vertex with wave-uniform (broadcast) LDS reads, skipping whatever cannot beat its
+// current 4th-best distance.  The lanes of a wavefront hold points that are neighbours in space (see the two-pass
+// renderer path below), so they agree on what to skip.  Small clusters matter for the samples that are 10-20 cm
+// away from the surface (most of the valid ones): their 4th-neighbour sphere grazes a wide patch of the mesh, and
+// the work is the number of vertices in the boxes it touches.
 // The per-vertex tables that are only gathered for the four winners (lbs_weights 24 floats,
 // ober2cano 12 floats) stay in L2.
 //
-// Index layout per body (floats): x[Vp] y[Vp] z[Vp] | cluster boxes NC x 8 | super boxes NS x 8 |
-// body box 8 | order[Vp] (int32: slot -> original vertex id).  Vp = 32 NC, NC = ceil(V/32), NS = ceil(NC/8).
+// Index layout per body (floats): x[Vp] y[Vp] z[Vp] | cluster boxes NC x 8 | super boxes NS x 8 | top boxes NT x 8 |
+// body box 8 | order[Vp] (int32: slot -> original vertex id).  Vp = 8 NC, NC = ceil(V/8), NS = ceil(NC/8), NT = ceil(NS/8).
 #include "anr_common.h"
 
 namespace anr {
 
 constexpr int WARP_THREADS = 1024;
-constexpr int CS = 32;                     // vertices per cluster
+constexpr int CS = 8;                      // vertices per cluster
 constexpr int SC = 8;                      // clusters per super-cluster
+constexpr int TC = 8;                      // super-clusters per top
+constexpr int MAX_NC = 2048;               // clusters the build kernel can hold (V <= 16384)
 constexpr int MAX_J = 32;
 constexpr float FAR = 1.0e18f;
 
 struct IndexDims {
-    int V, NC, NS, Vp;
+    int V, NC, NS, NT, Vp;
     __host__ __device__ int box_off() const { return 3 * Vp; }
     __host__ __device__ int sbox_off() const { return 3 * Vp + 8 * NC; }
-    __host__ __device__ int body_off() const { return 3 * Vp + 8 * NC + 8 * NS; }
-    __host__ __device__ int order_off() const { return 3 * Vp + 8 * NC + 8 * NS + 8; }
+    __host__ __device__ int tbox_off() const { return 3 * Vp + 8 * NC + 8 * NS; }
+    __host__ __device__ int body_off() const { return 3 * Vp + 8 * NC + 8 * NS + 8 * NT; }
+    __host__ __device__ int order_off() const { return body_off() + 8; }
     __host__ __device__ int lds_floats() const { return order_off(); }
     __host__ __device__ int total_floats() const { return order_off() + Vp; }
 };
@@ -37,6 +43,7 @@ inline IndexDims index_dims(int V) {
     d.V = V;
     d.NC = (V + CS - 1) / CS;
     d.NS = (d.NC + SC - 1) / SC;
+    d.NT = (d.NS + TC - 1) / TC;
     d.Vp = d.NC * CS;
     return d;
 }
@@ -50,7 +57,8 @@ __global__ __launch_bounds__(256) void knn_index_build_kernel(const float* __res
     const float* v = verts + (int64_t)b * d.V * 3;
     float* out = index + (int64_t)b * d.total_floats();
     int32_t* ord_out = reinterpret_cast<int32_t*>(out + d.order_off());
-    __shared__ float cbox[512][6];
+    __shared__ float cbox[MAX_NC][6];
+    __shared__ float sbox[MAX_NC / SC][6];
     for (int c = threadIdx.x; c < d.NC; c += blockDim.x) {
         float lo[3] = {FAR, FAR, FAR}, hi[3] = {-FAR, -FAR, -FAR};
         for (int i = 0; i < CS; ++i) {
@@ -79,14 +87,25 @@ __global__ __launch_bounds__(256) void knn_index_build_kernel(const float* __res
             for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], cbox[c][a]); hi[a] = fmaxf(hi[a], cbox[c][3 + a]); }
         float* bx = out + d.sbox_off() + s * 8;
 #pragma unroll
+        for (int a = 0; a < 3; ++a) { bx[a] = lo[a]; bx[4 + a] = hi[a]; sbox[s][a] = lo[a]; sbox[s][3 + a] = hi[a]; }
+        bx[3] = 0.f; bx[7] = 0.f;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < d.NT; t += blockDim.x) {
+        float lo[3] = {FAR, FAR, FAR}, hi[3] = {-FAR, -FAR, -FAR};
+        for (int q = t * TC; q < min((t + 1) * TC, d.NS); ++q)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], sbox[q][a]); hi[a] = fmaxf(hi[a], sbox[q][3 + a]); }
+        float* bx = out + d.tbox_off() + t * 8;
+#pragma unroll
         for (int a = 0; a < 3; ++a) { bx[a] = lo[a]; bx[4 + a] = hi[a]; }
         bx[3] = 0.f; bx[7] = 0.f;
     }
     if (threadIdx.x == 0) {
         float lo[3] = {FAR, FAR, FAR}, hi[3] = {-FAR, -FAR, -FAR};
-        for (int c = 0; c < d.NC; ++c)
+        for (int q = 0; q < d.NS; ++q)
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], cbox[c][a]); hi[a] = fmaxf(hi[a], cbox[c][3 + a]); }
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], sbox[q][a]); hi[a] = fmaxf(hi[a], sbox[q][3 + a]); }
         float* bx = out + d.body_off();
 #pragma unroll
         for (int a = 0; a < 3; ++a) { bx[a] = lo[a]; bx[4 + a] = hi[a]; }
@@ -104,18 +123,19 @@ __device__ __forceinline__ void best_init(Best4& b, float cap2 = 3.0e38f) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) { b.d[k] = cap2; b.i[k] = -1; }
 }
-// insert (c, v) keeping d ascending; strict < : the first visited vertex wins exact ties
+// insert (c, v) keeping d ascending; strict < : the first visited vertex wins exact ties.  Branch-free:
+// new d[k] = median(d[k-1], d[k], c) for a sorted list, the ids follow the four comparisons.
 __device__ __forceinline__ void best_insert(Best4& b, float c, int v) {
-    if (c < b.d[3]) {
-        b.d[3] = c; b.i[3] = v;
-#pragma unroll
-        for (int k = 3; k > 0; --k) {
-            if (b.d[k] < b.d[k - 1]) {
-                float td = b.d[k]; b.d[k] = b.d[k - 1]; b.d[k - 1] = td;
-                int ti = b.i[k]; b.i[k] = b.i[k - 1]; b.i[k - 1] = ti;
-            }
-        }
-    }
+    const bool m0 = c < b.d[0], m1 = c < b.d[1], m2 = c < b.d[2], m3 = c < b.d[3];
+    b.i[3] = m3 ? (m2 ? b.i[2] : v) : b.i[3];
+    b.i[2] = m2 ? (m1 ? b.i[1] : v) : b.i[2];
+    b.i[1] = m1 ? (m0 ? b.i[0] : v) : b.i[1];
+    b.i[0] = m0 ? v : b.i[0];
+    const float d0 = b.d[0], d1 = b.d[1], d2 = b.d[2], d3 = b.d[3];
+    b.d[0] = fminf(d0, c);
+    b.d[1] = __builtin_amdgcn_fmed3f(d0, d1, c);
+    b.d[2] = __builtin_amdgcn_fmed3f(d1, d2, c);
+    b.d[3] = __builtin_amdgcn_fmed3f(d2, d3, c);
 }
 
 // squared distance from p to an axis-aligned box (0 inside)
@@ -159,38 +179,54 @@ __device__ __forceinline__ void search(const float* lds, const IndexDims& d, flo
                                        Best4& best) {
     const float* boxes = lds + d.box_off();
     const float* sboxes = lds + d.sbox_off();
-    // 1. seed: nearest super-cluster by box distance, nearest cluster inside it -> scan it
-    int seed_s = 0;
+    const float* tboxes = lds + d.tbox_off();
+    // 1. seed: greedy descent by box distance (per-lane LDS addresses below the top level) -> scan that cluster
+    int seed_t = 0;
     float seed_v = 3.0e38f;
-    for (int s = 0; s < d.NS; ++s) {
-        float v = box_d2(sboxes + s * 8, px, py, pz);
-        if (v < seed_v) { seed_v = v; seed_s = s; }
+    for (int t = 0; t < d.NT; ++t) {
+        const float v = box_d2(tboxes + t * 8, px, py, pz);
+        if (v < seed_v) { seed_v = v; seed_t = t; }
+    }
+    int seed_s = seed_t * TC;
+    seed_v = 3.0e38f;
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+        const int q = min(seed_t * TC + j, d.NS - 1);
+        const float v = box_d2(sboxes + q * 8, px, py, pz);
+        if (v < seed_v) { seed_v = v; seed_s = q; }
     }
     int seed_c = seed_s * SC;
     seed_v = 3.0e38f;
+#pragma unroll
     for (int j = 0; j < SC; ++j) {
-        // every lane evaluates the j-th cluster of ITS OWN seed super-cluster (per-lane LDS address)
-        int c = min(seed_s * SC + j, d.NC - 1);
-        float v = box_d2(boxes + c * 8, px, py, pz);
+        const int c = min(seed_s * SC + j, d.NC - 1);
+        const float v = box_d2(boxes + c * 8, px, py, pz);
         if (v < seed_v) { seed_v = v; seed_c = c; }
     }
     if (!active) seed_c = -1;
-    for (int c = 0; c < d.NC; ++c) {
-        const bool mine = (c == seed_c);
-        if (__any(mine)) {
-            if (mine) scan_cluster(lds, d.Vp, c, px, py, pz, best);
-        }
+    unsigned long long rem = __ballot(active);
+    while (rem) {                                   // one pass per distinct seed cluster in the wavefront
+        const int first = __builtin_ctzll(rem);
+        const int c = __builtin_amdgcn_readlane(seed_c, first);
+        const bool mine = (seed_c == c);
+        if (mine) scan_cluster(lds, d.Vp, c, px, py, pz, best);
+        rem &= ~__ballot(mine);
     }
     // 2. every other cluster whose box can still beat the current 4th-best
-    for (int s = 0; s < d.NS; ++s) {
-        const float sv = box_d2(sboxes + s * 8, px, py, pz);
-        if (!__any(active && sv < best.d[3])) continue;
-        const int c_end = min((s + 1) * SC, d.NC);
-        for (int c = s * SC; c < c_end; ++c) {
-            const float v = box_d2(boxes + c * 8, px, py, pz);
-            const bool need = active && (c != seed_c) && (v < best.d[3]);
-            if (__any(need)) {
-                if (need) scan_cluster(lds, d.Vp, c, px, py, pz, best);
+    for (int t = 0; t < d.NT; ++t) {
+        const float tv = box_d2(tboxes + t * 8, px, py, pz);
+        if (!__any(active && tv < best.d[3])) continue;
+        const int s_end = min((t + 1) * TC, d.NS);
+        for (int q = t * TC; q < s_end; ++q) {
+            const float sv = box_d2(sboxes + q * 8, px, py, pz);
+            if (!__any(active && sv < best.d[3])) continue;
+            const int c_end = min((q + 1) * SC, d.NC);
+            for (int c = q * SC; c < c_end; ++c) {
+                const float v = box_d2(boxes + c * 8, px, py, pz);
+                const bool need = active && (c != seed_c) && (v < best.d[3]);
+                if (__any(need)) {
+                    if (need) scan_cluster(lds, d.Vp, c, px, py, pz, best);
+                }
             }
         }
     }
@@ -327,7 +363,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_points_kernel(
     };
 
     // Pass 0 (renderer only): a workgroup whose samples are ALL farther than the threshold from the body's
-    // bounding box writes (x, 0) and leaves without staging the 91 KB index — most of the frame is empty space.
+    // bounding box writes (x, 0) and leaves without staging the index — most of the frame is empty space.
     if (threadIdx.x == 0) next_item = 0;
     if (skip_far) {
         const float* gbox = my_index + d.body_off();
@@ -414,17 +450,23 @@ constexpr int NCELL = GRID * GRID * GRID;
 constexpr float MIN_CELL = 0.04f;
 
 struct WarpWs {
-    int32_t *list, *cells, *sorted, *count, *cursor, *cell_count, *cell_start;
-    __host__ static int64_t ints(int bs, int64_t N) { return 3 * (int64_t)bs * N + 2 * bs + 2 * (int64_t)bs * NCELL; }
+    int32_t *list, *cells, *sorted, *count, *cursor, *live, *cell_count, *cell_start;
+    float* cell_cap2;
+    __host__ static int64_t ints(int bs, int64_t N) { return 3 * (int64_t)bs * N + 3 * bs + 3 * (int64_t)bs * NCELL; }
+    __host__ static int64_t zeroed_ints(int bs) { return 3 * bs + (int64_t)bs * NCELL; }      // from `count` on
     __host__ WarpWs(int32_t* ws, int bs, int64_t N) {
         list = ws; cells = list + (int64_t)bs * N; sorted = cells + (int64_t)bs * N; count = sorted + (int64_t)bs * N;
-        cursor = count + bs; cell_count = cursor + bs; cell_start = cell_count + (int64_t)bs * NCELL;
+        cursor = count + bs; live = cursor + bs; cell_count = live + bs; cell_start = cell_count + (int64_t)bs * NCELL;
+        cell_cap2 = reinterpret_cast<float*>(cell_start + (int64_t)bs * NCELL);
     }
 };
 
-__device__ __forceinline__ int cell_of(const float* gbox, float thr, float px, float py, float pz) {
+__device__ __forceinline__ float cell_size(const float* gbox, float thr) {
     const float ex = gbox[4] - gbox[0], ey = gbox[5] - gbox[1], ez = gbox[6] - gbox[2];
-    const float c = fmaxf(MIN_CELL, (fmaxf(fmaxf(ex, ey), ez) + 2.0f * thr) * (1.0f / GRID));
+    return fmaxf(MIN_CELL, (fmaxf(fmaxf(ex, ey), ez) + 2.0f * thr) * (1.0f / GRID));
+}
+__device__ __forceinline__ int cell_of(const float* gbox, float thr, float px, float py, float pz) {
+    const float c = cell_size(gbox, thr);
     const float inv = 1.0f / c;
     const int ix = min(max((int)((px - gbox[0] + thr) * inv), 0), GRID - 1);
     const int iy = min(max((int)((py - gbox[1] + thr) * inv), 0), GRID - 1);
@@ -515,9 +557,49 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
         if (hkeys[s] >= 0) atomicAdd(cell_count + (int64_t)b * NCELL + hkeys[s], hcnt[s]);
 }
 
-// one workgroup per body: cell_start = exclusive scan of cell_count; cell_count is zeroed (it becomes the fill counter)
+// Per occupied cell, one exact search from the cell's centre c (r = half diagonal):
+//   * nearest vertex farther than dis_threshold + r  ->  every point of the cell is farther than dis_threshold from
+//     every vertex, its blended distance (a convex combination of neighbour distances) too: the cell is dead, its
+//     samples stay (x, 0) and are dropped from the list;
+//   * otherwise (d4(c) + r)^2 bounds the 4th-neighbour distance of every point of the cell: searching inside that
+//     radius finds the exact four neighbours in one go (no unbounded retry).
+// cell_cap2[cell] = that squared radius, or -1 for a dead cell; defined for cells with a non-zero count only.
+__global__ __launch_bounds__(WARP_THREADS) void warp_cells_kernel(const float* __restrict__ index, IndexDims d, float thr,
+                                                                  const int32_t* __restrict__ cell_count,
+                                                                  float* __restrict__ cell_cap2) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.y;
+    const int32_t* cnt = cell_count + (int64_t)b * NCELL;
+    float* cap = cell_cap2 + (int64_t)b * NCELL;
+    stage_index(index + (int64_t)b * d.total_floats(), d.lds_floats(), lds);
+    const float* gbox = lds + d.body_off();
+    const float cs = cell_size(gbox, thr);
+    const float r = cs * 0.8662f;                        // sqrt(3)/2, rounded up
+    for (int chunk = blockIdx.x; chunk < NCELL / WARP_THREADS; chunk += gridDim.x) {
+        const int cell = chunk * WARP_THREADS + threadIdx.x;
+        const bool occ = cnt[cell] > 0;
+        if (!__any(occ)) continue;
+        const int ix = cell / (GRID * GRID), iy = (cell / GRID) % GRID, iz = cell % GRID;
+        const float cx = gbox[0] - thr + ((float)ix + 0.5f) * cs;
+        const float cy = gbox[1] - thr + ((float)iy + 0.5f) * cs;
+        const float cz = gbox[2] - thr + ((float)iz + 0.5f) * cs;
+        Best4 best;
+        best_init(best);
+        search(lds, d, cx, cy, cz, occ, best);
+        if (occ) {
+            const float d1 = sqrtf(best.d[0]), d4 = sqrtf(best.d[3]);
+            const float reach = d4 + r;
+            cap[cell] = (d1 - r >= thr) ? -1.0f : reach * reach * 1.001f;
+        }
+    }
+}
+
+// one workgroup per body: cell_start = exclusive scan of the live cells' counts; cell_count is zeroed (it becomes the
+// fill counter); live[b] = number of list entries in live cells
 __global__ __launch_bounds__(1024) void warp_cell_scan_kernel(int32_t* __restrict__ cell_count,
-                                                              int32_t* __restrict__ cell_start) {
+                                                              int32_t* __restrict__ cell_start,
+                                                              const float* __restrict__ cell_cap2,
+                                                              int32_t* __restrict__ live) {
     __shared__ int wave_tot[16];
     __shared__ int carry;
     int32_t* cnt = cell_count + (int64_t)blockIdx.x * NCELL;
@@ -529,6 +611,11 @@ __global__ __launch_bounds__(1024) void warp_cell_scan_kernel(int32_t* __restric
         // 4 consecutive cells per thread
         int4 v = reinterpret_cast<const int4*>(cnt + base)[threadIdx.x];
         reinterpret_cast<int4*>(cnt + base)[threadIdx.x] = make_int4(0, 0, 0, 0);
+        const float4 cp = reinterpret_cast<const float4*>(cell_cap2 + (int64_t)blockIdx.x * NCELL + base)[threadIdx.x];
+        if (v.x > 0 && cp.x < 0.f) v.x = 0;               // dead cells take no room in the sorted list
+        if (v.y > 0 && cp.y < 0.f) v.y = 0;
+        if (v.z > 0 && cp.z < 0.f) v.z = 0;
+        if (v.w > 0 && cp.w < 0.f) v.w = 0;
         const int mine = v.x + v.y + v.z + v.w;
         int incl = mine;
 #pragma unroll
@@ -546,6 +633,7 @@ __global__ __launch_bounds__(1024) void warp_cell_scan_kernel(int32_t* __restric
         if (threadIdx.x == 1023) carry = off + incl;
         __syncthreads();
     }
+    if (threadIdx.x == 0) live[blockIdx.x] = carry;
 }
 
 // counting-sort scatter of the near list by cell: a workgroup ranks 4096 consecutive list entries per cell in its
@@ -555,6 +643,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cell_scatter_kernel(const i
                                                                          const int32_t* __restrict__ count, int64_t N,
                                                                          const int32_t* __restrict__ cell_start,
                                                                          int32_t* __restrict__ cell_fill,
+                                                                         const float* __restrict__ cell_cap2,
                                                                          int32_t* __restrict__ sorted) {
     __shared__ int hkeys[HN], hcnt[HN];
     const int b = blockIdx.y;
@@ -563,6 +652,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cell_scatter_kernel(const i
     const int32_t* my_list = list + (int64_t)b * N;
     const int32_t* start = cell_start + (int64_t)b * NCELL;
     int32_t* fill = cell_fill + (int64_t)b * NCELL;
+    const float* cap = cell_cap2 + (int64_t)b * NCELL;
     for (int base = blockIdx.x * 4 * WARP_THREADS; base < cnt; base += gridDim.x * 4 * WARP_THREADS) {
         for (int s = threadIdx.x; s < HN; s += WARP_THREADS) { hkeys[s] = -1; hcnt[s] = 0; }
         __syncthreads();
@@ -570,11 +660,14 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cell_scatter_kernel(const i
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int i = base + j * WARP_THREADS + threadIdx.x;
-            slot[j] = -1; rank[j] = 0; cell[j] = 0;
+            slot[j] = -1; rank[j] = 0; cell[j] = -1;
             if (i < cnt) {
-                cell[j] = my_cells[i];
-                slot[j] = hash_slot(hkeys, cell[j]);
-                if (slot[j] >= 0) rank[j] = atomicAdd(&hcnt[slot[j]], 1);
+                const int cl = my_cells[i];
+                if (!(cap[cl] < 0.f)) {                     // entries of dead cells are dropped here
+                    cell[j] = cl;
+                    slot[j] = hash_slot(hkeys, cl);
+                    if (slot[j] >= 0) rank[j] = atomicAdd(&hcnt[slot[j]], 1);
+                }
             }
         }
         __syncthreads();
@@ -584,7 +677,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cell_scatter_kernel(const i
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int i = base + j * WARP_THREADS + threadIdx.x;
-            if (i < cnt) {
+            if (i < cnt && cell[j] >= 0) {
                 const int pos = slot[j] >= 0 ? hcnt[slot[j]] + rank[j] : start[cell[j]] + atomicAdd(fill + cell[j], 1);
                 sorted[(int64_t)b * N + pos] = my_list[i];
             }
@@ -596,7 +689,8 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cell_scatter_kernel(const i
 __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
     const float* __restrict__ index, IndexDims d, const float* __restrict__ ober2cano, const float* __restrict__ lbs_w,
     int J, int64_t N, float thr, float4* __restrict__ pts_out, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w,
-    const int32_t* __restrict__ list, const int32_t* __restrict__ count, int32_t* __restrict__ cursor) {
+    const int32_t* __restrict__ list, const int32_t* __restrict__ count, int32_t* __restrict__ cursor,
+    const float* __restrict__ cell_cap2) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.y;
     const int cnt = count[b];
@@ -606,8 +700,10 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
     const int32_t* order = reinterpret_cast<const int32_t*>(my_index + d.order_off());
     const float* O2C = ober2cano + (int64_t)b * d.V * 16;
     const int32_t* my_list = list + (int64_t)b * N;
+    const float* cap = cell_cap2 + (int64_t)b * NCELL;
     const int lane = threadIdx.x & 63;
     stage_index(my_index, d.lds_floats(), lds);
+    const float* gbox = lds + d.body_off();
     for (;;) {
         int item = 0;
         if (lane == 0) item = atomicAdd(cursor + b, 1);
@@ -617,20 +713,11 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
         const bool go = i < cnt;
         const int64_t o = (int64_t)b * N + my_list[go ? i : cnt - 1];
         const float4 p = pts_out[o];
-        // search inside the validity radius first: nothing there -> invalid, (x, 0) is already in place; four or
-        // more -> the exact 4-NN; 1-3 -> repeat unbounded (see warp_points_kernel)
+        // inside the cell's radius the exact four neighbours are guaranteed to be found (warp_cells_kernel)
         Best4 best;
-        best_init(best, thr * thr * 1.0002f);
+        best_init(best, cap[cell_of(gbox, thr, p.x, p.y, p.z)]);
         search(lds, d, p.x, p.y, p.z, go, best);
-        const bool none = best.i[0] < 0;
-        const bool partial = go && !none && best.i[3] < 0;
-        if (__any(partial)) {
-            Best4 full;
-            best_init(full);
-            search(lds, d, p.x, p.y, p.z, partial, full);
-            if (partial) best = full;
-        }
-        if (!go || none) continue;
+        if (!go) continue;
         blend_and_store(best, order, lbs_w, J, O2C, thr, p.x, p.y, p.z, o, pts_out, nullptr, nullptr, nullptr, nbr_idx, nbr_w);
     }
 }
@@ -740,7 +827,7 @@ extern "C" int anr_knn_index_build(const float* verts, const int32_t* order, int
     ANR_REQUIRE(bs > 0 && V >= 4, ANR_E_BADARG, "anr_knn_index_build: bs=%d V=%d", bs, V);
     ANR_REQUIRE(((uintptr_t)index_out & 15) == 0, ANR_E_ALIGN, "anr_knn_index_build: index_out must be 16-B aligned");
     IndexDims d = index_dims(V);
-    ANR_REQUIRE(d.NC <= 512, ANR_E_SHAPE, "anr_knn_index_build: V=%d too large (max 16384)", V);
+    ANR_REQUIRE(d.NC <= MAX_NC, ANR_E_SHAPE, "anr_knn_index_build: V=%d too large (max %d)", V, MAX_NC * CS);
     hipLaunchKernelGGL(knn_index_build_kernel, dim3(bs), dim3(256), 0, (hipStream_t)stream, verts, order, d,
                        reinterpret_cast<float*>(index_out));
     return check_launch("anr_knn_index_build");
@@ -781,7 +868,7 @@ extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* ra
         ANR_REQUIRE(dist_out == nullptr, ANR_E_BADARG, "anr_warp_points: debug outputs need skip_far = 0");
         ANR_REQUIRE(N < (int64_t)1 << 31, ANR_E_BADARG, "anr_warp_points: N=%lld does not fit the int32 list", (long long)N);
         WarpWs w(ws, bs, N);
-        hipError_t e = hipMemsetAsync(w.count, 0, sizeof(int32_t) * (2 * bs + (int64_t)bs * NCELL), st);
+        hipError_t e = hipMemsetAsync(w.count, 0, sizeof(int32_t) * WarpWs::zeroed_ints(bs), st);
         if (e != hipSuccess) return fail((int)e, "anr_warp_points: hipMemsetAsync: %s", hipGetErrorString(e));
         dim3 g1((unsigned)((N + CLS_ITERS * WARP_THREADS - 1) / (CLS_ITERS * WARP_THREADS)), bs);
         if (xyz == nullptr)
@@ -793,20 +880,23 @@ extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* ra
                                z, K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
                                w.list, w.cells, w.count, w.cell_count);
         if (int rc = check_launch("anr_warp_points (classify)")) return rc;
-        hipLaunchKernelGGL(warp_cell_scan_kernel, dim3(bs), dim3(1024), 0, st, w.cell_count, w.cell_start);
-        const int64_t sc_blocks = (N + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
-        hipLaunchKernelGGL(warp_cell_scatter_kernel, dim3((unsigned)(sc_blocks < 1024 ? sc_blocks : 1024), bs), dim3(WARP_THREADS), 0, st,
-                           w.list, w.cells, w.count, N, w.cell_start, w.cell_count, w.sorted);
-        if (int rc = check_launch("anr_warp_points (bin)")) return rc;
-        if (int rc = allow_big_lds(warp_search_kernel, bytes, "anr_warp_points")) return rc;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         int64_t gx = (cus + bs - 1) / bs;                                   // one persistent workgroup per CU in total
+        if (int rc = allow_big_lds(warp_cells_kernel, bytes, "anr_warp_points")) return rc;
+        hipLaunchKernelGGL(warp_cells_kernel, dim3((unsigned)(gx < NCELL / WARP_THREADS ? gx : NCELL / WARP_THREADS), bs),
+                           dim3(WARP_THREADS), bytes, st, index, d, dis_threshold, w.cell_count, w.cell_cap2);
+        hipLaunchKernelGGL(warp_cell_scan_kernel, dim3(bs), dim3(1024), 0, st, w.cell_count, w.cell_start, w.cell_cap2, w.live);
+        const int64_t sc_blocks = (N + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
+        hipLaunchKernelGGL(warp_cell_scatter_kernel, dim3((unsigned)(sc_blocks < 1024 ? sc_blocks : 1024), bs), dim3(WARP_THREADS), 0, st,
+                           w.list, w.cells, w.count, N, w.cell_start, w.cell_count, w.cell_cap2, w.sorted);
+        if (int rc = check_launch("anr_warp_points (bin)")) return rc;
+        if (int rc = allow_big_lds(warp_search_kernel, bytes, "anr_warp_points")) return rc;
         const int64_t max_wg = (N + 64 * (WARP_THREADS / 64) - 1) / (64 * (WARP_THREADS / 64));
         if (gx > max_wg) gx = max_wg;
         hipLaunchKernelGGL(warp_search_kernel, dim3((unsigned)gx, bs), dim3(WARP_THREADS), bytes, st, index, d, ober2cano,
                            lbs_weights, J, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                           w.sorted, w.count, w.cursor);
+                           w.sorted, w.live, w.cursor, w.cell_cap2);
         return check_launch("anr_warp_points (search)");
     }
     if (xyz == nullptr) {
