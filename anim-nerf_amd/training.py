@@ -89,26 +89,32 @@ def compute_loss(anim_nerf, hp: TrainHParams, rgbs, alphas, results, fg_points=N
         details["loss_alphas_fine"] = F.l1_loss(results["alphas_fine"], alphas)
         loss = loss + hp.lambda_alphas * details["loss_alphas_fine"]
     k = -2.0 / hp.n_samples
-    if hp.use_unpose and fg_points is not None:
-        for tag, use_fine in (("", False),) + ((("_fine", True),) if fine else ()):
-            s = anim_nerf.query_canonical_space(fg_points, use_fine=use_fine, only_sigma=True)
-            details["loss_foreground" + tag] = torch.mean(torch.exp(k * torch.relu(s)))
-            loss = loss + hp.lambda_foreground * details["loss_foreground" + tag]
-    if hp.use_unpose and bg_points is not None:
-        for tag, use_fine in (("", False),) + ((("_fine", True),) if fine else ()):
-            s = anim_nerf.query_canonical_space(bg_points, use_fine=use_fine, only_sigma=True)
-            details["loss_background" + tag] = torch.mean(1 - torch.exp(k * torch.relu(s)))
-            loss = loss + hp.lambda_background * details["loss_background" + tag]
+    nets = (("", False),) + ((("_fine", True),) if fine else ())
+    want_fg = hp.use_unpose and fg_points is not None
+    want_bg = hp.use_unpose and bg_points is not None
+    if want_fg or want_bg:
+        # one sigma-only field query per network for both point sets (the reference issues them one by one,
+        # train.py:262-286; the per-point results are the same, the backward is one pass instead of two)
+        both = torch.cat([p for p, w in ((fg_points, want_fg), (bg_points, want_bg)) if w], dim=1)
+        n_fg = fg_points.shape[1] if want_fg else 0
+        for tag, use_fine in nets:
+            s = anim_nerf.query_canonical_space(both, use_fine=use_fine, only_sigma=True)
+            if want_fg:
+                details["loss_foreground" + tag] = torch.mean(torch.exp(k * torch.relu(s[:, :n_fg])))
+                loss = loss + hp.lambda_foreground * details["loss_foreground" + tag]
+            if want_bg:
+                details["loss_background" + tag] = torch.mean(1 - torch.exp(k * torch.relu(s[:, n_fg:])))
+                loss = loss + hp.lambda_background * details["loss_background" + tag]
     if hp.lambda_normals != 0:                                  # train.py:288-309
         pts = anim_nerf.verts_template.detach()
         pts = pts + torch.randn_like(pts) * hp.dis_threshold * 0.5
         nbr = pts + torch.randn_like(pts) * hp.epsilon
-        for tag, use_fine in (("", False),) + ((("_fine", True),) if fine else ()):
-            n0 = anim_nerf.query_canonical_space(pts, use_fine=use_fine, only_normal=True)
-            n1 = anim_nerf.query_canonical_space(nbr, use_fine=use_fine, only_normal=True)
-            n0 = n0 / (torch.norm(n0, p=2, dim=-1, keepdim=True) + 1e-5)
-            n1 = n1 / (torch.norm(n1, p=2, dim=-1, keepdim=True) + 1e-5)
-            details["loss_normals" + tag] = F.mse_loss(n0, n1)
+        nv = pts.shape[1]
+        for tag, use_fine in nets:
+            # both point sets through one second-order pass (per-point gradients are independent of the batch)
+            nrm = anim_nerf.query_canonical_space(torch.cat([pts, nbr], 1), use_fine=use_fine, only_normal=True)
+            nrm = nrm / (torch.norm(nrm, p=2, dim=-1, keepdim=True) + 1e-5)
+            details["loss_normals" + tag] = F.mse_loss(nrm[:, :nv], nrm[:, nv:])
             loss = loss + hp.lambda_normals * details["loss_normals" + tag]
     return loss, details
 

@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--hw", type=int, default=1024)
     ap.add_argument("--n-coarse", type=int, default=64)
     ap.add_argument("--n-fine", type=int, default=64)
-    ap.add_argument("--chunk", type=int, default=1 << 18, help="rays per renderer call")
+    ap.add_argument("--chunk", type=int, default=1 << 20, help="rays per renderer call")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="upper bound on the rays timed on the host oracle (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target duration of the host-oracle sample")
     ap.add_argument("--sigma-gain", type=float, default=3000.0,
@@ -249,7 +249,7 @@ def train_bench(args, rank, local_rank, world, dev):
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.mode, "data": "synthetic",
         "config": {"workload": "BASELINE configs[3] shape: train step, %d frames x 32x32 rays per GPU, 64 coarse + 32 fine, "
-                               "perturb=1, rgb+alpha+fg/bg losses (no normals term), pose refinement on (optim_body_params), "
+                               "perturb=1, rgb + alpha + fg/bg + normals losses (reference defaults), pose refinement on (optim_body_params), "
                                "flat-gradient all-reduce (4.7 MB) + Adam" % F,
                    "mlp_on_valid_samples_only": bool(model.evaluate_valid_only),
                    "mlp_rows_per_step": mlp_pts // max(args.steps, 1),
