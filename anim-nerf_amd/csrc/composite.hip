@@ -255,8 +255,34 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void sample_fine_merge_kern
     }
     __syncthreads();
 
-    // stable rank sort of the Kc+Kf depths (handles unsorted fine samples too)
+    // Stable sort of the Kc+Kf depths: rank(p) = #(y < x) + #(y == x, q < p).  Both halves are normally ascending
+    // already (stratified coarse depths; fine depths from ascending u through a monotone inverse cdf), and then the
+    // rank is the element's own index plus one binary search in the other half.  Anything else (random u, a 1-ulp
+    // inversion at a bin edge) takes the all-pairs count, which is valid for any input.
     const int K = Kc + Kf;
+    bool ordered = true;
+    for (int p = lane; p < K; p += 64)
+        if (p + 1 < K && p + 1 != Kc) ordered &= zall[p] <= zall[p + 1];
+    if (__all(ordered)) {
+        for (int p = lane; p < K; p += 64) {
+            const float x = zall[p];
+            int rank;
+            if (p < Kc) {                       // + fine entries strictly below x
+                int lo = 0, hi = Kf;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (zall[Kc + mid] < x) lo = mid + 1; else hi = mid; }
+                rank = p + lo;
+            } else {                            // + coarse entries below or equal to x
+                int lo = 0, hi = Kc;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (zall[mid] <= x) lo = mid + 1; else hi = mid; }
+                rank = (p - Kc) + lo;
+            }
+            if (active) {
+                z_sorted_out[r * K + rank] = x;
+                if (perm_out != nullptr) perm_out[r * K + rank] = p;  // z_sorted[rank] = cat(z_coarse, z_fine)[p]
+            }
+        }
+        return;
+    }
     for (int p = lane; p < K; p += 64) {
         float x = zall[p];
         int rank = 0;
