@@ -134,6 +134,14 @@ def main():
     achieved = (mlp_pts * MLP_FLOP_PER_POINT / mlp_s / 1e12) if mlp_s > 0 else 0.0
     kernel_share = {k: round(v[0] / elapsed * 1.0, 4) for k, v in per_kernel.items()}
 
+    # HBM bytes per launch of the MLP kernel: bytes per point measured with rocprofv3 PMC passes (FETCH_SIZE and
+    # WRITE_SIZE in separate runs, gfx950 correction applied; profiles/r01/mlp_hbm_traffic.json) x points per launch
+    traffic = None
+    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "mlp_hbm_traffic.json")
+    if args.mode == "bf16" and mlp_launches and os.path.exists(tf):
+        with open(tf) as fh:
+            traffic = json.load(fh)["bytes_per_point"] * mlp_pts / mlp_launches
+
     result = {
         "metric": "rays/sec (64+64 samples, 256-wide MLP)",
         "value": n_rays * args.steps * world / elapsed,
@@ -163,7 +171,8 @@ def main():
         "roofline": {
             "kernel": f"mlp_kernel<{args.mode}> (fused Fourier encoding + 11 GEMMs)",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": None,
+            "frac": achieved / peak, "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (PMC: 32.1 B per point measured, 32 B algorithmic)",
             "launches": mlp_launches, "avg_launch_ms": (mlp_s / mlp_launches * 1e3) if mlp_launches else None,
             "flop_per_point": MLP_FLOP_PER_POINT,
         },
