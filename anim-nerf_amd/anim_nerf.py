@@ -12,13 +12,16 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .body_model import SMPL, create
+from .body_model import SMPL, create, small_matmul, small_matvec
 from .nerf import NeRF
 
 
 def batch_transform(P, v, pad_ones=True):
     """(P @ [v, 1|0])[:3]   (models/anim_nerf.py:31-39)."""
-    out = (P[..., :3, :3] @ v[..., None])[..., 0]
+    if torch.is_grad_enabled() and (P.requires_grad or v.requires_grad):
+        out = small_matvec(P[..., :3, :3], v)             # training: no batched-GEMM call per tiny product
+    else:
+        out = (P[..., :3, :3] @ v[..., None])[..., 0]
     return out + P[..., :3, 3] if pad_ones else out
 
 
@@ -31,12 +34,12 @@ def _ober2cano_autograd(T, T_template, offset_delta):
     adj = torch.stack([c(r1, r2), c(r2, r0), c(r0, r1)], dim=-1)          # columns = cofactor rows -> adjugate
     det = (r0 * c(r1, r2)).sum(-1)
     Rinv = adj / det[..., None, None]
-    tinv = -(Rinv @ t[..., None])[..., 0] + offset_delta
+    tinv = -small_matvec(Rinv, t) + offset_delta
     M = torch.zeros_like(T)
     M[..., :3, :3] = Rinv
     M[..., :3, 3] = tinv
     M[..., 3, 3] = 1
-    return T_template @ M
+    return small_matmul(T_template, M)
 
 
 class AnimNeRF(nn.Module):
@@ -132,7 +135,8 @@ class AnimNeRF(nn.Module):
         self._knn_index = None
         self.joints = batch_transform(G, self.joints)
         self.global_transform = g_inv @ self.global_transform
-        self.verts_transform = G @ self.verts_transform
+        self.verts_transform = (small_matmul(G, self.verts_transform) if self._pose_grad()
+                                else G @ self.verts_transform)
         return new_rays
 
     def clac_ober2cano_transform(self):

@@ -158,6 +158,83 @@ class MLPFunction(torch.autograd.Function):
         return (d_pts, None, None, None, *out_grads)
 
 
+class NormalFunction(torch.autograd.Function):
+    """normal[n,3] = d alpha / d xyz with alpha = 1 - exp(-delta relu(sigma(xyz))) (models/nerf.py:177-190), and its
+    gradient w.r.t. the trunk and sigma weights — the second-order term of the normals regulariser (train.py:288-309).
+
+    Forward mode instead of autograd-of-autograd: the three tangents d/dx, d/dy, d/dz ride through the trunk as three
+    extra rows per point (no bias, gated by the ReLU mask of the point's own activations), so the whole term is ONE
+    4n-row pass through 9 library GEMMs; ReLU has zero curvature almost everywhere, so the backward is the plain linear
+    backward of that 4n-row pass (bias gradients from the primal rows only).  ~80 launches instead of ~1400."""
+
+    KEYS = [k for i in range(1, 9) for k in (f"xyz_encoding_{i}.0.weight", f"xyz_encoding_{i}.0.bias")] + ["sigma.weight", "sigma.bias"]
+
+    @staticmethod
+    def forward(ctx, xyz, delta, *params):
+        P = dict(zip(NormalFunction.KEYS, [p.detach() for p in params]))
+        n = xyz.shape[0]
+        x = xyz.detach()
+        e = _encode(x)                                                # [n,63]
+        # tangents of the encoding: d e / d x_d  -> T0[3, n, 63]
+        T0 = x.new_zeros(3, n, 63)
+        eye = torch.eye(3, device=x.device, dtype=x.dtype)
+        T0[:, :, 0:3] = eye[:, None, :]
+        for k in range(10):
+            f = float(2 ** k)
+            sin, cos = e[:, 3 + 6 * k:6 + 6 * k], e[:, 6 + 6 * k:9 + 6 * k]
+            T0[:, :, 3 + 6 * k:6 + 6 * k] = eye[:, None, :] * (f * cos)[None]
+            T0[:, :, 6 + 6 * k:9 + 6 * k] = eye[:, None, :] * (-f * sin)[None]
+        X0 = torch.cat([e[None], T0], 0)                              # [4, n, 63]: primal row group + 3 tangent groups
+        saved_in, masks = [], []
+        h = X0
+        for l in range(1, 9):
+            inp = X0 if l == 1 else torch.cat([X0, h], -1) if l == 5 else h
+            pre = inp @ P[f"xyz_encoding_{l}.0.weight"].t()           # [4, n, 256]
+            pre[0] += P[f"xyz_encoding_{l}.0.bias"]
+            mask = pre[0] > 0
+            h = pre * mask
+            saved_in.append(inp)
+            masks.append(mask)
+        sig = h @ P["sigma.weight"].t()                               # [4, n, 1]
+        sig[0] += P["sigma.bias"]
+        s0 = sig[0, :, 0]
+        pos = s0 > 0
+        scale = torch.where(pos, delta * torch.exp(-delta * s0), torch.zeros_like(s0))     # d alpha / d sigma
+        normal = (scale[None] * sig[1:, :, 0]).t().contiguous()       # [n, 3]
+        ctx.save_for_backward(h, sig, scale, *saved_in, *masks, *params)
+        ctx.delta = delta
+        return normal
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        h8, sig, scale = saved[:3]
+        saved_in, masks, params = saved[3:11], saved[11:19], saved[19:]
+        P = dict(zip(NormalFunction.KEYS, params))
+        delta = ctx.delta
+        grads = {}
+        gt = g.t()                                                    # [3, n]
+        d_sig = torch.empty_like(sig)                                 # [4, n, 1]
+        d_sig[1:, :, 0] = gt * scale[None]
+        # d scale / d sigma = -delta * scale where sigma > 0
+        d_sig[0, :, 0] = (gt * sig[1:, :, 0]).sum(0) * (-delta) * scale
+        grads["sigma.weight"] = torch.einsum("gno,gnc->oc", d_sig, h8)
+        grads["sigma.bias"] = d_sig[0].sum(0)
+        dh = d_sig * P["sigma.weight"]                                # [4, n, 256]
+        for l in range(8, 0, -1):
+            dpre = dh * masks[l - 1]
+            inp = saved_in[l - 1]
+            W = P[f"xyz_encoding_{l}.0.weight"]
+            grads[f"xyz_encoding_{l}.0.weight"] = dpre.reshape(-1, dpre.shape[-1]).t() @ inp.reshape(-1, inp.shape[-1])
+            grads[f"xyz_encoding_{l}.0.bias"] = dpre[0].sum(0)
+            if l > 1:
+                dh = dpre @ (W[:, 63:] if l == 5 else W)
+        out = [grads[k].reshape(p.shape) if ctx.needs_input_grad[2 + i] else None
+               for i, (k, p) in enumerate(zip(NormalFunction.KEYS, params))]
+        return (None, None, *out)
+
+
 class CompositeFunction(torch.autograd.Function):
     """(weights, rgb, depth, acc) = composite(rgbs[R,K,4], z[R,K], rays[R,>=8]); differentiable w.r.t. rgbs."""
 

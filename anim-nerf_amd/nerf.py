@@ -117,8 +117,7 @@ class NeRF(nn.Module):
         return self.eval_points(self._pack_xyz(xyz), sigma_only=True).view(*xyz.shape[:-1], 1)
 
     def _sigma_dense(self, xyz):
-        """sigma(xyz) as a chain of library GEMMs under torch autograd — ONLY for get_normal, whose loss needs the
-        gradient of a gradient (second order), which the fused kernel's hand-written backward does not provide."""
+        """sigma(xyz) as a chain of library GEMMs under torch autograd (cross-check of get_normal in the tests)."""
         e = self.encoding_xyz(xyz)
         h = e
         for i in range(self.D):
@@ -129,9 +128,18 @@ class NeRF(nn.Module):
         return self.sigma(h)
 
     def get_normal(self, xyz, deformation_code=None, delta=0.02):
-        """models/nerf.py:177-190: d alpha / d xyz with create_graph=True (the normals regulariser, train.py:288-309,
-        differentiates it again w.r.t. the weights).  441 k points per step on the template vertices: a small
-        side computation, kept on torch autograd (documented in DESIGN.md section 7)."""
+        """models/nerf.py:177-190: d alpha / d xyz, differentiable once more w.r.t. the weights (the normals regulariser,
+        train.py:288-309).  Forward-mode tangents through library GEMMs with a hand-written backward
+        (`autograd.NormalFunction`); the inputs are constants of the loss, as in the reference's call sites."""
+        from .autograd import NormalFunction
+        named = dict(self.named_parameters())
+        flat = xyz.detach().reshape(-1, 3)
+        with torch.set_grad_enabled(True):
+            n = NormalFunction.apply(flat, float(delta), *[named[k] for k in NormalFunction.KEYS])
+        return n.view(*xyz.shape[:-1], 3)
+
+    def _normal_autograd(self, xyz, delta=0.02):
+        """The same quantity by autograd of autograd over `_sigma_dense` (reference formulation; used by the tests)."""
         with torch.set_grad_enabled(True):
             xyz = xyz.detach().requires_grad_(True)
             alpha = 1 - torch.exp(-delta * torch.relu(self._sigma_dense(xyz)))

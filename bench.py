@@ -178,6 +178,19 @@ def main():
         },
         "kernel_time_share": kernel_share,
     }
+    # everything around the MLP (sampling, point generation / warp, compaction, compositing,
+    # importance sampling) against the HBM roofline on its COMPULSORY bytes: 52 B per ray + 36 B per sample
+    # (z 4 B, canonical point 16 B, rgb-sigma 16 B).  With the warp on the binding resource is VALU issue (exact KNN),
+    # so the HBM fraction there is a lower bound on how far those kernels are from their own limit.
+    other_s = sum(v[0] for k, v in per_kernel.items() if k != "mlp_forward")
+    evals = args.n_coarse + (args.n_coarse + args.n_fine if args.n_fine else 0)
+    comp_bytes = n_rays * args.steps * (52 + 36 * evals)
+    result["roofline_hbm_kernels"] = {
+        "kernels": sorted(k for k in per_kernel if k != "mlp_forward"), "bound": "hbm" if not use_warp else "valu (exact 4-NN)",
+        "achieved": comp_bytes / other_s / 1e9 if other_s > 0 else None, "peak": 8000.0, "unit": "GB/s",
+        "frac": comp_bytes / other_s / 8e12 if other_s > 0 else None, "compulsory_bytes_per_ray": 52 + 36 * evals,
+        "ms_per_step": other_s / args.steps * 1e3,
+    }
 
     if rank == 0 and world == 1:
         if not args.no_psnr:

@@ -95,3 +95,28 @@ def test_shard_range_partitions_exactly():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_forward_mode_normals_equal_double_backward():
+    """NeRF.get_normal (forward-mode tangents + hand-written backward, autograd.NormalFunction) against autograd of
+    autograd over the same layers (models/nerf.py:177-190), in fp64 on the CPU: values and all 18 weight gradients."""
+    import anim_nerf_amd as ana
+    torch.manual_seed(0)
+    net = ana.NeRF(freqs_dir=0, use_view=False).double()
+    xyz = torch.rand(1, 200, 3, dtype=torch.double) * 1.2 - 0.6
+    with torch.no_grad():                                   # sigma must straddle 0 or every normal is 0
+        med = net._sigma_dense(xyz).median()
+        net.sigma.weight.mul_(300)
+        net.sigma.bias.mul_(300).add_(-300 * med)
+    grads = []
+    for fn in (net.get_normal, net._normal_autograd):
+        net.zero_grad()
+        n = fn(xyz)
+        (n ** 2).sum().backward()
+        grads.append((n.detach(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+    (n1, g1), (n2, g2) = grads
+    assert 0.2 < (n2.abs().sum(-1) > 0).double().mean() < 0.8
+    assert (n1 - n2).abs().max() < 1e-12 * n2.abs().max()
+    assert set(g1) == set(g2) and len(g1) == 18
+    for k in g2:
+        assert (g1[k] - g2[k]).norm() <= 1e-12 * g2[k].norm(), k
