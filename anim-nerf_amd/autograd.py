@@ -158,6 +158,18 @@ class MLPFunction(torch.autograd.Function):
         return (d_pts, None, None, None, *out_grads)
 
 
+def _splitk_tn(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dy[rows, o]^T @ x[rows, c] with the long reduction split into S batches: a [256 x rows] x [rows x 256] product gives
+    the library 16 output tiles for 256 CUs."""
+    rows = dy.shape[0]
+    S = 1
+    while S < 64 and rows % (2 * S) == 0 and rows // (2 * S) >= 512:
+        S *= 2
+    if S == 1:
+        return dy.t() @ x
+    return torch.bmm(dy.view(S, rows // S, -1).transpose(1, 2), x.view(S, rows // S, -1)).sum(0)
+
+
 class NormalFunction(torch.autograd.Function):
     """normal[n,3] = d alpha / d xyz with alpha = 1 - exp(-delta relu(sigma(xyz))) (models/nerf.py:177-190), and its
     gradient w.r.t. the trunk and sigma weights — the second-order term of the normals regulariser (train.py:288-309).
@@ -226,7 +238,7 @@ class NormalFunction(torch.autograd.Function):
             dpre = dh * masks[l - 1]
             inp = saved_in[l - 1]
             W = P[f"xyz_encoding_{l}.0.weight"]
-            grads[f"xyz_encoding_{l}.0.weight"] = dpre.reshape(-1, dpre.shape[-1]).t() @ inp.reshape(-1, inp.shape[-1])
+            grads[f"xyz_encoding_{l}.0.weight"] = _splitk_tn(dpre.reshape(-1, dpre.shape[-1]), inp.reshape(-1, inp.shape[-1]))
             grads[f"xyz_encoding_{l}.0.bias"] = dpre[0].sum(0)
             if l > 1:
                 dh = dpre @ (W[:, 63:] if l == 5 else W)
