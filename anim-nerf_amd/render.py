@@ -78,7 +78,9 @@ def sigma_grid(anim_nerf, N_grid=256, x_range=(-1.2, 1.2), y_range=(-1.2, 1.2), 
         pts = ops.grid_points(N_grid, x_range, y_range, z_range, center[0], s, n)
         if anim_nerf.use_unpose:
             pts = anim_nerf.warped_points(xyz=pts.view(1, n, 4), skip_far=True)
-        out[s - lo:s - lo + n] = torch.relu_(net.eval_points(pts, sigma_only=True))
+        # voxels farther than dis_threshold from the body are sigma = -1e5 -> relu = 0: the MLP runs on the others only
+        out[s - lo:s - lo + n] = torch.relu_(net.eval_points(pts, sigma_only=True,
+                                                             only_valid=anim_nerf.evaluate_valid_only))
     return out, lo
 
 
