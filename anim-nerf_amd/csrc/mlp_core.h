@@ -272,26 +272,42 @@ struct Mlp {
 #endif
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                f32x4 keep;
+                if constexpr (C::IS_BF16) {
+                    // round the pairs to bf16 first, then ReLU both halves of a dword with one packed integer max
+                    // (sign bit set <=> negative as int16): 2 + 2 instructions per 4 values instead of 4 + 2
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    typedef short s16x2 __attribute__((ext_vector_type(2)));
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    unsigned pk[2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = a[n][4 * Q + i];
-                    if (RELU) v = __int_as_float(max(__float_as_int(v), 0));       // relu as one v_max_i32
-                    put(Y[n][TB + (4 * Q + i) / EPF], (4 * Q + i) % EPF, v);
-                    keep[i] = v;
-                }
-                if ((4 * Q + 4) % EPF == 0) pin(Y[n][TB + (4 * Q) / EPF]);
-                // features 32t + 8Q + 4h + (0..3) of this lane's point: 16 contiguous bytes of its row
-                if (SAVE && ar[n] != nullptr) {
-                    if constexpr (C::IS_BF16) {
-                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                        bf16x4 k4;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) k4[i] = (__bf16)keep[i];
-                        *reinterpret_cast<bf16x4*>(ar[n] + act_col(TG) + 8 * Q) = k4;
-                    } else {
-                        *reinterpret_cast<f32x4*>(ar[n] + act_col(TG) + 8 * Q) = keep;
+                    for (int i = 0; i < 2; ++i) {
+                        const f32x2 v2 = {a[n][4 * Q + 2 * i], a[n][4 * Q + 2 * i + 1]};
+                        const bf16x2 b2 = __builtin_convertvector(v2, bf16x2);
+                        s16x2 s2 = __builtin_bit_cast(s16x2, b2);
+                        if (RELU) s2 = __builtin_elementwise_max(s2, s16x2{0, 0});
+                        pk[i] = __builtin_bit_cast(unsigned, s2);
                     }
+                    Frag& dst = Y[n][TB + (4 * Q) / EPF];
+                    u32x4 d4 = __builtin_bit_cast(u32x4, dst);
+                    d4[((4 * Q) % EPF) / 2] = pk[0];
+                    d4[((4 * Q) % EPF) / 2 + 1] = pk[1];
+                    dst = __builtin_bit_cast(Frag, d4);
+                    if ((4 * Q + 4) % EPF == 0) pin(dst);
+                    // features 32t + 8Q + 4h + (0..3) of this lane's point: 8 contiguous bytes of its row
+                    if (SAVE && ar[n] != nullptr)
+                        *reinterpret_cast<uint2*>(ar[n] + act_col(TG) + 8 * Q) = make_uint2(pk[0], pk[1]);
+                } else {
+                    f32x4 keep;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = a[n][4 * Q + i];
+                        if (RELU) v = __int_as_float(max(__float_as_int(v), 0));   // relu as one v_max_i32
+                        put(Y[n][TB + (4 * Q + i) / EPF], (4 * Q + i) % EPF, v);
+                        keep[i] = v;
+                    }
+                    if ((4 * Q + 4) % EPF == 0) pin(Y[n][TB + (4 * Q) / EPF]);
+                    if (SAVE && ar[n] != nullptr) *reinterpret_cast<f32x4*>(ar[n] + act_col(TG) + 8 * Q) = keep;
                 }
             }
         }
