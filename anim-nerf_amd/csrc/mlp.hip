@@ -6,7 +6,7 @@ namespace anr {
 
 // instantiated in mlp_inst_*.hip
 #define ANR_MLP_EXTERN(M, D, S, V) \
-    extern template int launch_mlp<M, D, S, V>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*);
+    extern template int launch_mlp<M, D, S, V>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*, const float*, int, int);
 ANR_MLP_EXTERN(ANR_MLP_F32, true, false, false)  ANR_MLP_EXTERN(ANR_MLP_F32, false, false, false)
 ANR_MLP_EXTERN(ANR_MLP_F32, true, true, false)   ANR_MLP_EXTERN(ANR_MLP_F32, true, false, true)
 ANR_MLP_EXTERN(ANR_MLP_F32, true, true, true)
@@ -174,6 +174,23 @@ extern "C" int anr_mlp_forward_save_indexed(const void* pack, int mode, const fl
 
 extern "C" int anr_mlp_forward(const void* pack, int mode, const float* pts, int64_t n, float* out, void* stream) {
     return anr_mlp_forward_indexed(pack, mode, pts, nullptr, nullptr, n, out, stream);
+}
+
+extern "C" int anr_mlp_forward_rays(const void* pack, int mode, const float* rays, int ray_stride, const float* z, int K,
+                                    int64_t n, float* out, void* stream) {
+    ANR_REQUIRE(pack && rays && z && out, ANR_E_BADARG, "anr_mlp_forward_rays: null pointer");
+    ANR_REQUIRE(n > 0 && n < (int64_t)1 << 32 && K > 0 && n % K == 0 && ray_stride >= 8, ANR_E_BADARG,
+                "anr_mlp_forward_rays: n=%lld K=%d stride=%d", (long long)n, K, ray_stride);
+    ANR_REQUIRE((((uintptr_t)pack | (uintptr_t)out) & 15) == 0, ANR_E_ALIGN, "anr_mlp_forward_rays: pack/out must be 16-B aligned");
+    ANR_REQUIRE(!(mode & ANR_MLP_FLAG_SIGMA_ONLY), ANR_E_BADARG, "anr_mlp_forward_rays: rgb + sigma only");
+    hipStream_t st = (hipStream_t)stream;
+    switch (mode & 0xff) {
+        case ANR_MLP_F32:
+            return launch_mlp<ANR_MLP_F32, true, false, false>(pack, z, n, out, st, nullptr, nullptr, nullptr, rays, ray_stride, K);
+        case ANR_MLP_BF16:
+            return launch_mlp<ANR_MLP_BF16_W8, true, false, false>(pack, z, n, out, st, nullptr, nullptr, nullptr, rays, ray_stride, K);
+        default: return fail(ANR_E_BADARG, "anr_mlp_forward_rays: unknown mode %d", mode);
+    }
 }
 
 extern "C" int anr_mlp_forward_indexed(const void* pack, int mode, const float* pts, const int32_t* index,

@@ -398,7 +398,8 @@ struct Mlp {
     // compacted list of valid samples (anr_compact_valid); saved activations are rows i of the compacted order.
     __device__ __forceinline__ void run(const char* __restrict__ pack, const float4* __restrict__ pts, int64_t n_pts,
                                         void* __restrict__ out_v, float* __restrict__ act, char* lds,
-                                        const int32_t* __restrict__ index, const int32_t* __restrict__ count) {
+                                        const int32_t* __restrict__ index, const int32_t* __restrict__ count,
+                                        const float* __restrict__ rays, int ray_stride, int K) {
         if (count) {
             const int64_t cnt = *count;
             n_pts = cnt < n_pts ? cnt : n_pts;
@@ -438,6 +439,18 @@ struct Mlp {
                     const int32_t id = index[idx];
                     dst[n] = pts[id];
                     dst[n].w = __int_as_float(id);
+#ifndef ANR_ABL_NO_RAYS
+                } else if (rays) {
+                    // no warp (use_unpose=False): the sample point is generated here, x = o + z d with the product and
+                    // the sum rounded separately like anr_points_from_rays; `pts` is then the depth array z[n]
+                    const float zz = reinterpret_cast<const float*>(pts)[idx];
+                    const float* ry = rays + (int64_t)((uint32_t)idx / (uint32_t)K) * ray_stride;
+                    // (the product goes through an asm statement: hipcc would contract it into an fma otherwise)
+                    float m[3];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) asm("v_mul_f32_e32 %0, %1, %2" : "=v"(m[a]) : "v"(zz), "v"(ry[3 + a]));
+                    dst[n] = make_float4(ry[0] + m[0], ry[1] + m[1], ry[2] + m[2], 1.0f);
+#endif
                 } else {
                     dst[n] = pts[idx];
                 }
@@ -564,15 +577,17 @@ __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void m
                                                              const float4* __restrict__ pts, int64_t n_pts,
                                                              void* __restrict__ out, float* __restrict__ act,
                                                              const int32_t* __restrict__ index,
-                                                             const int32_t* __restrict__ count) {
+                                                             const int32_t* __restrict__ count,
+                                                             const float* __restrict__ rays, int ray_stride, int K) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     Mlp<MODE, DMA, SIGMA_ONLY, SAVE> m;
-    m.run(pack, pts, n_pts, out, act, lds, index, count);
+    m.run(pack, pts, n_pts, out, act, lds, index, count, rays, ray_stride, K);
 }
 
 template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE>
 int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStream_t st, float* act,
-               const int32_t* index = nullptr, const int32_t* count = nullptr) {
+               const int32_t* index = nullptr, const int32_t* count = nullptr, const float* rays = nullptr,
+               int ray_stride = 0, int K = 1) {
     using C = Cfg<MODE>;
     const int lds = BIAS_BYTES + 3 * slot_bytes<C>();
     auto kern = mlp_kernel<MODE, DMA, SIGMA_ONLY, SAVE>;
@@ -584,7 +599,7 @@ int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStr
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     dim3 grid((unsigned)(n_tiles < cus ? n_tiles : cus));          // one persistent workgroup per CU (LDS-limited)
     hipLaunchKernelGGL(kern, grid, dim3(C::WAVES * 64), lds, st, reinterpret_cast<const char*>(pack),
-                       reinterpret_cast<const float4*>(pts), n, reinterpret_cast<void*>(out), act, index, count);
+                       reinterpret_cast<const float4*>(pts), n, reinterpret_cast<void*>(out), act, index, count, rays, ray_stride, K);
     return check_launch("anr_mlp_forward");
 }
 

@@ -2,6 +2,6 @@
 #include "mlp_core.h"
 
 namespace anr {
-template int launch_mlp<ANR_MLP_F32, true, false, true>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*);
-template int launch_mlp<ANR_MLP_F32, true, true, true>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*);
+template int launch_mlp<ANR_MLP_F32, true, false, true>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*, const float*, int, int);
+template int launch_mlp<ANR_MLP_F32, true, true, true>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*, const float*, int, int);
 }  // namespace anr

@@ -101,6 +101,12 @@ class NeRF(nn.Module):
         pack, mode_id = self.weight_pack(mode)
         return ops.mlp_forward(pack, mode_id, pts, sigma_only=sigma_only, only_valid=only_valid)
 
+    def eval_rays(self, rays: torch.Tensor, z: torch.Tensor, mode: Optional[str] = None) -> torch.Tensor:
+        """[n,4] = (r,g,b,sigma) at the samples o + z d of rays[bs,R,>=8], z[bs,R,K] (inference, no warp): the kernel
+        generates the points itself."""
+        pack, mode_id = self.weight_pack(mode)
+        return ops.mlp_forward_rays(pack, mode_id, rays, z)
+
     def _pack_xyz(self, xyz):
         flat = xyz.reshape(-1, 3)
         return torch.cat([flat, torch.ones_like(flat[:, :1])], -1)

@@ -332,6 +332,20 @@ def mlp_forward(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bo
     return out
 
 
+def mlp_forward_rays(pack: torch.Tensor, mode: int, rays: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    """use_unpose=False: out[n,4] = NeRF(o + z d) for rays[bs,R,>=8], z[bs,R,K], n = bs R K; the sample points are
+    generated inside the MLP kernel (no pts array)."""
+    lib = _lib.load()
+    rays, z = _dev(rays, "rays"), _dev(z, "z")
+    K = z.shape[-1]
+    n = z.numel()
+    out = torch.empty(n, 4, dtype=torch.float32, device=z.device)
+    with _timed("mlp_forward", n):
+        _lib.check(lib.anr_mlp_forward_rays(_ptr(pack), mode & 0xff, _ptr(rays), rays.shape[-1], _ptr(z), K, n, _ptr(out),
+                                            _stream(out)), "anr_mlp_forward_rays")
+    return out
+
+
 def grid_points(N: int, x_range, y_range, z_range, center: torch.Tensor, first: int, count: int) -> torch.Tensor:
     """extract_mesh.py:27-35,152-157: slab [first, first+count) of the flattened N^3 grid -> pts[count,4]."""
     lib = _lib.load()

@@ -58,7 +58,11 @@ class VolumeRenderer(nn.Module):
     def _shade(self, model, rays, z, coarse, perturb, want_weights, **kwargs):
         bs, R, K = z.shape
         fused = hasattr(model, "warped_points") and hasattr(model, "_net")
-        if fused:
+        net = model._net(not coarse) if fused else None
+        if fused and not model.use_unpose and not (torch.is_grad_enabled() and (
+                rays.requires_grad or z.requires_grad or any(p.requires_grad for p in net.parameters()))):
+            out = net.eval_rays(rays, z)                         # no warp, inference: points are generated in the MLP kernel
+        elif fused:
             pts = model.warped_points(rays=rays, z=z, skip_far=True)
             # with the warp on, only samples near the body carry a density: the MLP runs on those (bit-identical
             # render: the others composite with weight exactly 0)

@@ -187,6 +187,11 @@ int anr_mlp_forward(const void* pack, int mode, const float* pts, int64_t n,
  *
  * anr_mlp_forward_indexed: for i < min(n, *count) (count may be NULL: all n): out[index[i]] = NeRF(pts[index[i]]);
  * other rows of out are not touched.  index = NULL is anr_mlp_forward.  n bounds the launch (n < 2^31). */
+/* No warp (use_unpose=False, models/anim_nerf.py:296-297): the kernel generates the sample points itself,
+ * point i = ray i / K, depth z[i], x = o + z d (rounded like anr_points_from_rays), valid = 1 — the 16-B point array
+ * of anr_points_from_rays + anr_mlp_forward is never written or read.  Same output bits.  n < 2^32, n % K == 0. */
+int anr_mlp_forward_rays(const void* pack, int mode, const float* rays, int ray_stride, const float* z, int K,
+                         int64_t n, float* out, void* stream);
 int anr_compact_valid(const float* pts, int64_t n, int32_t* index_out, int32_t* count_out,
                       float* fill_out, int fill_cols, void* stream);
 int anr_mlp_forward_indexed(const void* pack, int mode, const float* pts, const int32_t* index,

@@ -348,6 +348,22 @@ def test_generic_model_path_equals_fused_path(dev, smpl_table):
         torch.testing.assert_close(generic[k], fused[k], rtol=2e-3, atol=2e-4)
 
 
+def test_mlp_from_rays_equals_points_then_mlp(dev, smpl_table):
+    """anr_mlp_forward_rays (points generated inside the MLP kernel) = anr_points_from_rays + anr_mlp_forward, bit for bit."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import ops
+    torch.manual_seed(4)
+    net = ana.NeRF(freqs_dir=0, use_view=False).to(dev)
+    rays = torch.from_numpy(golden("frame")["rays_body"]).to(dev)              # [2, R, 8]
+    for K in (1, 7, 64):
+        z = ana.VolumeRenderer(n_coarse=max(K, 3)).sample_coarse(rays)[..., :K].contiguous()
+        for mode in ("f32", "bf16"):
+            pack, mode_id = net.weight_pack(mode)
+            a = ops.mlp_forward(pack, mode_id, ops.points_from_rays(rays, z))
+            b = ops.mlp_forward_rays(pack, mode_id, rays, z)
+            assert torch.equal(a, b), (K, mode)
+
+
 def test_compact_valid_and_indexed_mlp(dev, smpl_table):
     """anr_compact_valid lists exactly the samples with valid >= 1; anr_mlp_forward_indexed gives those the bits the
     dense kernel gives them and leaves (0,0,0,-1e5) elsewhere (query_canonical_space_inside, models/anim_nerf.py:245-290)."""
