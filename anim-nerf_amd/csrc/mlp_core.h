@@ -362,10 +362,25 @@ struct Mlp {
                     if (f == 0) acc[PAR][n] = mma_c(use[q], x, bias_c);
                     else        mma(use[q], x, acc[PAR][n]);
                 }
+#ifdef ANR_EPI_ONE_GROUP
                 if (j == 0) {
                     pending.template part<q>();
                     __builtin_amdgcn_sched_barrier(0);  // keep the epilogue pieces between the MFMAs
                 }
+#else
+                // The four quarters of the previous tile's epilogue ride behind MFMAs of the first TWO groups (one
+                // quarter per two MFMA steps): packed into one group they need more issue slots than its MFMAs leave.
+                // (A two-group tile consumes the fragments the epilogue produces in its second group: keep one group.)
+                if constexpr (NG >= 3) {
+                    if (j < 2 && (q & 1)) {
+                        pending.template part<2 * (j < 2 ? j : 0) + (q >> 1)>();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (j == 0) {
+                    pending.template part<q>();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
             });
         });
 #pragma unroll
