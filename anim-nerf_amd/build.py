@@ -13,6 +13,11 @@ SOURCES = ["frame_ops.hip", "smpl.hip", "composite.hip", "compact.hip", "warp.hi
 HEADERS = ["anr_common.h", "mlp_core.h", os.path.join("..", "..", "include", "animnerf_hip.h")]
 
 
+# The 4-wave x 64-point bf16 variant needs more than 256 registers per lane: with the accumulators in AGPRs (hipcc's
+# default) its epilogue spends 2,700 v_accvgpr_read per point tile; VGPR-form MFMAs cut that to 500 (51 -> 54 % of peak).
+PER_SOURCE_FLAGS = {"mlp_inst_bf16_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
@@ -28,20 +33,22 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, defines=(), out: str = None) -> str:
+def build(force: bool = False, verbose: bool = False, defines=(), out: str = None, extra_flags=()) -> str:
     """Compile every HIP source for gfx950 and link the shared library.  Returns its path.
     `defines`/`out` build an experiment variant (e.g. timing ablations) next to the product library."""
     lib_path = out or LIB_PATH
-    if not defines and not out and not force and not _stale():
+    if not defines and not out and not force and not extra_flags and not _stale():
         return LIB_PATH
     objs = []
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
-             "-Wno-unused-value", "-Wno-pass-failed"] + [f"-D{d}" for d in defines]
+             "-Wno-unused-value", "-Wno-pass-failed"] + [f"-D{d}" for d in defines] + list(extra_flags)
     tag = ("." + "_".join(defines)) if defines else ""
+    if extra_flags:
+        tag += ".x%08x" % (hash(tuple(extra_flags)) & 0xffffffff)
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", tag + ".o"))
-        cmd = [_hipcc(), *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc(), *flags, *PER_SOURCE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -62,4 +69,6 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = Non
 if __name__ == "__main__":
     defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
     outs = [a[6:] for a in sys.argv[1:] if a.startswith("--out=")]
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, defines=defs, out=outs[0] if outs else None))
+    extra = [f for a in sys.argv[1:] if a.startswith("--flag=") for f in a[7:].split(",")]
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, defines=defs, out=outs[0] if outs else None,
+                extra_flags=extra))
