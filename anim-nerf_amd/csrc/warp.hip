@@ -450,14 +450,16 @@ constexpr int NCELL = GRID * GRID * GRID;
 constexpr float MIN_CELL = 0.04f;
 
 struct WarpWs {
-    int32_t *list, *cells, *sorted, *count, *cursor, *live, *cell_count, *cell_start;
+    int32_t *list, *cells, *sorted, *count, *cursor, *live, *occ_count, *occ_cursor, *cell_count, *cell_start, *occ_list;
     float* cell_cap2;
-    __host__ static int64_t ints(int bs, int64_t N) { return 3 * (int64_t)bs * N + 3 * bs + 3 * (int64_t)bs * NCELL; }
-    __host__ static int64_t zeroed_ints(int bs) { return 3 * bs + (int64_t)bs * NCELL; }      // from `count` on
+    __host__ static int64_t ints(int bs, int64_t N) { return 3 * (int64_t)bs * N + 5 * bs + 4 * (int64_t)bs * NCELL; }
+    __host__ static int64_t zeroed_ints(int bs) { return 5 * bs + (int64_t)bs * NCELL; }      // from `count` on
     __host__ WarpWs(int32_t* ws, int bs, int64_t N) {
         list = ws; cells = list + (int64_t)bs * N; sorted = cells + (int64_t)bs * N; count = sorted + (int64_t)bs * N;
-        cursor = count + bs; live = cursor + bs; cell_count = live + bs; cell_start = cell_count + (int64_t)bs * NCELL;
+        cursor = count + bs; live = cursor + bs; occ_count = live + bs; occ_cursor = occ_count + bs;
+        cell_count = occ_cursor + bs; cell_start = cell_count + (int64_t)bs * NCELL;
         cell_cap2 = reinterpret_cast<float*>(cell_start + (int64_t)bs * NCELL);
+        occ_list = cell_start + 2 * (int64_t)bs * NCELL;
     }
 };
 
@@ -564,29 +566,74 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
 //   * otherwise (d4(c) + r)^2 bounds the 4th-neighbour distance of every point of the cell: searching inside that
 //     radius finds the exact four neighbours in one go (no unbounded retry).
 // cell_cap2[cell] = that squared radius, or -1 for a dead cell; defined for cells with a non-zero count only.
+__global__ __launch_bounds__(WARP_THREADS) void warp_cell_list_kernel(const int32_t* __restrict__ cell_count,
+                                                                      int32_t* __restrict__ occ_list,
+                                                                      int32_t* __restrict__ occ_count) {
+    // ids of the occupied cells, compacted (order preserved inside blocks of 4096 cells): the per-cell searches below
+    // then run with full wavefronts instead of one wavefront per 64 consecutive cells of which a few are occupied
+    __shared__ int wave_cnt[WARP_THREADS / 64];
+    __shared__ int block_base;
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int first = (blockIdx.x * WARP_THREADS + threadIdx.x) * 4;
+    const int4 v = *reinterpret_cast<const int4*>(cell_count + (int64_t)b * NCELL + first);
+    const int mine = (v.x > 0) + (v.y > 0) + (v.z > 0) + (v.w > 0);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_cnt[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < WARP_THREADS / 64; ++w) { int c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
+        block_base = tot ? atomicAdd(occ_count + b, tot) : 0;
+    }
+    __syncthreads();
+    int pos = block_base + wave_cnt[wave] + incl - mine;
+    int32_t* out = occ_list + (int64_t)b * NCELL;
+    if (v.x > 0) out[pos++] = first;
+    if (v.y > 0) out[pos++] = first + 1;
+    if (v.z > 0) out[pos++] = first + 2;
+    if (v.w > 0) out[pos++] = first + 3;
+}
+
 __global__ __launch_bounds__(WARP_THREADS) void warp_cells_kernel(const float* __restrict__ index, IndexDims d, float thr,
-                                                                  const int32_t* __restrict__ cell_count,
+                                                                  const int32_t* __restrict__ occ_list,
+                                                                  const int32_t* __restrict__ occ_count,
+                                                                  int32_t* __restrict__ occ_cursor,
                                                                   float* __restrict__ cell_cap2) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.y;
-    const int32_t* cnt = cell_count + (int64_t)b * NCELL;
+    const int n_occ = occ_count[b];
+    const int n_items = (n_occ + 63) >> 6;
+    if ((int)blockIdx.x * (WARP_THREADS / 64) >= n_items) return;
+    const int32_t* occ = occ_list + (int64_t)b * NCELL;
     float* cap = cell_cap2 + (int64_t)b * NCELL;
     stage_index(index + (int64_t)b * d.total_floats(), d.lds_floats(), lds);
     const float* gbox = lds + d.body_off();
     const float cs = cell_size(gbox, thr);
     const float r = cs * 0.8662f;                        // sqrt(3)/2, rounded up
-    for (int chunk = blockIdx.x; chunk < NCELL / WARP_THREADS; chunk += gridDim.x) {
-        const int cell = chunk * WARP_THREADS + threadIdx.x;
-        const bool occ = cnt[cell] > 0;
-        if (!__any(occ)) continue;
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(occ_cursor + b, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const int i = item * 64 + lane;
+        const bool go = i < n_occ;
+        const int cell = occ[go ? i : n_occ - 1];
         const int ix = cell / (GRID * GRID), iy = (cell / GRID) % GRID, iz = cell % GRID;
         const float cx = gbox[0] - thr + ((float)ix + 0.5f) * cs;
         const float cy = gbox[1] - thr + ((float)iy + 0.5f) * cs;
         const float cz = gbox[2] - thr + ((float)iz + 0.5f) * cs;
         Best4 best;
         best_init(best);
-        search(lds, d, cx, cy, cz, occ, best);
-        if (occ) {
+        search(lds, d, cx, cy, cz, go, best);
+        if (go) {
             const float d1 = sqrtf(best.d[0]), d4 = sqrtf(best.d[3]);
             const float reach = d4 + r;
             cap[cell] = (d1 - r >= thr) ? -1.0f : reach * reach * 1.001f;
@@ -884,8 +931,11 @@ extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* ra
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         int64_t gx = (cus + bs - 1) / bs;                                   // one persistent workgroup per CU in total
         if (int rc = allow_big_lds(warp_cells_kernel, bytes, "anr_warp_points")) return rc;
+        hipLaunchKernelGGL(warp_cell_list_kernel, dim3(NCELL / (4 * WARP_THREADS), bs), dim3(WARP_THREADS), 0, st, w.cell_count,
+                           w.occ_list, w.occ_count);
         hipLaunchKernelGGL(warp_cells_kernel, dim3((unsigned)(gx < NCELL / WARP_THREADS ? gx : NCELL / WARP_THREADS), bs),
-                           dim3(WARP_THREADS), bytes, st, index, d, dis_threshold, w.cell_count, w.cell_cap2);
+                           dim3(WARP_THREADS), bytes, st, index, d, dis_threshold, w.occ_list, w.occ_count, w.occ_cursor,
+                           w.cell_cap2);
         hipLaunchKernelGGL(warp_cell_scan_kernel, dim3(bs), dim3(1024), 0, st, w.cell_count, w.cell_start, w.cell_cap2, w.live);
         const int64_t sc_blocks = (N + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
         hipLaunchKernelGGL(warp_cell_scatter_kernel, dim3((unsigned)(sc_blocks < 1024 ? sc_blocks : 1024), bs), dim3(WARP_THREADS), 0, st,
