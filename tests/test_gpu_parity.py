@@ -321,6 +321,31 @@ def test_render_matches_reference(dev, smpl_table, case):
         assert not off.any()
 
 
+def test_rays_that_miss_the_body_render_background(dev, smpl_table):
+    """A whole call without a single near / valid sample (empty lists all the way: no live cell, no MLP tile):
+    white background, alpha 0, depth = far', in inference and under autograd."""
+    import anim_nerf_amd as ana
+    g = golden("render_cfg3_warp_gain")
+    m = seeded_model(smpl_table, g["seed"], True, g["gain"], g["shift"], device=dev)
+    world = torch.from_numpy(g["rays_world"]).to(dev).clone()
+    world[..., 3:6] = -world[..., 3:6]                          # look away from the body
+    vr = ana.VolumeRenderer(n_coarse=16, n_fine=8)
+    for grad in (False, True):
+        with torch.set_grad_enabled(grad):
+            m.set_body_model(_to(tdict(g), dev), _templ(dev))
+            rays = m.convert_to_body_model_space(world)
+            m.clac_ober2cano_transform()
+            out = vr(m, rays)
+        for k in ("rgbs", "rgbs_fine"):
+            assert torch.equal(out[k], torch.ones_like(out[k])), k
+        for k in ("alphas", "alphas_fine"):
+            assert out[k].abs().max() == 0, k
+        assert torch.equal(out["depths_fine"][..., 0], rays[..., 7])
+        if grad:
+            out["rgbs_fine"].sum().backward()                   # nothing to differentiate, nothing to crash on
+            assert all(p.grad is None or p.grad.abs().max() == 0 for p in m.nerf_fine.parameters())
+
+
 def test_generic_model_path_equals_fused_path(dev, smpl_table):
     """VolumeRenderer.forward(model=<any callable>) hands materialised xyz to the model, as the reference does."""
     import anim_nerf_amd as ana
