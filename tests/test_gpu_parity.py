@@ -346,6 +346,36 @@ def test_rays_that_miss_the_body_render_background(dev, smpl_table):
             assert all(p.grad is None or p.grad.abs().max() == 0 for p in m.nerf_fine.parameters())
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_sparse_paths_are_bit_identical_on_random_frames(dev, smpl_table, seed):
+    """Random poses, camera distances, image sizes and sample counts (two bodies per call): the renderer's sparse path
+    (bounding-box classification, cell sort, dead cells, per-cell radii, MLP on valid samples only) against the dense
+    one (exact search everywhere, MLP everywhere) — every output tensor bit for bit, bf16 and fp32 MLP."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    rng = np.random.RandomState(seed)
+    hw = int(rng.choice([9, 16, 23]))
+    kc, kf = int(rng.choice([8, 33, 64])), int(rng.choice([0, 16, 64]))
+    m = seeded_model(smpl_table, 10 + seed, True, 3000.0, (100.0, 100.0), device=dev)   # sigma > 0 wherever valid
+    pose_np = syn.animated_pose_params(seed=50 + seed, bs=2, pose_std=0.35, transl_z=float(rng.uniform(-4.5, -2.0)))
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in pose_np.items()}
+    c2w, focal, cen = syn.pinhole_camera(hw, hw)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), hw, hw, focal.tolist(), 0.1, 10.0, cen.tolist()).view(1, -1, 8)
+    rays = rays.repeat(2, 1, 1)
+    vr = ana.VolumeRenderer(n_coarse=kc, n_fine=kf)
+    for mode in ("f32", "bf16"):
+        m.nerf.mlp_mode = m.nerf_fine.mlp_mode = mode
+        outs = []
+        for sparse in (True, False):
+            m.skip_far_samples = m.skip_invalid_samples = sparse
+            with torch.no_grad():
+                outs.append(ana.batched_inference(vr, m, rays, pose, _templ(dev), chunk=int(rng.choice([37, 4096]))))
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], outs[1][k]), (k, mode, hw, kc, kf)
+        key = "alphas_fine" if kf else "alphas"
+        assert outs[0][key].max() > 0.2, "the body must be in view"
+
+
 def test_generic_model_path_equals_fused_path(dev, smpl_table):
     """VolumeRenderer.forward(model=<any callable>) hands materialised xyz to the model, as the reference does."""
     import anim_nerf_amd as ana
