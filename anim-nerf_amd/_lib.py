@@ -66,6 +66,11 @@ SIGNATURES = {
     "anr_mlp_act_cols": (_I, []),
     "anr_mlp_forward_save": (_I, [_P, _I, _P, _L, _P, _P, _P]),
     "anr_mlp_forward_save_indexed": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _P]),
+    "anr_encode": (_I, [_P, _I, _L, _I, _P, _P]),
+    "anr_encode_backward": (_I, [_P, _I, _P, _L, _P, _P]),
+    "anr_mlp_bwd_pack_bytes": (_L, [_I]),
+    "anr_mlp_bwd_pack": (_I, [C.POINTER(AnrMlpParams), _I, _P, _P]),
+    "anr_mlp_backward": (_I, [_P, _I, _P, _P, _P, _L, _P]),
     "anr_grid_points": (_I, [_I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, _L, _L, _P, _P]),
     "anr_composite": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "anr_composite_backward": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -32,6 +32,7 @@ class MLPFunction(torch.autograd.Function):
     """out[n,4] = (r,g,b,sigma) (or sigma[n]) = NeRF(pts[n,4]); differentiable w.r.t. the 22 parameter tensors."""
 
     PAD = 4096      # compacted row count is rounded up to this (keeps the split-K weight-gradient GEMMs regular)
+    FUSED_BACKWARD = True    # activation-gradient chain in one HIP kernel (False: the library-GEMM chain, kept as a cross-check)
 
     @staticmethod
     def forward(ctx, pts, sigma_only, mode_id, only_valid, *params):
@@ -39,6 +40,7 @@ class MLPFunction(torch.autograd.Function):
         pts = pts.detach()
         n = pts.shape[0]
         ctx.sigma_only = sigma_only
+        ctx.mode_id = mode_id
         ctx.n_full = n
         idx = None
         if only_valid:
@@ -79,7 +81,12 @@ class MLPFunction(torch.autograd.Function):
         else:
             pts, out, act, *params = ctx.saved_tensors
         dt = act.dtype                                              # fp32 (parity mode) or bf16 (mixed precision)
-        P = {k: (p if p.dtype == dt else p.to(dt)) for k, p in zip(PARAM_KEYS, params)}
+        class _Lazy(dict):                                          # parameters in the compute dtype, cast on first use
+            def __missing__(self, k):
+                p = params[PARAM_KEYS.index(k)]
+                self[k] = p if p.dtype == dt else p.to(dt)
+                return self[k]
+        P = _Lazy()
         n = pts.shape[0]
         H = act[:, :2048].view(n, 8, 256)
         grads = {}
@@ -101,51 +108,79 @@ class MLPFunction(torch.autograd.Function):
             return torch.ops.aten.threshold_backward(dy, h, 0)
 
         valid = (pts[:, 3] >= 1.0).to(g.dtype)                       # sigma is the constant -1e5 where invalid
-        if ctx.sigma_only:
-            g_sig = (g.reshape(n) * valid).to(dt)
-            dh = g_sig[:, None] * P["sigma.weight"]
-        else:
-            g_sig = (g[:, 3] * valid).to(dt)
-            rgb = out[:, :3]
-            d_rgb = (g[:, :3] * rgb * (1 - rgb)).to(dt)               # sigmoid'
-            G = act[:, 2304:2432]
-            F = act[:, 2048:2304]
-            grads["rgb.0.weight"] = wgrad(d_rgb, G)
-            grads["rgb.0.bias"] = d_rgb.sum(0, dtype=torch.float32)
-            dG = relu_bwd(d_rgb @ P["rgb.0.weight"], G)
-            grads["dir_encoding.0.weight"] = wgrad(dG, F)
-            grads["dir_encoding.0.bias"] = dG.sum(0, dtype=torch.float32)
-            dF = dG @ P["dir_encoding.0.weight"]
-            grads["xyz_encoding_final.weight"] = wgrad(dF, H[:, 7])
-            grads["xyz_encoding_final.bias"] = dF.sum(0, dtype=torch.float32)
-            dh = torch.addmm(g_sig[:, None] * P["sigma.weight"], dF, P["xyz_encoding_final.weight"])
-        # (a 1-row operand sends the library down a GEMV path that costs ~11 ms of host time: pad to 2 rows)
-        grads["sigma.weight"] = wgrad(torch.stack([g_sig, torch.zeros_like(g_sig)], 1), H[:, 7])[:1]
-        grads["sigma.bias"] = g_sig.sum(dtype=torch.float32).reshape(1)
-        enc = _encode(pts[:, :3]).to(dt)
+        enc = ops.encode(pts, dt) if pts.is_cuda else _encode(pts[:, :3]).to(dt)
         want_pts = ctx.needs_input_grad[0]
         d_enc = None
-        for l in range(8, 0, -1):
-            dpre = relu_bwd(dh, H[:, l - 1])
-            inp = enc if l == 1 else torch.cat([enc, H[:, l - 2]], -1) if l == 5 else H[:, l - 2]
-            grads[f"xyz_encoding_{l}.0.weight"] = wgrad(dpre, inp)
-            grads[f"xyz_encoding_{l}.0.bias"] = dpre.sum(0, dtype=torch.float32)
-            W = P[f"xyz_encoding_{l}.0.weight"]
-            if l > 1:
-                dh = dpre @ (W[:, 63:] if l == 5 else W)
-            if want_pts and l in (1, 5):
-                t = (dpre @ W[:, :63]).float()
-                d_enc = t if d_enc is None else d_enc + t
+        if MLPFunction.FUSED_BACKWARD:
+            # ONE kernel for the whole activation-gradient chain (csrc/mlp_bwd.hip); the weight gradients below are
+            # plain GEMMs between its output columns and the saved activations
+            g4 = torch.zeros(n, 4, dtype=torch.float32, device=g.device)
+            if ctx.sigma_only:
+                g4[:, 3] = g.reshape(n) * valid
+            else:
+                rgb = out[:, :3]
+                g4[:, :3] = g[:, :3] * rgb * (1 - rgb)                # sigmoid'
+                g4[:, 3] = g[:, 3] * valid
+            bpack = ops.mlp_pack(dict(zip(PARAM_KEYS, params)), ctx.mode_id, backward=True)
+            dact = ops.mlp_backward(bpack, ctx.mode_id, g4, act, sigma_only=ctx.sigma_only)
+            g_sig = g4[:, 3].to(dt)
+            if not ctx.sigma_only:
+                d_rgb = g4[:, :3].to(dt)
+                G, F = act[:, 2304:2432], act[:, 2048:2304]
+                dG, dF = dact[:, 2304:2432], dact[:, 2048:2304]
+                grads["rgb.0.weight"] = wgrad(d_rgb, G)
+                grads["rgb.0.bias"] = d_rgb.sum(0, dtype=torch.float32)
+                grads["dir_encoding.0.weight"] = wgrad(dG, F)
+                grads["dir_encoding.0.bias"] = dG.sum(0, dtype=torch.float32)
+                grads["xyz_encoding_final.weight"] = wgrad(dF, H[:, 7])
+                grads["xyz_encoding_final.bias"] = dF.sum(0, dtype=torch.float32)
+            grads["sigma.weight"] = wgrad(torch.stack([g_sig, torch.zeros_like(g_sig)], 1), H[:, 7])[:1]
+            grads["sigma.bias"] = g_sig.sum(dtype=torch.float32).reshape(1)
+            D = dact[:, :2048].view(n, 8, 256)
+            for l in range(8, 0, -1):
+                dpre = D[:, l - 1]
+                inp = enc if l == 1 else torch.cat([enc, H[:, l - 2]], -1) if l == 5 else H[:, l - 2]
+                grads[f"xyz_encoding_{l}.0.weight"] = wgrad(dpre, inp)
+                grads[f"xyz_encoding_{l}.0.bias"] = dpre.sum(0, dtype=torch.float32)
+                if want_pts and l in (1, 5):
+                    t = (dpre @ P[f"xyz_encoding_{l}.0.weight"][:, :63]).float()
+                    d_enc = t if d_enc is None else d_enc + t
+        else:
+            if ctx.sigma_only:
+                g_sig = (g.reshape(n) * valid).to(dt)
+                dh = g_sig[:, None] * P["sigma.weight"]
+            else:
+                g_sig = (g[:, 3] * valid).to(dt)
+                rgb = out[:, :3]
+                d_rgb = (g[:, :3] * rgb * (1 - rgb)).to(dt)               # sigmoid'
+                G = act[:, 2304:2432]
+                F = act[:, 2048:2304]
+                grads["rgb.0.weight"] = wgrad(d_rgb, G)
+                grads["rgb.0.bias"] = d_rgb.sum(0, dtype=torch.float32)
+                dG = relu_bwd(d_rgb @ P["rgb.0.weight"], G)
+                grads["dir_encoding.0.weight"] = wgrad(dG, F)
+                grads["dir_encoding.0.bias"] = dG.sum(0, dtype=torch.float32)
+                dF = dG @ P["dir_encoding.0.weight"]
+                grads["xyz_encoding_final.weight"] = wgrad(dF, H[:, 7])
+                grads["xyz_encoding_final.bias"] = dF.sum(0, dtype=torch.float32)
+                dh = torch.addmm(g_sig[:, None] * P["sigma.weight"], dF, P["xyz_encoding_final.weight"])
+            # (a 1-row operand sends the library down a GEMV path that costs ~11 ms of host time: pad to 2 rows)
+            grads["sigma.weight"] = wgrad(torch.stack([g_sig, torch.zeros_like(g_sig)], 1), H[:, 7])[:1]
+            grads["sigma.bias"] = g_sig.sum(dtype=torch.float32).reshape(1)
+            for l in range(8, 0, -1):
+                dpre = relu_bwd(dh, H[:, l - 1])
+                inp = enc if l == 1 else torch.cat([enc, H[:, l - 2]], -1) if l == 5 else H[:, l - 2]
+                grads[f"xyz_encoding_{l}.0.weight"] = wgrad(dpre, inp)
+                grads[f"xyz_encoding_{l}.0.bias"] = dpre.sum(0, dtype=torch.float32)
+                W = P[f"xyz_encoding_{l}.0.weight"]
+                if l > 1:
+                    dh = dpre @ (W[:, 63:] if l == 5 else W)
+                if want_pts and l in (1, 5):
+                    t = (dpre @ W[:, :63]).float()
+                    d_enc = t if d_enc is None else d_enc + t
         d_pts = None
         if want_pts:                                                # through x -> (x, sin 2^k x, cos 2^k x)
-            x = pts[:, :3]
-            d_x = d_enc[:, :3].clone()
-            e32 = enc.float()
-            for k in range(10):
-                f = float(2 ** k)
-                sin, cos = e32[:, 3 + 6 * k:6 + 6 * k], e32[:, 6 + 6 * k:9 + 6 * k]
-                d_x += f * (cos * d_enc[:, 3 + 6 * k:6 + 6 * k] - sin * d_enc[:, 6 + 6 * k:9 + 6 * k])
-            d_pts = torch.cat([d_x, torch.zeros_like(d_x[:, :1])], 1)
+            d_pts = ops.encode_backward(pts, d_enc.contiguous())
             if idx is not None:
                 full = d_pts.new_zeros(ctx.n_full, 4)
                 full[idx] = d_pts[:idx.shape[0]]
@@ -180,22 +215,42 @@ class NormalFunction(torch.autograd.Function):
     backward of that 4n-row pass (bias gradients from the primal rows only).  ~80 launches instead of ~1400."""
 
     KEYS = [k for i in range(1, 9) for k in (f"xyz_encoding_{i}.0.weight", f"xyz_encoding_{i}.0.bias")] + ["sigma.weight", "sigma.bias"]
+    _tables = {}
+
+    @staticmethod
+    def _tangent_tables(device, dtype):
+        key = (str(device), dtype)
+        if key not in NormalFunction._tables:
+            perm, scale = list(range(63)), [0.0] * 63
+            for c in range(3):
+                scale[c] = 0.0                                        # d x / d x = 1: patched below via the ones column
+            for k in range(10):
+                f = float(2 ** k)
+                for d in range(3):
+                    s_ch, c_ch = 3 + 6 * k + d, 6 + 6 * k + d
+                    perm[s_ch], scale[s_ch] = c_ch, f
+                    perm[c_ch], scale[c_ch] = s_ch, -f
+            axis = torch.zeros(3, 63)
+            for c in range(63):
+                axis[c % 3, c] = 1.0
+            add = torch.zeros(63)
+            add[:3] = 1.0
+            NormalFunction._tables[key] = (torch.tensor(perm, device=device), torch.tensor(scale, device=device, dtype=dtype),
+                                           axis.to(device=device, dtype=dtype), add.to(device=device, dtype=dtype))
+        t = NormalFunction._tables[key]
+        return t[0], t[1], t[2]
 
     @staticmethod
     def forward(ctx, xyz, delta, *params):
         P = dict(zip(NormalFunction.KEYS, [p.detach() for p in params]))
         n = xyz.shape[0]
         x = xyz.detach()
-        e = _encode(x)                                                # [n,63]
-        # tangents of the encoding: d e / d x_d  -> T0[3, n, 63]
-        T0 = x.new_zeros(3, n, 63)
-        eye = torch.eye(3, device=x.device, dtype=x.dtype)
-        T0[:, :, 0:3] = eye[:, None, :]
-        for k in range(10):
-            f = float(2 ** k)
-            sin, cos = e[:, 3 + 6 * k:6 + 6 * k], e[:, 6 + 6 * k:9 + 6 * k]
-            T0[:, :, 3 + 6 * k:6 + 6 * k] = eye[:, None, :] * (f * cos)[None]
-            T0[:, :, 6 + 6 * k:9 + 6 * k] = eye[:, None, :] * (-f * sin)[None]
+        e = ops.encode(x) if (x.is_cuda and x.dtype == torch.float32) else _encode(x)      # [n,63]
+        # tangents of the encoding d e / d x_d -> T0[3, n, 63]: channel c belongs to axis c % 3; d sin(f x) = f cos(f x)
+        # and d cos(f x) = -f sin(f x) are the partner channel times +-f
+        perm, scale, axis = NormalFunction._tangent_tables(x.device, x.dtype)
+        dE = torch.addcmul(NormalFunction._tables[(str(x.device), x.dtype)][3], e.index_select(1, perm), scale)
+        T0 = dE[None] * axis[:, None, :]
         X0 = torch.cat([e[None], T0], 0)                              # [4, n, 63]: primal row group + 3 tangent groups
         saved_in, masks = [], []
         h = X0

@@ -246,3 +246,68 @@ extern "C" int anr_points_from_rays(const float* rays, int ray_stride, const flo
                        (hipStream_t)stream, rays, ray_stride, z, K, n_points, reinterpret_cast<float4*>(pts_out));
     return check_launch("anr_points_from_rays");
 }
+
+// ------------------------------------------------------------------ encoding for the weight-gradient GEMMs (a16)
+// models/embedding.py:22-39 as a row-major [n][63] matrix (the input of dW_1 and dW_5 in the backward pass), and the
+// chain rule back through it.  The forward pass never materialises this (the MLP kernel encodes in registers).
+namespace anr {
+
+template <typename T>
+__global__ __launch_bounds__(256) void encode_kernel(const float* __restrict__ pts, int stride, int64_t n, T* __restrict__ enc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x[3] = {pts[i * stride], pts[i * stride + 1], pts[i * stride + 2]};
+    T* row = enc + i * 63;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) row[d] = (T)x[d];
+    for (int k = 0; k < 10; ++k) {
+        const float f = (float)(1 << k);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            row[3 + 6 * k + d] = (T)sinf(f * x[d]);
+            row[6 + 6 * k + d] = (T)cosf(f * x[d]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void encode_backward_kernel(const float* __restrict__ pts, int stride, const float* __restrict__ d_enc,
+                                                              int64_t n, float4* __restrict__ d_pts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* g = d_enc + i * 63;
+    float dx[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float x = pts[i * stride + d];
+        float a = g[d];
+        for (int k = 0; k < 10; ++k) {
+            const float f = (float)(1 << k);
+            a += f * (cosf(f * x) * g[3 + 6 * k + d] - sinf(f * x) * g[6 + 6 * k + d]);
+        }
+        dx[d] = a;
+    }
+    d_pts[i] = make_float4(dx[0], dx[1], dx[2], 0.0f);
+}
+
+}  // namespace anr
+
+extern "C" int anr_encode(const float* pts, int pts_stride, int64_t n, int bf16_out, void* enc_out, void* stream) {
+    ANR_REQUIRE(pts && enc_out, ANR_E_BADARG, "anr_encode: null pointer");
+    ANR_REQUIRE(n > 0 && pts_stride >= 3, ANR_E_BADARG, "anr_encode: n=%lld stride=%d", (long long)n, pts_stride);
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (bf16_out)
+        hipLaunchKernelGGL(anr::encode_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (__bf16*)enc_out);
+    else
+        hipLaunchKernelGGL(anr::encode_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (float*)enc_out);
+    return anr::check_launch("anr_encode");
+}
+
+extern "C" int anr_encode_backward(const float* pts, int pts_stride, const float* d_enc, int64_t n, float* d_pts_out,
+                                   void* stream) {
+    ANR_REQUIRE(pts && d_enc && d_pts_out, ANR_E_BADARG, "anr_encode_backward: null pointer");
+    ANR_REQUIRE(n > 0 && pts_stride >= 3, ANR_E_BADARG, "anr_encode_backward: n=%lld stride=%d", (long long)n, pts_stride);
+    ANR_REQUIRE(((uintptr_t)d_pts_out & 15) == 0, ANR_E_ALIGN, "anr_encode_backward: d_pts_out must be 16-B aligned");
+    hipLaunchKernelGGL(anr::encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pts,
+                       pts_stride, d_enc, n, reinterpret_cast<float4*>(d_pts_out));
+    return anr::check_launch("anr_encode_backward");
+}

@@ -1,0 +1,448 @@
+// Backward of the fused MLP w.r.t. its activations (training, a16): the chain
+//     dG = (Wr^T d_rgb') . 1[G>0]      dF = Wd^T dG      dh8' = (Wf^T dF + w_sigma d_sigma) . 1[h8>0]
+//     dh'_{l-1} = (W_l^T dh'_l) . 1[h_{l-1}>0]    l = 8..2          (models/nerf.py:129-175 differentiated)
+// as ONE kernel built like the forward one (mlp_core.h): transposed GEMMs on the matrix cores with the points as
+// columns, the gradient fragments never leaving registers between the 10 GEMMs, W^T tiles streamed L2 -> LDS through
+// the same 3-slot LDS-DMA ring, persistent workgroups.  The ReLU masks come from the activations the training forward
+// saved (anr_mlp_forward_save), read in exactly the 8-byte pieces it wrote; every pre-activation gradient is written
+// in the same [point][2432] layout (dact), which is what the weight-gradient GEMMs (dW_l = dact_l^T act_{l-1},
+// library split-K) consume.  22 library GEMMs + 11 mask kernels of the first version become this launch + the dW GEMMs.
+//
+// Tile schedule (76 out-tiles of 32 rows): 0-3 rgb^T (K = 3, padded to one fragment group), 4-11 dir^T (K = 128),
+// 12-19 final^T (+ the rank-1 sigma term as the C operand of the first MFMA), 20-75 trunk layers 8..2 transposed.
+// sigma-only queries (foreground / background priors) start at tile 20 from dh8' = w_sigma d_sigma . 1[h8>0].
+#include "mlp_core.h"
+
+namespace anr {
+
+constexpr int BWD_TABLE_BYTES = 1024;          // w_sigma, 256 fp32, in accumulator-register order per tile
+constexpr int BWD_TILES = 76;
+
+template <class C> __host__ __device__ constexpr int btile_frags(int t) { return t < 4 ? 4 : t < 12 ? C::DF : C::HF; }
+template <class C> __host__ __device__ constexpr int bfrag_offset(int t) {
+    int n = 0;
+    for (int i = 0; i < t; ++i) n += btile_frags<C>(i);
+    return n;
+}
+template <class C> constexpr int btotal_frags() { return bfrag_offset<C>(BWD_TILES); }
+// column (in a [2432]-wide row) of the activation whose sign gates out-tile t, and where its result is stored
+__host__ __device__ constexpr int bcol(int t) {
+    return t < 4 ? 2304 + 32 * t : t < 12 ? 2048 + 32 * (t - 4) : 256 * (7 - (t - 12) / 8) + 32 * ((t - 12) % 8);
+}
+__host__ __device__ constexpr bool bmasked(int t) { return !(t >= 4 && t < 12); }      // xyz_encoding_final has no ReLU
+
+template <int MODE, bool SIGMA_ONLY>
+struct MlpBwd {
+    using C = Cfg<MODE>;
+    using Frag = typename C::Frag;
+    static constexpr int NT = C::NT, EPF = C::EPF, HF = C::HF, DF = C::DF, WAVES = C::WAVES, TPC = C::TPC;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int FPT = 16 / EPF;
+    static constexpr int SLOT = TPC * HF * FRAG_BYTES;
+    static constexpr int FIRST = SIGMA_ONLY ? 20 : 0;
+    static constexpr int LAST = BWD_TILES - 1;
+    static constexpr int NCHUNK = (BWD_TILES - FIRST) / TPC;
+    using ActT = std::conditional_t<C::IS_BF16, __bf16, float>;
+    using MaskT = std::conditional_t<C::IS_BF16, uint2, f32x4>;      // four saved activations (one accumulator quarter)
+
+    static __host__ __device__ constexpr int chunk_frags(int c) {
+        int n = 0;
+        for (int i = 0; i < TPC; ++i) n += btile_frags<C>(FIRST + c * TPC + i);
+        return n;
+    }
+
+    const char* gnext;
+    const char* gbase;
+    bool more;
+    char* lds_base;
+    unsigned slot_cur, slot_nxt, slot_stage;
+    int c;
+    int wave, lane, half;
+    f32x16 acc[2][NT];
+    Frag w0[4];
+    MaskT mk[2][NT][4];          // masks of tile c (parity) and of tile c-1 (its epilogue is pending)
+    const ActT* act_row[NT];
+    ActT* dact_row[NT];
+
+    __device__ __forceinline__ void advance() {
+        dma_wait();
+        __syncthreads();
+        if (c + 2 < NCHUNK || more) {
+            if (c + 2 == NCHUNK) gnext = gbase;
+            const int nf = chunk_frags((c + 2) % NCHUNK);
+            stage_chunk<true, WAVES>(gnext, lds_base, slot_stage, nf, wave, lane);
+            gnext += nf * FRAG_BYTES;
+        }
+    }
+    __device__ __forceinline__ void rotate() {
+        unsigned t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_stage; slot_stage = t;
+        ++c;
+    }
+
+    struct NoEpi {
+        template <int Q> __device__ __forceinline__ void part() const {}
+    };
+    // mask + conversion into fragments [TB, TB+FPT) of the next stage's input, and the store into dact
+    template <int YF, int TB, int TG>
+    struct MaskEpi {
+        const f32x16 (&a)[NT];
+        Frag (&Y)[NT][YF];
+        const MaskT (&m)[NT][4];
+        ActT* const (&dr)[NT];
+        template <int Q> __device__ __forceinline__ void part() const {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                if constexpr (C::IS_BF16) {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    typedef short s16x2 __attribute__((ext_vector_type(2)));
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    unsigned pk[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const f32x2 v2 = {a[n][4 * Q + 2 * i], a[n][4 * Q + 2 * i + 1]};
+                        pk[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16x2));
+                        if (bmasked(TG)) {
+                            // saved h is relu'd bf16: > 0 <=> bit pattern in [1, 0x7fff]; (0 - h) >> 15 (arithmetic,
+                            // per 16-bit half) is 0xffff there and 0 for h = +0
+                            const s16x2 hb = __builtin_bit_cast(s16x2, i == 0 ? m[n][Q].x : m[n][Q].y);
+                            const s16x2 keep = (s16x2{0, 0} - hb) >> 15;
+                            pk[i] &= __builtin_bit_cast(unsigned, keep);
+                        }
+                    }
+                    Frag& dst = Y[n][TB + (4 * Q) / EPF];
+                    u32x4 d4 = __builtin_bit_cast(u32x4, dst);
+                    d4[((4 * Q) % EPF) / 2] = pk[0];
+                    d4[((4 * Q) % EPF) / 2 + 1] = pk[1];
+                    dst = __builtin_bit_cast(Frag, d4);
+                    if ((4 * Q + 4) % EPF == 0) pin(dst);
+                    if (dr[n] != nullptr) *reinterpret_cast<uint2*>(dr[n] + bcol(TG) + 8 * Q) = make_uint2(pk[0], pk[1]);
+                } else {
+                    f32x4 keep;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = a[n][4 * Q + i];
+                        if (bmasked(TG)) v = (m[n][Q][i] > 0.0f) ? v : 0.0f;
+                        put(Y[n][TB + (4 * Q + i) / EPF], (4 * Q + i) % EPF, v);
+                        keep[i] = v;
+                    }
+                    if ((4 * Q + 4) % EPF == 0) pin(Y[n][TB + (4 * Q) / EPF]);
+                    if (dr[n] != nullptr) *reinterpret_cast<f32x4*>(dr[n] + bcol(TG) + 8 * Q) = keep;
+                }
+            }
+        }
+    };
+
+    // One out-tile: acc[PAR] = cinit + W^T_tile . X (NF fragments).  Same software pipeline as the forward tile().
+    template <int T, int NF, int XF, class Pending>
+    __device__ __forceinline__ void tile(const Frag (&X)[NT][XF], const Pending& pending, const float (&dsig)[NT]) {
+        static_assert(NF % 4 == 0 && NF == btile_frags<C>(T), "tile schedule mismatch");
+        constexpr int NG = NF / 4;
+        constexpr int PAR = T & 1;
+        constexpr int POS = (T - FIRST) % TPC;
+        constexpr int OFF = (POS == 0) ? 0 : btile_frags<C>(T - 1);
+        constexpr bool END = (T == LAST);
+        if constexpr (POS == 0) advance();
+        const Frag* cur = reinterpret_cast<const Frag*>(lds_base + slot_cur) + OFF * 64 + lane;
+        const Frag* nxt = (POS + 1 < TPC && !END) ? cur + NF * 64 : reinterpret_cast<const Frag*>(lds_base + slot_nxt) + lane;
+        // the saved activations that gate THIS tile's result (used by its epilogue, one tile later)
+        if constexpr (bmasked(T)) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mk[PAR][n][q] = *reinterpret_cast<const MaskT*>(act_row[n] + bcol(T) + 8 * q);
+        }
+        // C operand: zero, except the rank-1 sigma term on the final^T tiles
+        f32x16 cinit[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if constexpr (T >= 12 && T < 20) {
+                const f32x4* tb = reinterpret_cast<const f32x4*>(lds_base + ((T - 12) * 32 + half * 16) * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w4 = tb[q];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cinit[n][4 * q + i] = w4[i] * dsig[n];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) cinit[n][i] = 0.0f;
+            }
+        }
+        Frag wa[4], wb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wa[q] = w0[q];
+        static_for<NG>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            Frag (&use)[4] = (j & 1) ? wb : wa;
+            Frag (&ld)[4] = (j & 1) ? wa : wb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ld[q] = (j + 1 < NG) ? cur[((j + 1) * 4 + q) * 64] : nxt[q * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int f = 4 * j + q;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    if (f == 0) acc[PAR][n] = mma_c(use[q], X[n][f], cinit[n]);
+                    else        mma(use[q], X[n][f], acc[PAR][n]);
+                }
+                if constexpr (NG >= 3) {
+                    if (j < 2 && (q & 1)) {
+                        pending.template part<2 * (j < 2 ? j : 0) + (q >> 1)>();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (j == 0) {
+                    pending.template part<q>();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        });
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w0[q] = (NG & 1) ? wb[q] : wa[q];
+        if constexpr (POS + 1 == TPC || END) rotate();
+    }
+
+    template <int T0, int NTILES, int NF, int XF, int YF, class Pending>
+    __device__ __forceinline__ void layer(const Frag (&X)[NT][XF], Frag (&Y)[NT][YF], const Pending& first,
+                                          const float (&dsig)[NT]) {
+        static_for<NTILES>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int PAR = (T0 + t) & 1;
+            if constexpr (t == 0) {
+                tile<T0 + t, NF, XF>(X, first, dsig);
+            } else {
+                tile<T0 + t, NF, XF>(X, MaskEpi<YF, (t - 1) * FPT, T0 + t - 1>{acc[PAR ^ 1], Y, mk[PAR ^ 1], dact_row}, dsig);
+            }
+        });
+    }
+    template <int T0, int NTILES, int YF>
+    __device__ __forceinline__ auto last_of(Frag (&Y)[NT][YF]) {
+        constexpr int T = T0 + NTILES - 1;
+        return MaskEpi<YF, (NTILES - 1) * FPT, T>{acc[T & 1], Y, mk[T & 1], dact_row};
+    }
+
+    __device__ __forceinline__ void run(const char* __restrict__ pack, const float4* __restrict__ g, const ActT* __restrict__ act,
+                                        ActT* __restrict__ dact, int64_t n_pts, char* lds) {
+        const int64_t n_tiles = (n_pts + WAVES * NT * 32 - 1) / (WAVES * NT * 32);
+        if ((int64_t)blockIdx.x >= n_tiles) return;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        lane = threadIdx.x & 63;
+        half = lane >> 5;
+        lds_base = lds;
+        slot_cur = BWD_TABLE_BYTES;
+        slot_nxt = slot_cur + SLOT;
+        slot_stage = slot_nxt + SLOT;
+        gbase = pack + BWD_TABLE_BYTES + bfrag_offset<C>(FIRST) * FRAG_BYTES;
+        for (int i = threadIdx.x; i < BWD_TABLE_BYTES / 16; i += THREADS)
+            reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(pack)[i];
+        gnext = gbase;
+        stage_chunk<true, WAVES>(gnext, lds_base, slot_cur, chunk_frags(0), wave, lane);
+        gnext += chunk_frags(0) * FRAG_BYTES;
+        stage_chunk<true, WAVES>(gnext, lds_base, slot_nxt, chunk_frags(1), wave, lane);
+        gnext += chunk_frags(1) * FRAG_BYTES;
+        bool first = true;
+
+        for (int64_t pt = blockIdx.x; pt < n_tiles; pt += gridDim.x) {
+            more = pt + gridDim.x < n_tiles;
+            c = 0;
+            float dsig[NT];
+            float4 gin[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int64_t idx = (pt * WAVES + wave) * (NT * 32) + n * 32 + (lane & 31);
+                const int64_t cl = idx < n_pts ? idx : n_pts - 1;
+                gin[n] = g[cl];
+                dsig[n] = gin[n].w;
+                act_row[n] = act + cl * ACT_COLS + 4 * half;
+                dact_row[n] = idx < n_pts ? dact + idx * ACT_COLS + 4 * half : nullptr;
+            }
+            if (first) {
+                dma_wait();
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w0[q] = (reinterpret_cast<const Frag*>(lds_base + slot_cur) + lane)[q * 64];
+                first = false;
+            }
+            Frag A[NT][HF], B[NT][HF];
+            if constexpr (!SIGMA_ONLY) {
+                // stage R input: d_rgb' (3 values) sits in slots 0..2 of fragment 0 of the lower half-wave
+                Frag X0[NT][4];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+#pragma unroll
+                        for (int e = 0; e < EPF; ++e) put(X0[n][f], e, 0.0f);
+                    put(X0[n][0], 0, half ? 0.0f : gin[n].x);
+                    put(X0[n][0], 1, half ? 0.0f : gin[n].y);
+                    put(X0[n][0], 2, half ? 0.0f : gin[n].z);
+                }
+                Frag (&Gd)[NT][HF] = B;                                                    // dG lives in B[.][0..DF)
+                layer<0, 4, 4, 4, HF>(X0, Gd, NoEpi{}, dsig);                               // rgb^T  : d_rgb' -> dG
+                layer<4, 8, DF, HF, HF>(B, A, last_of<0, 4, HF>(B), dsig);                  // dir^T  : dG -> dF (A)
+                layer<12, 8, HF, HF, HF>(A, B, last_of<4, 8, HF>(A), dsig);                 // final^T: dF -> dh8' (B)
+                layer<20, 8, HF, HF, HF>(B, A, last_of<12, 8, HF>(B), dsig);                // W8^T   : dh8' -> dh7' (A)
+            } else {
+                // dh8' = w_sigma d_sigma . 1[h8 > 0], straight into fragments (B) and into dact
+                static_for<8>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const f32x4* tb = reinterpret_cast<const f32x4*>(lds_base + (j * 32 + half * 16) * 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 w4 = tb[q];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[0][n][4 * q + i] = w4[i] * dsig[n];
+                            mk[0][n][q] = *reinterpret_cast<const MaskT*>(act_row[n] + bcol(12 + j) + 8 * q);
+                        }
+                    }
+                    MaskEpi<HF, j * FPT, 12 + j> epi{acc[0], B, mk[0], dact_row};
+                    epi.template part<0>(); epi.template part<1>(); epi.template part<2>(); epi.template part<3>();
+                });
+                layer<20, 8, HF, HF, HF>(B, A, NoEpi{}, dsig);                              // W8^T   : dh8' -> dh7' (A)
+            }
+            layer<28, 8, HF, HF, HF>(A, B, last_of<20, 8, HF>(A), dsig);                    // W7^T
+            layer<36, 8, HF, HF, HF>(B, A, last_of<28, 8, HF>(B), dsig);                    // W6^T
+            layer<44, 8, HF, HF, HF>(A, B, last_of<36, 8, HF>(A), dsig);                    // W5^T (hidden part)
+            layer<52, 8, HF, HF, HF>(B, A, last_of<44, 8, HF>(B), dsig);                    // W4^T
+            layer<60, 8, HF, HF, HF>(A, B, last_of<52, 8, HF>(A), dsig);                    // W3^T
+            layer<68, 8, HF, HF, HF>(B, A, last_of<60, 8, HF>(B), dsig);                    // W2^T   : -> dh1' (stored)
+            {
+                auto fin = last_of<68, 8, HF>(A);
+                fin.template part<0>(); fin.template part<1>(); fin.template part<2>(); fin.template part<3>();
+            }
+        }
+    }
+};
+
+template <int MODE, bool SIGMA_ONLY>
+__global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void mlp_bwd_kernel(
+    const char* __restrict__ pack, const float4* __restrict__ g, const void* __restrict__ act, void* __restrict__ dact,
+    int64_t n_pts) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using M = MlpBwd<MODE, SIGMA_ONLY>;
+    M m;
+    m.run(pack, g, reinterpret_cast<const typename M::ActT*>(act), reinterpret_cast<typename M::ActT*>(dact), n_pts, lds);
+}
+
+template <int MODE, bool SIGMA_ONLY>
+int launch_mlp_bwd(const void* pack, const float* g, const void* act, void* dact, int64_t n, hipStream_t st) {
+    using C = Cfg<MODE>;
+    const int lds = BWD_TABLE_BYTES + 3 * MlpBwd<MODE, SIGMA_ONLY>::SLOT;
+    auto kern = mlp_bwd_kernel<MODE, SIGMA_ONLY>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail((int)e, "anr_mlp_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    const int pts_per_wg = C::WAVES * C::NT * 32;
+    const int64_t n_tiles = (n + pts_per_wg - 1) / pts_per_wg;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    dim3 grid((unsigned)(n_tiles < cus ? n_tiles : cus));
+    hipLaunchKernelGGL(kern, grid, dim3(C::WAVES * 64), lds, st, reinterpret_cast<const char*>(pack),
+                       reinterpret_cast<const float4*>(g), act, dact, n);
+    return check_launch("anr_mlp_backward");
+}
+
+// ---------------------------------------------------------------------------------------------
+// W^T in fragment order.  Fragment (tile t, k-fragment kf), lane (i = lane & 31, h = lane >> 5), element e:
+//   row  = input feature 32 t' + i of the forward layer (t' = tile inside its stage)
+//   k    = output feature of the forward layer in the slot order of the gradient fragments (mlp_core.h header)
+struct BwdStage { const float* W; int ld, in_off, in_dim, out_dim, tile0, nf; };
+struct BwdPlan { BwdStage s[10]; const float* w_sigma; };
+
+template <int MODE>
+__global__ void mlp_bwd_pack_kernel(BwdPlan plan, char* __restrict__ pack) {
+    using C = Cfg<MODE>;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_pieces = (int64_t)btotal_frags<C>() * 64;
+    if (gid < n_pieces) {
+        const int frag = (int)(gid >> 6), lane = (int)(gid & 63);
+        const int i = lane & 31, h = lane >> 5;
+        int t = 0, base = 0;
+        while (base + btile_frags<C>(t) <= frag) { base += btile_frags<C>(t); ++t; }
+        const int kf = frag - base;
+        int si = 0;
+        while (si + 1 < 10 && plan.s[si + 1].tile0 <= t) ++si;
+        const BwdStage& st = plan.s[si];
+        const int row = 32 * (t - st.tile0) + i;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < C::EPF; ++e) {
+            const int feat = C::IS_BF16 ? 16 * kf + 8 * (e >> 2) + 4 * h + (e & 3) : 8 * kf + 4 * h + e;
+            v[e] = (row < st.in_dim && feat < st.out_dim) ? st.W[(int64_t)feat * st.ld + st.in_off + row] : 0.0f;
+        }
+        char* dst = pack + BWD_TABLE_BYTES + (int64_t)frag * FRAG_BYTES + lane * 16;
+        if constexpr (C::IS_BF16) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+            *reinterpret_cast<bf16x8*>(dst) = o;
+        } else {
+            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    } else {
+        const int64_t bi = gid - n_pieces;                 // w_sigma table: [tile j][half][reg]
+        if (bi >= BWD_TABLE_BYTES / 4) return;
+        const int j = (int)(bi / 32), h = (int)((bi % 32) / 16), reg = (int)(bi % 16);
+        reinterpret_cast<float*>(pack)[bi] = plan.w_sigma[32 * j + 8 * (reg >> 2) + 4 * h + (reg & 3)];
+    }
+}
+
+}  // namespace anr
+
+using namespace anr;
+
+extern "C" int64_t anr_mlp_bwd_pack_bytes(int mode) {
+    switch (mode & 0xff) {
+        case ANR_MLP_F32:  return BWD_TABLE_BYTES + (int64_t)btotal_frags<Cfg<ANR_MLP_F32>>() * FRAG_BYTES;
+        case ANR_MLP_BF16: return BWD_TABLE_BYTES + (int64_t)btotal_frags<Cfg<ANR_MLP_BF16>>() * FRAG_BYTES;
+        default: return ANR_E_BADARG;
+    }
+}
+
+extern "C" int anr_mlp_bwd_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream) {
+    ANR_REQUIRE(p && pack_out, ANR_E_BADARG, "anr_mlp_bwd_pack: null pointer");
+    for (int l = 1; l < 8; ++l) ANR_REQUIRE(p->w_trunk[l], ANR_E_BADARG, "anr_mlp_bwd_pack: null trunk tensor %d", l);
+    ANR_REQUIRE(p->w_sigma && p->w_final && p->w_dir && p->w_rgb, ANR_E_BADARG, "anr_mlp_bwd_pack: null head tensor");
+    ANR_REQUIRE(((uintptr_t)pack_out & 15) == 0, ANR_E_ALIGN, "anr_mlp_bwd_pack: pack_out must be 16-B aligned");
+    BwdPlan plan{};
+    plan.s[0] = BwdStage{p->w_rgb, 128, 0, 128, 3, 0, 4};                 // rgb.0.weight [3,128]
+    plan.s[1] = BwdStage{p->w_dir, 256, 0, 256, 128, 4, 0};               // dir_encoding.0.weight [128,256]
+    plan.s[2] = BwdStage{p->w_final, 256, 0, 256, 256, 12, 0};            // xyz_encoding_final.weight [256,256]
+    for (int s = 0; s < 7; ++s) {                                         // xyz_encoding_{8..2}: [256, 256] ([256,319] for 5)
+        const int l = 7 - s;                                              // index into w_trunk (layer l+1)
+        plan.s[3 + s] = BwdStage{p->w_trunk[l], l == 4 ? 319 : 256, l == 4 ? 63 : 0, 256, 256, 20 + 8 * s, 0};
+    }
+    plan.w_sigma = p->w_sigma;
+    hipStream_t st = (hipStream_t)stream;
+    if ((mode & 0xff) == ANR_MLP_F32) {
+        int64_t n = (int64_t)btotal_frags<Cfg<ANR_MLP_F32>>() * 64 + BWD_TABLE_BYTES / 4;
+        hipLaunchKernelGGL(mlp_bwd_pack_kernel<ANR_MLP_F32>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, plan, (char*)pack_out);
+    } else if ((mode & 0xff) == ANR_MLP_BF16) {
+        int64_t n = (int64_t)btotal_frags<Cfg<ANR_MLP_BF16>>() * 64 + BWD_TABLE_BYTES / 4;
+        hipLaunchKernelGGL(mlp_bwd_pack_kernel<ANR_MLP_BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, plan, (char*)pack_out);
+    } else {
+        return fail(ANR_E_BADARG, "anr_mlp_bwd_pack: unknown mode %d", mode);
+    }
+    return check_launch("anr_mlp_bwd_pack");
+}
+
+extern "C" int anr_mlp_backward(const void* bwd_pack, int mode, const float* g, const void* act, void* dact, int64_t n,
+                                void* stream) {
+    ANR_REQUIRE(bwd_pack && g && act && dact, ANR_E_BADARG, "anr_mlp_backward: null pointer");
+    ANR_REQUIRE(n > 0, ANR_E_BADARG, "anr_mlp_backward: n=%lld", (long long)n);
+    ANR_REQUIRE((((uintptr_t)bwd_pack | (uintptr_t)g | (uintptr_t)act | (uintptr_t)dact) & 15) == 0, ANR_E_ALIGN,
+                "anr_mlp_backward: bwd_pack/g/act/dact must be 16-B aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const bool so = (mode & ANR_MLP_FLAG_SIGMA_ONLY) != 0;
+    switch (mode & 0xff) {
+        case ANR_MLP_F32:
+            return so ? launch_mlp_bwd<ANR_MLP_F32, true>(bwd_pack, g, act, dact, n, st)
+                      : launch_mlp_bwd<ANR_MLP_F32, false>(bwd_pack, g, act, dact, n, st);
+        case ANR_MLP_BF16:
+            return so ? launch_mlp_bwd<ANR_MLP_BF16_W8, true>(bwd_pack, g, act, dact, n, st)
+                      : launch_mlp_bwd<ANR_MLP_BF16_W8, false>(bwd_pack, g, act, dact, n, st);
+        default: return fail(ANR_E_BADARG, "anr_mlp_backward: unknown mode %d", mode);
+    }
+}

@@ -263,8 +263,9 @@ def points_from_rays(rays: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     return pts
 
 
-def mlp_pack(params: dict, mode: int) -> torch.Tensor:
-    """Pack the 11 weight/bias tensors (reference state-dict keys, PyTorch [out,in] layout) for anr_mlp_forward."""
+def mlp_pack(params: dict, mode: int, backward: bool = False) -> torch.Tensor:
+    """Pack the 11 weight/bias tensors (reference state-dict keys, PyTorch [out,in] layout) for anr_mlp_forward, or —
+    `backward` — their transposes for anr_mlp_backward."""
     lib = _lib.load()
     keep = []
 
@@ -286,10 +287,50 @@ def mlp_pack(params: dict, mode: int) -> torch.Tensor:
             raise ValueError(f"xyz_encoding_{i+1}.0.weight: expected {shp}")
     if tuple(params["dir_encoding.0.weight"].shape) != (128, 256) or tuple(params["rgb.0.weight"].shape) != (3, 128):
         raise ValueError("head shapes must be dir_encoding [128,256], rgb [3,128] (use_view=False, no latent codes)")
+    if backward:
+        pack = torch.empty(lib.anr_mlp_bwd_pack_bytes(mode & 0xff), dtype=torch.uint8, device=keep[0].device)
+        _lib.check(lib.anr_mlp_bwd_pack(C.byref(st), mode & 0xff, _ptr(pack), _stream(pack)), "anr_mlp_bwd_pack")
+        return pack
     nbytes = lib.anr_mlp_pack_bytes(mode & 0xff)
     pack = torch.empty(nbytes, dtype=torch.uint8, device=keep[0].device)
     _lib.check(lib.anr_mlp_pack(C.byref(st), mode & 0xff, _ptr(pack), _stream(pack)), "anr_mlp_pack")
     return pack
+
+
+def encode(pts: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    """enc[n,63] = Embedding(pts[:, :3]) (models/embedding.py:22-39) in one launch, fp32 or bf16."""
+    lib = _lib.load()
+    pts = _dev(pts, "pts")
+    n = pts.shape[0]
+    enc = torch.empty(n, 63, dtype=dtype, device=pts.device)
+    _lib.check(lib.anr_encode(_ptr(pts), pts.shape[1], n, 1 if dtype == torch.bfloat16 else 0, _ptr(enc), _stream(enc)),
+               "anr_encode")
+    return enc
+
+
+def encode_backward(pts: torch.Tensor, d_enc: torch.Tensor) -> torch.Tensor:
+    """d_pts[n,4] = (dL/dxyz, 0) from d_enc[n,63] (fp32)."""
+    lib = _lib.load()
+    pts, d_enc = _dev(pts, "pts"), _dev(d_enc, "d_enc")
+    n = pts.shape[0]
+    d_pts = torch.empty(n, 4, dtype=torch.float32, device=pts.device)
+    _lib.check(lib.anr_encode_backward(_ptr(pts), pts.shape[1], _ptr(d_enc), n, _ptr(d_pts), _stream(d_pts)),
+               "anr_encode_backward")
+    return d_pts
+
+
+def mlp_backward(bwd_pack: torch.Tensor, mode: int, g: torch.Tensor, act: torch.Tensor, sigma_only: bool = False):
+    """g[n,4] = (dL/d rgb_pre, dL/d sigma), act[n,2432] from mlp_forward_save -> dact[n,2432] (same dtype): the
+    pre-activation gradient of every layer (trunk columns only if sigma_only)."""
+    lib = _lib.load()
+    g, act = _dev(g, "g"), _dev(act, "act", act.dtype)
+    n = g.shape[0]
+    dact = torch.empty_like(act)
+    m = (mode & 0xff) | (ANR_MLP_FLAG_SIGMA_ONLY if sigma_only else 0)
+    with _timed("mlp_backward", n):
+        _lib.check(lib.anr_mlp_backward(_ptr(bwd_pack), m, _ptr(g), _ptr(act), _ptr(dact), n, _stream(dact)),
+                   "anr_mlp_backward")
+    return dact
 
 
 def compact_valid(pts: torch.Tensor, fill: Optional[torch.Tensor] = None):

@@ -209,6 +209,25 @@ int anr_mlp_forward_save(const void* pack, int mode, const float* pts, int64_t n
 int anr_mlp_forward_save_indexed(const void* pack, int mode, const float* pts, const int32_t* index,
                                  const int32_t* count, int64_t n, float* out, void* act, void* stream);
 
+/* ---- a16 (part): backward of the MLP w.r.t. its activations ------------------------------------------------------
+ * What autograd differentiates in models/nerf.py:129-175, as one kernel (csrc/mlp_bwd.hip): from
+ *   g[n*4] = (dL/d rgb_pre (3: upstream x sigmoid'), dL/d sigma (already 0 where the sample is invalid))
+ * and the activations saved by anr_mlp_forward_save, the pre-activation gradient of every layer in the SAME
+ * [n][anr_mlp_act_cols()] layout and dtype as `act`: columns 256(l-1).. = layer l of the trunk, 2048.. =
+ * xyz_encoding_final, 2304.. = dir_encoding.  The weight gradients are then plain GEMMs dact_l^T act_{l-1}
+ * (library).  With ANR_MLP_FLAG_SIGMA_ONLY only the trunk columns are written (g = (., ., ., dL/d sigma)).
+ * The transposed weights are handed over pre-packed: anr_mlp_bwd_pack_bytes(mode) bytes from anr_mlp_bwd_pack(). */
+/* models/embedding.py:22-39 as a row-major matrix enc[n*63] (fp32, or bf16 if bf16_out) — the input operand of the
+ * weight-gradient GEMMs of xyz_encoding_1 / _5 — and its chain rule: d_pts[n*4] = (dL/dx, dL/dy, dL/dz, 0) from
+ * d_enc[n*63] (fp32).  pts[n*pts_stride] with xyz first. */
+int anr_encode(const float* pts, int pts_stride, int64_t n, int bf16_out, void* enc_out, void* stream);
+int anr_encode_backward(const float* pts, int pts_stride, const float* d_enc, int64_t n, float* d_pts_out,
+                        void* stream);
+int64_t anr_mlp_bwd_pack_bytes(int mode);
+int anr_mlp_bwd_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream);
+int anr_mlp_backward(const void* bwd_pack, int mode, const float* g, const void* act, void* dact, int64_t n,
+                     void* stream);
+
 /* ---- sigma-grid points for mesh extraction -------------------------------------------------------
  * extract_mesh.py:27-35 (create_grid: np.meshgrid(x, y, z), 'xy' indexing, fp64 linspace -> fp32) and :152-157
  * (+ bounding-box centre of the posed vertices).  Flat index n = (j*N + i)*N + k -> (x[i], y[j], z[k]).

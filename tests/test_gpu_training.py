@@ -86,6 +86,39 @@ def test_mlp_backward_matches_autograd(dev, smpl_table, sigma_only, only_valid):
         assert err <= 2e-4 * ref.abs().max().item() + 1e-6, (k, err, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("sigma_only", [False, True])
+def test_fused_mlp_backward_equals_gemm_chain(dev, smpl_table, mode, sigma_only):
+    """anr_mlp_backward (one kernel for the activation-gradient chain) against the chain of library GEMMs + mask
+    kernels it replaces, same saved activations: every weight / bias gradient and dL/d pts."""
+    from anim_nerf_amd.autograd import MLPFunction
+    m = seeded_model(smpl_table, 9, True, gain=50.0, device=dev)
+    net = m.nerf
+    gen = torch.Generator().manual_seed(3)
+    n = 5000 if mode == "bf16" else 777
+    pts = torch.cat([torch.rand(n, 3, generator=gen) * 2 - 1, torch.ones(n, 1)], -1)
+    pts[::13, 3] = 0.0
+    g = torch.randn(n, 1 if sigma_only else 4, generator=gen).to(dev)
+    res = []
+    for fused in (True, False):
+        MLPFunction.FUSED_BACKWARD = fused
+        try:
+            net.zero_grad()
+            p = pts.to(dev).requires_grad_(True)
+            out = net.eval_points(p, mode, sigma_only=sigma_only)
+            (out.reshape(n, -1) * g).sum().backward()
+            res.append(({k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None}, p.grad.clone()))
+        finally:
+            MLPFunction.FUSED_BACKWARD = True
+    (ga, pa), (gb, pb) = res
+    assert set(ga) == set(gb)
+    tol = 2e-5 if mode == "f32" else 3e-2        # bf16: the two chains round their intermediates at different points
+    for k in gb:
+        err = (ga[k] - gb[k]).norm() / (gb[k].norm() + 1e-20)
+        assert err < tol, (k, err.item())
+    assert (pa - pb).norm() / pb.norm() < tol
+
+
 def test_training_loss_gradients_match_oracle(dev, smpl_table):
     """One whole training-style forward (2 frames, warp on, coarse + fine, all four loss families) and backward."""
     import anim_nerf_amd as ana
