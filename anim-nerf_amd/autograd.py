@@ -124,16 +124,18 @@ class MLPFunction(torch.autograd.Function):
             bpack = ops.mlp_pack(dict(zip(PARAM_KEYS, params)), ctx.mode_id, backward=True)
             dact = ops.mlp_backward(bpack, ctx.mode_id, g4, act, sigma_only=ctx.sigma_only)
             g_sig = g4[:, 3].to(dt)
+            # every bias gradient is a column sum of dact: one reduction for all of them
+            colsum = (dact[:, :2048] if ctx.sigma_only else dact).sum(0, dtype=torch.float32)
             if not ctx.sigma_only:
                 d_rgb = g4[:, :3].to(dt)
                 G, F = act[:, 2304:2432], act[:, 2048:2304]
                 dG, dF = dact[:, 2304:2432], dact[:, 2048:2304]
                 grads["rgb.0.weight"] = wgrad(d_rgb, G)
-                grads["rgb.0.bias"] = d_rgb.sum(0, dtype=torch.float32)
+                grads["rgb.0.bias"] = g4[:, :3].sum(0)
                 grads["dir_encoding.0.weight"] = wgrad(dG, F)
-                grads["dir_encoding.0.bias"] = dG.sum(0, dtype=torch.float32)
+                grads["dir_encoding.0.bias"] = colsum[2304:2432]
                 grads["xyz_encoding_final.weight"] = wgrad(dF, H[:, 7])
-                grads["xyz_encoding_final.bias"] = dF.sum(0, dtype=torch.float32)
+                grads["xyz_encoding_final.bias"] = colsum[2048:2304]
             grads["sigma.weight"] = wgrad(torch.stack([g_sig, torch.zeros_like(g_sig)], 1), H[:, 7])[:1]
             grads["sigma.bias"] = g_sig.sum(dtype=torch.float32).reshape(1)
             D = dact[:, :2048].view(n, 8, 256)
@@ -141,7 +143,7 @@ class MLPFunction(torch.autograd.Function):
                 dpre = D[:, l - 1]
                 inp = enc if l == 1 else torch.cat([enc, H[:, l - 2]], -1) if l == 5 else H[:, l - 2]
                 grads[f"xyz_encoding_{l}.0.weight"] = wgrad(dpre, inp)
-                grads[f"xyz_encoding_{l}.0.bias"] = dpre.sum(0, dtype=torch.float32)
+                grads[f"xyz_encoding_{l}.0.bias"] = colsum[256 * (l - 1):256 * l]
                 if want_pts and l in (1, 5):
                     t = (dpre @ P[f"xyz_encoding_{l}.0.weight"][:, :63]).float()
                     d_enc = t if d_enc is None else d_enc + t
