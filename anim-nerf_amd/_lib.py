@@ -54,6 +54,7 @@ SIGNATURES = {
     "anr_knn": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),
     "anr_sample_coarse": (_I, [_P, _I, _P, _P, _L, _I, _P, _P]),
     "anr_warp_ws_ints": (_L, [_I, _L]),
+    "anr_warp_points_lean": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _L, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "anr_warp_points": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _L, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "anr_warp_backward": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P]),
     "anr_points_from_rays": (_I, [_P, _I, _P, _I, _L, _P, _P]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "anr_mlp_bwd_pack": (_I, [C.POINTER(AnrMlpParams), _I, _P, _P]),
     "anr_mlp_backward": (_I, [_P, _I, _P, _P, _P, _L, _P]),
     "anr_grid_points": (_I, [_I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, _L, _L, _P, _P]),
+    "anr_composite_masked": (_I, [_P, _P, _P, _I, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "anr_composite": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "anr_composite_backward": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "anr_sample_fine_merge": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P]),

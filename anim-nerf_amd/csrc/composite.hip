@@ -39,12 +39,14 @@ template <int S>
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_kernel(
     const float4* __restrict__ rgbs, const float* __restrict__ z, const float* __restrict__ rays, int stride,
     const float* __restrict__ noise, int64_t R, int K, int white_bkgd, float* __restrict__ weights_out,
-    float* __restrict__ rgb_out, float* __restrict__ depth_out, float* __restrict__ acc_out) {
+    float* __restrict__ rgb_out, float* __restrict__ depth_out, float* __restrict__ acc_out,
+    const uint8_t* __restrict__ valid) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (r >= R) return;
     const float4* c = rgbs + r * K;
     const float* zr = z + r * K;
+    const uint8_t* vr = valid ? valid + r * K : nullptr;
 
     float alpha[S], tr[S], zz[S];
     float4 col[S];
@@ -54,7 +56,9 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_kernel(
         int k = lane * S + s;
         alpha[s] = 0.0f; tr[s] = 1.0f; zz[s] = 0.0f; col[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < K) {
-            col[s] = c[k];
+            // a sample the warp found invalid is (0, 0, 0, -1e5) by definition (models/anim_nerf.py:245-290, :305):
+            // its rgb-sigma row was never written and is not read
+            col[s] = (vr != nullptr && vr[k] == 0) ? make_float4(0.f, 0.f, 0.f, -1e5f) : c[k];
             zz[s] = zr[k];
             float delta = (k + 1 < K) ? (zr[k + 1] - zz[s]) : 1e10f;
             float sg = col[s].w;
@@ -304,6 +308,13 @@ using namespace anr;
 extern "C" int anr_composite(const float* rgbs, const float* z, const float* rays, int stride, const float* noise,
                              int64_t R, int K, int white_bkgd, float* weights_out, float* rgb_out,
                              float* depth_out, float* acc_out, void* stream) {
+    return anr_composite_masked(rgbs, z, rays, stride, noise, nullptr, R, K, white_bkgd, weights_out, rgb_out, depth_out,
+                                acc_out, stream);
+}
+
+extern "C" int anr_composite_masked(const float* rgbs, const float* z, const float* rays, int stride, const float* noise,
+                                    const uint8_t* valid, int64_t R, int K, int white_bkgd, float* weights_out,
+                                    float* rgb_out, float* depth_out, float* acc_out, void* stream) {
     ANR_REQUIRE(rgbs && z && rays && rgb_out && depth_out && acc_out, ANR_E_BADARG, "anr_composite: null pointer");
     ANR_REQUIRE(R > 0 && K > 0 && stride >= 8, ANR_E_BADARG, "anr_composite: R=%lld K=%d stride=%d", (long long)R, K, stride);
     ANR_REQUIRE(K <= ANR_MAX_SAMPLES, ANR_E_SHAPE, "anr_composite: K=%d > %d", K, ANR_MAX_SAMPLES);
@@ -314,7 +325,7 @@ extern "C" int anr_composite(const float* rgbs, const float* z, const float* ray
     int S = (K + 63) / 64;
 #define ANR_LAUNCH_COMPOSITE(SS)                                                                          \
     hipLaunchKernelGGL(composite_kernel<SS>, grid, block, 0, st, c, z, rays, stride, noise, R, K, white_bkgd, \
-                       weights_out, rgb_out, depth_out, acc_out)
+                       weights_out, rgb_out, depth_out, acc_out, valid)
     switch (S) {
         case 1: ANR_LAUNCH_COMPOSITE(1); break;
         case 2: ANR_LAUNCH_COMPOSITE(2); break;

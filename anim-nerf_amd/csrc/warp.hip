@@ -240,7 +240,7 @@ __device__ __forceinline__ void stage_index(const float* __restrict__ index, int
 }
 
 // Blend the four neighbours (models/anim_nerf.py:165-192) and store the canonical point; best.i are index slots.
-__device__ __forceinline__ void blend_and_store(const Best4& best, const int32_t* __restrict__ order,
+__device__ __forceinline__ bool blend_and_store(const Best4& best, const int32_t* __restrict__ order,
                                                 const float* __restrict__ lbs_w, int J, const float* __restrict__ O2C,
                                                 float thr, float px, float py, float pz, int64_t o,
                                                 float4* __restrict__ pts_out, float* __restrict__ dist_out,
@@ -310,6 +310,7 @@ __device__ __forceinline__ void blend_and_store(const Best4& best, const int32_t
         for (int k = 0; k < 4; ++k) { dist_out[o * 4 + k] = dist[k]; idx_out[o * 4 + k] = vid[k]; }
         blended_out[o] = db;
     }
+    return db < thr;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -497,7 +498,8 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
     const float* __restrict__ xyz, int xyz_stride, const float* __restrict__ rays, int ray_stride,
     const float* __restrict__ z, int K, const float* __restrict__ index, IndexDims d, int64_t N, float thr,
     float4* __restrict__ pts_out, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w, int32_t* __restrict__ list,
-    int32_t* __restrict__ cells, int32_t* __restrict__ count, int32_t* __restrict__ cell_count) {
+    int32_t* __restrict__ cells, int32_t* __restrict__ count, int32_t* __restrict__ cell_count,
+    uint8_t* __restrict__ valid_mask) {
     __shared__ int wave_cnt[WARP_THREADS / 64];
     __shared__ int block_base;
     __shared__ int hkeys[HN], hcnt[HN];
@@ -524,13 +526,16 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
                 px = sp[0]; py = sp[1]; pz = sp[2];
             }
             const int64_t o = (int64_t)b * N + n;
-            pts_out[o] = make_float4(px, py, pz, 0.0f);
+            // farther than the threshold from the whole body -> cannot be valid (see warp_points_kernel)
+            near = box_d2(gbox, px, py, pz) < thr * thr;
+            // lean mode (validity bytes requested): consumers look at the byte, not at the point, so the 16-B point of a
+            // far sample is not written at all
+            if (valid_mask != nullptr) valid_mask[o] = 0;
+            if (valid_mask == nullptr || near) pts_out[o] = make_float4(px, py, pz, 0.0f);
             if (nbr_w != nullptr) {
                 reinterpret_cast<float4*>(nbr_w)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
                 reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(0, 0, 0, 0);
             }
-            // farther than the threshold from the whole body -> cannot be valid (see warp_points_kernel)
-            near = box_d2(gbox, px, py, pz) < thr * thr;
             if (near) {
                 cell = cell_of(gbox, thr, px, py, pz);
                 const int slot = hash_slot(hkeys, cell);
@@ -737,7 +742,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
     const float* __restrict__ index, IndexDims d, const float* __restrict__ ober2cano, const float* __restrict__ lbs_w,
     int J, int64_t N, float thr, float4* __restrict__ pts_out, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w,
     const int32_t* __restrict__ list, const int32_t* __restrict__ count, int32_t* __restrict__ cursor,
-    const float* __restrict__ cell_cap2) {
+    const float* __restrict__ cell_cap2, uint8_t* __restrict__ valid_mask) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.y;
     const int cnt = count[b];
@@ -758,14 +763,54 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
         if (item >= n_items) break;
         const int i = item * 64 + lane;
         const bool go = i < cnt;
-        const int64_t o = (int64_t)b * N + my_list[go ? i : cnt - 1];
-        const float4 p = pts_out[o];
+        const int64_t o = (int64_t)b * N + (go ? my_list[i] : 0);
+        const float4 p = go ? pts_out[o] : make_float4(0.f, 0.f, 0.f, 0.f);
         // inside the cell's radius the exact four neighbours are guaranteed to be found (warp_cells_kernel)
         Best4 best;
         best_init(best, cap[cell_of(gbox, thr, p.x, p.y, p.z)]);
         search(lds, d, p.x, p.y, p.z, go, best);
         if (!go) continue;
-        blend_and_store(best, order, lbs_w, J, O2C, thr, p.x, p.y, p.z, o, pts_out, nullptr, nullptr, nullptr, nbr_idx, nbr_w);
+        const bool ok = blend_and_store(best, order, lbs_w, J, O2C, thr, p.x, p.y, p.z, o, pts_out, nullptr, nullptr, nullptr,
+                                        nbr_idx, nbr_w);
+        if (valid_mask != nullptr && ok) valid_mask[o] = 1;     // lean mode: the byte the compositor and the MLP's list go by
+    }
+}
+
+// lean mode: validity bytes -> list of the valid samples' flat positions for anr_mlp_forward_indexed, in sample order
+// (the MLP's gather of points and scatter of results then walk memory the way the rays were laid out); 4 bytes per thread
+__global__ __launch_bounds__(WARP_THREADS) void warp_valid_list_kernel(const uint8_t* __restrict__ mask, int64_t n,
+                                                                       int32_t* __restrict__ valid_index,
+                                                                       int32_t* __restrict__ valid_count) {
+    __shared__ int wave_cnt[WARP_THREADS / 64];
+    __shared__ int block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_blocks = (n + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
+    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const int64_t i0 = (blk * WARP_THREADS + threadIdx.x) * 4;
+        unsigned v = 0;
+        if (i0 + 3 < n) v = *reinterpret_cast<const unsigned*>(mask + i0);
+        else for (int k = 0; k < 4; ++k) if (i0 + k < n) v |= (unsigned)mask[i0 + k] << (8 * k);
+        const int mine = __popc(v & 0x01010101u);
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wave_cnt[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+#pragma unroll
+            for (int w = 0; w < WARP_THREADS / 64; ++w) { int c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
+            block_base = tot ? atomicAdd(valid_count, tot) : 0;
+        }
+        __syncthreads();
+        int pos = block_base + wave_cnt[wave] + incl - mine;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((v >> (8 * k)) & 1u) valid_index[pos++] = (int32_t)(i0 + k);
+        __syncthreads();
     }
 }
 
@@ -890,6 +935,22 @@ extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* ra
                                int V, int J, int64_t N, float dis_threshold, int skip_far, float* pts_out,
                                float* dist_out, int32_t* idx_out, float* blended_out, int32_t* nbr_idx_out,
                                float* nbr_w_out, int32_t* ws, void* stream) {
+    return anr_warp_points_lean(xyz, xyz_stride, rays, ray_stride, z, K, knn_index, ober2cano, lbs_weights, bs, V, J, N,
+                                dis_threshold, skip_far, pts_out, dist_out, idx_out, blended_out, nbr_idx_out, nbr_w_out, ws,
+                                nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int anr_warp_points_lean(const float* xyz, int xyz_stride, const float* rays, int ray_stride, const float* z,
+                                    int K, const void* knn_index, const float* ober2cano, const float* lbs_weights, int bs,
+                                    int V, int J, int64_t N, float dis_threshold, int skip_far, float* pts_out,
+                                    float* dist_out, int32_t* idx_out, float* blended_out, int32_t* nbr_idx_out,
+                                    float* nbr_w_out, int32_t* ws, uint8_t* valid_mask_out, int32_t* valid_index_out,
+                                    int32_t* valid_count_out, void* stream) {
+    const bool lean = valid_mask_out != nullptr;
+    ANR_REQUIRE((valid_mask_out != nullptr) == (valid_index_out != nullptr) && (valid_mask_out != nullptr) == (valid_count_out != nullptr),
+                ANR_E_BADARG, "anr_warp_points_lean: valid_mask_out / valid_index_out / valid_count_out go together");
+    ANR_REQUIRE(!lean || (skip_far && ws != nullptr), ANR_E_BADARG, "anr_warp_points_lean: the validity outputs need skip_far and ws");
+    ANR_REQUIRE(!lean || (int64_t)bs * N < (int64_t)1 << 31, ANR_E_BADARG, "anr_warp_points_lean: bs*N does not fit int32");
     ANR_REQUIRE(knn_index && ober2cano && lbs_weights && pts_out, ANR_E_BADARG, "anr_warp_points: null pointer");
     ANR_REQUIRE((xyz != nullptr) || (rays != nullptr && z != nullptr), ANR_E_BADARG,
                 "anr_warp_points: need xyz or (rays, z)");
@@ -921,11 +982,11 @@ extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* ra
         if (xyz == nullptr)
             hipLaunchKernelGGL(warp_classify_kernel<true>, g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride, z,
                                K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                               w.list, w.cells, w.count, w.cell_count);
+                               w.list, w.cells, w.count, w.cell_count, valid_mask_out);
         else
             hipLaunchKernelGGL(warp_classify_kernel<false>, g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride,
                                z, K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                               w.list, w.cells, w.count, w.cell_count);
+                               w.list, w.cells, w.count, w.cell_count, valid_mask_out);
         if (int rc = check_launch("anr_warp_points (classify)")) return rc;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -946,8 +1007,18 @@ extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* ra
         if (gx > max_wg) gx = max_wg;
         hipLaunchKernelGGL(warp_search_kernel, dim3((unsigned)gx, bs), dim3(WARP_THREADS), bytes, st, index, d, ober2cano,
                            lbs_weights, J, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                           w.sorted, w.live, w.cursor, w.cell_cap2);
-        return check_launch("anr_warp_points (search)");
+                           w.sorted, w.live, w.cursor, w.cell_cap2, valid_mask_out);
+        if (int rc = check_launch("anr_warp_points (search)")) return rc;
+        if (lean) {
+            e = hipMemsetAsync(valid_count_out, 0, sizeof(int32_t), st);
+            if (e != hipSuccess) return fail((int)e, "anr_warp_points_lean: hipMemsetAsync: %s", hipGetErrorString(e));
+            const int64_t total = (int64_t)bs * N;
+            const int64_t vb = (total + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
+            hipLaunchKernelGGL(warp_valid_list_kernel, dim3((unsigned)(vb < 4096 ? vb : 4096)), dim3(WARP_THREADS), 0, st,
+                               valid_mask_out, total, valid_index_out, valid_count_out);
+            return check_launch("anr_warp_points_lean (valid list)");
+        }
+        return 0;
     }
     if (xyz == nullptr) {
         if (int rc = allow_big_lds(warp_points_kernel<true>, bytes, "anr_warp_points")) return rc;

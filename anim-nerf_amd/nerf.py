@@ -88,7 +88,7 @@ class NeRF(nn.Module):
         return hit[1], mode_id
 
     def eval_points(self, pts: torch.Tensor, mode: Optional[str] = None, sigma_only: bool = False,
-                    only_valid: bool = False) -> torch.Tensor:
+                    only_valid: bool = False, valid_list=None) -> torch.Tensor:
         """pts[n,4] = (x,y,z,valid) -> [n,4] = (r,g,b,sigma), or sigma[n] (trunk + sigma row only).  The fused kernel entry.
         only_valid: run the network on the samples with valid >= 1 only; the rest get (0,0,0,-1e5)."""
         if torch.is_grad_enabled() and (pts.requires_grad or any(p.requires_grad for p in self.parameters())):
@@ -99,7 +99,7 @@ class NeRF(nn.Module):
             return MLPFunction.apply(pts, sigma_only, ops.MLP_MODES[mode or self.mlp_mode] & 0xff, only_valid,
                                      *[named[k] for k in PARAM_KEYS])
         pack, mode_id = self.weight_pack(mode)
-        return ops.mlp_forward(pack, mode_id, pts, sigma_only=sigma_only, only_valid=only_valid)
+        return ops.mlp_forward(pack, mode_id, pts, sigma_only=sigma_only, only_valid=only_valid, valid_list=valid_list)
 
     def eval_rays(self, rays: torch.Tensor, z: torch.Tensor, mode: Optional[str] = None) -> torch.Tensor:
         """[n,4] = (r,g,b,sigma) at the samples o + z d of rays[bs,R,>=8], z[bs,R,K] (inference, no warp): the kernel

@@ -188,7 +188,7 @@ def sample_coarse(rays: torch.Tensor, steps: torch.Tensor, t_rand: Optional[torc
 
 
 def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays=None, z=None, debug=False,
-                skip_far=False, neighbours=False, two_pass=True):
+                skip_far=False, neighbours=False, two_pass=True, lean=False):
     """models/anim_nerf.py:153-192.  Either xyz[bs,N,3|4] or (rays[bs,R,>=8], z[bs,R,K]).
     `index` = knn_index_build(posed verts).  Returns pts[bs,N,4] = (x_c, y_c, z_c, valid)
     (+ dist[bs,N,4], idx[bs,N,4] i32, blended[bs,N] if debug)."""
@@ -222,12 +222,23 @@ def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
     # renderer mode: classify + compact the samples near the body, then search the compacted list
     ws = (torch.empty(lib.anr_warp_ws_ints(bs, N), dtype=torch.int32, device=dev)
           if (skip_far and two_pass) else None)
+    vmask = vindex = vcount = None
+    if lean:
+        # renderer only: validity as one byte per sample + the list of valid positions; pts rows of far samples stay
+        # unwritten (-> (pts, valid[bs,N] u8, index[bs*N] i32, count[1] i32 on the device))
+        if not (skip_far and two_pass):
+            raise ValueError("lean=True needs skip_far=True and two_pass=True")
+        vmask = torch.empty(bs, N, dtype=torch.uint8, device=dev)
+        vindex = torch.empty(bs * N, dtype=torch.int32, device=dev)
+        vcount = torch.empty(1, dtype=torch.int32, device=dev)
     with _timed("warp_points", bs * N):
-        _lib.check(lib.anr_warp_points(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(index), _ptr(o2c),
-                                       _ptr(lbs_weights), bs, V, J, N, float(dis_threshold), 1 if skip_far else 0,
-                                       _ptr(pts), _ptr(dist), _ptr(idx), _ptr(blended), _ptr(nidx), _ptr(nw), _ptr(ws),
-                                       _stream(pts)),
+        _lib.check(lib.anr_warp_points_lean(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(index), _ptr(o2c),
+                                            _ptr(lbs_weights), bs, V, J, N, float(dis_threshold), 1 if skip_far else 0,
+                                            _ptr(pts), _ptr(dist), _ptr(idx), _ptr(blended), _ptr(nidx), _ptr(nw), _ptr(ws),
+                                            _ptr(vmask), _ptr(vindex), _ptr(vcount), _stream(pts)),
                    "anr_warp_points")
+    if lean:
+        return pts, vmask, vindex, vcount
     if neighbours:
         return pts, nidx, nw
     return (pts, dist, idx, blended) if debug else pts
@@ -349,7 +360,7 @@ def compact_valid(pts: torch.Tensor, fill: Optional[torch.Tensor] = None):
 
 
 def mlp_forward(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bool = False,
-                only_valid: bool = False) -> torch.Tensor:
+                only_valid: bool = False, valid_list=None) -> torch.Tensor:
     """pts[n,4] = (x,y,z,valid) -> out[n,4] = (r,g,b,sigma), or sigma[n] if sigma_only.
     only_valid: evaluate the samples with valid >= 1 only; the others get (0,0,0,-1e5) as in the reference's
     query_canonical_space_inside (models/anim_nerf.py:245-290).  Sigma is the same either way; rgb of an invalid
@@ -362,6 +373,14 @@ def mlp_forward(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bo
         out = torch.empty(n, dtype=torch.float32, device=pts.device)
     else:
         out = torch.empty(n, 4, dtype=torch.float32, device=pts.device)
+    if valid_list is not None:
+        # (index, count) from warp_points(lean=True): rows of the other samples stay uninitialised — their consumer
+        # (composite(valid=...)) does not read them
+        index, count = valid_list
+        with _timed("mlp_forward", count):
+            _lib.check(lib.anr_mlp_forward_indexed(_ptr(pack), mode, _ptr(pts), _ptr(index), _ptr(count), n, _ptr(out),
+                                                   _stream(out)), "anr_mlp_forward_indexed")
+        return out
     if only_valid:
         index, count = compact_valid(pts, fill=out)
         with _timed("mlp_forward", count):                 # units resolved after the timed region (device counter)
@@ -398,8 +417,9 @@ def grid_points(N: int, x_range, y_range, z_range, center: torch.Tensor, first: 
     return pts
 
 
-def composite(rgbs, z, rays, white_bkgd: bool, noise=None, want_weights: bool = True):
-    """models/volume_rendering.py:131-160.  rgbs[R,K,4], z[R,K], rays[R,>=8]."""
+def composite(rgbs, z, rays, white_bkgd: bool, noise=None, want_weights: bool = True, valid=None):
+    """models/volume_rendering.py:131-160.  rgbs[R,K,4], z[R,K], rays[R,>=8].
+    valid[R,K] uint8 (from warp_points(lean=True)): samples with 0 count as (0,0,0,-1e5) and their rows are not read."""
     lib = _lib.load()
     rgbs, z, rays = _dev(rgbs, "rgbs"), _dev(z, "z"), _dev(rays, "rays")
     R, K = z.shape
@@ -410,9 +430,11 @@ def composite(rgbs, z, rays, white_bkgd: bool, noise=None, want_weights: bool = 
     acc = torch.empty(R, 1, dtype=torch.float32, device=dev)
     if noise is not None:
         noise = _dev(noise, "noise")
+    if valid is not None:
+        valid = _dev(valid, "valid", torch.uint8)
     with _timed("composite", R * K):
-        _lib.check(lib.anr_composite(_ptr(rgbs), _ptr(z), _ptr(rays), rays.shape[-1], _ptr(noise), R, K,
-                                     1 if white_bkgd else 0, _ptr(w), _ptr(rgb), _ptr(depth), _ptr(acc), _stream(z)),
+        _lib.check(lib.anr_composite_masked(_ptr(rgbs), _ptr(z), _ptr(rays), rays.shape[-1], _ptr(noise), _ptr(valid), R, K,
+                                            1 if white_bkgd else 0, _ptr(w), _ptr(rgb), _ptr(depth), _ptr(acc), _stream(z)),
                    "anr_composite")
     return w, rgb, depth, acc
 

@@ -59,9 +59,16 @@ class VolumeRenderer(nn.Module):
         bs, R, K = z.shape
         fused = hasattr(model, "warped_points") and hasattr(model, "_net")
         net = model._net(not coarse) if fused else None
+        valid = None
         if fused and not model.use_unpose and not (torch.is_grad_enabled() and (
                 rays.requires_grad or z.requires_grad or any(p.requires_grad for p in net.parameters()))):
             out = net.eval_rays(rays, z)                         # no warp, inference: points are generated in the MLP kernel
+        elif (fused and getattr(model, "evaluate_valid_only", False) and model.skip_far_samples
+              and not torch.is_grad_enabled()):
+            # inference with the warp on: validity travels as one byte per sample (compositor) and as the list of valid
+            # positions (MLP); neither the points of far samples nor the rgb-sigma rows of invalid ones are ever written
+            pts, valid, vindex, vcount = model.warped_points(rays=rays, z=z, skip_far=True, lean=True)
+            out = net.eval_points(pts, valid_list=(vindex, vcount))
         elif fused:
             pts = model.warped_points(rays=rays, z=z, skip_far=True)
             # with the warp on, only samples near the body carry a density: the MLP runs on those (bit-identical
@@ -81,7 +88,8 @@ class VolumeRenderer(nn.Module):
                                                          rays.reshape(bs * R, -1), noise, self.white_bkgd)
         else:
             w, rgb, depth, acc = ops.composite(out.view(bs * R, K, 4), z.view(bs * R, K), rays.reshape(bs * R, -1),
-                                               self.white_bkgd, noise=noise, want_weights=want_weights)
+                                               self.white_bkgd, noise=noise, want_weights=want_weights,
+                                               valid=None if valid is None else valid.view(bs * R, K))
         return (w, rgb.view(bs, R, 3), depth.view(bs, R, 1), acc.view(bs, R, 1))
 
     def sample_fine_sorted(self, z_coarse, weights, perturb=0.):

@@ -142,6 +142,19 @@ int anr_warp_points(const float* xyz, int xyz_stride,
                     float* pts_out, float* dist_out, int32_t* idx_out, float* blended_out,
                     int32_t* nbr_idx_out, float* nbr_w_out, int32_t* ws, void* stream);
 
+/* Renderer variant with the validity handed over the cheap way (needs skip_far != 0 and ws): valid_mask_out[bs*N]
+ * (1 byte per sample: 1 iff valid), valid_index_out[bs*N] / valid_count_out[1] (DEVICE counter) = the flat positions
+ * b*N + n of the valid samples, ready for anr_mlp_forward_indexed.  pts_out rows of samples outside the body's
+ * bounding box + dis_threshold are then NOT written (nothing reads them: the MLP goes by the list, the compositor by
+ * the byte, anr_composite_masked).  All three NULL = anr_warp_points. */
+int anr_warp_points_lean(const float* xyz, int xyz_stride,
+                         const float* rays, int ray_stride, const float* z, int K,
+                         const void* knn_index, const float* ober2cano, const float* lbs_weights,
+                         int bs, int V, int J, int64_t N, float dis_threshold, int skip_far,
+                         float* pts_out, float* dist_out, int32_t* idx_out, float* blended_out,
+                         int32_t* nbr_idx_out, float* nbr_w_out, int32_t* ws,
+                         uint8_t* valid_mask_out, int32_t* valid_index_out, int32_t* valid_count_out, void* stream);
+
 /* Backward of anr_warp_points (rays mode) for pose refinement (a16): d_pts[bs*N*4] (w component ignored) ->
  * d_ober2cano[bs*V*16] and d_rays[bs*R*8] (ACCUMULATED with atomics: zero them first), d_z[bs*N] (written).
  * nbr_idx / nbr_w are the training outputs of the forward. */
@@ -245,6 +258,12 @@ int anr_composite(const float* rgbs, const float* z, const float* rays, int stri
                   const float* noise, int64_t R, int K, int white_bkgd,
                   float* weights_out, float* rgb_out, float* depth_out, float* acc_out,
                   void* stream);
+/* ... with the warp's per-sample validity bytes valid[R*K] (anr_warp_points): a sample with valid == 0 is taken as
+ * (0, 0, 0, -1e5) — what the reference gives it — and its row of rgbs is not read (it need not be initialised). */
+int anr_composite_masked(const float* rgbs, const float* z, const float* rays, int stride,
+                         const float* noise, const uint8_t* valid, int64_t R, int K, int white_bkgd,
+                         float* weights_out, float* rgb_out, float* depth_out, float* acc_out,
+                         void* stream);
 
 /* ---- a16 (part): backward of anr_composite -------------------------------------------------------------
  * What autograd differentiates in models/volume_rendering.py:131-160: upstream gradients of the per-ray outputs
