@@ -10,6 +10,25 @@ namespace anr {
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int MAXS = ANR_MAX_SAMPLES / WAVE;    // samples per lane, max
 
+// the same over segments of W lanes (W = 32: two rays per wavefront); l = lane inside the segment
+template <int W>
+__device__ __forceinline__ float seg_excl_prod(float v, int l) {
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < W; o <<= 1) {
+        float t = __shfl_up(inc, o, W);
+        if (l >= o) inc *= t;
+    }
+    float ex = __shfl_up(inc, 1, W);
+    return l == 0 ? 1.0f : ex;
+}
+template <int W>
+__device__ __forceinline__ float seg_sum(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 // exclusive multiplicative scan across the wave; returns product of lanes < lane
 __device__ __forceinline__ float wave_excl_prod(float v, int lane) {
     float inc = v;
@@ -35,15 +54,21 @@ __device__ __forceinline__ float wave_excl_sum(float v, int lane, float* total) 
 }
 
 // reference: models/volume_rendering.py:122-160
-template <int S>
+// LPR lanes per ray (64: one ray per wavefront; 32: two — for K <= 128 the instruction stream, which is what bounds this
+// kernel, then serves two rays), S samples per lane.
+template <int S, int LPR>
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_kernel(
     const float4* __restrict__ rgbs, const float* __restrict__ z, const float* __restrict__ rays, int stride,
     const float* __restrict__ noise, int64_t R, int K, int white_bkgd, float* __restrict__ weights_out,
     float* __restrict__ rgb_out, float* __restrict__ depth_out, float* __restrict__ acc_out,
     const uint8_t* __restrict__ valid) {
+    constexpr int RPW = WAVE / LPR;
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (r >= R) return;
+    const int l = lane % LPR;
+    const int64_t r_raw = ((int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool active = r_raw < R;
+    if (RPW == 1 && !active) return;
+    const int64_t r = active ? r_raw : R - 1;              // an idle half-wave shadows the last ray, stores nothing
     const float4* c = rgbs + r * K;
     const float* zr = z + r * K;
     const uint8_t* vr = valid ? valid + r * K : nullptr;
@@ -53,7 +78,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_kernel(
     float prod = 1.0f;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        int k = lane * S + s;
+        int k = l * S + s;
         alpha[s] = 0.0f; tr[s] = 1.0f; zz[s] = 0.0f; col[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < K) {
             // a sample the warp found invalid is (0, 0, 0, -1e5) by definition (models/anim_nerf.py:245-290, :305):
@@ -68,19 +93,19 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_kernel(
             prod = prod * (1.0f - alpha[s] + 1e-10f);
         }
     }
-    const float before = wave_excl_prod(prod, lane);
+    const float before = seg_excl_prod<LPR>(prod, l);
     float wsum = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dep = 0.f;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        int k = lane * S + s;
+        int k = l * S + s;
         if (k < K) {
             float w = alpha[s] * (before * tr[s]);
-            if (weights_out != nullptr) weights_out[r * K + k] = w;
+            if (weights_out != nullptr && active) weights_out[r * K + k] = w;
             wsum += w; cr += w * col[s].x; cg += w * col[s].y; cb += w * col[s].z; dep += w * zz[s];
         }
     }
-    wsum = wave_sum(wsum); cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); dep = wave_sum(dep);
-    if (lane == 0) {
+    wsum = seg_sum<LPR>(wsum); cr = seg_sum<LPR>(cr); cg = seg_sum<LPR>(cg); cb = seg_sum<LPR>(cb); dep = seg_sum<LPR>(dep);
+    if (l == 0 && active) {
         if (white_bkgd) {
             float far = rays[r * stride + 7];
             dep = dep + (1.0f - wsum) * far;
@@ -319,19 +344,18 @@ extern "C" int anr_composite_masked(const float* rgbs, const float* z, const flo
     ANR_REQUIRE(R > 0 && K > 0 && stride >= 8, ANR_E_BADARG, "anr_composite: R=%lld K=%d stride=%d", (long long)R, K, stride);
     ANR_REQUIRE(K <= ANR_MAX_SAMPLES, ANR_E_SHAPE, "anr_composite: K=%d > %d", K, ANR_MAX_SAMPLES);
     ANR_REQUIRE(((uintptr_t)rgbs & 15) == 0, ANR_E_ALIGN, "anr_composite: rgbs must be 16-B aligned");
-    dim3 grid((unsigned)((R + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), block(WAVE * WAVES_PER_BLOCK);
     const float4* c = reinterpret_cast<const float4*>(rgbs);
     hipStream_t st = (hipStream_t)stream;
-    int S = (K + 63) / 64;
-#define ANR_LAUNCH_COMPOSITE(SS)                                                                          \
-    hipLaunchKernelGGL(composite_kernel<SS>, grid, block, 0, st, c, z, rays, stride, noise, R, K, white_bkgd, \
-                       weights_out, rgb_out, depth_out, acc_out, valid)
-    switch (S) {
-        case 1: ANR_LAUNCH_COMPOSITE(1); break;
-        case 2: ANR_LAUNCH_COMPOSITE(2); break;
-        case 3: ANR_LAUNCH_COMPOSITE(3); break;
-        default: ANR_LAUNCH_COMPOSITE(4); break;
-    }
+    dim3 block(WAVE * WAVES_PER_BLOCK);
+#define ANR_LAUNCH_COMPOSITE(SS, LPR)                                                                              \
+    hipLaunchKernelGGL((composite_kernel<SS, LPR>), dim3((unsigned)((R + WAVES_PER_BLOCK * (WAVE / LPR) - 1) /       \
+                                                                    (WAVES_PER_BLOCK * (WAVE / LPR)))),              \
+                       block, 0, st, c, z, rays, stride, noise, R, K, white_bkgd, weights_out, rgb_out, depth_out,   \
+                       acc_out, valid)
+    if (K <= 64)       { ANR_LAUNCH_COMPOSITE(2, 32); }         // two rays per wavefront
+    else if (K <= 128) { ANR_LAUNCH_COMPOSITE(4, 32); }
+    else if (K <= 192) { ANR_LAUNCH_COMPOSITE(3, 64); }
+    else               { ANR_LAUNCH_COMPOSITE(4, 64); }
 #undef ANR_LAUNCH_COMPOSITE
     return check_launch("anr_composite");
 }
