@@ -174,7 +174,7 @@ class AnimNeRF(nn.Module):
             return net.get_normal(xyz)
         return net(xyz, viewdir=viewdir)
 
-    def warped_points(self, *, xyz=None, rays=None, z=None, skip_far=False, lean=False):
+    def warped_points(self, *, xyz=None, rays=None, z=None, skip_far=False, lean=False, reuse=None):
         """pts[bs*N,4] = (canonical xyz, valid) for explicit points or for samples along rays.
         skip_far: provably-invalid samples (farther than dis_threshold from the body's bounding box) skip the
         neighbour search; only legal where sigma = -1e5 is all that is consumed (the renderer)."""
@@ -188,7 +188,7 @@ class AnimNeRF(nn.Module):
             if lean:                                            # (pts, valid bytes, valid list, device count)
                 pts, vm, vi, vc = ops.warp_points(self.knn_index(), self.ober2cano_transform.detach(),
                                                   self.body_model.lbs_weights, self.dis_threshold, xyz=xyz, rays=rays,
-                                                  z=z, skip_far=True, lean=True)
+                                                  z=z, skip_far=True, lean=True, reuse=reuse)
                 return pts.view(-1, 4), vm, vi, vc
             return ops.warp_points(self.knn_index(), self.ober2cano_transform.detach(), self.body_model.lbs_weights,
                                    self.dis_threshold, xyz=xyz, rays=rays, z=z, skip_far=far).view(-1, 4)

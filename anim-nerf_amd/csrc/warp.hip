@@ -499,7 +499,8 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
     const float* __restrict__ z, int K, const float* __restrict__ index, IndexDims d, int64_t N, float thr,
     float4* __restrict__ pts_out, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w, int32_t* __restrict__ list,
     int32_t* __restrict__ cells, int32_t* __restrict__ count, int32_t* __restrict__ cell_count,
-    uint8_t* __restrict__ valid_mask) {
+    uint8_t* __restrict__ valid_mask, const float4* __restrict__ reuse_pts, const uint8_t* __restrict__ reuse_mask,
+    const int32_t* __restrict__ perm, int reuse_K) {
     __shared__ int wave_cnt[WARP_THREADS / 64];
     __shared__ int block_base;
     __shared__ int hkeys[HN], hcnt[HN];
@@ -528,6 +529,21 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
             const int64_t o = (int64_t)b * N + n;
             // farther than the threshold from the whole body -> cannot be valid (see warp_points_kernel)
             near = box_d2(gbox, px, py, pz) < thr * thr;
+            bool reused = false;
+            if (FROM_RAYS && perm != nullptr) {
+                // fine pass: this sorted sample IS coarse sample p of the same ray (z_sorted[j] = cat(z_coarse, z_fine)
+                // [perm[j]]) -> its canonical point and validity were computed in the coarse pass: copy, do not search
+                const int pj = perm[o];
+                if (pj < reuse_K) {
+                    const int64_t src = ((int64_t)b * (N / K) + n / K) * reuse_K + pj;
+                    const uint8_t m = reuse_mask[src];
+                    valid_mask[o] = m;
+                    if (m) pts_out[o] = reuse_pts[src];
+                    near = false;
+                    reused = true;
+                }
+            }
+            if (!reused) {
             // lean mode (validity bytes requested): consumers look at the byte, not at the point, so the 16-B point of a
             // far sample is not written at all
             if (valid_mask != nullptr) valid_mask[o] = 0;
@@ -541,6 +557,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
                 const int slot = hash_slot(hkeys, cell);
                 if (slot >= 0) atomicAdd(&hcnt[slot], 1);
                 else atomicAdd(cell_count + (int64_t)b * NCELL + cell, 1);
+            }
             }
         }
         const unsigned long long m = __ballot(near);
@@ -937,7 +954,7 @@ extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* ra
                                float* nbr_w_out, int32_t* ws, void* stream) {
     return anr_warp_points_lean(xyz, xyz_stride, rays, ray_stride, z, K, knn_index, ober2cano, lbs_weights, bs, V, J, N,
                                 dis_threshold, skip_far, pts_out, dist_out, idx_out, blended_out, nbr_idx_out, nbr_w_out, ws,
-                                nullptr, nullptr, nullptr, stream);
+                                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int anr_warp_points_lean(const float* xyz, int xyz_stride, const float* rays, int ray_stride, const float* z,
@@ -945,8 +962,13 @@ extern "C" int anr_warp_points_lean(const float* xyz, int xyz_stride, const floa
                                     int V, int J, int64_t N, float dis_threshold, int skip_far, float* pts_out,
                                     float* dist_out, int32_t* idx_out, float* blended_out, int32_t* nbr_idx_out,
                                     float* nbr_w_out, int32_t* ws, uint8_t* valid_mask_out, int32_t* valid_index_out,
-                                    int32_t* valid_count_out, void* stream) {
+                                    int32_t* valid_count_out, const float* reuse_pts, const uint8_t* reuse_mask,
+                                    const int32_t* reuse_perm, int reuse_K, void* stream) {
     const bool lean = valid_mask_out != nullptr;
+    ANR_REQUIRE((reuse_pts != nullptr) == (reuse_mask != nullptr) && (reuse_pts != nullptr) == (reuse_perm != nullptr),
+                ANR_E_BADARG, "anr_warp_points_lean: reuse_pts / reuse_mask / reuse_perm go together");
+    ANR_REQUIRE(reuse_pts == nullptr || (lean && xyz == nullptr && reuse_K > 0 && reuse_K <= K && ((uintptr_t)reuse_pts & 15) == 0),
+                ANR_E_BADARG, "anr_warp_points_lean: reuse needs the validity outputs, rays mode, 0 < reuse_K <= K");
     ANR_REQUIRE((valid_mask_out != nullptr) == (valid_index_out != nullptr) && (valid_mask_out != nullptr) == (valid_count_out != nullptr),
                 ANR_E_BADARG, "anr_warp_points_lean: valid_mask_out / valid_index_out / valid_count_out go together");
     ANR_REQUIRE(!lean || (skip_far && ws != nullptr), ANR_E_BADARG, "anr_warp_points_lean: the validity outputs need skip_far and ws");
@@ -982,11 +1004,12 @@ extern "C" int anr_warp_points_lean(const float* xyz, int xyz_stride, const floa
         if (xyz == nullptr)
             hipLaunchKernelGGL(warp_classify_kernel<true>, g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride, z,
                                K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                               w.list, w.cells, w.count, w.cell_count, valid_mask_out);
+                               w.list, w.cells, w.count, w.cell_count, valid_mask_out,
+                               reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K);
         else
             hipLaunchKernelGGL(warp_classify_kernel<false>, g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride,
                                z, K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                               w.list, w.cells, w.count, w.cell_count, valid_mask_out);
+                               w.list, w.cells, w.count, w.cell_count, valid_mask_out, nullptr, nullptr, nullptr, 0);
         if (int rc = check_launch("anr_warp_points (classify)")) return rc;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -188,7 +188,7 @@ def sample_coarse(rays: torch.Tensor, steps: torch.Tensor, t_rand: Optional[torc
 
 
 def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays=None, z=None, debug=False,
-                skip_far=False, neighbours=False, two_pass=True, lean=False):
+                skip_far=False, neighbours=False, two_pass=True, lean=False, reuse=None):
     """models/anim_nerf.py:153-192.  Either xyz[bs,N,3|4] or (rays[bs,R,>=8], z[bs,R,K]).
     `index` = knn_index_build(posed verts).  Returns pts[bs,N,4] = (x_c, y_c, z_c, valid)
     (+ dist[bs,N,4], idx[bs,N,4] i32, blended[bs,N] if debug)."""
@@ -231,11 +231,19 @@ def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
         vmask = torch.empty(bs, N, dtype=torch.uint8, device=dev)
         vindex = torch.empty(bs * N, dtype=torch.int32, device=dev)
         vcount = torch.empty(1, dtype=torch.int32, device=dev)
+    r_pts = r_mask = r_perm = None
+    r_k = 0
+    if reuse is not None:                   # (pts, valid bytes) of the coarse call + the merge's perm: see the header
+        if not lean or xyz is not None:
+            raise ValueError("reuse needs lean=True and rays mode")
+        r_pts, r_mask, r_perm = _dev(reuse[0], "reuse pts"), _dev(reuse[1], "reuse mask", torch.uint8), _dev(reuse[2], "perm", torch.int32)
+        r_k = r_mask.numel() // (bs * (N // K))
     with _timed("warp_points", bs * N):
         _lib.check(lib.anr_warp_points_lean(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(index), _ptr(o2c),
                                             _ptr(lbs_weights), bs, V, J, N, float(dis_threshold), 1 if skip_far else 0,
                                             _ptr(pts), _ptr(dist), _ptr(idx), _ptr(blended), _ptr(nidx), _ptr(nw), _ptr(ws),
-                                            _ptr(vmask), _ptr(vindex), _ptr(vcount), _stream(pts)),
+                                            _ptr(vmask), _ptr(vindex), _ptr(vcount), _ptr(r_pts), _ptr(r_mask), _ptr(r_perm),
+                                            r_k, _stream(pts)),
                    "anr_warp_points")
     if lean:
         return pts, vmask, vindex, vcount

@@ -55,7 +55,9 @@ class VolumeRenderer(nn.Module):
         z = ops.sample_coarse(rays, self._table(rays.device, "steps", self.n_coarse), t_rand)
         return z.view(bs, R, self.n_coarse)
 
-    def _shade(self, model, rays, z, coarse, perturb, want_weights, **kwargs):
+    def _shade(self, model, rays, z, coarse, perturb, want_weights, lean_state=None, **kwargs):
+        """lean_state (inference with the warp on): dict carrying the coarse pass's canonical points / validity bytes
+        and the merge's permutation to the fine pass, which re-visits the coarse samples."""
         bs, R, K = z.shape
         fused = hasattr(model, "warped_points") and hasattr(model, "_net")
         net = model._net(not coarse) if fused else None
@@ -67,7 +69,12 @@ class VolumeRenderer(nn.Module):
               and not torch.is_grad_enabled()):
             # inference with the warp on: validity travels as one byte per sample (compositor) and as the list of valid
             # positions (MLP); neither the points of far samples nor the rgb-sigma rows of invalid ones are ever written
-            pts, valid, vindex, vcount = model.warped_points(rays=rays, z=z, skip_far=True, lean=True)
+            reuse = None
+            if lean_state is not None and not coarse and "perm" in lean_state and getattr(self, "reuse_coarse_warp", True):
+                reuse = (lean_state["pts"], lean_state["valid"], lean_state["perm"])
+            pts, valid, vindex, vcount = model.warped_points(rays=rays, z=z, skip_far=True, lean=True, reuse=reuse)
+            if lean_state is not None and coarse:
+                lean_state["pts"], lean_state["valid"] = pts, valid
             out = net.eval_points(pts, valid_list=(vindex, vcount))
         elif fused:
             pts = model.warped_points(rays=rays, z=z, skip_far=True)
@@ -92,7 +99,7 @@ class VolumeRenderer(nn.Module):
                                                valid=None if valid is None else valid.view(bs * R, K))
         return (w, rgb.view(bs, R, 3), depth.view(bs, R, 1), acc.view(bs, R, 1))
 
-    def sample_fine_sorted(self, z_coarse, weights, perturb=0.):
+    def sample_fine_sorted(self, z_coarse, weights, perturb=0., lean_state=None):
         """z_sorted[bs,R,Kc+Kf] = sort(cat(z_coarse, inverse-CDF samples))."""
         bs, R, Kc = z_coarse.shape
         if perturb == 0:
@@ -106,7 +113,11 @@ class VolumeRenderer(nn.Module):
             both = torch.cat([z_coarse.view(bs * R, Kc), zf], -1)
             return torch.gather(both, -1, perm.long()).view(bs, R, Kc + self.n_fine)
         with torch.no_grad():
-            zs = ops.sample_fine_merge(z_coarse.detach().view(bs * R, Kc), weights, u)
+            if lean_state is not None and "pts" in lean_state:       # the fine pass will copy the coarse samples' warps
+                zs, perm = ops.sample_fine_merge(z_coarse.detach().view(bs * R, Kc), weights, u, want_perm=True)
+                lean_state["perm"] = perm
+            else:
+                zs = ops.sample_fine_merge(z_coarse.detach().view(bs * R, Kc), weights, u)
         return zs.view(bs, R, Kc + self.n_fine)
 
     def forward(self, model, rays, perturb=0., **kwargs):
@@ -114,11 +125,12 @@ class VolumeRenderer(nn.Module):
         as in the reference: z_fine is detached, models/volume_rendering.py:200)."""
         rays = rays if rays.is_contiguous() else rays.contiguous()
         z_coarse = self.sample_coarse(rays, perturb=perturb)
-        w, rgbs, depths, alphas = self._shade(model, rays, z_coarse, True, perturb, self.n_fine > 0, **kwargs)
+        lean_state = {} if self.n_fine > 0 else None
+        w, rgbs, depths, alphas = self._shade(model, rays, z_coarse, True, perturb, self.n_fine > 0, lean_state, **kwargs)
         output = {"rgbs": rgbs, "alphas": alphas, "depths": depths}
         if self.n_fine > 0:
-            z_all = self.sample_fine_sorted(z_coarse, w.detach(), perturb)
-            _, rgbs_f, depths_f, alphas_f = self._shade(model, rays, z_all, False, perturb, False, **kwargs)
+            z_all = self.sample_fine_sorted(z_coarse, w.detach(), perturb, lean_state)
+            _, rgbs_f, depths_f, alphas_f = self._shade(model, rays, z_all, False, perturb, False, lean_state, **kwargs)
             if self.share_fine:
                 output = {"rgbs": rgbs_f, "alphas": alphas_f, "depths": depths_f}
             else:

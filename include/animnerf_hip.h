@@ -146,14 +146,20 @@ int anr_warp_points(const float* xyz, int xyz_stride,
  * (1 byte per sample: 1 iff valid), valid_index_out[bs*N] / valid_count_out[1] (DEVICE counter) = the flat positions
  * b*N + n of the valid samples, ready for anr_mlp_forward_indexed.  pts_out rows of samples outside the body's
  * bounding box + dis_threshold are then NOT written (nothing reads them: the MLP goes by the list, the compositor by
- * the byte, anr_composite_masked).  All three NULL = anr_warp_points. */
+ * the byte, anr_composite_masked).  All three NULL = anr_warp_points.
+ * reuse_* (all or none; rays mode): the fine pass re-visits the coarse samples — sorted sample j of a ray is its
+ *   coarse sample p = reuse_perm[j] when p < reuse_K (anr_sample_fine_merge's perm_out) — so their canonical points
+ *   reuse_pts[bs*R*reuse_K*4] and validity bytes reuse_mask[bs*R*reuse_K] from the coarse call are copied, not searched
+ *   for again. */
 int anr_warp_points_lean(const float* xyz, int xyz_stride,
                          const float* rays, int ray_stride, const float* z, int K,
                          const void* knn_index, const float* ober2cano, const float* lbs_weights,
                          int bs, int V, int J, int64_t N, float dis_threshold, int skip_far,
                          float* pts_out, float* dist_out, int32_t* idx_out, float* blended_out,
                          int32_t* nbr_idx_out, float* nbr_w_out, int32_t* ws,
-                         uint8_t* valid_mask_out, int32_t* valid_index_out, int32_t* valid_count_out, void* stream);
+                         uint8_t* valid_mask_out, int32_t* valid_index_out, int32_t* valid_count_out,
+                         const float* reuse_pts, const uint8_t* reuse_mask, const int32_t* reuse_perm, int reuse_K,
+                         void* stream);
 
 /* Backward of anr_warp_points (rays mode) for pose refinement (a16): d_pts[bs*N*4] (w component ignored) ->
  * d_ober2cano[bs*V*16] and d_rays[bs*R*8] (ACCUMULATED with atomics: zero them first), d_z[bs*N] (written).
