@@ -206,7 +206,22 @@ def main():
                 net.mlp_mode = args.mode
             result["psnr_vs_fp32_path_db"] = orc.psnr(out["rgbs_fine"][:, idx].cpu(), ref["rgbs_fine"].cpu())
         if args.cpu_rays > 0:
-            result["cpu_baseline"] = cpu_baseline(args, tbl, model, rays, pose_np, use_warp)
+            result["cpu_baseline"], pick, ref = cpu_baseline(args, tbl, model, rays, pose_np, use_warp)
+            # the oracle as the checker: the same rays through the HIP path (fp32 parity mode and the benchmarked mode)
+            from oracle import animnerf_oracle as orc
+            sub = rays[:, pick.to(dev)].contiguous()
+            key = "rgbs_fine" if args.n_fine else "rgbs"
+            check = {"rays": int(pick.numel())}
+            for mode in dict.fromkeys(("f32", args.mode)):
+                for net in (model.nerf, model.nerf_fine):
+                    net.mlp_mode = mode
+                got = ana.batched_inference(vr, model, sub, pose, templ, chunk=1 << 16)[key].cpu()
+                err = (got - ref[key]).abs().max(-1).values / ref[key].abs().max(-1).values.clamp_min(1e-3)
+                check[mode] = {"max_rel_err_rgb": err.max().item(), "rays_within_1e-4": (err <= 1e-4).float().mean().item(),
+                               "psnr_db": orc.psnr(got, ref[key])}
+            for net in (model.nerf, model.nerf_fine):
+                net.mlp_mode = args.mode
+            result["oracle_check"] = check
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -311,14 +326,22 @@ def cpu_baseline(args, tbl, model, rays, pose_np, use_warp):
     orc.render_frame(otbl, Pc, Pf, probe, pose, templ, **kw)
     rate = 64 / (time.perf_counter() - t0)
     n = int(min(args.cpu_rays, max(64, rate * args.cpu_seconds)))
-    stride = max(1, rays.shape[1] // n)
-    sample = rays[:, ::stride][:, :n].cpu().contiguous()
+    # a regular grid over the central half of the image (where the body is: the oracle's cost does not depend on the
+    # content, the check below does)
+    H = W = int(round(rays.shape[1] ** 0.5))
+    side = max(2, int(n ** 0.5))
+    ys = torch.linspace(H // 4, 3 * H // 4 - 1, side).long()
+    xs = torch.linspace(W // 4, 3 * W // 4 - 1, side).long()
+    pick = (ys[:, None] * W + xs[None, :]).reshape(-1)
+    stride = f"{side}x{side} grid over the central half"
+    sample = rays[:, pick.to(rays.device)].cpu().contiguous()
     t0 = time.perf_counter()
-    orc.render_frame(otbl, Pc, Pf, sample, pose, templ, **kw)
+    ref = orc.render_frame(otbl, Pc, Pf, sample, pose, templ, **kw)
     dt = time.perf_counter() - t0
-    return {"value": sample.shape[1] / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{sample.shape[1]} rays of the same frame (every {stride}th), {args.n_coarse}+{args.n_fine} samples, "
+    base = {"value": sample.shape[1] / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{sample.shape[1]} rays of the same frame ({stride}), {args.n_coarse}+{args.n_fine} samples, "
                       f"oracle/animnerf_oracle.py on torch CPU fp32, {dt:.1f} s"}
+    return base, pick, ref
 
 
 if __name__ == "__main__":
