@@ -8,12 +8,12 @@
 // ONE point.  With the K index of the next layer's weights permuted to match (done once by
 // anr_mlp_pack), those 16 accumulators ARE the next layer's B fragments: activations never
 // leave registers for the whole 11-GEMM chain, there is no LDS/HBM round trip and no cross-lane
-// shuffle between layers.  Weights stream L2 -> LDS (32-row tiles through a 3-slot ring, LDS-DMA) and are
-// shared by the workgroup's 4 wavefronts (3-slot ring); each wavefront owns NT x 32 points.
+// shuffle between layers.  Weights stream L2 -> LDS (chunks of 32-row tiles through a 3-slot ring, LDS-DMA) and are
+// shared by the workgroup's wavefronts; each wavefront owns NT x 32 points; workgroups are persistent (one per CU).
 //
-//   mode BF16: v_mfma_f32_32x32x16_bf16, NT = 2 (64 points / wave, 256 / workgroup)
-//   mode F32 : v_mfma_f32_32x32x2_f32  , NT = 1 (32 points / wave, 128 / workgroup) — exact fp32
-//              fmaf chains, the parity mode.
+//   mode BF16 (default shape, Cfg<ANR_MLP_BF16_W8>): v_mfma_f32_32x32x16_bf16, 8 waves x 32 points = 256 / workgroup
+//   mode BF16 (flag 0x200, Cfg<ANR_MLP_BF16>):        4 waves x 64 points (NT = 2), half the LDS reads per flop
+//   mode F32 : v_mfma_f32_32x32x2_f32, 4 waves x 32 points = 128 / workgroup — exact fp32 fmaf chains, the parity mode.
 //
 // Slot algebra (h = lane>>5, i = lane&31; "frag" = 16 bytes per lane = 1 KiB per wave):
 //   accumulator reg (g = reg>>2, r = reg&3) of out-tile t  <->  out feature 32t + 8g + 4h + r
