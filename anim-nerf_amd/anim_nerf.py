@@ -25,6 +25,22 @@ def batch_transform(P, v, pad_ones=True):
     return out + P[..., :3, 3] if pad_ones else out
 
 
+def _affine_inverse(T):
+    """Inverse of affine 4x4 matrices [..., 4, 4] with bottom row (0,0,0,1) in closed form (adjugate / determinant):
+    differentiable tensor ops only — no LAPACK call, nothing that reads the device back (graph-capturable)."""
+    R, t = T[..., :3, :3], T[..., :3, 3]
+    c = torch.linalg.cross
+    r0, r1, r2 = R[..., 0, :], R[..., 1, :], R[..., 2, :]
+    adj = torch.stack([c(r1, r2), c(r2, r0), c(r0, r1)], dim=-1)
+    det = (r0 * c(r1, r2)).sum(-1)
+    Rinv = adj / det[..., None, None]
+    out = torch.zeros_like(T)
+    out[..., :3, :3] = Rinv
+    out[..., :3, 3] = -small_matvec(Rinv, t)
+    out[..., 3, 3] = 1
+    return out
+
+
 def _ober2cano_autograd(T, T_template, offset_delta):
     """models/anim_nerf.py:147-151 as differentiable tensor ops (closed-form inverse of the affine T, per frame):
     out = T_template @ [R^-1 | -R^-1 t + offset_delta]."""
@@ -122,7 +138,8 @@ class AnimNeRF(nn.Module):
 
     def convert_to_body_model_space(self, rays):
         """rays[bs,R,>=8] -> rays in the root-joint frame; moves the cached body state too."""
-        g_inv = torch.inverse(self.global_transform)                       # [bs,4,4]; bs tiny
+        # [bs,4,4]; bs tiny.  Under pose refinement the closed form (differentiable, no LAPACK launch sequence)
+        g_inv = _affine_inverse(self.global_transform) if self._pose_grad() else torch.inverse(self.global_transform)
         if self._pose_grad():                                              # per-frame, differentiable form of the kernel
             o = batch_transform(g_inv[:, None], rays[..., 0:3])
             d = batch_transform(g_inv[:, None], rays[..., 3:6], pad_ones=False)

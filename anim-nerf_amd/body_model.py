@@ -77,7 +77,7 @@ def rodrigues(rv: torch.Tensor) -> torch.Tensor:
     return torch.eye(3, dtype=rv.dtype, device=rv.device) + s * K + (1 - c) * (K @ K)
 
 
-def rigid_chain(R: torch.Tensor, J: torch.Tensor, parents: torch.Tensor):
+def rigid_chain(R: torch.Tensor, J: torch.Tensor, parents: torch.Tensor, parents_host=None):
     """World joint transforms along the kinematic tree, and the same relative to the rest
     pose (smplx/lbs.py:348-404).  R[B,J,3,3], J[B,J,3] -> posed[B,J,3], A[B,J,4,4]."""
     B, nj = J.shape[:2]
@@ -88,7 +88,7 @@ def rigid_chain(R: torch.Tensor, J: torch.Tensor, parents: torch.Tensor):
     local[..., :3, 3] = rel
     local[..., 3, 3] = 1
     world = [local[:, 0]]
-    par = parents.tolist()
+    par = parents_host if parents_host is not None else parents.tolist()      # (host copy: no device read per call)
     for j in range(1, nj):
         world.append(world[par[j]] @ local[:, j])
     world = torch.stack(world, 1)
@@ -136,6 +136,7 @@ class SMPL(nn.Module):
         parents = torch.from_numpy(np.array(d["kintree_table"][0], dtype=np.float32)).long()
         parents[0] = -1
         self.register_buffer("parents", parents)
+        self._parents_host = parents.tolist()
         self.register_buffer("lbs_weights", _as_f32(d["weights"]))
 
     @property
@@ -181,7 +182,7 @@ class SMPL(nn.Module):
         feat = (R[:, 1:] - torch.eye(3, dtype=R.dtype, device=R.device)).reshape(B, -1)
         pose_off = (feat @ self.posedirs).view(B, -1, 3)
         v_posed = v_shaped + pose_off
-        Jp, A = rigid_chain(R, J, self.parents)
+        Jp, A = rigid_chain(R, J, self.parents, self._parents_host)
         nj = self.J_regressor.shape[0]
         # skinning as ONE [V,J] x [J, 16 B] GEMM (a broadcast batched matmul would be B products 16 columns wide)
         nv = self.lbs_weights.shape[0]
