@@ -77,24 +77,61 @@ def rodrigues(rv: torch.Tensor) -> torch.Tensor:
     return torch.eye(3, dtype=rv.dtype, device=rv.device) + s * K + (1 - c) * (K @ K)
 
 
+_LEVEL_CACHE = {}
+
+
+def _tree_plan(par, device):
+    """Index tensors of the level-wise walk, built once per (tree, device): [(ids, parent positions or None)], inverse order."""
+    key = (tuple(par), str(device))
+    if key not in _LEVEL_CACHE:
+        order, steps, prev_n = [0], [], 1
+        for ids, pos in _tree_levels(par):
+            same = len(pos) == prev_n and pos == list(range(len(pos)))
+            steps.append((torch.tensor(ids, device=device), None if same else torch.tensor(pos, device=device)))
+            order += ids
+            prev_n = len(ids)
+        inv = [0] * len(par)
+        for k, j in enumerate(order):
+            inv[j] = k
+        _LEVEL_CACHE[key] = (steps, torch.tensor(inv, device=device))
+    return _LEVEL_CACHE[key]
+
+
+def _tree_levels(par):
+    """Joints grouped by depth: [(joint ids, position of each joint's parent inside the previous level)]."""
+    depth = [0] * len(par)
+    for j in range(1, len(par)):
+        depth[j] = depth[par[j]] + 1
+    levels, prev = [], [0]
+    for d in range(1, max(depth) + 1):
+        ids = [j for j in range(len(par)) if depth[j] == d]
+        levels.append((ids, [prev.index(par[j]) for j in ids]))
+        prev = ids
+    return levels
+
+
 def rigid_chain(R: torch.Tensor, J: torch.Tensor, parents: torch.Tensor, parents_host=None):
     """World joint transforms along the kinematic tree, and the same relative to the rest
-    pose (smplx/lbs.py:348-404).  R[B,J,3,3], J[B,J,3] -> posed[B,J,3], A[B,J,4,4]."""
+    pose (smplx/lbs.py:348-404).  R[B,J,3,3], J[B,J,3] -> posed[B,J,3], A[B,J,4,4].
+    The tree is walked level by level (9 levels for SMPL's 24 joints) with one batched product per level instead of
+    one per joint: a third of the launches, forward and backward."""
     B, nj = J.shape[:2]
+    par = parents_host if parents_host is not None else parents.tolist()      # (host copy: no device read per call)
     rel = J.clone()
     rel[:, 1:] = J[:, 1:] - J[:, parents[1:]]
     local = torch.zeros(B, nj, 4, 4, dtype=R.dtype, device=R.device)
     local[..., :3, :3] = R
     local[..., :3, 3] = rel
     local[..., 3, 3] = 1
-    world = [local[:, 0]]
-    par = parents_host if parents_host is not None else parents.tolist()      # (host copy: no device read per call)
-    for j in range(1, nj):
-        world.append(world[par[j]] @ local[:, j])
-    world = torch.stack(world, 1)
+    steps, inv = _tree_plan(par, R.device)
+    chunks = [local[:, 0:1]]
+    for idx, pos in steps:
+        up = chunks[-1] if pos is None else chunks[-1].index_select(1, pos)
+        chunks.append(small_matmul(up, local.index_select(1, idx)))
+    world = torch.cat(chunks, 1).index_select(1, inv)
     rest = torch.cat([J, torch.zeros_like(J[..., :1])], -1)[..., None]      # [B,J,4,1], w = 0
     A = world.clone()
-    A[..., :, 3:4] = world[..., :, 3:4] - world @ rest
+    A[..., :, 3:4] = world[..., :, 3:4] - small_matmul(world, rest)
     return world[..., :3, 3], A
 
 
