@@ -34,7 +34,7 @@ rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("at
 rows.sort(key=lambda e: -e.device_time_total)
 for e in rows[:25]:
     print(f"{e.key:14s} n={e.count:3d} gpu {e.device_time_total/1e3:7.3f} ms  cpu {e.cpu_time_total/1e3:7.3f} ms  {e.input_shapes}")
-print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=18, max_name_column_width=50))
+print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=22, max_name_column_width=50))
 nodes = [e for e in prof.key_averages() if e.key.endswith("Backward") or e.key.endswith("Backward0") or e.key.endswith("Backward1") or "Function" in e.key]
 nodes.sort(key=lambda e: -e.cpu_time_total)
 print("--- autograd nodes by total CPU time")
