@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--n-coarse", type=int, default=64)
     ap.add_argument("--n-fine", type=int, default=64)
     ap.add_argument("--chunk", type=int, default=1 << 20, help="rays per renderer call")
-    ap.add_argument("--cpu-rays", type=int, default=4096, help="upper bound on the rays timed on the host oracle (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=16384, help="upper bound on the rays timed on the host oracle (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target duration of the host-oracle sample")
     ap.add_argument("--sigma-gain", type=float, default=3000.0,
                     help="scale the sigma heads about their median (0 = literal random init, which renders a blank image)")
@@ -318,13 +318,20 @@ def cpu_baseline(args, tbl, model, rays, pose_np, use_warp):
     templ = {k: torch.from_numpy(v) for k, v in syn.template_pose_params().items()}
     kw = dict(n_coarse=args.n_coarse, n_fine=args.n_fine, use_unpose=use_warp, chunk=512 if not use_warp else 128,
               knn_chunk=2048)
-    # warm-up doubles as calibration: size the sample for about --cpu-seconds of work
+    # warm-up doubles as calibration: the thread count that serves this op mix best (hundreds of threads on ops this small
+    # lose to a few dozen), then the sample size for about --cpu-seconds of work
     centre = rays.shape[1] // 2
     probe = rays[:, centre:centre + 64].cpu().contiguous()
     orc.render_frame(otbl, Pc, Pf, probe[:, :8], pose, templ, **kw)
-    t0 = time.perf_counter()
-    orc.render_frame(otbl, Pc, Pf, probe, pose, templ, **kw)
-    rate = 64 / (time.perf_counter() - t0)
+    rate, best = 0.0, cores
+    for t in sorted({min(cores, c) for c in (8, 16, 32, 64, cores)}):
+        torch.set_num_threads(t)
+        t0 = time.perf_counter()
+        orc.render_frame(otbl, Pc, Pf, probe, pose, templ, **kw)
+        r = 64 / (time.perf_counter() - t0)
+        if r > rate:
+            rate, best = r, t
+    torch.set_num_threads(best)
     n = int(min(args.cpu_rays, max(64, rate * args.cpu_seconds)))
     # a regular grid over the central half of the image (where the body is: the oracle's cost does not depend on the
     # content, the check below does)
@@ -338,7 +345,7 @@ def cpu_baseline(args, tbl, model, rays, pose_np, use_warp):
     t0 = time.perf_counter()
     ref = orc.render_frame(otbl, Pc, Pf, sample, pose, templ, **kw)
     dt = time.perf_counter() - t0
-    base = {"value": sample.shape[1] / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+    base = {"value": sample.shape[1] / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "host_cores": cores, "kind": "port",
             "sample": f"{sample.shape[1]} rays of the same frame ({stride}), {args.n_coarse}+{args.n_fine} samples, "
                       f"oracle/animnerf_oracle.py on torch CPU fp32, {dt:.1f} s"}
     return base, pick, ref
