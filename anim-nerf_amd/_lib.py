@@ -77,6 +77,7 @@ SIGNATURES = {
     "anr_composite": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "anr_composite_backward": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "anr_sample_fine_merge": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P]),
+    "anr_sample_fine_merge_u8": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P]),
 }
 
 _lock = threading.Lock()

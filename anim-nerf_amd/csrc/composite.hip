@@ -218,10 +218,11 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_backward_ker
 }
 
 // reference: models/volume_rendering.py:59-97 (sample_fine) and :199-207 (cat + sort)
+template <typename PermT>
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void sample_fine_merge_kernel(
     const float* __restrict__ z_coarse, const float* __restrict__ weights, const float* __restrict__ u,
     int u_per_ray, int64_t R, int Kc, int Kf, float* __restrict__ z_fine_out, float* __restrict__ z_sorted_out,
-    int32_t* __restrict__ perm_out) {
+    PermT* __restrict__ perm_out) {
     __shared__ float lds[WAVES_PER_BLOCK][3 * ANR_MAX_SAMPLES];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void sample_fine_merge_kern
             }
             if (active) {
                 z_sorted_out[r * K + rank] = x;
-                if (perm_out != nullptr) perm_out[r * K + rank] = p;  // z_sorted[rank] = cat(z_coarse, z_fine)[p]
+                if (perm_out != nullptr) perm_out[r * K + rank] = (PermT)p;  // z_sorted[rank] = cat(z_coarse, z_fine)[p]
             }
         }
         return;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void sample_fine_merge_kern
         }
         if (active) {
             z_sorted_out[r * K + rank] = x;
-            if (perm_out != nullptr) perm_out[r * K + rank] = p;      // z_sorted[rank] = cat(z_coarse, z_fine)[p]
+            if (perm_out != nullptr) perm_out[r * K + rank] = (PermT)p;      // z_sorted[rank] = cat(z_coarse, z_fine)[p]
         }
     }
 }
@@ -392,7 +393,19 @@ extern "C" int anr_sample_fine_merge(const float* z_coarse, const float* weights
     ANR_REQUIRE(R > 0 && Kc >= 3 && Kf > 0, ANR_E_BADARG, "anr_sample_fine_merge: R=%lld Kc=%d Kf=%d", (long long)R, Kc, Kf);
     ANR_REQUIRE(Kc + Kf <= ANR_MAX_SAMPLES, ANR_E_SHAPE, "anr_sample_fine_merge: Kc+Kf=%d > %d", Kc + Kf, ANR_MAX_SAMPLES);
     dim3 grid((unsigned)((R + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), block(WAVE * WAVES_PER_BLOCK);
-    hipLaunchKernelGGL(sample_fine_merge_kernel, grid, block, 0, (hipStream_t)stream, z_coarse, weights, u,
+    hipLaunchKernelGGL(sample_fine_merge_kernel<int32_t>, grid, block, 0, (hipStream_t)stream, z_coarse, weights, u,
                        u_per_ray, R, Kc, Kf, z_fine_out, z_sorted_out, perm_out);
     return check_launch("anr_sample_fine_merge");
+}
+
+extern "C" int anr_sample_fine_merge_u8(const float* z_coarse, const float* weights, const float* u, int u_per_ray,
+                                        int64_t R, int Kc, int Kf, float* z_fine_out, float* z_sorted_out,
+                                        uint8_t* perm_out, void* stream) {
+    ANR_REQUIRE(z_coarse && weights && u && z_sorted_out && perm_out, ANR_E_BADARG, "anr_sample_fine_merge_u8: null pointer");
+    ANR_REQUIRE(R > 0 && Kc >= 3 && Kf > 0, ANR_E_BADARG, "anr_sample_fine_merge_u8: R=%lld Kc=%d Kf=%d", (long long)R, Kc, Kf);
+    ANR_REQUIRE(Kc + Kf <= ANR_MAX_SAMPLES && ANR_MAX_SAMPLES <= 256, ANR_E_SHAPE, "anr_sample_fine_merge_u8: Kc+Kf=%d > %d", Kc + Kf, ANR_MAX_SAMPLES);
+    dim3 grid((unsigned)((R + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), block(WAVE * WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(sample_fine_merge_kernel<uint8_t>, grid, block, 0, (hipStream_t)stream, z_coarse, weights, u,
+                       u_per_ray, R, Kc, Kf, z_fine_out, z_sorted_out, perm_out);
+    return check_launch("anr_sample_fine_merge_u8");
 }

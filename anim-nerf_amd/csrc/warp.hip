@@ -500,7 +500,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
     float4* __restrict__ pts_out, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w, int32_t* __restrict__ list,
     int32_t* __restrict__ cells, int32_t* __restrict__ count, int32_t* __restrict__ cell_count,
     uint8_t* __restrict__ valid_mask, const float4* __restrict__ reuse_pts, const uint8_t* __restrict__ reuse_mask,
-    const int32_t* __restrict__ perm, int reuse_K) {
+    const uint8_t* __restrict__ perm, int reuse_K) {
     __shared__ int wave_cnt[WARP_THREADS / 64];
     __shared__ int block_base;
     __shared__ int hkeys[HN], hcnt[HN];
@@ -963,7 +963,7 @@ extern "C" int anr_warp_points_lean(const float* xyz, int xyz_stride, const floa
                                     float* dist_out, int32_t* idx_out, float* blended_out, int32_t* nbr_idx_out,
                                     float* nbr_w_out, int32_t* ws, uint8_t* valid_mask_out, int32_t* valid_index_out,
                                     int32_t* valid_count_out, const float* reuse_pts, const uint8_t* reuse_mask,
-                                    const int32_t* reuse_perm, int reuse_K, void* stream) {
+                                    const uint8_t* reuse_perm, int reuse_K, void* stream) {
     const bool lean = valid_mask_out != nullptr;
     ANR_REQUIRE((reuse_pts != nullptr) == (reuse_mask != nullptr) && (reuse_pts != nullptr) == (reuse_perm != nullptr),
                 ANR_E_BADARG, "anr_warp_points_lean: reuse_pts / reuse_mask / reuse_perm go together");

@@ -236,7 +236,7 @@ def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
     if reuse is not None:                   # (pts, valid bytes) of the coarse call + the merge's perm: see the header
         if not lean or xyz is not None:
             raise ValueError("reuse needs lean=True and rays mode")
-        r_pts, r_mask, r_perm = _dev(reuse[0], "reuse pts"), _dev(reuse[1], "reuse mask", torch.uint8), _dev(reuse[2], "perm", torch.int32)
+        r_pts, r_mask, r_perm = _dev(reuse[0], "reuse pts"), _dev(reuse[1], "reuse mask", torch.uint8), _dev(reuse[2], "perm", torch.uint8)
         r_k = r_mask.numel() // (bs * (N // K))
     with _timed("warp_points", bs * N):
         _lib.check(lib.anr_warp_points_lean(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(index), _ptr(o2c),
@@ -488,7 +488,7 @@ def mlp_forward_save(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_onl
     return out, act
 
 
-def sample_fine_merge(z_coarse, weights, u, want_fine: bool = False, want_perm: bool = False):
+def sample_fine_merge(z_coarse, weights, u, want_fine: bool = False, want_perm: bool = False, perm_u8: bool = False):
     """models/volume_rendering.py:59-97,199-207.  z_coarse[R,Kc], weights[R,Kc], u[Kf] or u[R,Kf]."""
     lib = _lib.load()
     z_coarse, weights, u = _dev(z_coarse, "z_coarse"), _dev(weights, "weights"), _dev(u, "u")
@@ -498,10 +498,11 @@ def sample_fine_merge(z_coarse, weights, u, want_fine: bool = False, want_perm: 
     dev = z_coarse.device
     zf = torch.empty(R, Kf, dtype=torch.float32, device=dev) if want_fine else None
     zs = torch.empty(R, Kc + Kf, dtype=torch.float32, device=dev)
-    perm = torch.empty(R, Kc + Kf, dtype=torch.int32, device=dev) if want_perm else None
+    perm = torch.empty(R, Kc + Kf, dtype=torch.uint8 if perm_u8 else torch.int32, device=dev) if want_perm else None
+    fn = lib.anr_sample_fine_merge_u8 if (want_perm and perm_u8) else lib.anr_sample_fine_merge
     with _timed("sample_fine_merge", R * (Kc + Kf)):
-        _lib.check(lib.anr_sample_fine_merge(_ptr(z_coarse), _ptr(weights), _ptr(u), per_ray, R, Kc, Kf, _ptr(zf),
-                                             _ptr(zs), _ptr(perm), _stream(zs)), "anr_sample_fine_merge")
+        _lib.check(fn(_ptr(z_coarse), _ptr(weights), _ptr(u), per_ray, R, Kc, Kf, _ptr(zf), _ptr(zs), _ptr(perm),
+                      _stream(zs)), "anr_sample_fine_merge")
     if want_perm:
         return (zs, zf, perm) if want_fine else (zs, perm)
     return (zs, zf) if want_fine else zs

@@ -114,7 +114,7 @@ class VolumeRenderer(nn.Module):
             return torch.gather(both, -1, perm.long()).view(bs, R, Kc + self.n_fine)
         with torch.no_grad():
             if lean_state is not None and "pts" in lean_state:       # the fine pass will copy the coarse samples' warps
-                zs, perm = ops.sample_fine_merge(z_coarse.detach().view(bs * R, Kc), weights, u, want_perm=True)
+                zs, perm = ops.sample_fine_merge(z_coarse.detach().view(bs * R, Kc), weights, u, want_perm=True, perm_u8=True)
                 lean_state["perm"] = perm
             else:
                 zs = ops.sample_fine_merge(z_coarse.detach().view(bs * R, Kc), weights, u)

@@ -148,7 +148,7 @@ int anr_warp_points(const float* xyz, int xyz_stride,
  * bounding box + dis_threshold are then NOT written (nothing reads them: the MLP goes by the list, the compositor by
  * the byte, anr_composite_masked).  All three NULL = anr_warp_points.
  * reuse_* (all or none; rays mode): the fine pass re-visits the coarse samples — sorted sample j of a ray is its
- *   coarse sample p = reuse_perm[j] when p < reuse_K (anr_sample_fine_merge's perm_out) — so their canonical points
+ *   coarse sample p = reuse_perm[j] when p < reuse_K (anr_sample_fine_merge_u8's perm_out) — so their canonical points
  *   reuse_pts[bs*R*reuse_K*4] and validity bytes reuse_mask[bs*R*reuse_K] from the coarse call are copied, not searched
  *   for again. */
 int anr_warp_points_lean(const float* xyz, int xyz_stride,
@@ -158,7 +158,7 @@ int anr_warp_points_lean(const float* xyz, int xyz_stride,
                          float* pts_out, float* dist_out, int32_t* idx_out, float* blended_out,
                          int32_t* nbr_idx_out, float* nbr_w_out, int32_t* ws,
                          uint8_t* valid_mask_out, int32_t* valid_index_out, int32_t* valid_count_out,
-                         const float* reuse_pts, const uint8_t* reuse_mask, const int32_t* reuse_perm, int reuse_K,
+                         const float* reuse_pts, const uint8_t* reuse_mask, const uint8_t* reuse_perm, int reuse_K,
                          void* stream);
 
 /* Backward of anr_warp_points (rays mode) for pose refinement (a16): d_pts[bs*N*4] (w component ignored) ->
@@ -291,6 +291,10 @@ int anr_composite_backward(const float* rgbs, const float* z, const float* rays,
 int anr_sample_fine_merge(const float* z_coarse, const float* weights, const float* u,
                           int u_per_ray, int64_t R, int Kc, int Kf,
                           float* z_fine_out, float* z_sorted_out, int32_t* perm_out, void* stream);
+/* ... with the permutation as bytes (Kc + Kf <= 256): what anr_warp_points_lean's reuse_perm takes. */
+int anr_sample_fine_merge_u8(const float* z_coarse, const float* weights, const float* u, int u_per_ray,
+                             int64_t R, int Kc, int Kf,
+                             float* z_fine_out, float* z_sorted_out, uint8_t* perm_out, void* stream);
 
 #ifdef __cplusplus
 }
