@@ -509,15 +509,21 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int s = threadIdx.x; s < HN; s += WARP_THREADS) { hkeys[s] = -1; hcnt[s] = 0; }
     __syncthreads();
+    // each thread classifies CLS_ITERS samples (1024 apart) and remembers its near ones; the list is then written with ONE
+    // block-wide compaction (one scan, one global atomic, no barrier per iteration)
+    int my_cell[CLS_ITERS];
+    unsigned near_bits = 0;
+    const uint32_t R32 = (uint32_t)(N / (K > 0 ? K : 1));
+#pragma unroll
     for (int it = 0; it < CLS_ITERS; ++it) {
         const int64_t n = ((int64_t)blockIdx.x * CLS_ITERS + it) * WARP_THREADS + threadIdx.x;
         bool near = false;
         int cell = 0;
         if (n < N) {
             float px, py, pz;
+            const uint32_t ray = FROM_RAYS ? (uint32_t)n / (uint32_t)K : 0;        // (N < 2^31 on this path)
             if (FROM_RAYS) {
-                const int64_t R = N / K;
-                const float* ry = rays + ((int64_t)b * R + n / K) * ray_stride;
+                const float* ry = rays + ((int64_t)b * R32 + ray) * ray_stride;
                 const float zz = z[(int64_t)b * N + n];
                 px = __fadd_rn(ry[0], __fmul_rn(zz, ry[3]));
                 py = __fadd_rn(ry[1], __fmul_rn(zz, ry[4]));
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
                 // [perm[j]]) -> its canonical point and validity were computed in the coarse pass: copy, do not search
                 const int pj = perm[o];
                 if (pj < reuse_K) {
-                    const int64_t src = ((int64_t)b * (N / K) + n / K) * reuse_K + pj;
+                    const int64_t src = ((int64_t)b * R32 + ray) * reuse_K + pj;
                     const uint8_t m = reuse_mask[src];
                     valid_mask[o] = m;
                     if (m) pts_out[o] = reuse_pts[src];
@@ -544,24 +550,34 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
                 }
             }
             if (!reused) {
-            // lean mode (validity bytes requested): consumers look at the byte, not at the point, so the 16-B point of a
-            // far sample is not written at all
-            if (valid_mask != nullptr) valid_mask[o] = 0;
-            if (valid_mask == nullptr || near) pts_out[o] = make_float4(px, py, pz, 0.0f);
-            if (nbr_w != nullptr) {
-                reinterpret_cast<float4*>(nbr_w)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
-                reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(0, 0, 0, 0);
-            }
-            if (near) {
-                cell = cell_of(gbox, thr, px, py, pz);
-                const int slot = hash_slot(hkeys, cell);
-                if (slot >= 0) atomicAdd(&hcnt[slot], 1);
-                else atomicAdd(cell_count + (int64_t)b * NCELL + cell, 1);
-            }
+                // lean mode (validity bytes requested): consumers look at the byte, not at the point, so the 16-B point
+                // of a far sample is not written at all
+                if (valid_mask != nullptr) valid_mask[o] = 0;
+                if (valid_mask == nullptr || near) pts_out[o] = make_float4(px, py, pz, 0.0f);
+                if (nbr_w != nullptr) {
+                    reinterpret_cast<float4*>(nbr_w)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(0, 0, 0, 0);
+                }
+                if (near) {
+                    cell = cell_of(gbox, thr, px, py, pz);
+                    const int slot = hash_slot(hkeys, cell);
+                    if (slot >= 0) atomicAdd(&hcnt[slot], 1);
+                    else atomicAdd(cell_count + (int64_t)b * NCELL + cell, 1);
+                }
             }
         }
-        const unsigned long long m = __ballot(near);
-        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        my_cell[it] = cell;
+        near_bits |= (near ? 1u : 0u) << it;
+    }
+    {
+        const int mine = __popc(near_bits);
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wave_cnt[wave] = incl;
         __syncthreads();
         if (threadIdx.x == 0) {
             int tot = 0;
@@ -570,13 +586,17 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
             block_base = tot ? atomicAdd(count + b, tot) : 0;
         }
         __syncthreads();
-        if (near) {
-            const int64_t pos = (int64_t)b * N + block_base + wave_cnt[wave] + __popcll(m & ((1ull << lane) - 1ull));
-            list[pos] = (int32_t)n;
-            cells[pos] = cell;
+        int64_t pos = (int64_t)b * N + block_base + wave_cnt[wave] + incl - mine;
+#pragma unroll
+        for (int it = 0; it < CLS_ITERS; ++it) {
+            if ((near_bits >> it) & 1u) {
+                list[pos] = (int32_t)(((int64_t)blockIdx.x * CLS_ITERS + it) * WARP_THREADS + threadIdx.x);
+                cells[pos] = my_cell[it];
+                ++pos;
+            }
         }
-        __syncthreads();
     }
+    __syncthreads();
     for (int s = threadIdx.x; s < HN; s += WARP_THREADS)
         if (hkeys[s] >= 0) atomicAdd(cell_count + (int64_t)b * NCELL + hkeys[s], hcnt[s]);
 }
