@@ -173,14 +173,11 @@ __device__ __forceinline__ void scan_cluster(const float* lds, int Vp, int c, fl
     }
 }
 
-// exact 4 nearest vertices of (px,py,pz); best.i are index SLOTS (map through order[] for vertex ids).
-// Control flow is wave-uniform (ballots); per-lane work is predicated.
-__device__ __forceinline__ void search(const float* lds, const IndexDims& d, float px, float py, float pz, bool active,
-                                       Best4& best) {
+// greedy descent by box distance (per-lane LDS addresses below the top level) -> the cluster to scan first
+__device__ __forceinline__ int seed_cluster(const float* lds, const IndexDims& d, float px, float py, float pz) {
     const float* boxes = lds + d.box_off();
     const float* sboxes = lds + d.sbox_off();
     const float* tboxes = lds + d.tbox_off();
-    // 1. seed: greedy descent by box distance (per-lane LDS addresses below the top level) -> scan that cluster
     int seed_t = 0;
     float seed_v = 3.0e38f;
     for (int t = 0; t < d.NT; ++t) {
@@ -203,6 +200,17 @@ __device__ __forceinline__ void search(const float* lds, const IndexDims& d, flo
         const float v = box_d2(boxes + c * 8, px, py, pz);
         if (v < seed_v) { seed_v = v; seed_c = c; }
     }
+    return seed_c;
+}
+
+// exact 4 nearest vertices of (px,py,pz); best.i are index SLOTS (map through order[] for vertex ids).
+// Control flow is wave-uniform (ballots); per-lane work is predicated.  seed_c: the cluster each lane scans first
+// (any cluster is correct; a near one makes the bound tight before the traversal starts).
+__device__ __forceinline__ void search_from(const float* lds, const IndexDims& d, float px, float py, float pz, bool active,
+                                            Best4& best, int seed_c) {
+    const float* boxes = lds + d.box_off();
+    const float* sboxes = lds + d.sbox_off();
+    const float* tboxes = lds + d.tbox_off();
     if (!active) seed_c = -1;
     unsigned long long rem = __ballot(active);
     while (rem) {                                   // one pass per distinct seed cluster in the wavefront
@@ -212,7 +220,7 @@ __device__ __forceinline__ void search(const float* lds, const IndexDims& d, flo
         if (mine) scan_cluster(lds, d.Vp, c, px, py, pz, best);
         rem &= ~__ballot(mine);
     }
-    // 2. every other cluster whose box can still beat the current 4th-best
+    // every other cluster whose box can still beat the current 4th-best
     for (int t = 0; t < d.NT; ++t) {
         const float tv = box_d2(tboxes + t * 8, px, py, pz);
         if (!__any(active && tv < best.d[3])) continue;
@@ -230,6 +238,10 @@ __device__ __forceinline__ void search(const float* lds, const IndexDims& d, flo
             }
         }
     }
+}
+__device__ __forceinline__ void search(const float* lds, const IndexDims& d, float px, float py, float pz, bool active,
+                                       Best4& best) {
+    search_from(lds, d, px, py, pz, active, best, seed_cluster(lds, d, px, py, pz));
 }
 
 __device__ __forceinline__ void stage_index(const float* __restrict__ index, int n_floats, float* lds) {
@@ -451,9 +463,9 @@ constexpr int NCELL = GRID * GRID * GRID;
 constexpr float MIN_CELL = 0.04f;
 
 struct WarpWs {
-    int32_t *list, *cells, *sorted, *count, *cursor, *live, *occ_count, *occ_cursor, *cell_count, *cell_start, *occ_list;
+    int32_t *list, *cells, *sorted, *count, *cursor, *live, *occ_count, *occ_cursor, *cell_count, *cell_start, *occ_list, *cell_seed;
     float* cell_cap2;
-    __host__ static int64_t ints(int bs, int64_t N) { return 3 * (int64_t)bs * N + 5 * bs + 4 * (int64_t)bs * NCELL; }
+    __host__ static int64_t ints(int bs, int64_t N) { return 3 * (int64_t)bs * N + 5 * bs + 5 * (int64_t)bs * NCELL; }
     __host__ static int64_t zeroed_ints(int bs) { return 5 * bs + (int64_t)bs * NCELL; }      // from `count` on
     __host__ WarpWs(int32_t* ws, int bs, int64_t N) {
         list = ws; cells = list + (int64_t)bs * N; sorted = cells + (int64_t)bs * N; count = sorted + (int64_t)bs * N;
@@ -461,6 +473,7 @@ struct WarpWs {
         cell_count = occ_cursor + bs; cell_start = cell_count + (int64_t)bs * NCELL;
         cell_cap2 = reinterpret_cast<float*>(cell_start + (int64_t)bs * NCELL);
         occ_list = cell_start + 2 * (int64_t)bs * NCELL;
+        cell_seed = cell_start + 3 * (int64_t)bs * NCELL;
     }
 };
 
@@ -647,7 +660,8 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cells_kernel(const float* _
                                                                   const int32_t* __restrict__ occ_list,
                                                                   const int32_t* __restrict__ occ_count,
                                                                   int32_t* __restrict__ occ_cursor,
-                                                                  float* __restrict__ cell_cap2) {
+                                                                  float* __restrict__ cell_cap2,
+                                                                  int32_t* __restrict__ cell_seed) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.y;
     const int n_occ = occ_count[b];
@@ -679,6 +693,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cells_kernel(const float* _
             const float d1 = sqrtf(best.d[0]), d4 = sqrtf(best.d[3]);
             const float reach = d4 + r;
             cap[cell] = (d1 - r >= thr) ? -1.0f : reach * reach * 1.001f;
+            cell_seed[(int64_t)b * NCELL + cell] = best.i[0] / CS;      // cluster of the centre's nearest vertex
         }
     }
 }
@@ -779,7 +794,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
     const float* __restrict__ index, IndexDims d, const float* __restrict__ ober2cano, const float* __restrict__ lbs_w,
     int J, int64_t N, float thr, float4* __restrict__ pts_out, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w,
     const int32_t* __restrict__ list, const int32_t* __restrict__ count, int32_t* __restrict__ cursor,
-    const float* __restrict__ cell_cap2, uint8_t* __restrict__ valid_mask) {
+    const float* __restrict__ cell_cap2, uint8_t* __restrict__ valid_mask, const int32_t* __restrict__ cell_seed) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.y;
     const int cnt = count[b];
@@ -803,9 +818,11 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
         const int64_t o = (int64_t)b * N + (go ? my_list[i] : 0);
         const float4 p = go ? pts_out[o] : make_float4(0.f, 0.f, 0.f, 0.f);
         // inside the cell's radius the exact four neighbours are guaranteed to be found (warp_cells_kernel)
+        // ... and the first cluster to scan is the one the cell's own search found nearest: no descent per point
         Best4 best;
-        best_init(best, cap[cell_of(gbox, thr, p.x, p.y, p.z)]);
-        search(lds, d, p.x, p.y, p.z, go, best);
+        const int cell = cell_of(gbox, thr, p.x, p.y, p.z);
+        best_init(best, cap[cell]);
+        search_from(lds, d, p.x, p.y, p.z, go, best, go ? cell_seed[(int64_t)b * NCELL + cell] : 0);
         if (!go) continue;
         const bool ok = blend_and_store(best, order, lbs_w, J, O2C, thr, p.x, p.y, p.z, o, pts_out, nullptr, nullptr, nullptr,
                                         nbr_idx, nbr_w);
@@ -1039,7 +1056,7 @@ extern "C" int anr_warp_points_lean(const float* xyz, int xyz_stride, const floa
                            w.occ_list, w.occ_count);
         hipLaunchKernelGGL(warp_cells_kernel, dim3((unsigned)(gx < NCELL / WARP_THREADS ? gx : NCELL / WARP_THREADS), bs),
                            dim3(WARP_THREADS), bytes, st, index, d, dis_threshold, w.occ_list, w.occ_count, w.occ_cursor,
-                           w.cell_cap2);
+                           w.cell_cap2, w.cell_seed);
         hipLaunchKernelGGL(warp_cell_scan_kernel, dim3(bs), dim3(1024), 0, st, w.cell_count, w.cell_start, w.cell_cap2, w.live);
         const int64_t sc_blocks = (N + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
         hipLaunchKernelGGL(warp_cell_scatter_kernel, dim3((unsigned)(sc_blocks < 1024 ? sc_blocks : 1024), bs), dim3(WARP_THREADS), 0, st,
@@ -1050,7 +1067,7 @@ extern "C" int anr_warp_points_lean(const float* xyz, int xyz_stride, const floa
         if (gx > max_wg) gx = max_wg;
         hipLaunchKernelGGL(warp_search_kernel, dim3((unsigned)gx, bs), dim3(WARP_THREADS), bytes, st, index, d, ober2cano,
                            lbs_weights, J, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                           w.sorted, w.live, w.cursor, w.cell_cap2, valid_mask_out);
+                           w.sorted, w.live, w.cursor, w.cell_cap2, valid_mask_out, w.cell_seed);
         if (int rc = check_launch("anr_warp_points (search)")) return rc;
         if (lean) {
             e = hipMemsetAsync(valid_count_out, 0, sizeof(int32_t), st);
