@@ -138,7 +138,7 @@ def main():
     # WRITE_SIZE in separate runs, gfx950 correction applied; profiles/r01/mlp_hbm_traffic.json) x points per launch
     traffic = None
     tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "mlp_hbm_traffic.json")
-    if args.mode == "bf16" and mlp_launches and os.path.exists(tf):
+    if args.mode == "bf16" and not use_warp and mlp_launches and os.path.exists(tf):
         with open(tf) as fh:
             traffic = json.load(fh)["bytes_per_point"] * mlp_pts / mlp_launches
 
@@ -172,7 +172,7 @@ def main():
             "kernel": f"mlp_kernel<{args.mode}> (fused Fourier encoding + 11 GEMMs)",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak, "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (PMC: 32.1 B per point measured, 32 B algorithmic)",
+            "traffic_unit": "HBM bytes per launch (PMC, profiles/r01/mlp_hbm_traffic.json: 20.6 B per point measured on the no-warp path, 20 B algorithmic)",
             "launches": mlp_launches, "avg_launch_ms": (mlp_s / mlp_launches * 1e3) if mlp_launches else None,
             "flop_per_point": MLP_FLOP_PER_POINT,
         },
