@@ -138,9 +138,9 @@ def main():
     # WRITE_SIZE in separate runs, gfx950 correction applied; profiles/r01/mlp_hbm_traffic.json) x points per launch
     traffic = None
     tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "mlp_hbm_traffic.json")
-    if args.mode == "bf16" and not use_warp and mlp_launches and os.path.exists(tf):
+    if args.mode == "bf16" and mlp_launches and os.path.exists(tf):
         with open(tf) as fh:
-            traffic = json.load(fh)["bytes_per_point"] * mlp_pts / mlp_launches
+            traffic = json.load(fh)["bytes_per_point_indexed" if model.evaluate_valid_only else "bytes_per_point"] * mlp_pts / mlp_launches
 
     result = {
         "metric": "rays/sec (64+64 samples, 256-wide MLP)",
@@ -172,7 +172,7 @@ def main():
             "kernel": f"mlp_kernel<{args.mode}> (fused Fourier encoding + 11 GEMMs)",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak, "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (PMC, profiles/r01/mlp_hbm_traffic.json: 20.6 B per point measured on the no-warp path, 20 B algorithmic)",
+            "traffic_unit": "HBM bytes per launch (PMC, profiles/r01/mlp_hbm_traffic.json: 20.6 B per point measured on the no-warp path / 20 algorithmic; 40.1 / 36 per evaluated point with the warp on)",
             "launches": mlp_launches, "avg_launch_ms": (mlp_s / mlp_launches * 1e3) if mlp_launches else None,
             "flop_per_point": MLP_FLOP_PER_POINT,
         },
