@@ -140,7 +140,8 @@ def main():
     tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "mlp_hbm_traffic.json")
     if args.mode == "bf16" and mlp_launches and os.path.exists(tf):
         with open(tf) as fh:
-            traffic = json.load(fh)["bytes_per_point_indexed" if model.evaluate_valid_only else "bytes_per_point"] * mlp_pts / mlp_launches
+            traffic = json.load(fh)["bytes_per_point_indexed" if model.evaluate_valid_only else
+                                    "bytes_per_point_explicit" if use_warp else "bytes_per_point"] * mlp_pts / mlp_launches
 
     result = {
         "metric": "rays/sec (64+64 samples, 256-wide MLP)",
