@@ -22,10 +22,9 @@ class VolumeRenderer(nn.Module):
         self.share_fine = share_fine
         self.noise_std, self.depth_std = noise_std, depth_std
         self.lindisp, self.white_bkgd = lindisp, white_bkgd
-        if not lindisp:
-            raise NotImplementedError("lindisp=False (disparity sampling) is never selected by the reference's callers")
-        if n_fine_depth > 0:
-            raise NotImplementedError("n_fine_depth > 0 (depth-guided samples) is unused: n_depth = 0 in every config")
+        # lindisp=False (sampling linear in disparity) and n_fine_depth > 0 (samples around the coarse depth) are never
+        # selected by the reference's callers or configs: they are served by the tensor-op forms below (sampling is a
+        # few bytes per ray), everything per point still runs in the kernels
         self._tables = {}
 
     def _table(self, device, kind, n):
@@ -44,9 +43,13 @@ class VolumeRenderer(nn.Module):
         t_rand = None
         if perturb > 0:
             t_rand = perturb * torch.rand(bs * R, self.n_coarse, device=rays.device)
-        if torch.is_grad_enabled() and rays.requires_grad:       # pose refinement: near'/far' depend on the root transform
+        if (torch.is_grad_enabled() and rays.requires_grad) or not self.lindisp:
+            # pose refinement (near'/far' depend on the root transform), or the disparity branch (:45-46)
             s = self._table(rays.device, "steps", self.n_coarse)
-            z = rays[..., 6:7] * (1 - s) + rays[..., 7:8] * s
+            if self.lindisp:
+                z = rays[..., 6:7] * (1 - s) + rays[..., 7:8] * s
+            else:
+                z = 1 / (1 / rays[..., 6:7] * (1 - s) + 1 / rays[..., 7:8] * s)
             if t_rand is not None:
                 mids = .5 * (z[..., 1:] + z[..., :-1])
                 upper, lower = torch.cat([mids, z[..., -1:]], -1), torch.cat([z[..., :1], mids], -1)
@@ -120,16 +123,34 @@ class VolumeRenderer(nn.Module):
                 zs = ops.sample_fine_merge(z_coarse.detach().view(bs * R, Kc), weights, u)
         return zs.view(bs, R, Kc + self.n_fine)
 
+    def sample_fine_depth(self, rays, depth):
+        """models/volume_rendering.py:99-111: n_fine_depth samples ~ N(depth, depth_std), clamped to [near', far']."""
+        z = depth.repeat(1, 1, self.n_fine_depth)
+        z = z + torch.randn_like(z) * self.depth_std
+        return torch.min(torch.max(z, rays[..., 6:7]), rays[..., 7:8])
+
     def forward(self, model, rays, perturb=0., **kwargs):
         """Differentiable w.r.t. the MLP weights when autograd is enabled (sampling itself carries no gradient,
         as in the reference: z_fine is detached, models/volume_rendering.py:200)."""
         rays = rays if rays.is_contiguous() else rays.contiguous()
         z_coarse = self.sample_coarse(rays, perturb=perturb)
-        lean_state = {} if self.n_fine > 0 else None
+        lean_state = {} if (self.n_fine > 0 and self.n_fine_depth == 0) else None
         w, rgbs, depths, alphas = self._shade(model, rays, z_coarse, True, perturb, self.n_fine > 0, lean_state, **kwargs)
         output = {"rgbs": rgbs, "alphas": alphas, "depths": depths}
-        if self.n_fine > 0:
-            z_all = self.sample_fine_sorted(z_coarse, w.detach(), perturb, lean_state)
+        if self.n_fine > 0 or self.n_fine_depth > 0:
+            if self.n_fine_depth > 0:
+                # the general merge (:199-207): cat + sort of coarse, importance and depth-guided samples
+                parts = [z_coarse]
+                if self.n_fine > 0:
+                    bs, R, Kc = z_coarse.shape
+                    u = (self._table(rays.device, "u", self.n_fine) if perturb == 0
+                         else torch.rand(bs * R, self.n_fine, device=rays.device))
+                    _, zf = ops.sample_fine_merge(z_coarse.detach().view(bs * R, Kc), w.detach(), u, want_fine=True)
+                    parts.append(zf.view(bs, R, -1))
+                parts.append(self.sample_fine_depth(rays, depths).detach())
+                z_all = torch.sort(torch.cat(parts, -1), -1).values.contiguous()
+            else:
+                z_all = self.sample_fine_sorted(z_coarse, w.detach(), perturb, lean_state)
             _, rgbs_f, depths_f, alphas_f = self._shade(model, rays, z_all, False, perturb, False, lean_state, **kwargs)
             if self.share_fine:
                 output = {"rgbs": rgbs_f, "alphas": alphas_f, "depths": depths_f}

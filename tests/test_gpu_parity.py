@@ -376,6 +376,41 @@ def test_sparse_paths_are_bit_identical_on_random_frames(dev, smpl_table, seed):
         assert outs[0][key].max() > 0.2, "the body must be in view"
 
 
+def test_disparity_sampling_and_depth_guided_samples(dev, smpl_table):
+    """The two VolumeRenderer options no shipped config selects: lindisp=False (models/volume_rendering.py:45-46) and
+    n_fine_depth > 0 (:99-111, :204-207)."""
+    import anim_nerf_amd as ana
+    g = golden("render_cfg3_warp_gain")
+    m = seeded_model(smpl_table, g["seed"], True, g["gain"], g["shift"], device=dev)
+    with torch.no_grad():
+        m.set_body_model(_to(tdict(g), dev), _templ(dev))
+        rays = m.convert_to_body_model_space(torch.from_numpy(g["rays_world"]).to(dev))
+        m.clac_ober2cano_transform()
+        vr = ana.VolumeRenderer(n_coarse=16, n_fine=8, lindisp=False)
+        z = vr.sample_coarse(rays)
+        s = torch.linspace(0, 1 - 1.0 / 16, 16)
+        r = rays.cpu()
+        want = 1 / (1 / r[..., 6:7] * (1 - s) + 1 / r[..., 7:8] * s)
+        torch.testing.assert_close(z.cpu(), want, rtol=1e-6, atol=1e-6)
+        assert (z[..., 1:] > z[..., :-1]).all()
+        out = vr(m, rays)
+        gen = vr(lambda xyz, viewdir, use_fine=False: m(xyz, viewdir, use_fine=use_fine), rays)
+        for k in out:
+            torch.testing.assert_close(gen[k], out[k], rtol=2e-3, atol=2e-4)
+        # depth-guided samples: Kc + Kf + Kfd sorted depths inside [near', far'], reproducible under a seed
+        vd = ana.VolumeRenderer(n_coarse=16, n_fine=8, n_fine_depth=4, depth_std=0.02)
+        torch.manual_seed(1)
+        a = vd(m, rays)
+        torch.manual_seed(1)
+        b = vd(m, rays)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+        assert set(a) == set(out) and a["rgbs_fine"].shape == out["rgbs_fine"].shape
+        zd = vd.sample_fine_depth(rays, a["depths"])
+        assert zd.shape[-1] == 4 and (zd >= rays[..., 6:7]).all() and (zd <= rays[..., 7:8]).all()
+        assert a["alphas_fine"].max() > 0.2
+
+
 def test_generic_model_path_equals_fused_path(dev, smpl_table):
     """VolumeRenderer.forward(model=<any callable>) hands materialised xyz to the model, as the reference does."""
     import anim_nerf_amd as ana
