@@ -35,8 +35,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
-                    help="cfg2/cfg3: BASELINE configs[1]/[2] (inference); cfg4: configs[3] training step (64+32, 32x32 rays per frame)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="cfg2/cfg3: BASELINE configs[1]/[2] (inference); cfg4: configs[3] training step (64+32, 32x32 rays per frame); "
+                         "cfg5: configs[4] 512^3 sigma grid, voxel-sharded")
     ap.add_argument("--frames-per-gpu", type=int, default=16, help="cfg4: frames (of 1024 rays) per step per GPU")
     ap.add_argument("--mode", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--hw", type=int, default=1024)
@@ -73,6 +74,8 @@ def main():
     ana._lib.load()                                   # fails loudly if the HIP library is missing
     if args.workload == "cfg4":
         return train_bench(args, rank, local_rank, world, dev)
+    if args.workload == "cfg5":
+        return grid_bench(args, rank, local_rank, world, dev)
     use_warp = args.workload == "cfg3"
     tbl = syn.make_smpl_table(0)
     torch.manual_seed(0)
@@ -223,6 +226,74 @@ def main():
             for net in (model.nerf, model.nerf_fine):
                 net.mlp_mode = args.mode
             result["oracle_check"] = check
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def grid_bench(args, rank, local_rank, world, dev):
+    """BASELINE configs[4]: relu(sigma) of the fine field on a 512^3 grid around the posed body (extract_mesh.py:152-158),
+    voxel-sharded: rank r evaluates slab r of the SAME grid (strong scaling), no collective on the data path."""
+    import torch.distributed as dist
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import ops, synthetic as syn
+    N = 512
+    tbl = syn.make_smpl_table(0)
+    torch.manual_seed(0)
+    model = ana.AnimNeRF(body_model_table=tbl, freqs_dir=0, use_view=False, use_unpose=True, use_knn=True,
+                         use_fine=True, mlp_mode=args.mode).eval().to(dev)
+    g = torch.Generator().manual_seed(5)
+    probe = (torch.rand(1, 4096, 3, generator=g) * 1.6 - 0.8).to(dev)
+    with torch.no_grad():
+        for net in (model.nerf, model.nerf_fine):
+            net.mlp_mode = "f32"
+            med = net(probe)[1].median().item()
+            net.mlp_mode = args.mode
+            net.sigma.weight.mul_(args.sigma_gain or 1.0)
+            net.sigma.bias.mul_(args.sigma_gain or 1.0).add_(-(args.sigma_gain or 1.0) * med)
+        model.skip_invalid_samples = not args.dense
+        pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=100).items()}
+        templ = {k: torch.from_numpy(v).to(dev) for k, v in syn.template_pose_params().items()}
+        rays = torch.zeros(1, 1, 8, device=dev)
+        rays[..., 5], rays[..., 7] = -1, 10
+        model.set_body_model(pose, templ)
+        model.convert_to_body_model_space(rays)
+        model.clac_ober2cano_transform()
+
+        def step():
+            return ana.sigma_grid(model, N, chunk=1 << 25, rank=rank, world=world)
+
+        def barrier():
+            if world > 1:
+                dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize(dev)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        ops.KERNEL_TIMING = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sig, _ = step()
+        barrier()
+        elapsed = ana.max_over_ranks(time.perf_counter() - t0, dev)
+        timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
+    mlp_s = sum(e0.elapsed_time(e1) for n, e0, e1, u in timing if n == "mlp_forward") * 1e-3
+    mlp_pts = sum(int(u) for n, e0, e1, u in timing if n == "mlp_forward")
+    peak = PEAK_BF16_TFLOPS if args.mode == "bf16" else PEAK_F32_TFLOPS
+    flop = 982_528                                            # sigma-only: trunk + sigma row (SURVEY.md section 8d)
+    achieved = mlp_pts * flop / mlp_s / 1e12 if mlp_s else 0.0
+    result = {
+        "metric": "grid points/sec, 512^3 sigma query (mesh extraction input)", "value": N ** 3 * args.steps / elapsed,
+        "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": args.mode, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: 512^3 sigma grid around the posed body, fine network, voxel-sharded "
+                               "(contiguous slabs, no collective)", "grid": N, "mlp_on_valid_voxels_only": bool(model.evaluate_valid_only),
+                   "mlp_points_per_step_this_rank": mlp_pts // max(args.steps, 1), "occupied_voxels_this_rank": int((sig > 0).sum())},
+        "roofline": {"kernel": f"mlp_kernel<{args.mode}, sigma only>", "bound": "mfma", "achieved": achieved, "peak": peak,
+                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "flop_per_point": flop},
+    }
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
