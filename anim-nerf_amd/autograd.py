@@ -108,7 +108,7 @@ class MLPFunction(torch.autograd.Function):
             return torch.ops.aten.threshold_backward(dy, h, 0)
 
         valid = (pts[:, 3] >= 1.0).to(g.dtype)                       # sigma is the constant -1e5 where invalid
-        enc = ops.encode(pts, dt) if pts.is_cuda else _encode(pts[:, :3]).to(dt)
+        enc = ops.encode(pts, dt)
         want_pts = ctx.needs_input_grad[0]
         d_enc = None
         if MLPFunction.FUSED_BACKWARD:
