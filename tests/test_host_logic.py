@@ -33,6 +33,29 @@ def test_bad_arguments_are_reported_not_crashed():
     lib = ana._lib.load()
     rc = lib.anr_composite(None, None, None, 8, None, 4, 64, 1, None, None, None, None, None)
     assert rc == -1 and b"null pointer" in lib.anr_last_error()
+    # every entry point validates before it touches the device: null pointers / bad sizes come back as codes + text
+    calls = {
+        "anr_ray_gen": None, "anr_compact_valid": (None, 8, None, None, None, 0, None),
+        "anr_mlp_forward": (None, 1, None, 8, None, None),
+        "anr_mlp_forward_indexed": (None, 1, None, None, None, 8, None, None),
+        "anr_mlp_forward_rays": (None, 1, None, 8, None, 4, 8, None, None),
+        "anr_mlp_forward_save": (None, 1, None, 8, None, None, None),
+        "anr_mlp_backward": (None, 1, None, None, None, 8, None),
+        "anr_encode": (None, 4, 8, 0, None, None), "anr_encode_backward": (None, 4, None, 8, None, None),
+        "anr_composite_masked": (None, None, None, 8, None, None, 4, 64, 1, None, None, None, None, None),
+        "anr_sample_fine_merge": (None, None, None, 0, 4, 64, 64, None, None, None, None),
+        "anr_sample_fine_merge_u8": (None, None, None, 0, 4, 64, 64, None, None, None, None),
+        "anr_knn": (None, None, 1, 6890, 8, None, None, None),
+        "anr_warp_points_lean": (None, 0, None, 8, None, 4, None, None, None, 1, 6890, 24, 8, 0.2, 1, None, None, None, None,
+                                 None, None, None, None, None, None, None, None, None, 0, None),
+    }
+    for name, args in calls.items():
+        if args is None:
+            continue
+        rc = getattr(lib, name)(*args)
+        assert rc < 0, name
+        assert len(lib.anr_last_error()) > 0, name
+    assert lib.anr_mlp_pack_bytes(7) < 0 and lib.anr_mlp_bwd_pack_bytes(7) < 0 and lib.anr_warp_ws_ints(0, 5) < 0
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ana.ops.points_from_rays(torch.zeros(1, 4, 8), torch.zeros(1, 4, 8))
 
