@@ -16,3 +16,15 @@ def pytest_configure(config):
 def smpl_table():
     from anim_nerf_amd import synthetic
     return synthetic.make_smpl_table(0)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The tests load libanimnerf_hip.so (symbol surface on the CPU, everything on the GPU): build it if this checkout has
+    not been built yet (hipcc cross-compiles gfx950 without a GPU; about 90 s once)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("anr_build", os.path.join(ROOT, "anim-nerf_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.LIB_PATH) and not os.environ.get("ANIMNERF_HIP_LIB"):
+        mod.build()
