@@ -411,6 +411,28 @@ def test_disparity_sampling_and_depth_guided_samples(dev, smpl_table):
         assert a["alphas_fine"].max() > 0.2
 
 
+def test_share_fine_uses_one_network_and_returns_the_fine_triple(dev, smpl_table):
+    """share_fine=True (models/anim_nerf.py:90-95, models/volume_rendering.py:219-224): nerf_fine IS nerf, and the renderer
+    returns only the fine pass under the plain keys."""
+    import anim_nerf_amd as ana
+    g = golden("render_cfg3_warp_gain")
+    torch.manual_seed(int(g["seed"]))
+    m = ana.AnimNeRF(body_model_table=smpl_table, freqs_dir=0, use_view=False, use_unpose=True, use_fine=True,
+                     share_fine=True).eval().to(dev)
+    assert m.nerf_fine is m.nerf
+    with torch.no_grad():
+        m.nerf.sigma.weight.mul_(float(g["gain"]))
+        m.nerf.sigma.bias.mul_(float(g["gain"])).add_(float(np.atleast_1d(g["shift"])[0]))
+        m.set_body_model(_to(tdict(g), dev), _templ(dev))
+        rays = m.convert_to_body_model_space(torch.from_numpy(g["rays_world"]).to(dev))
+        m.clac_ober2cano_transform()
+        shared = ana.VolumeRenderer(n_coarse=16, n_fine=8, share_fine=True)(m, rays)
+        both = ana.VolumeRenderer(n_coarse=16, n_fine=8, share_fine=False)(m, rays)
+    assert set(shared) == {"rgbs", "alphas", "depths"}
+    for k in shared:
+        assert torch.equal(shared[k], both[k + "_fine"]), k
+
+
 def test_generic_model_path_equals_fused_path(dev, smpl_table):
     """VolumeRenderer.forward(model=<any callable>) hands materialised xyz to the model, as the reference does."""
     import anim_nerf_amd as ana
