@@ -218,5 +218,9 @@ class AnimNeRF(nn.Module):
         """xyz[bs,nv,3] -> rgb[bs,nv,3], sigma[bs,nv,1]; sigma = -1e5 outside dis_threshold."""
         bs, nv = xyz.shape[:2]
         pts = self.warped_points(xyz=xyz)
+        if self.use_view:                       # view-dependent colour: the head runs outside the fused kernel (inference)
+            out = self._net(use_fine).eval_points_view(pts, viewdir).view(bs, nv, 4).clone()
+            out[..., 3] = torch.where(pts[:, 3].view(bs, nv) < 1, torch.full_like(out[..., 3], -1e5), out[..., 3])
+            return out[..., :3], out[..., 3:4]
         out = self._net(use_fine).eval_points(pts, only_valid=self.use_unpose and self.query_inside).view(bs, nv, 4)
         return out[..., :3], out[..., 3:4]

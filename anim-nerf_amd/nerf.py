@@ -68,29 +68,60 @@ class NeRF(nn.Module):
         self._pack_cache = {}
 
     # -- weight pack (fragment-ordered copy for the kernel), rebuilt when any parameter changes
-    def _hip_supported(self):
+    def _trunk_supported(self):
         return (self.D == 8 and self.W == 256 and self.freqs_xyz == 10 and list(self.skips) == [4]
-                and not self.use_view and not self.use_normal and self.deformation_dim == 0
-                and self.apperance_dim == 0)
+                and not self.use_normal and self.deformation_dim == 0 and self.apperance_dim == 0)
+
+    def _hip_supported(self):
+        """The whole network in the fused kernel (every shipped config); use_view=True runs its colour head outside."""
+        return self._trunk_supported() and not self.use_view
 
     def weight_pack(self, mode: Optional[str] = None):
-        if not self._hip_supported():
+        if not self._trunk_supported():
             raise NotImplementedError(
-                "HIP MLP covers the shipped configuration: D=8, W=256, freqs_xyz=10, skips=[4], use_view=False, "
-                "no latent codes (configs/**/*.yaml)")
+                "HIP MLP covers D=8, W=256, freqs_xyz=10, skips=[4], no normal input, no latent codes (configs/**/*.yaml)")
         mode_id = ops.MLP_MODES[mode or self.mlp_mode]
         params = {k: v for k, v in self.named_parameters()}
         key = (mode_id, tuple((p.data_ptr(), p._version) for p in params.values()))
         hit = self._pack_cache.get(mode_id)
         if hit is None or hit[0] != key:
+            if self.use_view:       # the kernel's own colour head is not used then: give it the 256 feature columns
+                params = dict(params)
+                params["dir_encoding.0.weight"] = params["dir_encoding.0.weight"][:, :self.W].contiguous()
             hit = (key, ops.mlp_pack(params, mode_id))
             self._pack_cache[mode_id] = hit
         return hit[1], mode_id
+
+    @torch.no_grad()
+    def sigma_and_feature(self, pts: torch.Tensor, mode: Optional[str] = None, chunk: int = 1 << 20):
+        """(sigma[n], xyz_encoding_final[n,256]) of NeRF.get_sigma (models/nerf.py:155-175) from the training-forward
+        kernel, which stores that feature among the saved activations.  Inference only; `chunk` bounds the 4.9 KB per
+        point of saved activations."""
+        pack, mode_id = self.weight_pack(mode)
+        sig, feat = [], []
+        for i in range(0, pts.shape[0], chunk):
+            out, act = ops.mlp_forward_save(pack, mode_id, pts[i:i + chunk].contiguous())
+            sig.append(out[:, 3].clone())
+            feat.append(act[:, 2048:2304].float())
+        return torch.cat(sig), torch.cat(feat)
+
+    @torch.no_grad()
+    def eval_points_view(self, pts: torch.Tensor, viewdir: torch.Tensor, mode: Optional[str] = None) -> torch.Tensor:
+        """use_view=True (the class default of the reference, no shipped config): trunk, sigma and the 256-wide feature in
+        the fused kernel, the view-dependent colour head (models/nerf.py:141-153: [feature, encoding_dir(viewdir)] -> 128 ->
+        3) as two library GEMMs.  -> [n,4] = (r,g,b,sigma).  Inference only."""
+        sig, feat = self.sigma_and_feature(pts, mode)
+        x = torch.cat([feat, self.encoding_dir(viewdir.reshape(-1, 3).float())], -1)
+        rgb = self.rgb(self.dir_encoding(x))
+        return torch.cat([rgb, sig[:, None]], -1)
 
     def eval_points(self, pts: torch.Tensor, mode: Optional[str] = None, sigma_only: bool = False,
                     only_valid: bool = False, valid_list=None) -> torch.Tensor:
         """pts[n,4] = (x,y,z,valid) -> [n,4] = (r,g,b,sigma), or sigma[n] (trunk + sigma row only).  The fused kernel entry.
         only_valid: run the network on the samples with valid >= 1 only; the rest get (0,0,0,-1e5)."""
+        if self.use_view:
+            raise NotImplementedError("use_view=True: call eval_points_view(pts, viewdir) (inference); training with view "
+                                      "dependence is not built")
         if torch.is_grad_enabled() and (pts.requires_grad or any(p.requires_grad for p in self.parameters())):
             from .autograd import PARAM_KEYS, MLPFunction              # training: keep activations, differentiable
             if not self._hip_supported():
@@ -113,13 +144,19 @@ class NeRF(nn.Module):
 
     def forward(self, xyz, viewdir=None, deformation_code=None, apperance_code=None):
         """models/nerf.py:129-153 -> (rgb[...,3], sigma[...,1])."""
-        out = self.eval_points(self._pack_xyz(xyz)).view(*xyz.shape[:-1], 4)
+        if self.use_view:
+            out = self.eval_points_view(self._pack_xyz(xyz), viewdir).view(*xyz.shape[:-1], 4)
+        else:
+            out = self.eval_points(self._pack_xyz(xyz)).view(*xyz.shape[:-1], 4)
         return out[..., :3], out[..., 3:4]
 
     def get_sigma(self, xyz, deformation_code=None, only_sigma=False):
         """models/nerf.py:155-175.  The 256-wide feature is internal to the fused kernel."""
-        if not only_sigma:
-            raise NotImplementedError("get_sigma(only_sigma=False): xyz_encoding_final is not exported by the fused kernel")
+        if not only_sigma:              # (sigma, xyz_encoding_final): inference only
+            sig, feat = self.sigma_and_feature(self._pack_xyz(xyz))
+            return sig.view(*xyz.shape[:-1], 1), feat.view(*xyz.shape[:-1], self.W)
+        if self.use_view:
+            return self.sigma_and_feature(self._pack_xyz(xyz))[0].view(*xyz.shape[:-1], 1)
         return self.eval_points(self._pack_xyz(xyz), sigma_only=True).view(*xyz.shape[:-1], 1)
 
     def _sigma_dense(self, xyz):

@@ -62,7 +62,8 @@ class VolumeRenderer(nn.Module):
         """lean_state (inference with the warp on): dict carrying the coarse pass's canonical points / validity bytes
         and the merge's permutation to the fine pass, which re-visits the coarse samples."""
         bs, R, K = z.shape
-        fused = hasattr(model, "warped_points") and hasattr(model, "_net")
+        # (a view-dependent model goes through the generic branch below: it needs the ray direction per sample)
+        fused = hasattr(model, "warped_points") and hasattr(model, "_net") and not getattr(model, "use_view", False)
         net = model._net(not coarse) if fused else None
         valid = None
         if fused and not model.use_unpose and not (torch.is_grad_enabled() and (

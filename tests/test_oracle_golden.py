@@ -143,3 +143,18 @@ def test_reference_conditioning(smpl_table):
     a, b = render(False), render(True)
     rel = (a["alphas_fine"] - b["alphas_fine"]).abs() / a["alphas_fine"].abs().clamp_min(1e-3)
     assert rel.max() > 1e-4, rel.max()
+
+
+def test_mlp_with_view_direction():
+    """use_view=True (the reference class default): the oracle's view branch against the reference's output, and our
+    host class builds the same seeded weights."""
+    import anim_nerf_amd as ana
+    g = golden("mlp_view")
+    torch.manual_seed(int(g["seed"]))
+    net = ana.NeRF(freqs_xyz=10, freqs_dir=4, use_view=True)
+    chk = float(sum(p.detach().double().abs().sum() for p in net.parameters()))
+    assert abs(chk - float(g["weights_abs_sum"])) < 1e-6 * chk
+    P = {k: v.detach() for k, v in net.named_parameters()}
+    rgb, sig = orc.mlp_forward(P, torch.from_numpy(g["xyz"]), torch.from_numpy(g["viewdir"]), use_view=True)
+    torch.testing.assert_close(rgb, torch.from_numpy(g["rgb"]), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(sig, torch.from_numpy(g["sigma"]), rtol=1e-5, atol=1e-6)
