@@ -75,6 +75,9 @@ class AnimNeRF(nn.Module):
         if use_deformation:
             raise NotImplementedError("use_deformation is False in every shipped config and broken in the reference "
                                       "(models/nerf.py:54)")
+        if unpose_view:
+            raise NotImplementedError("unpose_view=True (view directions rotated into the canonical frame, "
+                                      "models/anim_nerf.py:188-190) is False in every shipped config and not built")
         if k_neigh != 4:
             raise NotImplementedError("the HIP warp kernel is built for k_neigh = 4 (every shipped config)")
 
