@@ -83,12 +83,11 @@ def rescale_camera(cam: dict, img_wh: Tuple[int, int]) -> dict:
 def camera_to_c2w(cam: dict) -> torch.Tensor:
     """datasets/anim_nerf_dataset.py:207-224: world->camera (R, t) in the OpenCV convention -> camera->world [3,4] in the
     OpenGL convention the ray generator expects (flip y and z)."""
-    R_ = np.array([[1., 0., 0.], [0., -1., 0.], [0., 0., -1.]]) @ np.asarray(cam["R"])
-    t_ = np.array([1, -1, -1]) * np.asarray(cam["t"])
-    pose = np.eye(4, dtype=np.float32)
-    pose[:3, :3] = R_.transpose()
-    pose[:3, 3] = R_.transpose() @ -t_
-    return torch.from_numpy(pose[:3, :4]).float()
+    flip = np.diag([1.0, -1.0, -1.0])                       # OpenCV (x right, y down, z forward) -> OpenGL axes
+    rot = (flip @ np.asarray(cam["R"], dtype=np.float64)).T    # camera -> world rotation
+    centre = rot @ -(flip @ np.asarray(cam["t"], dtype=np.float64))
+    c2w = np.concatenate([rot, centre[:, None]], axis=1).astype(np.float32)
+    return torch.from_numpy(c2w)
 
 
 def camera_rays(cam: dict, near: float = 0.1, far: float = 10.0, device=None) -> torch.Tensor:
@@ -174,34 +173,31 @@ def _rank_filter(mask: np.ndarray, k: int, take_max: bool) -> np.ndarray:
 
 def get_pixelcoords(H, W, mask=None, subsampletype="foreground_pixel", subsamplesize=32, fore_rate=0.9, fore_erode=3):
     """datasets/anim_nerf_dataset.py:10-54 -> pixelcoords[n, 2] = (row, col).  Draws from numpy's global generator in the
-    reference's order, so `np.random.seed(s)` reproduces the reference's picks.  'foreground_pixel' (every shipped
-    yaml): fore_rate of the pixels from the eroded mask, the rest from the band between the mask dilated by
-    fore_erode and by 64.  The morphology is restated from cv2's documented semantics (cv2 is not available where
-    this was written: that mode is checked against a brute-force min / max filter, not against cv2 itself)."""
-    def sample(indx, indy, n_pixels):
-        sel = np.random.choice(indx.shape[0], n_pixels, replace=True)
-        return indx[sel], indy[sel]
+    reference's order (one `choice` per pixel pool), so `np.random.seed(s)` reproduces the reference's picks.
+    'foreground_pixel' (every shipped yaml): fore_rate of the patch from the eroded mask, the rest from the band between
+    the mask dilated by fore_erode and by 64.  The morphology is restated from cv2's documented semantics (cv2 is not
+    available where this was written: that mode is checked against a brute-force min / max filter, not against cv2)."""
+    n_patch = subsamplesize * subsamplesize
+
+    def draw(rows, cols, count):                       # with replacement, as the reference does
+        pick = np.random.choice(rows.shape[0], count, replace=True)
+        return rows[pick], cols[pick]
 
     if subsampletype == "pixel":
-        indx, indy = np.meshgrid(np.arange(0, H), np.arange(0, W), indexing="ij")
-        px, py = sample(indx.flatten(), indy.flatten(), subsamplesize * subsamplesize)
-        px, py = px.reshape(subsamplesize, subsamplesize), py.reshape(subsamplesize, subsamplesize)
+        rr, cc = np.meshgrid(np.arange(0, H), np.arange(0, W), indexing="ij")
+        rows, cols = draw(rr.ravel(), cc.ravel(), n_patch)
     elif subsampletype == "foreground_pixel":
         m = np.asarray(mask)
-        if m.ndim == 3:
-            m = m[..., 0]
-        inside = _rank_filter(m, fore_erode, take_max=False)
-        dilate1 = _rank_filter(m, fore_erode, take_max=True)
-        dilate2 = _rank_filter(m, 64, take_max=True)
-        outside = dilate2 - dilate1
-        fore_pixels = int(subsamplesize * subsamplesize * fore_rate)
-        fore_px, fore_py = sample(*np.where(inside > 0), fore_pixels)
-        back_px, back_py = sample(*np.where(outside > 0), subsamplesize * subsamplesize - fore_pixels)
-        px = np.concatenate((fore_px, back_px), axis=0).reshape(subsamplesize, subsamplesize)
-        py = np.concatenate((fore_py, back_py), axis=0).reshape(subsamplesize, subsamplesize)
-    else:
-        px, py = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
-    return np.stack((px, py), axis=-1).reshape(-1, 2)
+        m = m[..., 0] if m.ndim == 3 else m
+        core = _rank_filter(m, fore_erode, take_max=False)
+        band = _rank_filter(m, 64, take_max=True) - _rank_filter(m, fore_erode, take_max=True)
+        n_fore = int(n_patch * fore_rate)
+        fr, fc = draw(*np.where(core > 0), n_fore)
+        br, bc = draw(*np.where(band > 0), n_patch - n_fore)
+        rows, cols = np.concatenate((fr, br)), np.concatenate((fc, bc))
+    else:                                              # every pixel, row-major
+        rows, cols = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    return np.stack((rows.reshape(-1), cols.reshape(-1)), axis=-1)
 
 
 def subsample_training_pixels(rays, rgbs, alphas, coords, subsamplesize=32):
