@@ -51,6 +51,21 @@ def make_rays(c2w: Tensor, H: int, W: int, focal, near: float, far: float, cente
     return torch.cat([o_world, d_world, near * one, far * one], dim=-1)
 
 
+def centred_pixel_directions(H: int, W: int, focal: float) -> Tensor:
+    """utils/ray_utils.py:74-96 (get_ray_directions, the dead twin of pixel_directions): scalar focal,
+    principal point at (W/2, H/2), normalised.  [H,W,3]"""
+    col = torch.linspace(0, W - 1, W)[None, :].expand(H, W)
+    row = torch.linspace(0, H - 1, H)[:, None].expand(H, W)
+    d = torch.stack([(col - W / 2) / focal, -(row - H / 2) / focal, -torch.ones(H, W)], dim=-1)
+    return d / torch.norm(d, dim=-1, keepdim=True)
+
+
+def rotate_directions(directions: Tensor, c2w: Tensor) -> Tuple[Tensor, Tensor]:
+    """utils/ray_utils.py:99-121 (get_rays) -> rays_o[H,W,3], rays_d[H,W,3]."""
+    rays_d = directions @ c2w[:, :3].T
+    return c2w[:, 3].expand(rays_d.shape), rays_d
+
+
 # ---------------------------------------------------------------------------
 # a2  SMPL forward / linear blend skinning
 # ---------------------------------------------------------------------------
@@ -296,12 +311,19 @@ def field_query(P, xyz, st, lbs_weights, use_unpose: bool, dis_threshold: float,
 # a6, a7, a13, a14  sampling + compositing
 # ---------------------------------------------------------------------------
 
-def coarse_depths(rays: Tensor, n_coarse: int) -> Tensor:
-    """models/volume_rendering.py:29-46 with lindisp=True, perturb=0:
-    z_k = near (1 - s_k) + far s_k, s = linspace(0, 1 - 1/Kc, Kc)."""
+def coarse_depths(rays: Tensor, n_coarse: int, t_rand: Optional[Tensor] = None) -> Tensor:
+    """models/volume_rendering.py:29-56 with lindisp=True:
+    z_k = near (1 - s_k) + far s_k, s = linspace(0, 1 - 1/Kc, Kc); with `t_rand` (= perturb * U[0,1), shape of z)
+    the stratified jitter of :48-54 — every depth moves inside [lower mid-point, upper mid-point]."""
     near, far = rays[..., 6:7], rays[..., 7:8]
     s = torch.linspace(0, 1 - 1.0 / n_coarse, n_coarse, dtype=rays.dtype)
-    return near * (1 - s) + far * s
+    z = near * (1 - s) + far * s
+    if t_rand is not None:
+        mids = .5 * (z[..., 1:] + z[..., :-1])
+        upper = torch.cat([mids, z[..., -1:]], -1)
+        lower = torch.cat([z[..., :1], mids], -1)
+        z = lower + (upper - lower) * t_rand
+    return z
 
 
 def composite(rgb: Tensor, sigma: Tensor, z: Tensor, far: Tensor, white_bkgd: bool = True):

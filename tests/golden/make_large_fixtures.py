@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""4,096-ray render fixtures (64 x 64 image, 64 + 64 samples) for BASELINE configs[1] and configs[2], produced by
+RUNNING THE REFERENCE (imported from /root/reference).  Build container only:
+
+    python tests/golden/make_large_fixtures.py
+
+The 144-ray cases of make_fixtures.py are too small to see a 1-2 % tail of rays; these are large enough to count it and
+to classify every ray of it (tests/test_gpu_parity.py::test_every_out_of_tolerance_ray_is_accounted_for).  Stored per
+case: the reference's six outputs, its z_fine and its coarse weights (fp16-free, fp32 as computed); rays, weights and the
+SMPL table are regenerated from seeds on the test side and guarded by checksums.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_fixtures as mf                                        # noqa: E402
+from anim_nerf_amd import synthetic as syn                        # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def main():
+    r_anim, r_vr, r_ds = mf.import_reference()
+    tbl = syn.make_smpl_table(0)
+    tmp = tempfile.mkdtemp(prefix="anr_smpl_")
+    os.makedirs(os.path.join(tmp, "smpl"))
+    tbl.write_pickle(os.path.join(tmp, "smpl", "SMPL_MALE.pkl"))
+
+    def case(name, use_unpose, pose_kind, gain, seed, hw=64, chunk=512):
+        torch.manual_seed(seed)
+        ref = r_anim.AnimNeRF(model_path=tmp, model_type="smpl", gender="male", freqs_xyz=10, freqs_dir=0,
+                              use_view=False, use_unpose=use_unpose, k_neigh=4, use_knn=False, use_fine=True,
+                              share_fine=False, dis_threshold=0.2).eval()
+        with torch.no_grad():
+            probe = torch.rand(1, 4096, 3, generator=torch.Generator().manual_seed(5)) * 1.6 - 0.8
+            shift_c = -gain * ref.nerf(probe)[1].median().item()
+            shift_f = -gain * ref.nerf_fine(probe)[1].median().item()
+        mf.sigma_gain_(ref.nerf, gain, shift_c)
+        mf.sigma_gain_(ref.nerf_fine, gain, shift_f)
+        pose = mf.t(syn.animated_pose_params(seed=3, bs=1) if pose_kind == "animated" else syn.static_pose_params(bs=1))
+        templ = mf.t(syn.template_pose_params())
+        c2w_i, foc_i, cen_i = syn.pinhole_camera(hw, hw)
+        rays = r_ds.gen_rays(torch.from_numpy(c2w_i), hw, hw, foc_i.tolist(), 0.1, 10.0, cen_i.tolist()).view(1, -1, 8)
+        vr = r_vr.VolumeRenderer(n_coarse=64, n_fine=64, n_fine_depth=0, share_fine=False, white_bkgd=True)
+        outs = []
+        with torch.no_grad():
+            ref.set_body_model(pose, templ)
+            rays_b = ref.convert_to_body_model_space(rays)
+            ref.clac_ober2cano_transform()
+            for i in range(0, rays_b.shape[1], chunk):
+                rc = rays_b[:, i:i + chunk]
+                o = dict(vr(ref, rc, perturb=0.0))
+                zc = vr.sample_coarse(rc[..., :8], perturb=0.0)
+                w, _, _, _ = vr.composite(ref, rc, zc, coarse=True, far=True, perturb=0.0)
+                mid = 0.5 * (zc[..., :-1] + zc[..., 1:])
+                o.update(z_fine=vr.sample_fine(mid, w[..., 1:-1].detach(), det=True), weights=w)
+                outs.append(o)
+                print(name, i, flush=True)
+        res = {k: torch.cat([o[k] for o in outs], 1).numpy() for k in outs[0]}
+        np.savez_compressed(
+            os.path.join(mf.OUT, f"render_{name}.npz"), rays_sha=np.array(mf.sha(rays)), rays_body_sha=np.array(mf.sha(rays_b)),
+            n_coarse=64, n_fine=64, use_unpose=use_unpose, pose_kind=pose_kind, gain=gain,
+            shift=np.float64((shift_c, shift_f)), seed=seed, hw=hw, w_coarse=mf.weights_checksum(ref.nerf),
+            w_fine=mf.weights_checksum(ref.nerf_fine), **{f"pose_{k}": v.numpy() for k, v in pose.items()}, **res)
+        print(name, {k: (float(v.min()), float(v.max())) for k, v in res.items()})
+
+    if "--only-small" not in sys.argv:
+        case("cfg2_nowarp_gain_4k", False, "static", 3000.0, 21)
+        case("cfg3_warp_gain_4k", True, "animated", 3000.0, 22)
+    small_cases(r_vr)
+
+
+def small_cases(r_vr):
+    """Branches round 1 left unpinned: the stratified jitter of sample_coarse (models/volume_rendering.py:48-54; the
+    uniforms are torch.rand under a recorded seed) and the dead-twin ray functions (utils/ray_utils.py:74-121)."""
+    import importlib.util
+    g = torch.Generator().manual_seed(31)
+    R = 257
+    rays = torch.zeros(2, R, 8)
+    rays[..., :3] = torch.randn(2, R, 3, generator=g)
+    rays[..., 3:6] = torch.nn.functional.normalize(torch.randn(2, R, 3, generator=g), dim=-1)
+    rays[..., 6] = 1.5 + torch.rand(2, R, generator=g)
+    rays[..., 7] = 3.5 + torch.rand(2, R, generator=g)
+    out = dict(rays=rays.numpy())
+    for kc, perturb, seed in ((64, 1.0, 41), (32, 0.5, 42), (7, 1.0, 43)):
+        vr = r_vr.VolumeRenderer(n_coarse=kc, n_fine=0)
+        torch.manual_seed(seed)
+        out[f"z_{kc}"] = vr.sample_coarse(rays, perturb=perturb).numpy()
+        out[f"cfg_{kc}"] = np.float64([kc, perturb, seed])
+    spec = importlib.util.spec_from_file_location("ref_ray_utils", os.path.join(mf.REF, "utils", "ray_utils.py"))
+    ru = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ru)
+    H, W, focal = 11, 14, 19.5
+    d = ru.get_ray_directions(H, W, focal)
+    c2w = torch.tensor([[0.8, -0.36, 0.48, 0.3], [0.6, 0.48, -0.64, -0.2], [0.0, 0.8, 0.6, 1.5]])
+    ro, rd = ru.get_rays(d, c2w)
+    out.update(twin_H=H, twin_W=W, twin_focal=focal, twin_c2w=c2w.numpy(), twin_dirs=d.numpy(), twin_rays_o=ro.numpy(),
+               twin_rays_d=rd.numpy())
+    np.savez_compressed(os.path.join(mf.OUT, "sampling_twins.npz"), **out)
+    print("sampling_twins written")
+
+
+if __name__ == "__main__":
+    main()

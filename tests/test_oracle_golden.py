@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import golden, net_params, oracle_table, seeded_model, tdict, weights_checksum
+from helpers import golden, net_params, oracle_table, seeded_model, sha, tdict, weights_checksum
 from oracle import animnerf_oracle as orc
 
 from anim_nerf_amd import synthetic as syn
@@ -105,6 +105,50 @@ def test_render_case(smpl_table, case):
         keys += ["rgbs_fine", "alphas_fine", "depths_fine"]
     for k in keys:
         torch.testing.assert_close(out[k], torch.from_numpy(g[k]), rtol=1e-4, atol=1e-5)
+
+
+def test_stratified_jitter_and_dead_twin_rays():
+    """sample_coarse with perturb > 0 (models/volume_rendering.py:48-54) and utils/ray_utils.py:74-121, against the
+    reference's outputs (tests/golden/sampling_twins.npz)."""
+    g = golden("sampling_twins")
+    rays = torch.from_numpy(g["rays"])
+    for kc in (64, 32, 7):
+        _, perturb, seed = g[f"cfg_{kc}"]
+        torch.manual_seed(int(seed))
+        t_rand = float(perturb) * torch.rand(*rays.shape[:2], kc)         # the reference draws torch.rand(z.shape)
+        z = orc.coarse_depths(rays, kc, t_rand)
+        assert torch.equal(z, torch.from_numpy(g[f"z_{kc}"])), kc
+    d = orc.centred_pixel_directions(int(g["twin_H"]), int(g["twin_W"]), float(g["twin_focal"]))
+    assert torch.equal(d, torch.from_numpy(g["twin_dirs"]))
+    ro, rd = orc.rotate_directions(d, torch.from_numpy(g["twin_c2w"]))
+    assert torch.equal(ro, torch.from_numpy(g["twin_rays_o"])) and torch.equal(rd, torch.from_numpy(g["twin_rays_d"]))
+
+
+def big_case_inputs(g):
+    """rays of a 4k fixture: regenerated from the seeded camera, guarded by the checksum of the reference's own rays."""
+    hw = int(g["hw"])
+    c2w, foc, cen = syn.pinhole_camera(hw, hw)
+    rays = orc.make_rays(torch.from_numpy(c2w), hw, hw, foc.tolist(), 0.1, 10.0, cen.tolist()).view(1, -1, 8)
+    assert sha(rays) == str(g["rays_sha"])
+    return rays
+
+
+@pytest.mark.parametrize("case,stride", [("cfg2_nowarp_gain_4k", 4), ("cfg3_warp_gain_4k", 16)])
+def test_render_case_4k(smpl_table, case, stride):
+    """The oracle against the 4,096-ray reference renders (a strided subset, to keep the CPU suite short)."""
+    g = golden("render_" + case)
+    m = seeded_model(smpl_table, g["seed"], g["use_unpose"], g["gain"], g["shift"])
+    assert weights_checksum(m.nerf) == str(g["w_coarse"]) and weights_checksum(m.nerf_fine) == str(g["w_fine"])
+    rays = big_case_inputs(g)
+    sub = torch.arange(0, rays.shape[1], stride)
+    tbl = oracle_table(smpl_table)
+    templ = {k: torch.from_numpy(v) for k, v in syn.template_pose_params().items()}
+    out = orc.render_frame(tbl, net_params(m.nerf), net_params(m.nerf_fine), rays[:, sub], tdict(g), templ, n_coarse=64,
+                           n_fine=64, use_unpose=bool(g["use_unpose"]), chunk=256, knn_chunk=2048)
+    torch.testing.assert_close(out["_weights"], torch.from_numpy(g["weights"])[:, sub], rtol=1e-4, atol=2e-6)
+    torch.testing.assert_close(out["_z_fine"], torch.from_numpy(g["z_fine"])[:, sub], rtol=1e-5, atol=1e-5)
+    for k in ("rgbs", "alphas", "depths", "rgbs_fine", "alphas_fine", "depths_fine"):
+        torch.testing.assert_close(out[k], torch.from_numpy(g[k])[:, sub], rtol=1e-4, atol=1e-5)
 
 
 def test_invariants_K3_K5_K6_K7():
