@@ -193,6 +193,23 @@ extern "C" int anr_mlp_forward_rays(const void* pack, int mode, const float* ray
     }
 }
 
+extern "C" int anr_mlp_forward_rays_steps(const void* pack, int mode, const float* rays, int ray_stride, const float* steps,
+                                          int K, int64_t n, float* out, void* stream) {
+    ANR_REQUIRE(pack && rays && steps && out, ANR_E_BADARG, "anr_mlp_forward_rays_steps: null pointer");
+    ANR_REQUIRE(n > 0 && n < (int64_t)1 << 32 && K > 0 && n % K == 0 && ray_stride >= 8, ANR_E_BADARG,
+                "anr_mlp_forward_rays_steps: n=%lld K=%d stride=%d", (long long)n, K, ray_stride);
+    ANR_REQUIRE((((uintptr_t)pack | (uintptr_t)out) & 15) == 0, ANR_E_ALIGN, "anr_mlp_forward_rays_steps: pack/out must be 16-B aligned");
+    ANR_REQUIRE(!(mode & ANR_MLP_FLAG_SIGMA_ONLY), ANR_E_BADARG, "anr_mlp_forward_rays_steps: rgb + sigma only");
+    hipStream_t st = (hipStream_t)stream;
+    switch (mode & 0xff) {                              // (K < 0 tells the kernel that `pts` is the step table)
+        case ANR_MLP_F32:
+            return launch_mlp<ANR_MLP_F32, true, false, false>(pack, steps, n, out, st, nullptr, nullptr, nullptr, rays, ray_stride, -K);
+        case ANR_MLP_BF16:
+            return launch_mlp<ANR_MLP_BF16_W8, true, false, false>(pack, steps, n, out, st, nullptr, nullptr, nullptr, rays, ray_stride, -K);
+        default: return fail(ANR_E_BADARG, "anr_mlp_forward_rays_steps: unknown mode %d", mode);
+    }
+}
+
 extern "C" int anr_mlp_forward_indexed(const void* pack, int mode, const float* pts, const int32_t* index,
                                        const int32_t* count, int64_t n, float* out, void* stream) {
     ANR_REQUIRE(pack && pts && out, ANR_E_BADARG, "anr_mlp_forward: null pointer");

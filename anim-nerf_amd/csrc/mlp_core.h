@@ -458,8 +458,22 @@ struct Mlp {
                 } else if (rays) {
                     // no warp (use_unpose=False): the sample point is generated here, x = o + z d with the product and
                     // the sum rounded separately like anr_points_from_rays; `pts` is then the depth array z[n]
-                    const float zz = reinterpret_cast<const float*>(pts)[idx];
-                    const float* ry = rays + (int64_t)((uint32_t)idx / (uint32_t)K) * ray_stride;
+                    // K < 0: no depth array either — `pts` is the step table s[|K|] of the deterministic stratified
+                    // depths, z = near' (1 - s) + far' s with the roundings of anr_sample_coarse
+                    const uint32_t Ka = (uint32_t)(K < 0 ? -K : K);
+                    const uint32_t ray = (uint32_t)idx / Ka;
+                    const float* ry = rays + (int64_t)ray * ray_stride;
+                    float zz;
+                    if (K < 0) {
+                        const float sk = reinterpret_cast<const float*>(pts)[(uint32_t)idx - ray * Ka];
+                        float one_minus, lo, hi;
+                        asm("v_sub_f32_e32 %0, 1.0, %1" : "=v"(one_minus) : "v"(sk));
+                        asm("v_mul_f32_e32 %0, %1, %2" : "=v"(lo) : "v"(ry[6]), "v"(one_minus));
+                        asm("v_mul_f32_e32 %0, %1, %2" : "=v"(hi) : "v"(ry[7]), "v"(sk));
+                        zz = lo + hi;
+                    } else {
+                        zz = reinterpret_cast<const float*>(pts)[idx];
+                    }
                     // (the product goes through an asm statement: hipcc would contract it into an fma otherwise)
                     float m[3];
 #pragma unroll

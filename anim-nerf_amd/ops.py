@@ -414,6 +414,20 @@ def mlp_forward_rays(pack: torch.Tensor, mode: int, rays: torch.Tensor, z: torch
     return out
 
 
+def mlp_forward_rays_steps(pack: torch.Tensor, mode: int, rays: torch.Tensor, steps: torch.Tensor) -> torch.Tensor:
+    """As mlp_forward_rays with the deterministic stratified depths z = near' (1 - steps) + far' steps computed in the
+    kernel too: no depth array.  rays[bs,R,>=8], steps[K] -> out[bs*R*K, 4]."""
+    lib = _lib.load()
+    rays, steps = _dev(rays, "rays"), _dev(steps, "steps")
+    K = steps.numel()
+    n = (rays.numel() // rays.shape[-1]) * K
+    out = torch.empty(n, 4, dtype=torch.float32, device=rays.device)
+    with _timed("mlp_forward", n):
+        _lib.check(lib.anr_mlp_forward_rays_steps(_ptr(pack), mode & 0xff, _ptr(rays), rays.shape[-1], _ptr(steps), K, n,
+                                                  _ptr(out), _stream(out)), "anr_mlp_forward_rays_steps")
+    return out
+
+
 def grid_points(N: int, x_range, y_range, z_range, center: torch.Tensor, first: int, count: int) -> torch.Tensor:
     """extract_mesh.py:27-35,152-157: slab [first, first+count) of the flattened N^3 grid -> pts[count,4]."""
     lib = _lib.load()
@@ -506,3 +520,33 @@ def sample_fine_merge(z_coarse, weights, u, want_fine: bool = False, want_perm: 
     if want_perm:
         return (zs, zf, perm) if want_fine else (zs, perm)
     return (zs, zf) if want_fine else zs
+
+
+def composite_sample(rgbs, rays, u, white_bkgd: bool, *, z=None, steps=None, valid=None, want_weights=False,
+                     want_fine=False, want_perm=False):
+    """The coarse pass of an inference render in one launch: composite(rgbs[R,Kc,4]) + importance samples from its
+    weights + merge (models/volume_rendering.py:172-178, :199-207).  Depths: z[R,Kc], or the step table steps[Kc] of the
+    deterministic stratified depths (computed in the kernel).  -> dict(rgb, depth, acc, z_sorted[R,Kc+Kf], weights?,
+    z_fine?, perm? (uint8))."""
+    lib = _lib.load()
+    rgbs, rays, u = _dev(rgbs, "rgbs"), _dev(rays, "rays"), _dev(u, "u")
+    if (z is None) == (steps is None):
+        raise ValueError("composite_sample: exactly one of z / steps")
+    R, Kc = rgbs.shape[0], rgbs.shape[1]
+    Kf = u.shape[-1]
+    per_ray = 1 if u.dim() > 1 else 0
+    dev = rgbs.device
+    new = lambda *shape, dt=torch.float32: torch.empty(*shape, dtype=dt, device=dev)
+    o = dict(rgb=new(R, 3), depth=new(R, 1), acc=new(R, 1), z_sorted=new(R, Kc + Kf))
+    o["weights"] = new(R, Kc) if want_weights else None
+    o["z_fine"] = new(R, Kf) if want_fine else None
+    o["perm"] = new(R, Kc + Kf, dt=torch.uint8) if want_perm else None
+    z = None if z is None else _dev(z, "z")
+    steps = None if steps is None else _dev(steps, "steps")
+    valid = None if valid is None else _dev(valid, "valid", torch.uint8)
+    with _timed("composite_sample", R * (Kc + Kc + Kf)):
+        _lib.check(lib.anr_composite_sample(_ptr(rgbs), _ptr(z), _ptr(steps), _ptr(rays), rays.shape[-1], _ptr(valid), _ptr(u),
+                                            per_ray, R, Kc, Kf, 1 if white_bkgd else 0, _ptr(o["weights"]), _ptr(o["rgb"]),
+                                            _ptr(o["depth"]), _ptr(o["acc"]), _ptr(o["z_fine"]), _ptr(o["z_sorted"]),
+                                            _ptr(o["perm"]), _stream(rgbs)), "anr_composite_sample")
+    return o

@@ -130,10 +130,61 @@ class VolumeRenderer(nn.Module):
         z = z + torch.randn_like(z) * self.depth_std
         return torch.min(torch.max(z, rays[..., 6:7]), rays[..., 7:8])
 
+    # -- inference, deterministic sampling: the lean schedule
+    fuse_coarse_pass = True          # composite + importance sampling + merge of the coarse pass in one launch
+
+    def _lean_inference_ok(self, model, rays, perturb, kwargs):
+        if not (self.fuse_coarse_pass and perturb == 0 and self.lindisp and self.n_fine > 0 and self.n_fine_depth == 0
+                and not kwargs and hasattr(model, "warped_points") and hasattr(model, "_net")
+                and not getattr(model, "use_view", False)):
+            return False
+        if torch.is_grad_enabled() and (rays.requires_grad or any(p.requires_grad for p in model.parameters())):
+            return False
+        return (not model.use_unpose) or (model.evaluate_valid_only and model.skip_far_samples)
+
+    def _forward_inference(self, model, rays):
+        """perturb = 0, no autograd: 5 launches without the warp (MLP, composite+sample, MLP, composite) — the coarse
+        depths are never stored (both consumers compute them from near'/far'), the coarse weights never leave the
+        compositor — and the same schedule around the warp kernels with it.  Same bits as the general path."""
+        bs, R = rays.shape[:2]
+        Kc, K = self.n_coarse, self.n_coarse + self.n_fine
+        steps, u = self._table(rays.device, "steps", Kc), self._table(rays.device, "u", self.n_fine)
+        flat = rays.view(bs * R, -1)
+        net_c, net_f = model._net(False), model._net(True)
+        with torch.no_grad():
+            if not model.use_unpose:
+                pack, mode = net_c.weight_pack()
+                out_c = ops.mlp_forward_rays_steps(pack, mode, rays, steps)
+                cs = ops.composite_sample(out_c.view(bs * R, Kc, 4), flat, u, self.white_bkgd, steps=steps)
+                zs = cs["z_sorted"]
+                out_f = net_f.eval_rays(rays, zs.view(bs, R, K))
+                valid_f = None
+            else:
+                zc = ops.sample_coarse(rays, steps)
+                reuse = getattr(self, "reuse_coarse_warp", True)
+                pts, valid, vindex, vcount = model.warped_points(rays=rays, z=zc.view(bs, R, Kc), skip_far=True, lean=True)
+                out_c = net_c.eval_points(pts, valid_list=(vindex, vcount))
+                cs = ops.composite_sample(out_c.view(bs * R, Kc, 4), flat, u, self.white_bkgd, z=zc, valid=valid.view(bs * R, Kc),
+                                          want_perm=reuse)
+                zs = cs["z_sorted"]
+                pts_f, valid_f, vindex, vcount = model.warped_points(
+                    rays=rays, z=zs.view(bs, R, K), skip_far=True, lean=True, reuse=(pts, valid, cs["perm"]) if reuse else None)
+                out_f = net_f.eval_points(pts_f, valid_list=(vindex, vcount))
+                valid_f = valid_f.view(bs * R, K)
+            _, rgb_f, dep_f, acc_f = ops.composite(out_f.view(bs * R, K, 4), zs, flat, self.white_bkgd, want_weights=False,
+                                                   valid=valid_f)
+        fine = {"rgbs": rgb_f.view(bs, R, 3), "alphas": acc_f.view(bs, R, 1), "depths": dep_f.view(bs, R, 1)}
+        if self.share_fine:
+            return fine
+        return {"rgbs": cs["rgb"].view(bs, R, 3), "alphas": cs["acc"].view(bs, R, 1), "depths": cs["depth"].view(bs, R, 1),
+                "rgbs_fine": fine["rgbs"], "alphas_fine": fine["alphas"], "depths_fine": fine["depths"]}
+
     def forward(self, model, rays, perturb=0., **kwargs):
         """Differentiable w.r.t. the MLP weights when autograd is enabled (sampling itself carries no gradient,
         as in the reference: z_fine is detached, models/volume_rendering.py:200)."""
         rays = rays if rays.is_contiguous() else rays.contiguous()
+        if self._lean_inference_ok(model, rays, perturb, kwargs):
+            return self._forward_inference(model, rays)
         z_coarse = self.sample_coarse(rays, perturb=perturb)
         lean_state = {} if (self.n_fine > 0 and self.n_fine_depth == 0) else None
         w, rgbs, depths, alphas = self._shade(model, rays, z_coarse, True, perturb, self.n_fine > 0, lean_state, **kwargs)

@@ -211,6 +211,10 @@ int anr_mlp_forward(const void* pack, int mode, const float* pts, int64_t n,
  * of anr_points_from_rays + anr_mlp_forward is never written or read.  Same output bits.  n < 2^32, n % K == 0. */
 int anr_mlp_forward_rays(const void* pack, int mode, const float* rays, int ray_stride, const float* z, int K,
                          int64_t n, float* out, void* stream);
+/* ... and no depth array either: the deterministic stratified depths of models/volume_rendering.py:43-44,
+ * z = near' (1 - steps[k]) + far' steps[k] (k = i % K; roundings of anr_sample_coarse), are computed in the kernel too. */
+int anr_mlp_forward_rays_steps(const void* pack, int mode, const float* rays, int ray_stride, const float* steps, int K,
+                               int64_t n, float* out, void* stream);
 int anr_compact_valid(const float* pts, int64_t n, int32_t* index_out, int32_t* count_out,
                       float* fill_out, int fill_cols, void* stream);
 int anr_mlp_forward_indexed(const void* pack, int mode, const float* pts, const int32_t* index,
@@ -295,6 +299,21 @@ int anr_sample_fine_merge(const float* z_coarse, const float* weights, const flo
 int anr_sample_fine_merge_u8(const float* z_coarse, const float* weights, const float* u, int u_per_ray,
                              int64_t R, int Kc, int Kf,
                              float* z_fine_out, float* z_sorted_out, uint8_t* perm_out, void* stream);
+
+
+/* ---- a13 + a14 fused: the coarse pass of an inference render ----------------------------------------------------
+ * models/volume_rendering.py:172-178 (composite of the Kc coarse samples) followed by :199-207 (importance samples from
+ * its weights, cat, sort) in ONE launch: the weights and the coarse depths stay in the wavefront / LDS instead of making
+ * an HBM round trip between anr_composite and anr_sample_fine_merge (bit-identical outputs to that pair).
+ * z_coarse[R*Kc], or NULL: then the coarse depths are the deterministic stratified ones of :43-44,
+ *   z_k = near' (1 - steps[k]) + far' steps[k]  (steps[Kc] = linspace(0, 1 - 1/Kc, Kc), near'/far' = rays[.., 6/7]),
+ *   computed in the kernel with the roundings of anr_sample_coarse (no z array exists at all).
+ * valid[R*Kc] (may be NULL) as in anr_composite_masked.  u as in anr_sample_fine_merge.
+ * weights_out[R*Kc], z_fine_out[R*Kf], perm_out[R*(Kc+Kf)] may be NULL. */
+int anr_composite_sample(const float* rgbs, const float* z_coarse, const float* steps, const float* rays, int stride,
+                         const uint8_t* valid, const float* u, int u_per_ray, int64_t R, int Kc, int Kf,
+                         int white_bkgd, float* weights_out, float* rgb_out, float* depth_out, float* acc_out,
+                         float* z_fine_out, float* z_sorted_out, uint8_t* perm_out, void* stream);
 
 #ifdef __cplusplus
 }
