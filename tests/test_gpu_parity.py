@@ -480,9 +480,11 @@ def test_every_out_of_tolerance_ray_is_accounted_for(dev, smpl_table, case):
     # the cause: fine depths that are not the reference's (beyond rounding), or validity bits that are not the oracle's
     zf_ref = torch.from_numpy(g["z_fine"])[:, bad]
     zs_ref = torch.sort(torch.cat([zc.cpu()[:, bad], zf_ref], -1), -1).values
-    zflip = ((zs.cpu()[:, bad] - zs_ref).abs() > 2e-5).any(-1)[0]
-    print(f"{case}: of {n} rays: {int(zflip.sum())} with a moved fine depth, {int(vflip.sum())} with a flipped "
-          f"validity bit, {int(residual.sum())} still outside 1e-4 of the oracle given the HIP path's depths/validity")
+    zflip = ((zs.cpu()[:, bad] - zs_ref).abs() > 2e-5).any(-1)[0]          # a sample that changed bins
+    zdiff = (zs.cpu()[:, bad] != zs_ref).any(-1)[0]                        # any bit of any depth (warp on: conditioning)
+    print(f"{case}: of {n} rays: {int(zflip.sum())} with a moved fine depth ({int(zdiff.sum())} with depths that are not "
+          f"the reference's bit for bit), {int(vflip.sum())} with a flipped validity bit, {int(residual.sum())} still outside "
+          f"1e-4 of the oracle given the HIP path's depths/validity")
     if not warp:
         assert not residual.any(), "rays that differ from the oracle even with identical sampling decisions: a real bug"
         assert zflip.all(), "out-of-tolerance rays without a discontinuity to blame"
@@ -494,14 +496,38 @@ def test_every_out_of_tolerance_ray_is_accounted_for(dev, smpl_table, case):
     # oracle within 1e-4 on every one of them, and (b) the injected points must be the oracle's up to fp32 rounding.
     rows = torch.nonzero(residual)[:, 0]
     if rows.numel():
-        pts_c = m.warped_points(rays=rays_b, z=zc)[:, :3].view(1, -1, 64, 3).cpu()[:, bad[rows]]
-        pts_f = m.warped_points(rays=rays_b, z=zs)[:, :3].view(1, -1, 128, 3).cpu()[:, bad[rows]]
-        res3, _, dx = residual_of(rows, (pts_c, pts_f))
+        sub = rays_b[:, bad[rows]].contiguous()
+        wargs = (m.knn_index(), m.ober2cano_transform, m.body_model.lbs_weights, 0.2)
+        dbg_c = ana.ops.warp_points(*wargs, rays=sub, z=zc[:, bad[rows]].contiguous(), debug=True)
+        dbg_f = ana.ops.warp_points(*wargs, rays=sub, z=zs[:, bad[rows]].contiguous(), debug=True)
+        res3, _, _ = residual_of(rows, (dbg_c[0][..., :3].cpu(), dbg_f[0][..., :3].cpu()))
+        # (b): sample by sample.  Where the HIP path's canonical point is not the oracle's up to rounding, the reference's
+        # third discontinuity must be in play: a different (tied) neighbour order, or a blend-weight confidence
+        # exp(-|w_k - w_0|_1 / 0.02) within rounding of its 0.9 threshold (models/anim_nerf.py:165-168).
+        moved = blamed = 0
+        worst_plain = 0.0
+        for (pts_h, dist_h, idx_h, _), z_ in ((dbg_c, zc), (dbg_f, zs)):
+            zz = z_.cpu()[:, bad[rows]]
+            rr = rb[:, rows]
+            xyz = (rr[..., None, :3] + zz[..., None] * rr[..., None, 3:6]).reshape(1, -1, 3)
+            xyz_c, valid_o, dbg = orc.warp_to_canonical(xyz, st["verts"], tbl["lbs_weights"], st["ober2cano"], 0.2, chunk=2048)
+            w_n = tbl["lbs_weights"][dbg["idx"]]
+            conf = torch.exp(-(w_n - w_n[..., 0:1, :]).abs().sum(-1) / (2.0 * orc.WEIGHT_STD ** 2))
+            near_threshold = ((conf - 0.9).abs() < 2e-6).any(-1)[0]
+            other_order = (idx_h.cpu().long() != dbg["idx"]).any(-1)[0]
+            assert ((dist_h.cpu() - dbg["dist"]).abs() <= 1e-6 + 1e-5 * dbg["dist"]).all(), "neighbour distances differ"
+            dx = (pts_h[..., :3].cpu() - xyz_c).abs().max(-1).values[0]
+            live = (valid_o[0, :, 0] >= 1) & (pts_h[0, :, 3].cpu() >= 1)
+            big = live & (dx > 5e-6)
+            moved += int(big.sum())
+            blamed += int((big & (near_threshold | other_order)).sum())
+            worst_plain = max(worst_plain, dx[live & ~big].max().item() if (live & ~big).any() else 0.0)
+            assert (big <= (near_threshold | other_order)).all(), "canonical points moved without a tie or a threshold to blame"
         print(f"{case}: the {rows.numel()} remaining rays with the HIP path's canonical points injected as well: "
-              f"{int(res3.sum())} outside 1e-4; max |x_c(HIP) - x_c(oracle)| on them = {dx:.2e}")
+              f"{int(res3.sum())} outside 1e-4; {moved} samples moved by > 5e-6 ({blamed} at a neighbour tie / confidence "
+              f"threshold), the others within {worst_plain:.1e}")
         assert not res3.any(), "MLP / compositing differ from the oracle on identical canonical points: a real bug"
-        assert dx < 5e-6, "canonical points differ from the oracle's by more than fp32 rounding"
-    assert (zflip | vflip | residual).all(), "out-of-tolerance rays without a discontinuity or conditioning to blame"
+    assert (zdiff | vflip | residual).all(), "out-of-tolerance rays without a discontinuity or conditioning to blame"
 
 
 def test_jittered_coarse_depths_and_dead_twin_rays(dev):
