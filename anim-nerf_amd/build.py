@@ -1,6 +1,7 @@
 """Builds libanimnerf_hip.so (gfx950) in-tree with hipcc.  No CPU fallback is ever built."""
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -44,7 +45,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = Non
              "-Wno-unused-value", "-Wno-pass-failed"] + [f"-D{d}" for d in defines] + list(extra_flags)
     tag = ("." + "_".join(defines)) if defines else ""
     if extra_flags:
-        tag += ".x%08x" % (hash(tuple(extra_flags)) & 0xffffffff)
+        tag += ".x" + hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:8]
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", tag + ".o"))

@@ -92,28 +92,37 @@ class NeRF(nn.Module):
             self._pack_cache[mode_id] = hit
         return hit[1], mode_id
 
-    @torch.no_grad()
+    def _refuse_training(self, what):
+        """The view-dependent colour head and the (sigma, feature) query run outside the fused kernels WITHOUT a backward:
+        under autograd they would silently return constants, and an optimiser would train on whatever other loss term
+        still carries a gradient."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(f"{what} is inference-only (no backward is built): call it under torch.no_grad(); "
+                                      "training is built for use_view=False, the setting of every shipped config")
+
     def sigma_and_feature(self, pts: torch.Tensor, mode: Optional[str] = None, chunk: int = 1 << 20):
         """(sigma[n], xyz_encoding_final[n,256]) of NeRF.get_sigma (models/nerf.py:155-175) from the training-forward
         kernel, which stores that feature among the saved activations.  Inference only; `chunk` bounds the 4.9 KB per
         point of saved activations."""
-        pack, mode_id = self.weight_pack(mode)
-        sig, feat = [], []
-        for i in range(0, pts.shape[0], chunk):
-            out, act = ops.mlp_forward_save(pack, mode_id, pts[i:i + chunk].contiguous())
-            sig.append(out[:, 3].clone())
-            feat.append(act[:, 2048:2304].float())
-        return torch.cat(sig), torch.cat(feat)
+        self._refuse_training("get_sigma(only_sigma=False) / the use_view=True forward")
+        with torch.no_grad():
+            pack, mode_id = self.weight_pack(mode)
+            sig, feat = [], []
+            for i in range(0, pts.shape[0], chunk):
+                out, act = ops.mlp_forward_save(pack, mode_id, pts[i:i + chunk].contiguous())
+                sig.append(out[:, 3].clone())
+                feat.append(act[:, 2048:2304].float())
+            return torch.cat(sig), torch.cat(feat)
 
-    @torch.no_grad()
     def eval_points_view(self, pts: torch.Tensor, viewdir: torch.Tensor, mode: Optional[str] = None) -> torch.Tensor:
         """use_view=True (the class default of the reference, no shipped config): trunk, sigma and the 256-wide feature in
         the fused kernel, the view-dependent colour head (models/nerf.py:141-153: [feature, encoding_dir(viewdir)] -> 128 ->
         3) as two library GEMMs.  -> [n,4] = (r,g,b,sigma).  Inference only."""
-        sig, feat = self.sigma_and_feature(pts, mode)
-        x = torch.cat([feat, self.encoding_dir(viewdir.reshape(-1, 3).float())], -1)
-        rgb = self.rgb(self.dir_encoding(x))
-        return torch.cat([rgb, sig[:, None]], -1)
+        sig, feat = self.sigma_and_feature(pts, mode)               # (refuses to run under autograd)
+        with torch.no_grad():
+            x = torch.cat([feat, self.encoding_dir(viewdir.reshape(-1, 3).float())], -1)
+            rgb = self.rgb(self.dir_encoding(x))
+            return torch.cat([rgb, sig[:, None]], -1)
 
     def eval_points(self, pts: torch.Tensor, mode: Optional[str] = None, sigma_only: bool = False,
                     only_valid: bool = False, valid_list=None) -> torch.Tensor:

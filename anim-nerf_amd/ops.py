@@ -19,14 +19,15 @@ MLP_MODES = {"f32": ANR_MLP_F32, "fp32": ANR_MLP_F32, "bf16": ANR_MLP_BF16,
              "bf16_w4": ANR_MLP_BF16 | ANR_MLP_FLAG_W4, "bf16_nodma": ANR_MLP_BF16 | ANR_MLP_FLAG_NO_DMA,
              "f32_nodma": ANR_MLP_F32 | ANR_MLP_FLAG_NO_DMA}
 
-# When set to a list (bench.py does), every launch appends (name, start_event, end_event, units): HIP events
-# recorded on the stream the kernel is launched on, so elapsed_time() is that kernel's device time.
+# When set to a list (bench.py does), every launch appends (name, start_event, end_event, units, bytes): HIP events
+# recorded on the stream the kernel is launched on, so elapsed_time() is that kernel's device time.  `bytes` = what the
+# launch moves through HBM by design (each input read once, each output written once), for the HBM-bound kernels.
 KERNEL_TIMING = None
 
 
 class _timed:
-    def __init__(self, name, units):
-        self.name, self.units = name, units
+    def __init__(self, name, units, nbytes=None):
+        self.name, self.units, self.nbytes = name, units, nbytes
 
     def __enter__(self):
         self.on = KERNEL_TIMING is not None
@@ -38,7 +39,7 @@ class _timed:
     def __exit__(self, *exc):
         if self.on:
             self.e1.record()
-            KERNEL_TIMING.append((self.name, self.e0, self.e1, self.units))
+            KERNEL_TIMING.append((self.name, self.e0, self.e1, self.units, self.nbytes))
         return False
 
 
@@ -47,6 +48,11 @@ def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
         raise RuntimeError(f"{name}: expected a tensor on the GPU (the HIP rendering path has no CPU fallback)")
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.device.index != torch.cuda.current_device():
+        # the library launches on the calling thread's current device (hipLaunchKernelGGL, hipGetDevice): a tensor of
+        # another GPU would be touched through a foreign stream
+        raise RuntimeError(f"{name} lives on cuda:{t.device.index} but the current device is cuda:{torch.cuda.current_device()}: "
+                           "call torch.cuda.set_device (one process per GPU) or wrap the call in torch.cuda.device(...)")
     return t if t.is_contiguous() else t.contiguous()
 
 
@@ -181,7 +187,7 @@ def sample_coarse(rays: torch.Tensor, steps: torch.Tensor, t_rand: Optional[torc
     z = torch.empty(R, K, dtype=torch.float32, device=rays.device)
     if t_rand is not None:
         t_rand = _dev(t_rand, "t_rand")
-    with _timed("sample_coarse", R * K):
+    with _timed("sample_coarse", R * K, R * (8 + 4 * K)):
         _lib.check(lib.anr_sample_coarse(_ptr(rays), stride, _ptr(steps), _ptr(t_rand), R, K, _ptr(z), _stream(z)),
                    "anr_sample_coarse")
     return z
@@ -276,7 +282,7 @@ def points_from_rays(rays: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     K = z.shape[-1]
     n = z.numel()
     pts = torch.empty(n, 4, dtype=torch.float32, device=z.device)
-    with _timed("points_from_rays", n):
+    with _timed("points_from_rays", n, n * 20 + (n // K) * 32):
         _lib.check(lib.anr_points_from_rays(_ptr(rays), rays.shape[-1], _ptr(z), K, n, _ptr(pts), _stream(pts)),
                    "anr_points_from_rays")
     return pts
@@ -361,7 +367,7 @@ def compact_valid(pts: torch.Tensor, fill: Optional[torch.Tensor] = None):
     index = torch.empty(n, dtype=torch.int32, device=pts.device)
     count = torch.empty(1, dtype=torch.int32, device=pts.device)
     cols = 0 if fill is None else (4 if fill.dim() == 2 else 1)
-    with _timed("compact_valid", n):
+    with _timed("compact_valid", n, n * 20):
         _lib.check(lib.anr_compact_valid(_ptr(pts), n, _ptr(index), _ptr(count), _ptr(fill), cols, _stream(pts)),
                    "anr_compact_valid")
     return index, count
@@ -454,7 +460,10 @@ def composite(rgbs, z, rays, white_bkgd: bool, noise=None, want_weights: bool = 
         noise = _dev(noise, "noise")
     if valid is not None:
         valid = _dev(valid, "valid", torch.uint8)
-    with _timed("composite", R * K):
+    moved = R * (K * (20 if valid is None else 5) + 8 + 20 + (4 * K if want_weights else 0))
+    if valid is not None:
+        moved = None                  # rows of invalid samples are skipped: data-dependent, counted by the PMC passes only
+    with _timed("composite", R * K, moved):
         _lib.check(lib.anr_composite_masked(_ptr(rgbs), _ptr(z), _ptr(rays), rays.shape[-1], _ptr(noise), _ptr(valid), R, K,
                                             1 if white_bkgd else 0, _ptr(w), _ptr(rgb), _ptr(depth), _ptr(acc), _stream(z)),
                    "anr_composite")
@@ -514,7 +523,8 @@ def sample_fine_merge(z_coarse, weights, u, want_fine: bool = False, want_perm: 
     zs = torch.empty(R, Kc + Kf, dtype=torch.float32, device=dev)
     perm = torch.empty(R, Kc + Kf, dtype=torch.uint8 if perm_u8 else torch.int32, device=dev) if want_perm else None
     fn = lib.anr_sample_fine_merge_u8 if (want_perm and perm_u8) else lib.anr_sample_fine_merge
-    with _timed("sample_fine_merge", R * (Kc + Kf)):
+    with _timed("sample_fine_merge", R * (Kc + Kf), R * (8 * Kc + 4 * (Kc + Kf) + (4 * Kf if want_fine else 0)
+                                                         + ((Kc + Kf) * (1 if perm_u8 else 4) if want_perm else 0))):
         _lib.check(fn(_ptr(z_coarse), _ptr(weights), _ptr(u), per_ray, R, Kc, Kf, _ptr(zf), _ptr(zs), _ptr(perm),
                       _stream(zs)), "anr_sample_fine_merge")
     if want_perm:
@@ -544,7 +554,11 @@ def composite_sample(rgbs, rays, u, white_bkgd: bool, *, z=None, steps=None, val
     z = None if z is None else _dev(z, "z")
     steps = None if steps is None else _dev(steps, "steps")
     valid = None if valid is None else _dev(valid, "valid", torch.uint8)
-    with _timed("composite_sample", R * (Kc + Kc + Kf)):
+    moved = R * (16 * Kc + (4 * Kc if z is not None else 0) + 8 + 20 + 4 * (Kc + Kf) + (4 * Kc if want_weights else 0)
+                 + (4 * Kf if want_fine else 0) + ((Kc + Kf) if want_perm else 0))
+    if valid is not None:
+        moved = None
+    with _timed("composite_sample", R * (Kc + Kc + Kf), moved):
         _lib.check(lib.anr_composite_sample(_ptr(rgbs), _ptr(z), _ptr(steps), _ptr(rays), rays.shape[-1], _ptr(valid), _ptr(u),
                                             per_ray, R, Kc, Kf, 1 if white_bkgd else 0, _ptr(o["weights"]), _ptr(o["rgb"]),
                                             _ptr(o["depth"]), _ptr(o["acc"]), _ptr(o["z_fine"]), _ptr(o["z_sorted"]),

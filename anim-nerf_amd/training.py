@@ -121,17 +121,90 @@ def compute_loss(anim_nerf, hp: TrainHParams, rgbs, alphas, results, fg_points=N
 
 def allreduce_gradients(params, world: Optional[int] = None):
     """Average gradients over ranks with ONE collective on a flat buffer (DataParallel's reduce_add, train.py:454-455,
-    as an all-reduce).  No-op without a process group."""
+    as an all-reduce).  The buffer covers EVERY parameter of the list, in list order, whether or not this rank produced
+    a gradient for it (a rank whose rays all miss the body has none: it contributes zeros and receives the average), so
+    all ranks issue the same collective.  No-op without a process group."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
-    grads = [p.grad for p in params if p.grad is not None]
+    params = list(params)
+    grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
     flat = torch._utils._flatten_dense_tensors(grads)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat.div_(world or dist.get_world_size())
-    for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-        g.copy_(f)
+    for p, g, f in zip(params, grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+        if p.grad is None:
+            p.grad = f.clone()
+        else:
+            g.copy_(f)
     return flat.numel()
+
+
+class GradientReducer:
+    """Bucketed gradient averaging overlapped with the backward pass (what Lightning's `strategy='dp'` does with a
+    per-step broadcast + reduce_add, config.py:77 / train.py:451-458, as RCCL all-reduces over xGMI).
+
+    * `buckets`: lists of parameters, in the order their gradients complete during backward (fine network first).  Each
+      bucket owns one flat fp32 buffer; `p.grad` of its parameters are VIEWS into it, so autograd accumulates straight into
+      the send buffer and nothing is copied before or after the collective.
+    * a post-accumulate hook per parameter counts arrivals; a full bucket is all-reduced asynchronously (RCCL runs on its
+      own stream) while autograd keeps going.  Buckets are always issued in list order, and `finish()` issues whatever is
+      left — a rank that produced no gradient at all (every ray missed the body) still joins every collective, with zeros.
+    * xGMI is point-to-point: a ring all-reduce of a 2.4 MB bucket is latency-bound (tens of microseconds), so two or three
+      buckets are the useful granularity here, not DDP's 25 MB.
+    """
+
+    def __init__(self, buckets, world: Optional[int] = None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = world or (dist.get_world_size() if self.active else 1)
+        self.buckets = [list(b) for b in buckets if len(b)]
+        self.flat, self.slot = [], {}                         # slot[p] = (bucket index, p's view into the bucket's buffer)
+        for bi, b in enumerate(self.buckets):
+            flat = torch.zeros(sum(p.numel() for p in b), dtype=b[0].dtype, device=b[0].device)
+            o = 0
+            for p in b:
+                self.slot[p] = (bi, flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
+            self.flat.append(flat)
+        if self.active:
+            for p in self.slot:
+                p.register_post_accumulate_grad_hook(self._arrived)
+        self._pending, self._next, self._handles = [], 0, []
+
+    def prepare(self):
+        """Before backward: zero the send buffers and point every p.grad at its slice."""
+        self._pending = [len(b) for b in self.buckets]
+        self._next, self._handles = 0, []
+        for flat in self.flat:
+            flat.zero_()
+        for p, (_, view) in self.slot.items():
+            p.grad = view
+
+    def _issue_ready(self, force=False):
+        while self._next < len(self.buckets) and (force or self._pending[self._next] == 0):
+            self._handles.append(self.dist.all_reduce(self.flat[self._next], op=self.dist.ReduceOp.SUM, async_op=True))
+            self._next += 1
+
+    def _arrived(self, p):
+        bi, view = self.slot[p]
+        if p.grad is not view:                                # a caller reset .grad after prepare(): move the value in
+            view.copy_(p.grad)
+            p.grad = view
+        self._pending[bi] -= 1
+        self._issue_ready()
+
+    def finish(self):
+        """After backward: issue what is left (in order), wait, average.  Returns the number of floats reduced."""
+        if not self.active:
+            return 0
+        self._issue_ready(force=True)
+        for h in self._handles:
+            h.wait()
+        for flat in self.flat:
+            flat.div_(self.world)
+        return sum(f.numel() for f in self.flat)
 
 
 class Trainer:
@@ -152,19 +225,29 @@ class Trainer:
         self.optimizer = torch.optim.Adam(groups, eps=1e-8, weight_decay=0)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(
             self.optimizer, lambda epoch: (1 - epoch / hp.max_epochs) ** hp.poly_exp)
+        # gradient buckets in the order backward completes them: fine network, coarse network, SMPL parameter rows
+        fine = [p for p in getattr(anim_nerf, "nerf_fine", anim_nerf.nerf).parameters() if p.requires_grad]
+        fine_ids = {id(p) for p in fine}
+        coarse = [p for p in anim_nerf.nerf.parameters() if p.requires_grad and id(p) not in fine_ids]
+        seen = fine_ids | {id(p) for p in coarse}
+        rest = [p for p in self.params if id(p) not in seen]
+        self.reducer = GradientReducer([fine, coarse + rest])
 
     def step(self, rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points=None, bg_points=None,
              perturb=1.0, frame_idx=None):
         """`body_model_params` is the dict of the batch, or — with a BodyModelParams table and `frame_idx` — replaced
         by the learnable rows of those frames (train.py:330-331)."""
-        self.optimizer.zero_grad(set_to_none=True)
+        if self.reducer.active:
+            self.reducer.prepare()                            # grads are views into the (zeroed) send buffers
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
         if self.body_model_params is not None and frame_idx is not None:
             body_model_params = self.body_model_params(frame_idx)
         results = system_forward(self.renderer, self.model, rays, body_model_params, body_model_params_template,
                                  perturb=perturb, chunk=self.hp.chunk)
         loss, details = compute_loss(self.model, self.hp, rgbs, alphas, results, fg_points, bg_points)
-        loss.backward()
-        allreduce_gradients(self.params)
+        loss.backward()                                       # full buckets are all-reduced while this is still running
+        self.reducer.finish()
         self.optimizer.step()
         with torch.no_grad():
             key = "rgbs_fine" if "rgbs_fine" in results else "rgbs"

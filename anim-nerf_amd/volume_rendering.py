@@ -187,7 +187,10 @@ class VolumeRenderer(nn.Module):
             return self._forward_inference(model, rays)
         z_coarse = self.sample_coarse(rays, perturb=perturb)
         lean_state = {} if (self.n_fine > 0 and self.n_fine_depth == 0) else None
-        w, rgbs, depths, alphas = self._shade(model, rays, z_coarse, True, perturb, self.n_fine > 0, lean_state, **kwargs)
+        # share_fine: the coarse composite only feeds the sampler and is dropped from the result — no graph, no saved
+        # activations (models/volume_rendering.py:168-178 runs it under no_grad too)
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not (self.share_fine and self.n_fine > 0)):
+            w, rgbs, depths, alphas = self._shade(model, rays, z_coarse, True, perturb, self.n_fine > 0, lean_state, **kwargs)
         output = {"rgbs": rgbs, "alphas": alphas, "depths": depths}
         if self.n_fine > 0 or self.n_fine_depth > 0:
             if self.n_fine_depth > 0:

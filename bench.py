@@ -7,15 +7,18 @@
 
 One step = one full 1024 x 1024 frame per GPU through the whole path (per-frame SMPL state, rays to
 the body frame, 64 coarse samples -> coarse net -> composite -> 64 importance samples -> fine net on
-all 128 sorted samples -> composite).  Workload = BASELINE.json configs[1] (no LBS warp) by default,
-`--workload cfg3` adds the inverse-LBS / 4-NN warp.  Rays are resident in HBM before the timed region.
-Ranks render independent frames (no data-path collective): weak scaling.
+all 128 sorted samples -> composite).  The headline line is BASELINE.json configs[1] (no LBS warp) in bf16;
+rays are resident in HBM before the timed region.  Ranks render independent frames (no data-path collective):
+weak scaling; `--scaling strong` slices ONE frame's rays over the ranks instead (per-frame setup replicated).
 
+The same JSON line also carries, each with its own warm-up and timed region (`--no-extras` skips them):
+  "modes"     : {"f32": ...}                   the parity-grade arithmetic on the same workload
+  "workloads" : {"cfg3", "cfg3_dense", "cfg4", "cfg5", "cfg2_strong"}   BASELINE configs[2], [3], [4]; strong scaling of [1]
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import math
 import json
+import math
 import os
 import sys
 import time
@@ -27,8 +30,9 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 MLP_FLOP_PER_POINT = 1_179_904          # 589,952 MACs, full rgb + sigma evaluation
-PEAK_BF16_TFLOPS = 2500.0               # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-PEAK_F32_TFLOPS = 157.3                 # f32-input MFMA = fp32 vector peak
+MLP_FLOP_SIGMA_ONLY = 982_528           # trunk + sigma row
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}    # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
 
 
 def _psnr(a, b):
@@ -44,6 +48,8 @@ def parse():
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="cfg2/cfg3: BASELINE configs[1]/[2] (inference); cfg4: configs[3] training step (64+32, 32x32 rays per frame); "
                          "cfg5: configs[4] 512^3 sigma grid, voxel-sharded")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="cfg2/cfg3 at N > 1: weak = one frame per GPU; strong = one frame's rays sliced over the GPUs")
     ap.add_argument("--frames-per-gpu", type=int, default=16, help="cfg4: frames (of 1024 rays) per step per GPU")
     ap.add_argument("--mode", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--hw", type=int, default=1024)
@@ -55,154 +61,163 @@ def parse():
     ap.add_argument("--sigma-gain", type=float, default=3000.0,
                     help="scale the sigma heads about their median (0 = literal random init, which renders a blank image)")
     ap.add_argument("--no-psnr", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no modes / workloads objects)")
     ap.add_argument("--dense", action="store_true",
                     help="cfg3/cfg4: run the MLP on every sample as the reference does, also on those outside dis_threshold "
                          "(sigma = -1e5, composite weight 0); default: only on the valid ones — same image, bit for bit")
     return ap.parse_args()
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+class Ctx:
+    """process-group plumbing shared by every timed region"""
 
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run "
+                             f"--nproc-per-node {args.gpus}")
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("nccl", device_id=self.dev)        # "nccl" = RCCL over xGMI on ROCm
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier(device_ids=[self.local_rank])
+        torch.cuda.synchronize(self.dev)
+
+    def timed(self, step, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks.
+        -> (seconds, per-kernel HIP-event records, last output)"""
+        import anim_nerf_amd as ana
+        from anim_nerf_amd import ops
+        out = None
+        for _ in range(warmup):
+            out = step()
+        self.barrier()
+        ops.KERNEL_TIMING = []                            # (name, start_event, end_event, units, bytes) per launch
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
+        per_kernel = {}
+        for name, e0, e1, units, nbytes in timing:
+            d = per_kernel.setdefault(name, {"s": 0.0, "units": 0, "launches": 0, "bytes": 0})
+            d["s"] += e0.elapsed_time(e1) * 1e-3
+            d["units"] += int(units)                      # (a device counter where the MLP ran on a compacted list)
+            d["launches"] += 1
+            d["bytes"] += int(nbytes or 0)
+        return ana.max_over_ranks(elapsed, self.dev), per_kernel, out
+
+
+def mlp_roofline(per_kernel, key, mode, flop_per_point, label):
+    k = per_kernel.get(key, {"s": 0.0, "units": 0, "launches": 0})
+    achieved = (k["units"] * flop_per_point / k["s"] / 1e12) if k["s"] > 0 else 0.0
+    return {"kernel": label, "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[mode], "unit": "TFLOP/s",
+            "frac": achieved / PEAK_TFLOPS[mode], "traffic": None, "launches": k["launches"],
+            "avg_launch_ms": (k["s"] / k["launches"] * 1e3) if k["launches"] else None, "flop_per_point": flop_per_point,
+            "points": k["units"]}
+
+
+def rescale_sigma(model, gain, mode, dev):
+    """random-init sigma is ~0.017 +- 0.003 (one sign everywhere): every ray renders white or saturates on the far sample.
+    Spread it about its median so that compositing, importance sampling and the PSNR mean something.  Same FLOPs, same
+    kernels; only the numbers in the sigma row change."""
+    if gain <= 0:
+        return
+    g = torch.Generator().manual_seed(5)
+    probe = (torch.rand(1, 4096, 3, generator=g) * 1.6 - 0.8).to(dev)
+    with torch.no_grad():
+        for net in (model.nerf, model.nerf_fine):
+            net.mlp_mode = "f32"
+            med = net(probe)[1].median().item()
+            net.mlp_mode = mode
+            net.sigma.weight.mul_(gain)
+            net.sigma.bias.mul_(gain).add_(-gain * med)
+
+
+def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling="weak", checks=False):
+    """BASELINE configs[1] / configs[2]: a full frame per step."""
     import anim_nerf_amd as ana
-    from anim_nerf_amd import ops, synthetic as syn
-
-    ana._lib.load()                                   # fails loudly if the HIP library is missing
-    if args.workload == "cfg4":
-        return train_bench(args, rank, local_rank, world, dev)
-    if args.workload == "cfg5":
-        return grid_bench(args, rank, local_rank, world, dev)
-    use_warp = args.workload == "cfg3"
+    from anim_nerf_amd import synthetic as syn
+    dev, rank, world = ctx.dev, ctx.rank, ctx.world
     tbl = syn.make_smpl_table(0)
     torch.manual_seed(0)
     model = ana.AnimNeRF(body_model_table=tbl, freqs_dir=0, use_view=False, use_unpose=use_warp, use_knn=True,
-                         use_fine=True, mlp_mode=args.mode).eval().to(dev)
-    if args.sigma_gain > 0:
-        # random-init sigma is ~0.017 +- 0.003 (one sign everywhere): every ray renders white or saturates on the far
-        # sample.  Spread it about its median so that compositing, importance sampling and the PSNR mean something.
-        # Same FLOPs, same kernels; only the numbers in the sigma row change.
-        g = torch.Generator().manual_seed(5)
-        probe = (torch.rand(1, 4096, 3, generator=g) * 1.6 - 0.8).to(dev)
-        with torch.no_grad():
-            for net in (model.nerf, model.nerf_fine):
-                net.mlp_mode = "f32"
-                med = net(probe)[1].median().item()
-                net.mlp_mode = args.mode
-                net.sigma.weight.mul_(args.sigma_gain)
-                net.sigma.bias.mul_(args.sigma_gain).add_(-args.sigma_gain * med)
-    model.skip_invalid_samples = not args.dense
+                         use_fine=True, mlp_mode=mode).eval().to(dev)
+    rescale_sigma(model, args.sigma_gain, mode, dev)
+    model.skip_invalid_samples = not dense
     vr = ana.VolumeRenderer(n_coarse=args.n_coarse, n_fine=args.n_fine, white_bkgd=True)
     H = W = args.hw
     c2w, focal, cen = syn.pinhole_camera(H, W)
-    # each rank renders its own frame: same camera, rank-seeded pose for the warp workload
-    pose_np = syn.animated_pose_params(seed=100 + rank) if use_warp else syn.static_pose_params()
+    strong = scaling == "strong" and world > 1
+    # weak: each rank renders its own frame (same camera, rank-seeded pose for the warp workload);
+    # strong: every rank sets up the SAME frame and renders its contiguous slice of the rays
+    pose_np = syn.animated_pose_params(seed=100 + (0 if strong else rank)) if use_warp else syn.static_pose_params()
     pose = {k: torch.from_numpy(v).to(dev) for k, v in pose_np.items()}
     templ = {k: torch.from_numpy(v).to(dev) for k, v in syn.template_pose_params().items()}
     rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), H, W, focal.tolist(), 0.1, 10.0, cen.tolist()).view(1, -1, 8)
+    n_frame = rays.shape[1]
+    if strong:
+        lo, hi = ana.shard_range(n_frame, rank, world)
+        rays = rays[:, lo:hi].contiguous()
     n_rays = rays.shape[1]
 
     def step():
         return ana.batched_inference(vr, model, rays, pose, templ, chunk=args.chunk)
 
-    def barrier():
-        if world > 1:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    ops.KERNEL_TIMING = []                            # (name, start_event, end_event, units) per launch
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
-    elapsed = ana.max_over_ranks(elapsed, dev)
-
-    # ---- dominant kernel: fused MLP; HIP events were recorded on the launch stream inside the timed region
-    per_kernel = {}
-    for name, e0, e1, units in timing:
-        d = per_kernel.setdefault(name, [0.0, 0, 0])
-        d[0] += e0.elapsed_time(e1) * 1e-3
-        d[1] += int(units)                            # (a device counter where the MLP ran on a compacted list)
-        d[2] += 1
-    mlp_s, mlp_pts, mlp_launches = per_kernel.get("mlp_forward", [0.0, 0, 0])
-    peak = PEAK_BF16_TFLOPS if args.mode == "bf16" else PEAK_F32_TFLOPS
-    achieved = (mlp_pts * MLP_FLOP_PER_POINT / mlp_s / 1e12) if mlp_s > 0 else 0.0
-    kernel_share = {k: round(v[0] / elapsed * 1.0, 4) for k, v in per_kernel.items()}
-
-    # HBM bytes per launch of the MLP kernel: bytes per point measured with rocprofv3 PMC passes (FETCH_SIZE and
-    # WRITE_SIZE in separate runs, gfx950 correction applied; profiles/r01/mlp_hbm_traffic.json) x points per launch
-    traffic = None
-    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "mlp_hbm_traffic.json")
-    if args.mode == "bf16" and mlp_launches and os.path.exists(tf):
-        with open(tf) as fh:
-            traffic = json.load(fh)["bytes_per_point_indexed" if model.evaluate_valid_only else
-                                    "bytes_per_point_explicit" if use_warp else "bytes_per_point"] * mlp_pts / mlp_launches
-
+    elapsed, per_kernel, out = ctx.timed(step, steps, warmup)
+    total_rays = (n_frame if strong else n_frame * world) * steps
+    evals = args.n_coarse + (args.n_coarse + args.n_fine if args.n_fine else 0)
+    mlp = per_kernel.get("mlp_forward", {"units": 0})
     result = {
-        "metric": "rays/sec (64+64 samples, 256-wide MLP)",
-        "value": n_rays * args.steps * world / elapsed,
-        "unit": "rays/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": args.mode,
-        "data": "synthetic",
+        "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "scaling": "strong" if strong else "weak", "dtype": mode,
         "config": {
             "workload": ("BASELINE configs[1]: 1024x1024 render, 64 coarse + 64 fine, random-init 8x256 MLP x2"
                          + (" (sigma rows rescaled about their median)" if args.sigma_gain > 0 else "")
                          + ", fixed SMPL pose, no LBS warp" if not use_warp else
                          "BASELINE configs[2]: configs[1] + inverse-LBS / exact 4-NN canonical warp (V=6890, animated pose)"),
-            "rays_per_step_per_gpu": n_rays, "n_coarse": args.n_coarse, "n_fine": args.n_fine,
-            "mlp_evals_per_ray": args.n_coarse + (args.n_coarse + args.n_fine if args.n_fine else 0),
-            "chunk_rays": args.chunk, "sharding": f"{world} independent frames (ray-parallel, no collective)",
+            "rays_per_step_per_gpu": n_rays, "n_coarse": args.n_coarse, "n_fine": args.n_fine, "mlp_evals_per_ray": evals,
+            "chunk_rays": args.chunk,
+            "sharding": (f"one frame's rays sliced over {world} GPUs (per-frame setup replicated, no collective)" if strong
+                         else f"{world} independent frames (ray-parallel, no collective)"),
             # warp on: samples farther than dis_threshold from the body are sigma = -1e5 / weight 0 whatever the MLP
-            # says; the MLP runs on the others only (identical image; --dense evaluates all of them like the reference)
+            # says; the MLP runs on the others only (identical image; dense evaluates all of them like the reference)
             "mlp_on_valid_samples_only": bool(model.evaluate_valid_only),
-            "mlp_points_per_step": mlp_pts // max(args.steps, 1),
+            "mlp_points_per_step": mlp["units"] // max(steps, 1),
         },
-        "roofline": {
-            "kernel": f"mlp_kernel<{args.mode}> (fused Fourier encoding + 11 GEMMs)",
-            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (PMC, profiles/r01/mlp_hbm_traffic.json: 20.6 B per point measured on the no-warp path / 20 algorithmic; 40.1 / 36 per evaluated point with the warp on)",
-            "launches": mlp_launches, "avg_launch_ms": (mlp_s / mlp_launches * 1e3) if mlp_launches else None,
-            "flop_per_point": MLP_FLOP_PER_POINT,
-        },
-        "kernel_time_share": kernel_share,
+        "roofline": mlp_roofline(per_kernel, "mlp_forward", mode, MLP_FLOP_PER_POINT,
+                                 f"mlp_kernel<{mode}> (fused Fourier encoding + 11 GEMMs)"),
+        "kernel_time_share": {k: round(v["s"] / elapsed, 4) for k, v in per_kernel.items()},
     }
-    # everything around the MLP (sampling, point generation / warp, compaction, compositing,
-    # importance sampling) against the HBM roofline on its COMPULSORY bytes: 52 B per ray + 36 B per sample
-    # (z 4 B, canonical point 16 B, rgb-sigma 16 B).  With the warp on the binding resource is VALU issue (exact KNN),
-    # so the HBM fraction there is a lower bound on how far those kernels are from their own limit.
-    other_s = sum(v[0] for k, v in per_kernel.items() if k != "mlp_forward")
-    evals = args.n_coarse + (args.n_coarse + args.n_fine if args.n_fine else 0)
-    comp_bytes = n_rays * args.steps * (52 + 36 * evals)
+    # Everything around the MLP (sampling, point generation / warp, compaction, compositing, importance sampling) against
+    # the HBM roofline.  `achieved` = the bytes those launches move BY DESIGN (every input read once, every output written
+    # once: what each wrapper in ops.py declares) / their summed HIP-event time; SURVEY.md section 8(d)'s compulsory figure
+    # (52 B per ray + 36 B per sample, which counts a 16-B canonical point per sample even where no kernel moves one) is
+    # kept beside it.  With the warp on the binding resource is VALU issue (exact KNN), not HBM.
+    others = {k: v for k, v in per_kernel.items() if k != "mlp_forward"}
+    other_s = sum(v["s"] for v in others.values())
+    moved = sum(v["bytes"] for v in others.values())
+    comp_bytes = n_rays * steps * (52 + 36 * evals)
     result["roofline_hbm_kernels"] = {
-        "kernels": sorted(k for k in per_kernel if k != "mlp_forward"), "bound": "hbm" if not use_warp else "valu (exact 4-NN)",
-        "achieved": comp_bytes / other_s / 1e9 if other_s > 0 else None, "peak": 8000.0, "unit": "GB/s",
-        "frac": comp_bytes / other_s / 8e12 if other_s > 0 else None, "compulsory_bytes_per_ray": 52 + 36 * evals,
-        "ms_per_step": other_s / args.steps * 1e3,
+        "kernels": {k: {"ms_per_step": v["s"] / steps * 1e3, "GB/s": (v["bytes"] / v["s"] / 1e9) if v["s"] > 0 and v["bytes"] else None}
+                    for k, v in sorted(others.items())},
+        "bound": "hbm" if not use_warp else "valu (exact 4-NN)",
+        "achieved": moved / other_s / 1e9 if other_s > 0 else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+        "frac": moved / other_s / (PEAK_HBM_GBS * 1e9) if other_s > 0 else None,
+        "bytes_per_ray_by_design": moved / max(n_rays * steps, 1),
+        "survey_compulsory_bytes_per_ray": 52 + 36 * evals,
+        "frac_on_survey_compulsory_bytes": comp_bytes / other_s / (PEAK_HBM_GBS * 1e9) if other_s > 0 else None,
+        "ms_per_step": other_s / steps * 1e3,
     }
-
-    if rank == 0 and world == 1:
+    if checks and rank == 0 and world == 1:
         if not args.no_psnr:
             # PSNR of this mode's image vs the fp32 parity path (pinned to the reference) on a centre crop
             c = min(256, H)
@@ -212,51 +227,44 @@ def main():
                 net.mlp_mode = "f32"
             ref = ana.batched_inference(vr, model, rays[:, idx].contiguous(), pose, templ, chunk=1 << 16)
             for net in (model.nerf, model.nerf_fine):
-                net.mlp_mode = args.mode
+                net.mlp_mode = mode
             result["psnr_vs_fp32_path_db"] = _psnr(out["rgbs_fine"][:, idx].cpu(), ref["rgbs_fine"].cpu())
         if args.cpu_rays > 0:
             result["cpu_baseline"], pick, ref = cpu_baseline(args, tbl, model, rays, pose_np, use_warp)
             # the oracle's output as the checker: the same rays through the HIP path (fp32 parity mode and the benchmarked mode)
             sub = rays[:, pick.to(dev)].contiguous()
             key = "rgbs_fine" if args.n_fine else "rgbs"
-            check = {"rays": int(pick.numel())}
-            for mode in dict.fromkeys(("f32", args.mode)):
+            check = {"rays": int(pick.numel()),
+                     "note": "rays outside 1e-4 in f32 mode are accounted for one by one in tests/test_gpu_parity.py::"
+                             "test_every_out_of_tolerance_ray_is_accounted_for (the reference's `denom < eps` branch of the "
+                             "inverse cdf moves a fine sample by up to a bin on the last ulp of the coarse weights)"}
+            for m in dict.fromkeys(("f32", mode)):
                 for net in (model.nerf, model.nerf_fine):
-                    net.mlp_mode = mode
+                    net.mlp_mode = m
                 got = ana.batched_inference(vr, model, sub, pose, templ, chunk=1 << 16)[key].cpu()
                 err = (got - ref[key]).abs().max(-1).values / ref[key].abs().max(-1).values.clamp_min(1e-3)
-                check[mode] = {"max_rel_err_rgb": err.max().item(), "rays_within_1e-4": (err <= 1e-4).float().mean().item(),
-                               "psnr_db": _psnr(got, ref[key])}
+                check[m] = {"max_rel_err_rgb": err.max().item(), "rays_within_1e-4": (err <= 1e-4).float().mean().item(),
+                            "psnr_db": _psnr(got, ref[key])}
             for net in (model.nerf, model.nerf_fine):
-                net.mlp_mode = args.mode
+                net.mlp_mode = mode
             result["oracle_check"] = check
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    return result
 
 
-def grid_bench(args, rank, local_rank, world, dev):
+def grid_bench(args, ctx, mode, steps, warmup, dense=False):
     """BASELINE configs[4]: relu(sigma) of the fine field on a 512^3 grid around the posed body (extract_mesh.py:152-158),
     voxel-sharded: rank r evaluates slab r of the SAME grid (strong scaling), no collective on the data path."""
-    import torch.distributed as dist
     import anim_nerf_amd as ana
-    from anim_nerf_amd import ops, synthetic as syn
+    from anim_nerf_amd import synthetic as syn
+    dev, rank, world = ctx.dev, ctx.rank, ctx.world
     N = 512
     tbl = syn.make_smpl_table(0)
     torch.manual_seed(0)
     model = ana.AnimNeRF(body_model_table=tbl, freqs_dir=0, use_view=False, use_unpose=True, use_knn=True,
-                         use_fine=True, mlp_mode=args.mode).eval().to(dev)
-    g = torch.Generator().manual_seed(5)
-    probe = (torch.rand(1, 4096, 3, generator=g) * 1.6 - 0.8).to(dev)
+                         use_fine=True, mlp_mode=mode).eval().to(dev)
+    rescale_sigma(model, args.sigma_gain or 1.0, mode, dev)
     with torch.no_grad():
-        for net in (model.nerf, model.nerf_fine):
-            net.mlp_mode = "f32"
-            med = net(probe)[1].median().item()
-            net.mlp_mode = args.mode
-            net.sigma.weight.mul_(args.sigma_gain or 1.0)
-            net.sigma.bias.mul_(args.sigma_gain or 1.0).add_(-(args.sigma_gain or 1.0) * med)
-        model.skip_invalid_samples = not args.dense
+        model.skip_invalid_samples = not dense
         pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=100).items()}
         templ = {k: torch.from_numpy(v).to(dev) for k, v in syn.template_pose_params().items()}
         rays = torch.zeros(1, 1, 8, device=dev)
@@ -267,54 +275,31 @@ def grid_bench(args, rank, local_rank, world, dev):
 
         def step():
             return ana.sigma_grid(model, N, chunk=1 << 25, rank=rank, world=world)
-
-        def barrier():
-            if world > 1:
-                dist.barrier(device_ids=[local_rank])
-            torch.cuda.synchronize(dev)
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        ops.KERNEL_TIMING = []
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            sig, _ = step()
-        barrier()
-        elapsed = ana.max_over_ranks(time.perf_counter() - t0, dev)
-        timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
-    mlp_s = sum(e0.elapsed_time(e1) for n, e0, e1, u in timing if n == "mlp_forward") * 1e-3
-    mlp_pts = sum(int(u) for n, e0, e1, u in timing if n == "mlp_forward")
-    peak = PEAK_BF16_TFLOPS if args.mode == "bf16" else PEAK_F32_TFLOPS
-    flop = 982_528                                            # sigma-only: trunk + sigma row
-    achieved = mlp_pts * flop / mlp_s / 1e12 if mlp_s else 0.0
-    result = {
-        "metric": "grid points/sec, 512^3 sigma query (mesh extraction input)", "value": N ** 3 * args.steps / elapsed,
-        "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": args.mode, "data": "synthetic",
+        elapsed, per_kernel, (sig, _) = ctx.timed(step, steps, warmup)
+    return {
+        "metric": "grid points/sec, 512^3 sigma query (mesh extraction input)", "value": N ** 3 * steps / elapsed,
+        "unit": "points/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "scaling": "strong", "dtype": mode,
         "config": {"workload": "BASELINE configs[4]: 512^3 sigma grid around the posed body, fine network, voxel-sharded "
                                "(contiguous slabs, no collective)", "grid": N, "mlp_on_valid_voxels_only": bool(model.evaluate_valid_only),
-                   "mlp_points_per_step_this_rank": mlp_pts // max(args.steps, 1), "occupied_voxels_this_rank": int((sig > 0).sum())},
-        "roofline": {"kernel": f"mlp_kernel<{args.mode}, sigma only>", "bound": "mfma", "achieved": achieved, "peak": peak,
-                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "flop_per_point": flop},
+                   "mlp_points_per_step_this_rank": per_kernel.get("mlp_forward", {"units": 0})["units"] // max(steps, 1),
+                   "occupied_voxels_this_rank": int((sig > 0).sum())},
+        "roofline": mlp_roofline(per_kernel, "mlp_forward", mode, MLP_FLOP_SIGMA_ONLY, f"mlp_kernel<{mode}, sigma only>"),
     }
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
-def train_bench(args, rank, local_rank, world, dev):
+def train_bench(args, ctx, mode, steps, warmup, dense=False):
     """BASELINE configs[3] shape: one optimisation step = `frames_per_gpu` frames x 32x32 rays, 64 coarse + 32 fine,
-    perturb = 1, rgb/alpha/foreground/background losses, backward, ONE flat gradient all-reduce (RCCL), Adam."""
-    import torch.distributed as dist
+    perturb = 1, rgb/alpha/foreground/background/normals losses, backward, bucketed gradient all-reduce (RCCL) overlapped
+    with backward, Adam."""
     import anim_nerf_amd as ana
-    from anim_nerf_amd import ops, synthetic as syn
+    from anim_nerf_amd import synthetic as syn
+    dev, rank, world = ctx.dev, ctx.rank, ctx.world
     tbl = syn.make_smpl_table(0)
     torch.manual_seed(0)
     model = ana.AnimNeRF(body_model_table=tbl, freqs_dir=0, use_view=False, use_unpose=True, use_knn=True,
-                         use_fine=True, mlp_mode=args.mode).to(dev)
-    model.skip_invalid_samples = not args.dense
+                         use_fine=True, mlp_mode=mode).to(dev)
+    model.skip_invalid_samples = not dense
     hp = ana.TrainHParams(n_samples=64, n_importance=32, chunk=2048)
     F = args.frames_per_gpu
     table = ana.BodyModelParams(114).to(dev)                  # 114 training frames (configs/people_snapshot/male-3-casual.yaml)
@@ -325,55 +310,98 @@ def train_bench(args, rank, local_rank, world, dev):
     frame_idx = torch.arange(F, device=dev) * (114 // F)
     c2w, focal, cen = syn.pinhole_camera(32, 32)
     rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), 32, 32, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(F, 1, 1, 1)
-    pose = None                                               # looked up from the table each step
     templ = {k: torch.from_numpy(v).to(dev) for k, v in syn.template_pose_params().items()}
     g = torch.Generator().manual_seed(rank)
     rgbs = torch.rand(F, 32, 32, 3, generator=g).to(dev)
     alphas = (torch.rand(F, 32, 32, 1, generator=g) > 0.5).float().to(dev)
     fg = (torch.rand(F, 128, 3, generator=g) * 0.4 - 0.2).to(dev)
     bg = (torch.rand(F, 128, 3, generator=g) * 2 - 1).to(dev)
+    last = {}
 
     def step():
-        return trainer.step(rays, rgbs, alphas, pose, templ, fg, bg, perturb=1.0, frame_idx=frame_idx)
+        last["loss"], _ = trainer.step(rays, rgbs, alphas, None, templ, fg, bg, perturb=1.0, frame_idx=frame_idx)
+        return last["loss"]
 
-    def barrier():
-        if world > 1:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ops.KERNEL_TIMING = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = step()
-    barrier()
-    elapsed = ana.max_over_ranks(time.perf_counter() - t0, dev)
-    timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
-    mlp_s = sum(e0.elapsed_time(e1) for n, e0, e1, u in timing if n == "mlp_forward_save") * 1e-3
-    mlp_pts = sum(int(u) for n, e0, e1, u in timing if n == "mlp_forward_save")
-    peak = PEAK_BF16_TFLOPS if args.mode == "bf16" else PEAK_F32_TFLOPS
-    achieved = mlp_pts * MLP_FLOP_PER_POINT / mlp_s / 1e12 if mlp_s else 0.0
+    elapsed, per_kernel, loss = ctx.timed(step, steps, warmup)
     n_rays = F * 1024
-    result = {
+    return {
         "metric": "rays/sec, training step (64+32 samples, 256-wide MLP x2, fwd+bwd+Adam)",
-        "value": n_rays * args.steps * world / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.mode, "data": "synthetic",
+        "value": n_rays * steps * world / elapsed, "unit": "rays/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "dtype": mode,
         "config": {"workload": "BASELINE configs[3] shape: train step, %d frames x 32x32 rays per GPU, 64 coarse + 32 fine, "
                                "perturb=1, rgb + alpha + fg/bg + normals losses (reference defaults), pose refinement on (optim_body_params), "
-                               "flat-gradient all-reduce (4.7 MB) + Adam" % F,
+                               "bucketed gradient all-reduce (2 x 2.4 MB, overlapped with backward) + Adam" % F,
                    "mlp_on_valid_samples_only": bool(model.evaluate_valid_only),
-                   "mlp_rows_per_step": mlp_pts // max(args.steps, 1),
-                   "rays_per_step_per_gpu": n_rays, "grad_floats": sum(p.numel() for p in trainer.params)},
-        "roofline": {"kernel": f"mlp_kernel<{args.mode}, save> (training forward)", "bound": "mfma", "achieved": achieved,
-                     "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None},
+                   "mlp_rows_per_step": per_kernel.get("mlp_forward_save", {"units": 0})["units"] // max(steps, 1),
+                   "rays_per_step_per_gpu": n_rays, "grad_floats": sum(p.numel() for p in trainer.params),
+                   "kernel_launches_timed_per_step": sum(v["launches"] for v in per_kernel.values()) // max(steps, 1)},
+        "roofline": mlp_roofline(per_kernel, "mlp_forward_save", mode, MLP_FLOP_PER_POINT,
+                                 f"mlp_kernel<{mode}, save> (training forward)"),
+        "kernel_time_share": {k: round(v["s"] / elapsed, 4) for k, v in per_kernel.items()},
         "final_loss": float(loss),
     }
+
+
+def measured_traffic(mode, variant, points_per_launch):
+    """HBM bytes per launch of the MLP kernel: bytes per point from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs, gfx950 correction applied) x points per launch.  The newest profiles/rNN/mlp_hbm_traffic.json wins; the
+    file names the commit it was measured at."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "mlp_hbm_traffic.json")))
+    if mode != "bf16" or not files or not points_per_launch:
+        return None, None
+    with open(files[-1]) as fh:
+        t = json.load(fh)
+    key = {"indexed": "bytes_per_point_indexed", "explicit": "bytes_per_point_explicit", "rays": "bytes_per_point"}[variant]
+    if key not in t:
+        return None, None
+    return t[key] * points_per_launch, (f"HBM bytes per launch = {t[key]:.1f} B per point (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                        f"separate passes; {os.path.relpath(files[-1], ROOT)}, measured at commit "
+                                        f"{t.get('commit', 'of round 1')}) x points per launch")
+
+
+def main():
+    args = parse()
+    ctx = Ctx(args)
+    import anim_nerf_amd as ana
+    ana._lib.load()                                   # fails loudly if the HIP library is missing
+    rank, world = ctx.rank, ctx.world
+
+    if args.workload == "cfg4":
+        result = train_bench(args, ctx, args.mode, args.steps, args.warmup, args.dense)
+    elif args.workload == "cfg5":
+        result = grid_bench(args, ctx, args.mode, args.steps, args.warmup, args.dense)
+    else:
+        use_warp = args.workload == "cfg3"
+        result = render_bench(args, ctx, use_warp, args.mode, args.steps, args.warmup, args.dense, args.scaling, checks=True)
+        result = {"metric": "rays/sec (64+64 samples, 256-wide MLP)", **result}
+        r = result["roofline"]
+        variant = "rays" if not use_warp else ("indexed" if result["config"]["mlp_on_valid_samples_only"] else "explicit")
+        r["traffic"], r["traffic_unit"] = measured_traffic(args.mode, variant, r["points"] / r["launches"] if r["launches"] else 0)
+    result.update({"higher_is_better": True, "vs_baseline": None, "data": "synthetic"})
+
+    if not args.no_extras and args.workload == "cfg2" and args.scaling == "weak":
+        # every other line this repository quotes, measured in the same process (own warm-up + timed region each)
+        def brief(r, *keep):
+            keys = ("value", "unit", "ms_per_step", "steps", "warmup", "n_gpus", "scaling", "dtype", "roofline") + keep
+            return {**{k: r[k] for k in keys if k in r}, "config": r["config"]}
+        if world == 1:
+            result["modes"] = {"f32": brief(render_bench(args, ctx, False, "f32", 2, 1), "roofline_hbm_kernels")}
+        w = {}
+        w["cfg3"] = brief(render_bench(args, ctx, True, args.mode, 3, 1), "roofline_hbm_kernels", "kernel_time_share")
+        if world == 1:
+            w["cfg3_dense"] = brief(render_bench(args, ctx, True, args.mode, 2, 1, dense=True))
+        w["cfg4"] = brief(train_bench(args, ctx, args.mode, 4, 2), "kernel_time_share", "final_loss")
+        w["cfg5"] = brief(grid_bench(args, ctx, args.mode, 3, 1))
+        if world > 1:
+            w["cfg2_strong"] = brief(render_bench(args, ctx, False, args.mode, 3, 1, scaling="strong"))
+            w["cfg3_strong"] = brief(render_bench(args, ctx, True, args.mode, 3, 1, scaling="strong"))
+        result["workloads"] = w
+
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

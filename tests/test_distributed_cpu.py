@@ -59,11 +59,36 @@ GRAD_WORKER = textwrap.dedent("""
                             rank=int(os.environ["RANK"]), world_size=2)
     rank = dist.get_rank()
     ps = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2))]
-    ps[0].grad = torch.full((5, 3), float(rank + 1)); ps[1].grad = torch.arange(7.) * (rank + 1)   # ps[2]: no grad
+    ps[0].grad = torch.full((5, 3), float(rank + 1)); ps[1].grad = torch.arange(7.) * (rank + 1)
+    if rank == 1:
+        ps[2].grad = torch.tensor([4.0, 8.0])            # rank 0 produced no gradient for ps[2] (its rays missed the body)
     n = ana.allreduce_gradients(ps)
-    assert n == 22, n                                                # ONE collective over the flat 22-float buffer
+    assert n == 24, n                                    # ONE collective over the flat buffer of EVERY parameter
     assert torch.equal(ps[0].grad, torch.full((5, 3), 1.5)) and torch.equal(ps[1].grad, torch.arange(7.) * 1.5)
-    assert ps[2].grad is None
+    assert torch.equal(ps[2].grad, torch.tensor([2.0, 4.0]))      # zeros from rank 0, averaged
+
+    # bucketed + overlapped with backward: gradients accumulate straight into the send buffers; buckets are issued in
+    # list order whatever order autograd finishes them in, and a rank without any gradient still joins every collective
+    a, b, c = (torch.nn.Parameter(torch.ones(4)) for _ in range(3))
+    red = ana.GradientReducer([[a], [b, c]])
+    assert red.active
+    for it in range(2):
+        red.prepare()
+        if rank == 0:
+            loss = (a * 2.0).sum() + (a * 1.0).sum() + (b * 5.0).sum()      # a used twice: its hook fires once; c unused
+            loss.backward()
+        # rank 1: no backward at all
+        assert red.finish() == 12
+        assert torch.equal(a.grad, torch.full((4,), 1.5)) and torch.equal(b.grad, torch.full((4,), 2.5)), (a.grad, b.grad)
+        assert torch.equal(c.grad, torch.zeros(4))
+    # order: bucket 1 complete before bucket 0 -> still issued 0, 1
+    red.prepare()
+    (b.sum() + c.sum()).backward()
+    assert red._next == 0                                # bucket 1 is ready, bucket 0 is not: nothing issued yet
+    (a.sum() * (rank + 1)).backward()
+    assert red._next == 2
+    red.finish()
+    assert torch.equal(a.grad, torch.full((4,), 1.5)) and torch.equal(c.grad, torch.ones(4))
     dist.destroy_process_group()
     print("ok", rank)
 """) % ROOT
