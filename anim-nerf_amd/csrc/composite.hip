@@ -10,24 +10,49 @@ namespace anr {
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int MAXS = ANR_MAX_SAMPLES / WAVE;    // samples per lane, max
 
-// the same over segments of W lanes (W = 32: two rays per wavefront); l = lane inside the segment
-template <int W>
-__device__ __forceinline__ float seg_excl_prod(float v, int l) {
-    float inc = v;
-#pragma unroll
-    for (int o = 1; o < W; o <<= 1) {
-        float t = __shfl_up(inc, o, W);
-        if (l >= o) inc *= t;
-    }
-    float ex = __shfl_up(inc, 1, W);
-    return l == 0 ? 1.0f : ex;
+// ---- cross-lane primitives on DPP (data-parallel-primitive modifiers of VALU instructions: no LDS crossbar, no
+// ds_bpermute latency).  Rows are 16 lanes; row_bcast:15 / row_bcast:31 carry a row's (two rows') last lane into the next
+// row(s), which is exactly the carry of a 32- or 64-lane segment.
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138, DPP_WAVE_SHL1 = 0x130;
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp(float old, float v) {     // lanes that receive nothing keep `old`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xf, false));
 }
+// inclusive product / sum over each segment of W lanes (W = 32: two rays per wavefront, W = 64: one)
 template <int W>
-__device__ __forceinline__ float seg_sum(float v) {
-#pragma unroll
-    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+__device__ __forceinline__ float seg_incl_prod(float v) {
+    v *= dpp<DPP_ROW_SHR1>(1.0f, v);
+    v *= dpp<DPP_ROW_SHR2>(1.0f, v);
+    v *= dpp<DPP_ROW_SHR4>(1.0f, v);
+    v *= dpp<DPP_ROW_SHR8>(1.0f, v);
+    v *= dpp<DPP_ROW_BCAST15, 0xA>(1.0f, v);
+    if (W == 64) v *= dpp<DPP_ROW_BCAST31, 0xC>(1.0f, v);
     return v;
 }
+template <int W>
+__device__ __forceinline__ float seg_incl_sum(float v) {
+    v += dpp<DPP_ROW_SHR1>(0.0f, v);
+    v += dpp<DPP_ROW_SHR2>(0.0f, v);
+    v += dpp<DPP_ROW_SHR4>(0.0f, v);
+    v += dpp<DPP_ROW_SHR8>(0.0f, v);
+    v += dpp<DPP_ROW_BCAST15, 0xA>(0.0f, v);
+    if (W == 64) v += dpp<DPP_ROW_BCAST31, 0xC>(0.0f, v);
+    return v;
+}
+// the value of the segment's last lane, in every lane of the segment
+template <int W>
+__device__ __forceinline__ float seg_last(float v, int lane) {
+    const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    if (W == 64) return hi;
+    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+    return lane < 32 ? lo : hi;
+}
+// sum over the segment, in every lane (order: the DPP tree above — every caller of a given W gets the same bits)
+template <int W>
+__device__ __forceinline__ float seg_sum(float v, int lane) { return seg_last<W>(seg_incl_sum<W>(v), lane); }
 
 // exclusive multiplicative scan across the wave; returns product of lanes < lane
 __device__ __forceinline__ float wave_excl_prod(float v, int lane) {
@@ -41,22 +66,59 @@ __device__ __forceinline__ float wave_excl_prod(float v, int lane) {
     return lane == 0 ? 1.0f : ex;
 }
 
-__device__ __forceinline__ float wave_excl_sum(float v, int lane, float* total) {
-    float inc = v;
+// reference: models/volume_rendering.py:122-160
+// LPR lanes per ray (64: one ray per wavefront; 32: two), S samples per lane.  Lane l owns samples l, l + LPR, ...: every
+// load instruction of a segment reads LPR consecutive 16-byte rows (a lane-contiguous split of the ray streams at 4.3 TB/s,
+// this one at 6.3: tools/exp/exp_composite.hip); the transmittance is one DPP scan per chunk of LPR samples with a carry.
+// Totals (wsum, colour, depth) come back in the segment's LAST lane.
+template <int S, int LPR, class Col, class Depth, class Noise>
+__device__ __forceinline__ void composite_ray(int lane, int K, Col col_of, Depth depth_of, Noise noise_of, float (&w)[S],
+                                              float (&zz)[S], float& wsum, float& cr, float& cg, float& cb, float& dep) {
+    const int l = lane % LPR;
+    float4 col[S];
+    float alpha[S];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        float t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
+    for (int s = 0; s < S; ++s) {                          // all loads first: S x LPR x 16 B in flight per ray
+        const int k = s * LPR + l;
+        col[s] = make_float4(0.f, 0.f, 0.f, 0.f); zz[s] = 0.0f;
+        if (k < K) { col[s] = col_of(k); zz[s] = depth_of(k); }
     }
-    *total = __shfl(inc, 63, 64);
-    float ex = __shfl_up(inc, 1, 64);
-    return lane == 0 ? 0.0f : ex;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int k = s * LPR + l;
+        // the next depth lives one lane up, or in the segment's first lane of the next chunk (re-loading z[k + 1] costs
+        // 15 % of the kernel: misaligned rows)
+        float nxt = dpp<DPP_WAVE_SHL1>(0.0f, zz[s]);
+        if (s + 1 < S) {
+            const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zz[s + 1 < S ? s + 1 : s]), 0));
+            const float hi = LPR == 64 ? lo : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zz[s + 1 < S ? s + 1 : s]), 32));
+            if (l == LPR - 1) nxt = (lane < 32) ? lo : hi;
+        }
+        alpha[s] = 0.0f;
+        if (k < K) {
+            const float delta = (k + 1 < K) ? (nxt - zz[s]) : 1e10f;
+            const float sg = col[s].w + noise_of(k);
+            alpha[s] = 1.0f - expf(-delta * fmaxf(sg, 0.0f));
+        }
+    }
+    float carry = 1.0f;
+    wsum = 0.f; cr = 0.f; cg = 0.f; cb = 0.f; dep = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const float inc = seg_incl_prod<LPR>(1.0f - alpha[s] + 1e-10f);      // (alpha = 0 beyond K: factor 1 + 1e-10 = 1)
+        float ex = dpp<DPP_WAVE_SHR1>(1.0f, inc);
+        ex = (l == 0) ? 1.0f : ex;
+        w[s] = alpha[s] * (carry * ex);
+        if (s + 1 < S) carry = carry * seg_last<LPR>(inc, lane);
+        wsum += w[s]; cr += w[s] * col[s].x; cg += w[s] * col[s].y; cb += w[s] * col[s].z; dep += w[s] * zz[s];
+    }
+    wsum = seg_incl_sum<LPR>(wsum); cr = seg_incl_sum<LPR>(cr); cg = seg_incl_sum<LPR>(cg); cb = seg_incl_sum<LPR>(cb);
+    dep = seg_incl_sum<LPR>(dep);
 }
 
-// reference: models/volume_rendering.py:122-160
-// LPR lanes per ray (64: one ray per wavefront; 32: two — for K <= 128 the instruction stream, which is what bounds this
-// kernel, then serves two rays), S samples per lane.
-template <int S, int LPR>
+// MASKED: validity bytes given; NOISY: sigma noise given (training) — compile-time, so that the S row loads of a lane are
+// issued back to back instead of behind a (uniform) branch each.
+template <int S, int LPR, bool MASKED, bool NOISY>
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_kernel(
     const float4* __restrict__ rgbs, const float* __restrict__ z, const float* __restrict__ rays, int stride,
     const float* __restrict__ noise, int64_t R, int K, int white_bkgd, float* __restrict__ weights_out,
@@ -71,41 +133,20 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_kernel(
     const int64_t r = active ? r_raw : R - 1;              // an idle half-wave shadows the last ray, stores nothing
     const float4* c = rgbs + r * K;
     const float* zr = z + r * K;
-    const uint8_t* vr = valid ? valid + r * K : nullptr;
-
-    float alpha[S], tr[S], zz[S];
-    float4 col[S];
-    float prod = 1.0f;
+    const uint8_t* vr = valid + r * K;
+    const float* nr = noise + r * K;
+    float w[S], zz[S], wsum, cr, cg, cb, dep;
+    // a sample the warp found invalid is (0, 0, 0, -1e5) by definition (models/anim_nerf.py:245-290, :305): its rgb-sigma
+    // row was never written and is not read
+    composite_ray<S, LPR>(lane, K,
+                          [&](int k) { if (MASKED) return vr[k] == 0 ? make_float4(0.f, 0.f, 0.f, -1e5f) : c[k]; return c[k]; },
+                          [&](int k) { return zr[k]; }, [&](int k) { return NOISY ? nr[k] : 0.0f; }, w, zz, wsum, cr, cg, cb, dep);
+    if (weights_out != nullptr && active) {
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        int k = l * S + s;
-        alpha[s] = 0.0f; tr[s] = 1.0f; zz[s] = 0.0f; col[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < K) {
-            // a sample the warp found invalid is (0, 0, 0, -1e5) by definition (models/anim_nerf.py:245-290, :305):
-            // its rgb-sigma row was never written and is not read
-            col[s] = (vr != nullptr && vr[k] == 0) ? make_float4(0.f, 0.f, 0.f, -1e5f) : c[k];
-            zz[s] = zr[k];
-            float delta = (k + 1 < K) ? (zr[k + 1] - zz[s]) : 1e10f;
-            float sg = col[s].w;
-            if (noise != nullptr) sg = sg + noise[r * K + k];
-            alpha[s] = 1.0f - expf(-delta * fmaxf(sg, 0.0f));
-            tr[s] = prod;                                  // local exclusive product
-            prod = prod * (1.0f - alpha[s] + 1e-10f);
-        }
+        for (int s = 0; s < S; ++s)
+            if (s * LPR + l < K) weights_out[r * K + s * LPR + l] = w[s];
     }
-    const float before = seg_excl_prod<LPR>(prod, l);
-    float wsum = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dep = 0.f;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        int k = l * S + s;
-        if (k < K) {
-            float w = alpha[s] * (before * tr[s]);
-            if (weights_out != nullptr && active) weights_out[r * K + k] = w;
-            wsum += w; cr += w * col[s].x; cg += w * col[s].y; cb += w * col[s].z; dep += w * zz[s];
-        }
-    }
-    wsum = seg_sum<LPR>(wsum); cr = seg_sum<LPR>(cr); cg = seg_sum<LPR>(cg); cb = seg_sum<LPR>(cb); dep = seg_sum<LPR>(dep);
-    if (l == 0 && active) {
+    if (l == LPR - 1 && active) {
         if (white_bkgd) {
             float far = rays[r * stride + 7];
             dep = dep + (1.0f - wsum) * far;
@@ -225,15 +266,22 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_backward_ker
 // wbuf[KT] (coarse weights, later: the sorted depths).  The cdf is accumulated as torch's CPU cumsum accumulates it:
 // in double, rounded to float per entry (at::acc_type<float, false> = double) — so that, given the same weights, the
 // `denom < eps` branch below takes the reference's side (it flips on the last ulp of the cdf in empty bins).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_d(double old, double v) {
+    const uint64_t o = __builtin_bit_cast(uint64_t, old), x = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)x, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(o >> 32), (int)(x >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+}
 template <int W>
 __device__ __forceinline__ double seg_excl_sum_d(double v, int l) {
-    double inc = v;
-#pragma unroll
-    for (int o = 1; o < W; o <<= 1) {
-        double t = __shfl_up(inc, o, W);
-        if (l >= o) inc += t;
-    }
-    double ex = __shfl_up(inc, 1, W);
+    v += dpp_d<DPP_ROW_SHR1>(0.0, v);
+    v += dpp_d<DPP_ROW_SHR2>(0.0, v);
+    v += dpp_d<DPP_ROW_SHR4>(0.0, v);
+    v += dpp_d<DPP_ROW_SHR8>(0.0, v);
+    v += dpp_d<DPP_ROW_BCAST15, 0xA>(0.0, v);
+    if (W == 64) v += dpp_d<DPP_ROW_BCAST31, 0xC>(0.0, v);
+    const double ex = dpp_d<DPP_WAVE_SHR1>(0.0, v);
     return l == 0 ? 0.0 : ex;
 }
 
@@ -241,14 +289,22 @@ template <int KT> struct RayLds {
     float zall[KT];
     float cdf[KT];
     float wbuf[KT];
+    int hist[KT + 4];                                     // hist[c] = number of fine samples with exactly c coarse depths <= them
 };
 
-// `sync` = a barrier that makes this segment's LDS writes visible to its other lanes.
-// Returns with wbuf[0..K) = sorted depths and (PERM) ((uint8_t*)cdf)[0..K) / ((int*)cdf) = permutation.
-template <int LPR, int KT, typename PermT, class Sync>
-__device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int l, const float* __restrict__ u_row, int Kc, int Kf,
+// `sync` = a barrier that makes this segment's LDS writes visible to its other lanes.  On entry zall[0..Kc) = coarse
+// depths, wbuf[0..Kc) = coarse weights, hist[0..Kc] = 0, all visible.
+// Returns with wbuf[0..K) = sorted depths and (want_perm) ((PermT*)cdf)[0..K) = permutation.
+// KC / KF > 0: the sample counts as compile-time constants (the shipped shapes): every bound check below folds away.
+template <int LPR, int KT, typename PermT, int KC = 0, int KF = 0, class Sync>
+__device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int lane, const float* __restrict__ u_row, int Kc_rt, int Kf_rt,
                                                float* __restrict__ z_fine_row, bool want_perm, Sync sync) {
     constexpr int MAXS = (KT + LPR - 1) / LPR;
+    const int Kc = KC ? KC : Kc_rt, Kf = KF ? KF : Kf_rt;
+    const int l = lane % LPR;
+#if defined(ANR_EXP_STOP)                                 // timing experiments only (tools/exp): cut the stage short
+    if (ANR_EXP_STOP == 1) return;
+#endif
     const float eps = 1e-5f;
     const int nb = Kc - 1;                                // bins and cdf entries
     const int np = Kc - 2;                                // pdf entries
@@ -262,7 +318,7 @@ __device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int l, const float
         wl[s] = (s < S && i < np) ? (L.wbuf[1 + i] + eps) : 0.f;
         loc += wl[s];
     }
-    const float total = seg_sum<LPR>(loc);
+    const float total = seg_sum<LPR>(loc, lane);
     double ploc = 0.0;
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) { wl[s] = wl[s] / total; ploc += (double)wl[s]; }
@@ -273,56 +329,114 @@ __device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int l, const float
         int i = l * S + s;
         if (s < S && i < np) { run += (double)wl[s]; L.cdf[i + 1] = (float)run; }
     }
-    sync();
+    sync();                                               // cdf complete; the weights in wbuf are dead
+#if defined(ANR_EXP_STOP)
+    if (ANR_EXP_STOP == 2) return;
+#endif
 
-    for (int j = l; j < Kf; j += LPR) {
-        const float uu = u_row[j];
-        int lo = 0, hi = nb;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (L.cdf[mid] <= uu) lo = mid + 1; else hi = mid; }
-        const int below = max(lo - 1, 0), above = min(lo, Kc - 2);
-        const float c0 = L.cdf[below], c1 = L.cdf[above];
-        const float b0 = 0.5f * (L.zall[below] + L.zall[below + 1]), b1 = 0.5f * (L.zall[above] + L.zall[above + 1]);
-        float den = c1 - c0;
-        if (den < eps) den = 1.0f;
-        const float zf = b0 + (uu - c0) / den * (b1 - b0);
-        L.zall[Kc + j] = zf;
-        if (z_fine_row != nullptr) z_fine_row[j] = zf;
+    // inverse cdf (models/volume_rendering.py:76-96): inds = searchsorted(cdf, u, right=True) = #{i : cdf[i] <= u}, by a
+    // branch-free binary search (fixed trip count: the lane's searches interleave).  The sample lands in
+    // [bins[below], bins[above]], bins = mid-points of the coarse depths, so the number of coarse depths <= it is
+    // below + 1 or below + 2 — that is its rank in the merge, no second search.
+    int top = 1;
+    while (top * 2 <= nb) top *= 2;                       // (wave-uniform; a constant for the static shapes)
+    float zfv[MAXS];
+    int fpos[MAXS];
+    bool ok = true;
+#pragma unroll
+    for (int f = 0; f < MAXS; ++f) {
+        const int j = f * LPR + l;
+        zfv[f] = 0.f; fpos[f] = 0;
+        if (j < Kf) {
+            const float uu = u_row[j];
+            int lo = 0;
+            auto probe = [&](int step) {
+                const int idx = lo + step;
+                const float v = L.cdf[min(idx, nb) - 1];
+                lo = (idx <= nb && v <= uu) ? idx : lo;
+            };
+            if (KC) {                                     // constant trip count: unrolled, the lane's searches interleave
+#pragma unroll
+                for (int step = 128; step > 0; step >>= 1)
+                    if (step <= (KC ? KC - 1 : 1)) probe(step);
+            } else {
+                for (int step = top; step > 0; step >>= 1) probe(step);
+            }
+            const int below = max(lo - 1, 0), above = min(lo, Kc - 2);
+            const float c0 = L.cdf[below], c1 = L.cdf[above];
+            const float zb = L.zall[below], zb1 = L.zall[below + 1];
+            const float b0 = 0.5f * (zb + zb1), b1 = 0.5f * (L.zall[above] + L.zall[above + 1]);
+            float den = c1 - c0;
+            if (den < eps) den = 1.0f;
+            const float zf = b0 + (uu - c0) / den * (b1 - b0);
+            const int cnt = below + 1 + (zb1 <= zf ? 1 : 0);
+            // (what the shortcut assumes: zall[cnt - 1] <= zf < zall[cnt]; anything else takes the general path below)
+            ok &= (zb <= zf) && (cnt >= Kc || zf < L.zall[min(cnt, Kc - 1)]);
+            zfv[f] = zf; fpos[f] = j + cnt;
+            L.zall[Kc + j] = zf;
+            L.wbuf[j + cnt] = zf;                         // its place in the sorted row, if the row is regular
+            atomicAdd(&L.hist[cnt], 1);
+            if (z_fine_row != nullptr) z_fine_row[j] = zf;
+        }
     }
     sync();
+#if defined(ANR_EXP_STOP)
+    if (ANR_EXP_STOP == 3) return;
+#endif
 
     // Stable sort of the Kc+Kf depths: rank(p) = #(y < x) + #(y == x, q < p).  Both halves are normally ascending
-    // already (stratified coarse depths; fine depths from ascending u through a monotone inverse cdf), and then the
-    // rank is the element's own index plus one binary search in the other half.  Anything else (random u, a 1-ulp
-    // inversion at a bin edge) takes the all-pairs count, which is valid for any input.
+    // (stratified coarse depths; fine depths from ascending u through a monotone inverse cdf): then a fine sample's rank
+    // is its index + the count above, and a coarse one's is its index + the number of fine samples whose count does not
+    // exceed it — a prefix sum of the histogram.  Anything else (random u, a 1-ulp inversion at a bin edge, coinciding
+    // depths) takes the all-pairs count, which is valid for any input.
     const int K = Kc + Kf;
-    bool ordered = true;
     for (int p = l; p < K; p += LPR)
-        if (p + 1 < K && p + 1 != Kc) ordered &= L.zall[p] <= L.zall[p + 1];
+        if (p + 1 < K && p + 1 != Kc) ok &= L.zall[p] <= L.zall[p + 1];
     // (the vote spans the wavefront: with two rays per wavefront both take the general path if either needs it)
-    const bool fast = __all(ordered);
+    const bool fast = __all(ok);
     PermT* perm = reinterpret_cast<PermT*>(L.cdf);        // the cdf is dead from here on (barrier after the sampling loop)
-    for (int p = l; p < K; p += LPR) {
-        const float x = L.zall[p];
-        int rank;
-        if (fast) {
-            if (p < Kc) {                       // + fine entries strictly below x
-                int lo = 0, hi = Kf;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.zall[Kc + mid] < x) lo = mid + 1; else hi = mid; }
-                rank = p + lo;
-            } else {                            // + coarse entries below or equal to x
-                int lo = 0, hi = Kc;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.zall[mid] <= x) lo = mid + 1; else hi = mid; }
-                rank = (p - Kc) + lo;
+    if (fast) {
+        const int SC = (Kc + LPR - 1) / LPR;              // coarse entries p = l*SC + s: a run per lane, then a DPP scan
+        int h[MAXS], mine = 0;
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const int p = l * SC + s;
+            h[s] = (s < SC && p < Kc) ? L.hist[p] : 0;
+            mine += h[s];
+        }
+        int inc = mine;
+        inc += __builtin_amdgcn_update_dpp(0, inc, DPP_ROW_SHR1, 0xf, 0xf, false);
+        inc += __builtin_amdgcn_update_dpp(0, inc, DPP_ROW_SHR2, 0xf, 0xf, false);
+        inc += __builtin_amdgcn_update_dpp(0, inc, DPP_ROW_SHR4, 0xf, 0xf, false);
+        inc += __builtin_amdgcn_update_dpp(0, inc, DPP_ROW_SHR8, 0xf, 0xf, false);
+        inc += __builtin_amdgcn_update_dpp(0, inc, DPP_ROW_BCAST15, 0xA, 0xf, false);
+        if (LPR == 64) inc += __builtin_amdgcn_update_dpp(0, inc, DPP_ROW_BCAST31, 0xC, 0xf, false);
+        int below_me = inc - mine;                        // fine samples counted by the lanes before this one
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const int p = l * SC + s;
+            if (s < SC && p < Kc) {
+                below_me += h[s];
+                L.wbuf[p + below_me] = L.zall[p];
+                if (want_perm) perm[p + below_me] = (PermT)p;
             }
-        } else {
-            rank = 0;
+        }
+        if (want_perm) {
+#pragma unroll
+            for (int f = 0; f < MAXS; ++f)
+                if (f * LPR + l < Kf) perm[fpos[f]] = (PermT)(Kc + f * LPR + l);
+        }
+    } else {                                              // (every slot of wbuf is rewritten)
+        for (int p = l; p < K; p += LPR) {
+            const float x = L.zall[p];
+            int rank = 0;
             for (int q = 0; q < K; ++q) {
                 const float y = L.zall[q];
                 rank += (y < x || (y == x && q < p)) ? 1 : 0;
             }
+            L.wbuf[rank] = x;
+            if (want_perm) perm[rank] = (PermT)p;           // z_sorted[rank] = cat(z_coarse, z_fine)[p]
         }
-        L.wbuf[rank] = x;
-        if (want_perm) perm[rank] = (PermT)p;               // z_sorted[rank] = cat(z_coarse, z_fine)[p]
     }
     sync();
 }
@@ -363,10 +477,11 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void sample_fine_merge_kern
     const int64_t r = active ? r_raw : R - 1;
     RayLds<KT>& L = lds[slot];
     for (int k = l; k < Kc; k += LPR) { L.zall[k] = z_coarse[r * Kc + k]; L.wbuf[k] = weights[r * Kc + k]; }
+    for (int k = l; k <= Kc; k += LPR) L.hist[k] = 0;
     auto sync = [] { __syncthreads(); };
     sync();
     const int K = Kc + Kf;
-    fine_and_merge<LPR, KT, PermT>(L, l, u_per_ray ? u + r * Kf : u, Kc, Kf,
+    fine_and_merge<LPR, KT, PermT>(L, lane, u_per_ray ? u + r * Kf : u, Kc, Kf,
                                    (active && z_fine_out != nullptr) ? z_fine_out + r * Kf : nullptr, perm_out != nullptr, sync);
     if (active) store_sorted<LPR, KT, PermT>(L, l, K, z_sorted_out + r * K, perm_out ? perm_out + r * K : nullptr);
 }
@@ -377,14 +492,15 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void sample_fine_merge_kern
 // against composite + sample_fine_merge).  z_coarse == nullptr: the depths are the deterministic stratified ones,
 // z_k = near (1 - steps_k) + far steps_k (models/volume_rendering.py:43-44), computed here with the same roundings as
 // anr_sample_coarse.
-template <int S, int LPR, int KT, typename PermT>
+template <int S, int LPR, int KT, typename PermT, bool MASKED, bool HAS_Z, int KC = 0, int KF = 0>
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_sample_kernel(
     const float4* __restrict__ rgbs, const float* __restrict__ z, const float* __restrict__ steps,
     const float* __restrict__ rays, int stride, const uint8_t* __restrict__ valid, const float* __restrict__ u,
-    int u_per_ray, int64_t R, int Kc, int Kf, int white_bkgd, float* __restrict__ weights_out,
+    int u_per_ray, int64_t R, int Kc_rt, int Kf_rt, int white_bkgd, float* __restrict__ weights_out,
     float* __restrict__ rgb_out, float* __restrict__ depth_out, float* __restrict__ acc_out,
     float* __restrict__ z_fine_out, float* __restrict__ z_sorted_out, PermT* __restrict__ perm_out) {
     constexpr int RPW = WAVE / LPR;
+    const int Kc = KC ? KC : Kc_rt, Kf = KF ? KF : Kf_rt;
     __shared__ __attribute__((aligned(16))) RayLds<KT> lds[WAVES_PER_BLOCK * RPW];
     const int lane = threadIdx.x & 63, l = lane % LPR;
     const int slot = (threadIdx.x >> 6) * RPW + lane / LPR;
@@ -393,41 +509,24 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_sample_kerne
     const int64_t r = active ? r_raw : R - 1;
     RayLds<KT>& L = lds[slot];
     const float4* c = rgbs + r * Kc;
-    const uint8_t* vr = valid ? valid + r * Kc : nullptr;
+    const uint8_t* vr = valid + r * Kc;
     const float near = rays[r * stride + 6], far = rays[r * stride + 7];
-    auto depth = [&](int k) { if (z) return z[r * Kc + k]; const float s = steps[k]; return near * (1.0f - s) + far * s; };
-
-    float alpha[S], tr[S], zz[S];
-    float4 col[S];
-    float prod = 1.0f;
+    float w[S], zz[S], wsum, cr, cg, cb, dep;
+    composite_ray<S, LPR>(lane, Kc,
+                          [&](int k) { if (MASKED) return vr[k] == 0 ? make_float4(0.f, 0.f, 0.f, -1e5f) : c[k]; return c[k]; },
+                          [&](int k) { if (HAS_Z) return z[r * Kc + k]; const float sk = steps[k]; return near * (1.0f - sk) + far * sk; },
+                          [](int) { return 0.0f; }, w, zz, wsum, cr, cg, cb, dep);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        const int k = l * S + s;
-        alpha[s] = 0.0f; tr[s] = 1.0f; zz[s] = 0.0f; col[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int k = s * LPR + l;
         if (k < Kc) {
-            col[s] = (vr != nullptr && vr[k] == 0) ? make_float4(0.f, 0.f, 0.f, -1e5f) : c[k];
-            zz[s] = depth(k);
             L.zall[k] = zz[s];
-            const float delta = (k + 1 < Kc) ? (depth(k + 1) - zz[s]) : 1e10f;
-            alpha[s] = 1.0f - expf(-delta * fmaxf(col[s].w, 0.0f));
-            tr[s] = prod;
-            prod = prod * (1.0f - alpha[s] + 1e-10f);
+            L.wbuf[k] = w[s];
+            if (weights_out != nullptr && active) weights_out[r * Kc + k] = w[s];
         }
     }
-    const float before = seg_excl_prod<LPR>(prod, l);
-    float wsum = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dep = 0.f;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int k = l * S + s;
-        if (k < Kc) {
-            const float w = alpha[s] * (before * tr[s]);
-            L.wbuf[k] = w;
-            if (weights_out != nullptr && active) weights_out[r * Kc + k] = w;
-            wsum += w; cr += w * col[s].x; cg += w * col[s].y; cb += w * col[s].z; dep += w * zz[s];
-        }
-    }
-    wsum = seg_sum<LPR>(wsum); cr = seg_sum<LPR>(cr); cg = seg_sum<LPR>(cg); cb = seg_sum<LPR>(cb); dep = seg_sum<LPR>(dep);
-    if (l == 0 && active) {
+    for (int k = l; k <= Kc; k += LPR) L.hist[k] = 0;
+    if (l == LPR - 1 && active) {
         if (white_bkgd) {
             dep = dep + (1.0f - wsum) * far;
             cr = cr + 1.0f - wsum; cg = cg + 1.0f - wsum; cb = cb + 1.0f - wsum;
@@ -439,7 +538,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_sample_kerne
     auto sync = [] { __syncthreads(); };
     sync();
     const int K = Kc + Kf;
-    fine_and_merge<LPR, KT, PermT>(L, l, u_per_ray ? u + r * Kf : u, Kc, Kf,
+    fine_and_merge<LPR, KT, PermT>(L, lane, u_per_ray ? u + r * Kf : u, Kc, Kf,
                                    (active && z_fine_out != nullptr) ? z_fine_out + r * Kf : nullptr, perm_out != nullptr, sync);
     if (active) store_sorted<LPR, KT, PermT>(L, l, K, z_sorted_out + r * K, perm_out ? perm_out + r * K : nullptr);
 }
@@ -465,15 +564,23 @@ extern "C" int anr_composite_masked(const float* rgbs, const float* z, const flo
     const float4* c = reinterpret_cast<const float4*>(rgbs);
     hipStream_t st = (hipStream_t)stream;
     dim3 block(WAVE * WAVES_PER_BLOCK);
-#define ANR_LAUNCH_COMPOSITE(SS, LPR)                                                                              \
-    hipLaunchKernelGGL((composite_kernel<SS, LPR>), dim3((unsigned)((R + WAVES_PER_BLOCK * (WAVE / LPR) - 1) /       \
-                                                                    (WAVES_PER_BLOCK * (WAVE / LPR)))),              \
+#define ANR_LAUNCH_COMPOSITE_(SS, LPR, M, N)                                                                        \
+    hipLaunchKernelGGL((composite_kernel<SS, LPR, M, N>), dim3((unsigned)((R + WAVES_PER_BLOCK * (WAVE / LPR) - 1) /  \
+                                                                          (WAVES_PER_BLOCK * (WAVE / LPR)))),        \
                        block, 0, st, c, z, rays, stride, noise, R, K, white_bkgd, weights_out, rgb_out, depth_out,   \
                        acc_out, valid)
+#define ANR_LAUNCH_COMPOSITE(SS, LPR)                                                                              \
+    do {                                                                                                           \
+        if (valid && noise) { ANR_LAUNCH_COMPOSITE_(SS, LPR, true, true); }                                        \
+        else if (valid)     { ANR_LAUNCH_COMPOSITE_(SS, LPR, true, false); }                                       \
+        else if (noise)     { ANR_LAUNCH_COMPOSITE_(SS, LPR, false, true); }                                       \
+        else                { ANR_LAUNCH_COMPOSITE_(SS, LPR, false, false); }                                      \
+    } while (0)
     if (K <= 64)       { ANR_LAUNCH_COMPOSITE(2, 32); }         // two rays per wavefront
     else if (K <= 128) { ANR_LAUNCH_COMPOSITE(4, 32); }
     else if (K <= 192) { ANR_LAUNCH_COMPOSITE(3, 64); }
     else               { ANR_LAUNCH_COMPOSITE(4, 64); }
+#undef ANR_LAUNCH_COMPOSITE_
 #undef ANR_LAUNCH_COMPOSITE
     return check_launch("anr_composite");
 }
@@ -552,11 +659,34 @@ extern "C" int anr_composite_sample(const float* rgbs, const float* z_coarse, co
     const float4* c = reinterpret_cast<const float4*>(rgbs);
     hipStream_t st = (hipStream_t)stream;
     dim3 block(WAVE * WAVES_PER_BLOCK);
-#define ANR_LAUNCH_CS(SS, LPR, KT)                                                                                   \
-    hipLaunchKernelGGL((composite_sample_kernel<SS, LPR, KT, uint8_t>),                                               \
+#define ANR_LAUNCH_CS_(SS, LPR, KT, M, Z)                                                                            \
+    hipLaunchKernelGGL((composite_sample_kernel<SS, LPR, KT, uint8_t, M, Z>),                                         \
                        dim3((unsigned)((R + WAVES_PER_BLOCK * (WAVE / LPR) - 1) / (WAVES_PER_BLOCK * (WAVE / LPR)))), \
                        block, 0, st, c, z_coarse, steps, rays, stride, valid, u, u_per_ray, R, Kc, Kf, white_bkgd,    \
                        weights_out, rgb_out, depth_out, acc_out, z_fine_out, z_sorted_out, perm_out)
+#define ANR_LAUNCH_CS(SS, LPR, KT)                                                                                   \
+    do {                                                                                                             \
+        if (valid && z_coarse) { ANR_LAUNCH_CS_(SS, LPR, KT, true, true); }                                          \
+        else if (valid)        { ANR_LAUNCH_CS_(SS, LPR, KT, true, false); }                                         \
+        else if (z_coarse)     { ANR_LAUNCH_CS_(SS, LPR, KT, false, true); }                                         \
+        else                   { ANR_LAUNCH_CS_(SS, LPR, KT, false, false); }                                        \
+    } while (0)
+    // the shipped shapes (64 + 64: BASELINE configs[1..2]; 64 + 32: configs/people_snapshot/*.yml) with every bound a constant
+#define ANR_LAUNCH_CS_STATIC(KC, KF)                                                                                 \
+    do {                                                                                                             \
+        const dim3 grid((unsigned)((R + WAVES_PER_BLOCK * 2 - 1) / (WAVES_PER_BLOCK * 2)));                          \
+        if (valid && z_coarse)                                                                                       \
+            hipLaunchKernelGGL((composite_sample_kernel<2, 32, 128, uint8_t, true, true, KC, KF>), grid, block, 0, st, c, z_coarse, steps, rays, stride, valid, u, u_per_ray, R, Kc, Kf, white_bkgd, weights_out, rgb_out, depth_out, acc_out, z_fine_out, z_sorted_out, perm_out); \
+        else if (valid)                                                                                              \
+            hipLaunchKernelGGL((composite_sample_kernel<2, 32, 128, uint8_t, true, false, KC, KF>), grid, block, 0, st, c, z_coarse, steps, rays, stride, valid, u, u_per_ray, R, Kc, Kf, white_bkgd, weights_out, rgb_out, depth_out, acc_out, z_fine_out, z_sorted_out, perm_out); \
+        else if (z_coarse)                                                                                           \
+            hipLaunchKernelGGL((composite_sample_kernel<2, 32, 128, uint8_t, false, true, KC, KF>), grid, block, 0, st, c, z_coarse, steps, rays, stride, valid, u, u_per_ray, R, Kc, Kf, white_bkgd, weights_out, rgb_out, depth_out, acc_out, z_fine_out, z_sorted_out, perm_out); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((composite_sample_kernel<2, 32, 128, uint8_t, false, false, KC, KF>), grid, block, 0, st, c, z_coarse, steps, rays, stride, valid, u, u_per_ray, R, Kc, Kf, white_bkgd, weights_out, rgb_out, depth_out, acc_out, z_fine_out, z_sorted_out, perm_out); \
+        return check_launch("anr_composite_sample");                                                                 \
+    } while (0)
+    if (Kc == 64 && Kf == 64) ANR_LAUNCH_CS_STATIC(64, 64);
+    if (Kc == 64 && Kf == 32) ANR_LAUNCH_CS_STATIC(64, 32);
     // (S, LPR) by Kc exactly as anr_composite picks them, LPR of the sampling stage by Kc as anr_sample_fine_merge does:
     // the fused launch returns the bits of the two separate ones
     if (Kc <= 64)       { if (Kc + Kf <= 128) { ANR_LAUNCH_CS(2, 32, 128); } else { ANR_LAUNCH_CS(2, 32, ANR_MAX_SAMPLES); } }
@@ -564,5 +694,7 @@ extern "C" int anr_composite_sample(const float* rgbs, const float* z_coarse, co
     else if (Kc <= 192) { ANR_LAUNCH_CS(3, 64, ANR_MAX_SAMPLES); }
     else                { ANR_LAUNCH_CS(4, 64, ANR_MAX_SAMPLES); }
 #undef ANR_LAUNCH_CS
+#undef ANR_LAUNCH_CS_
+#undef ANR_LAUNCH_CS_STATIC
     return check_launch("anr_composite_sample");
 }
