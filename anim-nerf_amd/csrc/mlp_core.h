@@ -349,9 +349,15 @@ struct Mlp {
             constexpr int j = decltype(jc)::value;
             Frag (&use)[4] = (j & 1) ? wb : wa;
             Frag (&ld)[4] = (j & 1) ? wa : wb;
+#ifdef ANR_ABL_NO_FRAG_LOAD                        // timing ablation: no LDS fragment reads (registers recycled)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ld[q] = use[q]; pin(ld[q]); }
+            if (j + 1 == NG) bias_n = bias_c;
+#else
 #pragma unroll
             for (int q = 0; q < 4; ++q) ld[q] = (j + 1 < NG) ? cur[((j + 1) * 4 + q) * 64] : nxt[q * 64];
             if (j + 1 == NG) bias_n = read_bias(END ? 0 : T + 1);
+#endif
             __builtin_amdgcn_sched_barrier(0);          // the loads above are issued before this group's MFMAs
             static_for<4>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
