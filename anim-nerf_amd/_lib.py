@@ -62,6 +62,7 @@ SIGNATURES = {
     "anr_mlp_pack": (_I, [C.POINTER(AnrMlpParams), _I, _P, _P]),
     "anr_mlp_forward": (_I, [_P, _I, _P, _L, _P, _P]),
     "anr_mlp_forward_rays": (_I, [_P, _I, _P, _I, _P, _I, _L, _P, _P]),
+    "anr_mlp_forward_embedded": (_I, [_P, _I, _P, _L, _P, _P, _P]),
     "anr_mlp_forward_rays_steps": (_I, [_P, _I, _P, _I, _P, _I, _L, _P, _P]),
     "anr_compact_valid": (_I, [_P, _L, _P, _P, _P, _I, _P]),
     "anr_mlp_forward_indexed": (_I, [_P, _I, _P, _P, _P, _L, _P, _P]),

@@ -15,6 +15,11 @@ ANR_MLP_EXTERN(ANR_MLP_BF16_W8, true, true, false)   ANR_MLP_EXTERN(ANR_MLP_BF16
 ANR_MLP_EXTERN(ANR_MLP_BF16_W8, true, true, true)
 ANR_MLP_EXTERN(ANR_MLP_BF16, true, false, false)  ANR_MLP_EXTERN(ANR_MLP_BF16, false, false, false)
 #undef ANR_MLP_EXTERN
+#define ANR_PRE(M, S) extern template int launch_mlp<M, true, S, false, true>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*, const float*, int, int);
+ANR_PRE(ANR_MLP_F32, false) ANR_PRE(ANR_MLP_F32, true) ANR_PRE(ANR_MLP_BF16_W8, false) ANR_PRE(ANR_MLP_BF16_W8, true)
+#undef ANR_PRE
+extern template int launch_mlp<ANR_MLP_F32, true, false, true, true>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*, const float*, int, int);
+extern template int launch_mlp<ANR_MLP_BF16_W8, true, false, true, true>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*, const float*, int, int);
 
 // ---------------------------------------------------------------------------------------------
 // weight packing: one thread per (frag, lane) 16-byte piece; tail threads fill the bias table
@@ -190,6 +195,34 @@ extern "C" int anr_mlp_forward_rays(const void* pack, int mode, const float* ray
         case ANR_MLP_BF16:
             return launch_mlp<ANR_MLP_BF16_W8, true, false, false>(pack, z, n, out, st, nullptr, nullptr, nullptr, rays, ray_stride, K);
         default: return fail(ANR_E_BADARG, "anr_mlp_forward_rays: unknown mode %d", mode);
+    }
+}
+
+extern "C" int anr_mlp_forward_embedded(const void* pack, int mode, const float* emb, int64_t n, float* out, void* act_v,
+                                        void* stream) {
+    ANR_REQUIRE(pack && emb && out, ANR_E_BADARG, "anr_mlp_forward_embedded: null pointer");
+    ANR_REQUIRE(n > 0, ANR_E_BADARG, "anr_mlp_forward_embedded: n=%lld", (long long)n);
+    ANR_REQUIRE((((uintptr_t)pack | (uintptr_t)out) & 15) == 0 && ((uintptr_t)emb & 3) == 0, ANR_E_ALIGN,
+                "anr_mlp_forward_embedded: pack/out must be 16-B aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const bool so = (mode & ANR_MLP_FLAG_SIGMA_ONLY) != 0;
+    if (act_v != nullptr) {
+        ANR_REQUIRE(!so && ((uintptr_t)act_v & 15) == 0, ANR_E_BADARG, "anr_mlp_forward_embedded: act needs the full network and 16-B alignment");
+        float* act = reinterpret_cast<float*>(act_v);
+        switch (mode & 0xff) {
+            case ANR_MLP_F32:  return launch_mlp<ANR_MLP_F32, true, false, true, true>(pack, emb, n, out, st, act);
+            case ANR_MLP_BF16: return launch_mlp<ANR_MLP_BF16_W8, true, false, true, true>(pack, emb, n, out, st, act);
+            default: return fail(ANR_E_BADARG, "anr_mlp_forward_embedded: unknown mode %d", mode);
+        }
+    }
+    switch (mode & 0xff) {
+        case ANR_MLP_F32:
+            return so ? launch_mlp<ANR_MLP_F32, true, true, false, true>(pack, emb, n, out, st, nullptr)
+                      : launch_mlp<ANR_MLP_F32, true, false, false, true>(pack, emb, n, out, st, nullptr);
+        case ANR_MLP_BF16:
+            return so ? launch_mlp<ANR_MLP_BF16_W8, true, true, false, true>(pack, emb, n, out, st, nullptr)
+                      : launch_mlp<ANR_MLP_BF16_W8, true, false, false, true>(pack, emb, n, out, st, nullptr);
+        default: return fail(ANR_E_BADARG, "anr_mlp_forward_embedded: unknown mode %d", mode);
     }
 }
 

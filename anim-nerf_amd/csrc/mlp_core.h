@@ -171,7 +171,9 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 constexpr int ACT_COLS = 2432;
 __host__ __device__ constexpr int act_col(int T) { return T < 64 ? 32 * T : T < 73 ? 2048 + 32 * (T - 65) : 2304 + 32 * (T - 73); }
 
-template <int MODE, bool DMA, bool SIGMA_ONLY = false, bool SAVE = false>
+// PRE: the input is the 63-channel Fourier embedding itself, emb[n][63] fp32 (models/mlp.py:268-297 takes it that way):
+// the encoder is skipped, the panel slots are loaded from the row.
+template <int MODE, bool DMA, bool SIGMA_ONLY = false, bool SAVE = false, bool PRE = false>
 struct Mlp {
     using C = Cfg<MODE>;
     using Frag = typename C::Frag;
@@ -492,13 +494,19 @@ struct Mlp {
             }
         };
         float4 p_cur[NT], p_nxt[NT];
-        fetch_pts(blockIdx.x, p_nxt);
+        if constexpr (PRE) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) p_nxt[n] = make_float4(0.f, 0.f, 0.f, 1.f);
+        } else {
+            fetch_pts(blockIdx.x, p_nxt);
+        }
         for (int64_t pt = blockIdx.x; pt < n_tiles; pt += gridDim.x) {
         more = pt + gridDim.x < n_tiles;
         c = 0;
 #pragma unroll
         for (int n = 0; n < NT; ++n) p_cur[n] = p_nxt[n];
-        if (more) fetch_pts(pt + gridDim.x, p_nxt);          // the next tile's points arrive under this tile's MFMAs
+        if constexpr (!PRE)
+            if (more) fetch_pts(pt + gridDim.x, p_nxt);      // the next tile's points arrive under this tile's MFMAs
         // this wave's points, Fourier-encoded straight into B fragments
         const int64_t wave_base = (pt * WAVES + wave) * (NT * 32);
         float valid[NT];
@@ -510,7 +518,20 @@ struct Mlp {
             valid[n] = p.w;
             act_row[n] = (SAVE && idx < n_pts) ? reinterpret_cast<ActT*>(act) + idx * ACT_COLS + 4 * half : nullptr;
             const float xs[3] = {p.x, p.y, p.z};
-            if constexpr (C::IS_BF16) {
+            if constexpr (PRE) {
+                int64_t row_i = idx < n_pts ? idx : n_pts - 1;
+                const float* row = reinterpret_cast<const float*>(pts) + row_i * 63;
+                valid[n] = 1.0f;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    // slot j, half h <-> reference channel (header): 3 + 6k + 3h + d for j = 3k + d < 30; x0/x2; x1/pad
+                    float v;
+                    if (j < 30) v = row[3 + 6 * (j / 3) + (j % 3) + 3 * half];
+                    else if (j == 30) v = row[2 * half];
+                    else v = half ? 0.0f : row[1];
+                    put(E[n][j / EPF], j % EPF, v);
+                }
+            } else if constexpr (C::IS_BF16) {
                 // bf16 mode: exact sin/cos of the base band, then angle doubling (error doubles per octave:
                 // 2^9 * 1e-7 << bf16's 2^-9) — 6 polynomial evaluations instead of 30 per lane
                 float sn[3], cs[3];
@@ -607,7 +628,7 @@ struct Mlp {
     }
 };
 
-template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE>
+template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE, bool PRE = false>
 __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void mlp_kernel(const char* __restrict__ pack,
                                                              const float4* __restrict__ pts, int64_t n_pts,
                                                              void* __restrict__ out, float* __restrict__ act,
@@ -615,17 +636,17 @@ __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void m
                                                              const int32_t* __restrict__ count,
                                                              const float* __restrict__ rays, int ray_stride, int K) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    Mlp<MODE, DMA, SIGMA_ONLY, SAVE> m;
+    Mlp<MODE, DMA, SIGMA_ONLY, SAVE, PRE> m;
     m.run(pack, pts, n_pts, out, act, lds, index, count, rays, ray_stride, K);
 }
 
-template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE>
+template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE, bool PRE = false>
 int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStream_t st, float* act,
                const int32_t* index = nullptr, const int32_t* count = nullptr, const float* rays = nullptr,
                int ray_stride = 0, int K = 1) {
     using C = Cfg<MODE>;
     const int lds = BIAS_BYTES + 3 * slot_bytes<C>();
-    auto kern = mlp_kernel<MODE, DMA, SIGMA_ONLY, SAVE>;
+    auto kern = mlp_kernel<MODE, DMA, SIGMA_ONLY, SAVE, PRE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail((int)e, "anr_mlp_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
     const int pts_per_wg = C::WAVES * C::NT * 32;

@@ -420,6 +420,26 @@ def mlp_forward_rays(pack: torch.Tensor, mode: int, rays: torch.Tensor, z: torch
     return out
 
 
+def mlp_forward_embedded(pack: torch.Tensor, mode: int, emb: torch.Tensor, sigma_only: bool = False, want_act: bool = False):
+    """emb[n,63] (already Fourier-embedded, models/mlp.py:268-297) -> out[n,4] = (r,g,b,sigma), or sigma[n];
+    want_act: (out, act[n, anr_mlp_act_cols()]) as mlp_forward_save."""
+    lib = _lib.load()
+    emb = _dev(emb, "emb")
+    if emb.shape[-1] != 63:
+        raise ValueError("mlp_forward_embedded: expected 63 embedded channels (in_channels_xyz = 3 + 3*10*2)")
+    n = emb.numel() // 63
+    mode = (mode & 0xff) | (ANR_MLP_FLAG_SIGMA_ONLY if sigma_only else 0)
+    out = torch.empty((n,) if sigma_only else (n, 4), dtype=torch.float32, device=emb.device)
+    act = None
+    if want_act:
+        act = torch.empty(n, lib.anr_mlp_act_cols(), device=emb.device,
+                          dtype=torch.bfloat16 if (mode & 0xff) == ANR_MLP_BF16 else torch.float32)
+    with _timed("mlp_forward", n):
+        _lib.check(lib.anr_mlp_forward_embedded(_ptr(pack), mode, _ptr(emb), n, _ptr(out), _ptr(act), _stream(out)),
+                   "anr_mlp_forward_embedded")
+    return (out, act) if want_act else out
+
+
 def mlp_forward_rays_steps(pack: torch.Tensor, mode: int, rays: torch.Tensor, steps: torch.Tensor) -> torch.Tensor:
     """As mlp_forward_rays with the deterministic stratified depths z = near' (1 - steps) + far' steps computed in the
     kernel too: no depth array.  rays[bs,R,>=8], steps[K] -> out[bs*R*K, 4]."""

@@ -215,6 +215,13 @@ int anr_mlp_forward_rays(const void* pack, int mode, const float* rays, int ray_
  * z = near' (1 - steps[k]) + far' steps[k] (k = i % K; roundings of anr_sample_coarse), are computed in the kernel too. */
 int anr_mlp_forward_rays_steps(const void* pack, int mode, const float* rays, int ray_stride, const float* steps, int K,
                                int64_t n, float* out, void* stream);
+/* The network on an already embedded input, emb[n*63] = (x, sin 2^k x, cos 2^k x)_k in the reference's channel order:
+ * models/mlp.py:268-297 (NeRF.forward(input_xyz, ...), the pre-embedded twin of models/nerf.py) — the encoder is skipped.
+ * out[n*4] = (r,g,b,sigma), or sigma[n] with ANR_MLP_FLAG_SIGMA_ONLY (only_sigma=True, :283-284).
+ * act (may be NULL): the saved activations of anr_mlp_forward_save — columns 2048..2303 are xyz_encoding_final, the input
+ * of a view-dependent colour head (in_channels_dir > 0) that the caller evaluates. */
+int anr_mlp_forward_embedded(const void* pack, int mode, const float* emb, int64_t n, float* out, void* act,
+                             void* stream);
 int anr_compact_valid(const float* pts, int64_t n, int32_t* index_out, int32_t* count_out,
                       float* fill_out, int fill_cols, void* stream);
 int anr_mlp_forward_indexed(const void* pack, int mode, const float* pts, const int32_t* index,

@@ -294,6 +294,26 @@ def mlp_forward(P: Dict[str, Tensor], xyz: Tensor, viewdir: Optional[Tensor] = N
     return rgb, sigma
 
 
+def mlp_forward_embedded(P: Dict[str, Tensor], input_xyz: Tensor, input_dir: Optional[Tensor] = None,
+                         only_sigma: bool = False):
+    """models/mlp.py:268-297 — the same network on an already embedded input (63 channels; the direction channels, if
+    any, are concatenated behind the 256-wide feature)."""
+    h = input_xyz
+    for i in range(8):
+        if i == 4:
+            h = torch.cat([input_xyz, h], dim=-1)
+        h = torch.relu(torch.nn.functional.linear(
+            h, P[f'xyz_encoding_{i+1}.0.weight'], P[f'xyz_encoding_{i+1}.0.bias']))
+    sigma = torch.nn.functional.linear(h, P['sigma.weight'], P['sigma.bias'])
+    if only_sigma:
+        return sigma
+    x = torch.nn.functional.linear(h, P['xyz_encoding_final.weight'], P['xyz_encoding_final.bias'])
+    if input_dir is not None and input_dir.shape[-1] > 0:
+        x = torch.cat([x, input_dir], dim=-1)
+    g = torch.relu(torch.nn.functional.linear(x, P['dir_encoding.0.weight'], P['dir_encoding.0.bias']))
+    return torch.sigmoid(torch.nn.functional.linear(g, P['rgb.0.weight'], P['rgb.0.bias'])), sigma
+
+
 def field_query(P, xyz, st, lbs_weights, use_unpose: bool, dis_threshold: float,
                 chunk: int = 4096):
     """models/anim_nerf.py:290-307 (AnimNeRF.forward): warp, MLP, sigma=-1e5 where invalid."""

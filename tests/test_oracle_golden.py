@@ -202,3 +202,27 @@ def test_mlp_with_view_direction():
     rgb, sig = orc.mlp_forward(P, torch.from_numpy(g["xyz"]), torch.from_numpy(g["viewdir"]), use_view=True)
     torch.testing.assert_close(rgb, torch.from_numpy(g["rgb"]), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(sig, torch.from_numpy(g["sigma"]), rtol=1e-5, atol=1e-6)
+
+
+def test_pre_embedded_twin_network():
+    """models/mlp.py's NeRF (input already embedded): the oracle against the reference's outputs, our host class builds the
+    same seeded weights, also for an input that is not the embedding of anything."""
+    import anim_nerf_amd as ana
+    g = golden("mlp_twin")
+    e_xyz = orc.fourier_encode(torch.from_numpy(g["xyz"]), 10)
+    e_dir = orc.fourier_encode(torch.from_numpy(g["viewdir"]), 4)
+    free = torch.from_numpy(g["free"])
+    for tag, dirs in (("view", 27), ("plain", 0)):
+        torch.manual_seed(int(g["seed"]))
+        net = ana.mlp.NeRF(in_channels_dir=dirs)
+        chk = float(sum(p.detach().double().abs().sum() for p in net.parameters()))
+        assert abs(chk - float(g[f"{tag}_weights_abs_sum"])) < 1e-6 * chk
+        P = {k: v.detach() for k, v in net.named_parameters()}
+        rgb, sig = orc.mlp_forward_embedded(P, e_xyz, e_dir if dirs else None)
+        torch.testing.assert_close(rgb, torch.from_numpy(g[f"{tag}_rgb"]), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(sig, torch.from_numpy(g[f"{tag}_sigma"]), rtol=1e-5, atol=1e-6)
+        rgb, sig = orc.mlp_forward_embedded(P, free, e_dir[:256] if dirs else None)
+        torch.testing.assert_close(rgb, torch.from_numpy(g[f"{tag}_rgb_free"]), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(sig, torch.from_numpy(g[f"{tag}_sigma_free"]), rtol=1e-5, atol=2e-6)
+        so = orc.mlp_forward_embedded(P, e_xyz, only_sigma=True)
+        torch.testing.assert_close(so, torch.from_numpy(g[f"{tag}_only_sigma"]), rtol=1e-5, atol=1e-6)
