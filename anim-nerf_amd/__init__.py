@@ -4,7 +4,7 @@ Python host classes keep the reference's names and signatures (AnimNeRF, VolumeR
 Embedding, SMPL/create, gen_rays, batched_inference); all per-ray and per-point work runs in
 libanimnerf_hip.so (hand-written HIP for gfx950, C ABI in include/animnerf_hip.h).
 """
-from . import _lib, data, drivers, mlp, ops, synthetic               # noqa: F401
+from . import _lib, data, mlp, ops, synthetic                        # noqa: F401
 from .anim_nerf import AnimNeRF, batch_transform                      # noqa: F401
 from .body_model import SMPL, create                                  # noqa: F401
 from .nerf import Embedding, NeRF                                     # noqa: F401
@@ -14,4 +14,11 @@ from .render import (batched_inference, gather_ray_shards, max_over_ranks, rende
 from .training import BodyModelParams, GradientReducer, TrainHParams, Trainer, allreduce_gradients, compute_loss   # noqa: F401
 from .volume_rendering import VolumeRenderer                          # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
+
+
+def __getattr__(name):              # `python -m anim_nerf_amd.drivers` must find the module un-imported: load it lazily
+    if name == "drivers":
+        import importlib
+        return importlib.import_module(".drivers", __name__)
+    raise AttributeError(name)
