@@ -28,37 +28,69 @@ def _encode(xyz: torch.Tensor, n_freqs: int = 10) -> torch.Tensor:
     return torch.cat(cols, -1)
 
 
-class MLPFunction(torch.autograd.Function):
-    """out[n,4] = (r,g,b,sigma) (or sigma[n]) = NeRF(pts[n,4]); differentiable w.r.t. the 22 parameter tensors."""
+_PACKS = {}
 
-    PAD = 4096      # compacted row count is rounded up to this (keeps the split-K weight-gradient GEMMs regular)
-    FUSED_BACKWARD = True    # activation-gradient chain in one HIP kernel (False: the library-GEMM chain, kept as a cross-check)
+
+def _cached_pack(params, mode_id, backward):
+    """Fragment-ordered weight pack for the forward / activation-gradient kernels, rebuilt only when a parameter changed:
+    one pack per network and optimiser step, not one per ray chunk.  Keyed by the parameter OBJECTS (weak references: a
+    new tensor that happens to reuse a freed one's address and version counter must not hit) and their version counters."""
+    import weakref
+    key = (mode_id, backward, tuple(id(p) for p in params))
+    ver = tuple(p._version for p in params)
+    hit = _PACKS.get(key)
+    if hit is None or hit[0] != ver or any(r() is not p for r, p in zip(hit[2], params)):
+        if len(_PACKS) > 64:
+            _PACKS.clear()
+        hit = (ver, ops.mlp_pack(dict(zip(PARAM_KEYS, params)), mode_id, backward=backward), [weakref.ref(p) for p in params])
+        _PACKS[key] = hit
+    return hit[1]
+
+
+PARAM_SHAPES = ([s for i in range(8) for s in ((256, 63 if i == 0 else 319 if i == 4 else 256), (256,))]
+                + [(1, 256), (1,), (256, 256), (256,), (128, 256), (128,), (3, 128), (3,)])
+
+
+class MLPFunction(torch.autograd.Function):
+    """out[n,4] = (r,g,b,sigma) (or sigma[n]) = NeRF(pts[n,4]); differentiable w.r.t. the 22 parameter tensors (and the
+    points).  Forward, activation gradients and weight gradients are three hand-written HIP kernels
+    (anr_mlp_forward_save, anr_mlp_backward, anr_mlp_wgrad); `LIBRARY_GEMMS = True` swaps the last two for the chain of
+    library GEMMs they replaced (a cross-check for the tests)."""
+
+    PAD = 64                 # rows are padded to a multiple of this (anr_mlp_wgrad's slab granularity): invalid points, zero gradient
+    LIBRARY_GEMMS = False
 
     @staticmethod
     def forward(ctx, pts, sigma_only, mode_id, only_valid, *params):
-        pack = ops.mlp_pack(dict(zip(PARAM_KEYS, params)), mode_id)
+        pack = _cached_pack(params, mode_id, False)
         pts = pts.detach()
         n = pts.shape[0]
         ctx.sigma_only = sigma_only
         ctx.mode_id = mode_id
         ctx.n_full = n
         idx = None
+        rows = n
         if only_valid:
             # samples outside dis_threshold have sigma = -1e5 and composite weight exactly 0: neither their outputs nor
             # their (exactly zero) gradients are needed.  Forward, saved activations and backward run on the rest.
             index, count = ops.compact_valid(pts)
-            cnt = int(count.item())                                   # the backward GEMM shapes need it on the host
+            cnt = int(count.item())                                   # the row counts of the saved tensors need it on the host
             if cnt < n:
-                n_pad = max(-(-cnt // MLPFunction.PAD), 1) * MLPFunction.PAD
-                idx = index[:cnt].long()
-                pts_c = pts.new_zeros(n_pad, 4)                       # padding rows: valid = 0, zero upstream gradient
-                pts_c[:cnt] = pts.index_select(0, idx)
-                pts = pts_c
+                # the compaction hands blocks out by atomic ticket: sort, so that the rows (and with them the order of every
+                # split-K sum downstream) are the same on every run
+                idx = torch.sort(index[:cnt]).values.long()
+                rows = cnt
+        n_pad = max(-(-rows // MLPFunction.PAD), 1) * MLPFunction.PAD
+        if idx is not None or n_pad != n:
+            pts_c = pts.new_zeros(n_pad, 4)                           # padding rows: valid = 0, zero upstream gradient
+            pts_c[:rows] = pts if idx is None else pts.index_select(0, idx)
+            pts = pts_c
         out, act = ops.mlp_forward_save(pack, mode_id, pts, sigma_only)
+        ctx.rows = rows
         if idx is None:
             ctx.save_for_backward(pts, out, act, *params)
             ctx.compacted = False
-            return out
+            return out[:n] if n_pad != n else out
         ctx.save_for_backward(pts, out, act, idx, *params)
         ctx.compacted = True
         full = out.new_zeros((n,) if sigma_only else (n, 4))
@@ -66,7 +98,7 @@ class MLPFunction(torch.autograd.Function):
             full.fill_(-1e5)
         else:
             full[:, 3] = -1e5
-        full[idx] = out[:idx.shape[0]]
+        full[idx] = out[:rows]
         return full
 
     @staticmethod
@@ -75,124 +107,114 @@ class MLPFunction(torch.autograd.Function):
         idx = None
         if ctx.compacted:
             pts, out, act, idx, *params = ctx.saved_tensors
-            g_c = g.new_zeros((pts.shape[0],) + tuple(g.shape[1:]))
-            g_c[:idx.shape[0]] = g.index_select(0, idx)
-            g = g_c
         else:
             pts, out, act, *params = ctx.saved_tensors
+        n, rows = pts.shape[0], ctx.rows
+        if idx is not None or n != g.shape[0]:                      # compacted and / or padded rows
+            g_c = g.new_zeros((n,) + tuple(g.shape[1:]))
+            g_c[:rows] = g if idx is None else g.index_select(0, idx)
+            g = g_c
         dt = act.dtype                                              # fp32 (parity mode) or bf16 (mixed precision)
-        class _Lazy(dict):                                          # parameters in the compute dtype, cast on first use
-            def __missing__(self, k):
-                p = params[PARAM_KEYS.index(k)]
-                self[k] = p if p.dtype == dt else p.to(dt)
-                return self[k]
-        P = _Lazy()
-        n = pts.shape[0]
-        H = act[:, :2048].view(n, 8, 256)
-        grads = {}
-
-        # dW = dY^T X is a [256 x n] x [n x 256] product with n ~ 1e6: the library picks one tile per 64x64 of the
-        # output (16 workgroups on a 256-CU chip), so the reduction dimension is split by hand into S batches
-        # (S x 16 workgroups) and the S partial products are summed.
-        S = 1
-        while S < 128 and n % (2 * S) == 0 and n // (2 * S) >= 256:
-            S *= 2
-
-        def wgrad(dy, x):                                            # accumulated and returned in fp32
-            a = dy.reshape(S, n // S, dy.shape[1]).transpose(1, 2)
-            b = x.reshape(S, n // S, x.shape[1])
-            part = torch.bmm(a, b) if dt == torch.float32 else torch.bmm(a, b, out_dtype=torch.float32)
-            return part.sum(0) if S > 1 else part[0]
-
-        def relu_bwd(dy, h):                                         # dy * (h > 0) in one kernel
-            return torch.ops.aten.threshold_backward(dy, h, 0)
-
         valid = (pts[:, 3] >= 1.0).to(g.dtype)                       # sigma is the constant -1e5 where invalid
-        enc = ops.encode(pts, dt)
         want_pts = ctx.needs_input_grad[0]
-        d_enc = None
-        if MLPFunction.FUSED_BACKWARD:
-            # ONE kernel for the whole activation-gradient chain (csrc/mlp_bwd.hip); the weight gradients below are
-            # plain GEMMs between its output columns and the saved activations
-            g4 = torch.zeros(n, 4, dtype=torch.float32, device=g.device)
-            if ctx.sigma_only:
-                g4[:, 3] = g.reshape(n) * valid
-            else:
-                rgb = out[:, :3]
-                g4[:, :3] = g[:, :3] * rgb * (1 - rgb)                # sigmoid'
-                g4[:, 3] = g[:, 3] * valid
-            bpack = ops.mlp_pack(dict(zip(PARAM_KEYS, params)), ctx.mode_id, backward=True)
-            dact = ops.mlp_backward(bpack, ctx.mode_id, g4, act, sigma_only=ctx.sigma_only)
-            g_sig = g4[:, 3].to(dt)
-            # every bias gradient is a column sum of dact: one reduction for all of them
-            colsum = (dact[:, :2048] if ctx.sigma_only else dact).sum(0, dtype=torch.float32)
-            if not ctx.sigma_only:
-                d_rgb = g4[:, :3].to(dt)
-                G, F = act[:, 2304:2432], act[:, 2048:2304]
-                dG, dF = dact[:, 2304:2432], dact[:, 2048:2304]
-                grads["rgb.0.weight"] = wgrad(d_rgb, G)
-                grads["rgb.0.bias"] = g4[:, :3].sum(0)
-                grads["dir_encoding.0.weight"] = wgrad(dG, F)
-                grads["dir_encoding.0.bias"] = colsum[2304:2432]
-                grads["xyz_encoding_final.weight"] = wgrad(dF, H[:, 7])
-                grads["xyz_encoding_final.bias"] = colsum[2048:2304]
-            grads["sigma.weight"] = wgrad(torch.stack([g_sig, torch.zeros_like(g_sig)], 1), H[:, 7])[:1]
-            grads["sigma.bias"] = g_sig.sum(dtype=torch.float32).reshape(1)
-            D = dact[:, :2048].view(n, 8, 256)
-            for l in range(8, 0, -1):
-                dpre = D[:, l - 1]
-                inp = enc if l == 1 else torch.cat([enc, H[:, l - 2]], -1) if l == 5 else H[:, l - 2]
-                grads[f"xyz_encoding_{l}.0.weight"] = wgrad(dpre, inp)
-                grads[f"xyz_encoding_{l}.0.bias"] = colsum[256 * (l - 1):256 * l]
-                if want_pts and l in (1, 5):
-                    t = (dpre @ P[f"xyz_encoding_{l}.0.weight"][:, :63]).float()
-                    d_enc = t if d_enc is None else d_enc + t
+        g4 = torch.zeros(n, 4, dtype=torch.float32, device=g.device)
+        if ctx.sigma_only:
+            g4[:, 3] = g.reshape(n) * valid
         else:
+            rgb = out[:, :3]
+            g4[:, :3] = g[:, :3] * rgb * (1 - rgb)                    # sigmoid'
+            g4[:, 3] = g[:, 3] * valid
+        if MLPFunction.LIBRARY_GEMMS:
+            grads, d_enc = _library_backward(ctx, params, pts, act, g4, want_pts)
+        else:
+            # activation gradients: ONE kernel for the whole chain (csrc/mlp_bwd.hip); weight + bias gradients: split-K MFMA
+            # GEMMs between its output columns, the saved activations and the encoding matrix (csrc/mlp_wgrad.hip)
+            dact = ops.mlp_backward(_cached_pack(params, ctx.mode_id, True), ctx.mode_id, g4, act, sigma_only=ctx.sigma_only)
+            flat = ops.mlp_wgrad(ctx.mode_id, act, dact, ops.encode64(pts, dt), g4, sigma_only=ctx.sigma_only)
+            grads, o = {}, 0
+            for k, shp in zip(PARAM_KEYS, PARAM_SHAPES):
+                cnt = 1
+                for d in shp:
+                    cnt *= d
+                grads[k] = flat[o:o + cnt].view(shp)
+                o += cnt
             if ctx.sigma_only:
-                g_sig = (g.reshape(n) * valid).to(dt)
-                dh = g_sig[:, None] * P["sigma.weight"]
-            else:
-                g_sig = (g[:, 3] * valid).to(dt)
-                rgb = out[:, :3]
-                d_rgb = (g[:, :3] * rgb * (1 - rgb)).to(dt)               # sigmoid'
-                G = act[:, 2304:2432]
-                F = act[:, 2048:2304]
-                grads["rgb.0.weight"] = wgrad(d_rgb, G)
-                grads["rgb.0.bias"] = d_rgb.sum(0, dtype=torch.float32)
-                dG = relu_bwd(d_rgb @ P["rgb.0.weight"], G)
-                grads["dir_encoding.0.weight"] = wgrad(dG, F)
-                grads["dir_encoding.0.bias"] = dG.sum(0, dtype=torch.float32)
-                dF = dG @ P["dir_encoding.0.weight"]
-                grads["xyz_encoding_final.weight"] = wgrad(dF, H[:, 7])
-                grads["xyz_encoding_final.bias"] = dF.sum(0, dtype=torch.float32)
-                dh = torch.addmm(g_sig[:, None] * P["sigma.weight"], dF, P["xyz_encoding_final.weight"])
-            # (a 1-row operand sends the library down a GEMV path that costs ~11 ms of host time: pad to 2 rows)
-            grads["sigma.weight"] = wgrad(torch.stack([g_sig, torch.zeros_like(g_sig)], 1), H[:, 7])[:1]
-            grads["sigma.bias"] = g_sig.sum(dtype=torch.float32).reshape(1)
-            for l in range(8, 0, -1):
-                dpre = relu_bwd(dh, H[:, l - 1])
-                inp = enc if l == 1 else torch.cat([enc, H[:, l - 2]], -1) if l == 5 else H[:, l - 2]
-                grads[f"xyz_encoding_{l}.0.weight"] = wgrad(dpre, inp)
-                grads[f"xyz_encoding_{l}.0.bias"] = dpre.sum(0, dtype=torch.float32)
-                W = P[f"xyz_encoding_{l}.0.weight"]
-                if l > 1:
-                    dh = dpre @ (W[:, 63:] if l == 5 else W)
-                if want_pts and l in (1, 5):
-                    t = (dpre @ W[:, :63]).float()
+                for k in PARAM_KEYS[18:]:
+                    grads[k] = None
+            d_enc = None
+            if want_pts:                                            # pose refinement: through the two encoding inputs
+                for l in (1, 5):
+                    W = params[PARAM_KEYS.index(f"xyz_encoding_{l}.0.weight")][:, :63].to(dt)
+                    t = (dact[:, 256 * (l - 1):256 * l] @ W).float()
                     d_enc = t if d_enc is None else d_enc + t
         d_pts = None
         if want_pts:                                                # through x -> (x, sin 2^k x, cos 2^k x)
             d_pts = ops.encode_backward(pts, d_enc.contiguous())
             if idx is not None:
                 full = d_pts.new_zeros(ctx.n_full, 4)
-                full[idx] = d_pts[:idx.shape[0]]
+                full[idx] = d_pts[:rows]
                 d_pts = full
+            elif d_pts.shape[0] != ctx.n_full:
+                d_pts = d_pts[:ctx.n_full]
         out_grads = []
         for i, k in enumerate(PARAM_KEYS):
             need = ctx.needs_input_grad[4 + i]
             gk = grads.get(k) if need else None
             out_grads.append(None if gk is None else gk.to(params[i].dtype).reshape(params[i].shape))
         return (d_pts, None, None, None, *out_grads)
+
+
+def _library_backward(ctx, params, pts, act, g4, want_pts):
+    """The backward of the MLP as the chain of library GEMMs the hand-written kernels replaced (dX = dY W, dW = dY^T X,
+    mask kernels in between).  Cross-check only (MLPFunction.LIBRARY_GEMMS): the tests hold the kernels to it."""
+    dt = act.dtype
+    n = pts.shape[0]
+
+    class _Lazy(dict):                                              # parameters in the compute dtype, cast on first use
+        def __missing__(self, k):
+            p = params[PARAM_KEYS.index(k)]
+            self[k] = p if p.dtype == dt else p.to(dt)
+            return self[k]
+    P = _Lazy()
+    H = act[:, :2048].view(n, 8, 256)
+    grads = {}
+
+    def wgrad(dy, x):                                               # accumulated and returned in fp32
+        return dy.float().t() @ x.float()
+
+    def relu_bwd(dy, h):
+        return torch.ops.aten.threshold_backward(dy, h, 0)
+    enc = ops.encode(pts, dt)
+    d_enc = None
+    g_sig = g4[:, 3].to(dt)
+    if ctx.sigma_only:
+        dh = g_sig[:, None] * P["sigma.weight"]
+    else:
+        d_rgb = g4[:, :3].to(dt)
+        G, F = act[:, 2304:2432], act[:, 2048:2304]
+        grads["rgb.0.weight"] = wgrad(d_rgb, G)
+        grads["rgb.0.bias"] = g4[:, :3].sum(0)
+        dG = relu_bwd(d_rgb @ P["rgb.0.weight"], G)
+        grads["dir_encoding.0.weight"] = wgrad(dG, F)
+        grads["dir_encoding.0.bias"] = dG.sum(0, dtype=torch.float32)
+        dF = dG @ P["dir_encoding.0.weight"]
+        grads["xyz_encoding_final.weight"] = wgrad(dF, H[:, 7])
+        grads["xyz_encoding_final.bias"] = dF.sum(0, dtype=torch.float32)
+        dh = torch.addmm(g_sig[:, None] * P["sigma.weight"], dF, P["xyz_encoding_final.weight"])
+    grads["sigma.weight"] = wgrad(g_sig[:, None], H[:, 7])
+    grads["sigma.bias"] = g4[:, 3].sum().reshape(1)
+    for l in range(8, 0, -1):
+        dpre = relu_bwd(dh, H[:, l - 1])
+        inp = enc if l == 1 else torch.cat([enc, H[:, l - 2]], -1) if l == 5 else H[:, l - 2]
+        grads[f"xyz_encoding_{l}.0.weight"] = wgrad(dpre, inp)
+        grads[f"xyz_encoding_{l}.0.bias"] = dpre.sum(0, dtype=torch.float32)
+        W = P[f"xyz_encoding_{l}.0.weight"]
+        if l > 1:
+            dh = dpre @ (W[:, 63:] if l == 5 else W)
+        if want_pts and l in (1, 5):
+            t = (dpre @ W[:, :63]).float()
+            d_enc = t if d_enc is None else d_enc + t
+    return grads, d_enc
 
 
 def _splitk_tn(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:

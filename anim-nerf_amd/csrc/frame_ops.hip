@@ -252,12 +252,14 @@ extern "C" int anr_points_from_rays(const float* rays, int ray_stride, const flo
 // chain rule back through it.  The forward pass never materialises this (the MLP kernel encodes in registers).
 namespace anr {
 
-template <typename T>
+// COLS = 63 (the reference's matrix) or 64 (one zero column of padding: the layout anr_mlp_wgrad stages)
+template <typename T, int COLS = 63>
 __global__ __launch_bounds__(256) void encode_kernel(const float* __restrict__ pts, int stride, int64_t n, T* __restrict__ enc) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float x[3] = {pts[i * stride], pts[i * stride + 1], pts[i * stride + 2]};
-    T* row = enc + i * 63;
+    T* row = enc + i * COLS;
+    if (COLS > 63) row[63] = (T)0.0f;
 #pragma unroll
     for (int d = 0; d < 3; ++d) row[d] = (T)x[d];
     for (int k = 0; k < 10; ++k) {
@@ -300,6 +302,17 @@ extern "C" int anr_encode(const float* pts, int pts_stride, int64_t n, int bf16_
     else
         hipLaunchKernelGGL(anr::encode_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (float*)enc_out);
     return anr::check_launch("anr_encode");
+}
+
+extern "C" int anr_encode64(const float* pts, int pts_stride, int64_t n, int bf16_out, void* enc_out, void* stream) {
+    ANR_REQUIRE(pts && enc_out, ANR_E_BADARG, "anr_encode64: null pointer");
+    ANR_REQUIRE(n > 0 && pts_stride >= 3, ANR_E_BADARG, "anr_encode64: n=%lld stride=%d", (long long)n, pts_stride);
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (bf16_out)
+        hipLaunchKernelGGL((anr::encode_kernel<__bf16, 64>), grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (__bf16*)enc_out);
+    else
+        hipLaunchKernelGGL((anr::encode_kernel<float, 64>), grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (float*)enc_out);
+    return anr::check_launch("anr_encode64");
 }
 
 extern "C" int anr_encode_backward(const float* pts, int pts_stride, const float* d_enc, int64_t n, float* d_pts_out,

@@ -1,0 +1,409 @@
+// Weight gradients of the fused MLP (training, a16): what autograd computes for every nn.Linear of
+// models/nerf.py:129-175 —  dW_l = dact_l^T . in_l,  db_l = column sums of dact_l — from the two [points][2432]
+// matrices the training forward (anr_mlp_forward_save: activations) and the activation-gradient kernel
+// (anr_mlp_backward: pre-activation gradients) leave behind, plus the encoding matrix enc[points][64].
+//
+// The contraction runs over the POINTS, i.e. over the slow index of both row-major operands, so an MFMA fragment
+// (one feature, 8 consecutive points per lane) is a column walk.  gfx950's transposing LDS read does it in hardware:
+// row slabs are copied L2 -> LDS as they lie in memory (LDS-DMA, 16 B per lane, rows padded to a pitch = 64 mod 256 bytes
+// so that the four rows one ds_read_b64_tr_b16 touches sit in different bank windows), and each fragment is two
+// ds_read_b64_tr_b16 (lane s of a 16-lane group points at row k0 + s/4, features f0 + 4 (s%4); it receives feature
+// f0 + s of rows k0 .. k0+3).  fp32 (parity mode): v_mfma_f32_32x32x2_f32 takes one point per half-wave and its
+// fragment is a plain row read.
+//
+// Work split: a task = (one GEMM, one slice of the points); 8 wavefronts share the staged slabs and own a
+// (TM x TN) block of 32x32 accumulator tiles each (256x256: 2x4 per wave, 128 accumulator registers).  Partial products
+// go to a workspace and a second kernel adds the slices in a fixed order (deterministic, no float atomics) while
+// scattering into the PyTorch [out][in] layouts; the same kernel pair produces the bias gradients and the two
+// skinny heads (sigma 1x256, rgb 3x128) as weighted column sums.
+#include "mlp_core.h"
+
+namespace anr {
+
+constexpr int WG_WAVES = 8;
+constexpr int WG_THREADS = WG_WAVES * 64;
+constexpr int WG_NBUF = 3;
+constexpr int WG_MAX_GEMMS = 8;
+
+struct WgradGemm {
+    int a_col;        // first column of dact (the M = out-feature side)
+    int b_src;        // 0: act, 1: enc
+    int b_col;        // first column of the source (the N = in-feature side)
+    int out_off;      // float offset of this GEMM's [S][M][N] block in the partial workspace
+};
+struct WgradArgs {
+    WgradGemm g[WG_MAX_GEMMS];
+    int n_gemms;
+    int splits;                   // S
+    int rows_per_split;           // multiple of the stage rows
+};
+
+template <bool BF16> struct WgCfg;
+template <> struct WgCfg<true> {
+    using T = __bf16;
+    static constexpr int SR = 32;                 // rows (points) per LDS stage
+    static constexpr int KSTEP = 16;              // rows per MFMA
+    static constexpr int pitch(int cols) { return cols * 2 + 64; }          // = 64 (mod 256) for cols in {64, 128, 256}
+};
+template <> struct WgCfg<false> {
+    using T = float;
+    static constexpr int SR = 16;
+    static constexpr int KSTEP = 2;
+    static constexpr int pitch(int cols) { return cols * 4; }
+};
+
+template <bool BF16, int TM, int TN, int WM>
+__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __restrict__ dact, const char* __restrict__ act,
+                                                              const char* __restrict__ enc, int64_t n, WgradArgs args,
+                                                              float* __restrict__ partial) {
+    using C = WgCfg<BF16>;
+    using T = typename C::T;
+    constexpr int WN = WG_WAVES / WM;
+    constexpr int M = TM * 32 * WM, N = TN * 32 * WN;
+    constexpr int ESZ = sizeof(T);
+    constexpr int PA = C::pitch(M), PB = C::pitch(N);
+    constexpr int SR = C::SR;
+    constexpr int STAGE_A = SR * PA, STAGE_B = SR * PB;
+    constexpr int PIECES = (STAGE_A + STAGE_B + 1023) / 1024;
+    constexpr int PPW = (PIECES + WG_WAVES - 1) / WG_WAVES;           // DMA pieces per wave and stage (padded: uniform waits)
+    constexpr int STAGE = PPW * WG_WAVES * 1024;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int gi = blockIdx.x / args.splits, sp = blockIdx.x % args.splits;
+    const WgradGemm gm = args.g[gi];
+    const int64_t r0 = (int64_t)sp * args.rows_per_split;
+    int64_t r1 = r0 + args.rows_per_split;
+    if (r1 > n) r1 = n;
+    const int n_stages = r1 > r0 ? (int)((r1 - r0) / SR) : 0;
+    const int64_t a_pitch = (int64_t)ACT_COLS * ESZ;
+    const char* b_base = gm.b_src ? enc : act;
+    const int64_t b_pitch = (gm.b_src ? 64 : ACT_COLS) * (int64_t)ESZ;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+    auto issue = [&](int st) {                                  // slab of stage st -> ring buffer st % NBUF
+        const int64_t row0 = r0 + (int64_t)st * SR;
+        const unsigned buf = lds0 + (unsigned)(st % WG_NBUF) * STAGE;
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) {
+            const int piece = wave + p * WG_WAVES;
+            const int q = piece * 1024 + lane * 16;               // byte position inside the stage image
+            const char* src;
+            if (q < STAGE_A) {
+                const int row = q / PA, off = q % PA;
+                src = dact + (row0 + row) * a_pitch + (int64_t)gm.a_col * ESZ + (off < M * ESZ ? off : 0);
+            } else if (q < STAGE_A + STAGE_B) {
+                const int row = (q - STAGE_A) / PB, off = (q - STAGE_A) % PB;
+                src = b_base + (row0 + row) * b_pitch + (int64_t)gm.b_col * ESZ + (off < N * ESZ ? off : 0);
+            } else {
+                src = dact + row0 * a_pitch;                        // padding piece: lands behind the images, never read
+            }
+            dma16(src, buf + piece * 1024);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+
+    const int wm = wave % WM, wn = wave / WM;
+    const int m_base = wm * TM * 32, n_base = wn * TN * 32;
+    if (n_stages > 0) issue(0);
+    if (n_stages > 1) issue(1);
+    for (int st = 0; st < n_stages; ++st) {
+        if (st + 1 < n_stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                          // stage st landed everywhere; stage st-1 is no longer read
+        if (st + 2 < n_stages) issue(st + 2);
+        const char* A = lds + (st % WG_NBUF) * STAGE;
+        const char* B = A + STAGE_A;
+        if constexpr (BF16) {
+            const int grp = lane >> 4, s = lane & 15, h = lane >> 5;
+            // lane's row / feature offset inside a [16 rows][32 features] fragment source block
+            const int frow = 4 * h + (s >> 2), fcol = 16 * (grp & 1) + 4 * (s & 3);
+#pragma unroll
+            for (int ks = 0; ks < SR / 16; ++ks) {
+                bf16x8 fa[TM], fb[TN];
+                uint2 alo[TM], ahi[TM], blo[TN], bhi[TN];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const unsigned ad = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)A +
+                                        (ks * 16 + frow) * PA + (m_base + a * 32 + fcol) * 2;
+                    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                                 : "=&v"(alo[a]), "=&v"(ahi[a]) : "v"(ad), "n"(8 * PA) : "memory");
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const unsigned ad = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)B +
+                                        (ks * 16 + frow) * PB + (n_base + b * 32 + fcol) * 2;
+                    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                                 : "=&v"(blo[b]), "=&v"(bhi[b]) : "v"(ad), "n"(8 * PB) : "memory");
+                }
+                // one wait for the whole batch; the operands tie every fragment to it (the reads are opaque to hipcc)
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[a]), "+v"(ahi[a])::"memory");
+                    fa[a] = __builtin_bit_cast(bf16x8, uint4{alo[a].x, alo[a].y, ahi[a].x, ahi[a].y});
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[b]), "+v"(bhi[b])::"memory");
+                    fb[b] = __builtin_bit_cast(bf16x8, uint4{blo[b].x, blo[b].y, bhi[b].x, bhi[b].y});
+                }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+        } else {
+            const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+            for (int ks = 0; ks < SR / 2; ++ks) {
+                float fa[TM], fb[TN];
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+                    fa[a] = *reinterpret_cast<const float*>(A + (ks * 2 + h) * PA + (m_base + a * 32 + i) * 4);
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    fb[b] = *reinterpret_cast<const float*>(B + (ks * 2 + h) * PB + (n_base + b * 32 + i) * 4);
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+    // partial[gemm][split][M][N]; accumulator register e of lane: row (e&3) + 8 (e>>2) + 4 (lane>>5), column lane&31
+    float* out = partial + gm.out_off + (int64_t)sp * M * N;
+    const int col = lane & 31, rofs = 4 * (lane >> 5);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                out[(int64_t)(m_base + a * 32 + (e & 3) + 8 * (e >> 2) + rofs) * N + n_base + b * 32 + col] = acc[a][b][e];
+}
+
+// ---- column sums: every bias gradient (columns of dact), and the skinny heads as weighted column sums:
+//   d sigma.weight[c] = sum_p g4[p][3] h8[p][c]     d rgb.weight[j][c] = sum_p g4[p][j] G[p][c]     (+ their biases)
+// One thread per output column of a slice of rows; slices are added by the reduction kernel.
+constexpr int CS_COLS = ACT_COLS + 256 + 3 * 128 + 4;       // dact columns | sigma.weight | rgb.weight | rgb.bias(3), sigma.bias
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dact, const T* __restrict__ act,
+                                                     const float* __restrict__ g4, int64_t n, int rows_per_slice,
+                                                     int sigma_only, float* __restrict__ partial) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice;
+    int64_t r1 = r0 + rows_per_slice;
+    if (r1 > n) r1 = n;
+    if (c >= CS_COLS) return;
+    float s = 0.0f;
+    if (c < ACT_COLS) {
+        if (!(sigma_only && c >= 2048))
+            for (int64_t r = r0; r < r1; ++r) s += (float)dact[r * ACT_COLS + c];
+    } else if (c < ACT_COLS + 256) {
+        const int k = 1792 + (c - ACT_COLS);                         // h8
+        for (int64_t r = r0; r < r1; ++r) s += g4[r * 4 + 3] * (float)act[r * ACT_COLS + k];
+    } else if (c < ACT_COLS + 256 + 384) {
+        const int j = (c - ACT_COLS - 256) / 128, k = 2304 + (c - ACT_COLS - 256) % 128;
+        if (!sigma_only)
+            for (int64_t r = r0; r < r1; ++r) s += g4[r * 4 + j] * (float)act[r * ACT_COLS + k];
+    } else {
+        const int j = c - (ACT_COLS + 256 + 384);
+        if (!(sigma_only && j < 3))
+            for (int64_t r = r0; r < r1; ++r) s += g4[r * 4 + j];
+    }
+    partial[(int64_t)blockIdx.y * CS_COLS + c] = s;
+}
+
+// ---- reduction over the slices + scatter into the 22 gradient tensors (flat, in the order of anr_mlp_wgrad_layout)
+struct WgradSeg {
+    int dst;          // first float of the segment in the flat gradient
+    int rows, cols;   // segment shape in the destination (a column window of a [rows][dst_pitch] matrix)
+    int dst_pitch;
+    int src_off;      // float offset in the workspace
+    int src_pitch;    // floats per source row
+    int src_slice;    // floats between consecutive slices
+    int slices;
+};
+struct WgradSegs { WgradSeg s[32]; int n; };
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradSegs segs, const float* __restrict__ ws, float* __restrict__ grads) {
+    const WgradSeg sg = segs.s[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= sg.rows * sg.cols) return;
+    const int r = i / sg.cols, c = i % sg.cols;
+    const float* src = ws + sg.src_off + (int64_t)r * sg.src_pitch + c;
+    float s = 0.0f;
+    for (int k = 0; k < sg.slices; ++k) s += src[(int64_t)k * sg.src_slice];
+    grads[sg.dst + (int64_t)r * sg.dst_pitch + c] = s;
+}
+
+}  // namespace anr
+
+using namespace anr;
+
+// flat gradient layout = the reference's parameter order used throughout (autograd.PARAM_KEYS):
+// W1[256x63] b1 W2 b2 W3 b3 W4 b4 W5[256x319] b5 W6 b6 W7 b7 W8 b8 | sigma.w[256] sigma.b[1] | final.w final.b | dir.w[128x256] dir.b | rgb.w[3x128] rgb.b[3]
+namespace {
+struct Layout {
+    int w[8], b[8], sw, sb, fw, fb, dw, db, rw, rb, total;
+    Layout() {
+        int o = 0;
+        for (int l = 0; l < 8; ++l) {
+            const int in = l == 0 ? 63 : l == 4 ? 319 : 256;
+            w[l] = o; o += 256 * in;
+            b[l] = o; o += 256;
+        }
+        sw = o; o += 256; sb = o; o += 1;
+        fw = o; o += 65536; fb = o; o += 256;
+        dw = o; o += 128 * 256; db = o; o += 128;
+        rw = o; o += 384; rb = o; o += 3;
+        total = o;
+    }
+};
+const Layout& layout() { static Layout L; return L; }
+
+int splits_for(int64_t n, int stage_rows, int gemms) {
+    // one workgroup per CU (the LDS ring admits one) over the GEMMs of one shape, at least 4 stages per task
+    int64_t want = (256 + gemms - 1) / gemms;
+    int64_t most = n / (4 * stage_rows);
+    int64_t s = want < most ? want : most;
+    return (int)(s < 1 ? 1 : s);
+}
+}  // namespace
+
+extern "C" int64_t anr_mlp_wgrad_floats(void) { return layout().total; }
+
+extern "C" int64_t anr_mlp_wgrad_ws_floats(int64_t n) {
+    // upper bound for any n: three GEMM shapes at their maximum split counts + the column-sum slices
+    (void)n;
+    return (int64_t)8 * 37 * 65536 + (int64_t)2 * 64 * 256 * 64 + (int64_t)256 * 128 * 256 + (int64_t)1024 * CS_COLS + 1024;
+}
+
+template <bool BF16>
+static int wgrad_launch(const void* act, const void* dact, const void* enc, const float* g4, int64_t n, int sigma_only,
+                        float* ws, float* grads, hipStream_t st) {
+    using C = WgCfg<BF16>;
+    const Layout& L = layout();
+    WgradSegs segs{};
+    auto seg = [&](int dst, int rows, int cols, int dst_pitch, int src_off, int src_pitch, int src_slice, int slices) {
+        segs.s[segs.n++] = WgradSeg{dst, rows, cols, dst_pitch, src_off, src_pitch, src_slice, slices};
+    };
+    int ws_off = 0;
+    const char* A = reinterpret_cast<const char*>(act);
+    const char* D = reinterpret_cast<const char*>(dact);
+    const char* E = reinterpret_cast<const char*>(enc);
+    auto lds_bytes = [](int M, int N) {
+        const int stage = C::SR * (C::pitch(M) + C::pitch(N));
+        const int pieces = (stage + 1023) / 1024, ppw = (pieces + WG_WAVES - 1) / WG_WAVES;
+        return WG_NBUF * ppw * WG_WAVES * 1024;
+    };
+    // ---- 256 x 256: trunk layers 2..8 (hidden part of layer 5) and xyz_encoding_final
+    {
+        WgradArgs a{};
+        const int n_g = sigma_only ? 7 : 8;
+        a.splits = splits_for(n, C::SR, n_g);
+        a.rows_per_split = (int)(((n + a.splits - 1) / a.splits + C::SR - 1) / C::SR * C::SR);
+        for (int l = 2; l <= 8; ++l) {
+            a.g[a.n_gemms] = WgradGemm{256 * (l - 1), 0, 256 * (l - 2), ws_off};
+            seg(L.w[l - 1] + (l == 5 ? 63 : 0), 256, 256, l == 5 ? 319 : 256, ws_off, 256, 65536, a.splits);
+            ws_off += a.splits * 65536;
+            ++a.n_gemms;
+        }
+        if (!sigma_only) {
+            a.g[a.n_gemms] = WgradGemm{2048, 0, 1792, ws_off};
+            seg(L.fw, 256, 256, 256, ws_off, 256, 65536, a.splits);
+            ws_off += a.splits * 65536;
+            ++a.n_gemms;
+        }
+        auto k = wgrad_kernel<BF16, 2, 4, 4>;
+        const int lds = lds_bytes(256, 256);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k, dim3(a.n_gemms * a.splits), dim3(WG_THREADS), lds, st, D, A, E, n, a, ws);
+    }
+    // ---- 256 x 64: the encoding columns of layers 1 and 5
+    {
+        WgradArgs a{};
+        a.splits = splits_for(n, C::SR, 2);
+        if (a.splits > 64) a.splits = 64;
+        a.rows_per_split = (int)(((n + a.splits - 1) / a.splits + C::SR - 1) / C::SR * C::SR);
+        for (int l : {1, 5}) {
+            a.g[a.n_gemms] = WgradGemm{256 * (l - 1), 1, 0, ws_off};
+            seg(L.w[l - 1], 256, 63, l == 5 ? 319 : 63, ws_off, 64, 256 * 64, a.splits);
+            ws_off += a.splits * 256 * 64;
+            ++a.n_gemms;
+        }
+        auto k = wgrad_kernel<BF16, 1, 2, 8>;
+        const int lds = lds_bytes(256, 64);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k, dim3(a.n_gemms * a.splits), dim3(WG_THREADS), lds, st, D, A, E, n, a, ws);
+    }
+    // ---- 128 x 256: dir_encoding
+    if (!sigma_only) {
+        WgradArgs a{};
+        a.splits = splits_for(n, C::SR, 1);
+        a.rows_per_split = (int)(((n + a.splits - 1) / a.splits + C::SR - 1) / C::SR * C::SR);
+        a.g[0] = WgradGemm{2304, 0, 2048, ws_off};
+        a.n_gemms = 1;
+        seg(L.dw, 128, 256, 256, ws_off, 256, 128 * 256, a.splits);
+        ws_off += a.splits * 128 * 256;
+        auto k = wgrad_kernel<BF16, 2, 2, 2>;
+        const int lds = lds_bytes(128, 256);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k, dim3(a.n_gemms * a.splits), dim3(WG_THREADS), lds, st, D, A, E, n, a, ws);
+    }
+    // ---- column sums (biases, sigma / rgb heads)
+    {
+        int slices = (int)((n + 255) / 256);
+        if (slices > 1024) slices = 1024;
+        const int rps = (int)((n + slices - 1) / slices);
+        slices = (int)((n + rps - 1) / rps);
+        using T = typename C::T;
+        hipLaunchKernelGGL(colsum_kernel<T>, dim3((CS_COLS + 255) / 256, slices), dim3(256), 0, st,
+                           reinterpret_cast<const T*>(dact), reinterpret_cast<const T*>(act), g4, n, rps, sigma_only, ws + ws_off);
+        for (int l = 0; l < 8; ++l) seg(L.b[l], 1, 256, 256, ws_off + 256 * l, CS_COLS, CS_COLS, slices);
+        seg(L.sw, 1, 256, 256, ws_off + ACT_COLS, CS_COLS, CS_COLS, slices);
+        seg(L.sb, 1, 1, 1, ws_off + ACT_COLS + 256 + 384 + 3, CS_COLS, CS_COLS, slices);
+        if (!sigma_only) {
+            seg(L.fb, 1, 256, 256, ws_off + 2048, CS_COLS, CS_COLS, slices);
+            seg(L.db, 1, 128, 128, ws_off + 2304, CS_COLS, CS_COLS, slices);
+            seg(L.rw, 1, 384, 384, ws_off + ACT_COLS + 256, CS_COLS, CS_COLS, slices);
+            seg(L.rb, 1, 3, 3, ws_off + ACT_COLS + 256 + 384, CS_COLS, CS_COLS, slices);
+        }
+        ws_off += slices * CS_COLS;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(256, segs.n), dim3(256), 0, st, segs, ws, grads);
+    return check_launch("anr_mlp_wgrad");
+}
+
+extern "C" int anr_mlp_wgrad(int mode, const void* act, const void* dact, const void* enc, const float* g4, int64_t n,
+                             float* workspace, float* grads_out, void* stream) {
+    ANR_REQUIRE(act && dact && enc && g4 && workspace && grads_out, ANR_E_BADARG, "anr_mlp_wgrad: null pointer");
+    ANR_REQUIRE(n > 0 && n % 64 == 0, ANR_E_BADARG, "anr_mlp_wgrad: n=%lld must be a positive multiple of 64", (long long)n);
+    ANR_REQUIRE((((uintptr_t)act | (uintptr_t)dact | (uintptr_t)enc | (uintptr_t)workspace) & 15) == 0, ANR_E_ALIGN,
+                "anr_mlp_wgrad: act/dact/enc/workspace must be 16-B aligned");
+    const int so = (mode & ANR_MLP_FLAG_SIGMA_ONLY) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (so) {                                                        // tensors this call does not produce: zeros
+        const Layout& L = layout();
+        hipError_t e = hipMemsetAsync(grads_out + L.fw, 0, sizeof(float) * (L.total - L.fw), st);
+        if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    switch (mode & 0xff) {
+        case ANR_MLP_BF16: return wgrad_launch<true>(act, dact, enc, g4, n, so, workspace, grads_out, st);
+        case ANR_MLP_F32:  return wgrad_launch<false>(act, dact, enc, g4, n, so, workspace, grads_out, st);
+        default: return fail(ANR_E_BADARG, "anr_mlp_wgrad: unknown mode %d", mode);
+    }
+}

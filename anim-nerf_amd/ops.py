@@ -333,6 +333,40 @@ def encode(pts: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
     return enc
 
 
+def encode64(pts: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    """enc[n,64] = [Embedding(pts[:, :3]), 0]: the operand layout of mlp_wgrad."""
+    lib = _lib.load()
+    pts = _dev(pts, "pts")
+    n = pts.shape[0]
+    enc = torch.empty(n, 64, dtype=dtype, device=pts.device)
+    _lib.check(lib.anr_encode64(_ptr(pts), pts.shape[1], n, 1 if dtype == torch.bfloat16 else 0, _ptr(enc), _stream(enc)),
+               "anr_encode64")
+    return enc
+
+
+_WGRAD_WS = {}
+
+
+def mlp_wgrad(mode: int, act: torch.Tensor, dact: torch.Tensor, enc: torch.Tensor, g4: torch.Tensor, sigma_only: bool = False):
+    """All 22 parameter gradients of one network from the saved activations, the activation gradients, the encoding matrix
+    (encode64) and g4 = (dL/d rgb_pre, dL/d sigma): a flat fp32 tensor in the order of autograd.PARAM_KEYS (PyTorch
+    [out][in] layouts).  Hand-written split-K MFMA GEMMs (csrc/mlp_wgrad.hip); n % 64 == 0."""
+    lib = _lib.load()
+    act, dact, enc, g4 = _dev(act, "act", act.dtype), _dev(dact, "dact", act.dtype), _dev(enc, "enc", act.dtype), _dev(g4, "g4")
+    n = act.shape[0]
+    m = (mode & 0xff) | (ANR_MLP_FLAG_SIGMA_ONLY if sigma_only else 0)
+    key = (act.device.index, torch.cuda.current_stream(act.device).cuda_stream)
+    ws = _WGRAD_WS.get(key)
+    need = lib.anr_mlp_wgrad_ws_floats(n)
+    if ws is None or ws.numel() < need:                    # per-stream scratch, reused by every call (split-K partials)
+        ws = _WGRAD_WS[key] = torch.empty(need, dtype=torch.float32, device=act.device)
+    grads = torch.empty(lib.anr_mlp_wgrad_floats(), dtype=torch.float32, device=act.device)
+    with _timed("mlp_wgrad", n):
+        _lib.check(lib.anr_mlp_wgrad(m, _ptr(act), _ptr(dact), _ptr(enc), _ptr(g4), n, _ptr(ws), _ptr(grads), _stream(grads)),
+                   "anr_mlp_wgrad")
+    return grads
+
+
 def encode_backward(pts: torch.Tensor, d_enc: torch.Tensor) -> torch.Tensor:
     """d_pts[n,4] = (dL/dxyz, 0) from d_enc[n,63] (fp32)."""
     lib = _lib.load()

@@ -253,10 +253,27 @@ int anr_mlp_forward_save_indexed(const void* pack, int mode, const float* pts, c
 int anr_encode(const float* pts, int pts_stride, int64_t n, int bf16_out, void* enc_out, void* stream);
 int anr_encode_backward(const float* pts, int pts_stride, const float* d_enc, int64_t n, float* d_pts_out,
                         void* stream);
+/* ... with a 64th, zero, column: the operand layout anr_mlp_wgrad stages (16-byte rows of 8 bf16 / 4 fp32). */
+int anr_encode64(const float* pts, int pts_stride, int64_t n, int bf16_out, void* enc_out, void* stream);
 int64_t anr_mlp_bwd_pack_bytes(int mode);
 int anr_mlp_bwd_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream);
 int anr_mlp_backward(const void* bwd_pack, int mode, const float* g, const void* act, void* dact, int64_t n,
                      void* stream);
+
+/* ---- a16 (part): weight and bias gradients of the MLP -----------------------------------------------------------
+ * What autograd computes for the 22 parameter tensors of models/nerf.py:60-127 once the activation gradients exist:
+ *   dW_l = dact_l^T in_l (in_1 = enc, in_5 = [enc, h4], in_l = h_{l-1}; xyz_encoding_final, dir_encoding on h8 / the
+ *   feature; sigma and rgb from g), db_l = column sums — hand-written split-K MFMA GEMMs over the points
+ *   (csrc/mlp_wgrad.hip; ds_read_b64_tr_b16 fragments in bf16, v_mfma_f32_32x32x2_f32 in fp32), slices added in a fixed order.
+ * act, dact: [n][anr_mlp_act_cols()] from anr_mlp_forward_save / anr_mlp_backward (dtype of `mode`), enc: anr_encode64 of
+ * the same points and dtype, g[n*4] as handed to anr_mlp_backward.  n % 64 == 0 (pad with rows whose g is 0).
+ * grads_out[anr_mlp_wgrad_floats()] fp32, PyTorch [out][in] layouts back to back in the order
+ *   xyz_encoding_1..8 {weight, bias}, sigma {w, b}, xyz_encoding_final {w, b}, dir_encoding {w, b}, rgb {w, b};
+ * with ANR_MLP_FLAG_SIGMA_ONLY the tensors behind sigma.bias are zero-filled.  workspace[anr_mlp_wgrad_ws_floats(n)] fp32. */
+int64_t anr_mlp_wgrad_floats(void);
+int64_t anr_mlp_wgrad_ws_floats(int64_t n);
+int anr_mlp_wgrad(int mode, const void* act, const void* dact, const void* enc, const float* g, int64_t n,
+                  float* workspace, float* grads_out, void* stream);
 
 /* ---- sigma-grid points for mesh extraction -------------------------------------------------------
  * extract_mesh.py:27-35 (create_grid: np.meshgrid(x, y, z), 'xy' indexing, fp64 linspace -> fp32) and :152-157

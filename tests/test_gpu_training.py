@@ -1,5 +1,6 @@
 """GPU tests of the training path (a16/a17): gradients of the HIP forward + custom backward against torch autograd
 through the CPU oracle (which restates the reference op for op, so its autograd IS the reference's backward)."""
+import numpy as np
 import pytest
 import torch
 
@@ -101,7 +102,7 @@ def test_fused_mlp_backward_equals_gemm_chain(dev, smpl_table, mode, sigma_only)
     g = torch.randn(n, 1 if sigma_only else 4, generator=gen).to(dev)
     res = []
     for fused in (True, False):
-        MLPFunction.FUSED_BACKWARD = fused
+        MLPFunction.LIBRARY_GEMMS = not fused
         try:
             net.zero_grad()
             p = pts.to(dev).requires_grad_(True)
@@ -109,7 +110,7 @@ def test_fused_mlp_backward_equals_gemm_chain(dev, smpl_table, mode, sigma_only)
             (out.reshape(n, -1) * g).sum().backward()
             res.append(({k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None}, p.grad.clone()))
         finally:
-            MLPFunction.FUSED_BACKWARD = True
+            MLPFunction.LIBRARY_GEMMS = False
     (ga, pa), (gb, pb) = res
     assert set(ga) == set(gb)
     tol = 2e-5 if mode == "f32" else 3e-2        # bf16: the two chains round their intermediates at different points
@@ -117,6 +118,62 @@ def test_fused_mlp_backward_equals_gemm_chain(dev, smpl_table, mode, sigma_only)
         err = (ga[k] - gb[k]).norm() / (gb[k].norm() + 1e-20)
         assert err < tol, (k, err.item())
     assert (pa - pb).norm() / pb.norm() < tol
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("n", [64, 4096 + 64, 70016])
+def test_weight_gradient_kernel(dev, smpl_table, mode, n):
+    """anr_mlp_wgrad (split-K MFMA GEMMs over the points, ds_read_b64_tr_b16 fragments in bf16) against float64 products
+    of the very same operands: every one of the 22 tensors, full network and sigma-only; deterministic from run to run."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import ops
+    from anim_nerf_amd.autograd import PARAM_KEYS, PARAM_SHAPES
+    m = seeded_model(smpl_table, 9, True, gain=50.0, device=dev)
+    net = m.nerf
+    gen = torch.Generator().manual_seed(n)
+    pts = torch.cat([torch.rand(n, 3, generator=gen) * 2 - 1, torch.ones(n, 1)], -1).to(dev)
+    named = dict(net.named_parameters())
+    P = {k: named[k].detach() for k in PARAM_KEYS}
+    mode_id = ops.MLP_MODES[mode]
+    for sigma_only in (False, True):
+        g4 = torch.randn(n, 4, generator=gen).to(dev)
+        if sigma_only:
+            g4[:, :3] = 0
+        out, act = ops.mlp_forward_save(ops.mlp_pack(P, mode_id), mode_id, pts, sigma_only)
+        dact = ops.mlp_backward(ops.mlp_pack(P, mode_id, backward=True), mode_id, g4, act, sigma_only=sigma_only)
+        enc = ops.encode64(pts, act.dtype)
+        assert torch.equal(enc[:, :63], ops.encode(pts, act.dtype)) and (enc[:, 63] == 0).all()
+        flat = ops.mlp_wgrad(mode_id, act, dact, enc, g4, sigma_only=sigma_only)
+        assert torch.equal(flat, ops.mlp_wgrad(mode_id, act, dact, enc, g4, sigma_only=sigma_only)), "not deterministic"
+        A, D, E, G = act.double(), dact.double(), enc.double()[:, :63], g4.double()
+        H = lambda l: A[:, 256 * (l - 1):256 * l]
+        want = {}
+        for l in range(1, 9):
+            inp = E if l == 1 else torch.cat([E, H(4)], 1) if l == 5 else H(l - 1)
+            want[f"xyz_encoding_{l}.0.weight"] = D[:, 256 * (l - 1):256 * l].t() @ inp
+            want[f"xyz_encoding_{l}.0.bias"] = D[:, 256 * (l - 1):256 * l].sum(0)
+        want["sigma.weight"] = (G[:, 3:4].t() @ H(8))
+        want["sigma.bias"] = G[:, 3].sum().reshape(1)
+        if not sigma_only:
+            want["xyz_encoding_final.weight"] = D[:, 2048:2304].t() @ H(8)
+            want["xyz_encoding_final.bias"] = D[:, 2048:2304].sum(0)
+            want["dir_encoding.0.weight"] = D[:, 2304:2432].t() @ A[:, 2048:2304]
+            want["dir_encoding.0.bias"] = D[:, 2304:2432].sum(0)
+            want["rgb.0.weight"] = G[:, :3].t() @ A[:, 2304:2432]
+            want["rgb.0.bias"] = G[:, :3].sum(0)
+        o = 0
+        for k, shp in zip(PARAM_KEYS, PARAM_SHAPES):
+            cnt = int(np.prod(shp))
+            got = flat[o:o + cnt].view(shp).double()
+            o += cnt
+            if k in want:
+                ref = want[k].view(shp)
+                err = (got - ref).norm() / (ref.norm() + 1e-30)
+                mfma = k.endswith("weight") and "encoding" in k          # the others are serial fp32 column sums
+                assert err < (2e-6 if mfma else 2e-5), (k, mode, n, sigma_only, err.item())
+            else:
+                assert (got == 0).all(), k
+        assert o == flat.numel()
 
 
 def test_training_loss_gradients_match_oracle(dev, smpl_table):
