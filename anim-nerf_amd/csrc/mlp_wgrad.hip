@@ -29,7 +29,8 @@ struct WgradGemm {
     int a_col;        // first column of dact (the M = out-feature side)
     int b_src;        // 0: act, 1: enc
     int b_col;        // first column of the source (the N = in-feature side)
-    int out_off;      // float offset of this GEMM's [S][M][N] block in the partial workspace
+    int out_off;      // float offset of this GEMM's [S][M*N + M] block in the partial workspace
+    int want_bias;    // also emit the column sums of the M side (the bias gradient) behind each [M][N] slice
 };
 struct WgradArgs {
     WgradGemm g[WG_MAX_GEMMS];
@@ -112,6 +113,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
 
     const int wm = wave % WM, wn = wave / WM;
     const int m_base = wm * TM * 32, n_base = wn * TN * 32;
+    // bias gradient = column sums of the M side = (M side)^T . ones: one more MFMA per row tile against a constant
+    // all-ones fragment, in the waves of the first column block (exact fp32 accumulation, no extra loads)
+    const bool do_bias = gm.want_bias && wn == 0;
+    f32x16 bacc[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bacc[a][e] = 0.0f;
     if (n_stages > 0) issue(0);
     if (n_stages > 1) issue(1);
     for (int st = 0; st < n_stages; ++st) {
@@ -159,6 +168,13 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                if (do_bias) {
+                    bf16x8 ones;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) bacc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], ones, bacc[a], 0, 0, 0);
+                }
             }
         } else {
             const int i = lane & 31, h = lane >> 5;
@@ -176,11 +192,15 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) bacc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], 1.0f, bacc[a], 0, 0, 0);
+                }
             }
         }
     }
     // partial[gemm][split][M][N]; accumulator register e of lane: row (e&3) + 8 (e>>2) + 4 (lane>>5), column lane&31
-    float* out = partial + gm.out_off + (int64_t)sp * M * N;
+    float* out = partial + gm.out_off + (int64_t)sp * (M * N + M);
     const int col = lane & 31, rofs = 4 * (lane >> 5);
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -189,39 +209,42 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 out[(int64_t)(m_base + a * 32 + (e & 3) + 8 * (e >> 2) + rofs) * N + n_base + b * 32 + col] = acc[a][b][e];
+    if (do_bias && col == 0) {                               // every column of bacc holds the same sums
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) out[M * N + m_base + a * 32 + (e & 3) + 8 * (e >> 2) + rofs] = bacc[a][e];
+    }
 }
 
-// ---- column sums: every bias gradient (columns of dact), and the skinny heads as weighted column sums:
-//   d sigma.weight[c] = sum_p g4[p][3] h8[p][c]     d rgb.weight[j][c] = sum_p g4[p][j] G[p][c]     (+ their biases)
-// One thread per output column of a slice of rows; slices are added by the reduction kernel.
-constexpr int CS_COLS = ACT_COLS + 256 + 3 * 128 + 4;       // dact columns | sigma.weight | rgb.weight | rgb.bias(3), sigma.bias
+// ---- the two skinny heads as weighted column sums (their M side is g, 4 fp32 columns):
+//   d sigma.weight[c] = sum_p g[p][3] h8[p][c]     d rgb.weight[j][c] = sum_p g[p][j] G[p][c]     biases: sum_p g[p][j]
+// One thread per output of a slice of rows, four rows in flight; slices are added by the reduction kernel.
+constexpr int CS_COLS = 256 + 3 * 128 + 4;                  // sigma.weight | rgb.weight | rgb.bias (3), sigma.bias
 
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dact, const T* __restrict__ act,
-                                                     const float* __restrict__ g4, int64_t n, int rows_per_slice,
-                                                     int sigma_only, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, const float* __restrict__ g4, int64_t n,
+                                                    int rows_per_slice, int sigma_only, float* __restrict__ partial) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice;
     int64_t r1 = r0 + rows_per_slice;
     if (r1 > n) r1 = n;
     if (c >= CS_COLS) return;
-    float s = 0.0f;
-    if (c < ACT_COLS) {
-        if (!(sigma_only && c >= 2048))
-            for (int64_t r = r0; r < r1; ++r) s += (float)dact[r * ACT_COLS + c];
-    } else if (c < ACT_COLS + 256) {
-        const int k = 1792 + (c - ACT_COLS);                         // h8
-        for (int64_t r = r0; r < r1; ++r) s += g4[r * 4 + 3] * (float)act[r * ACT_COLS + k];
-    } else if (c < ACT_COLS + 256 + 384) {
-        const int j = (c - ACT_COLS - 256) / 128, k = 2304 + (c - ACT_COLS - 256) % 128;
-        if (!sigma_only)
-            for (int64_t r = r0; r < r1; ++r) s += g4[r * 4 + j] * (float)act[r * ACT_COLS + k];
-    } else {
-        const int j = c - (ACT_COLS + 256 + 384);
-        if (!(sigma_only && j < 3))
-            for (int64_t r = r0; r < r1; ++r) s += g4[r * 4 + j];
+    int j, k;                                                // weight column j of g, activation column k (-1: bias)
+    if (c < 256) { j = 3; k = 1792 + c; }                    // h8
+    else if (c < 640) { j = (c - 256) / 128; k = 2304 + (c - 256) % 128; }
+    else { j = c - 640; k = -1; }
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!(sigma_only && j < 3)) {
+        int64_t r = r0;
+        for (; r + 4 <= r1; r += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                s[q] += g4[(r + q) * 4 + j] * (k >= 0 ? (float)act[(r + q) * ACT_COLS + k] : 1.0f);
+        }
+        for (; r < r1; ++r) s[0] += g4[r * 4 + j] * (k >= 0 ? (float)act[r * ACT_COLS + k] : 1.0f);
     }
-    partial[(int64_t)blockIdx.y * CS_COLS + c] = s;
+    partial[(int64_t)blockIdx.y * CS_COLS + c] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
 // ---- reduction over the slices + scatter into the 22 gradient tensors (flat, in the order of anr_mlp_wgrad_layout)
@@ -242,8 +265,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradSegs segs, const
     if (i >= sg.rows * sg.cols) return;
     const int r = i / sg.cols, c = i % sg.cols;
     const float* src = ws + sg.src_off + (int64_t)r * sg.src_pitch + c;
-    float s = 0.0f;
-    for (int k = 0; k < sg.slices; ++k) s += src[(int64_t)k * sg.src_slice];
+    float s = 0.0f;                                          // fixed order; eight loads in flight
+    int k = 0;
+    for (; k + 8 <= sg.slices; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = src[(int64_t)(k + q) * sg.src_slice];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; k < sg.slices; ++k) s += src[(int64_t)k * sg.src_slice];
     grads[sg.dst + (int64_t)r * sg.dst_pitch + c] = s;
 }
 
@@ -286,7 +317,7 @@ extern "C" int64_t anr_mlp_wgrad_floats(void) { return layout().total; }
 extern "C" int64_t anr_mlp_wgrad_ws_floats(int64_t n) {
     // upper bound for any n: three GEMM shapes at their maximum split counts + the column-sum slices
     (void)n;
-    return (int64_t)8 * 37 * 65536 + (int64_t)2 * 64 * 256 * 64 + (int64_t)256 * 128 * 256 + (int64_t)1024 * CS_COLS + 1024;
+    return (int64_t)8 * 37 * (65536 + 256) + (int64_t)2 * 64 * (256 * 64 + 256) + (int64_t)256 * (128 * 256 + 128) + (int64_t)1024 * CS_COLS + 1024;
 }
 
 template <bool BF16>
@@ -313,16 +344,19 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
         const int n_g = sigma_only ? 7 : 8;
         a.splits = splits_for(n, C::SR, n_g);
         a.rows_per_split = (int)(((n + a.splits - 1) / a.splits + C::SR - 1) / C::SR * C::SR);
+        constexpr int BLK = 65536 + 256;                       // [M][N] + the M column sums
         for (int l = 2; l <= 8; ++l) {
-            a.g[a.n_gemms] = WgradGemm{256 * (l - 1), 0, 256 * (l - 2), ws_off};
-            seg(L.w[l - 1] + (l == 5 ? 63 : 0), 256, 256, l == 5 ? 319 : 256, ws_off, 256, 65536, a.splits);
-            ws_off += a.splits * 65536;
+            a.g[a.n_gemms] = WgradGemm{256 * (l - 1), 0, 256 * (l - 2), ws_off, 1};
+            seg(L.w[l - 1] + (l == 5 ? 63 : 0), 256, 256, l == 5 ? 319 : 256, ws_off, 256, BLK, a.splits);
+            seg(L.b[l - 1], 1, 256, 256, ws_off + 65536, BLK, BLK, a.splits);
+            ws_off += a.splits * BLK;
             ++a.n_gemms;
         }
         if (!sigma_only) {
-            a.g[a.n_gemms] = WgradGemm{2048, 0, 1792, ws_off};
-            seg(L.fw, 256, 256, 256, ws_off, 256, 65536, a.splits);
-            ws_off += a.splits * 65536;
+            a.g[a.n_gemms] = WgradGemm{2048, 0, 1792, ws_off, 1};
+            seg(L.fw, 256, 256, 256, ws_off, 256, BLK, a.splits);
+            seg(L.fb, 1, 256, 256, ws_off + 65536, BLK, BLK, a.splits);
+            ws_off += a.splits * BLK;
             ++a.n_gemms;
         }
         auto k = wgrad_kernel<BF16, 2, 4, 4>;
@@ -337,10 +371,12 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
         a.splits = splits_for(n, C::SR, 2);
         if (a.splits > 64) a.splits = 64;
         a.rows_per_split = (int)(((n + a.splits - 1) / a.splits + C::SR - 1) / C::SR * C::SR);
+        constexpr int BLK = 256 * 64 + 256;
         for (int l : {1, 5}) {
-            a.g[a.n_gemms] = WgradGemm{256 * (l - 1), 1, 0, ws_off};
-            seg(L.w[l - 1], 256, 63, l == 5 ? 319 : 63, ws_off, 64, 256 * 64, a.splits);
-            ws_off += a.splits * 256 * 64;
+            a.g[a.n_gemms] = WgradGemm{256 * (l - 1), 1, 0, ws_off, l == 1};
+            seg(L.w[l - 1], 256, 63, l == 5 ? 319 : 63, ws_off, 64, BLK, a.splits);
+            if (l == 1) seg(L.b[0], 1, 256, 256, ws_off + 256 * 64, BLK, BLK, a.splits);
+            ws_off += a.splits * BLK;
             ++a.n_gemms;
         }
         auto k = wgrad_kernel<BF16, 1, 2, 8>;
@@ -354,33 +390,32 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
         WgradArgs a{};
         a.splits = splits_for(n, C::SR, 1);
         a.rows_per_split = (int)(((n + a.splits - 1) / a.splits + C::SR - 1) / C::SR * C::SR);
-        a.g[0] = WgradGemm{2304, 0, 2048, ws_off};
+        constexpr int BLK = 128 * 256 + 128;
+        a.g[0] = WgradGemm{2304, 0, 2048, ws_off, 1};
         a.n_gemms = 1;
-        seg(L.dw, 128, 256, 256, ws_off, 256, 128 * 256, a.splits);
-        ws_off += a.splits * 128 * 256;
+        seg(L.dw, 128, 256, 256, ws_off, 256, BLK, a.splits);
+        seg(L.db, 1, 128, 128, ws_off + 128 * 256, BLK, BLK, a.splits);
+        ws_off += a.splits * BLK;
         auto k = wgrad_kernel<BF16, 2, 2, 2>;
         const int lds = lds_bytes(128, 256);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(k, dim3(a.n_gemms * a.splits), dim3(WG_THREADS), lds, st, D, A, E, n, a, ws);
     }
-    // ---- column sums (biases, sigma / rgb heads)
+    // ---- the skinny heads (sigma, rgb) and their biases
     {
-        int slices = (int)((n + 255) / 256);
+        int slices = (int)((n + 127) / 128);
         if (slices > 1024) slices = 1024;
         const int rps = (int)((n + slices - 1) / slices);
         slices = (int)((n + rps - 1) / rps);
         using T = typename C::T;
-        hipLaunchKernelGGL(colsum_kernel<T>, dim3((CS_COLS + 255) / 256, slices), dim3(256), 0, st,
-                           reinterpret_cast<const T*>(dact), reinterpret_cast<const T*>(act), g4, n, rps, sigma_only, ws + ws_off);
-        for (int l = 0; l < 8; ++l) seg(L.b[l], 1, 256, 256, ws_off + 256 * l, CS_COLS, CS_COLS, slices);
-        seg(L.sw, 1, 256, 256, ws_off + ACT_COLS, CS_COLS, CS_COLS, slices);
-        seg(L.sb, 1, 1, 1, ws_off + ACT_COLS + 256 + 384 + 3, CS_COLS, CS_COLS, slices);
+        hipLaunchKernelGGL(heads_kernel<T>, dim3((CS_COLS + 255) / 256, slices), dim3(256), 0, st,
+                           reinterpret_cast<const T*>(act), g4, n, rps, sigma_only, ws + ws_off);
+        seg(L.sw, 1, 256, 256, ws_off, CS_COLS, CS_COLS, slices);
+        seg(L.sb, 1, 1, 1, ws_off + 643, CS_COLS, CS_COLS, slices);
         if (!sigma_only) {
-            seg(L.fb, 1, 256, 256, ws_off + 2048, CS_COLS, CS_COLS, slices);
-            seg(L.db, 1, 128, 128, ws_off + 2304, CS_COLS, CS_COLS, slices);
-            seg(L.rw, 1, 384, 384, ws_off + ACT_COLS + 256, CS_COLS, CS_COLS, slices);
-            seg(L.rb, 1, 3, 3, ws_off + ACT_COLS + 256 + 384, CS_COLS, CS_COLS, slices);
+            seg(L.rw, 1, 384, 384, ws_off + 256, CS_COLS, CS_COLS, slices);
+            seg(L.rb, 1, 3, 3, ws_off + 640, CS_COLS, CS_COLS, slices);
         }
         ws_off += slices * CS_COLS;
     }
