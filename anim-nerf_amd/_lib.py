@@ -17,6 +17,7 @@ ANR_MLP_F32 = 0
 ANR_MLP_BF16 = 1
 ANR_MLP_FLAG_NO_DMA = 0x100
 ANR_MLP_FLAG_SIGMA_ONLY = 0x400
+ANR_MLP_FLAG_TANGENT = 0x800
 ANR_MAX_SAMPLES = 256
 
 

@@ -3,8 +3,9 @@
 Forward runs on the same HIP kernels as inference (`anr_mlp_forward_save` additionally keeps each layer's
 post-activation output, `anr_composite`); backward:
   * compositing: `anr_composite_backward` (HIP, one wavefront per ray);
-  * MLP: the saved activations are plain row-major [points, features] matrices, and both gradient GEMM families
-    (dX = dY W, dW = dY^T X) are plain library GEMMs (rocBLAS/hipBLASLt through torch.matmul) — 22 per network.
+  * MLP: `anr_mlp_backward` (the whole activation-gradient chain in one kernel) and `anr_mlp_wgrad` (all weight and bias
+    gradients: split-K MFMA GEMMs over the points between the saved activations and the activation gradients);
+  * normals regulariser: the same three kernels in tangent mode (`NormalFunction`).
 Pose refinement (`optim_body_params`): dL/dx_c leaves the MLP backward through the encoding, `WarpFunction` routes it
 into the per-vertex observation->canonical transforms (scatter-add over the 4 neighbours, whose weights carry no
 gradient: KNN distances are `no_grad` in the reference, models/anim_nerf.py:158) and into the sample position
@@ -19,13 +20,6 @@ from . import ops
 PARAM_KEYS = ([k for i in range(1, 9) for k in (f"xyz_encoding_{i}.0.weight", f"xyz_encoding_{i}.0.bias")]
               + ["sigma.weight", "sigma.bias", "xyz_encoding_final.weight", "xyz_encoding_final.bias",
                  "dir_encoding.0.weight", "dir_encoding.0.bias", "rgb.0.weight", "rgb.0.bias"])
-
-
-def _encode(xyz: torch.Tensor, n_freqs: int = 10) -> torch.Tensor:
-    cols = [xyz]
-    for k in range(n_freqs):
-        cols += [torch.sin(xyz * float(2 ** k)), torch.cos(xyz * float(2 ** k))]
-    return torch.cat(cols, -1)
 
 
 _PACKS = {}
@@ -217,113 +211,57 @@ def _library_backward(ctx, params, pts, act, g4, want_pts):
     return grads, d_enc
 
 
-def _splitk_tn(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dy[rows, o]^T @ x[rows, c] with the long reduction split into S batches: a [256 x rows] x [rows x 256] product gives
-    the library 16 output tiles for 256 CUs."""
-    rows = dy.shape[0]
-    S = 1
-    while S < 64 and rows % (2 * S) == 0 and rows // (2 * S) >= 512:
-        S *= 2
-    if S == 1:
-        return dy.t() @ x
-    return torch.bmm(dy.view(S, rows // S, -1).transpose(1, 2), x.view(S, rows // S, -1)).sum(0)
-
-
 class NormalFunction(torch.autograd.Function):
     """normal[n,3] = d alpha / d xyz with alpha = 1 - exp(-delta relu(sigma(xyz))) (models/nerf.py:177-190), and its
     gradient w.r.t. the trunk and sigma weights — the second-order term of the normals regulariser (train.py:288-309).
 
-    Forward mode instead of autograd-of-autograd: the three tangents d/dx, d/dy, d/dz ride through the trunk as three
-    extra rows per point (no bias, gated by the ReLU mask of the point's own activations), so the whole term is ONE
-    4n-row pass through 9 library GEMMs; ReLU has zero curvature almost everywhere, so the backward is the plain linear
-    backward of that 4n-row pass (bias gradients from the primal rows only).  ~80 launches instead of ~1400."""
-
-    KEYS = [k for i in range(1, 9) for k in (f"xyz_encoding_{i}.0.weight", f"xyz_encoding_{i}.0.bias")] + ["sigma.weight", "sigma.bias"]
-    _tables = {}
-
-    @staticmethod
-    def _tangent_tables(device, dtype):
-        key = (str(device), dtype)
-        if key not in NormalFunction._tables:
-            perm, scale = list(range(63)), [0.0] * 63
-            for c in range(3):
-                scale[c] = 0.0                                        # d x / d x = 1: patched below via the ones column
-            for k in range(10):
-                f = float(2 ** k)
-                for d in range(3):
-                    s_ch, c_ch = 3 + 6 * k + d, 6 + 6 * k + d
-                    perm[s_ch], scale[s_ch] = c_ch, f
-                    perm[c_ch], scale[c_ch] = s_ch, -f
-            axis = torch.zeros(3, 63)
-            for c in range(63):
-                axis[c % 3, c] = 1.0
-            add = torch.zeros(63)
-            add[:3] = 1.0
-            NormalFunction._tables[key] = (torch.tensor(perm, device=device), torch.tensor(scale, device=device, dtype=dtype),
-                                           axis.to(device=device, dtype=dtype), add.to(device=device, dtype=dtype))
-        t = NormalFunction._tables[key]
-        return t[0], t[1], t[2]
+    Forward mode instead of autograd-of-autograd: the three tangents d/dx, d/dy, d/dz ride through the trunk next to
+    their point — quads of columns in the SAME fused kernels as everything else (ANR_MLP_FLAG_TANGENT: tangent columns
+    get the derivative of the encoding, no bias, and the ReLU gate of their point; csrc/mlp_core.h).  ReLU has zero
+    curvature almost everywhere, so the backward is the plain linear backward of that 4n-column pass: anr_mlp_backward +
+    anr_mlp_wgrad with the same flag (gates from the point's column, bias gradients from the point's column only).
+    Three launches forward + backward instead of ~80 library launches (first version) or ~1400 (double backward)."""
 
     @staticmethod
-    def forward(ctx, xyz, delta, *params):
-        P = dict(zip(NormalFunction.KEYS, [p.detach() for p in params]))
+    def forward(ctx, xyz, delta, mode_id, *params):
         n = xyz.shape[0]
-        x = xyz.detach()
-        e = ops.encode(x) if (x.is_cuda and x.dtype == torch.float32) else _encode(x)      # [n,63]
-        # tangents of the encoding d e / d x_d -> T0[3, n, 63]: channel c belongs to axis c % 3; d sin(f x) = f cos(f x)
-        # and d cos(f x) = -f sin(f x) are the partner channel times +-f
-        perm, scale, axis = NormalFunction._tangent_tables(x.device, x.dtype)
-        dE = torch.addcmul(NormalFunction._tables[(str(x.device), x.dtype)][3], e.index_select(1, perm), scale)
-        T0 = dE[None] * axis[:, None, :]
-        X0 = torch.cat([e[None], T0], 0)                              # [4, n, 63]: primal row group + 3 tangent groups
-        saved_in, masks = [], []
-        h = X0
-        for l in range(1, 9):
-            inp = X0 if l == 1 else torch.cat([X0, h], -1) if l == 5 else h
-            pre = inp @ P[f"xyz_encoding_{l}.0.weight"].t()           # [4, n, 256]
-            pre[0] += P[f"xyz_encoding_{l}.0.bias"]
-            mask = pre[0] > 0
-            h = pre * mask
-            saved_in.append(inp)
-            masks.append(mask)
-        sig = h @ P["sigma.weight"].t()                               # [4, n, 1]
-        sig[0] += P["sigma.bias"]
-        s0 = sig[0, :, 0]
-        pos = s0 > 0
-        scale = torch.where(pos, delta * torch.exp(-delta * s0), torch.zeros_like(s0))     # d alpha / d sigma
-        normal = (scale[None] * sig[1:, :, 0]).t().contiguous()       # [n, 3]
-        ctx.save_for_backward(h, sig, scale, *saved_in, *masks, *params)
-        ctx.delta = delta
-        return normal
+        n_pad = -(-n // 16) * 16                                      # 4 n_pad rows: a multiple of 64 (wgrad slabs)
+        pts = xyz.new_zeros(n_pad, 4)
+        pts[:n, :3] = xyz.detach()
+        pts[:n, 3] = 1.0
+        pts4 = pts.repeat_interleave(4, dim=0)                        # quad p = (point, d/dx, d/dy, d/dz)
+        out, act = ops.mlp_forward_save(_cached_pack(params, mode_id, False), mode_id, pts4, sigma_only=True, tangent=True)
+        sig = out.view(n_pad, 4)
+        s0 = sig[:, 0]
+        scale = torch.where(s0 > 0, delta * torch.exp(-delta * s0), torch.zeros_like(s0))     # d alpha / d sigma
+        scale[n:] = 0
+        ctx.save_for_backward(pts4, act, sig, scale, *params)
+        ctx.delta, ctx.mode_id, ctx.n = delta, mode_id, n
+        return (scale[:, None] * sig[:, 1:4])[:n]
 
     @staticmethod
     @torch.no_grad()
     def backward(ctx, g):
-        saved = ctx.saved_tensors
-        h8, sig, scale = saved[:3]
-        saved_in, masks, params = saved[3:11], saved[11:19], saved[19:]
-        P = dict(zip(NormalFunction.KEYS, params))
-        delta = ctx.delta
-        grads = {}
-        gt = g.t()                                                    # [3, n]
-        d_sig = torch.empty_like(sig)                                 # [4, n, 1]
-        d_sig[1:, :, 0] = gt * scale[None]
+        pts4, act, sig, scale, *params = ctx.saved_tensors
+        n, n_pad = ctx.n, sig.shape[0]
+        d_sig = sig.new_zeros(n_pad, 4)
+        d_sig[:n, 1:4] = g * scale[:n, None]
         # d scale / d sigma = -delta * scale where sigma > 0
-        d_sig[0, :, 0] = (gt * sig[1:, :, 0]).sum(0) * (-delta) * scale
-        grads["sigma.weight"] = torch.einsum("gno,gnc->oc", d_sig, h8)
-        grads["sigma.bias"] = d_sig[0].sum(0)
-        dh = d_sig * P["sigma.weight"]                                # [4, n, 256]
-        for l in range(8, 0, -1):
-            dpre = dh * masks[l - 1]
-            inp = saved_in[l - 1]
-            W = P[f"xyz_encoding_{l}.0.weight"]
-            grads[f"xyz_encoding_{l}.0.weight"] = _splitk_tn(dpre.reshape(-1, dpre.shape[-1]), inp.reshape(-1, inp.shape[-1]))
-            grads[f"xyz_encoding_{l}.0.bias"] = dpre[0].sum(0)
-            if l > 1:
-                dh = dpre @ (W[:, 63:] if l == 5 else W)
-        out = [grads[k].reshape(p.shape) if ctx.needs_input_grad[2 + i] else None
-               for i, (k, p) in enumerate(zip(NormalFunction.KEYS, params))]
-        return (None, None, *out)
+        d_sig[:n, 0] = (g * sig[:n, 1:4]).sum(-1) * (-ctx.delta) * scale[:n]
+        g4 = sig.new_zeros(4 * n_pad, 4)
+        g4[:, 3] = d_sig.reshape(-1)
+        dact = ops.mlp_backward(_cached_pack(params, ctx.mode_id, True), ctx.mode_id, g4, act, sigma_only=True, tangent=True)
+        flat = ops.mlp_wgrad(ctx.mode_id, act, dact, ops.encode64(pts4, act.dtype, tangent=True), g4, sigma_only=True,
+                             tangent=True)
+        out, o = [], 0
+        for i, (k, shp) in enumerate(zip(PARAM_KEYS, PARAM_SHAPES)):
+            cnt = 1
+            for d in shp:
+                cnt *= d
+            need = ctx.needs_input_grad[3 + i] and i < 18              # the colour head takes no part in sigma
+            out.append(flat[o:o + cnt].view(shp).to(params[i].dtype) if need else None)
+            o += cnt
+        return (None, None, None, *out)
 
 
 class CompositeFunction(torch.autograd.Function):

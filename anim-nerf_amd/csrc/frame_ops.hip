@@ -254,12 +254,27 @@ namespace anr {
 
 // COLS = 63 (the reference's matrix) or 64 (one zero column of padding: the layout anr_mlp_wgrad stages)
 template <typename T, int COLS = 63>
-__global__ __launch_bounds__(256) void encode_kernel(const float* __restrict__ pts, int stride, int64_t n, T* __restrict__ enc) {
+__global__ __launch_bounds__(256) void encode_kernel(const float* __restrict__ pts, int stride, int64_t n, T* __restrict__ enc,
+                                                     int tangent = 0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float x[3] = {pts[i * stride], pts[i * stride + 1], pts[i * stride + 2]};
     T* row = enc + i * COLS;
     if (COLS > 63) row[63] = (T)0.0f;
+    if (tangent && (i & 3)) {                              // row 4p + t, t = 1..3: d enc / d x_{t-1} (ANR_MLP_FLAG_TANGENT)
+        const int a = (int)(i & 3) - 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) row[d] = (T)(d == a ? 1.0f : 0.0f);
+        for (int k = 0; k < 10; ++k) {
+            const float f = (float)(1 << k);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                row[3 + 6 * k + d] = (T)(d == a ? f * cosf(f * x[d]) : 0.0f);
+                row[6 + 6 * k + d] = (T)(d == a ? -f * sinf(f * x[d]) : 0.0f);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int d = 0; d < 3; ++d) row[d] = (T)x[d];
     for (int k = 0; k < 10; ++k) {
@@ -298,20 +313,21 @@ extern "C" int anr_encode(const float* pts, int pts_stride, int64_t n, int bf16_
     ANR_REQUIRE(n > 0 && pts_stride >= 3, ANR_E_BADARG, "anr_encode: n=%lld stride=%d", (long long)n, pts_stride);
     dim3 grid((unsigned)((n + 255) / 256));
     if (bf16_out)
-        hipLaunchKernelGGL(anr::encode_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (__bf16*)enc_out);
+        hipLaunchKernelGGL(anr::encode_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (__bf16*)enc_out, 0);
     else
-        hipLaunchKernelGGL(anr::encode_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (float*)enc_out);
+        hipLaunchKernelGGL(anr::encode_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (float*)enc_out, 0);
     return anr::check_launch("anr_encode");
 }
 
-extern "C" int anr_encode64(const float* pts, int pts_stride, int64_t n, int bf16_out, void* enc_out, void* stream) {
+extern "C" int anr_encode64(const float* pts, int pts_stride, int64_t n, int flags, void* enc_out, void* stream) {
     ANR_REQUIRE(pts && enc_out, ANR_E_BADARG, "anr_encode64: null pointer");
     ANR_REQUIRE(n > 0 && pts_stride >= 3, ANR_E_BADARG, "anr_encode64: n=%lld stride=%d", (long long)n, pts_stride);
     dim3 grid((unsigned)((n + 255) / 256));
-    if (bf16_out)
-        hipLaunchKernelGGL((anr::encode_kernel<__bf16, 64>), grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (__bf16*)enc_out);
+    const int tan = (flags & ANR_MLP_FLAG_TANGENT) ? 1 : 0;
+    if (flags & 1)
+        hipLaunchKernelGGL((anr::encode_kernel<__bf16, 64>), grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (__bf16*)enc_out, tan);
     else
-        hipLaunchKernelGGL((anr::encode_kernel<float, 64>), grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (float*)enc_out);
+        hipLaunchKernelGGL((anr::encode_kernel<float, 64>), grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (float*)enc_out, tan);
     return anr::check_launch("anr_encode64");
 }
 

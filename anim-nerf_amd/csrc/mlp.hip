@@ -15,6 +15,8 @@ ANR_MLP_EXTERN(ANR_MLP_BF16_W8, true, true, false)   ANR_MLP_EXTERN(ANR_MLP_BF16
 ANR_MLP_EXTERN(ANR_MLP_BF16_W8, true, true, true)
 ANR_MLP_EXTERN(ANR_MLP_BF16, true, false, false)  ANR_MLP_EXTERN(ANR_MLP_BF16, false, false, false)
 #undef ANR_MLP_EXTERN
+extern template int launch_mlp<ANR_MLP_F32, true, true, true, false, true>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*, const float*, int, int);
+extern template int launch_mlp<ANR_MLP_BF16_W8, true, true, true, false, true>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*, const float*, int, int);
 #define ANR_PRE(M, S) extern template int launch_mlp<M, true, S, false, true>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*, const float*, int, int);
 ANR_PRE(ANR_MLP_F32, false) ANR_PRE(ANR_MLP_F32, true) ANR_PRE(ANR_MLP_BF16_W8, false) ANR_PRE(ANR_MLP_BF16_W8, true)
 #undef ANR_PRE
@@ -166,6 +168,15 @@ extern "C" int anr_mlp_forward_save_indexed(const void* pack, int mode, const fl
                 "anr_mlp_forward_save: pack/pts/out/act must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;
     const bool so = (mode & ANR_MLP_FLAG_SIGMA_ONLY) != 0;
+    if (mode & ANR_MLP_FLAG_TANGENT) {
+        ANR_REQUIRE(so && !index && n % 4 == 0, ANR_E_BADARG,
+                    "anr_mlp_forward_save: tangent mode = sigma only, no index list, points in quads (n %% 4 == 0)");
+        switch (mode & 0xff) {
+            case ANR_MLP_F32:  return launch_mlp<ANR_MLP_F32, true, true, true, false, true>(pack, pts, n, out, st, act);
+            case ANR_MLP_BF16: return launch_mlp<ANR_MLP_BF16_W8, true, true, true, false, true>(pack, pts, n, out, st, act);
+            default: return fail(ANR_E_BADARG, "anr_mlp_forward_save: unknown mode %d", mode);
+        }
+    }
     switch (mode & 0xff) {
         case ANR_MLP_F32:
             return so ? launch_mlp<ANR_MLP_F32, true, true, true>(pack, pts, n, out, st, act, index, count)

@@ -223,7 +223,7 @@ struct MlpBwd {
     }
 
     __device__ __forceinline__ void run(const char* __restrict__ pack, const float4* __restrict__ g, const ActT* __restrict__ act,
-                                        ActT* __restrict__ dact, int64_t n_pts, char* lds) {
+                                        ActT* __restrict__ dact, int64_t n_pts, char* lds, int tangent = 0) {
         const int64_t n_tiles = (n_pts + WAVES * NT * 32 - 1) / (WAVES * NT * 32);
         if ((int64_t)blockIdx.x >= n_tiles) return;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -254,7 +254,8 @@ struct MlpBwd {
                 const int64_t cl = idx < n_pts ? idx : n_pts - 1;
                 gin[n] = g[cl];
                 dsig[n] = gin[n].w;
-                act_row[n] = act + cl * ACT_COLS + 4 * half;
+                // tangent mode: the ReLU gates of a quad's four columns are the primal column's (row 4p)
+                act_row[n] = act + (tangent ? (cl & ~(int64_t)3) : cl) * ACT_COLS + 4 * half;
                 dact_row[n] = idx < n_pts ? dact + idx * ACT_COLS + 4 * half : nullptr;
             }
             if (first) {
@@ -320,15 +321,15 @@ struct MlpBwd {
 template <int MODE, bool SIGMA_ONLY>
 __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void mlp_bwd_kernel(
     const char* __restrict__ pack, const float4* __restrict__ g, const void* __restrict__ act, void* __restrict__ dact,
-    int64_t n_pts) {
+    int64_t n_pts, int tangent) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using M = MlpBwd<MODE, SIGMA_ONLY>;
     M m;
-    m.run(pack, g, reinterpret_cast<const typename M::ActT*>(act), reinterpret_cast<typename M::ActT*>(dact), n_pts, lds);
+    m.run(pack, g, reinterpret_cast<const typename M::ActT*>(act), reinterpret_cast<typename M::ActT*>(dact), n_pts, lds, tangent);
 }
 
 template <int MODE, bool SIGMA_ONLY>
-int launch_mlp_bwd(const void* pack, const float* g, const void* act, void* dact, int64_t n, hipStream_t st) {
+int launch_mlp_bwd(const void* pack, const float* g, const void* act, void* dact, int64_t n, hipStream_t st, int tangent = 0) {
     using C = Cfg<MODE>;
     const int lds = BWD_TABLE_BYTES + 3 * MlpBwd<MODE, SIGMA_ONLY>::SLOT;
     auto kern = mlp_bwd_kernel<MODE, SIGMA_ONLY>;
@@ -340,7 +341,7 @@ int launch_mlp_bwd(const void* pack, const float* g, const void* act, void* dact
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     dim3 grid((unsigned)(n_tiles < cus ? n_tiles : cus));
     hipLaunchKernelGGL(kern, grid, dim3(C::WAVES * 64), lds, st, reinterpret_cast<const char*>(pack),
-                       reinterpret_cast<const float4*>(g), act, dact, n);
+                       reinterpret_cast<const float4*>(g), act, dact, n, tangent);
     return check_launch("anr_mlp_backward");
 }
 
@@ -436,12 +437,14 @@ extern "C" int anr_mlp_backward(const void* bwd_pack, int mode, const float* g, 
                 "anr_mlp_backward: bwd_pack/g/act/dact must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;
     const bool so = (mode & ANR_MLP_FLAG_SIGMA_ONLY) != 0;
+    const int tan = (mode & ANR_MLP_FLAG_TANGENT) ? 1 : 0;
+    ANR_REQUIRE(!tan || (so && n % 4 == 0), ANR_E_BADARG, "anr_mlp_backward: tangent mode = sigma only, points in quads");
     switch (mode & 0xff) {
         case ANR_MLP_F32:
-            return so ? launch_mlp_bwd<ANR_MLP_F32, true>(bwd_pack, g, act, dact, n, st)
+            return so ? launch_mlp_bwd<ANR_MLP_F32, true>(bwd_pack, g, act, dact, n, st, tan)
                       : launch_mlp_bwd<ANR_MLP_F32, false>(bwd_pack, g, act, dact, n, st);
         case ANR_MLP_BF16:
-            return so ? launch_mlp_bwd<ANR_MLP_BF16_W8, true>(bwd_pack, g, act, dact, n, st)
+            return so ? launch_mlp_bwd<ANR_MLP_BF16_W8, true>(bwd_pack, g, act, dact, n, st, tan)
                       : launch_mlp_bwd<ANR_MLP_BF16_W8, false>(bwd_pack, g, act, dact, n, st);
         default: return fail(ANR_E_BADARG, "anr_mlp_backward: unknown mode %d", mode);
     }

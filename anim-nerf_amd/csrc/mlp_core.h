@@ -173,7 +173,11 @@ __host__ __device__ constexpr int act_col(int T) { return T < 64 ? 32 * T : T < 
 
 // PRE: the input is the 63-channel Fourier embedding itself, emb[n][63] fp32 (models/mlp.py:268-297 takes it that way):
 // the encoder is skipped, the panel slots are loaded from the row.
-template <int MODE, bool DMA, bool SIGMA_ONLY = false, bool SAVE = false, bool PRE = false>
+// TAN (forward-mode normals, models/nerf.py:177-190 without autograd-of-autograd): the points come in quads — column
+// 4p is point p itself, columns 4p+1..3 carry the tangents d/dx, d/dy, d/dz through the same layers: their encoding is the
+// derivative of the encoding, they get no bias, and their ReLU gate is the PRIMAL column's (one DPP quad broadcast).
+// sigma of a tangent column is then d sigma / d x_d.
+template <int MODE, bool DMA, bool SIGMA_ONLY = false, bool SAVE = false, bool PRE = false, bool TAN = false>
 struct Mlp {
     using C = Cfg<MODE>;
     using Frag = typename C::Frag;
@@ -253,6 +257,11 @@ struct Mlp {
             f32x4 t = b[q];
             v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
         }
+        if constexpr (TAN) {                               // tangent columns are linear in the tangent: no bias
+            const float keep = (lane & 3) ? 0.0f : 1.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] *= keep;
+        }
         return v;
     }
 
@@ -287,7 +296,18 @@ struct Mlp {
                         const f32x2 v2 = {a[n][4 * Q + 2 * i], a[n][4 * Q + 2 * i + 1]};
                         const bf16x2 b2 = __builtin_convertvector(v2, bf16x2);
                         s16x2 s2 = __builtin_bit_cast(s16x2, b2);
-                        if (RELU) s2 = __builtin_elementwise_max(s2, s16x2{0, 0});
+                        if (RELU) {
+                            if constexpr (TAN) {
+                                // gate of the whole quad = the primal column's sign (lane 4q): keep where its ReLU'd value
+                                // is > 0 — (0 - h) >> 15 per 16-bit half is 0xffff there, 0 for +0
+                                const s16x2 prim = __builtin_bit_cast(s16x2, __builtin_amdgcn_update_dpp(
+                                    0, __builtin_bit_cast(int, s2), 0x00 /* quad_perm:[0,0,0,0] */, 0xf, 0xf, false));
+                                const s16x2 hp = __builtin_elementwise_max(prim, s16x2{0, 0});
+                                s2 = s2 & ((s16x2{0, 0} - hp) >> 15);
+                            } else {
+                                s2 = __builtin_elementwise_max(s2, s16x2{0, 0});
+                            }
+                        }
                         pk[i] = __builtin_bit_cast(unsigned, s2);
                     }
                     Frag& dst = Y[n][TB + (4 * Q) / EPF];
@@ -304,7 +324,14 @@ struct Mlp {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float v = a[n][4 * Q + i];
-                        if (RELU) v = __int_as_float(max(__float_as_int(v), 0));   // relu as one v_max_i32
+                        if (RELU) {
+                            if constexpr (TAN) {
+                                const float prim = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x00, 0xf, 0xf, false));
+                                v = prim > 0.0f ? v : 0.0f;
+                            } else {
+                                v = __int_as_float(max(__float_as_int(v), 0));   // relu as one v_max_i32
+                            }
+                        }
                         put(Y[n][TB + (4 * Q + i) / EPF], (4 * Q + i) % EPF, v);
                         keep[i] = v;
                     }
@@ -531,6 +558,25 @@ struct Mlp {
                     else v = half ? 0.0f : row[1];
                     put(E[n][j / EPF], j % EPF, v);
                 }
+            } else if constexpr (TAN) {
+                // column t = lane & 3: 0 = the point, t = 1..3 = d/dx_{t-1} of the encoding:
+                //   d sin(f x_d) = f cos(f x_d),  d cos(f x_d) = -f sin(f x_d),  d x_d = 1;  0 for the other axes
+                const int t = lane & 3;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    float v;
+                    if (j < 30) {
+                        const int k = j / 3, d = j % 3;
+                        const float f = (float)(1 << k), a = xs[d] * f;
+                        const float prim = sin_or_cos(a, half);
+                        const float tang = half ? -f * sin_or_cos(a, 0) : f * sin_or_cos(a, 1);
+                        v = t == 0 ? prim : (t - 1 == d ? tang : 0.0f);
+                    } else {
+                        const int d = (j == 30) ? (half ? 2 : 0) : (half ? -1 : 1);
+                        v = d < 0 ? 0.0f : (t == 0 ? xs[d < 0 ? 0 : d] : (t - 1 == d ? 1.0f : 0.0f));
+                    }
+                    put(E[n][j / EPF], j % EPF, v);
+                }
             } else if constexpr (C::IS_BF16) {
                 // bf16 mode: exact sin/cos of the base band, then angle doubling (error doubles per octave:
                 // 2^9 * 1e-7 << bf16's 2^-9) — 6 polynomial evaluations instead of 30 per lane
@@ -628,7 +674,7 @@ struct Mlp {
     }
 };
 
-template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE, bool PRE = false>
+template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE, bool PRE = false, bool TAN = false>
 __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void mlp_kernel(const char* __restrict__ pack,
                                                              const float4* __restrict__ pts, int64_t n_pts,
                                                              void* __restrict__ out, float* __restrict__ act,
@@ -636,17 +682,17 @@ __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void m
                                                              const int32_t* __restrict__ count,
                                                              const float* __restrict__ rays, int ray_stride, int K) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    Mlp<MODE, DMA, SIGMA_ONLY, SAVE, PRE> m;
+    Mlp<MODE, DMA, SIGMA_ONLY, SAVE, PRE, TAN> m;
     m.run(pack, pts, n_pts, out, act, lds, index, count, rays, ray_stride, K);
 }
 
-template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE, bool PRE = false>
+template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE, bool PRE = false, bool TAN = false>
 int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStream_t st, float* act,
                const int32_t* index = nullptr, const int32_t* count = nullptr, const float* rays = nullptr,
                int ray_stride = 0, int K = 1) {
     using C = Cfg<MODE>;
     const int lds = BIAS_BYTES + 3 * slot_bytes<C>();
-    auto kern = mlp_kernel<MODE, DMA, SIGMA_ONLY, SAVE, PRE>;
+    auto kern = mlp_kernel<MODE, DMA, SIGMA_ONLY, SAVE, PRE, TAN>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail((int)e, "anr_mlp_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
     const int pts_per_wg = C::WAVES * C::NT * 32;

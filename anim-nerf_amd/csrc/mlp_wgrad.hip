@@ -37,6 +37,7 @@ struct WgradArgs {
     int n_gemms;
     int splits;                   // S
     int rows_per_split;           // multiple of the stage rows
+    int tangent;                  // ANR_MLP_FLAG_TANGENT: bias sums over the primal rows (row % 4 == 0) only
 };
 
 template <bool BF16> struct WgCfg;
@@ -169,9 +170,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
                 if (do_bias) {
+                    // fragment element e <-> row 8 (e >> 2) + 4 h + (e & 3) of the K-step: primal rows are e & 3 == 0
                     bf16x8 ones;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+                    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)((args.tangent && (e & 3)) ? 0.0f : 1.0f);
 #pragma unroll
                     for (int a = 0; a < TM; ++a) bacc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], ones, bacc[a], 0, 0, 0);
                 }
@@ -194,7 +196,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
                 if (do_bias) {
 #pragma unroll
-                    for (int a = 0; a < TM; ++a) bacc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], 1.0f, bacc[a], 0, 0, 0);
+                    for (int a = 0; a < TM; ++a)
+                        bacc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], (args.tangent && ((ks * 2 + h) & 3)) ? 0.0f : 1.0f, bacc[a], 0, 0, 0);
                 }
             }
         }
@@ -224,7 +227,7 @@ constexpr int CS_COLS = 256 + 3 * 128 + 4;                  // sigma.weight | rg
 
 template <typename T>
 __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, const float* __restrict__ g4, int64_t n,
-                                                    int rows_per_slice, int sigma_only, float* __restrict__ partial) {
+                                                    int rows_per_slice, int sigma_only, int tangent, float* __restrict__ partial) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice;
     int64_t r1 = r0 + rows_per_slice;
@@ -240,9 +243,9 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
         for (; r + 4 <= r1; r += 4) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                s[q] += g4[(r + q) * 4 + j] * (k >= 0 ? (float)act[(r + q) * ACT_COLS + k] : 1.0f);
+                s[q] += g4[(r + q) * 4 + j] * (k >= 0 ? (float)act[(r + q) * ACT_COLS + k] : (tangent && ((r + q) & 3)) ? 0.0f : 1.0f);
         }
-        for (; r < r1; ++r) s[0] += g4[r * 4 + j] * (k >= 0 ? (float)act[r * ACT_COLS + k] : 1.0f);
+        for (; r < r1; ++r) s[0] += g4[r * 4 + j] * (k >= 0 ? (float)act[r * ACT_COLS + k] : (tangent && (r & 3)) ? 0.0f : 1.0f);
     }
     partial[(int64_t)blockIdx.y * CS_COLS + c] = (s[0] + s[1]) + (s[2] + s[3]);
 }
@@ -322,7 +325,7 @@ extern "C" int64_t anr_mlp_wgrad_ws_floats(int64_t n) {
 
 template <bool BF16>
 static int wgrad_launch(const void* act, const void* dact, const void* enc, const float* g4, int64_t n, int sigma_only,
-                        float* ws, float* grads, hipStream_t st) {
+                        int tangent, float* ws, float* grads, hipStream_t st) {
     using C = WgCfg<BF16>;
     const Layout& L = layout();
     WgradSegs segs{};
@@ -341,6 +344,7 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
     // ---- 256 x 256: trunk layers 2..8 (hidden part of layer 5) and xyz_encoding_final
     {
         WgradArgs a{};
+        a.tangent = tangent;
         const int n_g = sigma_only ? 7 : 8;
         a.splits = splits_for(n, C::SR, n_g);
         a.rows_per_split = (int)(((n + a.splits - 1) / a.splits + C::SR - 1) / C::SR * C::SR);
@@ -368,6 +372,7 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
     // ---- 256 x 64: the encoding columns of layers 1 and 5
     {
         WgradArgs a{};
+        a.tangent = tangent;
         a.splits = splits_for(n, C::SR, 2);
         if (a.splits > 64) a.splits = 64;
         a.rows_per_split = (int)(((n + a.splits - 1) / a.splits + C::SR - 1) / C::SR * C::SR);
@@ -388,6 +393,7 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
     // ---- 128 x 256: dir_encoding
     if (!sigma_only) {
         WgradArgs a{};
+        a.tangent = tangent;
         a.splits = splits_for(n, C::SR, 1);
         a.rows_per_split = (int)(((n + a.splits - 1) / a.splits + C::SR - 1) / C::SR * C::SR);
         constexpr int BLK = 128 * 256 + 128;
@@ -410,7 +416,7 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
         slices = (int)((n + rps - 1) / rps);
         using T = typename C::T;
         hipLaunchKernelGGL(heads_kernel<T>, dim3((CS_COLS + 255) / 256, slices), dim3(256), 0, st,
-                           reinterpret_cast<const T*>(act), g4, n, rps, sigma_only, ws + ws_off);
+                           reinterpret_cast<const T*>(act), g4, n, rps, sigma_only, tangent, ws + ws_off);
         seg(L.sw, 1, 256, 256, ws_off, CS_COLS, CS_COLS, slices);
         seg(L.sb, 1, 1, 1, ws_off + 643, CS_COLS, CS_COLS, slices);
         if (!sigma_only) {
@@ -430,6 +436,8 @@ extern "C" int anr_mlp_wgrad(int mode, const void* act, const void* dact, const 
     ANR_REQUIRE((((uintptr_t)act | (uintptr_t)dact | (uintptr_t)enc | (uintptr_t)workspace) & 15) == 0, ANR_E_ALIGN,
                 "anr_mlp_wgrad: act/dact/enc/workspace must be 16-B aligned");
     const int so = (mode & ANR_MLP_FLAG_SIGMA_ONLY) ? 1 : 0;
+    const int tan = (mode & ANR_MLP_FLAG_TANGENT) ? 1 : 0;
+    ANR_REQUIRE(!tan || so, ANR_E_BADARG, "anr_mlp_wgrad: tangent mode = sigma only");
     hipStream_t st = (hipStream_t)stream;
     if (so) {                                                        // tensors this call does not produce: zeros
         const Layout& L = layout();
@@ -437,8 +445,8 @@ extern "C" int anr_mlp_wgrad(int mode, const void* act, const void* dact, const 
         if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipMemsetAsync: %s", hipGetErrorString(e));
     }
     switch (mode & 0xff) {
-        case ANR_MLP_BF16: return wgrad_launch<true>(act, dact, enc, g4, n, so, workspace, grads_out, st);
-        case ANR_MLP_F32:  return wgrad_launch<false>(act, dact, enc, g4, n, so, workspace, grads_out, st);
+        case ANR_MLP_BF16: return wgrad_launch<true>(act, dact, enc, g4, n, so, tan, workspace, grads_out, st);
+        case ANR_MLP_F32:  return wgrad_launch<false>(act, dact, enc, g4, n, so, tan, workspace, grads_out, st);
         default: return fail(ANR_E_BADARG, "anr_mlp_wgrad: unknown mode %d", mode);
     }
 }

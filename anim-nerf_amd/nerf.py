@@ -181,13 +181,15 @@ class NeRF(nn.Module):
 
     def get_normal(self, xyz, deformation_code=None, delta=0.02):
         """models/nerf.py:177-190: d alpha / d xyz, differentiable once more w.r.t. the weights (the normals regulariser,
-        train.py:288-309).  Forward-mode tangents through library GEMMs with a hand-written backward
+        train.py:288-309).  Forward-mode tangents through the fused kernels with a hand-written backward
         (`autograd.NormalFunction`); the inputs are constants of the loss, as in the reference's call sites."""
-        from .autograd import NormalFunction
+        from .autograd import PARAM_KEYS, NormalFunction
+        if not self._hip_supported():
+            raise NotImplementedError("get_normal is built for the shipped configuration (use_view=False, D=8, W=256)")
         named = dict(self.named_parameters())
-        flat = xyz.detach().reshape(-1, 3)
+        flat = xyz.detach().reshape(-1, 3).float().contiguous()
         with torch.set_grad_enabled(True):
-            n = NormalFunction.apply(flat, float(delta), *[named[k] for k in NormalFunction.KEYS])
+            n = NormalFunction.apply(flat, float(delta), ops.MLP_MODES[self.mlp_mode] & 0xff, *[named[k] for k in PARAM_KEYS])
         return n.view(*xyz.shape[:-1], 3)
 
     def _normal_autograd(self, xyz, delta=0.02):

@@ -11,7 +11,8 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ANR_MLP_BF16, ANR_MLP_F32, ANR_MLP_FLAG_NO_DMA, ANR_MLP_FLAG_SIGMA_ONLY, AnrMlpParams
+from ._lib import (ANR_MLP_BF16, ANR_MLP_F32, ANR_MLP_FLAG_NO_DMA, ANR_MLP_FLAG_SIGMA_ONLY, ANR_MLP_FLAG_TANGENT,
+                   AnrMlpParams)
 
 ANR_MLP_FLAG_W4 = 0x200
 MLP_MODES = {"f32": ANR_MLP_F32, "fp32": ANR_MLP_F32, "bf16": ANR_MLP_BF16,
@@ -333,28 +334,30 @@ def encode(pts: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
     return enc
 
 
-def encode64(pts: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
-    """enc[n,64] = [Embedding(pts[:, :3]), 0]: the operand layout of mlp_wgrad."""
+def encode64(pts: torch.Tensor, dtype=torch.float32, tangent: bool = False) -> torch.Tensor:
+    """enc[n,64] = [Embedding(pts[:, :3]), 0]: the operand layout of mlp_wgrad.  tangent: rows in quads, rows 4p+1..3 =
+    d enc / d x, y, z of point p (forward-mode normals)."""
     lib = _lib.load()
     pts = _dev(pts, "pts")
     n = pts.shape[0]
     enc = torch.empty(n, 64, dtype=dtype, device=pts.device)
-    _lib.check(lib.anr_encode64(_ptr(pts), pts.shape[1], n, 1 if dtype == torch.bfloat16 else 0, _ptr(enc), _stream(enc)),
-               "anr_encode64")
+    flags = (1 if dtype == torch.bfloat16 else 0) | (ANR_MLP_FLAG_TANGENT if tangent else 0)
+    _lib.check(lib.anr_encode64(_ptr(pts), pts.shape[1], n, flags, _ptr(enc), _stream(enc)), "anr_encode64")
     return enc
 
 
 _WGRAD_WS = {}
 
 
-def mlp_wgrad(mode: int, act: torch.Tensor, dact: torch.Tensor, enc: torch.Tensor, g4: torch.Tensor, sigma_only: bool = False):
+def mlp_wgrad(mode: int, act: torch.Tensor, dact: torch.Tensor, enc: torch.Tensor, g4: torch.Tensor, sigma_only: bool = False,
+              tangent: bool = False):
     """All 22 parameter gradients of one network from the saved activations, the activation gradients, the encoding matrix
     (encode64) and g4 = (dL/d rgb_pre, dL/d sigma): a flat fp32 tensor in the order of autograd.PARAM_KEYS (PyTorch
     [out][in] layouts).  Hand-written split-K MFMA GEMMs (csrc/mlp_wgrad.hip); n % 64 == 0."""
     lib = _lib.load()
     act, dact, enc, g4 = _dev(act, "act", act.dtype), _dev(dact, "dact", act.dtype), _dev(enc, "enc", act.dtype), _dev(g4, "g4")
     n = act.shape[0]
-    m = (mode & 0xff) | (ANR_MLP_FLAG_SIGMA_ONLY if sigma_only else 0)
+    m = (mode & 0xff) | (ANR_MLP_FLAG_SIGMA_ONLY if sigma_only else 0) | (ANR_MLP_FLAG_TANGENT if tangent else 0)
     key = (act.device.index, torch.cuda.current_stream(act.device).cuda_stream)
     ws = _WGRAD_WS.get(key)
     need = lib.anr_mlp_wgrad_ws_floats(n)
@@ -378,14 +381,15 @@ def encode_backward(pts: torch.Tensor, d_enc: torch.Tensor) -> torch.Tensor:
     return d_pts
 
 
-def mlp_backward(bwd_pack: torch.Tensor, mode: int, g: torch.Tensor, act: torch.Tensor, sigma_only: bool = False):
+def mlp_backward(bwd_pack: torch.Tensor, mode: int, g: torch.Tensor, act: torch.Tensor, sigma_only: bool = False,
+                 tangent: bool = False):
     """g[n,4] = (dL/d rgb_pre, dL/d sigma), act[n,2432] from mlp_forward_save -> dact[n,2432] (same dtype): the
     pre-activation gradient of every layer (trunk columns only if sigma_only)."""
     lib = _lib.load()
     g, act = _dev(g, "g"), _dev(act, "act", act.dtype)
     n = g.shape[0]
     dact = torch.empty_like(act)
-    m = (mode & 0xff) | (ANR_MLP_FLAG_SIGMA_ONLY if sigma_only else 0)
+    m = (mode & 0xff) | (ANR_MLP_FLAG_SIGMA_ONLY if sigma_only else 0) | (ANR_MLP_FLAG_TANGENT if tangent else 0)
     with _timed("mlp_backward", n):
         _lib.check(lib.anr_mlp_backward(_ptr(bwd_pack), m, _ptr(g), _ptr(act), _ptr(dact), n, _stream(dact)),
                    "anr_mlp_backward")
@@ -546,14 +550,15 @@ def composite_backward(rgbs, z, rays, white_bkgd: bool, g_rgb, g_depth, g_acc, n
     return (d, dz, dfar) if want_dz else d
 
 
-def mlp_forward_save(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bool = False):
-    """Training forward: (out, act[n, anr_mlp_act_cols()]) — act keeps every layer's post-activation output."""
+def mlp_forward_save(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bool = False, tangent: bool = False):
+    """Training forward: (out, act[n, anr_mlp_act_cols()]) — act keeps every layer's post-activation output.
+    tangent (with sigma_only): points in quads, rows 4p+1..3 carry d/dx, d/dy, d/dz (ANR_MLP_FLAG_TANGENT)."""
     lib = _lib.load()
     pts = _dev(pts, "pts")
     n = pts.numel() // 4
     mode = mode & 0xff
     if sigma_only:
-        mode |= ANR_MLP_FLAG_SIGMA_ONLY
+        mode |= ANR_MLP_FLAG_SIGMA_ONLY | (ANR_MLP_FLAG_TANGENT if tangent else 0)
         out = torch.empty(n, dtype=torch.float32, device=pts.device)
     else:
         out = torch.empty(n, 4, dtype=torch.float32, device=pts.device)

@@ -48,6 +48,11 @@ extern "C" {
 /* OR-ed into `mode` of anr_mlp_forward: evaluate the trunk and the sigma row only (NeRF.get_sigma(only_sigma=True),
  * models/nerf.py:155-170; what extract_mesh.py:49-61 keeps); `out` is then float[n]. */
 #define ANR_MLP_FLAG_SIGMA_ONLY 0x400
+/* forward-mode normals (models/nerf.py:177-190, train.py:288-309): points come in quads, row 4p = point p, rows 4p+1..3 =
+ * its tangents d/dx, d/dy, d/dz riding through the same layers (no bias, ReLU gate of the primal row).  Accepted, together
+ * with ANR_MLP_FLAG_SIGMA_ONLY, by anr_mlp_forward_save (sigma of a tangent row = d sigma / d x_d), anr_mlp_backward,
+ * anr_mlp_wgrad (bias gradients from the primal rows only) and anr_encode64 (rows 4p+1..3 = d enc / d x_d). */
+#define ANR_MLP_FLAG_TANGENT 0x800
 
 int         anr_version(void);
 const char* anr_last_error(void);
@@ -253,8 +258,9 @@ int anr_mlp_forward_save_indexed(const void* pack, int mode, const float* pts, c
 int anr_encode(const float* pts, int pts_stride, int64_t n, int bf16_out, void* enc_out, void* stream);
 int anr_encode_backward(const float* pts, int pts_stride, const float* d_enc, int64_t n, float* d_pts_out,
                         void* stream);
-/* ... with a 64th, zero, column: the operand layout anr_mlp_wgrad stages (16-byte rows of 8 bf16 / 4 fp32). */
-int anr_encode64(const float* pts, int pts_stride, int64_t n, int bf16_out, void* enc_out, void* stream);
+/* ... with a 64th, zero, column: the operand layout anr_mlp_wgrad stages (16-byte rows of 8 bf16 / 4 fp32).
+ * flags: 1 = bf16 output, ANR_MLP_FLAG_TANGENT = quads (see the flag). */
+int anr_encode64(const float* pts, int pts_stride, int64_t n, int flags, void* enc_out, void* stream);
 int64_t anr_mlp_bwd_pack_bytes(int mode);
 int anr_mlp_bwd_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream);
 int anr_mlp_backward(const void* bwd_pack, int mode, const float* g, const void* act, void* dact, int64_t n,

@@ -324,6 +324,42 @@ def test_trainer_updates_body_params_table(dev, smpl_table):
     assert (table.betas.weight.detach() - before["betas"]).abs().sum() > 0
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_tangent_mode_kernels_equal_forward_mode_reference(dev, smpl_table, mode):
+    """NeRF.get_normal on the fused kernels (ANR_MLP_FLAG_TANGENT: forward, activation gradients, weight gradients)
+    against the same forward-mode computation in plain fp32 tensor ops (tests/normal_reference.py, itself held to double
+    backward in fp64 by tests/test_host_logic.py): normals and all 18 gradients, 777 points (ragged: padding rows)."""
+    from normal_reference import NormalFunctionTorch
+    m = seeded_model(smpl_table, 7, True, gain=300.0, shift=(2.0, 2.0), device=dev, mlp_mode=mode)
+    net = m.nerf
+    gen = torch.Generator().manual_seed(8)
+    xyz = (torch.rand(777, 3, generator=gen) * 1.2 - 0.6).to(dev)
+    w = torch.randn(777, 3, generator=gen).to(dev)
+    named = dict(net.named_parameters())
+    res = []
+    for fn in (lambda: net.get_normal(xyz[None])[0],
+               lambda: NormalFunctionTorch.apply(xyz, 0.02, *[named[k] for k in NormalFunctionTorch.KEYS])):
+        net.zero_grad()
+        nrm = fn()
+        (nrm * w).sum().backward()
+        res.append((nrm.detach(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+    (n1, g1), (n2, g2) = res
+    assert set(g1) == set(g2) and len(g1) == 18
+    assert 0.1 < (n2.abs().sum(-1) > 0).float().mean() < 0.9
+    if mode == "f32":
+        # piecewise constant in the ReLU pattern: a pre-activation within rounding of 0 flips a term; allow a few points
+        bad = ((n1 - n2).abs() > 1e-5 + 1e-3 * n2.abs()).any(-1)
+        assert bad.float().mean() < 0.01, bad.float().mean()
+        for k in g2:
+            assert (g1[k] - g2[k]).norm() / g2[k].norm() < 2e-2, (k, ((g1[k] - g2[k]).norm() / g2[k].norm()).item())
+    else:
+        cos = torch.nn.functional.cosine_similarity(n1.flatten(), n2.flatten(), dim=0)
+        assert cos > 0.99, cos
+        for k in g2:
+            c = torch.nn.functional.cosine_similarity(g1[k].flatten(), g2[k].flatten(), dim=0)
+            assert c > 0.97, (k, c.item())
+
+
 def test_normals_regulariser_matches_oracle_autograd(dev, smpl_table):
     """NeRF.get_normal (models/nerf.py:177-190) and its second-order gradient w.r.t. the weights."""
     m = seeded_model(smpl_table, 7, True, gain=300.0, shift=(2.0, 2.0), device=dev)

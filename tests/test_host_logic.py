@@ -121,9 +121,12 @@ def test_shard_range_partitions_exactly():
 
 
 def test_forward_mode_normals_equal_double_backward():
-    """NeRF.get_normal (forward-mode tangents + hand-written backward, autograd.NormalFunction) against autograd of
-    autograd over the same layers (models/nerf.py:177-190), in fp64 on the CPU: values and all 18 weight gradients."""
+    """The forward-mode formulation of NeRF.get_normal (three tangents per point through the trunk, ReLU gates of the
+    point, plain linear backward: what autograd.NormalFunction runs in the fused kernels, restated with tensor ops in
+    tests/normal_reference.py) against autograd of autograd over the same layers (models/nerf.py:177-190), in fp64 on the
+    CPU: values and all 18 weight gradients."""
     import anim_nerf_amd as ana
+    from normal_reference import NormalFunctionTorch
     torch.manual_seed(0)
     net = ana.NeRF(freqs_dir=0, use_view=False).double()
     xyz = torch.rand(1, 200, 3, dtype=torch.double) * 1.2 - 0.6
@@ -131,8 +134,12 @@ def test_forward_mode_normals_equal_double_backward():
         med = net._sigma_dense(xyz).median()
         net.sigma.weight.mul_(300)
         net.sigma.bias.mul_(300).add_(-300 * med)
+    named = dict(net.named_parameters())
+
+    def forward_mode(x):
+        return NormalFunctionTorch.apply(x.reshape(-1, 3), 0.02, *[named[k] for k in NormalFunctionTorch.KEYS]).view(*x.shape)
     grads = []
-    for fn in (net.get_normal, net._normal_autograd):
+    for fn in (forward_mode, net._normal_autograd):
         net.zero_grad()
         n = fn(xyz)
         (n ** 2).sum().backward()
