@@ -91,6 +91,7 @@ class AnimNeRF(nn.Module):
         # fixed spatial order of the vertices for the per-frame KNN index (not part of the state dict)
         self.register_buffer("knn_order", ops.morton_order(self.body_model.v_template), persistent=False)
         self._knn_index = None
+        self._refine = None
         self.skip_far_samples = True     # renderer only: no neighbour search for provably-invalid samples
         # renderer only: the MLP runs on the samples within dis_threshold of the body (the rest is sigma = -1e5 and
         # composites with weight exactly 0).  `query_inside=True` asks for the same at the forward() level, where it
@@ -117,6 +118,14 @@ class AnimNeRF(nn.Module):
             self.apperance_code = latent_code[:, :self.apperance_dim]
 
     def set_body_model(self, body_model_params, body_model_params_template=None):
+        # Pose refinement (optim_body_params, train.py:141-144): the values still come from the forward kernels; the
+        # gradient of the whole per-frame chain is attached to its two consumed outputs (rays in the body frame,
+        # ober2cano) by autograd.FrameChainFunction / anr_frame_backward.
+        self._refine = None
+        on_gpu = self.body_model.v_template.is_cuda
+        if on_gpu and torch.is_grad_enabled() and any(torch.is_tensor(v) and v.requires_grad for v in body_model_params.values()):
+            self._refine = dict(body_model_params)
+            body_model_params = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in body_model_params.items()}
         o = self.body_model(**body_model_params, return_verts=True)
         self.verts = o["vertices"]
         self.joints = o["joints"][:, :self.lbs_dim]
@@ -136,8 +145,30 @@ class AnimNeRF(nn.Module):
             self.pose_offsets_template = t["pose_offsets"]
 
     def _pose_grad(self):
-        """True when gradients must reach the SMPL parameters (optim_body_params, train.py:141-144)."""
+        """True when gradients must reach the SMPL parameters through the tensor-op forms (CPU, or parameters that do not
+        come as a set_body_model dict); on the GPU the kernels + FrameChainFunction serve pose refinement."""
         return torch.is_grad_enabled() and self.verts_transform.requires_grad
+
+    def _chain_consts(self):
+        bm = self.body_model
+        dev = bm.v_template.device
+        c = getattr(self, "_chain_const_cache", None)
+        if c is None or c["J0"].device != dev:
+            with torch.no_grad():
+                c = dict(J0=(bm.J_regressor @ bm.v_template).contiguous(),
+                         JS=torch.einsum("jv,vck->jck", bm.J_regressor, bm.shapedirs).contiguous(),
+                         parents=bm.parents, lbs_weights=bm.lbs_weights, shapedirs=bm.shapedirs, posedirs=bm.posedirs)
+            self._chain_const_cache = c
+        return dict(c, T_template=self.verts_transform_template.detach().contiguous())
+
+    def _attach_chain(self, value, kind, rays_world=None):
+        from .autograd import FrameChainFunction
+        p = self._refine
+        bs = value.shape[0]
+        dev = value.device
+        zero = lambda n: torch.zeros(bs, n, device=dev)
+        return FrameChainFunction.apply(p.get("betas", zero(10)), p.get("global_orient", zero(3)), p.get("body_pose", zero(69)),
+                                        p.get("transl", zero(3)), value, kind, self._chain_consts(), rays_world)
 
     def convert_to_body_model_space(self, rays):
         """rays[bs,R,>=8] -> rays in the root-joint frame; moves the cached body state too."""
@@ -150,6 +181,8 @@ class AnimNeRF(nn.Module):
             new_rays = torch.cat([o, d, torch.max(rays[..., 6:7], dist - 1.0), torch.min(rays[..., 7:8], dist + 1.0)], -1)
         else:
             new_rays = ops.rays_to_body(g_inv, rays)
+            if self._refine is not None:
+                new_rays = self._attach_chain(new_rays, 1, rays.detach())
         G = g_inv[:, None]
         self.verts = batch_transform(G, self.verts)
         self._knn_index = None
@@ -168,6 +201,8 @@ class AnimNeRF(nn.Module):
         self.ober2cano_transform = ops.ober2cano(
             self.verts_transform, self.verts_transform_template, self.shape_offsets, self.shape_offsets_template,
             self.pose_offsets, self.pose_offsets_template)
+        if self._refine is not None:
+            self.ober2cano_transform = self._attach_chain(self.ober2cano_transform, 0)
 
     # ------------------------------------------------------------------ per-point queries
     def _net(self, use_fine):

@@ -315,3 +315,39 @@ class WarpFunction(torch.autograd.Function):
             pad[..., :8] = d_rays
             d_rays = pad
         return d_rays, d_z, d_o2c, None, None, None, None
+
+
+class FrameChainFunction(torch.autograd.Function):
+    """Attaches the per-frame chain's backward to a value the forward kernels already produced: `value` is ober2cano[bs,V,4,4]
+    (kind 0) or the rays in the body frame [bs,R,8] (kind 1), computed by anr_smpl_forward / anr_rays_to_body /
+    anr_ober2cano from the SMPL parameters; backward = anr_frame_backward (one launch, forward-mode tangents per
+    parameter, csrc/frame_bwd.hip) instead of torch autograd over ~480 tensor ops (smplx/lbs.py:152-251,
+    models/anim_nerf.py:128-151)."""
+
+    @staticmethod
+    def forward(ctx, betas, global_orient, body_pose, transl, value, kind, consts, rays_world):
+        ctx.kind, ctx.consts = kind, consts
+        ctx.save_for_backward(betas, global_orient, body_pose, transl, rays_world if rays_world is not None else value.new_empty(0))
+        return value.clone()
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g):
+        betas, go, bp, transl, rays_world = ctx.saved_tensors
+        c = ctx.consts
+        bs = go.shape[0]
+        pose = torch.cat([go, bp], 1).contiguous()
+        grads = ops.frame_backward(betas.expand(bs, -1).contiguous(), pose, transl.expand(bs, -1).contiguous(), c["J0"], c["JS"],
+                                   c["parents"], c["lbs_weights"], c["shapedirs"], c["posedirs"], c["T_template"],
+                                   rays_world=rays_world if ctx.kind == 1 else None,
+                                   d_o2c=g.contiguous() if ctx.kind == 0 else None,
+                                   d_rays=g[..., :8].contiguous() if ctx.kind == 1 else None)
+        d_betas = grads[:, :10]
+        if betas.shape[0] != bs:
+            d_betas = d_betas.sum(0, keepdim=True)
+        d_transl = grads[:, 82:85]
+        if transl.shape[0] != bs:
+            d_transl = d_transl.sum(0, keepdim=True)
+        need = ctx.needs_input_grad
+        return (d_betas if need[0] else None, grads[:, 10:13] if need[1] else None, grads[:, 13:82] if need[2] else None,
+                d_transl if need[3] else None, None, None, None, None)

@@ -103,6 +103,30 @@ def smpl_forward(betas, pose, transl, v_template, shapedirs, posedirs, J_regress
     return verts, joints, A, T, so, po
 
 
+def frame_backward(betas, pose, transl, J0, JS, parents, lbs_weights, shapedirs, posedirs, T_template, rays_world=None,
+                   d_o2c=None, d_rays=None) -> torch.Tensor:
+    """dL/d(betas | global_orient | body_pose | transl)[bs,85] of the per-frame chain (SMPL/LBS, root frame, ober2cano) from
+    dL/d ober2cano[bs,V,4,4] and / or dL/d rays_body[bs,R,8]: one launch (csrc/frame_bwd.hip)."""
+    lib = _lib.load()
+    betas, pose, transl = _dev(betas, "betas"), _dev(pose, "pose"), _dev(transl, "transl")
+    bs, V = pose.shape[0], lbs_weights.shape[0]
+    T_template = _dev(T_template, "T_template")
+    R, rs = 0, 0
+    if d_rays is not None:
+        d_rays, rays_world = _dev(d_rays, "d_rays"), _dev(rays_world, "rays_world")
+        R, rs = rays_world.shape[1], rays_world.shape[2]
+    if d_o2c is not None:
+        d_o2c = _dev(d_o2c, "d_o2c")
+    grads = torch.empty(bs, 85, dtype=torch.float32, device=pose.device)
+    with _timed("frame_backward", bs):
+        _lib.check(lib.anr_frame_backward(_ptr(betas), _ptr(pose), _ptr(transl), bs, _ptr(_dev(J0, "J0")), _ptr(_dev(JS, "JS")),
+                                          _ptr(_dev(parents, "parents", torch.int64)), _ptr(_dev(lbs_weights, "lbs_weights")),
+                                          _ptr(_dev(shapedirs, "shapedirs")), _ptr(_dev(posedirs, "posedirs")), V,
+                                          _ptr(T_template), T_template.shape[0], _ptr(rays_world), rs, R, _ptr(d_o2c),
+                                          _ptr(d_rays), _ptr(grads), _stream(grads)), "anr_frame_backward")
+    return grads
+
+
 def rays_to_body(g_inv: torch.Tensor, rays: torch.Tensor) -> torch.Tensor:
     """models/anim_nerf.py:128-137.  g_inv[bs,4,4], rays[bs,R,>=8] -> [bs,R,8]."""
     lib = _lib.load()

@@ -266,6 +266,21 @@ int anr_mlp_bwd_pack(const anr_mlp_params* p, int mode, void* pack_out, void* st
 int anr_mlp_backward(const void* bwd_pack, int mode, const float* g, const void* act, void* dact, int64_t n,
                      void* stream);
 
+/* ---- a16 / f2: backward of the per-frame chain (pose refinement, optim_body_params) ------------------------------
+ * dL/d(betas[10], global_orient[3], body_pose[69], transl[3]) per frame from dL/d ober2cano[bs*V*16] (may be NULL) and
+ * dL/d rays_body[bs*R*8] (may be NULL) — everything torch autograd differentiates in smplx/lbs.py:152-251,
+ * models/anim_nerf.py:128-151 — in ONE launch: a workgroup per (frame, parameter) pushes that parameter's unit tangent
+ * through the chain in forward mode and dots it with the upstream gradients (csrc/frame_bwd.hip).
+ * pose[bs*72] = (global_orient, body_pose); J0[24*3] = J_regressor . v_template, JS[24*3*10] = J_regressor . shapedirs
+ * (constants of the body model); posedirs[207 * 3V] row-major, shapedirs[V*3*10], lbs_weights[V*24], parents[24] int64;
+ * T_template[template_bs*V*16] = the template pose's per-vertex transforms (template_bs = 1: shared by all frames);
+ * rays_world[bs*R*ray_stride] = the rays before convert_to_body_model_space.  grads_out[bs*85] in the order above. */
+int anr_frame_backward(const float* betas, const float* pose, const float* transl, int bs, const float* J0,
+                       const float* JS, const int64_t* parents, const float* lbs_weights, const float* shapedirs,
+                       const float* posedirs, int V, const float* T_template, int template_bs,
+                       const float* rays_world, int ray_stride, int R, const float* d_ober2cano,
+                       const float* d_rays_body, float* grads_out, void* stream);
+
 /* ---- a16 (part): weight and bias gradients of the MLP -----------------------------------------------------------
  * What autograd computes for the 22 parameter tensors of models/nerf.py:60-127 once the activation gradients exist:
  *   dW_l = dact_l^T in_l (in_1 = enc, in_5 = [enc, h4], in_l = h_{l-1}; xyz_encoding_final, dir_encoding on h8 / the
