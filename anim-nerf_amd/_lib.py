@@ -75,6 +75,7 @@ SIGNATURES = {
     "anr_encode64": (_I, [_P, _I, _L, _I, _P, _P]),
     "anr_mlp_wgrad_floats": (_L, []),
     "anr_mlp_wgrad_ws_floats": (_L, [_L]),
+    "anr_mlp_denc": (_I, [_I, _P, _P, _P, _L, _P, _P]),
     "anr_mlp_wgrad": (_I, [_I, _P, _P, _P, _P, _L, _P, _P, _P]),
     "anr_encode_backward": (_I, [_P, _I, _P, _L, _P, _P]),
     "anr_mlp_bwd_pack_bytes": (_L, [_I]),

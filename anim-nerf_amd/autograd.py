@@ -137,10 +137,8 @@ class MLPFunction(torch.autograd.Function):
                     grads[k] = None
             d_enc = None
             if want_pts:                                            # pose refinement: through the two encoding inputs
-                for l in (1, 5):
-                    W = params[PARAM_KEYS.index(f"xyz_encoding_{l}.0.weight")][:, :63].to(dt)
-                    t = (dact[:, 256 * (l - 1):256 * l] @ W).float()
-                    d_enc = t if d_enc is None else d_enc + t
+                d_enc = ops.mlp_denc(ctx.mode_id, dact, params[PARAM_KEYS.index("xyz_encoding_1.0.weight")],
+                                     params[PARAM_KEYS.index("xyz_encoding_5.0.weight")])
         d_pts = None
         if want_pts:                                                # through x -> (x, sin 2^k x, cos 2^k x)
             d_pts = ops.encode_backward(pts, d_enc.contiguous())

@@ -450,3 +450,102 @@ extern "C" int anr_mlp_wgrad(int mode, const void* act, const void* dact, const 
         default: return fail(ANR_E_BADARG, "anr_mlp_wgrad: unknown mode %d", mode);
     }
 }
+
+// =====================================================================================================================
+// dL/d enc: the gradient that leaves the MLP through its two encoding inputs (layers 1 and 5) on its way to the sample
+// positions — pose refinement only (train.py:141-144):  d_enc[p][c] = dact_1[p] . W1[:, c] + dact_5[p] . W5[:, c],  c < 63.
+// Points are the MFMA row dimension here, so the A fragments (8 consecutive out-features of one point) are contiguous in
+// the row-major dact and come straight from global memory; the two 256 x 64 weight panels are converted to B-fragment
+// order in LDS once per workgroup.  One wave per 32 points, persistent workgroups.
+namespace anr {
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void denc_kernel(const char* __restrict__ dact, const float* __restrict__ W1,
+                                                   const float* __restrict__ W5, int64_t n, float* __restrict__ d_enc) {
+    using T = typename WgCfg<BF16>::T;
+    constexpr int KF = BF16 ? 16 : 128;                      // K fragments per layer (16 / 2 out-features each)
+    constexpr int EPL = BF16 ? 8 : 1;                        // elements per lane and fragment
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    T* panel = reinterpret_cast<T*>(lds);                    // [layer 2][kf][ntile 2][lane 64][EPL]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2 * KF * 2 * 64; i += 256) {
+        const int l = i & 63, nt = (i >> 6) & 1, kf = (i >> 7) % KF, layer = (i >> 7) / KF;
+        const int j = (l & 31) + 32 * nt, h = l >> 5;
+        const float* W = layer ? W5 : W1;
+        const int ld = layer ? 319 : 63;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int k = BF16 ? 16 * kf + 8 * (e >> 2) + 4 * h + (e & 3) : 2 * kf + h;
+            panel[(int64_t)i * EPL + e] = (T)(j < 63 ? W[(int64_t)k * ld + j] : 0.0f);
+        }
+    }
+    __syncthreads();
+    const int64_t n_tiles = (n + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t p = tile * 32 + (lane & 31);
+        const int64_t row = p < n ? p : n - 1;
+        const char* arow = dact + row * (int64_t)ACT_COLS * sizeof(T);
+        const int h = lane >> 5;
+        f32x16 acc[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+#pragma unroll
+        for (int layer = 0; layer < 2; ++layer) {
+            const char* a0 = arow + (layer ? 1024 : 0) * sizeof(T);
+#pragma unroll 4
+            for (int kf = 0; kf < KF; ++kf) {
+                const T* b0 = panel + ((int64_t)((layer * KF + kf) * 2 + 0) * 64 + lane) * EPL;
+                const T* b1 = panel + ((int64_t)((layer * KF + kf) * 2 + 1) * 64 + lane) * EPL;
+                if constexpr (BF16) {
+                    const uint2 lo = *reinterpret_cast<const uint2*>(a0 + (16 * kf + 4 * h) * 2);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(a0 + (16 * kf + 8 + 4 * h) * 2);
+                    const bf16x8 fa = __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, *reinterpret_cast<const bf16x8*>(b0), acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, *reinterpret_cast<const bf16x8*>(b1), acc[1], 0, 0, 0);
+                } else {
+                    const float fa = *reinterpret_cast<const float*>(a0 + (2 * kf + h) * 4);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, *b0, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, *b1, acc[1], 0, 0, 0);
+                }
+            }
+        }
+        // D[row = point (e&3) + 8 (e>>2) + 4 h][col = channel lane&31 (+32)]
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t pr = tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int ch = (lane & 31) + 32 * nt;
+                if (pr < n && ch < 63) d_enc[pr * 63 + ch] = acc[nt][e];
+            }
+    }
+}
+
+}  // namespace anr
+
+extern "C" int anr_mlp_denc(int mode, const void* dact, const float* w1, const float* w5, int64_t n, float* d_enc_out,
+                            void* stream) {
+    ANR_REQUIRE(dact && w1 && w5 && d_enc_out, ANR_E_BADARG, "anr_mlp_denc: null pointer");
+    ANR_REQUIRE(n > 0 && ((uintptr_t)dact & 15) == 0, ANR_E_BADARG, "anr_mlp_denc: n=%lld / alignment", (long long)n);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t tiles = (n + 127) / 128;
+    dim3 grid((unsigned)(tiles < 2 * cus ? tiles : 2 * cus));
+    hipStream_t st = (hipStream_t)stream;
+    if ((mode & 0xff) == ANR_MLP_BF16) {
+        const int lds = 2 * 16 * 2 * 64 * 8 * 2;
+        auto k = denc_kernel<true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail((int)e, "anr_mlp_denc: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, reinterpret_cast<const char*>(dact), w1, w5, n, d_enc_out);
+    } else if ((mode & 0xff) == ANR_MLP_F32) {
+        const int lds = 2 * 128 * 2 * 64 * 4;
+        auto k = denc_kernel<false>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail((int)e, "anr_mlp_denc: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, reinterpret_cast<const char*>(dact), w1, w5, n, d_enc_out);
+    } else {
+        return fail(ANR_E_BADARG, "anr_mlp_denc: unknown mode %d", mode);
+    }
+    return check_launch("anr_mlp_denc");
+}

@@ -394,6 +394,19 @@ def mlp_wgrad(mode: int, act: torch.Tensor, dact: torch.Tensor, enc: torch.Tenso
     return grads
 
 
+def mlp_denc(mode: int, dact: torch.Tensor, w1: torch.Tensor, w5: torch.Tensor) -> torch.Tensor:
+    """d_enc[n,63] = dact_1 . W1[:, :63] + dact_5 . W5[:, :63] (fp32): the gradient leaving the MLP through its encoding
+    inputs (pose refinement).  w1 / w5 = xyz_encoding_1 / _5 weights as stored (fp32)."""
+    lib = _lib.load()
+    dact = _dev(dact, "dact", dact.dtype)
+    w1, w5 = _dev(w1.detach(), "w1"), _dev(w5.detach(), "w5")
+    n = dact.shape[0]
+    d_enc = torch.empty(n, 63, dtype=torch.float32, device=dact.device)
+    with _timed("mlp_denc", n):
+        _lib.check(lib.anr_mlp_denc(mode & 0xff, _ptr(dact), _ptr(w1), _ptr(w5), n, _ptr(d_enc), _stream(d_enc)), "anr_mlp_denc")
+    return d_enc
+
+
 def encode_backward(pts: torch.Tensor, d_enc: torch.Tensor) -> torch.Tensor:
     """d_pts[n,4] = (dL/dxyz, 0) from d_enc[n,63] (fp32)."""
     lib = _lib.load()

@@ -296,6 +296,11 @@ int64_t anr_mlp_wgrad_ws_floats(int64_t n);
 int anr_mlp_wgrad(int mode, const void* act, const void* dact, const void* enc, const float* g, int64_t n,
                   float* workspace, float* grads_out, void* stream);
 
+/* ... and the gradient that leaves the network through its two encoding inputs (pose refinement):
+ * d_enc_out[n*63] = dact[:, 0:256] . W1[:, 0:63] + dact[:, 1024:1280] . W5[:, 0:63]  (xyz_encoding_1 / _5 weights, fp32,
+ * PyTorch [256][63] / [256][319] layouts); anr_encode_backward turns it into dL/d xyz. */
+int anr_mlp_denc(int mode, const void* dact, const float* w1, const float* w5, int64_t n, float* d_enc_out, void* stream);
+
 /* ---- sigma-grid points for mesh extraction -------------------------------------------------------
  * extract_mesh.py:27-35 (create_grid: np.meshgrid(x, y, z), 'xy' indexing, fp64 linspace -> fp32) and :152-157
  * (+ bounding-box centre of the posed vertices).  Flat index n = (j*N + i)*N + k -> (x[i], y[j], z[k]).
