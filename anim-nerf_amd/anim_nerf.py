@@ -172,7 +172,16 @@ class AnimNeRF(nn.Module):
 
     def convert_to_body_model_space(self, rays):
         """rays[bs,R,>=8] -> rays in the root-joint frame; moves the cached body state too."""
-        # [bs,4,4]; bs tiny.  Under pose refinement the closed form (differentiable, no LAPACK launch sequence)
+        if not self._pose_grad() and rays.is_cuda:
+            # one launch for G^-1 and the body state, one for the rays (no LAPACK inverse: that call synchronises the host)
+            g_inv, self.global_transform, self.verts, self.joints, self.verts_transform = ops.to_root_frame(
+                self.global_transform, self.verts, self.joints, self.verts_transform)
+            self._knn_index = None
+            new_rays = ops.rays_to_body(g_inv, rays)
+            if self._refine is not None:
+                new_rays = self._attach_chain(new_rays, 1, rays.detach())
+            return new_rays
+        # tensor-op form: CPU, or gradients that must flow through torch autograd
         g_inv = _affine_inverse(self.global_transform) if self._pose_grad() else torch.inverse(self.global_transform)
         if self._pose_grad():                                              # per-frame, differentiable form of the kernel
             o = batch_transform(g_inv[:, None], rays[..., 0:3])
@@ -181,8 +190,6 @@ class AnimNeRF(nn.Module):
             new_rays = torch.cat([o, d, torch.max(rays[..., 6:7], dist - 1.0), torch.min(rays[..., 7:8], dist + 1.0)], -1)
         else:
             new_rays = ops.rays_to_body(g_inv, rays)
-            if self._refine is not None:
-                new_rays = self._attach_chain(new_rays, 1, rays.detach())
         G = g_inv[:, None]
         self.verts = batch_transform(G, self.verts)
         self._knn_index = None

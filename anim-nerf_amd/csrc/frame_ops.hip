@@ -71,6 +71,72 @@ __global__ void rays_to_body_kernel(const float* __restrict__ ginv, const float*
     dst[1] = make_float4(dn[1], dn[2], near, far);
 }
 
+// ------------------------------------------------------------------ a4 body state -> root frame
+// reference: models/anim_nerf.py:128-145: G^-1 (closed form: the root transform is affine), then verts, joints, the
+// root transform itself and the per-vertex transforms move into the root-joint frame.  One launch instead of a LAPACK
+// inverse (a host synchronisation on this stack) + four batched products of 4x4 matrices.
+__device__ __forceinline__ void affine_inverse12(const float* __restrict__ G, float (&I)[12]) {
+    const float a = G[0], b = G[1], c = G[2], d = G[4], e = G[5], f = G[6], g = G[8], h = G[9], i = G[10];
+    const float c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
+    const float det = a * c00 + b * c01 + c * c02;
+    const float r = 1.0f / det;
+    I[0] = c00 * r; I[1] = (c * h - b * i) * r; I[2] = (b * f - c * e) * r;
+    I[4] = c01 * r; I[5] = (a * i - c * g) * r; I[6] = (c * d - a * f) * r;
+    I[8] = c02 * r; I[9] = (b * g - a * h) * r; I[10] = (a * e - b * d) * r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) I[k * 4 + 3] = -(I[k * 4 + 0] * G[3] + I[k * 4 + 1] * G[7] + I[k * 4 + 2] * G[11]);
+}
+
+__global__ void to_root_frame_kernel(const float* __restrict__ G, const float* __restrict__ verts,
+                                     const float* __restrict__ joints, const float* __restrict__ T, int V, int J,
+                                     float* __restrict__ ginv_out, float* __restrict__ g_root_out,
+                                     float* __restrict__ verts_out, float* __restrict__ joints_out, float* __restrict__ T_out) {
+    const int b = blockIdx.y;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const float* Gb = G + b * 16;
+    float I[12];
+    affine_inverse12(Gb, I);
+    if (v == 0) {
+        float* o = ginv_out + b * 16;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) o[k] = I[k];
+        o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
+        float* gr = g_root_out + b * 16;                     // G^-1 . G (the reference keeps the product, not the identity)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                gr[r * 4 + c] = I[r * 4 + 0] * Gb[c] + I[r * 4 + 1] * Gb[4 + c] + I[r * 4 + 2] * Gb[8 + c] + (c == 3 ? I[r * 4 + 3] : 0.0f);
+        gr[12] = 0.f; gr[13] = 0.f; gr[14] = 0.f; gr[15] = 1.f;
+    }
+    if (v < J) {
+        const float* p = joints + ((int64_t)b * J + v) * 3;
+        float* o = joints_out + ((int64_t)b * J + v) * 3;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o[r] = I[r * 4 + 0] * p[0] + I[r * 4 + 1] * p[1] + I[r * 4 + 2] * p[2] + I[r * 4 + 3];
+    }
+    if (v >= V) return;
+    {
+        const float* p = verts + ((int64_t)b * V + v) * 3;
+        float* o = verts_out + ((int64_t)b * V + v) * 3;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o[r] = I[r * 4 + 0] * p[0] + I[r * 4 + 1] * p[1] + I[r * 4 + 2] * p[2] + I[r * 4 + 3];
+    }
+    const float4* t4 = reinterpret_cast<const float4*>(T + ((int64_t)b * V + v) * 16);
+    const float4 r0 = t4[0], r1 = t4[1], r2 = t4[2], r3 = t4[3];
+    const float M[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+    float4* o4 = reinterpret_cast<float4*>(T_out + ((int64_t)b * V + v) * 16);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float q[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)      // full 4x4 product as torch computes it (the bottom row of T is 0 0 0 1 up to rounding)
+            q[c] = I[r * 4 + 0] * M[c] + I[r * 4 + 1] * M[4 + c] + I[r * 4 + 2] * M[8 + c] + I[r * 4 + 3] * M[12 + c];
+        o4[r] = make_float4(q[0], q[1], q[2], q[3]);
+    }
+    o4[3] = r3;
+}
+
 // ------------------------------------------------------------------ a5 observation -> canonical
 // reference: models/anim_nerf.py:147-151.  One thread per vertex; affine closed-form inverse.
 __global__ void ober2cano_kernel(const float* __restrict__ tp, const float* __restrict__ tt,
@@ -212,6 +278,18 @@ extern "C" int anr_rays_to_body(const float* g_inv, const float* rays_in, float*
     hipLaunchKernelGGL(rays_to_body_kernel, dim3((R + 255) / 256, bs), dim3(256), 0, (hipStream_t)stream,
                        g_inv, rays_in, rays_out, R, stride_in);
     return check_launch("anr_rays_to_body");
+}
+
+extern "C" int anr_to_root_frame(const float* global_transform, const float* verts, const float* joints, const float* T, int bs,
+                                 int V, int J, float* g_inv_out, float* g_root_out, float* verts_out, float* joints_out,
+                                 float* T_out, void* stream) {
+    ANR_REQUIRE(global_transform && verts && joints && T && g_inv_out && g_root_out && verts_out && joints_out && T_out,
+                ANR_E_BADARG, "anr_to_root_frame: null pointer");
+    ANR_REQUIRE(bs > 0 && V > 0 && J > 0 && J <= V, ANR_E_BADARG, "anr_to_root_frame: bs=%d V=%d J=%d", bs, V, J);
+    ANR_REQUIRE((((uintptr_t)T | (uintptr_t)T_out) & 15) == 0, ANR_E_ALIGN, "anr_to_root_frame: T must be 16-B aligned");
+    hipLaunchKernelGGL(to_root_frame_kernel, dim3((V + 127) / 128, bs), dim3(128), 0, (hipStream_t)stream, global_transform, verts,
+                       joints, T, V, J, g_inv_out, g_root_out, verts_out, joints_out, T_out);
+    return check_launch("anr_to_root_frame");
 }
 
 extern "C" int anr_ober2cano(const float* t_pose, const float* t_template, const float* shape_off,

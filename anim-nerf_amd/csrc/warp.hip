@@ -123,10 +123,14 @@ __device__ __forceinline__ void best_init(Best4& b, float cap2 = 3.0e38f) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) { b.d[k] = cap2; b.i[k] = -1; }
 }
-// insert (c, v) keeping d ascending; strict < : the first visited vertex wins exact ties.  Branch-free:
-// new d[k] = median(d[k-1], d[k], c) for a sorted list, the ids follow the four comparisons.
+// insert (c, v) keeping (d, slot) ascending LEXICOGRAPHICALLY: among vertices at exactly the same distance the lower
+// index slot wins, whatever order the traversal visits them in — the exact search, the cell-sorted search and the
+// brute-force check then agree bit for bit also on ties (about one sample in 10^7 on a 1024^2 frame, enough to break
+// a bit-identity test).  Branch-free: new d[k] = median(d[k-1], d[k], c) for a sorted list, the ids follow the four
+// comparisons.
 __device__ __forceinline__ void best_insert(Best4& b, float c, int v) {
-    const bool m0 = c < b.d[0], m1 = c < b.d[1], m2 = c < b.d[2], m3 = c < b.d[3];
+    const bool m0 = c < b.d[0] || (c == b.d[0] && v < b.i[0]), m1 = c < b.d[1] || (c == b.d[1] && v < b.i[1]);
+    const bool m2 = c < b.d[2] || (c == b.d[2] && v < b.i[2]), m3 = c < b.d[3] || (c == b.d[3] && v < b.i[3]);
     b.i[3] = m3 ? (m2 ? b.i[2] : v) : b.i[3];
     b.i[2] = m2 ? (m1 ? b.i[1] : v) : b.i[2];
     b.i[1] = m1 ? (m0 ? b.i[0] : v) : b.i[1];
@@ -166,7 +170,7 @@ __device__ __forceinline__ void scan_cluster(const float* lds, int Vp, int c, fl
             d2[t] = dx * dx + dy * dy + dz * dz;
         }
         float m = fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3]));
-        if (m < best.d[3]) {
+        if (m <= best.d[3]) {                              // (<=: a tie with the current 4th may carry a lower slot)
 #pragma unroll
             for (int t = 0; t < 4; ++t) best_insert(best, d2[t], c * CS + q * 4 + t);
         }
@@ -223,15 +227,15 @@ __device__ __forceinline__ void search_from(const float* lds, const IndexDims& d
     // every other cluster whose box can still beat the current 4th-best
     for (int t = 0; t < d.NT; ++t) {
         const float tv = box_d2(tboxes + t * 8, px, py, pz);
-        if (!__any(active && tv < best.d[3])) continue;
+        if (!__any(active && tv <= best.d[3])) continue;
         const int s_end = min((t + 1) * TC, d.NS);
         for (int q = t * TC; q < s_end; ++q) {
             const float sv = box_d2(sboxes + q * 8, px, py, pz);
-            if (!__any(active && sv < best.d[3])) continue;
+            if (!__any(active && sv <= best.d[3])) continue;
             const int c_end = min((q + 1) * SC, d.NC);
             for (int c = q * SC; c < c_end; ++c) {
                 const float v = box_d2(boxes + c * 8, px, py, pz);
-                const bool need = active && (c != seed_c) && (v < best.d[3]);
+                const bool need = active && (c != seed_c) && (v <= best.d[3]);
                 if (__any(need)) {
                     if (need) scan_cluster(lds, d.Vp, c, px, py, pz, best);
                 }

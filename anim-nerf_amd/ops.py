@@ -127,6 +127,19 @@ def frame_backward(betas, pose, transl, J0, JS, parents, lbs_weights, shapedirs,
     return grads
 
 
+def to_root_frame(global_transform, verts, joints, T):
+    """models/anim_nerf.py:128-144 for the body state: -> (g_inv[bs,4,4], G_root[bs,4,4], verts, joints, T) in the
+    root-joint frame, one launch (closed-form affine inverse: no LAPACK call, no host synchronisation)."""
+    lib = _lib.load()
+    G, verts, joints, T = _dev(global_transform, "global_transform"), _dev(verts, "verts"), _dev(joints, "joints"), _dev(T, "T")
+    bs, V, J = verts.shape[0], verts.shape[1], joints.shape[1]
+    g_inv, g_root = torch.empty_like(G), torch.empty_like(G)
+    v2, j2, T2 = torch.empty_like(verts), torch.empty_like(joints), torch.empty_like(T)
+    _lib.check(lib.anr_to_root_frame(_ptr(G), _ptr(verts), _ptr(joints), _ptr(T), bs, V, J, _ptr(g_inv), _ptr(g_root), _ptr(v2),
+                                     _ptr(j2), _ptr(T2), _stream(T2)), "anr_to_root_frame")
+    return g_inv, g_root, v2, j2, T2
+
+
 def rays_to_body(g_inv: torch.Tensor, rays: torch.Tensor) -> torch.Tensor:
     """models/anim_nerf.py:128-137.  g_inv[bs,4,4], rays[bs,R,>=8] -> [bs,R,8]."""
     lib = _lib.load()

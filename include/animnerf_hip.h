@@ -87,6 +87,12 @@ int anr_smpl_forward(const float* betas, const float* pose, const float* transl,
  * (stride >= 8 floats; only the first 8 are read/written). */
 int anr_rays_to_body(const float* g_inv, const float* rays_in, float* rays_out,
                      int bs, int R, int stride_in, void* stream);
+/* ... and the body state: G^-1 in closed form (the root transform is affine) and verts[bs*V*3], joints[bs*J*3],
+ * vertices_transform T[bs*V*16] and G itself moved into the root frame (models/anim_nerf.py:138-144), one launch.
+ * g_inv_out[bs*16] is what anr_rays_to_body takes; g_root_out[bs*16] = G^-1 G. */
+int anr_to_root_frame(const float* global_transform, const float* verts, const float* joints, const float* T, int bs,
+                      int V, int J, float* g_inv_out, float* g_root_out, float* verts_out, float* joints_out,
+                      float* T_out, void* stream);
 
 /* ---- a5: observation -> canonical per-vertex transform -----------------------------
  * models/anim_nerf.py:147-151 (clac_ober2cano_transform):
