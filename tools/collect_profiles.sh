@@ -1,0 +1,25 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (gpurun -- bash tools/collect_profiles.sh): kernel-trace + PMC passes of the bench command for the
+# round's profiles.  rocprofv3 gets `python3 bench.py ...` directly (no wrapper between the profiler and the program);
+# --pmc passes are separate from each other and carry no trace domain besides --kernel-trace.
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out/prof_r02
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for wl in cfg2 cfg3 cfg4; do
+  extra="--no-extras --cpu-rays 0 --no-psnr --steps 3 --warmup 1"
+  [ $wl = cfg4 ] && extra="--no-extras --steps 4 --warmup 2"
+  rocprofv3 --kernel-trace --stats -d $OUT/${wl}_trace --output-format csv -- python3 $ROOT/bench.py --workload $wl $extra > $OUT/${wl}_trace.json 2> /dev/null
+  if [ $wl != cfg4 ]; then
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${wl}_fetch --output-format csv -- python3 $ROOT/bench.py --workload $wl $extra > /dev/null 2>&1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${wl}_write --output-format csv -- python3 $ROOT/bench.py --workload $wl $extra > /dev/null 2>&1
+  fi
+done
+cd $ROOT
+for wl in cfg2 cfg3; do
+  echo "== $wl (4 frames: 1 warm-up + 3 timed)" > $OUT/hbm_${wl}.txt
+  python3 tools/hbm_table.py $OUT/${wl}_fetch $OUT/${wl}_write $OUT/${wl}_trace >> $OUT/hbm_${wl}.txt
+  cat $OUT/hbm_${wl}.txt
+done
+ls $OUT
