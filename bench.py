@@ -217,6 +217,20 @@ def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling=
         "frac_on_survey_compulsory_bytes": comp_bytes / other_s / (PEAK_HBM_GBS * 1e9) if other_s > 0 else None,
         "ms_per_step": other_s / steps * 1e3,
     }
+    if not use_warp and H == 1024 and args.n_coarse == 64 and args.n_fine == 64:
+        # the same kernels by the memory-side counters (FETCH_SIZE x 2 + WRITE_SIZE of the round's PMC passes, per frame):
+        # what the launches really moved, rays and partial sectors included, over this run's HIP-event time
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "mlp_hbm_traffic.json")))
+        if files and other_s > 0:
+            with open(files[-1]) as fh:
+                t = json.load(fh)
+            grp = t.get("hbm_kernels_cfg2")
+            if grp:
+                per_frame = sum(v["read_GB_per_frame"] + v["write_GB_per_frame"] for v in grp.values()) * 1e9
+                result["roofline_hbm_kernels"].update({
+                    "traffic": per_frame, "traffic_unit": f"HBM bytes per frame by PMC counters ({os.path.relpath(files[-1], ROOT)}, commit {t.get('commit')})",
+                    "frac_by_counters": per_frame * (n_rays / n_frame) * steps / other_s / (PEAK_HBM_GBS * 1e9)})
     if checks and rank == 0 and world == 1:
         if not args.no_psnr:
             # PSNR of this mode's image vs the fp32 parity path (pinned to the reference) on a centre crop
