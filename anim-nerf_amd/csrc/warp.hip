@@ -462,8 +462,11 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_points_kernel(
 //           cells, so the lanes of the wave-uniform cluster traversal all want the same few clusters.
 // The order inside a cell depends on scheduling; every lane's search is independent of its wave-mates, so the
 // results do not.  Workspace: anr_warp_ws_ints(bs, N) int32.
-constexpr int GRID = 64;
-constexpr int NCELL = GRID * GRID * GRID;
+constexpr int GRID = 64;                       // finest cell grid (full frames); small batches use a coarser one, see grid_for()
+constexpr int NCELL = GRID * GRID * GRID;      // stride of the per-body cell arrays, whatever grid is in use
+// One exact search per occupied cell pays off when a cell serves many samples.  A training batch (1,024 rays per body)
+// occupies about as many 64^3 cells as it has near samples; a 32^3 grid has an eighth of the cells to search and scan.
+__host__ inline int grid_for(int64_t samples_per_body) { return samples_per_body >= (int64_t)1 << 19 ? 64 : 32; }
 constexpr float MIN_CELL = 0.04f;
 
 struct WarpWs {
@@ -481,17 +484,17 @@ struct WarpWs {
     }
 };
 
-__device__ __forceinline__ float cell_size(const float* gbox, float thr) {
+__device__ __forceinline__ float cell_size(const float* gbox, float thr, int G) {
     const float ex = gbox[4] - gbox[0], ey = gbox[5] - gbox[1], ez = gbox[6] - gbox[2];
-    return fmaxf(MIN_CELL, (fmaxf(fmaxf(ex, ey), ez) + 2.0f * thr) * (1.0f / GRID));
+    return fmaxf(MIN_CELL, (fmaxf(fmaxf(ex, ey), ez) + 2.0f * thr) * (1.0f / (float)G));
 }
-__device__ __forceinline__ int cell_of(const float* gbox, float thr, float px, float py, float pz) {
-    const float c = cell_size(gbox, thr);
+__device__ __forceinline__ int cell_of(const float* gbox, float thr, int G, float px, float py, float pz) {
+    const float c = cell_size(gbox, thr, G);
     const float inv = 1.0f / c;
-    const int ix = min(max((int)((px - gbox[0] + thr) * inv), 0), GRID - 1);
-    const int iy = min(max((int)((py - gbox[1] + thr) * inv), 0), GRID - 1);
-    const int iz = min(max((int)((pz - gbox[2] + thr) * inv), 0), GRID - 1);
-    return (ix * GRID + iy) * GRID + iz;
+    const int ix = min(max((int)((px - gbox[0] + thr) * inv), 0), G - 1);
+    const int iy = min(max((int)((py - gbox[1] + thr) * inv), 0), G - 1);
+    const int iz = min(max((int)((pz - gbox[2] + thr) * inv), 0), G - 1);
+    return (ix * G + iy) * G + iz;
 }
 
 // Per-workgroup aggregation of the cell counters: neighbouring rays and consecutive samples fall into the same few
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
     float4* __restrict__ pts_out, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w, int32_t* __restrict__ list,
     int32_t* __restrict__ cells, int32_t* __restrict__ count, int32_t* __restrict__ cell_count,
     uint8_t* __restrict__ valid_mask, const float4* __restrict__ reuse_pts, const uint8_t* __restrict__ reuse_mask,
-    const uint8_t* __restrict__ perm, int reuse_K) {
+    const uint8_t* __restrict__ perm, int reuse_K, int G) {
     __shared__ int wave_cnt[WARP_THREADS / 64];
     __shared__ int block_base;
     __shared__ int hkeys[HN], hcnt[HN];
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
                     reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(0, 0, 0, 0);
                 }
                 if (near) {
-                    cell = cell_of(gbox, thr, px, py, pz);
+                    cell = cell_of(gbox, thr, G, px, py, pz);
                     const int slot = hash_slot(hkeys, cell);
                     if (slot >= 0) atomicAdd(&hcnt[slot], 1);
                     else atomicAdd(cell_count + (int64_t)b * NCELL + cell, 1);
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cells_kernel(const float* _
                                                                   const int32_t* __restrict__ occ_count,
                                                                   int32_t* __restrict__ occ_cursor,
                                                                   float* __restrict__ cell_cap2,
-                                                                  int32_t* __restrict__ cell_seed) {
+                                                                  int32_t* __restrict__ cell_seed, int G) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.y;
     const int n_occ = occ_count[b];
@@ -675,7 +678,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cells_kernel(const float* _
     float* cap = cell_cap2 + (int64_t)b * NCELL;
     stage_index(index + (int64_t)b * d.total_floats(), d.lds_floats(), lds);
     const float* gbox = lds + d.body_off();
-    const float cs = cell_size(gbox, thr);
+    const float cs = cell_size(gbox, thr, G);
     const float r = cs * 0.8662f;                        // sqrt(3)/2, rounded up
     const int lane = threadIdx.x & 63;
     for (;;) {
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cells_kernel(const float* _
         const int i = item * 64 + lane;
         const bool go = i < n_occ;
         const int cell = occ[go ? i : n_occ - 1];
-        const int ix = cell / (GRID * GRID), iy = (cell / GRID) % GRID, iz = cell % GRID;
+        const int ix = cell / (G * G), iy = (cell / G) % G, iz = cell % G;
         const float cx = gbox[0] - thr + ((float)ix + 0.5f) * cs;
         const float cy = gbox[1] - thr + ((float)iy + 0.5f) * cs;
         const float cz = gbox[2] - thr + ((float)iz + 0.5f) * cs;
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cells_kernel(const float* _
 __global__ __launch_bounds__(1024) void warp_cell_scan_kernel(int32_t* __restrict__ cell_count,
                                                               int32_t* __restrict__ cell_start,
                                                               const float* __restrict__ cell_cap2,
-                                                              int32_t* __restrict__ live) {
+                                                              int32_t* __restrict__ live, int G) {
     __shared__ int wave_tot[16];
     __shared__ int carry;
     int32_t* cnt = cell_count + (int64_t)blockIdx.x * NCELL;
@@ -715,7 +718,7 @@ __global__ __launch_bounds__(1024) void warp_cell_scan_kernel(int32_t* __restric
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base < NCELL; base += 4096) {
+    for (int base = 0; base < G * G * G; base += 4096) {
         // 4 consecutive cells per thread
         int4 v = reinterpret_cast<const int4*>(cnt + base)[threadIdx.x];
         reinterpret_cast<int4*>(cnt + base)[threadIdx.x] = make_int4(0, 0, 0, 0);
@@ -798,7 +801,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
     const float* __restrict__ index, IndexDims d, const float* __restrict__ ober2cano, const float* __restrict__ lbs_w,
     int J, int64_t N, float thr, float4* __restrict__ pts_out, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w,
     const int32_t* __restrict__ list, const int32_t* __restrict__ count, int32_t* __restrict__ cursor,
-    const float* __restrict__ cell_cap2, uint8_t* __restrict__ valid_mask, const int32_t* __restrict__ cell_seed) {
+    const float* __restrict__ cell_cap2, uint8_t* __restrict__ valid_mask, const int32_t* __restrict__ cell_seed, int G) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.y;
     const int cnt = count[b];
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
         // inside the cell's radius the exact four neighbours are guaranteed to be found (warp_cells_kernel)
         // ... and the first cluster to scan is the one the cell's own search found nearest: no descent per point
         Best4 best;
-        const int cell = cell_of(gbox, thr, p.x, p.y, p.z);
+        const int cell = cell_of(gbox, thr, G, p.x, p.y, p.z);
         best_init(best, cap[cell]);
         search_from(lds, d, p.x, p.y, p.z, go, best, go ? cell_seed[(int64_t)b * NCELL + cell] : 0);
         if (!go) continue;
@@ -1039,6 +1042,8 @@ extern "C" int anr_warp_points_lean(const float* xyz, int xyz_stride, const floa
         ANR_REQUIRE(dist_out == nullptr, ANR_E_BADARG, "anr_warp_points: debug outputs need skip_far = 0");
         ANR_REQUIRE(N < (int64_t)1 << 31, ANR_E_BADARG, "anr_warp_points: N=%lld does not fit the int32 list", (long long)N);
         WarpWs w(ws, bs, N);
+        const int G = grid_for(N);
+        const int cells = G * G * G;
         hipError_t e = hipMemsetAsync(w.count, 0, sizeof(int32_t) * WarpWs::zeroed_ints(bs), st);
         if (e != hipSuccess) return fail((int)e, "anr_warp_points: hipMemsetAsync: %s", hipGetErrorString(e));
         dim3 g1((unsigned)((N + CLS_ITERS * WARP_THREADS - 1) / (CLS_ITERS * WARP_THREADS)), bs);
@@ -1046,22 +1051,22 @@ extern "C" int anr_warp_points_lean(const float* xyz, int xyz_stride, const floa
             hipLaunchKernelGGL(warp_classify_kernel<true>, g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride, z,
                                K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
                                w.list, w.cells, w.count, w.cell_count, valid_mask_out,
-                               reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K);
+                               reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K, G);
         else
             hipLaunchKernelGGL(warp_classify_kernel<false>, g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride,
                                z, K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                               w.list, w.cells, w.count, w.cell_count, valid_mask_out, nullptr, nullptr, nullptr, 0);
+                               w.list, w.cells, w.count, w.cell_count, valid_mask_out, nullptr, nullptr, nullptr, 0, G);
         if (int rc = check_launch("anr_warp_points (classify)")) return rc;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         int64_t gx = (cus + bs - 1) / bs;                                   // one persistent workgroup per CU in total
         if (int rc = allow_big_lds(warp_cells_kernel, bytes, "anr_warp_points")) return rc;
-        hipLaunchKernelGGL(warp_cell_list_kernel, dim3(NCELL / (4 * WARP_THREADS), bs), dim3(WARP_THREADS), 0, st, w.cell_count,
+        hipLaunchKernelGGL(warp_cell_list_kernel, dim3(cells / (4 * WARP_THREADS), bs), dim3(WARP_THREADS), 0, st, w.cell_count,
                            w.occ_list, w.occ_count);
-        hipLaunchKernelGGL(warp_cells_kernel, dim3((unsigned)(gx < NCELL / WARP_THREADS ? gx : NCELL / WARP_THREADS), bs),
+        hipLaunchKernelGGL(warp_cells_kernel, dim3((unsigned)(gx < cells / WARP_THREADS ? gx : cells / WARP_THREADS), bs),
                            dim3(WARP_THREADS), bytes, st, index, d, dis_threshold, w.occ_list, w.occ_count, w.occ_cursor,
-                           w.cell_cap2, w.cell_seed);
-        hipLaunchKernelGGL(warp_cell_scan_kernel, dim3(bs), dim3(1024), 0, st, w.cell_count, w.cell_start, w.cell_cap2, w.live);
+                           w.cell_cap2, w.cell_seed, G);
+        hipLaunchKernelGGL(warp_cell_scan_kernel, dim3(bs), dim3(1024), 0, st, w.cell_count, w.cell_start, w.cell_cap2, w.live, G);
         const int64_t sc_blocks = (N + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
         hipLaunchKernelGGL(warp_cell_scatter_kernel, dim3((unsigned)(sc_blocks < 1024 ? sc_blocks : 1024), bs), dim3(WARP_THREADS), 0, st,
                            w.list, w.cells, w.count, N, w.cell_start, w.cell_count, w.cell_cap2, w.sorted);
@@ -1071,7 +1076,7 @@ extern "C" int anr_warp_points_lean(const float* xyz, int xyz_stride, const floa
         if (gx > max_wg) gx = max_wg;
         hipLaunchKernelGGL(warp_search_kernel, dim3((unsigned)gx, bs), dim3(WARP_THREADS), bytes, st, index, d, ober2cano,
                            lbs_weights, J, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                           w.sorted, w.live, w.cursor, w.cell_cap2, valid_mask_out, w.cell_seed);
+                           w.sorted, w.live, w.cursor, w.cell_cap2, valid_mask_out, w.cell_seed, G);
         if (int rc = check_launch("anr_warp_points (search)")) return rc;
         if (lean) {
             e = hipMemsetAsync(valid_count_out, 0, sizeof(int32_t), st);
