@@ -78,16 +78,25 @@ class Ctx:
         if self.world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run "
                              f"--nproc-per-node {args.gpus}")
-        torch.cuda.set_device(self.local_rank)
-        self.dev = torch.device("cuda", self.local_rank)
+        # (test hooks: ANR_BENCH_BACKEND=gloo + ANR_BENCH_ONE_DEVICE=1 run the N > 1 code path on a single-GPU box)
+        self.backend = os.environ.get("ANR_BENCH_BACKEND", "nccl")
+        dev_index = 0 if os.environ.get("ANR_BENCH_ONE_DEVICE") else self.local_rank
+        torch.cuda.set_device(dev_index)
+        self.dev = torch.device("cuda", dev_index)
         if self.world > 1:
             import torch.distributed as dist
-            dist.init_process_group("nccl", device_id=self.dev)        # "nccl" = RCCL over xGMI on ROCm
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)    # "nccl" = RCCL over xGMI on ROCm
+            else:
+                dist.init_process_group(self.backend)
 
     def barrier(self):
         if self.world > 1:
             import torch.distributed as dist
-            dist.barrier(device_ids=[self.local_rank])
+            if self.backend == "nccl":
+                dist.barrier(device_ids=[self.dev.index])
+            else:
+                dist.barrier()
         torch.cuda.synchronize(self.dev)
 
     def timed(self, step, steps, warmup):
@@ -399,17 +408,28 @@ def main():
         def brief(r, *keep):
             keys = ("value", "unit", "ms_per_step", "steps", "warmup", "n_gpus", "scaling", "dtype", "roofline") + keep
             return {**{k: r[k] for k in keys if k in r}, "config": r["config"]}
-        if world == 1:
-            result["modes"] = {"f32": brief(render_bench(args, ctx, False, "f32", 2, 1), "roofline_hbm_kernels")}
+        def extra(fn, *a, keep=(), **kw):
+            # a failing extra must not take the headline line with it (every rank runs the same code, so a failure is
+            # symmetric and no rank is left waiting in a barrier)
+            try:
+                return brief(fn(*a, **kw), *keep)
+            except Exception as exc:                        # noqa: BLE001
+                return {"error": f"{type(exc).__name__}: {exc}"[:300]}
         w = {}
-        w["cfg3"] = brief(render_bench(args, ctx, True, args.mode, 3, 1), "roofline_hbm_kernels", "kernel_time_share")
         if world == 1:
-            w["cfg3_dense"] = brief(render_bench(args, ctx, True, args.mode, 2, 1, dense=True))
-        w["cfg4"] = brief(train_bench(args, ctx, args.mode, 4, 2), "kernel_time_share", "final_loss")
-        w["cfg5"] = brief(grid_bench(args, ctx, args.mode, 3, 1))
-        if world > 1:
-            w["cfg2_strong"] = brief(render_bench(args, ctx, False, args.mode, 3, 1, scaling="strong"))
-            w["cfg3_strong"] = brief(render_bench(args, ctx, True, args.mode, 3, 1, scaling="strong"))
+            result["modes"] = {"f32": extra(render_bench, args, ctx, False, "f32", 2, 1, keep=("roofline_hbm_kernels",))}
+            w["cfg3"] = extra(render_bench, args, ctx, True, args.mode, 3, 1, keep=("roofline_hbm_kernels", "kernel_time_share"))
+            w["cfg3_dense"] = extra(render_bench, args, ctx, True, args.mode, 2, 1, dense=True)
+            w["cfg4"] = extra(train_bench, args, ctx, args.mode, 4, 2, keep=("kernel_time_share", "final_loss"))
+            w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 1)
+        else:
+            # N > 1: the strong-scaling counterpart of the headline (one frame's rays sliced over the ranks), the warp
+            # workload, and the training step with its RCCL gradient buckets
+            w["cfg2_strong"] = extra(render_bench, args, ctx, False, args.mode, 3, 1, scaling="strong")
+            w["cfg3"] = extra(render_bench, args, ctx, True, args.mode, 3, 1)
+            w["cfg3_strong"] = extra(render_bench, args, ctx, True, args.mode, 3, 1, scaling="strong")
+            w["cfg4"] = extra(train_bench, args, ctx, args.mode, 4, 2, keep=("final_loss",))
+            w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 1)
         result["workloads"] = w
 
     if rank == 0:
