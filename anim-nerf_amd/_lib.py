@@ -18,6 +18,7 @@ ANR_MLP_BF16 = 1
 ANR_MLP_FLAG_NO_DMA = 0x100
 ANR_MLP_FLAG_SIGMA_ONLY = 0x400
 ANR_MLP_FLAG_TANGENT = 0x800
+ANR_MLP_FLAG_ACCUMULATE = 0x1000
 ANR_MAX_SAMPLES = 256
 
 
@@ -41,6 +42,19 @@ class AnrMlpParams(C.Structure):
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class AnrLossArgs(C.Structure):
+    _fields_ = ([(k, _P) for k in ("rgb", "acc", "rgb_fine", "acc_fine", "target_rgb", "target_alpha", "s", "s_fine", "quads",
+                                   "quads_fine")]
+                + [(k, _L) for k in ("R", "prior_rows", "nv", "normal_sets", "quad_rows")]
+                + [("n_fg", C.c_int32), ("n_bg", C.c_int32)]
+                + [(k, _F) for k in ("k", "delta", "lambda_alphas", "lambda_foreground", "lambda_background", "lambda_normals")])
+
+
+class AnrLossGrads(C.Structure):
+    _fields_ = [(k, _P) for k in ("rgb", "acc", "rgb_fine", "acc_fine", "s", "s_fine", "quads", "quads_fine")]
+
 
 # name -> (restype, argtypes); every symbol include/animnerf_hip.h declares
 SIGNATURES = {
@@ -88,6 +102,14 @@ SIGNATURES = {
     "anr_composite_backward": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "anr_sample_fine_merge": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P]),
     "anr_sample_fine_merge_u8": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P]),
+    "anr_compact_ws_ints": (_L, [_L]),
+    "anr_compact_ordered": (_I, [_P, _L, _P, _P, _P, _P, _P, _P]),
+    "anr_expand_rows": (_I, [_P, _P, _L, _I, _F, _P, _P]),
+    "anr_mlp_head_grad": (_I, [_P, _P, _P, _P, _L, _L, _I, _P, _P]),
+    "anr_tangent_quads": (_I, [_P, _L, _L, _P, _P]),
+    "anr_train_loss_ws_floats": (_L, []),
+    "anr_train_loss": (_I, [C.POINTER(AnrLossArgs), _P, _P, _P]),
+    "anr_train_loss_backward": (_I, [C.POINTER(AnrLossArgs), _P, C.POINTER(AnrLossGrads), _P]),
     "anr_composite_sample": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 

@@ -45,115 +45,151 @@ PARAM_SHAPES = ([s for i in range(8) for s in ((256, 63 if i == 0 else 319 if i 
                 + [(1, 256), (1,), (256, 256), (256,), (128, 256), (128,), (3, 128), (3,)])
 
 
+class GradSink:
+    """One flat fp32 gradient buffer for the 22 tensors of a NeRF, in PARAM_KEYS order — the layout anr_mlp_wgrad writes.
+    `p.grad` of every parameter is a VIEW into it, and each MLP backward pass adds its weight gradients with one
+    accumulating launch (ANR_MLP_FLAG_ACCUMULATE) instead of handing 22 tensors to autograd, which would add them to
+    `.grad` one by one (three passes per network and step: render, sigma priors, normals — ~90 launches).
+    A bucket of `training.GradientReducer` is exactly this buffer, so the all-reduce sends it as it is.
+
+    `on_complete` is called when the last backward pass that was announced by a forward pass (`announce`) has
+    contributed — the point at which the buffer can go on the wire."""
+
+    def __init__(self, net, flat: torch.Tensor = None):
+        named = dict(net.named_parameters())
+        self.params = [named[k] for k in PARAM_KEYS]
+        total = sum(p.numel() for p in self.params)
+        self.flat = flat if flat is not None else torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
+        assert self.flat.numel() == total and self.flat.dtype == torch.float32
+        self.views, o = [], 0
+        for p in self.params:
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        self.expected = self.done = 0
+        self.on_complete = None
+
+    def usable(self) -> bool:
+        """every parameter trains in fp32 and its .grad is still this buffer's view (a caller may have reset it)"""
+        return all(p.requires_grad and p.grad is v for p, v in zip(self.params, self.views))
+
+    def begin_step(self, zero: bool = True):
+        if zero:
+            self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        self.expected = self.done = 0
+
+    def announce(self):
+        self.expected += 1
+
+    def contributed(self):
+        self.done += 1
+        if self.done == self.expected and self.on_complete is not None:
+            self.on_complete(self)
+
+
+def _split_flat(flat, upto=len(PARAM_KEYS)):
+    grads, o = {}, 0
+    for i, (k, shp) in enumerate(zip(PARAM_KEYS, PARAM_SHAPES)):
+        cnt = 1
+        for d in shp:
+            cnt *= d
+        grads[k] = flat[o:o + cnt].view(shp) if i < upto else None
+        o += cnt
+    return grads
+
+
 class MLPFunction(torch.autograd.Function):
     """out[n,4] = (r,g,b,sigma) (or sigma[n]) = NeRF(pts[n,4]); differentiable w.r.t. the 22 parameter tensors (and the
     points).  Forward, activation gradients and weight gradients are three hand-written HIP kernels
-    (anr_mlp_forward_save, anr_mlp_backward, anr_mlp_wgrad); `LIBRARY_GEMMS = True` swaps the last two for the chain of
-    library GEMMs they replaced (a cross-check for the tests)."""
+    (anr_mlp_forward_save, anr_mlp_backward, anr_mlp_wgrad), the steps around them one launch each (csrc/train_glue.hip);
+    `LIBRARY_GEMMS = True` swaps the backward kernels for the chain of library GEMMs they replaced (a cross-check for the
+    tests).  sink: a GradSink of the network (weight gradients accumulate there, autograd gets None) or None."""
 
     PAD = 64                 # rows are padded to a multiple of this (anr_mlp_wgrad's slab granularity): invalid points, zero gradient
     LIBRARY_GEMMS = False
 
     @staticmethod
-    def forward(ctx, pts, sigma_only, mode_id, only_valid, *params):
+    def forward(ctx, pts, sigma_only, mode_id, only_valid, sink, *params):
         pack = _cached_pack(params, mode_id, False)
         pts = pts.detach()
         n = pts.shape[0]
         ctx.sigma_only = sigma_only
         ctx.mode_id = mode_id
         ctx.n_full = n
-        idx = None
+        ctx.sink = sink if (sink is not None and not MLPFunction.LIBRARY_GEMMS and sink.usable()) else None
+        if ctx.sink is not None:
+            ctx.sink.announce()
+        index = pos = None
         rows = n
         if only_valid:
             # samples outside dis_threshold have sigma = -1e5 and composite weight exactly 0: neither their outputs nor
-            # their (exactly zero) gradients are needed.  Forward, saved activations and backward run on the rest.
-            index, count = ops.compact_valid(pts)
+            # their (exactly zero) gradients are needed.  Forward, saved activations and backward run on the rest, listed
+            # in sample order (the row order fixes the order of every split-K sum downstream: same bits on every run).
+            index, pos, pts_c, count = ops.compact_ordered(pts)
             cnt = int(count.item())                                   # the row counts of the saved tensors need it on the host
             if cnt < n:
-                # the compaction hands blocks out by atomic ticket: sort, so that the rows (and with them the order of every
-                # split-K sum downstream) are the same on every run
-                idx = torch.sort(index[:cnt]).values.long()
                 rows = cnt
+                pts = pts_c[:max(-(-rows // MLPFunction.PAD), 1) * MLPFunction.PAD]
+            else:
+                index = pos = None
         n_pad = max(-(-rows // MLPFunction.PAD), 1) * MLPFunction.PAD
-        if idx is not None or n_pad != n:
+        if index is None and n_pad != n:
             pts_c = pts.new_zeros(n_pad, 4)                           # padding rows: valid = 0, zero upstream gradient
-            pts_c[:rows] = pts if idx is None else pts.index_select(0, idx)
+            pts_c[:rows] = pts
             pts = pts_c
         out, act = ops.mlp_forward_save(pack, mode_id, pts, sigma_only)
         ctx.rows = rows
-        if idx is None:
+        ctx.compacted = index is not None
+        if index is None:
             ctx.save_for_backward(pts, out, act, *params)
-            ctx.compacted = False
             return out[:n] if n_pad != n else out
-        ctx.save_for_backward(pts, out, act, idx, *params)
-        ctx.compacted = True
-        full = out.new_zeros((n,) if sigma_only else (n, 4))
-        if sigma_only:
-            full.fill_(-1e5)
-        else:
-            full[:, 3] = -1e5
-        full[idx] = out[:rows]
-        return full
+        ctx.save_for_backward(pts, out, act, index, pos, *params)
+        return ops.expand_rows(out, pos, -1e5)                        # (0,0,0,-1e5) / -1e5 for the samples not listed
 
     @staticmethod
     @torch.no_grad()
     def backward(ctx, g):
-        idx = None
+        index = pos = None
         if ctx.compacted:
-            pts, out, act, idx, *params = ctx.saved_tensors
+            pts, out, act, index, pos, *params = ctx.saved_tensors
         else:
             pts, out, act, *params = ctx.saved_tensors
         n, rows = pts.shape[0], ctx.rows
-        if idx is not None or n != g.shape[0]:                      # compacted and / or padded rows
-            g_c = g.new_zeros((n,) + tuple(g.shape[1:]))
-            g_c[:rows] = g if idx is None else g.index_select(0, idx)
-            g = g_c
         dt = act.dtype                                              # fp32 (parity mode) or bf16 (mixed precision)
-        valid = (pts[:, 3] >= 1.0).to(g.dtype)                       # sigma is the constant -1e5 where invalid
         want_pts = ctx.needs_input_grad[0]
-        g4 = torch.zeros(n, 4, dtype=torch.float32, device=g.device)
-        if ctx.sigma_only:
-            g4[:, 3] = g.reshape(n) * valid
-        else:
-            rgb = out[:, :3]
-            g4[:, :3] = g[:, :3] * rgb * (1 - rgb)                    # sigmoid'
-            g4[:, 3] = g[:, 3] * valid
+        # (dL/d rgb x sigmoid', dL/d sigma where the sample is valid) on the compacted + padded rows
+        g4 = ops.mlp_head_grad(g, index, None if ctx.sigma_only else out, pts, rows, ctx.sigma_only)
+        d_enc = None
+        grads = {}
         if MLPFunction.LIBRARY_GEMMS:
             grads, d_enc = _library_backward(ctx, params, pts, act, g4, want_pts)
         else:
             # activation gradients: ONE kernel for the whole chain (csrc/mlp_bwd.hip); weight + bias gradients: split-K MFMA
             # GEMMs between its output columns, the saved activations and the encoding matrix (csrc/mlp_wgrad.hip)
             dact = ops.mlp_backward(_cached_pack(params, ctx.mode_id, True), ctx.mode_id, g4, act, sigma_only=ctx.sigma_only)
-            flat = ops.mlp_wgrad(ctx.mode_id, act, dact, ops.encode64(pts, dt), g4, sigma_only=ctx.sigma_only)
-            grads, o = {}, 0
-            for k, shp in zip(PARAM_KEYS, PARAM_SHAPES):
-                cnt = 1
-                for d in shp:
-                    cnt *= d
-                grads[k] = flat[o:o + cnt].view(shp)
-                o += cnt
-            if ctx.sigma_only:
-                for k in PARAM_KEYS[18:]:
-                    grads[k] = None
-            d_enc = None
+            flat = ops.mlp_wgrad(ctx.mode_id, act, dact, ops.encode64(pts, dt), g4, sigma_only=ctx.sigma_only,
+                                 accumulate_into=None if ctx.sink is None else ctx.sink.flat)
+            if ctx.sink is None:
+                grads = _split_flat(flat, 18 if ctx.sigma_only else len(PARAM_KEYS))
             if want_pts:                                            # pose refinement: through the two encoding inputs
                 d_enc = ops.mlp_denc(ctx.mode_id, dact, params[PARAM_KEYS.index("xyz_encoding_1.0.weight")],
                                      params[PARAM_KEYS.index("xyz_encoding_5.0.weight")])
         d_pts = None
         if want_pts:                                                # through x -> (x, sin 2^k x, cos 2^k x)
             d_pts = ops.encode_backward(pts, d_enc.contiguous())
-            if idx is not None:
-                full = d_pts.new_zeros(ctx.n_full, 4)
-                full[idx] = d_pts[:rows]
-                d_pts = full
+            if pos is not None:
+                d_pts = ops.expand_rows(d_pts, pos, 0.0)
             elif d_pts.shape[0] != ctx.n_full:
                 d_pts = d_pts[:ctx.n_full]
         out_grads = []
         for i, k in enumerate(PARAM_KEYS):
-            need = ctx.needs_input_grad[4 + i]
+            need = ctx.needs_input_grad[5 + i]
             gk = grads.get(k) if need else None
             out_grads.append(None if gk is None else gk.to(params[i].dtype).reshape(params[i].shape))
-        return (d_pts, None, None, None, *out_grads)
+        if ctx.sink is not None:
+            ctx.sink.contributed()
+        return (d_pts, None, None, None, None, *out_grads)
 
 
 def _library_backward(ctx, params, pts, act, g4, want_pts):
@@ -221,20 +257,16 @@ class NormalFunction(torch.autograd.Function):
     Three launches forward + backward instead of ~80 library launches (first version) or ~1400 (double backward)."""
 
     @staticmethod
-    def forward(ctx, xyz, delta, mode_id, *params):
+    def forward(ctx, xyz, delta, mode_id, sink, *params):
         n = xyz.shape[0]
-        n_pad = -(-n // 16) * 16                                      # 4 n_pad rows: a multiple of 64 (wgrad slabs)
-        pts = xyz.new_zeros(n_pad, 4)
-        pts[:n, :3] = xyz.detach()
-        pts[:n, 3] = 1.0
-        pts4 = pts.repeat_interleave(4, dim=0)                        # quad p = (point, d/dx, d/dy, d/dz)
-        out, act = ops.mlp_forward_save(_cached_pack(params, mode_id, False), mode_id, pts4, sigma_only=True, tangent=True)
-        sig = out.view(n_pad, 4)
+        pts4, act, sig = _tangent_forward(xyz, mode_id, params)
+        n_pad = sig.shape[0]
         s0 = sig[:, 0]
         scale = torch.where(s0 > 0, delta * torch.exp(-delta * s0), torch.zeros_like(s0))     # d alpha / d sigma
         scale[n:] = 0
         ctx.save_for_backward(pts4, act, sig, scale, *params)
         ctx.delta, ctx.mode_id, ctx.n = delta, mode_id, n
+        ctx.sink = _announce(sink)
         return (scale[:, None] * sig[:, 1:4])[:n]
 
     @staticmethod
@@ -246,20 +278,87 @@ class NormalFunction(torch.autograd.Function):
         d_sig[:n, 1:4] = g * scale[:n, None]
         # d scale / d sigma = -delta * scale where sigma > 0
         d_sig[:n, 0] = (g * sig[:n, 1:4]).sum(-1) * (-ctx.delta) * scale[:n]
-        g4 = sig.new_zeros(4 * n_pad, 4)
-        g4[:, 3] = d_sig.reshape(-1)
-        dact = ops.mlp_backward(_cached_pack(params, ctx.mode_id, True), ctx.mode_id, g4, act, sigma_only=True, tangent=True)
-        flat = ops.mlp_wgrad(ctx.mode_id, act, dact, ops.encode64(pts4, act.dtype, tangent=True), g4, sigma_only=True,
-                             tangent=True)
-        out, o = [], 0
-        for i, (k, shp) in enumerate(zip(PARAM_KEYS, PARAM_SHAPES)):
-            cnt = 1
-            for d in shp:
-                cnt *= d
-            need = ctx.needs_input_grad[3 + i] and i < 18              # the colour head takes no part in sigma
-            out.append(flat[o:o + cnt].view(shp).to(params[i].dtype) if need else None)
-            o += cnt
-        return (None, None, None, *out)
+        return (None, None, None, None, *_tangent_backward(ctx, params, pts4, act, d_sig, 4))
+
+
+class QuadSigmaFunction(torch.autograd.Function):
+    """quads[n_pad,4] = (sigma, d sigma/dx, d sigma/dy, d sigma/dz) at xyz[n,3] (n_pad = n rounded up to 16; the padding rows
+    are zero) — the tangent-mode pass NormalFunction is built on, without the d alpha / d sigma factor: the fused loss
+    kernels (anr_train_loss*) apply it, the normalisation and the MSE themselves (train.py:288-309)."""
+
+    @staticmethod
+    def forward(ctx, xyz, mode_id, sink, *params):
+        pts4, act, sig = _tangent_forward(xyz, mode_id, params)
+        ctx.save_for_backward(pts4, act, *params)
+        ctx.mode_id = mode_id
+        ctx.sink = _announce(sink)
+        return sig
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g):
+        pts4, act, *params = ctx.saved_tensors
+        return (None, None, None, *_tangent_backward(ctx, params, pts4, act, g, 3))
+
+
+def _announce(sink):
+    if sink is not None and sink.usable():
+        sink.announce()
+        return sink
+    return None
+
+
+def _tangent_forward(xyz, mode_id, params):
+    n = xyz.shape[0]
+    n_pad = -(-n // 16) * 16                                          # 4 n_pad rows: a multiple of 64 (wgrad slabs)
+    pts4 = ops.tangent_quads(xyz.detach().float().contiguous(), n_pad)  # quad p = (point, d/dx, d/dy, d/dz)
+    out, act = ops.mlp_forward_save(_cached_pack(params, mode_id, False), mode_id, pts4, sigma_only=True, tangent=True)
+    return pts4, act, out.view(n_pad, 4)
+
+
+def _tangent_backward(ctx, params, pts4, act, d_quads, first_param):
+    """Parameter gradients of a tangent-mode pass from dL/d quads[n_pad,4] (list in PARAM_KEYS order; None where the
+    gradient went to the network's GradSink or is not needed)."""
+    g4 = ops.mlp_head_grad(d_quads.reshape(-1), None, None, pts4, pts4.shape[0], True)
+    dact = ops.mlp_backward(_cached_pack(params, ctx.mode_id, True), ctx.mode_id, g4, act, sigma_only=True, tangent=True)
+    flat = ops.mlp_wgrad(ctx.mode_id, act, dact, ops.encode64(pts4, act.dtype, tangent=True), g4, sigma_only=True, tangent=True,
+                         accumulate_into=None if ctx.sink is None else ctx.sink.flat)
+    if ctx.sink is not None:
+        ctx.sink.contributed()
+        return [None] * len(PARAM_KEYS)
+    grads = _split_flat(flat, 18)                                     # the colour head takes no part in sigma
+    return [grads[k].to(params[i].dtype) if (grads[k] is not None and ctx.needs_input_grad[first_param + i]) else None
+            for i, k in enumerate(PARAM_KEYS)]
+
+
+class TrainLossFunction(torch.autograd.Function):
+    """total, details[10] = every loss term of train.py:228-309 and the weighted total (anr_train_loss), differentiable
+    w.r.t. the rendered colours / opacities, the prior sigmas and the tangent quads (anr_train_loss_backward): two
+    launches instead of ~180 framework ones."""
+    KEYS = ("rgb", "acc", "rgb_fine", "acc_fine", "s", "s_fine", "quads", "quads_fine")
+
+    @staticmethod
+    def forward(ctx, consts, target_rgb, target_alpha, *inputs):
+        tensors = dict(zip(TrainLossFunction.KEYS, (None if t is None else t.detach() for t in inputs)))
+        tensors["target_rgb"], tensors["target_alpha"] = target_rgb, target_alpha
+        vals = ops.train_loss(tensors, consts)
+        ctx.consts = consts
+        ctx.present = [t is not None for t in inputs]
+        ctx.save_for_backward(target_rgb, target_alpha, *[t for t in inputs if t is not None])
+        details = vals[:10]
+        ctx.mark_non_differentiable(details)
+        return vals[10].clone(), details
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g_total, _):
+        target_rgb, target_alpha, *rest = ctx.saved_tensors
+        it = iter(rest)
+        tensors = {k: (next(it) if here else None) for k, here in zip(TrainLossFunction.KEYS, ctx.present)}
+        tensors["target_rgb"], tensors["target_alpha"] = target_rgb, target_alpha
+        want = {k: ctx.needs_input_grad[3 + i] for i, k in enumerate(TrainLossFunction.KEYS)}
+        grads = ops.train_loss_backward(tensors, ctx.consts, g_total.float(), want)
+        return (None, None, None, *[grads.get(k) for k in TrainLossFunction.KEYS])
 
 
 class CompositeFunction(torch.autograd.Function):
@@ -278,11 +377,10 @@ class CompositeFunction(torch.autograd.Function):
     def backward(ctx, g_w, g_rgb, g_depth, g_acc):
         rgbs, z, rays, noise = ctx.saved_tensors
         R = z.shape[0]
-        zero = lambda t, shape: torch.zeros(shape, device=z.device) if t is None else t.contiguous()
+        flat = lambda t: None if t is None else t.reshape(R, -1)               # None: an output the loss does not use
         want_geo = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]          # pose refinement: dL/dz, dL/dfar'
-        res = ops.composite_backward(rgbs, z, rays, ctx.white, zero(g_rgb, (R, 3)), zero(g_depth, (R, 1)).reshape(R),
-                                     zero(g_acc, (R, 1)).reshape(R), noise=noise if noise.numel() else None,
-                                     want_dz=want_geo)
+        res = ops.composite_backward(rgbs, z, rays, ctx.white, flat(g_rgb), flat(g_depth), flat(g_acc),
+                                     noise=noise if noise.numel() else None, want_dz=want_geo)
         if not want_geo:
             return res, None, None, None, None
         d, dz, dfar = res

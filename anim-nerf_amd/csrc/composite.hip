@@ -185,8 +185,10 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_backward_ker
     if (r >= R) return;
     const float4* c = rgbs + r * K;
     const float* zr = z + r * K;
-    const float gr = g_rgb[r * 3 + 0], gg = g_rgb[r * 3 + 1], gb = g_rgb[r * 3 + 2], gd = g_depth[r];
-    float ga = g_acc[r];
+    // a NULL upstream gradient is a zero one (autograd hands over None for outputs the loss does not use)
+    const float gr = g_rgb ? g_rgb[r * 3 + 0] : 0.f, gg = g_rgb ? g_rgb[r * 3 + 1] : 0.f, gb = g_rgb ? g_rgb[r * 3 + 2] : 0.f;
+    const float gd = g_depth ? g_depth[r] : 0.f;
+    float ga = g_acc ? g_acc[r] : 0.f;
     if (white_bkgd) ga = ga - (gr + gg + gb) - gd * rays[r * stride + 7];
 
     float alpha[S], tr[S], zz[S], delta[S], sg[S];
@@ -589,7 +591,7 @@ extern "C" int anr_composite_backward(const float* rgbs, const float* z, const f
                                       const float* noise, int64_t R, int K, int white_bkgd, const float* g_weights,
                                       const float* g_rgb, const float* g_depth, const float* g_acc, float* d_rgbs,
                                       float* d_z, float* d_far, void* stream) {
-    ANR_REQUIRE(rgbs && z && rays && g_rgb && g_depth && g_acc && d_rgbs, ANR_E_BADARG, "anr_composite_backward: null pointer");
+    ANR_REQUIRE(rgbs && z && rays && d_rgbs, ANR_E_BADARG, "anr_composite_backward: null pointer");
     ANR_REQUIRE(R > 0 && K > 0 && stride >= 8, ANR_E_BADARG, "anr_composite_backward: R=%lld K=%d stride=%d", (long long)R, K, stride);
     ANR_REQUIRE(K <= ANR_MAX_SAMPLES, ANR_E_SHAPE, "anr_composite_backward: K=%d > %d", K, ANR_MAX_SAMPLES);
     ANR_REQUIRE((((uintptr_t)rgbs | (uintptr_t)d_rgbs) & 15) == 0, ANR_E_ALIGN, "anr_composite_backward: rgbs/d_rgbs must be 16-B aligned");

@@ -262,7 +262,7 @@ struct WgradSeg {
 };
 struct WgradSegs { WgradSeg s[32]; int n; };
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradSegs segs, const float* __restrict__ ws, float* __restrict__ grads) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradSegs segs, const float* __restrict__ ws, float* __restrict__ grads, int accumulate) {
     const WgradSeg sg = segs.s[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= sg.rows * sg.cols) return;
@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradSegs segs, const
         for (int q = 0; q < 8; ++q) s += v[q];
     }
     for (; k < sg.slices; ++k) s += src[(int64_t)k * sg.src_slice];
-    grads[sg.dst + (int64_t)r * sg.dst_pitch + c] = s;
+    float* dst = grads + sg.dst + (int64_t)r * sg.dst_pitch + c;
+    *dst = accumulate ? *dst + s : s;
 }
 
 }  // namespace anr
@@ -325,7 +326,7 @@ extern "C" int64_t anr_mlp_wgrad_ws_floats(int64_t n) {
 
 template <bool BF16>
 static int wgrad_launch(const void* act, const void* dact, const void* enc, const float* g4, int64_t n, int sigma_only,
-                        int tangent, float* ws, float* grads, hipStream_t st) {
+                        int tangent, int accumulate, float* ws, float* grads, hipStream_t st) {
     using C = WgCfg<BF16>;
     const Layout& L = layout();
     WgradSegs segs{};
@@ -425,7 +426,7 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
         }
         ws_off += slices * CS_COLS;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(256, segs.n), dim3(256), 0, st, segs, ws, grads);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(256, segs.n), dim3(256), 0, st, segs, ws, grads, accumulate);
     return check_launch("anr_mlp_wgrad");
 }
 
@@ -439,14 +440,15 @@ extern "C" int anr_mlp_wgrad(int mode, const void* act, const void* dact, const 
     const int tan = (mode & ANR_MLP_FLAG_TANGENT) ? 1 : 0;
     ANR_REQUIRE(!tan || so, ANR_E_BADARG, "anr_mlp_wgrad: tangent mode = sigma only");
     hipStream_t st = (hipStream_t)stream;
-    if (so) {                                                        // tensors this call does not produce: zeros
+    const int accumulate = (mode & ANR_MLP_FLAG_ACCUMULATE) ? 1 : 0;
+    if (so && !accumulate) {                                         // tensors this call does not produce: zeros
         const Layout& L = layout();
         hipError_t e = hipMemsetAsync(grads_out + L.fw, 0, sizeof(float) * (L.total - L.fw), st);
         if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipMemsetAsync: %s", hipGetErrorString(e));
     }
     switch (mode & 0xff) {
-        case ANR_MLP_BF16: return wgrad_launch<true>(act, dact, enc, g4, n, so, tan, workspace, grads_out, st);
-        case ANR_MLP_F32:  return wgrad_launch<false>(act, dact, enc, g4, n, so, tan, workspace, grads_out, st);
+        case ANR_MLP_BF16: return wgrad_launch<true>(act, dact, enc, g4, n, so, tan, accumulate, workspace, grads_out, st);
+        case ANR_MLP_F32:  return wgrad_launch<false>(act, dact, enc, g4, n, so, tan, accumulate, workspace, grads_out, st);
         default: return fail(ANR_E_BADARG, "anr_mlp_wgrad: unknown mode %d", mode);
     }
 }

@@ -1,0 +1,346 @@
+// The small data-movement and loss steps of the training step (train.py:228-322) that sit between the big kernels:
+// each replaces a chain of 5-40 framework launches of a few microseconds each by one launch.  All HBM-bound and tiny
+// (tens of KB to a few MB); what they buy is launch count, not bandwidth.
+//
+//   anr_compact_ordered   inside_inds of models/anim_nerf.py:253 in sample ORDER (three launches: count, scan, gather) —
+//                         replaces the ticket compaction + a radix sort of the index for the training path, where the row
+//                         order fixes the summation order of every split-K weight gradient
+//   anr_expand_rows       out[i] = src[pos[i]] or the fill row: the scatter back to all samples (and of dL/dx on the way back)
+//   anr_mlp_head_grad     upstream gradient of (rgb, sigma) -> the g[n][4] operand of anr_mlp_backward (sigmoid', validity,
+//                         gather to the compacted rows, zero padding rows)
+//   anr_tangent_quads     xyz[n][3] -> the quads of rows the tangent-mode MLP kernels take (ANR_MLP_FLAG_TANGENT)
+//   anr_train_loss        every loss term of train.py:228-309 and the weighted total in one launch
+//   anr_train_loss_backward  ... and its gradient w.r.t. every rendered / queried value in one launch
+#include "anr_common.h"
+
+namespace anr {
+
+constexpr int CB = 1024;   // samples per compaction block
+
+__global__ __launch_bounds__(CB) void compact_count_kernel(const float4* __restrict__ pts, int64_t n, int32_t* __restrict__ block_cnt) {
+    __shared__ int wave_cnt[CB / WAVE];
+    const int64_t i = (int64_t)blockIdx.x * CB + threadIdx.x;
+    const bool keep = i < n && !(pts[i].w < 1.0f);
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < CB / WAVE; ++w) tot += wave_cnt[w];
+        block_cnt[blockIdx.x] = tot;
+    }
+}
+
+// exclusive scan of the block counts in place (one workgroup), total -> *count
+__global__ __launch_bounds__(1024) void compact_scan_kernel(int32_t* __restrict__ block_cnt, int n_blocks, int32_t* __restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_blocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n_blocks ? block_cnt[i] : 0;
+        int s = v;                                           // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(s, o, 64); if (lane >= o) s += t; }
+        if (lane == 63) wsum[wave] = s;
+        __syncthreads();
+        int off = carry;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (i < n_blocks) block_cnt[i] = off + s - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = off + s;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = carry;
+}
+
+__global__ __launch_bounds__(CB) void compact_gather_kernel(const float4* __restrict__ pts, int64_t n, const int32_t* __restrict__ block_base,
+                                                            const int32_t* __restrict__ count, int32_t* __restrict__ index,
+                                                            int32_t* __restrict__ pos, float4* __restrict__ pts_out) {
+    __shared__ int wave_cnt[CB / WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * CB + threadIdx.x;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) p = pts[i];
+    const bool keep = i < n && !(p.w < 1.0f);
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = block_base[blockIdx.x];
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    const int r = off + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep) { index[r] = (int32_t)i; pts_out[r] = p; }
+    if (i < n) pos[i] = keep ? r : -1;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {               // padding rows up to the next multiple of 64: valid = 0
+        const int c = *count, pad = (c + 63) / 64 * 64;
+        if (c + (int)threadIdx.x < (pad > 0 ? pad : 64)) pts_out[c + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int COLS>
+__global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ pos, int64_t n,
+                                                          float fill, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = pos[i];
+    if (COLS == 4) {
+        reinterpret_cast<float4*>(out)[i] = r >= 0 ? reinterpret_cast<const float4*>(src)[r] : make_float4(0.f, 0.f, 0.f, fill);
+    } else {
+        out[i] = r >= 0 ? src[r] : fill;
+    }
+}
+
+__global__ __launch_bounds__(256) void head_grad_kernel(const float* __restrict__ g, const int32_t* __restrict__ index,
+                                                        const float4* __restrict__ out, const float4* __restrict__ pts, int64_t rows,
+                                                        int64_t n_pad, int sigma_only, float4* __restrict__ g4) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_pad) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) {
+        const int64_t s = index ? index[r] : r;
+        const float valid = pts[r].w >= 1.0f ? 1.0f : 0.0f;      // sigma is the constant -1e5 where the sample is invalid
+        if (sigma_only) v.w = g[s] * valid;
+        else {
+            const float4 u = reinterpret_cast<const float4*>(g)[s];
+            const float4 o = out[r];
+            v = make_float4(u.x * o.x * (1.0f - o.x), u.y * o.y * (1.0f - o.y), u.z * o.z * (1.0f - o.z), u.w * valid);   // sigmoid'
+        }
+    }
+    g4[r] = v;
+}
+
+__global__ __launch_bounds__(256) void tangent_quads_kernel(const float* __restrict__ xyz, int64_t n, int64_t n_pad, float4* __restrict__ pts4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one row of a quad
+    if (i >= 4 * n_pad) return;
+    const int64_t p = i >> 2;
+    pts4[i] = p < n ? make_float4(xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2], 1.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// losses
+constexpr int LOSS_BLOCKS = 64, LOSS_TERMS = 10;
+
+struct Normal { float x, y, z, r; };
+// models/nerf.py:177-190 from a tangent quad (sigma, d sigma/dx, dy, dz): d alpha / d xyz = delta exp(-delta sigma) grad sigma
+// where sigma > 0, then train.py:303: n / (|n| + 1e-5)
+__device__ __forceinline__ Normal unit_normal(const float4 q, float delta, float& scale) {
+    scale = q.x > 0.0f ? delta * expf(-delta * q.x) : 0.0f;
+    Normal a{scale * q.y, scale * q.z, scale * q.w, 0.f};
+    a.r = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+    return a;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {     // 256 threads; result valid in thread 0
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void train_loss_kernel(anr_loss_args a, float* __restrict__ partials, unsigned* __restrict__ ticket,
+                                                         float* __restrict__ vals) {
+    __shared__ float sh[4];
+    __shared__ bool last;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)LOSS_BLOCKS * 256;
+    float acc[LOSS_TERMS];
+#pragma unroll
+    for (int t = 0; t < LOSS_TERMS; ++t) acc[t] = 0.0f;
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* rgb = pass ? a.rgb_fine : a.rgb;
+        const float* al = pass ? a.acc_fine : a.acc;
+        const float* s = pass ? a.s_fine : a.s;
+        const float4* q = reinterpret_cast<const float4*>(pass ? a.quads_fine : a.quads);
+        float s_rgb = 0.f, s_al = 0.f, s_fg = 0.f, s_bg = 0.f, s_n = 0.f;
+        if (rgb)
+            for (int64_t i = tid; i < a.R * 3; i += nth) { const float d = rgb[i] - a.target_rgb[i]; s_rgb += d * d; }
+        if (al)
+            for (int64_t i = tid; i < a.R; i += nth) s_al += fabsf(al[i] - a.target_alpha[i]);
+        if (s) {
+            const int per = a.n_fg + a.n_bg;
+            for (int64_t i = tid; i < a.prior_rows * per; i += nth) {
+                const float e = expf(a.k * fmaxf(s[i], 0.0f));
+                if ((int)(i % per) < a.n_fg) s_fg += e; else s_bg += 1.0f - e;
+            }
+        }
+        if (q)
+            for (int64_t p = tid; p < a.normal_sets * a.nv; p += nth) {
+                const int64_t ia = (p / a.nv) * 2 * a.nv + p % a.nv;
+                float sa, sb;
+                const Normal u = unit_normal(q[ia], a.delta, sa), v = unit_normal(q[ia + a.nv], a.delta, sb);
+                const float iu = 1.0f / (u.r + 1e-5f), iv = 1.0f / (v.r + 1e-5f);
+                const float dx = u.x * iu - v.x * iv, dy = u.y * iu - v.y * iv, dz = u.z * iu - v.z * iv;
+                s_n += dx * dx + dy * dy + dz * dz;
+            }
+        acc[0 + pass] = s_rgb; acc[2 + pass] = s_al; acc[4 + 2 * pass] = s_fg; acc[5 + 2 * pass] = s_bg; acc[8 + pass] = s_n;
+    }
+#pragma unroll
+    for (int t = 0; t < LOSS_TERMS; ++t) {
+        const float v = block_sum(acc[t], sh);
+        if (threadIdx.x == 0) partials[blockIdx.x * LOSS_TERMS + t] = v;
+    }
+    // the last workgroup to finish adds the partial sums up in workgroup order (same bits on every run) and resets the ticket
+    __threadfence();
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == LOSS_BLOCKS - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (threadIdx.x < LOSS_TERMS) {
+        float v = 0.0f;
+        for (int b = 0; b < LOSS_BLOCKS; ++b) v += __builtin_nontemporal_load(&partials[b * LOSS_TERMS + threadIdx.x]);
+        const int t = threadIdx.x;
+        const float cnt = t < 2 ? (float)(a.R * 3) : t < 4 ? (float)a.R
+                        : t < 8 ? (float)(a.prior_rows * ((t & 1) ? a.n_bg : a.n_fg)) : (float)(a.normal_sets * a.nv * 3);
+        vals[t] = cnt > 0.0f ? v / cnt : 0.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float w[LOSS_TERMS] = {1.f, 1.f, a.lambda_alphas, a.lambda_alphas, a.lambda_foreground, a.lambda_background,
+                                     a.lambda_foreground, a.lambda_background, a.lambda_normals, a.lambda_normals};
+        float tot = 0.0f;
+        for (int t = 0; t < LOSS_TERMS; ++t) tot += w[t] * vals[t];
+        vals[LOSS_TERMS] = tot;
+        *ticket = 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void train_loss_backward_kernel(anr_loss_args a, const float* __restrict__ g_total, anr_loss_grads d) {
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+    const float g = *g_total;
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* rgb = pass ? a.rgb_fine : a.rgb;
+        const float* al = pass ? a.acc_fine : a.acc;
+        const float* s = pass ? a.s_fine : a.s;
+        const float4* q = reinterpret_cast<const float4*>(pass ? a.quads_fine : a.quads);
+        float* d_rgb = pass ? d.rgb_fine : d.rgb;
+        float* d_al = pass ? d.acc_fine : d.acc;
+        float* d_s = pass ? d.s_fine : d.s;
+        float4* d_q = reinterpret_cast<float4*>(pass ? d.quads_fine : d.quads);
+        if (rgb && d_rgb) {
+            const float c = g * 2.0f / (float)(a.R * 3);
+            for (int64_t i = tid; i < a.R * 3; i += nth) d_rgb[i] = c * (rgb[i] - a.target_rgb[i]);
+        }
+        if (al && d_al) {
+            const float c = g * a.lambda_alphas / (float)a.R;
+            for (int64_t i = tid; i < a.R; i += nth) {
+                const float e = al[i] - a.target_alpha[i];
+                d_al[i] = e > 0.0f ? c : e < 0.0f ? -c : 0.0f;
+            }
+        }
+        if (s && d_s) {
+            const int per = a.n_fg + a.n_bg;
+            const float cf = a.n_fg ? g * a.lambda_foreground * a.k / (float)(a.prior_rows * a.n_fg) : 0.0f;
+            const float cb = a.n_bg ? -g * a.lambda_background * a.k / (float)(a.prior_rows * a.n_bg) : 0.0f;
+            for (int64_t i = tid; i < a.prior_rows * per; i += nth) {
+                const float v = s[i];
+                d_s[i] = v > 0.0f ? ((int)(i % per) < a.n_fg ? cf : cb) * expf(a.k * v) : 0.0f;
+            }
+        }
+        if (q && d_q) {
+            const float c = g * a.lambda_normals * 2.0f / (float)(a.normal_sets * a.nv * 3);
+            for (int64_t p = tid; p < a.normal_sets * a.nv; p += nth) {
+                const int64_t ia = (p / a.nv) * 2 * a.nv + p % a.nv, ib = ia + a.nv;
+                const float4 qa = q[ia], qb = q[ib];
+                float sa, sb;
+                const Normal u = unit_normal(qa, a.delta, sa), v = unit_normal(qb, a.delta, sb);
+                const float iu = 1.0f / (u.r + 1e-5f), iv = 1.0f / (v.r + 1e-5f);
+                const float dx = c * (u.x * iu - v.x * iv), dy = c * (u.y * iu - v.y * iv), dz = c * (u.z * iu - v.z * iv);
+                // d (n / (|n| + eps)) : I / (|n| + eps) - n n^T / (|n| (|n| + eps)^2); the norm's subgradient at 0 is 0
+                auto through = [&](const Normal& w, float iw, float sgn, float scale, const float4 qq) -> float4 {
+                    const float dot = w.x * dx + w.y * dy + w.z * dz;
+                    const float k2 = w.r > 0.0f ? dot * iw * iw / w.r : 0.0f;
+                    const float gx = sgn * (dx * iw - w.x * k2), gy = sgn * (dy * iw - w.y * k2), gz = sgn * (dz * iw - w.z * k2);
+                    // n = scale(sigma) * grad sigma;  d scale / d sigma = -delta * scale
+                    return make_float4(-a.delta * scale * (gx * qq.y + gy * qq.z + gz * qq.w), scale * gx, scale * gy, scale * gz);
+                };
+                d_q[ia] = through(u, iu, 1.0f, sa, qa);
+                d_q[ib] = through(v, iv, -1.0f, sb, qb);
+            }
+            for (int64_t p = a.normal_sets * 2 * a.nv + tid; p < a.quad_rows; p += nth) d_q[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+}  // namespace anr
+
+using namespace anr;
+
+extern "C" int64_t anr_compact_ws_ints(int64_t n) { return (n + CB - 1) / CB; }
+
+extern "C" int anr_compact_ordered(const float* pts, int64_t n, int32_t* index_out, int32_t* pos_out, float* pts_out,
+                                   int32_t* count_out, int32_t* workspace, void* stream) {
+    ANR_REQUIRE(pts && index_out && pos_out && pts_out && count_out && workspace, ANR_E_BADARG, "anr_compact_ordered: null pointer");
+    ANR_REQUIRE(n > 0 && n < (int64_t)1 << 31, ANR_E_BADARG, "anr_compact_ordered: n=%lld", (long long)n);
+    ANR_REQUIRE((((uintptr_t)pts | (uintptr_t)pts_out) & 15) == 0, ANR_E_ALIGN, "anr_compact_ordered: pts/pts_out must be 16-B aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (int)((n + CB - 1) / CB);
+    hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(CB), 0, st, reinterpret_cast<const float4*>(pts), n, workspace);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, workspace, nb, count_out);
+    hipLaunchKernelGGL(compact_gather_kernel, dim3(nb), dim3(CB), 0, st, reinterpret_cast<const float4*>(pts), n, workspace, count_out,
+                       index_out, pos_out, reinterpret_cast<float4*>(pts_out));
+    return check_launch("anr_compact_ordered");
+}
+
+extern "C" int anr_expand_rows(const float* src, const int32_t* pos, int64_t n, int cols, float fill, float* out, void* stream) {
+    ANR_REQUIRE(src && pos && out, ANR_E_BADARG, "anr_expand_rows: null pointer");
+    ANR_REQUIRE(n > 0 && (cols == 1 || cols == 4), ANR_E_BADARG, "anr_expand_rows: n=%lld cols=%d (1 or 4)", (long long)n, cols);
+    ANR_REQUIRE(cols == 1 || (((uintptr_t)src | (uintptr_t)out) & 15) == 0, ANR_E_ALIGN, "anr_expand_rows: src/out must be 16-B aligned");
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (cols == 4) hipLaunchKernelGGL(expand_rows_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, pos, n, fill, out);
+    else hipLaunchKernelGGL(expand_rows_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, pos, n, fill, out);
+    return check_launch("anr_expand_rows");
+}
+
+extern "C" int anr_mlp_head_grad(const float* g, const int32_t* index, const float* out, const float* pts, int64_t rows, int64_t n_pad,
+                                 int sigma_only, float* g4_out, void* stream) {
+    ANR_REQUIRE(g && pts && g4_out && (sigma_only || out), ANR_E_BADARG, "anr_mlp_head_grad: null pointer");
+    ANR_REQUIRE(rows >= 0 && n_pad >= rows && n_pad > 0, ANR_E_BADARG, "anr_mlp_head_grad: rows=%lld n_pad=%lld", (long long)rows, (long long)n_pad);
+    ANR_REQUIRE((((uintptr_t)g4_out | (uintptr_t)pts | (uintptr_t)out | (sigma_only ? 0 : (uintptr_t)g)) & 15) == 0, ANR_E_ALIGN,
+                "anr_mlp_head_grad: 16-B alignment");
+    hipLaunchKernelGGL(head_grad_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, index,
+                       reinterpret_cast<const float4*>(out), reinterpret_cast<const float4*>(pts), rows, n_pad, sigma_only,
+                       reinterpret_cast<float4*>(g4_out));
+    return check_launch("anr_mlp_head_grad");
+}
+
+extern "C" int anr_tangent_quads(const float* xyz, int64_t n, int64_t n_pad, float* pts4_out, void* stream) {
+    ANR_REQUIRE(xyz && pts4_out, ANR_E_BADARG, "anr_tangent_quads: null pointer");
+    ANR_REQUIRE(n > 0 && n_pad >= n, ANR_E_BADARG, "anr_tangent_quads: n=%lld n_pad=%lld", (long long)n, (long long)n_pad);
+    hipLaunchKernelGGL(tangent_quads_kernel, dim3((unsigned)((4 * n_pad + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xyz, n, n_pad,
+                       reinterpret_cast<float4*>(pts4_out));
+    return check_launch("anr_tangent_quads");
+}
+
+extern "C" int64_t anr_train_loss_ws_floats(void) { return LOSS_BLOCKS * LOSS_TERMS + 4; }
+
+static int check_loss_args(const anr_loss_args* a, const char* who) {
+    ANR_REQUIRE(a, ANR_E_BADARG, "%s: null args", who);
+    ANR_REQUIRE(a->R >= 0 && a->prior_rows >= 0 && a->n_fg >= 0 && a->n_bg >= 0 && a->nv >= 0 && a->normal_sets >= 0, ANR_E_BADARG,
+                "%s: negative size", who);
+    ANR_REQUIRE(!(a->rgb || a->acc || a->rgb_fine || a->acc_fine) || (a->target_rgb && a->target_alpha && a->R > 0), ANR_E_BADARG,
+                "%s: rendered values without targets", who);
+    ANR_REQUIRE(!(a->s || a->s_fine) || (a->prior_rows > 0 && a->n_fg + a->n_bg > 0), ANR_E_BADARG, "%s: prior sizes", who);
+    ANR_REQUIRE(!(a->quads || a->quads_fine) || (a->nv > 0 && a->normal_sets > 0 && a->quad_rows >= 2 * a->nv * a->normal_sets),
+                ANR_E_BADARG, "%s: normal sizes", who);
+    ANR_REQUIRE((((uintptr_t)a->quads | (uintptr_t)a->quads_fine) & 15) == 0, ANR_E_ALIGN, "%s: quads must be 16-B aligned", who);
+    return 0;
+}
+
+extern "C" int anr_train_loss(const anr_loss_args* a, float* workspace, float* vals_out, void* stream) {
+    if (int rc = check_loss_args(a, "anr_train_loss")) return rc;
+    ANR_REQUIRE(workspace && vals_out, ANR_E_BADARG, "anr_train_loss: null pointer");
+    hipLaunchKernelGGL(train_loss_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, (hipStream_t)stream, *a, workspace + 4,
+                       reinterpret_cast<unsigned*>(workspace), vals_out);
+    return check_launch("anr_train_loss");
+}
+
+extern "C" int anr_train_loss_backward(const anr_loss_args* a, const float* g_total, const anr_loss_grads* d, void* stream) {
+    if (int rc = check_loss_args(a, "anr_train_loss_backward")) return rc;
+    ANR_REQUIRE(g_total && d, ANR_E_BADARG, "anr_train_loss_backward: null pointer");
+    ANR_REQUIRE((((uintptr_t)d->quads | (uintptr_t)d->quads_fine) & 15) == 0, ANR_E_ALIGN, "anr_train_loss_backward: quads must be 16-B aligned");
+    hipLaunchKernelGGL(train_loss_backward_kernel, dim3(128), dim3(256), 0, (hipStream_t)stream, *a, g_total, *d);
+    return check_launch("anr_train_loss_backward");
+}

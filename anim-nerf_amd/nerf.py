@@ -66,6 +66,7 @@ class NeRF(nn.Module):
         self.sigma = nn.Linear(W, 1)
         self.rgb = nn.Sequential(nn.Linear(W // 2, 3), nn.Sigmoid())
         self._pack_cache = {}
+        self.grad_sink = None            # autograd.GradSink, attached by the trainer: weight gradients accumulate in one flat buffer
 
     # -- weight pack (fragment-ordered copy for the kernel), rebuilt when any parameter changes
     def _trunk_supported(self):
@@ -136,7 +137,7 @@ class NeRF(nn.Module):
             if not self._hip_supported():
                 raise NotImplementedError("HIP MLP covers the shipped configuration only")
             named = dict(self.named_parameters())
-            return MLPFunction.apply(pts, sigma_only, ops.MLP_MODES[mode or self.mlp_mode] & 0xff, only_valid,
+            return MLPFunction.apply(pts, sigma_only, ops.MLP_MODES[mode or self.mlp_mode] & 0xff, only_valid, self.grad_sink,
                                      *[named[k] for k in PARAM_KEYS])
         pack, mode_id = self.weight_pack(mode)
         return ops.mlp_forward(pack, mode_id, pts, sigma_only=sigma_only, only_valid=only_valid, valid_list=valid_list)
@@ -189,8 +190,21 @@ class NeRF(nn.Module):
         named = dict(self.named_parameters())
         flat = xyz.detach().reshape(-1, 3).float().contiguous()
         with torch.set_grad_enabled(True):
-            n = NormalFunction.apply(flat, float(delta), ops.MLP_MODES[self.mlp_mode] & 0xff, *[named[k] for k in PARAM_KEYS])
+            n = NormalFunction.apply(flat, float(delta), ops.MLP_MODES[self.mlp_mode] & 0xff, self.grad_sink,
+                                     *[named[k] for k in PARAM_KEYS])
         return n.view(*xyz.shape[:-1], 3)
+
+    def tangent_sigma(self, xyz):
+        """quads[n_pad,4] = (sigma, d sigma / d xyz) at xyz[...,3] flattened (n_pad = n rounded up to 16, zero rows after n):
+        what get_normal is computed from, for the fused loss kernels (autograd.QuadSigmaFunction)."""
+        from .autograd import PARAM_KEYS, QuadSigmaFunction
+        if not self._hip_supported():
+            raise NotImplementedError("tangent_sigma is built for the shipped configuration (use_view=False, D=8, W=256)")
+        named = dict(self.named_parameters())
+        flat = xyz.detach().reshape(-1, 3)
+        with torch.set_grad_enabled(True):
+            return QuadSigmaFunction.apply(flat, ops.MLP_MODES[self.mlp_mode] & 0xff, self.grad_sink,
+                                           *[named[k] for k in PARAM_KEYS])
 
     def _normal_autograd(self, xyz, delta=0.02):
         """The same quantity by autograd of autograd over `_sigma_dense` (reference formulation; used by the tests)."""

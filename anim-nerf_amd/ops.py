@@ -387,7 +387,7 @@ _WGRAD_WS = {}
 
 
 def mlp_wgrad(mode: int, act: torch.Tensor, dact: torch.Tensor, enc: torch.Tensor, g4: torch.Tensor, sigma_only: bool = False,
-              tangent: bool = False):
+              tangent: bool = False, accumulate_into: Optional[torch.Tensor] = None):
     """All 22 parameter gradients of one network from the saved activations, the activation gradients, the encoding matrix
     (encode64) and g4 = (dL/d rgb_pre, dL/d sigma): a flat fp32 tensor in the order of autograd.PARAM_KEYS (PyTorch
     [out][in] layouts).  Hand-written split-K MFMA GEMMs (csrc/mlp_wgrad.hip); n % 64 == 0."""
@@ -400,7 +400,13 @@ def mlp_wgrad(mode: int, act: torch.Tensor, dact: torch.Tensor, enc: torch.Tenso
     need = lib.anr_mlp_wgrad_ws_floats(n)
     if ws is None or ws.numel() < need:                    # per-stream scratch, reused by every call (split-K partials)
         ws = _WGRAD_WS[key] = torch.empty(need, dtype=torch.float32, device=act.device)
-    grads = torch.empty(lib.anr_mlp_wgrad_floats(), dtype=torch.float32, device=act.device)
+    if accumulate_into is not None:                        # += into a flat gradient buffer (autograd.GradSink)
+        grads = _dev(accumulate_into, "accumulate_into")
+        if grads.numel() != lib.anr_mlp_wgrad_floats():
+            raise ValueError("accumulate_into must hold anr_mlp_wgrad_floats() floats")
+        m |= _lib.ANR_MLP_FLAG_ACCUMULATE
+    else:
+        grads = torch.empty(lib.anr_mlp_wgrad_floats(), dtype=torch.float32, device=act.device)
     with _timed("mlp_wgrad", n):
         _lib.check(lib.anr_mlp_wgrad(m, _ptr(act), _ptr(dact), _ptr(enc), _ptr(g4), n, _ptr(ws), _ptr(grads), _stream(grads)),
                    "anr_mlp_wgrad")
@@ -583,7 +589,7 @@ def composite_backward(rgbs, z, rays, white_bkgd: bool, g_rgb, g_depth, g_acc, n
     """Backward of `composite`: -> d_rgbs[R,K,4] (and d_z[R,K], d_far[R] if want_dz)."""
     lib = _lib.load()
     rgbs, z, rays = _dev(rgbs, "rgbs"), _dev(z, "z"), _dev(rays, "rays")
-    g_rgb, g_depth, g_acc = _dev(g_rgb, "g_rgb"), _dev(g_depth, "g_depth"), _dev(g_acc, "g_acc")
+    g_rgb, g_depth, g_acc = (None if g is None else _dev(g, nm) for g, nm in ((g_rgb, "g_rgb"), (g_depth, "g_depth"), (g_acc, "g_acc")))
     R, K = z.shape
     if noise is not None:
         noise = _dev(noise, "noise")
@@ -673,3 +679,102 @@ def composite_sample(rgbs, rays, u, white_bkgd: bool, *, z=None, steps=None, val
                                             _ptr(o["depth"]), _ptr(o["acc"]), _ptr(o["z_fine"]), _ptr(o["z_sorted"]),
                                             _ptr(o["perm"]), _stream(rgbs)), "anr_composite_sample")
     return o
+
+
+# ---- the steps between the big kernels of a training step (csrc/train_glue.hip)
+def compact_ordered(pts: torch.Tensor):
+    """-> (index[n] int32 — first `count` entries: the positions with valid >= 1, ascending —, pos[n] int32 (row in that
+    list or -1), pts_c[roundup64(n), 4] (the listed points, then zero rows to the next multiple of 64), count[1] int32 on
+    the device)."""
+    lib = _lib.load()
+    pts = _dev(pts, "pts")
+    n = pts.numel() // 4
+    index = torch.empty(n, dtype=torch.int32, device=pts.device)
+    pos = torch.empty(n, dtype=torch.int32, device=pts.device)
+    pts_c = torch.empty(-(-n // 64) * 64, 4, dtype=torch.float32, device=pts.device)
+    count = torch.empty(1, dtype=torch.int32, device=pts.device)
+    ws = torch.empty(lib.anr_compact_ws_ints(n), dtype=torch.int32, device=pts.device)
+    with _timed("compact_ordered", n, n * 24):
+        _lib.check(lib.anr_compact_ordered(_ptr(pts), n, _ptr(index), _ptr(pos), _ptr(pts_c), _ptr(count), _ptr(ws), _stream(pts)),
+                   "anr_compact_ordered")
+    return index, pos, pts_c, count
+
+
+def expand_rows(src: torch.Tensor, pos: torch.Tensor, fill: float) -> torch.Tensor:
+    """out[i] = src[pos[i]] where pos[i] >= 0, else (0,0,0,fill) (src[., 4]) or fill (src[.])."""
+    lib = _lib.load()
+    src = _dev(src, "src")
+    n = pos.numel()
+    cols = 4 if src.dim() == 2 else 1
+    out = torch.empty((n, 4) if cols == 4 else (n,), dtype=torch.float32, device=src.device)
+    _lib.check(lib.anr_expand_rows(_ptr(src), _ptr(pos), n, cols, float(fill), _ptr(out), _stream(out)), "anr_expand_rows")
+    return out
+
+
+def mlp_head_grad(g: torch.Tensor, index: Optional[torch.Tensor], out: Optional[torch.Tensor], pts: torch.Tensor, rows: int,
+                  sigma_only: bool) -> torch.Tensor:
+    """The g[n_pad,4] operand of mlp_backward / mlp_wgrad from the upstream gradient of (rgb, sigma) (see the header)."""
+    lib = _lib.load()
+    g, pts = _dev(g, "g"), _dev(pts, "pts")
+    n_pad = pts.shape[0]
+    g4 = torch.empty(n_pad, 4, dtype=torch.float32, device=pts.device)
+    _lib.check(lib.anr_mlp_head_grad(_ptr(g), _ptr(index), _ptr(out), _ptr(pts), rows, n_pad, 1 if sigma_only else 0, _ptr(g4),
+                                     _stream(g4)), "anr_mlp_head_grad")
+    return g4
+
+
+def tangent_quads(xyz: torch.Tensor, n_pad: int) -> torch.Tensor:
+    """xyz[n,3] -> pts4[4 n_pad, 4]: four rows (x,y,z,1) per point, zero rows for the padding points."""
+    lib = _lib.load()
+    xyz = _dev(xyz, "xyz")
+    pts4 = torch.empty(4 * n_pad, 4, dtype=torch.float32, device=xyz.device)
+    _lib.check(lib.anr_tangent_quads(_ptr(xyz), xyz.shape[0], n_pad, _ptr(pts4), _stream(pts4)), "anr_tangent_quads")
+    return pts4
+
+
+_LOSS_WS = {}
+LOSS_NAMES = ("loss_rgb", "loss_rgb_fine", "loss_alphas", "loss_alphas_fine", "loss_foreground", "loss_background",
+              "loss_foreground_fine", "loss_background_fine", "loss_normals", "loss_normals_fine")
+
+
+def _loss_args(t: dict, c: dict):
+    a = _lib.AnrLossArgs()
+    for k in ("rgb", "acc", "rgb_fine", "acc_fine", "target_rgb", "target_alpha", "s", "s_fine", "quads", "quads_fine"):
+        v = t.get(k)
+        setattr(a, k, None if v is None else _ptr(_dev(v, k)))
+    for k in ("R", "prior_rows", "nv", "normal_sets", "quad_rows", "n_fg", "n_bg"):
+        setattr(a, k, int(c.get(k, 0)))
+    for k in ("k", "delta", "lambda_alphas", "lambda_foreground", "lambda_background", "lambda_normals"):
+        setattr(a, k, float(c.get(k, 0.0)))
+    return a
+
+
+def train_loss(tensors: dict, consts: dict) -> torch.Tensor:
+    """vals[11]: the ten loss terms (LOSS_NAMES) and their weighted total, one launch (anr_train_loss)."""
+    import ctypes as C
+    lib = _lib.load()
+    ref = next(v for v in tensors.values() if v is not None)
+    key = (ref.device.index, torch.cuda.current_stream(ref.device).cuda_stream)
+    ws = _LOSS_WS.get(key)
+    if ws is None:
+        ws = _LOSS_WS[key] = torch.zeros(lib.anr_train_loss_ws_floats(), dtype=torch.float32, device=ref.device)
+    vals = torch.empty(11, dtype=torch.float32, device=ref.device)
+    a = _loss_args(tensors, consts)
+    _lib.check(lib.anr_train_loss(C.byref(a), _ptr(ws), _ptr(vals), _stream(vals)), "anr_train_loss")
+    return vals
+
+
+def train_loss_backward(tensors: dict, consts: dict, g_total: torch.Tensor, want: dict) -> dict:
+    """Gradients of the total w.r.t. the tensors named in `want` (rgb, acc, rgb_fine, acc_fine, s, s_fine, quads, quads_fine)."""
+    import ctypes as C
+    lib = _lib.load()
+    a = _loss_args(tensors, consts)
+    d = _lib.AnrLossGrads()
+    out = {}
+    for k in ("rgb", "acc", "rgb_fine", "acc_fine", "s", "s_fine", "quads", "quads_fine"):
+        if want.get(k) and tensors.get(k) is not None:
+            out[k] = torch.empty_like(tensors[k], memory_format=torch.contiguous_format)
+            setattr(d, k, _ptr(out[k]))
+    g_total = _dev(g_total.reshape(1), "g_total")
+    _lib.check(lib.anr_train_loss_backward(C.byref(a), _ptr(g_total), C.byref(d), _stream(g_total)), "anr_train_loss_backward")
+    return out

@@ -36,11 +36,12 @@ class TrainHParams:
     lambda_alphas: float = 0.1
     lambda_foreground: float = 0.01
     lambda_background: float = 0.01
-    lambda_normals: float = 0.01         # config.py:60; second-order term, evaluated with torch autograd (nerf.get_normal)
+    lambda_normals: float = 0.01         # config.py:60; second-order term (forward-mode tangents through the fused kernels)
     epsilon: float = 0.01                # config.py:63
     dis_threshold: float = 0.2
     max_epochs: int = 30
     poly_exp: float = 0.9
+    fused_losses: bool = True            # all loss terms in one launch (anr_train_loss) instead of ~100 framework ops
 
 
 class BodyModelParams(nn.Module):
@@ -77,6 +78,9 @@ class BodyModelParams(nn.Module):
 
 def compute_loss(anim_nerf, hp: TrainHParams, rgbs, alphas, results, fg_points=None, bg_points=None):
     """train.py:228-286 (rgb MSE, alpha L1, foreground / background sigma priors), coarse and fine."""
+    if (hp.fused_losses and rgbs.is_cuda and hasattr(anim_nerf, "_net") and torch.is_grad_enabled()
+            and all(anim_nerf._net(f)._hip_supported() for f in (False, True))):
+        return _compute_loss_fused(anim_nerf, hp, rgbs, alphas, results, fg_points, bg_points)
     details: Dict[str, torch.Tensor] = {}
     fine = hp.n_importance > 0 and not hp.share_fine
     loss = details.setdefault("loss_rgb", F.mse_loss(results["rgbs"], rgbs))
@@ -117,6 +121,44 @@ def compute_loss(anim_nerf, hp: TrainHParams, rgbs, alphas, results, fg_points=N
             details["loss_normals" + tag] = F.mse_loss(nrm[:, :nv], nrm[:, nv:])
             loss = loss + hp.lambda_normals * details["loss_normals" + tag]
     return loss, details
+
+
+def _compute_loss_fused(anim_nerf, hp, rgbs, alphas, results, fg_points, bg_points):
+    """compute_loss with every term, the weighted total and their gradients in two launches (autograd.TrainLossFunction);
+    the field queries behind the priors and the normals hand over raw sigmas / tangent quads.  Same random draws, same
+    values (tests/test_gpu_training.py::test_fused_losses_equal_the_term_by_term_version)."""
+    from . import ops
+    from .autograd import TrainLossFunction
+    fine = hp.n_importance > 0 and not hp.share_fine
+    t = {"rgb": results["rgbs"].reshape(-1, 3), "acc": results["alphas"].reshape(-1)}
+    if fine:
+        t["rgb_fine"], t["acc_fine"] = results["rgbs_fine"].reshape(-1, 3), results["alphas_fine"].reshape(-1)
+    consts = {"R": rgbs.numel() // 3, "k": -2.0 / hp.n_samples, "lambda_alphas": hp.lambda_alphas,
+              "lambda_foreground": hp.lambda_foreground, "lambda_background": hp.lambda_background,
+              "lambda_normals": hp.lambda_normals}
+    tags = [("", False)] + ([("_fine", True)] if fine else [])
+    want_fg = hp.use_unpose and fg_points is not None
+    want_bg = hp.use_unpose and bg_points is not None
+    if want_fg or want_bg:
+        both = torch.cat([p for p, w in ((fg_points, want_fg), (bg_points, want_bg)) if w], dim=1)
+        consts.update(prior_rows=both.shape[0], n_fg=fg_points.shape[1] if want_fg else 0, n_bg=bg_points.shape[1] if want_bg else 0)
+        for tag, use_fine in tags:
+            t["s" + tag] = anim_nerf.query_canonical_space(both, use_fine=use_fine, only_sigma=True).reshape(-1)
+    if hp.lambda_normals != 0:
+        pts = anim_nerf.verts_template.detach()
+        pts = pts + torch.randn_like(pts) * hp.dis_threshold * 0.5
+        nbr = pts + torch.randn_like(pts) * hp.epsilon
+        pair = torch.cat([pts, nbr], 1)
+        for tag, use_fine in tags:
+            t["quads" + tag] = anim_nerf._net(use_fine).tangent_sigma(pair)
+        consts.update(nv=pts.shape[1], normal_sets=pts.shape[0], quad_rows=t["quads"].shape[0], delta=0.02)
+    total, vals = TrainLossFunction.apply(consts, rgbs.reshape(-1, 3).contiguous(), alphas.reshape(-1).contiguous(),
+                                          *[t.get(k) for k in TrainLossFunction.KEYS])
+    present = {"loss_rgb": True, "loss_rgb_fine": fine, "loss_alphas": True, "loss_alphas_fine": fine,
+               "loss_foreground": want_fg, "loss_background": want_bg, "loss_foreground_fine": want_fg and fine,
+               "loss_background_fine": want_bg and fine, "loss_normals": hp.lambda_normals != 0,
+               "loss_normals_fine": hp.lambda_normals != 0 and fine}
+    return total, {k: vals[i] for i, k in enumerate(ops.LOSS_NAMES) if present[k]}
 
 
 def allreduce_gradients(params, world: Optional[int] = None):
@@ -172,6 +214,36 @@ class GradientReducer:
             for p in self.slot:
                 p.register_post_accumulate_grad_hook(self._arrived)
         self._pending, self._next, self._handles = [], 0, []
+        self.sinks = []
+
+    def attach_sink(self, net):
+        """If the 22 tensors of `net` lie back to back in PARAM_KEYS order in one bucket, make that stretch the network's
+        GradSink: its MLP backward passes accumulate straight into the send buffer and report completion per network."""
+        from .autograd import PARAM_KEYS, GradSink
+        named = dict(net.named_parameters())
+        params = [named.get(k) for k in PARAM_KEYS]
+        if any(p is None or p not in self.slot or not p.requires_grad or p.dtype != torch.float32 for p in params):
+            return None
+        bi = self.slot[params[0]][0]
+        views = [self.slot[p][1] for p in params]
+        first = views[0].data_ptr()
+        o = 0
+        for p, v in zip(params, views):
+            if self.slot[p][0] != bi or v.data_ptr() != first + 4 * o:
+                return None
+            o += p.numel()
+        start = (first - self.flat[bi].data_ptr()) // 4
+        sink = GradSink(net, self.flat[bi][start:start + o])
+        sink.views = views                                    # the very tensors prepare() installs as .grad
+        sink.on_complete = lambda s, bi=bi, k=len(params): self._sink_done(bi, k)
+        net.grad_sink = sink
+        self.sinks.append(sink)
+        return sink
+
+    def _sink_done(self, bi, k):
+        if self.active:
+            self._pending[bi] -= k
+            self._issue_ready()
 
     def prepare(self):
         """Before backward: zero the send buffers and point every p.grad at its slice."""
@@ -181,6 +253,8 @@ class GradientReducer:
             flat.zero_()
         for p, (_, view) in self.slot.items():
             p.grad = view
+        for sink in self.sinks:
+            sink.begin_step(zero=False)
 
     def _issue_ready(self, force=False):
         while self._next < len(self.buckets) and (force or self._pending[self._next] == 0):
@@ -226,21 +300,36 @@ class Trainer:
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(
             self.optimizer, lambda epoch: (1 - epoch / hp.max_epochs) ** hp.poly_exp)
         # gradient buckets in the order backward completes them: fine network, coarse network, SMPL parameter rows
-        fine = [p for p in getattr(anim_nerf, "nerf_fine", anim_nerf.nerf).parameters() if p.requires_grad]
+        # (inside a network: the order anr_mlp_wgrad writes, so that the bucket is the kernel's output buffer)
+        from .autograd import PARAM_KEYS
+
+        def ordered(net):
+            named = dict(net.named_parameters())
+            head = [named[k] for k in PARAM_KEYS if k in named]
+            ids = {id(p) for p in head}
+            return [p for p in head + [p for p in net.parameters() if id(p) not in ids] if p.requires_grad]
+        nets = [getattr(anim_nerf, "nerf_fine", anim_nerf.nerf)]
+        fine = ordered(nets[0])
         fine_ids = {id(p) for p in fine}
-        coarse = [p for p in anim_nerf.nerf.parameters() if p.requires_grad and id(p) not in fine_ids]
+        coarse = [p for p in ordered(anim_nerf.nerf) if id(p) not in fine_ids]
+        if coarse:
+            nets.append(anim_nerf.nerf)
         seen = fine_ids | {id(p) for p in coarse}
         rest = [p for p in self.params if id(p) not in seen]
         self.reducer = GradientReducer([fine, coarse + rest])
+        if self.params and self.params[0].is_cuda:
+            for net in nets:
+                self.reducer.attach_sink(net)
+
+    def begin_step(self):
+        """Zero the flat gradient buffers and point every p.grad at its slice (instead of optimizer.zero_grad)."""
+        self.reducer.prepare()
 
     def step(self, rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points=None, bg_points=None,
              perturb=1.0, frame_idx=None):
         """`body_model_params` is the dict of the batch, or — with a BodyModelParams table and `frame_idx` — replaced
         by the learnable rows of those frames (train.py:330-331)."""
-        if self.reducer.active:
-            self.reducer.prepare()                            # grads are views into the (zeroed) send buffers
-        else:
-            self.optimizer.zero_grad(set_to_none=True)
+        self.begin_step()                                     # grads are views into the (zeroed) flat buffers
         if self.body_model_params is not None and frame_idx is not None:
             body_model_params = self.body_model_params(frame_idx)
         results = system_forward(self.renderer, self.model, rays, body_model_params, body_model_params_template,

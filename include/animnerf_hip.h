@@ -53,6 +53,9 @@ extern "C" {
  * with ANR_MLP_FLAG_SIGMA_ONLY, by anr_mlp_forward_save (sigma of a tangent row = d sigma / d x_d), anr_mlp_backward,
  * anr_mlp_wgrad (bias gradients from the primal rows only) and anr_encode64 (rows 4p+1..3 = d enc / d x_d). */
 #define ANR_MLP_FLAG_TANGENT 0x800
+/* anr_mlp_wgrad: grads_out += (gradients accumulate over several calls, as autograd's .grad does; tensors a
+ * sigma-only call does not produce are left alone instead of zero-filled). */
+#define ANR_MLP_FLAG_ACCUMULATE 0x1000
 
 int         anr_version(void);
 const char* anr_last_error(void);
@@ -307,6 +310,55 @@ int anr_mlp_wgrad(int mode, const void* act, const void* dact, const void* enc, 
  * PyTorch [256][63] / [256][319] layouts); anr_encode_backward turns it into dL/d xyz. */
 int anr_mlp_denc(int mode, const void* dact, const float* w1, const float* w5, int64_t n, float* d_enc_out, void* stream);
 
+/* ---- a16 / f1: the steps between the big kernels of a training step, one launch each (csrc/train_glue.hip) --------
+ * anr_compact_ordered: `inside_inds` of models/anim_nerf.py:253 in sample order.  index_out[0..*count) = positions i with
+ *   pts[4i+3] >= 1, ascending; pos_out[i] = row of sample i in that list or -1; pts_out[r] = pts[index[r]], followed by
+ *   zero rows (valid = 0) up to the next multiple of 64 (at least 64 rows): the operand of anr_mlp_forward_save.
+ *   pts_out needs ((n + 63) / 64) * 64 rows; workspace anr_compact_ws_ints(n) int32; *count_out is a DEVICE int32.
+ * anr_expand_rows: out[i] = pos[i] >= 0 ? src[pos[i]] : (0, 0, 0, fill) (cols = 4) / fill (cols = 1), i < n — what the
+ *   reference's masked assignment does (models/anim_nerf.py:284-289).
+ * anr_mlp_head_grad: the g[n_pad*4] operand of anr_mlp_backward / anr_mlp_wgrad from autograd's upstream gradient
+ *   g_in ([n_full][4] on (rgb, sigma), or [n_full] on sigma with sigma_only): row r < rows reads g_in[index ? index[r] : r],
+ *   rgb columns times sigmoid' = out (1 - out) (out[n_pad*4] from anr_mlp_forward_save), sigma column zeroed where
+ *   pts[4r+3] < 1; rows >= `rows` are zero.
+ * anr_tangent_quads: xyz[n*3] -> pts4[4*n_pad*4]: rows 4p..4p+3 = (x, y, z, 1) for p < n, zero rows after
+ *   (ANR_MLP_FLAG_TANGENT operand: a point and its three directional derivatives). */
+int64_t anr_compact_ws_ints(int64_t n);
+int anr_compact_ordered(const float* pts, int64_t n, int32_t* index_out, int32_t* pos_out, float* pts_out,
+                        int32_t* count_out, int32_t* workspace, void* stream);
+int anr_expand_rows(const float* src, const int32_t* pos, int64_t n, int cols, float fill, float* out, void* stream);
+int anr_mlp_head_grad(const float* g_in, const int32_t* index, const float* out, const float* pts, int64_t rows,
+                      int64_t n_pad, int sigma_only, float* g_out, void* stream);
+int anr_tangent_quads(const float* xyz, int64_t n, int64_t n_pad, float* pts4_out, void* stream);
+
+/* Every loss term of train.py:228-309 in one launch, and their gradients in another.  Pointers of terms that are not
+ * wanted are NULL (fine pass, priors, normals).  All device fp32.
+ *   rgb[R*3], acc[R] (+ _fine), target_rgb[R*3], target_alpha[R]: MSE and L1 (train.py:228-246);
+ *   s[prior_rows * (n_fg + n_bg)] (+ _fine): sigma at the foreground points followed by the background points of each row;
+ *     mean exp(k relu(s)) / mean 1 - exp(k relu(s)), k = -2 / n_samples (train.py:262-286);
+ *   quads[quad_rows*4] (+ _fine): tangent-mode sigma (sigma, d/dx, d/dy, d/dz) of normal_sets x (nv points, nv perturbed
+ *     neighbours); normal = delta exp(-delta sigma) grad sigma where sigma > 0 (models/nerf.py:177-190), unit length with
+ *     eps 1e-5, MSE between a point's and its neighbour's (train.py:288-309).
+ * vals_out[11] = loss_rgb, loss_rgb_fine, loss_alphas, loss_alphas_fine, loss_foreground, loss_background,
+ *   loss_foreground_fine, loss_background_fine, loss_normals, loss_normals_fine, total (weighted by the lambdas).
+ * workspace[anr_train_loss_ws_floats()], zero before its first use (the kernel leaves it ready for the next call). */
+typedef struct {
+    const float *rgb, *acc, *rgb_fine, *acc_fine, *target_rgb, *target_alpha;
+    const float *s, *s_fine;
+    const float *quads, *quads_fine;
+    int64_t R, prior_rows, nv, normal_sets, quad_rows;
+    int32_t n_fg, n_bg;
+    float k, delta, lambda_alphas, lambda_foreground, lambda_background, lambda_normals;
+} anr_loss_args;
+/* gradient destinations, same shapes as the inputs (NULL: not wanted); quads: all quad_rows rows are written */
+typedef struct {
+    float *rgb, *acc, *rgb_fine, *acc_fine, *s, *s_fine, *quads, *quads_fine;
+} anr_loss_grads;
+int64_t anr_train_loss_ws_floats(void);
+int anr_train_loss(const anr_loss_args* args, float* workspace, float* vals_out, void* stream);
+/* g_total: DEVICE pointer to dL/d total (autograd's upstream scalar) */
+int anr_train_loss_backward(const anr_loss_args* args, const float* g_total, const anr_loss_grads* grads, void* stream);
+
 /* ---- sigma-grid points for mesh extraction -------------------------------------------------------
  * extract_mesh.py:27-35 (create_grid: np.meshgrid(x, y, z), 'xy' indexing, fp64 linspace -> fp32) and :152-157
  * (+ bounding-box centre of the posed vertices).  Flat index n = (j*N + i)*N + k -> (x[i], y[j], z[k]).
@@ -333,7 +385,7 @@ int anr_composite_masked(const float* rgbs, const float* z, const float* rays, i
 
 /* ---- a16 (part): backward of anr_composite -------------------------------------------------------------
  * What autograd differentiates in models/volume_rendering.py:131-160: upstream gradients of the per-ray outputs
- * g_rgb[R*3], g_depth[R], g_acc[R] (and optionally of the weights, g_weights[R*K] or NULL) ->
+ * g_rgb[R*3], g_depth[R], g_acc[R] (each may be NULL = zero; and optionally of the weights, g_weights[R*K] or NULL) ->
  * d_rgbs[R*K*4] = dL/d(r, g, b, sigma) per sample; optionally also dL/dz (through the interval lengths and the
  * depth output) and dL/dfar' (white-background depth term), which pose refinement needs.
  * Same inputs as the forward (nothing is kept by the library). */

@@ -379,3 +379,108 @@ def test_normals_regulariser_matches_oracle_autograd(dev, smpl_table):
     k = "xyz_encoding_3.0.weight"
     a, b = dict(m.nerf.named_parameters())[k].grad.cpu(), P[k].grad
     assert (a - b).norm() / b.norm() < 5e-2
+
+
+def _loss_scene(dev, smpl_table, frames=2):
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    g = golden("render_cfg3_warp_gain")
+    m = seeded_model(smpl_table, g["seed"], True, g["gain"], g["shift"], device=dev)
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=3, bs=frames).items()}
+    c2w, focal, cen = syn.pinhole_camera(8, 8)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), 8, 8, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(frames, 1, 1, 1)
+    gen = torch.Generator().manual_seed(4)
+    tgt_rgb = torch.rand(frames, 8, 8, 3, generator=gen).to(dev)
+    tgt_a = (torch.rand(frames, 8, 8, 1, generator=gen) > 0.5).float().to(dev)
+    fg = (torch.rand(frames, 64, 3, generator=gen) * 0.4 - 0.2).to(dev)
+    bg = (torch.rand(frames, 48, 3, generator=gen) * 2 - 1).to(dev)
+    return m, pose, rays, tgt_rgb, tgt_a, fg, bg
+
+
+@pytest.mark.parametrize("terms", ["all", "no_background", "coarse_only"])
+def test_fused_losses_equal_the_term_by_term_version(dev, smpl_table, terms):
+    """anr_train_loss / anr_train_loss_backward (every term of train.py:228-309 in one launch each) against the same
+    terms written as framework ops (mse_loss, l1_loss, exp/relu/mean, norm): values of every term and of the total, and
+    the gradient of every network parameter."""
+    import anim_nerf_amd as ana
+    m, pose, rays, tgt_rgb, tgt_a, fg, bg = _loss_scene(dev, smpl_table)
+    n_imp = 0 if terms == "coarse_only" else 8
+    vr = ana.VolumeRenderer(n_coarse=16, n_fine=n_imp)
+    got = {}
+    for fused in (False, True):
+        hp = ana.TrainHParams(n_samples=16, n_importance=n_imp, chunk=40, lambda_normals=0.05, fused_losses=fused)
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(123)                                   # the normals term draws its points
+        res = ana.system_forward(vr, m, rays, pose, _templ(dev), perturb=0.0, chunk=hp.chunk)
+        loss, details = ana.compute_loss(m, hp, tgt_rgb, tgt_a, res, fg, None if terms == "no_background" else bg)
+        loss.backward()
+        got[fused] = (loss.item(), {k: v.item() for k, v in details.items()},
+                      {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    (l0, d0, g0), (l1, d1, g1) = got[False], got[True]
+    assert set(d0) == set(d1), (sorted(d0), sorted(d1))
+    assert abs(l0 - l1) <= 1e-5 * abs(l0), (l0, l1)
+    for k in d0:
+        assert abs(d0[k] - d1[k]) <= 1e-5 * abs(d0[k]) + 1e-9, (k, d0[k], d1[k])
+    assert set(g0) == set(g1)
+    for k in g0:
+        scale = g0[k].abs().max().item()
+        assert (g0[k] - g1[k]).abs().max().item() <= 2e-4 * scale + 1e-10, (k, scale, (g0[k] - g1[k]).abs().max().item())
+
+
+def test_gradient_sink_equals_autograd_accumulation(dev, smpl_table):
+    """Trainer's flat gradient buffers (autograd.GradSink: the weight-gradient kernel accumulates into .grad's storage,
+    autograd gets None) against plain autograd accumulation of the 22 tensors of each pass: same gradients, and .grad of
+    every parameter is a view of the flat buffer."""
+    import anim_nerf_amd as ana
+    m, pose, rays, tgt_rgb, tgt_a, fg, bg = _loss_scene(dev, smpl_table)
+    hp = ana.TrainHParams(n_samples=16, n_importance=8, chunk=40, lambda_normals=0.05)
+    vr = ana.VolumeRenderer(n_coarse=16, n_fine=8)
+
+    def one():
+        torch.manual_seed(77)
+        res = ana.system_forward(vr, m, rays, pose, _templ(dev), perturb=0.0, chunk=hp.chunk)
+        ana.compute_loss(m, hp, tgt_rgb, tgt_a, res, fg, bg)[0].backward()
+    m.zero_grad(set_to_none=True)
+    one()
+    plain = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    tr = ana.Trainer(m, vr, hp)
+    assert m.nerf.grad_sink is not None and m.nerf_fine.grad_sink is not None
+    for rep in range(2):                                        # twice: the buffers are re-zeroed, nothing carries over
+        tr.begin_step()
+        one()
+        assert m.nerf.grad_sink.done == m.nerf.grad_sink.expected == 4      # two ray chunks, priors, normals
+        for net in (m.nerf, m.nerf_fine):
+            flat = net.grad_sink.flat
+            for p in net.grad_sink.params:
+                assert flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel()
+        for k, p in m.named_parameters():
+            if k in plain:
+                scale = plain[k].abs().max().item()
+                assert (p.grad - plain[k]).abs().max().item() <= 1e-5 * scale + 1e-12, (rep, k)
+
+
+def test_ordered_compaction_and_row_expansion(dev):
+    from anim_nerf_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    for n, frac in ((1, 1.0), (63, 0.5), (1024, 0.0), (5000, 0.07), (200_003, 0.3)):
+        pts = torch.rand(n, 4, generator=gen)
+        pts[:, 3] = (torch.rand(n, generator=gen) < frac).float() * (1 + torch.rand(n, generator=gen))
+        pts = pts.to(dev)
+        index, pos, pts_c, count = ops.compact_ordered(pts)
+        want = torch.nonzero(pts[:, 3] >= 1)[:, 0]
+        c = int(count.item())
+        assert c == want.numel()
+        assert torch.equal(index[:c].long(), want)
+        assert torch.equal(pts_c[:c], pts[want])
+        pad = max(-(-c // 64) * 64, 64)
+        assert not pts_c[c:pad].any()
+        ref_pos = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        ref_pos[want] = torch.arange(c, dtype=torch.int32, device=dev)
+        assert torch.equal(pos, ref_pos)
+        src = torch.rand(pad, 4, device=dev)
+        full = ops.expand_rows(src, pos, -1e5)
+        ref = torch.zeros(n, 4, device=dev)
+        ref[:, 3] = -1e5
+        ref[want] = src[:c]
+        assert torch.equal(full, ref)
+        assert torch.equal(ops.expand_rows(src[:, 0].contiguous(), pos, -1e5), ref[:, 3].where(pos < 0, src[:, 0][pos.clamp(min=0).long()]))

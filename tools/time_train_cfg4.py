@@ -37,12 +37,17 @@ def one(count=False):
         if count:
             with profile(activities=[ProfilerActivity.CUDA]) as prof:
                 out = fn(); torch.cuda.synchronize()
-            n = sum(e.count for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA)
+            evs = [e for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA]
+            n = sum(e.count for e in evs)
+            if os.environ.get("ANR_LAUNCH_NAMES"):
+                print(f"--- {name}: {n} launches")
+                for e in sorted(evs, key=lambda e: -e.count)[:40]:
+                    print(f"   {e.count:4d} x {e.key[:110]}  ({e.device_time_total / max(e.count, 1):.1f} us)")
         else:
             out = fn(); n = -1
         marks.append((name, 1e3 * (sync() - t0), n))
         return out
-    tr.optimizer.zero_grad(set_to_none=True)
+    tr.begin_step()
     pose = phase("table", lambda: table(frame_idx))
     phase("smpl", lambda: model.set_body_model(pose, templ))
     flat = phase("frame-prep", lambda: (model.convert_to_body_model_space(rays.view(F, 1024, 8)), model.clac_ober2cano_transform(), model.knn_index())[0])
