@@ -65,7 +65,7 @@ SIGNATURES = {
     "anr_frame_backward": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P]),
     "anr_to_root_frame": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "anr_rays_to_body": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "anr_ober2cano": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "anr_ober2cano": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _P]),
     "anr_knn_index_bytes": (_L, [_I]),
     "anr_knn_index_build": (_I, [_P, _P, _I, _I, _P, _P]),
     "anr_knn": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),

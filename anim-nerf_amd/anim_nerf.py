@@ -58,6 +58,10 @@ def _ober2cano_autograd(T, T_template, offset_delta):
     return small_matmul(T_template, M)
 
 
+def on_same_device(a, b):
+    return a is not None and b is not None and a.device == b.device
+
+
 class AnimNeRF(nn.Module):
     def __init__(self, model_path="smplx/models", model_type="smpl", gender="male", freqs_xyz=10, freqs_dir=4,
                  use_view=False, use_unpose=False, unpose_view=False, k_neigh=4, use_knn=False,
@@ -135,7 +139,8 @@ class AnimNeRF(nn.Module):
         self.pose_offsets = o["pose_offsets"]
         self.global_transform = o["joints_transform"][:, 0].clone()
         self._knn_index = None
-        if body_model_params_template is not None:
+        self._o2c_attached = None
+        if body_model_params_template is not None and not self._same_template(body_model_params_template):
             t = self.body_model(**body_model_params_template, return_verts=True)
             self.verts_template = t["vertices"]
             self.joints_template = t["joints"][:, :self.lbs_dim]
@@ -143,6 +148,20 @@ class AnimNeRF(nn.Module):
             self.joints_transform_template = t["joints_transform"]
             self.shape_offsets_template = t["shape_offsets"]
             self.pose_offsets_template = t["pose_offsets"]
+
+    def _same_template(self, template):
+        """The template pose is one dict for a whole run (datasets/anim_nerf_dataset.py hands the same tensors to every
+        step): its body state is computed once, not once per step.  The cache holds the tensors themselves (identity +
+        version counter), so a changed or replaced template is always recomputed."""
+        ref = getattr(self, "_template_ref", None)
+        tensors = [v for v in template.values() if torch.is_tensor(v)]
+        cacheable = all(v.is_cuda and not v.requires_grad for v in tensors)
+        same = (cacheable and ref is not None and on_same_device(getattr(self, "verts_template", None), self.body_model.v_template)
+                and ref.keys() == template.keys()
+                and all((v is ref[k][0] and v._version == ref[k][1]) if torch.is_tensor(v) else v == ref[k][0]
+                        for k, v in template.items()))
+        self._template_ref = {k: (v, v._version if torch.is_tensor(v) else None) for k, v in template.items()} if cacheable else None
+        return same
 
     def _pose_grad(self):
         """True when gradients must reach the SMPL parameters through the tensor-op forms (CPU, or parameters that do not
@@ -161,14 +180,19 @@ class AnimNeRF(nn.Module):
             self._chain_const_cache = c
         return dict(c, T_template=self.verts_transform_template.detach().contiguous())
 
-    def _attach_chain(self, value, kind, rays_world=None):
+    def _attach_chain(self, rays_body, rays_world, o2c):
+        """(rays_body, o2c) with the per-frame chain's backward attached (either may be None): ONE anr_frame_backward launch
+        serves both gradients."""
         from .autograd import FrameChainFunction
         p = self._refine
-        bs = value.shape[0]
-        dev = value.device
-        zero = lambda n: torch.zeros(bs, n, device=dev)
-        return FrameChainFunction.apply(p.get("betas", zero(10)), p.get("global_orient", zero(3)), p.get("body_pose", zero(69)),
-                                        p.get("transl", zero(3)), value, kind, self._chain_consts(), rays_world)
+        bs = (rays_body if rays_body is not None else o2c).shape[0]
+        dev = (rays_body if rays_body is not None else o2c).device
+        get = lambda k, n: p[k] if p.get(k) is not None else torch.zeros(bs, n, device=dev)
+        betas, go, bp, transl = get("betas", 10), get("global_orient", 3), get("body_pose", 69), get("transl", 3)
+        with torch.no_grad():                                   # the values the forward kernels consumed, packed once
+            packed = (betas.detach().expand(bs, -1).contiguous(), torch.cat([go.detach(), bp.detach()], 1),
+                      transl.detach().expand(bs, -1).contiguous())
+        return FrameChainFunction.apply(betas, go, bp, transl, rays_body, o2c, self._chain_consts(), rays_world, packed)
 
     def convert_to_body_model_space(self, rays):
         """rays[bs,R,>=8] -> rays in the root-joint frame; moves the cached body state too."""
@@ -179,7 +203,10 @@ class AnimNeRF(nn.Module):
             self._knn_index = None
             new_rays = ops.rays_to_body(g_inv, rays)
             if self._refine is not None:
-                new_rays = self._attach_chain(new_rays, 1, rays.detach())
+                # the chain's two consumed outputs leave through one autograd node: ober2cano is computed here already
+                o2c = self._ober2cano_values() if getattr(self, "verts_transform_template", None) is not None else None
+                new_rays, o2c = self._attach_chain(new_rays, rays.detach(), o2c)
+                self._o2c_attached = (self.verts_transform, o2c)
             return new_rays
         # tensor-op form: CPU, or gradients that must flow through torch autograd
         g_inv = _affine_inverse(self.global_transform) if self._pose_grad() else torch.inverse(self.global_transform)
@@ -205,11 +232,18 @@ class AnimNeRF(nn.Module):
                 self.verts_transform, self.verts_transform_template,
                 (self.shape_offsets_template - self.shape_offsets) + (self.pose_offsets_template - self.pose_offsets))
             return
-        self.ober2cano_transform = ops.ober2cano(
-            self.verts_transform, self.verts_transform_template, self.shape_offsets, self.shape_offsets_template,
-            self.pose_offsets, self.pose_offsets_template)
         if self._refine is not None:
-            self.ober2cano_transform = self._attach_chain(self.ober2cano_transform, 0)
+            hit = self._o2c_attached
+            if hit is not None and hit[0] is self.verts_transform and hit[1] is not None:
+                self.ober2cano_transform = hit[1]
+            else:
+                self.ober2cano_transform = self._attach_chain(None, None, self._ober2cano_values())[1]
+            return
+        self.ober2cano_transform = self._ober2cano_values()
+
+    def _ober2cano_values(self):
+        return ops.ober2cano(self.verts_transform, self.verts_transform_template, self.shape_offsets,
+                             self.shape_offsets_template, self.pose_offsets, self.pose_offsets_template)
 
     # ------------------------------------------------------------------ per-point queries
     def _net(self, use_fine):

@@ -23,15 +23,33 @@ PARAM_KEYS = ([k for i in range(1, 9) for k in (f"xyz_encoding_{i}.0.weight", f"
 
 
 _PACKS = {}
+_GEN = {}                      # id(first parameter) -> [generation, a backward pass ran since the last forward]
+
+
+def weights_generation(first_param, backward: bool = False) -> int:
+    """Counts optimiser steps without trusting the parameters' version counters (torch's fused Adam updates in place
+    WITHOUT bumping them): the first forward pass after a backward pass starts a new generation, and every cached weight
+    pack — training, backward and inference (NeRF.weight_pack) — carries the generation it was built in."""
+    st = _GEN.setdefault(id(first_param), [0, False])
+    if backward:
+        st[1] = True
+    elif st[1]:
+        st[0] += 1
+        st[1] = False
+    if len(_GEN) > 256:
+        _GEN.clear()
+        _GEN[id(first_param)] = st
+    return st[0]
 
 
 def _cached_pack(params, mode_id, backward):
     """Fragment-ordered weight pack for the forward / activation-gradient kernels, rebuilt only when a parameter changed:
     one pack per network and optimiser step, not one per ray chunk.  Keyed by the parameter OBJECTS (weak references: a
-    new tensor that happens to reuse a freed one's address and version counter must not hit) and their version counters."""
+    new tensor that happens to reuse a freed one's address and version counter must not hit), their version counters and
+    the generation above."""
     import weakref
     key = (mode_id, backward, tuple(id(p) for p in params))
-    ver = tuple(p._version for p in params)
+    ver = (tuple(p._version for p in params), weights_generation(params[0], backward))
     hit = _PACKS.get(key)
     if hit is None or hit[0] != ver or any(r() is not p for r, p in zip(hit[2], params)):
         if len(_PACKS) > 64:
@@ -158,6 +176,7 @@ class MLPFunction(torch.autograd.Function):
         n, rows = pts.shape[0], ctx.rows
         dt = act.dtype                                              # fp32 (parity mode) or bf16 (mixed precision)
         want_pts = ctx.needs_input_grad[0]
+        weights_generation(params[0], backward=True)
         # (dL/d rgb x sigmoid', dL/d sigma where the sample is valid) on the compacted + padded rows
         g4 = ops.mlp_head_grad(g, index, None if ctx.sigma_only else out, pts, rows, ctx.sigma_only)
         d_enc = None
@@ -414,36 +433,36 @@ class WarpFunction(torch.autograd.Function):
 
 
 class FrameChainFunction(torch.autograd.Function):
-    """Attaches the per-frame chain's backward to a value the forward kernels already produced: `value` is ober2cano[bs,V,4,4]
-    (kind 0) or the rays in the body frame [bs,R,8] (kind 1), computed by anr_smpl_forward / anr_rays_to_body /
-    anr_ober2cano from the SMPL parameters; backward = anr_frame_backward (one launch, forward-mode tangents per
-    parameter, csrc/frame_bwd.hip) instead of torch autograd over ~480 tensor ops (smplx/lbs.py:152-251,
-    models/anim_nerf.py:128-151)."""
+    """Attaches the per-frame chain's backward to the two values of it the renderer consumes, both already produced by the
+    forward kernels (anr_smpl_forward / anr_to_root_frame / anr_rays_to_body / anr_ober2cano from the SMPL parameters):
+    the rays in the body frame [bs,R,8] and ober2cano[bs,V,4,4] (either may be None).  Backward = ONE anr_frame_backward
+    launch for both gradients (forward-mode tangents per parameter, csrc/frame_bwd.hip) instead of torch autograd over
+    ~480 tensor ops (smplx/lbs.py:152-251, models/anim_nerf.py:128-151).
+    packed = (betas[bs,10], pose[bs,72], transl[bs,3]): the parameter values as the kernels take them."""
 
     @staticmethod
-    def forward(ctx, betas, global_orient, body_pose, transl, value, kind, consts, rays_world):
-        ctx.kind, ctx.consts = kind, consts
-        ctx.save_for_backward(betas, global_orient, body_pose, transl, rays_world if rays_world is not None else value.new_empty(0))
-        return value.clone()
+    def forward(ctx, betas, global_orient, body_pose, transl, rays_body, o2c, consts, rays_world, packed):
+        ctx.consts = consts
+        ctx.shared = (betas.shape[0] != packed[0].shape[0], transl.shape[0] != packed[2].shape[0])
+        ctx.save_for_backward(*packed, rays_world if rays_world is not None else packed[0].new_empty(0))
+        return (None if rays_body is None else rays_body.detach(), None if o2c is None else o2c.detach())
 
     @staticmethod
     @torch.no_grad()
-    def backward(ctx, g):
-        betas, go, bp, transl, rays_world = ctx.saved_tensors
+    def backward(ctx, g_rays, g_o2c):
+        betas, pose, transl, rays_world = ctx.saved_tensors
+        if g_rays is None and g_o2c is None:
+            return (None,) * 9
         c = ctx.consts
-        bs = go.shape[0]
-        pose = torch.cat([go, bp], 1).contiguous()
-        grads = ops.frame_backward(betas.expand(bs, -1).contiguous(), pose, transl.expand(bs, -1).contiguous(), c["J0"], c["JS"],
-                                   c["parents"], c["lbs_weights"], c["shapedirs"], c["posedirs"], c["T_template"],
-                                   rays_world=rays_world if ctx.kind == 1 else None,
-                                   d_o2c=g.contiguous() if ctx.kind == 0 else None,
-                                   d_rays=g[..., :8].contiguous() if ctx.kind == 1 else None)
+        grads = ops.frame_backward(betas, pose, transl, c["J0"], c["JS"], c["parents"], c["lbs_weights"], c["shapedirs"],
+                                   c["posedirs"], c["T_template"], rays_world=rays_world if g_rays is not None else None,
+                                   d_o2c=g_o2c, d_rays=g_rays)
         d_betas = grads[:, :10]
-        if betas.shape[0] != bs:
+        if ctx.shared[0]:
             d_betas = d_betas.sum(0, keepdim=True)
         d_transl = grads[:, 82:85]
-        if transl.shape[0] != bs:
+        if ctx.shared[1]:
             d_transl = d_transl.sum(0, keepdim=True)
         need = ctx.needs_input_grad
         return (d_betas if need[0] else None, grads[:, 10:13] if need[1] else None, grads[:, 13:82] if need[2] else None,
-                d_transl if need[3] else None, None, None, None, None)
+                d_transl if need[3] else None, None, None, None, None, None)

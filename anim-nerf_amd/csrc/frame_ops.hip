@@ -142,12 +142,13 @@ __global__ void to_root_frame_kernel(const float* __restrict__ G, const float* _
 __global__ void ober2cano_kernel(const float* __restrict__ tp, const float* __restrict__ tt,
                                  const float* __restrict__ so, const float* __restrict__ sot,
                                  const float* __restrict__ po, const float* __restrict__ pot,
-                                 float* __restrict__ out, int64_t n) {
+                                 float* __restrict__ out, int64_t n, int64_t n_template) {
     int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
+    const int64_t vt = v % n_template;                       // one template for all frames, or one per frame
     float A[12], B[12];
     const float4* pa = reinterpret_cast<const float4*>(tp + v * 16);
-    const float4* pb = reinterpret_cast<const float4*>(tt + v * 16);
+    const float4* pb = reinterpret_cast<const float4*>(tt + vt * 16);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         float4 a = pa[r], b = pb[r];
@@ -173,8 +174,8 @@ __global__ void ober2cano_kernel(const float* __restrict__ tp, const float* __re
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         float t = -(I[r * 4 + 0] * A[3] + I[r * 4 + 1] * A[7] + I[r * 4 + 2] * A[11]);
-        t += sot[v * 3 + r] - so[v * 3 + r];
-        t += pot[v * 3 + r] - po[v * 3 + r];
+        t += sot[vt * 3 + r] - so[v * 3 + r];
+        t += pot[vt * 3 + r] - po[v * 3 + r];
         I[r * 4 + 3] = t;
     }
     float4* dst = reinterpret_cast<float4*>(out + v * 16);
@@ -294,14 +295,15 @@ extern "C" int anr_to_root_frame(const float* global_transform, const float* ver
 
 extern "C" int anr_ober2cano(const float* t_pose, const float* t_template, const float* shape_off,
                              const float* shape_off_t, const float* pose_off, const float* pose_off_t,
-                             float* out, int64_t n, void* stream) {
+                             float* out, int64_t n, int64_t n_template, void* stream) {
     ANR_REQUIRE(t_pose && t_template && shape_off && shape_off_t && pose_off && pose_off_t && out,
                 ANR_E_BADARG, "anr_ober2cano: null pointer");
-    ANR_REQUIRE(n > 0, ANR_E_BADARG, "anr_ober2cano: n=%lld", (long long)n);
+    ANR_REQUIRE(n > 0 && n_template > 0 && n % n_template == 0, ANR_E_BADARG, "anr_ober2cano: n=%lld n_template=%lld", (long long)n,
+                (long long)n_template);
     ANR_REQUIRE((((uintptr_t)t_pose | (uintptr_t)t_template | (uintptr_t)out) & 15) == 0, ANR_E_ALIGN,
                 "anr_ober2cano: matrices must be 16-B aligned");
     hipLaunchKernelGGL(ober2cano_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
-                       t_pose, t_template, shape_off, shape_off_t, pose_off, pose_off_t, out, n);
+                       t_pose, t_template, shape_off, shape_off_t, pose_off, pose_off_t, out, n, n_template);
     return check_launch("anr_ober2cano");
 }
 

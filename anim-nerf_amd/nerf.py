@@ -82,8 +82,10 @@ class NeRF(nn.Module):
             raise NotImplementedError(
                 "HIP MLP covers D=8, W=256, freqs_xyz=10, skips=[4], no normal input, no latent codes (configs/**/*.yaml)")
         mode_id = ops.MLP_MODES[mode or self.mlp_mode]
+        from .autograd import weights_generation
         params = {k: v for k, v in self.named_parameters()}
-        key = (mode_id, tuple((p.data_ptr(), p._version) for p in params.values()))
+        # (the generation: an optimiser step that does not bump the version counters — torch's fused Adam — still repacks)
+        key = (mode_id, weights_generation(params["xyz_encoding_1.0.weight"]), tuple((p.data_ptr(), p._version) for p in params.values()))
         hit = self._pack_cache.get(mode_id)
         if hit is None or hit[0] != key:
             if self.use_view:       # the kernel's own colour head is not used then: give it the 256 feature columns

@@ -153,18 +153,20 @@ def rays_to_body(g_inv: torch.Tensor, rays: torch.Tensor) -> torch.Tensor:
 
 
 def ober2cano(t_pose, t_template, shape_off, shape_off_t, pose_off, pose_off_t) -> torch.Tensor:
-    """models/anim_nerf.py:147-151.  [bs,V,4,4] x2, [bs,V,3] x4 -> [bs,V,4,4]."""
+    """models/anim_nerf.py:147-151.  t_pose[bs,V,4,4], shape_off / pose_off[bs,V,3]; the template's [bs or 1, V, ...] (one
+    template for all frames is read in place, not expanded) -> [bs,V,4,4]."""
     lib = _lib.load()
     t_pose = _dev(t_pose, "t_pose")
-    t_template = _dev(t_template, "t_template").expand_as(t_pose).contiguous()
+    t_template = _dev(t_template, "t_template")
     so, sot = _dev(shape_off, "shape_off"), _dev(shape_off_t, "shape_off_t")
     po, pot = _dev(pose_off, "pose_off"), _dev(pose_off_t, "pose_off_t")
-    sot = sot.expand_as(so).contiguous()
-    pot = pot.expand_as(po).contiguous()
+    tb = t_template.shape[0]
+    if tb not in (1, t_pose.shape[0]) or sot.shape[0] != tb or pot.shape[0] != tb:
+        raise ValueError("template batch must be 1 or the frames' batch")
     out = torch.empty_like(t_pose)
     n = t_pose.shape[0] * t_pose.shape[1]
     _lib.check(lib.anr_ober2cano(_ptr(t_pose), _ptr(t_template), _ptr(so), _ptr(sot), _ptr(po), _ptr(pot),
-                                 _ptr(out), n, _stream(out)), "anr_ober2cano")
+                                 _ptr(out), n, tb * t_pose.shape[1], _stream(out)), "anr_ober2cano")
     return out
 
 

@@ -296,7 +296,8 @@ class Trainer:
             if bp:
                 groups.append({"params": bp, "lr": hp.lr * 0.5})
         self.params = [p for g in groups for p in g["params"]]
-        self.optimizer = torch.optim.Adam(groups, eps=1e-8, weight_decay=0)
+        # (one fused update kernel per parameter group on the GPU instead of seven list kernels)
+        self.optimizer = torch.optim.Adam(groups, eps=1e-8, weight_decay=0, fused=bool(self.params and self.params[0].is_cuda))
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(
             self.optimizer, lambda epoch: (1 - epoch / hp.max_epochs) ** hp.poly_exp)
         # gradient buckets in the order backward completes them: fine network, coarse network, SMPL parameter rows

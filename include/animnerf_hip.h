@@ -101,11 +101,12 @@ int anr_to_root_frame(const float* global_transform, const float* verts, const f
  * models/anim_nerf.py:147-151 (clac_ober2cano_transform):
  *   M = inverse(T_pose); M[:3,3] += (shape_t - shape) + (pose_t - pose); out = T_template @ M.
  * Matrices are affine (last row 0 0 0 1): the inverse is the closed-form 3x3 adjugate.
- * t_pose, t_template, out: [n*16] row-major 4x4; offsets: [n*3] each. */
+ * t_pose, out: [n*16] row-major 4x4, shape_off / pose_off: [n*3]; the template's three arrays hold n_template entries
+ * (n_template = n: one template per frame; n_template = V: one template shared by all frames, n % n_template == 0). */
 int anr_ober2cano(const float* t_pose, const float* t_template,
                   const float* shape_off, const float* shape_off_t,
                   const float* pose_off, const float* pose_off_t,
-                  float* out, int64_t n, void* stream);
+                  float* out, int64_t n, int64_t n_template, void* stream);
 
 /* ---- a8: exact k=4 nearest SMPL vertices (replaces knn_cuda.KNN) ----------------------
  * models/anim_nerf.py:157-163.  The search is exact but spatially pruned, so it runs against a per-frame

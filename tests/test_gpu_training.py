@@ -237,6 +237,13 @@ def test_adam_steps_reduce_loss(dev, smpl_table):
     alp = torch.ones(1, 16, 16, 1, device=dev)
     losses = [tr.step(rays, tgt, alp, pose, _templ(dev), perturb=0.0)[0].item() for _ in range(25)]
     assert losses[-1] < 0.7 * losses[0], losses
+    # the optimiser (fused Adam: updates in place without bumping the tensors' version counters) must not leave a stale
+    # weight pack behind for inference either
+    with torch.no_grad():
+        pts = torch.cat([torch.rand(256, 3, device=dev) * 2 - 1, torch.ones(256, 1, device=dev)], -1)
+        cached = m.nerf.eval_points(pts)
+        m.nerf._pack_cache.clear()
+        assert torch.equal(cached, m.nerf.eval_points(pts))
 
 
 def test_bf16_training_gradients_close_to_fp32(dev, smpl_table):
