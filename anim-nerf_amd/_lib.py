@@ -107,6 +107,8 @@ SIGNATURES = {
     "anr_expand_rows": (_I, [_P, _P, _L, _I, _F, _P, _P]),
     "anr_mlp_head_grad": (_I, [_P, _P, _P, _P, _L, _L, _I, _P, _P]),
     "anr_tangent_quads": (_I, [_P, _L, _L, _P, _P]),
+    "anr_sample_coarse_backward": (_I, [_P, _P, _P, _L, _I, _P, _P]),
+    "anr_merge_backward": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "anr_train_loss_ws_floats": (_L, []),
     "anr_train_loss": (_I, [C.POINTER(AnrLossArgs), _P, _P, _P]),
     "anr_train_loss_backward": (_I, [C.POINTER(AnrLossArgs), _P, C.POINTER(AnrLossGrads), _P]),

@@ -380,6 +380,46 @@ class TrainLossFunction(torch.autograd.Function):
         return (None, None, None, *[grads.get(k) for k in TrainLossFunction.KEYS])
 
 
+class CoarseDepthFunction(torch.autograd.Function):
+    """z[bs,R,K] = sample_coarse(rays, steps, t_rand) (models/volume_rendering.py:29-56), differentiable w.r.t. near'/far'
+    (columns 6, 7 of the rays in the body frame: they move with the root transform under pose refinement)."""
+
+    @staticmethod
+    def forward(ctx, rays, steps, t_rand):
+        ctx.save_for_backward(steps, t_rand if t_rand is not None else steps.new_empty(0))
+        ctx.shape = rays.shape
+        return ops.sample_coarse(rays.detach(), steps, t_rand).view(*rays.shape[:-1], steps.numel())
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g):
+        steps, t_rand = ctx.saved_tensors
+        d = ops.sample_coarse_backward(g, steps, t_rand if t_rand.numel() else None)
+        if ctx.shape[-1] != 8:
+            full = d.new_zeros(*ctx.shape)
+            full.view(-1, ctx.shape[-1])[:, :8] = d
+            return full, None, None
+        return d.view(ctx.shape), None, None
+
+
+class FineMergeFunction(torch.autograd.Function):
+    """z_sorted[R,Kc+Kf] = sort(cat(z_coarse, inverse-CDF samples)) (models/volume_rendering.py:59-97,199-207); the fine
+    depths are detached in the reference, the coarse ones pass their gradient through the sort's permutation."""
+
+    @staticmethod
+    def forward(ctx, z_coarse, weights, u):
+        zs, perm = ops.sample_fine_merge(z_coarse.detach(), weights, u, want_perm=True)
+        ctx.save_for_backward(perm)
+        ctx.Kc = z_coarse.shape[-1]
+        return zs
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g):
+        (perm,) = ctx.saved_tensors
+        return ops.merge_backward(g, perm, ctx.Kc), None, None
+
+
 class CompositeFunction(torch.autograd.Function):
     """(weights, rgb, depth, acc) = composite(rgbs[R,K,4], z[R,K], rays[R,>=8]); differentiable w.r.t. rgbs."""
 

@@ -9,6 +9,7 @@
 //   anr_mlp_head_grad     upstream gradient of (rgb, sigma) -> the g[n][4] operand of anr_mlp_backward (sigmoid', validity,
 //                         gather to the compacted rows, zero padding rows)
 //   anr_tangent_quads     xyz[n][3] -> the quads of rows the tangent-mode MLP kernels take (ANR_MLP_FLAG_TANGENT)
+//   anr_sample_coarse_backward, anr_merge_backward   the depths' way back to near'/far' and through the sort (pose refinement)
 //   anr_train_loss        every loss term of train.py:228-309 and the weighted total in one launch
 //   anr_train_loss_backward  ... and its gradient w.r.t. every rendered / queried value in one launch
 #include "anr_common.h"
@@ -117,6 +118,40 @@ __global__ __launch_bounds__(256) void tangent_quads_kernel(const float* __restr
     if (i >= 4 * n_pad) return;
     const int64_t p = i >> 2;
     pts4[i] = p < n ? make_float4(xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2], 1.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// z_k = near' + (far' - near') e_k with e_k = the (jittered) step: d near' = sum g_k (1 - e_k), d far' = sum g_k e_k
+// (models/volume_rendering.py:29-56; pose refinement moves near'/far' with the root transform).  One thread per ray.
+__global__ __launch_bounds__(256) void sample_coarse_backward_kernel(const float* __restrict__ g, const float* __restrict__ steps,
+                                                                     const float* __restrict__ t_rand, int64_t R, int K,
+                                                                     float* __restrict__ d_rays) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float dn = 0.0f, df = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const float s = steps[k];
+        float e = s;
+        if (t_rand) {
+            const float lo = k > 0 ? 0.5f * (s + steps[k - 1]) : s, up = k + 1 < K ? 0.5f * (steps[k + 1] + s) : s;
+            e = lo + (up - lo) * t_rand[r * K + k];
+        }
+        const float gk = g[r * K + k];
+        dn += gk * (1.0f - e);
+        df += gk * e;
+    }
+    float4* o = reinterpret_cast<float4*>(d_rays + r * 8);
+    o[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    o[1] = make_float4(0.f, 0.f, dn, df);
+}
+
+// z_sorted[j] = cat(z_coarse, z_fine)[perm[j]], z_fine detached (models/volume_rendering.py:199-207): the gradient of the
+// sorted depths goes back to the coarse ones through the permutation.
+__global__ __launch_bounds__(256) void merge_backward_kernel(const float* __restrict__ g, const int32_t* __restrict__ perm, int64_t n, int K,
+                                                             int Kc, float* __restrict__ d_zc) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int p = perm[i];
+    if (p < Kc) d_zc[(i / K) * Kc + p] = g[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -343,4 +378,23 @@ extern "C" int anr_train_loss_backward(const anr_loss_args* a, const float* g_to
     ANR_REQUIRE((((uintptr_t)d->quads | (uintptr_t)d->quads_fine) & 15) == 0, ANR_E_ALIGN, "anr_train_loss_backward: quads must be 16-B aligned");
     hipLaunchKernelGGL(train_loss_backward_kernel, dim3(128), dim3(256), 0, (hipStream_t)stream, *a, g_total, *d);
     return check_launch("anr_train_loss_backward");
+}
+
+extern "C" int anr_sample_coarse_backward(const float* g_z, const float* steps, const float* t_rand, int64_t R, int K, float* d_rays_out,
+                                          void* stream) {
+    ANR_REQUIRE(g_z && steps && d_rays_out, ANR_E_BADARG, "anr_sample_coarse_backward: null pointer");
+    ANR_REQUIRE(R > 0 && K > 0, ANR_E_BADARG, "anr_sample_coarse_backward: R=%lld K=%d", (long long)R, K);
+    ANR_REQUIRE(((uintptr_t)d_rays_out & 15) == 0, ANR_E_ALIGN, "anr_sample_coarse_backward: d_rays_out must be 16-B aligned");
+    hipLaunchKernelGGL(sample_coarse_backward_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_z, steps,
+                       t_rand, R, K, d_rays_out);
+    return check_launch("anr_sample_coarse_backward");
+}
+
+extern "C" int anr_merge_backward(const float* g_sorted, const int32_t* perm, int64_t R, int K, int Kc, float* d_z_coarse_out, void* stream) {
+    ANR_REQUIRE(g_sorted && perm && d_z_coarse_out, ANR_E_BADARG, "anr_merge_backward: null pointer");
+    ANR_REQUIRE(R > 0 && Kc > 0 && K >= Kc, ANR_E_BADARG, "anr_merge_backward: R=%lld K=%d Kc=%d", (long long)R, K, Kc);
+    const int64_t n = R * K;
+    hipLaunchKernelGGL(merge_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_sorted, perm, n, K, Kc,
+                       d_z_coarse_out);
+    return check_launch("anr_merge_backward");
 }

@@ -734,6 +734,28 @@ def tangent_quads(xyz: torch.Tensor, n_pad: int) -> torch.Tensor:
     return pts4
 
 
+def sample_coarse_backward(g_z: torch.Tensor, steps: torch.Tensor, t_rand: Optional[torch.Tensor]) -> torch.Tensor:
+    """d_rays[R,8] (columns 6, 7 = d near', d far'; the rest zero) from dL/dz[R,K] of sample_coarse."""
+    lib = _lib.load()
+    g_z, steps = _dev(g_z, "g_z"), _dev(steps, "steps")
+    K = steps.numel()
+    R = g_z.numel() // K
+    d_rays = torch.empty(R, 8, dtype=torch.float32, device=g_z.device)
+    _lib.check(lib.anr_sample_coarse_backward(_ptr(g_z), _ptr(steps), _ptr(None if t_rand is None else _dev(t_rand, "t_rand")), R, K,
+                                              _ptr(d_rays), _stream(d_rays)), "anr_sample_coarse_backward")
+    return d_rays
+
+
+def merge_backward(g_sorted: torch.Tensor, perm: torch.Tensor, Kc: int) -> torch.Tensor:
+    """dL/dz_coarse[R,Kc] from dL/dz_sorted[R,K] and sample_fine_merge's permutation (int32)."""
+    lib = _lib.load()
+    g_sorted, perm = _dev(g_sorted, "g_sorted"), _dev(perm, "perm", torch.int32)
+    R, K = perm.shape
+    d = torch.empty(R, Kc, dtype=torch.float32, device=g_sorted.device)
+    _lib.check(lib.anr_merge_backward(_ptr(g_sorted), _ptr(perm), R, K, Kc, _ptr(d), _stream(d)), "anr_merge_backward")
+    return d
+
+
 _LOSS_WS = {}
 LOSS_NAMES = ("loss_rgb", "loss_rgb_fine", "loss_alphas", "loss_alphas_fine", "loss_foreground", "loss_background",
               "loss_foreground_fine", "loss_background_fine", "loss_normals", "loss_normals_fine")

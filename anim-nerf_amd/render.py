@@ -43,7 +43,7 @@ def render_prepared(volume_renderer, anim_nerf, rays, chunk=2048, perturb=0.0):
         part = volume_renderer(anim_nerf, rays[:, i:i + chunk], perturb=perturb)
         for k, v in part.items():
             pieces[k].append(v)
-    return {k: torch.cat(v, 1) for k, v in pieces.items()}
+    return {k: (v[0] if len(v) == 1 else torch.cat(v, 1)) for k, v in pieces.items()}
 
 
 def system_forward(volume_renderer, anim_nerf, rays, body_model_params, body_model_params_template,

@@ -43,8 +43,11 @@ class VolumeRenderer(nn.Module):
         t_rand = None
         if perturb > 0:
             t_rand = perturb * torch.rand(bs * R, self.n_coarse, device=rays.device)
+        if torch.is_grad_enabled() and rays.requires_grad and self.lindisp and rays.is_cuda:
+            from .autograd import CoarseDepthFunction           # pose refinement: near'/far' depend on the root transform
+            return CoarseDepthFunction.apply(rays, self._table(rays.device, "steps", self.n_coarse), t_rand)
         if (torch.is_grad_enabled() and rays.requires_grad) or not self.lindisp:
-            # pose refinement (near'/far' depend on the root transform), or the disparity branch (:45-46)
+            # the disparity branch (:45-46), or gradients on the CPU
             s = self._table(rays.device, "steps", self.n_coarse)
             if self.lindisp:
                 z = rays[..., 6:7] * (1 - s) + rays[..., 7:8] * s
@@ -112,10 +115,8 @@ class VolumeRenderer(nn.Module):
             u = torch.rand(bs * R, self.n_fine, device=z_coarse.device)
         if torch.is_grad_enabled() and z_coarse.requires_grad:
             # torch.sort routes gradients of the sorted depths back to z_coarse (z_fine is detached, :200)
-            zs, zf, perm = ops.sample_fine_merge(z_coarse.detach().view(bs * R, Kc), weights, u, want_fine=True,
-                                                 want_perm=True)
-            both = torch.cat([z_coarse.view(bs * R, Kc), zf], -1)
-            return torch.gather(both, -1, perm.long()).view(bs, R, Kc + self.n_fine)
+            from .autograd import FineMergeFunction
+            return FineMergeFunction.apply(z_coarse.view(bs * R, Kc), weights, u).view(bs, R, Kc + self.n_fine)
         with torch.no_grad():
             if lean_state is not None and "pts" in lean_state:       # the fine pass will copy the coarse samples' warps
                 zs, perm = ops.sample_fine_merge(z_coarse.detach().view(bs * R, Kc), weights, u, want_perm=True, perm_u8=True)

@@ -332,6 +332,16 @@ int anr_mlp_head_grad(const float* g_in, const int32_t* index, const float* out,
                       int64_t n_pad, int sigma_only, float* g_out, void* stream);
 int anr_tangent_quads(const float* xyz, int64_t n, int64_t n_pad, float* pts4_out, void* stream);
 
+/* Pose refinement moves near'/far' (models/anim_nerf.py:128-137), so the sampled depths carry a gradient to the rays:
+ * anr_sample_coarse_backward: d_rays_out[R*8] = (0,0,0, 0,0,0, d near', d far') from g_z[R*K] (steps, t_rand as handed to
+ *   anr_sample_coarse; models/volume_rendering.py:29-56);
+ * anr_merge_backward: d_z_coarse_out[R*Kc] from g_sorted[R*K] and the permutation anr_sample_fine_merge returned
+ *   (z_sorted[j] = cat(z_coarse, z_fine)[perm[j]]; z_fine is detached, models/volume_rendering.py:199-207). */
+int anr_sample_coarse_backward(const float* g_z, const float* steps, const float* t_rand, int64_t R, int K,
+                               float* d_rays_out, void* stream);
+int anr_merge_backward(const float* g_sorted, const int32_t* perm, int64_t R, int K, int Kc, float* d_z_coarse_out,
+                       void* stream);
+
 /* Every loss term of train.py:228-309 in one launch, and their gradients in another.  Pointers of terms that are not
  * wanted are NULL (fine pass, priors, normals).  All device fp32.
  *   rgb[R*3], acc[R] (+ _fine), target_rgb[R*3], target_alpha[R]: MSE and L1 (train.py:228-246);

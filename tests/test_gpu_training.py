@@ -491,3 +491,42 @@ def test_ordered_compaction_and_row_expansion(dev):
         ref[want] = src[:c]
         assert torch.equal(full, ref)
         assert torch.equal(ops.expand_rows(src[:, 0].contiguous(), pos, -1e5), ref[:, 3].where(pos < 0, src[:, 0][pos.clamp(min=0).long()]))
+
+
+def test_depth_sampling_backward_kernels(dev):
+    """CoarseDepthFunction / FineMergeFunction (anr_sample_coarse_backward, anr_merge_backward) against autograd over the
+    tensor-op forms of models/volume_rendering.py:29-56 and :199-207."""
+    from anim_nerf_amd import ops
+    from anim_nerf_amd.autograd import CoarseDepthFunction, FineMergeFunction
+    gen = torch.Generator().manual_seed(3)
+    R, Kc, Kf = 300, 64, 32
+    rays = torch.rand(1, R, 8, generator=gen)
+    rays[..., 6], rays[..., 7] = 1.0 + rays[..., 6], 3.0 + rays[..., 7]
+    steps = torch.linspace(0, 1 - 1.0 / Kc, Kc)
+    for jitter in (False, True):
+        t_rand = torch.rand(R, Kc, generator=gen) if jitter else None
+        a = rays.clone().requires_grad_(True)
+        z = a[..., 6:7] * (1 - steps) + a[..., 7:8] * steps
+        if jitter:
+            mids = .5 * (z[..., 1:] + z[..., :-1])
+            upper, lower = torch.cat([mids, z[..., -1:]], -1), torch.cat([z[..., :1], mids], -1)
+            z = lower + (upper - lower) * t_rand.view(1, R, Kc)
+        g = torch.randn(1, R, Kc, generator=gen)
+        (z * g).sum().backward()
+        b = rays.clone().to(dev).requires_grad_(True)
+        z2 = CoarseDepthFunction.apply(b, steps.to(dev), None if t_rand is None else t_rand.to(dev))
+        (z2 * g.to(dev)).sum().backward()
+        torch.testing.assert_close(z2.detach().cpu(), z.detach(), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(b.grad.cpu(), a.grad, rtol=1e-5, atol=1e-5)
+    zc = torch.sort(2 + 2 * torch.rand(R, Kc, generator=gen), -1).values
+    w = torch.rand(R, Kc, generator=gen)
+    u = torch.rand(R, Kf, generator=gen)
+    g = torch.randn(R, Kc + Kf, generator=gen).to(dev)
+    zs_ref, zf, perm = ops.sample_fine_merge(zc.to(dev), w.to(dev), u.to(dev), want_fine=True, want_perm=True)
+    a = zc.clone().to(dev).requires_grad_(True)
+    (torch.gather(torch.cat([a, zf], -1), -1, perm.long()) * g).sum().backward()
+    b = zc.clone().to(dev).requires_grad_(True)
+    zs = FineMergeFunction.apply(b, w.to(dev), u.to(dev))
+    (zs * g).sum().backward()
+    assert torch.equal(zs.detach(), zs_ref)
+    assert torch.equal(a.grad, b.grad)
