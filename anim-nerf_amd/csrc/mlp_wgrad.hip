@@ -222,7 +222,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
 
 // ---- the two skinny heads as weighted column sums (their M side is g, 4 fp32 columns):
 //   d sigma.weight[c] = sum_p g[p][3] h8[p][c]     d rgb.weight[j][c] = sum_p g[p][j] G[p][c]     biases: sum_p g[p][j]
-// One thread per output of a slice of rows, four rows in flight; slices are added by the reduction kernel.
+// One thread per output of a slice of rows, sixteen rows in flight; slices are added by the reduction kernel.
 constexpr int CS_COLS = 256 + 3 * 128 + 4;                  // sigma.weight | rgb.weight | rgb.bias (3), sigma.bias
 
 template <typename T>
@@ -237,16 +237,29 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
     if (c < 256) { j = 3; k = 1792 + c; }                    // h8
     else if (c < 640) { j = (c - 256) / 128; k = 2304 + (c - 256) % 128; }
     else { j = c - 640; k = -1; }
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    // (latency-bound: one column per thread walks its slice of rows with RIF independent loads in flight)
+    constexpr int RIF = 16;
+    float s[RIF];
+#pragma unroll
+    for (int q = 0; q < RIF; ++q) s[q] = 0.0f;
     if (!(sigma_only && j < 3)) {
         int64_t r = r0;
-        for (; r + 4 <= r1; r += 4) {
+        for (; r + RIF <= r1; r += RIF) {
+            float a[RIF], gv[RIF];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                s[q] += g4[(r + q) * 4 + j] * (k >= 0 ? (float)act[(r + q) * ACT_COLS + k] : (tangent && ((r + q) & 3)) ? 0.0f : 1.0f);
+            for (int q = 0; q < RIF; ++q) {
+                gv[q] = g4[(r + q) * 4 + j];
+                a[q] = k >= 0 ? (float)act[(r + q) * ACT_COLS + k] : (tangent && ((r + q) & 3)) ? 0.0f : 1.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < RIF; ++q) s[q] += gv[q] * a[q];
         }
         for (; r < r1; ++r) s[0] += g4[r * 4 + j] * (k >= 0 ? (float)act[r * ACT_COLS + k] : (tangent && (r & 3)) ? 0.0f : 1.0f);
     }
+#pragma unroll
+    for (int w = RIF / 2; w >= 4; w >>= 1)
+#pragma unroll
+        for (int q = 0; q < w; ++q) s[q] += s[q + w];
     partial[(int64_t)blockIdx.y * CS_COLS + c] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
