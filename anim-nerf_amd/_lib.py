@@ -96,6 +96,7 @@ SIGNATURES = {
     "anr_mlp_bwd_pack_bytes": (_L, [_I]),
     "anr_mlp_bwd_pack": (_I, [C.POINTER(AnrMlpParams), _I, _P, _P]),
     "anr_mlp_backward": (_I, [_P, _I, _P, _P, _P, _L, _P]),
+    "anr_mlp_backward_feature": (_I, [_P, _I, _P, _P, _P, _P, _L, _P]),
     "anr_grid_points": (_I, [_I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, _L, _L, _P, _P]),
     "anr_composite_masked": (_I, [_P, _P, _P, _I, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "anr_composite": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P]),

@@ -297,7 +297,7 @@ class AnimNeRF(nn.Module):
         """xyz[bs,nv,3] -> rgb[bs,nv,3], sigma[bs,nv,1]; sigma = -1e5 outside dis_threshold."""
         bs, nv = xyz.shape[:2]
         pts = self.warped_points(xyz=xyz)
-        if self.use_view:                       # view-dependent colour: the head runs outside the fused kernel (inference)
+        if self.use_view:                       # view-dependent colour: the head runs outside the fused kernels
             out = self._net(use_fine).eval_points_view(pts, viewdir).view(bs, nv, 4).clone()
             out[..., 3] = torch.where(pts[:, 3].view(bs, nv) < 1, torch.full_like(out[..., 3], -1e5), out[..., 3])
             return out[..., :3], out[..., 3:4]

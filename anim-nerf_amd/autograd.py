@@ -54,13 +54,59 @@ def _cached_pack(params, mode_id, backward):
     if hit is None or hit[0] != ver or any(r() is not p for r, p in zip(hit[2], params)):
         if len(_PACKS) > 64:
             _PACKS.clear()
-        hit = (ver, ops.mlp_pack(dict(zip(PARAM_KEYS, params)), mode_id, backward=backward), [weakref.ref(p) for p in params])
+        named = dict(zip(PARAM_KEYS, params))
+        if named["dir_encoding.0.weight"].shape[1] > 256:       # use_view: the kernels see the 256 feature columns only
+            named["dir_encoding.0.weight"] = named["dir_encoding.0.weight"][:, :256].contiguous()
+        hit = (ver, ops.mlp_pack(named, mode_id, backward=backward), [weakref.ref(p) for p in params])
         _PACKS[key] = hit
     return hit[1]
 
 
 PARAM_SHAPES = ([s for i in range(8) for s in ((256, 63 if i == 0 else 319 if i == 4 else 256), (256,))]
                 + [(1, 256), (1,), (256, 256), (256,), (128, 256), (128,), (3, 128), (3,)])
+
+
+class FeatureFunction(torch.autograd.Function):
+    """(sigma[n], feature[n,256]) = NeRF.get_sigma(xyz) (models/nerf.py:155-175) at pts[n,4] = (x, y, z, valid): trunk, sigma
+    and xyz_encoding_final in the fused kernels, differentiable w.r.t. their 20 tensors and the points.  What a
+    view-dependent colour head (use_view=True, models/nerf.py:141-153) is built on: it runs as framework ops on
+    [feature, encoding(viewdir)], and its gradient w.r.t. the feature re-enters the fused backward through
+    anr_mlp_backward_feature.  sigma = -1e5 where valid < 1."""
+
+    @staticmethod
+    def forward(ctx, pts, mode_id, *params):
+        pts = pts.detach()
+        n = pts.shape[0]
+        n_pad = max(-(-n // MLPFunction.PAD), 1) * MLPFunction.PAD
+        if n_pad != n:
+            padded = pts.new_zeros(n_pad, 4)
+            padded[:n] = pts
+            pts = padded
+        out, act = ops.mlp_forward_save(_cached_pack(params, mode_id, False), mode_id, pts)
+        ctx.mode_id, ctx.n = mode_id, n
+        ctx.save_for_backward(pts, act, *params)
+        return out[:n, 3].contiguous(), act[:n, 2048:2304].float()
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g_sigma, g_feat):
+        pts, act, *params = ctx.saved_tensors
+        n, n_pad = ctx.n, pts.shape[0]
+        weights_generation(params[0], backward=True)
+        g_sigma = g_sigma if g_sigma is not None else pts.new_zeros(n)
+        g4 = ops.mlp_head_grad(g_sigma, None, None, pts, n, True)                 # (0, 0, 0, d sigma where valid)
+        d_feat = pts.new_zeros(n_pad, 256)
+        if g_feat is not None:
+            d_feat[:n] = g_feat
+        dact = ops.mlp_backward_feature(_cached_pack(params, ctx.mode_id, True), ctx.mode_id, g4, d_feat, act)
+        flat = ops.mlp_wgrad(ctx.mode_id, act, dact, ops.encode64(pts, act.dtype), g4)
+        grads = _split_flat(flat, 20)                                             # the colour head is not this function's
+        d_pts = None
+        if ctx.needs_input_grad[0]:
+            d_enc = ops.mlp_denc(ctx.mode_id, dact, params[0], params[PARAM_KEYS.index("xyz_encoding_5.0.weight")])
+            d_pts = ops.encode_backward(pts, d_enc)[:n]
+        return (d_pts, None, *[grads[k].to(params[i].dtype) if (grads[k] is not None and ctx.needs_input_grad[2 + i]) else None
+                                for i, k in enumerate(PARAM_KEYS)])
 
 
 class GradSink:

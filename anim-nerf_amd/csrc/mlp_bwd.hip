@@ -31,15 +31,19 @@ __host__ __device__ constexpr int bcol(int t) {
 }
 __host__ __device__ constexpr bool bmasked(int t) { return !(t >= 4 && t < 12); }      // xyz_encoding_final has no ReLU
 
-template <int MODE, bool SIGMA_ONLY>
+// START: the first tile of the chain = where the upstream gradient enters: 0 (d rgb' and d sigma), 12 (FEATURE: d
+// xyz_encoding_final[256] and d sigma — the view-dependent colour head, use_view=True, lives outside the kernels and hands
+// over the gradient of its input), 20 (sigma only).
+template <int MODE, int START>
 struct MlpBwd {
+    static constexpr bool SIGMA_ONLY = START == 20, FEATURE = START == 12;
     using C = Cfg<MODE>;
     using Frag = typename C::Frag;
     static constexpr int NT = C::NT, EPF = C::EPF, HF = C::HF, DF = C::DF, WAVES = C::WAVES, TPC = C::TPC;
     static constexpr int THREADS = WAVES * 64;
     static constexpr int FPT = 16 / EPF;
     static constexpr int SLOT = TPC * HF * FRAG_BYTES;
-    static constexpr int FIRST = SIGMA_ONLY ? 20 : 0;
+    static constexpr int FIRST = START;
     static constexpr int LAST = BWD_TILES - 1;
     static constexpr int NCHUNK = (BWD_TILES - FIRST) / TPC;
     using ActT = std::conditional_t<C::IS_BF16, __bf16, float>;
@@ -223,7 +227,8 @@ struct MlpBwd {
     }
 
     __device__ __forceinline__ void run(const char* __restrict__ pack, const float4* __restrict__ g, const ActT* __restrict__ act,
-                                        ActT* __restrict__ dact, int64_t n_pts, char* lds, int tangent = 0) {
+                                        ActT* __restrict__ dact, int64_t n_pts, char* lds, int tangent = 0,
+                                        const float* __restrict__ dfeat = nullptr) {
         const int64_t n_tiles = (n_pts + WAVES * NT * 32 - 1) / (WAVES * NT * 32);
         if ((int64_t)blockIdx.x >= n_tiles) return;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -266,7 +271,39 @@ struct MlpBwd {
                 first = false;
             }
             Frag A[NT][HF], B[NT][HF];
-            if constexpr (!SIGMA_ONLY) {
+            if constexpr (FEATURE) {
+                // dF comes from outside (fp32 [n][256]): through the epilogue of the stage that would have produced it —
+                // conversion into the fragments of A, store into dact (the weight-gradient GEMM of xyz_encoding_final reads it
+                // there) — and zeros into the dact columns of the colour head this pass does not run
+                static_for<8>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int64_t idx = (pt * WAVES + wave) * (NT * 32) + n * 32 + (lane & 31);
+                        const float* src = dfeat + (idx < n_pts ? idx : n_pts - 1) * 256 + 32 * j + 4 * half;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(src + 8 * q);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[0][n][4 * q + i] = v[i];
+                        }
+                    }
+                    MaskEpi<HF, j * FPT, 4 + j> epi{acc[0], A, mk[0], dact_row};
+                    epi.template part<0>(); epi.template part<1>(); epi.template part<2>(); epi.template part<3>();
+                });
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    if (dact_row[n] != nullptr)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                if constexpr (C::IS_BF16) *reinterpret_cast<uint2*>(dact_row[n] + bcol(t) + 8 * q) = make_uint2(0u, 0u);
+                                else *reinterpret_cast<f32x4*>(dact_row[n] + bcol(t) + 8 * q) = f32x4{0.f, 0.f, 0.f, 0.f};
+                            }
+                layer<12, 8, HF, HF, HF>(A, B, NoEpi{}, dsig);                              // final^T: dF -> dh8' (B)
+                layer<20, 8, HF, HF, HF>(B, A, last_of<12, 8, HF>(B), dsig);                // W8^T   : dh8' -> dh7' (A)
+            } else if constexpr (!SIGMA_ONLY) {
                 // stage R input: d_rgb' (3 values) sits in slots 0..2 of fragment 0 of the lower half-wave
                 Frag X0[NT][4];
 #pragma unroll
@@ -318,21 +355,23 @@ struct MlpBwd {
     }
 };
 
-template <int MODE, bool SIGMA_ONLY>
+template <int MODE, int START>
 __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void mlp_bwd_kernel(
     const char* __restrict__ pack, const float4* __restrict__ g, const void* __restrict__ act, void* __restrict__ dact,
-    int64_t n_pts, int tangent) {
+    int64_t n_pts, int tangent, const float* __restrict__ dfeat) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    using M = MlpBwd<MODE, SIGMA_ONLY>;
+    using M = MlpBwd<MODE, START>;
     M m;
-    m.run(pack, g, reinterpret_cast<const typename M::ActT*>(act), reinterpret_cast<typename M::ActT*>(dact), n_pts, lds, tangent);
+    m.run(pack, g, reinterpret_cast<const typename M::ActT*>(act), reinterpret_cast<typename M::ActT*>(dact), n_pts, lds, tangent,
+          dfeat);
 }
 
-template <int MODE, bool SIGMA_ONLY>
-int launch_mlp_bwd(const void* pack, const float* g, const void* act, void* dact, int64_t n, hipStream_t st, int tangent = 0) {
+template <int MODE, int START>
+int launch_mlp_bwd(const void* pack, const float* g, const void* act, void* dact, int64_t n, hipStream_t st, int tangent = 0,
+                   const float* dfeat = nullptr) {
     using C = Cfg<MODE>;
-    const int lds = BWD_TABLE_BYTES + 3 * MlpBwd<MODE, SIGMA_ONLY>::SLOT;
-    auto kern = mlp_bwd_kernel<MODE, SIGMA_ONLY>;
+    const int lds = BWD_TABLE_BYTES + 3 * MlpBwd<MODE, START>::SLOT;
+    auto kern = mlp_bwd_kernel<MODE, START>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail((int)e, "anr_mlp_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
     const int pts_per_wg = C::WAVES * C::NT * 32;
@@ -341,7 +380,7 @@ int launch_mlp_bwd(const void* pack, const float* g, const void* act, void* dact
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     dim3 grid((unsigned)(n_tiles < cus ? n_tiles : cus));
     hipLaunchKernelGGL(kern, grid, dim3(C::WAVES * 64), lds, st, reinterpret_cast<const char*>(pack),
-                       reinterpret_cast<const float4*>(g), act, dact, n, tangent);
+                       reinterpret_cast<const float4*>(g), act, dact, n, tangent, dfeat);
     return check_launch("anr_mlp_backward");
 }
 
@@ -441,11 +480,26 @@ extern "C" int anr_mlp_backward(const void* bwd_pack, int mode, const float* g, 
     ANR_REQUIRE(!tan || (so && n % 4 == 0), ANR_E_BADARG, "anr_mlp_backward: tangent mode = sigma only, points in quads");
     switch (mode & 0xff) {
         case ANR_MLP_F32:
-            return so ? launch_mlp_bwd<ANR_MLP_F32, true>(bwd_pack, g, act, dact, n, st, tan)
-                      : launch_mlp_bwd<ANR_MLP_F32, false>(bwd_pack, g, act, dact, n, st);
+            return so ? launch_mlp_bwd<ANR_MLP_F32, 20>(bwd_pack, g, act, dact, n, st, tan)
+                      : launch_mlp_bwd<ANR_MLP_F32, 0>(bwd_pack, g, act, dact, n, st);
         case ANR_MLP_BF16:
-            return so ? launch_mlp_bwd<ANR_MLP_BF16_W8, true>(bwd_pack, g, act, dact, n, st, tan)
-                      : launch_mlp_bwd<ANR_MLP_BF16_W8, false>(bwd_pack, g, act, dact, n, st);
+            return so ? launch_mlp_bwd<ANR_MLP_BF16_W8, 20>(bwd_pack, g, act, dact, n, st, tan)
+                      : launch_mlp_bwd<ANR_MLP_BF16_W8, 0>(bwd_pack, g, act, dact, n, st);
         default: return fail(ANR_E_BADARG, "anr_mlp_backward: unknown mode %d", mode);
+    }
+}
+
+extern "C" int anr_mlp_backward_feature(const void* bwd_pack, int mode, const float* g, const float* d_feature, const void* act,
+                                        void* dact, int64_t n, void* stream) {
+    ANR_REQUIRE(bwd_pack && g && d_feature && act && dact, ANR_E_BADARG, "anr_mlp_backward_feature: null pointer");
+    ANR_REQUIRE(n > 0, ANR_E_BADARG, "anr_mlp_backward_feature: n=%lld", (long long)n);
+    ANR_REQUIRE((((uintptr_t)bwd_pack | (uintptr_t)g | (uintptr_t)d_feature | (uintptr_t)act | (uintptr_t)dact) & 15) == 0, ANR_E_ALIGN,
+                "anr_mlp_backward_feature: bwd_pack/g/d_feature/act/dact must be 16-B aligned");
+    ANR_REQUIRE(!(mode & (ANR_MLP_FLAG_SIGMA_ONLY | ANR_MLP_FLAG_TANGENT)), ANR_E_BADARG, "anr_mlp_backward_feature: no sigma-only / tangent mode");
+    hipStream_t st = (hipStream_t)stream;
+    switch (mode & 0xff) {
+        case ANR_MLP_F32:  return launch_mlp_bwd<ANR_MLP_F32, 12>(bwd_pack, g, act, dact, n, st, 0, d_feature);
+        case ANR_MLP_BF16: return launch_mlp_bwd<ANR_MLP_BF16_W8, 12>(bwd_pack, g, act, dact, n, st, 0, d_feature);
+        default: return fail(ANR_E_BADARG, "anr_mlp_backward_feature: unknown mode %d", mode);
     }
 }

@@ -95,19 +95,18 @@ class NeRF(nn.Module):
             self._pack_cache[mode_id] = hit
         return hit[1], mode_id
 
-    def _refuse_training(self, what):
-        """The view-dependent colour head and the (sigma, feature) query run outside the fused kernels WITHOUT a backward:
-        under autograd they would silently return constants, and an optimiser would train on whatever other loss term
-        still carries a gradient."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(f"{what} is inference-only (no backward is built): call it under torch.no_grad(); "
-                                      "training is built for use_view=False, the setting of every shipped config")
+    def _training(self, pts=None):
+        return torch.is_grad_enabled() and ((pts is not None and pts.requires_grad) or any(p.requires_grad for p in self.parameters()))
 
     def sigma_and_feature(self, pts: torch.Tensor, mode: Optional[str] = None, chunk: int = 1 << 20):
         """(sigma[n], xyz_encoding_final[n,256]) of NeRF.get_sigma (models/nerf.py:155-175) from the training-forward
-        kernel, which stores that feature among the saved activations.  Inference only; `chunk` bounds the 4.9 KB per
-        point of saved activations."""
-        self._refuse_training("get_sigma(only_sigma=False) / the use_view=True forward")
+        kernel, which stores that feature among the saved activations.  Under autograd: `autograd.FeatureFunction`
+        (differentiable w.r.t. the trunk / sigma / xyz_encoding_final tensors and the points; the feature's gradient
+        re-enters the fused backward kernel).  `chunk` bounds the 4.9 KB per point of saved activations in inference."""
+        if self._training(pts):
+            from .autograd import PARAM_KEYS, FeatureFunction
+            named = dict(self.named_parameters())
+            return FeatureFunction.apply(pts, ops.MLP_MODES[mode or self.mlp_mode] & 0xff, *[named[k] for k in PARAM_KEYS])
         with torch.no_grad():
             pack, mode_id = self.weight_pack(mode)
             sig, feat = [], []
@@ -119,10 +118,11 @@ class NeRF(nn.Module):
 
     def eval_points_view(self, pts: torch.Tensor, viewdir: torch.Tensor, mode: Optional[str] = None) -> torch.Tensor:
         """use_view=True (the class default of the reference, no shipped config): trunk, sigma and the 256-wide feature in
-        the fused kernel, the view-dependent colour head (models/nerf.py:141-153: [feature, encoding_dir(viewdir)] -> 128 ->
-        3) as two library GEMMs.  -> [n,4] = (r,g,b,sigma).  Inference only."""
-        sig, feat = self.sigma_and_feature(pts, mode)               # (refuses to run under autograd)
-        with torch.no_grad():
+        the fused kernels, the view-dependent colour head (models/nerf.py:141-153: [feature, encoding_dir(viewdir)] -> 128 ->
+        3) as two library GEMMs — under autograd too: the head is ordinary framework ops, its input gradient goes back
+        into the fused backward (sigma_and_feature).  -> [n,4] = (r,g,b,sigma)."""
+        sig, feat = self.sigma_and_feature(pts, mode)
+        with torch.set_grad_enabled(self._training(pts)):
             x = torch.cat([feat, self.encoding_dir(viewdir.reshape(-1, 3).float())], -1)
             rgb = self.rgb(self.dir_encoding(x))
             return torch.cat([rgb, sig[:, None]], -1)
@@ -132,8 +132,7 @@ class NeRF(nn.Module):
         """pts[n,4] = (x,y,z,valid) -> [n,4] = (r,g,b,sigma), or sigma[n] (trunk + sigma row only).  The fused kernel entry.
         only_valid: run the network on the samples with valid >= 1 only; the rest get (0,0,0,-1e5)."""
         if self.use_view:
-            raise NotImplementedError("use_view=True: call eval_points_view(pts, viewdir) (inference); training with view "
-                                      "dependence is not built")
+            raise NotImplementedError("use_view=True: the colour needs the view direction, call eval_points_view(pts, viewdir)")
         if torch.is_grad_enabled() and (pts.requires_grad or any(p.requires_grad for p in self.parameters())):
             from .autograd import PARAM_KEYS, MLPFunction              # training: keep activations, differentiable
             if not self._hip_supported():

@@ -454,6 +454,18 @@ def mlp_backward(bwd_pack: torch.Tensor, mode: int, g: torch.Tensor, act: torch.
     return dact
 
 
+def mlp_backward_feature(bwd_pack: torch.Tensor, mode: int, g: torch.Tensor, d_feature: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
+    """mlp_backward entered at xyz_encoding_final: g[n,4] (4th column = dL/d sigma), d_feature[n,256] fp32 -> dact."""
+    lib = _lib.load()
+    g, d_feature, act = _dev(g, "g"), _dev(d_feature, "d_feature"), _dev(act, "act", act.dtype)
+    n = act.shape[0]
+    dact = torch.empty_like(act)
+    with _timed("mlp_backward", n):
+        _lib.check(lib.anr_mlp_backward_feature(_ptr(bwd_pack), mode & 0xff, _ptr(g), _ptr(d_feature), _ptr(act), _ptr(dact), n,
+                                                _stream(dact)), "anr_mlp_backward_feature")
+    return dact
+
+
 def compact_valid(pts: torch.Tensor, fill: Optional[torch.Tensor] = None):
     """-> (index[n] int32, count[1] int32 on the device): positions of the samples with valid >= 1
     (`inside_inds`, models/anim_nerf.py:253).  fill[n,4] or fill[n]: rows of the other samples := (0,0,0,-1e5) / -1e5."""

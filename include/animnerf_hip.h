@@ -275,6 +275,13 @@ int64_t anr_mlp_bwd_pack_bytes(int mode);
 int anr_mlp_bwd_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream);
 int anr_mlp_backward(const void* bwd_pack, int mode, const float* g, const void* act, void* dact, int64_t n,
                      void* stream);
+/* ... entered at xyz_encoding_final instead of at the colour head: use_view=True (models/nerf.py:141-153) evaluates
+ * [feature, encoding(viewdir)] -> 128 -> 3 outside the kernels and hands over d_feature[n*256] (fp32) = dL/d
+ * xyz_encoding_final; g[n*4] carries dL/d sigma in its 4th column (columns 0..2 are ignored).  dact columns 0..2303 are
+ * written as by anr_mlp_backward (2048.. = d_feature in the activation dtype), 2304..2431 are zero-filled, so that
+ * anr_mlp_wgrad on the result gives the trunk, sigma and xyz_encoding_final gradients (and zeros for the colour head). */
+int anr_mlp_backward_feature(const void* bwd_pack, int mode, const float* g, const float* d_feature, const void* act,
+                             void* dact, int64_t n, void* stream);
 
 /* ---- a16 / f2: backward of the per-frame chain (pose refinement, optim_body_params) ------------------------------
  * dL/d(betas[10], global_orient[3], body_pose[69], transl[3]) per frame from dL/d ober2cano[bs*V*16] (may be NULL) and

@@ -530,3 +530,63 @@ def test_depth_sampling_backward_kernels(dev):
     (zs * g).sum().backward()
     assert torch.equal(zs.detach(), zs_ref)
     assert torch.equal(a.grad, b.grad)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_view_dependent_training_gradients_match_oracle(dev, smpl_table, mode):
+    """use_view=True (the reference's class default, models/nerf.py:141-153) under autograd: trunk / sigma / feature in the
+    fused kernels (autograd.FeatureFunction, anr_mlp_backward_feature), the colour head as framework ops.  Gradients of
+    a coarse + fine render loss w.r.t. every tensor of both networks against autograd of the oracle."""
+    import anim_nerf_amd as ana
+    g = golden("render_cfg3_warp_gain")
+    torch.manual_seed(5)
+    m = ana.AnimNeRF(body_model_table=smpl_table, freqs_dir=4, use_view=True, use_unpose=False, use_fine=True, mlp_mode=mode)
+    rays = torch.from_numpy(g["rays_world"])[:, :40]
+    R = rays.shape[1]
+    with torch.no_grad():                                        # sigma of both networks straddles 0 along these rays
+        z = rays[0, :, 6:7] + (rays[0, :, 7:8] - rays[0, :, 6:7]) * torch.linspace(0, 1, 16)
+        probe = (rays[0, :, None, :3] + z[..., None] * rays[0, :, None, 3:6]).reshape(1, -1, 3)
+        for net in (m.nerf, m.nerf_fine):
+            net.sigma.weight.mul_(300.0)
+            net.sigma.bias.mul_(300.0)
+            net.sigma.bias.sub_(orc.mlp_sigma_and_feature(net_params(net), probe)[0].median())
+    Pc = {k: v.clone().requires_grad_(True) for k, v in net_params(m.nerf).items()}
+    Pf = {k: v.clone().requires_grad_(True) for k, v in net_params(m.nerf_fine).items()}
+    m = m.to(dev)
+    gen = torch.Generator().manual_seed(8)
+    tgt = torch.rand(1, R, 3, generator=gen)
+
+    def field(xyz, use_fine):
+        K = xyz.shape[1] // R
+        vd = rays[..., None, 3:6].expand(-1, -1, K, -1).reshape(1, -1, 3)
+        return orc.mlp_forward(Pf if use_fine else Pc, xyz, vd, use_view=True)
+    ref = orc.render_rays(field, rays, 16, 8)
+    F = torch.nn.functional
+    (F.mse_loss(ref["rgbs"], tgt) + F.mse_loss(ref["rgbs_fine"], tgt) + 0.1 * ref["alphas_fine"].mean()).backward()
+    out = ana.VolumeRenderer(n_coarse=16, n_fine=8)(m, rays.to(dev))
+    (F.mse_loss(out["rgbs"], tgt.to(dev)) + F.mse_loss(out["rgbs_fine"], tgt.to(dev)) + 0.1 * out["alphas_fine"].mean()).backward()
+    assert out["alphas_fine"].max() > 0.5
+    # bf16 activations under a sigma gain of 300 (opacities flip on rounding): the direction is kept (cos > 0.95), digits not
+    tol = 5e-3 if mode == "f32" else 0.3
+    for net, P in ((m.nerf, Pc), (m.nerf_fine, Pf)):
+        num = den = 0.0
+        for k, p in net.named_parameters():
+            assert p.grad is not None and P[k].grad is not None, k
+            num += (p.grad.cpu() - P[k].grad).pow(2).sum().item()
+            den += P[k].grad.pow(2).sum().item()
+            if mode == "f32":
+                scale = P[k].grad.abs().max().item()
+                assert (p.grad.cpu() - P[k].grad).abs().max().item() <= 2e-2 * scale + 1e-9, k
+        assert den > 0 and (num / den) ** 0.5 < tol, (num / den) ** 0.5
+    # the sigma-only query of a view-dependent network trains too (priors: train.py:262-286)
+    m.zero_grad(set_to_none=True)
+    pts = torch.rand(1, 100, 3, generator=gen) * 0.4 - 0.2
+    s = m.query_canonical_space(pts.to(dev), use_fine=False, only_sigma=True)
+    torch.exp(-0.1 * torch.relu(s)).mean().backward()
+    for P in (Pc,):
+        for v in P.values():
+            v.grad = None
+        torch.exp(-0.1 * torch.relu(orc.mlp_sigma_and_feature(P, pts)[0])).mean().backward()
+    a, b = m.nerf.xyz_encoding_3[0].weight.grad.cpu(), Pc["xyz_encoding_3.0.weight"].grad
+    assert (a - b).norm() / b.norm() < tol
+    assert m.nerf.rgb[0].weight.grad is None
