@@ -79,9 +79,6 @@ class AnimNeRF(nn.Module):
         if use_deformation:
             raise NotImplementedError("use_deformation is False in every shipped config and broken in the reference "
                                       "(models/nerf.py:54)")
-        if unpose_view:
-            raise NotImplementedError("unpose_view=True (view directions rotated into the canonical frame, "
-                                      "models/anim_nerf.py:188-190) is False in every shipped config and not built")
         if k_neigh != 4:
             raise NotImplementedError("the HIP warp kernel is built for k_neigh = 4 (every shipped config)")
 
@@ -257,9 +254,22 @@ class AnimNeRF(nn.Module):
         return self._knn_index[1]
 
     def unpose(self, xyz, viewdir=None):
-        """-> xyz_unposed[bs,N,3], viewdir, valid[bs,N,1]   (models/anim_nerf.py:180-192)."""
-        pts = ops.warp_points(self.knn_index(), self.ober2cano_transform, self.body_model.lbs_weights,
-                              self.dis_threshold, xyz=xyz)
+        """-> xyz_unposed[bs,N,3], viewdir, valid[bs,N,1]   (models/anim_nerf.py:180-192).  With use_view and unpose_view
+        the directions go through the sample's blended transform too — as POINTS (batch_transform's default pad_ones=True
+        at :188-190 adds the translation), exactly as the reference does."""
+        carry = self.use_view and self.unpose_view and viewdir is not None
+        res = ops.warp_points(self.knn_index(), self.ober2cano_transform.detach(), self.body_model.lbs_weights,
+                              self.dis_threshold, xyz=xyz, neighbours=carry)
+        if not carry:
+            return res[..., :3], viewdir, res[..., 3:4]
+        pts, nidx, nw = res
+        bs, V = self.ober2cano_transform.shape[:2]
+        with torch.no_grad():
+            # blended transform of every sample from the kernel's neighbour ids / weights: sum_k w_k ober2cano[id_k]
+            flat = self.ober2cano_transform.detach().reshape(bs * V, 16)
+            gid = (nidx.long() + (torch.arange(bs, device=nidx.device) * V)[:, None, None]).reshape(-1)
+            T = (flat[gid].view(bs, -1, 4, 16) * nw[..., None]).sum(2).view(bs, -1, 4, 4)
+            viewdir = batch_transform(T, viewdir.reshape(bs, -1, 3), pad_ones=True)
         return pts[..., :3], viewdir, pts[..., 3:4]
 
     def query_canonical_space(self, xyz, viewdir=None, use_fine=False, only_sigma=False, only_normal=False):
@@ -296,7 +306,11 @@ class AnimNeRF(nn.Module):
     def forward(self, xyz, viewdir=None, use_fine=False):
         """xyz[bs,nv,3] -> rgb[bs,nv,3], sigma[bs,nv,1]; sigma = -1e5 outside dis_threshold."""
         bs, nv = xyz.shape[:2]
-        pts = self.warped_points(xyz=xyz)
+        if self.use_view and self.unpose_view and self.use_unpose and viewdir is not None:
+            xyz_c, viewdir, valid = self.unpose(xyz, viewdir)
+            pts = torch.cat([xyz_c, valid], -1).view(-1, 4)
+        else:
+            pts = self.warped_points(xyz=xyz)
         if self.use_view:                       # view-dependent colour: the head runs outside the fused kernels
             out = self._net(use_fine).eval_points_view(pts, viewdir).view(bs, nv, 4).clone()
             out[..., 3] = torch.where(pts[:, 3].view(bs, nv) < 1, torch.full_like(out[..., 3], -1e5), out[..., 3])

@@ -249,7 +249,13 @@ def warp_to_canonical(xyz: Tensor, verts: Tensor, lbs_weights: Tensor, ober2cano
         dist, idx = knn_bruteforce(verts, xyz, k, chunk)
     db, Tb, _ = blend_neighbours(dist, idx, lbs_weights, ober2cano)
     valid = (db < dis_threshold).float()
-    return apply_affine(Tb, xyz, 1.0), valid, dict(dist=dist, idx=idx, blended=db)
+    return apply_affine(Tb, xyz, 1.0), valid, dict(dist=dist, idx=idx, blended=db, transform=Tb)
+
+
+def unpose_directions(viewdir: Tensor, blended_T: Tensor) -> Tensor:
+    """models/anim_nerf.py:188-190 (unpose_view): batch_transform(xyz_transform_inv, viewdir) — with batch_transform's
+    default pad_ones=True (:31-39), i.e. the direction is carried as a POINT (the translation is added)."""
+    return apply_affine(blended_T, viewdir, 1.0)
 
 
 # ---------------------------------------------------------------------------

@@ -226,3 +226,35 @@ def test_pre_embedded_twin_network():
         torch.testing.assert_close(sig, torch.from_numpy(g[f"{tag}_sigma_free"]), rtol=1e-5, atol=2e-6)
         so = orc.mlp_forward_embedded(P, e_xyz, only_sigma=True)
         torch.testing.assert_close(so, torch.from_numpy(g[f"{tag}_only_sigma"]), rtol=1e-5, atol=1e-6)
+
+
+def _unpose_view_model(smpl_table, g, device=None):
+    import anim_nerf_amd as ana
+    torch.manual_seed(int(g["seed"]))
+    m = ana.AnimNeRF(body_model_table=smpl_table, freqs_xyz=10, freqs_dir=4, use_view=True, use_unpose=True, unpose_view=True,
+                     use_fine=True, mlp_mode="f32").eval()
+    chk = float(sum(p.detach().double().abs().sum() for p in m.nerf.parameters()))
+    assert abs(chk - float(g["weights_abs_sum"])) <= 1e-9 * chk, "seeded weights differ from the reference's"
+    return m.to(device) if device is not None else m
+
+
+def test_unpose_view_matches_reference(smpl_table):
+    """use_view + unpose_view (models/anim_nerf.py:188-190): the view directions go through each sample's blended
+    transform as points (batch_transform's default pad_ones=True).  Oracle against the reference's unpose() and forward()."""
+    g = golden("unpose_view")
+    pose = {k: torch.from_numpy(v) for k, v in syn.animated_pose_params(seed=1, bs=2).items()}
+    tbl, st = _frame(smpl_table, pose)
+    st, _ = orc.to_root_frame(st, torch.from_numpy(g["rays_world"]))
+    st["ober2cano"] = orc.observation_to_canonical(st)
+    xyz, vd = torch.from_numpy(g["xyz"]), torch.from_numpy(g["viewdir"])
+    xyz_c, valid, dbg = orc.warp_to_canonical(xyz, st["verts"], tbl["lbs_weights"], st["ober2cano"], 0.2, chunk=1024)
+    vd_c = orc.unpose_directions(vd, dbg["transform"])
+    assert (valid.numpy() == g["valid"]).all()
+    torch.testing.assert_close(xyz_c, torch.from_numpy(g["xyz_c"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(vd_c, torch.from_numpy(g["viewdir_c"]), rtol=1e-4, atol=1e-5)
+    m = _unpose_view_model(smpl_table, g)
+    for tag, net in (("", m.nerf), ("_fine", m.nerf_fine)):
+        rgb, sigma = orc.mlp_forward(net_params(net), xyz_c, vd_c, use_view=True)
+        sigma = torch.where(valid < 1, torch.full_like(sigma, -1e5), sigma)
+        torch.testing.assert_close(rgb, torch.from_numpy(g["rgb" + tag]), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(sigma, torch.from_numpy(g["sigma" + tag]), rtol=1e-4, atol=1e-5)
