@@ -69,6 +69,7 @@ SIGNATURES = {
     "anr_knn_index_bytes": (_L, [_I]),
     "anr_knn_index_build": (_I, [_P, _P, _I, _I, _P, _P]),
     "anr_knn": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),
+    "anr_knn_k": (_I, [_P, _P, _I, _I, _I, _L, _I, _P, _P, _P]),
     "anr_sample_coarse": (_I, [_P, _I, _P, _P, _L, _I, _P, _P]),
     "anr_warp_ws_ints": (_L, [_I, _L]),
     "anr_warp_points_lean": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _L, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),

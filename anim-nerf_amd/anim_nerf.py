@@ -79,8 +79,8 @@ class AnimNeRF(nn.Module):
         if use_deformation:
             raise NotImplementedError("use_deformation is False in every shipped config and broken in the reference "
                                       "(models/nerf.py:54)")
-        if k_neigh != 4:
-            raise NotImplementedError("the HIP warp kernel is built for k_neigh = 4 (every shipped config)")
+        if not 1 <= k_neigh <= 8:
+            raise NotImplementedError("k_neigh = 1..8 (the shipped configs use 4)")
 
         # `body_model_table` (a dict / SyntheticSMPL in SMPL-pickle layout) replaces the licensed file
         if body_model_table is not None:
@@ -98,6 +98,10 @@ class AnimNeRF(nn.Module):
         # composites with weight exactly 0).  `query_inside=True` asks for the same at the forward() level, where it
         # also zeroes rgb of the other samples (models/anim_nerf.py:245-290).
         self.skip_invalid_samples = True
+        if k_neigh != 4:
+            # no shipped config: served by an exhaustive exact search (anr_knn_k) + the blend as tensor ops
+            # (`_warp_generic`), without the renderer's far-sample pruning
+            self.skip_far_samples = False
 
         mk = dict(freqs_xyz=freqs_xyz, freqs_dir=freqs_dir, use_view=use_view, deformation_dim=deformation_dim,
                   apperance_dim=apperance_dim, mlp_mode=mlp_mode)
@@ -253,11 +257,40 @@ class AnimNeRF(nn.Module):
             self._knn_index = (self.verts, ops.knn_index_build(self.verts.detach(), self.knn_order))
         return self._knn_index[1]
 
+    def _warp_generic(self, xyz, want_transform=False, chunk=1 << 19):
+        """models/anim_nerf.py:153-192 for k_neigh != 4: exact k-NN (anr_knn_k, distances carry no gradient — the KNN_CUDA
+        branch, :157-159), confidence + blend + transform as tensor ops (differentiable w.r.t. ober2cano and xyz).
+        xyz[bs,N,>=3] -> pts[bs,N,4] = (canonical xyz, valid) (+ the blended transforms [bs,N,4,4])."""
+        bs, V = self.ober2cano_transform.shape[:2]
+        lbs, flat = self.body_model.lbs_weights, self.ober2cano_transform.reshape(bs * V, 4, 4)
+        off = (torch.arange(bs, device=xyz.device) * V)[:, None, None]
+        pts, Ts = [], []
+        for s in range(0, xyz.shape[1], chunk):
+            x = xyz[:, s:s + chunk, :3]
+            with torch.no_grad():
+                dist, idx = ops.knn_k(self.verts.detach(), x.detach().contiguous(), self.k_neigh)
+                w_n = lbs[idx]
+                conf = torch.exp(-(w_n - w_n[..., 0:1, :]).abs().sum(-1) / (2.0 * self.weight_std ** 2))
+                w = torch.exp(-dist) * (conf > 0.9).float()
+                w = w / w.sum(-1, keepdim=True)
+                valid = ((w * dist).sum(-1, keepdim=True) < self.dis_threshold).float()
+            T = (w[..., None, None] * flat[idx + off]).sum(2)
+            pts.append(torch.cat([batch_transform(T, x), valid], -1))
+            if want_transform:
+                Ts.append(T)
+        pts = torch.cat(pts, 1)
+        return (pts, torch.cat(Ts, 1)) if want_transform else pts
+
     def unpose(self, xyz, viewdir=None):
         """-> xyz_unposed[bs,N,3], viewdir, valid[bs,N,1]   (models/anim_nerf.py:180-192).  With use_view and unpose_view
         the directions go through the sample's blended transform too — as POINTS (batch_transform's default pad_ones=True
         at :188-190 adds the translation), exactly as the reference does."""
         carry = self.use_view and self.unpose_view and viewdir is not None
+        if self.k_neigh != 4:
+            pts, T = self._warp_generic(xyz, want_transform=True)
+            if carry:
+                viewdir = batch_transform(T, viewdir.reshape(pts.shape[0], -1, 3), pad_ones=True)
+            return pts[..., :3], viewdir, pts[..., 3:4]
         res = ops.warp_points(self.knn_index(), self.ober2cano_transform.detach(), self.body_model.lbs_weights,
                               self.dis_threshold, xyz=xyz, neighbours=carry)
         if not carry:
@@ -284,6 +317,12 @@ class AnimNeRF(nn.Module):
         """pts[bs*N,4] = (canonical xyz, valid) for explicit points or for samples along rays.
         skip_far: provably-invalid samples (farther than dis_threshold from the body's bounding box) skip the
         neighbour search; only legal where sigma = -1e5 is all that is consumed (the renderer)."""
+        if self.use_unpose and self.k_neigh != 4:
+            if lean:
+                raise NotImplementedError("the lean renderer schedule is built for k_neigh = 4")
+            if xyz is None:
+                xyz = (rays[..., None, :3] + z[..., None] * rays[..., None, 3:6]).reshape(rays.shape[0], -1, 3)
+            return self._warp_generic(xyz).view(-1, 4)
         if self.use_unpose:
             far = skip_far and self.skip_far_samples
             if xyz is None and torch.is_grad_enabled() and (rays.requires_grad or z.requires_grad

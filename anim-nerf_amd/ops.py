@@ -216,6 +216,21 @@ def knn(verts: torch.Tensor, xyz: torch.Tensor, index: Optional[torch.Tensor] = 
     return dist, idx
 
 
+def knn_k(verts: torch.Tensor, xyz: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """knn_cuda.KNN(k, transpose_mode=True)(ref, query) for any k in 1..8 (exhaustive exact search; k = 4 has the pruned
+    search of `knn`).  verts[bs,V,3], xyz[bs,N,>=3] -> dist[bs,N,k] ascending, idx[bs,N,k] int64."""
+    lib = _lib.load()
+    verts, xyz = _dev(verts, "verts"), _dev(xyz, "xyz")
+    bs, V, _ = verts.shape
+    N = xyz.shape[1]
+    dist = torch.empty(bs, N, k, dtype=torch.float32, device=xyz.device)
+    idx = torch.empty(bs, N, k, dtype=torch.int64, device=xyz.device)
+    with _timed("knn_k", bs * N):
+        _lib.check(lib.anr_knn_k(_ptr(verts), _ptr(xyz), xyz.shape[2], bs, V, N, int(k), _ptr(dist), _ptr(idx), _stream(xyz)),
+                   "anr_knn_k")
+    return dist, idx
+
+
 def sample_coarse(rays: torch.Tensor, steps: torch.Tensor, t_rand: Optional[torch.Tensor] = None) -> torch.Tensor:
     """models/volume_rendering.py:29-56.  rays[..., >=8] (flattened to R) -> z[R,K]."""
     lib = _lib.load()

@@ -121,6 +121,12 @@ int anr_knn_index_build(const float* verts, const int32_t* order, int bs, int V,
 int anr_knn(const void* knn_index, const float* xyz, int bs, int V, int64_t N,
             float* dist_out, int64_t* idx_out, void* stream);
 
+/* ... and for k_neigh != 4 (a constructor argument of the reference, models/anim_nerf.py:42; every shipped config: 4): an
+ * exhaustive exact search, k = 1..8, V <= 13000.  verts[bs*V*3], xyz[bs*N*xyz_stride] (xyz first) ->
+ * dist[bs*N*k] (ascending; ties: lower vertex id first), idx[bs*N*k] int64. */
+int anr_knn_k(const float* verts, const float* xyz, int xyz_stride, int bs, int V, int64_t N, int k, float* dist_out,
+              int64_t* idx_out, void* stream);
+
 /* ---- a6+a7: coarse depths and sample points ------------------------------------------
  * models/volume_rendering.py:29-46 (lindisp=True branch) and :117:
  *   z[r,k] = near (1 - s[k]) + far s[k];  if t_rand != NULL the stratified jitter of

@@ -1054,3 +1054,51 @@ def test_unpose_view_matches_reference(dev, smpl_table):
             r_ref, s_ref = torch.from_numpy(g["rgb" + tag]), torch.from_numpy(g["sigma" + tag])
             assert ((rgb.cpu() - r_ref).abs().max(-1).values[ok] <= 1e-5 + RTOL).all()
             assert ((sigma.cpu() - s_ref).abs()[ok] <= 1e-5 + RTOL * s_ref.abs()[ok]).all()
+
+
+@pytest.mark.parametrize("k", [3, 6])
+def test_other_neighbour_counts_match_reference(dev, smpl_table, k):
+    """AnimNeRF(k_neigh=3 / 6): anr_knn_k (exhaustive exact search) + the blend as tensor ops against the reference's
+    unpose() / forward() (tests/golden/kneigh.npz), the kernel's neighbours against a brute-force top-k, and a render
+    through the general renderer branch against the oracle's."""
+    from anim_nerf_amd import ops, synthetic as syn
+    import anim_nerf_amd as ana
+    from test_oracle_golden import _kneigh_model
+    g = golden("kneigh")
+    m = _kneigh_model(smpl_table, g, k, dev)
+    pose = {kk: torch.from_numpy(v).to(dev) for kk, v in syn.animated_pose_params(seed=1, bs=2).items()}
+    xyz = torch.from_numpy(g["xyz"]).to(dev)
+    with torch.no_grad():
+        m.set_body_model(pose, _templ(dev))
+        rays_b = m.convert_to_body_model_space(torch.from_numpy(g["rays_world"]).to(dev))
+        m.clac_ober2cano_transform()
+        dist, idx = ops.knn_k(m.verts, xyz, k)
+        d_all = torch.norm(xyz[:, :, None] - m.verts[:, None], dim=-1)
+        d_ref, i_ref = d_all.topk(k, largest=False, dim=-1)
+        torch.testing.assert_close(dist, d_ref, rtol=1e-6, atol=1e-6)
+        assert ((idx == i_ref) | ((dist - d_ref).abs() <= 1e-6)).all() and (idx == i_ref).float().mean() > 0.999
+        xc, _, valid = m.unpose(xyz)
+        x_ref = torch.from_numpy(g[f"xyz_c_{k}"])
+        ok = (xc.cpu() - x_ref).abs().max(-1).values <= 1e-5 + RTOL * x_ref.abs().max(-1).values
+        assert ok.float().mean() > 0.998                      # confidence-threshold flips on fp32 rounding aside
+        assert (valid.cpu() == torch.from_numpy(g[f"valid_{k}"]))[ok].all()
+        rgb, sigma = m(xyz, None, use_fine=False)
+        s_ref = torch.from_numpy(g[f"sigma_{k}"])
+        assert ((rgb.cpu() - torch.from_numpy(g[f"rgb_{k}"])).abs().max(-1).values[ok] <= 1e-5 + RTOL).all()
+        assert ((sigma.cpu() - s_ref).abs()[ok] <= 2e-4 + RTOL * s_ref.abs()[ok]).all()
+        out = ana.VolumeRenderer(n_coarse=16, n_fine=8)(m, rays_b)
+    tbl = oracle_table(smpl_table)
+    st = orc.frame_state(tbl, {kk: v.cpu() for kk, v in pose.items()}, {kk: torch.from_numpy(v) for kk, v in syn.template_pose_params().items()})
+    st, rays_o = orc.to_root_frame(st, torch.from_numpy(g["rays_world"]))
+    st["ober2cano"] = orc.observation_to_canonical(st)
+    Pc, Pf = net_params(m.nerf), net_params(m.nerf_fine)
+
+    def field(p, use_fine):
+        xc, valid, _ = orc.warp_to_canonical(p, st["verts"], tbl["lbs_weights"], st["ober2cano"], 0.2, k=k, chunk=1024)
+        rgb, sig = orc.mlp_forward(Pf if use_fine else Pc, xc)
+        return rgb, torch.where(valid < 1, torch.full_like(sig, -1e5), sig)
+    ref = orc.render_rays(field, rays_o, 16, 8)
+    bad = 0
+    for key in ("rgbs", "alphas", "depths", "rgbs_fine", "alphas_fine", "depths_fine"):
+        bad = bad | ((out[key].cpu() - ref[key]).abs() > 1e-5 + 1e-3 * ref[key].abs()).any(-1)
+    assert bad.float().mean() <= 0.1, bad.float().mean()       # 16 rays per body: a flipped sample moves a whole ray
