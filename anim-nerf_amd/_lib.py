@@ -62,7 +62,9 @@ SIGNATURES = {
     "anr_last_error": (C.c_char_p, []),
     "anr_ray_gen": (_I, [_P, _P, _P, _I, _I, _F, _F, _P, _P]),
     "anr_smpl_forward": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "anr_frame_backward": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P]),
+    "anr_frame_backward": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "anr_frame_backward_ws_floats": (_L, [_I, _I]),
+    "anr_frame_backward_adjoint": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
     "anr_to_root_frame": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "anr_rays_to_body": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "anr_ober2cano": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _P]),

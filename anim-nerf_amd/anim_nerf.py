@@ -177,7 +177,10 @@ class AnimNeRF(nn.Module):
             with torch.no_grad():
                 c = dict(J0=(bm.J_regressor @ bm.v_template).contiguous(),
                          JS=torch.einsum("jv,vck->jck", bm.J_regressor, bm.shapedirs).contiguous(),
-                         parents=bm.parents, lbs_weights=bm.lbs_weights, shapedirs=bm.shapedirs, posedirs=bm.posedirs)
+                         parents=bm.parents, lbs_weights=bm.lbs_weights, shapedirs=bm.shapedirs, posedirs=bm.posedirs,
+                         # bit j: the vertex has a skinning weight on joint j (anr_frame_backward skips what a joint cannot move)
+                         vjmask=((bm.lbs_weights != 0).to(torch.int64) << torch.arange(bm.lbs_weights.shape[1], device=dev)).sum(1).to(torch.int32)
+                         if bm.lbs_weights.shape[1] <= 31 else None)
             self._chain_const_cache = c
         return dict(c, T_template=self.verts_transform_template.detach().contiguous())
 

@@ -542,7 +542,7 @@ class FrameChainFunction(torch.autograd.Function):
         c = ctx.consts
         grads = ops.frame_backward(betas, pose, transl, c["J0"], c["JS"], c["parents"], c["lbs_weights"], c["shapedirs"],
                                    c["posedirs"], c["T_template"], rays_world=rays_world if g_rays is not None else None,
-                                   d_o2c=g_o2c, d_rays=g_rays)
+                                   d_o2c=g_o2c, d_rays=g_rays, vertex_joint_mask=c.get("vjmask"))
         d_betas = grads[:, :10]
         if ctx.shared[0]:
             d_betas = d_betas.sum(0, keepdim=True)

@@ -66,24 +66,24 @@ __device__ __forceinline__ Aff inverse(const Aff& a) {
 constexpr int FB_J = 24, FB_NB = 10, FB_NP = FB_NB + 3 * FB_J + 3;     // 85 parameters per frame
 constexpr int FB_THREADS = 256;
 
-// grads[bs][85] = (betas 10 | global_orient 3 | body_pose 69 | transl 3)
-__global__ __launch_bounds__(FB_THREADS, 2) void frame_backward_kernel(
-    const float* __restrict__ betas, const float* __restrict__ pose, const float* __restrict__ transl,
-    const float* __restrict__ J0, const float* __restrict__ JS, const int64_t* __restrict__ parents,
-    const float* __restrict__ lbs_w, const float* __restrict__ shapedirs, const float* __restrict__ posedirs,
-    const float* __restrict__ T_templ, int64_t templ_stride, const float* __restrict__ rays_world, int ray_stride, int R,
-    const float* __restrict__ d_o2c, const float* __restrict__ d_rays, int V, float* __restrict__ grads) {
-    const int b = blockIdx.y, pi = blockIdx.x;
-    __shared__ float sA[FB_J][12][2];            // joint transforms relative to the rest pose (no transl): value, tangent
-    __shared__ float sG[12][2];                  // inverse of the root transform
-    __shared__ float sTr[3][2];                  // transl
-    __shared__ float sFeat[9];                   // tangent of the 9 pose-feature entries of the parameter's joint
-    __shared__ float sRed[FB_THREADS / 64];
-    const int pj = (pi >= FB_NB && pi < FB_NB + 3 * FB_J) ? (pi - FB_NB) / 3 : -1;      // joint of a pose parameter
+// The joint chain of one (frame, parameter) in LDS, value + tangent of parameter `pi` (pi < 0: values only): joint
+// transforms relative to the rest pose, the inverse of the root transform, transl, and the tangent of the pose feature of
+// the parameter's joint `pj`.  Called by every thread of the workgroup (it synchronises); blockDim.x >= 24.
+struct ChainLds {
+    float A[FB_J][12][2];            // joint transforms relative to the rest pose (no transl): value, tangent
+    float G[12][2];                  // inverse of the root transform
+    float Tr[3][2];                  // transl
+    float Feat[9];                   // tangent of the 9 pose-feature entries of the parameter's joint
+    float Rot[FB_J][9][2], Jr[FB_J][3][2], World[FB_J][12][2];
+    int desc;                        // bit j: joint j lies in the subtree of the parameter's joint
+};
 
+__device__ __forceinline__ void run_chain(ChainLds& L, int b, int pi, int pj, const float* __restrict__ betas,
+                                          const float* __restrict__ pose, const float* __restrict__ transl,
+                                          const float* __restrict__ J0, const float* __restrict__ JS,
+                                          const int64_t* __restrict__ parents) {
     // ---- the joint chain of this (frame, parameter), value + tangent, cooperatively and out of LDS (a single thread with
     // its 24 transforms in private memory spends milliseconds in scratch accesses)
-    __shared__ float sRot[FB_J][9][2], sJr[FB_J][3][2], sWorld[FB_J][12][2];
     auto seed = [&](int idx, float val) { return Dual(val, idx == pi ? 1.0f : 0.0f); };
     if (threadIdx.x < FB_J) {
         const int j = threadIdx.x;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void frame_backward_kernel(
             Dual s(J0[j * 3 + c]);
 #pragma unroll 1
             for (int k = 0; k < FB_NB; ++k) s = s + seed(k, betas[b * FB_NB + k]) * Dual(JS[(j * 3 + c) * FB_NB + k]);
-            sJr[j][c][0] = s.v; sJr[j][c][1] = s.d;
+            L.Jr[j][c][0] = s.v; L.Jr[j][c][1] = s.d;
         }
         // Rodrigues, angle = |rv + 1e-8| (smplx/lbs.py:316)
         Dual rv[3];
@@ -107,14 +107,24 @@ __global__ __launch_bounds__(FB_THREADS, 2) void frame_backward_kernel(
             for (int c = 0; c < 3; ++c) {
                 const Dual kk = K[r * 3 + 0] * K[0 * 3 + c] + K[r * 3 + 1] * K[1 * 3 + c] + K[r * 3 + 2] * K[2 * 3 + c];
                 const Dual m = Dual(r == c ? 1.0f : 0.0f) + sn * K[r * 3 + c] + c1 * kk;
-                sRot[j][r * 3 + c][0] = m.v; sRot[j][r * 3 + c][1] = m.d;
-                if (j == pj) sFeat[r * 3 + c] = m.d;              // pose feature = R - I: same tangent
+                L.Rot[j][r * 3 + c][0] = m.v; L.Rot[j][r * 3 + c][1] = m.d;
+                if (j == pj) L.Feat[r * 3 + c] = m.d;              // pose feature = R - I: same tangent
             }
     }
-    if (threadIdx.x < 9 && pj < 1) sFeat[threadIdx.x] = 0.0f;      // the root joint has no pose blend shapes
+    if (threadIdx.x < 9 && pj < 1) L.Feat[threadIdx.x] = 0.0f;      // the root joint has no pose blend shapes
+    if (threadIdx.x == 0) {
+        int m = 0;
+        if (pj >= 1)
+            for (int j = 0; j < FB_J; ++j) {
+                int k = j;
+                while (k > 0 && k != pj) k = (int)parents[k];
+                if (k == pj) m |= 1 << j;
+            }
+        L.desc = m;
+    }
     if (threadIdx.x < 3) {
         const Dual t = seed(FB_NB + 3 * FB_J + threadIdx.x, transl[b * 3 + threadIdx.x]);
-        sTr[threadIdx.x][0] = t.v; sTr[threadIdx.x][1] = t.d;
+        L.Tr[threadIdx.x][0] = t.v; L.Tr[threadIdx.x][1] = t.d;
     }
     __syncthreads();
     // world_j = world_parent . [R_j | J_j - J_parent], one element (r, c) per lane, joints in tree order
@@ -124,51 +134,92 @@ __global__ __launch_bounds__(FB_THREADS, 2) void frame_backward_kernel(
             const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
             const int par = (int)parents[j];
             auto local = [&](int k, int cc) {                     // element (k, cc) of joint j's local transform
-                if (cc < 3) return Dual(sRot[j][k * 3 + cc][0], sRot[j][k * 3 + cc][1]);
-                Dual t(sJr[j][k][0], sJr[j][k][1]);
-                if (j > 0) t = t - Dual(sJr[par][k][0], sJr[par][k][1]);
+                if (cc < 3) return Dual(L.Rot[j][k * 3 + cc][0], L.Rot[j][k * 3 + cc][1]);
+                Dual t(L.Jr[j][k][0], L.Jr[j][k][1]);
+                if (j > 0) t = t - Dual(L.Jr[par][k][0], L.Jr[par][k][1]);
                 return t;
             };
             Dual w;
             if (j == 0) {
                 w = local(r, c);
             } else {
-                w = Dual(sWorld[par][r * 4 + 0][0], sWorld[par][r * 4 + 0][1]) * local(0, c) +
-                    Dual(sWorld[par][r * 4 + 1][0], sWorld[par][r * 4 + 1][1]) * local(1, c) +
-                    Dual(sWorld[par][r * 4 + 2][0], sWorld[par][r * 4 + 2][1]) * local(2, c);
-                if (c == 3) w = w + Dual(sWorld[par][r * 4 + 3][0], sWorld[par][r * 4 + 3][1]);
+                w = Dual(L.World[par][r * 4 + 0][0], L.World[par][r * 4 + 0][1]) * local(0, c) +
+                    Dual(L.World[par][r * 4 + 1][0], L.World[par][r * 4 + 1][1]) * local(1, c) +
+                    Dual(L.World[par][r * 4 + 2][0], L.World[par][r * 4 + 2][1]) * local(2, c);
+                if (c == 3) w = w + Dual(L.World[par][r * 4 + 3][0], L.World[par][r * 4 + 3][1]);
             }
-            sWorld[j][threadIdx.x][0] = w.v; sWorld[j][threadIdx.x][1] = w.d;
+            L.World[j][threadIdx.x][0] = w.v; L.World[j][threadIdx.x][1] = w.d;
         }
         __syncthreads();
     }
     // relative to the rest pose: t -= R_world . J_rest
-    for (int i = threadIdx.x; i < FB_J * 12; i += FB_THREADS) {
+    for (int i = threadIdx.x; i < FB_J * 12; i += (int)blockDim.x) {
         const int j = i / 12, e = i % 12, r = e >> 2, c = e & 3;
-        Dual a(sWorld[j][e][0], sWorld[j][e][1]);
+        Dual a(L.World[j][e][0], L.World[j][e][1]);
         if (c == 3)
-            a = a - (Dual(sWorld[j][r * 4 + 0][0], sWorld[j][r * 4 + 0][1]) * Dual(sJr[j][0][0], sJr[j][0][1]) +
-                     Dual(sWorld[j][r * 4 + 1][0], sWorld[j][r * 4 + 1][1]) * Dual(sJr[j][1][0], sJr[j][1][1]) +
-                     Dual(sWorld[j][r * 4 + 2][0], sWorld[j][r * 4 + 2][1]) * Dual(sJr[j][2][0], sJr[j][2][1]));
-        sA[j][e][0] = a.v; sA[j][e][1] = a.d;
+            a = a - (Dual(L.World[j][r * 4 + 0][0], L.World[j][r * 4 + 0][1]) * Dual(L.Jr[j][0][0], L.Jr[j][0][1]) +
+                     Dual(L.World[j][r * 4 + 1][0], L.World[j][r * 4 + 1][1]) * Dual(L.Jr[j][1][0], L.Jr[j][1][1]) +
+                     Dual(L.World[j][r * 4 + 2][0], L.World[j][r * 4 + 2][1]) * Dual(L.Jr[j][2][0], L.Jr[j][2][1]));
+        L.A[j][e][0] = a.v; L.A[j][e][1] = a.d;
     }
     __syncthreads();
     if (threadIdx.x == 0) {                                        // global transform = A_0 + transl (body_models.py:373)
         Aff G;
-        for (int e = 0; e < 12; ++e) G.m[e] = Dual(sA[0][e][0], sA[0][e][1]);
-        for (int r = 0; r < 3; ++r) G.m[r * 4 + 3] = G.m[r * 4 + 3] + Dual(sTr[r][0], sTr[r][1]);
+        for (int e = 0; e < 12; ++e) G.m[e] = Dual(L.A[0][e][0], L.A[0][e][1]);
+        for (int r = 0; r < 3; ++r) G.m[r * 4 + 3] = G.m[r * 4 + 3] + Dual(L.Tr[r][0], L.Tr[r][1]);
         const Aff Gi0 = inverse(G);
-        for (int e = 0; e < 12; ++e) { sG[e][0] = Gi0.m[e].v; sG[e][1] = Gi0.m[e].d; }
+        for (int e = 0; e < 12; ++e) { L.G[e][0] = Gi0.m[e].v; L.G[e][1] = Gi0.m[e].d; }
     }
     __syncthreads();
 
+}
+
+// grads[bs][85] = (betas 10 | global_orient 3 | body_pose 69 | transl 3)
+__global__ __launch_bounds__(FB_THREADS, 2) void frame_backward_kernel(
+    const float* __restrict__ betas, const float* __restrict__ pose, const float* __restrict__ transl,
+    const float* __restrict__ J0, const float* __restrict__ JS, const int64_t* __restrict__ parents,
+    const float* __restrict__ lbs_w, const float* __restrict__ shapedirs, const float* __restrict__ posedirs,
+    const float* __restrict__ T_templ, int64_t templ_stride, const float* __restrict__ rays_world, int ray_stride, int R,
+    const float* __restrict__ d_o2c, const float* __restrict__ d_rays, int V, const int32_t* __restrict__ vjmask,
+    float* __restrict__ grads) {
+    const int b = blockIdx.y, pi = blockIdx.x;
+    __shared__ ChainLds L;
+    __shared__ float sRed[FB_THREADS / 64];
+    const int pj = (pi >= FB_NB && pi < FB_NB + 3 * FB_J) ? (pi - FB_NB) / 3 : -1;      // joint of a pose parameter
+
+    run_chain(L, b, pi, pj, betas, pose, transl, J0, JS, parents);
+
     Aff Gi;
 #pragma unroll
-    for (int e = 0; e < 12; ++e) Gi.m[e] = Dual(sG[e][0], sG[e][1]);
+    for (int e = 0; e < 12; ++e) Gi.m[e] = Dual(L.G[e][0], L.G[e][1]);
     float acc = 0.0f;
     // ---- every vertex: tangent of T_template . inverse(G^-1 . T_v) (+ offsets), dotted with dL/d ober2cano
+    // A body_pose parameter (joint pj >= 1) moves only the joints of its subtree: the root transform, the translation and
+    // every vertex without a skinning weight on that subtree have a zero tangent, and only the pose blend shape of the
+    // vertex is left of its term — 27 loads and a 3x3 product instead of the dual-number inverse.  Exact (the skipped
+    // tangents are exact zeros); vjmask[v] = bit mask of the joints vertex v has a non-zero weight on (may be NULL).
+    const int desc = L.desc;
+    const bool local = pj >= 1 && vjmask != nullptr;
 #pragma unroll 1
     for (int v = threadIdx.x; v < V; v += FB_THREADS) {
+        if (local && !(vjmask[v] & desc)) {
+            if (d_o2c == nullptr) break;
+            float dpo[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* pd = posedirs + (int64_t)(9 * (pj - 1)) * (3 * V) + 3 * v + c;
+                float s = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) s += L.Feat[e] * pd[(int64_t)e * 3 * V];
+                dpo[c] = s;
+            }
+            const float* Tt = T_templ + b * templ_stride + (int64_t)v * 16;
+            const float* g = d_o2c + ((int64_t)b * V + v) * 16;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                acc -= g[r * 4 + 3] * (Tt[r * 4 + 0] * dpo[0] + Tt[r * 4 + 1] * dpo[1] + Tt[r * 4 + 2] * dpo[2]);
+            continue;
+        }
         Aff T;
 #pragma unroll
         for (int e = 0; e < 12; ++e) T.m[e] = Dual(0.f);
@@ -178,11 +229,11 @@ __global__ __launch_bounds__(FB_THREADS, 2) void frame_backward_kernel(
             const float wj = w[j];
             if (wj != 0.0f) {
 #pragma unroll
-                for (int e = 0; e < 12; ++e) { T.m[e].v += wj * sA[j][e][0]; T.m[e].d += wj * sA[j][e][1]; }
+                for (int e = 0; e < 12; ++e) { T.m[e].v += wj * L.A[j][e][0]; T.m[e].d += wj * L.A[j][e][1]; }
             }
         }
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { T.m[r * 4 + 3].v += sTr[r][0]; T.m[r * 4 + 3].d += sTr[r][1]; }
+        for (int r = 0; r < 3; ++r) { T.m[r * 4 + 3].v += L.Tr[r][0]; T.m[r * 4 + 3].d += L.Tr[r][1]; }
         const Aff M = inverse(compose(Gi, T));
         float dM[12];
 #pragma unroll
@@ -195,7 +246,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void frame_backward_kernel(
             if (pj >= 1) {
                 const float* pd = posedirs + (int64_t)(9 * (pj - 1)) * (3 * V) + 3 * v + c;
 #pragma unroll
-                for (int e = 0; e < 9; ++e) dpo += sFeat[e] * pd[(int64_t)e * 3 * V];
+                for (int e = 0; e < 9; ++e) dpo += L.Feat[e] * pd[(int64_t)e * 3 * V];
             }
             dM[c * 4 + 3] -= dso + dpo;
         }
@@ -211,7 +262,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void frame_backward_kernel(
             }
     }
     // ---- every ray: o' = G^-1 [o,1], d' = G^-1 [d,0], near' = max(near, |o'| - 1), far' = min(far, |o'| + 1)
-    if (d_rays != nullptr) {
+    if (d_rays != nullptr && pj < 1) {                             // (a body_pose parameter does not move the root frame)
 #pragma unroll 1
         for (int r = threadIdx.x; r < R; r += FB_THREADS) {
             const float* ry = rays_world + ((int64_t)b * R + r) * ray_stride;
@@ -241,6 +292,204 @@ __global__ __launch_bounds__(FB_THREADS, 2) void frame_backward_kernel(
     }
 }
 
+// =====================================================================================================================
+// The same gradient the other way round: reverse mode through the 6,890 per-vertex inverses (once per frame, not once per
+// parameter), forward mode only through the 24-joint chain.
+//   A  frame_adjoint_kernel: one workgroup per 256 vertices (or 256 rays) of a frame.  Per vertex: T = sum_j w_j A_j + transl,
+//      X = G^-1 T, M = X^-1 (+ offsets), out = T_template M; the upstream gradient of `out` is pulled back to
+//        g_off (3, the adjoint of the blend-shape offsets)   -> goff[b][v][3]
+//        g_T (12) -> g_A[j] += w_j g_T, g_transl += g_T[:,3]     g_Ginv (12)
+//      and, per ray, o' = G^-1 [o,1], d' = G^-1 [d,0], near'/far' = clamp(|o'| -+ 1) to g_Ginv.
+//      Accumulated per workgroup in LDS, then one atomic per value into acc[b][303] = (g_A 24x12 | g_Ginv 12 | g_transl 3).
+//   B  frame_offsets_kernel: H[b][f] = - sum_{v,c} goff[b][v][c] posedirs[f][3v+c] (f < 207: adjoint of the pose features),
+//      H[b][207+k] = - sum goff . shapedirs[.,.,k] (betas through the shape blend shapes).  Fixed-order block reductions.
+//   C  frame_params_kernel: one small workgroup per (frame, parameter): the chain above in forward mode (24 joints, nothing
+//      per vertex) and the dot of its tangents with acc and H.
+// ~0.1 GFLOP per 16-frame step instead of ~5; checked against the forward-mode kernel
+// (tests/test_gpu_training.py::test_frame_backward_adjoint_equals_forward_mode).
+constexpr int FA_ACC = FB_J * 12 + 12 + 3;
+constexpr int FA_H = 207 + FB_NB;
+
+__global__ __launch_bounds__(FB_THREADS) void frame_adjoint_kernel(
+    const float* __restrict__ betas, const float* __restrict__ pose, const float* __restrict__ transl,
+    const float* __restrict__ J0, const float* __restrict__ JS, const int64_t* __restrict__ parents,
+    const float* __restrict__ lbs_w, const float* __restrict__ T_templ, int64_t templ_stride,
+    const float* __restrict__ rays_world, int ray_stride, int R, const float* __restrict__ d_o2c,
+    const float* __restrict__ d_rays, int V, int n_vblocks, float* __restrict__ acc, float* __restrict__ goff) {
+    __shared__ ChainLds L;
+    __shared__ float sAcc[FA_ACC];
+    const int b = blockIdx.y;
+    run_chain(L, b, -1, -1, betas, pose, transl, J0, JS, parents);
+    for (int i = threadIdx.x; i < FA_ACC; i += FB_THREADS) sAcc[i] = 0.0f;
+    __syncthreads();
+    float Gi[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) Gi[e] = L.G[e][0];
+    float gG[12], gTr[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 12; ++e) gG[e] = 0.0f;
+    if ((int)blockIdx.x < n_vblocks) {
+        const int v = blockIdx.x * FB_THREADS + threadIdx.x;
+        if (v < V) {
+            float T[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = 0.0f;
+            const float* w = lbs_w + (int64_t)v * FB_J;
+#pragma unroll 1
+            for (int j = 0; j < FB_J; ++j) {
+                const float wj = w[j];
+                if (wj != 0.0f) {
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) T[e] += wj * L.A[j][e][0];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) T[r * 4 + 3] += L.Tr[r][0];
+            float X[12];                                                  // X = G^-1 . T
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    X[r * 4 + c] = Gi[r * 4 + 0] * T[c] + Gi[r * 4 + 1] * T[4 + c] + Gi[r * 4 + 2] * T[8 + c] + (c == 3 ? Gi[r * 4 + 3] : 0.0f);
+            // Y = inverse of the 3x3 block (adjugate / determinant)
+            float Y[9];
+            {
+                const float c00 = X[5] * X[10] - X[6] * X[9], c01 = X[6] * X[8] - X[4] * X[10], c02 = X[4] * X[9] - X[5] * X[8];
+                const float id = 1.0f / (X[0] * c00 + X[1] * c01 + X[2] * c02);
+                Y[0] = c00 * id; Y[1] = (X[2] * X[9] - X[1] * X[10]) * id; Y[2] = (X[1] * X[6] - X[2] * X[5]) * id;
+                Y[3] = c01 * id; Y[4] = (X[0] * X[10] - X[2] * X[8]) * id; Y[5] = (X[2] * X[4] - X[0] * X[6]) * id;
+                Y[6] = c02 * id; Y[7] = (X[1] * X[8] - X[0] * X[9]) * id; Y[8] = (X[0] * X[5] - X[1] * X[4]) * id;
+            }
+            const float* Tt = T_templ + b * templ_stride + (int64_t)v * 16;
+            const float* g = d_o2c + ((int64_t)b * V + v) * 16;
+            float gM[12];                                                 // gM[k][c] = sum_r Tt[r][k] g[r][c]
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gM[k * 4 + c] = Tt[k] * g[c] + Tt[4 + k] * g[4 + c] + Tt[8 + k] * g[8 + c];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) goff[((int64_t)b * V + v) * 3 + k] = gM[k * 4 + 3];
+            // M_R = Y, M_t = -Y X_t + off:  GR = gM_R - gM_t (x) X_t,  gX_t = -Y^T gM_t,  gX_R = -Y^T GR Y^T
+            float GR[9], gXt[3], P[9], gXR[9];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) GR[k * 3 + m] = gM[k * 4 + m] - gM[k * 4 + 3] * X[m * 4 + 3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) gXt[m] = -(Y[0 * 3 + m] * gM[3] + Y[1 * 3 + m] * gM[7] + Y[2 * 3 + m] * gM[11]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) P[k * 3 + n] = GR[k * 3 + 0] * Y[n * 3 + 0] + GR[k * 3 + 1] * Y[n * 3 + 1] + GR[k * 3 + 2] * Y[n * 3 + 2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) gXR[i * 3 + n] = -(Y[0 * 3 + i] * P[0 * 3 + n] + Y[1 * 3 + i] * P[1 * 3 + n] + Y[2 * 3 + i] * P[2 * 3 + n]);
+            // X_R = G_R T_R, X_t = G_R T_t + G_t
+            float gT[12];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gT[k * 4 + c] = Gi[0 * 4 + k] * gXR[0 * 3 + c] + Gi[1 * 4 + k] * gXR[1 * 3 + c] + Gi[2 * 4 + k] * gXR[2 * 3 + c];
+                gT[k * 4 + 3] = Gi[0 * 4 + k] * gXt[0] + Gi[1 * 4 + k] * gXt[1] + Gi[2 * 4 + k] * gXt[2];
+                gTr[k] = gT[k * 4 + 3];
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    gG[r * 4 + k] = gXR[r * 3 + 0] * T[k * 4 + 0] + gXR[r * 3 + 1] * T[k * 4 + 1] + gXR[r * 3 + 2] * T[k * 4 + 2] + gXt[r] * T[k * 4 + 3];
+                gG[r * 4 + 3] = gXt[r];
+            }
+#pragma unroll 1
+            for (int j = 0; j < FB_J; ++j) {
+                const float wj = w[j];
+                if (wj != 0.0f) {
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) atomicAdd(&sAcc[j * 12 + e], wj * gT[e]);
+                }
+            }
+        }
+    } else {
+        const int r = ((int)blockIdx.x - n_vblocks) * FB_THREADS + threadIdx.x;
+        if (r < R) {
+            const float* ry = rays_world + ((int64_t)b * R + r) * ray_stride;
+            const float* g = d_rays + ((int64_t)b * R + r) * 8;
+            float o[3], norm2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                o[i] = Gi[i * 4 + 0] * ry[0] + Gi[i * 4 + 1] * ry[1] + Gi[i * 4 + 2] * ry[2] + Gi[i * 4 + 3];
+                norm2 += o[i] * o[i];
+            }
+            const float dist = sqrtf(norm2);
+            // torch.max / torch.min pass the gradient to the larger / smaller argument
+            const float gd = ((dist - 1.0f > ry[6]) ? g[6] : 0.0f) + ((dist + 1.0f < ry[7]) ? g[7] : 0.0f);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float go = g[i] + gd * o[i] / dist;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) gG[i * 4 + k] = go * ry[k] + g[3 + i] * ry[3 + k];
+                gG[i * 4 + 3] = go;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+        const float sum = wave_sum(gG[e]);
+        if ((threadIdx.x & 63) == 0 && sum != 0.0f) atomicAdd(&sAcc[FB_J * 12 + e], sum);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float sum = wave_sum(gTr[c]);
+        if ((threadIdx.x & 63) == 0 && sum != 0.0f) atomicAdd(&sAcc[FB_J * 12 + 12 + c], sum);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < FA_ACC; i += FB_THREADS)
+        if (sAcc[i] != 0.0f) atomicAdd(&acc[(int64_t)b * FA_ACC + i], sAcc[i]);
+}
+
+__global__ __launch_bounds__(FB_THREADS) void frame_offsets_kernel(const float* __restrict__ goff, const float* __restrict__ shapedirs,
+                                                                   const float* __restrict__ posedirs, int V, float* __restrict__ H) {
+    __shared__ float sRed[FB_THREADS / 64];
+    const int b = blockIdx.y, f = blockIdx.x;
+    const float* gb = goff + (int64_t)b * V * 3;
+    float s = 0.0f;
+    if (f < 207) {
+        const float* pd = posedirs + (int64_t)f * 3 * V;
+        for (int i = threadIdx.x; i < 3 * V; i += FB_THREADS) s += gb[i] * pd[i];
+    } else {
+        const int k = f - 207;
+        for (int i = threadIdx.x; i < 3 * V; i += FB_THREADS) s += gb[i] * shapedirs[(int64_t)i * FB_NB + k];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) H[(int64_t)b * FA_H + f] = -((sRed[0] + sRed[1]) + (sRed[2] + sRed[3]));
+}
+
+__global__ __launch_bounds__(64) void frame_params_kernel(
+    const float* __restrict__ betas, const float* __restrict__ pose, const float* __restrict__ transl,
+    const float* __restrict__ J0, const float* __restrict__ JS, const int64_t* __restrict__ parents,
+    const float* __restrict__ acc, const float* __restrict__ H, float* __restrict__ grads) {
+    __shared__ ChainLds L;
+    const int b = blockIdx.y, pi = blockIdx.x;
+    const int pj = (pi >= FB_NB && pi < FB_NB + 3 * FB_J) ? (pi - FB_NB) / 3 : -1;
+    run_chain(L, b, pi, pj, betas, pose, transl, J0, JS, parents);
+    const float* a = acc + (int64_t)b * FA_ACC;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < FA_ACC; i += 64) {
+        const float t = i < FB_J * 12 ? L.A[i / 12][i % 12][1] : i < FB_J * 12 + 12 ? L.G[i - FB_J * 12][1] : L.Tr[i - FB_J * 12 - 12][1];
+        s += a[i] * t;
+    }
+    if (H != nullptr) {
+        const float* h = H + (int64_t)b * FA_H;
+        if (pj >= 1 && threadIdx.x < 9) s += h[9 * (pj - 1) + threadIdx.x] * L.Feat[threadIdx.x];
+        if (pi < FB_NB && threadIdx.x == 0) s += h[207 + pi];
+    }
+    s = wave_sum(s);
+    if (threadIdx.x == 0) grads[(int64_t)b * FB_NP + pi] = s;
+}
+
 }  // namespace anr
 
 using namespace anr;
@@ -249,7 +498,7 @@ extern "C" int anr_frame_backward(const float* betas, const float* pose, const f
                                   const float* JS, const int64_t* parents, const float* lbs_weights, const float* shapedirs,
                                   const float* posedirs, int V, const float* T_template, int template_bs,
                                   const float* rays_world, int ray_stride, int R, const float* d_ober2cano,
-                                  const float* d_rays_body, float* grads_out, void* stream) {
+                                  const float* d_rays_body, const int32_t* vertex_joint_mask, float* grads_out, void* stream) {
     ANR_REQUIRE(betas && pose && transl && J0 && JS && parents && lbs_weights && shapedirs && posedirs && T_template &&
                 (d_ober2cano || d_rays_body) && grads_out, ANR_E_BADARG, "anr_frame_backward: null pointer");
     ANR_REQUIRE(bs > 0 && V > 0 && (template_bs == 1 || template_bs == bs), ANR_E_BADARG, "anr_frame_backward: bs=%d V=%d template_bs=%d",
@@ -258,6 +507,37 @@ extern "C" int anr_frame_backward(const float* betas, const float* pose, const f
     hipLaunchKernelGGL(frame_backward_kernel, dim3(FB_NP, bs), dim3(FB_THREADS), 0, (hipStream_t)stream, betas, pose, transl,
                        J0, JS, parents, lbs_weights, shapedirs, posedirs, T_template,
                        template_bs == 1 ? (int64_t)0 : (int64_t)V * 16, rays_world, ray_stride, R, d_ober2cano, d_rays_body, V,
-                       grads_out);
+                       vertex_joint_mask, grads_out);
     return check_launch("anr_frame_backward");
+}
+
+extern "C" int64_t anr_frame_backward_ws_floats(int bs, int V) { return (int64_t)bs * (FA_ACC + FA_H + 3 * (int64_t)V); }
+
+extern "C" int anr_frame_backward_adjoint(const float* betas, const float* pose, const float* transl, int bs, const float* J0,
+                                          const float* JS, const int64_t* parents, const float* lbs_weights, const float* shapedirs,
+                                          const float* posedirs, int V, const float* T_template, int template_bs,
+                                          const float* rays_world, int ray_stride, int R, const float* d_ober2cano,
+                                          const float* d_rays_body, float* workspace, float* grads_out, void* stream) {
+    ANR_REQUIRE(betas && pose && transl && J0 && JS && parents && lbs_weights && shapedirs && posedirs && T_template &&
+                (d_ober2cano || d_rays_body) && workspace && grads_out, ANR_E_BADARG, "anr_frame_backward_adjoint: null pointer");
+    ANR_REQUIRE(bs > 0 && V > 0 && (template_bs == 1 || template_bs == bs), ANR_E_BADARG,
+                "anr_frame_backward_adjoint: bs=%d V=%d template_bs=%d", bs, V, template_bs);
+    ANR_REQUIRE(!d_rays_body || (rays_world && R > 0 && ray_stride >= 8), ANR_E_BADARG, "anr_frame_backward_adjoint: rays R=%d stride=%d", R,
+                ray_stride);
+    hipStream_t st = (hipStream_t)stream;
+    float* acc = workspace;
+    float* H = acc + (int64_t)bs * FA_ACC;
+    float* goff = H + (int64_t)bs * FA_H;
+    hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * (size_t)bs * FA_ACC, st);
+    if (e != hipSuccess) return fail((int)e, "anr_frame_backward_adjoint: hipMemsetAsync: %s", hipGetErrorString(e));
+    const int nvb = d_ober2cano ? (V + FB_THREADS - 1) / FB_THREADS : 0;
+    const int nrb = d_rays_body ? (R + FB_THREADS - 1) / FB_THREADS : 0;
+    hipLaunchKernelGGL(frame_adjoint_kernel, dim3(nvb + nrb, bs), dim3(FB_THREADS), 0, st, betas, pose, transl, J0, JS, parents,
+                       lbs_weights, T_template, template_bs == 1 ? (int64_t)0 : (int64_t)V * 16, rays_world, ray_stride, R, d_ober2cano,
+                       d_rays_body, V, nvb, acc, goff);
+    if (d_ober2cano)
+        hipLaunchKernelGGL(frame_offsets_kernel, dim3(FA_H, bs), dim3(FB_THREADS), 0, st, goff, shapedirs, posedirs, V, H);
+    hipLaunchKernelGGL(frame_params_kernel, dim3(FB_NP, bs), dim3(64), 0, st, betas, pose, transl, J0, JS, parents, acc,
+                       d_ober2cano ? H : (const float*)nullptr, grads_out);
+    return check_launch("anr_frame_backward_adjoint");
 }

@@ -104,9 +104,10 @@ def smpl_forward(betas, pose, transl, v_template, shapedirs, posedirs, J_regress
 
 
 def frame_backward(betas, pose, transl, J0, JS, parents, lbs_weights, shapedirs, posedirs, T_template, rays_world=None,
-                   d_o2c=None, d_rays=None) -> torch.Tensor:
+                   d_o2c=None, d_rays=None, vertex_joint_mask=None, forward_mode: bool = False) -> torch.Tensor:
     """dL/d(betas | global_orient | body_pose | transl)[bs,85] of the per-frame chain (SMPL/LBS, root frame, ober2cano) from
-    dL/d ober2cano[bs,V,4,4] and / or dL/d rays_body[bs,R,8]: one launch (csrc/frame_bwd.hip)."""
+    dL/d ober2cano[bs,V,4,4] and / or dL/d rays_body[bs,R,8] (csrc/frame_bwd.hip).  forward_mode=True: the one-launch
+    forward-mode kernel (one workgroup per frame and parameter), kept as the cross-check of the adjoint kernels."""
     lib = _lib.load()
     betas, pose, transl = _dev(betas, "betas"), _dev(pose, "pose"), _dev(transl, "transl")
     bs, V = pose.shape[0], lbs_weights.shape[0]
@@ -118,12 +119,23 @@ def frame_backward(betas, pose, transl, J0, JS, parents, lbs_weights, shapedirs,
     if d_o2c is not None:
         d_o2c = _dev(d_o2c, "d_o2c")
     grads = torch.empty(bs, 85, dtype=torch.float32, device=pose.device)
+    if not forward_mode:
+        # reverse mode through the per-vertex inverses, forward mode through the 24-joint chain (csrc/frame_bwd.hip)
+        ws = torch.empty(lib.anr_frame_backward_ws_floats(bs, V), dtype=torch.float32, device=pose.device)
+        with _timed("frame_backward", bs):
+            _lib.check(lib.anr_frame_backward_adjoint(
+                _ptr(betas), _ptr(pose), _ptr(transl), bs, _ptr(_dev(J0, "J0")), _ptr(_dev(JS, "JS")),
+                _ptr(_dev(parents, "parents", torch.int64)), _ptr(_dev(lbs_weights, "lbs_weights")), _ptr(_dev(shapedirs, "shapedirs")),
+                _ptr(_dev(posedirs, "posedirs")), V, _ptr(T_template), T_template.shape[0], _ptr(rays_world), rs, R, _ptr(d_o2c),
+                _ptr(d_rays), _ptr(ws), _ptr(grads), _stream(grads)), "anr_frame_backward_adjoint")
+        return grads
     with _timed("frame_backward", bs):
         _lib.check(lib.anr_frame_backward(_ptr(betas), _ptr(pose), _ptr(transl), bs, _ptr(_dev(J0, "J0")), _ptr(_dev(JS, "JS")),
                                           _ptr(_dev(parents, "parents", torch.int64)), _ptr(_dev(lbs_weights, "lbs_weights")),
                                           _ptr(_dev(shapedirs, "shapedirs")), _ptr(_dev(posedirs, "posedirs")), V,
                                           _ptr(T_template), T_template.shape[0], _ptr(rays_world), rs, R, _ptr(d_o2c),
-                                          _ptr(d_rays), _ptr(grads), _stream(grads)), "anr_frame_backward")
+                                          _ptr(d_rays), _ptr(None if vertex_joint_mask is None else _dev(vertex_joint_mask, "vertex_joint_mask", torch.int32)),
+                                          _ptr(grads), _stream(grads)), "anr_frame_backward")
     return grads
 
 

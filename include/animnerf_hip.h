@@ -297,12 +297,26 @@ int anr_mlp_backward_feature(const void* bwd_pack, int mode, const float* g, con
  * pose[bs*72] = (global_orient, body_pose); J0[24*3] = J_regressor . v_template, JS[24*3*10] = J_regressor . shapedirs
  * (constants of the body model); posedirs[207 * 3V] row-major, shapedirs[V*3*10], lbs_weights[V*24], parents[24] int64;
  * T_template[template_bs*V*16] = the template pose's per-vertex transforms (template_bs = 1: shared by all frames);
- * rays_world[bs*R*ray_stride] = the rays before convert_to_body_model_space.  grads_out[bs*85] in the order above. */
+ * rays_world[bs*R*ray_stride] = the rays before convert_to_body_model_space.  grads_out[bs*85] in the order above.
+ * vertex_joint_mask[V] (int32, may be NULL): bit j set where lbs_weights[v][j] != 0 — lets a body_pose parameter's
+ * workgroup skip the dual-number inverse of every vertex its joint's subtree does not move (exact: zero tangents). */
 int anr_frame_backward(const float* betas, const float* pose, const float* transl, int bs, const float* J0,
                        const float* JS, const int64_t* parents, const float* lbs_weights, const float* shapedirs,
                        const float* posedirs, int V, const float* T_template, int template_bs,
                        const float* rays_world, int ray_stride, int R, const float* d_ober2cano,
-                       const float* d_rays_body, float* grads_out, void* stream);
+                       const float* d_rays_body, const int32_t* vertex_joint_mask, float* grads_out, void* stream);
+
+/* The same gradients with the work the other way round (what the training step calls): reverse mode through the per-vertex
+ * inverses once per frame — g_A[24][12], g_Ginv[12], g_transl[3] and the adjoint of the blend-shape offsets —, the
+ * contraction of the latter with posedirs / shapedirs, and forward mode only through the 24-joint chain, dotted with those
+ * (three launches, ~50x fewer flops; atomics over the vertices, like anr_warp_backward).  anr_frame_backward above is kept
+ * as the cross-check.  workspace[anr_frame_backward_ws_floats(bs, V)] fp32. */
+int64_t anr_frame_backward_ws_floats(int bs, int V);
+int anr_frame_backward_adjoint(const float* betas, const float* pose, const float* transl, int bs, const float* J0,
+                               const float* JS, const int64_t* parents, const float* lbs_weights, const float* shapedirs,
+                               const float* posedirs, int V, const float* T_template, int template_bs,
+                               const float* rays_world, int ray_stride, int R, const float* d_ober2cano,
+                               const float* d_rays_body, float* workspace, float* grads_out, void* stream);
 
 /* ---- a16 (part): weight and bias gradients of the MLP -----------------------------------------------------------
  * What autograd computes for the 22 parameter tensors of models/nerf.py:60-127 once the activation gradients exist:

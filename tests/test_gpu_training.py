@@ -590,3 +590,62 @@ def test_view_dependent_training_gradients_match_oracle(dev, smpl_table, mode):
     a, b = m.nerf.xyz_encoding_3[0].weight.grad.cpu(), Pc["xyz_encoding_3.0.weight"].grad
     assert (a - b).norm() / b.norm() < tol
     assert m.nerf.rgb[0].weight.grad is None
+
+
+def test_frame_backward_subtree_skip_is_exact(dev, smpl_table):
+    """anr_frame_backward with the vertex-joint mask (a body_pose parameter's workgroup skips every vertex its joint's
+    subtree does not move) against the same launch without it: the skipped tangents are exact zeros."""
+    from anim_nerf_amd import ops, synthetic as syn
+    m = seeded_model(smpl_table, 3, True, device=dev)
+    bs, R = 3, 50
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=5, bs=bs).items()}
+    with torch.no_grad():
+        m.set_body_model(pose, _templ(dev))
+    c = m._chain_consts()
+    assert c["vjmask"] is not None and c["vjmask"].dtype == torch.int32
+    gen = torch.Generator().manual_seed(1)
+    d_o2c = torch.randn(bs, m.body_model.lbs_weights.shape[0], 4, 4, generator=gen).to(dev)
+    d_rays = torch.randn(bs, R, 8, generator=gen).to(dev)
+    rays_w = torch.randn(bs, R, 8, generator=gen).to(dev)
+    rays_w[..., 6], rays_w[..., 7] = 0.1, 10.0
+    args = (pose["betas"].expand(bs, -1).contiguous(), torch.cat([pose["global_orient"], pose["body_pose"]], 1).contiguous(),
+            pose["transl"].expand(bs, -1).contiguous(), c["J0"], c["JS"], c["parents"], c["lbs_weights"], c["shapedirs"],
+            c["posedirs"], c["T_template"])
+    for kw in (dict(d_o2c=d_o2c), dict(d_rays=d_rays, rays_world=rays_w), dict(d_o2c=d_o2c, d_rays=d_rays, rays_world=rays_w)):
+        plain = ops.frame_backward(*args, **kw)
+        fast = ops.frame_backward(*args, **kw, vertex_joint_mask=c["vjmask"])
+        scale = plain.abs().max().item()
+        assert (plain - fast).abs().max().item() <= 2e-6 * scale, kw.keys()
+        assert plain.abs().sum() > 0
+
+
+def test_frame_backward_adjoint_equals_forward_mode(dev, smpl_table):
+    """anr_frame_backward_adjoint (reverse mode through the per-vertex inverses, forward mode through the joint chain:
+    what the training step calls) against anr_frame_backward (everything in forward mode, one workgroup per parameter —
+    itself held to oracle autograd by test_pose_refinement_gradients_match_oracle): all 85 gradients of every frame."""
+    from anim_nerf_amd import ops, synthetic as syn
+    m = seeded_model(smpl_table, 3, True, device=dev)
+    bs, R = 4, 300
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=6, bs=bs).items()}
+    with torch.no_grad():
+        m.set_body_model(pose, _templ(dev))
+    c = m._chain_consts()
+    gen = torch.Generator().manual_seed(2)
+    d_o2c = torch.randn(bs, m.body_model.lbs_weights.shape[0], 4, 4, generator=gen).to(dev)
+    d_rays = torch.randn(bs, R, 8, generator=gen).to(dev)
+    rays_w = torch.randn(bs, R, 8, generator=gen).to(dev)
+    rays_w[..., 6], rays_w[..., 7] = 0.1 + 3 * torch.rand(bs, R, generator=gen).to(dev), 3.5 + 3 * torch.rand(bs, R, generator=gen).to(dev)
+    args = (pose["betas"].expand(bs, -1).contiguous(), torch.cat([pose["global_orient"], pose["body_pose"]], 1).contiguous(),
+            pose["transl"].expand(bs, -1).contiguous(), c["J0"], c["JS"], c["parents"], c["lbs_weights"], c["shapedirs"],
+            c["posedirs"], c["T_template"])
+    for kw in (dict(d_o2c=d_o2c), dict(d_rays=d_rays, rays_world=rays_w), dict(d_o2c=d_o2c, d_rays=d_rays, rays_world=rays_w)):
+        ref = ops.frame_backward(*args, **kw, forward_mode=True)
+        got = ops.frame_backward(*args, **kw)
+        whole = ref.abs().max().item()
+        for lo, hi, name in ((0, 10, "betas"), (10, 13, "global_orient"), (13, 82, "body_pose"), (82, 85, "transl")):
+            # (ober2cano does not depend on global_orient / transl — the root frame cancels them: those gradients are
+            # rounding noise of sums over 6,890 vertices in both kernels, hence the floor relative to the whole gradient)
+            scale = ref[:, lo:hi].abs().max().item()
+            err = (ref[:, lo:hi] - got[:, lo:hi]).abs().max().item()
+            assert err <= 2e-4 * scale + 2e-5 * whole, (tuple(kw), name, err, scale, whole)
+        assert whole > 0
