@@ -1,0 +1,74 @@
+"""Worker of tests/test_gpu_training.py::test_two_process_training_step_averages_gradients: two processes (gloo) on ONE
+GPU run Trainer.step on different batches; the gradients left in the flat buffers must be the average of the two
+batches' single-process gradients, and the parameters must be identical on both ranks afterwards."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import anim_nerf_amd as ana                                        # noqa: E402
+from anim_nerf_amd import synthetic as syn                          # noqa: E402
+from helpers import golden, seeded_model                            # noqa: E402
+
+
+def batch(rank, dev):
+    gen = torch.Generator().manual_seed(100 + rank)
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=3 + rank, bs=2).items()}
+    c2w, focal, cen = syn.pinhole_camera(8, 8)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), 8, 8, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(2, 1, 1, 1)
+    tgt = torch.rand(2, 8, 8, 3, generator=gen).to(dev)
+    alp = (torch.rand(2, 8, 8, 1, generator=gen) > 0.5).float().to(dev)
+    fg = (torch.rand(2, 64, 3, generator=gen) * 0.4 - 0.2).to(dev)
+    bg = (torch.rand(2, 64, 3, generator=gen) * 2 - 1).to(dev)
+    return pose, rays, tgt, alp, fg, bg
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    tbl = syn.make_smpl_table(0)
+    g = golden("render_cfg3_warp_gain")
+    templ = {k: torch.from_numpy(v).to(dev) for k, v in syn.template_pose_params().items()}
+    hp = ana.TrainHParams(n_samples=16, n_importance=8, chunk=64, lambda_normals=0.05, lr=1e-3)
+    vr = ana.VolumeRenderer(n_coarse=16, n_fine=8)
+
+    # single-process gradients of every rank's batch (plain autograd accumulation, no reducer, no sinks)
+    ref = None
+    for r in range(world):
+        m = seeded_model(tbl, g["seed"], True, g["gain"], g["shift"], device=dev)
+        pose, rays, tgt, alp, fg, bg = batch(r, dev)
+        torch.manual_seed(500 + r)
+        res = ana.system_forward(vr, m, rays, pose, templ, perturb=0.0, chunk=hp.chunk)
+        ana.compute_loss(m, hp, tgt, alp, res, fg, bg)[0].backward()
+        gr = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        ref = gr if ref is None else {k: ref[k] + gr[k] for k in ref}
+    ref = {k: v / world for k, v in ref.items()}
+
+    m = seeded_model(tbl, g["seed"], True, g["gain"], g["shift"], device=dev)
+    tr = ana.Trainer(m, vr, hp)
+    assert tr.reducer.active and m.nerf.grad_sink is not None and m.nerf_fine.grad_sink is not None
+    pose, rays, tgt, alp, fg, bg = batch(rank, dev)
+    torch.manual_seed(500 + rank)
+    tr.step(rays, tgt, alp, pose, templ, fg, bg, perturb=0.0)
+    for k, p in m.named_parameters():
+        if k in ref:
+            scale = ref[k].abs().max().item()
+            err = (p.grad - ref[k]).abs().max().item()
+            assert err <= 2e-5 * scale + 1e-12, (rank, k, err, scale)
+    flat = torch.cat([p.detach().reshape(-1) for p in tr.params]).cpu()
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert all(torch.equal(both[0], b) for b in both[1:]), "parameters differ between ranks after the step"
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank}: ok")
+
+
+if __name__ == "__main__":
+    main()

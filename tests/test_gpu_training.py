@@ -649,3 +649,17 @@ def test_frame_backward_adjoint_equals_forward_mode(dev, smpl_table):
             err = (ref[:, lo:hi] - got[:, lo:hi]).abs().max().item()
             assert err <= 2e-4 * scale + 2e-5 * whole, (tuple(kw), name, err, scale, whole)
         assert whole > 0
+
+
+def test_two_process_training_step_averages_gradients(dev):
+    """The N > 1 training path end to end on one GPU: two processes (gloo), Trainer.step on different batches — flat
+    gradient buffers as all-reduce buckets, completion reported per network by the sinks — must leave the average of
+    the two single-process gradients in .grad and identical parameters on both ranks (tests/ddp_worker.py)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29533", os.path.join(here, "ddp_worker.py")], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "rank 0: ok" in r.stdout and "rank 1: ok" in r.stdout
