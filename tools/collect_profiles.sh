@@ -22,4 +22,15 @@ for wl in cfg2 cfg3; do
   python3 tools/hbm_table.py $OUT/${wl}_fetch $OUT/${wl}_write $OUT/${wl}_trace >> $OUT/hbm_${wl}.txt
   cat $OUT/hbm_${wl}.txt
 done
-ls $OUT
+# the files the judge reads, named as in profiles/r02/
+DST=$ROOT/gpurun_out/profiles_r02
+mkdir -p $DST
+for wl in cfg2 cfg3 cfg4; do
+  cp $OUT/${wl}_trace/*/*kernel_stats.csv $DST/bench_${wl}_bf16_kernel_stats.csv
+  grep '^{' $OUT/${wl}_trace.json > $DST/bench_${wl}_bf16_under_rocprof.json
+done
+cp $OUT/hbm_cfg2.txt $OUT/hbm_cfg3.txt $DST/
+python3 tools/traffic_json.py $OUT ${ANR_COMMIT:-unknown} 4 > $DST/mlp_hbm_traffic.json
+python3 tools/time_train_cfg4.py 2>/dev/null | tail -3 > $DST/train_step_launches.txt
+python3 bench.py 2>/dev/null | grep '^{' > $DST/bench_default_line.json
+ls $DST
