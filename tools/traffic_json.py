@@ -34,7 +34,7 @@ for wl, key in (("cfg2", "bytes_per_point"), ("cfg3", "bytes_per_point_indexed")
     rd, wr = pmc(os.path.join(prof, wl + "_fetch"), "FETCH_SIZE"), pmc(os.path.join(prof, wl + "_write"), "WRITE_SIZE")
     r = line(wl)["roofline"]
     per_frame = r["points"] / (frames - 1)                      # the line counts the timed steps; the passes saw all frames
-    k = next(k for k in rd if "mlp_kernel" in k)
+    k = max((k for k in rd if "mlp_kernel" in k), key=lambda k: rd[k] * 2 + wr.get(k, 0))     # (not the fp32 check launches)
     pts = per_frame * frames
     out[key] = (rd[k] * 2 + wr[k]) * 1024 / pts
     out[key + "_detail"] = {"kernel": k, "points": int(pts), "FETCH_SIZE_KB": rd[k], "WRITE_SIZE_KB": wr[k]}
