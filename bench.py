@@ -420,7 +420,7 @@ def main():
             result["modes"] = {"f32": extra(render_bench, args, ctx, False, "f32", 2, 1, keep=("roofline_hbm_kernels",))}
             w["cfg3"] = extra(render_bench, args, ctx, True, args.mode, 3, 1, keep=("roofline_hbm_kernels", "kernel_time_share"))
             w["cfg3_dense"] = extra(render_bench, args, ctx, True, args.mode, 2, 1, dense=True)
-            w["cfg4"] = extra(train_bench, args, ctx, args.mode, 4, 2, keep=("kernel_time_share", "final_loss"))
+            w["cfg4"] = extra(train_bench, args, ctx, args.mode, 8, 4, keep=("kernel_time_share", "final_loss"))
             w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 1)
         else:
             # N > 1: the strong-scaling counterpart of the headline (one frame's rays sliced over the ranks), the warp
@@ -428,7 +428,7 @@ def main():
             w["cfg2_strong"] = extra(render_bench, args, ctx, False, args.mode, 3, 1, scaling="strong")
             w["cfg3"] = extra(render_bench, args, ctx, True, args.mode, 3, 1)
             w["cfg3_strong"] = extra(render_bench, args, ctx, True, args.mode, 3, 1, scaling="strong")
-            w["cfg4"] = extra(train_bench, args, ctx, args.mode, 4, 2, keep=("final_loss",))
+            w["cfg4"] = extra(train_bench, args, ctx, args.mode, 8, 4, keep=("final_loss",))
             w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 1)
         result["workloads"] = w
 
