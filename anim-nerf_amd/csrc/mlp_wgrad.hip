@@ -222,45 +222,104 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
 
 // ---- the two skinny heads as weighted column sums (their M side is g, 4 fp32 columns):
 //   d sigma.weight[c] = sum_p g[p][3] h8[p][c]     d rgb.weight[j][c] = sum_p g[p][j] G[p][c]     biases: sum_p g[p][j]
-// One thread per output of a slice of rows, sixteen rows in flight; slices are added by the reduction kernel.
+// One workgroup per slice of rows.  A wave reads a whole row of h8 (256 columns, four per lane: one 8- / 16-byte load) or
+// two rows of G (128 columns) per instruction, four rows in flight; its four waves interleave the rows and meet in LDS;
+// slices are added by the reduction kernel.  (First version: one thread per output column with 2-byte loads, 72 us per
+// call at any row count; this one moves the same bytes in a quarter of the load instructions.)
 constexpr int CS_COLS = 256 + 3 * 128 + 4;                  // sigma.weight | rgb.weight | rgb.bias (3), sigma.bias
+
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float (&v)[4]) {
+    if constexpr (sizeof(T) == 2) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    } else {
+        const float4 f = *reinterpret_cast<const float4*>(p);
+        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    }
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, const float* __restrict__ g4, int64_t n,
                                                     int rows_per_slice, int sigma_only, int tangent, float* __restrict__ partial) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice;
+    __shared__ float sh[4][CS_COLS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_slice;
     int64_t r1 = r0 + rows_per_slice;
     if (r1 > n) r1 = n;
-    if (c >= CS_COLS) return;
-    int j, k;                                                // weight column j of g, activation column k (-1: bias)
-    if (c < 256) { j = 3; k = 1792 + c; }                    // h8
-    else if (c < 640) { j = (c - 256) / 128; k = 2304 + (c - 256) % 128; }
-    else { j = c - 640; k = -1; }
-    // (latency-bound: one column per thread walks its slice of rows with RIF independent loads in flight)
-    constexpr int RIF = 16;
-    float s[RIF];
-#pragma unroll
-    for (int q = 0; q < RIF; ++q) s[q] = 0.0f;
-    if (!(sigma_only && j < 3)) {
-        int64_t r = r0;
-        for (; r + RIF <= r1; r += RIF) {
-            float a[RIF], gv[RIF];
+    constexpr int RIF = 4;
+    // sigma.weight (+ all four bias sums, lane 0): wave w takes rows r0 + w, r0 + w + 4, ...
+    float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        int64_t r = r0 + wave;
+        for (; r + 4 * (RIF - 1) < r1; r += 4 * RIF) {
+            float h[RIF][4];
+            float4 g[RIF];
 #pragma unroll
             for (int q = 0; q < RIF; ++q) {
-                gv[q] = g4[(r + q) * 4 + j];
-                a[q] = k >= 0 ? (float)act[(r + q) * ACT_COLS + k] : (tangent && ((r + q) & 3)) ? 0.0f : 1.0f;
+                load4(act + (r + 4 * q) * ACT_COLS + 1792 + 4 * lane, h[q]);
+                g[q] = reinterpret_cast<const float4*>(g4)[r + 4 * q];
             }
 #pragma unroll
-            for (int q = 0; q < RIF; ++q) s[q] += gv[q] * a[q];
+            for (int q = 0; q < RIF; ++q) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sw[i] += g[q].w * h[q][i];
+                const float one = (tangent && ((r + 4 * q) & 3)) ? 0.0f : 1.0f;
+                sb[0] += g[q].x * one; sb[1] += g[q].y * one; sb[2] += g[q].z * one; sb[3] += g[q].w * one;
+            }
         }
-        for (; r < r1; ++r) s[0] += g4[r * 4 + j] * (k >= 0 ? (float)act[r * ACT_COLS + k] : (tangent && (r & 3)) ? 0.0f : 1.0f);
+        for (; r < r1; r += 4) {
+            float h[4];
+            load4(act + r * ACT_COLS + 1792 + 4 * lane, h);
+            const float4 g = reinterpret_cast<const float4*>(g4)[r];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sw[i] += g.w * h[i];
+            const float one = (tangent && (r & 3)) ? 0.0f : 1.0f;
+            sb[0] += g.x * one; sb[1] += g.y * one; sb[2] += g.z * one; sb[3] += g.w * one;
+        }
+    }
+    // rgb.weight: 128 columns = 32 lanes x 4; the two half-waves take alternate rows
+    float sr[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (!sigma_only) {
+        const int col = 2304 + 4 * (lane & 31);
+        int64_t r = r0 + 2 * wave + (lane >> 5);
+        for (; r + 8 * (RIF - 1) < r1; r += 8 * RIF) {
+            float h[RIF][4];
+            float4 g[RIF];
+#pragma unroll
+            for (int q = 0; q < RIF; ++q) {
+                load4(act + (r + 8 * q) * ACT_COLS + col, h[q]);
+                g[q] = reinterpret_cast<const float4*>(g4)[r + 8 * q];
+            }
+#pragma unroll
+            for (int q = 0; q < RIF; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { sr[0][i] += g[q].x * h[q][i]; sr[1][i] += g[q].y * h[q][i]; sr[2][i] += g[q].z * h[q][i]; }
+        }
+        for (; r < r1; r += 8) {
+            float h[4];
+            load4(act + r * ACT_COLS + col, h);
+            const float4 g = reinterpret_cast<const float4*>(g4)[r];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sr[0][i] += g.x * h[i]; sr[1][i] += g.y * h[i]; sr[2][i] += g.z * h[i]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sr[j][i] += __shfl_xor(sr[j][i], 32, 64);      // the two half-waves' rows
     }
 #pragma unroll
-    for (int w = RIF / 2; w >= 4; w >>= 1)
+    for (int i = 0; i < 4; ++i) sh[wave][4 * lane + i] = sw[i];
+    if (lane < 32)
 #pragma unroll
-        for (int q = 0; q < w; ++q) s[q] += s[q + w];
-    partial[(int64_t)blockIdx.y * CS_COLS + c] = (s[0] + s[1]) + (s[2] + s[3]);
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sh[wave][256 + 128 * j + 4 * lane + i] = sr[j][i];
+    if (lane == 0) { sh[wave][640] = sb[0]; sh[wave][641] = sb[1]; sh[wave][642] = sb[2]; sh[wave][643] = sb[3]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < CS_COLS; c += 256)
+        partial[(int64_t)blockIdx.x * CS_COLS + c] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
 }
 
 // ---- reduction over the slices + scatter into the 22 gradient tensors (flat, in the order of anr_mlp_wgrad_layout)
@@ -429,7 +488,7 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
         const int rps = (int)((n + slices - 1) / slices);
         slices = (int)((n + rps - 1) / rps);
         using T = typename C::T;
-        hipLaunchKernelGGL(heads_kernel<T>, dim3((CS_COLS + 255) / 256, slices), dim3(256), 0, st,
+        hipLaunchKernelGGL(heads_kernel<T>, dim3(slices), dim3(256), 0, st,
                            reinterpret_cast<const T*>(act), g4, n, rps, sigma_only, tangent, ws + ws_off);
         seg(L.sw, 1, 256, 256, ws_off, CS_COLS, CS_COLS, slices);
         seg(L.sb, 1, 1, 1, ws_off + 643, CS_COLS, CS_COLS, slices);
