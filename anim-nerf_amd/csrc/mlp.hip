@@ -152,7 +152,7 @@ extern "C" int anr_mlp_pack(const anr_mlp_params* p, int mode, void* pack_out, v
     return check_launch("anr_mlp_pack");
 }
 
-extern "C" int anr_mlp_act_cols(void) { return ACT_COLS; }
+extern "C" int anr_mlp_act_cols(void) { return ACT_PITCH; }
 
 extern "C" int anr_mlp_forward_save(const void* pack, int mode, const float* pts, int64_t n, float* out, void* act_v,
                                     void* stream) {

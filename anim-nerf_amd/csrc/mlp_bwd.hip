@@ -64,10 +64,21 @@ struct MlpBwd {
     int wave, lane, half;
     f32x16 acc[2][NT];
     Frag w0[4];
-    MaskT mk[2][NT][4];          // masks of tile c (parity) and of tile c-1 (its epilogue is pending)
+    unsigned mk[2][NT];          // sign bits (16: four quarters x four rows) of tile c (parity) and of tile c-1 (pending epilogue)
+    unsigned mkg[NT][4];         // ... of the 8 (4) blocks of the current stage: one 16-byte (8-byte) load per lane and stage
     const ActT* act_row[NT];
     ActT* dact_row[NT];
 
+    template <int W> __device__ __forceinline__ void load_stage_bits(int n) {
+        const char* p = act_bits(act_row[n], half, W);
+        if constexpr (W < 72) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p);
+            mkg[n][0] = v.x; mkg[n][1] = v.y; mkg[n][2] = v.z; mkg[n][3] = v.w;
+        } else {
+            const uint2 v = *reinterpret_cast<const uint2*>(p);
+            mkg[n][0] = v.x; mkg[n][1] = v.y;
+        }
+    }
     __device__ __forceinline__ void advance() {
         dma_wait();
         __syncthreads();
@@ -91,7 +102,7 @@ struct MlpBwd {
     struct MaskEpi {
         const f32x16 (&a)[NT];
         Frag (&Y)[NT][YF];
-        const MaskT (&m)[NT][4];
+        const unsigned (&m)[NT];
         ActT* const (&dr)[NT];
         template <int Q> __device__ __forceinline__ void part() const {
 #pragma unroll
@@ -107,11 +118,9 @@ struct MlpBwd {
                         const f32x2 v2 = {a[n][4 * Q + 2 * i], a[n][4 * Q + 2 * i + 1]};
                         pk[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16x2));
                         if (bmasked(TG)) {
-                            // saved h is relu'd bf16: > 0 <=> bit pattern in [1, 0x7fff]; (0 - h) >> 15 (arithmetic,
-                            // per 16-bit half) is 0xffff there and 0 for h = +0
-                            const s16x2 hb = __builtin_bit_cast(s16x2, i == 0 ? m[n][Q].x : m[n][Q].y);
-                            const s16x2 keep = (s16x2{0, 0} - hb) >> 15;
-                            pk[i] &= __builtin_bit_cast(unsigned, keep);
+                            // sign bits saved by the forward: bit 4Q + 2i (+1) <-> the low (high) half of this dword
+                            const unsigned b2 = (m[n] >> (4 * Q + 2 * i)) & 3u;
+                            pk[i] &= (b2 & 1u) * 0x0000ffffu | (b2 >> 1) * 0xffff0000u;
                         }
                     }
                     Frag& dst = Y[n][TB + (4 * Q) / EPF];
@@ -120,13 +129,15 @@ struct MlpBwd {
                     d4[((4 * Q) % EPF) / 2 + 1] = pk[1];
                     dst = __builtin_bit_cast(Frag, d4);
                     if ((4 * Q + 4) % EPF == 0) pin(dst);
+#ifndef ANR_ABL_NO_DACT_STORE
                     if (dr[n] != nullptr) *reinterpret_cast<uint2*>(dr[n] + bcol(TG) + 8 * Q) = make_uint2(pk[0], pk[1]);
+#endif
                 } else {
                     f32x4 keep;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float v = a[n][4 * Q + i];
-                        if (bmasked(TG)) v = (m[n][Q][i] > 0.0f) ? v : 0.0f;
+                        if (bmasked(TG)) v = ((m[n] >> (4 * Q + i)) & 1u) ? v : 0.0f;
                         put(Y[n][TB + (4 * Q + i) / EPF], (4 * Q + i) % EPF, v);
                         keep[i] = v;
                     }
@@ -152,9 +163,11 @@ struct MlpBwd {
         // the saved activations that gate THIS tile's result (used by its epilogue, one tile later)
         if constexpr (bmasked(T)) {
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) mk[PAR][n][q] = *reinterpret_cast<const MaskT*>(act_row[n] + bcol(T) + 8 * q);
+            for (int n = 0; n < NT; ++n) {
+                constexpr int w = bcol(T) / 32, j = w < 72 ? w % 8 : w - 72;
+                if constexpr (j == 0) load_stage_bits<w>(n);
+                mk[PAR][n] = (mkg[n][j / 2] >> (16 * (j & 1))) & 0xffffu;
+            }
         }
         // C operand: zero, except the rank-1 sigma term on the final^T tiles
         f32x16 cinit[NT];
@@ -260,8 +273,8 @@ struct MlpBwd {
                 gin[n] = g[cl];
                 dsig[n] = gin[n].w;
                 // tangent mode: the ReLU gates of a quad's four columns are the primal column's (row 4p)
-                act_row[n] = act + (tangent ? (cl & ~(int64_t)3) : cl) * ACT_COLS + 4 * half;
-                dact_row[n] = idx < n_pts ? dact + idx * ACT_COLS + 4 * half : nullptr;
+                act_row[n] = act + (tangent ? (cl & ~(int64_t)3) : cl) * ACT_PITCH + 4 * half;
+                dact_row[n] = idx < n_pts ? dact + idx * ACT_PITCH + 4 * half : nullptr;
             }
             if (first) {
                 dma_wait();
@@ -333,8 +346,9 @@ struct MlpBwd {
                             const f32x4 w4 = tb[q];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) acc[0][n][4 * q + i] = w4[i] * dsig[n];
-                            mk[0][n][q] = *reinterpret_cast<const MaskT*>(act_row[n] + bcol(12 + j) + 8 * q);
                         }
+                        if constexpr (j == 0) load_stage_bits<bcol(12) / 32>(n);
+                        mk[0][n] = (mkg[n][j / 2] >> (16 * (j & 1))) & 0xffffu;
                     }
                     MaskEpi<HF, j * FPT, 12 + j> epi{acc[0], B, mk[0], dact_row};
                     epi.template part<0>(); epi.template part<1>(); epi.template part<2>(); epi.template part<3>();

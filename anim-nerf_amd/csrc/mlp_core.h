@@ -169,7 +169,20 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 
 // column of out-tile T's 32 features in a saved-activation row: [h1..h8 (8 x 256) | final (256) | dir hidden (128)]
 constexpr int ACT_COLS = 2432;
+// ... followed by the SIGN BITS of the ReLU'd columns (bit 4Q+i of the uint16 of (block w of 32 features, half-wave h) <->
+// feature 32w + 8Q + 4h + i is > 0), grouped the way the kernels produce and consume them: per layer (8 blocks) 16 bytes of
+// half-wave 0 then 16 bytes of half-wave 1; the 4 blocks of the colour head's hidden layer as 8 + 8 bytes — 304 bytes.
+// The activation-gradient kernel gates with these instead of re-reading the 4,864 bytes of activations (its mask loads
+// were 40 % of its time); one 16-byte piece per lane and layer each way.  Row pitch in ELEMENTS of either dtype (the
+// bits start at element ACT_COLS; an fp32 row wastes a few hundred bytes behind them):
+constexpr int ACT_PITCH = 2592;
 __host__ __device__ constexpr int act_col(int T) { return T < 64 ? 32 * T : T < 73 ? 2048 + 32 * (T - 65) : 2304 + 32 * (T - 73); }
+// byte offset, inside the bits region, of the group of block w for half-wave `half`
+__host__ __device__ constexpr int act_bits_group(int w, int half) { return w < 72 ? 32 * (w / 8) + 16 * half : 288 + 8 * half; }
+template <class ActT>
+__device__ __forceinline__ char* act_bits(ActT* row_plus_4half, int half, int w) {
+    return const_cast<char*>(reinterpret_cast<const char*>(row_plus_4half + (ACT_COLS - 4 * half))) + act_bits_group(w, half);
+}
 
 // PRE: the input is the 63-channel Fourier embedding itself, emb[n][63] fp32 (models/mlp.py:268-297 takes it that way):
 // the encoder is skipped, the panel slots are loaded from the row.
@@ -209,6 +222,7 @@ struct Mlp {
     f32x16 bias_c;           // bias of tile c: C operand of its first MFMA
     Frag w0[4];              // first fragment group of tile c
     ActT* act_row[NT];       // SAVE: this lane's row of saved activations (+ 4*half), or null
+    unsigned savebits[NT];   // SAVE: sign bits of the tile whose epilogue is pending
 
     // barrier: chunk c+1 has landed everywhere and nobody reads chunk c-1 any more -> stage chunk c+2 over it
     static constexpr int MAXP = (TPC * (HF + EF) + WAVES - 1) / WAVES;   // register-staged pieces per wave (DMA off)
@@ -277,6 +291,8 @@ struct Mlp {
         const f32x16 (&a)[NT];
         Frag (&Y)[NT][YF];
         ActT* const (&ar)[NT];
+        unsigned (&sb)[NT];              // SAVE, parity mode: sign bits of this tile's four quarters, collected across the parts
+        int half;
         template <int Q> __device__ __forceinline__ void part() const {
 #ifdef ANR_ABL_NO_EPILOGUE
             if (Q > 0) return;
@@ -319,6 +335,21 @@ struct Mlp {
                     // features 32t + 8Q + 4h + (0..3) of this lane's point: 8 contiguous bytes of its row
                     if (SAVE && ar[n] != nullptr)
                         *reinterpret_cast<uint2*>(ar[n] + act_col(TG) + 8 * Q) = make_uint2(pk[0], pk[1]);
+                    if constexpr (SAVE && RELU && Q == 3) {
+                        // sign bits of the tile's 16 values, read back from the two fragments just completed (nothing is
+                        // carried across the parts: the kernel sits at its register limit); after the ReLU a bf16 is > 0
+                        // exactly when its bit pattern is non-zero
+                        static_assert(EPF == 8, "two fragments per tile");
+                        const u32x4 lo4 = __builtin_bit_cast(u32x4, Y[n][TB]), hi4 = __builtin_bit_cast(u32x4, Y[n][TB + 1]);
+                        unsigned bits = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            bits |= ((lo4[k] & 0xffffu) ? 1u : 0u) << (2 * k) | ((lo4[k] >> 16) ? 1u : 0u) << (2 * k + 1);
+                            bits |= ((hi4[k] & 0xffffu) ? 1u : 0u) << (8 + 2 * k) | ((hi4[k] >> 16) ? 1u : 0u) << (9 + 2 * k);
+                        }
+                        constexpr int w = act_col(TG) / 32, j = w < 72 ? w % 8 : w - 72;
+                        if (ar[n] != nullptr) *reinterpret_cast<uint16_t*>(act_bits(ar[n], half, w) + 2 * j) = (uint16_t)bits;
+                    }
                 } else {
                     f32x4 keep;
 #pragma unroll
@@ -337,6 +368,13 @@ struct Mlp {
                     }
                     if ((4 * Q + 4) % EPF == 0) pin(Y[n][TB + (4 * Q) / EPF]);
                     if (SAVE && ar[n] != nullptr) *reinterpret_cast<f32x4*>(ar[n] + act_col(TG) + 8 * Q) = keep;
+                    if constexpr (SAVE && RELU) {                              // (parity mode: carried across the parts)
+                        const unsigned nib = (keep[0] > 0.0f ? 1u : 0u) | (keep[1] > 0.0f ? 2u : 0u) | (keep[2] > 0.0f ? 4u : 0u) |
+                                             (keep[3] > 0.0f ? 8u : 0u);
+                        sb[n] = Q == 0 ? nib : (sb[n] | (nib << (4 * Q)));
+                        constexpr int w = act_col(TG) / 32, j = w < 72 ? w % 8 : w - 72;
+                        if (Q == 3 && ar[n] != nullptr) *reinterpret_cast<uint16_t*>(act_bits(ar[n], half, w) + 2 * j) = (uint16_t)sb[n];
+                    }
                 }
             }
         }
@@ -435,13 +473,13 @@ struct Mlp {
             if constexpr (t == 0) {
                 tile<T0 + t, NFE, NFH, XF>(E, X, first);
             } else {
-                tile<T0 + t, NFE, NFH, XF>(E, X, FragEpi<RELU, YF, (t - 1) * FPT, T0 + t - 1>{acc[PAR ^ 1], Y, act_row});
+                tile<T0 + t, NFE, NFH, XF>(E, X, FragEpi<RELU, YF, (t - 1) * FPT, T0 + t - 1>{acc[PAR ^ 1], Y, act_row, savebits, half});
             }
         });
     }
     template <int T0, int NTILES, bool RELU, int YF>
     __device__ __forceinline__ auto last_of(Frag (&Y)[NT][YF]) {
-        return FragEpi<RELU, YF, (NTILES - 1) * FPT, T0 + NTILES - 1>{acc[(T0 + NTILES - 1) & 1], Y, act_row};
+        return FragEpi<RELU, YF, (NTILES - 1) * FPT, T0 + NTILES - 1>{acc[(T0 + NTILES - 1) & 1], Y, act_row, savebits, half};
     }
 
     // index/count (both optional): evaluate pts[index[i]] for i < min(n_pts, *count) and write out[index[i]] — the
@@ -543,7 +581,7 @@ struct Mlp {
             int64_t idx = wave_base + n * 32 + (lane & 31);
             const float4 p = p_cur[n];
             valid[n] = p.w;
-            act_row[n] = (SAVE && idx < n_pts) ? reinterpret_cast<ActT*>(act) + idx * ACT_COLS + 4 * half : nullptr;
+            act_row[n] = (SAVE && idx < n_pts) ? reinterpret_cast<ActT*>(act) + idx * ACT_PITCH + 4 * half : nullptr;
             const float xs[3] = {p.x, p.y, p.z};
             if constexpr (PRE) {
                 int64_t row_i = idx < n_pts ? idx : n_pts - 1;

@@ -78,9 +78,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
     int64_t r1 = r0 + args.rows_per_split;
     if (r1 > n) r1 = n;
     const int n_stages = r1 > r0 ? (int)((r1 - r0) / SR) : 0;
-    const int64_t a_pitch = (int64_t)ACT_COLS * ESZ;
+    const int64_t a_pitch = (int64_t)ACT_PITCH * ESZ;
     const char* b_base = gm.b_src ? enc : act;
-    const int64_t b_pitch = (gm.b_src ? 64 : ACT_COLS) * (int64_t)ESZ;
+    const int64_t b_pitch = (gm.b_src ? 64 : ACT_PITCH) * (int64_t)ESZ;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
     auto issue = [&](int st) {                                  // slab of stage st -> ring buffer st % NBUF
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
             float4 g[RIF];
 #pragma unroll
             for (int q = 0; q < RIF; ++q) {
-                load4(act + (r + 4 * q) * ACT_COLS + 1792 + 4 * lane, h[q]);
+                load4(act + (r + 4 * q) * ACT_PITCH + 1792 + 4 * lane, h[q]);
                 g[q] = reinterpret_cast<const float4*>(g4)[r + 4 * q];
             }
 #pragma unroll
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
         }
         for (; r < r1; r += 4) {
             float h[4];
-            load4(act + r * ACT_COLS + 1792 + 4 * lane, h);
+            load4(act + r * ACT_PITCH + 1792 + 4 * lane, h);
             const float4 g = reinterpret_cast<const float4*>(g4)[r];
 #pragma unroll
             for (int i = 0; i < 4; ++i) sw[i] += g.w * h[i];
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
             float4 g[RIF];
 #pragma unroll
             for (int q = 0; q < RIF; ++q) {
-                load4(act + (r + 8 * q) * ACT_COLS + col, h[q]);
+                load4(act + (r + 8 * q) * ACT_PITCH + col, h[q]);
                 g[q] = reinterpret_cast<const float4*>(g4)[r + 8 * q];
             }
 #pragma unroll
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
         }
         for (; r < r1; r += 8) {
             float h[4];
-            load4(act + r * ACT_COLS + col, h);
+            load4(act + r * ACT_PITCH + col, h);
             const float4 g = reinterpret_cast<const float4*>(g4)[r];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { sr[0][i] += g.x * h[i]; sr[1][i] += g.y * h[i]; sr[2][i] += g.z * h[i]; }
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void denc_kernel(const char* __restrict__ dact
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t p = tile * 32 + (lane & 31);
         const int64_t row = p < n ? p : n - 1;
-        const char* arow = dact + row * (int64_t)ACT_COLS * sizeof(T);
+        const char* arow = dact + row * (int64_t)ACT_PITCH * sizeof(T);
         const int h = lane >> 5;
         f32x16 acc[2];
 #pragma unroll

@@ -251,8 +251,12 @@ int anr_mlp_forward_indexed(const void* pack, int mode, const float* pts, const 
 /* Training forward: the same kernel, additionally storing each layer's post-activation output for the backward
  * pass (what autograd keeps alive in the reference, models/nerf.py:163-175): act[n * anr_mlp_act_cols()],
  * fp32 in mode ANR_MLP_F32 and bf16 in mode ANR_MLP_BF16 (the value the next layer consumed),
- * row = [h1..h8 (8 x 256, post-ReLU) | xyz_encoding_final (256) | dir hidden (128, post-ReLU)]; with
- * ANR_MLP_FLAG_SIGMA_ONLY only h1..h8 are written. */
+ * row = [h1..h8 (8 x 256, post-ReLU) | xyz_encoding_final (256) | dir hidden (128, post-ReLU) | sign bits]; with
+ * ANR_MLP_FLAG_SIGMA_ONLY only h1..h8 (and their bits) are written.  anr_mlp_act_cols() = 2592 elements per row in
+ * either dtype: columns 0..2431 are the activations; from column 2432 on the row holds 304 bytes of SIGN BITS of the
+ * ReLU'd columns (one uint16 per block of 32 features and half-wave: bit 4Q+i <-> feature 32w + 8Q + 4h + i is > 0; per
+ * layer the 8 uint16 of half-wave 0, then the 8 of half-wave 1; the colour head's 4 + 4 last) — what
+ * anr_mlp_backward gates with, instead of re-reading the activations.  dact rows have the same pitch; their tail is unused. */
 int anr_mlp_act_cols(void);
 int anr_mlp_forward_save(const void* pack, int mode, const float* pts, int64_t n,
                          float* out, void* act, void* stream);
