@@ -104,6 +104,7 @@ struct MlpBwd {
         Frag (&Y)[NT][YF];
         const unsigned (&m)[NT];
         ActT* const (&dr)[NT];
+        int half;
         template <int Q> __device__ __forceinline__ void part() const {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -130,7 +131,17 @@ struct MlpBwd {
                     dst = __builtin_bit_cast(Frag, d4);
                     if ((4 * Q + 4) % EPF == 0) pin(dst);
 #ifndef ANR_ABL_NO_DACT_STORE
-                    if (dr[n] != nullptr) *reinterpret_cast<uint2*>(dr[n] + bcol(TG) + 8 * Q) = make_uint2(pk[0], pk[1]);
+                    // the two half-waves hold alternate 8-byte pieces of a row; one v_permlane32_swap per dword hands the lower
+                    // half-wave both pieces of the even quarter and the upper one both of the odd quarter: 16-byte stores, 32
+                    // contiguous bytes per row and instruction (8-byte pieces: 16) — half the store instructions
+                    if constexpr (Q & 1) {
+                        const u32x4 prev = __builtin_bit_cast(u32x4, Y[n][TB + (4 * (Q - 1)) / EPF]);
+                        constexpr int pd = ((4 * (Q - 1)) % EPF) / 2;
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(prev[pd], pk[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(prev[pd + 1], pk[1], false, false);
+                        if (dr[n] != nullptr)
+                            *reinterpret_cast<uint4*>(dr[n] + bcol(TG) + 16 * (Q >> 1) + 4 * half) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    }
 #endif
                 } else {
                     f32x4 keep;
@@ -229,14 +240,14 @@ struct MlpBwd {
             if constexpr (t == 0) {
                 tile<T0 + t, NF, XF>(X, first, dsig);
             } else {
-                tile<T0 + t, NF, XF>(X, MaskEpi<YF, (t - 1) * FPT, T0 + t - 1>{acc[PAR ^ 1], Y, mk[PAR ^ 1], dact_row}, dsig);
+                tile<T0 + t, NF, XF>(X, MaskEpi<YF, (t - 1) * FPT, T0 + t - 1>{acc[PAR ^ 1], Y, mk[PAR ^ 1], dact_row, half}, dsig);
             }
         });
     }
     template <int T0, int NTILES, int YF>
     __device__ __forceinline__ auto last_of(Frag (&Y)[NT][YF]) {
         constexpr int T = T0 + NTILES - 1;
-        return MaskEpi<YF, (NTILES - 1) * FPT, T>{acc[T & 1], Y, mk[T & 1], dact_row};
+        return MaskEpi<YF, (NTILES - 1) * FPT, T>{acc[T & 1], Y, mk[T & 1], dact_row, half};
     }
 
     __device__ __forceinline__ void run(const char* __restrict__ pack, const float4* __restrict__ g, const ActT* __restrict__ act,
@@ -301,7 +312,7 @@ struct MlpBwd {
                             for (int i = 0; i < 4; ++i) acc[0][n][4 * q + i] = v[i];
                         }
                     }
-                    MaskEpi<HF, j * FPT, 4 + j> epi{acc[0], A, mk[0], dact_row};
+                    MaskEpi<HF, j * FPT, 4 + j> epi{acc[0], A, mk[0], dact_row, half};
                     epi.template part<0>(); epi.template part<1>(); epi.template part<2>(); epi.template part<3>();
                 });
 #pragma unroll
@@ -350,7 +361,7 @@ struct MlpBwd {
                         if constexpr (j == 0) load_stage_bits<bcol(12) / 32>(n);
                         mk[0][n] = (mkg[n][j / 2] >> (16 * (j & 1))) & 0xffffu;
                     }
-                    MaskEpi<HF, j * FPT, 12 + j> epi{acc[0], B, mk[0], dact_row};
+                    MaskEpi<HF, j * FPT, 12 + j> epi{acc[0], B, mk[0], dact_row, half};
                     epi.template part<0>(); epi.template part<1>(); epi.template part<2>(); epi.template part<3>();
                 });
                 layer<20, 8, HF, HF, HF>(B, A, NoEpi{}, dsig);                              // W8^T   : dh8' -> dh7' (A)

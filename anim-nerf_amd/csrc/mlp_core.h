@@ -333,8 +333,17 @@ struct Mlp {
                     dst = __builtin_bit_cast(Frag, d4);
                     if ((4 * Q + 4) % EPF == 0) pin(dst);
                     // features 32t + 8Q + 4h + (0..3) of this lane's point: 8 contiguous bytes of its row
-                    if (SAVE && ar[n] != nullptr)
-                        *reinterpret_cast<uint2*>(ar[n] + act_col(TG) + 8 * Q) = make_uint2(pk[0], pk[1]);
+                    // (the two half-waves hold alternate 8-byte pieces of the row: one v_permlane32_swap per dword hands the lower
+                    // half-wave both pieces of the even quarter, the upper one both of the odd quarter -> 16-byte stores, 32
+                    // contiguous bytes per row and instruction)
+                    if constexpr (SAVE && (Q & 1)) {
+                        const u32x4 prev = __builtin_bit_cast(u32x4, Y[n][TB + (4 * (Q - 1)) / EPF]);
+                        constexpr int pd = ((4 * (Q - 1)) % EPF) / 2;
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(prev[pd], pk[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(prev[pd + 1], pk[1], false, false);
+                        if (ar[n] != nullptr)
+                            *reinterpret_cast<uint4*>(ar[n] + act_col(TG) + 16 * (Q >> 1) + 4 * half) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    }
                     if constexpr (SAVE && RELU && Q == 3) {
                         // sign bits of the tile's 16 values, read back from the two fragments just completed (nothing is
                         // carried across the parts: the kernel sits at its register limit); after the ReLU a bf16 is > 0
