@@ -480,7 +480,10 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void sample_fine_merge_kern
     RayLds<KT>& L = lds[slot];
     for (int k = l; k < Kc; k += LPR) { L.zall[k] = z_coarse[r * Kc + k]; L.wbuf[k] = weights[r * Kc + k]; }
     for (int k = l; k <= Kc; k += LPR) L.hist[k] = 0;
-    auto sync = [] { __syncthreads(); };
+    // a ray's LDS segment is touched by the lanes of ONE wavefront only (LPR <= 64 lanes of it): the LDS unit executes a
+    // wave's instructions in order, so the compiler fence is all the "barrier" the segment needs — no workgroup barrier
+    // that makes four wavefronts wait for each other eight times per ray
+    auto sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
     sync();
     const int K = Kc + Kf;
     fine_and_merge<LPR, KT, PermT>(L, lane, u_per_ray ? u + r * Kf : u, Kc, Kf,
@@ -537,7 +540,10 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_sample_kerne
         depth_out[r] = dep;
         acc_out[r] = wsum;
     }
-    auto sync = [] { __syncthreads(); };
+    // a ray's LDS segment is touched by the lanes of ONE wavefront only (LPR <= 64 lanes of it): the LDS unit executes a
+    // wave's instructions in order, so the compiler fence is all the "barrier" the segment needs — no workgroup barrier
+    // that makes four wavefronts wait for each other eight times per ray
+    auto sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
     sync();
     const int K = Kc + Kf;
     fine_and_merge<LPR, KT, PermT>(L, lane, u_per_ray ? u + r * Kf : u, Kc, Kf,
