@@ -160,14 +160,16 @@ __device__ __forceinline__ void scan_cluster(const float* lds, int Vp, int c, fl
 #pragma unroll
     for (int q = 0; q < CS / 4; ++q) {
         const float4 vx = X[q], vy = Y[q], vz = Z[q];
-        const float ax[4] = {vx.x, vx.y, vx.z, vx.w};
-        const float ay[4] = {vy.x, vy.y, vy.z, vy.w};
-        const float az[4] = {vz.x, vz.y, vz.z, vz.w};
+        // two vertices per instruction (v_pk_add/mul/fma_f32): the same operations in the same order as the scalar form
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 P[3] = {f2{px, px}, f2{py, py}, f2{pz, pz}};
         float d2[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float dx = px - ax[t], dy = py - ay[t], dz = pz - az[t];
-            d2[t] = dx * dx + dy * dy + dz * dz;
+        for (int t = 0; t < 2; ++t) {
+            const f2 ax = t ? f2{vx.z, vx.w} : f2{vx.x, vx.y}, ay = t ? f2{vy.z, vy.w} : f2{vy.x, vy.y}, az = t ? f2{vz.z, vz.w} : f2{vz.x, vz.y};
+            const f2 dx = P[0] - ax, dy = P[1] - ay, dz = P[2] - az;
+            const f2 r = dx * dx + dy * dy + dz * dz;
+            d2[2 * t] = r.x; d2[2 * t + 1] = r.y;
         }
         float m = fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3]));
         if (m <= best.d[3]) {                              // (<=: a tie with the current 4th may carry a lower slot)
