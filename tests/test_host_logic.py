@@ -48,10 +48,28 @@ def test_bad_arguments_are_reported_not_crashed():
         "anr_knn": (None, None, 1, 6890, 8, None, None, None),
         "anr_warp_points_lean": (None, 0, None, 8, None, 4, None, None, None, 1, 6890, 24, 8, 0.2, 1, None, None, None, None,
                                  None, None, None, None, None, None, None, None, None, 0, None),
+        # round 2: the training-step kernels
+        "anr_knn_k": (None, None, 3, 1, 6890, 8, 9, None, None, None),
+        "anr_compact_ordered": (None, 8, None, None, None, None, None, None),
+        "anr_expand_rows": (None, None, 8, 3, 0.0, None, None),
+        "anr_mlp_head_grad": (None, None, None, None, 8, 64, 0, None, None),
+        "anr_tangent_quads": (None, 8, 16, None, None),
+        "anr_sample_coarse_backward": (None, None, None, 8, 64, None, None),
+        "anr_merge_backward": (None, None, 8, 96, 64, None, None),
+        "anr_mlp_wgrad": (1, None, None, None, None, 64, None, None, None),
+        "anr_mlp_denc": (1, None, None, None, 64, None, None),
+        "anr_mlp_backward_feature": (None, 1, None, None, None, None, 64, None),
+        "anr_train_loss": (None, None, None, None),
+        "anr_train_loss_backward": (None, None, None, None),
+        "anr_frame_backward": (None,) * 3 + (1,) + (None,) * 6 + (6890, None, 1, None, 8, 0, None, None, None, None, None),
+        "anr_frame_backward_adjoint": (None,) * 3 + (1,) + (None,) * 6 + (6890, None, 1, None, 8, 0, None, None, None, None, None),
+        "anr_to_root_frame": (None, None, None, None, 1, 6890, 24, None, None, None, None, None, None),
+        "anr_composite_sample": (None,) * 4 + (8, None, None, 0, 4, 64, 64, 1) + (None,) * 8,
     }
     for name, args in calls.items():
         if args is None:
             continue
+        assert len(args) == len(ana._lib.SIGNATURES[name][1]), name
         rc = getattr(lib, name)(*args)
         assert rc < 0, name
         assert len(lib.anr_last_error()) > 0, name
