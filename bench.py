@@ -62,10 +62,41 @@ def parse():
                     help="scale the sigma heads about their median (0 = literal random init, which renders a blank image)")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no modes / workloads objects)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="N > 1 plumbing check without a GPU (tests/test_distributed_cpu.py): launch, rendezvous, verified "
+                         "all-reduce, barrier-bracketed timing of a sleep, one JSON line")
     ap.add_argument("--dense", action="store_true",
                     help="cfg3/cfg4: run the MLP on every sample as the reference does, also on those outside dis_threshold "
                          "(sigma = -1e5, composite weight 0); default: only on the valid ones — same image, bit for bit")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): start the N ranks as a
+    CHILD `torch.distributed.run` (the reference gets the same from Lightning's `gpus=-1`, train.py:451-458), relay its
+    output and leave with its exit code.  Nothing in this process has touched the GPU when the child starts, and the child
+    is a child, not an exec."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)     # stderr passes through
+    line = None
+    for text in proc.stdout:
+        t = text.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t                                   # rank 0's one JSON line
+        elif t:
+            print(t, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    raise SystemExit(rc if rc != 0 or line is not None else 1)
 
 
 class Ctx:
@@ -76,19 +107,32 @@ class Ctx:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         if self.world != args.gpus:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run "
-                             f"--nproc-per-node {args.gpus}")
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
         # (test hooks: ANR_BENCH_BACKEND=gloo + ANR_BENCH_ONE_DEVICE=1 run the N > 1 code path on a single-GPU box)
         self.backend = os.environ.get("ANR_BENCH_BACKEND", "nccl")
-        dev_index = 0 if os.environ.get("ANR_BENCH_ONE_DEVICE") else self.local_rank
-        torch.cuda.set_device(dev_index)
-        self.dev = torch.device("cuda", dev_index)
+        self.collective_ranks = 1
+        self.rank_ms = None
+        if args.plumbing_only and not (self.backend == "nccl" and torch.cuda.device_count() > self.local_rank):
+            self.dev = torch.device("cpu")
+        else:
+            dev_index = 0 if os.environ.get("ANR_BENCH_ONE_DEVICE") else self.local_rank
+            torch.cuda.set_device(dev_index)
+            self.dev = torch.device("cuda", dev_index)
         if self.world > 1:
+            import datetime
             import torch.distributed as dist
+            # a rank that dies (OOM, HIP error on one GPU) must not leave the others in a collective for ever
+            limit = datetime.timedelta(seconds=float(os.environ.get("ANR_BENCH_COLLECTIVE_TIMEOUT", "600")))
             if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=self.dev)    # "nccl" = RCCL over xGMI on ROCm
+                dist.init_process_group("nccl", device_id=self.dev, timeout=limit)    # "nccl" = RCCL over xGMI on ROCm
             else:
-                dist.init_process_group(self.backend)
+                dist.init_process_group(self.backend, timeout=limit)
+            # the number the line reports as `collective_ranks` comes out of a real all-reduce on the data backend
+            one = torch.ones(1, dtype=torch.float32, device=self.dev)
+            dist.all_reduce(one)
+            self.collective_ranks = int(round(one.item()))
+            if self.collective_ranks != self.world or dist.get_world_size() != self.world:
+                raise SystemExit(f"all-reduce over {self.backend} summed {self.collective_ranks} ranks, expected {self.world}")
 
     def barrier(self):
         if self.world > 1:
@@ -97,7 +141,27 @@ class Ctx:
                 dist.barrier(device_ids=[self.dev.index])
             else:
                 dist.barrier()
-        torch.cuda.synchronize(self.dev)
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+
+    def all_ok(self, ok):
+        """True iff `ok` on every rank (one MIN all-reduce): a rank-local failure becomes everybody's failure instead of a
+        hang in the next barrier."""
+        if self.world == 1:
+            return ok
+        import torch.distributed as dist
+        flag = torch.tensor([1.0 if ok else 0.0], device=self.dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return flag.item() > 0.5
+
+    def spread(self, elapsed, steps):
+        """per-rank ms per step: (fastest rank, slowest rank)"""
+        if self.world == 1:
+            return [elapsed / steps * 1e3] * 2
+        import torch.distributed as dist
+        t = torch.tensor([elapsed, -elapsed], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [-t[1].item() / steps * 1e3, t[0].item() / steps * 1e3]
 
     def timed(self, step, steps, warmup):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks.
@@ -112,8 +176,13 @@ class Ctx:
         t0 = time.perf_counter()
         for _ in range(steps):
             out = step()
+        # this rank's own clock stops when ITS queue is empty; the job's clock (below) after the barrier
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+        own = time.perf_counter() - t0
         self.barrier()
         elapsed = time.perf_counter() - t0
+        self.rank_ms = self.spread(own, steps)
         timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
         per_kernel = {}
         for name, e0, e1, units, nbytes in timing:
@@ -196,7 +265,8 @@ def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling=
             "rays_per_step_per_gpu": n_rays, "n_coarse": args.n_coarse, "n_fine": args.n_fine, "mlp_evals_per_ray": evals,
             "chunk_rays": args.chunk,
             "sharding": (f"one frame's rays sliced over {world} GPUs (per-frame setup replicated, no collective)" if strong
-                         else f"{world} independent frames (ray-parallel, no collective)"),
+                         else f"{world} independent frames (ray-parallel, no collective): the same camera on every rank"
+                              + (", rank-seeded body pose" if use_warp else "")),
             # warp on: samples farther than dis_threshold from the body are sigma = -1e5 / weight 0 whatever the MLP
             # says; the MLP runs on the others only (identical image; dense evaluates all of them like the reference)
             "mlp_on_valid_samples_only": bool(model.evaluate_valid_only),
@@ -326,11 +396,11 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False):
     hp = ana.TrainHParams(n_samples=64, n_importance=32, chunk=2048)
     F = args.frames_per_gpu
     table = ana.BodyModelParams(114).to(dev)                  # 114 training frames (configs/people_snapshot/male-3-casual.yaml)
-    seeded = syn.animated_pose_params(seed=200 + rank, bs=114)
+    seeded = syn.animated_pose_params(seed=200, bs=114)        # the SAME table on every rank: its gradients are all-reduced
     for name in table.param_names:                            # optim_body_params: True
         table.init_parameters(name, torch.from_numpy(seeded[name]).to(dev), requires_grad=True)
     trainer = ana.Trainer(model, ana.VolumeRenderer(n_coarse=64, n_fine=32), hp, body_model_params=table)
-    frame_idx = torch.arange(F, device=dev) * (114 // F)
+    frame_idx = (torch.arange(F, device=dev) * (114 // F) + rank) % 114      # a rank's own frames, as a distributed sampler deals them
     c2w, focal, cen = syn.pinhole_camera(32, 32)
     rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), 32, 32, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(F, 1, 1, 1)
     templ = {k: torch.from_numpy(v).to(dev) for k, v in syn.template_pose_params().items()}
@@ -383,9 +453,40 @@ def measured_traffic(mode, variant, points_per_launch):
                                         f"{t.get('commit', 'of round 1')}) x points per launch")
 
 
+def collective_fields(ctx):
+    """what the line says about the process group: ranks counted by a real all-reduce on the data backend, and the spread of
+    the ranks' own clocks over the headline's timed region"""
+    return {"collective_backend": (ctx.backend if ctx.world > 1 else None),
+            "rccl_ranks": ctx.collective_ranks if ctx.backend == "nccl" and ctx.world > 1 else None,
+            "collective_ranks": ctx.collective_ranks,
+            "rank_ms_per_step": {"min": ctx.rank_ms[0], "max": ctx.rank_ms[1]} if ctx.rank_ms else None}
+
+
+def plumbing_only(args, ctx):
+    """--plumbing-only: everything bench.py does around the kernels at N ranks, with a sleep as the step"""
+    def step():
+        time.sleep(0.01 * (1 + ctx.rank))                 # rank r is slower than rank r - 1
+        return None
+    elapsed, _, _ = ctx.timed(step, args.steps, args.warmup)
+    ok = ctx.all_ok(True)
+    result = {"metric": "plumbing only (no kernels)", "value": ctx.world * args.steps / elapsed, "unit": "steps/s",
+              "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": None, "data": "none",
+              "config": {"workload": "sleep(10 ms x (rank + 1))"}, "all_ranks_ok": ok, **collective_fields(ctx)}
+    if ctx.rank == 0:
+        print(json.dumps(result), flush=True)
+    if ctx.world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                             # never returns
     ctx = Ctx(args)
+    if args.plumbing_only:
+        return plumbing_only(args, ctx)
     import anim_nerf_amd as ana
     ana._lib.load()                                   # fails loudly if the HIP library is missing
     rank, world = ctx.rank, ctx.world
@@ -401,7 +502,7 @@ def main():
         r = result["roofline"]
         variant = "rays" if not use_warp else ("indexed" if result["config"]["mlp_on_valid_samples_only"] else "explicit")
         r["traffic"], r["traffic_unit"] = measured_traffic(args.mode, variant, r["points"] / r["launches"] if r["launches"] else 0)
-    result.update({"higher_is_better": True, "vs_baseline": None, "data": "synthetic"})
+    result.update({"higher_is_better": True, "vs_baseline": None, "data": "synthetic", **collective_fields(ctx)})
 
     if not args.no_extras and args.workload == "cfg2" and args.scaling == "weak":
         # every other line this repository quotes, measured in the same process (own warm-up + timed region each)
@@ -409,12 +510,20 @@ def main():
             keys = ("value", "unit", "ms_per_step", "steps", "warmup", "n_gpus", "scaling", "dtype", "roofline") + keep
             return {**{k: r[k] for k in keys if k in r}, "config": r["config"]}
         def extra(fn, *a, keep=(), **kw):
-            # a failing extra must not take the headline line with it (every rank runs the same code, so a failure is
-            # symmetric and no rank is left waiting in a barrier)
+            # a failing extra must not take the headline line with it.  At N > 1 a failure need not be symmetric (OOM or
+            # a HIP error on ONE GPU): the ranks agree on the outcome after each extra, and if any of them failed the job
+            # stops there with the headline printed — the others would otherwise wait in the next barrier (which, like
+            # every collective here, also carries a timeout)
             try:
-                return brief(fn(*a, **kw), *keep)
+                got, err = brief(fn(*a, **kw), *keep), None
             except Exception as exc:                        # noqa: BLE001
-                return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                got, err = None, f"{type(exc).__name__}: {exc}"[:300]
+            if world > 1 and not ctx.all_ok(err is None):
+                if rank == 0:
+                    result["workloads"] = {**w, fn.__name__: {"error": err or "failed on another rank"}}
+                    print(json.dumps(result), flush=True)
+                os._exit(3)                                 # no destroy_process_group: a failed rank may not answer
+            return got if err is None else {"error": err}
         w = {}
         if world == 1:
             result["modes"] = {"f32": extra(render_bench, args, ctx, False, "f32", 2, 1, keep=("roofline_hbm_kernels",))}

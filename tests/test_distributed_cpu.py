@@ -104,3 +104,36 @@ def test_two_rank_gradient_allreduce():
     for rank, p in enumerate(procs):
         out, _ = p.communicate(timeout=240)
         assert p.returncode == 0 and f"ok {rank}" in out, out
+
+
+def test_bench_self_launch_at_two_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py starts its own ranks as a child
+    `torch.distributed.run`, relays rank 0's ONE JSON line and its exit code.  The plumbing-only step (a sleep) runs the
+    rendezvous, the verified all-reduce (`collective_ranks`), the barrier-bracketed max-over-ranks timing and the
+    per-rank spread without a GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ANR_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--plumbing-only"], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout                      # ONE line on stdout, whatever the children printed
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["collective_ranks"] == 2 and line["collective_backend"] == "gloo"
+    assert line["steps"] == 3 and line["warmup"] == 1 and line["all_ranks_ok"] is True
+    spread = line["rank_ms_per_step"]
+    # rank 1 sleeps twice as long as rank 0; the job's clock is the slowest rank's
+    assert 9.0 < spread["min"] < spread["max"] and 19.0 < spread["max"] <= line["ms_per_step"] + 1e-6
+    assert abs(line["value"] - 2 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    """a child that cannot start its backend (nccl without a GPU here) must surface as a non-zero exit code and no line"""
+    import torch
+    if torch.cuda.device_count() > 0:
+        return                                            # on a GPU box RCCL comes up: covered by the -m gpu tests
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "ANR_BENCH_BACKEND")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--plumbing-only"], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode != 0 and p.stdout.strip() == ""

@@ -663,3 +663,26 @@ def test_two_process_training_step_averages_gradients(dev):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "rank 0: ok" in r.stdout and "rank 1: ok" in r.stdout
+
+
+def test_bench_self_launch_two_ranks_on_one_device(dev):
+    """`python bench.py --gpus 2` without a launcher: bench.py starts both ranks itself (child torch.distributed.run),
+    they render on this box's one GPU with gloo as the collective backend, and exactly one valid line comes back with the
+    extras of the N > 1 branch (strong-scaling slices, the training step with its gradient buckets)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ANR_BENCH_BACKEND="gloo", ANR_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--hw", "256", "--cpu-rays", "0", "--no-psnr"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["collective_ranks"] == 2 and line["scaling"] == "weak"
+    assert line["unit"] == "rays/s" and line["value"] > 0 and line["roofline"]["frac"] > 0
+    assert abs(line["value"] - 2 * 256 * 256 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    assert line["rank_ms_per_step"]["max"] <= line["ms_per_step"] + 1e-6
+    w = line["workloads"]
+    assert set(w) == {"cfg2_strong", "cfg3", "cfg3_strong", "cfg4", "cfg5"} and not any("error" in v for v in w.values()), w
+    assert w["cfg2_strong"]["scaling"] == "strong" and w["cfg4"]["n_gpus"] == 2
