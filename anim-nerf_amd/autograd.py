@@ -42,6 +42,16 @@ def weights_generation(first_param, backward: bool = False) -> int:
     return st[0]
 
 
+def bump_generation(params):
+    """Call after an optimiser step that may not have bumped the parameters' version counters (torch's fused Adam does
+    not): raises the counters themselves, which every weight-pack cache — `_cached_pack` here, `NeRF.weight_pack` on the
+    inference side — is keyed by.  `Trainer.step` does it; the call-order heuristic of `weights_generation` stays as the
+    fallback for loops that do not."""
+    params = [p for p in params if isinstance(p, torch.Tensor)]
+    if params:
+        torch.autograd.graph.increment_version(params)
+
+
 def _cached_pack(params, mode_id, backward):
     """Fragment-ordered weight pack for the forward / activation-gradient kernels, rebuilt only when a parameter changed:
     one pack per network and optimiser step, not one per ray chunk.  Keyed by the parameter OBJECTS (weak references: a
@@ -110,9 +120,9 @@ class FeatureFunction(torch.autograd.Function):
 
 
 class GradSink:
-    """One flat fp32 gradient buffer for the 22 tensors of a NeRF, in PARAM_KEYS order — the layout anr_mlp_wgrad writes.
+    """One flat fp32 gradient buffer for the 24 tensors of a NeRF, in PARAM_KEYS order — the layout anr_mlp_wgrad writes.
     `p.grad` of every parameter is a VIEW into it, and each MLP backward pass adds its weight gradients with one
-    accumulating launch (ANR_MLP_FLAG_ACCUMULATE) instead of handing 22 tensors to autograd, which would add them to
+    accumulating launch (ANR_MLP_FLAG_ACCUMULATE) instead of handing 24 tensors to autograd, which would add them to
     `.grad` one by one (three passes per network and step: render, sigma priors, normals — ~90 launches).
     A bucket of `training.GradientReducer` is exactly this buffer, so the all-reduce sends it as it is.
 
@@ -164,7 +174,7 @@ def _split_flat(flat, upto=len(PARAM_KEYS)):
 
 
 class MLPFunction(torch.autograd.Function):
-    """out[n,4] = (r,g,b,sigma) (or sigma[n]) = NeRF(pts[n,4]); differentiable w.r.t. the 22 parameter tensors (and the
+    """out[n,4] = (r,g,b,sigma) (or sigma[n]) = NeRF(pts[n,4]); differentiable w.r.t. the 24 parameter tensors (and the
     points).  Forward, activation gradients and weight gradients are three hand-written HIP kernels
     (anr_mlp_forward_save, anr_mlp_backward, anr_mlp_wgrad), the steps around them one launch each (csrc/train_glue.hip);
     `LIBRARY_GEMMS = True` swaps the backward kernels for the chain of library GEMMs they replaced (a cross-check for the

@@ -9,8 +9,10 @@ Pose refinement (`optim_body_params`, train.py:141-144,221-222): pass a `BodyMod
 up per frame, gradients reach them through the differentiable warp (autograd.WarpFunction) and per-frame chain, and
 they join the optimiser at half the learning rate and the same gradient all-reduce.
 
-The normals regulariser (train.py:288-309) differentiates d alpha/d xyz a second time; that small side computation
-(template vertices only) runs on torch autograd over library GEMMs (`NeRF.get_normal`), not on the fused kernels.
+The normals regulariser (train.py:288-309) differentiates d alpha/d xyz a second time: the three directional derivatives
+ride through the fused forward / activation-gradient / weight-gradient kernels as forward-mode tangent columns
+(`autograd.NormalFunction` / `QuadSigmaFunction`, ANR_MLP_FLAG_TANGENT), and the loss kernels (`anr_train_loss*`) apply
+the normalisation and the MSE.
 """
 from __future__ import annotations
 
@@ -78,8 +80,9 @@ class BodyModelParams(nn.Module):
 
 def compute_loss(anim_nerf, hp: TrainHParams, rgbs, alphas, results, fg_points=None, bg_points=None):
     """train.py:228-286 (rgb MSE, alpha L1, foreground / background sigma priors), coarse and fine."""
+    fine_net = hp.n_importance > 0 and not hp.share_fine       # a coarse-only model has no `nerf_fine` to probe
     if (hp.fused_losses and rgbs.is_cuda and hasattr(anim_nerf, "_net") and torch.is_grad_enabled()
-            and all(anim_nerf._net(f)._hip_supported() for f in (False, True))):
+            and all(anim_nerf._net(f)._hip_supported() for f in ((False, True) if fine_net else (False,)))):
         return _compute_loss_fused(anim_nerf, hp, rgbs, alphas, results, fg_points, bg_points)
     details: Dict[str, torch.Tensor] = {}
     fine = hp.n_importance > 0 and not hp.share_fine
@@ -199,8 +202,9 @@ class GradientReducer:
     def __init__(self, buckets, world: Optional[int] = None):
         import torch.distributed as dist
         self.dist = dist
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        self.world = world or (dist.get_world_size() if self.active else 1)
+        self._world_arg = world
+        self.active, self.world = False, 1                   # decided per step in prepare(): the process group may be
+        self._probe()                                         # initialised after the Trainer was built
         self.buckets = [list(b) for b in buckets if len(b)]
         self.flat, self.slot = [], {}                         # slot[p] = (bucket index, p's view into the bucket's buffer)
         for bi, b in enumerate(self.buckets):
@@ -210,14 +214,18 @@ class GradientReducer:
                 self.slot[p] = (bi, flat[o:o + p.numel()].view_as(p))
                 o += p.numel()
             self.flat.append(flat)
-        if self.active:
-            for p in self.slot:
-                p.register_post_accumulate_grad_hook(self._arrived)
+        for p in self.slot:
+            p.register_post_accumulate_grad_hook(self._arrived)
         self._pending, self._next, self._handles = [], 0, []
         self.sinks = []
 
+    def _probe(self):
+        dist = self.dist
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = self._world_arg or (dist.get_world_size() if self.active else 1)
+
     def attach_sink(self, net):
-        """If the 22 tensors of `net` lie back to back in PARAM_KEYS order in one bucket, make that stretch the network's
+        """If the 24 tensors (PARAM_KEYS) of `net` lie back to back in PARAM_KEYS order in one bucket, make that stretch the network's
         GradSink: its MLP backward passes accumulate straight into the send buffer and report completion per network."""
         from .autograd import PARAM_KEYS, GradSink
         named = dict(net.named_parameters())
@@ -241,13 +249,24 @@ class GradientReducer:
         return sink
 
     def _sink_done(self, bi, k):
+        """the network's last announced backward pass has added its gradients: its k tensors have arrived"""
         if self.active:
-            self._pending[bi] -= k
+            self._take(bi, k)
             self._issue_ready()
+
+    def _take(self, bi, k):
+        if bi < self._next:
+            raise RuntimeError(f"a gradient for bucket {bi} arrived after its all-reduce was issued: a backward pass on a "
+                               "sink-attached network delivered gradients through autograd after the sink had reported "
+                               "completion (announce() every pass in its forward, or detach the sink)")
+        self._pending[bi] -= k
+        assert self._pending[bi] >= 0, (bi, self._pending)
 
     def prepare(self):
         """Before backward: zero the send buffers and point every p.grad at its slice."""
+        self._probe()
         self._pending = [len(b) for b in self.buckets]
+        self._sink_params = {id(p) for s in self.sinks for p in s.params}
         self._next, self._handles = 0, []
         for flat in self.flat:
             flat.zero_()
@@ -262,16 +281,27 @@ class GradientReducer:
             self._next += 1
 
     def _arrived(self, p):
+        if not self.active or not self._pending:
+            return
         bi, view = self.slot[p]
         if p.grad is not view:                                # a caller reset .grad after prepare(): move the value in
             view.copy_(p.grad)
             p.grad = view
-        self._pending[bi] -= 1
+        if id(p) in self._sink_params:
+            # a sink-owned tensor that autograd delivered itself (FeatureFunction, a pass that found the sink unusable).
+            # Its arrival is counted ONCE, by the sink's completion (all k tensors together), never here: the hook only
+            # checks that the bucket has not left yet.  A network whose passes all bypass the sink is sent by finish().
+            self._take(bi, 0)
+            return
+        self._take(bi, 1)
         self._issue_ready()
 
     def finish(self):
         """After backward: issue what is left (in order), wait, average.  Returns the number of floats reduced."""
         if not self.active:
+            if self.dist.is_available() and self.dist.is_initialized() and self.dist.get_world_size() > 1:
+                raise RuntimeError("the process group came up between prepare() and finish(): gradients of this step "
+                                   "were not set up for reduction")
             return 0
         self._issue_ready(force=True)
         for h in self._handles:
@@ -339,6 +369,10 @@ class Trainer:
         loss.backward()                                       # full buckets are all-reduced while this is still running
         self.reducer.finish()
         self.optimizer.step()
+        # torch's fused Adam updates in place WITHOUT bumping the tensors' version counters; every cached weight pack
+        # (training, backward, inference) is keyed by them.  A loop that steps a fused optimiser itself must do the same.
+        from .autograd import bump_generation
+        bump_generation(self.params)
         with torch.no_grad():
             key = "rgbs_fine" if "rgbs_fine" in results else "rgbs"
             details["psnr"] = -10.0 * torch.log10(F.mse_loss(results[key], rgbs))

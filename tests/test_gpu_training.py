@@ -246,6 +246,51 @@ def test_adam_steps_reduce_loss(dev, smpl_table):
         assert torch.equal(cached, m.nerf.eval_points(pts))
 
 
+def test_coarse_only_trainer_and_forward_between_backward_and_step(dev, smpl_table):
+    """(a) a model without a fine network (use_fine=False, n_importance=0) trains through the fused loss path — there is no
+    `nerf_fine` to probe; (b) a forward pass between `backward()` and `optimizer.step()` (an eval render, a gradient-norm
+    probe) must not leave any weight-pack cache stale: Trainer.step raises the version counters after the fused Adam."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    torch.manual_seed(3)
+    m = ana.AnimNeRF(body_model_table=smpl_table, freqs_dir=0, use_view=False, use_unpose=True, use_fine=False).to(dev)
+    assert not hasattr(m, "nerf_fine")
+    with torch.no_grad():
+        m.nerf.sigma.weight.mul_(300.0)
+    hp = ana.TrainHParams(n_samples=16, n_importance=0, chunk=512, lr=1e-3)
+    tr = ana.Trainer(m, ana.VolumeRenderer(n_coarse=16, n_fine=0), hp)
+    c2w, focal, cen = syn.pinhole_camera(8, 8)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), 8, 8, focal.tolist(), 0.1, 10.0, cen.tolist())[None]
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=2).items()}
+    gen = torch.Generator().manual_seed(0)
+    tgt, alp = torch.rand(1, 8, 8, 3, generator=gen).to(dev), torch.ones(1, 8, 8, 1, device=dev)
+    fg = (torch.rand(1, 64, 3, generator=gen) * 0.4 - 0.2).to(dev)
+    bg = (torch.rand(1, 64, 3, generator=gen) * 2 - 1).to(dev)
+    loss, details = tr.step(rays, tgt, alp, pose, _templ(dev), fg, bg, perturb=0.0)
+    assert torch.isfinite(loss) and "loss_rgb_fine" not in details and "loss_normals" in details
+    # (b) by hand: forward, backward, a probing forward, THEN the optimiser step
+    pts = torch.cat([torch.rand(256, 3, device=dev) * 2 - 1, torch.ones(256, 1, device=dev)], -1)
+    versions = [p._version for p in tr.params]
+    tr.begin_step()
+    res = ana.system_forward(tr.renderer, m, rays, pose, _templ(dev), perturb=0.0, chunk=hp.chunk)
+    ana.compute_loss(m, hp, tgt, alp, res, fg, bg)[0].backward()
+    with torch.no_grad():
+        before = m.nerf.eval_points(pts).clone()          # consumes the call-order heuristic's "a backward ran" flag
+    tr.optimizer.step()
+    from anim_nerf_amd.autograd import bump_generation
+    bump_generation(tr.params)
+    assert all(p._version > v for p, v in zip(tr.params, versions))
+    with torch.no_grad():
+        after = m.nerf.eval_points(pts)
+        m.nerf._pack_cache.clear()
+        fresh = m.nerf.eval_points(pts)
+    assert torch.equal(after, fresh) and not torch.equal(after, before)
+    # and the training-side pack: one more step must see the updated weights (loss changes from step to step)
+    l2 = tr.step(rays, tgt, alp, pose, _templ(dev), fg, bg, perturb=0.0)[0]
+    l3 = tr.step(rays, tgt, alp, pose, _templ(dev), fg, bg, perturb=0.0)[0]
+    assert l2.item() != l3.item()
+
+
 def test_bf16_training_gradients_close_to_fp32(dev, smpl_table):
     """Mixed precision (bf16 forward, bf16 activations and GEMM inputs, fp32 accumulation): gradient direction is kept."""
     m = seeded_model(smpl_table, 7, True, gain=50.0, device=dev)
