@@ -95,7 +95,7 @@ class FeatureFunction(torch.autograd.Function):
         out, act = ops.mlp_forward_save(_cached_pack(params, mode_id, False), mode_id, pts)
         ctx.mode_id, ctx.n = mode_id, n
         ctx.save_for_backward(pts, act, *params)
-        return out[:n, 3].contiguous(), act[:n, 2048:2304].float()
+        return out[:n, 3].contiguous(), ops.act_columns(act, 2048, 2304)[:n].float()
 
     @staticmethod
     @torch.no_grad()
@@ -279,7 +279,7 @@ def _library_backward(ctx, params, pts, act, g4, want_pts):
             self[k] = p if p.dtype == dt else p.to(dt)
             return self[k]
     P = _Lazy()
-    H = act[:, :2048].view(n, 8, 256)
+    H = ops.act_columns(act, 0, 2048).view(n, 8, 256)
     grads = {}
 
     def wgrad(dy, x):                                               # accumulated and returned in fp32
@@ -294,7 +294,7 @@ def _library_backward(ctx, params, pts, act, g4, want_pts):
         dh = g_sig[:, None] * P["sigma.weight"]
     else:
         d_rgb = g4[:, :3].to(dt)
-        G, F = act[:, 2304:2432], act[:, 2048:2304]
+        G, F = ops.act_columns(act, 2304, 2432), ops.act_columns(act, 2048, 2304)
         grads["rgb.0.weight"] = wgrad(d_rgb, G)
         grads["rgb.0.bias"] = g4[:, :3].sum(0)
         dG = relu_bwd(d_rgb @ P["rgb.0.weight"], G)

@@ -3,10 +3,13 @@
 //     dh'_{l-1} = (W_l^T dh'_l) . 1[h_{l-1}>0]    l = 8..2          (models/nerf.py:129-175 differentiated)
 // as ONE kernel built like the forward one (mlp_core.h): transposed GEMMs on the matrix cores with the points as
 // columns, the gradient fragments never leaving registers between the 10 GEMMs, W^T tiles streamed L2 -> LDS through
-// the same 3-slot LDS-DMA ring, persistent workgroups.  The ReLU masks come from the activations the training forward
-// saved (anr_mlp_forward_save), read in exactly the 8-byte pieces it wrote; every pre-activation gradient is written
-// in the same [point][2432] layout (dact), which is what the weight-gradient GEMMs (dW_l = dact_l^T act_{l-1},
-// library split-K) consume.  22 library GEMMs + 11 mask kernels of the first version become this launch + the dW GEMMs.
+// the same 3-slot LDS-DMA ring, persistent workgroups.  The ReLU gates are the sign bits the training forward left behind
+// each row (anr_mlp_forward_save: 16 bytes per row half and layer); a wave gathers them for the NEXT stage with one more
+// LDS-DMA instruction (per-lane source address, its own 1 KiB of LDS) issued next to the weight chunk, so that no ordinary
+// load — whose wait would drain the kernel's stores — sits in the steady state.  Every pre-activation gradient is written
+// in the same blocked layout as the activations (dact: mlp_core.h), which is what the weight-gradient kernel
+// (dW_l = dact_l^T act_{l-1}) consumes.
+// The stores are never waited for: the wait in front of a barrier is `vmcnt(stores issued since the DMA it needs)`.
 //
 // Tile schedule (76 out-tiles of 32 rows): 0-3 rgb^T (K = 3, padded to one fragment group), 4-11 dir^T (K = 128),
 // 12-19 final^T (+ the rank-1 sigma term as the C operand of the first MFMA), 20-75 trunk layers 8..2 transposed.
@@ -25,7 +28,7 @@ template <class C> __host__ __device__ constexpr int bfrag_offset(int t) {
     return n;
 }
 template <class C> constexpr int btotal_frags() { return bfrag_offset<C>(BWD_TILES); }
-// column (in a [2432]-wide row) of the activation whose sign gates out-tile t, and where its result is stored
+// column (block = column / 32 of the blocked buffers) of the activation whose sign gates out-tile t, and where its result is stored
 __host__ __device__ constexpr int bcol(int t) {
     return t < 4 ? 2304 + 32 * t : t < 12 ? 2048 + 32 * (t - 4) : 256 * (7 - (t - 12) / 8) + 32 * ((t - 12) % 8);
 }
@@ -65,22 +68,69 @@ struct MlpBwd {
     f32x16 acc[2][NT];
     Frag w0[4];
     unsigned mk[2][NT];          // sign bits (16: four quarters x four rows) of tile c (parity) and of tile c-1 (pending epilogue)
-    unsigned mkg[NT][4];         // ... of the 8 (4) blocks of the current stage: one 16-byte (8-byte) load per lane and stage
-    const ActT* act_row[NT];
-    ActT* dact_row[NT];
+    unsigned mkg[NT][4];         // ... of the 8 (4) blocks of the current stage: one 16-byte LDS read per lane and stage
+    const char* act_base;        // the saved activations (only their sign bits are read here) and the gradient buffer: R rows
+    char* dact_base;
+    int64_t R;
+    BlockWalk dact_blk;          // the block of dact the next epilogue stores into (mlp_core.h)
+    unsigned gate_off[NT];       // row * 32 + 16 * half of the row whose sign bits gate this lane's column, and of the next point tile's
+    unsigned gate_off_next[NT];
+    unsigned dact_off[NT];       // byte offset of this lane's row (+ 4*half features) inside a block of dact (rows past the end
+                                 // alias the last row: same values, same bytes)
+    char* lds_bits;              // this wave's [2 buffers][NT][64 lanes x 16 B] of gathered sign bits
+    static constexpr int ESZ = sizeof(ActT);
 
-    template <int W> __device__ __forceinline__ void load_stage_bits(int n) {
-        const char* p = act_bits(act_row[n], half, W);
-        if constexpr (W < 72) {
-            const uint4 v = *reinterpret_cast<const uint4*>(p);
-            mkg[n][0] = v.x; mkg[n][1] = v.y; mkg[n][2] = v.z; mkg[n][3] = v.w;
-        } else {
-            const uint2 v = *reinterpret_cast<const uint2*>(p);
-            mkg[n][0] = v.x; mkg[n][1] = v.y;
+    // ---- the sign-bit groups ("bit stages") one point tile consumes, in order: START = 0: the colour head's (block 72, tile
+    // 0), then h8 (blocks 56.., tile 12), h7 (tile 20) ... h1 (tile 68); START = 12: h8 (tile 12) ...; START = 20: h8 (the
+    // prologue), h7 (tile 20) ...  Stage k lives in buffer k & 1.
+    static constexpr int NBITS = START == 0 ? 9 : 8;
+    static constexpr int LAST_ADV = BWD_TILES - TPC;                    // the tile in front of which the last advance() runs
+    static __host__ __device__ constexpr int bits_w(int k) { return START == 0 ? (k == 0 ? 72 : 64 - 8 * k) : 56 - 8 * k; }
+    static __host__ __device__ constexpr int bits_tile(int k) {
+        return START == 0 ? (k == 0 ? 0 : 4 + 8 * k) : START == 12 ? 12 + 8 * k : (k == 0 ? -1 : 12 + 8 * k);
+    }
+    static __host__ __device__ constexpr int bits_stage_of_w(int w) { return START == 0 ? (w == 72 ? 0 : (64 - w) / 8) : (56 - w) / 8; }
+    // a gather issued by the advance() in front of tile X has landed once the NEXT advance() has waited (it is older than
+    // the weight chunk that one waits for): stage k is issued one chunk ahead of the tile that reads it, wrapping into the
+    // previous point tile (then for the next tile's rows) for the stages read at the start
+    static __host__ __device__ constexpr bool bits_wrapped(int k) { return bits_tile(k) - TPC < FIRST; }
+    static __host__ __device__ constexpr int bits_issue_tile(int k) {
+        if (bits_tile(k) < 0) return LAST_ADV - TPC;                    // the prologue reads it before the first advance()
+        return bits_wrapped(k) ? bits_tile(k) - TPC + (BWD_TILES - FIRST) : bits_tile(k) - TPC;
+    }
+    template <int K> __device__ __forceinline__ void issue_bits(const unsigned (&rows)[NT]) {
+        constexpr int W = bits_w(K);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            // the head's four blocks are 8 bytes per half-wave: both halves fetch the row's 16 and pick their own on the way out
+            const char* src = act_base + act_bits_off(R, ESZ, W) + (W < 72 ? rows[n] : (rows[n] >> 1) - 8 * half);
+            const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_bits + (((K & 1) * NT + n) << 10);
+            dma16(src, dst);
         }
     }
-    __device__ __forceinline__ void advance() {
-        dma_wait();
+    template <int K> __device__ __forceinline__ void read_bits(int n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(lds_bits + (((K & 1) * NT + n) << 10) + lane * 16);
+        if constexpr (bits_w(K) < 72) {
+            mkg[n][0] = v.x; mkg[n][1] = v.y; mkg[n][2] = v.z; mkg[n][3] = v.w;
+        } else {
+            mkg[n][0] = half ? v.z : v.x; mkg[n][1] = half ? v.w : v.y;
+        }
+    }
+    // the uint16 of block J of the stage in mkg; bf16: its two bytes spread to bytes 0 and 2 (what MaskEpi shifts)
+    template <int J> __device__ __forceinline__ unsigned block_mask(int n) const {
+        if constexpr (C::IS_BF16) return __builtin_amdgcn_perm(0u, mkg[n][J / 2], (J & 1) ? 0x0c030c02u : 0x0c010c00u);
+        else return (mkg[n][J / 2] >> (16 * (J & 1))) & 0xffffu;
+    }
+    // stores issued between the DMA of the chunk the advance() in front of tile T waits for and that wait: the epilogues
+    // of the chunk before (the vector-memory counter retires in issue order; a lower bound is always safe)
+    static __host__ __device__ constexpr int stores_since_dma(int T) {
+        const int first = T == FIRST ? BWD_TILES - TPC : T - TPC, last = T == FIRST ? BWD_TILES - 1 : T - 1;
+        int n = 0;
+        for (int U = first; U <= last; ++U) n += (U - 1 >= FIRST) ? (C::IS_BF16 ? 2 : 4) : 0;
+        return n * NT;
+    }
+    template <int T> __device__ __forceinline__ void advance() {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(stores_since_dma(T)) : "memory");
         __syncthreads();
         if (c + 2 < NCHUNK || more) {
             if (c + 2 == NCHUNK) gnext = gbase;
@@ -88,6 +138,13 @@ struct MlpBwd {
             stage_chunk<true, WAVES>(gnext, lds_base, slot_stage, nf, wave, lane);
             gnext += nf * FRAG_BYTES;
         }
+        static_for<NBITS>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (bits_issue_tile(k) == T) {
+                if constexpr (bits_wrapped(k)) { if (more) issue_bits<k>(gate_off_next); }
+                else issue_bits<k>(gate_off);
+            }
+        });
     }
     __device__ __forceinline__ void rotate() {
         unsigned t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_stage; slot_stage = t;
@@ -103,9 +160,15 @@ struct MlpBwd {
         const f32x16 (&a)[NT];
         Frag (&Y)[NT][YF];
         const unsigned (&m)[NT];
-        ActT* const (&dr)[NT];
+        BlockWalk& db;                   // the block of dact this tile's result goes to, the lane's offset inside a block
+        const unsigned (&dof)[NT];
         int half;
         template <int Q> __device__ __forceinline__ void part() const {
+            parts<Q>();
+            // on to the block of the next tile of the chain (the schedule walks the blocks in a static order)
+            if constexpr (Q == 3 && TG + 1 < BWD_TILES) db.template step<bcol(TG + 1) / 32 - bcol(TG) / 32>();
+        }
+        template <int Q> __device__ __forceinline__ void parts() const {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 if constexpr (C::IS_BF16) {
@@ -119,9 +182,11 @@ struct MlpBwd {
                         const f32x2 v2 = {a[n][4 * Q + 2 * i], a[n][4 * Q + 2 * i + 1]};
                         pk[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16x2));
                         if (bmasked(TG)) {
-                            // sign bits saved by the forward: bit 4Q + 2i (+1) <-> the low (high) half of this dword
-                            const unsigned b2 = (m[n] >> (4 * Q + 2 * i)) & 3u;
-                            pk[i] &= (b2 & 1u) * 0x0000ffffu | (b2 >> 1) * 0xffff0000u;
+                            // sign flags saved by the forward, spread by tile(): pair k = 2Q + i has its two flags at bits
+                            // 7 - k and 23 - k; << (8 + k) puts them on top of the 16-bit halves, >> 15 (arithmetic, per
+                            // half) makes them the masks
+                            const s16x2 top = __builtin_bit_cast(s16x2, m[n] << (8 + 2 * Q + i));
+                            pk[i] &= __builtin_bit_cast(unsigned, top >> 15);
                         }
                     }
                     Frag& dst = Y[n][TB + (4 * Q) / EPF];
@@ -139,8 +204,7 @@ struct MlpBwd {
                         constexpr int pd = ((4 * (Q - 1)) % EPF) / 2;
                         const auto s0 = __builtin_amdgcn_permlane32_swap(prev[pd], pk[0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(prev[pd + 1], pk[1], false, false);
-                        if (dr[n] != nullptr)
-                            *reinterpret_cast<uint4*>(dr[n] + bcol(TG) + 16 * (Q >> 1) + 4 * half) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        *reinterpret_cast<g_uint4*>(db.p + dof[n] + (16 * (Q >> 1) + 4 * half) * ESZ) = u32x4n{s0[0], s1[0], s0[1], s1[1]};
                     }
 #endif
                 } else {
@@ -148,12 +212,12 @@ struct MlpBwd {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float v = a[n][4 * Q + i];
-                        if (bmasked(TG)) v = ((m[n] >> (4 * Q + i)) & 1u) ? v : 0.0f;
+                        if (bmasked(TG)) v = ((m[n] >> act_sign_bit(Q, i)) & 1u) ? v : 0.0f;
                         put(Y[n][TB + (4 * Q + i) / EPF], (4 * Q + i) % EPF, v);
                         keep[i] = v;
                     }
                     if ((4 * Q + 4) % EPF == 0) pin(Y[n][TB + (4 * Q) / EPF]);
-                    if (dr[n] != nullptr) *reinterpret_cast<f32x4*>(dr[n] + bcol(TG) + 8 * Q) = keep;
+                    *reinterpret_cast<g_f32x4*>(db.p + dof[n] + 8 * Q * ESZ) = keep;
                 }
             }
         }
@@ -168,7 +232,7 @@ struct MlpBwd {
         constexpr int POS = (T - FIRST) % TPC;
         constexpr int OFF = (POS == 0) ? 0 : btile_frags<C>(T - 1);
         constexpr bool END = (T == LAST);
-        if constexpr (POS == 0) advance();
+        if constexpr (POS == 0) advance<T>();
         const Frag* cur = reinterpret_cast<const Frag*>(lds_base + slot_cur) + OFF * 64 + lane;
         const Frag* nxt = (POS + 1 < TPC && !END) ? cur + NF * 64 : reinterpret_cast<const Frag*>(lds_base + slot_nxt) + lane;
         // the saved activations that gate THIS tile's result (used by its epilogue, one tile later)
@@ -176,8 +240,8 @@ struct MlpBwd {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 constexpr int w = bcol(T) / 32, j = w < 72 ? w % 8 : w - 72;
-                if constexpr (j == 0) load_stage_bits<w>(n);
-                mk[PAR][n] = (mkg[n][j / 2] >> (16 * (j & 1))) & 0xffffu;
+                if constexpr (j == 0) read_bits<bits_stage_of_w(w)>(n);
+                mk[PAR][n] = block_mask<j>(n);
             }
         }
         // C operand: zero, except the rank-1 sigma term on the final^T tiles
@@ -240,14 +304,14 @@ struct MlpBwd {
             if constexpr (t == 0) {
                 tile<T0 + t, NF, XF>(X, first, dsig);
             } else {
-                tile<T0 + t, NF, XF>(X, MaskEpi<YF, (t - 1) * FPT, T0 + t - 1>{acc[PAR ^ 1], Y, mk[PAR ^ 1], dact_row, half}, dsig);
+                tile<T0 + t, NF, XF>(X, MaskEpi<YF, (t - 1) * FPT, T0 + t - 1>{acc[PAR ^ 1], Y, mk[PAR ^ 1], dact_blk, dact_off, half}, dsig);
             }
         });
     }
     template <int T0, int NTILES, int YF>
     __device__ __forceinline__ auto last_of(Frag (&Y)[NT][YF]) {
         constexpr int T = T0 + NTILES - 1;
-        return MaskEpi<YF, (NTILES - 1) * FPT, T>{acc[T & 1], Y, mk[T & 1], dact_row, half};
+        return MaskEpi<YF, (NTILES - 1) * FPT, T>{acc[T & 1], Y, mk[T & 1], dact_blk, dact_off, half};
     }
 
     __device__ __forceinline__ void run(const char* __restrict__ pack, const float4* __restrict__ g, const ActT* __restrict__ act,
@@ -265,12 +329,36 @@ struct MlpBwd {
         gbase = pack + BWD_TABLE_BYTES + bfrag_offset<C>(FIRST) * FRAG_BYTES;
         for (int i = threadIdx.x; i < BWD_TABLE_BYTES / 16; i += THREADS)
             reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(pack)[i];
+        lds_bits = lds + BWD_TABLE_BYTES + 3 * SLOT + wave * (2 * NT * 1024);
         gnext = gbase;
         stage_chunk<true, WAVES>(gnext, lds_base, slot_cur, chunk_frags(0), wave, lane);
         gnext += chunk_frags(0) * FRAG_BYTES;
         stage_chunk<true, WAVES>(gnext, lds_base, slot_nxt, chunk_frags(1), wave, lane);
         gnext += chunk_frags(1) * FRAG_BYTES;
         bool first = true;
+        // rows of point tile `t`: a lane past the end aliases the last row (it recomputes and rewrites that row's values:
+        // every wave issues the same stores whatever n is — advance() counts them)
+        auto rows_of = [&](int64_t t, int n) {
+            const int64_t idx = (t * WAVES + wave) * (NT * 32) + n * 32 + (lane & 31);
+            return idx < n_pts ? idx : n_pts - 1;
+        };
+        // tangent mode: the ReLU gates of a quad's four columns are the primal column's (row 4p)
+        auto gate_row = [&](int64_t cl) { return (unsigned)(tangent ? (cl & ~(int64_t)3) : cl) * 32u + 16u * half; };
+        act_base = reinterpret_cast<const char*>(act);
+        dact_base = reinterpret_cast<char*>(dact);
+        R = n_pts;
+        float4 g_next[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int64_t cl = rows_of(blockIdx.x, n);
+            g_next[n] = g[cl];
+            gate_off_next[n] = gate_row(cl);
+        }
+        // the first point tile's own opening bit stages (later ones are gathered from inside the tile before)
+        static_for<NBITS>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (bits_wrapped(k)) issue_bits<k>(gate_off_next);
+        });
 
         for (int64_t pt = blockIdx.x; pt < n_tiles; pt += gridDim.x) {
             more = pt + gridDim.x < n_tiles;
@@ -279,13 +367,15 @@ struct MlpBwd {
             float4 gin[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                const int64_t idx = (pt * WAVES + wave) * (NT * 32) + n * 32 + (lane & 31);
-                const int64_t cl = idx < n_pts ? idx : n_pts - 1;
-                gin[n] = g[cl];
+                gin[n] = g_next[n];
                 dsig[n] = gin[n].w;
-                // tangent mode: the ReLU gates of a quad's four columns are the primal column's (row 4p)
-                act_row[n] = act + (tangent ? (cl & ~(int64_t)3) : cl) * ACT_PITCH + 4 * half;
-                dact_row[n] = idx < n_pts ? dact + idx * ACT_PITCH + 4 * half : nullptr;
+                gate_off[n] = gate_off_next[n];
+                dact_off[n] = ((unsigned)rows_of(pt, n) * 32 + 4 * half) * ESZ;
+                if (more) {                                   // the next tile's upstream gradient arrives under this tile's MFMAs
+                    const int64_t cl = rows_of(pt + gridDim.x, n);
+                    g_next[n] = g[cl];
+                    gate_off_next[n] = gate_row(cl);
+                }
             }
             if (first) {
                 dma_wait();
@@ -294,6 +384,9 @@ struct MlpBwd {
                 for (int q = 0; q < 4; ++q) w0[q] = (reinterpret_cast<const Frag*>(lds_base + slot_cur) + lane)[q * 64];
                 first = false;
             }
+            // the first epilogue of the chain: tile 0 (rgb^T), 4 (FEATURE: d feature enters through dir^T's), 12 (sigma only)
+            dact_blk.stride = act_block_off(R, ESZ, 1);
+            dact_blk.reset(dact_base, bcol(FEATURE ? 4 : SIGMA_ONLY ? 12 : 0) / 32);
             Frag A[NT][HF], B[NT][HF];
             if constexpr (FEATURE) {
                 // dF comes from outside (fp32 [n][256]): through the epilogue of the stage that would have produced it —
@@ -303,8 +396,7 @@ struct MlpBwd {
                     constexpr int j = decltype(jc)::value;
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        const int64_t idx = (pt * WAVES + wave) * (NT * 32) + n * 32 + (lane & 31);
-                        const float* src = dfeat + (idx < n_pts ? idx : n_pts - 1) * 256 + 32 * j + 4 * half;
+                        const float* src = dfeat + rows_of(pt, n) * 256 + 32 * j + 4 * half;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const f32x4 v = *reinterpret_cast<const f32x4*>(src + 8 * q);
@@ -312,18 +404,18 @@ struct MlpBwd {
                             for (int i = 0; i < 4; ++i) acc[0][n][4 * q + i] = v[i];
                         }
                     }
-                    MaskEpi<HF, j * FPT, 4 + j> epi{acc[0], A, mk[0], dact_row, half};
+                    MaskEpi<HF, j * FPT, 4 + j> epi{acc[0], A, mk[0], dact_blk, dact_off, half};
                     epi.template part<0>(); epi.template part<1>(); epi.template part<2>(); epi.template part<3>();
                 });
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    if (dact_row[n] != nullptr)
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                if constexpr (C::IS_BF16) *reinterpret_cast<uint2*>(dact_row[n] + bcol(t) + 8 * q) = make_uint2(0u, 0u);
-                                else *reinterpret_cast<f32x4*>(dact_row[n] + bcol(t) + 8 * q) = f32x4{0.f, 0.f, 0.f, 0.f};
+                                char* dst = dact_base + act_block_off(R, ESZ, bcol(t) / 32) + dact_off[n] + 8 * q * ESZ;
+                                if constexpr (C::IS_BF16) *reinterpret_cast<uint2*>(dst) = make_uint2(0u, 0u);
+                                else *reinterpret_cast<f32x4*>(dst) = f32x4{0.f, 0.f, 0.f, 0.f};
                             }
                 layer<12, 8, HF, HF, HF>(A, B, NoEpi{}, dsig);                              // final^T: dF -> dh8' (B)
                 layer<20, 8, HF, HF, HF>(B, A, last_of<12, 8, HF>(B), dsig);                // W8^T   : dh8' -> dh7' (A)
@@ -358,10 +450,10 @@ struct MlpBwd {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) acc[0][n][4 * q + i] = w4[i] * dsig[n];
                         }
-                        if constexpr (j == 0) load_stage_bits<bcol(12) / 32>(n);
-                        mk[0][n] = (mkg[n][j / 2] >> (16 * (j & 1))) & 0xffffu;
+                        if constexpr (j == 0) read_bits<0>(n);
+                        mk[0][n] = block_mask<j>(n);
                     }
-                    MaskEpi<HF, j * FPT, 12 + j> epi{acc[0], B, mk[0], dact_row, half};
+                    MaskEpi<HF, j * FPT, 12 + j> epi{acc[0], B, mk[0], dact_blk, dact_off, half};
                     epi.template part<0>(); epi.template part<1>(); epi.template part<2>(); epi.template part<3>();
                 });
                 layer<20, 8, HF, HF, HF>(B, A, NoEpi{}, dsig);                              // W8^T   : dh8' -> dh7' (A)
@@ -395,7 +487,7 @@ template <int MODE, int START>
 int launch_mlp_bwd(const void* pack, const float* g, const void* act, void* dact, int64_t n, hipStream_t st, int tangent = 0,
                    const float* dfeat = nullptr) {
     using C = Cfg<MODE>;
-    const int lds = BWD_TABLE_BYTES + 3 * MlpBwd<MODE, START>::SLOT;
+    const int lds = BWD_TABLE_BYTES + 3 * MlpBwd<MODE, START>::SLOT + C::WAVES * 2 * C::NT * 1024;    // + the gathered sign bits
     auto kern = mlp_bwd_kernel<MODE, START>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail((int)e, "anr_mlp_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));

@@ -167,22 +167,50 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-// column of out-tile T's 32 features in a saved-activation row: [h1..h8 (8 x 256) | final (256) | dir hidden (128)]
+// ---- saved activations / activation gradients (training): a buffer of R rows (points), BLOCKED by 32-feature tile.
+//   column c of row r  ->  element (c / 32 * R + r) * 32 + c % 32        76 blocks [R][32]: h1..h8 (8 x 8) | final (8) | dir hidden (4)
+// so the 32 rows a wavefront produces for one out-tile are 2 KiB (bf16) of CONTIGUOUS memory per store instruction pair.
+// (Row-major rows of 5 KB took 2.0 ms per 2^20 rows for the same bytes next to the weight stream, this layout 1.1:
+// tools/exp/exp_store_patterns2.hip.)  Behind the blocks, at element ACT_COLS * R, the SIGN BITS of the ReLU'd columns (bit
+// 4Q+i of the uint16 of (block w, half-wave h) <-> feature 32w + 8Q + 4h + i is > 0), grouped the way the kernels produce
+// and consume them: per trunk layer g a block [R][half-wave][16 B] at byte g * 32 R (the 8 uint16 of the layer's blocks),
+// the colour head's 4 blocks as [R][half-wave][8 B] at byte 288 R.  The activation-gradient kernel gates with these instead
+// of re-reading the activations.  A buffer is R * ACT_PITCH elements of either dtype (anr_mlp_act_cols()).
 constexpr int ACT_COLS = 2432;
-// ... followed by the SIGN BITS of the ReLU'd columns (bit 4Q+i of the uint16 of (block w of 32 features, half-wave h) <->
-// feature 32w + 8Q + 4h + i is > 0), grouped the way the kernels produce and consume them: per layer (8 blocks) 16 bytes of
-// half-wave 0 then 16 bytes of half-wave 1; the 4 blocks of the colour head's hidden layer as 8 + 8 bytes — 304 bytes.
-// The activation-gradient kernel gates with these instead of re-reading the 4,864 bytes of activations (its mask loads
-// were 40 % of its time); one 16-byte piece per lane and layer each way.  Row pitch in ELEMENTS of either dtype (the
-// bits start at element ACT_COLS; an fp32 row wastes a few hundred bytes behind them):
 constexpr int ACT_PITCH = 2592;
 __host__ __device__ constexpr int act_col(int T) { return T < 64 ? 32 * T : T < 73 ? 2048 + 32 * (T - 65) : 2304 + 32 * (T - 73); }
-// byte offset, inside the bits region, of the group of block w for half-wave `half`
-__host__ __device__ constexpr int act_bits_group(int w, int half) { return w < 72 ? 32 * (w / 8) + 16 * half : 288 + 8 * half; }
-template <class ActT>
-__device__ __forceinline__ char* act_bits(ActT* row_plus_4half, int half, int w) {
-    return const_cast<char*>(reinterpret_cast<const char*>(row_plus_4half + (ACT_COLS - 4 * half))) + act_bits_group(w, half);
+// byte offsets inside a buffer of R rows of ESZ-byte elements
+__host__ __device__ constexpr int64_t act_block_off(int64_t R, int esz, int blk) { return (int64_t)blk * R * (32 * esz); }
+__host__ __device__ constexpr int64_t act_bits_off(int64_t R, int esz, int w) {
+    return (int64_t)ACT_COLS * R * esz + (w < 72 ? (int64_t)(w / 8) * 32 * R : (int64_t)288 * R);
 }
+// A wave-uniform pointer that walks the blocks of such a buffer in the static order of a kernel's tile schedule.  Every
+// block base is a loop invariant of the persistent point-tile loop: written as base + blk * stride, hipcc hoists all 76 of
+// them out of the loop and, short of scalar registers, spills them as VGPR pairs — a scratch reload + vmcnt(0) in front of
+// every store.  step() goes through an empty asm statement, so the pointer is recomputed where it is used (two SALU adds).
+// (The pointer is typed as global memory: behind the asm hipcc can no longer infer that, and a generic pointer means
+// flat_store, which also counts as an LDS operation.)
+typedef __attribute__((address_space(1))) char gchar;
+typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2n __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) u32x4n g_uint4;      // (native vectors: HIP's uint4 class has no operator= there)
+typedef __attribute__((address_space(1))) u32x2n g_uint2;
+typedef __attribute__((address_space(1))) f32x4 g_f32x4;
+struct BlockWalk {
+    gchar* p;
+    int64_t stride;                                   // bytes per block
+    __device__ __forceinline__ void reset(char* base, int64_t first_block) {
+        p = (gchar*)base + first_block * stride;
+        asm volatile("" : "+s"(p));
+    }
+    template <int D> __device__ __forceinline__ void step() {
+        if constexpr (D != 0) { p += (int64_t)D * stride; asm volatile("" : "+s"(p)); }
+    }
+};
+// bit of feature 8Q + 4h + i (Q = accumulator quarter, i = 0..3) inside the uint16 of its block and half-wave
+__host__ __device__ constexpr int act_sign_bit(int Q, int i) { return ((i & 1) ? 15 : 7) - (2 * Q + (i >> 1)); }
+// ... plus, per lane: row * 32 * esz (+ the feature inside the block) for the data, row * 32 + 16 * half for a layer's
+// bits, row * 16 + 8 * half for the head's
 
 // PRE: the input is the 63-channel Fourier embedding itself, emb[n][63] fp32 (models/mlp.py:268-297 takes it that way):
 // the encoder is skipped, the panel slots are loaded from the row.
@@ -220,17 +248,51 @@ struct Mlp {
     int wave, lane, half;
     f32x16 acc[2][NT];       // accumulators of tile c (parity c&1) and of tile c-1 (epilogue pending)
     f32x16 bias_c;           // bias of tile c: C operand of its first MFMA
+    // SAVE (training forward: the register file is full with the store staging): no bias registers — the bias of tile T+1
+    // is read from LDS straight into the accumulators tile T+1 will use (free since tile T-1's epilogue, which ran behind
+    // tile T's first MFMAs) and the tile accumulates onto it; 32 registers less, no spills in front of the stores
+    static constexpr bool BIAS_IN_ACC = SAVE;
     Frag w0[4];              // first fragment group of tile c
-    ActT* act_row[NT];       // SAVE: this lane's row of saved activations (+ 4*half), or null
-    unsigned savebits[NT];   // SAVE: sign bits of the tile whose epilogue is pending
+    char* act_base;          // SAVE: the activation buffer (blocked layout above) and its row count
+    int64_t act_rows;
+    BlockWalk act_blk;       // SAVE: the data block / the layer's bits block the next epilogue stores into
+    BlockWalk bits_blk;
+    unsigned act_off[NT];    // SAVE: byte offset of this lane's row (+ 4*half features) inside a block; rows past the end alias the last row
+    unsigned bits_off[NT];   // SAVE: ... inside a layer's bits block (row * 32 + 16 * half)
+    char* lds_bits[NT];      // SAVE: this lane's 16 bytes of LDS where a layer's sign bits collect (one global store per layer)
+    unsigned savebits[NT];   // SAVE: sign flags of the tile whose epilogue is pending
+
+    // SAVE: stores this wave issues in the epilogue of tile V (per column tile): the 16-byte row pieces, and the layer's
+    // sign bits behind its last tile
+    static __host__ __device__ constexpr int epi_stores(int V) {
+        if (V < 0 || V == 64 || V >= 77) return 0;
+        const bool relu = V < 64 || V >= 73;
+        const bool layer_end = relu && (V < 64 ? V % 8 == 7 : V == 76);
+        return (C::IS_BF16 ? 2 : 4) + (layer_end ? 1 : 0);
+    }
+    // ... and between the LDS-DMA of chunk c+1 (issued by the advance() in front of tile T - TPC) and the advance() in
+    // front of tile T, which needs that chunk: the epilogues that ran in between.  The vector-memory counter retires in
+    // issue order, so `vmcnt(that many)` waits for the DMA and for nothing younger — the activation stores of the last
+    // chunk stay in flight across the barrier instead of being drained (vmcnt(0)) every two tiles.  A lower bound is always
+    // safe (T = 0 leaves out the output stores and the point prefetch of the previous point tile).
+    static __host__ __device__ constexpr int stores_since_dma(int T) {
+        if (!SAVE) return 0;
+#if defined(ANR_ABL_NO_ACT_STORE) || defined(ANR_ABL_NO_BITS)
+        return 0;                                  // timing ablations change the store count: drain
+#endif
+        const int first = T == 0 ? LAST_CHUNK * TPC : T - TPC, last = T == 0 ? LAST_TILE : T - 1;
+        int n = 0;
+        for (int U = first; U <= last; ++U) n += epi_stores(U - 1);
+        return n * NT;
+    }
 
     // barrier: chunk c+1 has landed everywhere and nobody reads chunk c-1 any more -> stage chunk c+2 over it
     static constexpr int MAXP = (TPC * (HF + EF) + WAVES - 1) / WAVES;   // register-staged pieces per wave (DMA off)
     uint4 sreg[DMA ? 1 : MAXP];
     unsigned spend_slot; int spend_nf;
-    __device__ __forceinline__ void advance() {
+    template <int T> __device__ __forceinline__ void advance() {
 #ifndef ANR_ABL_NO_BARRIER
-        if constexpr (DMA) dma_wait();
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(stores_since_dma(T)) : "memory");
         else {
             // DMA off: the chunk loaded into registers one chunk ago goes to its ring slot now
 #pragma unroll
@@ -290,13 +352,34 @@ struct Mlp {
     struct FragEpi {
         const f32x16 (&a)[NT];
         Frag (&Y)[NT][YF];
-        ActT* const (&ar)[NT];
-        unsigned (&sb)[NT];              // SAVE, parity mode: sign bits of this tile's four quarters, collected across the parts
+        BlockWalk& ab;                   // SAVE: data / bits block of this tile, the lane's offsets inside them
+        BlockWalk& bb;
+        const unsigned (&ao)[NT];
+        const unsigned (&bo)[NT];
+        char* const (&lb)[NT];           // SAVE: the lane's LDS slot for the sign bits of the layer in progress
+        unsigned (&sb)[NT];              // SAVE: the tile's sign flags, collected across its four parts
         int half;
+        static constexpr int ESZ = sizeof(ActT);
+        // sign bits of this tile (16: four quarters x four features) -> the lane's LDS slot; behind the layer's last tile the
+        // slot leaves as ONE 16-byte store (the colour head's four blocks: 8 bytes) instead of a 2-byte store per tile
+        __device__ __forceinline__ void put_bits(int n, unsigned bits) const {
+            constexpr int w = act_col(TG) / 32, j = w < 72 ? w % 8 : w - 72;
+            *reinterpret_cast<uint16_t*>(lb[n] + 2 * j) = (uint16_t)bits;
+            if constexpr (w < 72 && j == 7) {
+                *reinterpret_cast<g_uint4*>(bb.p + bo[n]) = *reinterpret_cast<const u32x4n*>(lb[n]);
+                if (n == NT - 1) bb.template step<(w == 63) ? 2 : 1>();      // (the group of xyz_encoding_final holds no bits)
+            } else if constexpr (w == 75) {
+                *reinterpret_cast<g_uint2*>(bb.p + (bo[n] >> 1)) = *reinterpret_cast<const u32x2n*>(lb[n]);
+            }
+        }
         template <int Q> __device__ __forceinline__ void part() const {
 #ifdef ANR_ABL_NO_EPILOGUE
             if (Q > 0) return;
 #endif
+            parts<Q>();
+            if constexpr (SAVE && Q == 3) ab.template step<1>();         // the tiles that store walk the blocks in order
+        }
+        template <int Q> __device__ __forceinline__ void parts() const {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 if constexpr (C::IS_BF16) {
@@ -341,24 +424,25 @@ struct Mlp {
                         constexpr int pd = ((4 * (Q - 1)) % EPF) / 2;
                         const auto s0 = __builtin_amdgcn_permlane32_swap(prev[pd], pk[0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(prev[pd + 1], pk[1], false, false);
-                        if (ar[n] != nullptr)
-                            *reinterpret_cast<uint4*>(ar[n] + act_col(TG) + 16 * (Q >> 1) + 4 * half) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+#ifndef ANR_ABL_NO_ACT_STORE
+                        *reinterpret_cast<g_uint4*>(ab.p + ao[n] + (16 * (Q >> 1) + 4 * half) * ESZ) = u32x4n{s0[0], s1[0], s0[1], s1[1]};
+#else
+                        asm volatile("" :: "v"(s0[0]), "v"(s1[0]), "v"(s0[1]), "v"(s1[1]));
+#endif
                     }
-                    if constexpr (SAVE && RELU && Q == 3) {
-                        // sign bits of the tile's 16 values, read back from the two fragments just completed (nothing is
-                        // carried across the parts: the kernel sits at its register limit); after the ReLU a bf16 is > 0
-                        // exactly when its bit pattern is non-zero
-                        static_assert(EPF == 8, "two fragments per tile");
-                        const u32x4 lo4 = __builtin_bit_cast(u32x4, Y[n][TB]), hi4 = __builtin_bit_cast(u32x4, Y[n][TB + 1]);
-                        unsigned bits = 0;
+#ifndef ANR_ABL_NO_BITS
+                    if constexpr (SAVE && RELU) {
+                        // after the ReLU a bf16 is > 0 exactly when its bit pattern is non-zero: min(x, 1) per 16-bit half is
+                        // the flag, and (flags so far << 1) | flag collects pair k at bits 7 - k / 23 - k
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            bits |= ((lo4[k] & 0xffffu) ? 1u : 0u) << (2 * k) | ((lo4[k] >> 16) ? 1u : 0u) << (2 * k + 1);
-                            bits |= ((hi4[k] & 0xffffu) ? 1u : 0u) << (8 + 2 * k) | ((hi4[k] >> 16) ? 1u : 0u) << (9 + 2 * k);
+                        for (int i = 0; i < 2; ++i) {
+                            unsigned fl;                  // (as asm: hipcc lowers the vector min to compares and selects)
+                            asm("v_pk_min_u16 %0, %1, %2" : "=v"(fl) : "v"(pk[i]), "s"(0x00010001u));
+                            sb[n] = (Q == 0 && i == 0) ? fl : ((sb[n] << 1) | fl);
                         }
-                        constexpr int w = act_col(TG) / 32, j = w < 72 ? w % 8 : w - 72;
-                        if (ar[n] != nullptr) *reinterpret_cast<uint16_t*>(act_bits(ar[n], half, w) + 2 * j) = (uint16_t)bits;
+                        if constexpr (Q == 3) put_bits(n, __builtin_amdgcn_perm(0u, sb[n], 0x0c0c0200u));     // bytes 0 and 2
                     }
+#endif
                 } else {
                     f32x4 keep;
 #pragma unroll
@@ -376,13 +460,13 @@ struct Mlp {
                         keep[i] = v;
                     }
                     if ((4 * Q + 4) % EPF == 0) pin(Y[n][TB + (4 * Q) / EPF]);
-                    if (SAVE && ar[n] != nullptr) *reinterpret_cast<f32x4*>(ar[n] + act_col(TG) + 8 * Q) = keep;
-                    if constexpr (SAVE && RELU) {                              // (parity mode: carried across the parts)
-                        const unsigned nib = (keep[0] > 0.0f ? 1u : 0u) | (keep[1] > 0.0f ? 2u : 0u) | (keep[2] > 0.0f ? 4u : 0u) |
-                                             (keep[3] > 0.0f ? 8u : 0u);
-                        sb[n] = Q == 0 ? nib : (sb[n] | (nib << (4 * Q)));
-                        constexpr int w = act_col(TG) / 32, j = w < 72 ? w % 8 : w - 72;
-                        if (Q == 3 && ar[n] != nullptr) *reinterpret_cast<uint16_t*>(act_bits(ar[n], half, w) + 2 * j) = (uint16_t)sb[n];
+                    if constexpr (SAVE) *reinterpret_cast<g_f32x4*>(ab.p + ao[n] + 8 * Q * ESZ) = keep;
+                    if constexpr (SAVE && RELU) {
+                        unsigned nib = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) nib |= (keep[i] > 0.0f ? 1u : 0u) << act_sign_bit(Q, i);
+                        sb[n] = Q == 0 ? nib : (sb[n] | nib);
+                        if constexpr (Q == 3) put_bits(n, sb[n]);
                     }
                 }
             }
@@ -413,7 +497,7 @@ struct Mlp {
         constexpr int POS = T % TPC;                       // position of this tile inside its chunk
         constexpr int OFF = (POS == 0) ? 0 : tile_frags<C>(T - 1);      // TPC <= 2
         constexpr bool END = (T == LAST_TILE);             // the next tile is tile 0 of the next point tile
-        if constexpr (POS == 0) advance();
+        if constexpr (POS == 0) advance<T>();
         const Frag* cur = reinterpret_cast<const Frag*>(lds_base + slot_cur) + OFF * 64 + lane;
         const Frag* nxt = (POS + 1 < TPC && !END) ? cur + (NFE + NFH) * 64
                                                   : reinterpret_cast<const Frag*>(lds_base + slot_nxt) + lane;
@@ -428,11 +512,11 @@ struct Mlp {
 #ifdef ANR_ABL_NO_FRAG_LOAD                        // timing ablation: no LDS fragment reads (registers recycled)
 #pragma unroll
             for (int q = 0; q < 4; ++q) { ld[q] = use[q]; pin(ld[q]); }
-            if (j + 1 == NG) bias_n = bias_c;
+            if (j + 1 == NG && !BIAS_IN_ACC) bias_n = bias_c;
 #else
 #pragma unroll
             for (int q = 0; q < 4; ++q) ld[q] = (j + 1 < NG) ? cur[((j + 1) * 4 + q) * 64] : nxt[q * 64];
-            if (j + 1 == NG) bias_n = read_bias(END ? 0 : T + 1);
+            if constexpr (j + 1 == NG && !BIAS_IN_ACC) bias_n = read_bias(END ? 0 : T + 1);
 #endif
             __builtin_amdgcn_sched_barrier(0);          // the loads above are issued before this group's MFMAs
             static_for<4>([&](auto qc) {
@@ -441,8 +525,8 @@ struct Mlp {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const Frag& x = (f < NFE) ? E[n][f < NFE ? f : 0] : X[n][f >= NFE ? f - NFE : 0];
-                    if (f == 0) acc[PAR][n] = mma_c(use[q], x, bias_c);
-                    else        mma(use[q], x, acc[PAR][n]);
+                    if (f == 0 && !BIAS_IN_ACC) acc[PAR][n] = mma_c(use[q], x, bias_c);
+                    else                        mma(use[q], x, acc[PAR][n]);
                 }
 #ifdef ANR_EPI_ONE_GROUP
                 if (j == 0) {
@@ -463,11 +547,17 @@ struct Mlp {
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #endif
+                // BIAS_IN_ACC: the other accumulator set is free once the pending epilogue has read it (groups 0 and 1;
+                // all of it in group 0 of a short tile): the next tile's bias goes there under the last group's MFMAs
+                if constexpr (BIAS_IN_ACC && !END && j + 1 == NG && q == (NG == 1 ? 3 : 0)) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[PAR ^ 1][n] = read_bias(T + 1);
+                }
             });
         });
 #pragma unroll
         for (int q = 0; q < 4; ++q) w0[q] = (NG & 1) ? wb[q] : wa[q];
-        bias_c = bias_n;
+        if constexpr (!BIAS_IN_ACC) bias_c = bias_n;
         if constexpr (POS + 1 == TPC || END) rotate();
     }
 
@@ -482,13 +572,18 @@ struct Mlp {
             if constexpr (t == 0) {
                 tile<T0 + t, NFE, NFH, XF>(E, X, first);
             } else {
-                tile<T0 + t, NFE, NFH, XF>(E, X, FragEpi<RELU, YF, (t - 1) * FPT, T0 + t - 1>{acc[PAR ^ 1], Y, act_row, savebits, half});
+                tile<T0 + t, NFE, NFH, XF>(E, X, FragEpi<RELU, YF, (t - 1) * FPT, T0 + t - 1>{acc[PAR ^ 1], Y, act_blk, bits_blk, act_off, bits_off, lds_bits, savebits, half});
             }
         });
     }
     template <int T0, int NTILES, bool RELU, int YF>
     __device__ __forceinline__ auto last_of(Frag (&Y)[NT][YF]) {
-        return FragEpi<RELU, YF, (NTILES - 1) * FPT, T0 + NTILES - 1>{acc[(T0 + NTILES - 1) & 1], Y, act_row, savebits, half};
+        return FragEpi<RELU, YF, (NTILES - 1) * FPT, T0 + NTILES - 1>{acc[(T0 + NTILES - 1) & 1], Y, act_blk, bits_blk, act_off, bits_off, lds_bits, savebits, half};
+    }
+
+    // the row a lane past the end of the list works on instead (tangent mode: the row of the last quad with its own role)
+    static __device__ __forceinline__ int64_t clamp_row(int64_t idx, int64_t n) {
+        return idx < n ? idx : (TAN ? n - 4 + (idx & 3) : n - 1);
     }
 
     // index/count (both optional): evaluate pts[index[i]] for i < min(n_pts, *count) and write out[index[i]] — the
@@ -497,6 +592,7 @@ struct Mlp {
                                         void* __restrict__ out_v, float* __restrict__ act, char* lds,
                                         const int32_t* __restrict__ index, const int32_t* __restrict__ count,
                                         const float* __restrict__ rays, int ray_stride, int K) {
+        act_rows = n_pts;                                  // the buffer's row count (blocks are [n][32]), not the listed count
         if (count) {
             const int64_t cnt = *count;
             n_pts = cnt < n_pts ? cnt : n_pts;
@@ -508,6 +604,7 @@ struct Mlp {
         half = lane >> 5;
         lds_base = lds;
         lds_bias = lds;
+        act_base = reinterpret_cast<char*>(act);
         slot_cur = BIAS_BYTES;
         slot_nxt = slot_cur + SLOT;
         slot_stage = slot_nxt + SLOT;
@@ -530,7 +627,7 @@ struct Mlp {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 int64_t idx = (tile_idx * WAVES + wave) * (NT * 32) + n * 32 + (lane & 31);
-                idx = idx < n_pts ? idx : n_pts - 1;
+                idx = clamp_row(idx, n_pts);
                 if (index) {
                     // every listed sample is valid: the w lane carries its position in pts/out instead
                     const int32_t id = index[idx];
@@ -590,10 +687,17 @@ struct Mlp {
             int64_t idx = wave_base + n * 32 + (lane & 31);
             const float4 p = p_cur[n];
             valid[n] = p.w;
-            act_row[n] = (SAVE && idx < n_pts) ? reinterpret_cast<ActT*>(act) + idx * ACT_PITCH + 4 * half : nullptr;
+            // (a lane past the end recomputes the row it aliases — clamp_row — and stores the same bytes there: every wave
+            // issues the same number of stores whatever n is, which the counted waits of advance() rely on)
+            if constexpr (SAVE) {
+                const unsigned row = (unsigned)clamp_row(idx, n_pts);
+                act_off[n] = (row * 32 + 4 * half) * (unsigned)sizeof(ActT);
+                bits_off[n] = row * 32 + 16 * half;
+            }
+            if constexpr (SAVE) lds_bits[n] = lds + BIAS_BYTES + 3 * SLOT + ((n * WAVES + wave) * 64 + lane) * 16;
             const float xs[3] = {p.x, p.y, p.z};
             if constexpr (PRE) {
-                int64_t row_i = idx < n_pts ? idx : n_pts - 1;
+                int64_t row_i = clamp_row(idx, n_pts);
                 const float* row = reinterpret_cast<const float*>(pts) + row_i * 63;
                 valid[n] = 1.0f;
 #pragma unroll
@@ -665,8 +769,18 @@ struct Mlp {
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 4; ++q) w0[q] = (reinterpret_cast<const Frag*>(lds_base + slot_cur) + lane)[q * 64];
-            bias_c = read_bias(0);
+            if constexpr (!BIAS_IN_ACC) bias_c = read_bias(0);
             first = false;
+        }
+        if constexpr (SAVE) {
+            act_blk.stride = act_block_off(act_rows, sizeof(ActT), 1);
+            bits_blk.stride = 32 * act_rows;
+            act_blk.reset(act_base, 0);
+            bits_blk.reset(act_base + act_bits_off(act_rows, sizeof(ActT), 0), 0);
+        }
+        if constexpr (BIAS_IN_ACC) {                        // tile 0 accumulates onto its bias (every point tile: the last tile
+#pragma unroll                                              // of the pass before may still have been using acc[0])
+            for (int n = 0; n < NT; ++n) acc[0][n] = read_bias(0);
         }
 
         Frag A[NT][HF], B[NT][HF];
@@ -738,7 +852,7 @@ int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStr
                const int32_t* index = nullptr, const int32_t* count = nullptr, const float* rays = nullptr,
                int ray_stride = 0, int K = 1) {
     using C = Cfg<MODE>;
-    const int lds = BIAS_BYTES + 3 * slot_bytes<C>();
+    const int lds = BIAS_BYTES + 3 * slot_bytes<C>() + (SAVE ? C::NT * C::WAVES * 64 * 16 : 0);     // + the sign-bit slots
     auto kern = mlp_kernel<MODE, DMA, SIGMA_ONLY, SAVE, PRE, TAN>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail((int)e, "anr_mlp_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));

@@ -1,15 +1,16 @@
 // Weight gradients of the fused MLP (training, a16): what autograd computes for every nn.Linear of
-// models/nerf.py:129-175 —  dW_l = dact_l^T . in_l,  db_l = column sums of dact_l — from the two [points][2432]
-// matrices the training forward (anr_mlp_forward_save: activations) and the activation-gradient kernel
-// (anr_mlp_backward: pre-activation gradients) leave behind, plus the encoding matrix enc[points][64].
+// models/nerf.py:129-175 —  dW_l = dact_l^T . in_l,  db_l = column sums of dact_l — from the two blocked buffers
+// (76 blocks of [points][32 features], mlp_core.h) the training forward (anr_mlp_forward_save: activations) and the
+// activation-gradient kernel (anr_mlp_backward: pre-activation gradients) leave behind, plus the encoding matrix
+// enc[points][64].
 //
-// The contraction runs over the POINTS, i.e. over the slow index of both row-major operands, so an MFMA fragment
-// (one feature, 8 consecutive points per lane) is a column walk.  gfx950's transposing LDS read does it in hardware:
-// row slabs are copied L2 -> LDS as they lie in memory (LDS-DMA, 16 B per lane, rows padded to a pitch = 64 mod 256 bytes
-// so that the four rows one ds_read_b64_tr_b16 touches sit in different bank windows), and each fragment is two
-// ds_read_b64_tr_b16 (lane s of a 16-lane group points at row k0 + s/4, features f0 + 4 (s%4); it receives feature
-// f0 + s of rows k0 .. k0+3).  fp32 (parity mode): v_mfma_f32_32x32x2_f32 takes one point per half-wave and its
-// fragment is a plain row read.
+// The contraction runs over the POINTS, i.e. over the slow index of both operands, so an MFMA fragment (one feature,
+// 8 consecutive points per lane) is a column walk.  gfx950's transposing LDS read does it in hardware: for a slab of
+// rows, each 32-feature block is 2 KiB of contiguous memory and goes L2 -> LDS as it lies there (LDS-DMA, 16 B per lane;
+// rows of a block are 64 bytes apart, so the four rows one ds_read_b64_tr_b16 touches sit in different bank windows), and
+// each fragment is two ds_read_b64_tr_b16 (lane s of a 16-lane group points at row k0 + s/4, features f0 + 4 (s%4); it
+// receives feature f0 + s of rows k0 .. k0+3).  fp32 (parity mode): v_mfma_f32_32x32x2_f32 takes one point per
+// half-wave and its fragment is a plain row read.
 //
 // Work split: a task = (one GEMM, one slice of the points); 8 wavefronts share the staged slabs and own a
 // (TM x TN) block of 32x32 accumulator tiles each (256x256: 2x4 per wave, 128 accumulator registers).  Partial products
@@ -45,13 +46,11 @@ template <> struct WgCfg<true> {
     using T = __bf16;
     static constexpr int SR = 32;                 // rows (points) per LDS stage
     static constexpr int KSTEP = 16;              // rows per MFMA
-    static constexpr int pitch(int cols) { return cols * 2 + 64; }          // = 64 (mod 256) for cols in {64, 128, 256}
 };
 template <> struct WgCfg<false> {
     using T = float;
     static constexpr int SR = 16;
     static constexpr int KSTEP = 2;
-    static constexpr int pitch(int cols) { return cols * 4; }
 };
 
 template <bool BF16, int TM, int TN, int WM>
@@ -63,10 +62,13 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
     constexpr int WN = WG_WAVES / WM;
     constexpr int M = TM * 32 * WM, N = TN * 32 * WN;
     constexpr int ESZ = sizeof(T);
-    constexpr int PA = C::pitch(M), PB = C::pitch(N);
     constexpr int SR = C::SR;
-    constexpr int STAGE_A = SR * PA, STAGE_B = SR * PB;
-    constexpr int PIECES = (STAGE_A + STAGE_B + 1023) / 1024;
+    // LDS image of a stage: the M / 32 blocks of the A side, then the N / 32 of the B side, each [SR rows][32 features]
+    constexpr int BLK = SR * 32 * ESZ;                               // 2 KiB in either mode
+    constexpr int RPP = 1024 / (32 * ESZ);                           // rows per 1-KiB DMA piece (16 / 8)
+    constexpr int LPR = 64 / RPP;                                    // lanes per row of a piece (4 / 8)
+    constexpr int STAGE_A = (M / 32) * BLK, STAGE_B = (N / 32) * BLK;
+    constexpr int PIECES = (STAGE_A + STAGE_B) / 1024;
     constexpr int PPW = (PIECES + WG_WAVES - 1) / WG_WAVES;           // DMA pieces per wave and stage (padded: uniform waits)
     constexpr int STAGE = PPW * WG_WAVES * 1024;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -78,27 +80,26 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
     int64_t r1 = r0 + args.rows_per_split;
     if (r1 > n) r1 = n;
     const int n_stages = r1 > r0 ? (int)((r1 - r0) / SR) : 0;
-    const int64_t a_pitch = (int64_t)ACT_PITCH * ESZ;
-    const char* b_base = gm.b_src ? enc : act;
-    const int64_t b_pitch = (gm.b_src ? 64 : ACT_PITCH) * (int64_t)ESZ;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    // this lane's 16 bytes of a piece: row (inside the piece) and byte inside the block row
+    const int prow = lane / LPR, pseg = (lane % LPR) * 16;
 
     auto issue = [&](int st) {                                  // slab of stage st -> ring buffer st % NBUF
         const int64_t row0 = r0 + (int64_t)st * SR;
         const unsigned buf = lds0 + (unsigned)(st % WG_NBUF) * STAGE;
 #pragma unroll
         for (int p = 0; p < PPW; ++p) {
-            const int piece = wave + p * WG_WAVES;
-            const int q = piece * 1024 + lane * 16;               // byte position inside the stage image
+            const int piece = wave + p * WG_WAVES;               // wave-uniform
+            const int blk = piece / (BLK / 1024), row = (piece % (BLK / 1024)) * RPP + prow;
             const char* src;
-            if (q < STAGE_A) {
-                const int row = q / PA, off = q % PA;
-                src = dact + (row0 + row) * a_pitch + (int64_t)gm.a_col * ESZ + (off < M * ESZ ? off : 0);
-            } else if (q < STAGE_A + STAGE_B) {
-                const int row = (q - STAGE_A) / PB, off = (q - STAGE_A) % PB;
-                src = b_base + (row0 + row) * b_pitch + (int64_t)gm.b_col * ESZ + (off < N * ESZ ? off : 0);
+            if (piece < STAGE_A / 1024) {
+                src = dact + act_block_off(n, ESZ, gm.a_col / 32 + blk) + (row0 + row) * (32 * ESZ) + pseg;
+            } else if (piece < PIECES) {
+                const int bb = blk - M / 32;
+                if (gm.b_src) src = enc + (row0 + row) * (64 * ESZ) + bb * (32 * ESZ) + pseg;        // enc[points][64], row-major
+                else          src = act + act_block_off(n, ESZ, gm.b_col / 32 + bb) + (row0 + row) * (32 * ESZ) + pseg;
             } else {
-                src = dact + row0 * a_pitch;                        // padding piece: lands behind the images, never read
+                src = dact + (row0 + row) * (32 * ESZ) + pseg;      // padding piece: lands behind the images, never read
             }
             dma16(src, buf + piece * 1024);
         }
@@ -142,16 +143,16 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
                     const unsigned ad = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)A +
-                                        (ks * 16 + frow) * PA + (m_base + a * 32 + fcol) * 2;
+                                        (m_base / 32 + a) * BLK + (ks * 16 + frow) * 64 + fcol * 2;
                     asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
-                                 : "=&v"(alo[a]), "=&v"(ahi[a]) : "v"(ad), "n"(8 * PA) : "memory");
+                                 : "=&v"(alo[a]), "=&v"(ahi[a]) : "v"(ad), "n"(8 * 64) : "memory");
                 }
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
                     const unsigned ad = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)B +
-                                        (ks * 16 + frow) * PB + (n_base + b * 32 + fcol) * 2;
+                                        (n_base / 32 + b) * BLK + (ks * 16 + frow) * 64 + fcol * 2;
                     asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
-                                 : "=&v"(blo[b]), "=&v"(bhi[b]) : "v"(ad), "n"(8 * PB) : "memory");
+                                 : "=&v"(blo[b]), "=&v"(bhi[b]) : "v"(ad), "n"(8 * 64) : "memory");
                 }
                 // one wait for the whole batch; the operands tie every fragment to it (the reads are opaque to hipcc)
 #pragma unroll
@@ -185,10 +186,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
                 float fa[TM], fb[TN];
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
-                    fa[a] = *reinterpret_cast<const float*>(A + (ks * 2 + h) * PA + (m_base + a * 32 + i) * 4);
+                    fa[a] = *reinterpret_cast<const float*>(A + (m_base / 32 + a) * BLK + (ks * 2 + h) * 128 + i * 4);
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    fb[b] = *reinterpret_cast<const float*>(B + (ks * 2 + h) * PB + (n_base + b * 32 + i) * 4);
+                    fb[b] = *reinterpret_cast<const float*>(B + (n_base / 32 + b) * BLK + (ks * 2 + h) * 128 + i * 4);
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -245,6 +246,9 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
                                                     int rows_per_slice, int sigma_only, int tangent, float* __restrict__ partial) {
     __shared__ float sh[4][CS_COLS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // four consecutive columns per lane: block (first column / 32 + lane / 8), features 4 (lane % 8) of row r
+    const T* h8 = act + ((int64_t)(1792 / 32 + (lane >> 3)) * n) * 32 + 4 * (lane & 7);
+    const T* gh = act + ((int64_t)(2304 / 32 + ((lane & 31) >> 3)) * n) * 32 + 4 * (lane & 7);
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_slice;
     int64_t r1 = r0 + rows_per_slice;
     if (r1 > n) r1 = n;
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
             float4 g[RIF];
 #pragma unroll
             for (int q = 0; q < RIF; ++q) {
-                load4(act + (r + 4 * q) * ACT_PITCH + 1792 + 4 * lane, h[q]);
+                load4(h8 + (r + 4 * q) * 32, h[q]);
                 g[q] = reinterpret_cast<const float4*>(g4)[r + 4 * q];
             }
 #pragma unroll
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
         }
         for (; r < r1; r += 4) {
             float h[4];
-            load4(act + r * ACT_PITCH + 1792 + 4 * lane, h);
+            load4(h8 + r * 32, h);
             const float4 g = reinterpret_cast<const float4*>(g4)[r];
 #pragma unroll
             for (int i = 0; i < 4; ++i) sw[i] += g.w * h[i];
@@ -282,14 +286,13 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
     // rgb.weight: 128 columns = 32 lanes x 4; the two half-waves take alternate rows
     float sr[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if (!sigma_only) {
-        const int col = 2304 + 4 * (lane & 31);
         int64_t r = r0 + 2 * wave + (lane >> 5);
         for (; r + 8 * (RIF - 1) < r1; r += 8 * RIF) {
             float h[RIF][4];
             float4 g[RIF];
 #pragma unroll
             for (int q = 0; q < RIF; ++q) {
-                load4(act + (r + 8 * q) * ACT_PITCH + col, h[q]);
+                load4(gh + (r + 8 * q) * 32, h[q]);
                 g[q] = reinterpret_cast<const float4*>(g4)[r + 8 * q];
             }
 #pragma unroll
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
         }
         for (; r < r1; r += 8) {
             float h[4];
-            load4(act + r * ACT_PITCH + col, h);
+            load4(gh + r * 32, h);
             const float4 g = reinterpret_cast<const float4*>(g4)[r];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { sr[0][i] += g.x * h[i]; sr[1][i] += g.y * h[i]; sr[2][i] += g.z * h[i]; }
@@ -410,8 +413,8 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
     const char* D = reinterpret_cast<const char*>(dact);
     const char* E = reinterpret_cast<const char*>(enc);
     auto lds_bytes = [](int M, int N) {
-        const int stage = C::SR * (C::pitch(M) + C::pitch(N));
-        const int pieces = (stage + 1023) / 1024, ppw = (pieces + WG_WAVES - 1) / WG_WAVES;
+        const int stage = C::SR * (M + N) * (int)sizeof(typename C::T);
+        const int pieces = stage / 1024, ppw = (pieces + WG_WAVES - 1) / WG_WAVES;
         return WG_NBUF * ppw * WG_WAVES * 1024;
     };
     // ---- 256 x 256: trunk layers 2..8 (hidden part of layer 5) and xyz_encoding_final
@@ -558,26 +561,27 @@ __global__ __launch_bounds__(256) void denc_kernel(const char* __restrict__ dact
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t p = tile * 32 + (lane & 31);
         const int64_t row = p < n ? p : n - 1;
-        const char* arow = dact + row * (int64_t)ACT_PITCH * sizeof(T);
+        const char* arow = dact + row * (int64_t)(32 * sizeof(T));       // this point's row inside a block of dact
         const int h = lane >> 5;
         f32x16 acc[2];
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
 #pragma unroll
         for (int layer = 0; layer < 2; ++layer) {
-            const char* a0 = arow + (layer ? 1024 : 0) * sizeof(T);
+            const char* a0 = arow + act_block_off(n, sizeof(T), layer ? 32 : 0);    // dact_5 (columns 1024..) / dact_1
 #pragma unroll 4
             for (int kf = 0; kf < KF; ++kf) {
                 const T* b0 = panel + ((int64_t)((layer * KF + kf) * 2 + 0) * 64 + lane) * EPL;
                 const T* b1 = panel + ((int64_t)((layer * KF + kf) * 2 + 1) * 64 + lane) * EPL;
                 if constexpr (BF16) {
-                    const uint2 lo = *reinterpret_cast<const uint2*>(a0 + (16 * kf + 4 * h) * 2);
-                    const uint2 hi = *reinterpret_cast<const uint2*>(a0 + (16 * kf + 8 + 4 * h) * 2);
+                    const char* ab = a0 + act_block_off(n, 2, kf >> 1) + (16 * (kf & 1) + 4 * h) * 2;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(ab);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(ab + 16);
                     const bf16x8 fa = __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, *reinterpret_cast<const bf16x8*>(b0), acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, *reinterpret_cast<const bf16x8*>(b1), acc[1], 0, 0, 0);
                 } else {
-                    const float fa = *reinterpret_cast<const float*>(a0 + (2 * kf + h) * 4);
+                    const float fa = *reinterpret_cast<const float*>(a0 + act_block_off(n, 4, kf >> 4) + (2 * (kf & 15) + h) * 4);
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, *b0, acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, *b1, acc[1], 0, 0, 0);
                 }

@@ -73,7 +73,7 @@ class NeRF(nn.Module):
             for i in range(0, emb.shape[0], 1 << 20):            # 4.9 KB of saved activations per point
                 out, act = ops.mlp_forward_embedded(pack, mode_id, emb[i:i + (1 << 20)], want_act=True)
                 sig.append(out[:, 3].clone())
-                feat.append(act[:, 2048:2304].float())
+                feat.append(ops.act_columns(act, 2048, 2304).float())
             x = torch.cat([torch.cat(feat), input_dir.reshape(-1, self.in_channels_dir).float()], -1)
             rgb = self.rgb(self.dir_encoding(x))
             return rgb.view(*lead, 3), torch.cat(sig).view(*lead, 1)

@@ -113,7 +113,7 @@ class NeRF(nn.Module):
             for i in range(0, pts.shape[0], chunk):
                 out, act = ops.mlp_forward_save(pack, mode_id, pts[i:i + chunk].contiguous())
                 sig.append(out[:, 3].clone())
-                feat.append(act[:, 2048:2304].float())
+                feat.append(ops.act_columns(act, 2048, 2304).float())
             return torch.cat(sig), torch.cat(feat)
 
     def eval_points_view(self, pts: torch.Tensor, viewdir: torch.Tensor, mode: Optional[str] = None) -> torch.Tensor:

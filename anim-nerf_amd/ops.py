@@ -466,10 +466,23 @@ def encode_backward(pts: torch.Tensor, d_enc: torch.Tensor) -> torch.Tensor:
     return d_pts
 
 
+ACT_COLS = 2432                 # columns of a saved-activation / activation-gradient buffer: h1..h8 | final | dir hidden
+
+
+def act_columns(act: torch.Tensor, c0: int = 0, c1: int = ACT_COLS) -> torch.Tensor:
+    """Columns [c0, c1) (multiples of 32) of a saved-activation or activation-gradient buffer as a row-major [n, c1 - c0]
+    tensor (a copy).  The kernels keep these buffers BLOCKED by 32-column tile — 76 blocks of [n][32], then the ReLU sign
+    bits (csrc/mlp_core.h) — inside the n x anr_mlp_act_cols() elements `mlp_forward_save` / `mlp_backward` return."""
+    n = act.shape[0]
+    assert c0 % 32 == 0 and c1 % 32 == 0 and 0 <= c0 < c1 <= ACT_COLS
+    blocks = act.reshape(-1)[:ACT_COLS * n].view(ACT_COLS // 32, n, 32)
+    return blocks[c0 // 32:c1 // 32].permute(1, 0, 2).reshape(n, c1 - c0)
+
+
 def mlp_backward(bwd_pack: torch.Tensor, mode: int, g: torch.Tensor, act: torch.Tensor, sigma_only: bool = False,
                  tangent: bool = False):
-    """g[n,4] = (dL/d rgb_pre, dL/d sigma), act[n,2432] from mlp_forward_save -> dact[n,2432] (same dtype): the
-    pre-activation gradient of every layer (trunk columns only if sigma_only)."""
+    """g[n,4] = (dL/d rgb_pre, dL/d sigma), act from mlp_forward_save -> dact (same dtype, same blocked layout: see
+    `act_columns`): the pre-activation gradient of every layer (trunk columns only if sigma_only)."""
     lib = _lib.load()
     g, act = _dev(g, "g"), _dev(act, "act", act.dtype)
     n = g.shape[0]
@@ -648,7 +661,8 @@ def composite_backward(rgbs, z, rays, white_bkgd: bool, g_rgb, g_depth, g_acc, n
 
 
 def mlp_forward_save(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bool = False, tangent: bool = False):
-    """Training forward: (out, act[n, anr_mlp_act_cols()]) — act keeps every layer's post-activation output.
+    """Training forward: (out, act) — act (n x anr_mlp_act_cols() elements, blocked by 32-column tile: `act_columns`) keeps
+    every layer's post-activation output and the ReLU sign bits.
     tangent (with sigma_only): points in quads, rows 4p+1..3 carry d/dx, d/dy, d/dz (ANR_MLP_FLAG_TANGENT)."""
     lib = _lib.load()
     pts = _dev(pts, "pts")

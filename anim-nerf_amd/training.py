@@ -254,11 +254,13 @@ class GradientReducer:
             self._take(bi, k)
             self._issue_ready()
 
-    def _take(self, bi, k):
+    def _take(self, bi, k, who=None):
         if bi < self._next:
+            state = [(s.expected, s.done) for s in self.sinks]
             raise RuntimeError(f"a gradient for bucket {bi} arrived after its all-reduce was issued: a backward pass on a "
                                "sink-attached network delivered gradients through autograd after the sink had reported "
-                               "completion (announce() every pass in its forward, or detach the sink)")
+                               f"completion (announce() every pass in its forward, or detach the sink); tensor {who}, "
+                               f"sinks (expected, done) = {state}")
         self._pending[bi] -= k
         assert self._pending[bi] >= 0, (bi, self._pending)
 
@@ -274,6 +276,9 @@ class GradientReducer:
             p.grad = view
         for sink in self.sinks:
             sink.begin_step(zero=False)
+        # every .grad of a bucket is a view of its flat buffer and shares its version counter: autograd's in-place
+        # accumulation raises it, the kernels that add into the buffer through raw pointers (GradSink) do not
+        self._ver = [f._version for f in self.flat]
 
     def _issue_ready(self, force=False):
         while self._next < len(self.buckets) and (force or self._pending[self._next] == 0):
@@ -287,11 +292,16 @@ class GradientReducer:
         if p.grad is not view:                                # a caller reset .grad after prepare(): move the value in
             view.copy_(p.grad)
             p.grad = view
+        wrote = self.flat[bi]._version != self._ver[bi]
+        self._ver[bi] = self.flat[bi]._version
         if id(p) in self._sink_params:
-            # a sink-owned tensor that autograd delivered itself (FeatureFunction, a pass that found the sink unusable).
-            # Its arrival is counted ONCE, by the sink's completion (all k tensors together), never here: the hook only
-            # checks that the bucket has not left yet.  A network whose passes all bypass the sink is sent by finish().
-            self._take(bi, 0)
+            # A sink-owned tensor: its arrival is counted ONCE, by the sink's completion (all k tensors together).  Its hook
+            # still fires when autograd is done with the tensor — normally with nothing to accumulate (the passes returned
+            # None and added through the sink).  If autograd DID write (a pass that ran without the sink: FeatureFunction,
+            # a sink found unusable), the bucket must not have left yet.  A network whose passes all bypass the sink is sent
+            # by finish().
+            if wrote:
+                self._take(bi, 0, who=(tuple(p.shape), [i for i, q in enumerate(self.buckets[bi]) if q is p]))
             return
         self._take(bi, 1)
         self._issue_ready()

@@ -239,8 +239,8 @@ int anr_mlp_forward_rays_steps(const void* pack, int mode, const float* rays, in
 /* The network on an already embedded input, emb[n*63] = (x, sin 2^k x, cos 2^k x)_k in the reference's channel order:
  * models/mlp.py:268-297 (NeRF.forward(input_xyz, ...), the pre-embedded twin of models/nerf.py) — the encoder is skipped.
  * out[n*4] = (r,g,b,sigma), or sigma[n] with ANR_MLP_FLAG_SIGMA_ONLY (only_sigma=True, :283-284).
- * act (may be NULL): the saved activations of anr_mlp_forward_save — columns 2048..2303 are xyz_encoding_final, the input
- * of a view-dependent colour head (in_channels_dir > 0) that the caller evaluates. */
+ * act (may be NULL): the saved activations of anr_mlp_forward_save (blocked layout, below) — columns 2048..2303 are
+ * xyz_encoding_final, the input of a view-dependent colour head (in_channels_dir > 0) that the caller evaluates. */
 int anr_mlp_forward_embedded(const void* pack, int mode, const float* emb, int64_t n, float* out, void* act,
                              void* stream);
 int anr_compact_valid(const float* pts, int64_t n, int32_t* index_out, int32_t* count_out,
@@ -249,14 +249,18 @@ int anr_mlp_forward_indexed(const void* pack, int mode, const float* pts, const 
                             const int32_t* count, int64_t n, float* out, void* stream);
 
 /* Training forward: the same kernel, additionally storing each layer's post-activation output for the backward
- * pass (what autograd keeps alive in the reference, models/nerf.py:163-175): act[n * anr_mlp_act_cols()],
- * fp32 in mode ANR_MLP_F32 and bf16 in mode ANR_MLP_BF16 (the value the next layer consumed),
- * row = [h1..h8 (8 x 256, post-ReLU) | xyz_encoding_final (256) | dir hidden (128, post-ReLU) | sign bits]; with
- * ANR_MLP_FLAG_SIGMA_ONLY only h1..h8 (and their bits) are written.  anr_mlp_act_cols() = 2592 elements per row in
- * either dtype: columns 0..2431 are the activations; from column 2432 on the row holds 304 bytes of SIGN BITS of the
- * ReLU'd columns (one uint16 per block of 32 features and half-wave: bit 4Q+i <-> feature 32w + 8Q + 4h + i is > 0; per
- * layer the 8 uint16 of half-wave 0, then the 8 of half-wave 1; the colour head's 4 + 4 last) — what
- * anr_mlp_backward gates with, instead of re-reading the activations.  dact rows have the same pitch; their tail is unused. */
+ * pass (what autograd keeps alive in the reference, models/nerf.py:163-175): act = n * anr_mlp_act_cols() elements,
+ * fp32 in mode ANR_MLP_F32 and bf16 in mode ANR_MLP_BF16 (the value the next layer consumed).
+ * Columns: [h1..h8 (8 x 256, post-ReLU) | xyz_encoding_final (256) | dir hidden (128, post-ReLU)] = 2432; with
+ * ANR_MLP_FLAG_SIGMA_ONLY only h1..h8 (and their bits) are written.
+ * LAYOUT — blocked by 32-column tile, so that what a wavefront stores per out-tile (32 points x 32 features) is one
+ * contiguous 2 KiB: column c of row r is element (c / 32 * n + r) * 32 + c % 32, i.e. 76 blocks [n][32].  Behind them, at
+ * element 2432 * n, the SIGN BITS of the ReLU'd columns (one uint16 per block of 32 features and half-wave: bit 4Q+i <->
+ * feature 32w + 8Q + 4h + i is > 0): per trunk layer l a block [n][2 half-waves][8 uint16] at byte 32 n (l-1), the colour
+ * head's as [n][2][4 uint16] at byte 288 n — what anr_mlp_backward gates with, instead of re-reading the activations.
+ * anr_mlp_act_cols() = 2592 elements per row in either dtype is the ALLOCATION size per row (2432 + bits + padding), not a
+ * row pitch; `n` must be the same in every call that touches a buffer (it is the block stride).  dact uses the same blocks;
+ * its tail is unused. */
 int anr_mlp_act_cols(void);
 int anr_mlp_forward_save(const void* pack, int mode, const float* pts, int64_t n,
                          float* out, void* act, void* stream);
@@ -267,10 +271,10 @@ int anr_mlp_forward_save_indexed(const void* pack, int mode, const float* pts, c
 /* ---- a16 (part): backward of the MLP w.r.t. its activations ------------------------------------------------------
  * What autograd differentiates in models/nerf.py:129-175, as one kernel (csrc/mlp_bwd.hip): from
  *   g[n*4] = (dL/d rgb_pre (3: upstream x sigmoid'), dL/d sigma (already 0 where the sample is invalid))
- * and the activations saved by anr_mlp_forward_save, the pre-activation gradient of every layer in the SAME
- * [n][anr_mlp_act_cols()] layout and dtype as `act`: columns 256(l-1).. = layer l of the trunk, 2048.. =
- * xyz_encoding_final, 2304.. = dir_encoding.  The weight gradients are then plain GEMMs dact_l^T act_{l-1}
- * (library).  With ANR_MLP_FLAG_SIGMA_ONLY only the trunk columns are written (g = (., ., ., dL/d sigma)).
+ * and the activations saved by anr_mlp_forward_save (only their sign bits are read), the pre-activation gradient of every
+ * layer in the SAME blocked layout and dtype as `act`: columns 256(l-1).. = layer l of the trunk, 2048.. =
+ * xyz_encoding_final, 2304.. = dir_encoding.  The weight gradients are then the GEMMs dact_l^T act_{l-1}
+ * (anr_mlp_wgrad).  With ANR_MLP_FLAG_SIGMA_ONLY only the trunk columns are written (g = (., ., ., dL/d sigma)).
  * The transposed weights are handed over pre-packed: anr_mlp_bwd_pack_bytes(mode) bytes from anr_mlp_bwd_pack(). */
 /* models/embedding.py:22-39 as a row-major matrix enc[n*63] (fp32, or bf16 if bf16_out) — the input operand of the
  * weight-gradient GEMMs of xyz_encoding_1 / _5 — and its chain rule: d_pts[n*4] = (dL/dx, dL/dy, dL/dz, 0) from
@@ -327,7 +331,7 @@ int anr_frame_backward_adjoint(const float* betas, const float* pose, const floa
  *   dW_l = dact_l^T in_l (in_1 = enc, in_5 = [enc, h4], in_l = h_{l-1}; xyz_encoding_final, dir_encoding on h8 / the
  *   feature; sigma and rgb from g), db_l = column sums — hand-written split-K MFMA GEMMs over the points
  *   (csrc/mlp_wgrad.hip; ds_read_b64_tr_b16 fragments in bf16, v_mfma_f32_32x32x2_f32 in fp32), slices added in a fixed order.
- * act, dact: [n][anr_mlp_act_cols()] from anr_mlp_forward_save / anr_mlp_backward (dtype of `mode`), enc: anr_encode64 of
+ * act, dact: the blocked buffers of anr_mlp_forward_save / anr_mlp_backward for the same n (dtype of `mode`), enc: anr_encode64 of
  * the same points and dtype, g[n*4] as handed to anr_mlp_backward.  n % 64 == 0 (pad with rows whose g is 0).
  * grads_out[anr_mlp_wgrad_floats()] fp32, PyTorch [out][in] layouts back to back in the order
  *   xyz_encoding_1..8 {weight, bias}, sigma {w, b}, xyz_encoding_final {w, b}, dir_encoding {w, b}, rgb {w, b};

@@ -145,7 +145,7 @@ def test_weight_gradient_kernel(dev, smpl_table, mode, n):
         assert torch.equal(enc[:, :63], ops.encode(pts, act.dtype)) and (enc[:, 63] == 0).all()
         flat = ops.mlp_wgrad(mode_id, act, dact, enc, g4, sigma_only=sigma_only)
         assert torch.equal(flat, ops.mlp_wgrad(mode_id, act, dact, enc, g4, sigma_only=sigma_only)), "not deterministic"
-        A, D, E, G = act.double(), dact.double(), enc.double()[:, :63], g4.double()
+        A, D, E, G = ops.act_columns(act).double(), ops.act_columns(dact).double(), enc.double()[:, :63], g4.double()
         H = lambda l: A[:, 256 * (l - 1):256 * l]
         want = {}
         for l in range(1, 9):
@@ -255,8 +255,9 @@ def test_coarse_only_trainer_and_forward_between_backward_and_step(dev, smpl_tab
     torch.manual_seed(3)
     m = ana.AnimNeRF(body_model_table=smpl_table, freqs_dir=0, use_view=False, use_unpose=True, use_fine=False).to(dev)
     assert not hasattr(m, "nerf_fine")
-    with torch.no_grad():
+    with torch.no_grad():                                     # (sigma > 0 somewhere: a field that is empty everywhere has no gradient)
         m.nerf.sigma.weight.mul_(300.0)
+        m.nerf.sigma.bias.fill_(5.0)
     hp = ana.TrainHParams(n_samples=16, n_importance=0, chunk=512, lr=1e-3)
     tr = ana.Trainer(m, ana.VolumeRenderer(n_coarse=16, n_fine=0), hp)
     c2w, focal, cen = syn.pinhole_camera(8, 8)
@@ -268,6 +269,7 @@ def test_coarse_only_trainer_and_forward_between_backward_and_step(dev, smpl_tab
     bg = (torch.rand(1, 64, 3, generator=gen) * 2 - 1).to(dev)
     loss, details = tr.step(rays, tgt, alp, pose, _templ(dev), fg, bg, perturb=0.0)
     assert torch.isfinite(loss) and "loss_rgb_fine" not in details and "loss_normals" in details
+    assert sum(float(p.grad.abs().sum()) for p in m.nerf.parameters()) > 0
     # (b) by hand: forward, backward, a probing forward, THEN the optimiser step
     pts = torch.cat([torch.rand(256, 3, device=dev) * 2 - 1, torch.ones(256, 1, device=dev)], -1)
     versions = [p._version for p in tr.params]

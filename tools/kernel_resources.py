@@ -12,8 +12,14 @@ if r.returncode:
     print(r.stderr); sys.exit(1)
 asm = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")][0]
 txt = open(os.path.join(tmp, asm)).read()
-for m in re.finditer(r"^(_Z\w+):.*?\n(.*?)\.Lfunc_end\d+:(.*?); -- End function", txt, re.S | re.M):
-    name, body, tail = m.group(1), m.group(2), m.group(3)
+heads = list(re.finditer(r"^(_Z\w+):", txt, re.M))
+for hi, m in enumerate(heads):
+    name = m.group(1)
+    chunk = txt[m.end():heads[hi + 1].start() if hi + 1 < len(heads) else len(txt)]
+    end = re.search(r"\.Lfunc_end\d+:", chunk)
+    if not end:
+        continue
+    body, tail = chunk[:end.start()], chunk[end.end():]
     if filt not in name:
         continue
     ops = collections.Counter(re.findall(r"^\s+([a-z_0-9]+)\s", body, re.M))
