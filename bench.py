@@ -220,7 +220,7 @@ def rescale_sigma(model, gain, mode, dev):
             net.sigma.bias.mul_(gain).add_(-gain * med)
 
 
-def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling="weak", checks=False):
+def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling="weak", checks=False, check_rays=None):
     """BASELINE configs[1] / configs[2]: a full frame per step."""
     import anim_nerf_amd as ana
     from anim_nerf_amd import synthetic as syn
@@ -311,7 +311,7 @@ def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling=
                     "traffic": per_frame, "traffic_unit": f"HBM bytes per frame by PMC counters ({os.path.relpath(files[-1], ROOT)}, commit {t.get('commit')})",
                     "frac_by_counters": per_frame * (n_rays / n_frame) * steps / other_s / (PEAK_HBM_GBS * 1e9)})
     if checks and rank == 0 and world == 1:
-        if not args.no_psnr:
+        if not args.no_psnr and check_rays is None:
             # PSNR of this mode's image vs the fp32 parity path (pinned to the reference) on a centre crop
             c = min(256, H)
             lo = (H - c) // 2
@@ -323,7 +323,7 @@ def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling=
                 net.mlp_mode = mode
             result["psnr_vs_fp32_path_db"] = _psnr(out["rgbs_fine"][:, idx].cpu(), ref["rgbs_fine"].cpu())
         if args.cpu_rays > 0:
-            result["cpu_baseline"], pick, ref = cpu_baseline(args, tbl, model, rays, pose_np, use_warp)
+            result["cpu_baseline"], pick, ref = cpu_baseline(args, tbl, model, rays, pose_np, use_warp, check_rays)
             # the oracle's output as the checker: the same rays through the HIP path (fp32 parity mode and the benchmarked mode)
             sub = rays[:, pick.to(dev)].contiguous()
             key = "rgbs_fine" if args.n_fine else "rgbs"
@@ -527,7 +527,9 @@ def main():
         w = {}
         if world == 1:
             result["modes"] = {"f32": extra(render_bench, args, ctx, False, "f32", 2, 1, keep=("roofline_hbm_kernels",))}
-            w["cfg3"] = extra(render_bench, args, ctx, True, args.mode, 3, 1, keep=("roofline_hbm_kernels", "kernel_time_share"))
+            # (with its own oracle check: 1,024 rays through the oracle's brute-force 4-NN warp, ~25 s of host time)
+            w["cfg3"] = extra(render_bench, args, ctx, True, args.mode, 3, 1, checks=True, check_rays=1024,
+                              keep=("roofline_hbm_kernels", "kernel_time_share", "oracle_check", "cpu_baseline"))
             w["cfg3_dense"] = extra(render_bench, args, ctx, True, args.mode, 2, 1, dense=True)
             w["cfg4"] = extra(train_bench, args, ctx, args.mode, 8, 4, keep=("kernel_time_share", "final_loss"))
             w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 1)
@@ -548,7 +550,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, tbl, model, rays, pose_np, use_warp):
+def cpu_baseline(args, tbl, model, rays, pose_np, use_warp, max_rays=None):
     """The oracle (CPU restatement of the reference, torch CPU ops, all host cores) on a bounded
     sample of the same workload: `cpu_rays` rays of the same frame, same sample counts."""
     from anim_nerf_amd import synthetic as syn
@@ -579,7 +581,7 @@ def cpu_baseline(args, tbl, model, rays, pose_np, use_warp):
         if r > rate:
             rate, best = r, t
     torch.set_num_threads(best)
-    n = int(min(args.cpu_rays, max(64, rate * args.cpu_seconds)))
+    n = int(min(max_rays or args.cpu_rays, args.cpu_rays, max(64, rate * args.cpu_seconds)))
     # a regular grid over the central half of the image (where the body is: the oracle's cost does not depend on the
     # content, the check below does)
     H = W = int(round(rays.shape[1] ** 0.5))

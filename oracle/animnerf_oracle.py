@@ -390,9 +390,12 @@ def fine_depths(z_coarse: Tensor, weights: Tensor, n_fine: int, u: Optional[Tens
     return b0 + (u - c0) / den * (b1 - b0)
 
 
-def render_rays(field, rays: Tensor, n_coarse: int, n_fine: int, white_bkgd: bool = True):
+def render_rays(field, rays: Tensor, n_coarse: int, n_fine: int, white_bkgd: bool = True, z_fine: Optional[Tensor] = None):
     """models/volume_rendering.py:163-232 with perturb=0, share_fine=False.
-    `field(xyz[bs,N,3], use_fine) -> rgb[bs,N,3], sigma[bs,N,1]`."""
+    `field(xyz[bs,N,3], use_fine) -> rgb[bs,N,3], sigma[bs,N,1]`.
+    z_fine (a checker's option, not the reference's): use these importance samples [bs,R,n_fine] instead of drawing them —
+    the sampler is discontinuous (`denom < eps`, :92-93) and carries no gradient (:200), so a gradient check injects the
+    samples of the path under test and compares everything that IS differentiated."""
     bs, R = rays.shape[:2]
 
     def shade(z, use_fine):
@@ -405,7 +408,7 @@ def render_rays(field, rays: Tensor, n_coarse: int, n_fine: int, white_bkgd: boo
     w, col, dep, acc = shade(zc, False)
     out = dict(rgbs=col, alphas=acc, depths=dep, _z_coarse=zc, _weights=w)
     if n_fine > 0:
-        zf = fine_depths(zc, w.detach(), n_fine).detach()        # volume_rendering.py:200: no gradient through sampling
+        zf = (fine_depths(zc, w.detach(), n_fine) if z_fine is None else z_fine.to(zc)).detach()   # volume_rendering.py:200: no gradient through sampling
         zs, _ = torch.sort(torch.cat([zc, zf], -1), dim=-1)
         w2, col2, dep2, acc2 = shade(zs, True)
         out.update(rgbs_fine=col2, alphas_fine=acc2, depths_fine=dep2,
@@ -418,8 +421,8 @@ def render_rays(field, rays: Tensor, n_coarse: int, n_fine: int, white_bkgd: boo
 # ---------------------------------------------------------------------------
 
 def render_frame(tbl, P_coarse, P_fine, rays, pose_params, template_params, *, n_coarse, n_fine,
-                 use_unpose, dis_threshold=0.2, chunk=512, white_bkgd=True, knn_chunk=2048):
-    """train.py:189-215 / novel_view.py:78-98 — per-frame setup, ray-chunk loop, cat."""
+                 use_unpose, dis_threshold=0.2, chunk=512, white_bkgd=True, knn_chunk=2048, z_fine=None):
+    """train.py:189-215 / novel_view.py:78-98 — per-frame setup, ray-chunk loop, cat.  (z_fine: see render_rays.)"""
     st = frame_state(tbl, pose_params, template_params)
     st, rays_b = to_root_frame(st, rays)
     st['ober2cano'] = observation_to_canonical(st)
@@ -430,7 +433,8 @@ def render_frame(tbl, P_coarse, P_fine, rays, pose_params, template_params, *, n
 
     pieces = []
     for s in range(0, rays_b.shape[1], chunk):
-        pieces.append(render_rays(field, rays_b[:, s:s + chunk], n_coarse, n_fine, white_bkgd))
+        pieces.append(render_rays(field, rays_b[:, s:s + chunk], n_coarse, n_fine, white_bkgd,
+                                  None if z_fine is None else z_fine[:, s:s + chunk]))
     out = {k: torch.cat([p[k] for p in pieces], 1) for k in pieces[0]}
     out['_rays_body'] = rays_b
     return out

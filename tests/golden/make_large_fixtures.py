@@ -36,12 +36,14 @@ def main():
         ref = r_anim.AnimNeRF(model_path=tmp, model_type="smpl", gender="male", freqs_xyz=10, freqs_dir=0,
                               use_view=False, use_unpose=use_unpose, k_neigh=4, use_knn=False, use_fine=True,
                               share_fine=False, dis_threshold=0.2).eval()
-        with torch.no_grad():
-            probe = torch.rand(1, 4096, 3, generator=torch.Generator().manual_seed(5)) * 1.6 - 0.8
-            shift_c = -gain * ref.nerf(probe)[1].median().item()
-            shift_f = -gain * ref.nerf_fine(probe)[1].median().item()
-        mf.sigma_gain_(ref.nerf, gain, shift_c)
-        mf.sigma_gain_(ref.nerf_fine, gain, shift_f)
+        shift_c = shift_f = 0.0
+        if gain != 1.0:                                       # gain 1 = the reference's literal initialisation, untouched
+            with torch.no_grad():
+                probe = torch.rand(1, 4096, 3, generator=torch.Generator().manual_seed(5)) * 1.6 - 0.8
+                shift_c = -gain * ref.nerf(probe)[1].median().item()
+                shift_f = -gain * ref.nerf_fine(probe)[1].median().item()
+            mf.sigma_gain_(ref.nerf, gain, shift_c)
+            mf.sigma_gain_(ref.nerf_fine, gain, shift_f)
         pose = mf.t(syn.animated_pose_params(seed=3, bs=1) if pose_kind == "animated" else syn.static_pose_params(bs=1))
         templ = mf.t(syn.template_pose_params())
         c2w_i, foc_i, cen_i = syn.pinhole_camera(hw, hw)
@@ -69,9 +71,14 @@ def main():
             w_fine=mf.weights_checksum(ref.nerf_fine), **{f"pose_{k}": v.numpy() for k, v in pose.items()}, **res)
         print(name, {k: (float(v.min()), float(v.max())) for k, v in res.items()})
 
+    if "--only-init" in sys.argv:
+        # configs[2] at the reference's LITERAL initialisation (no sigma gain: sigma ~ 0.017 +- 0.003, a faint image, but none
+        # of the conditioning the gain adds): 1,024 rays, 64 + 64 — the warp held to 1e-4 on every ray
+        return case("cfg3_warp_init_1k", True, "animated", 1.0, 23, hw=32)
     if "--only-small" not in sys.argv:
         case("cfg2_nowarp_gain_4k", False, "static", 3000.0, 21)
         case("cfg3_warp_gain_4k", True, "animated", 3000.0, 22)
+        case("cfg3_warp_init_1k", True, "animated", 1.0, 23, hw=32)
     small_cases(r_vr)
 
 

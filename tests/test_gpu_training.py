@@ -18,9 +18,30 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _templ(device):
+def _templ(device=None):
     from anim_nerf_amd import synthetic as syn
-    return {k: torch.from_numpy(v).to(device) for k, v in syn.template_pose_params().items()}
+    return {k: torch.from_numpy(v).to(device) if device is not None else torch.from_numpy(v)
+            for k, v in syn.template_pose_params().items()}
+
+
+def _fp64(d):
+    return {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
+
+
+def _hip_fine_samples(m, vr, rays, pose, dev):
+    """z_fine[bs,R,Kf] the HIP path draws for this batch (perturb = 0), stage by stage with the same kernels — what the
+    oracle is handed when a gradient check must differentiate the same function (the sampler has no gradient and is
+    discontinuous: models/volume_rendering.py:92-93,200)."""
+    from anim_nerf_amd import ops
+    with torch.no_grad():
+        m.set_body_model({k: v.detach().to(dev) for k, v in pose.items()}, _templ(dev))
+        bs = rays.shape[0]
+        rays_b = m.convert_to_body_model_space(rays.to(dev).view(bs, -1, 8))
+        m.clac_ober2cano_transform()
+        zc = vr.sample_coarse(rays_b)
+        w_c = vr._shade(m, rays_b, zc, True, 0.0, True)[0]
+        _, zf = ops.sample_fine_merge(zc.view(-1, vr.n_coarse), w_c, vr._table(dev, "u", vr.n_fine), want_fine=True)
+    return zf.view(bs, -1, vr.n_fine).cpu().double()
 
 
 def test_composite_backward_matches_autograd(dev):
@@ -198,14 +219,17 @@ def test_training_loss_gradients_match_oracle(dev, smpl_table):
                              chunk=hp.chunk)
     loss, details = ana.compute_loss(m, hp, tgt_rgb.to(dev), tgt_a.to(dev), res, fg.to(dev), bg.to(dev))
     loss.backward()
-    # oracle
-    tbl = oracle_table(smpl_table)
-    Pc = {k: v.clone().requires_grad_(True) for k, v in net_params(m.nerf).items()}
-    Pf = {k: v.clone().requires_grad_(True) for k, v in net_params(m.nerf_fine).items()}
-    out = orc.render_frame(tbl, Pc, Pf, rays.view(2, 64, 8), pose, templ, n_coarse=16, n_fine=8, use_unpose=True,
-                           chunk=40, knn_chunk=512)
+    # oracle in float64, importance samples of the HIP path injected (they carry no gradient; drawn afresh they differ in a
+    # few bins at this sigma gain and move the whole gradient by ~1 %, which is what this gate used to absorb)
+    tbl = _fp64(oracle_table(smpl_table))
+    Pc = {k: v.double().requires_grad_(True) for k, v in net_params(m.nerf).items()}
+    Pf = {k: v.double().requires_grad_(True) for k, v in net_params(m.nerf_fine).items()}
+    z_fine = _hip_fine_samples(m, vr, rays, pose, dev)
+    out = orc.render_frame(tbl, Pc, Pf, rays.view(2, 64, 8).double(), _fp64(pose), _fp64(templ), n_coarse=16, n_fine=8,
+                           use_unpose=True, chunk=40, knn_chunk=512, z_fine=z_fine)
     F = torch.nn.functional
-    t_rgb, t_a = tgt_rgb.view(2, 64, 3), tgt_a.view(2, 64, 1)
+    t_rgb, t_a = tgt_rgb.view(2, 64, 3).double(), tgt_a.view(2, 64, 1).double()
+    fg, bg = fg.double(), bg.double()
     ref = (F.mse_loss(out["rgbs"], t_rgb) + F.mse_loss(out["rgbs_fine"], t_rgb)
            + 0.1 * (F.l1_loss(out["alphas"], t_a) + F.l1_loss(out["alphas_fine"], t_a)))
     for P in (Pc, Pf):
@@ -219,9 +243,10 @@ def test_training_loss_gradients_match_oracle(dev, smpl_table):
     for net, P in ((m.nerf, Pc), (m.nerf_fine, Pf)):
         num = den = 0.0
         for k, p in net.named_parameters():
-            num += (p.grad.cpu() - P[k].grad).pow(2).sum().item()
+            num += (p.grad.cpu().double() - P[k].grad).pow(2).sum().item()
             den += P[k].grad.pow(2).sum().item()
-        assert den > 0 and (num / den) ** 0.5 < 5e-3, (num / den) ** 0.5     # relative L2 error of the whole gradient
+        print("relative L2 error of the whole weight gradient vs fp64:", (num / den) ** 0.5)
+        assert den > 0 and (num / den) ** 0.5 < 1e-3, (num / den) ** 0.5     # relative L2 error of the whole gradient
 
 
 def test_adam_steps_reduce_loss(dev, smpl_table):
@@ -310,48 +335,140 @@ def test_bf16_training_gradients_close_to_fp32(dev, smpl_table):
     assert (grads["bf16"] - grads["f32"]).norm() / grads["f32"].norm() < 0.05
 
 
-def test_pose_refinement_gradients_match_oracle(dev, smpl_table):
-    """optim_body_params (train.py:141-144): gradients of the rendering loss w.r.t. betas / global_orient / body_pose /
-    transl through warp, sampling, compositing and the per-frame chain, against autograd of the oracle."""
+def test_frame_chain_backward_matches_fp64_oracle(dev, smpl_table):
+    """anr_frame_backward_adjoint (what the step calls) and anr_frame_backward (all forward mode) against FLOAT64 autograd
+    of the oracle's per-frame chain (smplx/lbs.py:152-251, models/anim_nerf.py:128-151: SMPL/LBS -> root frame -> 6,890
+    affine inverses) under the same upstream gradients: 1e-5 relative per parameter group.  Where the true gradient is zero
+    (ober2cano does not depend on global_orient / transl: the root frame cancels them) the kernels must return rounding
+    noise only, measured against the whole gradient."""
+    from anim_nerf_amd import ops, synthetic as syn
+    m = seeded_model(smpl_table, 3, True, device=dev)
+    bs, R = 4, 300
+    pose_np = syn.animated_pose_params(seed=6, bs=bs)
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in pose_np.items()}
+    with torch.no_grad():
+        m.set_body_model(pose, _templ(dev))
+    c = m._chain_consts()
+    gen = torch.Generator().manual_seed(2)
+    d_o2c = torch.randn(bs, m.body_model.lbs_weights.shape[0], 4, 4, generator=gen)
+    d_rays = torch.randn(bs, R, 8, generator=gen)
+    rays_w = torch.randn(bs, R, 8, generator=gen)
+    rays_w[..., 6], rays_w[..., 7] = 0.1 + 3 * torch.rand(bs, R, generator=gen), 3.5 + 3 * torch.rand(bs, R, generator=gen)
+    args = (pose["betas"].expand(bs, -1).contiguous(), torch.cat([pose["global_orient"], pose["body_pose"]], 1).contiguous(),
+            pose["transl"].expand(bs, -1).contiguous(), c["J0"], c["JS"], c["parents"], c["lbs_weights"], c["shapedirs"],
+            c["posedirs"], c["T_template"])
+    names = ("betas", "global_orient", "body_pose", "transl")
+    p64 = {k: torch.from_numpy(pose_np[k]).double().expand(bs, -1).clone().requires_grad_(True) for k in names}
+    st = orc.frame_state(_fp64(oracle_table(smpl_table)), p64, _fp64(_templ()))
+    st, rb = orc.to_root_frame(st, rays_w.double())
+    o2c = orc.observation_to_canonical(st)
+    for what, L in (("o2c", (o2c * d_o2c.double()).sum()), ("rays", (rb * d_rays.double()).sum())):
+        gr = torch.autograd.grad(L, [p64[k] for k in names], retain_graph=True, allow_unused=True)
+        ref = torch.cat([g_ if g_ is not None else torch.zeros_like(p64[k]) for g_, k in zip(gr, names)], 1)
+        kw = dict(d_o2c=d_o2c.to(dev)) if what == "o2c" else dict(d_rays=d_rays.to(dev), rays_world=rays_w.to(dev))
+        whole = ref.norm().item()
+        for forward_mode in (False, True):
+            got = ops.frame_backward(*args, **kw, forward_mode=forward_mode).cpu().double()
+            for lo, hi, name in ((0, 10, "betas"), (10, 13, "global_orient"), (13, 82, "body_pose"), (82, 85, "transl")):
+                err, scale = (got[:, lo:hi] - ref[:, lo:hi]).norm().item(), ref[:, lo:hi].norm().item()
+                assert err <= 1e-5 * scale + 2e-6 * whole, (what, forward_mode, name, err, scale, whole)
+
+
+@pytest.mark.parametrize("n_fine", [0, 8])
+@pytest.mark.parametrize("loss_on", ["rgb", "alpha", "depth"])
+def test_pose_refinement_gradients_match_fp64_oracle(dev, smpl_table, n_fine, loss_on):
+    """dL/d(betas, global_orient, body_pose, transl) of a rendering loss, HIP path in fp32 against FLOAT64 autograd of the
+    oracle, term by term — one loss per compositing output (colour, opacity, depth), so that no term hides behind another:
+
+    (1) at the interface between the per-frame chain and the renderer: dL/d o', dL/d d', dL/d near', dL/d far' (each its own
+        gate) and dL/d ober2cano[V,4,4] — near'/far' -> coarse depths, the sorted merge's permutation, the warp's blended
+        transforms, the encoding, the MLP's input gradient, compositing.  Gate 1e-4 (measured 2e-5).
+    (2) the chain below that interface is held to fp64 at 1e-5 by test_frame_chain_backward_matches_fp64_oracle; here: the
+        end-to-end gradient of the HIP path IS (1) pushed through the fp64 chain, to 1e-5 — nothing is lost in between.
+    (3) end to end against the fp64 oracle: 2e-3 on the coarse pass.  Through the fine pass the pose gradient is a
+        cancelling sum over 6,890 vertices that amplifies rounding ~500 x: the ORACLE ITSELF in fp32 is 1-2 % off its own fp64
+        value there (measured below, same injected samples; two realisations of that rounding noise), so the gate is
+        "within 3 x the deviation of the reference's own fp32 arithmetic, and under 5 %", not a number below it.
+    The importance sampler carries no gradient and is discontinuous (volume_rendering.py:92-93,200): the oracle is given the
+    HIP path's fine samples, so that both differentiate the same function."""
     import anim_nerf_amd as ana
     from anim_nerf_amd import synthetic as syn
     g = golden("render_cfg3_warp_gain")
-    m = seeded_model(smpl_table, g["seed"], True, g["gain"], g["shift"], device=dev)
+    gain = 50.0
+    m = seeded_model(smpl_table, g["seed"], True, gain, g["shift"] * gain / float(g["gain"]), device=dev, mlp_mode="f32")
     for p in m.parameters():
         p.requires_grad_(False)
-    vr = ana.VolumeRenderer(n_coarse=16, n_fine=8)
+    vr = ana.VolumeRenderer(n_coarse=16, n_fine=n_fine)
     pose_np = syn.animated_pose_params(seed=3, bs=2)
-    templ = {k: torch.from_numpy(v) for k, v in syn.template_pose_params().items()}
+    names = ("betas", "global_orient", "body_pose", "transl")
+    pose = {k: torch.from_numpy(pose_np[k]) for k in names}
     c2w, focal, cen = syn.pinhole_camera(8, 8)
     rays = orc.make_rays(torch.from_numpy(c2w), 8, 8, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(2, 1, 1, 1)
     gen = torch.Generator().manual_seed(4)
-    tgt_rgb, tgt_a = torch.rand(2, 8, 8, 3, generator=gen), (torch.rand(2, 8, 8, 1, generator=gen) > 0.5).float()
-    tgt_d = 3 + torch.rand(2, 8, 8, 1, generator=gen)
-    names = ("betas", "global_orient", "body_pose", "transl")
+    target = {"rgb": torch.rand(2, 64, 3, generator=gen), "alpha": (torch.rand(2, 64, 1, generator=gen) > 0.5).float(),
+              "depth": 3 + torch.rand(2, 64, 1, generator=gen)}[loss_on]
+    key = {"rgb": "rgbs", "alpha": "alphas", "depth": "depths"}[loss_on] + ("_fine" if n_fine else "")
 
-    def loss_of(res, t_rgb, t_a, t_d):
-        F = torch.nn.functional
-        return (F.mse_loss(res["rgbs"], t_rgb) + F.mse_loss(res["rgbs_fine"], t_rgb) + 0.1 * F.l1_loss(res["alphas"], t_a)
-                + 0.1 * F.l1_loss(res["alphas_fine"], t_a) + 0.05 * F.mse_loss(res["depths_fine"], t_d))
+    def loss_of(res):
+        d = res[key].reshape(target.shape) - target.to(res[key])
+        return d.abs().mean() if loss_on == "alpha" else (d ** 2).mean()
 
-    # HIP path
-    pose_g = {k: torch.from_numpy(pose_np[k]).to(dev).requires_grad_(True) for k in names}
-    res = ana.system_forward(vr, m, rays.to(dev), pose_g, _templ(dev), perturb=0.0, chunk=40)
-    loss = loss_of(res, tgt_rgb.to(dev), tgt_a.to(dev), tgt_d.to(dev))
+    def rel(a, b):
+        return ((a.double().cpu() - b).norm() / b.norm()).item()
+    z_fine = _hip_fine_samples(m, vr, rays, pose, dev) if n_fine else None      # the very samples the HIP path draws
+    tbl64, templ64 = _fp64(oracle_table(smpl_table)), _fp64(_templ())
+    P = [_fp64(net_params(n)) for n in (m.nerf, m.nerf_fine)]
+
+    # ---- (1) leaves at the chain / renderer interface
+    with torch.no_grad():
+        m.set_body_model({k: v.to(dev) for k, v in pose.items()}, _templ(dev))
+        rays_b = m.convert_to_body_model_space(rays.view(2, 64, 8).to(dev))
+        m.clac_ober2cano_transform()
+    rays_b = rays_b.detach().clone().requires_grad_(True)
+    m.ober2cano_transform = m.ober2cano_transform.detach().clone().requires_grad_(True)
+    loss_leaf = loss_of(vr(m, rays_b, perturb=0.0))
+    loss_leaf.backward()
+    st = orc.frame_state(tbl64, _fp64(pose), templ64)
+    st, _ = orc.to_root_frame(st, rays.view(2, 64, 8).double())
+    st["ober2cano"] = m.ober2cano_transform.detach().cpu().double().requires_grad_(True)
+    rb = rays_b.detach().cpu().double().requires_grad_(True)
+    field = lambda xyz, fine: orc.field_query(P[1 if fine else 0], xyz, st, tbl64["lbs_weights"], True, 0.2, chunk=512)
+    ref_leaf = loss_of(orc.render_rays(field, rb, 16, n_fine, z_fine=z_fine))
+    ref_leaf.backward()
+    assert abs(loss_leaf.item() - ref_leaf.item()) <= 1e-5 * abs(ref_leaf.item())
+    for name, cols in (("o'", slice(0, 3)), ("d'", slice(3, 6)), ("near'", slice(6, 7)), ("far'", slice(7, 8))):
+        assert rb.grad[..., cols].norm() > 0, name
+        assert rel(rays_b.grad[..., cols], rb.grad[..., cols]) < 1e-4, (name, rel(rays_b.grad[..., cols], rb.grad[..., cols]))
+    assert rel(m.ober2cano_transform.grad, st["ober2cano"].grad) < 1e-4
+    d_rays, d_o2c = rays_b.grad.cpu().double(), m.ober2cano_transform.grad.cpu().double()
+
+    # ---- (2) + (3) end to end
+    pose_g = {k: pose[k].clone().to(dev).requires_grad_(True) for k in names}
+    loss = loss_of(ana.system_forward(vr, m, rays.to(dev), pose_g, _templ(dev), perturb=0.0, chunk=64))
     loss.backward()
-    # oracle
-    tbl = oracle_table(smpl_table)
-    pose_o = {k: torch.from_numpy(pose_np[k]).clone().requires_grad_(True) for k in names}
-    out = orc.render_frame(tbl, net_params(m.nerf), net_params(m.nerf_fine), rays.view(2, 64, 8), pose_o, templ,
-                           n_coarse=16, n_fine=8, use_unpose=True, chunk=40, knn_chunk=512)
-    ref = loss_of(out, tgt_rgb.view(2, 64, 3), tgt_a.view(2, 64, 1), tgt_d.view(2, 64, 1))
-    ref.backward()
-    assert abs(loss.item() - ref.item()) <= 5e-4 * abs(ref.item())
+    grads = {}
+    for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        cast = _fp64 if dt == torch.float64 else (lambda d: d)
+        pose_o = {k: pose[k].clone().to(dt).requires_grad_(True) for k in names}
+        out = orc.render_frame(cast(oracle_table(smpl_table)), *[cast(net_params(n)) for n in (m.nerf, m.nerf_fine)],
+                               rays.view(2, 64, 8).to(dt), pose_o, cast(_templ()), n_coarse=16, n_fine=n_fine, use_unpose=True,
+                               chunk=64, knn_chunk=512, z_fine=None if z_fine is None else z_fine.to(dt))
+        ref = loss_of(out)
+        ref.backward()
+        grads[tag] = {k: pose_o[k].grad.double() for k in names}
+        if tag == "f64":
+            assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item()), (loss.item(), ref.item())
+    chain = {k: pose[k].clone().double().requires_grad_(True) for k in names}
+    st_c = orc.frame_state(tbl64, chain, templ64)
+    st_c, rb_c = orc.to_root_frame(st_c, rays.view(2, 64, 8).double())
+    ((rb_c * d_rays).sum() + (orc.observation_to_canonical(st_c) * d_o2c).sum()).backward()
     for k in names:
-        a, b = pose_g[k].grad.cpu(), pose_o[k].grad
-        assert b.abs().max() > 0, k
-        rel = (a - b).norm() / b.norm()
-        assert rel < 0.05, (k, rel.item(), a.flatten()[:4], b.flatten()[:4])
+        truth = grads["f64"][k]
+        assert truth.norm() > 0, k
+        assert rel(pose_g[k].grad, chain[k].grad) < 1e-5, (k, "composition", rel(pose_g[k].grad, chain[k].grad))
+        own = rel(grads["f32"][k], truth)                              # the reference's arithmetic against its fp64 self
+        got = rel(pose_g[k].grad, truth)
+        assert got < (2e-3 if n_fine == 0 else max(2e-3, 3.0 * own)) and got < 5e-2, (k, got, own)
 
 
 def test_trainer_updates_body_params_table(dev, smpl_table):
@@ -669,7 +786,7 @@ def test_frame_backward_subtree_skip_is_exact(dev, smpl_table):
 def test_frame_backward_adjoint_equals_forward_mode(dev, smpl_table):
     """anr_frame_backward_adjoint (reverse mode through the per-vertex inverses, forward mode through the joint chain:
     what the training step calls) against anr_frame_backward (everything in forward mode, one workgroup per parameter —
-    itself held to oracle autograd by test_pose_refinement_gradients_match_oracle): all 85 gradients of every frame."""
+    both held to fp64 oracle autograd by test_frame_chain_backward_matches_fp64_oracle): all 85 gradients of every frame."""
     from anim_nerf_amd import ops, synthetic as syn
     m = seeded_model(smpl_table, 3, True, device=dev)
     bs, R = 4, 300

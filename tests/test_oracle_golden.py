@@ -133,7 +133,7 @@ def big_case_inputs(g):
     return rays
 
 
-@pytest.mark.parametrize("case,stride", [("cfg2_nowarp_gain_4k", 4), ("cfg3_warp_gain_4k", 16)])
+@pytest.mark.parametrize("case,stride", [("cfg2_nowarp_gain_4k", 4), ("cfg3_warp_gain_4k", 16), ("cfg3_warp_init_1k", 4)])
 def test_render_case_4k(smpl_table, case, stride):
     """The oracle against the 4,096-ray reference renders (a strided subset, to keep the CPU suite short)."""
     g = golden("render_" + case)
