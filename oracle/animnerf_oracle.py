@@ -390,27 +390,36 @@ def fine_depths(z_coarse: Tensor, weights: Tensor, n_fine: int, u: Optional[Tens
     return b0 + (u - c0) / den * (b1 - b0)
 
 
-def render_rays(field, rays: Tensor, n_coarse: int, n_fine: int, white_bkgd: bool = True, z_fine: Optional[Tensor] = None):
-    """models/volume_rendering.py:163-232 with perturb=0, share_fine=False.
+def render_rays(field, rays: Tensor, n_coarse: int, n_fine: int, white_bkgd: bool = True, z_fine: Optional[Tensor] = None,
+                t_rand: Optional[Tensor] = None, noise=None, u: Optional[Tensor] = None):
+    """models/volume_rendering.py:163-232, share_fine=False.
     `field(xyz[bs,N,3], use_fine) -> rgb[bs,N,3], sigma[bs,N,1]`.
+    perturb = 0 by default; the training branches (perturb > 0) with their random numbers HANDED IN, so that a checker can
+    feed both sides the same draws: t_rand[bs,R,Kc] = perturb * U[0,1) (the stratified jitter, :48-54), noise =
+    (coarse[bs,R,Kc], fine[bs,R,Kc+Kf]) = noise_std * N(0,1) added to sigma before compositing (:128-129), u[bs,R,Kf] the
+    importance sampler's uniforms (:66-70).
     z_fine (a checker's option, not the reference's): use these importance samples [bs,R,n_fine] instead of drawing them —
     the sampler is discontinuous (`denom < eps`, :92-93) and carries no gradient (:200), so a gradient check injects the
     samples of the path under test and compares everything that IS differentiated."""
     bs, R = rays.shape[:2]
 
-    def shade(z, use_fine):
+    def shade(z, use_fine, nz):
         K = z.shape[-1]
         xyz = rays[..., None, :3] + z[..., None] * rays[..., None, 3:6]
         rgb, sig = field(xyz.reshape(bs, -1, 3), use_fine)
-        return composite(rgb.reshape(bs, R, K, 3), sig.reshape(bs, R, K), z, rays[..., 7:8], white_bkgd)
+        sig = sig.reshape(bs, R, K)
+        if nz is not None:
+            sig = sig + nz.to(sig)
+        return composite(rgb.reshape(bs, R, K, 3), sig, z, rays[..., 7:8], white_bkgd)
 
-    zc = coarse_depths(rays, n_coarse)
-    w, col, dep, acc = shade(zc, False)
+    zc = coarse_depths(rays, n_coarse, None if t_rand is None else t_rand.to(rays))
+    w, col, dep, acc = shade(zc, False, None if noise is None else noise[0])
     out = dict(rgbs=col, alphas=acc, depths=dep, _z_coarse=zc, _weights=w)
     if n_fine > 0:
-        zf = (fine_depths(zc, w.detach(), n_fine) if z_fine is None else z_fine.to(zc)).detach()   # volume_rendering.py:200: no gradient through sampling
+        # volume_rendering.py:200: no gradient through sampling
+        zf = (fine_depths(zc, w.detach(), n_fine, None if u is None else u.to(zc)) if z_fine is None else z_fine.to(zc)).detach()
         zs, _ = torch.sort(torch.cat([zc, zf], -1), dim=-1)
-        w2, col2, dep2, acc2 = shade(zs, True)
+        w2, col2, dep2, acc2 = shade(zs, True, None if noise is None else noise[1])
         out.update(rgbs_fine=col2, alphas_fine=acc2, depths_fine=dep2,
                    _z_fine=zf, _z_sorted=zs, _weights_fine=w2)
     return out
@@ -421,8 +430,10 @@ def render_rays(field, rays: Tensor, n_coarse: int, n_fine: int, white_bkgd: boo
 # ---------------------------------------------------------------------------
 
 def render_frame(tbl, P_coarse, P_fine, rays, pose_params, template_params, *, n_coarse, n_fine,
-                 use_unpose, dis_threshold=0.2, chunk=512, white_bkgd=True, knn_chunk=2048, z_fine=None):
-    """train.py:189-215 / novel_view.py:78-98 — per-frame setup, ray-chunk loop, cat.  (z_fine: see render_rays.)"""
+                 use_unpose, dis_threshold=0.2, chunk=512, white_bkgd=True, knn_chunk=2048, z_fine=None, t_rand=None,
+                 noise=None, u=None):
+    """train.py:189-215 / novel_view.py:78-98 — per-frame setup, ray-chunk loop, cat.
+    (z_fine, t_rand, noise, u: see render_rays; per-ray tensors for the whole frame, chunked here.)"""
     st = frame_state(tbl, pose_params, template_params)
     st, rays_b = to_root_frame(st, rays)
     st['ober2cano'] = observation_to_canonical(st)
@@ -433,8 +444,9 @@ def render_frame(tbl, P_coarse, P_fine, rays, pose_params, template_params, *, n
 
     pieces = []
     for s in range(0, rays_b.shape[1], chunk):
-        pieces.append(render_rays(field, rays_b[:, s:s + chunk], n_coarse, n_fine, white_bkgd,
-                                  None if z_fine is None else z_fine[:, s:s + chunk]))
+        cut = lambda t: None if t is None else t[:, s:s + chunk]
+        pieces.append(render_rays(field, rays_b[:, s:s + chunk], n_coarse, n_fine, white_bkgd, cut(z_fine), cut(t_rand),
+                                  None if noise is None else (cut(noise[0]), cut(noise[1])), cut(u)))
     out = {k: torch.cat([p[k] for p in pieces], 1) for k in pieces[0]}
     out['_rays_body'] = rays_b
     return out

@@ -61,3 +61,49 @@ def rel_err(a, b, floor=1e-3):
     """max |a-b| / max(|b|, floor)."""
     a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
     return ((a - b).abs() / b.abs().clamp_min(floor)).max().item()
+
+
+class InjectedDraws:
+    """Context manager: every torch.rand / torch.randn / torch.randn_like inside comes from a seeded CPU generator (record
+    mode) or from a given list of tensors (replay mode), and is kept in `.drawn` — so that a training step with perturb > 0
+    can be run twice on the same random numbers, on a sub-batch of them, and through the CPU oracle."""
+
+    def __init__(self, seed=None, replay=None):
+        self.gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        self.replay = list(replay) if replay is not None else None
+        self.drawn = []
+
+    def _next(self, kind, shape, device):
+        if self.replay is not None:
+            t = self.replay[len(self.drawn)]
+            assert tuple(t.shape) == tuple(shape), (kind, tuple(t.shape), tuple(shape))
+        else:
+            t = (torch.rand if kind == "rand" else torch.randn)(*shape, generator=self.gen)
+        self.drawn.append(t)
+        return t.to(device)
+
+    def __enter__(self):
+        self._orig = (torch.rand, torch.randn, torch.randn_like)
+        orig_rand, orig_randn, _ = self._orig
+
+        def shape_of(args):
+            return tuple(args[0]) if len(args) == 1 and isinstance(args[0], (tuple, list, torch.Size)) else tuple(args)
+
+        def rand(*args, device=None, generator=None, **kw):
+            if generator is not None:
+                return orig_rand(*args, device=device, generator=generator, **kw)
+            return self._next("rand", shape_of(args), device)
+
+        def randn(*args, device=None, generator=None, **kw):
+            if generator is not None:
+                return orig_randn(*args, device=device, generator=generator, **kw)
+            return self._next("randn", shape_of(args), device)
+
+        def randn_like(t, **kw):
+            return self._next("randn", tuple(t.shape), t.device).to(t.dtype)
+        torch.rand, torch.randn, torch.randn_like = rand, randn, randn_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randn, torch.randn_like = self._orig
+        return False

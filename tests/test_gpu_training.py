@@ -850,3 +850,235 @@ def test_bench_self_launch_two_ranks_on_one_device(dev):
     w = line["workloads"]
     assert set(w) == {"cfg2_strong", "cfg3", "cfg3_strong", "cfg4", "cfg5"} and not any("error" in v for v in w.values()), w
     assert w["cfg2_strong"]["scaling"] == "strong" and w["cfg4"]["n_gpus"] == 2
+
+
+def _config3_scene(dev, smpl_table, F=16, H=32):
+    """BASELINE configs[3]'s batch shape (configs/people_snapshot/male-3-casual.yaml:23-51, train.py:324-348): F frames x H x H
+    rays, 64 coarse + 32 fine samples, perturb = 1 (jitter, sigma noise, random importance samples), foreground /
+    background prior points, learnable SMPL rows (optim_body_params)."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    m = seeded_model(smpl_table, 13, True, device=dev, mlp_mode="f32")
+    probe = (torch.rand(1, 4096, 3, generator=torch.Generator().manual_seed(5)) * 1.6 - 0.8).to(dev)
+    with torch.no_grad():                                     # random-init sigma has one sign everywhere: spread it about its
+        for net in (m.nerf, m.nerf_fine):                     # median (gain 300), so that about half of the body is opaque
+            med = net(probe)[1].median().item()
+            net.sigma.weight.mul_(300.0)
+            net.sigma.bias.mul_(300.0).add_(-300.0 * med)
+    m.train()
+    table = ana.BodyModelParams(40).to(dev)
+    seeded = syn.animated_pose_params(seed=200, bs=40)
+    for name in table.param_names:
+        table.init_parameters(name, torch.from_numpy(seeded[name]).to(dev), requires_grad=True)
+    c2w, focal, cen = syn.pinhole_camera(H, H)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), H, H, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(F, 1, 1, 1)
+    gen = torch.Generator().manual_seed(17)
+    batch = dict(rays=rays, rgbs=torch.rand(F, H, H, 3, generator=gen).to(dev),
+                 alphas=(torch.rand(F, H, H, 1, generator=gen) > 0.5).float().to(dev),
+                 fg=(torch.rand(F, 128, 3, generator=gen) * 0.4 - 0.2).to(dev), bg=(torch.rand(F, 128, 3, generator=gen) * 2 - 1).to(dev),
+                 frame_idx=(torch.arange(F) * 2 + 1).to(dev))
+    return m, table, batch
+
+
+def _step_gradients(m, table, vr, hp, batch, draws, frames=None, rows=None):
+    """loss.backward() of one training step (no optimiser) on the frames / image rows given -> (loss, details, gradients by
+    name, the draws made).  Plain autograd accumulation (no GradSink)."""
+    import anim_nerf_amd as ana
+    sel = slice(None) if frames is None else frames
+    rsel = slice(None) if rows is None else rows
+    for p in list(m.parameters()) + list(table.parameters()):
+        p.grad = None
+    with draws:
+        pose = table(batch["frame_idx"][sel])
+        res = ana.system_forward(vr, m, batch["rays"][sel][:, rsel].contiguous(), pose, _templ(batch["rays"].device), perturb=1.0,
+                                 chunk=hp.chunk)
+        loss, details = ana.compute_loss(m, hp, batch["rgbs"][sel][:, rsel], batch["alphas"][sel][:, rsel], res,
+                                         batch["fg"][sel], batch["bg"][sel])
+        loss.backward()
+    grads = {"nerf." + k: p.grad.clone() for k, p in m.nerf.named_parameters() if p.grad is not None}
+    grads.update({"nerf_fine." + k: p.grad.clone() for k, p in m.nerf_fine.named_parameters() if p.grad is not None})
+    grads.update({"smpl." + k: p.grad.clone() for k, p in table.named_parameters() if p.grad is not None})
+    return loss.detach(), details, grads, draws.drawn
+
+
+def test_config3_shape_training_step(dev, smpl_table):
+    """One optimisation step at configs[3]'s REAL batch shape — 16 frames x 32 x 32 rays, 64 + 32 samples, perturb = 1 with
+    the jitter / sigma noise / importance uniforms / normals points injected from a recorded stream, every reference-default
+    loss term, pose refinement on — in fp32 (the arithmetic the oracle can be held to):
+      (a) finite everywhere; a second run over the same draws gives the same bits (loss, all 48 network tensors);
+      (b) the Trainer's flat GradSink buffers (what RCCL sends) == plain autograd accumulation;
+      (c) the batch gradient is the mean of its eight 2-frame sub-batches' (rendering + prior terms): sub-batches compose;
+      (d) a sub-batch the CPU can afford (frames 0-1, image rows 12-19: 512 rays x 160 samples) against FLOAT64 autograd of the
+          oracle fed the same draws (and the HIP path's fine samples: the sampler is discontinuous): loss 1e-5, each
+          network's whole gradient 1e-3, every one of the 2 x 24 weight tensors 5e-3, the SMPL rows."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import ops
+    from helpers import InjectedDraws
+    F, H = 16, 32
+    m, table, batch = _config3_scene(dev, smpl_table, F, H)
+    vr = ana.VolumeRenderer(n_coarse=64, n_fine=32)
+    hp = ana.TrainHParams(n_samples=64, n_importance=32, chunk=2048)
+    assert vr.noise_std == 1.0 and hp.lambda_normals == 0.01
+
+    # ---- (a)
+    loss, details, grads, drawn = _step_gradients(m, table, vr, hp, batch, InjectedDraws(seed=5))
+    assert [tuple(t.shape) for t in drawn[:4]] == [(F * H * H, 64), (F * H * H, 64), (F * H * H, 32), (F * H * H, 96)]
+    assert len(drawn) == 6 and torch.isfinite(loss) and all(torch.isfinite(g).all() for g in grads.values())
+    assert len(grads) == 48 + 4 and all(float(g.abs().max()) > 0 for g in grads.values())
+    assert {"loss_rgb", "loss_rgb_fine", "loss_alphas_fine", "loss_foreground_fine", "loss_background", "loss_normals_fine"} <= set(details)
+    loss2, _, grads2, _ = _step_gradients(m, table, vr, hp, batch, InjectedDraws(replay=drawn))
+    # (the 48 network tensors bit for bit: fixed-order split-K sums, no float atomics; the SMPL rows collect the warp's
+    # per-vertex gradient with atomics — anr_warp_backward — and are reproducible to rounding only)
+    differ = [k for k in grads if not torch.equal(grads[k], grads2[k])]
+    assert torch.equal(loss, loss2) and all(k.startswith("smpl.") for k in differ), differ
+    for k in differ:
+        assert (grads[k] - grads2[k]).abs().max().item() <= 1e-5 * grads[k].abs().max().item(), k
+
+    # ---- (b) the same step through the Trainer's sinks / flat buffers (no optimiser step)
+    tr = ana.Trainer(m, vr, hp, body_model_params=table)
+    assert m.nerf.grad_sink is not None and m.nerf_fine.grad_sink is not None
+    tr.begin_step()
+    with InjectedDraws(replay=drawn):
+        res = ana.system_forward(vr, m, batch["rays"], table(batch["frame_idx"]), _templ(dev), perturb=1.0, chunk=hp.chunk)
+        loss3 = ana.compute_loss(m, hp, batch["rgbs"], batch["alphas"], res, batch["fg"], batch["bg"])[0]
+        loss3.backward()
+    assert torch.equal(loss3.detach(), loss)
+    for prefix, net in (("nerf.", m.nerf), ("nerf_fine.", m.nerf_fine)):
+        for k, p in net.named_parameters():
+            ref = grads[prefix + k]
+            assert (p.grad - ref).abs().max().item() <= 2e-6 * ref.abs().max().item() + 1e-12, (prefix + k)
+    for k, p in table.named_parameters():
+        assert (p.grad - grads["smpl." + k]).abs().max().item() <= 2e-6 * grads["smpl." + k].abs().max().item() + 1e-12, k
+    for net in (m.nerf, m.nerf_fine):
+        net.grad_sink = None
+
+    # ---- (c) without the normals term (its random points are not per frame)
+    hp0 = ana.TrainHParams(n_samples=64, n_importance=32, chunk=2048, lambda_normals=0.0)
+    per_ray = lambda t, fr, rows=None: t.view(F, H, H, -1)[fr][:, slice(None) if rows is None else rows].reshape(-1, t.shape[-1])
+    _, _, g_full, _ = _step_gradients(m, table, vr, hp0, batch, InjectedDraws(replay=drawn[:4]))
+    mean = None
+    for i in range(F // 2):
+        fr = slice(2 * i, 2 * i + 2)
+        _, _, g_i, _ = _step_gradients(m, table, vr, hp0, batch, InjectedDraws(replay=[per_ray(t, fr) for t in drawn[:4]]), frames=fr)
+        mean = g_i if mean is None else {k: mean[k] + g_i[k] for k in mean}
+    for k in g_full:
+        want = mean[k] / (F // 2)
+        assert (g_full[k] - want).norm().item() <= 2e-5 * want.norm().item() + 1e-12, (k, (g_full[k] - want).norm().item(), want.norm().item())
+
+    # ---- (d)
+    fr, rows = slice(0, 2), slice(12, 20)
+    sub = [per_ray(t, fr, rows) for t in drawn[:4]]
+    seen = {}
+    orig_merge = ops.sample_fine_merge
+
+    def spy(z_coarse, weights, u, **kw):                        # the HIP path's own importance samples of this sub-batch
+        out = orig_merge(z_coarse, weights, u, **kw)
+        seen["z_fine"] = orig_merge(z_coarse.detach(), weights, u, want_fine=True)[1].cpu().double()
+        return out
+    ops.sample_fine_merge = spy
+    try:
+        l_sub, _, g_sub, _ = _step_gradients(m, table, vr, hp0, batch, InjectedDraws(replay=sub), frames=fr, rows=rows)
+    finally:
+        ops.sample_fine_merge = orig_merge
+    R = 8 * H
+    names = ("betas", "global_orient", "body_pose", "transl")
+    idx = batch["frame_idx"][fr].cpu()
+    rows_o = {k: getattr(table, k).weight.detach().cpu().double() for k in names}
+    leaf = {k: (rows_o[k][idx] if k != "betas" else rows_o[k][:1].expand(2, -1)).clone().requires_grad_(True) for k in names}
+    Pc = {k: v.double().requires_grad_(True) for k, v in net_params(m.nerf).items()}
+    Pf = {k: v.double().requires_grad_(True) for k, v in net_params(m.nerf_fine).items()}
+    t_rand, n_c, _, n_f = [t.view(2, R, -1).double() for t in sub]
+    out = orc.render_frame(_fp64(oracle_table(smpl_table)), Pc, Pf, batch["rays"][fr][:, rows].reshape(2, R, 8).cpu().double(), leaf,
+                           _fp64(_templ()), n_coarse=64, n_fine=32, use_unpose=True, chunk=R, knn_chunk=2048, t_rand=t_rand,
+                           noise=(n_c * vr.noise_std, n_f * vr.noise_std), z_fine=seen["z_fine"].view(2, R, 32))
+    Fn = torch.nn.functional
+    t_rgb = batch["rgbs"][fr][:, rows].reshape(2, R, 3).cpu().double()
+    t_a = batch["alphas"][fr][:, rows].reshape(2, R, 1).cpu().double()
+    ref = (Fn.mse_loss(out["rgbs"], t_rgb) + Fn.mse_loss(out["rgbs_fine"], t_rgb)
+           + hp0.lambda_alphas * (Fn.l1_loss(out["alphas"], t_a) + Fn.l1_loss(out["alphas_fine"], t_a)))
+    fg, bg = batch["fg"][fr].cpu().double(), batch["bg"][fr].cpu().double()
+    for P in (Pc, Pf):
+        ref = ref + hp0.lambda_foreground * torch.mean(torch.exp(-2.0 / 64 * torch.relu(orc.mlp_sigma_and_feature(P, fg)[0]))) \
+                  + hp0.lambda_background * torch.mean(1 - torch.exp(-2.0 / 64 * torch.relu(orc.mlp_sigma_and_feature(P, bg)[0])))
+    ref.backward()
+    assert out["alphas_fine"].max() > 0.2 and (out["alphas_fine"] > 0.05).float().mean() > 0.1, "the test scene must not be empty"
+    assert abs(l_sub.item() - ref.item()) <= 1e-5 * abs(ref.item()), (l_sub.item(), ref.item())
+    worst = 0.0
+    for prefix, P in (("nerf.", Pc), ("nerf_fine.", Pf)):
+        num = den = 0.0
+        for k in P:
+            a, b = g_sub[prefix + k].cpu().double(), P[k].grad
+            err = ((a - b).norm() / b.norm()).item()
+            worst = max(worst, err)
+            num, den = num + (a - b).pow(2).sum().item(), den + b.pow(2).sum().item()
+            assert err < 5e-3, (prefix + k, err)                    # every tensor on its own (the small ones are the noisy ones)
+        assert (num / den) ** 0.5 < 1e-3, (prefix, (num / den) ** 0.5)  # the network's whole gradient
+        print(f"\nconfigs[3] shape, {prefix} whole gradient vs fp64 oracle: {(num / den) ** 0.5:.1e}")
+    print(f"configs[3] shape, sub-batch vs fp64 oracle: loss {l_sub.item():.6f} / {ref.item():.6f}, worst weight-tensor error {worst:.1e}")
+    for k in names:
+        b = leaf[k].grad if k != "betas" else leaf[k].grad.sum(0, keepdim=True)
+        a = g_sub["smpl." + k + ".weight"].cpu().double()
+        a = a[idx] if k != "betas" else a[:1]
+        # (the pose gradient through the fine pass is a cancelling sum that amplifies fp32 rounding to the per-cent level in the
+        # reference's own arithmetic as well: test_pose_refinement_gradients_match_fp64_oracle takes it apart)
+        assert ((a - b).norm() / b.norm()).item() < 5e-2, (k, ((a - b).norm() / b.norm()).item())
+
+
+def test_training_tracks_an_oracle_trained_copy(dev, smpl_table):
+    """150 optimisation steps (perturb = 0, rgb + alpha + foreground / background terms, Adam 1e-3 with the polynomial
+    schedule off) on the HIP path and on a copy trained through the ORACLE's autograd on the CPU — same initialisation, same
+    batches, same optimiser.  Training is judged by where it ends up (SURVEY hard part 5): the two loss curves must stay
+    within 2 % of each other at every step and end within 0.1 dB of PSNR.  (They are two fp32 realisations of one
+    trajectory: rounding differences are fed back 150 times, so the band is not a rounding bound.)"""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    steps = 150
+    m = seeded_model(smpl_table, 11, True, 300.0, (2.0, 2.0), device=dev, mlp_mode="f32")
+    with torch.no_grad():
+        probe = (torch.rand(1, 4096, 3, generator=torch.Generator().manual_seed(5)) * 1.6 - 0.8).to(dev)
+        for net in (m.nerf, m.nerf_fine):
+            net.sigma.bias.add_(-net(probe)[1].median().item())
+    Pc = {k: v.clone().requires_grad_(True) for k, v in net_params(m.nerf).items()}
+    Pf = {k: v.clone().requires_grad_(True) for k, v in net_params(m.nerf_fine).items()}
+    hp = ana.TrainHParams(n_samples=16, n_importance=8, chunk=64, lambda_normals=0.0, lr=1e-3, max_epochs=10 ** 9)
+    vr = ana.VolumeRenderer(n_coarse=16, n_fine=8)
+    tr = ana.Trainer(m, vr, hp)
+    opt = torch.optim.Adam(list(Pc.values()) + list(Pf.values()), lr=1e-3, eps=1e-8)
+    pose_np = syn.animated_pose_params(seed=3, bs=2)
+    pose = {k: torch.from_numpy(v) for k, v in pose_np.items()}
+    c2w, focal, cen = syn.pinhole_camera(8, 8)
+    rays = orc.make_rays(torch.from_numpy(c2w), 8, 8, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(2, 1, 1, 1)
+    gen = torch.Generator().manual_seed(4)
+    # a target that can be fitted: a smooth image, opaque where the initial model is
+    tgt_rgb = torch.rand(2, 1, 1, 3, generator=gen).expand(2, 8, 8, 3).contiguous() * 0.5 + 0.25
+    with torch.no_grad():
+        first = ana.batched_inference(vr, m, rays.view(2, 64, 8).to(dev), {k: v.to(dev) for k, v in pose.items()}, _templ(dev), chunk=64)
+    tgt_a = (first["alphas_fine"].view(2, 8, 8, 1).cpu() > 0.3).float()
+    fg = torch.rand(2, 64, 3, generator=gen) * 0.4 - 0.2
+    bg = torch.rand(2, 64, 3, generator=gen) * 2 - 1
+    tbl, templ = oracle_table(smpl_table), _templ()
+    F = torch.nn.functional
+    pose_d, dev_batch = {k: v.to(dev) for k, v in pose.items()}, [t.to(dev) for t in (rays, tgt_rgb, tgt_a, fg, bg)]
+    curve_h, curve_o = [], []
+    for it in range(steps):
+        loss_h, det = tr.step(dev_batch[0], dev_batch[1], dev_batch[2], pose_d, _templ(dev), dev_batch[3], dev_batch[4], perturb=0.0)
+        curve_h.append(loss_h.item())
+        opt.zero_grad(set_to_none=True)
+        out = orc.render_frame(tbl, Pc, Pf, rays.view(2, 64, 8), pose, templ, n_coarse=16, n_fine=8, use_unpose=True, chunk=64, knn_chunk=512)
+        t_rgb, t_a = tgt_rgb.view(2, 64, 3), tgt_a.view(2, 64, 1)
+        ref = (F.mse_loss(out["rgbs"], t_rgb) + F.mse_loss(out["rgbs_fine"], t_rgb)
+               + 0.1 * (F.l1_loss(out["alphas"], t_a) + F.l1_loss(out["alphas_fine"], t_a)))
+        for P in (Pc, Pf):
+            ref = ref + 0.01 * torch.mean(torch.exp(-2.0 / 16 * torch.relu(orc.mlp_sigma_and_feature(P, fg)[0]))) \
+                      + 0.01 * torch.mean(1 - torch.exp(-2.0 / 16 * torch.relu(orc.mlp_sigma_and_feature(P, bg)[0])))
+        ref.backward()
+        opt.step()
+        curve_o.append(ref.item())
+    psnr_h = det["psnr"].item()
+    psnr_o = -10.0 * torch.log10(F.mse_loss(out["rgbs_fine"], t_rgb)).item()
+    gap = max(abs(a - b) / b for a, b in zip(curve_h, curve_o))
+    print(f"\nloss {curve_o[0]:.4f} -> HIP {curve_h[-1]:.4f} / oracle {curve_o[-1]:.4f}; widest gap of the curves {gap:.2%}; "
+          f"PSNR (last step's batch) HIP {psnr_h:.2f} dB / oracle {psnr_o:.2f} dB")
+    assert curve_o[-1] < 0.85 * curve_o[0], "the run must actually train"
+    assert abs(curve_h[0] - curve_o[0]) <= 1e-4 * curve_o[0]
+    assert gap < 0.02 and abs(psnr_h - psnr_o) < 0.1
