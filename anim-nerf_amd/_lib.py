@@ -111,6 +111,12 @@ SIGNATURES = {
     "anr_expand_rows": (_I, [_P, _P, _L, _I, _F, _P, _P]),
     "anr_mlp_head_grad": (_I, [_P, _P, _P, _P, _L, _L, _I, _P, _P]),
     "anr_tangent_quads": (_I, [_P, _L, _L, _P, _P]),
+    "anr_mlp_head_grad_counted": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "anr_mlp_backward_counted": (_I, [_P, _I, _P, _P, _P, _L, _P, _P]),
+    "anr_encode64_counted": (_I, [_P, _I, _L, _P, _I, _P, _P]),
+    "anr_mlp_wgrad_counted": (_I, [_I, _P, _P, _P, _P, _L, _P, _P, _P, _P]),
+    "anr_mlp_denc_counted": (_I, [_I, _P, _P, _P, _L, _P, _P, _P]),
+    "anr_encode_backward_counted": (_I, [_P, _I, _P, _L, _P, _P, _P]),
     "anr_sample_coarse_backward": (_I, [_P, _P, _P, _L, _I, _P, _P]),
     "anr_merge_backward": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "anr_train_loss_ws_floats": (_L, []),

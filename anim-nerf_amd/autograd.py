@@ -194,32 +194,30 @@ class MLPFunction(torch.autograd.Function):
         ctx.sink = sink if (sink is not None and not MLPFunction.LIBRARY_GEMMS and sink.usable()) else None
         if ctx.sink is not None:
             ctx.sink.announce()
-        index = pos = None
-        rows = n
         if only_valid:
             # samples outside dis_threshold have sigma = -1e5 and composite weight exactly 0: neither their outputs nor
             # their (exactly zero) gradients are needed.  Forward, saved activations and backward run on the rest, listed
             # in sample order (the row order fixes the order of every split-K sum downstream: same bits on every run).
+            # How many there are stays ON THE DEVICE (count[0]; count[1] = padded to 64 rows): every buffer is sized for all n
+            # samples — rows that are never written cost address space only — and the kernels stop at the count.  Reading
+            # it back to size the buffers drained the queue once per network pass.
             index, pos, pts_c, count = ops.compact_ordered(pts)
-            cnt = int(count.item())                                   # the row counts of the saved tensors need it on the host
-            if cnt < n:
-                rows = cnt
-                pts = pts_c[:max(-(-rows // MLPFunction.PAD), 1) * MLPFunction.PAD]
-            else:
-                index = pos = None
-        n_pad = max(-(-rows // MLPFunction.PAD), 1) * MLPFunction.PAD
-        if index is None and n_pad != n:
+            rows_dev = count[1:2]
+            out, act = ops.mlp_forward_save(pack, mode_id, pts_c, sigma_only, count=rows_dev)
+            ctx.count = count
+            ctx.compacted = True
+            ctx.save_for_backward(pts_c, out, act, index, pos, *params)
+            return ops.expand_rows(out, pos, -1e5)                    # (0,0,0,-1e5) / -1e5 for the samples not listed
+        n_pad = max(-(-n // MLPFunction.PAD), 1) * MLPFunction.PAD
+        if n_pad != n:
             pts_c = pts.new_zeros(n_pad, 4)                           # padding rows: valid = 0, zero upstream gradient
-            pts_c[:rows] = pts
+            pts_c[:n] = pts
             pts = pts_c
         out, act = ops.mlp_forward_save(pack, mode_id, pts, sigma_only)
-        ctx.rows = rows
-        ctx.compacted = index is not None
-        if index is None:
-            ctx.save_for_backward(pts, out, act, *params)
-            return out[:n] if n_pad != n else out
-        ctx.save_for_backward(pts, out, act, index, pos, *params)
-        return ops.expand_rows(out, pos, -1e5)                        # (0,0,0,-1e5) / -1e5 for the samples not listed
+        ctx.count = None
+        ctx.compacted = False
+        ctx.save_for_backward(pts, out, act, *params)
+        return out[:n] if n_pad != n else out
 
     @staticmethod
     @torch.no_grad()
@@ -229,30 +227,36 @@ class MLPFunction(torch.autograd.Function):
             pts, out, act, index, pos, *params = ctx.saved_tensors
         else:
             pts, out, act, *params = ctx.saved_tensors
-        n, rows = pts.shape[0], ctx.rows
+        n = pts.shape[0]
+        count = ctx.count                                           # compacted: (rows, rows padded to 64) on the device
+        rows_dev = None if count is None else count[1:2]
         dt = act.dtype                                              # fp32 (parity mode) or bf16 (mixed precision)
         want_pts = ctx.needs_input_grad[0]
         weights_generation(params[0], backward=True)
         # (dL/d rgb x sigmoid', dL/d sigma where the sample is valid) on the compacted + padded rows
-        g4 = ops.mlp_head_grad(g, index, None if ctx.sigma_only else out, pts, rows, ctx.sigma_only)
+        g4 = ops.mlp_head_grad(g, index, None if ctx.sigma_only else out, pts, ctx.n_full if count is None else count, ctx.sigma_only)
         d_enc = None
         grads = {}
         if MLPFunction.LIBRARY_GEMMS:
-            grads, d_enc = _library_backward(ctx, params, pts, act, g4, want_pts)
+            # (the cross-check path works on host-sized tensors: it reads the row count back)
+            grads, d_enc = _library_backward(ctx, params, pts, act, g4, want_pts, None if count is None else int(count[1].item()))
+            if d_enc is not None and d_enc.shape[0] != pts.shape[0]:
+                d_enc = torch.cat([d_enc, d_enc.new_zeros(pts.shape[0] - d_enc.shape[0], d_enc.shape[1])])
         else:
             # activation gradients: ONE kernel for the whole chain (csrc/mlp_bwd.hip); weight + bias gradients: split-K MFMA
             # GEMMs between its output columns, the saved activations and the encoding matrix (csrc/mlp_wgrad.hip)
-            dact = ops.mlp_backward(_cached_pack(params, ctx.mode_id, True), ctx.mode_id, g4, act, sigma_only=ctx.sigma_only)
-            flat = ops.mlp_wgrad(ctx.mode_id, act, dact, ops.encode64(pts, dt), g4, sigma_only=ctx.sigma_only,
-                                 accumulate_into=None if ctx.sink is None else ctx.sink.flat)
+            dact = ops.mlp_backward(_cached_pack(params, ctx.mode_id, True), ctx.mode_id, g4, act, sigma_only=ctx.sigma_only,
+                                    count=rows_dev)
+            flat = ops.mlp_wgrad(ctx.mode_id, act, dact, ops.encode64(pts, dt, count=rows_dev), g4, sigma_only=ctx.sigma_only,
+                                 accumulate_into=None if ctx.sink is None else ctx.sink.flat, count=rows_dev)
             if ctx.sink is None:
                 grads = _split_flat(flat, 18 if ctx.sigma_only else len(PARAM_KEYS))
             if want_pts:                                            # pose refinement: through the two encoding inputs
                 d_enc = ops.mlp_denc(ctx.mode_id, dact, params[PARAM_KEYS.index("xyz_encoding_1.0.weight")],
-                                     params[PARAM_KEYS.index("xyz_encoding_5.0.weight")])
+                                     params[PARAM_KEYS.index("xyz_encoding_5.0.weight")], count=rows_dev)
         d_pts = None
         if want_pts:                                                # through x -> (x, sin 2^k x, cos 2^k x)
-            d_pts = ops.encode_backward(pts, d_enc.contiguous())
+            d_pts = ops.encode_backward(pts, d_enc.contiguous(), count=rows_dev)
             if pos is not None:
                 d_pts = ops.expand_rows(d_pts, pos, 0.0)
             elif d_pts.shape[0] != ctx.n_full:
@@ -267,11 +271,15 @@ class MLPFunction(torch.autograd.Function):
         return (d_pts, None, None, None, None, *out_grads)
 
 
-def _library_backward(ctx, params, pts, act, g4, want_pts):
+def _library_backward(ctx, params, pts, act, g4, want_pts, rows=None):
     """The backward of the MLP as the chain of library GEMMs the hand-written kernels replaced (dX = dY W, dW = dY^T X,
-    mask kernels in between).  Cross-check only (MLPFunction.LIBRARY_GEMMS): the tests hold the kernels to it."""
+    mask kernels in between).  Cross-check only (MLPFunction.LIBRARY_GEMMS): the tests hold the kernels to it.
+    rows: the compacted list's padded length (the buffers are sized for all samples; rows past it hold nothing)."""
     dt = act.dtype
-    n = pts.shape[0]
+    n_all = pts.shape[0]
+    n = n_all if rows is None else rows
+    cols = lambda c0, c1: ops.act_columns(act, c0, c1)[:n]
+    pts, g4 = pts[:n], g4[:n]
 
     class _Lazy(dict):                                              # parameters in the compute dtype, cast on first use
         def __missing__(self, k):
@@ -279,7 +287,7 @@ def _library_backward(ctx, params, pts, act, g4, want_pts):
             self[k] = p if p.dtype == dt else p.to(dt)
             return self[k]
     P = _Lazy()
-    H = ops.act_columns(act, 0, 2048).view(n, 8, 256)
+    H = cols(0, 2048).view(n, 8, 256)
     grads = {}
 
     def wgrad(dy, x):                                               # accumulated and returned in fp32
@@ -294,7 +302,7 @@ def _library_backward(ctx, params, pts, act, g4, want_pts):
         dh = g_sig[:, None] * P["sigma.weight"]
     else:
         d_rgb = g4[:, :3].to(dt)
-        G, F = ops.act_columns(act, 2304, 2432), ops.act_columns(act, 2048, 2304)
+        G, F = cols(2304, 2432), cols(2048, 2304)
         grads["rgb.0.weight"] = wgrad(d_rgb, G)
         grads["rgb.0.bias"] = g4[:, :3].sum(0)
         dG = relu_bwd(d_rgb @ P["rgb.0.weight"], G)

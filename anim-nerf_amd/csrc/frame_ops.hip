@@ -335,8 +335,9 @@ namespace anr {
 // COLS = 63 (the reference's matrix) or 64 (one zero column of padding: the layout anr_mlp_wgrad stages)
 template <typename T, int COLS = 63>
 __global__ __launch_bounds__(256) void encode_kernel(const float* __restrict__ pts, int stride, int64_t n, T* __restrict__ enc,
-                                                     int tangent = 0) {
+                                                     int tangent = 0, const int32_t* __restrict__ count = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (count && *count < n) n = *count;                    // row limit on the device (training: the compacted list's padded length)
     if (i >= n) return;
     const float x[3] = {pts[i * stride], pts[i * stride + 1], pts[i * stride + 2]};
     T* row = enc + i * COLS;
@@ -368,8 +369,9 @@ __global__ __launch_bounds__(256) void encode_kernel(const float* __restrict__ p
 }
 
 __global__ __launch_bounds__(256) void encode_backward_kernel(const float* __restrict__ pts, int stride, const float* __restrict__ d_enc,
-                                                              int64_t n, float4* __restrict__ d_pts) {
+                                                              int64_t n, float4* __restrict__ d_pts, const int32_t* __restrict__ count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (count && *count < n) n = *count;
     if (i >= n) return;
     const float* g = d_enc + i * 63;
     float dx[3];
@@ -399,24 +401,39 @@ extern "C" int anr_encode(const float* pts, int pts_stride, int64_t n, int bf16_
     return anr::check_launch("anr_encode");
 }
 
-extern "C" int anr_encode64(const float* pts, int pts_stride, int64_t n, int flags, void* enc_out, void* stream) {
+static int encode64(const float* pts, int pts_stride, int64_t n, const int32_t* count, int flags, void* enc_out, void* stream) {
     ANR_REQUIRE(pts && enc_out, ANR_E_BADARG, "anr_encode64: null pointer");
     ANR_REQUIRE(n > 0 && pts_stride >= 3, ANR_E_BADARG, "anr_encode64: n=%lld stride=%d", (long long)n, pts_stride);
     dim3 grid((unsigned)((n + 255) / 256));
     const int tan = (flags & ANR_MLP_FLAG_TANGENT) ? 1 : 0;
     if (flags & 1)
-        hipLaunchKernelGGL((anr::encode_kernel<__bf16, 64>), grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (__bf16*)enc_out, tan);
+        hipLaunchKernelGGL((anr::encode_kernel<__bf16, 64>), grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (__bf16*)enc_out, tan, count);
     else
-        hipLaunchKernelGGL((anr::encode_kernel<float, 64>), grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (float*)enc_out, tan);
+        hipLaunchKernelGGL((anr::encode_kernel<float, 64>), grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (float*)enc_out, tan, count);
     return anr::check_launch("anr_encode64");
 }
+extern "C" int anr_encode64(const float* pts, int pts_stride, int64_t n, int flags, void* enc_out, void* stream) {
+    return encode64(pts, pts_stride, n, nullptr, flags, enc_out, stream);
+}
+extern "C" int anr_encode64_counted(const float* pts, int pts_stride, int64_t n, const int32_t* count, int flags, void* enc_out, void* stream) {
+    ANR_REQUIRE(count, ANR_E_BADARG, "anr_encode64_counted: null count");
+    return encode64(pts, pts_stride, n, count, flags, enc_out, stream);
+}
 
-extern "C" int anr_encode_backward(const float* pts, int pts_stride, const float* d_enc, int64_t n, float* d_pts_out,
-                                   void* stream) {
+static int encode_backward(const float* pts, int pts_stride, const float* d_enc, int64_t n, const int32_t* count, float* d_pts_out,
+                           void* stream) {
     ANR_REQUIRE(pts && d_enc && d_pts_out, ANR_E_BADARG, "anr_encode_backward: null pointer");
     ANR_REQUIRE(n > 0 && pts_stride >= 3, ANR_E_BADARG, "anr_encode_backward: n=%lld stride=%d", (long long)n, pts_stride);
     ANR_REQUIRE(((uintptr_t)d_pts_out & 15) == 0, ANR_E_ALIGN, "anr_encode_backward: d_pts_out must be 16-B aligned");
     hipLaunchKernelGGL(anr::encode_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pts,
-                       pts_stride, d_enc, n, reinterpret_cast<float4*>(d_pts_out));
+                       pts_stride, d_enc, n, reinterpret_cast<float4*>(d_pts_out), count);
     return anr::check_launch("anr_encode_backward");
+}
+extern "C" int anr_encode_backward(const float* pts, int pts_stride, const float* d_enc, int64_t n, float* d_pts_out, void* stream) {
+    return encode_backward(pts, pts_stride, d_enc, n, nullptr, d_pts_out, stream);
+}
+extern "C" int anr_encode_backward_counted(const float* pts, int pts_stride, const float* d_enc, int64_t n, const int32_t* count,
+                                           float* d_pts_out, void* stream) {
+    ANR_REQUIRE(count, ANR_E_BADARG, "anr_encode_backward_counted: null count");
+    return encode_backward(pts, pts_stride, d_enc, n, count, d_pts_out, stream);
 }

@@ -316,7 +316,12 @@ struct MlpBwd {
 
     __device__ __forceinline__ void run(const char* __restrict__ pack, const float4* __restrict__ g, const ActT* __restrict__ act,
                                         ActT* __restrict__ dact, int64_t n_pts, char* lds, int tangent = 0,
-                                        const float* __restrict__ dfeat = nullptr) {
+                                        const float* __restrict__ dfeat = nullptr, const int32_t* __restrict__ count = nullptr) {
+        R = n_pts;                                         // the buffers' row count (block stride); the rows worked on may be fewer:
+        if (count) {                                       // the padded length of a compacted list, known on the device only
+            const int64_t cnt = *count;
+            n_pts = cnt < n_pts ? cnt : n_pts;
+        }
         const int64_t n_tiles = (n_pts + WAVES * NT * 32 - 1) / (WAVES * NT * 32);
         if ((int64_t)blockIdx.x >= n_tiles) return;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -346,7 +351,6 @@ struct MlpBwd {
         auto gate_row = [&](int64_t cl) { return (unsigned)(tangent ? (cl & ~(int64_t)3) : cl) * 32u + 16u * half; };
         act_base = reinterpret_cast<const char*>(act);
         dact_base = reinterpret_cast<char*>(dact);
-        R = n_pts;
         float4 g_next[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -475,17 +479,17 @@ struct MlpBwd {
 template <int MODE, int START>
 __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void mlp_bwd_kernel(
     const char* __restrict__ pack, const float4* __restrict__ g, const void* __restrict__ act, void* __restrict__ dact,
-    int64_t n_pts, int tangent, const float* __restrict__ dfeat) {
+    int64_t n_pts, int tangent, const float* __restrict__ dfeat, const int32_t* __restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using M = MlpBwd<MODE, START>;
     M m;
     m.run(pack, g, reinterpret_cast<const typename M::ActT*>(act), reinterpret_cast<typename M::ActT*>(dact), n_pts, lds, tangent,
-          dfeat);
+          dfeat, count);
 }
 
 template <int MODE, int START>
 int launch_mlp_bwd(const void* pack, const float* g, const void* act, void* dact, int64_t n, hipStream_t st, int tangent = 0,
-                   const float* dfeat = nullptr) {
+                   const float* dfeat = nullptr, const int32_t* count = nullptr) {
     using C = Cfg<MODE>;
     const int lds = BWD_TABLE_BYTES + 3 * MlpBwd<MODE, START>::SLOT + C::WAVES * 2 * C::NT * 1024;    // + the gathered sign bits
     auto kern = mlp_bwd_kernel<MODE, START>;
@@ -497,7 +501,7 @@ int launch_mlp_bwd(const void* pack, const float* g, const void* act, void* dact
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     dim3 grid((unsigned)(n_tiles < cus ? n_tiles : cus));
     hipLaunchKernelGGL(kern, grid, dim3(C::WAVES * 64), lds, st, reinterpret_cast<const char*>(pack),
-                       reinterpret_cast<const float4*>(g), act, dact, n, tangent, dfeat);
+                       reinterpret_cast<const float4*>(g), act, dact, n, tangent, dfeat, count);
     return check_launch("anr_mlp_backward");
 }
 
@@ -587,6 +591,11 @@ extern "C" int anr_mlp_bwd_pack(const anr_mlp_params* p, int mode, void* pack_ou
 
 extern "C" int anr_mlp_backward(const void* bwd_pack, int mode, const float* g, const void* act, void* dact, int64_t n,
                                 void* stream) {
+    return anr_mlp_backward_counted(bwd_pack, mode, g, act, dact, n, nullptr, stream);
+}
+
+extern "C" int anr_mlp_backward_counted(const void* bwd_pack, int mode, const float* g, const void* act, void* dact, int64_t n,
+                                        const int32_t* count, void* stream) {
     ANR_REQUIRE(bwd_pack && g && act && dact, ANR_E_BADARG, "anr_mlp_backward: null pointer");
     ANR_REQUIRE(n > 0, ANR_E_BADARG, "anr_mlp_backward: n=%lld", (long long)n);
     ANR_REQUIRE((((uintptr_t)bwd_pack | (uintptr_t)g | (uintptr_t)act | (uintptr_t)dact) & 15) == 0, ANR_E_ALIGN,
@@ -597,11 +606,11 @@ extern "C" int anr_mlp_backward(const void* bwd_pack, int mode, const float* g, 
     ANR_REQUIRE(!tan || (so && n % 4 == 0), ANR_E_BADARG, "anr_mlp_backward: tangent mode = sigma only, points in quads");
     switch (mode & 0xff) {
         case ANR_MLP_F32:
-            return so ? launch_mlp_bwd<ANR_MLP_F32, 20>(bwd_pack, g, act, dact, n, st, tan)
-                      : launch_mlp_bwd<ANR_MLP_F32, 0>(bwd_pack, g, act, dact, n, st);
+            return so ? launch_mlp_bwd<ANR_MLP_F32, 20>(bwd_pack, g, act, dact, n, st, tan, nullptr, count)
+                      : launch_mlp_bwd<ANR_MLP_F32, 0>(bwd_pack, g, act, dact, n, st, 0, nullptr, count);
         case ANR_MLP_BF16:
-            return so ? launch_mlp_bwd<ANR_MLP_BF16_W8, 20>(bwd_pack, g, act, dact, n, st, tan)
-                      : launch_mlp_bwd<ANR_MLP_BF16_W8, 0>(bwd_pack, g, act, dact, n, st);
+            return so ? launch_mlp_bwd<ANR_MLP_BF16_W8, 20>(bwd_pack, g, act, dact, n, st, tan, nullptr, count)
+                      : launch_mlp_bwd<ANR_MLP_BF16_W8, 0>(bwd_pack, g, act, dact, n, st, 0, nullptr, count);
         default: return fail(ANR_E_BADARG, "anr_mlp_backward: unknown mode %d", mode);
     }
 }

@@ -138,7 +138,16 @@ __device__ __forceinline__ float sin_or_cos(float a, int q_off) {
 // DMA's own completion is waited for by hand (`vmcnt(0)` in front of the workgroup barrier, dma_wait()).
 __device__ __forceinline__ void dma16(const char* gsrc_lane, unsigned dst /* LDS byte address, wave-uniform */) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+#if !defined(ANR_DMA_MODE) || ANR_DMA_MODE == 0      /* cache-policy experiment (profiles/r03/mlp_weight_stream.md) */
+#define ANR_DMA_MOD ""
+#elif ANR_DMA_MODE == 1
+#define ANR_DMA_MOD " sc1"
+#elif ANR_DMA_MODE == 2
+#define ANR_DMA_MOD " nt"
+#else
+#define ANR_DMA_MOD " sc0 sc1"
+#endif
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ANR_DMA_MOD "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc_lane), "s"(__builtin_amdgcn_readfirstlane(dst))
                  : "memory");

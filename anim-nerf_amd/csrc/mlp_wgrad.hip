@@ -39,6 +39,7 @@ struct WgradArgs {
     int splits;                   // S
     int rows_per_split;           // multiple of the stage rows
     int tangent;                  // ANR_MLP_FLAG_TANGENT: bias sums over the primal rows (row % 4 == 0) only
+    const int32_t* count;         // device row count (a multiple of 64; NULL: all n rows): the slices are cut on the device
 };
 
 template <bool BF16> struct WgCfg;
@@ -76,9 +77,15 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int gi = blockIdx.x / args.splits, sp = blockIdx.x % args.splits;
     const WgradGemm gm = args.g[gi];
-    const int64_t r0 = (int64_t)sp * args.rows_per_split;
-    int64_t r1 = r0 + args.rows_per_split;
-    if (r1 > n) r1 = n;
+    int64_t n_rows = n, per = args.rows_per_split;          // n stays the buffers' row count (the block stride)
+    if (args.count) {
+        const int64_t cnt = *args.count;
+        n_rows = cnt < n ? cnt : n;
+        per = ((n_rows + args.splits - 1) / args.splits + SR - 1) / SR * SR;
+    }
+    const int64_t r0 = (int64_t)sp * per;
+    int64_t r1 = r0 + per;
+    if (r1 > n_rows) r1 = n_rows;
     const int n_stages = r1 > r0 ? (int)((r1 - r0) / SR) : 0;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     // this lane's 16 bytes of a piece: row (inside the piece) and byte inside the block row
@@ -243,15 +250,22 @@ __device__ __forceinline__ void load4(const T* p, float (&v)[4]) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, const float* __restrict__ g4, int64_t n,
-                                                    int rows_per_slice, int sigma_only, int tangent, float* __restrict__ partial) {
+                                                    int rows_per_slice, int sigma_only, int tangent, float* __restrict__ partial,
+                                                    const int32_t* __restrict__ count) {
     __shared__ float sh[4][CS_COLS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t n_rows = n;                                      // (n stays the buffer's row count: the block stride)
+    if (count) {
+        const int64_t cnt = *count;
+        n_rows = cnt < n ? cnt : n;
+        rows_per_slice = (int)((n_rows + gridDim.x - 1) / gridDim.x);
+    }
     // four consecutive columns per lane: block (first column / 32 + lane / 8), features 4 (lane % 8) of row r
     const T* h8 = act + ((int64_t)(1792 / 32 + (lane >> 3)) * n) * 32 + 4 * (lane & 7);
     const T* gh = act + ((int64_t)(2304 / 32 + ((lane & 31) >> 3)) * n) * 32 + 4 * (lane & 7);
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_slice;
     int64_t r1 = r0 + rows_per_slice;
-    if (r1 > n) r1 = n;
+    if (r1 > n_rows) r1 = n_rows;
     constexpr int RIF = 4;
     // sigma.weight (+ all four bias sums, lane 0): wave w takes rows r0 + w, r0 + w + 4, ...
     float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -401,7 +415,7 @@ extern "C" int64_t anr_mlp_wgrad_ws_floats(int64_t n) {
 
 template <bool BF16>
 static int wgrad_launch(const void* act, const void* dact, const void* enc, const float* g4, int64_t n, int sigma_only,
-                        int tangent, int accumulate, float* ws, float* grads, hipStream_t st) {
+                        int tangent, int accumulate, float* ws, float* grads, hipStream_t st, const int32_t* count) {
     using C = WgCfg<BF16>;
     const Layout& L = layout();
     WgradSegs segs{};
@@ -421,6 +435,7 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
     {
         WgradArgs a{};
         a.tangent = tangent;
+        a.count = count;
         const int n_g = sigma_only ? 7 : 8;
         a.splits = splits_for(n, C::SR, n_g);
         a.rows_per_split = (int)(((n + a.splits - 1) / a.splits + C::SR - 1) / C::SR * C::SR);
@@ -449,6 +464,7 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
     {
         WgradArgs a{};
         a.tangent = tangent;
+        a.count = count;
         a.splits = splits_for(n, C::SR, 2);
         if (a.splits > 64) a.splits = 64;
         a.rows_per_split = (int)(((n + a.splits - 1) / a.splits + C::SR - 1) / C::SR * C::SR);
@@ -470,6 +486,7 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
     if (!sigma_only) {
         WgradArgs a{};
         a.tangent = tangent;
+        a.count = count;
         a.splits = splits_for(n, C::SR, 1);
         a.rows_per_split = (int)(((n + a.splits - 1) / a.splits + C::SR - 1) / C::SR * C::SR);
         constexpr int BLK = 128 * 256 + 128;
@@ -492,7 +509,7 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
         slices = (int)((n + rps - 1) / rps);
         using T = typename C::T;
         hipLaunchKernelGGL(heads_kernel<T>, dim3(slices), dim3(256), 0, st,
-                           reinterpret_cast<const T*>(act), g4, n, rps, sigma_only, tangent, ws + ws_off);
+                           reinterpret_cast<const T*>(act), g4, n, rps, sigma_only, tangent, ws + ws_off, count);
         seg(L.sw, 1, 256, 256, ws_off, CS_COLS, CS_COLS, slices);
         seg(L.sb, 1, 1, 1, ws_off + 643, CS_COLS, CS_COLS, slices);
         if (!sigma_only) {
@@ -507,6 +524,11 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
 
 extern "C" int anr_mlp_wgrad(int mode, const void* act, const void* dact, const void* enc, const float* g4, int64_t n,
                              float* workspace, float* grads_out, void* stream) {
+    return anr_mlp_wgrad_counted(mode, act, dact, enc, g4, n, nullptr, workspace, grads_out, stream);
+}
+
+extern "C" int anr_mlp_wgrad_counted(int mode, const void* act, const void* dact, const void* enc, const float* g4, int64_t n,
+                                     const int32_t* count, float* workspace, float* grads_out, void* stream) {
     ANR_REQUIRE(act && dact && enc && g4 && workspace && grads_out, ANR_E_BADARG, "anr_mlp_wgrad: null pointer");
     ANR_REQUIRE(n > 0 && n % 64 == 0, ANR_E_BADARG, "anr_mlp_wgrad: n=%lld must be a positive multiple of 64", (long long)n);
     ANR_REQUIRE((((uintptr_t)act | (uintptr_t)dact | (uintptr_t)enc | (uintptr_t)workspace) & 15) == 0, ANR_E_ALIGN,
@@ -522,8 +544,8 @@ extern "C" int anr_mlp_wgrad(int mode, const void* act, const void* dact, const 
         if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipMemsetAsync: %s", hipGetErrorString(e));
     }
     switch (mode & 0xff) {
-        case ANR_MLP_BF16: return wgrad_launch<true>(act, dact, enc, g4, n, so, tan, accumulate, workspace, grads_out, st);
-        case ANR_MLP_F32:  return wgrad_launch<false>(act, dact, enc, g4, n, so, tan, accumulate, workspace, grads_out, st);
+        case ANR_MLP_BF16: return wgrad_launch<true>(act, dact, enc, g4, n, so, tan, accumulate, workspace, grads_out, st, count);
+        case ANR_MLP_F32:  return wgrad_launch<false>(act, dact, enc, g4, n, so, tan, accumulate, workspace, grads_out, st, count);
         default: return fail(ANR_E_BADARG, "anr_mlp_wgrad: unknown mode %d", mode);
     }
 }
@@ -538,7 +560,8 @@ namespace anr {
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void denc_kernel(const char* __restrict__ dact, const float* __restrict__ W1,
-                                                   const float* __restrict__ W5, int64_t n, float* __restrict__ d_enc) {
+                                                   const float* __restrict__ W5, int64_t n, float* __restrict__ d_enc,
+                                                   const int32_t* __restrict__ count) {
     using T = typename WgCfg<BF16>::T;
     constexpr int KF = BF16 ? 16 : 128;                      // K fragments per layer (16 / 2 out-features each)
     constexpr int EPL = BF16 ? 8 : 1;                        // elements per lane and fragment
@@ -557,10 +580,12 @@ __global__ __launch_bounds__(256) void denc_kernel(const char* __restrict__ dact
         }
     }
     __syncthreads();
-    const int64_t n_tiles = (n + 31) / 32;
+    int64_t n_rows = n;                                      // (n stays the buffer's row count: the block stride)
+    if (count) { const int64_t cnt = *count; n_rows = cnt < n ? cnt : n; }
+    const int64_t n_tiles = (n_rows + 31) / 32;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t p = tile * 32 + (lane & 31);
-        const int64_t row = p < n ? p : n - 1;
+        const int64_t row = p < n_rows ? p : n_rows - 1;
         const char* arow = dact + row * (int64_t)(32 * sizeof(T));       // this point's row inside a block of dact
         const int h = lane >> 5;
         f32x16 acc[2];
@@ -594,7 +619,7 @@ __global__ __launch_bounds__(256) void denc_kernel(const char* __restrict__ dact
             for (int e = 0; e < 16; ++e) {
                 const int64_t pr = tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 const int ch = (lane & 31) + 32 * nt;
-                if (pr < n && ch < 63) d_enc[pr * 63 + ch] = acc[nt][e];
+                if (pr < n_rows && ch < 63) d_enc[pr * 63 + ch] = acc[nt][e];
             }
     }
 }
@@ -603,6 +628,11 @@ __global__ __launch_bounds__(256) void denc_kernel(const char* __restrict__ dact
 
 extern "C" int anr_mlp_denc(int mode, const void* dact, const float* w1, const float* w5, int64_t n, float* d_enc_out,
                             void* stream) {
+    return anr_mlp_denc_counted(mode, dact, w1, w5, n, nullptr, d_enc_out, stream);
+}
+
+extern "C" int anr_mlp_denc_counted(int mode, const void* dact, const float* w1, const float* w5, int64_t n, const int32_t* count,
+                                    float* d_enc_out, void* stream) {
     ANR_REQUIRE(dact && w1 && w5 && d_enc_out, ANR_E_BADARG, "anr_mlp_denc: null pointer");
     ANR_REQUIRE(n > 0 && ((uintptr_t)dact & 15) == 0, ANR_E_BADARG, "anr_mlp_denc: n=%lld / alignment", (long long)n);
     int dev = 0, cus = 256;
@@ -615,13 +645,13 @@ extern "C" int anr_mlp_denc(int mode, const void* dact, const float* w1, const f
         auto k = denc_kernel<true>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail((int)e, "anr_mlp_denc: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, reinterpret_cast<const char*>(dact), w1, w5, n, d_enc_out);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, reinterpret_cast<const char*>(dact), w1, w5, n, d_enc_out, count);
     } else if ((mode & 0xff) == ANR_MLP_F32) {
         const int lds = 2 * 128 * 2 * 64 * 4;
         auto k = denc_kernel<false>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail((int)e, "anr_mlp_denc: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, reinterpret_cast<const char*>(dact), w1, w5, n, d_enc_out);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, reinterpret_cast<const char*>(dact), w1, w5, n, d_enc_out, count);
     } else {
         return fail(ANR_E_BADARG, "anr_mlp_denc: unknown mode %d", mode);
     }

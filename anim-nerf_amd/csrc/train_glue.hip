@@ -55,7 +55,10 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(int32_t* __restrict_
         if (threadIdx.x == 1023) carry = off + s;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *count = carry;
+    if (threadIdx.x == 0) {
+        count[0] = carry;
+        count[1] = carry > 0 ? (carry + 63) / 64 * 64 : 64;      // ... and the row count the MLP kernels work on (padding rows: valid = 0)
+    }
 }
 
 __global__ __launch_bounds__(CB) void compact_gather_kernel(const float4* __restrict__ pts, int64_t n, const int32_t* __restrict__ block_base,
@@ -96,8 +99,13 @@ __global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restric
 
 __global__ __launch_bounds__(256) void head_grad_kernel(const float* __restrict__ g, const int32_t* __restrict__ index,
                                                         const float4* __restrict__ out, const float4* __restrict__ pts, int64_t rows,
-                                                        int64_t n_pad, int sigma_only, float4* __restrict__ g4) {
+                                                        int64_t n_pad, int sigma_only, float4* __restrict__ g4,
+                                                        const int32_t* __restrict__ count) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (count) {                                             // rows on the device: count[0] listed rows, count[1] padded
+        rows = count[0];
+        n_pad = count[1] < n_pad ? count[1] : n_pad;
+    }
     if (r >= n_pad) return;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < rows) {
@@ -329,16 +337,25 @@ extern "C" int anr_expand_rows(const float* src, const int32_t* pos, int64_t n, 
     return check_launch("anr_expand_rows");
 }
 
-extern "C" int anr_mlp_head_grad(const float* g, const int32_t* index, const float* out, const float* pts, int64_t rows, int64_t n_pad,
-                                 int sigma_only, float* g4_out, void* stream) {
+static int head_grad(const float* g, const int32_t* index, const float* out, const float* pts, int64_t rows, int64_t n_pad,
+                     int sigma_only, float* g4_out, const int32_t* count, void* stream) {
     ANR_REQUIRE(g && pts && g4_out && (sigma_only || out), ANR_E_BADARG, "anr_mlp_head_grad: null pointer");
     ANR_REQUIRE(rows >= 0 && n_pad >= rows && n_pad > 0, ANR_E_BADARG, "anr_mlp_head_grad: rows=%lld n_pad=%lld", (long long)rows, (long long)n_pad);
     ANR_REQUIRE((((uintptr_t)g4_out | (uintptr_t)pts | (uintptr_t)out | (sigma_only ? 0 : (uintptr_t)g)) & 15) == 0, ANR_E_ALIGN,
                 "anr_mlp_head_grad: 16-B alignment");
     hipLaunchKernelGGL(head_grad_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, index,
                        reinterpret_cast<const float4*>(out), reinterpret_cast<const float4*>(pts), rows, n_pad, sigma_only,
-                       reinterpret_cast<float4*>(g4_out));
+                       reinterpret_cast<float4*>(g4_out), count);
     return check_launch("anr_mlp_head_grad");
+}
+extern "C" int anr_mlp_head_grad(const float* g, const int32_t* index, const float* out, const float* pts, int64_t rows, int64_t n_pad,
+                                 int sigma_only, float* g4_out, void* stream) {
+    return head_grad(g, index, out, pts, rows, n_pad, sigma_only, g4_out, nullptr, stream);
+}
+extern "C" int anr_mlp_head_grad_counted(const float* g, const int32_t* index, const float* out, const float* pts, const int32_t* count,
+                                         int64_t n_alloc, int sigma_only, float* g4_out, void* stream) {
+    ANR_REQUIRE(count, ANR_E_BADARG, "anr_mlp_head_grad_counted: null count");
+    return head_grad(g, index, out, pts, 0, n_alloc, sigma_only, g4_out, count, stream);
 }
 
 extern "C" int anr_tangent_quads(const float* xyz, int64_t n, int64_t n_pad, float* pts4_out, void* stream) {

@@ -665,6 +665,45 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cell_list_kernel(const int3
     if (v.w > 0) out[pos++] = first + 3;
 }
 
+// lanes per work item of the two search kernels: 64 when there is plenty of work, down to 8 when there is not
+__device__ __forceinline__ int lanes_per_item(int n, int wave_slots) {
+    int lpi = 64;
+    while (lpi > 8 && (n + lpi - 1) / lpi < 2 * wave_slots) lpi >>= 1;
+    return lpi;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// k-th smallest (k = 1..4 -> out[k-1]) of the union of the lanes' ascending lists a[4]: four rounds of "take the wave's
+// minimum, the lowest lane that holds it moves on to its next entry"
+__device__ __forceinline__ void wave_smallest4(const float (&a)[4], float (&out)[4], int& first_lane) {
+    int p = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float cur = p == 0 ? a[0] : p == 1 ? a[1] : p == 2 ? a[2] : p == 3 ? a[3] : 3.0e38f;
+        const float m = wave_min(cur);
+        const int who = __builtin_ctzll(__ballot(cur == m));
+        if (k == 0) first_lane = who;
+        if ((int)(threadIdx.x & 63) == who) ++p;
+        out[k] = m;
+    }
+}
+
+// ONE WAVEFRONT PER OCCUPIED CELL, the lanes splitting the index: a lane owns the clusters lane, lane + 64, ...  (A lane per
+// cell — the first version — made a wavefront walk the union of what 64 cells scattered over the body need, ~10^5 dependent
+// instructions per item at one instruction per ~12 cycles, and a training batch has only ~10^3 such items for 4,096 wave
+// slots: 0.58 ms per call at 9 % VALU issue.)
+//   1. every lane: box distance of each of its clusters, the nearest one remembered; the wave's minimum is a LOWER bound on
+//      the distance to the nearest vertex: at dis_threshold + r or more the cell is dead, done (most occupied cells lie
+//      inside the body's bounding box but far from its surface);
+//   2. every lane scans its nearest cluster; the 4th smallest distance over the wave bounds d4 from above;
+//   3. every lane scans those of its other clusters whose box is inside that bound (and its own 4th best);
+//   4. d1, d4 and the nearest vertex = the wave's 1st / 4th smallest over the lanes' best lists.
+// What the search pass needs from here is a radius that contains the four neighbours of every point of the cell and a
+// cluster to start from; neither depends on the order of the scan.
 __global__ __launch_bounds__(WARP_THREADS) void warp_cells_kernel(const float* __restrict__ index, IndexDims d, float thr,
                                                                   const int32_t* __restrict__ occ_list,
                                                                   const int32_t* __restrict__ occ_count,
@@ -674,35 +713,58 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cells_kernel(const float* _
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.y;
     const int n_occ = occ_count[b];
-    const int n_items = (n_occ + 63) >> 6;
-    if ((int)blockIdx.x * (WARP_THREADS / 64) >= n_items) return;
+    if ((int)blockIdx.x * (WARP_THREADS / 64) >= n_occ) return;          // not even one cell per wavefront left
     const int32_t* occ = occ_list + (int64_t)b * NCELL;
     float* cap = cell_cap2 + (int64_t)b * NCELL;
     stage_index(index + (int64_t)b * d.total_floats(), d.lds_floats(), lds);
     const float* gbox = lds + d.body_off();
+    const float* boxes = lds + d.box_off();
     const float cs = cell_size(gbox, thr, G);
     const float r = cs * 0.8662f;                        // sqrt(3)/2, rounded up
+    const float lim2 = (thr + r) * (thr + r);
     const int lane = threadIdx.x & 63;
+    constexpr int BATCH = 4;                             // cells per trip to the cursor
     for (;;) {
-        int item = 0;
-        if (lane == 0) item = atomicAdd(occ_cursor + b, 1);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) break;
-        const int i = item * 64 + lane;
-        const bool go = i < n_occ;
-        const int cell = occ[go ? i : n_occ - 1];
-        const int ix = cell / (G * G), iy = (cell / G) % G, iz = cell % G;
-        const float cx = gbox[0] - thr + ((float)ix + 0.5f) * cs;
-        const float cy = gbox[1] - thr + ((float)iy + 0.5f) * cs;
-        const float cz = gbox[2] - thr + ((float)iz + 0.5f) * cs;
-        Best4 best;
-        best_init(best);
-        search(lds, d, cx, cy, cz, go, best);
-        if (go) {
-            const float d1 = sqrtf(best.d[0]), d4 = sqrtf(best.d[3]);
-            const float reach = d4 + r;
-            cap[cell] = (d1 - r >= thr) ? -1.0f : reach * reach * 1.001f;
-            cell_seed[(int64_t)b * NCELL + cell] = best.i[0] / CS;      // cluster of the centre's nearest vertex
+        int first = 0;
+        if (lane == 0) first = atomicAdd(occ_cursor + b, BATCH);
+        first = __builtin_amdgcn_readfirstlane(first);
+        if (first >= n_occ) break;
+        for (int i = first; i < min(first + BATCH, n_occ); ++i) {
+            const int cell = occ[i];
+            const int ix = cell / (G * G), iy = (cell / G) % G, iz = cell % G;
+            const float cx = gbox[0] - thr + ((float)ix + 0.5f) * cs;
+            const float cy = gbox[1] - thr + ((float)iy + 0.5f) * cs;
+            const float cz = gbox[2] - thr + ((float)iz + 0.5f) * cs;
+            int c_near = -1;
+            float b_near = 3.0e38f;
+            for (int c = lane; c < d.NC; c += 64) {
+                const float v = box_d2(boxes + c * 8, cx, cy, cz);
+                if (v < b_near) { b_near = v; c_near = c; }
+            }
+            if (wave_min(b_near) >= lim2) {
+                if (lane == 0) cap[cell] = -1.0f;
+                continue;
+            }
+            Best4 best;
+            best_init(best);
+            if (c_near >= 0) scan_cluster(lds, d.Vp, c_near, cx, cy, cz, best);
+            float sm[4];
+            int who;
+            wave_smallest4(best.d, sm, who);
+            const float bound = sm[3];                   // >= d4^2: the 4th smallest of a subset of the vertices
+            for (int c = lane; c < d.NC; c += 64) {
+                if (c == c_near) continue;
+                const float v = box_d2(boxes + c * 8, cx, cy, cz);
+                if (v <= bound && v <= best.d[3]) scan_cluster(lds, d.Vp, c, cx, cy, cz, best);
+            }
+            wave_smallest4(best.d, sm, who);
+            const int nearest = __shfl(best.i[0], who, 64);
+            if (lane == 0) {
+                const float d1 = sqrtf(sm[0]), d4 = sqrtf(sm[3]);
+                const float reach = d4 + r;
+                cap[cell] = (d1 - r >= thr) ? -1.0f : reach * reach * 1.001f;
+                cell_seed[(int64_t)b * NCELL + cell] = nearest / CS;      // cluster of the centre's nearest vertex
+            }
         }
     }
 }
@@ -807,8 +869,9 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.y;
     const int cnt = count[b];
-    const int n_items = (cnt + 63) >> 6;
-    if ((int)blockIdx.x * (WARP_THREADS / 64) >= n_items) return;        // nothing left for this workgroup
+    if ((int)blockIdx.x * (WARP_THREADS / 64) * 8 >= cnt) return;        // nothing left for this workgroup
+    const int lpi = lanes_per_item(cnt, (int)gridDim.x * (WARP_THREADS / 64));      // (see warp_cells_kernel)
+    const int n_items = (cnt + lpi - 1) / lpi;
     const float* my_index = index + (int64_t)b * d.total_floats();
     const int32_t* order = reinterpret_cast<const int32_t*>(my_index + d.order_off());
     const float* O2C = ober2cano + (int64_t)b * d.V * 16;
@@ -822,8 +885,8 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
         if (lane == 0) item = atomicAdd(cursor + b, 1);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_items) break;
-        const int i = item * 64 + lane;
-        const bool go = i < cnt;
+        const int i = item * lpi + lane;
+        const bool go = lane < lpi && i < cnt;
         const int64_t o = (int64_t)b * N + (go ? my_list[i] : 0);
         const float4 p = go ? pts_out[o] : make_float4(0.f, 0.f, 0.f, 0.f);
         // inside the cell's radius the exact four neighbours are guaranteed to be found (warp_cells_kernel)

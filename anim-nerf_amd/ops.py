@@ -400,15 +400,18 @@ def encode(pts: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
     return enc
 
 
-def encode64(pts: torch.Tensor, dtype=torch.float32, tangent: bool = False) -> torch.Tensor:
+def encode64(pts: torch.Tensor, dtype=torch.float32, tangent: bool = False, count: Optional[torch.Tensor] = None) -> torch.Tensor:
     """enc[n,64] = [Embedding(pts[:, :3]), 0]: the operand layout of mlp_wgrad.  tangent: rows in quads, rows 4p+1..3 =
-    d enc / d x, y, z of point p (forward-mode normals)."""
+    d enc / d x, y, z of point p (forward-mode normals).  count: device int32 — only that many rows are computed."""
     lib = _lib.load()
     pts = _dev(pts, "pts")
     n = pts.shape[0]
     enc = torch.empty(n, 64, dtype=dtype, device=pts.device)
     flags = (1 if dtype == torch.bfloat16 else 0) | (ANR_MLP_FLAG_TANGENT if tangent else 0)
-    _lib.check(lib.anr_encode64(_ptr(pts), pts.shape[1], n, flags, _ptr(enc), _stream(enc)), "anr_encode64")
+    if count is not None:
+        _lib.check(lib.anr_encode64_counted(_ptr(pts), pts.shape[1], n, _ptr(count), flags, _ptr(enc), _stream(enc)), "anr_encode64")
+    else:
+        _lib.check(lib.anr_encode64(_ptr(pts), pts.shape[1], n, flags, _ptr(enc), _stream(enc)), "anr_encode64")
     return enc
 
 
@@ -416,7 +419,7 @@ _WGRAD_WS = {}
 
 
 def mlp_wgrad(mode: int, act: torch.Tensor, dact: torch.Tensor, enc: torch.Tensor, g4: torch.Tensor, sigma_only: bool = False,
-              tangent: bool = False, accumulate_into: Optional[torch.Tensor] = None):
+              tangent: bool = False, accumulate_into: Optional[torch.Tensor] = None, count: Optional[torch.Tensor] = None):
     """All 22 parameter gradients of one network from the saved activations, the activation gradients, the encoding matrix
     (encode64) and g4 = (dL/d rgb_pre, dL/d sigma): a flat fp32 tensor in the order of autograd.PARAM_KEYS (PyTorch
     [out][in] layouts).  Hand-written split-K MFMA GEMMs (csrc/mlp_wgrad.hip); n % 64 == 0."""
@@ -436,13 +439,17 @@ def mlp_wgrad(mode: int, act: torch.Tensor, dact: torch.Tensor, enc: torch.Tenso
         m |= _lib.ANR_MLP_FLAG_ACCUMULATE
     else:
         grads = torch.empty(lib.anr_mlp_wgrad_floats(), dtype=torch.float32, device=act.device)
-    with _timed("mlp_wgrad", n):
-        _lib.check(lib.anr_mlp_wgrad(m, _ptr(act), _ptr(dact), _ptr(enc), _ptr(g4), n, _ptr(ws), _ptr(grads), _stream(grads)),
-                   "anr_mlp_wgrad")
+    with _timed("mlp_wgrad", n if count is None else count):
+        if count is not None:                              # rows on the device (a multiple of 64 <= n); n = the buffers' rows
+            _lib.check(lib.anr_mlp_wgrad_counted(m, _ptr(act), _ptr(dact), _ptr(enc), _ptr(g4), n, _ptr(count), _ptr(ws), _ptr(grads),
+                                                 _stream(grads)), "anr_mlp_wgrad")
+        else:
+            _lib.check(lib.anr_mlp_wgrad(m, _ptr(act), _ptr(dact), _ptr(enc), _ptr(g4), n, _ptr(ws), _ptr(grads), _stream(grads)),
+                       "anr_mlp_wgrad")
     return grads
 
 
-def mlp_denc(mode: int, dact: torch.Tensor, w1: torch.Tensor, w5: torch.Tensor) -> torch.Tensor:
+def mlp_denc(mode: int, dact: torch.Tensor, w1: torch.Tensor, w5: torch.Tensor, count: Optional[torch.Tensor] = None) -> torch.Tensor:
     """d_enc[n,63] = dact_1 . W1[:, :63] + dact_5 . W5[:, :63] (fp32): the gradient leaving the MLP through its encoding
     inputs (pose refinement).  w1 / w5 = xyz_encoding_1 / _5 weights as stored (fp32)."""
     lib = _lib.load()
@@ -450,19 +457,27 @@ def mlp_denc(mode: int, dact: torch.Tensor, w1: torch.Tensor, w5: torch.Tensor) 
     w1, w5 = _dev(w1.detach(), "w1"), _dev(w5.detach(), "w5")
     n = dact.shape[0]
     d_enc = torch.empty(n, 63, dtype=torch.float32, device=dact.device)
-    with _timed("mlp_denc", n):
-        _lib.check(lib.anr_mlp_denc(mode & 0xff, _ptr(dact), _ptr(w1), _ptr(w5), n, _ptr(d_enc), _stream(d_enc)), "anr_mlp_denc")
+    with _timed("mlp_denc", n if count is None else count):
+        if count is not None:
+            _lib.check(lib.anr_mlp_denc_counted(mode & 0xff, _ptr(dact), _ptr(w1), _ptr(w5), n, _ptr(count), _ptr(d_enc), _stream(d_enc)),
+                       "anr_mlp_denc")
+        else:
+            _lib.check(lib.anr_mlp_denc(mode & 0xff, _ptr(dact), _ptr(w1), _ptr(w5), n, _ptr(d_enc), _stream(d_enc)), "anr_mlp_denc")
     return d_enc
 
 
-def encode_backward(pts: torch.Tensor, d_enc: torch.Tensor) -> torch.Tensor:
+def encode_backward(pts: torch.Tensor, d_enc: torch.Tensor, count: Optional[torch.Tensor] = None) -> torch.Tensor:
     """d_pts[n,4] = (dL/dxyz, 0) from d_enc[n,63] (fp32)."""
     lib = _lib.load()
     pts, d_enc = _dev(pts, "pts"), _dev(d_enc, "d_enc")
     n = pts.shape[0]
     d_pts = torch.empty(n, 4, dtype=torch.float32, device=pts.device)
-    _lib.check(lib.anr_encode_backward(_ptr(pts), pts.shape[1], _ptr(d_enc), n, _ptr(d_pts), _stream(d_pts)),
-               "anr_encode_backward")
+    if count is not None:
+        _lib.check(lib.anr_encode_backward_counted(_ptr(pts), pts.shape[1], _ptr(d_enc), n, _ptr(count), _ptr(d_pts), _stream(d_pts)),
+                   "anr_encode_backward")
+    else:
+        _lib.check(lib.anr_encode_backward(_ptr(pts), pts.shape[1], _ptr(d_enc), n, _ptr(d_pts), _stream(d_pts)),
+                   "anr_encode_backward")
     return d_pts
 
 
@@ -480,7 +495,7 @@ def act_columns(act: torch.Tensor, c0: int = 0, c1: int = ACT_COLS) -> torch.Ten
 
 
 def mlp_backward(bwd_pack: torch.Tensor, mode: int, g: torch.Tensor, act: torch.Tensor, sigma_only: bool = False,
-                 tangent: bool = False):
+                 tangent: bool = False, count: Optional[torch.Tensor] = None):
     """g[n,4] = (dL/d rgb_pre, dL/d sigma), act from mlp_forward_save -> dact (same dtype, same blocked layout: see
     `act_columns`): the pre-activation gradient of every layer (trunk columns only if sigma_only)."""
     lib = _lib.load()
@@ -488,9 +503,13 @@ def mlp_backward(bwd_pack: torch.Tensor, mode: int, g: torch.Tensor, act: torch.
     n = g.shape[0]
     dact = torch.empty_like(act)
     m = (mode & 0xff) | (ANR_MLP_FLAG_SIGMA_ONLY if sigma_only else 0) | (ANR_MLP_FLAG_TANGENT if tangent else 0)
-    with _timed("mlp_backward", n):
-        _lib.check(lib.anr_mlp_backward(_ptr(bwd_pack), m, _ptr(g), _ptr(act), _ptr(dact), n, _stream(dact)),
-                   "anr_mlp_backward")
+    with _timed("mlp_backward", n if count is None else count):
+        if count is not None:
+            _lib.check(lib.anr_mlp_backward_counted(_ptr(bwd_pack), m, _ptr(g), _ptr(act), _ptr(dact), n, _ptr(count), _stream(dact)),
+                       "anr_mlp_backward")
+        else:
+            _lib.check(lib.anr_mlp_backward(_ptr(bwd_pack), m, _ptr(g), _ptr(act), _ptr(dact), n, _stream(dact)),
+                       "anr_mlp_backward")
     return dact
 
 
@@ -660,7 +679,8 @@ def composite_backward(rgbs, z, rays, white_bkgd: bool, g_rgb, g_depth, g_acc, n
     return (d, dz, dfar) if want_dz else d
 
 
-def mlp_forward_save(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bool = False, tangent: bool = False):
+def mlp_forward_save(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bool = False, tangent: bool = False,
+                     count: Optional[torch.Tensor] = None):
     """Training forward: (out, act) — act (n x anr_mlp_act_cols() elements, blocked by 32-column tile: `act_columns`) keeps
     every layer's post-activation output and the ReLU sign bits.
     tangent (with sigma_only): points in quads, rows 4p+1..3 carry d/dx, d/dy, d/dz (ANR_MLP_FLAG_TANGENT)."""
@@ -675,9 +695,13 @@ def mlp_forward_save(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_onl
         out = torch.empty(n, 4, dtype=torch.float32, device=pts.device)
     act = torch.empty(n, lib.anr_mlp_act_cols(), device=pts.device,
                       dtype=torch.bfloat16 if (mode & 0xff) == ANR_MLP_BF16 else torch.float32)
-    with _timed("mlp_forward_save", n):
-        _lib.check(lib.anr_mlp_forward_save(_ptr(pack), mode, _ptr(pts), n, _ptr(out), _ptr(act), _stream(out)),
-                   "anr_mlp_forward_save")
+    with _timed("mlp_forward_save", n if count is None else count):
+        if count is not None:                              # rows on the device; act is sized (and blocked) for all n
+            _lib.check(lib.anr_mlp_forward_save_indexed(_ptr(pack), mode, _ptr(pts), None, _ptr(count), n, _ptr(out), _ptr(act),
+                                                        _stream(out)), "anr_mlp_forward_save")
+        else:
+            _lib.check(lib.anr_mlp_forward_save(_ptr(pack), mode, _ptr(pts), n, _ptr(out), _ptr(act), _stream(out)),
+                       "anr_mlp_forward_save")
     return out, act
 
 
@@ -739,15 +763,15 @@ def composite_sample(rgbs, rays, u, white_bkgd: bool, *, z=None, steps=None, val
 # ---- the steps between the big kernels of a training step (csrc/train_glue.hip)
 def compact_ordered(pts: torch.Tensor):
     """-> (index[n] int32 — first `count` entries: the positions with valid >= 1, ascending —, pos[n] int32 (row in that
-    list or -1), pts_c[roundup64(n), 4] (the listed points, then zero rows to the next multiple of 64), count[1] int32 on
-    the device)."""
+    list or -1), pts_c[roundup64(n), 4] (the listed points, then zero rows to the next multiple of 64), count[2] int32 on
+    the device: the listed rows, and that rounded up to a multiple of 64 — the row count of the *_counted kernels)."""
     lib = _lib.load()
     pts = _dev(pts, "pts")
     n = pts.numel() // 4
     index = torch.empty(n, dtype=torch.int32, device=pts.device)
     pos = torch.empty(n, dtype=torch.int32, device=pts.device)
     pts_c = torch.empty(-(-n // 64) * 64, 4, dtype=torch.float32, device=pts.device)
-    count = torch.empty(1, dtype=torch.int32, device=pts.device)
+    count = torch.empty(2, dtype=torch.int32, device=pts.device)
     ws = torch.empty(lib.anr_compact_ws_ints(n), dtype=torch.int32, device=pts.device)
     with _timed("compact_ordered", n, n * 24):
         _lib.check(lib.anr_compact_ordered(_ptr(pts), n, _ptr(index), _ptr(pos), _ptr(pts_c), _ptr(count), _ptr(ws), _stream(pts)),
@@ -766,15 +790,20 @@ def expand_rows(src: torch.Tensor, pos: torch.Tensor, fill: float) -> torch.Tens
     return out
 
 
-def mlp_head_grad(g: torch.Tensor, index: Optional[torch.Tensor], out: Optional[torch.Tensor], pts: torch.Tensor, rows: int,
+def mlp_head_grad(g: torch.Tensor, index: Optional[torch.Tensor], out: Optional[torch.Tensor], pts: torch.Tensor, rows,
                   sigma_only: bool) -> torch.Tensor:
-    """The g[n_pad,4] operand of mlp_backward / mlp_wgrad from the upstream gradient of (rgb, sigma) (see the header)."""
+    """The g[n_pad,4] operand of mlp_backward / mlp_wgrad from the upstream gradient of (rgb, sigma) (see the header).
+    rows: int, or the device count[2] of compact_ordered (rows past count[1] are left unwritten)."""
     lib = _lib.load()
     g, pts = _dev(g, "g"), _dev(pts, "pts")
     n_pad = pts.shape[0]
     g4 = torch.empty(n_pad, 4, dtype=torch.float32, device=pts.device)
-    _lib.check(lib.anr_mlp_head_grad(_ptr(g), _ptr(index), _ptr(out), _ptr(pts), rows, n_pad, 1 if sigma_only else 0, _ptr(g4),
-                                     _stream(g4)), "anr_mlp_head_grad")
+    if isinstance(rows, torch.Tensor):
+        _lib.check(lib.anr_mlp_head_grad_counted(_ptr(g), _ptr(index), _ptr(out), _ptr(pts), _ptr(rows), n_pad, 1 if sigma_only else 0,
+                                                 _ptr(g4), _stream(g4)), "anr_mlp_head_grad")
+    else:
+        _lib.check(lib.anr_mlp_head_grad(_ptr(g), _ptr(index), _ptr(out), _ptr(pts), rows, n_pad, 1 if sigma_only else 0, _ptr(g4),
+                                         _stream(g4)), "anr_mlp_head_grad")
     return g4
 
 

@@ -346,11 +346,33 @@ int anr_mlp_wgrad(int mode, const void* act, const void* dact, const void* enc, 
  * PyTorch [256][63] / [256][319] layouts); anr_encode_backward turns it into dL/d xyz. */
 int anr_mlp_denc(int mode, const void* dact, const float* w1, const float* w5, int64_t n, float* d_enc_out, void* stream);
 
+/* ---- a16: the same steps on a compacted list whose LENGTH IS KNOWN ON THE DEVICE ONLY ------------------------------------
+ * The reference's masked assignment (models/anim_nerf.py:284-289) makes the number of valid samples data dependent; reading it
+ * back to size the saved activations costs a device -> host synchronisation per network pass (4 per training step: the queue
+ * drains each time).  Instead every buffer is allocated for the upper bound n (all samples; rows that are never written cost
+ * address space only) and the kernels take the length from `count`, a device int32: anr_compact_ordered writes
+ * count_out[0] = listed rows and count_out[1] = that rounded up to a multiple of 64 (at least 64; the padding rows are valid =
+ * 0 / gradient 0) — pass count_out + 1 to the *_counted entry points and to anr_mlp_forward_save_indexed (index = NULL),
+ * count_out itself to anr_mlp_head_grad_counted.  n stays the row count of the BUFFERS (the block stride of act / dact).
+ * Rows past the count are neither read nor written. */
+int anr_mlp_head_grad_counted(const float* g, const int32_t* index, const float* out, const float* pts, const int32_t* count,
+                              int64_t n, int sigma_only, float* g4_out, void* stream);
+int anr_mlp_backward_counted(const void* bwd_pack, int mode, const float* g, const void* act, void* dact, int64_t n,
+                             const int32_t* count, void* stream);
+int anr_encode64_counted(const float* pts, int pts_stride, int64_t n, const int32_t* count, int flags, void* enc_out, void* stream);
+int anr_mlp_wgrad_counted(int mode, const void* act, const void* dact, const void* enc, const float* g, int64_t n,
+                          const int32_t* count, float* workspace, float* grads_out, void* stream);
+int anr_mlp_denc_counted(int mode, const void* dact, const float* w1, const float* w5, int64_t n, const int32_t* count,
+                         float* d_enc_out, void* stream);
+int anr_encode_backward_counted(const float* pts, int pts_stride, const float* d_enc, int64_t n, const int32_t* count,
+                                float* d_pts_out, void* stream);
+
 /* ---- a16 / f1: the steps between the big kernels of a training step, one launch each (csrc/train_glue.hip) --------
  * anr_compact_ordered: `inside_inds` of models/anim_nerf.py:253 in sample order.  index_out[0..*count) = positions i with
  *   pts[4i+3] >= 1, ascending; pos_out[i] = row of sample i in that list or -1; pts_out[r] = pts[index[r]], followed by
  *   zero rows (valid = 0) up to the next multiple of 64 (at least 64 rows): the operand of anr_mlp_forward_save.
- *   pts_out needs ((n + 63) / 64) * 64 rows; workspace anr_compact_ws_ints(n) int32; *count_out is a DEVICE int32.
+ *   pts_out needs ((n + 63) / 64) * 64 rows; workspace anr_compact_ws_ints(n) int32; count_out is TWO DEVICE int32: the number
+ *   of listed rows, and that number rounded up to a multiple of 64 (at least 64) — the rows the *_counted kernels work on.
  * anr_expand_rows: out[i] = pos[i] >= 0 ? src[pos[i]] : (0, 0, 0, fill) (cols = 4) / fill (cols = 1), i < n — what the
  *   reference's masked assignment does (models/anim_nerf.py:284-289).
  * anr_mlp_head_grad: the g[n_pad*4] operand of anr_mlp_backward / anr_mlp_wgrad from autograd's upstream gradient

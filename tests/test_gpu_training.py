@@ -639,8 +639,8 @@ def test_ordered_compaction_and_row_expansion(dev):
         pts = pts.to(dev)
         index, pos, pts_c, count = ops.compact_ordered(pts)
         want = torch.nonzero(pts[:, 3] >= 1)[:, 0]
-        c = int(count.item())
-        assert c == want.numel()
+        c = int(count[0].item())
+        assert c == want.numel() and int(count[1].item()) == max(-(-c // 64) * 64, 64)     # listed rows; padded: the kernels' row count
         assert torch.equal(index[:c].long(), want)
         assert torch.equal(pts_c[:c], pts[want])
         pad = max(-(-c // 64) * 64, 64)
