@@ -4,7 +4,7 @@ Python host classes keep the reference's names and signatures (AnimNeRF, VolumeR
 Embedding, SMPL/create, gen_rays, batched_inference); all per-ray and per-point work runs in
 libanimnerf_hip.so (hand-written HIP for gfx950, C ABI in include/animnerf_hip.h).
 """
-from . import _lib, data, mlp, ops, synthetic                        # noqa: F401
+from . import _lib, data, mesh, mlp, ops, synthetic                  # noqa: F401
 from .anim_nerf import AnimNeRF, batch_transform                      # noqa: F401
 from .body_model import SMPL, create                                  # noqa: F401
 from .nerf import Embedding, NeRF                                     # noqa: F401

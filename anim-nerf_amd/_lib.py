@@ -111,6 +111,8 @@ SIGNATURES = {
     "anr_expand_rows": (_I, [_P, _P, _L, _I, _F, _P, _P]),
     "anr_mlp_head_grad": (_I, [_P, _P, _P, _P, _L, _L, _I, _P, _P]),
     "anr_tangent_quads": (_I, [_P, _L, _L, _P, _P]),
+    "anr_mc_classify": (_I, [_P, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
+    "anr_mc_emit": (_I, [_P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "anr_mlp_head_grad_counted": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P]),
     "anr_mlp_backward_counted": (_I, [_P, _I, _P, _P, _P, _L, _P, _P]),
     "anr_encode64_counted": (_I, [_P, _I, _L, _P, _I, _P, _P]),

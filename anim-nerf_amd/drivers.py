@@ -1,5 +1,5 @@
-"""Runnable drivers over the rendering path: the novel-view orbit (novel_view.py:144-210) and the sigma-grid export that
-feeds marching cubes (extract_mesh.py:142-173).  Everything heavy is `batched_inference(P=...)` / `sigma_grid`; this file
+"""Runnable drivers over the rendering path: the novel-view orbit (novel_view.py:144-210) and mesh extraction — sigma grid,
+marching cubes, rescale, .obj (extract_mesh.py:142-173).  Everything heavy is `batched_inference(P=...)` / `sigma_grid`; this file
 is the argument handling, the data-folder / checkpoint plumbing (`anim_nerf_amd.data`) and the image writer the
 reference delegates to torchvision / imageio (absent here: PNGs are written with zlib).
 
@@ -7,8 +7,9 @@ reference delegates to torchvision / imageio (absent here: PNGs are written with
     python -m anim_nerf_amd.drivers novel_view   --root_dir DATA --ckpt_path CKPT --frame_id 1 --n_views 120
     python -m anim_nerf_amd.drivers extract_grid --synthetic --N_grid 256 --out out/mesh
 
-Marching cubes itself (PyMCubes) and the GIF writer are out of scope: `extract_grid` stops at the
-thresholded sigma volume (`sigma.npy`, what `mcubes.marching_cubes(-sigmas, 0.)` takes) and the posed SMPL mesh.
+`extract_grid` writes the thresholded sigma volume (`sigma.npy`), the posed SMPL mesh (`smpl.obj`) and the level-set mesh
+(`mesh.obj`: `anim_nerf_amd.mesh`, marching cubes on the GPU — PyMCubes is absent from the image, so that step is held to
+properties, not to PyMCubes' output).  The GIF writer is out of scope.
 """
 from __future__ import annotations
 
@@ -142,7 +143,8 @@ def novel_view(args):
 
 
 def extract_grid(args):
-    """extract_mesh.py:142-173 up to the marching-cubes call: posed SMPL mesh (smpl.obj) and the thresholded sigma volume."""
+    """extract_mesh.py:142-173: posed SMPL mesh (smpl.obj), the thresholded sigma volume, and the level-set mesh (mesh.obj) —
+    sigma grid, marching cubes (anim_nerf_amd.mesh: PyMCubes is not in the image, parity-unpinned), rescale, export."""
     model, _, rays, pose, templ = _scene(args)
     with torch.no_grad():
         model.set_body_model(pose, templ)
@@ -167,6 +169,18 @@ def extract_grid(args):
             f.write(f"f {t[0] + 1} {t[1] + 1} {t[2] + 1}\n")
     occupied = int((vol > 0).sum())
     print(f"{N}^3 sigma grid in {dt * 1e3:.1f} ms ({N ** 3 / dt / 1e9:.2f} G points/s), {occupied} voxels above the threshold -> {args.out}")
+    # extract_mesh.py:162-173: (smooth,) marching cubes on -sigmas at level 0, index coordinates -> world, + centre, mesh.obj
+    from . import mesh
+    field = -(sig.view(N, N, N) - args.sigma_threshold)
+    if getattr(args, "smooth", False):
+        field = mesh.gaussian_smooth(field)
+    t0 = time.perf_counter()
+    v_idx, faces_m = mesh.marching_cubes(field.contiguous(), 0.0)
+    torch.cuda.synchronize()
+    dt_m = time.perf_counter() - t0
+    verts_m = mesh.mcubes_to_world(v_idx.cpu().numpy(), N, args.x_range, args.y_range, args.z_range) + center
+    mesh.export_obj(verts_m, faces_m.cpu().numpy(), os.path.join(args.out, "mesh.obj"))
+    print(f"marching cubes: {verts_m.shape[0]} vertices, {faces_m.shape[0]} triangles in {dt_m * 1e3:.1f} ms -> {os.path.join(args.out, 'mesh.obj')}")
     return args.out
 
 
@@ -201,6 +215,7 @@ def parser():
     eg.add_argument("--z_range", type=float, nargs=2, default=[-1.2, 1.2])
     eg.add_argument("--sigma_threshold", type=float, default=20.0)
     eg.add_argument("--chunk_points", type=int, default=1 << 24)
+    eg.add_argument("--smooth", action="store_true", help="Gaussian-filter the volume first (the reference: mcubes.smooth)")
     return ap
 
 

@@ -884,3 +884,37 @@ def train_loss_backward(tensors: dict, consts: dict, g_total: torch.Tensor, want
     g_total = _dev(g_total.reshape(1), "g_total")
     _lib.check(lib.anr_train_loss_backward(C.byref(a), _ptr(g_total), C.byref(d), _stream(g_total)), "anr_train_loss_backward")
     return out
+
+
+_MC_TABLES = {}
+
+
+def marching_cubes(volume: torch.Tensor, level: float = 0.0):
+    """(vertices[V,3] float32 in index coordinates, triangles[T,3] int64) of the surface volume == level (inside = value <
+    level; normals point out of the inside): marching cubes over volume[N0,N1,N2] in two launches (csrc/mesh.hip) with the
+    case table of anim_nerf_amd.mesh.case_table."""
+    from .mesh import case_table
+    lib = _lib.load()
+    volume = _dev(volume, "volume")
+    n0, n1, n2 = volume.shape
+    key = volume.device.index
+    if key not in _MC_TABLES:
+        n_tris, tris = case_table()
+        _MC_TABLES[key] = (torch.from_numpy(n_tris).to(volume.device), torch.from_numpy(tris.reshape(-1)).to(volume.device))
+    n_tris, tris = _MC_TABLES[key]
+    total = n0 * n1 * n2
+    vmask = torch.empty(total, dtype=torch.uint8, device=volume.device)
+    vcnt = torch.empty(total, dtype=torch.int32, device=volume.device)
+    tcnt = torch.empty(total, dtype=torch.int32, device=volume.device)
+    with _timed("mc_classify", total, total * 13):
+        _lib.check(lib.anr_mc_classify(_ptr(volume), n0, n1, n2, float(level), _ptr(n_tris), _ptr(vmask), _ptr(vcnt), _ptr(tcnt),
+                                       _stream(volume)), "anr_mc_classify")
+    vend, tend = torch.cumsum(vcnt, 0), torch.cumsum(tcnt, 0)               # int64
+    V, T = int(vend[-1].item()), int(tend[-1].item())
+    vstart, tstart = vend - vcnt, tend - tcnt
+    verts = torch.empty(max(V, 1), 3, dtype=torch.float32, device=volume.device)
+    faces = torch.empty(max(T, 1), 3, dtype=torch.int32, device=volume.device)
+    with _timed("mc_emit", total, total * 21 + V * 12 + T * 12):
+        _lib.check(lib.anr_mc_emit(_ptr(volume), n0, n1, n2, float(level), _ptr(n_tris), _ptr(tris), _ptr(vmask), _ptr(vstart),
+                                   _ptr(tstart), _ptr(verts), _ptr(faces), _stream(volume)), "anr_mc_emit")
+    return verts[:V], faces[:T].long()

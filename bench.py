@@ -369,6 +369,17 @@ def grid_bench(args, ctx, mode, steps, warmup, dense=False):
         def step():
             return ana.sigma_grid(model, N, chunk=1 << 25, rank=rank, world=world)
         elapsed, per_kernel, (sig, _) = ctx.timed(step, steps, warmup)
+        # what extract_mesh.py does with the grid next (:159-165), outside the timed region and on rank 0's slab only when the
+        # grid is sharded: the level set by marching cubes (csrc/mesh.hip)
+        mesh_ms = mesh_tris = None
+        if world == 1:
+            field = (5.0 - sig.view(N, N, N)).contiguous()
+            ana.mesh.marching_cubes(field, 0.0)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            _, tris = ana.mesh.marching_cubes(field, 0.0)
+            torch.cuda.synchronize(dev)
+            mesh_ms, mesh_tris = (time.perf_counter() - t0) * 1e3, int(tris.shape[0])
     return {
         "metric": "grid points/sec, 512^3 sigma query (mesh extraction input)", "value": N ** 3 * steps / elapsed,
         "unit": "points/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -376,7 +387,8 @@ def grid_bench(args, ctx, mode, steps, warmup, dense=False):
         "config": {"workload": "BASELINE configs[4]: 512^3 sigma grid around the posed body, fine network, voxel-sharded "
                                "(contiguous slabs, no collective)", "grid": N, "mlp_on_valid_voxels_only": bool(model.evaluate_valid_only),
                    "mlp_points_per_step_this_rank": per_kernel.get("mlp_forward", {"units": 0})["units"] // max(steps, 1),
-                   "occupied_voxels_this_rank": int((sig > 0).sum())},
+                   "occupied_voxels_this_rank": int((sig > 0).sum()),
+                   "marching_cubes_after_the_timed_region": {"ms": mesh_ms, "triangles": mesh_tris, "threshold": 5.0}},
         "roofline": mlp_roofline(per_kernel, "mlp_forward", mode, MLP_FLOP_SIGMA_ONLY, f"mlp_kernel<{mode}, sigma only>"),
     }
 

@@ -367,6 +367,23 @@ int anr_mlp_denc_counted(int mode, const void* dact, const float* w1, const floa
 int anr_encode_backward_counted(const float* pts, int pts_stride, const float* d_enc, int64_t n, const int32_t* count,
                                 float* d_pts_out, void* stream);
 
+/* ---- f4: the level set of the density grid as a triangle mesh (extract_mesh.py:159-173: mcubes.marching_cubes(-sigmas, 0.)) ---
+ * Marching cubes over volume[n0][n1][n2] (fp32, axis 2 fastest), inside = value < level, in two passes with the caller's
+ * exclusive prefix sums in between (csrc/mesh.hip):
+ *   anr_mc_classify: vmask_out[p] bit a = the grid edge from point p along axis a crosses the level (one vertex each),
+ *     vcount_out[p] = popcount, tcount_out[p] = triangles of the cube based at p (n_tris[256]: triangles per sign case, bit c
+ *     of the case = corner (c&1, (c>>1)&1, (c>>2)&1) inside);
+ *   anr_mc_emit: verts_out[V*3] in index coordinates (vertex vstart[p] + rank of its axis among p's crossing edges, at the
+ *     linear interpolation point), faces_out[T*3] vertex ids; tris[256*8*3] int8: the case table's triangles as cube-edge ids
+ *     (edges enumerated as the corner pairs (a < b) differing in one bit, in lexicographic order; -1 padded).
+ * The case table itself is generated by anim_nerf_amd/mesh.py (same face rule on both sides of a shared face: no cracks).
+ * PyMCubes is absent from the image: parity-unpinned, held to properties (tests/test_mesh.py, test_gpu_parity.py). */
+int anr_mc_classify(const float* volume, int n0, int n1, int n2, float level, const uint8_t* n_tris, uint8_t* vmask_out,
+                    int32_t* vcount_out, int32_t* tcount_out, void* stream);
+int anr_mc_emit(const float* volume, int n0, int n1, int n2, float level, const uint8_t* n_tris, const int8_t* tris,
+                const uint8_t* vmask, const int64_t* vstart, const int64_t* tstart, float* verts_out, int32_t* faces_out,
+                void* stream);
+
 /* ---- a16 / f1: the steps between the big kernels of a training step, one launch each (csrc/train_glue.hip) --------
  * anr_compact_ordered: `inside_inds` of models/anim_nerf.py:253 in sample order.  index_out[0..*count) = positions i with
  *   pts[4i+3] >= 1, ascending; pos_out[i] = row of sample i in that list or -1; pts_out[r] = pts[index[r]], followed by

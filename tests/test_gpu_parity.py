@@ -1067,6 +1067,20 @@ def test_drivers_novel_view_and_sigma_grid_export(dev, tmp_path):
         sig, _ = ana.sigma_grid(model, 24)
     assert vol.shape == (24, 24, 24) and np.array_equal(vol.reshape(-1), sig.cpu().numpy() - 5.0)
     assert (vol > 0).any() and open(f"{out}/smpl.obj").readline().startswith("v ")
+    # mesh.obj (extract_mesh.py:165-173): the level set of that volume, closed, every vertex on a grid edge that straddles the
+    # threshold, placed in the world by the reference's rescale (/ N, x and y swapped) + the body's centre
+    from test_mesh import check_closed_oriented_surface
+    lines = open(f"{out}/mesh.obj").read().split("\n")
+    mv = np.array([[float(x) for x in ln.split()[1:]] for ln in lines if ln.startswith("v ")])
+    mf = np.array([[int(x) - 1 for x in ln.split()[1:]] for ln in lines if ln.startswith("f ")])
+    assert mv.shape[0] > 0 and mf.min() == 0 and mf.max() == mv.shape[0] - 1
+    check_closed_oriented_surface(mv, mf)
+    crossings = sum(int(((np.take(vol, range(0, 23), a) > 0) != (np.take(vol, range(1, 24), a) > 0)).sum()) for a in range(3))
+    assert mv.shape[0] == crossings
+    center = np.load(f"{out}/center.npy")
+    idx = (mv - center)[:, [1, 0, 2]]                                      # undo the swap ...
+    idx = (idx + 1.2) / 2.4 * 24                                           # ... and the rescale: index coordinates again
+    assert idx.min() >= 0 and idx.max() <= 23 and (np.abs(idx - np.round(idx)) < 1e-5).sum(1).min() >= 2     # on grid edges
 
 
 # ----------------------------------------------------------------------------- a2: SMPL / LBS kernels
@@ -1169,3 +1183,42 @@ def test_other_neighbour_counts_match_reference(dev, smpl_table, k):
     for key in ("rgbs", "alphas", "depths", "rgbs_fine", "alphas_fine", "depths_fine"):
         bad = bad | ((out[key].cpu() - ref[key]).abs() > 1e-5 + 1e-3 * ref[key].abs()).any(-1)
     assert bad.float().mean() <= 0.1, bad.float().mean()       # 16 rays per body: a flipped sample moves a whole ray
+
+
+def test_marching_cubes_kernels(dev):
+    """anr_mc_classify / anr_mc_emit (extract_mesh.py:165: mcubes.marching_cubes(-sigmas, 0.); PyMCubes is absent, so: the
+    numpy cube-by-cube restatement of tests/test_mesh.py on small volumes — same vertices, same triangles — and properties at
+    size: a closed, consistently oriented surface whose vertices lie on the level set)."""
+    import anim_nerf_amd as ana
+    from test_mesh import check_closed_oriented_surface, numpy_marching_cubes
+    rng = np.random.default_rng(3)
+    for shape in ((7, 9, 6), (12, 12, 12)):
+        g = np.stack(np.meshgrid(*[np.linspace(-1, 1, n) for n in shape], indexing="ij"), -1)
+        f = (np.linalg.norm(g, axis=-1) - 0.6 + 0.3 * rng.standard_normal(shape)).astype(np.float32)      # ambiguous faces included
+        v_ref, t_ref = numpy_marching_cubes(f)
+        v, t = ana.mesh.marching_cubes(torch.from_numpy(f).to(dev), 0.0)
+        v, t = v.cpu().numpy().astype(np.float64), t.cpu().numpy()
+        assert v.shape == v_ref.shape and t.shape == t_ref.shape
+        # same vertex set (the order differs: grid point, then axis) ...
+        key = lambda a: np.lexsort(np.round(a * 4096).astype(np.int64).T[::-1])
+        o, o_ref = key(v), key(v_ref)
+        np.testing.assert_allclose(v[o], v_ref[o_ref], atol=2e-6)
+        # ... and the same triangles on it, up to a rotation of their corners
+        rank, rank_ref = np.empty_like(o), np.empty_like(o_ref)
+        rank[o], rank_ref[o_ref] = np.arange(len(o)), np.arange(len(o_ref))
+        canon = lambda tri: {tuple(np.roll(r, -int(np.argmin(r)))) for r in tri}
+        assert canon(rank[t]) == canon(rank_ref[t_ref])
+    n = 160
+    x = torch.linspace(-1, 1, n, device=dev)
+    gx, gy, gz = torch.meshgrid(x, x, x, indexing="ij")
+    sphere = torch.sqrt(gx ** 2 + gy ** 2 + gz ** 2) - 0.7
+    v, t = ana.mesh.marching_cubes(sphere.contiguous(), 0.0)
+    vn, tn = v.cpu().numpy(), t.cpu().numpy()
+    n_edges = check_closed_oriented_surface(vn, tn)
+    assert vn.shape[0] - n_edges + tn.shape[0] == 2                      # a sphere
+    p = vn / (n - 1) * 2 - 1
+    assert np.abs(np.linalg.norm(p, axis=-1) - 0.7).max() < 1e-4
+    vol = np.einsum("ij,ij->i", p[tn[:, 0]], np.cross(p[tn[:, 1]], p[tn[:, 2]])).sum() / 6
+    assert abs(vol - 4 / 3 * np.pi * 0.7 ** 3) < 2e-3 * vol              # outward normals, the ball's volume
+    empty_v, empty_t = ana.mesh.marching_cubes(torch.ones(5, 5, 5, device=dev), 0.0)
+    assert empty_v.shape == (0, 3) and empty_t.shape == (0, 3)
