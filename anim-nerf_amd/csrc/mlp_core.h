@@ -260,7 +260,13 @@ struct Mlp {
     // SAVE (training forward: the register file is full with the store staging): no bias registers — the bias of tile T+1
     // is read from LDS straight into the accumulators tile T+1 will use (free since tile T-1's epilogue, which ran behind
     // tile T's first MFMAs) and the tile accumulates onto it; 32 registers less, no spills in front of the stores
+#ifdef ANR_EXP_BIAS_IN_ACC_ALL
+    static constexpr bool BIAS_IN_ACC = true;
+#elif defined(ANR_EXP_BIAS_IN_ACC_W4)
+    static constexpr bool BIAS_IN_ACC = SAVE || NT == 2;
+#else
     static constexpr bool BIAS_IN_ACC = SAVE;
+#endif
     Frag w0[4];              // first fragment group of tile c
     char* act_base;          // SAVE: the activation buffer (blocked layout above) and its row count
     int64_t act_rows;

@@ -17,6 +17,7 @@
 // Index layout per body (floats): x[Vp] y[Vp] z[Vp] | cluster boxes NC x 8 | super boxes NS x 8 | top boxes NT x 8 |
 // body box 8 | order[Vp] (int32: slot -> original vertex id).  Vp = 8 NC, NC = ceil(V/8), NS = ceil(NC/8), NT = ceil(NS/8).
 #include "anr_common.h"
+#include <stdlib.h>
 
 namespace anr {
 
@@ -515,7 +516,10 @@ __device__ __forceinline__ int hash_slot(int* keys, int cell) {
 }
 
 constexpr int CLS_ITERS = 8;                   // samples per classify workgroup = 8 x 1024
-template <bool FROM_RAYS>
+// VEC4 (rays mode, K % 4 == 0): a thread takes FOUR CONSECUTIVE samples of one ray per step — one 16-byte load of depths, one
+// dword of merge permutation in, one dword of validity bytes out — instead of four byte-wide accesses 1,024 samples apart:
+// the pass is a stream over z / perm / mask (11 B per sample) and ran at 1.4 TB/s on byte traffic.
+template <bool FROM_RAYS, bool VEC4>
 __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
     const float* __restrict__ xyz, int xyz_stride, const float* __restrict__ rays, int ray_stride,
     const float* __restrict__ z, int K, const float* __restrict__ index, IndexDims d, int64_t N, float thr,
@@ -523,6 +527,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
     int32_t* __restrict__ cells, int32_t* __restrict__ count, int32_t* __restrict__ cell_count,
     uint8_t* __restrict__ valid_mask, const float4* __restrict__ reuse_pts, const uint8_t* __restrict__ reuse_mask,
     const uint8_t* __restrict__ perm, int reuse_K, int G) {
+    static_assert(!VEC4 || FROM_RAYS, "four samples per thread: rays mode");
     __shared__ int wave_cnt[WARP_THREADS / 64];
     __shared__ int block_base;
     __shared__ int hkeys[HN], hcnt[HN];
@@ -531,65 +536,82 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int s = threadIdx.x; s < HN; s += WARP_THREADS) { hkeys[s] = -1; hcnt[s] = 0; }
     __syncthreads();
-    // each thread classifies CLS_ITERS samples (1024 apart) and remembers its near ones; the list is then written with ONE
+    // each thread classifies CLS_ITERS samples and remembers its near ones; the list is then written with ONE
     // block-wide compaction (one scan, one global atomic, no barrier per iteration)
+    constexpr int VS = VEC4 ? 4 : 1, STEPS = CLS_ITERS / VS;
     int my_cell[CLS_ITERS];
     unsigned near_bits = 0;
     const uint32_t R32 = (uint32_t)(N / (K > 0 ? K : 1));
+    // flat index of the thread's sample (step, v)
+    auto sample_of = [&](int step, int v) { return (((int64_t)blockIdx.x * STEPS + step) * WARP_THREADS + threadIdx.x) * VS + v; };
 #pragma unroll
-    for (int it = 0; it < CLS_ITERS; ++it) {
-        const int64_t n = ((int64_t)blockIdx.x * CLS_ITERS + it) * WARP_THREADS + threadIdx.x;
-        bool near = false;
-        int cell = 0;
-        if (n < N) {
-            float px, py, pz;
-            const uint32_t ray = FROM_RAYS ? (uint32_t)n / (uint32_t)K : 0;        // (N < 2^31 on this path)
-            if (FROM_RAYS) {
-                const float* ry = rays + ((int64_t)b * R32 + ray) * ray_stride;
-                const float zz = z[(int64_t)b * N + n];
-                px = __fadd_rn(ry[0], __fmul_rn(zz, ry[3]));
-                py = __fadd_rn(ry[1], __fmul_rn(zz, ry[4]));
-                pz = __fadd_rn(ry[2], __fmul_rn(zz, ry[5]));
-            } else {
-                const float* sp = xyz + ((int64_t)b * N + n) * xyz_stride;
-                px = sp[0]; py = sp[1]; pz = sp[2];
-            }
-            const int64_t o = (int64_t)b * N + n;
-            // farther than the threshold from the whole body -> cannot be valid (see warp_points_kernel)
-            near = box_d2(gbox, px, py, pz) < thr * thr;
-            bool reused = false;
-            if (FROM_RAYS && perm != nullptr) {
-                // fine pass: this sorted sample IS coarse sample p of the same ray (z_sorted[j] = cat(z_coarse, z_fine)
-                // [perm[j]]) -> its canonical point and validity were computed in the coarse pass: copy, do not search
-                const int pj = perm[o];
-                if (pj < reuse_K) {
-                    const int64_t src = ((int64_t)b * R32 + ray) * reuse_K + pj;
-                    const uint8_t m = reuse_mask[src];
-                    valid_mask[o] = m;
-                    if (m) pts_out[o] = reuse_pts[src];
-                    near = false;
-                    reused = true;
-                }
-            }
-            if (!reused) {
-                // lean mode (validity bytes requested): consumers look at the byte, not at the point, so the 16-B point
-                // of a far sample is not written at all
-                if (valid_mask != nullptr) valid_mask[o] = 0;
-                if (valid_mask == nullptr || near) pts_out[o] = make_float4(px, py, pz, 0.0f);
-                if (nbr_w != nullptr) {
-                    reinterpret_cast<float4*>(nbr_w)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(0, 0, 0, 0);
-                }
-                if (near) {
-                    cell = cell_of(gbox, thr, G, px, py, pz);
-                    const int slot = hash_slot(hkeys, cell);
-                    if (slot >= 0) atomicAdd(&hcnt[slot], 1);
-                    else atomicAdd(cell_count + (int64_t)b * NCELL + cell, 1);
-                }
-            }
+    for (int step = 0; step < STEPS; ++step) {
+        const int64_t n0 = sample_of(step, 0);
+        float zz[VS];
+        unsigned pm = 0, mask_out = 0;
+        if (VEC4 && n0 < N) {                                   // (N % 4 == 0: the four samples are in range together)
+            const float4 z4 = *reinterpret_cast<const float4*>(z + (int64_t)b * N + n0);
+            zz[0] = z4.x; zz[VS > 1 ? 1 : 0] = z4.y; zz[VS > 2 ? 2 : 0] = z4.z; zz[VS > 3 ? 3 : 0] = z4.w;
+            if (perm != nullptr) pm = *reinterpret_cast<const unsigned*>(perm + (int64_t)b * N + n0);
         }
-        my_cell[it] = cell;
-        near_bits |= (near ? 1u : 0u) << it;
+#pragma unroll
+        for (int v = 0; v < VS; ++v) {
+            const int it = step * VS + v;
+            const int64_t n = n0 + v;
+            bool near = false;
+            int cell = 0;
+            if (n < N) {
+                float px, py, pz;
+                const uint32_t ray = FROM_RAYS ? (uint32_t)n / (uint32_t)K : 0;        // (N < 2^31 on this path)
+                if (FROM_RAYS) {
+                    const float* ry = rays + ((int64_t)b * R32 + ray) * ray_stride;
+                    const float zv = VEC4 ? zz[v] : z[(int64_t)b * N + n];
+                    px = __fadd_rn(ry[0], __fmul_rn(zv, ry[3]));
+                    py = __fadd_rn(ry[1], __fmul_rn(zv, ry[4]));
+                    pz = __fadd_rn(ry[2], __fmul_rn(zv, ry[5]));
+                } else {
+                    const float* sp = xyz + ((int64_t)b * N + n) * xyz_stride;
+                    px = sp[0]; py = sp[1]; pz = sp[2];
+                }
+                const int64_t o = (int64_t)b * N + n;
+                // farther than the threshold from the whole body -> cannot be valid (see warp_points_kernel)
+                near = box_d2(gbox, px, py, pz) < thr * thr;
+                bool reused = false;
+                if (FROM_RAYS && perm != nullptr) {
+                    // fine pass: this sorted sample IS coarse sample p of the same ray (z_sorted[j] = cat(z_coarse, z_fine)
+                    // [perm[j]]) -> its canonical point and validity were computed in the coarse pass: copy, do not search
+                    const int pj = VEC4 ? (int)((pm >> (8 * v)) & 0xffu) : (int)perm[o];
+                    if (pj < reuse_K) {
+                        const int64_t src = ((int64_t)b * R32 + ray) * reuse_K + pj;
+                        const uint8_t m = reuse_mask[src];
+                        if (VEC4) mask_out |= (unsigned)m << (8 * v);
+                        else valid_mask[o] = m;
+                        if (m) pts_out[o] = reuse_pts[src];
+                        near = false;
+                        reused = true;
+                    }
+                }
+                if (!reused) {
+                    // lean mode (validity bytes requested): consumers look at the byte, not at the point, so the 16-B point
+                    // of a far sample is not written at all
+                    if (!VEC4 && valid_mask != nullptr) valid_mask[o] = 0;
+                    if (valid_mask == nullptr || near) pts_out[o] = make_float4(px, py, pz, 0.0f);
+                    if (nbr_w != nullptr) {
+                        reinterpret_cast<float4*>(nbr_w)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(0, 0, 0, 0);
+                    }
+                    if (near) {
+                        cell = cell_of(gbox, thr, G, px, py, pz);
+                        const int slot = hash_slot(hkeys, cell);
+                        if (slot >= 0) atomicAdd(&hcnt[slot], 1);
+                        else atomicAdd(cell_count + (int64_t)b * NCELL + cell, 1);
+                    }
+                }
+            }
+            my_cell[it] = cell;
+            near_bits |= (near ? 1u : 0u) << it;
+        }
+        if (VEC4 && valid_mask != nullptr && n0 < N) *reinterpret_cast<unsigned*>(valid_mask + (int64_t)b * N + n0) = mask_out;
     }
     {
         const int mine = __popc(near_bits);
@@ -612,7 +634,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
 #pragma unroll
         for (int it = 0; it < CLS_ITERS; ++it) {
             if ((near_bits >> it) & 1u) {
-                list[pos] = (int32_t)(((int64_t)blockIdx.x * CLS_ITERS + it) * WARP_THREADS + threadIdx.x);
+                list[pos] = (int32_t)sample_of(it / VS, it % VS);
                 cells[pos] = my_cell[it];
                 ++pos;
             }
@@ -876,7 +898,13 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
     const int32_t* order = reinterpret_cast<const int32_t*>(my_index + d.order_off());
     const float* O2C = ober2cano + (int64_t)b * d.V * 16;
     const int32_t* my_list = list + (int64_t)b * N;
-    const float* cap = cell_cap2 + (int64_t)b * NCELL;
+    // DIRECT (cell_cap2 == NULL): no cell pass ran — a small batch has about as many occupied cells as near samples, so a
+    // search per cell buys nothing per sample.  The list is the classify pass's own (sample order: the lanes of an item are
+    // consecutive samples of a ray), and each sample searches inside the validity radius first: nothing there -> it is
+    // invalid (the blended distance is a convex combination of neighbour distances >= dis_threshold) and stays (x, 0); four
+    // or more -> those ARE the exact neighbours; one to three -> the search is repeated without a bound.
+    const bool direct = cell_cap2 == nullptr;
+    const float* cap = direct ? nullptr : cell_cap2 + (int64_t)b * NCELL;
     const int lane = threadIdx.x & 63;
     stage_index(my_index, d.lds_floats(), lds);
     const float* gbox = lds + d.body_off();
@@ -892,10 +920,23 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
         // inside the cell's radius the exact four neighbours are guaranteed to be found (warp_cells_kernel)
         // ... and the first cluster to scan is the one the cell's own search found nearest: no descent per point
         Best4 best;
-        const int cell = cell_of(gbox, thr, G, p.x, p.y, p.z);
-        best_init(best, cap[cell]);
-        search_from(lds, d, p.x, p.y, p.z, go, best, go ? cell_seed[(int64_t)b * NCELL + cell] : 0);
-        if (!go) continue;
+        if (direct) {
+            best_init(best, thr * thr * 1.0002f);
+            search(lds, d, p.x, p.y, p.z, go, best);
+            const bool partial = go && best.i[0] >= 0 && best.i[3] < 0;
+            if (__any(partial)) {
+                Best4 full;
+                best_init(full);
+                search(lds, d, p.x, p.y, p.z, partial, full);
+                if (partial) best = full;
+            }
+            if (!go || best.i[0] < 0) continue;
+        } else {
+            const int cell = cell_of(gbox, thr, G, p.x, p.y, p.z);
+            best_init(best, cap[cell]);
+            search_from(lds, d, p.x, p.y, p.z, go, best, go ? cell_seed[(int64_t)b * NCELL + cell] : 0);
+            if (!go) continue;
+        }
         const bool ok = blend_and_store(best, order, lbs_w, J, O2C, thr, p.x, p.y, p.z, o, pts_out, nullptr, nullptr, nullptr,
                                         nbr_idx, nbr_w);
         if (valid_mask != nullptr && ok) valid_mask[o] = 1;     // lean mode: the byte the compositor and the MLP's list go by
@@ -1112,19 +1153,47 @@ extern "C" int anr_warp_points_lean(const float* xyz, int xyz_stride, const floa
         hipError_t e = hipMemsetAsync(w.count, 0, sizeof(int32_t) * WarpWs::zeroed_ints(bs), st);
         if (e != hipSuccess) return fail((int)e, "anr_warp_points: hipMemsetAsync: %s", hipGetErrorString(e));
         dim3 g1((unsigned)((N + CLS_ITERS * WARP_THREADS - 1) / (CLS_ITERS * WARP_THREADS)), bs);
-        if (xyz == nullptr)
-            hipLaunchKernelGGL(warp_classify_kernel<true>, g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride, z,
+        // four consecutive samples per thread where the shapes allow dword / 16-byte accesses (every shipped shape)
+        const bool vec4 = xyz == nullptr && K % 4 == 0 && N % 4 == 0 && ((uintptr_t)z & 15) == 0 && ((uintptr_t)valid_mask_out & 3) == 0 &&
+                          ((uintptr_t)reuse_perm & 3) == 0;
+        if (vec4)
+            hipLaunchKernelGGL((warp_classify_kernel<true, true>), g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride, z,
+                               K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
+                               w.list, w.cells, w.count, w.cell_count, valid_mask_out,
+                               reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K, G);
+        else if (xyz == nullptr)
+            hipLaunchKernelGGL((warp_classify_kernel<true, false>), g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride, z,
                                K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
                                w.list, w.cells, w.count, w.cell_count, valid_mask_out,
                                reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K, G);
         else
-            hipLaunchKernelGGL(warp_classify_kernel<false>, g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride,
+            hipLaunchKernelGGL((warp_classify_kernel<false, false>), g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride,
                                z, K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
                                w.list, w.cells, w.count, w.cell_count, valid_mask_out, nullptr, nullptr, nullptr, 0, G);
         if (int rc = check_launch("anr_warp_points (classify)")) return rc;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         int64_t gx = (cus + bs - 1) / bs;                                   // one persistent workgroup per CU in total
+        if (N < (int64_t)1 << 19 && !getenv("ANR_WARP_CELLS_ALWAYS")) {
+            // a small batch per body (training: 1,024 rays): straight to the per-sample search (see warp_search_kernel)
+            if (int rc = allow_big_lds(warp_search_kernel, bytes, "anr_warp_points")) return rc;
+            const int64_t max_wg = (N + 64 * (WARP_THREADS / 64) - 1) / (64 * (WARP_THREADS / 64));
+            if (gx > max_wg) gx = max_wg;
+            hipLaunchKernelGGL(warp_search_kernel, dim3((unsigned)gx, bs), dim3(WARP_THREADS), bytes, st, index, d, ober2cano,
+                               lbs_weights, J, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
+                               w.list, w.count, w.cursor, nullptr, valid_mask_out, nullptr, G);
+            if (int rc = check_launch("anr_warp_points (search)")) return rc;
+            if (lean) {
+                e = hipMemsetAsync(valid_count_out, 0, sizeof(int32_t), st);
+                if (e != hipSuccess) return fail((int)e, "anr_warp_points_lean: hipMemsetAsync: %s", hipGetErrorString(e));
+                const int64_t total = (int64_t)bs * N;
+                const int64_t vb = (total + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
+                hipLaunchKernelGGL(warp_valid_list_kernel, dim3((unsigned)(vb < 4096 ? vb : 4096)), dim3(WARP_THREADS), 0, st,
+                                   valid_mask_out, total, valid_index_out, valid_count_out);
+                return check_launch("anr_warp_points_lean (valid list)");
+            }
+            return 0;
+        }
         if (int rc = allow_big_lds(warp_cells_kernel, bytes, "anr_warp_points")) return rc;
         hipLaunchKernelGGL(warp_cell_list_kernel, dim3(cells / (4 * WARP_THREADS), bs), dim3(WARP_THREADS), 0, st, w.cell_count,
                            w.occ_list, w.occ_count);
