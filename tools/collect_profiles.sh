@@ -4,7 +4,7 @@
 # --pmc passes are separate from each other and carry no trace domain besides --kernel-trace.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$ROOT/gpurun_out/prof_r02
+OUT=$ROOT/gpurun_out/prof_r03
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for wl in cfg2 cfg3 cfg4; do
@@ -22,8 +22,8 @@ for wl in cfg2 cfg3; do
   python3 tools/hbm_table.py $OUT/${wl}_fetch $OUT/${wl}_write $OUT/${wl}_trace >> $OUT/hbm_${wl}.txt
   cat $OUT/hbm_${wl}.txt
 done
-# the files the judge reads, named as in profiles/r02/
-DST=$ROOT/gpurun_out/profiles_r02
+# the files the judge reads, named as in profiles/r03/
+DST=$ROOT/gpurun_out/profiles_r03
 mkdir -p $DST
 for wl in cfg2 cfg3 cfg4; do
   cp $OUT/${wl}_trace/*/*kernel_stats.csv $DST/bench_${wl}_bf16_kernel_stats.csv
@@ -33,4 +33,12 @@ cp $OUT/hbm_cfg2.txt $OUT/hbm_cfg3.txt $DST/
 python3 tools/traffic_json.py $OUT ${ANR_COMMIT:-unknown} 4 > $DST/mlp_hbm_traffic.json
 python3 tools/time_train_cfg4.py 2>/dev/null | tail -3 > $DST/train_step_launches.txt
 python3 bench.py 2>/dev/null | grep '^{' > $DST/bench_default_line.json
+ls $DST
+# round 3 additions: the training MLP kernels by row count, the MLP kernel's matrix-pipe occupancy at HEAD
+python3 tools/bench_train_kernels.py > $DST/train_kernels_scaling.txt 2>/dev/null
+cd /tmp
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $OUT/mlp_pmc --output-format csv -- python3 $ROOT/tools/bench_mlp.py 4194304 3 bf16 > $OUT/mlp_pmc.txt 2>&1
+cd $ROOT
+python3 tools/pmc_summary.py $OUT/mlp_pmc mlp_kernel > $DST/mlp_pmc_head.txt
+python3 tools/bench_mlp.py 4194304 7 bf16,bf16_w4,f32 >> $DST/mlp_pmc_head.txt
 ls $DST
