@@ -531,10 +531,13 @@ def main():
             except Exception as exc:                        # noqa: BLE001
                 got, err = None, f"{type(exc).__name__}: {exc}"[:300]
             if world > 1 and not ctx.all_ok(err is None):
+                # every rank knows: the headline (measured, valid) is printed with the failure recorded, and the job ends
+                # HERE with exit code 0 on all ranks — the scaling measurement reads the line, not the extras
                 if rank == 0:
                     result["workloads"] = {**w, fn.__name__: {"error": err or "failed on another rank"}}
                     print(json.dumps(result), flush=True)
-                os._exit(3)                                 # no destroy_process_group: a failed rank may not answer
+                sys.stdout.flush()
+                os._exit(0)                                 # no destroy_process_group: a failed rank may not answer
             return got if err is None else {"error": err}
         w = {}
         if world == 1:
