@@ -367,7 +367,7 @@ def grid_bench(args, ctx, mode, steps, warmup, dense=False):
         model.clac_ober2cano_transform()
 
         def step():
-            return ana.sigma_grid(model, N, chunk=1 << 25, rank=rank, world=world)
+            return ana.sigma_grid(model, N, chunk=1 << 27, rank=rank, world=world)
         elapsed, per_kernel, (sig, _) = ctx.timed(step, steps, warmup)
         # what extract_mesh.py does with the grid next (:159-165), outside the timed region and on rank 0's slab only when the
         # grid is sharded: the level set by marching cubes (csrc/mesh.hip)
