@@ -164,6 +164,10 @@ extern "C" int anr_mlp_forward_save_indexed(const void* pack, int mode, const fl
     float* act = reinterpret_cast<float*>(act_v);
     ANR_REQUIRE(pack && pts && out && act, ANR_E_BADARG, "anr_mlp_forward_save: null pointer");
     ANR_REQUIRE(n > 0, ANR_E_BADARG, "anr_mlp_forward_save: n=%lld", (long long)n);
+    // (a lane addresses its row inside a 32-feature block with a 32-bit byte offset)
+    ANR_REQUIRE(n <= (((mode & 0xff) == ANR_MLP_F32) ? (int64_t)1 << 25 : (int64_t)1 << 26), ANR_E_BADARG,
+                "anr_mlp_forward_save: n=%lld rows per call exceed the saved-activation layout (2^25 fp32 / 2^26 bf16): chunk the call",
+                (long long)n);
     ANR_REQUIRE((((uintptr_t)pack | (uintptr_t)pts | (uintptr_t)out | (uintptr_t)act) & 15) == 0, ANR_E_ALIGN,
                 "anr_mlp_forward_save: pack/pts/out/act must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;

@@ -598,6 +598,8 @@ extern "C" int anr_mlp_backward_counted(const void* bwd_pack, int mode, const fl
                                         const int32_t* count, void* stream) {
     ANR_REQUIRE(bwd_pack && g && act && dact, ANR_E_BADARG, "anr_mlp_backward: null pointer");
     ANR_REQUIRE(n > 0, ANR_E_BADARG, "anr_mlp_backward: n=%lld", (long long)n);
+    ANR_REQUIRE(n <= (((mode & 0xff) == ANR_MLP_F32) ? (int64_t)1 << 25 : (int64_t)1 << 26), ANR_E_BADARG,
+                "anr_mlp_backward: n=%lld rows per call exceed the blocked layout (2^25 fp32 / 2^26 bf16): chunk the call", (long long)n);
     ANR_REQUIRE((((uintptr_t)bwd_pack | (uintptr_t)g | (uintptr_t)act | (uintptr_t)dact) & 15) == 0, ANR_E_ALIGN,
                 "anr_mlp_backward: bwd_pack/g/act/dact must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;

@@ -1082,3 +1082,20 @@ def test_training_tracks_an_oracle_trained_copy(dev, smpl_table):
     assert curve_o[-1] < 0.85 * curve_o[0], "the run must actually train"
     assert abs(curve_h[0] - curve_o[0]) <= 1e-4 * curve_o[0]
     assert gap < 0.02 and abs(psnr_h - psnr_o) < 0.1
+
+
+def test_training_pass_without_a_single_valid_sample(dev, smpl_table):
+    """every ray misses the body (a rank's batch can look like that): the compacted list is empty, its length stays on the
+    device, and forward, backward and weight gradients run on the 64 padding rows — finite outputs, exactly zero gradients."""
+    m = seeded_model(smpl_table, 7, True, gain=50.0, device=dev)
+    net = m.nerf
+    pts = torch.cat([torch.rand(5000, 3) * 2 - 1, torch.zeros(5000, 1)], -1).to(dev).requires_grad_(True)      # valid = 0 everywhere
+    for sigma_only in (False, True):
+        net.zero_grad(set_to_none=True)
+        out = net.eval_points(pts, "bf16", sigma_only=sigma_only, only_valid=True)
+        flat = out.reshape(5000, -1)
+        assert (flat[:, -1] == -1e5).all() and (flat[:, :-1] == 0).all()
+        (flat * torch.randn_like(flat)).sum().backward()
+        assert all(p.grad is None or (torch.isfinite(p.grad).all() and p.grad.abs().max() == 0) for p in net.parameters())
+        assert pts.grad is not None and pts.grad.abs().max() == 0
+        pts.grad = None
