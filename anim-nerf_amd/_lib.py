@@ -19,6 +19,7 @@ ANR_MLP_FLAG_NO_DMA = 0x100
 ANR_MLP_FLAG_SIGMA_ONLY = 0x400
 ANR_MLP_FLAG_TANGENT = 0x800
 ANR_MLP_FLAG_ACCUMULATE = 0x1000
+ANR_MLP_FLAG_VIEW = 0x2000
 ANR_MAX_SAMPLES = 256
 
 
@@ -87,6 +88,8 @@ SIGNATURES = {
     "anr_compact_valid": (_I, [_P, _L, _P, _P, _P, _I, _P]),
     "anr_mlp_forward_indexed": (_I, [_P, _I, _P, _P, _P, _L, _P, _P]),
     "anr_mlp_act_cols": (_I, []),
+    "anr_mlp_pack_view": (_I, [C.POINTER(AnrMlpParams), _I, _I, _P, _P]),
+    "anr_mlp_forward_view": (_I, [_P, _I, _P, _P, _I, _P, _P, _L, _P, _P]),
     "anr_mlp_forward_save": (_I, [_P, _I, _P, _L, _P, _P, _P]),
     "anr_mlp_forward_save_indexed": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _P]),
     "anr_encode": (_I, [_P, _I, _L, _I, _P, _P]),

@@ -28,6 +28,7 @@ extern template int launch_mlp<ANR_MLP_BF16_W8, true, false, true, true>(const v
 struct PackStage {
     const float* W; const float* B;
     int out_dim, in_dim, enc_cols, n_tiles, nf_enc, nf_hid, frag0, tile0;
+    int enc_col0, hid_col0;     // first column of the encoding channels / of the hidden features in W's rows
 };
 struct PackPlan { PackStage s[12]; int n_stages; int total_frags; };
 
@@ -57,11 +58,11 @@ __global__ void mlp_pack_kernel(PackPlan plan, char* __restrict__ pack) {
             int col;
             if (kf < st.nf_enc) {
                 int ch = enc_channel(C::EPF * kf + e, h);
-                col = (ch >= 0 && ch < st.enc_cols) ? ch : -1;
+                col = (ch >= 0 && ch < st.enc_cols) ? st.enc_col0 + ch : -1;
             } else {
                 int f = kf - st.nf_enc;
                 int feat = C::IS_BF16 ? 16 * f + 8 * (e >> 2) + 4 * h + (e & 3) : 8 * f + 4 * h + e;
-                col = st.enc_cols + feat;
+                col = st.hid_col0 + feat;
             }
             v[e] = (row < st.out_dim && col >= 0 && col < st.in_dim) ? st.W[(int64_t)row * st.in_dim + col] : 0.0f;
         }
@@ -90,13 +91,16 @@ __global__ void mlp_pack_kernel(PackPlan plan, char* __restrict__ pack) {
     }
 }
 
+// dir_channels > 0: the view-dependent colour head (models/nerf.py:141-153): dir_encoding.0.weight is [128][256 + dir_channels],
+// its last dir_channels columns = the Fourier encoding of the view direction -> the panel fragments of tiles 73..76
 template <int MODE>
-PackPlan make_plan(const anr_mlp_params* p) {
+PackPlan make_plan(const anr_mlp_params* p, int dir_channels = 0) {
     using C = Cfg<MODE>;
     PackPlan plan{};
     int frag = 0, tile = 0, n = 0;
-    auto add = [&](const float* W, const float* B, int out_dim, int in_dim, int enc_cols, int n_tiles, int nfe, int nfh) {
-        plan.s[n++] = PackStage{W, B, out_dim, in_dim, enc_cols, n_tiles, nfe, nfh, frag, tile};
+    auto add = [&](const float* W, const float* B, int out_dim, int in_dim, int enc_cols, int n_tiles, int nfe, int nfh,
+                   int enc_col0 = 0, int hid_col0 = -1) {
+        plan.s[n++] = PackStage{W, B, out_dim, in_dim, enc_cols, n_tiles, nfe, nfh, frag, tile, enc_col0, hid_col0 < 0 ? enc_cols : hid_col0};
         frag += n_tiles * (nfe + nfh);
         tile += n_tiles;
     };
@@ -107,7 +111,8 @@ PackPlan make_plan(const anr_mlp_params* p) {
     }
     add(p->w_sigma, p->b_sigma, 1, 256, 0, 1, 0, C::HF);          // tile 64: sigma row on h8
     add(p->w_final, p->b_final, 256, 256, 0, 8, 0, C::HF);        // tiles 65..72
-    add(p->w_dir, p->b_dir, 128, 256, 0, 4, 0, C::HF);
+    if (dir_channels > 0) add(p->w_dir, p->b_dir, 128, 256 + dir_channels, dir_channels, 4, C::EF, C::HF, 256, 0);
+    else                  add(p->w_dir, p->b_dir, 128, 256, 0, 4, 0, C::HF);
     add(p->w_rgb, p->b_rgb, 3, 128, 0, 1, 0, C::DF);
     plan.n_stages = n;
     plan.total_frags = frag;
@@ -119,19 +124,27 @@ PackPlan make_plan(const anr_mlp_params* p) {
 using namespace anr;
 
 #define ANR_MLP_FLAG_NO_DMA 0x100      /* debug: stage weights through registers instead of the LDS-DMA engine */
+/* ANR_MLP_FLAG_VIEW (0x2000) is public: include/animnerf_hip.h */
 #define ANR_MLP_FLAG_W4     0x200      /* bf16 only: 4 waves x 64 points per workgroup instead of 8 waves x 32 */
 /* ANR_MLP_FLAG_SIGMA_ONLY (0x400) is public: include/animnerf_hip.h */
 
 extern "C" int64_t anr_mlp_pack_bytes(int mode) {
+    const bool view = (mode & ANR_MLP_FLAG_VIEW) != 0;
     switch (mode & 0xff) {
-        case ANR_MLP_F32:  return BIAS_BYTES + (int64_t)total_frags<Cfg<ANR_MLP_F32>>() * FRAG_BYTES;
-        case ANR_MLP_BF16: return BIAS_BYTES + (int64_t)total_frags<Cfg<ANR_MLP_BF16>>() * FRAG_BYTES;
+        case ANR_MLP_F32:  return BIAS_BYTES + (int64_t)(view ? total_frags<Cfg<ANR_MLP_F32>, true>() : total_frags<Cfg<ANR_MLP_F32>>()) * FRAG_BYTES;
+        case ANR_MLP_BF16: return BIAS_BYTES + (int64_t)(view ? total_frags<Cfg<ANR_MLP_BF16>, true>() : total_frags<Cfg<ANR_MLP_BF16>>()) * FRAG_BYTES;
         default: return ANR_E_BADARG;
     }
 }
 
 extern "C" int anr_mlp_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream) {
+    return anr_mlp_pack_view(p, mode, 0, pack_out, stream);
+}
+
+extern "C" int anr_mlp_pack_view(const anr_mlp_params* p, int mode, int dir_channels, void* pack_out, void* stream) {
     ANR_REQUIRE(p && pack_out, ANR_E_BADARG, "anr_mlp_pack: null pointer");
+    ANR_REQUIRE(dir_channels >= 0 && dir_channels <= 63 && (dir_channels == 0 || dir_channels % 6 == 3), ANR_E_BADARG,
+                "anr_mlp_pack_view: dir_channels=%d (0, or 3 + 6 freqs_dir <= 63)", dir_channels);
     for (int l = 0; l < 8; ++l)
         ANR_REQUIRE(p->w_trunk[l] && p->b_trunk[l], ANR_E_BADARG, "anr_mlp_pack: null trunk tensor %d", l);
     ANR_REQUIRE(p->w_sigma && p->b_sigma && p->w_final && p->b_final && p->w_dir && p->b_dir && p->w_rgb && p->b_rgb,
@@ -139,11 +152,11 @@ extern "C" int anr_mlp_pack(const anr_mlp_params* p, int mode, void* pack_out, v
     ANR_REQUIRE(((uintptr_t)pack_out & 15) == 0, ANR_E_ALIGN, "anr_mlp_pack: pack_out must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;
     if ((mode & 0xff) == ANR_MLP_F32) {
-        PackPlan plan = make_plan<ANR_MLP_F32>(p);
+        PackPlan plan = make_plan<ANR_MLP_F32>(p, dir_channels);
         int64_t n = (int64_t)plan.total_frags * 64 + BIAS_BYTES / 4;
         hipLaunchKernelGGL(mlp_pack_kernel<ANR_MLP_F32>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, plan, (char*)pack_out);
     } else if ((mode & 0xff) == ANR_MLP_BF16) {
-        PackPlan plan = make_plan<ANR_MLP_BF16>(p);
+        PackPlan plan = make_plan<ANR_MLP_BF16>(p, dir_channels);
         int64_t n = (int64_t)plan.total_frags * 64 + BIAS_BYTES / 4;
         hipLaunchKernelGGL(mlp_pack_kernel<ANR_MLP_BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, plan, (char*)pack_out);
     } else {
@@ -284,5 +297,24 @@ extern "C" int anr_mlp_forward_indexed(const void* pack, int mode, const float* 
             return dma ? launch_mlp<ANR_MLP_BF16_W8, true, false, false>(pack, pts, n, out, st, nullptr, index, count) : launch_mlp<ANR_MLP_BF16_W8, false, false, false>(pack, pts, n, out, st, nullptr, index, count);
         default:
             return fail(ANR_E_BADARG, "anr_mlp_forward: unknown mode %d", mode);
+    }
+}
+
+extern "C" int anr_mlp_forward_view(const void* pack, int mode, const float* pts, const float* viewdir, int view_stride,
+                                    const int32_t* index, const int32_t* count, int64_t n, float* out, void* stream) {
+    ANR_REQUIRE(pack && pts && viewdir && out, ANR_E_BADARG, "anr_mlp_forward_view: null pointer");
+    ANR_REQUIRE(index || !count, ANR_E_BADARG, "anr_mlp_forward_view: count without index");
+    ANR_REQUIRE(n > 0 && view_stride >= 3 && (!index || n < (int64_t)1 << 31), ANR_E_BADARG, "anr_mlp_forward_view: n=%lld stride=%d",
+                (long long)n, view_stride);
+    ANR_REQUIRE((((uintptr_t)pack | (uintptr_t)pts | (uintptr_t)out) & 15) == 0 && ((uintptr_t)viewdir & 3) == 0, ANR_E_ALIGN,
+                "anr_mlp_forward_view: pack/pts/out must be 16-B aligned");
+    ANR_REQUIRE(!(mode & (ANR_MLP_FLAG_SIGMA_ONLY | ANR_MLP_FLAG_TANGENT)), ANR_E_BADARG, "anr_mlp_forward_view: full network only");
+    hipStream_t st = (hipStream_t)stream;
+    switch (mode & 0xff) {
+        case ANR_MLP_F32:
+            return launch_mlp<ANR_MLP_F32, true, false, false, false, false, true>(pack, pts, n, out, st, nullptr, index, count, viewdir, view_stride, 1);
+        case ANR_MLP_BF16:
+            return launch_mlp<ANR_MLP_BF16_W8, true, false, false, false, false, true>(pack, pts, n, out, st, nullptr, index, count, viewdir, view_stride, 1);
+        default: return fail(ANR_E_BADARG, "anr_mlp_forward_view: unknown mode %d", mode);
     }
 }

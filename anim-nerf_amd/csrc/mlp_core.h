@@ -69,16 +69,18 @@ template <> struct Cfg<ANR_MLP_F32> {
 };
 
 // frags of out-tile t of the flat 78-tile schedule, and of staged chunk c (= TPC consecutive tiles)
-template <class C> __host__ __device__ constexpr int tile_frags(int t) {
-    return t < 8 ? C::EF : t < 32 ? C::HF : t < 40 ? C::EF + C::HF : t < 77 ? C::HF : t < 78 ? C::DF : 0;
+// VIEW (use_view=True, models/nerf.py:141-153): the four dir_encoding tiles (73..76) take the Fourier panel of the view
+// direction in front of the 256-wide feature, as the skip layer takes the position's
+template <class C, bool VIEW = false> __host__ __device__ constexpr int tile_frags(int t) {
+    return t < 8 ? C::EF : t < 32 ? C::HF : t < 40 ? C::EF + C::HF : t < 73 ? C::HF : t < 77 ? (VIEW ? C::EF + C::HF : C::HF) : t < 78 ? C::DF : 0;
 }
-template <class C> __host__ __device__ constexpr int chunk_frags(int c) {
+template <class C, bool VIEW = false> __host__ __device__ constexpr int chunk_frags(int c) {
     int n = 0;
-    for (int i = 0; i < C::TPC; ++i) n += tile_frags<C>(c * C::TPC + i);
+    for (int i = 0; i < C::TPC; ++i) n += tile_frags<C, VIEW>(c * C::TPC + i);
     return n;
 }
-template <class C> constexpr int total_frags() {
-    return 8 * C::EF + 24 * C::HF + 8 * (C::EF + C::HF) + 24 * C::HF + 9 * C::HF + 4 * C::HF + C::DF;
+template <class C, bool VIEW = false> constexpr int total_frags() {
+    return 8 * C::EF + 24 * C::HF + 8 * (C::EF + C::HF) + 24 * C::HF + 9 * C::HF + 4 * (C::HF + (VIEW ? C::EF : 0)) + C::DF;
 }
 template <class C> constexpr int slot_bytes() { return C::TPC * (C::EF + C::HF) * FRAG_BYTES; }
 
@@ -227,8 +229,11 @@ __host__ __device__ constexpr int act_sign_bit(int Q, int i) { return ((i & 1) ?
 // 4p is point p itself, columns 4p+1..3 carry the tangents d/dx, d/dy, d/dz through the same layers: their encoding is the
 // derivative of the encoding, they get no bias, and their ReLU gate is the PRIMAL column's (one DPP quad broadcast).
 // sigma of a tangent column is then d sigma / d x_d.
-template <int MODE, bool DMA, bool SIGMA_ONLY = false, bool SAVE = false, bool PRE = false, bool TAN = false>
+// VIEW: the colour head takes the view direction (viewdir[n][stride], handed in where the rays-mode kernels take `rays`):
+// its Fourier panel is computed like the position's and multiplied in front of the feature in the dir_encoding tiles.
+template <int MODE, bool DMA, bool SIGMA_ONLY = false, bool SAVE = false, bool PRE = false, bool TAN = false, bool VIEW = false>
 struct Mlp {
+    static_assert(!VIEW || (!SIGMA_ONLY && !SAVE && !PRE && !TAN), "the fused view-dependent head: inference, full network");
     using C = Cfg<MODE>;
     using Frag = typename C::Frag;
     static constexpr int NT = C::NT, EPF = C::EPF, HF = C::HF, EF = C::EF, DF = C::DF, WAVES = C::WAVES, TPC = C::TPC;
@@ -323,7 +328,7 @@ struct Mlp {
         // stream never drains between tiles.  Nothing may be in flight into LDS when the workgroup ends.
         if (c + 2 < NCHUNK || more) {
             if (c + 2 == NCHUNK) gnext = gbase;
-            const int nf = chunk_frags<C>((c + 2) % NCHUNK);
+            const int nf = chunk_frags<C, VIEW>((c + 2) % NCHUNK);
             if constexpr (DMA) stage_chunk<DMA, WAVES>(gnext, lds_base, slot_stage, nf, wave, lane);
             else {
 #pragma unroll
@@ -506,11 +511,11 @@ struct Mlp {
     template <int T, int NFE, int NFH, int XF, class Pending>
     __device__ __forceinline__ void tile(const Frag (&E)[NT][EF], const Frag (&X)[NT][XF], const Pending& pending) {
         static_assert((NFE + NFH) % 4 == 0, "fragment groups of 4");
-        static_assert(NFE + NFH == tile_frags<C>(T), "tile schedule mismatch");
+        static_assert(NFE + NFH == tile_frags<C, VIEW>(T), "tile schedule mismatch");
         constexpr int NG = (NFE + NFH) / 4;
         constexpr int PAR = T & 1;
         constexpr int POS = T % TPC;                       // position of this tile inside its chunk
-        constexpr int OFF = (POS == 0) ? 0 : tile_frags<C>(T - 1);      // TPC <= 2
+        constexpr int OFF = (POS == 0) ? 0 : tile_frags<C, VIEW>(T - 1);      // TPC <= 2
         constexpr bool END = (T == LAST_TILE);             // the next tile is tile 0 of the next point tile
         if constexpr (POS == 0) advance<T>();
         const Frag* cur = reinterpret_cast<const Frag*>(lds_base + slot_cur) + OFF * 64 + lane;
@@ -596,6 +601,44 @@ struct Mlp {
         return FragEpi<RELU, YF, (NTILES - 1) * FPT, T0 + NTILES - 1>{acc[(T0 + NTILES - 1) & 1], Y, act_blk, bits_blk, act_off, bits_off, lds_bits, savebits, half};
     }
 
+    // The Fourier panel of a 3-vector as B fragments (slot map in the header comment): the position's, and with VIEW the view
+    // direction's (its weights are zero in the slots of the octaves encoding_dir does not have).
+    __device__ __forceinline__ void encode_panel(const float (&xs)[3], Frag (&dst)[EF]) const {
+        if constexpr (C::IS_BF16) {
+            // bf16 mode: exact sin/cos of the base band, then angle doubling (error doubles per octave:
+            // 2^9 * 1e-7 << bf16's 2^-9) — 6 polynomial evaluations instead of 30 per lane
+            float sn[3], cs[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { sn[d] = sin_or_cos(xs[d], 0); cs[d] = sin_or_cos(xs[d], 1); }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int j = 3 * k + d;
+                    put(dst[j / EPF], j % EPF, half ? cs[d] : sn[d]);
+                    const float s2 = 2.0f * sn[d] * cs[d], c2 = 1.0f - 2.0f * sn[d] * sn[d];
+                    sn[d] = s2; cs[d] = c2;
+                }
+            }
+            put(dst[30 / EPF], 30 % EPF, half ? xs[2] : xs[0]);
+            put(dst[31 / EPF], 31 % EPF, half ? 0.0f : xs[1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                float v;
+                if (j < 30) {
+                    const int k = j / 3, d = j % 3;
+                    v = sin_or_cos(xs[d] * (float)(1 << k), half);
+                } else if (j == 30) {
+                    v = half ? xs[2] : xs[0];
+                } else {
+                    v = half ? 0.0f : xs[1];
+                }
+                put(dst[j / EPF], j % EPF, v);
+            }
+        }
+    }
+
     // the row a lane past the end of the list works on instead (tangent mode: the row of the last quad with its own role)
     static __device__ __forceinline__ int64_t clamp_row(int64_t idx, int64_t n) {
         return idx < n ? idx : (TAN ? n - 4 + (idx & 3) : n - 1);
@@ -630,10 +673,10 @@ struct Mlp {
             reinterpret_cast<uint4*>(lds_bias)[i] = reinterpret_cast<const uint4*>(pack)[i];
         gnext = gbase;
         spend_nf = 0; spend_slot = 0;
-        stage_chunk<DMA, WAVES>(gnext, lds_base, slot_cur, chunk_frags<C>(0), wave, lane);
-        gnext += chunk_frags<C>(0) * FRAG_BYTES;
-        stage_chunk<DMA, WAVES>(gnext, lds_base, slot_nxt, chunk_frags<C>(1), wave, lane);
-        gnext += chunk_frags<C>(1) * FRAG_BYTES;
+        stage_chunk<DMA, WAVES>(gnext, lds_base, slot_cur, chunk_frags<C, VIEW>(0), wave, lane);
+        gnext += chunk_frags<C, VIEW>(0) * FRAG_BYTES;
+        stage_chunk<DMA, WAVES>(gnext, lds_base, slot_nxt, chunk_frags<C, VIEW>(1), wave, lane);
+        gnext += chunk_frags<C, VIEW>(1) * FRAG_BYTES;
 
         // Persistent workgroup: point tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The weight ring, the bias table,
         // w0 and bias_c carry over from one tile to the next.
@@ -649,7 +692,7 @@ struct Mlp {
                     dst[n] = pts[id];
                     dst[n].w = __int_as_float(id);
 #ifndef ANR_ABL_NO_RAYS
-                } else if (rays) {
+                } else if (!VIEW && rays) {
                     // no warp (use_unpose=False): the sample point is generated here, x = o + z d with the product and
                     // the sum rounded separately like anr_points_from_rays; `pts` is then the depth array z[n]
                     // K < 0: no depth array either — `pts` is the step table s[|K|] of the deterministic stratified
@@ -743,38 +786,8 @@ struct Mlp {
                     }
                     put(E[n][j / EPF], j % EPF, v);
                 }
-            } else if constexpr (C::IS_BF16) {
-                // bf16 mode: exact sin/cos of the base band, then angle doubling (error doubles per octave:
-                // 2^9 * 1e-7 << bf16's 2^-9) — 6 polynomial evaluations instead of 30 per lane
-                float sn[3], cs[3];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) { sn[d] = sin_or_cos(xs[d], 0); cs[d] = sin_or_cos(xs[d], 1); }
-#pragma unroll
-                for (int k = 0; k < 10; ++k) {
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        const int j = 3 * k + d;
-                        put(E[n][j / EPF], j % EPF, half ? cs[d] : sn[d]);
-                        const float s2 = 2.0f * sn[d] * cs[d], c2 = 1.0f - 2.0f * sn[d] * sn[d];
-                        sn[d] = s2; cs[d] = c2;
-                    }
-                }
-                put(E[n][30 / EPF], 30 % EPF, half ? xs[2] : xs[0]);
-                put(E[n][31 / EPF], 31 % EPF, half ? 0.0f : xs[1]);
             } else {
-#pragma unroll
-                for (int j = 0; j < 32; ++j) {
-                    float v;
-                    if (j < 30) {
-                        const int k = j / 3, d = j % 3;
-                        v = sin_or_cos(xs[d] * (float)(1 << k), half);
-                    } else if (j == 30) {
-                        v = half ? xs[2] : xs[0];
-                    } else {
-                        v = half ? 0.0f : xs[1];
-                    }
-                    put(E[n][j / EPF], j % EPF, v);
-                }
+                encode_panel(xs, E[n]);
             }
         }
 
@@ -827,7 +840,22 @@ struct Mlp {
             layer<65, 8, 0, HF, false, HF, HF>(E, B, A, SigmaEpi{acc[64 & 1], sigma});
             // dir_encoding: A -> G (256 -> 128, relu); rgb: G -> 3, sigmoid
             Frag G[NT][DF];
-            layer<73, 4, 0, HF, true, HF, DF>(E, A, G, last_of<65, 8, false>(A));
+            if constexpr (VIEW) {
+                // [feature, encoding_dir(viewdir)] -> 128: the direction's panel in front, like the skip layer's (the pack puts
+                // dir_encoding's last columns there).  Computed here, not at the top: 16 registers live for four tiles only.
+                Frag Ed[NT][EF];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int64_t idx = wave_base + n * 32 + (lane & 31);
+                    const int64_t row = index ? (int64_t)__float_as_int(valid[n]) : clamp_row(idx, n_pts);
+                    const float* vd = rays + row * ray_stride;
+                    const float dv[3] = {vd[0], vd[1], vd[2]};
+                    encode_panel(dv, Ed[n]);
+                }
+                layer<73, 4, EF, HF, true, HF, DF>(Ed, A, G, last_of<65, 8, false>(A));
+            } else {
+                layer<73, 4, 0, HF, true, HF, DF>(E, A, G, last_of<65, 8, false>(A));
+            }
             tile<77, 0, DF, DF>(E, G, last_of<73, 4, true>(G));
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -850,7 +878,7 @@ struct Mlp {
     }
 };
 
-template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE, bool PRE = false, bool TAN = false>
+template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE, bool PRE = false, bool TAN = false, bool VIEW = false>
 __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void mlp_kernel(const char* __restrict__ pack,
                                                              const float4* __restrict__ pts, int64_t n_pts,
                                                              void* __restrict__ out, float* __restrict__ act,
@@ -858,17 +886,17 @@ __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void m
                                                              const int32_t* __restrict__ count,
                                                              const float* __restrict__ rays, int ray_stride, int K) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    Mlp<MODE, DMA, SIGMA_ONLY, SAVE, PRE, TAN> m;
+    Mlp<MODE, DMA, SIGMA_ONLY, SAVE, PRE, TAN, VIEW> m;
     m.run(pack, pts, n_pts, out, act, lds, index, count, rays, ray_stride, K);
 }
 
-template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE, bool PRE = false, bool TAN = false>
+template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE, bool PRE = false, bool TAN = false, bool VIEW = false>
 int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStream_t st, float* act,
                const int32_t* index = nullptr, const int32_t* count = nullptr, const float* rays = nullptr,
                int ray_stride = 0, int K = 1) {
     using C = Cfg<MODE>;
     const int lds = BIAS_BYTES + 3 * slot_bytes<C>() + (SAVE ? C::NT * C::WAVES * 64 * 16 : 0);     // + the sign-bit slots
-    auto kern = mlp_kernel<MODE, DMA, SIGMA_ONLY, SAVE, PRE, TAN>;
+    auto kern = mlp_kernel<MODE, DMA, SIGMA_ONLY, SAVE, PRE, TAN, VIEW>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail((int)e, "anr_mlp_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
     const int pts_per_wg = C::WAVES * C::NT * 32;

@@ -77,7 +77,12 @@ class NeRF(nn.Module):
         """The whole network in the fused kernel (every shipped config); use_view=True runs its colour head outside."""
         return self._trunk_supported() and not self.use_view
 
-    def weight_pack(self, mode: Optional[str] = None):
+    def _view_fused(self):
+        """the view-dependent colour head inside the fused kernel: [feature, Embedding(viewdir)] -> 128 -> 3 and nothing else
+        in the head's input (no normal input, no appearance code)"""
+        return self._trunk_supported() and self.use_view and self.in_channels_dir == 3 + 6 * self.freqs_dir and self.freqs_dir <= 10
+
+    def weight_pack(self, mode: Optional[str] = None, view: bool = False):
         if not self._trunk_supported():
             raise NotImplementedError(
                 "HIP MLP covers D=8, W=256, freqs_xyz=10, skips=[4], no normal input, no latent codes (configs/**/*.yaml)")
@@ -86,13 +91,17 @@ class NeRF(nn.Module):
         params = {k: v for k, v in self.named_parameters()}
         # (the generation: an optimiser step that does not bump the version counters — torch's fused Adam — still repacks)
         key = (mode_id, weights_generation(params["xyz_encoding_1.0.weight"]), tuple((p.data_ptr(), p._version) for p in params.values()))
-        hit = self._pack_cache.get(mode_id)
+        slot = (mode_id, view)
+        hit = self._pack_cache.get(slot)
         if hit is None or hit[0] != key:
-            if self.use_view:       # the kernel's own colour head is not used then: give it the 256 feature columns
-                params = dict(params)
-                params["dir_encoding.0.weight"] = params["dir_encoding.0.weight"][:, :self.W].contiguous()
-            hit = (key, ops.mlp_pack(params, mode_id))
-            self._pack_cache[mode_id] = hit
+            if view:                # the whole network, view-dependent head included (inference)
+                hit = (key, ops.mlp_pack(params, mode_id, view_channels=self.in_channels_dir))
+            else:
+                if self.use_view:   # the kernel's own colour head is not used then: give it the 256 feature columns
+                    params = dict(params)
+                    params["dir_encoding.0.weight"] = params["dir_encoding.0.weight"][:, :self.W].contiguous()
+                hit = (key, ops.mlp_pack(params, mode_id))
+            self._pack_cache[slot] = hit
         return hit[1], mode_id
 
     def _training(self, pts=None):
@@ -117,10 +126,14 @@ class NeRF(nn.Module):
             return torch.cat(sig), torch.cat(feat)
 
     def eval_points_view(self, pts: torch.Tensor, viewdir: torch.Tensor, mode: Optional[str] = None) -> torch.Tensor:
-        """use_view=True (the class default of the reference, no shipped config): trunk, sigma and the 256-wide feature in
-        the fused kernels, the view-dependent colour head (models/nerf.py:141-153: [feature, encoding_dir(viewdir)] -> 128 ->
-        3) as two library GEMMs — under autograd too: the head is ordinary framework ops, its input gradient goes back
-        into the fused backward (sigma_and_feature).  -> [n,4] = (r,g,b,sigma)."""
+        """use_view=True (the class default of the reference, no shipped config).  Inference: the whole network — trunk, sigma,
+        feature and the view-dependent colour head (models/nerf.py:141-153: [feature, encoding_dir(viewdir)] -> 128 -> 3) — in
+        the fused kernel (anr_mlp_forward_view).  Under autograd: trunk, sigma and the feature in the fused kernels, the head as
+        framework ops whose input gradient goes back into the fused backward (sigma_and_feature).  -> [n,4] = (r,g,b,sigma)."""
+        if not self._training(pts) and self._view_fused() and pts.is_cuda:
+            # inference: the whole network in the fused kernel (anr_mlp_forward_view), the direction's Fourier panel in registers
+            pack, mode_id = self.weight_pack(mode, view=True)
+            return ops.mlp_forward_view(pack, mode_id, pts, viewdir.reshape(-1, 3).float().contiguous())
         sig, feat = self.sigma_and_feature(pts, mode)
         with torch.set_grad_enabled(self._training(pts)):
             x = torch.cat([feat, self.encoding_dir(viewdir.reshape(-1, 3).float())], -1)

@@ -355,9 +355,10 @@ def points_from_rays(rays: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     return pts
 
 
-def mlp_pack(params: dict, mode: int, backward: bool = False) -> torch.Tensor:
+def mlp_pack(params: dict, mode: int, backward: bool = False, view_channels: int = 0) -> torch.Tensor:
     """Pack the 11 weight/bias tensors (reference state-dict keys, PyTorch [out,in] layout) for anr_mlp_forward, or —
-    `backward` — their transposes for anr_mlp_backward."""
+    `backward` — their transposes for anr_mlp_backward.  view_channels = 3 + 6 freqs_dir: the pack of mlp_forward_view
+    (use_view=True: dir_encoding.0.weight is [128, 256 + view_channels])."""
     lib = _lib.load()
     keep = []
 
@@ -377,8 +378,14 @@ def mlp_pack(params: dict, mode: int, backward: bool = False) -> torch.Tensor:
     for i, shp in enumerate(shapes):
         if tuple(params[f"xyz_encoding_{i+1}.0.weight"].shape) != shp:
             raise ValueError(f"xyz_encoding_{i+1}.0.weight: expected {shp}")
-    if tuple(params["dir_encoding.0.weight"].shape) != (128, 256) or tuple(params["rgb.0.weight"].shape) != (3, 128):
-        raise ValueError("head shapes must be dir_encoding [128,256], rgb [3,128] (use_view=False, no latent codes)")
+    if tuple(params["dir_encoding.0.weight"].shape) != (128, 256 + view_channels) or tuple(params["rgb.0.weight"].shape) != (3, 128):
+        raise ValueError(f"head shapes must be dir_encoding [128,{256 + view_channels}], rgb [3,128] (no latent codes)")
+    if view_channels:
+        if backward:
+            raise ValueError("the view-dependent head is fused in inference only")
+        pack = torch.empty(lib.anr_mlp_pack_bytes((mode & 0xff) | _lib.ANR_MLP_FLAG_VIEW), dtype=torch.uint8, device=keep[0].device)
+        _lib.check(lib.anr_mlp_pack_view(C.byref(st), mode & 0xff, view_channels, _ptr(pack), _stream(pack)), "anr_mlp_pack_view")
+        return pack
     if backward:
         pack = torch.empty(lib.anr_mlp_bwd_pack_bytes(mode & 0xff), dtype=torch.uint8, device=keep[0].device)
         _lib.check(lib.anr_mlp_bwd_pack(C.byref(st), mode & 0xff, _ptr(pack), _stream(pack)), "anr_mlp_bwd_pack")
@@ -570,6 +577,25 @@ def mlp_forward(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bo
         return out
     with _timed("mlp_forward", n):
         _lib.check(lib.anr_mlp_forward(_ptr(pack), mode, _ptr(pts), n, _ptr(out), _stream(out)), "anr_mlp_forward")
+    return out
+
+
+def mlp_forward_view(pack: torch.Tensor, mode: int, pts: torch.Tensor, viewdir: torch.Tensor, only_valid: bool = False) -> torch.Tensor:
+    """use_view=True, inference: out[n,4] = (r,g,b,sigma) of pts[n,4] = (x,y,z,valid) seen along viewdir[n,3], the whole
+    network — view-dependent colour head included — in the fused kernel (pack from mlp_pack(view_channels=...)).
+    only_valid: as mlp_forward."""
+    lib = _lib.load()
+    pts, viewdir = _dev(pts, "pts"), _dev(viewdir, "viewdir")
+    n = pts.numel() // 4
+    if viewdir.numel() != 3 * n:
+        raise ValueError("one view direction per point")
+    out = torch.empty(n, 4, dtype=torch.float32, device=pts.device)
+    index = count = None
+    if only_valid:
+        index, count = compact_valid(pts, fill=out)
+    with _timed("mlp_forward", n if count is None else count):
+        _lib.check(lib.anr_mlp_forward_view(_ptr(pack), mode & 0xff, _ptr(pts), _ptr(viewdir), 3, _ptr(index), _ptr(count), n, _ptr(out),
+                                            _stream(out)), "anr_mlp_forward_view")
     return out
 
 

@@ -56,6 +56,8 @@ extern "C" {
 /* anr_mlp_wgrad: grads_out += (gradients accumulate over several calls, as autograd's .grad does; tensors a
  * sigma-only call does not produce are left alone instead of zero-filled). */
 #define ANR_MLP_FLAG_ACCUMULATE 0x1000
+/* anr_mlp_pack_bytes: the pack of a network with the view-dependent colour head fused (anr_mlp_pack_view / anr_mlp_forward_view) */
+#define ANR_MLP_FLAG_VIEW 0x2000
 
 int         anr_version(void);
 const char* anr_last_error(void);
@@ -211,6 +213,17 @@ typedef struct anr_mlp_params {
 } anr_mlp_params;
 
 int anr_mlp_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream);
+/* use_view=True (the reference's class default, models/nerf.py:60-153; no shipped config selects it): the colour head reads
+ * [xyz_encoding_final (256), Embedding(viewdir) (dir_channels = 3 + 6 freqs_dir)] -> 128 -> 3.  anr_mlp_pack_view takes
+ * p->w_dir as [128][256 + dir_channels] (pack_out: anr_mlp_pack_bytes(mode | ANR_MLP_FLAG_VIEW) bytes) and
+ * anr_mlp_forward_view evaluates the whole network in the fused kernel: the direction's Fourier panel is computed in registers
+ * like the position's and enters the four dir_encoding tiles in front of the feature, as the skip layer takes the position's.
+ * viewdir[n * view_stride] (xyz first): one direction per point of pts (per listed point pts[index[i]] reads viewdir[index[i]]).
+ * index / count as in anr_mlp_forward_indexed (NULL: all n points).  Inference; under autograd the head runs as framework ops
+ * on the kernel's feature (anr_mlp_backward_feature). */
+int anr_mlp_pack_view(const anr_mlp_params* p, int mode, int dir_channels, void* pack_out, void* stream);
+int anr_mlp_forward_view(const void* pack, int mode, const float* pts, const float* viewdir, int view_stride,
+                         const int32_t* index, const int32_t* count, int64_t n, float* out, void* stream);
 
 int anr_mlp_forward(const void* pack, int mode, const float* pts, int64_t n,
                     float* out, void* stream);

@@ -780,8 +780,10 @@ def test_mlp_from_rays_equals_points_then_mlp(dev, smpl_table):
 
 
 def test_view_dependent_colour_head(dev, smpl_table):
-    """NeRF(use_view=True): trunk / sigma / feature from the fused kernel + the colour head as library GEMMs, against the
-    reference's output (tests/golden/mlp_view.npz); get_sigma(only_sigma=False) returns the 256-wide feature."""
+    """NeRF(use_view=True) against the reference's output (tests/golden/mlp_view.npz).  Inference runs the whole network, the
+    view-dependent colour head included, in the fused kernel (anr_mlp_forward_view); the path autograd takes — trunk / sigma /
+    feature from the fused kernel + the head as library GEMMs — must give the same colours; get_sigma(only_sigma=False)
+    returns the 256-wide feature."""
     import anim_nerf_amd as ana
     g = golden("mlp_view")
     torch.manual_seed(int(g["seed"]))
@@ -796,9 +798,29 @@ def test_view_dependent_colour_head(dev, smpl_table):
         assert torch.equal(s2, sig)
         f_ref = torch.from_numpy(g["feature"])
         assert ((feat.cpu() - f_ref).abs() <= RTOL * f_ref.abs() + 2e-6).all()
+        # the fused head against the head as framework ops on the kernel's feature (what training differentiates)
+        pts = torch.cat([xyz.reshape(-1, 3), torch.ones_like(xyz.reshape(-1, 3)[:, :1])], -1)
+        x = torch.cat([feat.reshape(-1, 256), net.encoding_dir(vd.reshape(-1, 3))], -1)
+        rgb_ops = net.rgb(net.dir_encoding(x))
+        assert (rgb.reshape(-1, 3) - rgb_ops).abs().max() < 2e-6
+        # a direction per listed point: the compacted evaluation reads viewdir[index[i]]
+        pts[::3, 3] = 0.0
+        pack, mode_id = net.weight_pack("f32", view=True)
+        sparse = ana.ops.mlp_forward_view(pack, mode_id, pts, vd.reshape(-1, 3).contiguous(), only_valid=True)
+        keep = pts[:, 3] >= 1
+        assert torch.equal(sparse[keep][:, :3], rgb.reshape(-1, 3)[keep]) and (sparse[~keep][:, 3] == -1e5).all()
         net.mlp_mode = "bf16"
         rgb16, _ = net(xyz, vd)
         assert (rgb16 - rgb).abs().max() < 2e-2
+    # other octave counts of the direction encoding (the panel has room for 10)
+    for freqs_dir in (0, 1, 10):
+        torch.manual_seed(3)
+        other = ana.NeRF(freqs_xyz=10, freqs_dir=freqs_dir, use_view=True, mlp_mode="f32").to(dev)
+        with torch.no_grad():
+            got, sg = other(xyz, vd)
+            _, ft = other.get_sigma(xyz)
+            want = other.rgb(other.dir_encoding(torch.cat([ft.reshape(-1, 256), other.encoding_dir(vd.reshape(-1, 3))], -1)))
+        assert (got.reshape(-1, 3) - want).abs().max() < 2e-6, freqs_dir
     with pytest.raises(NotImplementedError):
         net.eval_points(torch.cat([xyz[0], torch.ones_like(xyz[0, :, :1])], -1))
 
