@@ -153,6 +153,13 @@ __device__ __forceinline__ float box_d2(const float* bx, float px, float py, flo
     return dx * dx + dy * dy + dz * dz;
 }
 
+// squared distance, ONE sequence of roundings wherever it is computed (the searches must agree bit for bit):
+// fma(dz, dz, fma(dx, dx, dy * dy)) — what hipcc's contraction made of dx*dx + dy*dy + dz*dz in scan_cluster, spelled out
+__device__ __forceinline__ float dist2(float px, float py, float pz, float vx, float vy, float vz) {
+    const float dx = __fsub_rn(px, vx), dy = __fsub_rn(py, vy), dz = __fsub_rn(pz, vz);
+    return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
+}
+
 __device__ __forceinline__ void scan_cluster(const float* lds, int Vp, int c, float px, float py, float pz,
                                              Best4& best) {
     const float4* X = reinterpret_cast<const float4*>(lds + c * CS);
@@ -169,7 +176,7 @@ __device__ __forceinline__ void scan_cluster(const float* lds, int Vp, int c, fl
         for (int t = 0; t < 2; ++t) {
             const f2 ax = t ? f2{vx.z, vx.w} : f2{vx.x, vx.y}, ay = t ? f2{vy.z, vy.w} : f2{vy.x, vy.y}, az = t ? f2{vz.z, vz.w} : f2{vz.x, vz.y};
             const f2 dx = P[0] - ax, dy = P[1] - ay, dz = P[2] - az;
-            const f2 r = dx * dx + dy * dy + dz * dz;
+            const f2 r = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));      // == dist2()
             d2[2 * t] = r.x; d2[2 * t + 1] = r.y;
         }
         float m = fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3]));
@@ -254,7 +261,23 @@ __device__ __forceinline__ void search(const float* lds, const IndexDims& d, flo
 __device__ __forceinline__ void stage_index(const float* __restrict__ index, int n_floats, float* lds) {
     const float4* src = reinterpret_cast<const float4*>(index);
     float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = threadIdx.x; i < n_floats / 4; i += blockDim.x) dst[i] = src[i];
+    // seven loads in flight per thread, then seven LDS stores (one at a time, each load waited for before the next is
+    // issued, the 114 KB took 28 round trips to L2 per workgroup: ~10 % of a small-batch search)
+    constexpr int U = 7;
+    const int n4 = n_floats / 4, step = (int)blockDim.x;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += U * step) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * step;
+            v[u] = src[i < n4 ? i : n4 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * step;
+            if (i < n4) dst[i] = v[u];
+        }
+    }
     __syncthreads();
 }
 
@@ -943,6 +966,242 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// SMALL BATCHES (training: 1,024 rays per body): EIGHT LANES PER SAMPLE.
+// A lane per sample makes a wavefront walk the union of what its samples need, and the near samples of a training batch are
+// ~10^2 times sparser than a frame's: 32 consecutive list entries span a metre of a ray and want different parts of the body
+// (0.68 ms per call for 4 x 10^5 near samples, most of the time spent in clusters that one or two lanes asked for).  The
+// tree has fan-out 8 at every level, so here the 8 lanes of a GROUP take the 8 children of one node — 8 box tests or 8 vertex
+// distances per instruction — and the 8 groups of a wavefront each walk their OWN sample's tree: every step a group either
+// scans the nearest pending cluster, or opens the nearest pending super-cluster / top (nearest first: the bound is tight
+// after the first cluster).  What is pending lives in the lanes (the box distance a lane computed for its child, +inf once
+// taken); the choice is a DPP minimum over the group of (distance bits | lane), no LDS traffic, no divergence between groups
+// other than in the number of steps.  The 4 best are kept REPLICATED in the group's lanes: candidates of a cluster are
+// inserted in ascending order, one per round, while any still beats the 4th (4 rounds for the first cluster, ~0 later).
+// Groups are persistent: a finished group takes the next sample from a small pool the wavefront prefetched (index and
+// point), and the blend of a finished sample is queued in LDS until 64 of them can run with every lane busy.
+// Same results as the lane-per-sample search bit for bit: dist2(), best_insert()'s (distance, slot) order, and the same
+// bounded-then-unbounded rule for samples with 1-3 vertices inside the validity radius.
+constexpr unsigned PICK_NONE = 0xffffffffu;
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+// minimum over the 8 lanes of a group (lanes 8g..8g+7), in every lane of the group
+__device__ __forceinline__ unsigned group8_min(unsigned v) {
+    // three v_min_u32 with the DPP modifier on one operand (through the builtin hipcc emits mov + mov_dpp + min per step);
+    // s_nop 1: the two wait states between a VALU write and a DPP read of the same register
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+                 : "+v"(v));
+    return v;
+}
+// sort key of a pending child: its (non-negative) box distance with the low bits replaced by who holds it
+__device__ __forceinline__ unsigned pick_key(float dist, float bound, unsigned tag, unsigned tag_mask) {
+    return dist <= bound ? ((__float_as_uint(dist) & ~tag_mask) | tag) : PICK_NONE;
+}
+constexpr int GPOOL = 16;                      // list entries a wavefront takes per trip to the cursor (2 per group): a training
+                                               // batch has ~100 near samples per wavefront, and a run of 64 consecutive ones is
+                                               // either all empty space or all torso — with 64 per trip the wavefronts were
+                                               // resident 28 % of the kernel's time on average, waiting for the unlucky ones
+constexpr int GQ_ENTRIES = 64;                 // blend queue per wavefront: {sample, slots 0|1, slots 2|3}
+constexpr int GQ_BYTES = GQ_ENTRIES * 12;
+
+__global__ __launch_bounds__(WARP_THREADS) void warp_search_groups_kernel(
+    const float* __restrict__ index, IndexDims d, const float* __restrict__ ober2cano, const float* __restrict__ lbs_w,
+    int J, int64_t N, float thr, float4* __restrict__ pts_out, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w,
+    const int32_t* __restrict__ list, const int32_t* __restrict__ count, int32_t* __restrict__ cursor,
+    uint8_t* __restrict__ valid_mask) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int body_open;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 7, gbase = lane & 56;
+    // A workgroup starts on its own body and, when that list is exhausted, moves on to the other bodies' (their index
+    // re-staged: 114 KB, a few microseconds): the bodies of a batch do not have the same number of near samples, and a
+    // static share of the chip per body waits for the busiest one.
+    for (int hop = 0; hop < (int)gridDim.y; ++hop) {
+    const int b = ((int)blockIdx.y + hop) % (int)gridDim.y;
+    const int cnt = count[b];
+    if (hop == 0) {
+        if ((int)blockIdx.x * (WARP_THREADS / 64) * 8 >= cnt) continue;  // not even one sample per group left
+    } else {
+        __syncthreads();                                                 // every wavefront is done with the index in LDS
+        if (threadIdx.x == 0) body_open = __hip_atomic_load(cursor + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt;
+        __syncthreads();
+        if (!body_open) continue;
+    }
+    const float* my_index = index + (int64_t)b * d.total_floats();
+    const int32_t* order = reinterpret_cast<const int32_t*>(my_index + d.order_off());
+    const float* O2C = ober2cano + (int64_t)b * d.V * 16;
+    const int32_t* my_list = list + (int64_t)b * N;
+    stage_index(my_index, d.lds_floats(), lds);
+    const float* boxes = lds + d.box_off();
+    const float* sboxes = lds + d.sbox_off();
+    const float* tboxes = lds + d.tbox_off();
+    int32_t* queue = reinterpret_cast<int32_t*>(lds + d.lds_floats()) + wave * (GQ_BYTES / 4);
+    const float INF = __builtin_inff();
+    const float cap2 = thr * thr * 1.0002f;
+
+    // blend the queued samples, one per lane
+    int q_n = 0;
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < q_n) {
+            const int32_t smp = queue[lane];
+            const unsigned s01 = (unsigned)queue[GQ_ENTRIES + lane], s23 = (unsigned)queue[2 * GQ_ENTRIES + lane];
+            const int64_t o = (int64_t)b * N + smp;
+            const float4 p = pts_out[o];
+            Best4 r;
+            r.i[0] = (int)(s01 & 0xffffu); r.i[1] = (int)(s01 >> 16); r.i[2] = (int)(s23 & 0xffffu); r.i[3] = (int)(s23 >> 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r.d[k] = dist2(p.x, p.y, p.z, lds[r.i[k]], lds[d.Vp + r.i[k]], lds[2 * d.Vp + r.i[k]]);
+            const bool ok = blend_and_store(r, order, lbs_w, J, O2C, thr, p.x, p.y, p.z, o, pts_out, nullptr, nullptr, nullptr,
+                                            nbr_idx, nbr_w);
+            if (valid_mask != nullptr && ok) valid_mask[o] = 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        q_n = 0;
+    };
+
+    // the pool: GPOOL list entries and their points, one per lane
+    int pool_smp = 0, pool_n = 0, pool_next = 0;
+    float pool_x = 0.f, pool_y = 0.f, pool_z = 0.f;
+    bool list_done = false;
+
+    // group state (the same in the 8 lanes of a group, except the pending distances)
+    bool idle = true;                          // no sample
+    bool second = false;                       // the unbounded repeat
+    int smp = 0, s_base = 0, c_base = 0;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    float td[4] = {INF, INF, INF, INF}, sd = INF, cd = INF;
+    Best4 best;
+    best_init(best, cap2);
+
+    auto open_tops = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = j + 8 * r;
+            td[r] = t < d.NT ? box_d2(tboxes + min(t, d.NT - 1) * 8, px, py, pz) : INF;
+        }
+        sd = INF; cd = INF;
+    };
+
+    for (;;) {
+        // ---- hand samples to the idle groups (wave-uniform control flow: every lane takes part in the permutes)
+        unsigned long long idle_groups = __ballot(idle && j == 0);
+        while (idle_groups) {
+            if (pool_next >= pool_n) {
+                if (list_done) break;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(cursor + b, GPOOL);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= cnt) { list_done = true; break; }
+                pool_n = min(GPOOL, cnt - base);
+                pool_next = 0;
+                if (lane < pool_n) {
+                    pool_smp = my_list[base + lane];
+                    const float4 p = pts_out[(int64_t)b * N + pool_smp];
+                    pool_x = p.x; pool_y = p.y; pool_z = p.z;
+                }
+            }
+            const int rank = __popcll(idle_groups & ((1ull << gbase) - 1ull));
+            const int src = pool_next + rank;
+            const bool take = idle && src < pool_n;
+            const int addr = min(src, 63) * 4;
+            const int t_smp = __builtin_amdgcn_ds_bpermute(addr, pool_smp);
+            const float t_x = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(pool_x)));
+            const float t_y = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(pool_y)));
+            const float t_z = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(pool_z)));
+            pool_next = min(pool_n, pool_next + __popcll(idle_groups));
+            if (take) {
+                smp = t_smp; px = t_x; py = t_y; pz = t_z;
+                idle = false; second = false;
+                best_init(best, cap2);
+                open_tops();
+            }
+            idle_groups = __ballot(idle && j == 0);
+        }
+        if (!__any(!idle)) break;
+
+        // ---- one step of every group's traversal
+        bool done = idle;
+        if (!idle) {
+            unsigned cm = group8_min(pick_key(cd, best.d[3], j, 7));
+            if (cm == PICK_NONE) {                               // no cluster pending: open the nearest pending super-cluster
+                unsigned sm = group8_min(pick_key(sd, best.d[3], j, 7));
+                if (sm == PICK_NONE) {                           // ... after opening the nearest pending top
+                    unsigned tk = PICK_NONE;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tk = min(tk, pick_key(td[r], best.d[3], j + 8 * r, 31));
+                    const unsigned tm = group8_min(tk);
+                    if (tm == PICK_NONE) {
+                        done = true;
+                    } else {
+                        const int t = (int)(tm & 31u);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (t == j + 8 * r) td[r] = INF;
+                        s_base = t * TC;
+                        const int q = s_base + j;
+                        sd = q < d.NS ? box_d2(sboxes + min(q, d.NS - 1) * 8, px, py, pz) : INF;
+                        sm = group8_min(pick_key(sd, best.d[3], j, 7));
+                    }
+                }
+                if (sm != PICK_NONE) {
+                    const int k = (int)(sm & 7u);
+                    if (j == k) sd = INF;
+                    c_base = (s_base + k) * SC;
+                    const int c = c_base + j;
+                    cd = c < d.NC ? box_d2(boxes + min(c, d.NC - 1) * 8, px, py, pz) : INF;
+                    cm = group8_min(pick_key(cd, best.d[3], j, 7));
+                }
+            }
+            if (cm != PICK_NONE) {                               // scan the nearest pending cluster: a vertex per lane
+                const int k = (int)(cm & 7u);
+                if (j == k) cd = INF;
+                const int slot0 = (c_base + k) * CS;
+                const float d2 = dist2(px, py, pz, lds[slot0 + j], lds[d.Vp + slot0 + j], lds[2 * d.Vp + slot0 + j]);
+                bool pend = d2 <= best.d[3];                     // (<=: a tie with the current 4th may carry a lower slot)
+                while (__any(pend)) {
+                    const unsigned m = group8_min(pend ? __float_as_uint(d2) : PICK_NONE);
+                    const unsigned long long bal = __ballot(pend && __float_as_uint(d2) == m);
+                    const unsigned mine = (unsigned)(bal >> gbase) & 0xffu;
+                    if (mine) {
+                        const int k2 = __builtin_ctz(mine);
+                        best_insert(best, __uint_as_float(m), slot0 + k2);
+                        if (j == k2) pend = false;
+                    }
+                    pend = pend && d2 <= best.d[3];
+                }
+            }
+        }
+
+        // ---- finished groups: repeat unbounded (1-3 vertices inside the radius), or queue the blend; then idle
+        if (__any(done && !idle)) {
+            const bool fin = done && !idle;
+            const bool partial = fin && !second && best.i[0] >= 0 && best.i[3] < 0;
+            if (partial) {
+                second = true;
+                best_init(best);
+                open_tops();
+            }
+            const bool live = fin && !partial && best.i[0] >= 0;
+            const unsigned long long live_groups = __ballot(live && j == 0);
+            if (q_n + __popcll(live_groups) > GQ_ENTRIES) flush();
+            if (live && j == 0) {
+                const int at = q_n + __popcll(live_groups & ((1ull << gbase) - 1ull));
+                queue[at] = smp;
+                queue[GQ_ENTRIES + at] = (int32_t)((unsigned)best.i[0] | ((unsigned)best.i[1] << 16));
+                queue[2 * GQ_ENTRIES + at] = (int32_t)((unsigned)best.i[2] | ((unsigned)best.i[3] << 16));
+            }
+            q_n += __popcll(live_groups);
+            if (fin && !partial) idle = true;
+        }
+    }
+    flush();
+    }
+}
+
 // lean mode: validity bytes -> list of the valid samples' flat positions for anr_mlp_forward_indexed, in sample order
 // (the MLP's gather of points and scatter of results then walk memory the way the rays were laid out); 4 bytes per thread
 __global__ __launch_bounds__(WARP_THREADS) void warp_valid_list_kernel(const uint8_t* __restrict__ mask, int64_t n,
@@ -1176,12 +1435,21 @@ extern "C" int anr_warp_points_lean(const float* xyz, int xyz_stride, const floa
         int64_t gx = (cus + bs - 1) / bs;                                   // one persistent workgroup per CU in total
         if (N < (int64_t)1 << 19 && !getenv("ANR_WARP_CELLS_ALWAYS")) {
             // a small batch per body (training: 1,024 rays): straight to the per-sample search (see warp_search_kernel)
-            if (int rc = allow_big_lds(warp_search_kernel, bytes, "anr_warp_points")) return rc;
             const int64_t max_wg = (N + 64 * (WARP_THREADS / 64) - 1) / (64 * (WARP_THREADS / 64));
             if (gx > max_wg) gx = max_wg;
-            hipLaunchKernelGGL(warp_search_kernel, dim3((unsigned)gx, bs), dim3(WARP_THREADS), bytes, st, index, d, ober2cano,
-                               lbs_weights, J, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                               w.list, w.count, w.cursor, nullptr, valid_mask_out, nullptr, G);
+            const int group_bytes = bytes + (WARP_THREADS / 64) * GQ_BYTES;
+            if (group_bytes <= 160 * 1024 && d.NT <= 32 && !getenv("ANR_WARP_LANE_PER_SAMPLE")) {
+                // eight lanes per sample (warp_search_groups_kernel); the index + the blend queues fit for V <= ~9,000
+                if (int rc = allow_big_lds(warp_search_groups_kernel, group_bytes, "anr_warp_points")) return rc;
+                hipLaunchKernelGGL(warp_search_groups_kernel, dim3((unsigned)gx, bs), dim3(WARP_THREADS), group_bytes, st, index, d,
+                                   ober2cano, lbs_weights, J, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out,
+                                   nbr_w_out, w.list, w.count, w.cursor, valid_mask_out);
+            } else {
+                if (int rc = allow_big_lds(warp_search_kernel, bytes, "anr_warp_points")) return rc;
+                hipLaunchKernelGGL(warp_search_kernel, dim3((unsigned)gx, bs), dim3(WARP_THREADS), bytes, st, index, d, ober2cano,
+                                   lbs_weights, J, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
+                                   w.list, w.count, w.cursor, nullptr, valid_mask_out, nullptr, G);
+            }
             if (int rc = check_launch("anr_warp_points (search)")) return rc;
             if (lean) {
                 e = hipMemsetAsync(valid_count_out, 0, sizeof(int32_t), st);

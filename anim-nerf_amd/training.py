@@ -16,6 +16,7 @@ the normalisation and the MSE.
 """
 from __future__ import annotations
 
+import contextlib
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -324,9 +325,16 @@ class GradientReducer:
 class Trainer:
     """optimizer + schedule + step; `step(batch)` mirrors AnimNeRFSystem.training_step (train.py:324-348)."""
 
-    def __init__(self, anim_nerf, volume_renderer, hp: TrainHParams, body_model_params: Optional[BodyModelParams] = None):
+    def __init__(self, anim_nerf, volume_renderer, hp: TrainHParams, body_model_params: Optional[BodyModelParams] = None,
+                 graph: bool = False):
+        """graph=True: `step_graphed` may capture the whole step (forward, losses, backward, Adam) into ONE HIP graph and
+        replay it — ~190 launches per step leave the host as one (the step holds no device -> host read: row counts stay
+        on the device).  Adam then runs `capturable` (its step counter lives on the device)."""
         self.model, self.renderer, self.hp = anim_nerf, volume_renderer, hp
         self.body_model_params = body_model_params
+        self.graph_enabled = bool(graph)
+        self._graph = None                                    # (signature, CUDAGraph, static inputs, static outputs)
+        self._graph_warm = 0
         for name, p in anim_nerf.named_parameters():          # SMPL member params are unused by the forward
             if name.startswith("body_model."):
                 p.requires_grad_(False)
@@ -337,7 +345,14 @@ class Trainer:
                 groups.append({"params": bp, "lr": hp.lr * 0.5})
         self.params = [p for g in groups for p in g["params"]]
         # (one fused update kernel per parameter group on the GPU instead of seven list kernels)
-        self.optimizer = torch.optim.Adam(groups, eps=1e-8, weight_decay=0, fused=bool(self.params and self.params[0].is_cuda))
+        on_gpu = bool(self.params and self.params[0].is_cuda)
+        if self.graph_enabled and on_gpu:
+            # (capturable: the step counter lives on the device.  The learning rates stay host floats — a capture bakes them in,
+            # and step_graphed captures again when the scheduler has moved them: once per epoch, tens of milliseconds.  Device
+            # -side lr tensors + LambdaLR + the fused kernel crashed hipGraphInstantiate on ROCm 7.2 / torch 2.10.)
+            self.optimizer = torch.optim.Adam(groups, eps=1e-8, weight_decay=0, fused=True, capturable=True)
+        else:
+            self.optimizer = torch.optim.Adam(groups, eps=1e-8, weight_decay=0, fused=on_gpu)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(
             self.optimizer, lambda epoch: (1 - epoch / hp.max_epochs) ** hp.poly_exp)
         # gradient buckets in the order backward completes them: fine network, coarse network, SMPL parameter rows
@@ -357,19 +372,114 @@ class Trainer:
             nets.append(anim_nerf.nerf)
         seen = fine_ids | {id(p) for p in coarse}
         rest = [p for p in self.params if id(p) not in seen]
-        self.reducer = GradientReducer([fine, coarse + rest])
-        if self.params and self.params[0].is_cuda:
-            for net in nets:
-                self.reducer.attach_sink(net)
+        # A capture must never touch the legacy default stream, and autograd synchronises the stream an AccumulateGrad node was
+        # CREATED under with the stream that produces its gradient.  A graphed Trainer therefore owns a stream: the hooks below
+        # (which create those nodes), every eager step, the capture and the replays all run on it, fenced against the caller's
+        # current stream on both sides.
+        self._stream = torch.cuda.Stream(self.params[0].device) if (self.graph_enabled and on_gpu) else None
+        with self._own_stream():
+            self.reducer = GradientReducer([fine, coarse + rest])
+            if on_gpu:
+                for net in nets:
+                    self.reducer.attach_sink(net)
+
+    @contextlib.contextmanager
+    def _own_stream(self):
+        cur = torch.cuda.current_stream(self._stream.device) if self._stream is not None else None
+        if cur is None or cur == self._stream:
+            yield
+            return
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            yield
+        cur.wait_stream(self._stream)
 
     def begin_step(self):
         """Zero the flat gradient buffers and point every p.grad at its slice (instead of optimizer.zero_grad)."""
         self.reducer.prepare()
 
+    # eager steps before a capture: lazy initialisation (library handles, allocator pools, autograd's threads) must not
+    # happen inside a capture
+    GRAPH_WARM_STEPS = 3
+
+    def step_graphed(self, rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points=None, bg_points=None,
+                     perturb=1.0, frame_idx=None):
+        """`step` with the same arguments and results, replayed from a HIP graph once the shapes have been seen
+        GRAPH_WARM_STEPS times (those steps, and every step of a Trainer built without graph=True or of a process group
+        with more than one rank, run eagerly).  Inputs are copied into the graph's own buffers, the loss and the details
+        come back as fresh tensors; random draws (stratified offsets, sigma noise, loss points) advance per replay through
+        the generator state torch registers with the graph."""
+        dist = torch.distributed
+        eager = (not self.graph_enabled or not rays.is_cuda or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1))
+        args = {"rays": rays, "rgbs": rgbs, "alphas": alphas, "bmp": body_model_params, "templ": body_model_params_template,
+                "fg": fg_points, "bg": bg_points, "frame_idx": frame_idx}
+
+        def flat(v, prefix):
+            if isinstance(v, dict):
+                return [x for k in sorted(v) for x in flat(v[k], f"{prefix}.{k}")]
+            return [(prefix, v)] if torch.is_tensor(v) else []
+        leaves = [x for k in sorted(args) for x in flat(args[k], k)]
+        with self._own_stream():
+            return self._step_graphed(args, leaves, perturb, eager)
+
+    def _step_graphed(self, args, leaves, perturb, eager):
+        shapes = (float(perturb), tuple((n, tuple(t.shape), t.dtype) for n, t in leaves))
+        baked = tuple(float(g["lr"]) for g in self.optimizer.param_groups)      # host values a capture freezes
+        sig = (shapes, baked)
+        if not eager and (self._graph is None or self._graph[0] != sig):
+            if self._graph is not None and self._graph[0][0] == shapes:
+                self._capture(sig, args, leaves, perturb)       # the scheduler moved the learning rates: capture again
+            elif self._graph is not None or self._graph_warm < self.GRAPH_WARM_STEPS:
+                # (other shapes — the short last batch of an epoch — are not captured: one graph per Trainer, the step stays
+                # correct through the eager path)
+                self._graph_warm += 1
+                eager = True
+            else:
+                self._capture(sig, args, leaves, perturb)
+        if eager:
+            return self.step(args["rays"], args["rgbs"], args["alphas"], args["bmp"], args["templ"], args["fg"], args["bg"],
+                             perturb=perturb, frame_idx=args["frame_idx"])
+        _, graph, static_leaves, outs = self._graph
+        for (_, src), dst in zip(leaves, static_leaves):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        graph.replay()
+        from .autograd import bump_generation
+        bump_generation(self.params)                          # the packs cached under the old generation belong to the graph
+        loss, details = outs
+        return loss.clone(), {k: (v.clone() if torch.is_tensor(v) else v) for k, v in details.items()}
+
+    def _capture(self, sig, args, leaves, perturb):
+        def rebuild(v, it):
+            if isinstance(v, dict):
+                return {k: rebuild(v[k], it) for k in sorted(v)}
+            return next(it) if torch.is_tensor(v) else v
+        static_leaves = [t.clone() for _, t in leaves]
+        it = iter(static_leaves)
+        st = {k: rebuild(args[k], it) for k in sorted(args)}
+        torch.cuda.synchronize()
+        self._graph = None                                    # (a previous capture's pool goes back to the allocator first)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=self._stream):
+            loss, details = self._step_body(st["rays"], st["rgbs"], st["alphas"], st["bmp"], st["templ"], st["fg"], st["bg"],
+                                            perturb, st["frame_idx"])
+        self._graph = (sig, graph, static_leaves, (loss, details))
+
     def step(self, rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points=None, bg_points=None,
              perturb=1.0, frame_idx=None):
         """`body_model_params` is the dict of the batch, or — with a BodyModelParams table and `frame_idx` — replaced
         by the learnable rows of those frames (train.py:330-331)."""
+        with self._own_stream():
+            loss, details = self._step_body(rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points,
+                                            bg_points, perturb, frame_idx)
+        # torch's fused Adam updates in place WITHOUT bumping the tensors' version counters; every cached weight pack
+        # (training, backward, inference) is keyed by them.  A loop that steps a fused optimiser itself must do the same.
+        from .autograd import bump_generation
+        bump_generation(self.params)
+        return loss, details
+
+    def _step_body(self, rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points, bg_points, perturb,
+                   frame_idx):
         self.begin_step()                                     # grads are views into the (zeroed) flat buffers
         if self.body_model_params is not None and frame_idx is not None:
             body_model_params = self.body_model_params(frame_idx)
@@ -379,10 +489,6 @@ class Trainer:
         loss.backward()                                       # full buckets are all-reduced while this is still running
         self.reducer.finish()
         self.optimizer.step()
-        # torch's fused Adam updates in place WITHOUT bumping the tensors' version counters; every cached weight pack
-        # (training, backward, inference) is keyed by them.  A loop that steps a fused optimiser itself must do the same.
-        from .autograd import bump_generation
-        bump_generation(self.params)
         with torch.no_grad():
             key = "rgbs_fine" if "rgbs_fine" in results else "rgbs"
             details["psnr"] = -10.0 * torch.log10(F.mse_loss(results[key], rgbs))

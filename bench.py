@@ -411,7 +411,10 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False):
     seeded = syn.animated_pose_params(seed=200, bs=114)        # the SAME table on every rank: its gradients are all-reduced
     for name in table.param_names:                            # optim_body_params: True
         table.init_parameters(name, torch.from_numpy(seeded[name]).to(dev), requires_grad=True)
-    trainer = ana.Trainer(model, ana.VolumeRenderer(n_coarse=64, n_fine=32), hp, body_model_params=table)
+    # one rank: the whole step replayed from ONE HIP graph (Trainer.step_graphed; ~190 launches per step otherwise, and the
+    # host, not the GPU, sets the pace on a slow box).  More ranks: eager, the bucketed all-reduce overlapping backward.
+    graphed = world == 1 and dev.type == "cuda" and not os.environ.get("ANR_BENCH_NO_GRAPH")
+    trainer = ana.Trainer(model, ana.VolumeRenderer(n_coarse=64, n_fine=32), hp, body_model_params=table, graph=graphed)
     frame_idx = (torch.arange(F, device=dev) * (114 // F) + rank) % 114      # a rank's own frames, as a distributed sampler deals them
     c2w, focal, cen = syn.pinhole_camera(32, 32)
     rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), 32, 32, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(F, 1, 1, 1)
@@ -424,10 +427,24 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False):
     last = {}
 
     def step():
+        last["loss"], _ = trainer.step_graphed(rays, rgbs, alphas, None, templ, fg, bg, perturb=1.0, frame_idx=frame_idx)
+        return last["loss"]
+
+    def eager_step():
         last["loss"], _ = trainer.step(rays, rgbs, alphas, None, templ, fg, bg, perturb=1.0, frame_idx=frame_idx)
         return last["loss"]
 
+    if graphed:
+        # untimed set-up, like a compilation: GRAPH_WARM_STEPS eager steps, then the capture (which executes nothing)
+        while trainer._graph is None:
+            step()
     elapsed, per_kernel, loss = ctx.timed(step, steps, warmup)
+    eager_elapsed, eager_steps = elapsed, steps
+    if graphed:
+        # a replay launches nothing from Python, so the per-kernel HIP events come from a few EAGER steps of the same batch
+        # right after the timed region (same kernels, same shapes; their host-side pace does not enter any number below)
+        eager_steps = min(steps, 5)
+        eager_elapsed, per_kernel, _ = ctx.timed(eager_step, eager_steps, 0)
     n_rays = F * 1024
     return {
         "metric": "rays/sec, training step (64+32 samples, 256-wide MLP x2, fwd+bwd+Adam)",
@@ -437,12 +454,16 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False):
                                "perturb=1, rgb + alpha + fg/bg + normals losses (reference defaults), pose refinement on (optim_body_params), "
                                "bucketed gradient all-reduce (2 x 2.4 MB, overlapped with backward) + Adam" % F,
                    "mlp_on_valid_samples_only": bool(model.evaluate_valid_only),
-                   "mlp_rows_per_step": per_kernel.get("mlp_forward_save", {"units": 0})["units"] // max(steps, 1),
+                   "mlp_rows_per_step": per_kernel.get("mlp_forward_save", {"units": 0})["units"] // max(eager_steps, 1),
                    "rays_per_step_per_gpu": n_rays, "grad_floats": sum(p.numel() for p in trainer.params),
-                   "kernel_launches_timed_per_step": sum(v["launches"] for v in per_kernel.values()) // max(steps, 1)},
+                   "kernel_launches_timed_per_step": sum(v["launches"] for v in per_kernel.values()) // max(eager_steps, 1),
+                   "step_launch": ("one HIP graph replay per step (captured after %d eager steps, untimed); per-kernel times from "
+                                   "%d eager steps after the timed region, %.2f ms per step there"
+                                   % (trainer.GRAPH_WARM_STEPS, eager_steps, eager_elapsed / eager_steps * 1e3)) if graphed
+                   else "eager: one launch per kernel"},
         "roofline": mlp_roofline(per_kernel, "mlp_forward_save", mode, MLP_FLOP_PER_POINT,
                                  f"mlp_kernel<{mode}, save> (training forward)"),
-        "kernel_time_share": {k: round(v["s"] / elapsed, 4) for k, v in per_kernel.items()},
+        "kernel_time_share": {k: round(v["s"] / eager_steps / (elapsed / steps), 4) for k, v in per_kernel.items()},
         "final_loss": float(loss),
     }
 

@@ -170,6 +170,46 @@ def test_warp_two_pass_equals_one_pass(dev, smpl_table):
     assert torch.equal(one[..., 3], two[..., 3]) and torch.equal(one[one[..., 3] == 1], two[two[..., 3] == 1])
 
 
+@pytest.mark.parametrize("bs,n_rays,K", [(4, 1024, 64), (1, 77, 20), (3, 300, 33)])
+def test_warp_small_batch_group_search_is_bit_identical(dev, smpl_table, bs, n_rays, K, monkeypatch):
+    """A training-shaped batch (random pixels, a few bodies in different poses) goes through warp_search_groups_kernel
+    (eight lanes per sample): on every valid sample the canonical point, the neighbour ids and the blend weights carry the
+    bits of the lane-per-sample search of the same list (ANR_WARP_LANE_PER_SAMPLE) and of the exact search of every
+    sample; valid flags identical everywhere; the lean outputs (validity bytes, list of valid samples) agree too."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    m = seeded_model(smpl_table, 3, True, device=dev)
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=90 + bs, bs=bs, pose_std=0.4).items()}
+    hw = 128
+    c2w, focal, cen = syn.pinhole_camera(hw, hw)
+    full = ana.gen_rays(torch.from_numpy(c2w).to(dev), hw, hw, focal.tolist(), 0.1, 10.0, cen.tolist()).view(-1, 8)
+    gen = torch.Generator().manual_seed(bs)
+    pick = torch.stack([torch.randperm(hw * hw, generator=gen)[:n_rays] for _ in range(bs)]).to(dev)
+    with torch.no_grad():
+        m.set_body_model(pose, _templ(dev))
+        rays = m.convert_to_body_model_space(full[pick].contiguous())
+        m.clac_ober2cano_transform()
+        z = ana.VolumeRenderer(n_coarse=K).sample_coarse(rays)
+        args = (m.knn_index(), m.ober2cano_transform, m.body_model.lbs_weights, 0.2)
+        groups = ana.ops.warp_points(*args, rays=rays, z=z, skip_far=True, neighbours=True, two_pass=True)
+        lean_g = ana.ops.warp_points(*args, rays=rays, z=z, skip_far=True, lean=True)
+        monkeypatch.setenv("ANR_WARP_LANE_PER_SAMPLE", "1")
+        lanes = ana.ops.warp_points(*args, rays=rays, z=z, skip_far=True, neighbours=True, two_pass=True)
+        lean_l = ana.ops.warp_points(*args, rays=rays, z=z, skip_far=True, lean=True)
+        monkeypatch.delenv("ANR_WARP_LANE_PER_SAMPLE")
+        exact = ana.ops.warp_points(*args, rays=rays, z=z, skip_far=False, neighbours=True)
+    v = exact[0][..., 3] == 1
+    assert 0.01 < v.float().mean() < 0.9
+    for got in (groups, lanes):
+        assert torch.equal(got[0][..., 3], exact[0][..., 3])
+        for a, b in zip(got, exact):
+            assert torch.equal(a[v], b[v])
+    for lean in (lean_g, lean_l):                       # (pts, validity bytes, list of valid positions, their count)
+        assert torch.equal(lean[1].bool(), v) and torch.equal(lean[0][v], exact[0][v])
+        n_valid = int(lean[3].item())
+        assert n_valid == int(v.sum()) and torch.equal(lean[2][:n_valid].long().sort().values, v.view(-1).nonzero()[:, 0])
+
+
 # ----------------------------------------------------------------------------- a11-a12
 @pytest.mark.parametrize("flag", [0, 0x100], ids=["lds_dma", "reg_staged"])
 def test_mlp_fp32_matches_reference(dev, smpl_table, flag):

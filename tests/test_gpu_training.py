@@ -1099,3 +1099,66 @@ def test_training_pass_without_a_single_valid_sample(dev, smpl_table):
         assert all(p.grad is None or (torch.isfinite(p.grad).all() and p.grad.abs().max() == 0) for p in net.parameters())
         assert pts.grad is not None and pts.grad.abs().max() == 0
         pts.grad = None
+
+
+def test_graphed_training_step_equals_the_eager_step(dev, smpl_table):
+    """Trainer(graph=True).step_graphed: the whole step (SMPL, warp, both networks, losses, backward, pose gradients, Adam)
+    captured into one HIP graph after GRAPH_WARM_STEPS eager steps.  Two copies of one scene, one stepped eagerly and one
+    through the graph, with changing batches (frames, targets) and no random draw in the step (perturb 0, no normals term):
+    the same losses and, after 8 steps, the same weights and SMPL rows up to the order of the backward's atomic adds.
+    Then with every random draw on (perturb 1, normals): replays draw fresh numbers (the loss of a repeated batch moves),
+    the learning-rate schedule reaches the captured Adam (a capture bakes the rates in: a new one is taken when the scheduler
+    moves them), and a changed shape falls back to the eager step."""
+    import copy
+    import anim_nerf_amd as ana
+    m0, table0, batch = _config3_scene(dev, smpl_table, F=4, H=16)
+    hp = ana.TrainHParams(n_samples=32, n_importance=16, lambda_normals=0.0, lr=1e-3, max_epochs=4)
+    trainers = []
+    for graph in (False, True):
+        m, table = copy.deepcopy(m0), copy.deepcopy(table0)
+        m.nerf.mlp_mode = m.nerf_fine.mlp_mode = "bf16"
+        trainers.append((ana.Trainer(m, ana.VolumeRenderer(n_coarse=32, n_fine=16), hp, body_model_params=table, graph=graph), m, table))
+    gen = torch.Generator().manual_seed(3)
+    losses = [[], []]
+    for it in range(8):
+        rgbs = torch.rand(batch["rgbs"].shape, generator=gen).to(dev)
+        fidx = torch.randperm(40, generator=gen)[:4].to(dev)
+        for k, (tr, m, table) in enumerate(trainers):
+            loss, det = tr.step_graphed(batch["rays"], rgbs, batch["alphas"], None, _templ(dev), batch["fg"], batch["bg"],
+                                        perturb=0.0, frame_idx=fidx)
+            losses[k].append(float(loss))
+            assert torch.isfinite(det["psnr"])
+        if it == 4:
+            for tr, _, _ in trainers:
+                tr.scheduler.step()                             # an epoch boundary in the middle of the replays
+    (te, me, tabe), (tg, mg, tabg) = trainers
+    assert tg._graph is not None and te._graph is None
+    assert float(tg.optimizer.param_groups[0]["lr"]) == pytest.approx(te.optimizer.param_groups[0]["lr"], rel=1e-6) and \
+        float(tg.optimizer.param_groups[0]["lr"]) < hp.lr
+    np.testing.assert_allclose(losses[1], losses[0], rtol=2e-3)
+    # (Adam moves a weight by ~lr per step whatever the size of its gradient: where a gradient is rounding noise — the
+    # order of the backward's atomic adds — the two copies may walk apart by a step or two; everywhere else they agree)
+    pairs = [(n, a, b) for (n, a), (_, b) in zip(me.named_parameters(), mg.named_parameters()) if a.requires_grad]
+    pairs += [(n, getattr(tabe, n).weight, getattr(tabg, n).weight) for n in tabe.param_names]
+    for n, a, b in pairs:
+        d = (a - b).abs()
+        assert d.max() <= 2.0 * hp.lr and d.mean() <= 0.02 * hp.lr, (n, float(d.max()), float(d.mean()))
+    assert (me.nerf_fine.sigma.weight - m0.nerf_fine.sigma.weight).abs().max() > 0
+    # inference after replays sees the CURRENT weights (the packs cached by the capture belong to the graph)
+    with torch.no_grad():
+        pts = torch.rand(1, 256, 3, device=dev) - 0.5
+        assert (mg.nerf_fine(pts)[1] - me.nerf_fine(pts)[1]).abs().max() <= 2e-2 * me.nerf_fine(pts)[1].abs().max()
+    # random draws advance per replay
+    hp2 = ana.TrainHParams(n_samples=32, n_importance=16, lr=0.0)
+    m, table = copy.deepcopy(m0), copy.deepcopy(table0)
+    tr = ana.Trainer(m, ana.VolumeRenderer(n_coarse=32, n_fine=16), hp2, body_model_params=table, graph=True)
+    seen = []
+    for it in range(7):
+        loss, _ = tr.step_graphed(batch["rays"], batch["rgbs"], batch["alphas"], None, _templ(dev), batch["fg"], batch["bg"],
+                                  perturb=1.0, frame_idx=batch["frame_idx"])
+        seen.append(float(loss))
+    assert tr._graph is not None and len(set(seen[3:])) == 4 and max(seen) - min(seen) < 0.05 * abs(seen[0])
+    # another shape: eager, the graph untouched
+    loss, _ = tr.step_graphed(batch["rays"][:2], batch["rgbs"][:2], batch["alphas"][:2], None, _templ(dev), batch["fg"][:2],
+                              batch["bg"][:2], perturb=1.0, frame_idx=batch["frame_idx"][:2])
+    assert torch.isfinite(loss) and tr._graph[0][0][1][0][1] != tuple(batch["alphas"][:2].shape)
