@@ -514,13 +514,15 @@ __device__ __forceinline__ float cell_size(const float* gbox, float thr, int G) 
     const float ex = gbox[4] - gbox[0], ey = gbox[5] - gbox[1], ez = gbox[6] - gbox[2];
     return fmaxf(MIN_CELL, (fmaxf(fmaxf(ex, ey), ez) + 2.0f * thr) * (1.0f / (float)G));
 }
-__device__ __forceinline__ int cell_of(const float* gbox, float thr, int G, float px, float py, float pz) {
-    const float c = cell_size(gbox, thr, G);
-    const float inv = 1.0f / c;
+// (inv = 1.0f / cell_size(gbox, thr, G): the same for every sample of a body — callers in a loop compute it once)
+__device__ __forceinline__ int cell_of_inv(const float* gbox, float thr, int G, float inv, float px, float py, float pz) {
     const int ix = min(max((int)((px - gbox[0] + thr) * inv), 0), G - 1);
     const int iy = min(max((int)((py - gbox[1] + thr) * inv), 0), G - 1);
     const int iz = min(max((int)((pz - gbox[2] + thr) * inv), 0), G - 1);
     return (ix * G + iy) * G + iz;
+}
+__device__ __forceinline__ int cell_of(const float* gbox, float thr, int G, float px, float py, float pz) {
+    return cell_of_inv(gbox, thr, G, 1.0f / cell_size(gbox, thr, G), px, py, pz);
 }
 
 // Per-workgroup aggregation of the cell counters: neighbouring rays and consecutive samples fall into the same few
@@ -565,6 +567,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
     int my_cell[CLS_ITERS];
     unsigned near_bits = 0;
     const uint32_t R32 = (uint32_t)(N / (K > 0 ? K : 1));
+    const float cell_inv = 1.0f / cell_size(gbox, thr, G);
     // flat index of the thread's sample (step, v)
     auto sample_of = [&](int step, int v) { return (((int64_t)blockIdx.x * STEPS + step) * WARP_THREADS + threadIdx.x) * VS + v; };
 #pragma unroll
@@ -577,6 +580,14 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
             zz[0] = z4.x; zz[VS > 1 ? 1 : 0] = z4.y; zz[VS > 2 ? 2 : 0] = z4.z; zz[VS > 3 ? 3 : 0] = z4.w;
             if (perm != nullptr) pm = *reinterpret_cast<const unsigned*>(perm + (int64_t)b * N + n0);
         }
+        // VEC4: the four samples belong to one ray (K % 4 == 0, n0 % 4 == 0): its index and its six floats once per step
+        uint32_t ray4 = 0;
+        float ro[3] = {0.f, 0.f, 0.f}, rd[3] = {0.f, 0.f, 0.f};
+        if (VEC4 && n0 < N) {
+            ray4 = (uint32_t)n0 / (uint32_t)K;                                         // (N < 2^31 on this path)
+            const float* ry = rays + ((int64_t)b * R32 + ray4) * ray_stride;
+            ro[0] = ry[0]; ro[1] = ry[1]; ro[2] = ry[2]; rd[0] = ry[3]; rd[1] = ry[4]; rd[2] = ry[5];
+        }
 #pragma unroll
         for (int v = 0; v < VS; ++v) {
             const int it = step * VS + v;
@@ -585,10 +596,14 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
             int cell = 0;
             if (n < N) {
                 float px, py, pz;
-                const uint32_t ray = FROM_RAYS ? (uint32_t)n / (uint32_t)K : 0;        // (N < 2^31 on this path)
-                if (FROM_RAYS) {
+                const uint32_t ray = VEC4 ? ray4 : FROM_RAYS ? (uint32_t)n / (uint32_t)K : 0;
+                if (VEC4) {
+                    px = __fadd_rn(ro[0], __fmul_rn(zz[v], rd[0]));
+                    py = __fadd_rn(ro[1], __fmul_rn(zz[v], rd[1]));
+                    pz = __fadd_rn(ro[2], __fmul_rn(zz[v], rd[2]));
+                } else if (FROM_RAYS) {
                     const float* ry = rays + ((int64_t)b * R32 + ray) * ray_stride;
-                    const float zv = VEC4 ? zz[v] : z[(int64_t)b * N + n];
+                    const float zv = z[(int64_t)b * N + n];
                     px = __fadd_rn(ry[0], __fmul_rn(zv, ry[3]));
                     py = __fadd_rn(ry[1], __fmul_rn(zv, ry[4]));
                     pz = __fadd_rn(ry[2], __fmul_rn(zv, ry[5]));
@@ -600,7 +615,11 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
                 // farther than the threshold from the whole body -> cannot be valid (see warp_points_kernel)
                 near = box_d2(gbox, px, py, pz) < thr * thr;
                 bool reused = false;
+#ifdef ANR_ABL_CLS_NOREUSE
+                if (false) {
+#else
                 if (FROM_RAYS && perm != nullptr) {
+#endif
                     // fine pass: this sorted sample IS coarse sample p of the same ray (z_sorted[j] = cat(z_coarse, z_fine)
                     // [perm[j]]) -> its canonical point and validity were computed in the coarse pass: copy, do not search
                     const int pj = VEC4 ? (int)((pm >> (8 * v)) & 0xffu) : (int)perm[o];
@@ -618,16 +637,20 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
                     // lean mode (validity bytes requested): consumers look at the byte, not at the point, so the 16-B point
                     // of a far sample is not written at all
                     if (!VEC4 && valid_mask != nullptr) valid_mask[o] = 0;
+#ifndef ANR_ABL_CLS_NOPTS
                     if (valid_mask == nullptr || near) pts_out[o] = make_float4(px, py, pz, 0.0f);
+#endif
                     if (nbr_w != nullptr) {
                         reinterpret_cast<float4*>(nbr_w)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
                         reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(0, 0, 0, 0);
                     }
                     if (near) {
-                        cell = cell_of(gbox, thr, G, px, py, pz);
+                        cell = cell_of_inv(gbox, thr, G, cell_inv, px, py, pz);
+#ifndef ANR_ABL_CLS_NOHASH
                         const int slot = hash_slot(hkeys, cell);
                         if (slot >= 0) atomicAdd(&hcnt[slot], 1);
                         else atomicAdd(cell_count + (int64_t)b * NCELL + cell, 1);
+#endif
                     }
                 }
             }
@@ -654,6 +677,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
         }
         __syncthreads();
         int64_t pos = (int64_t)b * N + block_base + wave_cnt[wave] + incl - mine;
+#ifndef ANR_ABL_CLS_NOLIST
 #pragma unroll
         for (int it = 0; it < CLS_ITERS; ++it) {
             if ((near_bits >> it) & 1u) {
@@ -662,6 +686,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
                 ++pos;
             }
         }
+#endif
     }
     __syncthreads();
     for (int s = threadIdx.x; s < HN; s += WARP_THREADS)
@@ -814,46 +839,64 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cells_kernel(const float* _
     }
 }
 
-// one workgroup per body: cell_start = exclusive scan of the live cells' counts; cell_count is zeroed (it becomes the
-// fill counter); live[b] = number of list entries in live cells
-__global__ __launch_bounds__(1024) void warp_cell_scan_kernel(int32_t* __restrict__ cell_count,
+// cell_start = exclusive scan of the live cells' counts, one workgroup per 4,096 cells: it first adds up the live counts of
+// every cell in front of its chunk (the arrays are 1 MB per body and sit in L2; a single workgroup walking the 64 chunks one
+// after the other took 0.12 ms per call), then scans its own.  cell_fill (the scatter's fill counters) is zeroed here;
+// live[b] = number of list entries in live cells, written by the last chunk.
+__global__ __launch_bounds__(1024) void warp_cell_scan_kernel(const int32_t* __restrict__ cell_count,
                                                               int32_t* __restrict__ cell_start,
                                                               const float* __restrict__ cell_cap2,
+                                                              int32_t* __restrict__ cell_fill,
                                                               int32_t* __restrict__ live, int G) {
     __shared__ int wave_tot[16];
     __shared__ int carry;
-    int32_t* cnt = cell_count + (int64_t)blockIdx.x * NCELL;
-    int32_t* start = cell_start + (int64_t)blockIdx.x * NCELL;
+    const int32_t* cnt = cell_count + (int64_t)blockIdx.y * NCELL;
+    const float* cap = cell_cap2 + (int64_t)blockIdx.y * NCELL;
+    int32_t* start = cell_start + (int64_t)blockIdx.y * NCELL;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < G * G * G; base += 4096) {
-        // 4 consecutive cells per thread
+    auto live_counts = [&](int base) {                   // 4 consecutive cells per thread; dead cells take no room
         int4 v = reinterpret_cast<const int4*>(cnt + base)[threadIdx.x];
-        reinterpret_cast<int4*>(cnt + base)[threadIdx.x] = make_int4(0, 0, 0, 0);
-        const float4 cp = reinterpret_cast<const float4*>(cell_cap2 + (int64_t)blockIdx.x * NCELL + base)[threadIdx.x];
-        if (v.x > 0 && cp.x < 0.f) v.x = 0;               // dead cells take no room in the sorted list
+        const float4 cp = reinterpret_cast<const float4*>(cap + base)[threadIdx.x];
+        if (v.x > 0 && cp.x < 0.f) v.x = 0;
         if (v.y > 0 && cp.y < 0.f) v.y = 0;
         if (v.z > 0 && cp.z < 0.f) v.z = 0;
         if (v.w > 0 && cp.w < 0.f) v.w = 0;
-        const int mine = v.x + v.y + v.z + v.w;
-        int incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        int off = carry;
-        for (int w = 0; w < wave; ++w) off += wave_tot[w];
-        const int ex = off + incl - mine;
-        reinterpret_cast<int4*>(start + base)[threadIdx.x] = make_int4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = off + incl;
-        __syncthreads();
+        return v;
+    };
+    const int my_base = (int)blockIdx.x * 4096;
+    int before = 0;
+#pragma unroll 4
+    for (int base = 0; base < my_base; base += 4096) {
+        const int4 v = live_counts(base);
+        before += v.x + v.y + v.z + v.w;
     }
-    if (threadIdx.x == 0) live[blockIdx.x] = carry;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    if (lane == 0) wave_tot[wave] = before;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += wave_tot[w];
+        carry = t;
+    }
+    __syncthreads();
+    const int4 v = live_counts(my_base);
+    reinterpret_cast<int4*>(cell_fill + (int64_t)blockIdx.y * NCELL + my_base)[threadIdx.x] = make_int4(0, 0, 0, 0);
+    const int mine = v.x + v.y + v.z + v.w;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();                                     // (wave_tot is reused)
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int off = carry;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    const int ex = off + incl - mine;
+    reinterpret_cast<int4*>(start + my_base)[threadIdx.x] = make_int4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
+    if (my_base + 4096 >= G * G * G && threadIdx.x == 1023) live[blockIdx.y] = off + incl;
 }
 
 // counting-sort scatter of the near list by cell: a workgroup ranks 4096 consecutive list entries per cell in its
@@ -1279,16 +1322,17 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(
     int64_t N, float* __restrict__ d_o2c, float* __restrict__ d_rays, float* __restrict__ d_z) {
     const int b = blockIdx.y;
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const int64_t o = (int64_t)b * N + n;
-    const float4 g = d_pts[o];
-    const float4 w4 = nbr_w[o];
+    const bool in_range = n < N;
+    const int64_t o = (int64_t)b * N + (in_range ? n : 0);
+    const float4 g = in_range ? d_pts[o] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 w4 = in_range ? nbr_w[o] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float w[4] = {w4.x, w4.y, w4.z, w4.w};
     const bool live = (w[0] != 0.f || w[1] != 0.f || w[2] != 0.f || w[3] != 0.f) && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
+    const int64_t R = N / K;
+    const int64_t ray = (in_range ? n : N - 1) / K;
     float dzv = 0.f;
+    float dray[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (live) {
-        const int64_t R = N / K;
-        const int64_t ray = n / K;
         const float* ry = rays + ((int64_t)b * R + ray) * ray_stride;
         const float zz = z[o];
         const float x[4] = {ry[0] + zz * ry[3], ry[1] + zz * ry[4], ry[2] + zz * ry[5], 1.0f};
@@ -1311,16 +1355,39 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(
         }
         float dx[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dx[c] = Rb[c] * gv[0] + Rb[3 + c] * gv[1] + Rb[6 + c] * gv[2];
-        float* dr = d_rays + ((int64_t)b * R + ray) * 8;
-#pragma unroll
         for (int c = 0; c < 3; ++c) {
-            atomicAdd(dr + c, dx[c]);
-            atomicAdd(dr + 3 + c, zz * dx[c]);
+            dx[c] = Rb[c] * gv[0] + Rb[3 + c] * gv[1] + Rb[6 + c] * gv[2];
+            dray[c] = dx[c];
+            dray[3 + c] = zz * dx[c];
         }
         dzv = dx[0] * ry[3] + dx[1] * ry[4] + dx[2] * ry[5];
     }
-    d_z[o] = dzv;
+    // d o', d d': the lanes of a wavefront are consecutive samples — of ONE ray, or of two or three — and a per-lane atomic
+    // sends 64 adds to the same six addresses one behind the other.  Segmented sum over the lanes of a ray first (the rays of
+    // a wavefront are contiguous runs of lanes), one set of atomics per run.
+    const int lane = threadIdx.x & 63;
+    if (__any(live)) {
+        const int ray_lo = (int)(ray & 0x7fffffff);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int other = __shfl_down(ray_lo, off, 64);
+            const bool same = lane + off < 64 && other == ray_lo;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const float v = __shfl_down(dray[c], off, 64);
+                if (same) dray[c] += v;
+            }
+        }
+        const int prev = __shfl_up(ray_lo, 1, 64);
+        const bool head = lane == 0 || prev != ray_lo;
+        if (head && in_range) {
+            float* dr = d_rays + ((int64_t)b * R + ray) * 8;
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                if (dray[c] != 0.f) atomicAdd(dr + c, dray[c]);
+        }
+    }
+    if (in_range) d_z[o] = dzv;
 }
 
 template <typename Kern>
@@ -1468,10 +1535,12 @@ extern "C" int anr_warp_points_lean(const float* xyz, int xyz_stride, const floa
         hipLaunchKernelGGL(warp_cells_kernel, dim3((unsigned)(gx < cells / WARP_THREADS ? gx : cells / WARP_THREADS), bs),
                            dim3(WARP_THREADS), bytes, st, index, d, dis_threshold, w.occ_list, w.occ_count, w.occ_cursor,
                            w.cell_cap2, w.cell_seed, G);
-        hipLaunchKernelGGL(warp_cell_scan_kernel, dim3(bs), dim3(1024), 0, st, w.cell_count, w.cell_start, w.cell_cap2, w.live, G);
+        // (occ_list is dead once the cells kernel has run: it becomes the scatter's fill counters)
+        hipLaunchKernelGGL(warp_cell_scan_kernel, dim3(cells / 4096, bs), dim3(1024), 0, st, w.cell_count, w.cell_start, w.cell_cap2,
+                           w.occ_list, w.live, G);
         const int64_t sc_blocks = (N + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
         hipLaunchKernelGGL(warp_cell_scatter_kernel, dim3((unsigned)(sc_blocks < 1024 ? sc_blocks : 1024), bs), dim3(WARP_THREADS), 0, st,
-                           w.list, w.cells, w.count, N, w.cell_start, w.cell_count, w.cell_cap2, w.sorted);
+                           w.list, w.cells, w.count, N, w.cell_start, w.occ_list, w.cell_cap2, w.sorted);
         if (int rc = check_launch("anr_warp_points (bin)")) return rc;
         if (int rc = allow_big_lds(warp_search_kernel, bytes, "anr_warp_points")) return rc;
         const int64_t max_wg = (N + 64 * (WARP_THREADS / 64) - 1) / (64 * (WARP_THREADS / 64));

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""From a rocprofv3 kernel trace of `bench.py --workload cfg4`: per training step (delimited by the fused-Adam launches),
+the step's wall time on the GPU, the sum of its kernel durations and the idle time between kernels; the median step, and its
+kernels ranked by time.   python tools/step_gaps.py <dir with *_kernel_trace.csv>"""
+import collections
+import csv
+import glob
+import os
+import sys
+
+f = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)[0]
+rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))))
+ends = [i for i, r in enumerate(rows) if "FusedOptimizerTensorListMetadata" in r[2] or "fused_adam" in r[2].lower()]
+# a step has a few Adam launches back to back: keep the last of each cluster
+last = [i for k, i in enumerate(ends) if k + 1 == len(ends) or ends[k + 1] - i > 5]
+steps = []
+for a, b in zip(last[:-1], last[1:]):
+    seg = rows[a + 1:b + 1]
+    wall = seg[-1][1] - rows[a][1]
+    busy = sum(e - s for s, e, _ in seg)
+    steps.append((wall, busy, len(seg), seg))
+steps.sort(key=lambda t: t[0])
+print("steps found", len(steps))
+for q in (0.1, 0.5, 0.9):
+    w, b, n, _ = steps[int(q * (len(steps) - 1))]
+    print(f"  q{int(q * 100):02d}: wall {w / 1e6:.3f} ms   kernels {b / 1e6:.3f} ms   idle {(w - b) / 1e6:.3f} ms   launches {n}")
+w, b, n, seg = steps[len(steps) // 2]
+acc = collections.defaultdict(lambda: [0, 0])
+for s, e, name in seg:
+    acc[name.split("(")[0][:80]][0] += e - s
+    acc[name.split("(")[0][:80]][1] += 1
+for name, (t, c) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:28]:
+    print(f"  {t / 1e3:8.1f} us {c:4d}x  {name}")
