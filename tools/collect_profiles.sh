@@ -9,11 +9,11 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for wl in cfg2 cfg3 cfg4; do
   extra="--no-extras --cpu-rays 0 --no-psnr --steps 3 --warmup 1"
-  [ $wl = cfg4 ] && extra="--no-extras --steps 4 --warmup 2"
-  rocprofv3 --kernel-trace --stats -d $OUT/${wl}_trace --output-format csv -- python3 $ROOT/bench.py --workload $wl $extra > $OUT/${wl}_trace.json 2> /dev/null
+  [ $wl = cfg4 ] && extra="--no-extras --steps 30 --warmup 2"
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${wl}_trace --output-format csv -- python3 $ROOT/bench.py --workload $wl $extra > $OUT/${wl}_trace.json 2> /dev/null
   if [ $wl != cfg4 ]; then
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${wl}_fetch --output-format csv -- python3 $ROOT/bench.py --workload $wl $extra > /dev/null 2>&1
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${wl}_write --output-format csv -- python3 $ROOT/bench.py --workload $wl $extra > /dev/null 2>&1
+    timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${wl}_fetch --output-format csv -- python3 $ROOT/bench.py --workload $wl $extra > /dev/null 2>&1
+    timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${wl}_write --output-format csv -- python3 $ROOT/bench.py --workload $wl $extra > /dev/null 2>&1
   fi
 done
 cd $ROOT
@@ -37,8 +37,12 @@ ls $DST
 # round 3 additions: the training MLP kernels by row count, the MLP kernel's matrix-pipe occupancy at HEAD
 python3 tools/bench_train_kernels.py > $DST/train_kernels_scaling.txt 2>/dev/null
 cd /tmp
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $OUT/mlp_pmc --output-format csv -- python3 $ROOT/tools/bench_mlp.py 4194304 3 bf16 > $OUT/mlp_pmc.txt 2>&1
+timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $OUT/mlp_pmc --output-format csv -- python3 $ROOT/tools/bench_mlp.py 4194304 3 bf16 > $OUT/mlp_pmc.txt 2>&1
 cd $ROOT
 python3 tools/pmc_summary.py $OUT/mlp_pmc mlp_kernel > $DST/mlp_pmc_head.txt
 python3 tools/bench_mlp.py 4194304 7 bf16,bf16_w4,f32 >> $DST/mlp_pmc_head.txt
+ls $DST
+# second half of round 3: the training step as one graph replay (idle time between its kernels), the small-batch warp search
+python3 tools/step_gaps.py $OUT/cfg4_trace > $DST/train_step_graph_gaps.txt
+python3 tools/bench_warp_small.py 20 both 2>/dev/null | tail -2 > $DST/warp_small_batch.txt
 ls $DST
