@@ -11,7 +11,8 @@ from .nerf import Embedding, NeRF                                     # noqa: F4
 from .rays import gen_ray_directions, gen_rays, get_ray_directions, get_rays   # noqa: F401
 from .render import (batched_inference, gather_ray_shards, max_over_ranks, render_prepared,   # noqa: F401
                      shard_range, sigma_grid, sigma_grid_inference, system_forward)
-from .training import BodyModelParams, GradientReducer, TrainHParams, Trainer, allreduce_gradients, compute_loss   # noqa: F401
+from .training import (BodyModelParams, FlatAdam, GradientReducer, TrainHParams, Trainer, allreduce_gradients,   # noqa: F401
+                       compute_loss)
 from .volume_rendering import VolumeRenderer                          # noqa: F401
 
 __version__ = "0.2.0"

@@ -126,6 +126,9 @@ SIGNATURES = {
     "anr_merge_backward": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "anr_train_loss_ws_floats": (_L, []),
     "anr_train_loss": (_I, [C.POINTER(AnrLossArgs), _P, _P, _P]),
+    "anr_adam_chunk_floats": (_I, []),
+    "anr_adam_chunk_bytes": (_I, []),
+    "anr_adam_step": (_I, [_P, _I, _P, C.POINTER(_F), _I, C.c_double, C.c_double, C.c_double, _P]),
     "anr_train_loss_backward": (_I, [C.POINTER(AnrLossArgs), _P, C.POINTER(AnrLossGrads), _P]),
     "anr_composite_sample": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
 }

@@ -53,7 +53,9 @@ class SMPLOutput(SimpleNamespace):
 def _as_f32(a):
     if "scipy.sparse" in str(type(a)):
         a = a.todense()
-    return torch.from_numpy(np.array(a, dtype=np.float32))
+    # C order: np.array keeps the layout of a transposed view (posedirs), and a strided buffer is copied by every kernel call
+    # that takes it (17 MB per call for posedirs)
+    return torch.from_numpy(np.ascontiguousarray(np.array(a, dtype=np.float32)))
 
 
 def small_matmul(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:

@@ -12,6 +12,8 @@
 //   anr_sample_coarse_backward, anr_merge_backward   the depths' way back to near'/far' and through the sort (pose refinement)
 //   anr_train_loss        every loss term of train.py:228-309 and the weighted total in one launch
 //   anr_train_loss_backward  ... and its gradient w.r.t. every rendered / queried value in one launch
+//   anr_adam_step         Adam (train.py:216-226: torch.optim.Adam, eps 1e-8, no weight decay) over every parameter tensor of
+//                         the step in ONE launch, through a table of chunks; the step counter stays on the device
 #include "anr_common.h"
 
 namespace anr {
@@ -414,4 +416,68 @@ extern "C" int anr_merge_backward(const float* g_sorted, const int32_t* perm, in
     hipLaunchKernelGGL(merge_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_sorted, perm, n, K, Kc,
                        d_z_coarse_out);
     return check_launch("anr_merge_backward");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam over a table of chunks: chunk c = {param, grad, exp_avg, exp_avg_sq, count <= ADAM_CHUNK, group | tensor << 8}.  46 tensors of a
+// few hundred to 80 k floats each are one launch of ~300 workgroups instead of a multi-tensor apply per parameter group
+// (0.21 ms per step -> 0.02).  The arithmetic is torch.optim.Adam's (amsgrad off, maximize off, weight_decay 0):
+//   m = lerp(m, g, 1 - b1);  v = b2 v + (1 - b2) g^2;  p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// t = steps[tensor], one counter per tensor as in torch (a tensor that gets its first gradient late starts at 1), read from
+// the device (the caller increments the counters before the launch: a captured step replays with the right counts).
+namespace anr {
+constexpr int ADAM_CHUNK = 4096;
+struct AdamChunk { float* p; const float* g; float* m; float* v; int32_t count; int32_t group; };
+struct AdamHyper { float lr[4]; double beta1, beta2; float eps; };
+
+__global__ __launch_bounds__(256) void adam_kernel(const AdamChunk* __restrict__ chunks, const float* __restrict__ step, AdamHyper h) {
+    const AdamChunk c = chunks[blockIdx.x];
+    const float t = step[c.group >> 8];
+    // (1 - beta and the bias corrections in double, as the host-side arithmetic of torch.optim.Adam: 1 - 0.999f is off by 1e-5)
+    const float omb1 = (float)(1.0 - h.beta1), omb2 = (float)(1.0 - h.beta2), b2 = (float)h.beta2;
+    const float bc1 = (float)(1.0 - pow(h.beta1, (double)t)), bc2_sqrt = (float)sqrt(1.0 - pow(h.beta2, (double)t));
+    const float step_size = h.lr[c.group & 0xff] / bc1;
+    for (int i = threadIdx.x * 4; i < c.count; i += 256 * 4) {
+        if (i + 4 <= c.count && ((((uintptr_t)c.p | (uintptr_t)c.g | (uintptr_t)c.m | (uintptr_t)c.v) & 15) == 0)) {
+            float4 p = *reinterpret_cast<const float4*>(c.p + i), m = *reinterpret_cast<const float4*>(c.m + i);
+            float4 v = *reinterpret_cast<const float4*>(c.v + i);
+            const float4 g = *reinterpret_cast<const float4*>(c.g + i);
+            float* pp = &p.x; float* mm = &m.x; float* vv = &v.x; const float* gg = &g.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mm[k] = mm[k] + (gg[k] - mm[k]) * omb1;
+                vv[k] = b2 * vv[k] + omb2 * gg[k] * gg[k];
+                pp[k] -= step_size * mm[k] / (sqrtf(vv[k]) / bc2_sqrt + h.eps);
+            }
+            *reinterpret_cast<float4*>(c.p + i) = p;
+            *reinterpret_cast<float4*>(c.m + i) = m;
+            *reinterpret_cast<float4*>(c.v + i) = v;
+        } else {
+            for (int k = i; k < min(i + 4, c.count); ++k) {
+                const float g = c.g[k];
+                const float m = c.m[k] + (g - c.m[k]) * omb1;
+                const float v = b2 * c.v[k] + omb2 * g * g;
+                c.m[k] = m; c.v[k] = v;
+                c.p[k] -= step_size * m / (sqrtf(v) / bc2_sqrt + h.eps);
+            }
+        }
+    }
+}
+}  // namespace anr
+
+extern "C" int anr_adam_chunk_floats(void) { return anr::ADAM_CHUNK; }
+extern "C" int anr_adam_chunk_bytes(void) { return (int)sizeof(anr::AdamChunk); }
+
+extern "C" int anr_adam_step(const void* chunks, int n_chunks, const float* step, const float* lr, int n_groups, double beta1, double beta2,
+                             double eps, void* stream) {
+    ANR_REQUIRE(chunks && step && lr, ANR_E_BADARG, "anr_adam_step: null pointer");
+    ANR_REQUIRE(n_chunks > 0 && n_groups >= 1 && n_groups <= 4, ANR_E_BADARG, "anr_adam_step: n_chunks=%d n_groups=%d (1..4)", n_chunks, n_groups);
+    ANR_REQUIRE(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, ANR_E_BADARG, "anr_adam_step: betas=(%g, %g) eps=%g",
+                beta1, beta2, eps);
+    anr::AdamHyper h;
+    for (int g = 0; g < 4; ++g) h.lr[g] = g < n_groups ? lr[g] : 0.f;
+    h.beta1 = beta1; h.beta2 = beta2; h.eps = (float)eps;
+    hipLaunchKernelGGL(anr::adam_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const anr::AdamChunk*>(chunks), step, h);
+    return anr::check_launch("anr_adam_step");
 }

@@ -944,3 +944,13 @@ def marching_cubes(volume: torch.Tensor, level: float = 0.0):
         _lib.check(lib.anr_mc_emit(_ptr(volume), n0, n1, n2, float(level), _ptr(n_tris), _ptr(tris), _ptr(vmask), _ptr(vstart),
                                    _ptr(tstart), _ptr(verts), _ptr(faces), _stream(volume)), "anr_mc_emit")
     return verts[:V], faces[:T].long()
+
+
+def adam_step(chunks: torch.Tensor, n_chunks: int, step: torch.Tensor, lrs, beta1: float, beta2: float, eps: float) -> None:
+    """torch.optim.Adam's update (train.py:216-226) over a table of tensor chunks in one launch (include/animnerf_hip.h:
+    anr_adam_step); `step` is the device-side count of THIS update, `lrs` the host learning rates of the groups."""
+    lib = _lib.load()
+    chunks, step = _dev(chunks, "chunks", torch.uint8), _dev(step, "step")
+    arr = (C.c_float * len(lrs))(*[float(x) for x in lrs])
+    _lib.check(lib.anr_adam_step(_ptr(chunks), int(n_chunks), _ptr(step), arr, len(lrs), float(beta1), float(beta2), float(eps),
+                                 _stream(step)), "anr_adam_step")

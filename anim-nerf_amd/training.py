@@ -322,6 +322,97 @@ class GradientReducer:
         return sum(f.numel() for f in self.flat)
 
 
+class FlatAdam(torch.optim.Optimizer):
+    """`torch.optim.Adam(params, lr, betas, eps)` (train.py:216-226; amsgrad / maximize off, no weight decay) as ONE kernel
+    launch per step over every tensor of every group (`anr_adam_step`): the moments live in two flat buffers (`state[p]`
+    holds views, so `state_dict()` has torch.optim.Adam's layout), the step counters (one per tensor, as torch keeps them) on the device (a captured step
+    replays with the right bias corrections), the learning rates stay host floats in `param_groups` (schedulers work as usual; a
+    graph capture bakes them in).  A parameter whose `.grad` is None is skipped, as torch does."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        ps = [p for g in self.param_groups for p in g["params"]]
+        if not ps or len(self.param_groups) > 4:
+            raise ValueError("FlatAdam: 1 to 4 parameter groups with at least one tensor")
+        if any(not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() for p in ps):
+            raise ValueError("FlatAdam: contiguous float32 parameters on the GPU (the CPU path is torch.optim.Adam)")
+        if any(g["betas"] != self.param_groups[0]["betas"] or g["eps"] != self.param_groups[0]["eps"] for g in self.param_groups):
+            raise ValueError("FlatAdam: one (betas, eps) for all groups")
+        dev = ps[0].device
+        offs, o = [], 0
+        for p in ps:
+            offs.append(o)
+            o += (p.numel() + 3) // 4 * 4                       # 16-byte aligned slices: the kernel moves float4
+        self._m = torch.zeros(o, dtype=torch.float32, device=dev)
+        self._v = torch.zeros(o, dtype=torch.float32, device=dev)
+        self._steps = torch.zeros(len(ps), dtype=torch.float32, device=dev)   # one counter per tensor, as torch keeps them
+        self._active = torch.zeros(len(ps), dtype=torch.float32, device=dev)  # 1 where the tensor has a gradient this step
+        self._index = {p: i for i, p in enumerate(ps)}
+        self._slices = {p: (off, p.numel()) for p, off in zip(ps, offs)}
+        self._bind_state()
+        self._table, self._table_key, self._n_chunks = None, None, 0
+
+    def _bind_state(self):
+        for p, (off, n) in self._slices.items():
+            self.state[p] = {"step": self._steps[self._index[p]], "exp_avg": self._m[off:off + n].view_as(p),
+                             "exp_avg_sq": self._v[off:off + n].view_as(p)}
+
+    def _build_table(self):
+        import numpy as np
+        from . import _lib
+        key = tuple((p.data_ptr(), None if p.grad is None else p.grad.data_ptr()) for p in self._slices)
+        if key == self._table_key:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("FlatAdam: parameter or gradient storage changed inside a graph capture (run one eager step first)")
+        lib = _lib.load()
+        chunk = lib.anr_adam_chunk_floats()
+        rec = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("count", "<i4"), ("group", "<i4")])
+        assert rec.itemsize == lib.anr_adam_chunk_bytes()
+        rows = []
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse or p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or p.grad.shape != p.shape:
+                    raise ValueError("FlatAdam: dense contiguous float32 gradients of the parameter's shape")
+                off, n = self._slices[p]
+                for c in range(0, n, chunk):
+                    rows.append((p.data_ptr() + 4 * c, p.grad.data_ptr() + 4 * c, self._m.data_ptr() + 4 * (off + c),
+                                 self._v.data_ptr() + 4 * (off + c), min(chunk, n - c), gi | (self._index[p] << 8)))
+        self._n_chunks = len(rows)
+        self._active.copy_(torch.tensor([0.0 if p.grad is None else 1.0 for p in self._slices], dtype=torch.float32))
+        arr = np.array(rows, dtype=rec) if rows else np.zeros(1, dtype=rec)
+        self._table = torch.from_numpy(arr.view(np.uint8).copy()).to(self._m.device)
+        self._table_key = key
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._build_table()
+        if self._n_chunks:
+            from . import ops
+            g0 = self.param_groups[0]
+            self._steps.add_(self._active)
+            ops.adam_step(self._table, self._n_chunks, self._steps, [float(g["lr"]) for g in self.param_groups],
+                          g0["betas"][0], g0["betas"][1], g0["eps"])
+        return loss
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)                     # (torch replaces the state tensors by copies of the loaded ones)
+        loaded = dict(self.state)
+        self._bind_state()
+        with torch.no_grad():
+            for p, st in loaded.items():
+                if p in self._slices and "exp_avg" in st:
+                    self.state[p]["exp_avg"].copy_(st["exp_avg"])
+                    self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
+                    self._steps[self._index[p]] = float(st["step"])
+
+
 class Trainer:
     """optimizer + schedule + step; `step(batch)` mirrors AnimNeRFSystem.training_step (train.py:324-348)."""
 
@@ -329,7 +420,7 @@ class Trainer:
                  graph: bool = False):
         """graph=True: `step_graphed` may capture the whole step (forward, losses, backward, Adam) into ONE HIP graph and
         replay it — ~190 launches per step leave the host as one (the step holds no device -> host read: row counts stay
-        on the device).  Adam then runs `capturable` (its step counter lives on the device)."""
+        on the device; FlatAdam keeps its step counter there too)."""
         self.model, self.renderer, self.hp = anim_nerf, volume_renderer, hp
         self.body_model_params = body_model_params
         self.graph_enabled = bool(graph)
@@ -346,11 +437,10 @@ class Trainer:
         self.params = [p for g in groups for p in g["params"]]
         # (one fused update kernel per parameter group on the GPU instead of seven list kernels)
         on_gpu = bool(self.params and self.params[0].is_cuda)
-        if self.graph_enabled and on_gpu:
-            # (capturable: the step counter lives on the device.  The learning rates stay host floats — a capture bakes them in,
-            # and step_graphed captures again when the scheduler has moved them: once per epoch, tens of milliseconds.  Device
-            # -side lr tensors + LambdaLR + the fused kernel crashed hipGraphInstantiate on ROCm 7.2 / torch 2.10.)
-            self.optimizer = torch.optim.Adam(groups, eps=1e-8, weight_decay=0, fused=True, capturable=True)
+        if on_gpu and all(p.dtype == torch.float32 and p.is_contiguous() for p in self.params):
+            # one launch for every tensor of both groups, step counter on the device (capturable).  The learning rates stay host
+            # floats — a capture bakes them in, and step_graphed captures again when the scheduler has moved them: once per epoch.
+            self.optimizer = FlatAdam(groups, eps=1e-8)
         else:
             self.optimizer = torch.optim.Adam(groups, eps=1e-8, weight_decay=0, fused=on_gpu)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(

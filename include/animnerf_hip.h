@@ -521,6 +521,21 @@ int anr_composite_sample(const float* rgbs, const float* z_coarse, const float* 
                          int white_bkgd, float* weights_out, float* rgb_out, float* depth_out, float* acc_out,
                          float* z_fine_out, float* z_sorted_out, uint8_t* perm_out, void* stream);
 
+/* ---- optimiser step (f1: train.py:216-226, `torch.optim.Adam(lr, eps=1e-8)` over the networks + the SMPL rows) ---------------
+ * Adam over every parameter tensor of the step in ONE launch.  `chunks` is a device array of n_chunks records of
+ * anr_adam_chunk_bytes() bytes each: {float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32 count, int32
+ * group_and_tensor}, count <= anr_adam_chunk_floats() consecutive floats of one tensor (a tensor = ceil(numel / chunk) records);
+ * group_and_tensor = group | tensor << 8: group < n_groups <= 4 selects lr[group] (HOST array), tensor indexes step[] (DEVICE
+ * floats): the 1-based count t of THIS update of that tensor — torch keeps one counter per tensor; the caller increments them on
+ * the device before the launch, so a captured step replays with the right bias corrections.
+ *   m = m + (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;  p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ * (torch.optim.Adam with amsgrad = maximize = False, weight_decay = 0; 1 - beta and the bias corrections are formed in double,
+ * as torch's host-side arithmetic does, then used in float). */
+int anr_adam_chunk_floats(void);
+int anr_adam_chunk_bytes(void);
+int anr_adam_step(const void* chunks, int n_chunks, const float* step, const float* lr, int n_groups, double beta1, double beta2,
+                  double eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1162,3 +1162,46 @@ def test_graphed_training_step_equals_the_eager_step(dev, smpl_table):
     loss, _ = tr.step_graphed(batch["rays"][:2], batch["rgbs"][:2], batch["alphas"][:2], None, _templ(dev), batch["fg"][:2],
                               batch["bg"][:2], perturb=1.0, frame_idx=batch["frame_idx"][:2])
     assert torch.isfinite(loss) and tr._graph[0][0][1][0][1] != tuple(batch["alphas"][:2].shape)
+
+
+def test_flat_adam_equals_torch_adam(dev):
+    """FlatAdam (anr_adam_step: one launch over a table of tensor chunks) against torch.optim.Adam on the same tensors and
+    gradients: two groups with their own learning rates, sizes that are not multiples of 4 or of the chunk, a tensor without
+    a gradient (skipped, as torch does), a learning-rate change between steps, and a state_dict round trip."""
+    import anim_nerf_amd as ana
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(256, 63), (256,), (3, 128), (3,), (1, 10), (114, 69), (9001,), (7,)]
+    ours = [torch.randn(s, generator=gen).to(dev).requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone().requires_grad_(True) for p in ours]
+
+    def groups(ps):
+        return [{"params": ps[:5], "lr": 1e-2}, {"params": ps[5:], "lr": 5e-3}]
+    oa, ob = ana.FlatAdam(groups(ours), eps=1e-8), torch.optim.Adam(groups(ref), eps=1e-8)
+    for it in range(7):
+        for p, q in zip(ours, ref):
+            g = torch.randn(p.shape, generator=gen).to(dev) * (10.0 ** float(torch.randint(-6, 2, (1,), generator=gen)))
+            p.grad, q.grad = g.clone(), g.clone()
+        ours[3].grad = ref[3].grad = None                        # gets its first gradient after the loop: its own step count
+        if it == 4:
+            for o in (oa, ob):
+                o.param_groups[0]["lr"] = 2e-3
+        oa.step()
+        ob.step()
+        for k, (p, q) in enumerate(zip(ours, ref)):
+            torch.testing.assert_close(p, q, rtol=2e-6, atol=1e-7, msg=lambda m: f"step {it} tensor {k}: {m}")
+    assert float(oa.state[ours[0]]["step"]) == 7 and float(oa.state[ours[3]]["step"]) == 0 and torch.equal(ours[3], ref[3])
+    torch.testing.assert_close(oa.state[ours[5]]["exp_avg_sq"], ob.state[ref[5]]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+    # state_dict: torch.optim.Adam's layout; loading it into a fresh FlatAdam continues the same trajectory
+    sd = oa.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and len(sd["param_groups"]) == 2
+    again = [p.detach().clone().requires_grad_(True) for p in ours]
+    oc = ana.FlatAdam(groups(again), eps=1e-8)
+    oc.load_state_dict(sd)
+    for p, q, r in zip(ours, ref, again):
+        g = torch.randn(p.shape, generator=gen).to(dev)
+        p.grad, q.grad, r.grad = g.clone(), g.clone(), g.clone()
+    for o in (oa, ob, oc):
+        o.step()
+    for p, q, r in zip(ours, ref, again):
+        torch.testing.assert_close(p, q, rtol=2e-6, atol=1e-7)
+        assert torch.equal(p, r)

@@ -40,3 +40,21 @@ nodes.sort(key=lambda e: -e.cpu_time_total)
 print("--- autograd nodes by total CPU time")
 for e in nodes[:28]:
     print(f"{e.key:44s} n={e.count:4d} cpu {e.cpu_time_total/1e3:7.3f} ms  gpu {e.device_time_total/1e3:7.3f} ms")
+# framework-side kernels of the step: which line of the package issues them
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof2:
+    step(); torch.cuda.synchronize()
+import collections
+acc = collections.defaultdict(lambda: [0.0, 0])
+for ev in prof2.events():
+    if not ev.key.startswith("aten::") or ev.self_device_time_total <= 0:
+        continue
+    where = next((f for f in ev.stack if "anim-nerf_amd" in f or "anim_nerf_amd" in f), "?") if ev.stack else "?"
+    k = (ev.key, str(ev.input_shapes)[:60], where.split("anim-nerf_amd/")[-1][:60])
+    acc[k][0] += ev.self_device_time_total
+    acc[k][1] += 1
+print("--- aten ops with device time, by issuing line")
+tot = 0.0
+for k, (t, c) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:60]:
+    tot += t
+    print(f"{t:8.1f} us {c:3d}x  {k[0]:28s} {k[1]:60s} {k[2]}")
+print("sum of all aten device time", sum(v[0] for v in acc.values()))
