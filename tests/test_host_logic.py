@@ -65,6 +65,19 @@ def test_bad_arguments_are_reported_not_crashed():
         "anr_frame_backward_adjoint": (None,) * 3 + (1,) + (None,) * 6 + (6890, None, 1, None, 8, 0, None, None, None, None, None),
         "anr_to_root_frame": (None, None, None, None, 1, 6890, 24, None, None, None, None, None, None),
         "anr_composite_sample": (None,) * 4 + (8, None, None, 0, 4, 64, 64, 1) + (None,) * 8,
+        # round 3: device-side row counts, the fused view-dependent head, marching cubes, Adam
+        "anr_mlp_forward_save_indexed": (None, 1, None, None, None, 8, None, None, None),
+        "anr_mlp_backward_counted": (None, 1, None, None, None, 64, None, None),
+        "anr_mlp_wgrad_counted": (1, None, None, None, None, 64, None, None, None, None),
+        "anr_mlp_denc_counted": (1, None, None, None, 64, None, None, None),
+        "anr_encode64_counted": (None, 4, 64, None, 0, None, None),
+        "anr_encode_backward_counted": (None, 4, None, 64, None, None, None),
+        "anr_mlp_head_grad_counted": (None, None, None, None, None, 64, 0, None, None),
+        "anr_mlp_pack_view": (None, 1, 27, None, None),
+        "anr_mlp_forward_view": (None, 1, None, None, 3, None, None, 8, None, None),
+        "anr_mc_classify": (None, 8, 8, 8, 0.0, None, None, None, None, None),
+        "anr_mc_emit": (None, 8, 8, 8, 0.0) + (None,) * 8,
+        "anr_adam_step": (None, 1, None, None, 1, 0.9, 0.999, 1e-8, None),
     }
     for name, args in calls.items():
         if args is None:
