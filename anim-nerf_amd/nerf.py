@@ -151,10 +151,37 @@ class NeRF(nn.Module):
             if not self._hip_supported():
                 raise NotImplementedError("HIP MLP covers the shipped configuration only")
             named = dict(self.named_parameters())
+            riders = self._riders
+            if riders is not None and not sigma_only and pts.shape[0] >= 8 * riders.shape[0]:
+                # canonical points that ride along with this (much larger) batch: see attach_riders
+                self._riders = None
+                n = pts.shape[0]
+                both = torch.cat([pts, torch.cat([riders, torch.ones_like(riders[:, :1])], 1)], 0)
+                out = MLPFunction.apply(both, False, ops.MLP_MODES[mode or self.mlp_mode] & 0xff, only_valid, self.grad_sink,
+                                        *[named[k] for k in PARAM_KEYS])
+                self._rider_sigma = out[n:, 3].contiguous()
+                return out[:n]
             return MLPFunction.apply(pts, sigma_only, ops.MLP_MODES[mode or self.mlp_mode] & 0xff, only_valid, self.grad_sink,
                                      *[named[k] for k in PARAM_KEYS])
         pack, mode_id = self.weight_pack(mode)
         return ops.mlp_forward(pack, mode_id, pts, sigma_only=sigma_only, only_valid=only_valid, valid_list=valid_list)
+
+    # Riders: a small set of canonical points whose sigma a later loss term wants (the foreground / background priors of
+    # train.py:262-286: 4,096 points per step).  A field query of their own costs a forward, a backward, a weight-gradient and
+    # three glue launches per network, each at the ~50 us floor of streaming 1.2 MB of weights through sixteen CUs; appended to
+    # the next training-mode evaluation of this network (the step's ray samples, ~10^5 rows) they cost 3 % more rows there.
+    _riders = None
+    _rider_sigma = None
+
+    def attach_riders(self, xyz: Optional[torch.Tensor]):
+        """xyz[...,3] (no gradient w.r.t. the points) -> evaluated with the next training-mode `eval_points` call that is at
+        least 8 times their size; `take_rider_sigma()` then returns their raw sigma, once.  None detaches."""
+        self._riders = None if xyz is None else xyz.detach().reshape(-1, 3)
+        self._rider_sigma = None
+
+    def take_rider_sigma(self):
+        out, self._rider_sigma, self._riders = self._rider_sigma, None, None
+        return out
 
     def eval_rays(self, rays: torch.Tensor, z: torch.Tensor, mode: Optional[str] = None) -> torch.Tensor:
         """[n,4] = (r,g,b,sigma) at the samples o + z d of rays[bs,R,>=8], z[bs,R,K] (inference, no warp): the kernel

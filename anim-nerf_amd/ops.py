@@ -54,7 +54,19 @@ def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
         # another GPU would be touched through a foreign stream
         raise RuntimeError(f"{name} lives on cuda:{t.device.index} but the current device is cuda:{torch.cuda.current_device()}: "
                            "call torch.cuda.set_device (one process per GPU) or wrap the call in torch.cuda.device(...)")
-    return t if t.is_contiguous() else t.contiguous()
+    if t.is_contiguous():
+        return t
+    # A contiguous copy made here is often passed on as `_ptr(_dev(x))`: nothing else holds it, and a block freed before the
+    # launch is enqueued may be handed to the NEXT such copy and overwritten (stream order protects only against allocations
+    # made after the launch).  The last few copies are kept alive here.
+    c = t.contiguous()
+    _RECENT_COPIES.append(c)
+    if len(_RECENT_COPIES) > 32:
+        del _RECENT_COPIES[0]
+    return c
+
+
+_RECENT_COPIES = []
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -871,9 +883,13 @@ LOSS_NAMES = ("loss_rgb", "loss_rgb_fine", "loss_alphas", "loss_alphas_fine", "l
 
 def _loss_args(t: dict, c: dict):
     a = _lib.AnrLossArgs()
+    a._keep = []                                             # contiguous copies of strided inputs must outlive the launch
     for k in ("rgb", "acc", "rgb_fine", "acc_fine", "target_rgb", "target_alpha", "s", "s_fine", "quads", "quads_fine"):
         v = t.get(k)
-        setattr(a, k, None if v is None else _ptr(_dev(v, k)))
+        if v is not None:
+            v = _dev(v, k)
+            a._keep.append(v)
+        setattr(a, k, None if v is None else _ptr(v))
     for k in ("R", "prior_rows", "nv", "normal_sets", "quad_rows", "n_fg", "n_bg"):
         setattr(a, k, int(c.get(k, 0)))
     for k in ("k", "delta", "lambda_alphas", "lambda_foreground", "lambda_background", "lambda_normals"):

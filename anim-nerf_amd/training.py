@@ -147,7 +147,10 @@ def _compute_loss_fused(anim_nerf, hp, rgbs, alphas, results, fg_points, bg_poin
         both = torch.cat([p for p, w in ((fg_points, want_fg), (bg_points, want_bg)) if w], dim=1)
         consts.update(prior_rows=both.shape[0], n_fg=fg_points.shape[1] if want_fg else 0, n_bg=bg_points.shape[1] if want_bg else 0)
         for tag, use_fine in tags:
-            t["s" + tag] = anim_nerf.query_canonical_space(both, use_fine=use_fine, only_sigma=True).reshape(-1)
+            # (their sigma came out of the render pass if the caller attached them there: NeRF.attach_riders)
+            rode = anim_nerf._net(use_fine).take_rider_sigma()
+            t["s" + tag] = (rode if rode is not None and rode.numel() == both.shape[0] * both.shape[1]
+                            else anim_nerf.query_canonical_space(both, use_fine=use_fine, only_sigma=True).reshape(-1))
     if hp.lambda_normals != 0:
         pts = anim_nerf.verts_template.detach()
         pts = pts + torch.randn_like(pts) * hp.dis_threshold * 0.5
@@ -484,6 +487,18 @@ class Trainer:
             yield
         cur.wait_stream(self._stream)
 
+    def _attach_prior_points(self, fg_points, bg_points):
+        """The prior points' sigma comes out of the render passes (NeRF.attach_riders) when the fused losses will ask for it."""
+        import os
+        hp, m = self.hp, self.model
+        pts = [p for p in (fg_points, bg_points) if p is not None]
+        fine = hp.n_importance > 0 and not hp.share_fine
+        nets = [m._net(f) for f in ((False, True) if fine else (False,))] if hasattr(m, "_net") else []
+        on = (hp.fused_losses and hp.use_unpose and pts and pts[0].is_cuda and nets and all(n._hip_supported() for n in nets)
+              and not os.environ.get("ANR_TRAIN_SEPARATE_PRIOR_QUERY"))
+        for n in nets:
+            n.attach_riders(torch.cat(pts, dim=1) if on else None)
+
     def begin_step(self):
         """Zero the flat gradient buffers and point every p.grad at its slice (instead of optimizer.zero_grad)."""
         self.reducer.prepare()
@@ -573,6 +588,7 @@ class Trainer:
         self.begin_step()                                     # grads are views into the (zeroed) flat buffers
         if self.body_model_params is not None and frame_idx is not None:
             body_model_params = self.body_model_params(frame_idx)
+        self._attach_prior_points(fg_points, bg_points)
         results = system_forward(self.renderer, self.model, rays, body_model_params, body_model_params_template,
                                  perturb=perturb, chunk=self.hp.chunk)
         loss, details = compute_loss(self.model, self.hp, rgbs, alphas, results, fg_points, bg_points)

@@ -595,7 +595,8 @@ def cpu_baseline(args, tbl, model, rays, pose_np, use_warp, max_rays=None):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(cores)
     bm = ana.SMPL(data_struct=tbl)
-    otbl = dict(v_template=bm.v_template, shapedirs=bm.shapedirs, posedirs=bm.posedirs, J_regressor=bm.J_regressor,
+    otbl = dict(v_template=bm.v_template, shapedirs=bm.shapedirs, posedirs=bm.posedirs.T.contiguous().T,      # (the reference's layout)
+                J_regressor=bm.J_regressor,
                 parents=bm.parents, lbs_weights=bm.lbs_weights, extra_joints_idxs=bm.vertex_joint_selector.extra_joints_idxs)
     Pc = {k: v.detach().cpu() for k, v in model.nerf.named_parameters()}
     Pf = {k: v.detach().cpu() for k, v in model.nerf_fine.named_parameters()}

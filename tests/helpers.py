@@ -27,7 +27,10 @@ def oracle_table(tbl):
     """SyntheticSMPL -> dict of CPU tensors in the layout oracle.smpl_forward takes."""
     import anim_nerf_amd as ana
     bm = ana.SMPL(data_struct=tbl)
-    return dict(v_template=bm.v_template, shapedirs=bm.shapedirs, posedirs=bm.posedirs,
+    # posedirs in the REFERENCE's memory layout (smplx/body_models.py:214-217: a transposed view, column-major): the CPU
+    # matmul's summation order follows the layout, and the fixtures were produced with it.  (Our module keeps a row-major copy
+    # for the kernels.)
+    return dict(v_template=bm.v_template, shapedirs=bm.shapedirs, posedirs=bm.posedirs.T.contiguous().T,
                 J_regressor=bm.J_regressor, parents=bm.parents, lbs_weights=bm.lbs_weights,
                 extra_joints_idxs=bm.vertex_joint_selector.extra_joints_idxs)
 

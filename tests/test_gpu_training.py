@@ -1205,3 +1205,54 @@ def test_flat_adam_equals_torch_adam(dev):
     for p, q, r in zip(ours, ref, again):
         torch.testing.assert_close(p, q, rtol=2e-6, atol=1e-7)
         assert torch.equal(p, r)
+
+
+def test_prior_points_ride_with_the_render_pass(dev, smpl_table, monkeypatch):
+    """NeRF.attach_riders: the foreground / background prior points evaluated as extra rows of the step's render passes
+    instead of a field query of their own (six launches per network at the ~50 us floor).  Their sigma carries the bits of
+    `get_sigma`, the rows of the batch they ride with are untouched, the parameter gradients agree; a batch smaller than
+    8 x the riders leaves them to the fallback query; and a Trainer step gives the same loss and gradients either way."""
+    import anim_nerf_amd as ana
+    m = seeded_model(smpl_table, 3, True, device=dev, mlp_mode="f32")
+    net = m.nerf
+    gen = torch.Generator().manual_seed(2)
+    for only_valid in (False, True):
+        pts = (torch.rand(2048, 4, generator=gen) - 0.5).to(dev)
+        pts[:, 3] = (torch.rand(2048, generator=gen) > 0.4).float().to(dev)
+        riders = (torch.rand(2, 128, 3, generator=gen) * 2 - 1).to(dev)
+        base = net.eval_points(pts, only_valid=only_valid)
+        net.attach_riders(riders)
+        got = net.eval_points(pts, only_valid=only_valid)
+        rode = net.take_rider_sigma()
+        want = net.get_sigma(riders, only_sigma=True).reshape(-1)
+        assert torch.equal(base, got) and torch.equal(rode, want) and net.take_rider_sigma() is None
+        grads = []
+        for out, s in ((got, rode), (base, want)):
+            for p in net.parameters():
+                p.grad = None
+            (out[:, :3].sum() + (s * s).sum()).backward(retain_graph=True)
+            grads.append({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+        for k in grads[0]:
+            assert (grads[0][k] - grads[1][k]).abs().max() <= 2e-6 * grads[1][k].abs().max() + 1e-12, k
+    net.attach_riders(riders)
+    small = net.eval_points(pts[:1024], only_valid=False)        # 1,024 rows < 8 x 256 riders: not taken along
+    assert small.shape[0] == 1024 and net.take_rider_sigma() is None
+    # a whole training step, with and without
+    m2, table, batch = _config3_scene(dev, smpl_table, F=4, H=16)
+    hp = ana.TrainHParams(n_samples=32, n_importance=16, lambda_normals=0.0, lr=0.0)
+    res = []
+    for separate in ("", "1"):
+        if separate:
+            monkeypatch.setenv("ANR_TRAIN_SEPARATE_PRIOR_QUERY", separate)
+        tr = ana.Trainer(m2, ana.VolumeRenderer(n_coarse=32, n_fine=16), hp, body_model_params=table)
+        loss, det = tr.step(batch["rays"], batch["rgbs"], batch["alphas"], None, _templ(dev), batch["fg"], batch["bg"], perturb=0.0,
+                            frame_idx=batch["frame_idx"])
+        res.append((float(loss), {k: float(v) for k, v in det.items()}, [f.clone() for f in tr.reducer.flat],
+                    m2.nerf.grad_sink.expected))
+    monkeypatch.delenv("ANR_TRAIN_SEPARATE_PRIOR_QUERY")
+    assert res[0][3] == res[1][3] - 1                            # one backward pass per network less
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][0])
+    for k in res[1][1]:
+        assert abs(res[0][1][k] - res[1][1][k]) <= 1e-5 * abs(res[1][1][k]) + 1e-9, k
+    for a, b in zip(res[0][2], res[1][2]):
+        assert (a - b).abs().max() <= 2e-5 * b.abs().max() + 1e-12
