@@ -76,6 +76,8 @@ SIGNATURES = {
     "anr_sample_coarse": (_I, [_P, _I, _P, _P, _L, _I, _P, _P]),
     "anr_warp_ws_ints": (_L, [_I, _L]),
     "anr_warp_points_lean": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _L, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "anr_warp_points_reuse": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _L, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I,
+                                   _P, _P, _P]),
     "anr_warp_points": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _L, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "anr_warp_backward": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P]),
     "anr_points_from_rays": (_I, [_P, _I, _P, _I, _L, _P, _P]),

@@ -316,10 +316,13 @@ class AnimNeRF(nn.Module):
             return net.get_normal(xyz)
         return net(xyz, viewdir=viewdir)
 
-    def warped_points(self, *, xyz=None, rays=None, z=None, skip_far=False, lean=False, reuse=None):
+    def warped_points(self, *, xyz=None, rays=None, z=None, skip_far=False, lean=False, reuse=None, keep=None):
         """pts[bs*N,4] = (canonical xyz, valid) for explicit points or for samples along rays.
         skip_far: provably-invalid samples (farther than dis_threshold from the body's bounding box) skip the
-        neighbour search; only legal where sigma = -1e5 is all that is consumed (the renderer)."""
+        neighbour search; only legal where sigma = -1e5 is all that is consumed (the renderer).
+        keep (a dict, training): the call leaves what a later call on a superset of its samples can copy instead of searching
+        again under keep["train"] = (pts, nbr_idx, nbr_w); reuse = that tuple + (perm,): sorted sample j of a ray is sample
+        perm[j] of the kept call where perm[j] < its K (the fine pass of a step, anr_warp_points_reuse)."""
         if self.use_unpose and self.k_neigh != 4:
             if lean:
                 raise NotImplementedError("the lean renderer schedule is built for k_neigh = 4")
@@ -332,14 +335,22 @@ class AnimNeRF(nn.Module):
                                                             or self.ober2cano_transform.requires_grad):
                 from .autograd import WarpFunction               # pose refinement: differentiable warp
                 return WarpFunction.apply(rays, z, self.ober2cano_transform, self.knn_index(),
-                                          self.body_model.lbs_weights, self.dis_threshold, far).view(-1, 4)
+                                          self.body_model.lbs_weights, self.dis_threshold, far, reuse if far else None,
+                                          keep if far else None).view(-1, 4)
             if lean:                                            # (pts, valid bytes, valid list, device count)
                 pts, vm, vi, vc = ops.warp_points(self.knn_index(), self.ober2cano_transform.detach(),
                                                   self.body_model.lbs_weights, self.dis_threshold, xyz=xyz, rays=rays,
                                                   z=z, skip_far=True, lean=True, reuse=reuse)
                 return pts.view(-1, 4), vm, vi, vc
-            return ops.warp_points(self.knn_index(), self.ober2cano_transform.detach(), self.body_model.lbs_weights,
-                                   self.dis_threshold, xyz=xyz, rays=rays, z=z, skip_far=far).view(-1, 4)
+            if far and xyz is None and reuse is not None:        # training without pose refinement: rows only
+                reuse = (reuse[0], None, reuse[3])
+            else:
+                reuse = None
+            pts = ops.warp_points(self.knn_index(), self.ober2cano_transform.detach(), self.body_model.lbs_weights,
+                                  self.dis_threshold, xyz=xyz, rays=rays, z=z, skip_far=far, reuse=reuse)
+            if keep is not None and far and xyz is None:
+                keep["train"] = (pts, None, None)
+            return pts.view(-1, 4)
         if xyz is not None:
             flat = xyz.reshape(-1, xyz.shape[-1])[:, :3]
             return torch.cat([flat, torch.ones_like(flat[:, :1])], -1)

@@ -471,8 +471,10 @@ class FineMergeFunction(torch.autograd.Function):
     depths are detached in the reference, the coarse ones pass their gradient through the sort's permutation."""
 
     @staticmethod
-    def forward(ctx, z_coarse, weights, u):
+    def forward(ctx, z_coarse, weights, u, stash=None):
         zs, perm = ops.sample_fine_merge(z_coarse.detach(), weights, u, want_perm=True)
+        if stash is not None:                                   # the fine pass's warp copies the coarse samples' rows by it
+            stash["perm"] = perm.to(torch.uint8)
         ctx.save_for_backward(perm)
         ctx.Kc = z_coarse.shape[-1]
         return zs
@@ -481,7 +483,7 @@ class FineMergeFunction(torch.autograd.Function):
     @torch.no_grad()
     def backward(ctx, g):
         (perm,) = ctx.saved_tensors
-        return ops.merge_backward(g, perm, ctx.Kc), None, None
+        return ops.merge_backward(g, perm, ctx.Kc), None, None, None
 
 
 class CompositeFunction(torch.autograd.Function):
@@ -518,9 +520,17 @@ class WarpFunction(torch.autograd.Function):
     constants of the backward pass (KNN is `no_grad` in the reference)."""
 
     @staticmethod
-    def forward(ctx, rays, z, o2c, index, lbs_w, thr, skip_far):
+    def forward(ctx, rays, z, o2c, index, lbs_w, thr, skip_far, reuse=None, keep=None):
+        # reuse = (pts, nbr_idx, nbr_w, perm) of an earlier call on a subset of these samples (the coarse pass of the step):
+        # their rows are copied, not searched again; keep: a dict this call leaves its own (pts, nbr_idx, nbr_w) in
+        if reuse is not None and reuse[1] is not None:
+            reuse = (reuse[0], None, reuse[3], reuse[1], reuse[2])
+        else:
+            reuse = None
         pts, nidx, nw = ops.warp_points(index, o2c.detach(), lbs_w, thr, rays=rays.detach(), z=z.detach(),
-                                        skip_far=skip_far, neighbours=True)
+                                        skip_far=skip_far, neighbours=True, reuse=reuse)
+        if keep is not None:
+            keep["train"] = (pts, nidx, nw)
         ctx.save_for_backward(rays, z, o2c, nidx, nw)
         return pts
 
@@ -533,7 +543,7 @@ class WarpFunction(torch.autograd.Function):
             pad = torch.zeros_like(rays)
             pad[..., :8] = d_rays
             d_rays = pad
-        return d_rays, d_z, d_o2c, None, None, None, None
+        return d_rays, d_z, d_o2c, None, None, None, None, None, None
 
 
 class FrameChainFunction(torch.autograd.Function):

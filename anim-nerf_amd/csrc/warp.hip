@@ -551,7 +551,8 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
     float4* __restrict__ pts_out, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w, int32_t* __restrict__ list,
     int32_t* __restrict__ cells, int32_t* __restrict__ count, int32_t* __restrict__ cell_count,
     uint8_t* __restrict__ valid_mask, const float4* __restrict__ reuse_pts, const uint8_t* __restrict__ reuse_mask,
-    const uint8_t* __restrict__ perm, int reuse_K, int G) {
+    const uint8_t* __restrict__ perm, int reuse_K, int G, const int4* __restrict__ reuse_nbr_idx = nullptr,
+    const float4* __restrict__ reuse_nbr_w = nullptr) {
     static_assert(!VEC4 || FROM_RAYS, "four samples per thread: rays mode");
     __shared__ int wave_cnt[WARP_THREADS / 64];
     __shared__ int block_base;
@@ -625,10 +626,20 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
                     const int pj = VEC4 ? (int)((pm >> (8 * v)) & 0xffu) : (int)perm[o];
                     if (pj < reuse_K) {
                         const int64_t src = ((int64_t)b * R32 + ray) * reuse_K + pj;
-                        const uint8_t m = reuse_mask[src];
-                        if (VEC4) mask_out |= (unsigned)m << (8 * v);
-                        else valid_mask[o] = m;
-                        if (m) pts_out[o] = reuse_pts[src];
+                        if (reuse_mask != nullptr) {
+                            const uint8_t m = reuse_mask[src];
+                            if (VEC4) mask_out |= (unsigned)m << (8 * v);
+                            else valid_mask[o] = m;
+                            if (m) pts_out[o] = reuse_pts[src];
+                        } else {
+                            // training (no validity bytes): the coarse call's whole row — (x_c, 1) or (x, 0) — and, for the
+                            // backward pass, its neighbour ids and blend weights
+                            pts_out[o] = reuse_pts[src];
+                            if (nbr_w != nullptr) {
+                                reinterpret_cast<float4*>(nbr_w)[o] = reuse_nbr_w[src];
+                                reinterpret_cast<int4*>(nbr_idx)[o] = reuse_nbr_idx[src];
+                            }
+                        }
                         near = false;
                         reused = true;
                     }
@@ -1440,11 +1451,35 @@ extern "C" int anr_warp_points_lean(const float* xyz, int xyz_stride, const floa
                                     float* nbr_w_out, int32_t* ws, uint8_t* valid_mask_out, int32_t* valid_index_out,
                                     int32_t* valid_count_out, const float* reuse_pts, const uint8_t* reuse_mask,
                                     const uint8_t* reuse_perm, int reuse_K, void* stream) {
+    ANR_REQUIRE((reuse_pts != nullptr) == (reuse_mask != nullptr), ANR_E_BADARG,
+                "anr_warp_points_lean: reuse_pts / reuse_mask / reuse_perm go together");
+    return anr_warp_points_reuse(xyz, xyz_stride, rays, ray_stride, z, K, knn_index, ober2cano, lbs_weights, bs, V, J, N, dis_threshold,
+                                 skip_far, pts_out, dist_out, idx_out, blended_out, nbr_idx_out, nbr_w_out, ws, valid_mask_out,
+                                 valid_index_out, valid_count_out, reuse_pts, reuse_mask, reuse_perm, reuse_K, nullptr, nullptr, stream);
+}
+
+extern "C" int anr_warp_points_reuse(const float* xyz, int xyz_stride, const float* rays, int ray_stride, const float* z,
+                                     int K, const void* knn_index, const float* ober2cano, const float* lbs_weights, int bs,
+                                     int V, int J, int64_t N, float dis_threshold, int skip_far, float* pts_out,
+                                     float* dist_out, int32_t* idx_out, float* blended_out, int32_t* nbr_idx_out,
+                                     float* nbr_w_out, int32_t* ws, uint8_t* valid_mask_out, int32_t* valid_index_out,
+                                     int32_t* valid_count_out, const float* reuse_pts, const uint8_t* reuse_mask,
+                                     const uint8_t* reuse_perm, int reuse_K, const int32_t* reuse_nbr_idx, const float* reuse_nbr_w,
+                                     void* stream) {
     const bool lean = valid_mask_out != nullptr;
-    ANR_REQUIRE((reuse_pts != nullptr) == (reuse_mask != nullptr) && (reuse_pts != nullptr) == (reuse_perm != nullptr),
-                ANR_E_BADARG, "anr_warp_points_lean: reuse_pts / reuse_mask / reuse_perm go together");
-    ANR_REQUIRE(reuse_pts == nullptr || (lean && xyz == nullptr && reuse_K > 0 && reuse_K <= K && ((uintptr_t)reuse_pts & 15) == 0),
-                ANR_E_BADARG, "anr_warp_points_lean: reuse needs the validity outputs, rays mode, 0 < reuse_K <= K");
+    ANR_REQUIRE((reuse_pts != nullptr) == (reuse_perm != nullptr) && (reuse_mask == nullptr || reuse_pts != nullptr),
+                ANR_E_BADARG, "anr_warp_points: reuse_pts / reuse_perm (/ reuse_mask) go together");
+    ANR_REQUIRE(reuse_pts == nullptr || (skip_far && ws != nullptr && xyz == nullptr && reuse_K > 0 && reuse_K <= K &&
+                                         ((uintptr_t)reuse_pts & 15) == 0),
+                ANR_E_BADARG, "anr_warp_points: reuse needs skip_far with a workspace, rays mode, 0 < reuse_K <= K");
+    // with the validity outputs the coarse call's validity BYTES are copied; without them its whole rows (training)
+    ANR_REQUIRE(reuse_pts == nullptr || (lean == (reuse_mask != nullptr)), ANR_E_BADARG,
+                "anr_warp_points: reuse_mask goes with the validity outputs, and only with them");
+    ANR_REQUIRE((reuse_nbr_idx != nullptr) == (reuse_nbr_w != nullptr) &&
+                (reuse_nbr_idx == nullptr || (reuse_pts != nullptr && !lean && nbr_idx_out != nullptr)) &&
+                (reuse_pts == nullptr || lean || nbr_idx_out == nullptr || reuse_nbr_idx != nullptr) &&
+                (((uintptr_t)reuse_nbr_idx | (uintptr_t)reuse_nbr_w) & 15) == 0,
+                ANR_E_BADARG, "anr_warp_points: reuse_nbr_idx / reuse_nbr_w accompany reuse_pts exactly when the neighbour outputs are asked for");
     ANR_REQUIRE((valid_mask_out != nullptr) == (valid_index_out != nullptr) && (valid_mask_out != nullptr) == (valid_count_out != nullptr),
                 ANR_E_BADARG, "anr_warp_points_lean: valid_mask_out / valid_index_out / valid_count_out go together");
     ANR_REQUIRE(!lean || (skip_far && ws != nullptr), ANR_E_BADARG, "anr_warp_points_lean: the validity outputs need skip_far and ws");
@@ -1486,16 +1521,18 @@ extern "C" int anr_warp_points_lean(const float* xyz, int xyz_stride, const floa
             hipLaunchKernelGGL((warp_classify_kernel<true, true>), g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride, z,
                                K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
                                w.list, w.cells, w.count, w.cell_count, valid_mask_out,
-                               reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K, G);
+                               reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K, G,
+                               reinterpret_cast<const int4*>(reuse_nbr_idx), reinterpret_cast<const float4*>(reuse_nbr_w));
         else if (xyz == nullptr)
             hipLaunchKernelGGL((warp_classify_kernel<true, false>), g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride, z,
                                K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
                                w.list, w.cells, w.count, w.cell_count, valid_mask_out,
-                               reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K, G);
+                               reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K, G,
+                               reinterpret_cast<const int4*>(reuse_nbr_idx), reinterpret_cast<const float4*>(reuse_nbr_w));
         else
             hipLaunchKernelGGL((warp_classify_kernel<false, false>), g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride,
                                z, K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                               w.list, w.cells, w.count, w.cell_count, valid_mask_out, nullptr, nullptr, nullptr, 0, G);
+                               w.list, w.cells, w.count, w.cell_count, valid_mask_out, nullptr, nullptr, nullptr, 0, G, nullptr, nullptr);
         if (int rc = check_launch("anr_warp_points (classify)")) return rc;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

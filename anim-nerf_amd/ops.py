@@ -316,19 +316,25 @@ def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
         vmask = torch.empty(bs, N, dtype=torch.uint8, device=dev)
         vindex = torch.empty(bs * N, dtype=torch.int32, device=dev)
         vcount = torch.empty(1, dtype=torch.int32, device=dev)
-    r_pts = r_mask = r_perm = None
+    r_pts = r_mask = r_perm = r_nidx = r_nw = None
     r_k = 0
-    if reuse is not None:                   # (pts, valid bytes) of the coarse call + the merge's perm: see the header
-        if not lean or xyz is not None:
-            raise ValueError("reuse needs lean=True and rays mode")
-        r_pts, r_mask, r_perm = _dev(reuse[0], "reuse pts"), _dev(reuse[1], "reuse mask", torch.uint8), _dev(reuse[2], "perm", torch.uint8)
-        r_k = r_mask.numel() // (bs * (N // K))
+    if reuse is not None:
+        # inference (lean): (pts, valid bytes, perm) of the coarse call; training: (pts, None, perm, nbr_idx, nbr_w) — see the header
+        if xyz is not None or not (skip_far and two_pass):
+            raise ValueError("reuse needs rays mode, skip_far=True and two_pass=True")
+        if lean != (reuse[1] is not None):
+            raise ValueError("reuse: the coarse call's validity bytes go with lean=True, and only with it")
+        r_pts, r_perm = _dev(reuse[0], "reuse pts"), _dev(reuse[2], "perm", torch.uint8)
+        r_mask = None if reuse[1] is None else _dev(reuse[1], "reuse mask", torch.uint8)
+        r_k = r_pts.numel() // 4 // (bs * (N // K))
+        if neighbours:
+            r_nidx, r_nw = _dev(reuse[3], "reuse nbr_idx", torch.int32), _dev(reuse[4], "reuse nbr_w")
     with _timed("warp_points", bs * N):
-        _lib.check(lib.anr_warp_points_lean(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(index), _ptr(o2c),
-                                            _ptr(lbs_weights), bs, V, J, N, float(dis_threshold), 1 if skip_far else 0,
-                                            _ptr(pts), _ptr(dist), _ptr(idx), _ptr(blended), _ptr(nidx), _ptr(nw), _ptr(ws),
-                                            _ptr(vmask), _ptr(vindex), _ptr(vcount), _ptr(r_pts), _ptr(r_mask), _ptr(r_perm),
-                                            r_k, _stream(pts)),
+        _lib.check(lib.anr_warp_points_reuse(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(index), _ptr(o2c),
+                                             _ptr(lbs_weights), bs, V, J, N, float(dis_threshold), 1 if skip_far else 0,
+                                             _ptr(pts), _ptr(dist), _ptr(idx), _ptr(blended), _ptr(nidx), _ptr(nw), _ptr(ws),
+                                             _ptr(vmask), _ptr(vindex), _ptr(vcount), _ptr(r_pts), _ptr(r_mask), _ptr(r_perm),
+                                             r_k, _ptr(r_nidx), _ptr(r_nw), _stream(pts)),
                    "anr_warp_points")
     if lean:
         return pts, vmask, vindex, vcount

@@ -84,7 +84,14 @@ class VolumeRenderer(nn.Module):
                 lean_state["pts"], lean_state["valid"] = pts, valid
             out = net.eval_points(pts, valid_list=(vindex, vcount))
         elif fused:
-            pts = model.warped_points(rays=rays, z=z, skip_far=True)
+            # training: the fine pass re-visits the coarse samples — their warped rows (and, under pose refinement, neighbour ids
+            # and blend weights) are copied from the coarse call by the merge's permutation instead of being searched for again
+            reuse = None
+            if (lean_state is not None and not coarse and "train" in lean_state and "perm" in lean_state
+                    and getattr(self, "reuse_coarse_warp", True) and K <= 256):
+                reuse = lean_state["train"] + (lean_state["perm"],)
+            pts = model.warped_points(rays=rays, z=z, skip_far=True, reuse=reuse,
+                                      keep=lean_state if (coarse and lean_state is not None and model.use_unpose) else None)
             # with the warp on, only samples near the body carry a density: the MLP runs on those (bit-identical
             # render: the others composite with weight exactly 0)
             out = model._net(not coarse).eval_points(pts, only_valid=getattr(model, "evaluate_valid_only", False))
@@ -116,9 +123,11 @@ class VolumeRenderer(nn.Module):
         if torch.is_grad_enabled() and z_coarse.requires_grad:
             # torch.sort routes gradients of the sorted depths back to z_coarse (z_fine is detached, :200)
             from .autograd import FineMergeFunction
-            return FineMergeFunction.apply(z_coarse.view(bs * R, Kc), weights, u).view(bs, R, Kc + self.n_fine)
+            stash = lean_state if (lean_state is not None and "train" in lean_state and Kc + self.n_fine <= 256) else None
+            return FineMergeFunction.apply(z_coarse.view(bs * R, Kc), weights, u, stash).view(bs, R, Kc + self.n_fine)
         with torch.no_grad():
-            if lean_state is not None and "pts" in lean_state:       # the fine pass will copy the coarse samples' warps
+            if lean_state is not None and ("pts" in lean_state or "train" in lean_state) and Kc + self.n_fine <= 256:
+                # the fine pass will copy the coarse samples' warps
                 zs, perm = ops.sample_fine_merge(z_coarse.detach().view(bs * R, Kc), weights, u, want_perm=True, perm_u8=True)
                 lean_state["perm"] = perm
             else:

@@ -415,6 +415,7 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False):
     # host, not the GPU, sets the pace on a slow box).  More ranks: eager, the bucketed all-reduce overlapping backward.
     graphed = world == 1 and dev.type == "cuda" and not os.environ.get("ANR_BENCH_NO_GRAPH")
     trainer = ana.Trainer(model, ana.VolumeRenderer(n_coarse=64, n_fine=32), hp, body_model_params=table, graph=graphed)
+    trainer.renderer.reuse_coarse_warp = not os.environ.get("ANR_BENCH_NO_WARP_REUSE")     # (A/B switch for the fine pass's copy)
     frame_idx = (torch.arange(F, device=dev) * (114 // F) + rank) % 114      # a rank's own frames, as a distributed sampler deals them
     c2w, focal, cen = syn.pinhole_camera(32, 32)
     rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), 32, 32, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(F, 1, 1, 1)

@@ -183,6 +183,22 @@ int anr_warp_points_lean(const float* xyz, int xyz_stride,
                          uint8_t* valid_mask_out, int32_t* valid_index_out, int32_t* valid_count_out,
                          const float* reuse_pts, const uint8_t* reuse_mask, const uint8_t* reuse_perm, int reuse_K,
                          void* stream);
+/* ... and the same reuse for the TRAINING step (models/volume_rendering.py:199-207 + models/anim_nerf.py:153-192 under autograd:
+ * the fine pass of a step warps Kc + Kf sorted samples per ray, Kc of which the coarse pass has just warped).  Without the
+ * validity outputs (valid_mask_out = NULL) and with reuse_mask = NULL, sorted sample j of a ray with p = reuse_perm[j] < reuse_K
+ * takes the coarse call's WHOLE row reuse_pts[(ray, p)] = (x_c, valid) and — when nbr_idx_out / nbr_w_out are asked for — its
+ * neighbour ids and blend weights reuse_nbr_idx / reuse_nbr_w[bs*R*reuse_K*4] (what anr_warp_backward needs); only the Kf
+ * new samples are classified and searched.  Same bits as searching them again (z_sorted[j] IS z_coarse[p]).  With the validity
+ * outputs it is anr_warp_points_lean (reuse_nbr_* = NULL). */
+int anr_warp_points_reuse(const float* xyz, int xyz_stride,
+                          const float* rays, int ray_stride, const float* z, int K,
+                          const void* knn_index, const float* ober2cano, const float* lbs_weights,
+                          int bs, int V, int J, int64_t N, float dis_threshold, int skip_far,
+                          float* pts_out, float* dist_out, int32_t* idx_out, float* blended_out,
+                          int32_t* nbr_idx_out, float* nbr_w_out, int32_t* ws,
+                          uint8_t* valid_mask_out, int32_t* valid_index_out, int32_t* valid_count_out,
+                          const float* reuse_pts, const uint8_t* reuse_mask, const uint8_t* reuse_perm, int reuse_K,
+                          const int32_t* reuse_nbr_idx, const float* reuse_nbr_w, void* stream);
 
 /* Backward of anr_warp_points (rays mode) for pose refinement (a16): d_pts[bs*N*4] (w component ignored) ->
  * d_ober2cano[bs*V*16] and d_rays[bs*R*8] (ACCUMULATED with atomics: zero them first), d_z[bs*N] (written).

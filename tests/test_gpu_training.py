@@ -1256,3 +1256,36 @@ def test_prior_points_ride_with_the_render_pass(dev, smpl_table, monkeypatch):
         assert abs(res[0][1][k] - res[1][1][k]) <= 1e-5 * abs(res[1][1][k]) + 1e-9, k
     for a, b in zip(res[0][2], res[1][2]):
         assert (a - b).abs().max() <= 2e-5 * b.abs().max() + 1e-12
+
+
+@pytest.mark.parametrize("refine_pose", [True, False])
+def test_training_fine_pass_copies_the_coarse_samples_warp(dev, smpl_table, refine_pose):
+    """The fine pass of a training step warps 64 + 32 sorted samples per ray, 64 of which the coarse pass has just warped:
+    their rows (canonical point, validity and — under pose refinement — neighbour ids and blend weights) are copied by the
+    merge's permutation (anr_warp_points_reuse) instead of being searched for again.  Same rendered values bit for bit as with
+    `reuse_coarse_warp = False`, same gradients up to the order of the backward's atomic adds; perturb = 1 with injected
+    draws, pose refinement on and off."""
+    import anim_nerf_amd as ana
+    m, table, batch = _config3_scene(dev, smpl_table, F=4, H=16)
+    if not refine_pose:
+        for n in table.param_names:
+            table.set_requires_grad(n, False)
+    vr = ana.VolumeRenderer(n_coarse=64, n_fine=32)
+    res = []
+    for reuse in (True, False):
+        vr.reuse_coarse_warp = reuse
+        for p in list(m.parameters()) + list(table.parameters()):
+            p.grad = None
+        torch.manual_seed(9)
+        out = ana.system_forward(vr, m, batch["rays"], table(batch["frame_idx"][:4]), _templ(dev), perturb=1.0, chunk=1 << 20)
+        loss = sum(out[k].square().sum() for k in ("rgbs", "rgbs_fine", "alphas_fine", "depths_fine"))
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in list(m.named_parameters()) + list(table.named_parameters()) if p.grad is not None}
+        res.append(({k: v.detach().clone() for k, v in out.items()}, grads))
+    for k in res[0][0]:
+        assert torch.equal(res[0][0][k], res[1][0][k]), k
+    assert set(res[0][1]) == set(res[1][1]) and (not refine_pose or any("body_pose" in k for k in res[0][1]))
+    for k in res[0][1]:
+        a, b = res[0][1][k], res[1][1][k]
+        assert (a - b).abs().max() <= 2e-5 * b.abs().max() + 1e-12, k
+    assert res[0][0]["alphas_fine"].max() > 0.2

@@ -78,6 +78,7 @@ def test_bad_arguments_are_reported_not_crashed():
         "anr_mc_classify": (None, 8, 8, 8, 0.0, None, None, None, None, None),
         "anr_mc_emit": (None, 8, 8, 8, 0.0) + (None,) * 8,
         "anr_adam_step": (None, 1, None, None, 1, 0.9, 0.999, 1e-8, None),
+        "anr_warp_points_reuse": (None, 0, None, 8, None, 4, None, None, None, 1, 6890, 24, 8, 0.2, 1) + (None,) * 13 + (0, None, None, None),
     }
     for name, args in calls.items():
         if args is None:
