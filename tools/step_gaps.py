@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""From a rocprofv3 kernel trace of `bench.py --workload cfg4`: per training step (delimited by the fused-Adam launches),
+"""From a rocprofv3 kernel trace of `bench.py --workload cfg4`: per training step (delimited by the Adam launches),
 the step's wall time on the GPU, the sum of its kernel durations and the idle time between kernels; the median step, and its
 kernels ranked by time.   python tools/step_gaps.py <dir with *_kernel_trace.csv>"""
 import collections
@@ -10,7 +10,7 @@ import sys
 
 f = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)[0]
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))))
-ends = [i for i, r in enumerate(rows) if "FusedOptimizerTensorListMetadata" in r[2] or "fused_adam" in r[2].lower()]
+ends = [i for i, r in enumerate(rows) if "adam_kernel" in r[2] or "FusedOptimizerTensorListMetadata" in r[2]]
 # a step has a few Adam launches back to back: keep the last of each cluster
 last = [i for k, i in enumerate(ends) if k + 1 == len(ends) or ends[k + 1] - i > 5]
 steps = []
