@@ -1327,10 +1327,35 @@ __global__ __launch_bounds__(WARP_THREADS) void knn_kernel(const float* __restri
 // x = o' + z d'.  The neighbour ids and weights are constants (KNN is no_grad in the reference, anim_nerf.py:158).
 //   dM_{v_k}[r][c] += w_k * dxc[r] * [x,1][c]   (atomics: many samples share a vertex)
 //   dx = R_b^T dxc  ->  d o' += dx, d d' += z dx (atomics per ray), dz = dx . d'
-__global__ __launch_bounds__(256) void warp_backward_kernel(
+// dM: the samples of a workgroup (1,024 consecutive ones: ten to sixteen neighbouring rays) share their neighbour vertices —
+// ~300 live samples x 4 neighbours land on ~150 vertices — so the 12 entries per (sample, neighbour) are added into an LDS
+// table keyed by vertex (ds_add_f32, no return) and each distinct vertex goes to global memory once per workgroup: 48 global
+// float atomics per live sample became ~6.  A vertex that finds no slot within 16 probes takes the direct route.
+constexpr int WB_THREADS = 1024;
+constexpr int WB_SLOTS = 1024;
+__device__ __forceinline__ int wb_slot(int* keys, int v) {
+    unsigned s = ((unsigned)v * 2654435761u) >> 22;
+#pragma unroll 1
+    for (int t = 0; t < 16; ++t) {
+        const int prev = atomicCAS(&keys[s], -1, v);
+        if (prev == -1 || prev == v) return (int)s;
+        s = (s + 1) & (WB_SLOTS - 1);
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(WB_THREADS) void warp_backward_kernel(
     const float4* __restrict__ d_pts, const float* __restrict__ rays, int ray_stride, const float* __restrict__ z, int K,
     const float* __restrict__ ober2cano, const int4* __restrict__ nbr_idx, const float4* __restrict__ nbr_w, int V,
     int64_t N, float* __restrict__ d_o2c, float* __restrict__ d_rays, float* __restrict__ d_z) {
+    __shared__ int hkey[WB_SLOTS];
+    __shared__ float hval[WB_SLOTS][12];
+    for (int i = threadIdx.x; i < WB_SLOTS; i += WB_THREADS) {
+        hkey[i] = -1;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) hval[i][e] = 0.f;
+    }
+    __syncthreads();
     const int b = blockIdx.y;
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = n < N;
@@ -1355,13 +1380,15 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(
         for (int k = 0; k < 4; ++k) {
             if (w[k] == 0.f) continue;
             const float* M = ober2cano + ((int64_t)b * V + vid[k]) * 16;
-            float* dM = d_o2c + ((int64_t)b * V + vid[k]) * 16;
+            const int slot = wb_slot(hkey, vid[k]);
+            float* dM = slot >= 0 ? &hval[slot][0] : d_o2c + ((int64_t)b * V + vid[k]) * 16;
+            const int pitch = slot >= 0 ? 4 : 4;                 // (rows of 4 in both places: [3][4] of the table, [4][4] of M)
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) Rb[r * 3 + c] += w[k] * M[r * 4 + c];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) atomicAdd(dM + r * 4 + c, w[k] * gv[r] * x[c]);
+                for (int c = 0; c < 4; ++c) atomicAdd(dM + r * pitch + c, w[k] * gv[r] * x[c]);
             }
         }
         float dx[3];
@@ -1399,6 +1426,16 @@ __global__ __launch_bounds__(256) void warp_backward_kernel(
         }
     }
     if (in_range) d_z[o] = dzv;
+    // the table's vertices -> global memory, once each
+    __syncthreads();
+    for (int i = threadIdx.x; i < WB_SLOTS; i += WB_THREADS) {
+        const int v = hkey[i];
+        if (v < 0) continue;
+        float* dM = d_o2c + ((int64_t)b * V + v) * 16;
+#pragma unroll
+        for (int e = 0; e < 12; ++e)
+            if (hval[i][e] != 0.f) atomicAdd(dM + e, hval[i][e]);
+    }
 }
 
 template <typename Kern>
@@ -1623,8 +1660,8 @@ extern "C" int anr_warp_backward(const float* d_pts, const float* rays, int ray_
                 "anr_warp_backward: bs=%d V=%d N=%lld K=%d", bs, V, (long long)N, K);
     ANR_REQUIRE((((uintptr_t)d_pts | (uintptr_t)nbr_idx | (uintptr_t)nbr_w) & 15) == 0, ANR_E_ALIGN,
                 "anr_warp_backward: d_pts / nbr_idx / nbr_w must be 16-B aligned");
-    dim3 grid((unsigned)((N + 255) / 256), bs);
-    hipLaunchKernelGGL(warp_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+    dim3 grid((unsigned)((N + WB_THREADS - 1) / WB_THREADS), bs);
+    hipLaunchKernelGGL(warp_backward_kernel, grid, dim3(WB_THREADS), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(d_pts), rays, ray_stride, z, K, ober2cano,
                        reinterpret_cast<const int4*>(nbr_idx), reinterpret_cast<const float4*>(nbr_w), V, N,
                        d_ober2cano, d_rays, d_z);
