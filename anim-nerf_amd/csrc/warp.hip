@@ -498,11 +498,12 @@ constexpr float MIN_CELL = 0.04f;
 struct WarpWs {
     int32_t *list, *cells, *sorted, *count, *cursor, *live, *occ_count, *occ_cursor, *cell_count, *cell_start, *occ_list, *cell_seed;
     float* cell_cap2;
-    __host__ static int64_t ints(int bs, int64_t N) { return 3 * (int64_t)bs * N + 5 * bs + 5 * (int64_t)bs * NCELL; }
-    __host__ static int64_t zeroed_ints(int bs) { return 5 * bs + (int64_t)bs * NCELL; }      // from `count` on
+    static constexpr int CURSORS = 16;          // cursor rows per body (the small-batch search cuts a body's list into segments)
+    __host__ static int64_t ints(int bs, int64_t N) { return 3 * (int64_t)bs * N + (4 + CURSORS) * bs + 5 * (int64_t)bs * NCELL; }
+    __host__ static int64_t zeroed_ints(int bs) { return (4 + CURSORS) * bs + (int64_t)bs * NCELL; }      // from `count` on
     __host__ WarpWs(int32_t* ws, int bs, int64_t N) {
         list = ws; cells = list + (int64_t)bs * N; sorted = cells + (int64_t)bs * N; count = sorted + (int64_t)bs * N;
-        cursor = count + bs; live = cursor + bs; occ_count = live + bs; occ_cursor = occ_count + bs;
+        cursor = count + bs; live = cursor + CURSORS * bs; occ_count = live + bs; occ_cursor = occ_count + bs;
         cell_count = occ_cursor + bs; cell_start = cell_count + (int64_t)bs * NCELL;
         cell_cap2 = reinterpret_cast<float*>(cell_start + (int64_t)bs * NCELL);
         occ_list = cell_start + 2 * (int64_t)bs * NCELL;
@@ -1054,10 +1055,21 @@ __device__ __forceinline__ unsigned group8_min(unsigned v) {
 __device__ __forceinline__ unsigned pick_key(float dist, float bound, unsigned tag, unsigned tag_mask) {
     return dist <= bound ? ((__float_as_uint(dist) & ~tag_mask) | tag) : PICK_NONE;
 }
-constexpr int GPOOL = 16;                      // list entries a wavefront takes per trip to the cursor (2 per group): a training
+#ifndef ANR_GPOOL
+#define ANR_GPOOL 8
+#endif
+constexpr int GPOOL = ANR_GPOOL;               // list entries a wavefront takes per trip to a cursor (one per group): a training
                                                // batch has ~100 near samples per wavefront, and a run of 64 consecutive ones is
                                                // either all empty space or all torso — with 64 per trip the wavefronts were
-                                               // resident 28 % of the kernel's time on average, waiting for the unlucky ones
+                                               // resident 28 % of the kernel's time on average, waiting for the unlucky ones.
+                                               // Pool x cursors per body, ms per call (16 bodies x 65,536 samples): 16 x 1: 0.48,
+                                               // 8 x 1: 0.61 (256 wavefronts queue on the one cursor: ~20 us per trip), 16 x 4: 0.39,
+                                               // 8 x 4: 0.38, 8 x 8: 0.36, 8 x 16: 0.37, 4 x 16: 0.40, 16 x 16: 0.41
+#ifndef ANR_GSEG
+#define ANR_GSEG 8
+#endif
+constexpr int GSEG = ANR_GSEG;                 // cursors per body (<= WarpWs::CURSORS rows of the workspace): a body's list is cut
+                                               // into that many segments, a wavefront starts on segment (its number mod GSEG)
 constexpr int GQ_ENTRIES = 64;                 // blend queue per wavefront: {sample, slots 0|1, slots 2|3}
 constexpr int GQ_BYTES = GQ_ENTRIES * 12;
 
@@ -1079,7 +1091,13 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_groups_kernel(
         if ((int)blockIdx.x * (WARP_THREADS / 64) * 8 >= cnt) continue;  // not even one sample per group left
     } else {
         __syncthreads();                                                 // every wavefront is done with the index in LDS
-        if (threadIdx.x == 0) body_open = __hip_atomic_load(cursor + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt;
+        if (threadIdx.x == 0) {
+            const int sl = ((cnt + GSEG - 1) / GSEG + GPOOL - 1) / GPOOL * GPOOL;
+            bool open = false;
+            for (int q = 0; q < GSEG; ++q)
+                open |= q * sl + __hip_atomic_load(cursor + q * (int)gridDim.y + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < min(cnt, (q + 1) * sl);
+            body_open = open;
+        }
         __syncthreads();
         if (!body_open) continue;
     }
@@ -1118,6 +1136,8 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_groups_kernel(
     };
 
     // the pool: GPOOL list entries and their points, one per lane
+    const int seg_len = ((cnt + GSEG - 1) / GSEG + GPOOL - 1) / GPOOL * GPOOL;
+    int seg = ((int)blockIdx.x * (WARP_THREADS / 64) + wave) % GSEG, seg_tried = 0;
     int pool_smp = 0, pool_n = 0, pool_next = 0;
     float pool_x = 0.f, pool_y = 0.f, pool_z = 0.f;
     bool list_done = false;
@@ -1146,11 +1166,18 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_groups_kernel(
         while (idle_groups) {
             if (pool_next >= pool_n) {
                 if (list_done) break;
-                int base = 0;
-                if (lane == 0) base = atomicAdd(cursor + b, GPOOL);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= cnt) { list_done = true; break; }
-                pool_n = min(GPOOL, cnt - base);
+                // a body's list is cut into GSEG segments with a cursor each (256 wavefronts on ONE cursor wait ~20 us per trip)
+                int base = 0, seg_end = 0;
+                for (;;) {
+                    if (lane == 0) base = atomicAdd(cursor + seg * (int)gridDim.y + b, GPOOL);
+                    base = seg * seg_len + __builtin_amdgcn_readfirstlane(base);
+                    seg_end = min(cnt, (seg + 1) * seg_len);
+                    if (base < seg_end) break;
+                    seg = (seg + 1) % GSEG;
+                    if (++seg_tried == GSEG) break;
+                }
+                if (base >= seg_end) { list_done = true; break; }
+                pool_n = min(GPOOL, seg_end - base);
                 pool_next = 0;
                 if (lane < pool_n) {
                     pool_smp = my_list[base + lane];
