@@ -284,7 +284,24 @@ class GradientReducer:
         # accumulation raises it, the kernels that add into the buffer through raw pointers (GradSink) do not
         self._ver = [f._version for f in self.flat]
 
+    # deferred: hooks and finish() issue nothing; the caller reduces the buffers itself afterwards (`reduce_flat`).  What a
+    # captured forward + backward runs with: a collective cannot be issued from inside the capture on every backend, and
+    # two 2.4 MB buckets cost ~0.1 ms against a 5 ms step, so overlapping them with backward buys nothing there.
+    deferred = False
+
+    def reduce_flat(self):
+        """All-reduce + average the flat buffers now (the deferred mode's counterpart of the hooks + finish())."""
+        self._probe()
+        if not self.active:
+            return 0
+        for flat in self.flat:
+            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM)
+            flat.div_(self.world)
+        return sum(f.numel() for f in self.flat)
+
     def _issue_ready(self, force=False):
+        if self.deferred:
+            return
         while self._next < len(self.buckets) and (force or self._pending[self._next] == 0):
             self._handles.append(self.dist.all_reduce(self.flat[self._next], op=self.dist.ReduceOp.SUM, async_op=True))
             self._next += 1
@@ -312,6 +329,8 @@ class GradientReducer:
 
     def finish(self):
         """After backward: issue what is left (in order), wait, average.  Returns the number of floats reduced."""
+        if self.deferred:
+            return 0
         if not self.active:
             if self.dist.is_available() and self.dist.is_initialized() and self.dist.get_world_size() > 1:
                 raise RuntimeError("the process group came up between prepare() and finish(): gradients of this step "
@@ -429,6 +448,7 @@ class Trainer:
         self.graph_enabled = bool(graph)
         self._graph = None                                    # (signature, CUDAGraph, static inputs, static outputs)
         self._graph_warm = 0
+        self._graph_split = False                             # the graph ends with backward (more than one rank)
         for name, p in anim_nerf.named_parameters():          # SMPL member params are unused by the forward
             if name.startswith("body_model."):
                 p.requires_grad_(False)
@@ -510,12 +530,12 @@ class Trainer:
     def step_graphed(self, rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points=None, bg_points=None,
                      perturb=1.0, frame_idx=None):
         """`step` with the same arguments and results, replayed from a HIP graph once the shapes have been seen
-        GRAPH_WARM_STEPS times (those steps, and every step of a Trainer built without graph=True or of a process group
-        with more than one rank, run eagerly).  Inputs are copied into the graph's own buffers, the loss and the details
+        GRAPH_WARM_STEPS times (those steps, and every step of a Trainer built without graph=True, run eagerly).  In a
+        process group with more than one rank the graph holds forward + backward; the all-reduce of the two flat gradient
+        buffers and Adam follow each replay.  Inputs are copied into the graph's own buffers, the loss and the details
         come back as fresh tensors; random draws (stratified offsets, sigma noise, loss points) advance per replay through
         the generator state torch registers with the graph."""
-        dist = torch.distributed
-        eager = (not self.graph_enabled or not rays.is_cuda or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1))
+        eager = not self.graph_enabled or not rays.is_cuda
         args = {"rays": rays, "rgbs": rgbs, "alphas": alphas, "bmp": body_model_params, "templ": body_model_params_template,
                 "fg": fg_points, "bg": bg_points, "frame_idx": frame_idx}
 
@@ -528,8 +548,11 @@ class Trainer:
             return self._step_graphed(args, leaves, perturb, eager)
 
     def _step_graphed(self, args, leaves, perturb, eager):
-        shapes = (float(perturb), tuple((n, tuple(t.shape), t.dtype) for n, t in leaves))
-        baked = tuple(float(g["lr"]) for g in self.optimizer.param_groups)      # host values a capture freezes
+        dist = torch.distributed
+        split = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        shapes = (float(perturb), bool(split), tuple((n, tuple(t.shape), t.dtype) for n, t in leaves))
+        # host values a capture freezes (none when the optimiser step stays outside the graph)
+        baked = () if split else tuple(float(g["lr"]) for g in self.optimizer.param_groups)
         sig = (shapes, baked)
         if not eager and (self._graph is None or self._graph[0] != sig):
             if self._graph is not None and self._graph[0][0] == shapes:
@@ -549,6 +572,9 @@ class Trainer:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         graph.replay()
+        if self._graph_split:                                  # more than one rank: the graph ends with backward
+            self.reducer.reduce_flat()
+            self.optimizer.step()
         from .autograd import bump_generation
         bump_generation(self.params)                          # the packs cached under the old generation belong to the graph
         loss, details = outs
@@ -564,10 +590,18 @@ class Trainer:
         st = {k: rebuild(args[k], it) for k in sorted(args)}
         torch.cuda.synchronize()
         self._graph = None                                    # (a previous capture's pool goes back to the allocator first)
+        # More than one rank: the graph holds forward + backward into the flat buffers; the all-reduce of those buffers and
+        # Adam follow each replay eagerly (3 launches + 2 collectives instead of ~190 launches).
+        split = sig[0][1]
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=self._stream):
-            loss, details = self._step_body(st["rays"], st["rgbs"], st["alphas"], st["bmp"], st["templ"], st["fg"], st["bg"],
-                                            perturb, st["frame_idx"])
+        self.reducer.deferred = split
+        try:
+            with torch.cuda.graph(graph, stream=self._stream):
+                loss, details = self._step_body(st["rays"], st["rgbs"], st["alphas"], st["bmp"], st["templ"], st["fg"], st["bg"],
+                                                perturb, st["frame_idx"], apply=not split)
+        finally:
+            self.reducer.deferred = False
+        self._graph_split = split
         self._graph = (sig, graph, static_leaves, (loss, details))
 
     def step(self, rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points=None, bg_points=None,
@@ -584,7 +618,7 @@ class Trainer:
         return loss, details
 
     def _step_body(self, rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points, bg_points, perturb,
-                   frame_idx):
+                   frame_idx, apply=True):
         self.begin_step()                                     # grads are views into the (zeroed) flat buffers
         if self.body_model_params is not None and frame_idx is not None:
             body_model_params = self.body_model_params(frame_idx)
@@ -593,9 +627,13 @@ class Trainer:
                                  perturb=perturb, chunk=self.hp.chunk)
         loss, details = compute_loss(self.model, self.hp, rgbs, alphas, results, fg_points, bg_points)
         loss.backward()                                       # full buckets are all-reduced while this is still running
-        self.reducer.finish()
-        self.optimizer.step()
         with torch.no_grad():
             key = "rgbs_fine" if "rgbs_fine" in results else "rgbs"
             details["psnr"] = -10.0 * torch.log10(F.mse_loss(results[key], rgbs))
+        if apply:
+            self._apply_gradients()
         return loss.detach(), details
+
+    def _apply_gradients(self):
+        self.reducer.finish()
+        self.optimizer.step()

@@ -411,9 +411,10 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False):
     seeded = syn.animated_pose_params(seed=200, bs=114)        # the SAME table on every rank: its gradients are all-reduced
     for name in table.param_names:                            # optim_body_params: True
         table.init_parameters(name, torch.from_numpy(seeded[name]).to(dev), requires_grad=True)
-    # one rank: the whole step replayed from ONE HIP graph (Trainer.step_graphed; ~190 launches per step otherwise, and the
-    # host, not the GPU, sets the pace on a slow box).  More ranks: eager, the bucketed all-reduce overlapping backward.
-    graphed = world == 1 and dev.type == "cuda" and not os.environ.get("ANR_BENCH_NO_GRAPH")
+    # the step replayed from a HIP graph (Trainer.step_graphed; ~190 launches per step otherwise, and the host, not the GPU,
+    # sets the pace on a slow box): one rank — the whole step; more ranks — forward + backward, then the all-reduce of the two
+    # flat gradient buffers and Adam.  ANR_BENCH_NO_GRAPH=1: eager, the bucketed all-reduce overlapping backward.
+    graphed = dev.type == "cuda" and not os.environ.get("ANR_BENCH_NO_GRAPH")
     trainer = ana.Trainer(model, ana.VolumeRenderer(n_coarse=64, n_fine=32), hp, body_model_params=table, graph=graphed)
     trainer.renderer.reuse_coarse_warp = not os.environ.get("ANR_BENCH_NO_WARP_REUSE")     # (A/B switch for the fine pass's copy)
     frame_idx = (torch.arange(F, device=dev) * (114 // F) + rank) % 114      # a rank's own frames, as a distributed sampler deals them
@@ -453,12 +454,14 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False):
         "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "dtype": mode,
         "config": {"workload": "BASELINE configs[3] shape: train step, %d frames x 32x32 rays per GPU, 64 coarse + 32 fine, "
                                "perturb=1, rgb + alpha + fg/bg + normals losses (reference defaults), pose refinement on (optim_body_params), "
-                               "bucketed gradient all-reduce (2 x 2.4 MB, overlapped with backward) + Adam" % F,
+                               "%s + Adam" % (F, "gradient all-reduce (2 x 2.4 MB flat buffers, after the replayed backward)" if graphed
+                                              else "bucketed gradient all-reduce (2 x 2.4 MB, overlapped with backward)"),
                    "mlp_on_valid_samples_only": bool(model.evaluate_valid_only),
                    "mlp_rows_per_step": per_kernel.get("mlp_forward_save", {"units": 0})["units"] // max(eager_steps, 1),
                    "rays_per_step_per_gpu": n_rays, "grad_floats": sum(p.numel() for p in trainer.params),
                    "kernel_launches_timed_per_step": sum(v["launches"] for v in per_kernel.values()) // max(eager_steps, 1),
-                   "step_launch": ("one HIP graph replay per step (captured after %d eager steps, untimed); per-kernel times from "
+                   "step_launch": (("one HIP graph replay per step" if world == 1 else "forward + backward as one HIP graph replay per step")
+                                   + " (captured after %d eager steps, untimed); per-kernel times from "
                                    "%d eager steps after the timed region, %.2f ms per step there"
                                    % (trainer.GRAPH_WARM_STEPS, eager_steps, eager_elapsed / eager_steps * 1e3)) if graphed
                    else "eager: one launch per kernel"},

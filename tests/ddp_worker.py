@@ -65,6 +65,26 @@ def main():
     both = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
     assert all(torch.equal(both[0], b) for b in both[1:]), "parameters differ between ranks after the step"
+    # The graphed step with more than one rank: forward + backward replayed from a HIP graph, the all-reduce of the flat buffers
+    # and Adam after each replay.  Same trajectory as the eager step (overlapped bucket all-reduce) on a copy of the model.
+    import copy
+    hp2 = ana.TrainHParams(n_samples=16, n_importance=8, chunk=64, lambda_normals=0.0, lr=1e-3)
+    base = seeded_model(tbl, g["seed"], True, g["gain"], g["shift"], device=dev)
+    me, mg = copy.deepcopy(base), copy.deepcopy(base)
+    te, tg = ana.Trainer(me, vr, hp2), ana.Trainer(mg, vr, hp2, graph=True)
+    for it in range(6):
+        le, _ = te.step(rays, tgt, alp, pose, templ, fg, bg, perturb=0.0)
+        lg, _ = tg.step_graphed(rays, tgt, alp, pose, templ, fg, bg, perturb=0.0)
+        assert abs(float(le) - float(lg)) <= 2e-3 * abs(float(le)), (rank, it, float(le), float(lg))
+    assert tg._graph is not None and tg._graph_split and te._graph is None
+    for (k, a), (_, b) in zip(me.named_parameters(), mg.named_parameters()):
+        if a.requires_grad:
+            d = (a - b).abs()
+            assert d.max() <= 2.0 * hp2.lr and d.mean() <= 0.02 * hp2.lr, (rank, k, float(d.max()), float(d.mean()))
+    flat = torch.cat([p.detach().reshape(-1) for p in tg.params]).cpu()
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert all(torch.equal(both[0], b) for b in both[1:]), "parameters differ between ranks after the graphed steps"
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}: ok")
