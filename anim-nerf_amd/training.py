@@ -555,15 +555,22 @@ class Trainer:
         baked = () if split else tuple(float(g["lr"]) for g in self.optimizer.param_groups)
         sig = (shapes, baked)
         if not eager and (self._graph is None or self._graph[0] != sig):
-            if self._graph is not None and self._graph[0][0] == shapes:
-                self._capture(sig, args, leaves, perturb)       # the scheduler moved the learning rates: capture again
-            elif self._graph is not None or self._graph_warm < self.GRAPH_WARM_STEPS:
+            if self._graph is not None and self._graph[0][0] != shapes or (self._graph is None and self._graph_warm < self.GRAPH_WARM_STEPS):
                 # (other shapes — the short last batch of an epoch — are not captured: one graph per Trainer, the step stays
                 # correct through the eager path)
                 self._graph_warm += 1
                 eager = True
             else:
-                self._capture(sig, args, leaves, perturb)
+                # first capture, or the scheduler moved the learning rates: capture again
+                try:
+                    self._capture(sig, args, leaves, perturb)
+                except Exception as exc:                        # a capture that fails must not cost the step: eager from here on
+                    import warnings
+                    from .autograd import bump_generation
+                    warnings.warn(f"Trainer: graph capture failed ({type(exc).__name__}: {exc}); continuing with eager steps")
+                    self._graph, self.graph_enabled, eager = None, False, True
+                    self.reducer.deferred = False
+                    bump_generation(self.params)                # nothing cached during the capture survives it
         if eager:
             return self.step(args["rays"], args["rgbs"], args["alphas"], args["bmp"], args["templ"], args["fg"], args["bg"],
                              perturb=perturb, frame_idx=args["frame_idx"])

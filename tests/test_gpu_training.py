@@ -1162,6 +1162,18 @@ def test_graphed_training_step_equals_the_eager_step(dev, smpl_table):
     loss, _ = tr.step_graphed(batch["rays"][:2], batch["rgbs"][:2], batch["alphas"][:2], None, _templ(dev), batch["fg"][:2],
                               batch["bg"][:2], perturb=1.0, frame_idx=batch["frame_idx"][:2])
     assert torch.isfinite(loss) and tr._graph[0][0][2][0][1] != tuple(batch["alphas"][:2].shape)
+    # a capture that fails costs nothing but the graph: the step goes on eagerly
+    tr2 = ana.Trainer(copy.deepcopy(m0), ana.VolumeRenderer(n_coarse=32, n_fine=16), hp2, body_model_params=copy.deepcopy(table0), graph=True)
+
+    def broken(*a, **k):
+        raise RuntimeError("no capture today")
+    tr2._capture = broken
+    with pytest.warns(UserWarning, match="graph capture failed"):
+        for it in range(5):
+            loss, _ = tr2.step_graphed(batch["rays"], batch["rgbs"], batch["alphas"], None, _templ(dev), batch["fg"], batch["bg"],
+                                       perturb=1.0, frame_idx=batch["frame_idx"])
+            assert torch.isfinite(loss)
+    assert tr2._graph is None and not tr2.graph_enabled
 
 
 def test_flat_adam_equals_torch_adam(dev):
