@@ -552,6 +552,12 @@ def main():
             # stops there with the headline printed — the others would otherwise wait in the next barrier (which, like
             # every collective here, also carries a timeout)
             try:
+                # every workload starts with an empty allocator cache: the previous one's blocks (a training graph's private
+                # pool, 2-GB grid chunks) otherwise decide whether this one's first allocations are cache hits or hipMallocs
+                import gc
+                gc.collect()
+                if ctx.dev.type == "cuda":
+                    torch.cuda.empty_cache()
                 got, err = brief(fn(*a, **kw), *keep), None
             except Exception as exc:                        # noqa: BLE001
                 got, err = None, f"{type(exc).__name__}: {exc}"[:300]
@@ -572,7 +578,7 @@ def main():
                               keep=("roofline_hbm_kernels", "kernel_time_share", "oracle_check", "cpu_baseline"))
             w["cfg3_dense"] = extra(render_bench, args, ctx, True, args.mode, 2, 1, dense=True)
             w["cfg4"] = extra(train_bench, args, ctx, args.mode, 8, 4, keep=("kernel_time_share", "final_loss"))
-            w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 1)
+            w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 2)
         else:
             # N > 1: the strong-scaling counterpart of the headline (one frame's rays sliced over the ranks), the warp
             # workload, and the training step with its RCCL gradient buckets
@@ -580,7 +586,7 @@ def main():
             w["cfg3"] = extra(render_bench, args, ctx, True, args.mode, 3, 1)
             w["cfg3_strong"] = extra(render_bench, args, ctx, True, args.mode, 3, 1, scaling="strong")
             w["cfg4"] = extra(train_bench, args, ctx, args.mode, 8, 4, keep=("final_loss",))
-            w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 1)
+            w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 2)
         result["workloads"] = w
 
     if rank == 0:
