@@ -442,7 +442,9 @@ class Trainer:
                  graph: bool = False):
         """graph=True: `step_graphed` may capture the whole step (forward, losses, backward, Adam) into ONE HIP graph and
         replay it — ~190 launches per step leave the host as one (the step holds no device -> host read: row counts stay
-        on the device; FlatAdam keeps its step counter there too)."""
+        on the device; FlatAdam keeps its step counter there too).  Opt-in: on ROCm 7.2 a long run (> 50 replays) that then
+        called torch.cuda.synchronize() followed by .item() reads and went on replaying ended in a GPU memory fault (DESIGN.md
+        section 4.4, tools/soak_train.py) — read progress scalars without a device synchronise in front, or use `step`."""
         self.model, self.renderer, self.hp = anim_nerf, volume_renderer, hp
         self.body_model_params = body_model_params
         self.graph_enabled = bool(graph)
