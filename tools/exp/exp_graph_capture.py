@@ -128,6 +128,14 @@ if "sg" in stage:
                                   frame_idx=fidx if use_table else None)
     torch.cuda.synchronize()
     print("ms per graphed step", (time.perf_counter() - t0) / 50 * 1e3, float(loss))
+    if os.environ.get("HAZARD"):
+        torch.cuda.synchronize()
+        torch.ones(3, device=dev).sum().item()
+        for it in range(5):
+            loss, _ = tr.step_graphed(rays, rgbs, alphas, None if use_table else pose, templ, fg, bg, perturb=0.0 if "noperturb" in stage else 1.0,
+                                      frame_idx=fidx if use_table else None)
+        torch.cuda.synchronize()
+        print(stage, "hazard sequence survived", float(loss), flush=True)
     raise SystemExit(0)
 for _ in range(3):
     ref = body()
@@ -137,9 +145,22 @@ for _ in range(3):
 torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
 print(stage, "capturing", flush=True)
-with torch.cuda.graph(g):
+side = torch.cuda.Stream()
+with torch.cuda.graph(g, stream=side):
     out = body()
 print(stage, "captured", flush=True)
 g.replay()
 torch.cuda.synchronize()
+if os.environ.get("HAZARD"):
+    # the sequence of tools/soak_train.py: replays on a side stream, device synchronise, work on the default stream, replays
+    with torch.cuda.stream(side):
+        for _ in range(int(os.environ["HAZARD"])):
+            g.replay()
+    torch.cuda.synchronize()
+    torch.ones(3, device=dev).sum().item()
+    with torch.cuda.stream(side):
+        for _ in range(5):
+            g.replay()
+    torch.cuda.synchronize()
+    print(stage, "hazard sequence survived", flush=True)
 print(stage, "replayed OK", float(out.float().abs().sum()), float(ref.float().abs().sum()), flush=True)
