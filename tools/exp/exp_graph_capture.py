@@ -10,7 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import anim_nerf_amd as ana                                  # noqa: E402
 from anim_nerf_amd import synthetic as syn                   # noqa: E402
 
-stage = sys.argv[1]
+full_stage = sys.argv[1]
+stage = full_stage.replace("_bump", "") if not full_stage.startswith("trainer") else full_stage
 dev = torch.device("cuda:0")
 tbl = syn.make_smpl_table(0)
 torch.manual_seed(0)
@@ -110,7 +111,7 @@ if stage.startswith("trainer"):
 
 
 def bump():
-    if "bump" in stage:
+    if "bump" in full_stage:
         from anim_nerf_amd.autograd import bump_generation
         bump_generation([p for p in m.parameters()])
 
