@@ -26,6 +26,11 @@ pts = torch.rand(4096, 4, device=dev)
 pts[:, 3] = 1.0
 
 
+_g = torch.Generator().manual_seed(17)
+loss_rgb = torch.rand(F, H, H, 3, generator=_g).to(dev)
+loss_alp = (torch.rand(F, H, H, 1, generator=_g) > 0.5).float().to(dev)
+
+
 def body():
     if stage == "torch":
         return (pts * 2).sum()
@@ -45,6 +50,16 @@ def body():
         with torch.no_grad():
             m.set_body_model(pose, templ)
             return m.verts
+    if stage in ("sysfwd_simple", "sysfwd_loss", "sysfwd_termloss"):
+        # system_forward + (simple | fused | term-by-term) loss + backward
+        res = ana.system_forward(vr, m, rays, pose, templ, perturb=0.0, chunk=1 << 20)
+        if stage == "sysfwd_simple":
+            loss = res["rgbs_fine"].square().mean() + res["rgbs"].square().mean()
+        else:
+            hp_l = ana.TrainHParams(n_samples=32, n_importance=16, lambda_normals=0.0, fused_losses=stage == "sysfwd_loss")
+            loss = ana.compute_loss(m, hp_l, loss_rgb, loss_alp, res, None, None)[0]
+        loss.backward()
+        return loss.detach()
     if stage in ("warp", "render", "render_grad", "step", "fwd_bwd"):
         ctx = torch.no_grad() if stage in ("warp", "render") else torch.enable_grad()
         with ctx:
@@ -138,15 +153,25 @@ if "sg" in stage:
         torch.cuda.synchronize()
         print(stage, "hazard sequence survived", float(loss), flush=True)
     raise SystemExit(0)
-for _ in range(3):
-    ref = body()
-    bump()
-    for p in m.parameters():
-        p.grad = None
+if os.environ.get("WITH_TRAINER"):       # a Trainer exists (hooks, sinks, flat buffers, its stream) but the body does not go through it
+    tr = ana.Trainer(m, vr, ana.TrainHParams(n_samples=32, n_importance=16, lambda_normals=0.0), graph=True)
+    if os.environ["WITH_TRAINER"] == "prepare":
+        _body0 = body
+        def body():
+            tr.begin_step()
+            return _body0()
+side = tr._stream if ((stage.startswith("trainer") or os.environ.get("WITH_TRAINER")) and tr._stream is not None) else torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for _ in range(3):
+        ref = body()
+        bump()
+        if not stage.startswith("trainer"):
+            for p in m.parameters():
+                p.grad = None
 torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
 print(stage, "capturing", flush=True)
-side = torch.cuda.Stream()
 with torch.cuda.graph(g, stream=side):
     out = body()
 print(stage, "captured", flush=True)
