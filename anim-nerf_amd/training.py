@@ -442,15 +442,16 @@ class Trainer:
                  graph: bool = False):
         """graph=True: `step_graphed` may capture the whole step (forward, losses, backward, Adam) into ONE HIP graph and
         replay it — ~190 launches per step leave the host as one (the step holds no device -> host read: row counts stay
-        on the device; FlatAdam keeps its step counter there too).  Opt-in: on ROCm 7.2 a long run (> 50 replays) that then
-        called torch.cuda.synchronize() followed by .item() reads and went on replaying ended in a GPU memory fault (DESIGN.md
-        section 4.4, tools/soak_train.py) — read progress scalars without a device synchronise in front, or use `step`."""
+        on the device; FlatAdam keeps its step counter there too).  Opt-in, and meant to be driven inside `with
+        trainer.loop():` — from the default stream, a run that called torch.cuda.synchronize(), touched the default stream and
+        went on replaying ended in a GPU memory fault on ROCm 7.2 (tools/soak_train.py)."""
         self.model, self.renderer, self.hp = anim_nerf, volume_renderer, hp
         self.body_model_params = body_model_params
         self.graph_enabled = bool(graph)
         self._graph = None                                    # (signature, CUDAGraph, static inputs, static outputs)
         self._graph_warm = 0
         self._graph_split = False                             # the graph ends with backward (more than one rank)
+        self._warned_stream = False
         for name, p in anim_nerf.named_parameters():          # SMPL member params are unused by the forward
             if name.startswith("body_model."):
                 p.requires_grad_(False)
@@ -497,6 +498,22 @@ class Trainer:
             if on_gpu:
                 for net in nets:
                     self.reducer.attach_sink(net)
+
+    @property
+    def stream(self):
+        """The stream a graphed Trainer works on (None otherwise)."""
+        return self._stream
+
+    @contextlib.contextmanager
+    def loop(self):
+        """Run a training loop on the Trainer's stream: `with trainer.loop(): for batch in ...: trainer.step_graphed(...)`.
+        Everything inside — the steps, progress reads (`loss.item()`), validation renders — then shares ONE stream with the
+        replays and no event ever makes the legacy default stream wait for the capture stream.  That wait is what the replay
+        hazard of DESIGN.md section 4.4 needs (ROCm 7.2: replays, torch.cuda.synchronize(), any work on the default stream,
+        a replay -> GPU memory fault, as soon as the default stream has ONCE waited on the capture stream); `step_graphed`
+        called from the default stream issues one per step.  No-op for a Trainer without graph=True."""
+        with self._own_stream():
+            yield self
 
     @contextlib.contextmanager
     def _own_stream(self):
@@ -546,6 +563,12 @@ class Trainer:
                 return [x for k in sorted(v) for x in flat(v[k], f"{prefix}.{k}")]
             return [(prefix, v)] if torch.is_tensor(v) else []
         leaves = [x for k in sorted(args) for x in flat(args[k], k)]
+        if (self._stream is not None and not self._warned_stream and torch.cuda.current_stream(self._stream.device) != self._stream):
+            import warnings
+            self._warned_stream = True
+            warnings.warn("Trainer.step_graphed called from another stream than the Trainer's: wrap the training loop in "
+                          "`with trainer.loop():` (DESIGN.md section 4.4: replays issued across streams, a device "
+                          "synchronise and work on the default stream ended in a GPU memory fault on ROCm 7.2)")
         with self._own_stream():
             return self._step_graphed(args, leaves, perturb, eager)
 

@@ -436,17 +436,18 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False):
         last["loss"], _ = trainer.step(rays, rgbs, alphas, None, templ, fg, bg, perturb=1.0, frame_idx=frame_idx)
         return last["loss"]
 
-    if graphed:
-        # untimed set-up, like a compilation: GRAPH_WARM_STEPS eager steps, then the capture (which executes nothing)
-        while trainer._graph is None:
-            step()
-    elapsed, per_kernel, loss = ctx.timed(step, steps, warmup)
-    eager_elapsed, eager_steps = elapsed, steps
-    if graphed:
-        # a replay launches nothing from Python, so the per-kernel HIP events come from a few EAGER steps of the same batch
-        # right after the timed region (same kernels, same shapes; their host-side pace does not enter any number below)
-        eager_steps = min(steps, 5)
-        eager_elapsed, per_kernel, _ = ctx.timed(eager_step, eager_steps, 0)
+    with trainer.loop():                # (the Trainer's own stream for the whole loop: DESIGN section 4.4, the replay hazard)
+        if graphed:
+            # untimed set-up, like a compilation: GRAPH_WARM_STEPS eager steps, then the capture (which executes nothing)
+            while trainer._graph is None:
+                step()
+        elapsed, per_kernel, loss = ctx.timed(step, steps, warmup)
+        eager_elapsed, eager_steps = elapsed, steps
+        if graphed:
+            # a replay launches nothing from Python, so the per-kernel HIP events come from a few EAGER steps of the same batch
+            # right after the timed region (same kernels, same shapes; their host-side pace does not enter any number below)
+            eager_steps = min(steps, 5)
+            eager_elapsed, per_kernel, _ = ctx.timed(eager_step, eager_steps, 0)
     n_rays = F * 1024
     return {
         "metric": "rays/sec, training step (64+32 samples, 256-wide MLP x2, fwd+bwd+Adam)",

@@ -1162,6 +1162,20 @@ def test_graphed_training_step_equals_the_eager_step(dev, smpl_table):
     loss, _ = tr.step_graphed(batch["rays"][:2], batch["rgbs"][:2], batch["alphas"][:2], None, _templ(dev), batch["fg"][:2],
                               batch["bg"][:2], perturb=1.0, frame_idx=batch["frame_idx"][:2])
     assert torch.isfinite(loss) and tr._graph[0][0][2][0][1] != tuple(batch["alphas"][:2].shape)
+    # the loop the class is meant to be driven in: everything on the Trainer's stream.  The sequence that ends in a GPU memory
+    # fault when the steps are issued from the default stream (replays, device synchronise, other GPU work + scalar reads, more
+    # replays: DESIGN section 4.4) is harmless here
+    tr3 = ana.Trainer(copy.deepcopy(m0), ana.VolumeRenderer(n_coarse=32, n_fine=16), hp2, body_model_params=copy.deepcopy(table0), graph=True)
+    with tr3.loop():
+        assert torch.cuda.current_stream() == tr3.stream
+        for it in range(64):
+            loss, det = tr3.step_graphed(batch["rays"], batch["rgbs"], batch["alphas"], None, _templ(dev), batch["fg"], batch["bg"],
+                                         perturb=1.0, frame_idx=batch["frame_idx"])
+            if it in (40, 56):
+                torch.cuda.synchronize()
+                assert torch.ones(3, device=dev).sum().item() == 3 and torch.isfinite(loss).item() and det["psnr"].item() > 0
+    torch.cuda.synchronize()
+    assert tr3._graph is not None and torch.isfinite(loss)
     # a capture that fails costs nothing but the graph: the step goes on eagerly
     tr2 = ana.Trainer(copy.deepcopy(m0), ana.VolumeRenderer(n_coarse=32, n_fine=16), hp2, body_model_params=copy.deepcopy(table0), graph=True)
 

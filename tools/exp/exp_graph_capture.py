@@ -161,6 +161,17 @@ if os.environ.get("WITH_TRAINER"):       # a Trainer exists (hooks, sinks, flat 
             tr.begin_step()
             return _body0()
 side = tr._stream if ((stage.startswith("trainer") or os.environ.get("WITH_TRAINER")) and tr._stream is not None) else torch.cuda.Stream()
+pre = os.environ.get("PRE", "")
+if "alloc" in pre:                       # a persistent allocation made on the capture stream before anything else
+    with torch.cuda.stream(side):
+        keep_alive = torch.zeros(1 << 22, device=dev)
+if "wait" in pre:                        # the default stream has waited for the capture stream once
+    torch.cuda.current_stream().wait_stream(side)
+if "hooks" in pre:                       # post-accumulate-grad hooks on every parameter (they keep the AccumulateGrad nodes alive)
+    with torch.cuda.stream(side):
+        for p in m.parameters():
+            if p.requires_grad:
+                p.register_post_accumulate_grad_hook(lambda q: None)
 side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
     for _ in range(3):
