@@ -54,19 +54,11 @@ def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
         # another GPU would be touched through a foreign stream
         raise RuntimeError(f"{name} lives on cuda:{t.device.index} but the current device is cuda:{torch.cuda.current_device()}: "
                            "call torch.cuda.set_device (one process per GPU) or wrap the call in torch.cuda.device(...)")
-    if t.is_contiguous():
-        return t
-    # A contiguous copy made here is often passed on as `_ptr(_dev(x))`: nothing else holds it, and a block freed before the
-    # launch is enqueued may be handed to the NEXT such copy and overwritten (stream order protects only against allocations
-    # made after the launch).  The last few copies are kept alive here.
-    c = t.contiguous()
-    _RECENT_COPIES.append(c)
-    if len(_RECENT_COPIES) > 32:
-        del _RECENT_COPIES[0]
-    return c
-
-
-_RECENT_COPIES = []
+    # A strided input comes back as a contiguous COPY.  The caller must bind it to a local that lives until its launch is
+    # enqueued (never `_ptr(_dev(x))`): a copy nobody holds is freed at once, the caching allocator may hand the block to
+    # the next such copy, and that copy's kernel is enqueued BEFORE the launch — stream order only protects against
+    # allocations made after it.
+    return t if t.is_contiguous() else t.contiguous()
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -131,22 +123,24 @@ def frame_backward(betas, pose, transl, J0, JS, parents, lbs_weights, shapedirs,
     if d_o2c is not None:
         d_o2c = _dev(d_o2c, "d_o2c")
     grads = torch.empty(bs, 85, dtype=torch.float32, device=pose.device)
+    J0, JS, parents = _dev(J0, "J0"), _dev(JS, "JS"), _dev(parents, "parents", torch.int64)
+    lbs_weights, shapedirs, posedirs = _dev(lbs_weights, "lbs_weights"), _dev(shapedirs, "shapedirs"), _dev(posedirs, "posedirs")
+    if vertex_joint_mask is not None:
+        vertex_joint_mask = _dev(vertex_joint_mask, "vertex_joint_mask", torch.int32)
     if not forward_mode:
         # reverse mode through the per-vertex inverses, forward mode through the 24-joint chain (csrc/frame_bwd.hip)
         ws = torch.empty(lib.anr_frame_backward_ws_floats(bs, V), dtype=torch.float32, device=pose.device)
         with _timed("frame_backward", bs):
             _lib.check(lib.anr_frame_backward_adjoint(
-                _ptr(betas), _ptr(pose), _ptr(transl), bs, _ptr(_dev(J0, "J0")), _ptr(_dev(JS, "JS")),
-                _ptr(_dev(parents, "parents", torch.int64)), _ptr(_dev(lbs_weights, "lbs_weights")), _ptr(_dev(shapedirs, "shapedirs")),
-                _ptr(_dev(posedirs, "posedirs")), V, _ptr(T_template), T_template.shape[0], _ptr(rays_world), rs, R, _ptr(d_o2c),
+                _ptr(betas), _ptr(pose), _ptr(transl), bs, _ptr(J0), _ptr(JS), _ptr(parents), _ptr(lbs_weights), _ptr(shapedirs),
+                _ptr(posedirs), V, _ptr(T_template), T_template.shape[0], _ptr(rays_world), rs, R, _ptr(d_o2c),
                 _ptr(d_rays), _ptr(ws), _ptr(grads), _stream(grads)), "anr_frame_backward_adjoint")
         return grads
     with _timed("frame_backward", bs):
-        _lib.check(lib.anr_frame_backward(_ptr(betas), _ptr(pose), _ptr(transl), bs, _ptr(_dev(J0, "J0")), _ptr(_dev(JS, "JS")),
-                                          _ptr(_dev(parents, "parents", torch.int64)), _ptr(_dev(lbs_weights, "lbs_weights")),
-                                          _ptr(_dev(shapedirs, "shapedirs")), _ptr(_dev(posedirs, "posedirs")), V,
+        _lib.check(lib.anr_frame_backward(_ptr(betas), _ptr(pose), _ptr(transl), bs, _ptr(J0), _ptr(JS), _ptr(parents),
+                                          _ptr(lbs_weights), _ptr(shapedirs), _ptr(posedirs), V,
                                           _ptr(T_template), T_template.shape[0], _ptr(rays_world), rs, R, _ptr(d_o2c),
-                                          _ptr(d_rays), _ptr(None if vertex_joint_mask is None else _dev(vertex_joint_mask, "vertex_joint_mask", torch.int32)),
+                                          _ptr(d_rays), _ptr(vertex_joint_mask),
                                           _ptr(grads), _stream(grads)), "anr_frame_backward")
     return grads
 
@@ -867,7 +861,8 @@ def sample_coarse_backward(g_z: torch.Tensor, steps: torch.Tensor, t_rand: Optio
     K = steps.numel()
     R = g_z.numel() // K
     d_rays = torch.empty(R, 8, dtype=torch.float32, device=g_z.device)
-    _lib.check(lib.anr_sample_coarse_backward(_ptr(g_z), _ptr(steps), _ptr(None if t_rand is None else _dev(t_rand, "t_rand")), R, K,
+    t_rand = None if t_rand is None else _dev(t_rand, "t_rand")
+    _lib.check(lib.anr_sample_coarse_backward(_ptr(g_z), _ptr(steps), _ptr(t_rand), R, K,
                                               _ptr(d_rays), _stream(d_rays)), "anr_sample_coarse_backward")
     return d_rays
 

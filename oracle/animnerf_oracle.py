@@ -9,8 +9,9 @@ HIP library.
 Parity status: PINNED.  The reference holds no tests or golden vectors for
 this path, so every function below is checked against outputs
 of the reference itself, imported from /root/reference in the build container
-by tests/golden/make_fixtures.py; the outputs are committed under
-tests/golden/*.npz and compared in tests/test_oracle_golden.py.
+by tests/golden/make_fixtures.py (and make_loss_fixtures.py for the training
+side: NeRF.get_normal, AnimNeRFSystem.forward / compute_loss); the outputs are
+committed under tests/golden/*.npz and compared in tests/test_oracle_golden.py.
 
 Reference lines each function follows are cited in its docstring
 (paths relative to the reference repository).
@@ -450,6 +451,65 @@ def render_frame(tbl, P_coarse, P_fine, rays, pose_params, template_params, *, n
     out = {k: torch.cat([p[k] for p in pieces], 1) for k in pieces[0]}
     out['_rays_body'] = rays_b
     return out
+
+
+# ---------------------------------------------------------------------------
+# a16  losses + normals regulariser (training side; pinned by tests/golden/{normals,train_loss}.npz,
+#      outputs of the reference's own NeRF.get_normal / AnimNeRFSystem.compute_loss: make_loss_fixtures.py)
+# ---------------------------------------------------------------------------
+
+def point_normals(P: Dict[str, Tensor], xyz: Tensor, delta: float = 0.02, create_graph: bool = True) -> Tensor:
+    """models/nerf.py:177-190 (NeRF.get_normal) — d alpha / d xyz with alpha = 1 - exp(-delta relu(sigma)); the graph is
+    kept so that a loss on the normals differentiates a second time w.r.t. the weights."""
+    with torch.enable_grad():
+        x = xyz if xyz.requires_grad else xyz.detach().clone().requires_grad_(True)
+        sigma = mlp_sigma_and_feature(P, x)[0]
+        alpha = 1 - torch.exp(-delta * torch.relu(sigma))
+        return torch.autograd.grad(alpha, x, torch.ones_like(alpha), create_graph=create_graph, retain_graph=True)[0]
+
+
+def training_loss(P_coarse, P_fine, results: Dict[str, Tensor], rgbs: Tensor, alphas: Tensor, *, n_samples: int,
+                  fg_points: Optional[Tensor] = None, bg_points: Optional[Tensor] = None, verts_template: Optional[Tensor] = None,
+                  draws: Optional[Tuple[Tensor, Tensor]] = None, use_unpose: bool = True, lambda_alphas: float = 0.1,
+                  lambda_foreground: float = 0.01, lambda_background: float = 0.01, lambda_normals: float = 0.01,
+                  epsilon: float = 0.01, dis_threshold: float = 0.2):
+    """train.py:228-322 (AnimNeRFSystem.compute_loss) — rgb MSE, alpha L1, foreground / background sigma priors
+    (query_canonical_space = the network in canonical space, models/anim_nerf.py:211-243) and the normals regulariser,
+    coarse and — `P_fine` given, i.e. n_importance > 0 and not share_fine — fine.  `draws` = the two standard-normal tensors
+    the reference takes from randn_like (train.py:289-290), handed in; None skips the term.  -> (total, details)."""
+    mse, l1 = torch.nn.functional.mse_loss, torch.nn.functional.l1_loss
+    fine = P_fine is not None
+    d: Dict[str, Tensor] = {}
+    d['loss_rgb'] = mse(results['rgbs'], rgbs)
+    loss = d['loss_rgb']
+    if fine:
+        d['loss_rgb_fine'] = mse(results['rgbs_fine'], rgbs)
+        loss = loss + d['loss_rgb_fine']
+    d['loss_alphas'] = l1(results['alphas'], alphas)
+    loss = loss + lambda_alphas * d['loss_alphas']
+    if fine:
+        d['loss_alphas_fine'] = l1(results['alphas_fine'], alphas)
+        loss = loss + lambda_alphas * d['loss_alphas_fine']
+    nets = (('', P_coarse),) + ((('_fine', P_fine),) if fine else ())
+    k = -2.0 / n_samples
+    if use_unpose and fg_points is not None:
+        for tag, P in nets:
+            d['loss_foreground' + tag] = torch.mean(torch.exp(k * torch.relu(mlp_sigma_and_feature(P, fg_points)[0])))
+            loss = loss + lambda_foreground * d['loss_foreground' + tag]
+    if use_unpose and bg_points is not None:
+        for tag, P in nets:
+            d['loss_background' + tag] = torch.mean(1 - torch.exp(k * torch.relu(mlp_sigma_and_feature(P, bg_points)[0])))
+            loss = loss + lambda_background * d['loss_background' + tag]
+    if draws is not None:
+        points = verts_template.detach() + draws[0] * dis_threshold * 0.5
+        neighbs = points + draws[1] * epsilon
+        for tag, P in nets:
+            n0, n1 = point_normals(P, points), point_normals(P, neighbs)
+            n0 = n0 / (torch.norm(n0, p=2, dim=-1, keepdim=True) + 1e-5)
+            n1 = n1 / (torch.norm(n1, p=2, dim=-1, keepdim=True) + 1e-5)
+            d['loss_normals' + tag] = mse(n0, n1)
+            loss = loss + lambda_normals * d['loss_normals' + tag]
+    return loss, d
 
 
 def psnr(a: Tensor, b: Tensor) -> float:

@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/{normals,train_loss}.npz by RUNNING THE REFERENCE's training-side code on the seeded synthetic
+world (build container only; the reference never enters this repository):
+
+    python tests/golden/make_loss_fixtures.py
+
+* normals.npz    — `NeRF.get_normal` (/root/reference/models/nerf.py:177-190) on seeded points of a sigma-gain network
+                   (normals non-zero), and the gradient of sum(normal^2) w.r.t. every weight (second-order).
+* train_loss.npz — `AnimNeRFSystem.forward` + `AnimNeRFSystem.compute_loss` (/root/reference/train.py:189-215, 228-322),
+                   the functions themselves, called unbound on a namespace that carries `hparams`, the reference's
+                   AnimNeRF and VolumeRenderer: the rendered batch, the ten loss terms, their total, and the gradient of
+                   the total w.r.t. every weight of both networks.  train.py itself imports Lightning / yacs / lpips /
+                   torchmetrics / torchvision / cv2, none of which is installed: stub modules stand in for them (nothing
+                   of theirs is on the path measured here).
+
+What is stored: seeds and checksums for everything regenerated from seeds (SMPL-like table, MLP weights, the normal
+term's two `randn_like` draws), small inputs, and the reference's outputs.
+"""
+import importlib.util
+import os
+import sys
+import tempfile
+import types
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+REF = os.environ.get("ANIMNERF_REFERENCE", "/root/reference")
+OUT = os.environ.get("ANR_FIXTURE_OUT", os.path.join(ROOT, "tests", "golden"))
+
+from anim_nerf_amd import synthetic as syn                        # noqa: E402
+from make_fixtures import import_reference, sha, sigma_gain_, t, weights_checksum   # noqa: E402
+
+torch.set_num_threads(8)
+
+NORMALS = dict(seed=7, gain=300.0, shift=2.0, n=500, point_seed=6, delta=0.02)
+LOSS = dict(seed=21, gain=300.0, shift=0.5, frames=2, H=8, W=8, n_samples=16, n_importance=8, chunk=40, pose_seed=3,
+            target_seed=4, draw_seed=123, n_fg=64, n_bg=48, lambda_alphas=0.1, lambda_foreground=0.01, lambda_background=0.01,
+            lambda_normals=0.01, epsilon=0.01, dis_threshold=0.2)
+
+
+def stub_modules():
+    """Stand-ins for the packages train.py imports at module level and the image lacks."""
+    def mod(name, **attrs):
+        m = sys.modules.get(name)
+        if m is None:
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+
+    class LightningModule(torch.nn.Module):
+        def save_hyperparameters(self, hp):
+            self.hparams = hp
+
+        def log(self, *a, **k):
+            pass
+    tvu = mod("torchvision.utils", save_image=lambda *a, **k: None)
+    mod("torchvision", utils=tvu)
+    mod("config", get_cfg=lambda *a, **k: None)                   # (config.py needs yacs)
+    mod("lpips", LPIPS=lambda **k: None)
+    mod("torchmetrics")
+    mod("torchmetrics.functional")
+    mod("torchmetrics.functional.image")
+    mod("torchmetrics.functional.image.ssim", structural_similarity_index_measure=None)
+    mod("torchmetrics.functional.image.psnr", peak_signal_noise_ratio=None)
+    mod("pytorch_lightning", LightningDataModule=object, LightningModule=LightningModule, Trainer=object)
+    mod("pytorch_lightning.callbacks", ModelCheckpoint=object)
+    mod("pytorch_lightning.loggers", TensorBoardLogger=object)
+
+
+def load_train_module():
+    spec = importlib.util.spec_from_file_location("ref_train", os.path.join(REF, "train.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def main():
+    r_anim, r_vr, r_ds = import_reference()
+    stub_modules()
+    r_train = load_train_module()
+    import models.nerf as r_nerf
+
+    # ------------------------------------------------------------------ NeRF.get_normal
+    c = NORMALS
+    torch.manual_seed(c["seed"])
+    net = r_nerf.NeRF(freqs_xyz=10, freqs_dir=0, use_view=False)
+    sigma_gain_(net, c["gain"], c["shift"])
+    gen = torch.Generator().manual_seed(c["point_seed"])
+    xyz = torch.rand(1, c["n"], 3, generator=gen) * 1.2 - 0.6
+    x = xyz.clone()
+    normal = net.get_normal(x, delta=c["delta"])
+    (normal ** 2).sum().backward()
+    grads = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    assert (normal.abs().sum(-1) > 0).float().mean() > 0.2
+    np.savez_compressed(os.path.join(OUT, "normals.npz"), **{k: np.asarray(v) for k, v in c.items()},
+                        weights_checksum=weights_checksum(net), xyz=xyz.numpy(), normal=normal.detach().numpy(),
+                        grad_keys=np.array(sorted(grads)),
+                        grad_norms=np.float64([grads[k].double().norm().item() for k in sorted(grads)]),
+                        **{"grad/" + k: grads[k].numpy() for k in ("sigma.weight", "xyz_encoding_8.0.bias", "xyz_encoding_1.0.bias",
+                                                                   "xyz_encoding_5.0.bias")})
+    print("normals.npz: nonzero normals on", (normal.abs().sum(-1) > 0).float().mean().item(), "of the points;",
+          len(grads), "tensors with a gradient")
+
+    # ------------------------------------------------------------------ AnimNeRFSystem.forward + compute_loss
+    c = LOSS
+    tbl = syn.make_smpl_table(0)
+    tmp = tempfile.mkdtemp(prefix="anr_smpl_")
+    os.makedirs(os.path.join(tmp, "smpl"))
+    tbl.write_pickle(os.path.join(tmp, "smpl", "SMPL_MALE.pkl"))
+    torch.manual_seed(c["seed"])
+    model = r_anim.AnimNeRF(model_path=tmp, model_type="smpl", gender="male", freqs_xyz=10, freqs_dir=0, use_view=False,
+                            use_unpose=True, k_neigh=4, use_knn=False, use_fine=True, share_fine=False,
+                            dis_threshold=c["dis_threshold"])
+    # sigma spread about its median over a probe set, so that every loss term of BOTH networks is live (a random-init
+    # network's sigma has one sign almost everywhere); the resulting biases travel in the fixture
+    probe = torch.rand(1, 2000, 3, generator=torch.Generator().manual_seed(c["seed"])) * 1.6 - 0.8
+    for n_ in (model.nerf, model.nerf_fine):
+        with torch.no_grad():
+            med = n_.get_sigma(probe, only_sigma=True).median() - n_.sigma.bias
+            n_.sigma.weight.mul_(c["gain"])
+            n_.sigma.bias.copy_(c["shift"] - c["gain"] * med)
+    hp = Namespace(chunk=c["chunk"], n_importance=c["n_importance"], share_fine=False, use_unpose=True, n_samples=c["n_samples"],
+                   dis_threshold=c["dis_threshold"],
+                   train=Namespace(lambda_alphas=c["lambda_alphas"], lambda_foreground=c["lambda_foreground"],
+                                   lambda_background=c["lambda_background"], lambda_normals=c["lambda_normals"],
+                                   epsilon=c["epsilon"]))
+    system = Namespace(hparams=hp, anim_nerf=model,
+                       volume_renderer=r_vr.VolumeRenderer(n_coarse=c["n_samples"], n_fine=c["n_importance"]))
+    F_, H, W = c["frames"], c["H"], c["W"]
+    pose = t(syn.animated_pose_params(seed=c["pose_seed"], bs=F_))
+    templ = t(syn.template_pose_params())
+    c2w, focal, cen = syn.pinhole_camera(H, W)
+    rays = r_ds.gen_rays(torch.from_numpy(c2w), H, W, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(F_, 1, 1, 1)
+    gen = torch.Generator().manual_seed(c["target_seed"])
+    tgt_rgb = torch.rand(F_, H, W, 3, generator=gen)
+    tgt_a = (torch.rand(F_, H, W, 1, generator=gen) > 0.5).float()
+    fg = torch.rand(F_, c["n_fg"], 3, generator=gen) * 0.4 - 0.2
+    bg = torch.rand(F_, c["n_bg"], 3, generator=gen) * 2 - 1
+    # train.py:189-215 with perturb=0 (the reference's eval-style call; the jitter / noise draws are pinned elsewhere) ...
+    model.eval()                                                  # no sigma noise (volume_rendering.py:122-125 is train-only)
+    results = r_train.AnimNeRFSystem.forward(system, rays, pose, templ, perturb=0.0)
+    verts_template = model.verts_template.detach().clone()        # compute_loss adds its first draw to this tensor IN PLACE
+    # ... and train.py:228-322; the two randn_like draws of the normals term come from the global CPU generator
+    torch.manual_seed(c["draw_seed"])
+    drawn = []
+    real = torch.randn_like
+
+    def recording(x, *a, **k):
+        drawn.append(real(x, *a, **k))
+        return drawn[-1]
+    torch.randn_like = recording
+    try:
+        loss, details = r_train.AnimNeRFSystem.compute_loss(system, tgt_rgb, tgt_a, results, fg_points=fg, bg_points=bg)
+    finally:
+        torch.randn_like = real
+    assert len(drawn) == 2 and drawn[0].shape == verts_template.shape
+    torch.manual_seed(c["draw_seed"])                             # the test regenerates them this way
+    assert torch.equal(torch.randn(verts_template.shape), drawn[0]) and torch.equal(torch.randn(verts_template.shape), drawn[1])
+    loss.backward()
+    out = {k: np.asarray(v) for k, v in c.items()}
+    out.update(table_checksum=syn.table_checksum(tbl), weights_checksum=weights_checksum(model.nerf),
+               weights_checksum_fine=weights_checksum(model.nerf_fine), draws_checksum=sha(*drawn),
+               sigma_bias=model.nerf.sigma.bias.detach().numpy().copy(), sigma_bias_fine=model.nerf_fine.sigma.bias.detach().numpy().copy(),
+               rays=rays.numpy(), target_rgb=tgt_rgb.numpy(), target_alpha=tgt_a.numpy(), fg_points=fg.numpy(), bg_points=bg.numpy(),
+               verts_template_sub=verts_template[:, ::53].numpy(), total=np.float64(loss.item()))
+    for k, v in results.items():
+        out["results/" + k] = v.detach().numpy()
+    for k, v in details.items():
+        out["loss/" + k] = np.float64(v.item())
+    for tag, n_ in (("coarse", model.nerf), ("fine", model.nerf_fine)):
+        g = {k: p.grad for k, p in n_.named_parameters() if p.grad is not None}
+        out[f"grad_keys_{tag}"] = np.array(sorted(g))
+        out[f"grad_norms_{tag}"] = np.float64([g[k].double().norm().item() for k in sorted(g)])
+        for k in ("sigma.weight", "rgb.0.weight", "xyz_encoding_8.0.bias", "xyz_encoding_1.0.bias"):
+            out[f"grad_{tag}/" + k] = g[k].numpy()
+    np.savez_compressed(os.path.join(OUT, "train_loss.npz"), **out)
+    print("train_loss.npz:", {k: round(v.item(), 6) for k, v in details.items()}, "total", loss.item(),
+          "covered", (results["alphas_fine"] > 0.5).float().mean().item())
+
+
+if __name__ == "__main__":
+    main()

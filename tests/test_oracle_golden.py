@@ -288,3 +288,86 @@ def test_other_neighbour_counts_match_reference(smpl_table, k):
     sigma = torch.where(valid < 1, torch.full_like(sigma, -1e5), sigma)
     torch.testing.assert_close(rgb, torch.from_numpy(g[f"rgb_{k}"]), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(sigma, torch.from_numpy(g[f"sigma_{k}"]), rtol=1e-4, atol=2e-4)
+
+
+def test_point_normals_match_reference(smpl_table):
+    """orc.point_normals against NeRF.get_normal of the reference (models/nerf.py:177-190) and its second-order weight
+    gradients (tests/golden/normals.npz, make_loss_fixtures.py)."""
+    g = golden("normals")
+    m = seeded_model(smpl_table, g["seed"], True, g["gain"], (g["shift"], g["shift"]))
+    assert weights_checksum(m.nerf) == str(g["weights_checksum"])
+    P = {k: v.clone().requires_grad_(True) for k, v in net_params(m.nerf).items()}
+    n = orc.point_normals(P, torch.from_numpy(g["xyz"]), float(g["delta"]))
+    ref = torch.from_numpy(g["normal"])
+    assert (n.detach() - ref).abs().max() <= 1e-6 + 1e-5 * ref.abs().max()
+    (n ** 2).sum().backward()
+    keys = [str(k) for k in g["grad_keys"]]
+    assert sorted(k for k, v in P.items() if v.grad is not None) == keys
+    for k, want in zip(keys, g["grad_norms"]):
+        assert abs(P[k].grad.double().norm().item() - want) <= 1e-6 * want, k
+    for k in g:
+        if k.startswith("grad/"):
+            a, b = P[k[5:]].grad, torch.from_numpy(g[k])
+            assert (a - b).norm() <= 1e-6 * b.norm(), k
+
+
+def loss_fixture_model(smpl_table, g, device=None, **kw):
+    """Our AnimNeRF with the weights of tests/golden/train_loss.npz (seeded init, sigma gain about the probe median)."""
+    m = seeded_model(smpl_table, g["seed"], True, **kw)
+    with torch.no_grad():
+        for net, b in ((m.nerf, g["sigma_bias"]), (m.nerf_fine, g["sigma_bias_fine"])):
+            net.sigma.weight.mul_(float(g["gain"]))
+            net.sigma.bias.copy_(torch.from_numpy(b))
+    assert weights_checksum(m.nerf) == str(g["weights_checksum"]) and weights_checksum(m.nerf_fine) == str(g["weights_checksum_fine"])
+    return m.to(device) if device is not None else m
+
+
+def loss_fixture_draws(g, shape):
+    torch.manual_seed(int(g["draw_seed"]))
+    draws = (torch.randn(shape), torch.randn(shape))
+    assert sha(*draws) == str(g["draws_checksum"])
+    return draws
+
+
+def test_training_loss_matches_reference(smpl_table):
+    """orc.render_frame + orc.training_loss against AnimNeRFSystem.forward + compute_loss of the reference
+    (train.py:189-215, 228-322; tests/golden/train_loss.npz): the rendered batch, each of the ten loss terms, the total,
+    and the gradient of the total w.r.t. every weight of both networks."""
+    g = golden("train_loss")
+    m = loss_fixture_model(smpl_table, g)
+    tbl = oracle_table(smpl_table)
+    Pc = {k: v.clone().requires_grad_(True) for k, v in net_params(m.nerf).items()}
+    Pf = {k: v.clone().requires_grad_(True) for k, v in net_params(m.nerf_fine).items()}
+    F_, H, W = int(g["frames"]), int(g["H"]), int(g["W"])
+    pose = {k: torch.from_numpy(v) for k, v in syn.animated_pose_params(seed=int(g["pose_seed"]), bs=F_).items()}
+    templ = {k: torch.from_numpy(v) for k, v in syn.template_pose_params().items()}
+    rays = torch.from_numpy(g["rays"]).view(F_, H * W, 8)
+    out = orc.render_frame(tbl, Pc, Pf, rays, pose, templ, n_coarse=int(g["n_samples"]), n_fine=int(g["n_importance"]),
+                           use_unpose=True, chunk=int(g["chunk"]), dis_threshold=float(g["dis_threshold"]))
+    for k in ("rgbs", "alphas", "depths", "rgbs_fine", "alphas_fine", "depths_fine"):
+        ref = torch.from_numpy(g["results/" + k]).view(F_, H * W, -1)
+        assert (out[k].detach() - ref).abs().max() <= 1e-6, k
+    st = orc.frame_state(tbl, pose, templ)
+    assert torch.equal(st["verts_template"][:, ::53], torch.from_numpy(g["verts_template_sub"])) or \
+        (st["verts_template"][:, ::53] - torch.from_numpy(g["verts_template_sub"])).abs().max() < 1e-6
+    draws = loss_fixture_draws(g, st["verts_template"].shape)
+    hp = {k: float(g[k]) for k in ("lambda_alphas", "lambda_foreground", "lambda_background", "lambda_normals", "epsilon", "dis_threshold")}
+    total, d = orc.training_loss(Pc, Pf, out, torch.from_numpy(g["target_rgb"]).view(F_, H * W, 3),
+                                 torch.from_numpy(g["target_alpha"]).view(F_, H * W, 1), n_samples=int(g["n_samples"]),
+                                 fg_points=torch.from_numpy(g["fg_points"]), bg_points=torch.from_numpy(g["bg_points"]),
+                                 verts_template=st["verts_template"], draws=draws, **hp)
+    terms = [k[5:] for k in g if k.startswith("loss/")]
+    assert sorted(terms) == sorted(d) and len(terms) == 10
+    for k in terms:
+        assert abs(d[k].item() - float(g["loss/" + k])) <= 1e-6 + 1e-5 * abs(float(g["loss/" + k])), (k, d[k].item(), float(g["loss/" + k]))
+    assert abs(total.item() - float(g["total"])) <= 1e-6
+    total.backward()
+    for tag, P in (("coarse", Pc), ("fine", Pf)):
+        keys = [str(k) for k in g[f"grad_keys_{tag}"]]
+        assert sorted(k for k, v in P.items() if v.grad is not None) == keys
+        for k, want in zip(keys, g[f"grad_norms_{tag}"]):
+            assert abs(P[k].grad.double().norm().item() - want) <= 1e-6 * want + 1e-12, (tag, k, P[k].grad.double().norm().item(), want)
+        for k in g:
+            if k.startswith(f"grad_{tag}/"):
+                a, b = P[k.split("/", 1)[1]].grad, torch.from_numpy(g[k])
+                assert (a - b).norm() <= 1e-6 * b.norm(), (tag, k, ((a - b).norm() / b.norm()).item())

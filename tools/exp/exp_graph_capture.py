@@ -190,14 +190,15 @@ g.replay()
 torch.cuda.synchronize()
 if os.environ.get("HAZARD"):
     # the sequence of tools/soak_train.py: replays on a side stream, device synchronise, work on the default stream, replays
-    with torch.cuda.stream(side):
-        for _ in range(int(os.environ["HAZARD"])):
-            g.replay()
-    torch.cuda.synchronize()
-    torch.ones(3, device=dev).sum().item()
-    with torch.cuda.stream(side):
-        for _ in range(5):
-            g.replay()
-    torch.cuda.synchronize()
+    for _cycle in range(int(os.environ.get("HAZARD_CYCLES", "1"))):
+        with torch.cuda.stream(side):
+            for _ in range(int(os.environ["HAZARD"])):
+                g.replay()
+        torch.cuda.synchronize()
+        torch.ones(3, device=dev).sum().item()
+        with torch.cuda.stream(side):
+            for _ in range(5):
+                g.replay()
+        torch.cuda.synchronize()
     print(stage, "hazard sequence survived", flush=True)
 print(stage, "replayed OK", float(out.float().abs().sum()), float(ref.float().abs().sum()), flush=True)
