@@ -58,8 +58,7 @@ extern "C" int anr_compact_valid(const float* pts, int64_t n, int32_t* index_out
     ANR_REQUIRE(!fill_out || fill_cols == 4 || fill_cols == 1, ANR_E_BADARG, "anr_compact_valid: fill_cols=%d (1 or 4)", fill_cols);
     ANR_REQUIRE((((uintptr_t)pts | (uintptr_t)fill_out) & 15) == 0, ANR_E_ALIGN, "anr_compact_valid: pts/fill_out must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(count_out, 0, sizeof(int32_t), st);
-    if (e != hipSuccess) return fail((int)e, "anr_compact_valid: hipMemsetAsync: %s", hipGetErrorString(e));
+    if (int rc = zero_fill(count_out, sizeof(int32_t), st, "anr_compact_valid (zero)")) return rc;
     const int64_t n_blocks = (n + COMPACT_THREADS - 1) / COMPACT_THREADS;
     const unsigned grid = (unsigned)(n_blocks < 2048 ? n_blocks : 2048);
     hipLaunchKernelGGL(compact_valid_kernel, dim3(grid), dim3(COMPACT_THREADS), 0, st,

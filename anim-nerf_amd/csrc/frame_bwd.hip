@@ -528,8 +528,7 @@ extern "C" int anr_frame_backward_adjoint(const float* betas, const float* pose,
     float* acc = workspace;
     float* H = acc + (int64_t)bs * FA_ACC;
     float* goff = H + (int64_t)bs * FA_H;
-    hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * (size_t)bs * FA_ACC, st);
-    if (e != hipSuccess) return fail((int)e, "anr_frame_backward_adjoint: hipMemsetAsync: %s", hipGetErrorString(e));
+    if (int rc = zero_fill(acc, sizeof(float) * (size_t)bs * FA_ACC, st, "anr_frame_backward_adjoint (zero)")) return rc;
     const int nvb = d_ober2cano ? (V + FB_THREADS - 1) / FB_THREADS : 0;
     const int nrb = d_rays_body ? (R + FB_THREADS - 1) / FB_THREADS : 0;
     hipLaunchKernelGGL(frame_adjoint_kernel, dim3(nvb + nrb, bs), dim3(FB_THREADS), 0, st, betas, pose, transl, J0, JS, parents,

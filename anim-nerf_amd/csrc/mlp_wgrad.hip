@@ -540,8 +540,7 @@ extern "C" int anr_mlp_wgrad_counted(int mode, const void* act, const void* dact
     const int accumulate = (mode & ANR_MLP_FLAG_ACCUMULATE) ? 1 : 0;
     if (so && !accumulate) {                                         // tensors this call does not produce: zeros
         const Layout& L = layout();
-        hipError_t e = hipMemsetAsync(grads_out + L.fw, 0, sizeof(float) * (L.total - L.fw), st);
-        if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipMemsetAsync: %s", hipGetErrorString(e));
+        if (int rc = zero_fill(grads_out + L.fw, sizeof(float) * (L.total - L.fw), st, "anr_mlp_wgrad (zero)")) return rc;
     }
     switch (mode & 0xff) {
         case ANR_MLP_BF16: return wgrad_launch<true>(act, dact, enc, g4, n, so, tan, accumulate, workspace, grads_out, st, count);

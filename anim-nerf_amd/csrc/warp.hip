@@ -1575,8 +1575,7 @@ extern "C" int anr_warp_points_reuse(const float* xyz, int xyz_stride, const flo
         WarpWs w(ws, bs, N);
         const int G = grid_for(N);
         const int cells = G * G * G;
-        hipError_t e = hipMemsetAsync(w.count, 0, sizeof(int32_t) * WarpWs::zeroed_ints(bs), st);
-        if (e != hipSuccess) return fail((int)e, "anr_warp_points: hipMemsetAsync: %s", hipGetErrorString(e));
+        if (int rc = zero_fill(w.count, sizeof(int32_t) * WarpWs::zeroed_ints(bs), st, "anr_warp_points (zero)")) return rc;
         dim3 g1((unsigned)((N + CLS_ITERS * WARP_THREADS - 1) / (CLS_ITERS * WARP_THREADS)), bs);
         // four consecutive samples per thread where the shapes allow dword / 16-byte accesses (every shipped shape)
         const bool vec4 = xyz == nullptr && K % 4 == 0 && N % 4 == 0 && ((uintptr_t)z & 15) == 0 && ((uintptr_t)valid_mask_out & 3) == 0 &&
@@ -1620,8 +1619,7 @@ extern "C" int anr_warp_points_reuse(const float* xyz, int xyz_stride, const flo
             }
             if (int rc = check_launch("anr_warp_points (search)")) return rc;
             if (lean) {
-                e = hipMemsetAsync(valid_count_out, 0, sizeof(int32_t), st);
-                if (e != hipSuccess) return fail((int)e, "anr_warp_points_lean: hipMemsetAsync: %s", hipGetErrorString(e));
+                if (int rc = zero_fill(valid_count_out, sizeof(int32_t), st, "anr_warp_points_lean (zero)")) return rc;
                 const int64_t total = (int64_t)bs * N;
                 const int64_t vb = (total + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
                 hipLaunchKernelGGL(warp_valid_list_kernel, dim3((unsigned)(vb < 4096 ? vb : 4096)), dim3(WARP_THREADS), 0, st,
@@ -1651,8 +1649,7 @@ extern "C" int anr_warp_points_reuse(const float* xyz, int xyz_stride, const flo
                            w.sorted, w.live, w.cursor, w.cell_cap2, valid_mask_out, w.cell_seed, G);
         if (int rc = check_launch("anr_warp_points (search)")) return rc;
         if (lean) {
-            e = hipMemsetAsync(valid_count_out, 0, sizeof(int32_t), st);
-            if (e != hipSuccess) return fail((int)e, "anr_warp_points_lean: hipMemsetAsync: %s", hipGetErrorString(e));
+            if (int rc = zero_fill(valid_count_out, sizeof(int32_t), st, "anr_warp_points_lean (zero)")) return rc;
             const int64_t total = (int64_t)bs * N;
             const int64_t vb = (total + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
             hipLaunchKernelGGL(warp_valid_list_kernel, dim3((unsigned)(vb < 4096 ? vb : 4096)), dim3(WARP_THREADS), 0, st,

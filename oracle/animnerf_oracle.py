@@ -370,9 +370,12 @@ def composite(rgb: Tensor, sigma: Tensor, z: Tensor, far: Tensor, white_bkgd: bo
 
 
 def fine_depths(z_coarse: Tensor, weights: Tensor, n_fine: int, u: Optional[Tensor] = None,
-                eps: float = 1e-5) -> Tensor:
+                eps: float = 1e-5, details: bool = False):
     """models/volume_rendering.py:59-97,199-200 — inverse-CDF sampling over the
-    Kc-1 mid-points with weights[1:-1]; u = linspace(0,1,Kf) when deterministic."""
+    Kc-1 mid-points with weights[1:-1]; u = linspace(0,1,Kf) when deterministic.
+    details (a checker's option): also return, per sample, the cdf step `denom` before the `denom < eps -> 1` branch
+    (:92-93) and the distance of u to the nearer cdf entry of its bin (searchsorted's decision) — the two discontinuities a
+    checker must be able to name."""
     Kc = z_coarse.shape[-1]
     bins = 0.5 * (z_coarse[..., :-1] + z_coarse[..., 1:])
     w = weights[..., 1:-1] + eps
@@ -386,9 +389,10 @@ def fine_depths(z_coarse: Tensor, weights: Tensor, n_fine: int, u: Optional[Tens
     hi = torch.clamp_max(hi, Kc - 2)
     c0, c1 = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi)
     b0, b1 = torch.gather(bins, -1, lo), torch.gather(bins, -1, hi)
-    den = c1 - c0
-    den = torch.where(den < eps, torch.ones_like(den), den)
-    return b0 + (u - c0) / den * (b1 - b0)
+    den_raw = c1 - c0
+    den = torch.where(den_raw < eps, torch.ones_like(den_raw), den_raw)
+    z = b0 + (u - c0) / den * (b1 - b0)
+    return (z, den_raw, torch.minimum((u - c0).abs(), (c1 - u).abs())) if details else z
 
 
 def render_rays(field, rays: Tensor, n_coarse: int, n_fine: int, white_bkgd: bool = True, z_fine: Optional[Tensor] = None,

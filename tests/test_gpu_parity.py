@@ -70,6 +70,20 @@ def test_frame_state(dev, smpl_table):
     assert torch.equal(last, torch.tensor([0., 0, 0, 1], device=dev).expand_as(last))
 
 
+class _one_body:
+    """View of a posed model restricted to body b (what a bs = 1 checker needs)."""
+
+    def __init__(self, m, b):
+        self._m, self.verts, self.ober2cano_transform = m, m.verts[b:b + 1].contiguous(), m.ober2cano_transform[b:b + 1].contiguous()
+        self._index = m.knn_index()[b:b + 1].contiguous()
+
+    def knn_index(self):
+        return self._index
+
+    def __getattr__(self, k):
+        return getattr(self._m, k)
+
+
 def _warp_frame(dev, smpl_table):
     g = golden("frame")
     m = seeded_model(smpl_table, 7, True, device=dev)
@@ -91,7 +105,6 @@ def test_knn_matches_reference(dev, smpl_table):
     torch.testing.assert_close(dist.cpu(), d_ref, rtol=1e-5, atol=1e-6)
     same = (idx.cpu() == i_ref)
     # index differences are allowed only between (near-)tied distances
-    assert same.float().mean() > 0.999
     tied = (dist.cpu() - d_ref).abs() <= 1e-6
     assert (same | tied).all()
     assert (dist[..., 1:] >= dist[..., :-1]).all()          # ascending
@@ -106,7 +119,11 @@ def test_warp_matches_reference(dev, smpl_table):
                                                   xyz=xyz, debug=True)
     b_ref = torch.from_numpy(g["blended_dist"])[..., 0]
     ok = (blended.cpu() - b_ref).abs() <= 1e-5 + 1e-5 * b_ref.abs()
-    assert ok.float().mean() > 0.998, "blended distance mismatch beyond confidence-threshold flips"
+    from accounting import neighbour_discontinuity
+    lbs = oracle_table(smpl_table)["lbs_weights"]
+    excuse = neighbour_discontinuity(lbs, torch.from_numpy(g["knn_dist"]), torch.from_numpy(g["knn_idx"]).long())
+    assert (ok | excuse).all(), "blended distance differs away from a neighbour tie / confidence threshold"
+    assert (~ok).sum() <= 16, "sanity: those are a handful of points"
     v_ref = torch.from_numpy(g["valid"])[..., 0]
     v_ok = (pts[..., 3].cpu() == v_ref) | ((b_ref - 0.2).abs() < 1e-5)
     assert v_ok[ok].all()
@@ -134,13 +151,19 @@ def test_warp_from_rays_equals_explicit_points(dev, smpl_table):
     xyz = (rays[..., None, :3] + z[..., None] * rays[..., None, 3:6]).reshape(2, -1, 3)
     b = ana.ops.warp_points(m.knn_index(), m.ober2cano_transform, m.body_model.lbs_weights, 0.2, xyz=xyz)
     # torch may contract o + z*d into an fma (1 ulp); the kernel rounds product and sum separately
-    assert (a[..., 3] == b[..., 3]).float().mean() > 0.999
-    assert ((a[..., :3] - b[..., :3]).abs().max(-1).values < 2e-5).float().mean() > 0.999
-    # against the oracle
-    xc, valid, _ = orc.warp_to_canonical(xyz.cpu(), m.verts.cpu(), m.body_model.lbs_weights.cpu(),
-                                         m.ober2cano_transform.cpu(), 0.2, chunk=1024)
-    assert (a[..., 3].cpu() == valid[..., 0]).float().mean() > 0.999
-    assert ((a[..., :3].cpu() - xc).abs().max(-1).values < 1e-4).float().mean() > 0.998
+    # against the oracle; a point may differ only at one of the reference's discontinuities: the validity threshold, a
+    # neighbour tie, a confidence threshold
+    from accounting import neighbour_discontinuity
+    xc, valid, dbg = orc.warp_to_canonical(xyz.cpu(), m.verts.cpu(), m.body_model.lbs_weights.cpu(),
+                                           m.ober2cano_transform.cpu(), 0.2, chunk=1024)
+    tie = neighbour_discontinuity(m.body_model.lbs_weights.cpu(), dbg["dist"], dbg["idx"])
+    edge = (dbg["blended"][..., 0] - 0.2).abs() <= 1e-5
+    a_, b_ = a.cpu().view(2, -1, 4), b.cpu().view(2, -1, 4)
+    assert ((a_[..., 3] == b_[..., 3]) | edge | tie).all()
+    assert (((a_[..., :3] - b_[..., :3]).abs().max(-1).values < 2e-5) | tie).all()
+    assert ((a_[..., 3] == valid[..., 0]) | edge | tie).all()
+    both = (a_[..., 3] >= 1) & (valid[..., 0] >= 1)
+    assert (((a_[..., :3] - xc).abs().max(-1).values < 1e-5 + RTOL * xc.abs().max(-1).values) | tie | ~both).all()
 
 
 def test_warp_two_pass_equals_one_pass(dev, smpl_table):
@@ -251,13 +274,11 @@ def test_animnerf_forward_api(dev, smpl_table):
     xyz = torch.from_numpy(g["xyz"]).to(dev)[:, :512].contiguous()
     rgb, sigma = m(xyz, None, use_fine=True)
     assert rgb.shape == (2, 512, 3) and sigma.shape == (2, 512, 1)
-    tbl = oracle_table(smpl_table)
-    st = dict(verts=m.verts.cpu(), ober2cano=m.ober2cano_transform.cpu())
-    rgb_o, sig_o = orc.field_query(net_params(m.nerf_fine), xyz.cpu(), st, tbl["lbs_weights"], True, 0.2, chunk=512)
-    inval = sig_o[..., 0] == -1e5
-    assert ((sigma[..., 0].cpu() == -1e5) == inval).float().mean() > 0.998
-    both = (~inval) & (sigma[..., 0].cpu() != -1e5)
-    assert rel_err(rgb.cpu()[both], rgb_o[both]) < 5e-4
+    from accounting import account_for_points
+    for b in range(2):                                          # point by point: within 1e-4 or a named discontinuity
+        mb = _one_body(m, b)
+        st = account_for_points(mb, oracle_table(smpl_table), xyz[b:b + 1], sigma[b:b + 1], rgb[b:b + 1], use_fine=True, label=f"forward api, body {b}")
+        assert st["valid"] > 50
     sg = ana.sigma_grid_inference(m, xyz, chunk=200)
     assert torch.equal(sg, torch.relu(sigma))
 
@@ -315,7 +336,11 @@ def test_sampling_and_compositing_kernels(dev):
         u = torch.rand(R, Kf, generator=gen).to(dev)
         zs2, zf2 = ana.ops.sample_fine_merge(z[0], w, u, want_fine=True)
         assert torch.equal(torch.sort(torch.cat([z[0], zf2], -1), -1).values, zs2)
-        assert ((zf2.cpu() - orc.fine_depths(z_o[0], w_o, Kf, u=u.cpu())).abs() < 2e-5).float().mean() > 0.97
+        zf2_o, den2, gap2 = orc.fine_depths(z_o[0], w_o, Kf, u=u.cpu(), details=True)
+        # off only where the `denom < eps` branch is within rounding of flipping, or where u is within rounding of a cdf
+        # entry (the cdf of the HIP path's weights is 1e-7 from the oracle's): the reference's own discontinuities
+        off = (zf2.cpu() - zf2_o).abs() >= 2e-5
+        assert (off <= (((den2 - 1e-5).abs() <= 4e-7) | (gap2 <= 4e-7))).all(), int((off & ~(((den2 - 1e-5).abs() <= 4e-7) | (gap2 <= 4e-7))).sum())
 
 
 def test_fused_coarse_pass_equals_composite_then_merge(dev, smpl_table):
@@ -387,53 +412,41 @@ CASES = ["cfg2_nowarp", "cfg2_nowarp_gain", "cfg3_warp_gain", "cfg1_coarse32_war
 
 @pytest.mark.parametrize("case", CASES)
 def test_render_matches_reference(dev, smpl_table, case):
+    """The five 64..144-ray reference renders: every ray within 1e-4 of the reference, or accounted for by a named
+    discontinuity of the reference's own path (tests/accounting.py) — no percentage gate."""
     import anim_nerf_amd as ana
+    from accounting import account_for_rays, render_stages
+    from anim_nerf_amd import synthetic as syn
     g = golden("render_" + case)
-    m = seeded_model(smpl_table, g["seed"], g["use_unpose"], g["gain"], g["shift"], device=dev)
+    m = seeded_model(smpl_table, g["seed"], g["use_unpose"], g["gain"], g["shift"], device=dev, mlp_mode="f32")
     vr = ana.VolumeRenderer(n_coarse=int(g["n_coarse"]), n_fine=int(g["n_fine"]), white_bkgd=True)
-    out = ana.batched_inference(vr, m, torch.from_numpy(g["rays_world"]).to(dev), _to(tdict(g), dev), _templ(dev),
-                                chunk=50)
+    rays_w = torch.from_numpy(g["rays_world"])
+    pose, templ = tdict(g), {k: torch.from_numpy(v) for k, v in syn.template_pose_params().items()}
+    out = ana.batched_inference(vr, m, rays_w.to(dev), _to(pose, dev), _templ(dev), chunk=50)
+    stages = render_stages(m, vr, rays_w, pose, templ)
     keys = ["rgbs", "alphas", "depths"] + (["rgbs_fine", "alphas_fine", "depths_fine"] if int(g["n_fine"]) else [])
-    for k in keys:
-        ref = torch.from_numpy(g[k])
-        got = out[k].cpu()
-        assert got.shape == ref.shape
-        bad = ((got - ref).abs() > 1e-5 + RTOL * ref.abs()).any(-1)
-        if not bool(g["use_unpose"]):
-            assert not bad.any(), (k, bad.float().mean().item(), (got - ref).abs().max().item())
-        else:
-            # With the warp on, canonical coordinates carry ~3e-7 of fp32 rounding (4x4 inverses, blends) that
-            # the 2^9 Fourier band and the sigma gain of these fixtures amplify: the reference itself moves by
-            # more than 1e-4 on some rays under a 1-ulp input change (tests/test_oracle_golden.py::
-            # test_reference_conditioning).  Gate: >= 95 % of rays within 1e-4 relative, every ray within 5e-3.
-            assert bad.float().mean() <= 0.05, (k, bad.float().mean().item(), (got - ref).abs().max().item())
-            assert (got - ref).abs().max() < 5e-3 * max(1.0, ref.abs().max().item())
-    # stage-by-stage on the first chunk
-    rays_b = torch.from_numpy(g["rays_body"]).to(dev)
-    m.set_body_model(_to(tdict(g), dev), _templ(dev))
-    m.convert_to_body_model_space(torch.from_numpy(g["rays_world"]).to(dev))
-    m.clac_ober2cano_transform()
-    z = vr.sample_coarse(rays_b)
-    assert torch.equal(z.cpu(), torch.from_numpy(g["z_coarse"]))
-    w, _, _, _ = vr._shade(m, rays_b, z, True, 0.0, True)
-    w_ref = torch.from_numpy(g["weights"])[0]
-    off = (w.cpu() - w_ref).abs() > 2e-6 + RTOL * w_ref.abs()
-    if bool(g["use_unpose"]):       # per-sample weights feel the conditioning more than the per-ray sums do
-        assert off.float().mean() <= 0.01 and (w.cpu() - w_ref).abs().max() < 5e-3
-    else:
-        assert not off.any()
+    for k in keys:                                               # the chunk loop == one pass, bit for bit
+        assert out[k].shape == g[k].shape and torch.equal(out[k], stages["out"][k]), k
+    assert torch.equal(stages["zc"].cpu(), torch.from_numpy(g["z_coarse"]))
+    torch.testing.assert_close(stages["rays_b"].cpu(), torch.from_numpy(g["rays_body"]), rtol=1e-5, atol=5e-6)
+    stats = account_for_rays(m, vr, oracle_table(smpl_table), rays_w, pose, templ, g, stages=stages,
+                             z_fine_ref=g.get("z_fine"), label=case)
+    if not bool(g["use_unpose"]):
+        # no warp, no discontinuity in the coarse pass: per-sample weights too
+        w_ref = torch.from_numpy(g["weights"])[0]
+        assert ((stages["w_c"].cpu().view_as(w_ref) - w_ref).abs() <= 2e-6 + RTOL * w_ref.abs()).all()
+        if case == "cfg2_nowarp":
+            assert stats["outside"] == 0, "literal initialisation, no warp: every ray within 1e-4"
 
 
 @pytest.mark.parametrize("case", ["cfg2_nowarp_gain_4k", "cfg3_warp_gain_4k"])
 def test_every_out_of_tolerance_ray_is_accounted_for(dev, smpl_table, case):
     """4,096-ray reference renders (64 + 64 samples, sigma gain 3000).  North-star tolerance: 1e-4 relative on every
-    rendered value.  The reference's importance sampler is discontinuous (`denom < eps -> 1`, volume_rendering.py:92-93,
-    moves a fine sample by up to a bin when the cdf changes in its last ulp) and so is the warp's validity threshold
-    (anim_nerf.py:183); a ray whose sorted depths or validity bits differ from the reference's cannot be expected to
-    meet 1e-4.  So: every ray outside 1e-4 is re-rendered by the ORACLE with the HIP path's own sorted depths (and
-    validity bits) injected, and must then agree within 1e-4 — 100 % of them; and every such ray must show the cause
-    (a fine depth that differs from the reference's, or a validity bit that differs from the oracle's)."""
+    rendered value; every ray outside it is re-rendered by the ORACLE with the HIP path's own sorted depths, validity bits
+    and (last) canonical points injected and must then agree within 1e-4 — 100 % of them — and must show its cause
+    (tests/accounting.py)."""
     import anim_nerf_amd as ana
+    from accounting import account_for_rays, render_stages
     from test_oracle_golden import big_case_inputs
     from anim_nerf_amd import synthetic as syn
     g = golden("render_" + case)
@@ -444,130 +457,10 @@ def test_every_out_of_tolerance_ray_is_accounted_for(dev, smpl_table, case):
     vr = ana.VolumeRenderer(n_coarse=64, n_fine=64, white_bkgd=True)
     with torch.no_grad():
         out = ana.batched_inference(vr, m, rays_w.to(dev), _to(pose, dev), _templ(dev), chunk=4096)
-        # the same frame stage by stage, to get at the sorted depths and validity bits
-        m.set_body_model(_to(pose, dev), _templ(dev))
-        rays_b = m.convert_to_body_model_space(rays_w.to(dev))
-        m.clac_ober2cano_transform()
-        zc = vr.sample_coarse(rays_b)
-        w_c, rgb_c, dep_c, acc_c = vr._shade(m, rays_b, zc, True, 0.0, True)
-        zs = vr.sample_fine_sorted(zc, w_c)
-        _, rgb_f, dep_f, acc_f = vr._shade(m, rays_b, zs, False, 0.0, False)
-        for k, v in (("rgbs", rgb_c), ("alphas", acc_c), ("depths", dep_c), ("rgbs_fine", rgb_f), ("alphas_fine", acc_f),
-                     ("depths_fine", dep_f)):
-            assert torch.equal(out[k], v), k
-        valid_c = valid_f = None
-        if warp:
-            valid_c = m.warped_points(rays=rays_b, z=zc)[:, 3].view(1, -1, 64).cpu()
-            valid_f = m.warped_points(rays=rays_b, z=zs)[:, 3].view(1, -1, 128).cpu()
-    assert torch.equal(zc.cpu(), orc.coarse_depths(rays_b.cpu(), 64))
-    got = {k: v.cpu() for k, v in out.items()}
-    ref = {k: torch.from_numpy(g[k]) for k in got}
-
-    def outside(a, b):
-        return ((a - b).abs() > 1e-5 + RTOL * b.abs()).any(-1)[0]
-    bad_c = outside(got["rgbs"], ref["rgbs"]) | outside(got["alphas"], ref["alphas"]) | outside(got["depths"], ref["depths"])
-    bad_f = (outside(got["rgbs_fine"], ref["rgbs_fine"]) | outside(got["alphas_fine"], ref["alphas_fine"])
-             | outside(got["depths_fine"], ref["depths_fine"]))
-    bad = torch.nonzero(bad_c | bad_f)[:, 0]
-    R = rays_w.shape[1]
-    print(f"\n{case}: {int(bad_c.sum())} coarse / {int(bad_f.sum())} fine of {R} rays outside 1e-4 of the reference")
-    if not warp:
-        assert not bad_c.any(), "without the warp the coarse pass has no discontinuity: every ray must meet 1e-4"
-    assert bad.numel() <= 0.05 * R
-
-    # ---- the oracle on the out-of-tolerance rays, with the HIP path's decisions injected
-    tbl = oracle_table(smpl_table)
-    st = orc.frame_state(tbl, pose, templ)
-    st, rays_o = orc.to_root_frame(st, rays_w)
-    torch.testing.assert_close(rays_o, rays_b.cpu(), rtol=1e-5, atol=5e-6)
-    st["ober2cano"] = orc.observation_to_canonical(st)
-    Pc, Pf = net_params(m.nerf), net_params(m.nerf_fine)
-    rb = rays_b.cpu()[:, bad]
-    n = bad.numel()
-    if n == 0:
-        return
-
-    def oracle_pass(P, z, valid_hip, rows, xyz_c_hip=None):
-        """the oracle's composite of rays `rows` (indices into `bad`) at depths z; warp on: validity bits from the HIP
-        path, canonical points from the oracle's own warp or (xyz_c_hip) from the HIP path as well."""
-        K, nr = z.shape[-1], rows.numel()
-        rr = rb[:, rows]
-        xyz = (rr[..., None, :3] + z[..., None] * rr[..., None, 3:6]).reshape(1, -1, 3)
-        flips, dx = torch.zeros(nr, dtype=torch.bool), 0.0
-        if warp:
-            xyz_c, valid_o, _ = orc.warp_to_canonical(xyz, st["verts"], tbl["lbs_weights"], st["ober2cano"], 0.2, chunk=2048)
-            flips = (valid_o.view(1, nr, K) != valid_hip).any(-1)[0]
-            if xyz_c_hip is not None:
-                both = (valid_o.view(-1) >= 1) & (valid_hip.reshape(-1) >= 1)
-                dx = (xyz_c_hip.reshape(-1, 3) - xyz_c.reshape(-1, 3))[both].abs().max().item() if both.any() else 0.0
-                xyz_c = xyz_c_hip.reshape(1, -1, 3)
-            rgb, sig = orc.mlp_forward(P, xyz_c)
-            sig = torch.where(valid_hip.reshape(1, -1, 1) < 1, torch.full_like(sig, -1e5), sig)
-        else:
-            rgb, sig = orc.mlp_forward(P, xyz)
-        _, col, dep, acc = orc.composite(rgb.view(1, nr, K, 3), sig.view(1, nr, K), z, rr[..., 7:8])
-        return dict(rgbs=col, depths=dep, alphas=acc), flips, dx
-
-    def residual_of(rows, xyz_hip=(None, None)):
-        oc, vflip_c, dx_c = oracle_pass(Pc, zc.cpu()[:, bad[rows]], valid_c[:, bad[rows]] if warp else None, rows, xyz_hip[0])
-        of, vflip_f, dx_f = oracle_pass(Pf, zs.cpu()[:, bad[rows]], valid_f[:, bad[rows]] if warp else None, rows, xyz_hip[1])
-        res = torch.zeros(rows.numel(), dtype=torch.bool)
-        for k in ("rgbs", "alphas", "depths"):
-            res |= outside(got[k][:, bad[rows]], oc[k]) | outside(got[k + "_fine"][:, bad[rows]], of[k])
-        return res, vflip_c | vflip_f, max(dx_c, dx_f)
-    every = torch.arange(n)
-    residual, vflip, _ = residual_of(every)
-    # the cause: fine depths that are not the reference's (beyond rounding), or validity bits that are not the oracle's
-    zf_ref = torch.from_numpy(g["z_fine"])[:, bad]
-    zs_ref = torch.sort(torch.cat([zc.cpu()[:, bad], zf_ref], -1), -1).values
-    zflip = ((zs.cpu()[:, bad] - zs_ref).abs() > 2e-5).any(-1)[0]          # a sample that changed bins
-    zdiff = (zs.cpu()[:, bad] != zs_ref).any(-1)[0]                        # any bit of any depth (warp on: conditioning)
-    print(f"{case}: of {n} rays: {int(zflip.sum())} with a moved fine depth ({int(zdiff.sum())} with depths that are not "
-          f"the reference's bit for bit), {int(vflip.sum())} with a flipped validity bit, {int(residual.sum())} still outside "
-          f"1e-4 of the oracle given the HIP path's depths/validity")
-    if not warp:
-        assert not residual.any(), "rays that differ from the oracle even with identical sampling decisions: a real bug"
-        assert zflip.all(), "out-of-tolerance rays without a discontinuity to blame"
-        return
-    # Warp on: what is left is the conditioning of the canonical coordinates (tests/test_oracle_golden.py::
-    # test_reference_conditioning: a 1-ulp move of the sample points moves the reference itself by > 1e-4 on some rays;
-    # the 2^9 Fourier band and the sigma gain amplify ~1e-7 of fp32 rounding in the 4x4 inverses and blends).  Third
-    # injection for exactly those rays: the HIP path's canonical points.  Then (a) MLP + compositing must agree with the
-    # oracle within 1e-4 on every one of them, and (b) the injected points must be the oracle's up to fp32 rounding.
-    rows = torch.nonzero(residual)[:, 0]
-    if rows.numel():
-        sub = rays_b[:, bad[rows]].contiguous()
-        wargs = (m.knn_index(), m.ober2cano_transform, m.body_model.lbs_weights, 0.2)
-        dbg_c = ana.ops.warp_points(*wargs, rays=sub, z=zc[:, bad[rows]].contiguous(), debug=True)
-        dbg_f = ana.ops.warp_points(*wargs, rays=sub, z=zs[:, bad[rows]].contiguous(), debug=True)
-        res3, _, _ = residual_of(rows, (dbg_c[0][..., :3].cpu(), dbg_f[0][..., :3].cpu()))
-        # (b): sample by sample.  Where the HIP path's canonical point is not the oracle's up to rounding, the reference's
-        # third discontinuity must be in play: a different (tied) neighbour order, or a blend-weight confidence
-        # exp(-|w_k - w_0|_1 / 0.02) within rounding of its 0.9 threshold (models/anim_nerf.py:165-168).
-        moved = blamed = 0
-        worst_plain = 0.0
-        for (pts_h, dist_h, idx_h, _), z_ in ((dbg_c, zc), (dbg_f, zs)):
-            zz = z_.cpu()[:, bad[rows]]
-            rr = rb[:, rows]
-            xyz = (rr[..., None, :3] + zz[..., None] * rr[..., None, 3:6]).reshape(1, -1, 3)
-            xyz_c, valid_o, dbg = orc.warp_to_canonical(xyz, st["verts"], tbl["lbs_weights"], st["ober2cano"], 0.2, chunk=2048)
-            w_n = tbl["lbs_weights"][dbg["idx"]]
-            conf = torch.exp(-(w_n - w_n[..., 0:1, :]).abs().sum(-1) / (2.0 * orc.WEIGHT_STD ** 2))
-            near_threshold = ((conf - 0.9).abs() < 2e-6).any(-1)[0]
-            other_order = (idx_h.cpu().long() != dbg["idx"]).any(-1)[0]
-            assert ((dist_h.cpu() - dbg["dist"]).abs() <= 1e-6 + 1e-5 * dbg["dist"]).all(), "neighbour distances differ"
-            dx = (pts_h[..., :3].cpu() - xyz_c).abs().max(-1).values[0]
-            live = (valid_o[0, :, 0] >= 1) & (pts_h[0, :, 3].cpu() >= 1)
-            big = live & (dx > 5e-6)
-            moved += int(big.sum())
-            blamed += int((big & (near_threshold | other_order)).sum())
-            worst_plain = max(worst_plain, dx[live & ~big].max().item() if (live & ~big).any() else 0.0)
-            assert (big <= (near_threshold | other_order)).all(), "canonical points moved without a tie or a threshold to blame"
-        print(f"{case}: the {rows.numel()} remaining rays with the HIP path's canonical points injected as well: "
-              f"{int(res3.sum())} outside 1e-4; {moved} samples moved by > 5e-6 ({blamed} at a neighbour tie / confidence "
-              f"threshold), the others within {worst_plain:.1e}")
-        assert not res3.any(), "MLP / compositing differ from the oracle on identical canonical points: a real bug"
-    assert (zdiff | vflip | residual).all(), "out-of-tolerance rays without a discontinuity or conditioning to blame"
+    stages = render_stages(m, vr, rays_w, pose, templ)
+    for k, v in stages["out"].items():
+        assert torch.equal(out[k], v), k
+    account_for_rays(m, vr, oracle_table(smpl_table), rays_w, pose, templ, g, stages=stages, z_fine_ref=g["z_fine"], label=case)
 
 
 def test_warp_on_at_literal_init_every_ray_within_1e_4(dev, smpl_table):
@@ -605,15 +498,19 @@ def test_warp_on_at_literal_init_every_ray_within_1e_4(dev, smpl_table):
     st, rays_o = orc.to_root_frame(st, rays_w)
     st["ober2cano"] = orc.observation_to_canonical(st)
     rb = rays_b.cpu()
+    from accounting import neighbour_discontinuity
     flip = torch.zeros(R, dtype=torch.bool)
     for z_, v_hip in ((zc.cpu(), valid_c), (zs.cpu(), valid_f)):
         xyz = (rb[..., None, :3] + z_[..., None] * rb[..., None, 3:6]).reshape(1, -1, 3)
-        _, valid_o, _ = orc.warp_to_canonical(xyz, st["verts"], tbl["lbs_weights"], st["ober2cano"], 0.2, chunk=4096)
-        flip |= (valid_o.view(1, R, -1) != v_hip).any(-1)[0]
+        _, valid_o, dbg = orc.warp_to_canonical(xyz, st["verts"], tbl["lbs_weights"], st["ober2cano"], 0.2, chunk=4096)
+        flipped = valid_o.view(1, R, -1) != v_hip
+        excuse = ((dbg["blended"][..., 0] - 0.2).abs() <= 1e-5) | neighbour_discontinuity(tbl["lbs_weights"], dbg["dist"], dbg["idx"])
+        assert (flipped <= excuse.view(1, R, -1)).all(), "a validity bit differs from the oracle's away from the threshold"
+        flip |= flipped.any(-1)[0]
     keep = ~flip
-    print(f"\nliteral init: {int(flip.sum())} of {R} rays with a validity bit that is not the oracle's; "
-          f"{int((valid_f.sum(-1) > 0).sum())} rays touch the body")
-    assert flip.float().mean() <= 0.01 and (valid_f.sum(-1) > 0).float().mean() > 0.2
+    print(f"\nliteral init: {int(flip.sum())} of {R} rays with a validity bit that is not the oracle's (each within rounding of "
+          f"dis_threshold); {int((valid_f.sum(-1) > 0).sum())} rays touch the body")
+    assert (valid_f.sum(-1) > 0).float().mean() > 0.2
 
     ref = {k: torch.from_numpy(g[k]) for k in ("rgbs", "alphas", "depths", "rgbs_fine", "alphas_fine", "depths_fine", "z_fine", "weights")}
     far = rb[..., 7:8]
@@ -1072,13 +969,11 @@ def test_sigma_grid_matches_reference_loop(dev, smpl_table):
     center = (m.verts.max(dim=1)[0] + m.verts.min(dim=1)[0]) / 2.
     points = torch.from_numpy(grid).unsqueeze(0).float().to(dev) + center
     ref = ana.sigma_grid_inference(m, points, chunk=5000)[0, :, 0]                  # exact everywhere, full MLP
-    # oracle on a subset (CPU brute force)
-    tbl = oracle_table(smpl_table)
-    sub = torch.arange(0, N ** 3, 7)
-    st = dict(verts=m.verts.cpu(), ober2cano=m.ober2cano_transform.cpu())
-    _, sig_o = orc.field_query(net_params(m.nerf_fine), points[:, sub].cpu(), st, tbl["lbs_weights"], True, 0.2, chunk=512)
-    agree = (torch.relu(sig_o[0, :, 0]) - ref[sub].cpu()).abs() <= 1e-5 + 1e-3 * ref[sub].cpu().abs()
-    assert agree.float().mean() > 0.995
+    # oracle on a subset (CPU brute force), voxel by voxel: within 1e-4 or a named discontinuity
+    from accounting import account_for_points
+    sub = torch.arange(0, N ** 3, 7, device=dev)
+    st = account_for_points(m, oracle_table(smpl_table), points[:, sub], ref[sub], use_fine=True, relu=True, label="sigma grid 24^3")
+    assert st["valid"] > 20
     parts = [ana.sigma_grid(m, N, rng, rng, rng, chunk=3000, rank=r, world=3) for r in range(3)]
     assert [p[1] for p in parts] == [ana.shard_range(N ** 3, r, 3)[0] for r in range(3)]
     fast = torch.cat([p[0] for p in parts])
