@@ -304,9 +304,6 @@ __device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int lane, const fl
     constexpr int MAXS = (KT + LPR - 1) / LPR;
     const int Kc = KC ? KC : Kc_rt, Kf = KF ? KF : Kf_rt;
     const int l = lane % LPR;
-#if defined(ANR_EXP_STOP)                                 // timing experiments only (tools/exp): cut the stage short
-    if (ANR_EXP_STOP == 1) return;
-#endif
     const float eps = 1e-5f;
     const int nb = Kc - 1;                                // bins and cdf entries
     const int np = Kc - 2;                                // pdf entries
@@ -332,9 +329,6 @@ __device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int lane, const fl
         if (s < S && i < np) { run += (double)wl[s]; L.cdf[i + 1] = (float)run; }
     }
     sync();                                               // cdf complete; the weights in wbuf are dead
-#if defined(ANR_EXP_STOP)
-    if (ANR_EXP_STOP == 2) return;
-#endif
 
     // inverse cdf (models/volume_rendering.py:76-96): inds = searchsorted(cdf, u, right=True) = #{i : cdf[i] <= u}, by a
     // branch-free binary search (fixed trip count: the lane's searches interleave).  The sample lands in
@@ -382,9 +376,6 @@ __device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int lane, const fl
         }
     }
     sync();
-#if defined(ANR_EXP_STOP)
-    if (ANR_EXP_STOP == 3) return;
-#endif
 
     // Stable sort of the Kc+Kf depths: rank(p) = #(y < x) + #(y == x, q < p).  Both halves are normally ascending
     // (stratified coarse depths; fine depths from ascending u through a monotone inverse cdf): then a fine sample's rank

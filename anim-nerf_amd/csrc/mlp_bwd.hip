@@ -195,7 +195,6 @@ struct MlpBwd {
                     d4[((4 * Q) % EPF) / 2 + 1] = pk[1];
                     dst = __builtin_bit_cast(Frag, d4);
                     if ((4 * Q + 4) % EPF == 0) pin(dst);
-#ifndef ANR_ABL_NO_DACT_STORE
                     // the two half-waves hold alternate 8-byte pieces of a row; one v_permlane32_swap per dword hands the lower
                     // half-wave both pieces of the even quarter and the upper one both of the odd quarter: 16-byte stores, 32
                     // contiguous bytes per row and instruction (8-byte pieces: 16) — half the store instructions
@@ -206,7 +205,6 @@ struct MlpBwd {
                         const auto s1 = __builtin_amdgcn_permlane32_swap(prev[pd + 1], pk[1], false, false);
                         *reinterpret_cast<g_uint4*>(db.p + dof[n] + (16 * (Q >> 1) + 4 * half) * ESZ) = u32x4n{s0[0], s1[0], s0[1], s1[1]};
                     }
-#endif
                 } else {
                     f32x4 keep;
 #pragma unroll

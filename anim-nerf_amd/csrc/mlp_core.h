@@ -140,15 +140,7 @@ __device__ __forceinline__ float sin_or_cos(float a, int q_off) {
 // DMA's own completion is waited for by hand (`vmcnt(0)` in front of the workgroup barrier, dma_wait()).
 __device__ __forceinline__ void dma16(const char* gsrc_lane, unsigned dst /* LDS byte address, wave-uniform */) {
     unsigned keep;
-#if !defined(ANR_DMA_MODE) || ANR_DMA_MODE == 0      /* cache-policy experiment (profiles/r03/mlp_weight_stream.md) */
 #define ANR_DMA_MOD ""
-#elif ANR_DMA_MODE == 1
-#define ANR_DMA_MOD " sc1"
-#elif ANR_DMA_MODE == 2
-#define ANR_DMA_MOD " nt"
-#else
-#define ANR_DMA_MOD " sc0 sc1"
-#endif
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ANR_DMA_MOD "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc_lane), "s"(__builtin_amdgcn_readfirstlane(dst))
@@ -265,13 +257,7 @@ struct Mlp {
     // SAVE (training forward: the register file is full with the store staging): no bias registers — the bias of tile T+1
     // is read from LDS straight into the accumulators tile T+1 will use (free since tile T-1's epilogue, which ran behind
     // tile T's first MFMAs) and the tile accumulates onto it; 32 registers less, no spills in front of the stores
-#ifdef ANR_EXP_BIAS_IN_ACC_ALL
-    static constexpr bool BIAS_IN_ACC = true;
-#elif defined(ANR_EXP_BIAS_IN_ACC_W4)
-    static constexpr bool BIAS_IN_ACC = SAVE || NT == 2;
-#else
     static constexpr bool BIAS_IN_ACC = SAVE;
-#endif
     Frag w0[4];              // first fragment group of tile c
     char* act_base;          // SAVE: the activation buffer (blocked layout above) and its row count
     int64_t act_rows;
@@ -297,9 +283,6 @@ struct Mlp {
     // safe (T = 0 leaves out the output stores and the point prefetch of the previous point tile).
     static __host__ __device__ constexpr int stores_since_dma(int T) {
         if (!SAVE) return 0;
-#if defined(ANR_ABL_NO_ACT_STORE) || defined(ANR_ABL_NO_BITS)
-        return 0;                                  // timing ablations change the store count: drain
-#endif
         const int first = T == 0 ? LAST_CHUNK * TPC : T - TPC, last = T == 0 ? LAST_TILE : T - 1;
         int n = 0;
         for (int U = first; U <= last; ++U) n += epi_stores(U - 1);
@@ -311,7 +294,6 @@ struct Mlp {
     uint4 sreg[DMA ? 1 : MAXP];
     unsigned spend_slot; int spend_nf;
     template <int T> __device__ __forceinline__ void advance() {
-#ifndef ANR_ABL_NO_BARRIER
         if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(stores_since_dma(T)) : "memory");
         else {
             // DMA off: the chunk loaded into registers one chunk ago goes to its ring slot now
@@ -322,8 +304,6 @@ struct Mlp {
             spend_nf = 0;
         }
         __syncthreads();
-#endif
-#ifndef ANR_ABL_NO_STAGE
         // chunk c+2 of this pass, or — the workgroup is persistent — chunk 0/1 of the NEXT point tile: the weight
         // stream never drains between tiles.  Nothing may be in flight into LDS when the workgroup ends.
         if (c + 2 < NCHUNK || more) {
@@ -339,7 +319,6 @@ struct Mlp {
             }
             gnext += nf * FRAG_BYTES;
         }
-#endif
     }
     __device__ __forceinline__ void rotate() {
         unsigned t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_stage; slot_stage = t;
@@ -393,9 +372,6 @@ struct Mlp {
             }
         }
         template <int Q> __device__ __forceinline__ void part() const {
-#ifdef ANR_ABL_NO_EPILOGUE
-            if (Q > 0) return;
-#endif
             parts<Q>();
             if constexpr (SAVE && Q == 3) ab.template step<1>();         // the tiles that store walk the blocks in order
         }
@@ -444,13 +420,8 @@ struct Mlp {
                         constexpr int pd = ((4 * (Q - 1)) % EPF) / 2;
                         const auto s0 = __builtin_amdgcn_permlane32_swap(prev[pd], pk[0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(prev[pd + 1], pk[1], false, false);
-#ifndef ANR_ABL_NO_ACT_STORE
                         *reinterpret_cast<g_uint4*>(ab.p + ao[n] + (16 * (Q >> 1) + 4 * half) * ESZ) = u32x4n{s0[0], s1[0], s0[1], s1[1]};
-#else
-                        asm volatile("" :: "v"(s0[0]), "v"(s1[0]), "v"(s0[1]), "v"(s1[1]));
-#endif
                     }
-#ifndef ANR_ABL_NO_BITS
                     if constexpr (SAVE && RELU) {
                         // after the ReLU a bf16 is > 0 exactly when its bit pattern is non-zero: min(x, 1) per 16-bit half is
                         // the flag, and (flags so far << 1) | flag collects pair k at bits 7 - k / 23 - k
@@ -462,7 +433,6 @@ struct Mlp {
                         }
                         if constexpr (Q == 3) put_bits(n, __builtin_amdgcn_perm(0u, sb[n], 0x0c0c0200u));     // bytes 0 and 2
                     }
-#endif
                 } else {
                     f32x4 keep;
 #pragma unroll
@@ -529,15 +499,9 @@ struct Mlp {
             constexpr int j = decltype(jc)::value;
             Frag (&use)[4] = (j & 1) ? wb : wa;
             Frag (&ld)[4] = (j & 1) ? wa : wb;
-#ifdef ANR_ABL_NO_FRAG_LOAD                        // timing ablation: no LDS fragment reads (registers recycled)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { ld[q] = use[q]; pin(ld[q]); }
-            if (j + 1 == NG && !BIAS_IN_ACC) bias_n = bias_c;
-#else
 #pragma unroll
             for (int q = 0; q < 4; ++q) ld[q] = (j + 1 < NG) ? cur[((j + 1) * 4 + q) * 64] : nxt[q * 64];
             if constexpr (j + 1 == NG && !BIAS_IN_ACC) bias_n = read_bias(END ? 0 : T + 1);
-#endif
             __builtin_amdgcn_sched_barrier(0);          // the loads above are issued before this group's MFMAs
             static_for<4>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
@@ -548,12 +512,6 @@ struct Mlp {
                     if (f == 0 && !BIAS_IN_ACC) acc[PAR][n] = mma_c(use[q], x, bias_c);
                     else                        mma(use[q], x, acc[PAR][n]);
                 }
-#ifdef ANR_EPI_ONE_GROUP
-                if (j == 0) {
-                    pending.template part<q>();
-                    __builtin_amdgcn_sched_barrier(0);  // keep the epilogue pieces between the MFMAs
-                }
-#else
                 // The four quarters of the previous tile's epilogue ride behind MFMAs of the first TWO groups (one
                 // quarter per two MFMA steps): packed into one group they need more issue slots than its MFMAs leave.
                 // (A two-group tile consumes the fragments the epilogue produces in its second group: keep one group.)
@@ -566,7 +524,6 @@ struct Mlp {
                     pending.template part<q>();
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#endif
                 // BIAS_IN_ACC: the other accumulator set is free once the pending epilogue has read it (groups 0 and 1;
                 // all of it in group 0 of a short tile): the next tile's bias goes there under the last group's MFMAs
                 if constexpr (BIAS_IN_ACC && !END && j + 1 == NG && q == (NG == 1 ? 3 : 0)) {
@@ -691,7 +648,6 @@ struct Mlp {
                     const int32_t id = index[idx];
                     dst[n] = pts[id];
                     dst[n].w = __int_as_float(id);
-#ifndef ANR_ABL_NO_RAYS
                 } else if (!VIEW && rays) {
                     // no warp (use_unpose=False): the sample point is generated here, x = o + z d with the product and
                     // the sum rounded separately like anr_points_from_rays; `pts` is then the depth array z[n]
@@ -716,7 +672,6 @@ struct Mlp {
 #pragma unroll
                     for (int a = 0; a < 3; ++a) asm("v_mul_f32_e32 %0, %1, %2" : "=v"(m[a]) : "v"(zz), "v"(ry[3 + a]));
                     dst[n] = make_float4(ry[0] + m[0], ry[1] + m[1], ry[2] + m[2], 1.0f);
-#endif
                 } else {
                     dst[n] = pts[idx];
                 }

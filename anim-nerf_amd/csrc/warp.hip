@@ -617,11 +617,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
                 // farther than the threshold from the whole body -> cannot be valid (see warp_points_kernel)
                 near = box_d2(gbox, px, py, pz) < thr * thr;
                 bool reused = false;
-#ifdef ANR_ABL_CLS_NOREUSE
-                if (false) {
-#else
                 if (FROM_RAYS && perm != nullptr) {
-#endif
                     // fine pass: this sorted sample IS coarse sample p of the same ray (z_sorted[j] = cat(z_coarse, z_fine)
                     // [perm[j]]) -> its canonical point and validity were computed in the coarse pass: copy, do not search
                     const int pj = VEC4 ? (int)((pm >> (8 * v)) & 0xffu) : (int)perm[o];
@@ -649,20 +645,16 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
                     // lean mode (validity bytes requested): consumers look at the byte, not at the point, so the 16-B point
                     // of a far sample is not written at all
                     if (!VEC4 && valid_mask != nullptr) valid_mask[o] = 0;
-#ifndef ANR_ABL_CLS_NOPTS
                     if (valid_mask == nullptr || near) pts_out[o] = make_float4(px, py, pz, 0.0f);
-#endif
                     if (nbr_w != nullptr) {
                         reinterpret_cast<float4*>(nbr_w)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
                         reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(0, 0, 0, 0);
                     }
                     if (near) {
                         cell = cell_of_inv(gbox, thr, G, cell_inv, px, py, pz);
-#ifndef ANR_ABL_CLS_NOHASH
                         const int slot = hash_slot(hkeys, cell);
                         if (slot >= 0) atomicAdd(&hcnt[slot], 1);
                         else atomicAdd(cell_count + (int64_t)b * NCELL + cell, 1);
-#endif
                     }
                 }
             }
@@ -689,7 +681,6 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
         }
         __syncthreads();
         int64_t pos = (int64_t)b * N + block_base + wave_cnt[wave] + incl - mine;
-#ifndef ANR_ABL_CLS_NOLIST
 #pragma unroll
         for (int it = 0; it < CLS_ITERS; ++it) {
             if ((near_bits >> it) & 1u) {
@@ -698,7 +689,6 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
                 ++pos;
             }
         }
-#endif
     }
     __syncthreads();
     for (int s = threadIdx.x; s < HN; s += WARP_THREADS)

@@ -352,7 +352,11 @@ class FlatAdam(torch.optim.Optimizer):
     graph capture bakes them in).  A parameter whose `.grad` is None is skipped, as torch does."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        # (the keys torch.optim.Adam's param_groups carry, with the values this optimiser implements: a state_dict() of
+        # GPU training loads into torch.optim.Adam — the CPU / non-contiguous fallback and what the reference uses — and steps)
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=False))
         ps = [p for g in self.param_groups for p in g["params"]]
         if not ps or len(self.param_groups) > 4:
             raise ValueError("FlatAdam: 1 to 4 parameter groups with at least one tensor")
@@ -441,17 +445,17 @@ class Trainer:
     def __init__(self, anim_nerf, volume_renderer, hp: TrainHParams, body_model_params: Optional[BodyModelParams] = None,
                  graph: bool = False):
         """graph=True: `step_graphed` may capture the whole step (forward, losses, backward, Adam) into ONE HIP graph and
-        replay it — ~190 launches per step leave the host as one (the step holds no device -> host read: row counts stay
-        on the device; FlatAdam keeps its step counter there too).  Opt-in, and meant to be driven inside `with
-        trainer.loop():` — from the default stream, a run that called torch.cuda.synchronize(), touched the default stream and
-        went on replaying ended in a GPU memory fault on ROCm 7.2 (tools/soak_train.py)."""
+        replay it — every launch of the step leaves the host as one (the step holds no device -> host read: row counts stay
+        on the device; FlatAdam keeps its step counter there too).  Opt-in.  `with trainer.loop():` runs the loop on the
+        Trainer's stream and saves the two stream fences per step; it is an optimisation, not a requirement: the GPU memory
+        fault long replayed runs used to end in was a hipMemsetAsync NODE of the captured graph going stale (ROCm 7.2;
+        DESIGN.md section 4.4, tools/exp/graph_hazard_torch_only.py) and the library issues no memset any more."""
         self.model, self.renderer, self.hp = anim_nerf, volume_renderer, hp
         self.body_model_params = body_model_params
         self.graph_enabled = bool(graph)
         self._graph = None                                    # (signature, CUDAGraph, static inputs, static outputs)
         self._graph_warm = 0
         self._graph_split = False                             # the graph ends with backward (more than one rank)
-        self._warned_stream = False
         for name, p in anim_nerf.named_parameters():          # SMPL member params are unused by the forward
             if name.startswith("body_model."):
                 p.requires_grad_(False)
@@ -493,7 +497,8 @@ class Trainer:
         # (which create those nodes), every eager step, the capture and the replays all run on it, fenced against the caller's
         # current stream on both sides.
         self._stream = torch.cuda.Stream(self.params[0].device) if (self.graph_enabled and on_gpu) else None
-        with self._own_stream():
+        # (construction enqueues nothing the caller's stream must see: no fence against it here)
+        with (torch.cuda.stream(self._stream) if self._stream is not None else contextlib.nullcontext()):
             self.reducer = GradientReducer([fine, coarse + rest])
             if on_gpu:
                 for net in nets:
@@ -508,10 +513,8 @@ class Trainer:
     def loop(self):
         """Run a training loop on the Trainer's stream: `with trainer.loop(): for batch in ...: trainer.step_graphed(...)`.
         Everything inside — the steps, progress reads (`loss.item()`), validation renders — then shares ONE stream with the
-        replays and no event ever makes the legacy default stream wait for the capture stream.  That wait is what the replay
-        hazard of DESIGN.md section 4.4 needs (ROCm 7.2: replays, torch.cuda.synchronize(), any work on the default stream,
-        a replay -> GPU memory fault, as soon as the default stream has ONCE waited on the capture stream); `step_graphed`
-        called from the default stream issues one per step.  No-op for a Trainer without graph=True."""
+        replays, and `step_graphed` issues no fence against the caller's stream (two event records + waits per step otherwise).
+        No-op for a Trainer without graph=True."""
         with self._own_stream():
             yield self
 
@@ -522,9 +525,11 @@ class Trainer:
             yield
             return
         self._stream.wait_stream(cur)
-        with torch.cuda.stream(self._stream):
-            yield
-        cur.wait_stream(self._stream)
+        try:
+            with torch.cuda.stream(self._stream):
+                yield
+        finally:
+            cur.wait_stream(self._stream)
 
     def _attach_prior_points(self, fg_points, bg_points):
         """The prior points' sigma comes out of the render passes (NeRF.attach_riders) when the fused losses will ask for it."""
@@ -563,12 +568,6 @@ class Trainer:
                 return [x for k in sorted(v) for x in flat(v[k], f"{prefix}.{k}")]
             return [(prefix, v)] if torch.is_tensor(v) else []
         leaves = [x for k in sorted(args) for x in flat(args[k], k)]
-        if (self._stream is not None and not self._warned_stream and torch.cuda.current_stream(self._stream.device) != self._stream):
-            import warnings
-            self._warned_stream = True
-            warnings.warn("Trainer.step_graphed called from another stream than the Trainer's: wrap the training loop in "
-                          "`with trainer.loop():` (DESIGN.md section 4.4: replays issued across streams, a device "
-                          "synchronise and work on the default stream ended in a GPU memory fault on ROCm 7.2)")
         with self._own_stream():
             return self._step_graphed(args, leaves, perturb, eager)
 
@@ -599,7 +598,7 @@ class Trainer:
         if eager:
             return self.step(args["rays"], args["rgbs"], args["alphas"], args["bmp"], args["templ"], args["fg"], args["bg"],
                              perturb=perturb, frame_idx=args["frame_idx"])
-        _, graph, static_leaves, outs = self._graph
+        _, graph, static_leaves, outs, _pins = self._graph
         for (_, src), dst in zip(leaves, static_leaves):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
@@ -634,7 +633,13 @@ class Trainer:
         finally:
             self.reducer.deferred = False
         self._graph_split = split
-        self._graph = (sig, graph, static_leaves, (loss, details))
+        # Every address the capture baked in that is NOT in the graph's private pool must outlive the graph: module-level
+        # scratch that is REPLACED when a later eager call needs more (ops._WGRAD_WS, ops._LOSS_WS) and FlatAdam's chunk table
+        # (rebuilt when a .grad pointer moves).  The graph pins what it saw; a replacement allocates next to it.
+        from . import ops
+        pins = [list(ops._WGRAD_WS.values()), list(ops._LOSS_WS.values()), getattr(self.optimizer, "_table", None),
+                [p.grad for p in self.params]]
+        self._graph = (sig, graph, static_leaves, (loss, details), pins)
 
     def step(self, rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points=None, bg_points=None,
              perturb=1.0, frame_idx=None):

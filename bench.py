@@ -338,10 +338,34 @@ def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling=
                 err = (got - ref[key]).abs().max(-1).values / ref[key].abs().max(-1).values.clamp_min(1e-3)
                 check[m] = {"max_rel_err_rgb": err.max().item(), "rays_within_1e-4": (err <= 1e-4).float().mean().item(),
                             "psnr_db": _psnr(got, ref[key])}
+                if m == "f32":
+                    # every ray outside 1e-4 re-rendered by the oracle with the HIP path's sampling decisions injected
+                    # (tests/accounting.py: the checker, never on a timed path)
+                    check[m]["accounting"] = _account(lambda acc: acc.account_for_rays(
+                        model, vr, _oracle_table(tbl), sub.cpu(), {k: v.cpu() for k, v in pose.items()},
+                        {k: v.cpu() for k, v in templ.items()}, ref, z_fine_ref=ref.get("_z_fine"), label="bench", quiet=True))
             for net in (model.nerf, model.nerf_fine):
                 net.mlp_mode = mode
             result["oracle_check"] = check
     return result
+
+
+def _oracle_table(tbl):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_table
+    return oracle_table(tbl)
+
+
+def _account(fn):
+    """Run one of tests/accounting.py's checkers for an `oracle_check` entry: its statistics, or what it could not account for."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import accounting
+    try:
+        stats = fn(accounting)
+        stats["every_difference_accounted_for"] = True
+        return stats
+    except AssertionError as exc:
+        return {"every_difference_accounted_for": False, "unaccounted": str(exc)[:300]}
 
 
 def grid_bench(args, ctx, mode, steps, warmup, dense=False):
@@ -380,6 +404,38 @@ def grid_bench(args, ctx, mode, steps, warmup, dense=False):
             _, tris = ana.mesh.marching_cubes(field, 0.0)
             torch.cuda.synchronize(dev)
             mesh_ms, mesh_tris = (time.perf_counter() - t0) * 1e3, int(tris.shape[0])
+        check = None
+        if world == 1 and args.cpu_rays > 0:
+            # the oracle on sampled voxels of THIS grid (half of them occupied ones): extract_mesh.py:27-61 restated on the CPU,
+            # against the timed mode and — voxel by voxel, tests/accounting.py — against the fp32 parity mode
+            import numpy as np
+            g = torch.Generator().manual_seed(3)
+            flat_occ = torch.nonzero(sig > 0)[:, 0]
+            sel = torch.cat([flat_occ[torch.randint(0, flat_occ.numel(), (2048,), generator=g).to(dev)],
+                             torch.randint(0, N ** 3, (2048,), generator=g).to(dev)])
+            lin = np.linspace(-1.2, 1.2, N)
+            a, b, c = (sel // (N * N)).cpu().numpy(), ((sel // N) % N).cpu().numpy(), (sel % N).cpu().numpy()
+            center = (model.verts.max(dim=1)[0] + model.verts.min(dim=1)[0]) / 2.
+            points = torch.from_numpy(np.stack([lin[b], lin[a], lin[c]], -1)).unsqueeze(0).float().to(dev) + center
+            from oracle import animnerf_oracle as orc
+            otbl = _oracle_table(tbl)
+            st = dict(verts=model.verts.cpu(), ober2cano=model.ober2cano_transform.cpu())
+            P = {k: v.detach().cpu() for k, v in model._net(True).named_parameters()}
+            want = torch.relu(orc.field_query(P, points.cpu(), st, otbl["lbs_weights"], True, model.dis_threshold, chunk=1024)[1][0, :, 0])
+            got = sig[sel].cpu()
+            scale = want[want > 0].median().item() if (want > 0).any() else 1.0
+            check = {"voxels": int(sel.numel()), "occupied_in_oracle": int((want > 0).sum()),
+                     mode: {"occupancy_agreement": ((got > 0) == (want > 0)).float().mean().item(),
+                            "max_abs_err_over_median_sigma": ((got - want).abs().max() / scale).item(),
+                            "voxels_within_1e-4": ((got - want).abs() <= 1e-4 * want.abs() + 1e-4 * scale).float().mean().item()}}
+            for net in (model.nerf, model.nerf_fine):
+                net.mlp_mode = "f32"
+            sig32 = ana.sigma_grid(model, N, chunk=1 << 27)[0]
+            check["f32"] = {"voxels_within_1e-4": ((sig32[sel].cpu() - want).abs() <= 1e-4 * want.abs() + 1e-4 * scale).float().mean().item(),
+                            "accounting": _account(lambda acc: acc.account_for_points(model, otbl, points, sig32[sel], use_fine=True, relu=True,
+                                                                                      dis_threshold=model.dis_threshold, label="bench cfg5", quiet=True))}
+            for net in (model.nerf, model.nerf_fine):
+                net.mlp_mode = mode
     return {
         "metric": "grid points/sec, 512^3 sigma query (mesh extraction input)", "value": N ** 3 * steps / elapsed,
         "unit": "points/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -390,6 +446,7 @@ def grid_bench(args, ctx, mode, steps, warmup, dense=False):
                    "occupied_voxels_this_rank": int((sig > 0).sum()),
                    "marching_cubes_after_the_timed_region": {"ms": mesh_ms, "triangles": mesh_tris, "threshold": 5.0}},
         "roofline": mlp_roofline(per_kernel, "mlp_forward", mode, MLP_FLOP_SIGMA_ONLY, f"mlp_kernel<{mode}, sigma only>"),
+        **({"oracle_check": check} if check else {}),
     }
 
 
@@ -599,9 +656,18 @@ def main():
                 # HERE with exit code 0 on all ranks — the scaling measurement reads the line, not the extras
                 if rank == 0:
                     result["workloads"] = {**w, fn.__name__: {"error": err or "failed on another rank"}}
+                    result["extras_failed"] = True          # top level: a reader of the line need not walk the workloads
                     print(json.dumps(result), flush=True)
                 sys.stdout.flush()
-                os._exit(0)                                 # no destroy_process_group: a failed rank may not answer
+                # best-effort teardown (a failed rank may never answer: bounded), then leave.  Exit code 0 by default — the
+                # headline on the line is measured and valid, and the scaling harness reads the line; ANR_BENCH_STRICT=1
+                # (CI) turns a failed extra into exit code 3.
+                import threading
+                import torch.distributed as dist
+                t = threading.Thread(target=lambda: dist.destroy_process_group(), daemon=True)
+                t.start()
+                t.join(10.0)
+                os._exit(3 if os.environ.get("ANR_BENCH_STRICT") else 0)
             return got if err is None else {"error": err}
         w = {}
         if world == 1:
@@ -611,7 +677,7 @@ def main():
                               keep=("roofline_hbm_kernels", "kernel_time_share", "oracle_check", "cpu_baseline"))
             w["cfg3_dense"] = extra(render_bench, args, ctx, True, args.mode, 2, 1, dense=True)
             w["cfg4"] = extra(train_bench_child, args, ctx, args.mode, 8, 4, keep=("kernel_time_share", "final_loss"))
-            w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 2)
+            w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 2, keep=("oracle_check",))
         else:
             # N > 1: the strong-scaling counterpart of the headline (one frame's rays sliced over the ranks), the warp
             # workload, and the training step with its RCCL gradient buckets
@@ -621,12 +687,17 @@ def main():
             w["cfg4"] = extra(train_bench, args, ctx, args.mode, 8, 4, keep=("final_loss",))
             w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 2)
         result["workloads"] = w
+        failed = [k for k, v in {**w, **result.get("modes", {})}.items() if isinstance(v, dict) and "error" in v]
+        if failed:
+            result["extras_failed"] = True
 
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    if result.get("extras_failed") and os.environ.get("ANR_BENCH_STRICT"):
+        sys.exit(3)
 
 
 def cpu_baseline(args, tbl, model, rays, pose_np, use_warp, max_rays=None):

@@ -374,8 +374,8 @@ def fine_depths(z_coarse: Tensor, weights: Tensor, n_fine: int, u: Optional[Tens
     """models/volume_rendering.py:59-97,199-200 — inverse-CDF sampling over the
     Kc-1 mid-points with weights[1:-1]; u = linspace(0,1,Kf) when deterministic.
     details (a checker's option): also return, per sample, the cdf step `denom` before the `denom < eps -> 1` branch
-    (:92-93) and the distance of u to the nearer cdf entry of its bin (searchsorted's decision) — the two discontinuities a
-    checker must be able to name."""
+    (:92-93), the distance `gap` of u to the nearer cdf entry of its bin (searchsorted's decision) — the two discontinuities
+    a checker must be able to name — and the bin's `width` (d z / d cdf = width / denom: the sample's conditioning)."""
     Kc = z_coarse.shape[-1]
     bins = 0.5 * (z_coarse[..., :-1] + z_coarse[..., 1:])
     w = weights[..., 1:-1] + eps
@@ -392,7 +392,9 @@ def fine_depths(z_coarse: Tensor, weights: Tensor, n_fine: int, u: Optional[Tens
     den_raw = c1 - c0
     den = torch.where(den_raw < eps, torch.ones_like(den_raw), den_raw)
     z = b0 + (u - c0) / den * (b1 - b0)
-    return (z, den_raw, torch.minimum((u - c0).abs(), (c1 - u).abs())) if details else z
+    if details:
+        return z, dict(denom=den_raw, gap=torch.minimum((u - c0).abs(), (c1 - u).abs()), width=b1 - b0)
+    return z
 
 
 def render_rays(field, rays: Tensor, n_coarse: int, n_fine: int, white_bkgd: bool = True, z_fine: Optional[Tensor] = None,

@@ -54,23 +54,33 @@ def render_stages(model, vr, rays_w, pose, templ):
     return dict(out={k: shape(v) for k, v in out.items()}, rays_b=rays_b, zc=zc, zs=zs, w_c=w_c, valid_c=valid_c, valid_f=valid_f)
 
 
+def importance_sample_excuse(z_hip, z_oracle, det, eps=1e-5, cdf_rounding=1e-6):
+    """bool tensor: where a fine depth of the HIP path may differ from the reference sampler's on the same weights.  The cdf
+    entries are fp32 sums next to 1 over a pdf normalised by a 62-term fp32 sum: they carry ~`cdf_rounding` of absolute
+    rounding, whatever order the terms are added in.  That rounding (a) flips the `denom < eps -> 1` branch
+    (models/volume_rendering.py:92-93) where denom is within it of eps, (b) flips searchsorted's bin where u is within it of a
+    cdf entry, and (c) moves the interpolated depth by (rounding / denom) x bin width — nearly empty bins (denom just above
+    eps = 1e-5) are ill-conditioned by construction.  Anything beyond 2e-5 + (c) that is not (a) or (b) is a bug."""
+    den = det["denom"]
+    allowed = 2e-5 + cdf_rounding / torch.where(den < eps, torch.ones_like(den), den) * det["width"].abs()
+    off = (z_hip - z_oracle).abs() > allowed
+    return off, ((den - eps).abs() <= cdf_rounding) | (det["gap"] <= cdf_rounding)
+
+
 def check_importance_samples(vr, zc, w_c, zs, eps=1e-5):
-    """The HIP path's importance samples ARE the reference sampler's output on the HIP path's own coarse weights: every fine
-    depth within 2e-5 of orc.fine_depths(zc, w_c), except where the sampler's `denom < eps -> 1` branch
-    (models/volume_rendering.py:92-93) is within rounding of flipping — cdf entries are sums next to 1, so `denom` carries
-    ~1e-7 of absolute rounding against eps = 1e-5 — or u lies within that rounding of a cdf entry (searchsorted's side).  Returns (samples, samples at the branch that moved)."""
+    """The HIP path's importance samples ARE the reference sampler's output on the HIP path's own coarse weights, up to the
+    conditioning `importance_sample_excuse` spells out.  Returns (samples, samples that moved at a named discontinuity)."""
     import anim_nerf_amd as ana
     bs, R, Kc = zc.shape
     Kf = vr.n_fine
     u = vr._table(zc.device, "u", Kf)
     zs2, zf = ana.ops.sample_fine_merge(zc.view(bs * R, Kc), w_c.view(bs * R, Kc), u, want_fine=True)
     assert torch.equal(zs2.view_as(zs), zs), "fused coarse pass and the stand-alone sampler disagree"
-    zf_o, den, gap = orc.fine_depths(zc.cpu(), w_c.view(bs, R, Kc).cpu(), Kf, details=True)
-    moved = (zf.view(bs, R, Kf).cpu() - zf_o).abs() > 2e-5
-    at_branch = ((den - eps).abs() <= 4e-7) | (gap <= 4e-7)
-    assert (moved <= at_branch).all(), (f"{int((moved & ~at_branch).sum())} importance samples differ from the reference sampler's "
-                                        "on the same weights away from the denom < eps branch")
-    return moved.numel(), int(moved.sum())
+    zf_o, det = orc.fine_depths(zc.cpu(), w_c.view(bs, R, Kc).cpu(), Kf, details=True)
+    off, excuse = importance_sample_excuse(zf.view(bs, R, Kf).cpu(), zf_o, det, eps)
+    assert (off <= excuse).all(), (f"{int((off & ~excuse).sum())} importance samples differ from the reference sampler's on the "
+                                   "same weights away from its discontinuities")
+    return off.numel(), int(off.sum())
 
 
 def account_for_rays(model, vr, smpl_tbl_oracle, rays_w, pose, templ, ref, *, stages=None, z_fine_ref=None, label="", dis_threshold=0.2,

@@ -13,8 +13,8 @@ world (build container only; the reference never enters this repository):
                    torchmetrics / torchvision / cv2, none of which is installed: stub modules stand in for them (nothing
                    of theirs is on the path measured here).
 
-What is stored: seeds and checksums for everything regenerated from seeds (SMPL-like table, MLP weights, the normal
-term's two `randn_like` draws), small inputs, and the reference's outputs.
+What is stored: seeds and checksums for everything regenerated from seeds (SMPL-like table, MLP weights), small inputs, the
+normal term's two `randn_like` draws, and the reference's outputs.
 """
 import importlib.util
 import os
@@ -161,12 +161,11 @@ def main():
     finally:
         torch.randn_like = real
     assert len(drawn) == 2 and drawn[0].shape == verts_template.shape
-    torch.manual_seed(c["draw_seed"])                             # the test regenerates them this way
-    assert torch.equal(torch.randn(verts_template.shape), drawn[0]) and torch.equal(torch.randn(verts_template.shape), drawn[1])
+    # (the draws travel in the fixture: torch.randn(seed) on another CPU's vector units does not reproduce them bit for bit)
     loss.backward()
     out = {k: np.asarray(v) for k, v in c.items()}
     out.update(table_checksum=syn.table_checksum(tbl), weights_checksum=weights_checksum(model.nerf),
-               weights_checksum_fine=weights_checksum(model.nerf_fine), draws_checksum=sha(*drawn),
+               weights_checksum_fine=weights_checksum(model.nerf_fine), draw_0=drawn[0].numpy(), draw_1=drawn[1].numpy(),
                sigma_bias=model.nerf.sigma.bias.detach().numpy().copy(), sigma_bias_fine=model.nerf_fine.sigma.bias.detach().numpy().copy(),
                rays=rays.numpy(), target_rgb=tgt_rgb.numpy(), target_alpha=tgt_a.numpy(), fg_points=fg.numpy(), bg_points=bg.numpy(),
                verts_template_sub=verts_template[:, ::53].numpy(), total=np.float64(loss.item()))

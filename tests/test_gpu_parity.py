@@ -336,11 +336,10 @@ def test_sampling_and_compositing_kernels(dev):
         u = torch.rand(R, Kf, generator=gen).to(dev)
         zs2, zf2 = ana.ops.sample_fine_merge(z[0], w, u, want_fine=True)
         assert torch.equal(torch.sort(torch.cat([z[0], zf2], -1), -1).values, zs2)
-        zf2_o, den2, gap2 = orc.fine_depths(z_o[0], w_o, Kf, u=u.cpu(), details=True)
-        # off only where the `denom < eps` branch is within rounding of flipping, or where u is within rounding of a cdf
-        # entry (the cdf of the HIP path's weights is 1e-7 from the oracle's): the reference's own discontinuities
-        off = (zf2.cpu() - zf2_o).abs() >= 2e-5
-        assert (off <= (((den2 - 1e-5).abs() <= 4e-7) | (gap2 <= 4e-7))).all(), int((off & ~(((den2 - 1e-5).abs() <= 4e-7) | (gap2 <= 4e-7))).sum())
+        from accounting import importance_sample_excuse
+        zf2_o, det2 = orc.fine_depths(z_o[0], w_o, Kf, u=u.cpu(), details=True)
+        off, excuse = importance_sample_excuse(zf2.cpu(), zf2_o, det2)    # off only at the reference's own discontinuities
+        assert (off <= excuse).all(), int((off & ~excuse).sum())
 
 
 def test_fused_coarse_pass_equals_composite_then_merge(dev, smpl_table):
@@ -1179,3 +1178,92 @@ def test_marching_cubes_kernels(dev):
     assert abs(vol - 4 / 3 * np.pi * 0.7 ** 3) < 2e-3 * vol              # outward normals, the ball's volume
     empty_v, empty_t = ana.mesh.marching_cubes(torch.ones(5, 5, 5, device=dev), 0.0)
     assert empty_v.shape == (0, 3) and empty_t.shape == (0, 3)
+
+
+# ----------------------------------------------------------------------------- configs[4] at its real size
+def _grid_world(dev, smpl_table, mode):
+    """BASELINE configs[4] as bench.py runs it: the seeded animated pose, sigma rescaled about its median, fine network."""
+    from anim_nerf_amd import synthetic as syn
+    m = seeded_model(smpl_table, 0, True, device=dev, mlp_mode=mode)
+    with torch.no_grad():
+        probe = (torch.rand(1, 4096, 3, generator=torch.Generator().manual_seed(5)) * 1.2 - 0.6)
+        for net in (m.nerf, m.nerf_fine):                       # spread sigma about its median (literal init: one sign everywhere)
+            s = orc.mlp_sigma_and_feature(net_params(net), probe)[0]
+            net.sigma.weight.mul_(3000.0)
+            net.sigma.bias.copy_((5.0 - 3000.0 * (s.median() - net.sigma.bias.cpu())).to(dev))
+        pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=100).items()}
+        rays = torch.zeros(1, 1, 8, device=dev)
+        rays[..., 5], rays[..., 7] = -1, 10
+        m.set_body_model(pose, _templ(dev))
+        m.convert_to_body_model_space(rays)
+        m.clac_ober2cano_transform()
+    return m
+
+
+def check_closed_oriented_surface_torch(faces, n_verts):
+    """tests/test_mesh.py::check_closed_oriented_surface for millions of triangles: every directed edge once, and its opposite
+    present (closed, consistently oriented 2-manifold).  Returns the number of undirected edges."""
+    e = faces[:, [0, 1, 1, 2, 2, 0]].reshape(-1, 2)
+    assert (e[:, 0] != e[:, 1]).all(), "degenerate triangle"
+    key = torch.sort(e[:, 0] * n_verts + e[:, 1]).values
+    assert (key[1:] != key[:-1]).all(), "an oriented edge used twice"
+    assert torch.equal(key, torch.sort(e[:, 1] * n_verts + e[:, 0]).values), "an edge without its opposite: a hole or an orientation flip"
+    return key.numel() // 2
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_sigma_grid_at_512_cubed(dev, smpl_table, mode):
+    """extract_mesh.py:27-61,152-165 at BASELINE configs[4]'s real size, in the mode bench.py times (bf16) and in the parity
+    mode: (a) the 2^27-point grid as ONE call (a 2.1 GB point tensor: byte offsets past 2^31) == the same grid in 2^22-point
+    chunks, bit for bit; (b) on three 64^3 sub-blocks straddling the body the fast path (device grid, no search for
+    provably-empty voxels, sigma-only MLP on the valid voxels) == the exact path (explicit points through AnimNeRF.forward,
+    the reference's loop), bit for bit; f32: >= 20,000 sampled voxels against the oracle, voxel by voxel (tests/accounting.py);
+    (c) marching cubes on the 512^3 volume: closed, consistently oriented, exactly one vertex per straddling grid edge."""
+    import anim_nerf_amd as ana
+    from accounting import account_for_points
+    N, rng = 512, (-1.2, 1.2)
+    m = _grid_world(dev, smpl_table, mode)
+    one, first = ana.sigma_grid(m, N, rng, rng, rng, chunk=1 << 27)
+    assert first == 0 and one.shape == (N ** 3,)
+    parts = torch.cat([ana.sigma_grid(m, N, rng, rng, rng, chunk=1 << 22, rank=r, world=4)[0] for r in range(4)])
+    assert torch.equal(one, parts), f"one call != chunked: {(one != parts).sum().item()} voxels differ"
+    del parts
+    occ = one > 0
+    n_occ = int(occ.sum())
+    assert 1e6 < n_occ < 2e7 and (one >= 0).all(), n_occ                  # a body in mostly empty space
+    # (b) sub-blocks: the reference's create_grid (np.meshgrid 'xy': array axis 0 runs over y) + centre, explicit points
+    lin = np.linspace(rng[0], rng[1], N)
+    center = (m.verts.max(dim=1)[0] + m.verts.min(dim=1)[0]) / 2.
+    vol = one.view(N, N, N)
+    idx = torch.nonzero(occ.view(N, N, N))
+    gen = torch.Generator().manual_seed(11)
+    blocks = []
+    for pick in torch.randint(0, idx.shape[0], (3,), generator=gen):
+        a0, b0, c0 = [int(min(max(int(v) - 32, 0), N - 64)) for v in idx[pick]]
+        blocks.append((a0, b0, c0))
+        a, b, c = np.meshgrid(np.arange(a0, a0 + 64), np.arange(b0, b0 + 64), np.arange(c0, c0 + 64), indexing="ij")
+        pts = np.stack([lin[b], lin[a], lin[c]], -1).reshape(-1, 3)                 # grid[a, b, c] = (x[b], y[a], z[c])
+        points = torch.from_numpy(pts).unsqueeze(0).float().to(dev) + center
+        exact = ana.sigma_grid_inference(m, points, chunk=32 * 32 * 64)[0, :, 0]
+        fast = vol[a0:a0 + 64, b0:b0 + 64, c0:c0 + 64].reshape(-1)
+        assert (exact > 0).any(), "the block must straddle the body"
+        assert torch.equal(exact, fast), (blocks[-1], (exact != fast).sum().item(), (exact - fast).abs().max().item())
+    if mode == "f32":
+        # >= 20,000 voxels against the oracle: half of them occupied ones, half anywhere
+        flat_occ = torch.nonzero(occ)[:, 0]
+        sel = torch.cat([flat_occ[torch.randint(0, n_occ, (10240,), generator=gen).to(dev)],
+                         torch.randint(0, N ** 3, (10240,), generator=gen).to(dev)])
+        a, b, c = (sel // (N * N)).cpu().numpy(), ((sel // N) % N).cpu().numpy(), (sel % N).cpu().numpy()
+        points = torch.from_numpy(np.stack([lin[b], lin[a], lin[c]], -1)).unsqueeze(0).float().to(dev) + center
+        st = account_for_points(m, oracle_table(smpl_table), points, one[sel], use_fine=True, relu=True, label="sigma grid 512^3")
+        assert st["valid"] >= 10000
+    # (c) the level set extract_mesh.py takes next (:159-165)
+    field = (5.0 - vol).contiguous()
+    verts, tris = ana.mesh.marching_cubes(field, 0.0)
+    inside = field < 0
+    straddling = sum(int((inside.narrow(ax, 0, N - 1) != inside.narrow(ax, 1, N - 1)).sum()) for ax in range(3))
+    assert verts.shape[0] == straddling, (verts.shape[0], straddling)
+    edges = check_closed_oriented_surface_torch(tris, verts.shape[0])
+    assert tris.shape[0] > 1e6 and 2 * edges == 3 * tris.shape[0]
+    assert (verts >= 0).all() and (verts <= N - 1).all()
+    print(f"\nsigma grid 512^3 [{mode}]: {n_occ} occupied voxels, blocks {blocks}, mesh {verts.shape[0]} vertices / {tris.shape[0]} triangles")

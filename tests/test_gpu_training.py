@@ -227,16 +227,9 @@ def test_training_loss_gradients_match_oracle(dev, smpl_table):
     z_fine = _hip_fine_samples(m, vr, rays, pose, dev)
     out = orc.render_frame(tbl, Pc, Pf, rays.view(2, 64, 8).double(), _fp64(pose), _fp64(templ), n_coarse=16, n_fine=8,
                            use_unpose=True, chunk=40, knn_chunk=512, z_fine=z_fine)
-    F = torch.nn.functional
-    t_rgb, t_a = tgt_rgb.view(2, 64, 3).double(), tgt_a.view(2, 64, 1).double()
-    fg, bg = fg.double(), bg.double()
-    ref = (F.mse_loss(out["rgbs"], t_rgb) + F.mse_loss(out["rgbs_fine"], t_rgb)
-           + 0.1 * (F.l1_loss(out["alphas"], t_a) + F.l1_loss(out["alphas_fine"], t_a)))
-    for P in (Pc, Pf):
-        s_fg = orc.mlp_sigma_and_feature(P, fg)[0]
-        s_bg = orc.mlp_sigma_and_feature(P, bg)[0]
-        ref = ref + 0.01 * torch.mean(torch.exp(-2.0 / 16 * torch.relu(s_fg))) \
-                  + 0.01 * torch.mean(1 - torch.exp(-2.0 / 16 * torch.relu(s_bg)))
+    # the reference's compute_loss as the oracle restates it (pinned to train.py:228-322 by tests/golden/train_loss.npz)
+    ref, _ = orc.training_loss(Pc, Pf, out, tgt_rgb.view(2, 64, 3).double(), tgt_a.view(2, 64, 1).double(), n_samples=16,
+                               fg_points=fg.double(), bg_points=bg.double(), draws=None)
     ref.backward()
     assert out["alphas_fine"].max() > 0.5, "the test scene must not be empty"
     assert abs(loss.item() - ref.item()) <= 2e-4 * abs(ref.item()), (loss.item(), ref.item())
@@ -531,25 +524,133 @@ def test_tangent_mode_kernels_equal_forward_mode_reference(dev, smpl_table, mode
             assert c > 0.97, (k, c.item())
 
 
-def test_normals_regulariser_matches_oracle_autograd(dev, smpl_table):
-    """NeRF.get_normal (models/nerf.py:177-190) and its second-order gradient w.r.t. the weights."""
-    m = seeded_model(smpl_table, 7, True, gain=300.0, shift=(2.0, 2.0), device=dev)
-    gen = torch.Generator().manual_seed(6)
-    xyz = (torch.rand(1, 500, 3, generator=gen) * 1.2 - 0.6)
+def _near_relu_kink(P64, xyz64, tol=2e-6):
+    """[n] bool: some trunk pre-activation of the point lies within `tol` of 0 (fp64 oracle weights): d alpha / d xyz is
+    piecewise constant in the ReLU pattern, so an fp32 evaluation may put that unit on the other side — the ONLY excuse a
+    normal (or its second-order gradient) has for differing from the reference's."""
+    e = orc.fourier_encode(xyz64, 10)
+    h, near = e, torch.zeros(xyz64.shape[:-1], dtype=torch.bool)
+    for i in range(8):
+        if i == 4:
+            h = torch.cat([e, h], -1)
+        pre = torch.nn.functional.linear(h, P64[f"xyz_encoding_{i+1}.0.weight"], P64[f"xyz_encoding_{i+1}.0.bias"])
+        near |= (pre.abs() < tol).any(-1)
+        h = torch.relu(pre)
+    sigma = torch.nn.functional.linear(h, P64["sigma.weight"], P64["sigma.bias"])[..., 0]
+    return near | (sigma.abs() < 100 * tol)            # (alpha's own relu(sigma))
+
+
+def test_normals_regulariser_matches_reference(dev, smpl_table):
+    """NeRF.get_normal (models/nerf.py:177-190) and its second-order gradient w.r.t. the weights, against the REFERENCE's own
+    output (tests/golden/normals.npz) and against fp64 autograd of the pinned oracle: every point within 1e-4 of the reference
+    unless a ReLU pre-activation sits within rounding of 0 (named per point); the WHOLE gradient of sum(normal^2) over the
+    other points within 1e-3 relative L2."""
+    g = golden("normals")
+    m = seeded_model(smpl_table, g["seed"], True, gain=g["gain"], shift=(g["shift"], g["shift"]), device=dev, mlp_mode="f32")
+    xyz = torch.from_numpy(g["xyz"])
+    P64 = {k: v.double().requires_grad_(True) for k, v in net_params(m.nerf).items()}
+    kink = _near_relu_kink({k: v.detach() for k, v in P64.items()}, xyz.double())[0]
+    n_ref = torch.from_numpy(g["normal"])[0]
     n_hip = m.query_canonical_space(xyz.to(dev), use_fine=False, only_normal=True)
-    (n_hip ** 2).sum().backward()
-    P = {k: v.clone().requires_grad_(True) for k, v in net_params(m.nerf).items()}
-    x = xyz.clone().requires_grad_(True)
-    alpha = 1 - torch.exp(-0.02 * torch.relu(orc.mlp_sigma_and_feature(P, x)[0]))
-    n_ref = torch.autograd.grad(alpha, x, torch.ones_like(alpha), create_graph=True)[0]
-    (n_ref ** 2).sum().backward()
-    # d alpha/d xyz is piecewise constant in the ReLU pattern: a pre-activation within rounding of 0 flips a whole
-    # term between GPU and CPU GEMMs, so compare per point and allow a few flipped points
-    bad = ((n_hip.detach().cpu() - n_ref.detach()).abs() > 1e-5 + 2e-3 * n_ref.detach().abs()).any(-1)
-    assert bad.float().mean() < 0.02, bad.float().mean()
-    k = "xyz_encoding_3.0.weight"
-    a, b = dict(m.nerf.named_parameters())[k].grad.cpu(), P[k].grad
-    assert (a - b).norm() / b.norm() < 5e-2
+    err = (n_hip.detach().cpu()[0] - n_ref).abs()
+    bad = (err > 1e-6 + 1e-4 * n_ref.abs().max(-1, keepdim=True).values).any(-1)
+    print(f"\nnormals: {int(bad.sum())} of {bad.numel()} points outside 1e-4 of the reference, {int(kink.sum())} points within "
+          f"rounding of a ReLU kink; max err on the others {err[~kink].max().item():.2e}")
+    assert (bad <= kink).all(), f"{int((bad & ~kink).sum())} normals differ from the reference's away from any ReLU kink"
+    assert kink.float().mean() < 0.1 and (n_ref.abs().sum(-1) > 0).float().mean() > 0.2
+    # second order: d sum(w normal^2) / d weights, points at a kink masked out on both sides
+    w = (~kink).float()[None, :, None]
+    (w.to(dev) * n_hip ** 2).sum().backward()
+    n64 = orc.point_normals(P64, xyz.double(), float(g["delta"]))
+    assert (n64.detach()[0][~kink] - n_ref.double()[~kink]).abs().max() < 1e-5 * n_ref.abs().max()
+    (w.double() * n64 ** 2).sum().backward()
+    num = den = 0.0
+    for k, p in m.nerf.named_parameters():
+        if P64[k].grad is None:
+            assert p.grad is None or p.grad.abs().max() == 0, k
+            continue
+        num += (p.grad.cpu().double() - P64[k].grad).pow(2).sum().item()
+        den += P64[k].grad.pow(2).sum().item()
+    print(f"normals: relative L2 error of the whole second-order weight gradient vs fp64: {(num / den) ** 0.5:.2e}")
+    assert den > 0 and (num / den) ** 0.5 < 1e-3, (num / den) ** 0.5
+
+
+def test_training_step_matches_reference_loss_fixture(dev, smpl_table):
+    """AnimNeRFSystem.forward + compute_loss of the REFERENCE (train.py:189-215, 228-322; tests/golden/train_loss.npz) against
+    system_forward + compute_loss of the HIP path on the same batch, fp32 mode, the normals term's two randn_like draws
+    replayed: the rendered batch ray by ray (tests/accounting.py), each of the ten loss terms, the total, and the gradient of
+    the total w.r.t. every weight of both networks against fp64 autograd of the pinned oracle (the HIP path's importance
+    samples injected: they carry no gradient and are discontinuous)."""
+    import anim_nerf_amd as ana
+    from accounting import account_for_rays, render_stages
+    from anim_nerf_amd import synthetic as syn
+    from helpers import InjectedDraws
+    from test_oracle_golden import loss_fixture_draws, loss_fixture_model
+    g = golden("train_loss")
+    m = loss_fixture_model(smpl_table, g, device=dev, mlp_mode="f32")
+    F_, H, W, Kc, Kf = int(g["frames"]), int(g["H"]), int(g["W"]), int(g["n_samples"]), int(g["n_importance"])
+    hp = ana.TrainHParams(n_samples=Kc, n_importance=Kf, chunk=int(g["chunk"]), **{k: float(g[k]) for k in (
+        "lambda_alphas", "lambda_foreground", "lambda_background", "lambda_normals", "epsilon", "dis_threshold")})
+    vr = ana.VolumeRenderer(n_coarse=Kc, n_fine=Kf)
+    pose = {k: torch.from_numpy(v) for k, v in syn.animated_pose_params(seed=int(g["pose_seed"]), bs=F_).items()}
+    templ = _templ()
+    rays = torch.from_numpy(g["rays"])
+    tgt_rgb, tgt_a = torch.from_numpy(g["target_rgb"]), torch.from_numpy(g["target_alpha"])
+    fg, bg = torch.from_numpy(g["fg_points"]), torch.from_numpy(g["bg_points"])
+    m.eval()                                                    # as the fixture: no sigma noise
+    res = ana.system_forward(vr, m, rays.to(dev), {k: v.to(dev) for k, v in pose.items()}, _templ(dev), perturb=0.0, chunk=hp.chunk)
+    draws = loss_fixture_draws(g, (F_, syn.NUM_VERTS, 3))
+    with InjectedDraws(replay=draws):
+        loss, details = ana.compute_loss(m, hp, tgt_rgb.to(dev), tgt_a.to(dev), res, fg.to(dev), bg.to(dev))
+    loss.backward()
+    # (1) the rendered batch, frame by frame, ray by ray
+    tbl = oracle_table(smpl_table)
+    for b in range(F_):
+        ref_b = {k: g["results/" + k].reshape(F_, H * W, -1)[b:b + 1] for k in ("rgbs", "alphas", "depths", "rgbs_fine", "alphas_fine", "depths_fine")}
+        with torch.no_grad():
+            stages = render_stages(m, vr, rays[b:b + 1].view(1, -1, 8), {k: v[b:b + 1] for k, v in pose.items()}, templ)
+        for k, v in stages["out"].items():
+            # the training forward (kernels that save activations, compacted rows) renders what the inference kernels render;
+            # the accounting below is done on the TRAINING forward's values, with the sampling decisions of the stage-by-stage pass
+            got = res[k][b].detach().reshape(v.shape)
+            assert (v - got).abs().max() <= 2e-6 + 2e-6 * v.abs().max(), (k, b, (v - got).abs().max().item())
+            stages["out"][k] = got
+        account_for_rays(m, vr, tbl, rays[b:b + 1].view(1, -1, 8), {k: v[b:b + 1] for k, v in pose.items()}, templ, ref_b, stages=stages,
+                         label=f"train_loss fixture, frame {b}")
+    # (2) the loss terms against the reference's values
+    assert sorted(details) == sorted(k[5:] for k in g if k.startswith("loss/"))
+    for k, v in details.items():
+        want = float(g["loss/" + k])
+        assert abs(v.item() - want) <= 1e-6 + 2e-4 * abs(want), (k, v.item(), want)
+    assert abs(loss.item() - float(g["total"])) <= 2e-4 * float(g["total"])
+    # (3) every weight gradient against fp64 autograd of the oracle on the same importance samples and draws
+    Pc = {k: v.double().requires_grad_(True) for k, v in net_params(m.nerf).items()}
+    Pf = {k: v.double().requires_grad_(True) for k, v in net_params(m.nerf_fine).items()}
+    z_fine = _hip_fine_samples(m, vr, rays, pose, dev)
+    tbl64 = _fp64(tbl)
+    out = orc.render_frame(tbl64, Pc, Pf, rays.view(F_, H * W, 8).double(), _fp64(pose), _fp64(templ), n_coarse=Kc, n_fine=Kf,
+                           use_unpose=True, chunk=hp.chunk, knn_chunk=512, z_fine=z_fine)
+    st = orc.frame_state(tbl64, _fp64(pose), _fp64(templ))
+    ref, _ = orc.training_loss(Pc, Pf, out, tgt_rgb.view(F_, H * W, 3).double(), tgt_a.view(F_, H * W, 1).double(), n_samples=Kc,
+                               fg_points=fg.double(), bg_points=bg.double(), verts_template=st["verts_template"],
+                               draws=tuple(d.double() for d in draws), lambda_alphas=hp.lambda_alphas,
+                               lambda_foreground=hp.lambda_foreground, lambda_background=hp.lambda_background,
+                               lambda_normals=hp.lambda_normals, epsilon=hp.epsilon, dis_threshold=hp.dis_threshold)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 2e-4 * abs(ref.item()), (loss.item(), ref.item())
+    for tag, net, P in (("coarse", m.nerf, Pc), ("fine", m.nerf_fine, Pf)):
+        num = den = 0.0
+        for k, p in net.named_parameters():
+            num += (p.grad.cpu().double() - P[k].grad).pow(2).sum().item()
+            den += P[k].grad.pow(2).sum().item()
+        print(f"train_loss fixture: relative L2 error of the whole {tag} weight gradient vs fp64: {(num / den) ** 0.5:.2e}")
+        # (the normals term is 1 % of the total by weight but piecewise constant in 13,780 points' ReLU patterns: a handful sit
+        # within fp32 rounding of a kink, test_normals_regulariser_matches_reference names them one by one)
+        assert den > 0 and (num / den) ** 0.5 < 2e-3, (tag, (num / den) ** 0.5)
+        # and against the reference's own fp32 gradient norms
+        for k, want in zip(g[f"grad_keys_{tag}"], g[f"grad_norms_{tag}"]):
+            got = dict(net.named_parameters())[str(k)].grad.double().norm().item()
+            assert abs(got - want) <= 1e-2 * want + 1e-12, (tag, str(k), got, want)
 
 
 def _loss_scene(dev, smpl_table, frames=2):
@@ -1231,6 +1332,20 @@ def test_flat_adam_equals_torch_adam(dev):
     for p, q, r in zip(ours, ref, again):
         torch.testing.assert_close(p, q, rtol=2e-6, atol=1e-7)
         assert torch.equal(p, r)
+    # ... and into torch.optim.Adam itself (the Trainer's CPU / non-contiguous fallback, and what the reference uses,
+    # train.py:216-226): a checkpoint of GPU training resumes there, and the next step is the same step
+    sd = oa.state_dict()
+    assert set(sd["param_groups"][0]) >= set(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))]).defaults)
+    cpu = [p.detach().cpu().clone().requires_grad_(True) for p in ours]
+    od = torch.optim.Adam(groups(cpu), eps=1e-8)
+    od.load_state_dict(sd)
+    for p, r in zip(ours, cpu):
+        g = torch.randn(p.shape, generator=gen)
+        p.grad, r.grad = g.to(dev), g.clone()
+    oa.step()
+    od.step()
+    for p, r in zip(ours, cpu):
+        torch.testing.assert_close(p.detach().cpu(), r.detach(), rtol=2e-6, atol=1e-7)
 
 
 def test_prior_points_ride_with_the_render_pass(dev, smpl_table, monkeypatch):

@@ -323,9 +323,8 @@ def loss_fixture_model(smpl_table, g, device=None, **kw):
 
 
 def loss_fixture_draws(g, shape):
-    torch.manual_seed(int(g["draw_seed"]))
-    draws = (torch.randn(shape), torch.randn(shape))
-    assert sha(*draws) == str(g["draws_checksum"])
+    draws = (torch.from_numpy(g["draw_0"]), torch.from_numpy(g["draw_1"]))
+    assert tuple(draws[0].shape) == tuple(shape)
     return draws
 
 
