@@ -49,7 +49,9 @@ def parse():
                     help="cfg2/cfg3: BASELINE configs[1]/[2] (inference); cfg4: configs[3] training step (64+32, 32x32 rays per frame); "
                          "cfg5: configs[4] 512^3 sigma grid, voxel-sharded")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="cfg2/cfg3 at N > 1: weak = one frame per GPU; strong = one frame's rays sliced over the GPUs")
+                    help="cfg2/cfg3 at N > 1: weak = one frame per GPU; strong = one frame's rays sliced over the GPUs; "
+                         "cfg4: weak = frames-per-gpu frames on every rank; strong = ONE batch of 16 frames split over the ranks "
+                         "(the reference's DataParallel partitioning)")
     ap.add_argument("--frames-per-gpu", type=int, default=16, help="cfg4: frames (of 1024 rays) per step per GPU")
     ap.add_argument("--mode", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--hw", type=int, default=1024)
@@ -450,10 +452,13 @@ def grid_bench(args, ctx, mode, steps, warmup, dense=False):
     }
 
 
-def train_bench(args, ctx, mode, steps, warmup, dense=False):
+def train_bench(args, ctx, mode, steps, warmup, dense=False, scaling="weak", frames=None):
     """BASELINE configs[3] shape: one optimisation step = `frames_per_gpu` frames x 32x32 rays, 64 coarse + 32 fine,
-    perturb = 1, rgb/alpha/foreground/background/normals losses, backward, bucketed gradient all-reduce (RCCL) overlapped
-    with backward, Adam."""
+    perturb = 1, rgb/alpha/foreground/background/normals losses, backward, gradient all-reduce (RCCL), Adam.
+    scaling="strong": the reference's own partitioning (train.py:81-86,451-458, config.py:77 `strategy='dp'`,
+    configs/people_snapshot/male-3-casual.yaml `batch_size: 16`): ONE batch of 16 frames split over the ranks, 16 // world
+    frames each; every rank's loss is the mean over ITS frames and the gradients are averaged over the ranks — DataParallel's
+    mean over replicas of per-replica means.  scaling="weak": `frames_per_gpu` frames on every rank (global batch grows)."""
     import anim_nerf_amd as ana
     from anim_nerf_amd import synthetic as syn
     dev, rank, world = ctx.dev, ctx.rank, ctx.world
@@ -463,7 +468,11 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False):
                          use_fine=True, mlp_mode=mode).to(dev)
     model.skip_invalid_samples = not dense
     hp = ana.TrainHParams(n_samples=64, n_importance=32, chunk=2048)
-    F = args.frames_per_gpu
+    GLOBAL = 16                                                # batch_size of the shipped config
+    strong = scaling == "strong"
+    if strong and GLOBAL % world:
+        raise ValueError(f"cfg4 --scaling strong splits {GLOBAL} frames: the rank count must divide it")
+    F = GLOBAL // world if strong else (frames or args.frames_per_gpu)
     table = ana.BodyModelParams(114).to(dev)                  # 114 training frames (configs/people_snapshot/male-3-casual.yaml)
     seeded = syn.animated_pose_params(seed=200, bs=114)        # the SAME table on every rank: its gradients are all-reduced
     for name in table.param_names:                            # optim_body_params: True
@@ -474,15 +483,20 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False):
     graphed = dev.type == "cuda" and not os.environ.get("ANR_BENCH_NO_GRAPH")
     trainer = ana.Trainer(model, ana.VolumeRenderer(n_coarse=64, n_fine=32), hp, body_model_params=table, graph=graphed)
     trainer.renderer.reuse_coarse_warp = not os.environ.get("ANR_BENCH_NO_WARP_REUSE")     # (A/B switch for the fine pass's copy)
-    frame_idx = (torch.arange(F, device=dev) * (114 // F) + rank) % 114      # a rank's own frames, as a distributed sampler deals them
+    if strong:                                                # this rank's slice of the ONE global batch (DP's scatter on dim 0)
+        frame_idx = (torch.arange(GLOBAL, device=dev) * (114 // GLOBAL))[rank * F:(rank + 1) * F]
+    else:
+        frame_idx = (torch.arange(F, device=dev) * (114 // F) + rank) % 114  # a rank's own frames, as a distributed sampler deals them
     c2w, focal, cen = syn.pinhole_camera(32, 32)
     rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), 32, 32, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(F, 1, 1, 1)
     templ = {k: torch.from_numpy(v).to(dev) for k, v in syn.template_pose_params().items()}
-    g = torch.Generator().manual_seed(rank)
-    rgbs = torch.rand(F, 32, 32, 3, generator=g).to(dev)
-    alphas = (torch.rand(F, 32, 32, 1, generator=g) > 0.5).float().to(dev)
-    fg = (torch.rand(F, 128, 3, generator=g) * 0.4 - 0.2).to(dev)
-    bg = (torch.rand(F, 128, 3, generator=g) * 2 - 1).to(dev)
+    g = torch.Generator().manual_seed(0 if strong else rank)
+    nb = GLOBAL if strong else F                               # strong: targets of the global batch, sliced like the frames
+    cut = slice(rank * F, (rank + 1) * F) if strong else slice(None)
+    rgbs = torch.rand(nb, 32, 32, 3, generator=g)[cut].to(dev)
+    alphas = (torch.rand(nb, 32, 32, 1, generator=g) > 0.5).float()[cut].to(dev)
+    fg = (torch.rand(nb, 128, 3, generator=g) * 0.4 - 0.2)[cut].to(dev)
+    bg = (torch.rand(nb, 128, 3, generator=g) * 2 - 1)[cut].to(dev)
     last = {}
 
     def step():
@@ -509,8 +523,11 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False):
     return {
         "metric": "rays/sec, training step (64+32 samples, 256-wide MLP x2, fwd+bwd+Adam)",
         "value": n_rays * steps * world / elapsed, "unit": "rays/s", "n_gpus": world, "steps": steps,
-        "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "dtype": mode,
-        "config": {"workload": "BASELINE configs[3] shape: train step, %d frames x 32x32 rays per GPU, 64 coarse + 32 fine, "
+        "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "scaling": scaling, "dtype": mode,
+        "config": {"global_batch_frames": F * world, "frames_per_gpu": F,
+                   "partitioning": ("ONE batch of 16 frames split over the ranks (the reference's DP scatter on dim 0), gradients = mean "
+                                    "over ranks of per-rank means" if strong else "frames_per_gpu frames on every rank: the global batch grows with N"),
+                   "workload": "BASELINE configs[3] shape: train step, %d frames x 32x32 rays per GPU, 64 coarse + 32 fine, "
                                "perturb=1, rgb + alpha + fg/bg + normals losses (reference defaults), pose refinement on (optim_body_params), "
                                "%s + Adam" % (F, "gradient all-reduce (2 x 2.4 MB flat buffers, after the replayed backward)" if graphed
                                               else "bucketed gradient all-reduce (2 x 2.4 MB, overlapped with backward)"),
@@ -530,7 +547,7 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False):
     }
 
 
-def train_bench_child(args, ctx, mode, steps, warmup):
+def train_bench_child(args, ctx, mode, steps, warmup, frames=None):
     """cfg4 as an extra of the default run: the graphed training step in a CHILD process (`bench.py --workload cfg4
     --no-extras`), its line merged into this one.  A HIP-graph replay that goes wrong takes its process down with a GPU memory
     fault (tools/soak_train.py found one such sequence: > 50 replays, then a device synchronisation followed by scalar reads,
@@ -538,9 +555,9 @@ def train_bench_child(args, ctx, mode, steps, warmup):
     not deliver, the step is measured eagerly in this process and the entry says so."""
     import subprocess
     if ctx.world != 1 or ctx.dev.type != "cuda" or os.environ.get("ANR_BENCH_NO_GRAPH"):
-        return train_bench(args, ctx, mode, steps, warmup)
+        return train_bench(args, ctx, mode, steps, warmup, frames=frames)
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "cfg4", "--no-extras", "--steps", str(steps), "--warmup", str(warmup),
-           "--mode", mode, "--frames-per-gpu", str(args.frames_per_gpu)]
+           "--mode", mode, "--frames-per-gpu", str(frames or args.frames_per_gpu)]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     note = None
     try:
@@ -555,7 +572,7 @@ def train_bench_child(args, ctx, mode, steps, warmup):
         note = f"graphed child failed: {type(exc).__name__}: {exc}"[:300]
     os.environ["ANR_BENCH_NO_GRAPH"] = "1"
     try:
-        got = train_bench(args, ctx, mode, steps, warmup)
+        got = train_bench(args, ctx, mode, steps, warmup, frames=frames)
     finally:
         os.environ.pop("ANR_BENCH_NO_GRAPH", None)
     got["config"]["process"] = "eager step in the parent: " + note
@@ -619,7 +636,7 @@ def main():
     rank, world = ctx.rank, ctx.world
 
     if args.workload == "cfg4":
-        result = train_bench(args, ctx, args.mode, args.steps, args.warmup, args.dense)
+        result = train_bench(args, ctx, args.mode, args.steps, args.warmup, args.dense, scaling=args.scaling)
     elif args.workload == "cfg5":
         result = grid_bench(args, ctx, args.mode, args.steps, args.warmup, args.dense)
     else:
@@ -677,6 +694,8 @@ def main():
                               keep=("roofline_hbm_kernels", "kernel_time_share", "oracle_check", "cpu_baseline"))
             w["cfg3_dense"] = extra(render_bench, args, ctx, True, args.mode, 2, 1, dense=True)
             w["cfg4"] = extra(train_bench_child, args, ctx, args.mode, 8, 4, keep=("kernel_time_share", "final_loss"))
+            # the per-rank step of configs[3] on 8 GPUs: 2 of the batch's 16 frames (strong scaling's unit of work, on one GPU)
+            w["cfg4_f2"] = extra(train_bench_child, args, ctx, args.mode, 16, 4, frames=2, keep=("kernel_time_share", "final_loss"))
             w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 2, keep=("oracle_check",))
         else:
             # N > 1: the strong-scaling counterpart of the headline (one frame's rays sliced over the ranks), the warp
@@ -685,6 +704,8 @@ def main():
             w["cfg3"] = extra(render_bench, args, ctx, True, args.mode, 3, 1)
             w["cfg3_strong"] = extra(render_bench, args, ctx, True, args.mode, 3, 1, scaling="strong")
             w["cfg4"] = extra(train_bench, args, ctx, args.mode, 8, 4, keep=("final_loss",))
+            if 16 % world == 0:                             # configs[3] as the reference shards it: 16 frames / N per rank
+                w["cfg4_strong"] = extra(train_bench, args, ctx, args.mode, 16, 4, scaling="strong", keep=("final_loss",))
             w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 2)
         result["workloads"] = w
         failed = [k for k, v in {**w, **result.get("modes", {})}.items() if isinstance(v, dict) and "error" in v]

@@ -599,7 +599,7 @@ def test_training_step_matches_reference_loss_fixture(dev, smpl_table):
     fg, bg = torch.from_numpy(g["fg_points"]), torch.from_numpy(g["bg_points"])
     m.eval()                                                    # as the fixture: no sigma noise
     res = ana.system_forward(vr, m, rays.to(dev), {k: v.to(dev) for k, v in pose.items()}, _templ(dev), perturb=0.0, chunk=hp.chunk)
-    draws = loss_fixture_draws(g, (F_, syn.NUM_VERTS, 3))
+    draws = loss_fixture_draws(g, (1, syn.NUM_VERTS, 3))        # (the template body is one frame: verts_template[1,V,3])
     with InjectedDraws(replay=draws):
         loss, details = ana.compute_loss(m, hp, tgt_rgb.to(dev), tgt_a.to(dev), res, fg.to(dev), bg.to(dev))
     loss.backward()
@@ -1334,7 +1334,11 @@ def test_flat_adam_equals_torch_adam(dev):
         assert torch.equal(p, r)
     # ... and into torch.optim.Adam itself (the Trainer's CPU / non-contiguous fallback, and what the reference uses,
     # train.py:216-226): a checkpoint of GPU training resumes there, and the next step is the same step
-    sd = oa.state_dict()
+    import io
+    buf = io.BytesIO()
+    torch.save(oa.state_dict(), buf)                            # through a checkpoint file, as a resumed run would (and so that
+    buf.seek(0)                                                 # nothing of the loaded state aliases the live optimiser's)
+    sd = torch.load(buf, map_location="cpu")
     assert set(sd["param_groups"][0]) >= set(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))]).defaults)
     cpu = [p.detach().cpu().clone().requires_grad_(True) for p in ours]
     od = torch.optim.Adam(groups(cpu), eps=1e-8)

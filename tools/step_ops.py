@@ -9,7 +9,6 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from torch.profiler import ProfilerActivity, profile
 
 import anim_nerf_amd as ana
 from anim_nerf_amd import synthetic as syn
@@ -38,41 +37,53 @@ step = lambda: trainer.step(rays, rgbs, alphas, None, templ, fg, bg, perturb=1.0
 for _ in range(4):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
+# A dispatch mode sees every aten op with the Python stack that issued it; autograd's device threads are switched off so that
+# the backward pass (custom Function.backward bodies and autograd's own accumulations) runs under the mode too.
+import traceback
+from torch.utils._python_dispatch import TorchDispatchMode
+
+PKG = os.sep + "anim-nerf_amd" + os.sep
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.sep
+NO_LAUNCH = {"aten.empty.memory_format", "aten.empty_strided.default", "aten.view.default", "aten._unsafe_view.default", "aten.as_strided.default",
+             "aten.detach.default", "aten.alias.default", "aten.slice.Tensor", "aten.select.int", "aten.expand.default", "aten.t.default",
+             "aten.transpose.int", "aten.permute.default", "aten.unsqueeze.default", "aten.squeeze.dim", "aten.reshape.default",
+             "aten.empty_like.default", "aten.new_empty.default", "aten.lift_fresh.default", "aten.unbind.int", "aten.split.Tensor",
+             "aten._local_scalar_dense.default", "aten.view_as.default", "aten.unflatten.int", "aten.flatten.using_ints",
+             "aten.squeeze.default", "aten.narrow.default", "aten.is_same_size.default", "aten.split_with_sizes.default",
+             "aten.new_empty_strided.default", "aten.resize_.default", "aten.set_.source_Storage_storage_offset", "aten.unsafe_split.Tensor",
+             "aten._reshape_alias.default", "aten.movedim.int", "aten.chunk.default", "aten.result_type.Tensor", "aten.sym_size.int",
+             "aten.record_stream.default", "aten.is_pinned.default", "aten.unfold.default", "aten.diagonal.default", "aten.real.default"}
+
+
+class Log(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.rows = collections.Counter()
+        self.shape = {}
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        out = func(*args, **(kwargs or {}))
+        if name in NO_LAUNCH:
+            return out
+        t = next((a for a in args if torch.is_tensor(a)), None)
+        if t is not None and not t.is_cuda and not (torch.is_tensor(out) and out.is_cuda):
+            return out                                              # host-side arithmetic
+        frames = [f for f in traceback.extract_stack() if PKG in f.filename]
+        where = f"{frames[-1].filename.replace(ROOT, '')}:{frames[-1].lineno} {frames[-1].name}" if frames else "(autograd engine / torch internals)"
+        outer = f" <- {frames[-2].filename.replace(ROOT, '').split(os.sep)[-1]}:{frames[-2].lineno}" if len(frames) > 1 else ""
+        key = (where + outer, name)
+        self.rows[key] += 1
+        self.shape.setdefault(key, tuple(t.shape) if t is not None else ())
+        return out
+
+
+torch.autograd.set_multithreading_enabled(False)
+log = Log()
+with log:
     step()
 torch.cuda.synchronize()
-
-# leaf aten ops only (an aten::zeros contains aten::empty + aten::zero_ + aten::fill_: count the one that launches)
-LAUNCHING = {"aten::fill_", "aten::copy_", "aten::add", "aten::add_", "aten::mul", "aten::mul_", "aten::sub", "aten::div", "aten::div_",
-             "aten::cat", "aten::index_select", "aten::embedding", "aten::index", "aten::index_put_", "aten::sum", "aten::mean",
-             "aten::exp", "aten::log10", "aten::where", "aten::gt", "aten::lt", "aten::neg", "aten::mse_loss", "aten::normal_",
-             "aten::uniform_", "aten::_to_copy", "aten::clone", "aten::zero_", "aten::embedding_dense_backward", "aten::sqrt",
-             "aten::pow", "aten::rsub", "aten::relu", "aten::threshold_backward", "aten::mm", "aten::bmm", "aten::addmm",
-             "aten::_foreach_add_", "aten::select_backward", "aten::slice_backward", "aten::index_add_", "aten::scatter_add_",
-             "aten::randn_like", "aten::rand", "aten::randn", "aten::max", "aten::min", "aten::arange", "aten::linspace", "aten::sort",
-             "aten::cumsum", "aten::norm", "aten::linalg_vector_norm", "aten::eq", "aten::ne", "aten::bitwise_and", "aten::any"}
-PKG = os.sep + "anim-nerf_amd" + os.sep
-rows = collections.Counter()
-shapes = {}
-for ev in prof.events():
-    if not ev.name.startswith("aten::") or ev.name not in LAUNCHING:
-        continue
-    # skip ops nested inside another launching op (copy_ inside _to_copy / clone, fill_ inside zero_ ...)
-    parent, nested = ev.cpu_parent, False
-    while parent is not None:
-        if parent.name in LAUNCHING:
-            nested = True
-            break
-        parent = parent.cpu_parent
-    if nested:
-        continue
-    where = next((f for f in (ev.stack or []) if PKG in f), None)
-    if where is None:
-        where = next((f for f in (ev.stack or []) if "tools" in f or "torch/autograd" in f or "optim" in f), "(no package frame: autograd engine / optimiser)")
-    where = where.replace(os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.sep, "")
-    rows[(where, ev.name)] += 1
-    shapes.setdefault((where, ev.name), str(ev.input_shapes)[:70])
-total = sum(rows.values())
-print(f"cfg4 eager step, {F} frames: {total} launching framework ops")
-for (where, name), n in sorted(rows.items(), key=lambda kv: (kv[0][0], kv[0][1])):
-    print(f"{n:4d}  {name:28s} {where}   {shapes[(where, name)]}")
+total = sum(log.rows.values())
+print(f"cfg4 eager step, {F} frames: {total} framework ops that launch (or copy), by call site")
+for (where, name), n in sorted(log.rows.items(), key=lambda kv: kv[0]):
+    print(f"{n:4d}  {name:38s} {str(log.shape[(where, name)]):22s} {where}")
