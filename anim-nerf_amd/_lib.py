@@ -50,7 +50,14 @@ class AnrLossArgs(C.Structure):
                                    "quads_fine")]
                 + [(k, _L) for k in ("R", "prior_rows", "nv", "normal_sets", "quad_rows")]
                 + [("n_fg", C.c_int32), ("n_bg", C.c_int32)]
-                + [(k, _F) for k in ("k", "delta", "lambda_alphas", "lambda_foreground", "lambda_background", "lambda_normals")])
+                + [(k, _F) for k in ("k", "delta", "lambda_alphas", "lambda_foreground", "lambda_background", "lambda_normals")]
+                + [("s_stride", C.c_int32)])
+
+
+class AnrDrawPlan(C.Structure):
+    _fields_ = ([(k, _P) for k in ("t_rand", "noise_c", "u_fine", "noise_f")] + [(k, _L) for k in ("n_t", "n_nc", "n_u", "n_nf")]
+                + [("t_scale", _F), ("noise_scale", _F), ("verts_template", _P), ("n_v3", _L), ("point_scale", _F), ("neighbour_scale", _F)]
+                + [(k, _P) for k in ("n0", "n1", "pair")])
 
 
 class AnrLossGrads(C.Structure):
@@ -131,6 +138,15 @@ SIGNATURES = {
     "anr_adam_chunk_floats": (_I, []),
     "anr_adam_chunk_bytes": (_I, []),
     "anr_adam_step": (_I, [_P, _I, _P, C.POINTER(_F), _I, C.c_double, C.c_double, C.c_double, _P]),
+    "anr_compact_ordered_riders": (_I, [_P, _L, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "anr_train_draws": (_I, [_P, _P, _P]),
+    "anr_gather_frame_params": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "anr_scatter_frame_param_grads": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "anr_merge_backward2": (_I, [_P, _P, _P, _L, _I, _I, _P, _P]),
+    "anr_sample_coarse_backward_acc": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "anr_to_root_frame_strided": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "anr_zero_fill": (_I, [_P, _L, _P]),
+    "anr_adam_step_counting": (_I, [_P, _I, _P, _P, _I, _P, C.POINTER(_F), _I, C.c_double, C.c_double, C.c_double, _P]),
     "anr_train_loss_backward": (_I, [C.POINTER(AnrLossArgs), _P, C.POINTER(AnrLossGrads), _P]),
     "anr_composite_sample": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
 }

@@ -142,13 +142,16 @@ class AnimNeRF(nn.Module):
         self._knn_index = None
         self._o2c_attached = None
         if body_model_params_template is not None and not self._same_template(body_model_params_template):
-            t = self.body_model(**body_model_params_template, return_verts=True)
-            self.verts_template = t["vertices"]
-            self.joints_template = t["joints"][:, :self.lbs_dim]
-            self.verts_transform_template = t["vertices_transform"]
-            self.joints_transform_template = t["joints_transform"]
-            self.shape_offsets_template = t["shape_offsets"]
-            self.pose_offsets_template = t["pose_offsets"]
+            self._set_template(body_model_params_template)
+
+    def _set_template(self, body_model_params_template):
+        t = self.body_model(**body_model_params_template, return_verts=True)
+        self.verts_template = t["vertices"]
+        self.joints_template = t["joints"][:, :self.lbs_dim]
+        self.verts_transform_template = t["vertices_transform"]
+        self.joints_transform_template = t["joints_transform"]
+        self.shape_offsets_template = t["shape_offsets"]
+        self.pose_offsets_template = t["pose_offsets"]
 
     def _same_template(self, template):
         """The template pose is one dict for a whole run (datasets/anim_nerf_dataset.py hands the same tensors to every

@@ -87,13 +87,13 @@ __device__ __forceinline__ void affine_inverse12(const float* __restrict__ G, fl
     for (int k = 0; k < 3; ++k) I[k * 4 + 3] = -(I[k * 4 + 0] * G[3] + I[k * 4 + 1] * G[7] + I[k * 4 + 2] * G[11]);
 }
 
-__global__ void to_root_frame_kernel(const float* __restrict__ G, const float* __restrict__ verts,
+__global__ void to_root_frame_kernel(const float* __restrict__ G, int64_t g_stride, const float* __restrict__ verts,
                                      const float* __restrict__ joints, const float* __restrict__ T, int V, int J,
                                      float* __restrict__ ginv_out, float* __restrict__ g_root_out,
                                      float* __restrict__ verts_out, float* __restrict__ joints_out, float* __restrict__ T_out) {
     const int b = blockIdx.y;
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    const float* Gb = G + b * 16;
+    const float* Gb = G + b * g_stride;
     float I[12];
     affine_inverse12(Gb, I);
     if (v == 0) {
@@ -284,11 +284,19 @@ extern "C" int anr_rays_to_body(const float* g_inv, const float* rays_in, float*
 extern "C" int anr_to_root_frame(const float* global_transform, const float* verts, const float* joints, const float* T, int bs,
                                  int V, int J, float* g_inv_out, float* g_root_out, float* verts_out, float* joints_out,
                                  float* T_out, void* stream) {
+    return anr_to_root_frame_strided(global_transform, 16, verts, joints, T, bs, V, J, g_inv_out, g_root_out, verts_out, joints_out,
+                                     T_out, stream);
+}
+
+extern "C" int anr_to_root_frame_strided(const float* global_transform, int64_t g_stride, const float* verts, const float* joints,
+                                         const float* T, int bs, int V, int J, float* g_inv_out, float* g_root_out, float* verts_out,
+                                         float* joints_out, float* T_out, void* stream) {
     ANR_REQUIRE(global_transform && verts && joints && T && g_inv_out && g_root_out && verts_out && joints_out && T_out,
                 ANR_E_BADARG, "anr_to_root_frame: null pointer");
-    ANR_REQUIRE(bs > 0 && V > 0 && J > 0 && J <= V, ANR_E_BADARG, "anr_to_root_frame: bs=%d V=%d J=%d", bs, V, J);
+    ANR_REQUIRE(bs > 0 && V > 0 && J > 0 && J <= V && g_stride >= 16, ANR_E_BADARG, "anr_to_root_frame: bs=%d V=%d J=%d stride=%lld", bs, V, J,
+                (long long)g_stride);
     ANR_REQUIRE((((uintptr_t)T | (uintptr_t)T_out) & 15) == 0, ANR_E_ALIGN, "anr_to_root_frame: T must be 16-B aligned");
-    hipLaunchKernelGGL(to_root_frame_kernel, dim3((V + 127) / 128, bs), dim3(128), 0, (hipStream_t)stream, global_transform, verts,
+    hipLaunchKernelGGL(to_root_frame_kernel, dim3((V + 127) / 128, bs), dim3(128), 0, (hipStream_t)stream, global_transform, g_stride, verts,
                        joints, T, V, J, g_inv_out, g_root_out, verts_out, joints_out, T_out);
     return check_launch("anr_to_root_frame");
 }

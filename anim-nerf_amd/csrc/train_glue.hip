@@ -20,10 +20,25 @@ namespace anr {
 
 constexpr int CB = 1024;   // samples per compaction block
 
-__global__ __launch_bounds__(CB) void compact_count_kernel(const float4* __restrict__ pts, int64_t n, int32_t* __restrict__ block_cnt) {
+// riders: n_r = rows (n_fg + n_bg) extra points that count as samples n .. n + n_r - 1 with valid = 1 (the prior points of
+// train.py:262-286 evaluated with the step's ray samples) — listed behind the samples, never dropped.  Rider j is point
+// j % (n_fg + n_bg) of frame j / (n_fg + n_bg): the frame's foreground points fg[rows][n_fg][3], then its background points
+// bg[rows][n_bg][3] (either may be absent) — the order anr_train_loss reads their sigmas in, without a concatenated copy.
+struct Riders {
+    const float *fg, *bg;
+    int n_fg, n_bg, rows;
+    __host__ __device__ int64_t count() const { return (int64_t)rows * (n_fg + n_bg); }
+    __device__ float4 point(int64_t j) const {
+        const int per = n_fg + n_bg, b = (int)(j / per), w = (int)(j % per);
+        const float* p = w < n_fg ? fg + ((int64_t)b * n_fg + w) * 3 : bg + ((int64_t)b * n_bg + (w - n_fg)) * 3;
+        return make_float4(p[0], p[1], p[2], 1.0f);
+    }
+};
+__global__ __launch_bounds__(CB) void compact_count_kernel(const float4* __restrict__ pts, int64_t n, int64_t n_r,
+                                                           int32_t* __restrict__ block_cnt) {
     __shared__ int wave_cnt[CB / WAVE];
     const int64_t i = (int64_t)blockIdx.x * CB + threadIdx.x;
-    const bool keep = i < n && !(pts[i].w < 1.0f);
+    const bool keep = (i < n && !(pts[i].w < 1.0f)) || (i >= n && i < n + n_r);
     const unsigned long long m = __ballot(keep);
     if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(m);
     __syncthreads();
@@ -63,7 +78,8 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(int32_t* __restrict_
     }
 }
 
-__global__ __launch_bounds__(CB) void compact_gather_kernel(const float4* __restrict__ pts, int64_t n, const int32_t* __restrict__ block_base,
+__global__ __launch_bounds__(CB) void compact_gather_kernel(const float4* __restrict__ pts, int64_t n, Riders riders,
+                                                            int64_t n_r, const int32_t* __restrict__ block_base,
                                                             const int32_t* __restrict__ count, int32_t* __restrict__ index,
                                                             int32_t* __restrict__ pos, float4* __restrict__ pts_out) {
     __shared__ int wave_cnt[CB / WAVE];
@@ -71,7 +87,8 @@ __global__ __launch_bounds__(CB) void compact_gather_kernel(const float4* __rest
     const int64_t i = (int64_t)blockIdx.x * CB + threadIdx.x;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) p = pts[i];
-    const bool keep = i < n && !(p.w < 1.0f);
+    else if (i < n + n_r) p = riders.point(i - n);
+    const bool keep = (i < n && !(p.w < 1.0f)) || (i >= n && i < n + n_r);
     const unsigned long long m = __ballot(keep);
     if (lane == 0) wave_cnt[wave] = __popcll(m);
     __syncthreads();
@@ -79,7 +96,7 @@ __global__ __launch_bounds__(CB) void compact_gather_kernel(const float4* __rest
     for (int w = 0; w < wave; ++w) off += wave_cnt[w];
     const int r = off + __popcll(m & ((1ull << lane) - 1ull));
     if (keep) { index[r] = (int32_t)i; pts_out[r] = p; }
-    if (i < n) pos[i] = keep ? r : -1;
+    if (i < n + n_r) pos[i] = keep ? r : -1;
     if (blockIdx.x == 0 && threadIdx.x < 64) {               // padding rows up to the next multiple of 64: valid = 0
         const int c = *count, pad = (c + 63) / 64 * 64;
         if (c + (int)threadIdx.x < (pad > 0 ? pad : 64)) pts_out[c + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -206,8 +223,9 @@ __global__ __launch_bounds__(256) void train_loss_kernel(anr_loss_args a, float*
             for (int64_t i = tid; i < a.R; i += nth) s_al += fabsf(al[i] - a.target_alpha[i]);
         if (s) {
             const int per = a.n_fg + a.n_bg;
+            const int ss = a.s_stride > 0 ? a.s_stride : 1;
             for (int64_t i = tid; i < a.prior_rows * per; i += nth) {
-                const float e = expf(a.k * fmaxf(s[i], 0.0f));
+                const float e = expf(a.k * fmaxf(s[i * ss], 0.0f));
                 if ((int)(i % per) < a.n_fg) s_fg += e; else s_bg += 1.0f - e;
             }
         }
@@ -248,6 +266,8 @@ __global__ __launch_bounds__(256) void train_loss_kernel(anr_loss_args a, float*
         float tot = 0.0f;
         for (int t = 0; t < LOSS_TERMS; ++t) tot += w[t] * vals[t];
         vals[LOSS_TERMS] = tot;
+        // train.py:339-344: PSNR of the rendered batch (fine pass if there is one), data range 1 (models/evaluator.py:18)
+        vals[LOSS_TERMS + 1] = -10.0f * log10f(a.rgb_fine ? vals[1] : vals[0]);
         *ticket = 0u;
     }
 }
@@ -279,9 +299,13 @@ __global__ __launch_bounds__(256) void train_loss_backward_kernel(anr_loss_args 
             const int per = a.n_fg + a.n_bg;
             const float cf = a.n_fg ? g * a.lambda_foreground * a.k / (float)(a.prior_rows * a.n_fg) : 0.0f;
             const float cb = a.n_bg ? -g * a.lambda_background * a.k / (float)(a.prior_rows * a.n_bg) : 0.0f;
+            const int ss = a.s_stride > 0 ? a.s_stride : 1;
             for (int64_t i = tid; i < a.prior_rows * per; i += nth) {
-                const float v = s[i];
-                d_s[i] = v > 0.0f ? ((int)(i % per) < a.n_fg ? cf : cb) * expf(a.k * v) : 0.0f;
+                const float v = s[i * ss];
+                const float dv = v > 0.0f ? ((int)(i % per) < a.n_fg ? cf : cb) * expf(a.k * v) : 0.0f;
+                // s_stride 4: the sigmas are column 3 of (r, g, b, sigma) rows and so are their gradients (d_s points at row 0's r)
+                if (ss == 4) reinterpret_cast<float4*>(d_s)[i] = make_float4(0.f, 0.f, 0.f, dv);
+                else d_s[i * ss] = dv;
             }
         }
         if (q && d_q) {
@@ -315,18 +339,28 @@ using namespace anr;
 
 extern "C" int64_t anr_compact_ws_ints(int64_t n) { return (n + CB - 1) / CB; }
 
+extern "C" int anr_compact_ordered_riders(const float* pts, int64_t n, const float* fg, int n_fg, const float* bg, int n_bg, int rows,
+                                          int32_t* index_out, int32_t* pos_out, float* pts_out, int32_t* count_out, int32_t* workspace,
+                                          void* stream) {
+    ANR_REQUIRE(pts && index_out && pos_out && pts_out && count_out && workspace, ANR_E_BADARG, "anr_compact_ordered: null pointer");
+    ANR_REQUIRE(n_fg >= 0 && n_bg >= 0 && rows >= 0 && (n_fg == 0 || fg) && (n_bg == 0 || bg), ANR_E_BADARG,
+                "anr_compact_ordered: rider points without their array");
+    const Riders riders{fg, bg, n_fg, n_bg, rows};
+    const int64_t n_r = riders.count();
+    ANR_REQUIRE(n > 0 && n + n_r < (int64_t)1 << 31, ANR_E_BADARG, "anr_compact_ordered: n=%lld riders=%lld", (long long)n, (long long)n_r);
+    ANR_REQUIRE((((uintptr_t)pts | (uintptr_t)pts_out) & 15) == 0, ANR_E_ALIGN, "anr_compact_ordered: pts / pts_out must be 16-B aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (int)((n + n_r + CB - 1) / CB);
+    hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(CB), 0, st, reinterpret_cast<const float4*>(pts), n, n_r, workspace);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, workspace, nb, count_out);
+    hipLaunchKernelGGL(compact_gather_kernel, dim3(nb), dim3(CB), 0, st, reinterpret_cast<const float4*>(pts), n, riders, n_r, workspace,
+                       count_out, index_out, pos_out, reinterpret_cast<float4*>(pts_out));
+    return check_launch("anr_compact_ordered");
+}
+
 extern "C" int anr_compact_ordered(const float* pts, int64_t n, int32_t* index_out, int32_t* pos_out, float* pts_out,
                                    int32_t* count_out, int32_t* workspace, void* stream) {
-    ANR_REQUIRE(pts && index_out && pos_out && pts_out && count_out && workspace, ANR_E_BADARG, "anr_compact_ordered: null pointer");
-    ANR_REQUIRE(n > 0 && n < (int64_t)1 << 31, ANR_E_BADARG, "anr_compact_ordered: n=%lld", (long long)n);
-    ANR_REQUIRE((((uintptr_t)pts | (uintptr_t)pts_out) & 15) == 0, ANR_E_ALIGN, "anr_compact_ordered: pts/pts_out must be 16-B aligned");
-    hipStream_t st = (hipStream_t)stream;
-    const int nb = (int)((n + CB - 1) / CB);
-    hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(CB), 0, st, reinterpret_cast<const float4*>(pts), n, workspace);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, workspace, nb, count_out);
-    hipLaunchKernelGGL(compact_gather_kernel, dim3(nb), dim3(CB), 0, st, reinterpret_cast<const float4*>(pts), n, workspace, count_out,
-                       index_out, pos_out, reinterpret_cast<float4*>(pts_out));
-    return check_launch("anr_compact_ordered");
+    return anr_compact_ordered_riders(pts, n, nullptr, 0, nullptr, 0, 0, index_out, pos_out, pts_out, count_out, workspace, stream);
 }
 
 extern "C" int anr_expand_rows(const float* src, const int32_t* pos, int64_t n, int cols, float fill, float* out, void* stream) {
@@ -430,9 +464,13 @@ constexpr int ADAM_CHUNK = 4096;
 struct AdamChunk { float* p; const float* g; float* m; float* v; int32_t count; int32_t group; };
 struct AdamHyper { float lr[4]; double beta1, beta2; float eps; };
 
-__global__ __launch_bounds__(256) void adam_kernel(const AdamChunk* __restrict__ chunks, const float* __restrict__ step, AdamHyper h) {
+// active / ticket (anr_adam_step_counting): `step` holds the counts BEFORE this update — the kernel works with step + 1 and the
+// last workgroup to finish adds active[i] to every counter (every workgroup has read its counter by then), so the step needs
+// no separate increment launch
+__global__ __launch_bounds__(256) void adam_kernel(const AdamChunk* __restrict__ chunks, float* __restrict__ step, AdamHyper h,
+                                                   const float* __restrict__ active, int n_tensors, unsigned* __restrict__ ticket) {
     const AdamChunk c = chunks[blockIdx.x];
-    const float t = step[c.group >> 8];
+    const float t = step[c.group >> 8] + (active ? 1.0f : 0.0f);
     // (1 - beta and the bias corrections in double, as the host-side arithmetic of torch.optim.Adam: 1 - 0.999f is off by 1e-5)
     const float omb1 = (float)(1.0 - h.beta1), omb2 = (float)(1.0 - h.beta2), b2 = (float)h.beta2;
     const float bc1 = (float)(1.0 - pow(h.beta1, (double)t)), bc2_sqrt = (float)sqrt(1.0 - pow(h.beta2, (double)t));
@@ -462,6 +500,17 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamChunk* __restrict__
             }
         }
     }
+    if (active == nullptr) return;
+    __shared__ bool last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    for (int i = threadIdx.x; i < n_tensors; i += 256) step[i] += active[i];
+    if (threadIdx.x == 0) *ticket = 0u;
 }
 }  // namespace anr
 
@@ -478,6 +527,21 @@ extern "C" int anr_adam_step(const void* chunks, int n_chunks, const float* step
     for (int g = 0; g < 4; ++g) h.lr[g] = g < n_groups ? lr[g] : 0.f;
     h.beta1 = beta1; h.beta2 = beta2; h.eps = (float)eps;
     hipLaunchKernelGGL(anr::adam_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const anr::AdamChunk*>(chunks), step, h);
+                       reinterpret_cast<const anr::AdamChunk*>(chunks), const_cast<float*>(step), h, (const float*)nullptr, 0, (unsigned*)nullptr);
     return anr::check_launch("anr_adam_step");
+}
+
+extern "C" int anr_adam_step_counting(const void* chunks, int n_chunks, float* step, const float* active, int n_tensors, int32_t* ticket,
+                                      const float* lr, int n_groups, double beta1, double beta2, double eps, void* stream) {
+    ANR_REQUIRE(chunks && step && lr && active && ticket, ANR_E_BADARG, "anr_adam_step_counting: null pointer");
+    ANR_REQUIRE(n_chunks > 0 && n_tensors > 0 && n_groups >= 1 && n_groups <= 4, ANR_E_BADARG, "anr_adam_step_counting: n_chunks=%d n_groups=%d (1..4)",
+                n_chunks, n_groups);
+    ANR_REQUIRE(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, ANR_E_BADARG, "anr_adam_step_counting: betas=(%g, %g) eps=%g",
+                beta1, beta2, eps);
+    anr::AdamHyper h;
+    for (int g = 0; g < 4; ++g) h.lr[g] = g < n_groups ? lr[g] : 0.f;
+    h.beta1 = beta1; h.beta2 = beta2; h.eps = (float)eps;
+    hipLaunchKernelGGL(anr::adam_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const anr::AdamChunk*>(chunks), step, h, active, n_tensors, reinterpret_cast<unsigned*>(ticket));
+    return anr::check_launch("anr_adam_step_counting");
 }

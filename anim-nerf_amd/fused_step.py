@@ -1,0 +1,298 @@
+"""The training step of train.py:324-348 as a FIXED SEQUENCE of this library's launches: forward, losses and the whole
+backward pass written out by hand, no autograd graph.
+
+Why: the step's dataflow is static (frame state -> warp -> MLP -> compositor, coarse then fine, priors, normals, losses and the
+same way back), every backward piece is already a hand-written kernel (`autograd.*Function.backward`), and what torch autograd
+adds on top is ~85 framework launches per step — the sums of gradients that reach a tensor twice (`aten::add`), zero-filled
+gradient buffers, slices, clones, embedding look-ups, four random-number kernels — plus the host time to walk the graph.  In a
+HIP-graph replay each of those is a node; at the per-rank batch of the reference's 8-GPU run (2 frames) the ~210 nodes were
+most of the step.  Here the step is ~90 launches, all of this library:
+
+    draws | gather frame params | SMPL (3) | root frame | rays | ober2cano | KNN index | coarse depths |
+    warp (3) | compact (3) | MLP | expand | composite          (coarse; the prior points ride along as extra rows)
+    sample + merge | warp with reuse (3) | compact (3) | MLP | expand | composite          (fine)
+    tangent quads | MLP (tangent) x 2 | losses | losses' backward |
+    per network: head grad | activation grads | encode | weight grads (2)          (normals)
+    per pass: composite backward | head grad | activation grads | encode | weight grads (2) | d-encoding | encode backward |
+              expand | warp backward          (fine, then the merge's backward, then coarse)
+    coarse depths' backward | frame chain backward (4) | scatter table grads | [all-reduce] | Adam
+
+Gradients that autograd would sum are accumulated where they are produced: both warp backward passes add into one
+dL/d ober2cano and one dL/d rays buffer, the merge's and the coarse depths' backward kernels take their two / three upstream
+gradients as separate operands, the weight gradients of every pass add into the network's flat buffer (`GradSink`).
+
+Equality with the autograd step — same loss, same gradients on the same random numbers — is what
+tests/test_gpu_training.py::test_explicit_step_equals_the_autograd_step holds it to; the autograd step itself is held to the
+oracle's autograd (fp32 and fp64) and to the reference's own compute_loss by the other tests of that file.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib, ops
+from .autograd import PARAM_KEYS, _cached_pack, weights_generation
+
+
+class ExplicitTrainStep:
+    """Bound to a Trainer; `supported(...)` says whether a call can take this path (otherwise the autograd step runs)."""
+
+    def __init__(self, trainer):
+        self.tr = trainer
+        p0 = trainer.params[0]
+        self.dev = p0.device
+        # (seed, step counter, ticket): the random numbers of step k are a pure function of (seed, k) — torch.manual_seed
+        # before the Trainer is built fixes the run
+        self.draw_state = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64, device=self.dev)
+        self.last_draws = None         # the random tensors of the last step (t_rand, noise_c, u_fine, noise_f, n0, n1): for tests
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def supported(self, rays, body_model_params, frame_idx, fg_points, bg_points) -> bool:
+        tr, m, vr, hp = self.tr, self.tr.model, self.tr.renderer, self.tr.hp
+        if not (rays.is_cuda and torch.is_grad_enabled() and hp.fused_losses and hp.use_unpose):
+            return False
+        if not (getattr(m, "use_unpose", False) and m.k_neigh == 4 and not m.use_view and hasattr(m, "nerf_fine") and m.nerf_fine is not m.nerf
+                and m.evaluate_valid_only and m.skip_far_samples and m.nerf._hip_supported() and m.nerf_fine._hip_supported()):
+            return False
+        if not (vr.lindisp and vr.n_fine > 0 and vr.n_fine_depth == 0 and not vr.share_fine and hp.n_importance > 0 and not hp.share_fine
+                and vr.n_coarse + vr.n_fine <= 256 and getattr(vr, "reuse_coarse_warp", True)):
+            return False
+        if rays.dim() != 4 or rays.shape[-1] != 8 or rays.shape[1] * rays.shape[2] > hp.chunk or not rays.is_contiguous():
+            return False
+        if m.nerf.grad_sink is None or m.nerf_fine.grad_sink is None:
+            return False
+        # pose refinement through a BodyModelParams table (optim_body_params), or constant poses given as a dict
+        if tr.body_model_params is not None and frame_idx is not None:
+            t = tr.body_model_params
+            if not all(getattr(t, n).weight.is_cuda and getattr(t, n).weight.is_contiguous() for n in t.param_names):
+                return False
+            ws = [getattr(t, n).weight for n in t.param_names]
+            return all(w.requires_grad for w in ws) or not any(w.requires_grad for w in ws)
+        return body_model_params is not None and not any(torch.is_tensor(v) and v.requires_grad for v in body_model_params.values())
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _mlp_pass(self, net, mode_id, pts, fg, bg):
+        """compacted training forward of one network on pts[n,4] (+ the prior points as riders): -> state for the backward,
+        out_full[n + n_r, 4]"""
+        params = [dict(net.named_parameters())[k] for k in PARAM_KEYS]
+        pack = _cached_pack(params, mode_id, False)
+        index, pos, pts_c, count = ops.compact_ordered_riders(pts, fg, bg)
+        rows = count[1:2]
+        out_c, act = ops.mlp_forward_save(pack, mode_id, pts_c, False, count=rows)
+        out_full = ops.expand_rows(out_c, pos, -1e5)
+        return dict(net=net, params=params, index=index, pos=pos, pts_c=pts_c, count=count, rows=rows, out_c=out_c, act=act), out_full
+
+    def _mlp_backward(self, st, mode_id, d_out_full, want_pts):
+        """activation, weight (into the network's flat buffer) and — want_pts — point gradients of one compacted pass"""
+        params, act, rows = st["params"], st["act"], st["rows"]
+        weights_generation(params[0], backward=True)
+        g4 = ops.mlp_head_grad(d_out_full, st["index"], st["out_c"], st["pts_c"], st["count"], False)
+        dact = ops.mlp_backward(_cached_pack(params, mode_id, True), mode_id, g4, act, count=rows)
+        enc = ops.encode64(st["pts_c"], act.dtype, count=rows)
+        ops.mlp_wgrad(mode_id, act, dact, enc, g4, accumulate_into=st["net"].grad_sink.flat, count=rows)
+        if not want_pts:
+            return None
+        d_enc = ops.mlp_denc(mode_id, dact, params[PARAM_KEYS.index("xyz_encoding_1.0.weight")],
+                             params[PARAM_KEYS.index("xyz_encoding_5.0.weight")], count=rows)
+        d_pts_c = ops.encode_backward(st["pts_c"], d_enc, count=rows)
+        return ops.expand_rows(d_pts_c, st["pos"], 0.0)
+
+    def _loss_args(self, t, consts):
+        a = _lib.AnrLossArgs()
+        for k in ("rgb", "acc", "rgb_fine", "acc_fine", "target_rgb", "target_alpha", "quads", "quads_fine"):
+            v = t.get(k)
+            setattr(a, k, None if v is None else v.data_ptr())
+        for k in ("s", "s_fine"):
+            setattr(a, k, t.get(k))                              # raw addresses: column 3 of the rider rows
+        for k in ("R", "prior_rows", "nv", "normal_sets", "quad_rows", "n_fg", "n_bg", "s_stride"):
+            setattr(a, k, int(consts.get(k, 0)))
+        for k in ("k", "delta", "lambda_alphas", "lambda_foreground", "lambda_background", "lambda_normals"):
+            setattr(a, k, float(consts.get(k, 0.0)))
+        return a
+
+    # ------------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def run(self, rays, rgbs, alphas, body_model_params, template_params, fg_points, bg_points, perturb, frame_idx):
+        tr, m, vr, hp = self.tr, self.tr.model, self.tr.renderer, self.tr.hp
+        lib = _lib.load()
+        dev = rays.device
+        bm = m.body_model
+        bs, H, W = rays.shape[:3]
+        R, Kc, Kf = H * W, vr.n_coarse, vr.n_fine
+        K = Kc + Kf
+        n_c, n_f = bs * R * Kc, bs * R * K
+        mode_id = ops.MLP_MODES[m.nerf.mlp_mode] & 0xff
+        sinks = (m.nerf.grad_sink, m.nerf_fine.grad_sink)
+        refine = False
+        table = tr.body_model_params if (tr.body_model_params is not None and frame_idx is not None) else None
+
+        # ---- gradient buffers: the reducer's flat buffers are the destination of everything (zeroed by the library's fill)
+        tr.reducer.prepare(zero=False)
+        for flat in tr.reducer.flat:
+            ops.zero_fill(flat)
+
+        # ---- random numbers of the step: one launch, counter on the device
+        want_normals = hp.lambda_normals != 0
+        jitter = perturb > 0
+        noisy = vr.noise_std > 0.0 and perturb > 0
+        if not m._same_template(template_params):
+            m._set_template(template_params)
+        draws = ops.train_draws(self.draw_state, n_t=bs * R * Kc if jitter else 0, t_scale=float(perturb),
+                                n_nc=bs * R * Kc if noisy else 0, n_u=bs * R * Kf if jitter else 0, n_nf=bs * R * K if noisy else 0,
+                                noise_scale=float(vr.noise_std), verts_template=m.verts_template if want_normals else None,
+                                point_scale=hp.dis_threshold * 0.5, neighbour_scale=hp.epsilon)
+        self.last_draws = draws
+
+        # ---- per-frame state (models/anim_nerf.py:108-151) from the parameter tables
+        if table is not None:
+            w = {n: getattr(table, n).weight for n in table.param_names}
+            refine = all(v.requires_grad for v in w.values())
+            betas, pose, transl = ops.gather_frame_params(frame_idx, w["betas"], w["global_orient"], w["body_pose"], w["transl"])
+        else:
+            p = body_model_params
+            betas = p["betas"].expand(bs, -1).contiguous()
+            pose = torch.cat([p["global_orient"], p["body_pose"]], 1)
+            transl = p["transl"].expand(bs, -1).contiguous()
+        verts, joints, A, T, so, po = ops.smpl_forward(betas, pose, transl, bm.v_template, bm.shapedirs, bm.posedirs, bm.J_regressor,
+                                                       bm.parents, bm.lbs_weights)
+        m.shape_offsets, m.pose_offsets, m.joints_transform = so, po, A
+        g_inv, m.global_transform, m.verts, m.joints, m.verts_transform = ops.to_root_frame_from_chain(A, verts, joints, T)
+        m._knn_index = None
+        m._refine = None
+        rays_w = rays.view(bs, R, 8)
+        rays_b = ops.rays_to_body(g_inv, rays_w)
+        o2c = m._ober2cano_values()
+        m.ober2cano_transform = o2c
+        index = m.knn_index()
+        lbs, thr = bm.lbs_weights, m.dis_threshold
+
+        # ---- coarse pass
+        steps = vr._table(dev, "steps", Kc)
+        zc = ops.sample_coarse(rays_b, steps, draws["t_rand"].view(bs * R, Kc) if jitter else None).view(bs, R, Kc)
+        pts_c, nidx_c, nw_c = ops.warp_points(index, o2c, lbs, thr, rays=rays_b, z=zc, skip_far=True, neighbours=True)
+        n_r = bs * ((fg_points.shape[1] if fg_points is not None else 0) + (bg_points.shape[1] if bg_points is not None else 0))
+        st_c, out_c = self._mlp_pass(m.nerf, mode_id, pts_c.view(-1, 4), fg_points, bg_points)
+        flat_rays = rays_b.view(bs * R, 8)
+        noise_c = draws["noise_c"].view(bs * R, Kc) if noisy else None
+        w_c, rgb_c, dep_c, acc_c = ops.composite(out_c[:n_c].view(bs * R, Kc, 4), zc.view(bs * R, Kc), flat_rays, vr.white_bkgd,
+                                                 noise=noise_c, want_weights=True)
+        # ---- fine pass: importance samples + merge, the coarse samples' warp rows copied by the merge's permutation
+        u = draws["u_fine"].view(bs * R, Kf) if jitter else vr._table(dev, "u", Kf)
+        zs, perm = ops.sample_fine_merge(zc.view(bs * R, Kc), w_c, u, want_perm=True, perm_u8=True)
+        zs = zs.view(bs, R, K)
+        pts_f, nidx_f, nw_f = ops.warp_points(index, o2c, lbs, thr, rays=rays_b, z=zs, skip_far=True, neighbours=True,
+                                              reuse=(pts_c, None, perm, nidx_c, nw_c))
+        st_f, out_f = self._mlp_pass(m.nerf_fine, mode_id, pts_f.view(-1, 4), fg_points, bg_points)
+        noise_f = draws["noise_f"].view(bs * R, K) if noisy else None
+        _, rgb_f, dep_f, acc_f = ops.composite(out_f[:n_f].view(bs * R, K, 4), zs.view(bs * R, K), flat_rays, vr.white_bkgd,
+                                               noise=noise_f, want_weights=False)
+
+        # ---- normals regulariser: both networks on the same quads (forward-mode tangents, autograd.QuadSigmaFunction)
+        tan = []
+        pts4 = enc4 = None
+        if want_normals:
+            pair = draws["pair"]
+            n_pad = -(-pair.shape[0] // 16) * 16
+            pts4 = ops.tangent_quads(pair, n_pad)
+            for net in (m.nerf, m.nerf_fine):
+                params = [dict(net.named_parameters())[k] for k in PARAM_KEYS]
+                out_t, act_t = ops.mlp_forward_save(_cached_pack(params, mode_id, False), mode_id, pts4, sigma_only=True, tangent=True)
+                tan.append((net, params, act_t, out_t.view(n_pad, 4)))
+
+        # ---- losses (train.py:228-322) and their gradients: two launches
+        consts = {"R": bs * R, "k": -2.0 / hp.n_samples, "lambda_alphas": hp.lambda_alphas, "lambda_foreground": hp.lambda_foreground,
+                  "lambda_background": hp.lambda_background, "lambda_normals": hp.lambda_normals}
+        t = {"rgb": rgb_c, "acc": acc_c, "rgb_fine": rgb_f, "acc_fine": acc_f, "target_rgb": rgbs.reshape(-1, 3), "target_alpha": alphas.reshape(-1)}
+        assert t["target_rgb"].is_contiguous() and t["target_alpha"].is_contiguous()
+        d_out_c = torch.empty(n_c + n_r, 4, dtype=torch.float32, device=dev)
+        d_out_f = torch.empty(n_f + n_r, 4, dtype=torch.float32, device=dev)
+        if n_r:
+            t["s"], t["s_fine"] = out_c.data_ptr() + (4 * n_c + 3) * 4, out_f.data_ptr() + (4 * n_f + 3) * 4
+            consts.update(prior_rows=bs, n_fg=fg_points.shape[1] if fg_points is not None else 0,
+                          n_bg=bg_points.shape[1] if bg_points is not None else 0, s_stride=4)
+        if want_normals:
+            t["quads"], t["quads_fine"] = tan[0][3], tan[1][3]
+            consts.update(nv=m.verts_template.shape[1], normal_sets=m.verts_template.shape[0], quad_rows=tan[0][3].shape[0], delta=0.02)
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        ws = ops._LOSS_WS.get(key)
+        if ws is None:
+            ws = ops._LOSS_WS[key] = torch.zeros(lib.anr_train_loss_ws_floats(), dtype=torch.float32, device=dev)
+        vals = torch.empty(12, dtype=torch.float32, device=dev)
+        args = self._loss_args(t, consts)
+        _lib.check(lib.anr_train_loss(C.byref(args), ops._ptr(ws), ops._ptr(vals), ops._stream(vals)), "anr_train_loss")
+        g = _lib.AnrLossGrads()
+        d_rgb_c, d_acc_c, d_rgb_f, d_acc_f = (torch.empty_like(x) for x in (rgb_c, acc_c, rgb_f, acc_f))
+        g.rgb, g.acc, g.rgb_fine, g.acc_fine = (x.data_ptr() for x in (d_rgb_c, d_acc_c, d_rgb_f, d_acc_f))
+        if n_r:
+            g.s, g.s_fine = d_out_c.data_ptr() + 16 * n_c, d_out_f.data_ptr() + 16 * n_f
+        d_quads = []
+        if want_normals:
+            d_quads = [torch.empty_like(tan[0][3]), torch.empty_like(tan[1][3])]
+            g.quads, g.quads_fine = d_quads[0].data_ptr(), d_quads[1].data_ptr()
+        one = self._one()
+        _lib.check(lib.anr_train_loss_backward(C.byref(args), ops._ptr(one), C.byref(g), ops._stream(vals)), "anr_train_loss_backward")
+
+        # ---- backward: normals, fine pass, the merge, coarse pass, coarse depths, frame chain
+        if want_normals:
+            enc4 = None
+            for (net, params, act_t, _), dq in zip(tan, d_quads):
+                weights_generation(params[0], backward=True)
+                g4 = ops.mlp_head_grad(dq.reshape(-1), None, None, pts4, pts4.shape[0], True)
+                dact = ops.mlp_backward(_cached_pack(params, mode_id, True), mode_id, g4, act_t, sigma_only=True, tangent=True)
+                if enc4 is None:                                     # (the same rows for both networks)
+                    enc4 = ops.encode64(pts4, act_t.dtype, tangent=True)
+                ops.mlp_wgrad(mode_id, act_t, dact, enc4, g4, sigma_only=True, tangent=True, accumulate_into=net.grad_sink.flat)
+        acc_buf = None
+        d_o2c = d_rays = None
+        if refine:
+            V = o2c.shape[1]
+            acc_buf = ops.zero_fill(torch.empty(bs * V * 16 + bs * R * 8, dtype=torch.float32, device=dev))
+            d_o2c, d_rays = acc_buf[:bs * V * 16].view(bs, V, 4, 4), acc_buf[bs * V * 16:].view(bs, R, 8)
+        res = ops.composite_backward(out_f[:n_f].view(bs * R, K, 4), zs.view(bs * R, K), flat_rays, vr.white_bkgd, d_rgb_f, None, d_acc_f,
+                                     noise=noise_f, want_dz=refine, out=d_out_f)
+        dz_f = dfar_f = None
+        if refine:
+            _, dz_f, dfar_f = res
+        d_pts_f = self._mlp_backward(st_f, mode_id, d_out_f, refine)
+        dz_c_from_fine = None
+        if refine:
+            dzw_f = ops.warp_backward_acc(d_pts_f[:n_f].view(bs, R * K, 4), rays_b, zs, o2c, nidx_f, nw_f, d_o2c, d_rays)
+            dz_c_from_fine = ops.merge_backward2(dzw_f.view(bs * R, K), dz_f, perm, Kc)
+        res = ops.composite_backward(out_c[:n_c].view(bs * R, Kc, 4), zc.view(bs * R, Kc), flat_rays, vr.white_bkgd, d_rgb_c, None, d_acc_c,
+                                     noise=noise_c, want_dz=refine, out=d_out_c)
+        d_pts_c = self._mlp_backward(st_c, mode_id, d_out_c, refine)
+        if refine:
+            _, dz_c, dfar_c = res
+            dzw_c = ops.warp_backward_acc(d_pts_c[:n_c].view(bs, R * Kc, 4), rays_b, zc, o2c, nidx_c, nw_c, d_o2c, d_rays)
+            ops.sample_coarse_backward_acc(d_rays.view(bs * R, 8), steps, draws["t_rand"].view(bs * R, Kc) if jitter else None,
+                                           dzw_c.view(bs * R, Kc), dz_c, dz_c_from_fine, dfar_c, dfar_f)
+            c = m._chain_consts()
+            grads = ops.frame_backward(betas, pose, transl, c["J0"], c["JS"], c["parents"], c["lbs_weights"], c["shapedirs"], c["posedirs"],
+                                       c["T_template"], rays_world=rays_w, d_o2c=d_o2c, d_rays=d_rays)
+            wt = {n: getattr(table, n).weight for n in table.param_names}
+            ops.scatter_frame_param_grads(frame_idx, grads, wt["global_orient"].shape[0], wt["betas"].shape[0], wt["betas"].grad,
+                                          wt["global_orient"].grad, wt["body_pose"].grad, wt["transl"].grad)
+        for s in sinks:                                              # (three passes each went straight into the flat buffers)
+            s.expected = s.done = 0
+        details = {k: vals[i] for i, k in enumerate(ops.LOSS_NAMES)}
+        if not n_r:
+            for k in ("loss_foreground", "loss_background", "loss_foreground_fine", "loss_background_fine"):
+                details.pop(k)
+        else:
+            if fg_points is None:
+                details.pop("loss_foreground"), details.pop("loss_foreground_fine")
+            if bg_points is None:
+                details.pop("loss_background"), details.pop("loss_background_fine")
+        if not want_normals:
+            details.pop("loss_normals"), details.pop("loss_normals_fine")
+        details["psnr"] = vals[11]
+        return vals[10], details
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _one(self):
+        one = getattr(self, "_one_t", None)
+        if one is None or one.device != self.dev:
+            one = self._one_t = torch.ones(1, dtype=torch.float32, device=self.dev)
+        return one

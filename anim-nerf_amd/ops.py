@@ -696,8 +696,9 @@ def composite(rgbs, z, rays, white_bkgd: bool, noise=None, want_weights: bool = 
 
 
 def composite_backward(rgbs, z, rays, white_bkgd: bool, g_rgb, g_depth, g_acc, noise=None, g_weights=None,
-                       want_dz: bool = False):
-    """Backward of `composite`: -> d_rgbs[R,K,4] (and d_z[R,K], d_far[R] if want_dz)."""
+                       want_dz: bool = False, out: Optional[torch.Tensor] = None):
+    """Backward of `composite`: -> d_rgbs[R,K,4] (and d_z[R,K], d_far[R] if want_dz).  out: a caller-owned buffer whose first
+    R K rows receive d_rgbs (the explicit training step keeps rider rows behind them)."""
     lib = _lib.load()
     rgbs, z, rays = _dev(rgbs, "rgbs"), _dev(z, "z"), _dev(rays, "rays")
     g_rgb, g_depth, g_acc = (None if g is None else _dev(g, nm) for g, nm in ((g_rgb, "g_rgb"), (g_depth, "g_depth"), (g_acc, "g_acc")))
@@ -706,7 +707,11 @@ def composite_backward(rgbs, z, rays, white_bkgd: bool, g_rgb, g_depth, g_acc, n
         noise = _dev(noise, "noise")
     if g_weights is not None:
         g_weights = _dev(g_weights, "g_weights")
-    d = torch.empty(R, K, 4, dtype=torch.float32, device=z.device)
+    if out is not None:
+        out = _dev(out, "out")
+        if out.numel() < R * K * 4:
+            raise ValueError("composite_backward: out is smaller than R K rows")
+    d = out if out is not None else torch.empty(R, K, 4, dtype=torch.float32, device=z.device)
     dz = torch.empty(R, K, dtype=torch.float32, device=z.device) if want_dz else None
     dfar = torch.empty(R, dtype=torch.float32, device=z.device) if want_dz else None
     with _timed("composite_backward", R * K):
@@ -899,7 +904,7 @@ def _loss_args(t: dict, c: dict):
 
 
 def train_loss(tensors: dict, consts: dict) -> torch.Tensor:
-    """vals[11]: the ten loss terms (LOSS_NAMES) and their weighted total, one launch (anr_train_loss)."""
+    """vals[12]: the ten loss terms (LOSS_NAMES), their weighted total and the batch's PSNR, one launch (anr_train_loss)."""
     import ctypes as C
     lib = _lib.load()
     ref = next(v for v in tensors.values() if v is not None)
@@ -907,7 +912,7 @@ def train_loss(tensors: dict, consts: dict) -> torch.Tensor:
     ws = _LOSS_WS.get(key)
     if ws is None:
         ws = _LOSS_WS[key] = torch.zeros(lib.anr_train_loss_ws_floats(), dtype=torch.float32, device=ref.device)
-    vals = torch.empty(11, dtype=torch.float32, device=ref.device)
+    vals = torch.empty(12, dtype=torch.float32, device=ref.device)   # ten terms, the total, the batch's PSNR
     a = _loss_args(tensors, consts)
     _lib.check(lib.anr_train_loss(C.byref(a), _ptr(ws), _ptr(vals), _stream(vals)), "anr_train_loss")
     return vals
@@ -963,11 +968,156 @@ def marching_cubes(volume: torch.Tensor, level: float = 0.0):
     return verts[:V], faces[:T].long()
 
 
-def adam_step(chunks: torch.Tensor, n_chunks: int, step: torch.Tensor, lrs, beta1: float, beta2: float, eps: float) -> None:
+def adam_step(chunks: torch.Tensor, n_chunks: int, step: torch.Tensor, lrs, beta1: float, beta2: float, eps: float,
+              active: Optional[torch.Tensor] = None, ticket: Optional[torch.Tensor] = None) -> None:
     """torch.optim.Adam's update (train.py:216-226) over a table of tensor chunks in one launch (include/animnerf_hip.h:
-    anr_adam_step); `step` is the device-side count of THIS update, `lrs` the host learning rates of the groups."""
+    anr_adam_step); `step` is the device-side count of THIS update, `lrs` the host learning rates of the groups.
+    active / ticket (int32[1], zero): `step` holds the counts BEFORE this update and the kernel advances them itself."""
     lib = _lib.load()
     chunks, step = _dev(chunks, "chunks", torch.uint8), _dev(step, "step")
     arr = (C.c_float * len(lrs))(*[float(x) for x in lrs])
+    if active is not None:
+        active, ticket = _dev(active, "active"), _dev(ticket, "ticket", torch.int32)
+        _lib.check(lib.anr_adam_step_counting(_ptr(chunks), int(n_chunks), _ptr(step), _ptr(active), step.numel(), _ptr(ticket), arr, len(lrs),
+                                              float(beta1), float(beta2), float(eps), _stream(step)), "anr_adam_step_counting")
+        return
     _lib.check(lib.anr_adam_step(_ptr(chunks), int(n_chunks), _ptr(step), arr, len(lrs), float(beta1), float(beta2), float(eps),
                                  _stream(step)), "anr_adam_step")
+
+
+# ---- the explicit training step (fused_step.py): csrc/train_step.hip
+def zero_fill(t: torch.Tensor) -> torch.Tensor:
+    """t[:] = 0 by the library's own fill kernel (a memset node of a captured graph went stale on ROCm 7.2; a framework
+    fill is a launch the step's graph should not hold)."""
+    lib = _lib.load()
+    if not t.is_cuda or not t.is_contiguous():
+        raise RuntimeError("zero_fill: a contiguous tensor on the GPU")
+    _lib.check(lib.anr_zero_fill(_ptr(t), t.numel() * t.element_size(), _stream(t)), "anr_zero_fill")
+    return t
+
+
+def train_draws(state: torch.Tensor, *, n_t=0, t_scale=1.0, n_nc=0, n_u=0, n_nf=0, noise_scale=1.0, verts_template=None,
+                point_scale=0.0, neighbour_scale=0.0):
+    """Every random number of one training step in one launch (anr_train_draws): -> dict(t_rand[n_t], noise_c[n_nc],
+    u_fine[n_u], noise_f[n_nf], n0, n1 [like verts_template], pair[2 x verts_template rows, 3]); absent ones None.
+    state: int64[3] on the device = (seed, step counter, 0); the kernel advances the counter."""
+    lib = _lib.load()
+    state = _dev(state, "state", torch.int64)
+    dev = state.device
+    new = lambda n: torch.empty(n, dtype=torch.float32, device=dev) if n else None
+    o = dict(t_rand=new(n_t), noise_c=new(n_nc), u_fine=new(n_u), noise_f=new(n_nf), n0=None, n1=None, pair=None)
+    p = _lib.AnrDrawPlan()
+    for k in ("t_rand", "noise_c", "u_fine", "noise_f"):
+        setattr(p, k, None if o[k] is None else o[k].data_ptr())
+    p.n_t, p.n_nc, p.n_u, p.n_nf = n_t, n_nc, n_u, n_nf
+    p.t_scale, p.noise_scale = float(t_scale), float(noise_scale)
+    vt = None
+    if verts_template is not None:
+        vt = _dev(verts_template, "verts_template")
+        o["n0"], o["n1"] = torch.empty_like(vt), torch.empty_like(vt)
+        o["pair"] = torch.empty(2 * vt.numel() // 3, 3, dtype=torch.float32, device=dev)
+        p.verts_template, p.n_v3 = vt.data_ptr(), vt.numel()
+        p.point_scale, p.neighbour_scale = float(point_scale), float(neighbour_scale)
+        p.n0, p.n1, p.pair = o["n0"].data_ptr(), o["n1"].data_ptr(), o["pair"].data_ptr()
+    _lib.check(lib.anr_train_draws(_ptr(state), C.byref(p), _stream(state)), "anr_train_draws")
+    return o
+
+
+def gather_frame_params(frame_idx, betas_w, go_w, bp_w, tr_w):
+    """BodyModelParams.forward as one launch: -> betas[bs,10], pose[bs,72], transl[bs,3]."""
+    lib = _lib.load()
+    frame_idx = _dev(frame_idx, "frame_idx", torch.int64)
+    betas_w, go_w, bp_w, tr_w = _dev(betas_w, "betas"), _dev(go_w, "global_orient"), _dev(bp_w, "body_pose"), _dev(tr_w, "transl")
+    bs, dev = frame_idx.numel(), frame_idx.device
+    betas, pose, transl = (torch.empty(bs, c, dtype=torch.float32, device=dev) for c in (10, 72, 3))
+    _lib.check(lib.anr_gather_frame_params(_ptr(frame_idx), bs, _ptr(betas_w), betas_w.shape[0], _ptr(go_w), _ptr(bp_w), _ptr(tr_w),
+                                           _ptr(betas), _ptr(pose), _ptr(transl), _stream(betas)), "anr_gather_frame_params")
+    return betas, pose, transl
+
+
+def scatter_frame_param_grads(frame_idx, grads, table_rows, betas_rows, d_betas, d_go, d_bp, d_tr):
+    """grads[bs,85] -> the four tables' gradient buffers, written whole (None: skipped)."""
+    lib = _lib.load()
+    frame_idx, grads = _dev(frame_idx, "frame_idx", torch.int64), _dev(grads, "grads")
+    for t in (d_betas, d_go, d_bp, d_tr):
+        if t is not None and (not t.is_cuda or not t.is_contiguous() or t.dtype != torch.float32):
+            raise RuntimeError("scatter_frame_param_grads: contiguous float32 gradient buffers on the GPU")
+    _lib.check(lib.anr_scatter_frame_param_grads(_ptr(frame_idx), _ptr(grads), frame_idx.numel(), int(table_rows), int(betas_rows),
+                                                 _ptr(d_betas), _ptr(d_go), _ptr(d_bp), _ptr(d_tr), _stream(grads)),
+               "anr_scatter_frame_param_grads")
+
+
+def to_root_frame_from_chain(A, verts, joints, T):
+    """`to_root_frame` with the root transforms read in place from the joint chain A[bs,J,4,4] (joints_transform[:, 0])."""
+    lib = _lib.load()
+    A, verts, joints, T = _dev(A, "joints_transform"), _dev(verts, "verts"), _dev(joints, "joints"), _dev(T, "T")
+    bs, V, J = verts.shape[0], verts.shape[1], joints.shape[1]
+    g_inv = torch.empty(bs, 4, 4, dtype=torch.float32, device=A.device)
+    g_root = torch.empty_like(g_inv)
+    v2, j2, T2 = torch.empty_like(verts), torch.empty_like(joints), torch.empty_like(T)
+    _lib.check(lib.anr_to_root_frame_strided(_ptr(A), 16 * A.shape[1], _ptr(verts), _ptr(joints), _ptr(T), bs, V, J, _ptr(g_inv),
+                                             _ptr(g_root), _ptr(v2), _ptr(j2), _ptr(T2), _stream(T2)), "anr_to_root_frame")
+    return g_inv, g_root, v2, j2, T2
+
+
+def compact_ordered_riders(pts: torch.Tensor, fg: Optional[torch.Tensor] = None, bg: Optional[torch.Tensor] = None):
+    """`compact_ordered` with the prior points fg[rows,n_fg,3] / bg[rows,n_bg,3] appended as valid samples n .. n + n_r - 1, per
+    frame its foreground then its background points (index / pos: n + n_r entries)."""
+    lib = _lib.load()
+    pts = _dev(pts, "pts")
+    n = pts.numel() // 4
+    fg = None if fg is None else _dev(fg, "fg_points")
+    bg = None if bg is None else _dev(bg, "bg_points")
+    rows = 0 if (fg is None and bg is None) else (fg if fg is not None else bg).shape[0]
+    n_fg, n_bg = (0 if fg is None else fg.shape[1]), (0 if bg is None else bg.shape[1])
+    if fg is not None and bg is not None and fg.shape[0] != bg.shape[0]:
+        raise ValueError("fg / bg prior points: one row per frame each")
+    tot = n + rows * (n_fg + n_bg)
+    index = torch.empty(tot, dtype=torch.int32, device=pts.device)
+    pos = torch.empty(tot, dtype=torch.int32, device=pts.device)
+    pts_c = torch.empty(-(-tot // 64) * 64, 4, dtype=torch.float32, device=pts.device)
+    count = torch.empty(2, dtype=torch.int32, device=pts.device)
+    ws = torch.empty(lib.anr_compact_ws_ints(tot), dtype=torch.int32, device=pts.device)
+    with _timed("compact_ordered", tot, tot * 24):
+        _lib.check(lib.anr_compact_ordered_riders(_ptr(pts), n, _ptr(fg), n_fg, _ptr(bg), n_bg, rows, _ptr(index), _ptr(pos), _ptr(pts_c),
+                                                  _ptr(count), _ptr(ws), _stream(pts)), "anr_compact_ordered")
+    return index, pos, pts_c, count
+
+
+def merge_backward2(g_a, g_b, perm_u8, Kc: int) -> torch.Tensor:
+    """dL/dz_coarse[R,Kc] from (g_a + g_b)[R,K] and the byte permutation of sample_fine_merge(perm_u8=True)."""
+    lib = _lib.load()
+    g_a, perm_u8 = _dev(g_a, "g_a"), _dev(perm_u8, "perm", torch.uint8)
+    g_b = None if g_b is None else _dev(g_b, "g_b")
+    R, K = perm_u8.shape
+    d = torch.empty(R, Kc, dtype=torch.float32, device=g_a.device)
+    _lib.check(lib.anr_merge_backward2(_ptr(g_a), _ptr(g_b), _ptr(perm_u8), R, K, Kc, _ptr(d), _stream(d)), "anr_merge_backward2")
+    return d
+
+
+def sample_coarse_backward_acc(d_rays_acc, steps, t_rand, g_a, g_b=None, g_c=None, dfar_a=None, dfar_b=None) -> None:
+    """d_rays_acc[R,8] columns 6, 7 += d(near', far') of sample_coarse from (g_a + g_b + g_c)[R,K], + dfar_a + dfar_b."""
+    lib = _lib.load()
+    d_rays_acc, steps, g_a = _dev(d_rays_acc, "d_rays_acc"), _dev(steps, "steps"), _dev(g_a, "g_a")
+    opt = lambda t, nm: None if t is None else _dev(t, nm)
+    t_rand, g_b, g_c, dfar_a, dfar_b = opt(t_rand, "t_rand"), opt(g_b, "g_b"), opt(g_c, "g_c"), opt(dfar_a, "dfar_a"), opt(dfar_b, "dfar_b")
+    K = steps.numel()
+    R = g_a.numel() // K
+    _lib.check(lib.anr_sample_coarse_backward_acc(_ptr(g_a), _ptr(g_b), _ptr(g_c), _ptr(steps), _ptr(t_rand), _ptr(dfar_a), _ptr(dfar_b),
+                                                  R, K, _ptr(d_rays_acc), _stream(d_rays_acc)), "anr_sample_coarse_backward_acc")
+
+
+def warp_backward_acc(d_pts, rays, z, o2c, nbr_idx, nbr_w, d_o2c_acc, d_rays_acc) -> torch.Tensor:
+    """`warp_backward` adding into caller-owned accumulators d_o2c_acc[bs,V,4,4] / d_rays_acc[bs,R,8] (zeroed once per step:
+    the coarse and the fine pass both add there); -> d_z[bs,R,K]."""
+    lib = _lib.load()
+    d_pts, rays, z, o2c = _dev(d_pts, "d_pts"), _dev(rays, "rays"), _dev(z, "z"), _dev(o2c, "ober2cano")
+    nbr_idx, nbr_w = _dev(nbr_idx, "nbr_idx", torch.int32), _dev(nbr_w, "nbr_w")
+    d_o2c_acc, d_rays_acc = _dev(d_o2c_acc, "d_o2c_acc"), _dev(d_rays_acc, "d_rays_acc")
+    bs, R, K = z.shape
+    d_z = torch.empty_like(z)
+    with _timed("warp_backward", bs * R * K):
+        _lib.check(lib.anr_warp_backward(_ptr(d_pts), _ptr(rays), rays.shape[-1], _ptr(z), K, _ptr(o2c), _ptr(nbr_idx), _ptr(nbr_w), bs,
+                                         o2c.shape[1], R * K, _ptr(d_o2c_acc), _ptr(d_rays_acc), _ptr(d_z), _stream(z)),
+                   "anr_warp_backward")
+    return d_z

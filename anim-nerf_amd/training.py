@@ -268,14 +268,16 @@ class GradientReducer:
         self._pending[bi] -= k
         assert self._pending[bi] >= 0, (bi, self._pending)
 
-    def prepare(self):
-        """Before backward: zero the send buffers and point every p.grad at its slice."""
+    def prepare(self, zero: bool = True):
+        """Before backward: zero the send buffers and point every p.grad at its slice.  zero=False: the caller clears them
+        itself (the explicit step: the library's fill kernel instead of a framework launch)."""
         self._probe()
         self._pending = [len(b) for b in self.buckets]
         self._sink_params = {id(p) for s in self.sinks for p in s.params}
         self._next, self._handles = 0, []
         for flat in self.flat:
-            flat.zero_()
+            if zero:
+                flat.zero_()
         for p, (_, view) in self.slot.items():
             p.grad = view
         for sink in self.sinks:
@@ -373,6 +375,7 @@ class FlatAdam(torch.optim.Optimizer):
         self._v = torch.zeros(o, dtype=torch.float32, device=dev)
         self._steps = torch.zeros(len(ps), dtype=torch.float32, device=dev)   # one counter per tensor, as torch keeps them
         self._active = torch.zeros(len(ps), dtype=torch.float32, device=dev)  # 1 where the tensor has a gradient this step
+        self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self._index = {p: i for i, p in enumerate(ps)}
         self._slices = {p: (off, p.numel()) for p, off in zip(ps, offs)}
         self._bind_state()
@@ -422,9 +425,9 @@ class FlatAdam(torch.optim.Optimizer):
         if self._n_chunks:
             from . import ops
             g0 = self.param_groups[0]
-            self._steps.add_(self._active)
+            # (the kernel advances the per-tensor step counters itself: no increment launch in front of it)
             ops.adam_step(self._table, self._n_chunks, self._steps, [float(g["lr"]) for g in self.param_groups],
-                          g0["betas"][0], g0["betas"][1], g0["eps"])
+                          g0["betas"][0], g0["betas"][1], g0["eps"], active=self._active, ticket=self._ticket)
         return loss
 
     def load_state_dict(self, state_dict):
@@ -443,7 +446,7 @@ class Trainer:
     """optimizer + schedule + step; `step(batch)` mirrors AnimNeRFSystem.training_step (train.py:324-348)."""
 
     def __init__(self, anim_nerf, volume_renderer, hp: TrainHParams, body_model_params: Optional[BodyModelParams] = None,
-                 graph: bool = False):
+                 graph: bool = False, explicit_step: bool = True):
         """graph=True: `step_graphed` may capture the whole step (forward, losses, backward, Adam) into ONE HIP graph and
         replay it — every launch of the step leaves the host as one (the step holds no device -> host read: row counts stay
         on the device; FlatAdam keeps its step counter there too).  Opt-in.  `with trainer.loop():` runs the loop on the
@@ -497,12 +500,16 @@ class Trainer:
         # (which create those nodes), every eager step, the capture and the replays all run on it, fenced against the caller's
         # current stream on both sides.
         self._stream = torch.cuda.Stream(self.params[0].device) if (self.graph_enabled and on_gpu) else None
+        self.explicit = None                                  # fused_step.ExplicitTrainStep (GPU, the shipped configuration)
         # (construction enqueues nothing the caller's stream must see: no fence against it here)
         with (torch.cuda.stream(self._stream) if self._stream is not None else contextlib.nullcontext()):
             self.reducer = GradientReducer([fine, coarse + rest])
             if on_gpu:
                 for net in nets:
                     self.reducer.attach_sink(net)
+                if explicit_step:
+                    from .fused_step import ExplicitTrainStep
+                    self.explicit = ExplicitTrainStep(self)
 
     @property
     def stream(self):
@@ -656,6 +663,14 @@ class Trainer:
 
     def _step_body(self, rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points, bg_points, perturb,
                    frame_idx, apply=True):
+        if self.explicit is not None and self.explicit.supported(rays, body_model_params, frame_idx, fg_points, bg_points):
+            # forward, losses and backward as a fixed sequence of the library's launches (fused_step.py): no autograd graph,
+            # no framework kernel between the first and the last launch of the step
+            loss, details = self.explicit.run(rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points,
+                                              bg_points, perturb, frame_idx)
+            if apply:
+                self._apply_gradients()
+            return loss, details
         self.begin_step()                                     # grads are views into the (zeroed) flat buffers
         if self.body_model_params is not None and frame_idx is not None:
             body_model_params = self.body_model_params(frame_idx)

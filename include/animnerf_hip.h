@@ -430,6 +430,13 @@ int anr_mc_emit(const float* volume, int n0, int n1, int n2, float level, const 
 int64_t anr_compact_ws_ints(int64_t n);
 int anr_compact_ordered(const float* pts, int64_t n, int32_t* index_out, int32_t* pos_out, float* pts_out,
                         int32_t* count_out, int32_t* workspace, void* stream);
+/* ... with n_r = rows (n_fg + n_bg) RIDER points appended as samples n .. n + n_r - 1 with valid = 1 (the prior points of
+ * train.py:262-286 evaluated with the step's ray samples): per frame its foreground points fg[rows][n_fg][3], then its
+ * background points bg[rows][n_bg][3] (n_fg or n_bg = 0: absent) — the order anr_train_loss reads their sigmas in.
+ * index_out / pos_out hold n + n_r entries, pts_out roundup64(n + n_r) rows, workspace anr_compact_ws_ints(n + n_r) ints. */
+int anr_compact_ordered_riders(const float* pts, int64_t n, const float* fg, int n_fg, const float* bg, int n_bg, int rows,
+                               int32_t* index_out, int32_t* pos_out, float* pts_out, int32_t* count_out, int32_t* workspace,
+                               void* stream);
 int anr_expand_rows(const float* src, const int32_t* pos, int64_t n, int cols, float fill, float* out, void* stream);
 int anr_mlp_head_grad(const float* g_in, const int32_t* index, const float* out, const float* pts, int64_t rows,
                       int64_t n_pad, int sigma_only, float* g_out, void* stream);
@@ -453,8 +460,9 @@ int anr_merge_backward(const float* g_sorted, const int32_t* perm, int64_t R, in
  *   quads[quad_rows*4] (+ _fine): tangent-mode sigma (sigma, d/dx, d/dy, d/dz) of normal_sets x (nv points, nv perturbed
  *     neighbours); normal = delta exp(-delta sigma) grad sigma where sigma > 0 (models/nerf.py:177-190), unit length with
  *     eps 1e-5, MSE between a point's and its neighbour's (train.py:288-309).
- * vals_out[11] = loss_rgb, loss_rgb_fine, loss_alphas, loss_alphas_fine, loss_foreground, loss_background,
- *   loss_foreground_fine, loss_background_fine, loss_normals, loss_normals_fine, total (weighted by the lambdas).
+ * vals_out[12] = loss_rgb, loss_rgb_fine, loss_alphas, loss_alphas_fine, loss_foreground, loss_background,
+ *   loss_foreground_fine, loss_background_fine, loss_normals, loss_normals_fine, total (weighted by the lambdas), and the
+ *   batch's PSNR = -10 log10(loss_rgb_fine, or loss_rgb without a fine pass) (train.py:339-344).
  * workspace[anr_train_loss_ws_floats()], zero before its first use (the kernel leaves it ready for the next call). */
 typedef struct {
     const float *rgb, *acc, *rgb_fine, *acc_fine, *target_rgb, *target_alpha;
@@ -463,6 +471,9 @@ typedef struct {
     int64_t R, prior_rows, nv, normal_sets, quad_rows;
     int32_t n_fg, n_bg;
     float k, delta, lambda_alphas, lambda_foreground, lambda_background, lambda_normals;
+    int32_t s_stride;   /* floats between consecutive prior sigmas in s / s_fine: 0 or 1 = packed; 4 = column 3 of (r, g, b, sigma)
+                           rows (s points at row 0's sigma), and then the gradient d.s / d.s_fine (pointing at row 0's r) is written
+                           as whole rows (0, 0, 0, d sigma) */
 } anr_loss_args;
 /* gradient destinations, same shapes as the inputs (NULL: not wanted); quads: all quad_rows rows are written */
 typedef struct {
@@ -551,6 +562,60 @@ int anr_adam_chunk_floats(void);
 int anr_adam_chunk_bytes(void);
 int anr_adam_step(const void* chunks, int n_chunks, const float* step, const float* lr, int n_groups, double beta1, double beta2,
                   double eps, void* stream);
+/* ... with the counters advanced by the kernel itself: step[n_tensors] holds the counts BEFORE this update (the update uses
+ * step + 1), and the last workgroup to finish adds active[n_tensors] (1 where the tensor has a gradient this step) to them;
+ * ticket: one int32 on the device, zero at rest.  One launch instead of an increment launch + the update. */
+int anr_adam_step_counting(const void* chunks, int n_chunks, float* step, const float* active, int n_tensors, int32_t* ticket,
+                           const float* lr, int n_groups, double beta1, double beta2, double eps, void* stream);
+
+/* ---- the explicit training step (anim_nerf_amd/fused_step.py): what it needs beside the kernels above so that the step's
+ * HIP graph holds this library's launches only (csrc/train_step.hip) -------------------------------------------------
+ * anr_train_draws: every random number of one training step (train.py:324-348) in one launch — Philox4x32-10 keyed by
+ *   state[0] = seed and state[1] = a step counter that lives ON THE DEVICE and is advanced by the kernel (state[2]: a
+ *   ticket, zero at rest), so a replayed graph draws fresh numbers.  state: int64[3], device.
+ *   t_rand[n_t] = t_scale U[0,1) (the stratified jitter, models/volume_rendering.py:48-54: t_scale = perturb);
+ *   noise_c[n_nc], noise_f[n_nf] = noise_scale N(0,1) (sigma noise of the two passes, :122-129); u_fine[n_u] = U[0,1) (the
+ *   importance sampler's uniforms, :66-70); n0[n_v3], n1[n_v3] = N(0,1) and pair[2 n_v3] = (verts_template + point_scale n0,
+ *   that + neighbour_scale n1): the normal regulariser's points and their neighbours (train.py:289-290: point_scale =
+ *   dis_threshold / 2, neighbour_scale = epsilon).  A segment with n = 0 is skipped. */
+typedef struct {
+    float *t_rand, *noise_c, *u_fine, *noise_f;
+    int64_t n_t, n_nc, n_u, n_nf;
+    float t_scale, noise_scale;
+    const float* verts_template;
+    int64_t n_v3;
+    float point_scale, neighbour_scale;
+    float *n0, *n1, *pair;
+} anr_draw_plan;
+int anr_train_draws(int64_t* state, const anr_draw_plan* plan, void* stream);
+/* BodyModelParams.forward (models/body_model_params.py:5-68): rows frame_idx[bs] (int64) of the embedding tables
+ * global_orient[T][3], body_pose[T][69], transl[T][3] and betas[betas_rows][10] (betas_rows = 1: one shape for all frames) ->
+ * betas_out[bs][10], pose_out[bs][72] = (global_orient | body_pose), transl_out[bs][3]: the operands of anr_smpl_forward. */
+int anr_gather_frame_params(const int64_t* frame_idx, int bs, const float* betas_w, int betas_rows, const float* go_w,
+                            const float* bp_w, const float* tr_w, float* betas_out, float* pose_out, float* transl_out,
+                            void* stream);
+/* ... and its backward: grads[bs][85] = dL/d(betas 10 | global_orient 3 | body_pose 69 | transl 3) per frame (what
+ * anr_frame_backward_adjoint returns) -> the tables' gradients, WRITTEN whole (rows no frame of the batch uses get 0; a row
+ * used twice gets the sum in batch order; betas_rows = 1: the sum over the batch).  A NULL table is skipped. */
+int anr_scatter_frame_param_grads(const int64_t* frame_idx, const float* grads, int bs, int table_rows, int betas_rows,
+                                  float* d_betas_w, float* d_go_w, float* d_bp_w, float* d_tr_w, void* stream);
+/* anr_merge_backward on g_a + g_b (g_b may be NULL): the fine pass's warp and compositor both differentiate the sorted depths;
+ * perm: the byte permutation of anr_sample_fine_merge_u8 (K <= 256) */
+int anr_merge_backward2(const float* g_a, const float* g_b, const uint8_t* perm, int64_t R, int K, int Kc,
+                        float* d_z_coarse_out, void* stream);
+/* anr_sample_coarse_backward on g_a + g_b + g_c (g_b, g_c may be NULL), ADDED into columns 6, 7 of d_rays_acc[R*8] together
+ * with dfar_a[R] + dfar_b[R] (the two compositors' dL/d far', NULL = none): the ray gradient the warp's backward has been
+ * accumulating is complete after this launch. */
+int anr_sample_coarse_backward_acc(const float* g_a, const float* g_b, const float* g_c, const float* steps,
+                                   const float* t_rand, const float* dfar_a, const float* dfar_b, int64_t R, int K,
+                                   float* d_rays_acc, void* stream);
+/* anr_to_root_frame with the root transforms g_stride floats apart (g_stride = 16 J: joints_transform[:, 0] read in place) */
+int anr_to_root_frame_strided(const float* global_transform, int64_t g_stride, const float* verts, const float* joints,
+                              const float* T, int bs, int V, int J, float* g_inv_out, float* g_root_out, float* verts_out,
+                              float* joints_out, float* T_out, void* stream);
+/* zero `bytes` (a multiple of 4) at a 4-byte aligned device address: a kernel, not a memset (a memset NODE of a captured HIP
+ * graph went stale on ROCm 7.2: DESIGN.md section 4.4) */
+int anr_zero_fill(void* ptr, int64_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

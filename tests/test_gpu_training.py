@@ -1161,20 +1161,29 @@ def test_training_tracks_an_oracle_trained_copy(dev, smpl_table):
     F = torch.nn.functional
     pose_d, dev_batch = {k: v.to(dev) for k, v in pose.items()}, [t.to(dev) for t in (rays, tgt_rgb, tgt_a, fg, bg)]
     curve_h, curve_o = [], []
-    for it in range(steps):
-        loss_h, det = tr.step(dev_batch[0], dev_batch[1], dev_batch[2], pose_d, _templ(dev), dev_batch[3], dev_batch[4], perturb=0.0)
-        curve_h.append(loss_h.item())
-        opt.zero_grad(set_to_none=True)
-        out = orc.render_frame(tbl, Pc, Pf, rays.view(2, 64, 8), pose, templ, n_coarse=16, n_fine=8, use_unpose=True, chunk=64, knn_chunk=512)
-        t_rgb, t_a = tgt_rgb.view(2, 64, 3), tgt_a.view(2, 64, 1)
-        ref = (F.mse_loss(out["rgbs"], t_rgb) + F.mse_loss(out["rgbs_fine"], t_rgb)
-               + 0.1 * (F.l1_loss(out["alphas"], t_a) + F.l1_loss(out["alphas_fine"], t_a)))
-        for P in (Pc, Pf):
-            ref = ref + 0.01 * torch.mean(torch.exp(-2.0 / 16 * torch.relu(orc.mlp_sigma_and_feature(P, fg)[0]))) \
-                      + 0.01 * torch.mean(1 - torch.exp(-2.0 / 16 * torch.relu(orc.mlp_sigma_and_feature(P, bg)[0])))
-        ref.backward()
-        opt.step()
-        curve_o.append(ref.item())
+    # the oracle's per-frame state does not change while the weights train (the pose is a constant of this run): once, not 150 x
+    # (the SMPL chain and 13,780 4x4 LAPACK inverses per step were most of this test's 200 s)
+    st = orc.frame_state(tbl, pose, templ)
+    st, rays_b = orc.to_root_frame(st, rays.view(2, 64, 8))
+    st["ober2cano"] = orc.observation_to_canonical(st)
+
+    def field(xyz, use_fine):
+        return orc.field_query(Pf if use_fine else Pc, xyz, st, tbl["lbs_weights"], True, 0.2, chunk=512)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 16))                     # ops this small lose on hundreds of threads
+    try:
+        for it in range(steps):
+            loss_h, det = tr.step(dev_batch[0], dev_batch[1], dev_batch[2], pose_d, _templ(dev), dev_batch[3], dev_batch[4], perturb=0.0)
+            curve_h.append(loss_h.item())
+            opt.zero_grad(set_to_none=True)
+            out = orc.render_rays(field, rays_b, 16, 8)
+            t_rgb, t_a = tgt_rgb.view(2, 64, 3), tgt_a.view(2, 64, 1)
+            ref, _ = orc.training_loss(Pc, Pf, out, t_rgb, t_a, n_samples=16, fg_points=fg, bg_points=bg, draws=None)
+            ref.backward()
+            opt.step()
+            curve_o.append(ref.item())
+    finally:
+        torch.set_num_threads(threads)
     psnr_h = det["psnr"].item()
     psnr_o = -10.0 * torch.log10(F.mse_loss(out["rgbs_fine"], t_rgb)).item()
     gap = max(abs(a - b) / b for a, b in zip(curve_h, curve_o))
@@ -1434,3 +1443,101 @@ def test_training_fine_pass_copies_the_coarse_samples_warp(dev, smpl_table, refi
         a, b = res[0][1][k], res[1][1][k]
         assert (a - b).abs().max() <= 2e-5 * b.abs().max() + 1e-12, k
     assert res[0][0]["alphas_fine"].max() > 0.2
+
+
+def test_step_draws_kernel(dev):
+    """anr_train_draws: the random numbers of a training step from Philox4x32-10 keyed by (seed, step counter on the device):
+    the same state gives the same numbers, the kernel advances the counter, the streams have the moments of U[0,1) / N(0,1)
+    and are uncorrelated with each other, and the normals' points are verts_template + scale x the normals it reports."""
+    from anim_nerf_amd import ops
+    vt = torch.randn(1, 6890, 3, generator=torch.Generator().manual_seed(0)).to(dev)
+    kw = dict(n_t=16384 * 64, t_scale=1.0, n_nc=16384 * 64, n_u=16384 * 32 + 3, n_nf=16384 * 96, noise_scale=1.0, verts_template=vt,
+              point_scale=0.1, neighbour_scale=0.01)
+    st = torch.tensor([1234, 0, 0], dtype=torch.int64, device=dev)
+    a = ops.train_draws(st, **kw)
+    assert st.tolist() == [1234, 1, 0]
+    b = ops.train_draws(st, **kw)
+    assert st.tolist() == [1234, 2, 0]
+    c = ops.train_draws(torch.tensor([1234, 0, 0], dtype=torch.int64, device=dev), **kw)
+    for k in ("t_rand", "noise_c", "u_fine", "noise_f", "n0", "n1", "pair"):
+        assert torch.equal(a[k], c[k]), k                       # a pure function of (seed, step)
+        assert not torch.equal(a[k], b[k]), k                   # fresh numbers per step
+    for k in ("t_rand", "u_fine"):
+        u = a[k].double()
+        assert u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 2e-3 and abs(u.var() - 1 / 12) < 1e-3, k
+    for k in ("noise_c", "noise_f", "n0", "n1"):
+        x = a[k].double().flatten()
+        assert abs(x.mean()) < 1e-2 and abs(x.var() - 1) < 2e-2 and abs((x ** 4).mean() - 3) < 0.15 and x.abs().max() < 7, k
+    n = 16384 * 64
+    assert abs(torch.corrcoef(torch.stack([a["t_rand"][:n], a["noise_c"][:n]]))[0, 1]) < 5e-3
+    assert abs(torch.corrcoef(torch.stack([a["noise_c"][:n], a["noise_f"][:n]]))[0, 1]) < 5e-3
+    assert abs(torch.corrcoef(torch.stack([a["noise_c"][:-1], a["noise_c"][1:]]))[0, 1]) < 5e-3
+    assert abs(torch.corrcoef(torch.stack([a["n0"].flatten(), a["n1"].flatten()]))[0, 1]) < 2e-2
+    pts = vt + 0.1 * a["n0"]
+    torch.testing.assert_close(a["pair"][:6890], pts[0], rtol=0, atol=1e-6)
+    torch.testing.assert_close(a["pair"][6890:], (pts + 0.01 * a["n1"])[0], rtol=0, atol=1e-6)
+    # t_scale / noise_scale, and absent segments
+    d = ops.train_draws(torch.tensor([1234, 0, 0], dtype=torch.int64, device=dev), n_t=1024, t_scale=0.5, n_nc=1024, noise_scale=2.0)
+    assert torch.equal(d["t_rand"], 0.5 * a["t_rand"][:1024]) and torch.equal(d["noise_c"], 2.0 * a["noise_c"][:1024])
+    assert d["u_fine"] is None and d["pair"] is None
+
+
+@pytest.mark.parametrize("mode,frames", [("f32", 3), ("bf16", 2)])
+def test_explicit_step_equals_the_autograd_step(dev, smpl_table, mode, frames):
+    """fused_step.ExplicitTrainStep (forward, losses and backward as a fixed sequence of the library's launches) against the
+    autograd step on the same batch and the SAME random numbers (the explicit step's draws replayed into the autograd step's
+    rand / randn / randn_like calls): every loss term, the total, the PSNR, and the gradient of every tensor — both networks
+    and the four pose tables — before the optimiser touches them.  The kernels are the same ones; what differs is the order
+    in which contributions are added (atomics, three passes into one flat buffer)."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    from helpers import InjectedDraws
+    H = 16
+    c2w, focal, cen = syn.pinhole_camera(H, H)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), H, H, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(frames, 1, 1, 1).contiguous()
+    gen = torch.Generator().manual_seed(4)
+    rgbs = torch.rand(frames, H, H, 3, generator=gen).to(dev)
+    alphas = (torch.rand(frames, H, H, 1, generator=gen) > 0.5).float().to(dev)
+    fg = (torch.rand(frames, 96, 3, generator=gen) * 0.4 - 0.2).to(dev)
+    bg = (torch.rand(frames, 64, 3, generator=gen) * 2 - 1).to(dev)
+    frame_idx = torch.tensor([5, 17, 5][:frames], device=dev)     # (a table row used twice)
+    seeded = syn.animated_pose_params(seed=200, bs=40)
+    out = []
+    for explicit in (True, False):
+        m = seeded_model(smpl_table, 11, True, 300.0, (2.0, 2.0), device=dev, mlp_mode=mode)
+        m.train()
+        table = ana.BodyModelParams(40).to(dev)
+        for name in table.param_names:
+            table.init_parameters(name, torch.from_numpy(seeded[name]).to(dev), requires_grad=True)
+        hp = ana.TrainHParams(n_samples=64, n_importance=32, chunk=2048)
+        tr = ana.Trainer(m, ana.VolumeRenderer(n_coarse=64, n_fine=32), hp, body_model_params=table, explicit_step=explicit)
+        assert (tr.explicit is not None) == explicit
+        args = (rays, rgbs, alphas, None, _templ(dev), fg, bg, 1.0, frame_idx)
+        if explicit:
+            assert tr.explicit.supported(rays, None, frame_idx, fg, bg)
+            loss, det = tr._step_body(*args, apply=False)
+            d = tr.explicit.last_draws
+            R = frames * H * H
+            replay = [d["t_rand"].view(R, 64), d["noise_c"].view(R, 64), d["u_fine"].view(R, 32), d["noise_f"].view(R, 96), d["n0"], d["n1"]]
+        else:
+            with InjectedDraws(replay=replay) as inj:
+                loss, det = tr._step_body(*args, apply=False)
+            assert len(inj.drawn) == 6
+        grads = {("net", k): p.grad.clone() for k, p in m.named_parameters() if p.grad is not None and not k.startswith("body_model.")}
+        grads.update({("table", k): p.grad.clone() for k, p in table.named_parameters()})
+        out.append((loss.item(), {k: v.item() for k, v in det.items()}, grads))
+    (la, da, ga), (lb, db, gb) = out
+    tol = 2e-6 if mode == "f32" else 2e-5
+    assert abs(la - lb) <= tol * abs(lb), (la, lb)
+    assert set(da) == set(db) and "psnr" in da and len(da) == 11
+    for k in db:
+        assert abs(da[k] - db[k]) <= tol * abs(db[k]) + 1e-7, (k, da[k], db[k])
+    assert set(ga) == set(gb) and len(ga) == 2 * 24 + 4
+    for k in gb:
+        err = (ga[k] - gb[k]).norm() / gb[k].norm().clamp_min(1e-20)
+        assert gb[k].abs().max() > 0 and err < (2e-5 if mode == "f32" else 2e-3), (k, err.item())
+    # the table gradients: only the rows of the batch's frames, the twice-used row summed
+    g_pose = ga[("table", "body_pose.weight")]
+    used = torch.zeros(40, dtype=torch.bool)
+    used[frame_idx.cpu()] = True
+    assert (g_pose[~used].abs().max() == 0) and (g_pose[used].abs().sum(-1) > 0).all()
