@@ -242,9 +242,57 @@ __global__ void grid_points_kernel(int N, double x0, double x1, double y0, doubl
     pts[t] = make_float4(x + center[0], y + center[1], z + center[2], 1.0f);
 }
 
+// The same points for a LIST of 8 x 8 x 8-voxel cells (N % 8 == 0): cell id c = (cj * (N/8) + ci) * (N/8) + ck covers array
+// indices j in [8 cj, 8 cj + 8) and likewise i, k.  One workgroup per listed cell; pts[l * 512 + t] and the voxel's flat grid
+// index vox[l * 512 + t].  (Mesh extraction evaluates the field only where a cell can hold a valid voxel: sigma_grid.)
+__global__ __launch_bounds__(512) void grid_points_cells_kernel(int N, double x0, double x1, double y0, double y1, double z0, double z1,
+                                                                const float* __restrict__ center, const int32_t* __restrict__ cells,
+                                                                float4* __restrict__ pts, int32_t* __restrict__ vox) {
+    const int C = N / 8, c = cells[blockIdx.x], t = threadIdx.x;
+    const int ck = c % C, ci = (c / C) % C, cj = c / (C * C);
+    const int k = 8 * ck + (t & 7), i = 8 * ci + ((t >> 3) & 7), j = 8 * cj + (t >> 6);
+    auto lin = [N](double a, double b, int m) {
+        if (m == N - 1) return b;
+        double step = (b - a) / (double)(N - 1);
+        return __dadd_rn(__dmul_rn((double)m, step), a);
+    };
+    const float x = (float)lin(x0, x1, i), y = (float)lin(y0, y1, j), z = (float)lin(z0, z1, k);
+    const int64_t o = (int64_t)blockIdx.x * 512 + t;
+    pts[o] = make_float4(x + center[0], y + center[1], z + center[2], 1.0f);
+    vox[o] = (int32_t)(((int64_t)j * N + i) * N + k);
+}
+
+// out[vox[t] - first] = max(values[t], 0) for the voxels of [first, first + count) (a rank's slab)
+__global__ __launch_bounds__(256) void scatter_relu_kernel(const float* __restrict__ values, const int32_t* __restrict__ vox, int64_t n,
+                                                           int64_t first, int64_t count, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int64_t v = (int64_t)vox[t] - first;
+    if (v >= 0 && v < count) out[v] = fmaxf(values[t], 0.0f);
+}
+
 }  // namespace anr
 
 using namespace anr;
+
+extern "C" int anr_grid_points_cells(int N, double x0, double x1, double y0, double y1, double z0, double z1, const float* center,
+                                     const int32_t* cells, int64_t n_cells, float* pts_out, int32_t* vox_out, void* stream) {
+    ANR_REQUIRE(center && cells && pts_out && vox_out, ANR_E_BADARG, "anr_grid_points_cells: null pointer");
+    ANR_REQUIRE(N >= 8 && N % 8 == 0 && N <= 1288 && n_cells > 0 && n_cells <= (int64_t)(N / 8) * (N / 8) * (N / 8), ANR_E_BADARG,
+                "anr_grid_points_cells: N=%d (a multiple of 8, <= 1288) cells=%lld", N, (long long)n_cells);
+    ANR_REQUIRE(((uintptr_t)pts_out & 15) == 0, ANR_E_ALIGN, "anr_grid_points_cells: pts_out must be 16-B aligned");
+    hipLaunchKernelGGL(grid_points_cells_kernel, dim3((unsigned)n_cells), dim3(512), 0, (hipStream_t)stream, N, x0, x1, y0, y1, z0, z1,
+                       center, cells, reinterpret_cast<float4*>(pts_out), vox_out);
+    return check_launch("anr_grid_points_cells");
+}
+
+extern "C" int anr_scatter_relu(const float* values, const int32_t* vox, int64_t n, int64_t first, int64_t count, float* out, void* stream) {
+    ANR_REQUIRE(values && vox && out, ANR_E_BADARG, "anr_scatter_relu: null pointer");
+    ANR_REQUIRE(n > 0 && first >= 0 && count > 0, ANR_E_BADARG, "anr_scatter_relu: n=%lld first=%lld count=%lld", (long long)n, (long long)first,
+                (long long)count);
+    hipLaunchKernelGGL(scatter_relu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, values, vox, n, first, count, out);
+    return check_launch("anr_scatter_relu");
+}
 
 extern "C" int anr_grid_points(int N, double x0, double x1, double y0, double y1, double z0, double z1,
                                const float* center, int64_t first, int64_t count, float* pts_out, void* stream) {

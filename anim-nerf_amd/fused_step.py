@@ -36,8 +36,14 @@ from . import _lib, ops
 from .autograd import PARAM_KEYS, _cached_pack, weights_generation
 
 
+_TORCH_DRAWS = (torch.rand, torch.randn, torch.randn_like)
+
+
 class ExplicitTrainStep:
-    """Bound to a Trainer; `supported(...)` says whether a call can take this path (otherwise the autograd step runs)."""
+    """Bound to a Trainer; `supported(...)` says whether a call can take this path (otherwise the autograd step runs).
+    The step's random numbers come from the library's own counter-based generator (anr_train_draws), not from torch's: a
+    caller that substitutes torch.rand / randn / randn_like to control the draws (the tests' InjectedDraws) gets the autograd
+    step, which draws through them."""
 
     def __init__(self, trainer):
         self.tr = trainer
@@ -52,6 +58,8 @@ class ExplicitTrainStep:
     def supported(self, rays, body_model_params, frame_idx, fg_points, bg_points) -> bool:
         tr, m, vr, hp = self.tr, self.tr.model, self.tr.renderer, self.tr.hp
         if not (rays.is_cuda and torch.is_grad_enabled() and hp.fused_losses and hp.use_unpose):
+            return False
+        if (torch.rand, torch.randn, torch.randn_like) != _TORCH_DRAWS:
             return False
         if not (getattr(m, "use_unpose", False) and m.k_neigh == 4 and not m.use_view and hasattr(m, "nerf_fine") and m.nerf_fine is not m.nerf
                 and m.evaluate_valid_only and m.skip_far_samples and m.nerf._hip_supported() and m.nerf_fine._hip_supported()):

@@ -1121,3 +1121,25 @@ def warp_backward_acc(d_pts, rays, z, o2c, nbr_idx, nbr_w, d_o2c_acc, d_rays_acc
                                          o2c.shape[1], R * K, _ptr(d_o2c_acc), _ptr(d_rays_acc), _ptr(d_z), _stream(z)),
                    "anr_warp_backward")
     return d_z
+
+
+def grid_points_cells(N: int, x_range, y_range, z_range, center: torch.Tensor, cells: torch.Tensor):
+    """The grid points of the listed 8^3-voxel cells (int32 cell ids): -> pts[L*512,4], vox[L*512] int32 (flat grid indices)."""
+    lib = _lib.load()
+    center, cells = _dev(center.reshape(-1), "center"), _dev(cells, "cells", torch.int32)
+    L = cells.numel()
+    pts = torch.empty(L * 512, 4, dtype=torch.float32, device=center.device)
+    vox = torch.empty(L * 512, dtype=torch.int32, device=center.device)
+    _lib.check(lib.anr_grid_points_cells(N, float(x_range[0]), float(x_range[1]), float(y_range[0]), float(y_range[1]), float(z_range[0]),
+                                         float(z_range[1]), _ptr(center), _ptr(cells), L, _ptr(pts), _ptr(vox), _stream(pts)),
+               "anr_grid_points_cells")
+    return pts, vox
+
+
+def scatter_relu(values: torch.Tensor, vox: torch.Tensor, out: torch.Tensor, first: int) -> None:
+    """out[vox[t] - first] = relu(values[t]) for the voxels that fall inside out."""
+    lib = _lib.load()
+    values, vox, out = _dev(values, "values"), _dev(vox, "vox", torch.int32), _dev(out, "out")
+    with _timed("scatter_relu", values.numel(), values.numel() * 12):
+        _lib.check(lib.anr_scatter_relu(_ptr(values), _ptr(vox), values.numel(), int(first), out.numel(), _ptr(out), _stream(out)),
+                   "anr_scatter_relu")

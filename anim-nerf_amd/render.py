@@ -62,16 +62,47 @@ def system_forward(volume_renderer, anim_nerf, rays, body_model_params, body_mod
 
 @torch.no_grad()
 def sigma_grid(anim_nerf, N_grid=256, x_range=(-1.2, 1.2), y_range=(-1.2, 1.2), z_range=(-1.2, 1.2),
-               chunk=1 << 22, rank=0, world=1):
+               chunk=1 << 22, rank=0, world=1, cells: Optional[bool] = None):
     """extract_mesh.py:152-158 on the fast path: relu(sigma) of the fine (if any) field on this rank's contiguous
     slab of the N^3 grid around the posed body's bounding-box centre.  Grid points are generated on the device,
     provably-empty voxels skip the neighbour search, the MLP stops at the sigma row.  Returns (sigma[count], first).
-    Per-frame state (set_body_model / convert_to_body_model_space / clac_ober2cano_transform) must be set."""
+    Per-frame state (set_body_model / convert_to_body_model_space / clac_ober2cano_transform) must be set.
+
+    cells (default: whenever N % 8 == 0 and the warp is on): empty space is skipped by 8^3-voxel CELLS before a single voxel is
+    generated.  A voxel is valid only if its blended neighbour distance — never below its distance d1 to the nearest vertex —
+    is under dis_threshold (models/anim_nerf.py:183), so a cell whose centre is at least dis_threshold + r from every vertex
+    (r = the cell's half diagonal, ONE exact search per cell centre) holds only sigma = -1e5 -> relu = 0: its 512 voxels are
+    never generated, warped or compacted.  The other cells' voxels go through the same kernels as before: same bits."""
     from . import ops
     total = N_grid ** 3
     lo, hi = shard_range(total, rank, world)
     center = (anim_nerf.verts.max(dim=1)[0] + anim_nerf.verts.min(dim=1)[0]) / 2.     # [1,3]
     net = anim_nerf._net(anim_nerf.use_fine)
+    if cells is None:
+        cells = bool(anim_nerf.use_unpose and anim_nerf.k_neigh == 4 and N_grid % 8 == 0 and N_grid <= 1288 and anim_nerf.evaluate_valid_only)
+    if cells:
+        dev = center.device
+        C = N_grid // 8
+        axis = lambda r: r[0] + (r[1] - r[0]) * (8.0 * torch.arange(C, device=dev, dtype=torch.float64) + 3.5) / (N_grid - 1)
+        cx, cy, cz = axis(x_range), axis(y_range), axis(z_range)
+        # cell (cj, ci, ck) -> centre (x[ci], y[cj], z[ck]) (np.meshgrid 'xy': array axis 0 runs over y)
+        cen = torch.stack(torch.broadcast_tensors(cx[None, :, None], cy[:, None, None], cz[None, None, :]), -1).reshape(1, -1, 3)
+        cen = cen.float() + center
+        step = torch.tensor([(r[1] - r[0]) / (N_grid - 1) for r in (x_range, y_range, z_range)], dtype=torch.float64)
+        radius = float((3.5 * step).norm()) + 1e-4                  # half diagonal of the cell's voxel positions (+ rounding)
+        d1 = ops.knn(anim_nerf.verts[:1], cen, index=anim_nerf.knn_index()[:1])[0][0, :, 0]
+        live = d1 < anim_nerf.dis_threshold + radius
+        if world > 1:                                                # this rank's slab: cells whose j range meets [lo, hi)
+            cj = torch.arange(C ** 3, device=dev) // (C * C)
+            live &= (cj >= lo // (8 * N_grid * N_grid)) & (cj <= (hi - 1) // (8 * N_grid * N_grid))
+        ids = torch.nonzero(live)[:, 0].to(torch.int32)
+        out = ops.zero_fill(torch.empty(hi - lo, dtype=torch.float32, device=dev))
+        per = max(1, chunk // 512)
+        for s in range(0, ids.numel(), per):
+            pts, vox = ops.grid_points_cells(N_grid, x_range, y_range, z_range, center[0], ids[s:s + per])
+            pts = anim_nerf.warped_points(xyz=pts.view(1, -1, 4), skip_far=True)
+            ops.scatter_relu(net.eval_points(pts, sigma_only=True, only_valid=True), vox, out, lo)
+        return out, lo
     out = torch.empty(hi - lo, dtype=torch.float32, device=center.device)
     for s in range(lo, hi, chunk):
         n = min(chunk, hi - s)

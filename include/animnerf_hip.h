@@ -491,6 +491,13 @@ int anr_train_loss_backward(const anr_loss_args* args, const float* g_total, con
  * A rank of a voxel-sharded job asks for its own [first, first+count) slab. */
 int anr_grid_points(int N, double x0, double x1, double y0, double y1, double z0, double z1,
                     const float* center, int64_t first, int64_t count, float* pts_out, void* stream);
+/* The same points for a list of 8 x 8 x 8-voxel CELLS (N % 8 == 0; cell id = (cj (N/8) + ci) (N/8) + ck covers array
+ * indices j in [8 cj, 8 cj + 8) and likewise i, k): pts_out[n_cells*512][4] and the voxels' flat grid indices
+ * vox_out[n_cells*512] — for evaluating the field only in cells that can hold a valid voxel; anr_scatter_relu then writes
+ * out[vox[t] - first] = max(values[t], 0) for the voxels inside [first, first + count) (extract_mesh.py:49-61: relu(sigma)). */
+int anr_grid_points_cells(int N, double x0, double x1, double y0, double y1, double z0, double z1, const float* center,
+                          const int32_t* cells, int64_t n_cells, float* pts_out, int32_t* vox_out, void* stream);
+int anr_scatter_relu(const float* values, const int32_t* vox, int64_t n, int64_t first, int64_t count, float* out, void* stream);
 
 /* ---- a13: alpha compositing ----------------------------------------------------------------------
  * models/volume_rendering.py:131-160 (far=True, delta_last = 1e10).

@@ -51,7 +51,8 @@ def main():
     ref = {k: v / world for k, v in ref.items()}
 
     m = seeded_model(tbl, g["seed"], True, g["gain"], g["shift"], device=dev)
-    tr = ana.Trainer(m, vr, hp)
+    # (the autograd step: it draws the normal term's points through torch's generator, as the single-process reference above)
+    tr = ana.Trainer(m, vr, hp, explicit_step=False)
     assert tr.reducer.active and m.nerf.grad_sink is not None and m.nerf_fine.grad_sink is not None
     pose, rays, tgt, alp, fg, bg = batch(rank, dev)
     torch.manual_seed(500 + rank)
@@ -77,6 +78,7 @@ def main():
         lg, _ = tg.step_graphed(rays, tgt, alp, pose, templ, fg, bg, perturb=0.0)
         assert abs(float(le) - float(lg)) <= 2e-3 * abs(float(le)), (rank, it, float(le), float(lg))
     assert tg._graph is not None and tg._graph_split and te._graph is None
+    assert te.explicit is not None and tg.explicit is not None     # (both ran the explicit step: fused_step.py)
     for (k, a), (_, b) in zip(me.named_parameters(), mg.named_parameters()):
         if a.requires_grad:
             d = (a - b).abs()
