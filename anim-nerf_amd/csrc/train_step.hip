@@ -18,6 +18,9 @@
 //   anr_zero_fill                 the library's memset (anr_common.h: zero_fill)
 #include "anr_common.h"
 
+// (products and sums round separately in this file, as the framework ops they replace round them: `points + randn * scale`)
+#pragma clang fp contract(off)
+
 namespace anr {
 
 // ---- Philox4x32-10 (Salmon et al., SC'11): counter-based, stateless
@@ -76,11 +79,12 @@ __global__ __launch_bounds__(256) void train_draws_kernel(uint64_t* __restrict__
             const float d0[4] = {a0.x, a0.y, b0.x, b0.y}, d1[4] = {a1.x, a1.y, b1.x, b1.y};
             for (int i = 0; i < 4; ++i)
                 if (e + i < p.n_v3) {
-                    const float pt = p.verts_template[e + i] + d0[i] * p.point_scale;
+                    // (product and sum rounded separately, as the framework's `points + randn * scale` rounds them)
+                    const float pt = __fadd_rn(p.verts_template[e + i], __fmul_rn(d0[i], p.point_scale));
                     p.n0[e + i] = d0[i];
                     p.n1[e + i] = d1[i];
                     p.pair[e + i] = pt;
-                    p.pair[p.n_v3 + e + i] = pt + d1[i] * p.neighbour_scale;
+                    p.pair[p.n_v3 + e + i] = __fadd_rn(pt, __fmul_rn(d1[i], p.neighbour_scale));
                 }
         }
     }

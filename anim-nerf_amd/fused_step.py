@@ -53,6 +53,7 @@ class ExplicitTrainStep:
         # before the Trainer is built fixes the run
         self.draw_state = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64, device=self.dev)
         self.last_draws = None         # the random tensors of the last step (t_rand, noise_c, u_fine, noise_f, n0, n1): for tests
+        self.last_quads = None         # ... and its tangent quads (coarse, fine)
 
     # ------------------------------------------------------------------------------------------------------------------
     def supported(self, rays, body_model_params, frame_idx, fg_points, bg_points) -> bool:
@@ -209,6 +210,7 @@ class ExplicitTrainStep:
                 out_t, act_t = ops.mlp_forward_save(_cached_pack(params, mode_id, False), mode_id, pts4, sigma_only=True, tangent=True)
                 tan.append((net, params, act_t, out_t.view(n_pad, 4)))
 
+        self.last_quads = [x[3] for x in tan]
         # ---- losses (train.py:228-322) and their gradients: two launches
         consts = {"R": bs * R, "k": -2.0 / hp.n_samples, "lambda_alphas": hp.lambda_alphas, "lambda_foreground": hp.lambda_foreground,
                   "lambda_background": hp.lambda_background, "lambda_normals": hp.lambda_normals}

@@ -1019,6 +1019,8 @@ def train_draws(state: torch.Tensor, *, n_t=0, t_scale=1.0, n_nc=0, n_u=0, n_nf=
         p.verts_template, p.n_v3 = vt.data_ptr(), vt.numel()
         p.point_scale, p.neighbour_scale = float(point_scale), float(neighbour_scale)
         p.n0, p.n1, p.pair = o["n0"].data_ptr(), o["n1"].data_ptr(), o["pair"].data_ptr()
+    if n_t + n_nc + n_u + n_nf + int(p.n_v3) == 0:               # perturb = 0 and no normals term: nothing random in the step
+        return o
     _lib.check(lib.anr_train_draws(_ptr(state), C.byref(p), _stream(state)), "anr_train_draws")
     return o
 

@@ -456,7 +456,8 @@ class Trainer:
         self.model, self.renderer, self.hp = anim_nerf, volume_renderer, hp
         self.body_model_params = body_model_params
         self.graph_enabled = bool(graph)
-        self._graph = None                                    # (signature, CUDAGraph, static inputs, static outputs)
+        self._graph = None                                    # (signature, CUDAGraph, static inputs, static outputs, pins)
+        self._leaf_seen = []
         self._graph_warm = 0
         self._graph_split = False                             # the graph ends with backward (more than one rank)
         for name, p in anim_nerf.named_parameters():          # SMPL member params are unused by the forward
@@ -605,10 +606,21 @@ class Trainer:
         if eager:
             return self.step(args["rays"], args["rgbs"], args["alphas"], args["bmp"], args["templ"], args["fg"], args["bg"],
                              perturb=perturb, frame_idx=args["frame_idx"])
+        # inputs -> the graph's own buffers; a tensor that is the very object (and version) copied last time is not copied again
+        # (the template pose of a run, a data loader that reuses its batch buffers)
+        templ_changed = False
+        for i, ((name, src), dst) in enumerate(zip(leaves, self._graph[2])):
+            seen = self._leaf_seen[i]
+            if dst.data_ptr() == src.data_ptr() or (seen is not None and seen[0] is src and seen[1] == src._version):
+                continue
+            dst.copy_(src, non_blocking=True)
+            self._leaf_seen[i] = (src, src._version)
+            templ_changed |= name.startswith("templ")
+        if templ_changed:
+            # the template pose's body state is computed OUTSIDE the graph (once per run, models/anim_nerf.py:108-126): new
+            # template values mean a new state, and the graph holds the old one's addresses
+            self._capture(sig, args, leaves, perturb)
         _, graph, static_leaves, outs, _pins = self._graph
-        for (_, src), dst in zip(leaves, static_leaves):
-            if dst.data_ptr() != src.data_ptr():
-                dst.copy_(src, non_blocking=True)
         graph.replay()
         if self._graph_split:                                  # more than one rank: the graph ends with backward
             self.reducer.reduce_flat()
@@ -616,7 +628,18 @@ class Trainer:
         from .autograd import bump_generation
         bump_generation(self.params)                          # the packs cached under the old generation belong to the graph
         loss, details = outs
-        return loss.clone(), {k: (v.clone() if torch.is_tensor(v) else v) for k, v in details.items()}
+        # fresh tensors for the caller: outputs that are views of one buffer (the loss kernel's 12 values) share ONE copy
+        copies = {}
+
+        def fresh(v):
+            if not torch.is_tensor(v):
+                return v
+            base = v._base if v._base is not None else v
+            c = copies.get(id(base))
+            if c is None:
+                c = copies[id(base)] = base.clone()
+            return c if v._base is None else torch.as_strided(c, v.size(), v.stride(), v.storage_offset() - base.storage_offset())
+        return fresh(loss), {k: fresh(v) for k, v in details.items()}
 
     def _capture(self, sig, args, leaves, perturb):
         def rebuild(v, it):
@@ -624,8 +647,13 @@ class Trainer:
                 return {k: rebuild(v[k], it) for k in sorted(v)}
             return next(it) if torch.is_tensor(v) else v
         static_leaves = [t.clone() for _, t in leaves]
+        self._leaf_seen = [(t, t._version) for _, t in leaves]
         it = iter(static_leaves)
         st = {k: rebuild(args[k], it) for k in sorted(args)}
+        if st["templ"] is not None and hasattr(self.model, "_same_template"):
+            with torch.no_grad():                              # the template's body state: outside the graph (see the replay)
+                if not self.model._same_template(st["templ"]):
+                    self.model._set_template(st["templ"])
         torch.cuda.synchronize()
         self._graph = None                                    # (a previous capture's pool goes back to the allocator first)
         # More than one rank: the graph holds forward + backward into the flat buffers; the all-reduce of those buffers and
@@ -645,7 +673,11 @@ class Trainer:
         # (rebuilt when a .grad pointer moves).  The graph pins what it saw; a replacement allocates next to it.
         from . import ops
         pins = [list(ops._WGRAD_WS.values()), list(ops._LOSS_WS.values()), getattr(self.optimizer, "_table", None),
-                [p.grad for p in self.params]]
+                [p.grad for p in self.params],
+                # the template pose's body state, computed outside the graph (an eager call with another template replaces
+                # the model's attributes, not these tensors)
+                [getattr(self.model, n, None) for n in ("verts_template", "joints_template", "verts_transform_template",
+                                                        "joints_transform_template", "shape_offsets_template", "pose_offsets_template")]]
         self._graph = (sig, graph, static_leaves, (loss, details), pins)
 
     def step(self, rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points=None, bg_points=None,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The warp on a training-shaped batch (BASELINE configs[3]: 16 bodies x 1,024 random pixels x 64 samples): time per call of
 the small-batch path, eight lanes per sample (warp_search_groups_kernel) against a lane per sample (ANR_WARP_LANE_PER_SAMPLE=1).
-    python tools/bench_warp_small.py [reps] [groups|lanes|both]"""
+    python tools/bench_warp_small.py [reps] [groups|lanes|both] [bodies]"""
 import os
 import sys
 
@@ -14,7 +14,7 @@ from anim_nerf_amd import synthetic as syn                   # noqa: E402
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 which = sys.argv[2] if len(sys.argv) > 2 else "both"
 dev = torch.device("cuda:0")
-bs, n_rays, K, hw = 16, 1024, 64, 32
+bs, n_rays, K, hw = (int(sys.argv[3]) if len(sys.argv) > 3 else 16), 1024, 64, 32
 tbl = syn.make_smpl_table(0)
 torch.manual_seed(3)
 m = ana.AnimNeRF(body_model_table=tbl, freqs_dir=0, use_view=False, use_unpose=True, use_fine=True).eval().to(dev)
