@@ -79,12 +79,19 @@ __global__ __launch_bounds__(256) void train_draws_kernel(uint64_t* __restrict__
             const float d0[4] = {a0.x, a0.y, b0.x, b0.y}, d1[4] = {a1.x, a1.y, b1.x, b1.y};
             for (int i = 0; i < 4; ++i)
                 if (e + i < p.n_v3) {
-                    // (product and sum rounded separately, as the framework's `points + randn * scale` rounds them)
-                    const float pt = __fadd_rn(p.verts_template[e + i], __fmul_rn(d0[i], p.point_scale));
-                    p.n0[e + i] = d0[i];
-                    p.n1[e + i] = d1[i];
+                    // Every rounding step pinned to ONE materialised value: the normals that are stored are the normals that are
+                    // used, and product and sum round separately, as the framework's `points + randn * scale` rounds them — so that
+                    // a caller who recomputes the points from n0 / n1 gets these bits.
+                    float a = d0[i], b = d1[i];
+                    asm volatile("" : "+v"(a), "+v"(b));
+                    float pa = a * p.point_scale, pb = b * p.neighbour_scale;
+                    asm volatile("" : "+v"(pa), "+v"(pb));
+                    float pt = p.verts_template[e + i] + pa;
+                    asm volatile("" : "+v"(pt));
+                    p.n0[e + i] = a;
+                    p.n1[e + i] = b;
                     p.pair[e + i] = pt;
-                    p.pair[p.n_v3 + e + i] = __fadd_rn(pt, __fmul_rn(d1[i], p.neighbour_scale));
+                    p.pair[p.n_v3 + e + i] = pt + pb;
                 }
         }
     }

@@ -1063,39 +1063,53 @@ constexpr int GSEG = ANR_GSEG;                 // cursors per body (<= WarpWs::C
 constexpr int GQ_ENTRIES = 64;                 // blend queue per wavefront: {sample, slots 0|1, slots 2|3}
 constexpr int GQ_BYTES = GQ_ENTRIES * 12;
 
+#ifdef ANR_SEARCH_PROF
+// experiment builds only (tools/exp/search_prof.py): per wavefront {clocks total, in trips to the cursors, in index staging, trips,
+// traversal steps, samples started, unbounded repeats, flushes}
+__device__ long long anr_search_prof[8192 * 8];
+__device__ long long anr_search_events[64 * 256];          // wavefronts 0..63 of the launch: up to 128 {tag, time} pairs each
+#define PROF_T0(v) const long long v = wall_clock64()
+#define PROF_ADD(slot, v) prof[slot] += (v)
+#define PROF_EV(tag) do { if (ev_w >= 0 && ev_n < 127 && lane == 0) { anr_search_events[ev_w * 256 + 2 * ev_n] = (tag); \
+    anr_search_events[ev_w * 256 + 2 * ev_n + 1] = wall_clock64(); } ++ev_n; } while (0)
+#else
+#define PROF_T0(v)
+#define PROF_ADD(slot, v)
+#define PROF_EV(tag)
+#endif
 __global__ __launch_bounds__(WARP_THREADS) void warp_search_groups_kernel(
     const float* __restrict__ index, IndexDims d, const float* __restrict__ ober2cano, const float* __restrict__ lbs_w,
     int J, int64_t N, float thr, float4* __restrict__ pts_out, int32_t* __restrict__ nbr_idx, float* __restrict__ nbr_w,
-    const int32_t* __restrict__ list, const int32_t* __restrict__ count, int32_t* __restrict__ cursor,
-    uint8_t* __restrict__ valid_mask) {
+    const int32_t* __restrict__ list, const int32_t* __restrict__ count, uint8_t* __restrict__ valid_mask) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ int body_open;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 7, gbase = lane & 56;
-    // A workgroup starts on its own body and, when that list is exhausted, moves on to the other bodies' (their index
-    // re-staged: 114 KB, a few microseconds): the bodies of a batch do not have the same number of near samples, and a
-    // static share of the chip per body waits for the busiest one.
-    for (int hop = 0; hop < (int)gridDim.y; ++hop) {
-    const int b = ((int)blockIdx.y + hop) % (int)gridDim.y;
+#ifdef ANR_SEARCH_PROF
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long prof_begin = wall_clock64(), prof_cyc0 = clock64();
+    int ev_n = 0;
+    const int ev_gw = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * (WARP_THREADS / 64) + wave;
+    const int ev_w = ev_gw < 64 ? ev_gw : -1;
+    PROF_EV(1);
+#endif
+    // The body's list is dealt out STATICALLY and entry by entry: wavefront w of the body's W wavefronts takes the entries w,
+    // w + W, w + 2 W, ... — neighbouring entries (one stretch of a ray: all deep inside the body, or all in the empty space around
+    // it) go to different wavefronts, which balances the deep searches against the trivial ones without a single atomic (dealt
+    // out in blocks of 8 consecutive entries the slowest wavefront took 5 x the median).  (Round 3 handed blocks out through 8 cursors per body and let a finished workgroup help the other bodies: at 16
+    // wavefronts per workgroup that is ~45,000 atomic adds on 16 to 128 addresses per call — most of them the probes that find a
+    // segment exhausted — and a same-address atomic retires in ~0.1 us: the kernel took 0.33 ms whether the batch held 2 bodies
+    // or 16, i.e. however little there was to search.  Per-wavefront event log: tools/exp/search_prof.py.)
+    const int b = (int)blockIdx.y, hop = 0;
+    (void)hop;
     const int cnt = count[b];
-    if (hop == 0) {
-        if ((int)blockIdx.x * (WARP_THREADS / 64) * 8 >= cnt) continue;  // not even one sample per group left
-    } else {
-        __syncthreads();                                                 // every wavefront is done with the index in LDS
-        if (threadIdx.x == 0) {
-            const int sl = ((cnt + GSEG - 1) / GSEG + GPOOL - 1) / GPOOL * GPOOL;
-            bool open = false;
-            for (int q = 0; q < GSEG; ++q)
-                open |= q * sl + __hip_atomic_load(cursor + q * (int)gridDim.y + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < min(cnt, (q + 1) * sl);
-            body_open = open;
-        }
-        __syncthreads();
-        if (!body_open) continue;
-    }
+    const int n_waves = (int)gridDim.x * (WARP_THREADS / 64), my_wave = (int)blockIdx.x * (WARP_THREADS / 64) + wave;
+    if ((int)blockIdx.x * (WARP_THREADS / 64) >= cnt) return;            // not even one entry for this workgroup
     const float* my_index = index + (int64_t)b * d.total_floats();
     const int32_t* order = reinterpret_cast<const int32_t*>(my_index + d.order_off());
     const float* O2C = ober2cano + (int64_t)b * d.V * 16;
     const int32_t* my_list = list + (int64_t)b * N;
+    PROF_EV(20 + hop);
     stage_index(my_index, d.lds_floats(), lds);
+    PROF_EV(2);
     const float* boxes = lds + d.box_off();
     const float* sboxes = lds + d.sbox_off();
     const float* tboxes = lds + d.tbox_off();
@@ -1106,6 +1120,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_groups_kernel(
     // blend the queued samples, one per lane
     int q_n = 0;
     auto flush = [&]() {
+
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane < q_n) {
@@ -1126,8 +1141,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_groups_kernel(
     };
 
     // the pool: GPOOL list entries and their points, one per lane
-    const int seg_len = ((cnt + GSEG - 1) / GSEG + GPOOL - 1) / GPOOL * GPOOL;
-    int seg = ((int)blockIdx.x * (WARP_THREADS / 64) + wave) % GSEG, seg_tried = 0;
+    int trip = 0;
     int pool_smp = 0, pool_n = 0, pool_next = 0;
     float pool_x = 0.f, pool_y = 0.f, pool_z = 0.f;
     bool list_done = false;
@@ -1154,26 +1168,28 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_groups_kernel(
         // ---- hand samples to the idle groups (wave-uniform control flow: every lane takes part in the permutes)
         unsigned long long idle_groups = __ballot(idle && j == 0);
         while (idle_groups) {
+            PROF_ADD(3, 1);
             if (pool_next >= pool_n) {
                 if (list_done) break;
-                // a body's list is cut into GSEG segments with a cursor each (256 wavefronts on ONE cursor wait ~20 us per trip)
-                int base = 0, seg_end = 0;
-                for (;;) {
-                    if (lane == 0) base = atomicAdd(cursor + seg * (int)gridDim.y + b, GPOOL);
-                    base = seg * seg_len + __builtin_amdgcn_readfirstlane(base);
-                    seg_end = min(cnt, (seg + 1) * seg_len);
-                    if (base < seg_end) break;
-                    seg = (seg + 1) % GSEG;
-                    if (++seg_tried == GSEG) break;
-                }
-                if (base >= seg_end) { list_done = true; break; }
-                pool_n = min(GPOOL, seg_end - base);
+                PROF_T0(t_trip);
+                PROF_EV(3);
+                // entries my_wave + k n_waves, k = 64 trip + lane: consecutive list entries (a stretch of one ray: similar cost) go
+                // to different wavefronts
+                const int first = my_wave + trip * 64 * n_waves;
+                if (first >= cnt) { list_done = true; break; }
+                ++trip;
+                pool_n = min(64, (cnt - first + n_waves - 1) / n_waves);
                 pool_next = 0;
                 if (lane < pool_n) {
-                    pool_smp = my_list[base + lane];
+                    pool_smp = my_list[first + lane * n_waves];
                     const float4 p = pts_out[(int64_t)b * N + pool_smp];
                     pool_x = p.x; pool_y = p.y; pool_z = p.z;
                 }
+#ifdef ANR_SEARCH_PROF
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                prof[1] += wall_clock64() - t_trip;
+                PROF_EV(4);
+#endif
             }
             const int rank = __popcll(idle_groups & ((1ull << gbase) - 1ull));
             const int src = pool_next + rank;
@@ -1187,12 +1203,15 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_groups_kernel(
             if (take) {
                 smp = t_smp; px = t_x; py = t_y; pz = t_z;
                 idle = false; second = false;
+
                 best_init(best, cap2);
                 open_tops();
             }
             idle_groups = __ballot(idle && j == 0);
         }
+        PROF_ADD(6, 1);
         if (!__any(!idle)) break;
+        PROF_EV(5);
 
         // ---- one step of every group's traversal
         bool done = idle;
@@ -1253,6 +1272,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_groups_kernel(
             const bool partial = fin && !second && best.i[0] >= 0 && best.i[3] < 0;
             if (partial) {
                 second = true;
+
                 best_init(best);
                 open_tops();
             }
@@ -1269,9 +1289,31 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_groups_kernel(
             if (fin && !partial) idle = true;
         }
     }
+    PROF_EV(6);
     flush();
+    PROF_EV(7);
+#ifdef ANR_SEARCH_PROF
+    prof[0] = wall_clock64() - prof_begin;
+    prof[7] = clock64() - prof_cyc0;                          // shader cycles over the same interval: the clock the kernel ran at
+    {   // per-lane counters (samples, repeats) summed over the wavefront; the rest is wave-uniform
+        long long s5 = prof[5], s6 = prof[6];
+        const int w = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * (WARP_THREADS / 64) + wave;
+        if (lane == 0 && w < 8192) {
+            long long* o = anr_search_prof + (long long)w * 8;
+            o[0] = prof[0]; o[1] = prof[1]; o[2] = prof[2]; o[3] = prof[3]; o[4] = prof[4]; o[5] = s5; o[6] = s6; o[7] = prof[7];
+        }
     }
+#endif
 }
+
+#ifdef ANR_SEARCH_PROF
+extern "C" int anr_search_prof_read(long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(anr_search_prof), sizeof(long long) * 8192 * 8);
+}
+extern "C" int anr_search_events_read(long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(anr_search_events), sizeof(long long) * 64 * 256);
+}
+#endif
 
 // lean mode: validity bytes -> list of the valid samples' flat positions for anr_mlp_forward_indexed, in sample order
 // (the MLP's gather of points and scatter of results then walk memory the way the rays were laid out); 4 bytes per thread
@@ -1600,7 +1642,7 @@ extern "C" int anr_warp_points_reuse(const float* xyz, int xyz_stride, const flo
                 if (int rc = allow_big_lds(warp_search_groups_kernel, group_bytes, "anr_warp_points")) return rc;
                 hipLaunchKernelGGL(warp_search_groups_kernel, dim3((unsigned)gx, bs), dim3(WARP_THREADS), group_bytes, st, index, d,
                                    ober2cano, lbs_weights, J, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out,
-                                   nbr_w_out, w.list, w.count, w.cursor, valid_mask_out);
+                                   nbr_w_out, w.list, w.count, valid_mask_out);
             } else {
                 if (int rc = allow_big_lds(warp_search_kernel, bytes, "anr_warp_points")) return rc;
                 hipLaunchKernelGGL(warp_search_kernel, dim3((unsigned)gx, bs), dim3(WARP_THREADS), bytes, st, index, d, ober2cano,

@@ -28,6 +28,8 @@ with torch.no_grad():
     rays = m.convert_to_body_model_space(full[pick].contiguous())
     m.clac_ober2cano_transform()
     z = ana.VolumeRenderer(n_coarse=K).sample_coarse(rays)
+    if os.environ.get("WARP_BENCH_FAR"):                      # every sample far from the body: the call's fixed cost
+        z = z + 100.0
     args = (m.knn_index(), m.ober2cano_transform, m.body_model.lbs_weights, 0.2)
     for name in (("groups", "lanes") if which == "both" else (which,)):
         if name == "lanes":
