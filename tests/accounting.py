@@ -184,7 +184,9 @@ def account_for_rays(model, vr, smpl_tbl_oracle, rays_w, pose, templ, ref, *, st
     if not warp:
         assert not residual.any(), "rays that differ from the oracle even with identical sampling decisions: a real bug"
         if z_fine_ref is not None:
-            assert zflip.all(), "out-of-tolerance rays without a discontinuity to blame"
+            # (a depth that is not the reference's: moved by a bin at the sampler's branch, or by its conditioning in a nearly
+            # empty bin — at a sigma gain of thousands a 1e-5 move of a sample on a density edge is visible)
+            assert zdiff.all(), "out-of-tolerance rays whose sorted depths ARE the reference's, bit for bit: nothing to blame"
         return stats
     # Warp on: what is left is the conditioning of the canonical coordinates (tests/test_oracle_golden.py::
     # test_reference_conditioning: a 1-ulp move of the sample points moves the reference itself by > 1e-4 on some rays; the
