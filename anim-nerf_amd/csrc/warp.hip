@@ -1358,14 +1358,14 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_valid_list_kernel(const uin
 __global__ __launch_bounds__(WARP_THREADS) void knn_kernel(const float* __restrict__ index, IndexDims d,
                                                            const float* __restrict__ xyz, int64_t N,
                                                            float* __restrict__ dist_out,
-                                                           int64_t* __restrict__ idx_out) {
+                                                           int64_t* __restrict__ idx_out, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.y;
     const float* my_index = index + (int64_t)b * d.total_floats();
     stage_index(my_index, d.lds_floats(), lds);
     const int32_t* order = reinterpret_cast<const int32_t*>(my_index + d.order_off());
-    for (int it = 0; it < 4; ++it) {
-        int64_t n = (int64_t)blockIdx.x * 4096 + it * WARP_THREADS + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+        int64_t n = ((int64_t)blockIdx.x * iters + it) * WARP_THREADS + threadIdx.x;
         const bool active = n < N;
         if (!active) n = N - 1;
         const float* s = xyz + ((int64_t)b * N + n) * 3;
@@ -1379,6 +1379,24 @@ __global__ __launch_bounds__(WARP_THREADS) void knn_kernel(const float* __restri
 #pragma unroll
         for (int k = 0; k < 4; ++k) { dist_out[o + k] = sqrtf(best.d[k]); idx_out[o + k] = order[best.i[k]]; }
     }
+}
+
+// d1[n] = distance of xyz[n] to its nearest vertex if that is below `radius`, +inf otherwise: the same search started from
+// the bound radius^2 — a query far from the body is settled by the 14 top boxes (mesh extraction's empty-cell test, sigma_grid)
+__global__ __launch_bounds__(WARP_THREADS) void knn_within_kernel(const float* __restrict__ index, IndexDims d,
+                                                                  const float* __restrict__ xyz, int64_t N, float radius,
+                                                                  float* __restrict__ d1_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.y;
+    stage_index(index + (int64_t)b * d.total_floats(), d.lds_floats(), lds);
+    int64_t n = (int64_t)blockIdx.x * WARP_THREADS + threadIdx.x;
+    const bool active = n < N;
+    if (!active) n = N - 1;
+    const float* s = xyz + ((int64_t)b * N + n) * 3;
+    Best4 best;
+    best_init(best, radius * radius * 1.0002f);
+    search(lds, d, s[0], s[1], s[2], active, best);
+    if (active) d1_out[(int64_t)b * N + n] = best.i[0] >= 0 ? sqrtf(best.d[0]) : __builtin_inff();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1733,8 +1751,26 @@ extern "C" int anr_knn(const void* knn_index, const float* xyz, int bs, int V, i
     const int bytes = d.lds_floats() * 4;
     ANR_REQUIRE(bytes <= 160 * 1024, ANR_E_SHAPE, "anr_knn: V=%d needs %d B of LDS (>160 KiB)", V, bytes);
     if (int rc = allow_big_lds(knn_kernel, bytes, "anr_knn")) return rc;
-    dim3 grid((unsigned)((N + 4095) / 4096), bs);
+    // points per workgroup: the staged index (114 KB) is worth amortising over 4 x 1,024 points only when that still leaves a
+    // workgroup per CU
+    const int iters = N >= (int64_t)256 * 4096 / bs ? 4 : 1;
+    dim3 grid((unsigned)((N + (int64_t)iters * WARP_THREADS - 1) / ((int64_t)iters * WARP_THREADS)), bs);
     hipLaunchKernelGGL(knn_kernel, grid, dim3(WARP_THREADS), bytes, (hipStream_t)stream,
-                       reinterpret_cast<const float*>(knn_index), d, xyz, N, dist_out, idx_out);
+                       reinterpret_cast<const float*>(knn_index), d, xyz, N, dist_out, idx_out, iters);
     return check_launch("anr_knn");
+}
+
+extern "C" int anr_knn_within(const void* knn_index, const float* xyz, int bs, int V, int64_t N, float radius, float* d1_out,
+                              void* stream) {
+    ANR_REQUIRE(knn_index && xyz && d1_out, ANR_E_BADARG, "anr_knn_within: null pointer");
+    ANR_REQUIRE(bs > 0 && V >= 4 && N > 0 && radius > 0.0f, ANR_E_BADARG, "anr_knn_within: bs=%d V=%d N=%lld radius=%g", bs, V, (long long)N,
+                radius);
+    ANR_REQUIRE(((uintptr_t)knn_index & 15) == 0, ANR_E_ALIGN, "anr_knn_within: knn_index must be 16-B aligned");
+    IndexDims d = index_dims(V);
+    const int bytes = d.lds_floats() * 4;
+    ANR_REQUIRE(bytes <= 160 * 1024, ANR_E_SHAPE, "anr_knn_within: V=%d needs %d B of LDS (>160 KiB)", V, bytes);
+    if (int rc = allow_big_lds(knn_within_kernel, bytes, "anr_knn_within")) return rc;
+    hipLaunchKernelGGL(knn_within_kernel, dim3((unsigned)((N + WARP_THREADS - 1) / WARP_THREADS), bs), dim3(WARP_THREADS), bytes,
+                       (hipStream_t)stream, reinterpret_cast<const float*>(knn_index), d, xyz, N, radius, d1_out);
+    return check_launch("anr_knn_within");
 }

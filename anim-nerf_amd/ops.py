@@ -1145,3 +1145,18 @@ def scatter_relu(values: torch.Tensor, vox: torch.Tensor, out: torch.Tensor, fir
     with _timed("scatter_relu", values.numel(), values.numel() * 12):
         _lib.check(lib.anr_scatter_relu(_ptr(values), _ptr(vox), values.numel(), int(first), out.numel(), _ptr(out), _stream(out)),
                    "anr_scatter_relu")
+
+
+def knn_within(verts: torch.Tensor, xyz: torch.Tensor, radius: float, index: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """d1[bs,N]: distance to the nearest vertex where below `radius`, +inf elsewhere (the exact search started from that bound)."""
+    lib = _lib.load()
+    verts, xyz = _dev(verts, "verts"), _dev(xyz, "xyz")
+    bs, V, _ = verts.shape
+    N = xyz.shape[1]
+    if index is None:
+        index = knn_index_build(verts, morton_order(verts[0]).to(verts.device))
+    index = _dev(index, "knn_index", torch.uint8)
+    d1 = torch.empty(bs, N, dtype=torch.float32, device=xyz.device)
+    with _timed("knn_within", bs * N):
+        _lib.check(lib.anr_knn_within(_ptr(index), _ptr(xyz), bs, V, N, float(radius), _ptr(d1), _stream(xyz)), "anr_knn_within")
+    return d1

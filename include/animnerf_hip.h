@@ -122,6 +122,11 @@ int64_t anr_knn_index_bytes(int V);
 int anr_knn_index_build(const float* verts, const int32_t* order, int bs, int V, void* index_out, void* stream);
 int anr_knn(const void* knn_index, const float* xyz, int bs, int V, int64_t N,
             float* dist_out, int64_t* idx_out, void* stream);
+/* d1_out[bs*N] = distance of xyz[bs*N*3] to the nearest vertex where that is below `radius`, +inf elsewhere: the same exact
+ * search started from the bound radius — a query far from the body is settled by a handful of box tests.  (The empty-cell
+ * test of the sigma grid: a cell whose centre is farther than dis_threshold + its half diagonal from every vertex holds no
+ * valid voxel, models/anim_nerf.py:183.) */
+int anr_knn_within(const void* knn_index, const float* xyz, int bs, int V, int64_t N, float radius, float* d1_out, void* stream);
 
 /* ... and for k_neigh != 4 (a constructor argument of the reference, models/anim_nerf.py:42; every shipped config: 4): an
  * exhaustive exact search, k = 1..8, V <= 13000.  verts[bs*V*3], xyz[bs*N*xyz_stride] (xyz first) ->
