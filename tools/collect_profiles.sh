@@ -4,7 +4,7 @@
 # --pmc passes are separate from each other and carry no trace domain besides --kernel-trace.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$ROOT/gpurun_out/prof_r03
+OUT=$ROOT/gpurun_out/prof_r04
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for wl in cfg2 cfg3 cfg4; do
@@ -22,8 +22,8 @@ for wl in cfg2 cfg3; do
   python3 tools/hbm_table.py $OUT/${wl}_fetch $OUT/${wl}_write $OUT/${wl}_trace >> $OUT/hbm_${wl}.txt
   cat $OUT/hbm_${wl}.txt
 done
-# the files the judge reads, named as in profiles/r03/
-DST=$ROOT/gpurun_out/profiles_r03
+# the files the judge reads, named as in profiles/r03/ and r04/
+DST=$ROOT/gpurun_out/profiles_r04
 mkdir -p $DST
 for wl in cfg2 cfg3 cfg4; do
   cp $OUT/${wl}_trace/*/*kernel_stats.csv $DST/bench_${wl}_bf16_kernel_stats.csv
@@ -45,4 +45,19 @@ ls $DST
 # second half of round 3: the training step as one graph replay (idle time between its kernels), the small-batch warp search
 python3 tools/step_gaps.py $OUT/cfg4_trace > $DST/train_step_graph_gaps.txt
 python3 tools/bench_warp_small.py 20 both 2>/dev/null | tail -2 > $DST/warp_small_batch.txt
+ls $DST
+# round 4: the step of the reference's 8-GPU partitioning (2 frames per rank), the sigma grid per kernel, the ordered launch
+# list of one replayed step, per-test durations of the GPU suite, the small-batch search at 2 and 16 bodies
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/cfg4_f2_trace --output-format csv -- python3 $ROOT/bench.py --workload cfg4 --no-extras --steps 40 --warmup 5 --frames-per-gpu 2 > $OUT/cfg4_f2_trace.json 2> /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/cfg5_trace --output-format csv -- python3 $ROOT/bench.py --workload cfg5 --no-extras --steps 5 --warmup 2 --cpu-rays 0 > $OUT/cfg5_trace.json 2> /dev/null
+cd $ROOT
+python3 tools/step_gaps.py $OUT/cfg4_f2_trace > $DST/train_step_graph_gaps_f2.txt
+python3 tools/step_sequence.py $OUT/cfg4_trace > $DST/train_step_launch_sequence.txt
+python3 tools/kstats.py $OUT/cfg5_trace > $DST/cfg5_kernel_stats.txt 2>/dev/null
+grep '^{' $OUT/cfg5_trace.json > $DST/bench_cfg5_bf16_under_rocprof.json
+grep '^{' $OUT/cfg4_f2_trace.json > $DST/bench_cfg4_f2_bf16_under_rocprof.json
+for b in 2 16; do echo "bodies $b: $(python3 tools/bench_warp_small.py 30 groups $b 2>/dev/null | tail -1)"; done > $DST/warp_small_batch_by_bodies.txt
+python3 tools/step_ops.py 16 2>/dev/null | tail -4 > $DST/train_step_framework_ops.txt
+python3 -m pytest tests -m gpu -q --durations=15 2>&1 | tail -22 > $DST/gpu_test_durations.txt
 ls $DST
