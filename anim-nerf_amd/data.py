@@ -205,3 +205,24 @@ def subsample_training_pixels(rays, rgbs, alphas, coords, subsamplesize=32):
     r, c = coords[:, 0], coords[:, 1]
     s = subsamplesize
     return rays[r, c].view(s, s, 8), rgbs[r, c].view(s, s, 3), alphas[r, c].view(s, s, 1)
+
+
+def load_mixamo_smpl(actions_dir, action_type="0007", skip=1):
+    """novel_pose.py:26-41: a Mixamo action retargeted to SMPL, `<actions_dir>/<action_type>/result.pkl` = {anim_len,
+    smpl_array[anim_len * 72], cam_array[anim_len, 3]} -> per frame {global_orient[3], body_pose[69], transl[3]}; the root
+    translation of a frame is (cam[1], cam[2], 0), as the reference takes it."""
+    import os
+    import pickle
+    with open(os.path.join(actions_dir, action_type, "result.pkl"), "rb") as f:
+        result = pickle.load(f, encoding="latin1")
+    return mocap_frames(result, skip)
+
+
+def mocap_frames(result, skip=1):
+    """the frame list of novel_pose.py:29-41 from the already loaded dict"""
+    import numpy as np
+    anim_len = int(result["anim_len"])
+    pose = np.asarray(result["smpl_array"], dtype=np.float32).reshape(anim_len, -1)
+    cam = np.asarray(result["cam_array"], dtype=np.float32)
+    return [{"cam": cam[i], "global_orient": pose[i, :3], "body_pose": pose[i, 3:72],
+             "transl": np.array([cam[i, 1], cam[i, 2], 0.0], dtype=np.float32)} for i in range(0, anim_len, skip)]

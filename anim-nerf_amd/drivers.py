@@ -142,6 +142,47 @@ def novel_view(args):
     return args.out
 
 
+def novel_pose(args):
+    """novel_pose.py:118-176: one camera, the subject driven through a motion-capture sequence — per frame (global_orient,
+    body_pose) from the sequence, the subject's own betas, transl = the subject's transl + the sequence's root translation —
+    rendered with `batched_inference`; images (RGBA), masks and depth maps as PNG.  The sequence: `--actions_dir/--action_type`
+    (load_mixamo_smpl), or with --synthetic a seeded walk-like swing of the limbs (no mocap file ships with this repository).
+    Not reproduced: the SMPL overlay renders (pyrender) and the GIF (imageio) — neither library is in the image."""
+    model, vr, rays, pose, templ = _scene(args)
+    W, H = args.img_wh
+    dev = rays.device
+    if args.synthetic:
+        n = args.n_frames
+        base = synthetic.animated_pose_params(seed=300)
+        t = np.linspace(0, 2 * np.pi, n, endpoint=False, dtype=np.float32)
+        swing = np.zeros((n, 69), dtype=np.float32)
+        swing[:, 0], swing[:, 3] = 0.5 * np.sin(t), -0.5 * np.sin(t)                # hips, x axis
+        swing[:, 47], swing[:, 50] = 0.4 * np.sin(t), -0.4 * np.sin(t)              # shoulders
+        mocap = data.mocap_frames({"anim_len": n, "smpl_array": np.concatenate([np.tile(base["global_orient"], (n, 1)), base["body_pose"] * 0.3 + swing], 1),
+                                   "cam_array": np.stack([np.ones(n), 0.02 * np.sin(t), 0.01 * np.cos(2 * t)], 1)}, args.frame_skip)
+    else:
+        mocap = data.load_mixamo_smpl(args.actions_dir, args.action_type, args.frame_skip)
+    for sub in ("images", "masks", "depths"):
+        os.makedirs(os.path.join(args.out, sub), exist_ok=True)
+    flat = rays.view(1, H * W, -1)
+    t0 = time.perf_counter()
+    for i, fr in enumerate(mocap):
+        params = {"betas": pose["betas"], "global_orient": torch.from_numpy(fr["global_orient"]).float()[None].to(dev),
+                  "body_pose": torch.from_numpy(fr["body_pose"][:69]).float()[None].to(dev),
+                  "transl": pose["transl"] + torch.from_numpy(fr["transl"]).float()[None].to(dev)}
+        out = batched_inference(vr, model, flat, params, templ, chunk=args.chunk)
+        tag = "_fine" if "rgbs_fine" in out else ""
+        img = (out["rgbs" + tag].view(H, W, 3).clamp(0, 1) * 255).round().to(torch.uint8)
+        mask = (out["alphas" + tag].view(H, W, 1).clamp(0, 1) * 255).round().to(torch.uint8)
+        write_png(os.path.join(args.out, "images", f"{i:06d}.png"), torch.cat([img, mask], -1).cpu().numpy())
+        write_png(os.path.join(args.out, "masks", f"{i:06d}.png"), mask.expand(-1, -1, 3).contiguous().cpu().numpy())
+        write_png(os.path.join(args.out, "depths", f"{i:06d}.png"), depth_image(out["depths" + tag].view(H, W)))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"{len(mocap)} poses of {W}x{H} in {dt:.2f} s ({len(mocap) * W * H / dt / 1e6:.2f} M rays/s incl. PNG output) -> {args.out}")
+    return args.out
+
+
 def extract_grid(args):
     """extract_mesh.py:142-173: posed SMPL mesh (smpl.obj), the thresholded sigma volume, and the level-set mesh (mesh.obj) —
     sigma grid, marching cubes (anim_nerf_amd.mesh: PyMCubes is not in the image, parity-unpinned), rescale, export."""
@@ -207,6 +248,14 @@ def parser():
     nv.add_argument("--betas_2th", type=float, default=0.0)
     nv.add_argument("--n_views", type=int, default=120)
     nv.add_argument("--angle", type=int, default=0)
+    npz = sub.add_parser("novel_pose", help="novel_pose.py: the subject driven through a motion-capture sequence")
+    common(npz)
+    npz.add_argument("--chunk", type=int, default=1 << 20)
+    npz.add_argument("--actions_dir", type=str, default="mocap/mixamo/")
+    npz.add_argument("--action_type", type=str, default="0007")
+    npz.add_argument("--frame_skip", type=int, default=2)
+    npz.add_argument("--n_frames", type=int, default=16, help="--synthetic: frames of the seeded sequence (before frame_skip)")
+
     eg = sub.add_parser("extract_grid")
     common(eg)
     eg.add_argument("--N_grid", type=int, default=256)
@@ -223,7 +272,7 @@ def main(argv=None):
     args = parser().parse_args(argv)
     if args.synthetic and args.img_wh is None:
         args.img_wh = [256, 256]
-    return {"novel_view": novel_view, "extract_grid": extract_grid}[args.cmd](args)
+    return {"novel_view": novel_view, "novel_pose": novel_pose, "extract_grid": extract_grid}[args.cmd](args)
 
 
 if __name__ == "__main__":
