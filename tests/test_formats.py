@@ -142,3 +142,19 @@ def test_orbit_is_rodrigues_of_the_reference_axis_angles():
         ry = Rotation.from_rotvec([0, 2 * np.pi * i / 8, 0]).as_matrix()
         assert np.allclose(P[i, :3, :3], ry @ rx, atol=1e-6) and np.allclose(P[i, 3], [0, 0, 0, 1])
         assert np.allclose(P[i, :3, 3], 0)
+
+
+def test_mocap_sequence_matches_reference(tmp_path):
+    """data.load_mixamo_smpl against the reference's (novel_pose.py:26-41, tests/golden/mocap.npz): frame selection, the pose
+    split and the root translation (cam[1], cam[2], 0)."""
+    import pickle
+    from anim_nerf_amd import data
+    g = golden("mocap")
+    os.makedirs(tmp_path / "0007")
+    with open(tmp_path / "0007" / "result.pkl", "wb") as f:
+        pickle.dump({"anim_len": int(g["anim_len"]), "smpl_array": g["smpl_array"], "cam_array": g["cam_array"]}, f)
+    mocap = data.load_mixamo_smpl(str(tmp_path), "0007", int(g["skip"]))
+    assert len(mocap) == len(g["transl"])
+    for i, m in enumerate(mocap):
+        for k in ("global_orient", "body_pose", "transl", "cam"):
+            assert np.array_equal(np.asarray(m[k], dtype=np.float64), np.asarray(g[k][i], dtype=np.float64)), (i, k)

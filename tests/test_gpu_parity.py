@@ -3,6 +3,8 @@ classes) against the CPU oracle on the same seeded inputs and against the refere
 vectors.  Tolerance on rendered RGB / sigma: 1e-4 relative (BASELINE.json north_star), fp32 mode.
 Run with:  python -m pytest tests -m gpu
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1013,6 +1015,13 @@ def test_drivers_novel_view_and_sigma_grid_export(dev, tmp_path):
     assert img0.shape == (32, 40, 4) and np.array_equal(img0[..., :3], want)          # P_0 = identity
     assert not np.array_equal(read_png(f"{out}/images/000001.png")[..., :3], want)   # the orbit moves
     assert read_png(f"{out}/depths/000002.png").shape == (32, 40, 1)
+    # novel_pose.py:118-176: the subject driven through a (seeded) motion sequence; frame 0 is the plain render of its parameters
+    outp = ana.drivers.main(["novel_pose", "--synthetic", "--n_frames", "4", "--frame_skip", "2", "--img_wh", "40", "32",
+                             "--out", str(tmp_path / "np"), "--mlp_mode", "f32"])
+    a0, a1 = read_png(f"{outp}/images/000000.png"), read_png(f"{outp}/images/000001.png")
+    assert a0.shape == (32, 40, 4) and not np.array_equal(a0, a1) and not os.path.exists(f"{outp}/images/000002.png")
+    assert np.array_equal(read_png(f"{outp}/masks/000000.png")[..., 0], a0[..., 3]) and read_png(f"{outp}/depths/000001.png").shape == (32, 40, 1)
+    assert (a0[..., 3] > 128).mean() > 0.02, "the body must be in the picture"
     out = ana.drivers.main(["extract_grid", "--synthetic", "--N_grid", "24", "--sigma_threshold", "5", "--out", str(tmp_path / "m"),
                             "--mlp_mode", "f32"])
     vol = np.load(f"{out}/sigma.npy")
