@@ -503,8 +503,10 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
     }
     // ---- the skinny heads (sigma, rgb) and their biases
     {
+        // (256 slices at most: the reduction below adds a segment's slices one after the other per element, and with 1,024
+        // slices of the heads' column sums it was that chain — not the 32 slices of the big GEMMs — that set its 50-60 us)
         int slices = (int)((n + 127) / 128);
-        if (slices > 1024) slices = 1024;
+        if (slices > 256) slices = 256;
         const int rps = (int)((n + slices - 1) / slices);
         slices = (int)((n + rps - 1) / rps);
         using T = typename C::T;

@@ -60,6 +60,9 @@ def system_forward(volume_renderer, anim_nerf, rays, body_model_params, body_mod
     return {k: v.view(bs, h, w, -1) for k, v in out.items()}
 
 
+_CELL_CENTRES = {}
+
+
 @torch.no_grad()
 def sigma_grid(anim_nerf, N_grid=256, x_range=(-1.2, 1.2), y_range=(-1.2, 1.2), z_range=(-1.2, 1.2),
                chunk=1 << 22, rank=0, world=1, cells: Optional[bool] = None):
@@ -83,11 +86,17 @@ def sigma_grid(anim_nerf, N_grid=256, x_range=(-1.2, 1.2), y_range=(-1.2, 1.2), 
     if cells:
         dev = center.device
         C = N_grid // 8
-        axis = lambda r: r[0] + (r[1] - r[0]) * (8.0 * torch.arange(C, device=dev, dtype=torch.float64) + 3.5) / (N_grid - 1)
-        cx, cy, cz = axis(x_range), axis(y_range), axis(z_range)
-        # cell (cj, ci, ck) -> centre (x[ci], y[cj], z[ck]) (np.meshgrid 'xy': array axis 0 runs over y)
-        cen = torch.stack(torch.broadcast_tensors(cx[None, :, None], cy[:, None, None], cz[None, None, :]), -1).reshape(1, -1, 3)
-        cen = cen.float() + center
+        key = (N_grid, tuple(x_range), tuple(y_range), tuple(z_range), str(dev))
+        base = _CELL_CENTRES.get(key)
+        if base is None:                                             # constants of the grid: built once, not per call
+            axis = lambda r: r[0] + (r[1] - r[0]) * (8.0 * torch.arange(C, device=dev, dtype=torch.float64) + 3.5) / (N_grid - 1)
+            cx, cy, cz = axis(x_range), axis(y_range), axis(z_range)
+            # cell (cj, ci, ck) -> centre (x[ci], y[cj], z[ck]) (np.meshgrid 'xy': array axis 0 runs over y)
+            base = torch.stack(torch.broadcast_tensors(cx[None, :, None], cy[:, None, None], cz[None, None, :]), -1).reshape(1, -1, 3).float()
+            if len(_CELL_CENTRES) > 8:
+                _CELL_CENTRES.clear()
+            _CELL_CENTRES[key] = base
+        cen = base + center
         step = torch.tensor([(r[1] - r[0]) / (N_grid - 1) for r in (x_range, y_range, z_range)], dtype=torch.float64)
         radius = float((3.5 * step).norm()) + 1e-4                  # half diagonal of the cell's voxel positions (+ rounding)
         # (the search starts from the bound: a centre far from the body is settled by the index's 14 top boxes)
