@@ -49,9 +49,10 @@ class ExplicitTrainStep:
         self.tr = trainer
         p0 = trainer.params[0]
         self.dev = p0.device
-        # (seed, step counter, ticket): the random numbers of step k are a pure function of (seed, k) — torch.manual_seed
+        # (seed, step counter, tickets): the random numbers of step k are a pure function of (seed, k) — torch.manual_seed
         # before the Trainer is built fixes the run
-        self.draw_state = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64, device=self.dev)
+        self.draw_state = torch.zeros(ops.DRAW_STATE_WORDS, dtype=torch.int64, device=self.dev)
+        self.draw_state[0] = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
         self.last_draws = None         # the random tensors of the last step (t_rand, noise_c, u_fine, noise_f, n0, n1): for tests
         self.last_quads = None         # ... and its tangent quads (coarse, fine)
 

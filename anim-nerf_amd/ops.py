@@ -996,13 +996,18 @@ def zero_fill(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+DRAW_STATE_WORDS = 35                                         # include/animnerf_hip.h: ANR_DRAW_STATE_WORDS
+
+
 def train_draws(state: torch.Tensor, *, n_t=0, t_scale=1.0, n_nc=0, n_u=0, n_nf=0, noise_scale=1.0, verts_template=None,
                 point_scale=0.0, neighbour_scale=0.0):
     """Every random number of one training step in one launch (anr_train_draws): -> dict(t_rand[n_t], noise_c[n_nc],
     u_fine[n_u], noise_f[n_nf], n0, n1 [like verts_template], pair[2 x verts_template rows, 3]); absent ones None.
-    state: int64[3] on the device = (seed, step counter, 0); the kernel advances the counter."""
+    state: int64[DRAW_STATE_WORDS] on the device = (seed, step counter, tickets: zero); the kernel advances the counter."""
     lib = _lib.load()
     state = _dev(state, "state", torch.int64)
+    if state.numel() < DRAW_STATE_WORDS:
+        raise ValueError(f"train_draws: state holds {state.numel()} words, needs {DRAW_STATE_WORDS}")
     dev = state.device
     new = lambda n: torch.empty(n, dtype=torch.float32, device=dev) if n else None
     o = dict(t_rand=new(n_t), noise_c=new(n_nc), u_fine=new(n_u), noise_f=new(n_nf), n0=None, n1=None, pair=None)

@@ -583,8 +583,8 @@ int anr_adam_step_counting(const void* chunks, int n_chunks, float* step, const 
 /* ---- the explicit training step (anim_nerf_amd/fused_step.py): what it needs beside the kernels above so that the step's
  * HIP graph holds this library's launches only (csrc/train_step.hip) -------------------------------------------------
  * anr_train_draws: every random number of one training step (train.py:324-348) in one launch — Philox4x32-10 keyed by
- *   state[0] = seed and state[1] = a step counter that lives ON THE DEVICE and is advanced by the kernel (state[2]: a
- *   ticket, zero at rest), so a replayed graph draws fresh numbers.  state: int64[3], device.
+ *   state[0] = seed and state[1] = a step counter that lives ON THE DEVICE and is advanced by the kernel (state[2..34]:
+ *   tickets, zero at rest), so a replayed graph draws fresh numbers.  state: int64[ANR_DRAW_STATE_WORDS = 35], device.
  *   t_rand[n_t] = t_scale U[0,1) (the stratified jitter, models/volume_rendering.py:48-54: t_scale = perturb);
  *   noise_c[n_nc], noise_f[n_nf] = noise_scale N(0,1) (sigma noise of the two passes, :122-129); u_fine[n_u] = U[0,1) (the
  *   importance sampler's uniforms, :66-70); n0[n_v3], n1[n_v3] = N(0,1) and pair[2 n_v3] = (verts_template + point_scale n0,
@@ -599,6 +599,7 @@ typedef struct {
     float point_scale, neighbour_scale;
     float *n0, *n1, *pair;
 } anr_draw_plan;
+#define ANR_DRAW_STATE_WORDS 35
 int anr_train_draws(int64_t* state, const anr_draw_plan* plan, void* stream);
 /* BodyModelParams.forward (models/body_model_params.py:5-68): rows frame_idx[bs] (int64) of the embedding tables
  * global_orient[T][3], body_pose[T][69], transl[T][3] and betas[betas_rows][10] (betas_rows = 1: one shape for all frames) ->

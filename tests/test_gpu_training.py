@@ -1456,12 +1456,12 @@ def test_step_draws_kernel(dev):
     vt = torch.randn(1, 6890, 3, generator=torch.Generator().manual_seed(0)).to(dev)
     kw = dict(n_t=16384 * 64, t_scale=1.0, n_nc=16384 * 64, n_u=16384 * 32 + 3, n_nf=16384 * 96, noise_scale=1.0, verts_template=vt,
               point_scale=0.1, neighbour_scale=0.01)
-    st = torch.tensor([1234, 0, 0], dtype=torch.int64, device=dev)
+    st = torch.tensor([1234] + [0] * 34, dtype=torch.int64, device=dev)
     a = ops.train_draws(st, **kw)
-    assert st.tolist() == [1234, 1, 0]
+    assert st.tolist() == [1234, 1] + [0] * 33
     b = ops.train_draws(st, **kw)
-    assert st.tolist() == [1234, 2, 0]
-    c = ops.train_draws(torch.tensor([1234, 0, 0], dtype=torch.int64, device=dev), **kw)
+    assert st.tolist() == [1234, 2] + [0] * 33
+    c = ops.train_draws(torch.tensor([1234] + [0] * 34, dtype=torch.int64, device=dev), **kw)
     for k in ("t_rand", "noise_c", "u_fine", "noise_f", "n0", "n1", "pair"):
         assert torch.equal(a[k], c[k]), k                       # a pure function of (seed, step)
         assert not torch.equal(a[k], b[k]), k                   # fresh numbers per step
@@ -1480,7 +1480,7 @@ def test_step_draws_kernel(dev):
     torch.testing.assert_close(a["pair"][:6890], pts[0], rtol=0, atol=1e-6)
     torch.testing.assert_close(a["pair"][6890:], (pts + 0.01 * a["n1"])[0], rtol=0, atol=1e-6)
     # t_scale / noise_scale, and absent segments
-    d = ops.train_draws(torch.tensor([1234, 0, 0], dtype=torch.int64, device=dev), n_t=1024, t_scale=0.5, n_nc=1024, noise_scale=2.0)
+    d = ops.train_draws(torch.tensor([1234] + [0] * 34, dtype=torch.int64, device=dev), n_t=1024, t_scale=0.5, n_nc=1024, noise_scale=2.0)
     assert torch.equal(d["t_rand"], 0.5 * a["t_rand"][:1024]) and torch.equal(d["noise_c"], 2.0 * a["noise_c"][:1024])
     assert d["u_fine"] is None and d["pair"] is None
 

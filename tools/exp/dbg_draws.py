@@ -4,7 +4,7 @@ import torch
 from anim_nerf_amd import ops
 dev = torch.device("cuda:0")
 vt = torch.randn(1, 6890, 3, generator=torch.Generator().manual_seed(0)).to(dev)
-st = torch.tensor([1234, 0, 0], dtype=torch.int64, device=dev)
+st = torch.tensor([1234] + [0] * 34, dtype=torch.int64, device=dev)
 d = ops.train_draws(st, verts_template=vt, point_scale=0.2 * 0.5, neighbour_scale=0.01)
 n0, n1, pair = d["n0"], d["n1"], d["pair"]
 sep = vt + n0 * 0.2 * 0.5
