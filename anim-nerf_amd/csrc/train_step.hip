@@ -5,8 +5,8 @@
 //   anr_train_draws               every random number of a step in one launch: the stratified jitter (models/volume_rendering.py:
 //                                 48-54), the sigma noise of both passes (:122-129), the importance sampler's uniforms (:66-70)
 //                                 and the normal regulariser's two perturbations of the template vertices (train.py:289-290) —
-//                                 Philox4x32-10 keyed by (seed, step counter); the counter lives on the device and the kernel
-//                                 advances it, so a replayed graph draws fresh numbers
+//                                 Philox4x32-10 keyed by (seed, step counter); the counter lives on the device and a one-thread
+//                                 launch behind the draws advances it, so a replayed graph draws fresh numbers
 //   anr_gather_frame_params       BodyModelParams.forward (models/body_model_params.py:5-68): rows of the four embedding tables
 //                                 -> betas[bs][10], pose[bs][72], transl[bs][3]
 //   anr_scatter_frame_param_grads its backward: dL/d(betas | global_orient | body_pose | transl)[bs][85] -> the tables' gradients
@@ -38,11 +38,13 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * 5.9604644775390625e-8f; }
 // Box-Muller: two 32-bit draws -> two standard normals (u1 in (0, 1]: no log(0))
 __device__ __forceinline__ float2 normal2(unsigned a, unsigned b) {
+    // the hardware's transcendental units directly (v_log_f32 = log2, v_sqrt_f32, v_sin_f32 / v_cos_f32 take REVOLUTIONS):
+    // ~1e-6 of absolute error, irrelevant for noise; the library calls (IEEE sqrt, sincospif's reduction and polynomials)
+    // made this kernel 117 us for 4.2 M values
     const float u1 = ((float)(a >> 8) + 1.0f) * 5.9604644775390625e-8f;
-    const float r = sqrtf(-2.0f * __logf(u1));
-    float s, c;
-    sincospif(2.0f * u01(b), &s, &c);
-    return make_float2(r * c, r * s);
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));      // sqrt(-2 ln u1)
+    const float t = u01(b);
+    return make_float2(r * __builtin_amdgcn_cosf(t), r * __builtin_amdgcn_sinf(t));
 }
 
 __global__ __launch_bounds__(256) void train_draws_kernel(uint64_t* __restrict__ state, anr_draw_plan p, int64_t g0, int64_t g1, int64_t g2,
@@ -95,25 +97,12 @@ __global__ __launch_bounds__(256) void train_draws_kernel(uint64_t* __restrict__
                 }
         }
     }
-    // The last workgroup to finish advances the step counter (every thread has read it by then).  Tickets in two levels —
-    // 64 buckets by workgroup number, then one ticket per bucket — so that no address sees more than ~64 atomic adds: 4,096
-    // workgroups queuing on ONE ticket took 100 of the kernel's 118 us (a same-address atomic retires in ~25 ns).
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        unsigned* tick = reinterpret_cast<unsigned*>(state + 2);     // [0]: level 2, [2 + b]: bucket b (state[2] .. state[34])
-        const unsigned nb = gridDim.x < 64u ? gridDim.x : 64u, bkt = blockIdx.x & 63u;
-        const unsigned in_bkt = (gridDim.x - bkt + 63u) / 64u;
-        if (atomicAdd(tick + 2 + bkt, 1u) == in_bkt - 1) {
-            tick[2 + bkt] = 0u;
-            __threadfence();
-            if (atomicAdd(tick, 1u) == nb - 1) {
-                state[1] = step + 1;
-                tick[0] = 0u;
-            }
-        }
-    }
 }
+
+// The step counter is advanced by a launch of its own behind the draws (stream order: every thread of the draws kernel has read
+// it by then).  A "last workgroup" ticket inside the draws kernel cost 100 of its 118 us: 4,096 workgroups' atomic adds on one
+// cache line retire one after the other, ~25 ns each — also when spread over 64 addresses of that line.
+__global__ void draws_advance_kernel(uint64_t* __restrict__ state) { state[1] += 1; }
 
 constexpr int FP_COLS = 85;                      // betas 10 | global_orient 3 | body_pose 69 | transl 3
 __global__ __launch_bounds__(128) void gather_frame_params_kernel(const int64_t* __restrict__ idx, const float* __restrict__ betas_w,
@@ -203,6 +192,7 @@ extern "C" int anr_train_draws(int64_t* state, const anr_draw_plan* plan, void* 
     ANR_REQUIRE(g4 > 0 && g4 < ((int64_t)1 << 28) * 256, ANR_E_BADARG, "anr_train_draws: nothing to draw, or too much");
     hipLaunchKernelGGL(train_draws_kernel, dim3((unsigned)((g4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<uint64_t*>(state), p, g0, g1, g2, g3, g4);
+    hipLaunchKernelGGL(draws_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<uint64_t*>(state));
     return check_launch("anr_train_draws");
 }
 

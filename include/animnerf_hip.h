@@ -583,8 +583,9 @@ int anr_adam_step_counting(const void* chunks, int n_chunks, float* step, const 
 /* ---- the explicit training step (anim_nerf_amd/fused_step.py): what it needs beside the kernels above so that the step's
  * HIP graph holds this library's launches only (csrc/train_step.hip) -------------------------------------------------
  * anr_train_draws: every random number of one training step (train.py:324-348) in one launch — Philox4x32-10 keyed by
- *   state[0] = seed and state[1] = a step counter that lives ON THE DEVICE and is advanced by the kernel (state[2..34]:
- *   tickets, zero at rest), so a replayed graph draws fresh numbers.  state: int64[ANR_DRAW_STATE_WORDS = 35], device.
+ *   state[0] = seed and state[1] = a step counter that lives ON THE DEVICE and is advanced by a one-thread launch behind
+ *   the draws (state[2..34]: reserved, zero), so a replayed graph draws fresh numbers.  state: int64[ANR_DRAW_STATE_WORDS = 35],
+ *   device.
  *   t_rand[n_t] = t_scale U[0,1) (the stratified jitter, models/volume_rendering.py:48-54: t_scale = perturb);
  *   noise_c[n_nc], noise_f[n_nf] = noise_scale N(0,1) (sigma noise of the two passes, :122-129); u_fine[n_u] = U[0,1) (the
  *   importance sampler's uniforms, :66-70); n0[n_v3], n1[n_v3] = N(0,1) and pair[2 n_v3] = (verts_template + point_scale n0,
