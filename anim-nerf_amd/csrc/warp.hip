@@ -18,6 +18,7 @@
 // body box 8 | order[Vp] (int32: slot -> original vertex id).  Vp = 8 NC, NC = ceil(V/8), NS = ceil(NC/8), NT = ceil(NS/8).
 #include "anr_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace anr {
 
@@ -121,8 +122,11 @@ struct Best4 {
 };
 // cap2 = squared search radius: only vertices strictly closer than sqrt(cap2) are collected; slots stay -1 otherwise
 __device__ __forceinline__ void best_init(Best4& b, float cap2 = 3.0e38f) {
+    // (an empty slot holds the float just below cap2 and slot -1 = 0xffffffff: under best_insert's unsigned 64-bit order
+    // (distance bits : slot) a candidate enters exactly when its distance is < cap2)
+    const float below = __uint_as_float(__float_as_uint(cap2) - 1u);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { b.d[k] = cap2; b.i[k] = -1; }
+    for (int k = 0; k < 4; ++k) { b.d[k] = below; b.i[k] = -1; }
 }
 // insert (c, v) keeping (d, slot) ascending LEXICOGRAPHICALLY: among vertices at exactly the same distance the lower
 // index slot wins, whatever order the traversal visits them in — the exact search, the cell-sorted search and the
@@ -130,14 +134,18 @@ __device__ __forceinline__ void best_init(Best4& b, float cap2 = 3.0e38f) {
 // a bit-identity test).  Branch-free: new d[k] = median(d[k-1], d[k], c) for a sorted list, the ids follow the four
 // comparisons.
 __device__ __forceinline__ void best_insert(Best4& b, float c, int v) {
-    const bool m0 = c < b.d[0] || (c == b.d[0] && v < b.i[0]), m1 = c < b.d[1] || (c == b.d[1] && v < b.i[1]);
-    const bool m2 = c < b.d[2] || (c == b.d[2] && v < b.i[2]), m3 = c < b.d[3] || (c == b.d[3] && v < b.i[3]);
+    // the four tests as ONE unsigned 64-bit compare each — squared distances are non-negative floats, whose bit patterns order
+    // like the numbers — instead of three compares and two mask operations ((c < d) | ((c == d) & (v < i)); written with || and
+    // && hipcc even built each test out of three nested branches: ~60 instructions and eight s_cbranch per insertion)
+    const unsigned long long key = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned)v;
+    auto at = [&](int k) { return ((unsigned long long)__float_as_uint(b.d[k]) << 32) | (unsigned)b.i[k]; };
+    const bool m0 = key < at(0), m1 = key < at(1), m2 = key < at(2), m3 = key < at(3);
     b.i[3] = m3 ? (m2 ? b.i[2] : v) : b.i[3];
     b.i[2] = m2 ? (m1 ? b.i[1] : v) : b.i[2];
     b.i[1] = m1 ? (m0 ? b.i[0] : v) : b.i[1];
     b.i[0] = m0 ? v : b.i[0];
     const float d0 = b.d[0], d1 = b.d[1], d2 = b.d[2], d3 = b.d[3];
-    b.d[0] = fminf(d0, c);
+    b.d[0] = __builtin_amdgcn_fmed3f(d0, c, -1.0f);                  // = min(d0, c) for non-negative operands, one instruction
     b.d[1] = __builtin_amdgcn_fmed3f(d0, d1, c);
     b.d[2] = __builtin_amdgcn_fmed3f(d1, d2, c);
     b.d[3] = __builtin_amdgcn_fmed3f(d2, d3, c);
@@ -165,25 +173,34 @@ __device__ __forceinline__ void scan_cluster(const float* lds, int Vp, int c, fl
     const float4* X = reinterpret_cast<const float4*>(lds + c * CS);
     const float4* Y = reinterpret_cast<const float4*>(lds + Vp + c * CS);
     const float4* Z = reinterpret_cast<const float4*>(lds + 2 * Vp + c * CS);
+    // the cluster's 96 bytes in six reads issued together (one wait, not one per half), the eight distances two at a time
+    // (v_pk_add/mul/fma_f32: the same operations in the same order as the scalar form)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 P[3] = {f2{px, px}, f2{py, py}, f2{pz, pz}};
+    float4 vx[CS / 4], vy[CS / 4], vz[CS / 4];
+#pragma unroll
+    for (int q = 0; q < CS / 4; ++q) { vx[q] = X[q]; vy[q] = Y[q]; vz[q] = Z[q]; }
+    float d2[CS];
 #pragma unroll
     for (int q = 0; q < CS / 4; ++q) {
-        const float4 vx = X[q], vy = Y[q], vz = Z[q];
-        // two vertices per instruction (v_pk_add/mul/fma_f32): the same operations in the same order as the scalar form
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        const f2 P[3] = {f2{px, px}, f2{py, py}, f2{pz, pz}};
-        float d2[4];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const f2 ax = t ? f2{vx.z, vx.w} : f2{vx.x, vx.y}, ay = t ? f2{vy.z, vy.w} : f2{vy.x, vy.y}, az = t ? f2{vz.z, vz.w} : f2{vz.x, vz.y};
+            const f2 ax = t ? f2{vx[q].z, vx[q].w} : f2{vx[q].x, vx[q].y}, ay = t ? f2{vy[q].z, vy[q].w} : f2{vy[q].x, vy[q].y},
+                     az = t ? f2{vz[q].z, vz[q].w} : f2{vz[q].x, vz[q].y};
             const f2 dx = P[0] - ax, dy = P[1] - ay, dz = P[2] - az;
             const f2 r = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));      // == dist2()
-            d2[2 * t] = r.x; d2[2 * t + 1] = r.y;
+            d2[4 * q + 2 * t] = r.x; d2[4 * q + 2 * t + 1] = r.y;
         }
-        float m = fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3]));
-        if (m <= best.d[3]) {                              // (<=: a tie with the current 4th may carry a lower slot)
+    }
+    float m = d2[0];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) best_insert(best, d2[t], c * CS + q * 4 + t);
-        }
+    for (int t = 1; t < CS; ++t) m = fminf(m, d2[t]);
+    if (m <= best.d[3]) {                                  // (<=: a tie with the current 4th may carry a lower slot)
+        // ... and inside, vertex by vertex: a wavefront comes here when ANY lane has a candidate among the eight, mostly one
+        // or two of them — an insertion is ~40 instructions, the test that skips it four
+#pragma unroll
+        for (int t = 0; t < CS; ++t)
+            if (d2[t] <= best.d[3]) best_insert(best, d2[t], c * CS + t);
     }
 }
 
@@ -217,6 +234,15 @@ __device__ __forceinline__ int seed_cluster(const float* lds, const IndexDims& d
     return seed_c;
 }
 
+#ifdef ANR_SEARCH_PROF
+// experiment builds only (tools/exp/walk_prof.py): what a wavefront of the lane-per-sample search executes, summed over the
+// launches since the last read: {calls, top / super / cluster box tests, cluster scans, lanes that needed a scan, seed passes,
+// active lanes}
+__device__ unsigned long long anr_walk_prof[8];
+#define WALK_ADD(k, v) walk[k] += (v)
+#else
+#define WALK_ADD(k, v)
+#endif
 // exact 4 nearest vertices of (px,py,pz); best.i are index SLOTS (map through order[] for vertex ids).
 // Control flow is wave-uniform (ballots); per-lane work is predicated.  seed_c: the cluster each lane scans first
 // (any cluster is correct; a near one makes the bound tight before the traversal starts).
@@ -226,6 +252,9 @@ __device__ __forceinline__ void search_from(const float* lds, const IndexDims& d
     const float* sboxes = lds + d.sbox_off();
     const float* tboxes = lds + d.tbox_off();
     if (!active) seed_c = -1;
+#ifdef ANR_SEARCH_PROF
+    unsigned walk[8] = {1, 0, 0, 0, 0, 0, 0, (unsigned)__popcll(__ballot(active))};
+#endif
     unsigned long long rem = __ballot(active);
     while (rem) {                                   // one pass per distinct seed cluster in the wavefront
         const int first = __builtin_ctzll(rem);
@@ -233,25 +262,110 @@ __device__ __forceinline__ void search_from(const float* lds, const IndexDims& d
         const bool mine = (seed_c == c);
         if (mine) scan_cluster(lds, d.Vp, c, px, py, pz, best);
         rem &= ~__ballot(mine);
+        WALK_ADD(6, 1);
     }
     // every other cluster whose box can still beat the current 4th-best
     for (int t = 0; t < d.NT; ++t) {
         const float tv = box_d2(tboxes + t * 8, px, py, pz);
+        WALK_ADD(1, 1);
         if (!__any(active && tv <= best.d[3])) continue;
         const int s_end = min((t + 1) * TC, d.NS);
         for (int q = t * TC; q < s_end; ++q) {
             const float sv = box_d2(sboxes + q * 8, px, py, pz);
+            WALK_ADD(2, 1);
             if (!__any(active && sv <= best.d[3])) continue;
             const int c_end = min((q + 1) * SC, d.NC);
             for (int c = q * SC; c < c_end; ++c) {
                 const float v = box_d2(boxes + c * 8, px, py, pz);
                 const bool need = active && (c != seed_c) && (v <= best.d[3]);
+                WALK_ADD(3, 1);
                 if (__any(need)) {
+                    WALK_ADD(4, 1);
+                    WALK_ADD(5, (unsigned)__popcll(__ballot(need)));
                     if (need) scan_cluster(lds, d.Vp, c, px, py, pz, best);
                 }
             }
         }
     }
+#ifdef ANR_SEARCH_PROF
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&anr_walk_prof[k], (unsigned long long)walk[k]);
+#endif
+}
+// wave-wide max / min in every lane: four DPP steps inside the rows of 16, then the four row results through SGPRs
+template <bool MAX> __device__ __forceinline__ float wave_reduce(float v) {
+    auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
+    auto dpp = [](float x, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));      // quad_perm [1,0,3,2]
+    v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));      // quad_perm [2,3,0,1]
+    v = op(v, dpp(v, std::integral_constant<int, 0x141>{}));     // row_half_mirror
+    v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));     // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return op(op(r0, r1), op(r2, r3));
+}
+
+// The same search for a wavefront whose points are NEIGHBOURS IN SPACE (the cell-sorted list: 64 consecutive entries lie in one
+// or two 4-cm cells).  The walk above tests 14 top + ~42 super + ~98 cluster boxes per wavefront to find the ~23 clusters it
+// scans (tools/exp/walk_prof.py on a cfg3 frame) — every lane the same boxes: two thirds of the kernel's instructions.  Here the
+// LANES SPLIT THE BOXES once per wavefront: after the seed cluster, every point's four neighbours lie within
+// sqrt(max over the lanes of d4) of it, hence within R = that + the half diagonal of the points' bounding box of the box's
+// centre; lane j tests cluster box j, j + 64, ... against that sphere (14 tests for 862 clusters) and the ballots are the
+// candidate set, a superset of what any lane needs.  The lanes then test only the candidates against their own bound.
+// Any order of visits gives the same four neighbours ((distance, slot) is a total order: best_insert).
+__device__ __forceinline__ void search_near(const float* lds, const IndexDims& d, float px, float py, float pz, bool active,
+                                            Best4& best, int seed_c) {
+    const float* boxes = lds + d.box_off();
+    if (!active) seed_c = -1;
+#ifdef ANR_SEARCH_PROF
+    unsigned walk[8] = {1, 0, 0, 0, 0, 0, 0, (unsigned)__popcll(__ballot(active))};
+#endif
+    unsigned long long rem = __ballot(active);
+    while (rem) {                                   // one pass per distinct seed cluster in the wavefront
+        const int first = __builtin_ctzll(rem);
+        const int c = __builtin_amdgcn_readlane(seed_c, first);
+        const bool mine = (seed_c == c);
+        if (mine) scan_cluster(lds, d.Vp, c, px, py, pz, best);
+        rem &= ~__ballot(mine);
+        WALK_ADD(6, 1);
+    }
+    constexpr float BIG = 3.0e38f;
+    const float lox = wave_reduce<false>(active ? px : BIG), hix = wave_reduce<true>(active ? px : -BIG);
+    const float loy = wave_reduce<false>(active ? py : BIG), hiy = wave_reduce<true>(active ? py : -BIG);
+    const float loz = wave_reduce<false>(active ? pz : BIG), hiz = wave_reduce<true>(active ? pz : -BIG);
+    const float cx = 0.5f * (lox + hix), cy = 0.5f * (loy + hiy), cz = 0.5f * (loz + hiz);
+    const float ex = hix - cx, ey = hiy - cy, ez = hiz - cz;
+    const float reach = (sqrtf(wave_reduce<true>(active ? best.d[3] : 0.f)) + sqrtf(ex * ex + ey * ey + ez * ez)) * 1.001f + 1.0e-6f;
+    const float reach2 = reach * reach;
+    const int lane = threadIdx.x & 63;
+    // (measured and dropped: two rounds, the candidates within half the reach first and the reach taken again for the rest —
+    // 20.8 scans and 48 + 28 box tests per item instead of 22.7 and 52 + 14, but 5 % slower)
+    for (int c0 = 0; c0 < d.NC; c0 += 64) {
+        const int cj = c0 + lane;
+        const float cv = cj < d.NC ? box_d2(boxes + cj * 8, cx, cy, cz) : BIG;
+        unsigned long long cand = __ballot(cv <= reach2);
+        WALK_ADD(1, 1);
+        while (cand) {
+            const int c = c0 + __builtin_ctzll(cand);
+            cand &= cand - 1;
+            const float v = box_d2(boxes + c * 8, px, py, pz);
+            const bool need = active && (c != seed_c) && (v <= best.d[3]);
+            WALK_ADD(3, 1);
+            if (__any(need)) {
+                WALK_ADD(4, 1);
+                WALK_ADD(5, (unsigned)__popcll(__ballot(need)));
+                if (need) scan_cluster(lds, d.Vp, c, px, py, pz, best);
+            }
+        }
+    }
+#ifdef ANR_SEARCH_PROF
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&anr_walk_prof[k], (unsigned long long)walk[k]);
+#endif
 }
 __device__ __forceinline__ void search(const float* lds, const IndexDims& d, float px, float py, float pz, bool active,
                                        Best4& best) {
@@ -495,16 +609,60 @@ constexpr int NCELL = GRID * GRID * GRID;      // stride of the per-body cell ar
 __host__ inline int grid_for(int64_t samples_per_body) { return samples_per_body >= (int64_t)1 << 19 ? 64 : 32; }
 constexpr float MIN_CELL = 0.04f;
 
+// Work items of a persistent kernel, handed out WITHOUT A HOT COUNTER.  One atomicAdd per item on one address was the clock of
+// the search kernel: 86,760 items in 1.07 ms and 237,000 in 2.92 ms (the two passes of a cfg3 frame) are both 12.3 ns per
+// item — what a same-address returning atomic costs on this part — whatever the search itself executed (cutting its box tests
+// from 155 to 66 per item moved the time by 2 %).  So: the first three quarters of the items are dealt out statically
+// (wavefront w of W takes w, w + W, ...: neighbours in the list go to different wavefronts), and only the last quarter — what
+// evens out the unequal luck of the static part — goes through counters: DEAL_CURSORS of them, 128 bytes apart (atomics on one
+// cache line queue behind each other like atomics on one address), each owning a stretch of the tail; a wavefront starts on
+// cursor (its number mod DEAL_CURSORS) and moves on when a stretch is used up, looking before it queues.
+constexpr int DEAL_CURSORS = 4, DEAL_STRIDE = 32, DEAL_INTS = DEAL_CURSORS * DEAL_STRIDE;
+constexpr int DEAL_STATIC_16THS = 12;
+struct ItemDealer {
+    int n_items, n_static, n_waves, next_static, seg_len, q, tried;
+    int32_t* cur;
+    __device__ ItemDealer(int n_items_, int n_waves_, int my_wave, int32_t* cursors)
+        : n_items(n_items_), n_waves(n_waves_), next_static(my_wave), q(my_wave % DEAL_CURSORS), tried(0), cur(cursors) {
+        n_static = (int)((int64_t)n_items * DEAL_STATIC_16THS / 16) / n_waves * n_waves;
+        seg_len = (n_items - n_static + DEAL_CURSORS - 1) / DEAL_CURSORS;
+    }
+    // the wavefront's next item (wave-uniform), -1 when there is none left
+    __device__ __forceinline__ int next(int lane) {
+        if (next_static < n_static) {
+            const int item = next_static;
+            next_static += n_waves;
+            return item;
+        }
+        while (tried < DEAL_CURSORS) {
+            int got = seg_len;
+            if (lane == 0) {
+                int32_t* c = cur + q * DEAL_STRIDE;
+                if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg_len) got = atomicAdd(c, 1);
+            }
+            got = __builtin_amdgcn_readfirstlane(got);
+            const int item = n_static + q * seg_len + got;
+            if (got < seg_len && item < n_items) return item;
+            q = (q + 1) % DEAL_CURSORS;
+            ++tried;
+        }
+        return -1;
+    }
+};
+
 struct WarpWs {
     int32_t *list, *cells, *sorted, *count, *cursor, *live, *occ_count, *occ_cursor, *cell_count, *cell_start, *occ_list, *cell_seed;
     float* cell_cap2;
-    static constexpr int CURSORS = 16;          // cursor rows per body (the small-batch search cuts a body's list into segments)
-    __host__ static int64_t ints(int bs, int64_t N) { return 3 * (int64_t)bs * N + (4 + CURSORS) * bs + 5 * (int64_t)bs * NCELL; }
-    __host__ static int64_t zeroed_ints(int bs) { return (4 + CURSORS) * bs + (int64_t)bs * NCELL; }      // from `count` on
+    // [list | cells | sorted](bs N each) | count, live, occ_count (bs each, padded to a cache line) | cursor, occ_cursor
+    // (DEAL_INTS per body each: ItemDealer) | cell_count | cell_start | cell_cap2 | occ_list | cell_seed (bs NCELL each)
+    __host__ static int64_t up32(int64_t v) { return (v + 31) / 32 * 32; }
+    __host__ static int64_t ints(int bs, int64_t N) { return up32(3 * (int64_t)bs * N) + up32(3 * bs) + 2 * (int64_t)bs * DEAL_INTS + 5 * (int64_t)bs * NCELL; }
+    __host__ static int64_t zeroed_ints(int bs) { return up32(3 * bs) + 2 * (int64_t)bs * DEAL_INTS + (int64_t)bs * NCELL; }      // from `count` on
     __host__ WarpWs(int32_t* ws, int bs, int64_t N) {
-        list = ws; cells = list + (int64_t)bs * N; sorted = cells + (int64_t)bs * N; count = sorted + (int64_t)bs * N;
-        cursor = count + bs; live = cursor + CURSORS * bs; occ_count = live + bs; occ_cursor = occ_count + bs;
-        cell_count = occ_cursor + bs; cell_start = cell_count + (int64_t)bs * NCELL;
+        list = ws; cells = list + (int64_t)bs * N; sorted = cells + (int64_t)bs * N; count = list + up32(3 * (int64_t)bs * N);
+        live = count + bs; occ_count = live + bs;
+        cursor = count + up32(3 * bs); occ_cursor = cursor + (int64_t)bs * DEAL_INTS;
+        cell_count = occ_cursor + (int64_t)bs * DEAL_INTS; cell_start = cell_count + (int64_t)bs * NCELL;
         cell_cap2 = reinterpret_cast<float*>(cell_start + (int64_t)bs * NCELL);
         occ_list = cell_start + 2 * (int64_t)bs * NCELL;
         cell_seed = cell_start + 3 * (int64_t)bs * NCELL;
@@ -541,7 +699,8 @@ __device__ __forceinline__ int hash_slot(int* keys, int cell) {
     return -1;                                 // table crowded: the caller falls back to the global counter
 }
 
-constexpr int CLS_ITERS = 8;                   // samples per classify workgroup = 8 x 1024
+constexpr int CLS_ITERS = 8;                   // samples per classify workgroup = 8 x 1024 (16: 0.57 / 1.08 ms per call instead of
+                                               // 0.45 / 0.96; 32: 0.43 / 1.10)
 // VEC4 (rays mode, K % 4 == 0): a thread takes FOUR CONSECUTIVE samples of one ray per step — one 16-byte load of depths, one
 // dword of merge permutation in, one dword of validity bytes out — instead of four byte-wide accesses 1,024 samples apart:
 // the pass is a stream over z / perm / mask (11 B per sample) and ran at 1.4 TB/s on byte traffic.
@@ -795,10 +954,12 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cells_kernel(const float* _
     const float r = cs * 0.8662f;                        // sqrt(3)/2, rounded up
     const float lim2 = (thr + r) * (thr + r);
     const int lane = threadIdx.x & 63;
-    constexpr int BATCH = 4;                             // cells per trip to the cursor
+    // (cells are handed out by the counter, four per trip: dead cells cost a few instructions and live ones a search — dealt out
+    // statically (ItemDealer) the pass took 0.33 ms instead of 0.25; its ~20,000 trips are not what bounds it)
+    constexpr int BATCH = 4;
     for (;;) {
         int first = 0;
-        if (lane == 0) first = atomicAdd(occ_cursor + b, BATCH);
+        if (lane == 0) first = atomicAdd(occ_cursor + (int64_t)b * DEAL_INTS, BATCH);
         first = __builtin_amdgcn_readfirstlane(first);
         if (first >= n_occ) break;
         for (int i = first; i < min(first + BATCH, n_occ); ++i) {
@@ -976,11 +1137,11 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
     const int lane = threadIdx.x & 63;
     stage_index(my_index, d.lds_floats(), lds);
     const float* gbox = lds + d.body_off();
+    ItemDealer deal(n_items, (int)gridDim.x * (WARP_THREADS / 64), (int)(threadIdx.x >> 6) * (int)gridDim.x + (int)blockIdx.x,
+                    cursor + (int64_t)b * DEAL_INTS);
     for (;;) {
-        int item = 0;
-        if (lane == 0) item = atomicAdd(cursor + b, 1);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) break;
+        const int item = deal.next(lane);
+        if (item < 0) break;
         const int i = item * lpi + lane;
         const bool go = lane < lpi && i < cnt;
         const int64_t o = (int64_t)b * N + (go ? my_list[i] : 0);
@@ -1002,7 +1163,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_kernel(
         } else {
             const int cell = cell_of(gbox, thr, G, p.x, p.y, p.z);
             best_init(best, cap[cell]);
-            search_from(lds, d, p.x, p.y, p.z, go, best, go ? cell_seed[(int64_t)b * NCELL + cell] : 0);
+            search_near(lds, d, p.x, p.y, p.z, go, best, go ? cell_seed[(int64_t)b * NCELL + cell] : 0);
             if (!go) continue;
         }
         const bool ok = blend_and_store(best, order, lbs_w, J, O2C, thr, p.x, p.y, p.z, o, pts_out, nullptr, nullptr, nullptr,
@@ -1045,21 +1206,6 @@ __device__ __forceinline__ unsigned group8_min(unsigned v) {
 __device__ __forceinline__ unsigned pick_key(float dist, float bound, unsigned tag, unsigned tag_mask) {
     return dist <= bound ? ((__float_as_uint(dist) & ~tag_mask) | tag) : PICK_NONE;
 }
-#ifndef ANR_GPOOL
-#define ANR_GPOOL 8
-#endif
-constexpr int GPOOL = ANR_GPOOL;               // list entries a wavefront takes per trip to a cursor (one per group): a training
-                                               // batch has ~100 near samples per wavefront, and a run of 64 consecutive ones is
-                                               // either all empty space or all torso — with 64 per trip the wavefronts were
-                                               // resident 28 % of the kernel's time on average, waiting for the unlucky ones.
-                                               // Pool x cursors per body, ms per call (16 bodies x 65,536 samples): 16 x 1: 0.48,
-                                               // 8 x 1: 0.61 (256 wavefronts queue on the one cursor: ~20 us per trip), 16 x 4: 0.39,
-                                               // 8 x 4: 0.38, 8 x 8: 0.36, 8 x 16: 0.37, 4 x 16: 0.40, 16 x 16: 0.41
-#ifndef ANR_GSEG
-#define ANR_GSEG 8
-#endif
-constexpr int GSEG = ANR_GSEG;                 // cursors per body (<= WarpWs::CURSORS rows of the workspace): a body's list is cut
-                                               // into that many segments, a wavefront starts on segment (its number mod GSEG)
 constexpr int GQ_ENTRIES = 64;                 // blend queue per wavefront: {sample, slots 0|1, slots 2|3}
 constexpr int GQ_BYTES = GQ_ENTRIES * 12;
 
@@ -1140,7 +1286,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_groups_kernel(
         q_n = 0;
     };
 
-    // the pool: GPOOL list entries and their points, one per lane
+    // the pool: up to 64 list entries and their points, one per lane
     int trip = 0;
     int pool_smp = 0, pool_n = 0, pool_next = 0;
     float pool_x = 0.f, pool_y = 0.f, pool_z = 0.f;
@@ -1309,6 +1455,12 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_groups_kernel(
 #ifdef ANR_SEARCH_PROF
 extern "C" int anr_search_prof_read(long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(anr_search_prof), sizeof(long long) * 8192 * 8);
+}
+extern "C" int anr_walk_prof_read(unsigned long long* host_out) {                  // reads the counters and clears them
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(anr_walk_prof), sizeof(unsigned long long) * 8);
+    if (e != hipSuccess) return (int)e;
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(anr_walk_prof), zero, sizeof zero);
 }
 extern "C" int anr_search_events_read(long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(anr_search_events), sizeof(long long) * 64 * 256);
