@@ -452,7 +452,11 @@ class Trainer:
         on the device; FlatAdam keeps its step counter there too).  Opt-in.  `with trainer.loop():` runs the loop on the
         Trainer's stream and saves the two stream fences per step; it is an optimisation, not a requirement: the GPU memory
         fault long replayed runs used to end in was a hipMemsetAsync NODE of the captured graph going stale (ROCm 7.2;
-        DESIGN.md section 4.4, tools/exp/graph_hazard_torch_only.py) and the library issues no memset any more."""
+        DESIGN.md section 4.4, tools/exp/graph_hazard_torch_only.py) and the library issues no memset any more.
+        explicit_step=True (default): a step of the shipped configuration runs as one explicit sequence of library launches
+        (fused_step.ExplicitTrainStep: forward, losses, backward, every gradient accumulated in place — no autograd graph, no
+        framework kernel between the first launch and the last); any other configuration, or a caller that patches torch's
+        random functions to inject draws, goes through the autograd Functions (autograd.py).  False: always autograd."""
         self.model, self.renderer, self.hp = anim_nerf, volume_renderer, hp
         self.body_model_params = body_model_params
         self.graph_enabled = bool(graph)

@@ -507,7 +507,7 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False, scaling="weak", fra
         last["loss"], _ = trainer.step(rays, rgbs, alphas, None, templ, fg, bg, perturb=1.0, frame_idx=frame_idx)
         return last["loss"]
 
-    with trainer.loop():                # (the Trainer's own stream for the whole loop: DESIGN section 4.4, the replay hazard)
+    with trainer.loop():                # (the Trainer's own stream for the whole loop: no stream fences per step)
         if graphed:
             # untimed set-up, like a compilation: GRAPH_WARM_STEPS eager steps, then the capture (which executes nothing)
             while trainer._graph is None:
