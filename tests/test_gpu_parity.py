@@ -617,6 +617,30 @@ def test_sparse_paths_are_bit_identical_on_random_frames(dev, smpl_table, seed):
         assert outs[0][key].max() > 0.2, "the body must be in view"
 
 
+def test_cell_sorted_search_with_two_bodies_is_bit_identical(dev, smpl_table):
+    """Two bodies per call at 2^19+ samples per body — the size from which the warp sorts its near samples by cell and
+    searches them a wavefront per 64 neighbours (per-body rows of the cell workspace, of the item hand-out's counters and
+    of the index): sparse == dense bit for bit, and the two bodies (different poses) really differ."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    hw = 96                                                         # 9,216 rays x 64 (128) samples = 589,824 (1.18 M) per body
+    m = seeded_model(smpl_table, 17, True, 3000.0, (100.0, 100.0), device=dev, mlp_mode="bf16")
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=57, bs=2, pose_std=0.35, transl_z=-2.6).items()}
+    c2w, focal, cen = syn.pinhole_camera(hw, hw)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), hw, hw, focal.tolist(), 0.1, 10.0, cen.tolist()).view(1, -1, 8).repeat(2, 1, 1)
+    vr = ana.VolumeRenderer(n_coarse=64, n_fine=64)
+    outs = []
+    for sparse in (True, False):
+        m.skip_far_samples = m.skip_invalid_samples = sparse
+        with torch.no_grad():
+            outs.append(ana.batched_inference(vr, m, rays, pose, _templ(dev), chunk=1 << 14))
+    m.skip_far_samples = m.skip_invalid_samples = True
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert outs[0]["alphas_fine"].max() > 0.2, "the bodies must be in view"
+    assert not torch.equal(outs[0]["rgbs_fine"][0], outs[0]["rgbs_fine"][1])
+
+
 def test_disparity_sampling_and_depth_guided_samples(dev, smpl_table):
     """The two VolumeRenderer options no shipped config selects: lindisp=False (models/volume_rendering.py:45-46) and
     n_fine_depth > 0 (:99-111, :204-207)."""
