@@ -146,6 +146,7 @@ SIGNATURES = {
     "anr_sample_coarse_backward_acc": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
     "anr_to_root_frame_strided": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "anr_zero_fill": (_I, [_P, _L, _P]),
+    "anr_add_inplace": (_I, [_P, _P, _L, _P]),
     "anr_knn_within": (_I, [_P, _P, _I, _I, _L, _F, _P, _P]),
     "anr_grid_points_cells": (_I, [_I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, _P, _L, _P, _P, _P]),
     "anr_scatter_relu": (_I, [_P, _P, _L, _L, _L, _P, _P]),

@@ -16,6 +16,7 @@
 //   anr_sample_coarse_backward_acc  anr_sample_coarse_backward of the sum of up to three upstream gradients, ADDED into the
 //                                 accumulated ray gradient together with the two compositors' dL/d far'
 //   anr_zero_fill                 the library's memset (anr_common.h: zero_fill)
+//   anr_add_inplace               dst += src: the normals branch's weight gradients joining the render passes'
 #include "anr_common.h"
 
 // (products and sums round separately in this file, as the framework ops they replace round them: `points + randn * scale`)
@@ -234,6 +235,26 @@ extern "C" int anr_sample_coarse_backward_acc(const float* g_a, const float* g_b
     hipLaunchKernelGGL(sample_coarse_backward_acc_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_a, g_b,
                        g_c, steps, t_rand, dfar_a, dfar_b, R, K, d_rays_acc);
     return check_launch("anr_sample_coarse_backward_acc");
+}
+
+namespace anr {
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 4 <= n && ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0)) {
+        float4 a = *reinterpret_cast<const float4*>(dst + i);
+        const float4 b = *reinterpret_cast<const float4*>(src + i);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        *reinterpret_cast<float4*>(dst + i) = a;
+    } else {
+        for (int64_t k = i; k < n && k < i + 4; ++k) dst[k] += src[k];
+    }
+}
+}  // namespace anr
+
+extern "C" int anr_add_inplace(float* dst, const float* src, int64_t n, void* stream) {
+    ANR_REQUIRE(dst && src && n > 0, ANR_E_BADARG, "anr_add_inplace: null pointer or n=%lld", (long long)n);
+    hipLaunchKernelGGL(anr::add_inplace_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+    return anr::check_launch("anr_add_inplace");
 }
 
 extern "C" int anr_zero_fill(void* ptr, int64_t bytes, void* stream) {

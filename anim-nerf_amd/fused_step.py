@@ -55,6 +55,8 @@ class ExplicitTrainStep:
         self.draw_state[0] = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
         self.last_draws = None         # the random tensors of the last step (t_rand, noise_c, u_fine, noise_f, n0, n1): for tests
         self.last_quads = None         # ... and its tangent quads (coarse, fine)
+        self._side = None              # the normals branch's stream (see run())
+        self._wgrad_stream = None      # ... and the render passes' weight gradients'
 
     # ------------------------------------------------------------------------------------------------------------------
     def supported(self, rays, body_model_params, frame_idx, fg_points, bg_points) -> bool:
@@ -94,14 +96,21 @@ class ExplicitTrainStep:
         out_full = ops.expand_rows(out_c, pos, -1e5)
         return dict(net=net, params=params, index=index, pos=pos, pts_c=pts_c, count=count, rows=rows, out_c=out_c, act=act), out_full
 
-    def _mlp_backward(self, st, mode_id, d_out_full, want_pts):
-        """activation, weight (into the network's flat buffer) and — want_pts — point gradients of one compacted pass"""
+    def _mlp_backward(self, st, mode_id, d_out_full, want_pts, keep):
+        """activation, weight (into the network's flat buffer) and — want_pts — point gradients of one compacted pass.
+        The weight gradients feed nothing else in the step: they run on a stream of their own (`_wgrad_stream`) behind the
+        backward chain, which goes on with the gradient towards the points; `keep` holds what that stream still reads."""
         params, act, rows = st["params"], st["act"], st["rows"]
         weights_generation(params[0], backward=True)
         g4 = ops.mlp_head_grad(d_out_full, st["index"], st["out_c"], st["pts_c"], st["count"], False)
         dact = ops.mlp_backward(_cached_pack(params, mode_id, True), mode_id, g4, act, count=rows)
-        enc = ops.encode64(st["pts_c"], act.dtype, count=rows)
-        ops.mlp_wgrad(mode_id, act, dact, enc, g4, accumulate_into=st["net"].grad_sink.flat, count=rows)
+        main = torch.cuda.current_stream(self.dev)
+        side = self._wgrad_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            enc = ops.encode64(st["pts_c"], act.dtype, count=rows)
+            ops.mlp_wgrad(mode_id, act, dact, enc, g4, accumulate_into=st["net"].grad_sink.flat, count=rows)
+        keep.append((g4, dact, enc))
         if not want_pts:
             return None
         d_enc = ops.mlp_denc(mode_id, dact, params[PARAM_KEYS.index("xyz_encoding_1.0.weight")],
@@ -155,6 +164,33 @@ class ExplicitTrainStep:
                                 point_scale=hp.dis_threshold * 0.5, neighbour_scale=hp.epsilon)
         self.last_draws = draws
 
+        # ---- normals regulariser, forward: both networks on the same quads (forward-mode tangents, autograd.QuadSigmaFunction).
+        # It needs the draws and the weights, nothing of the render passes, and the render passes nothing of it until the
+        # losses: it runs on a SECOND STREAM next to them (a parallel branch of the step's HIP graph) — its launches fill the
+        # CUs the render passes' small launches and MLP tails leave idle.  The weight packs are made on the step's stream
+        # BEFORE the fork (both branches read them).
+        main = torch.cuda.current_stream(dev)
+        if self._wgrad_stream is None:
+            self._wgrad_stream = torch.cuda.Stream(device=dev)
+        keep = []
+        tan = []
+        pts4 = None
+        if want_normals:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            nets = []
+            for net in (m.nerf, m.nerf_fine):
+                params = [dict(net.named_parameters())[k] for k in PARAM_KEYS]
+                nets.append((net, params, _cached_pack(params, mode_id, False)))
+            pair = draws["pair"]
+            n_pad = -(-pair.shape[0] // 16) * 16
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                pts4 = ops.tangent_quads(pair, n_pad)
+                for net, params, pack in nets:
+                    out_t, act_t = ops.mlp_forward_save(pack, mode_id, pts4, sigma_only=True, tangent=True)
+                    tan.append((net, params, act_t, out_t.view(n_pad, 4)))
+
         # ---- per-frame state (models/anim_nerf.py:108-151) from the parameter tables
         if table is not None:
             w = {n: getattr(table, n).weight for n in table.param_names}
@@ -199,18 +235,8 @@ class ExplicitTrainStep:
         _, rgb_f, dep_f, acc_f = ops.composite(out_f[:n_f].view(bs * R, K, 4), zs.view(bs * R, K), flat_rays, vr.white_bkgd,
                                                noise=noise_f, want_weights=False)
 
-        # ---- normals regulariser: both networks on the same quads (forward-mode tangents, autograd.QuadSigmaFunction)
-        tan = []
-        pts4 = enc4 = None
         if want_normals:
-            pair = draws["pair"]
-            n_pad = -(-pair.shape[0] // 16) * 16
-            pts4 = ops.tangent_quads(pair, n_pad)
-            for net in (m.nerf, m.nerf_fine):
-                params = [dict(net.named_parameters())[k] for k in PARAM_KEYS]
-                out_t, act_t = ops.mlp_forward_save(_cached_pack(params, mode_id, False), mode_id, pts4, sigma_only=True, tangent=True)
-                tan.append((net, params, act_t, out_t.view(n_pad, 4)))
-
+            main.wait_stream(self._side)                             # the losses read the quads
         self.last_quads = [x[3] for x in tan]
         # ---- losses (train.py:228-322) and their gradients: two launches
         consts = {"R": bs * R, "k": -2.0 / hp.n_samples, "lambda_alphas": hp.lambda_alphas, "lambda_foreground": hp.lambda_foreground,
@@ -245,16 +271,23 @@ class ExplicitTrainStep:
         one = self._one()
         _lib.check(lib.anr_train_loss_backward(C.byref(args), ops._ptr(one), C.byref(g), ops._stream(vals)), "anr_train_loss_backward")
 
-        # ---- backward: normals, fine pass, the merge, coarse pass, coarse depths, frame chain
+        # ---- backward: normals (on the second stream again, its weight gradients into buffers of their own), fine pass, the
+        # merge, coarse pass, coarse depths, frame chain
+        tan_grads = []
         if want_normals:
-            enc4 = None
-            for (net, params, act_t, _), dq in zip(tan, d_quads):
+            packs_b = []
+            for net, params, _, _ in tan:
                 weights_generation(params[0], backward=True)
-                g4 = ops.mlp_head_grad(dq.reshape(-1), None, None, pts4, pts4.shape[0], True)
-                dact = ops.mlp_backward(_cached_pack(params, mode_id, True), mode_id, g4, act_t, sigma_only=True, tangent=True)
-                if enc4 is None:                                     # (the same rows for both networks)
-                    enc4 = ops.encode64(pts4, act_t.dtype, tangent=True)
-                ops.mlp_wgrad(mode_id, act_t, dact, enc4, g4, sigma_only=True, tangent=True, accumulate_into=net.grad_sink.flat)
+                packs_b.append(_cached_pack(params, mode_id, True))
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                enc4 = None
+                for (net, params, act_t, _), dq, pack_b in zip(tan, d_quads, packs_b):
+                    g4 = ops.mlp_head_grad(dq.reshape(-1), None, None, pts4, pts4.shape[0], True)
+                    dact = ops.mlp_backward(pack_b, mode_id, g4, act_t, sigma_only=True, tangent=True)
+                    if enc4 is None:                                 # (the same rows for both networks)
+                        enc4 = ops.encode64(pts4, act_t.dtype, tangent=True)
+                    tan_grads.append((net, ops.mlp_wgrad(mode_id, act_t, dact, enc4, g4, sigma_only=True, tangent=True)))
         acc_buf = None
         d_o2c = d_rays = None
         if refine:
@@ -266,14 +299,14 @@ class ExplicitTrainStep:
         dz_f = dfar_f = None
         if refine:
             _, dz_f, dfar_f = res
-        d_pts_f = self._mlp_backward(st_f, mode_id, d_out_f, refine)
+        d_pts_f = self._mlp_backward(st_f, mode_id, d_out_f, refine, keep)
         dz_c_from_fine = None
         if refine:
             dzw_f = ops.warp_backward_acc(d_pts_f[:n_f].view(bs, R * K, 4), rays_b, zs, o2c, nidx_f, nw_f, d_o2c, d_rays)
             dz_c_from_fine = ops.merge_backward2(dzw_f.view(bs * R, K), dz_f, perm, Kc)
         res = ops.composite_backward(out_c[:n_c].view(bs * R, Kc, 4), zc.view(bs * R, Kc), flat_rays, vr.white_bkgd, d_rgb_c, None, d_acc_c,
                                      noise=noise_c, want_dz=refine, out=d_out_c)
-        d_pts_c = self._mlp_backward(st_c, mode_id, d_out_c, refine)
+        d_pts_c = self._mlp_backward(st_c, mode_id, d_out_c, refine, keep)
         if refine:
             _, dz_c, dfar_c = res
             dzw_c = ops.warp_backward_acc(d_pts_c[:n_c].view(bs, R * Kc, 4), rays_b, zc, o2c, nidx_c, nw_c, d_o2c, d_rays)
@@ -285,6 +318,12 @@ class ExplicitTrainStep:
             wt = {n: getattr(table, n).weight for n in table.param_names}
             ops.scatter_frame_param_grads(frame_idx, grads, wt["global_orient"].shape[0], wt["betas"].shape[0], wt["betas"].grad,
                                           wt["global_orient"].grad, wt["body_pose"].grad, wt["transl"].grad)
+        main.wait_stream(self._wgrad_stream)
+        keep.clear()
+        if want_normals:                                             # flat = render passes' + normals' (0 + r + t == 0 + t + r bit for bit)
+            main.wait_stream(self._side)
+            for net, tg in tan_grads:
+                ops.add_inplace(net.grad_sink.flat, tg)
         for s in sinks:                                              # (three passes each went straight into the flat buffers)
             s.expected = s.done = 0
         details = {k: vals[i] for i, k in enumerate(ops.LOSS_NAMES)}

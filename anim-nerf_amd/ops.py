@@ -996,6 +996,16 @@ def zero_fill(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def add_inplace(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """dst += src (fp32, contiguous, same size) by a kernel of the library (no framework launch inside the training step)."""
+    lib = _lib.load()
+    if not (torch.is_tensor(dst) and dst.is_contiguous()) or dst.numel() != src.numel():
+        raise ValueError("add_inplace: dst must be contiguous and as long as src")
+    dst, src = _dev(dst, "dst"), _dev(src, "src")
+    _lib.check(lib.anr_add_inplace(_ptr(dst), _ptr(src), dst.numel(), _stream(dst)), "anr_add_inplace")
+    return dst
+
+
 DRAW_STATE_WORDS = 35                                         # include/animnerf_hip.h: ANR_DRAW_STATE_WORDS
 
 

@@ -630,6 +630,10 @@ int anr_to_root_frame_strided(const float* global_transform, int64_t g_stride, c
 /* zero `bytes` (a multiple of 4) at a 4-byte aligned device address: a kernel, not a memset (a memset NODE of a captured HIP
  * graph went stale on ROCm 7.2: DESIGN.md section 4.4) */
 int anr_zero_fill(void* ptr, int64_t bytes, void* stream);
+/* dst[0..n) += src[0..n) (fp32): the weight gradients of the normals-regulariser branch of the explicit training step, computed
+ * on a second stream next to the render passes, joining the network's flat gradient buffer — what autograd's accumulation of
+ * models/nerf.py:177-190's and the render passes' contributions into one .grad does (train.py:324-348) */
+int anr_add_inplace(float* dst, const float* src, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }
