@@ -57,6 +57,7 @@ class ExplicitTrainStep:
         self.last_quads = None         # ... and its tangent quads (coarse, fine)
         self._side = None              # the normals branch's stream (see run())
         self._wgrad_stream = None      # ... and the render passes' weight gradients'
+        self._coarse_stream = None     # ... and the coarse pass's backward chain's
 
     # ------------------------------------------------------------------------------------------------------------------
     def supported(self, rays, body_model_params, frame_idx, fg_points, bg_points) -> bool:
@@ -294,6 +295,21 @@ class ExplicitTrainStep:
             V = o2c.shape[1]
             acc_buf = ops.zero_fill(torch.empty(bs * V * 16 + bs * R * 8, dtype=torch.float32, device=dev))
             d_o2c, d_rays = acc_buf[:bs * V * 16].view(bs, V, 4, 4), acc_buf[bs * V * 16:].view(bs, R, 8)
+        # The coarse pass's backward chain needs nothing of the fine pass's (only the coarse depths' backward, at the end, takes both):
+        # it runs on a third stream next to it.  Both chains add into d_o2c / d_rays with atomics, as either did alone.
+        for st in (st_f, st_c):                                      # both backward packs on the step's stream, before the fork
+            weights_generation(st["params"][0], backward=True)
+            _cached_pack(st["params"], mode_id, True)
+        if self._coarse_stream is None:
+            self._coarse_stream = torch.cuda.Stream(device=dev)
+        self._coarse_stream.wait_stream(main)
+        with torch.cuda.stream(self._coarse_stream):
+            res_c = ops.composite_backward(out_c[:n_c].view(bs * R, Kc, 4), zc.view(bs * R, Kc), flat_rays, vr.white_bkgd, d_rgb_c, None,
+                                           d_acc_c, noise=noise_c, want_dz=refine, out=d_out_c)
+            d_pts_c = self._mlp_backward(st_c, mode_id, d_out_c, refine, keep)
+            if refine:
+                _, dz_c, dfar_c = res_c
+                dzw_c = ops.warp_backward_acc(d_pts_c[:n_c].view(bs, R * Kc, 4), rays_b, zc, o2c, nidx_c, nw_c, d_o2c, d_rays)
         res = ops.composite_backward(out_f[:n_f].view(bs * R, K, 4), zs.view(bs * R, K), flat_rays, vr.white_bkgd, d_rgb_f, None, d_acc_f,
                                      noise=noise_f, want_dz=refine, out=d_out_f)
         dz_f = dfar_f = None
@@ -304,12 +320,8 @@ class ExplicitTrainStep:
         if refine:
             dzw_f = ops.warp_backward_acc(d_pts_f[:n_f].view(bs, R * K, 4), rays_b, zs, o2c, nidx_f, nw_f, d_o2c, d_rays)
             dz_c_from_fine = ops.merge_backward2(dzw_f.view(bs * R, K), dz_f, perm, Kc)
-        res = ops.composite_backward(out_c[:n_c].view(bs * R, Kc, 4), zc.view(bs * R, Kc), flat_rays, vr.white_bkgd, d_rgb_c, None, d_acc_c,
-                                     noise=noise_c, want_dz=refine, out=d_out_c)
-        d_pts_c = self._mlp_backward(st_c, mode_id, d_out_c, refine, keep)
+        main.wait_stream(self._coarse_stream)
         if refine:
-            _, dz_c, dfar_c = res
-            dzw_c = ops.warp_backward_acc(d_pts_c[:n_c].view(bs, R * Kc, 4), rays_b, zc, o2c, nidx_c, nw_c, d_o2c, d_rays)
             ops.sample_coarse_backward_acc(d_rays.view(bs * R, 8), steps, draws["t_rand"].view(bs * R, Kc) if jitter else None,
                                            dzw_c.view(bs * R, Kc), dz_c, dz_c_from_fine, dfar_c, dfar_f)
             c = m._chain_consts()
