@@ -17,6 +17,15 @@ most of the step.  Here the step is ~90 launches, all of this library:
               expand | warp backward          (fine, then the merge's backward, then coarse)
     coarse depths' backward | frame chain backward (4) | scatter table grads | [all-reduce] | Adam
 
+Two parts of the step feed nothing that follows them until the very end, and run on STREAMS OF THEIR OWN — parallel branches of
+the captured graph: the normals regulariser (forward next to the frame set-up and the coarse pass, backward next to the render
+passes' backward; its weight gradients go to buffers of their own and join the flat gradient with one `anr_add_inplace` per
+network), and the render passes' weight gradients (behind the activation gradients, while the backward chain goes on towards
+the points and the poses).  The weight packs both branches read are made on the step's stream before the fork.  4.27 -> 3.85 ms
+per step at 16 frames, 2.14 -> 1.83 at 2 (`tools/exp/step_timeline.py`: 1.7 ms of the step with one launch running, 1.5 with
+two, 0.7 with three; launches that share the GPU slow each other down — the sum of the kernel times goes from 4.3 to 6.9 ms —
+which is why a third branch, the coarse pass's backward chain next to the fine pass's, bought nothing at 16 frames).
+
 Gradients that autograd would sum are accumulated where they are produced: both warp backward passes add into one
 dL/d ober2cano and one dL/d rays buffer, the merge's and the coarse depths' backward kernels take their two / three upstream
 gradients as separate operands, the weight gradients of every pass add into the network's flat buffer (`GradSink`).
@@ -57,7 +66,6 @@ class ExplicitTrainStep:
         self.last_quads = None         # ... and its tangent quads (coarse, fine)
         self._side = None              # the normals branch's stream (see run())
         self._wgrad_stream = None      # ... and the render passes' weight gradients'
-        self._coarse_stream = None     # ... and the coarse pass's backward chain's
 
     # ------------------------------------------------------------------------------------------------------------------
     def supported(self, rays, body_model_params, frame_idx, fg_points, bg_points) -> bool:
@@ -295,21 +303,6 @@ class ExplicitTrainStep:
             V = o2c.shape[1]
             acc_buf = ops.zero_fill(torch.empty(bs * V * 16 + bs * R * 8, dtype=torch.float32, device=dev))
             d_o2c, d_rays = acc_buf[:bs * V * 16].view(bs, V, 4, 4), acc_buf[bs * V * 16:].view(bs, R, 8)
-        # The coarse pass's backward chain needs nothing of the fine pass's (only the coarse depths' backward, at the end, takes both):
-        # it runs on a third stream next to it.  Both chains add into d_o2c / d_rays with atomics, as either did alone.
-        for st in (st_f, st_c):                                      # both backward packs on the step's stream, before the fork
-            weights_generation(st["params"][0], backward=True)
-            _cached_pack(st["params"], mode_id, True)
-        if self._coarse_stream is None:
-            self._coarse_stream = torch.cuda.Stream(device=dev)
-        self._coarse_stream.wait_stream(main)
-        with torch.cuda.stream(self._coarse_stream):
-            res_c = ops.composite_backward(out_c[:n_c].view(bs * R, Kc, 4), zc.view(bs * R, Kc), flat_rays, vr.white_bkgd, d_rgb_c, None,
-                                           d_acc_c, noise=noise_c, want_dz=refine, out=d_out_c)
-            d_pts_c = self._mlp_backward(st_c, mode_id, d_out_c, refine, keep)
-            if refine:
-                _, dz_c, dfar_c = res_c
-                dzw_c = ops.warp_backward_acc(d_pts_c[:n_c].view(bs, R * Kc, 4), rays_b, zc, o2c, nidx_c, nw_c, d_o2c, d_rays)
         res = ops.composite_backward(out_f[:n_f].view(bs * R, K, 4), zs.view(bs * R, K), flat_rays, vr.white_bkgd, d_rgb_f, None, d_acc_f,
                                      noise=noise_f, want_dz=refine, out=d_out_f)
         dz_f = dfar_f = None
@@ -320,8 +313,12 @@ class ExplicitTrainStep:
         if refine:
             dzw_f = ops.warp_backward_acc(d_pts_f[:n_f].view(bs, R * K, 4), rays_b, zs, o2c, nidx_f, nw_f, d_o2c, d_rays)
             dz_c_from_fine = ops.merge_backward2(dzw_f.view(bs * R, K), dz_f, perm, Kc)
-        main.wait_stream(self._coarse_stream)
+        res = ops.composite_backward(out_c[:n_c].view(bs * R, Kc, 4), zc.view(bs * R, Kc), flat_rays, vr.white_bkgd, d_rgb_c, None, d_acc_c,
+                                     noise=noise_c, want_dz=refine, out=d_out_c)
+        d_pts_c = self._mlp_backward(st_c, mode_id, d_out_c, refine, keep)
         if refine:
+            _, dz_c, dfar_c = res
+            dzw_c = ops.warp_backward_acc(d_pts_c[:n_c].view(bs, R * Kc, 4), rays_b, zc, o2c, nidx_c, nw_c, d_o2c, d_rays)
             ops.sample_coarse_backward_acc(d_rays.view(bs * R, 8), steps, draws["t_rand"].view(bs * R, Kc) if jitter else None,
                                            dzw_c.view(bs * R, Kc), dz_c, dz_c_from_fine, dfar_c, dfar_f)
             c = m._chain_consts()
