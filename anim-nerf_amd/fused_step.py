@@ -18,13 +18,16 @@ most of the step.  Here the step is ~90 launches, all of this library:
     coarse depths' backward | frame chain backward (4) | scatter table grads | [all-reduce] | Adam
 
 Two parts of the step feed nothing that follows them until the very end, and run on STREAMS OF THEIR OWN — parallel branches of
-the captured graph: the normals regulariser (forward next to the frame set-up and the coarse pass, backward next to the render
-passes' backward; its weight gradients go to buffers of their own and join the flat gradient with one `anr_add_inplace` per
-network), and the render passes' weight gradients (behind the activation gradients, while the backward chain goes on towards
-the points and the poses).  The weight packs both branches read are made on the step's stream before the fork.  4.27 -> 3.85 ms
-per step at 16 frames, 2.14 -> 1.83 at 2 (`tools/exp/step_timeline.py`: 1.7 ms of the step with one launch running, 1.5 with
-two, 0.7 with three; launches that share the GPU slow each other down — the sum of the kernel times goes from 4.3 to 6.9 ms —
-which is why a third branch, the coarse pass's backward chain next to the fine pass's, bought nothing at 16 frames).
+the captured graph: the normals regulariser — all of it: forward, the gradient of its loss term (a function of its own outputs:
+the total's upstream gradient is 1), backward, weight gradients into buffers of their own that join the flat gradient with one
+`anr_add_inplace` per network — next to the frame set-up and the render passes' forward, whose searches and small launches leave
+most of the GPU idle; and the render passes' weight gradients, behind the activation gradients, while the backward chain goes on
+towards the points and the poses.  The forward weight packs both branches read are made on the step's stream before the fork
+(the normals branch packs its own backward weights).  4.27 -> 3.85 ms per step at 16 frames, 2.14 -> 1.74 at 2
+(`tools/exp/step_timeline.py`: 1.7 ms of the step with one launch running, 1.5 with two, 0.7 with three; launches that share the
+GPU slow each other down — the sum of the kernel times goes from 4.3 to 6.9 ms — which is why a third branch, the coarse pass's
+backward chain next to the fine pass's, bought nothing at 16 frames).  `ANR_STEP_BRANCHES=0` puts every launch back on the
+step's stream (debugging).
 
 Gradients that autograd would sum are accumulated where they are produced: both warp backward passes add into one
 dL/d ober2cano and one dL/d rays buffer, the merge's and the coarse depths' backward kernels take their two / three upstream
@@ -37,6 +40,7 @@ oracle's autograd (fp32 and fp64) and to the reference's own compute_loss by the
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -65,6 +69,7 @@ class ExplicitTrainStep:
         self.last_draws = None         # the random tensors of the last step (t_rand, noise_c, u_fine, noise_f, n0, n1): for tests
         self.last_quads = None         # ... and its tangent quads (coarse, fine)
         self._side = None              # the normals branch's stream (see run())
+        self.parallel = os.environ.get("ANR_STEP_BRANCHES", "1") != "0"
         self._wgrad_stream = None      # ... and the render passes' weight gradients'
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -173,17 +178,22 @@ class ExplicitTrainStep:
                                 point_scale=hp.dis_threshold * 0.5, neighbour_scale=hp.epsilon)
         self.last_draws = draws
 
-        # ---- normals regulariser, forward: both networks on the same quads (forward-mode tangents, autograd.QuadSigmaFunction).
-        # It needs the draws and the weights, nothing of the render passes, and the render passes nothing of it until the
-        # losses: it runs on a SECOND STREAM next to them (a parallel branch of the step's HIP graph) — its launches fill the
-        # CUs the render passes' small launches and MLP tails leave idle.  The weight packs are made on the step's stream
-        # BEFORE the fork (both branches read them).
+        # ---- normals regulariser (models/nerf.py:177-190, train.py:298-309): both networks on the same quads (forward-mode
+        # tangents, autograd.QuadSigmaFunction).  It needs the draws and the weights and NOTHING of the render passes — its loss
+        # term's gradient is a function of its own outputs (the total's upstream gradient is 1) — and only the loss values and
+        # Adam need it: the whole branch, forward, loss gradient, backward and weight gradients (into buffers of their own), runs
+        # on a SECOND STREAM next to the frame set-up and the render passes' forward, whose searches and small launches leave
+        # most of the GPU idle (a parallel branch of the step's HIP graph).  The forward weight packs are made on the step's
+        # stream BEFORE the fork (both branches read them); the branch packs its own backward weights.
         main = torch.cuda.current_stream(dev)
-        if self._wgrad_stream is None:
+        if not self.parallel:                                        # (debugging: every launch on the step's own stream)
+            self._side = self._wgrad_stream = main
+        elif self._wgrad_stream is None:
             self._wgrad_stream = torch.cuda.Stream(device=dev)
         keep = []
-        tan = []
-        pts4 = None
+        tan, tan_grads = [], []
+        quads_ready = None
+        one = self._one()
         if want_normals:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
@@ -193,12 +203,32 @@ class ExplicitTrainStep:
                 nets.append((net, params, _cached_pack(params, mode_id, False)))
             pair = draws["pair"]
             n_pad = -(-pair.shape[0] // 16) * 16
+            consts_n = {"lambda_normals": hp.lambda_normals, "nv": m.verts_template.shape[1], "normal_sets": m.verts_template.shape[0],
+                        "quad_rows": n_pad, "delta": 0.02}
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 pts4 = ops.tangent_quads(pair, n_pad)
                 for net, params, pack in nets:
                     out_t, act_t = ops.mlp_forward_save(pack, mode_id, pts4, sigma_only=True, tangent=True)
                     tan.append((net, params, act_t, out_t.view(n_pad, 4)))
+                quads_ready = torch.cuda.Event()
+                quads_ready.record(self._side)
+                d_quads = [torch.empty_like(tan[0][3]), torch.empty_like(tan[1][3])]
+                args_n = self._loss_args({"quads": tan[0][3], "quads_fine": tan[1][3]}, consts_n)
+                g_n = _lib.AnrLossGrads()
+                g_n.quads, g_n.quads_fine = d_quads[0].data_ptr(), d_quads[1].data_ptr()
+                _lib.check(lib.anr_train_loss_backward(C.byref(args_n), ops._ptr(one), C.byref(g_n), ops._stream(one)), "anr_train_loss_backward")
+                enc4 = None
+                for (net, params, act_t, _), dq in zip(tan, d_quads):
+                    named = dict(zip(PARAM_KEYS, params))
+                    pack_b = ops.mlp_pack(named, mode_id, backward=True)
+                    g4 = ops.mlp_head_grad(dq.reshape(-1), None, None, pts4, pts4.shape[0], True)
+                    dact = ops.mlp_backward(pack_b, mode_id, g4, act_t, sigma_only=True, tangent=True)
+                    if enc4 is None:                                 # (the same rows for both networks)
+                        enc4 = ops.encode64(pts4, act_t.dtype, tangent=True)
+                    tan_grads.append((net, ops.mlp_wgrad(mode_id, act_t, dact, enc4, g4, sigma_only=True, tangent=True)))
+                    keep.append((pack_b, g4, dact))
+                keep.append((pts4, enc4, d_quads))
 
         # ---- per-frame state (models/anim_nerf.py:108-151) from the parameter tables
         if table is not None:
@@ -245,7 +275,7 @@ class ExplicitTrainStep:
                                                noise=noise_f, want_weights=False)
 
         if want_normals:
-            main.wait_stream(self._side)                             # the losses read the quads
+            main.wait_event(quads_ready)                             # the loss values read the quads
         self.last_quads = [x[3] for x in tan]
         # ---- losses (train.py:228-322) and their gradients: two launches
         consts = {"R": bs * R, "k": -2.0 / hp.n_samples, "lambda_alphas": hp.lambda_alphas, "lambda_foreground": hp.lambda_foreground,
@@ -273,30 +303,9 @@ class ExplicitTrainStep:
         g.rgb, g.acc, g.rgb_fine, g.acc_fine = (x.data_ptr() for x in (d_rgb_c, d_acc_c, d_rgb_f, d_acc_f))
         if n_r:
             g.s, g.s_fine = d_out_c.data_ptr() + 16 * n_c, d_out_f.data_ptr() + 16 * n_f
-        d_quads = []
-        if want_normals:
-            d_quads = [torch.empty_like(tan[0][3]), torch.empty_like(tan[1][3])]
-            g.quads, g.quads_fine = d_quads[0].data_ptr(), d_quads[1].data_ptr()
-        one = self._one()
         _lib.check(lib.anr_train_loss_backward(C.byref(args), ops._ptr(one), C.byref(g), ops._stream(vals)), "anr_train_loss_backward")
 
-        # ---- backward: normals (on the second stream again, its weight gradients into buffers of their own), fine pass, the
-        # merge, coarse pass, coarse depths, frame chain
-        tan_grads = []
-        if want_normals:
-            packs_b = []
-            for net, params, _, _ in tan:
-                weights_generation(params[0], backward=True)
-                packs_b.append(_cached_pack(params, mode_id, True))
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                enc4 = None
-                for (net, params, act_t, _), dq, pack_b in zip(tan, d_quads, packs_b):
-                    g4 = ops.mlp_head_grad(dq.reshape(-1), None, None, pts4, pts4.shape[0], True)
-                    dact = ops.mlp_backward(pack_b, mode_id, g4, act_t, sigma_only=True, tangent=True)
-                    if enc4 is None:                                 # (the same rows for both networks)
-                        enc4 = ops.encode64(pts4, act_t.dtype, tangent=True)
-                    tan_grads.append((net, ops.mlp_wgrad(mode_id, act_t, dact, enc4, g4, sigma_only=True, tangent=True)))
+        # ---- backward: fine pass, the merge, coarse pass, coarse depths, frame chain (the normals' went with their forward)
         acc_buf = None
         d_o2c = d_rays = None
         if refine:
@@ -328,11 +337,11 @@ class ExplicitTrainStep:
             ops.scatter_frame_param_grads(frame_idx, grads, wt["global_orient"].shape[0], wt["betas"].shape[0], wt["betas"].grad,
                                           wt["global_orient"].grad, wt["body_pose"].grad, wt["transl"].grad)
         main.wait_stream(self._wgrad_stream)
-        keep.clear()
         if want_normals:                                             # flat = render passes' + normals' (0 + r + t == 0 + t + r bit for bit)
             main.wait_stream(self._side)
             for net, tg in tan_grads:
                 ops.add_inplace(net.grad_sink.flat, tg)
+        keep.clear()
         for s in sinks:                                              # (three passes each went straight into the flat buffers)
             s.expected = s.done = 0
         details = {k: vals[i] for i, k in enumerate(ops.LOSS_NAMES)}
