@@ -192,7 +192,6 @@ class ExplicitTrainStep:
             self._wgrad_stream = torch.cuda.Stream(device=dev)
         keep = []
         tan, tan_grads = [], []
-        quads_ready = None
         one = self._one()
         if want_normals:
             if self._side is None:
@@ -206,29 +205,41 @@ class ExplicitTrainStep:
             consts_n = {"lambda_normals": hp.lambda_normals, "nv": m.verts_template.shape[1], "normal_sets": m.verts_template.shape[0],
                         "quad_rows": n_pad, "delta": 0.02}
             self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                pts4 = ops.tangent_quads(pair, n_pad)
-                for net, params, pack in nets:
-                    out_t, act_t = ops.mlp_forward_save(pack, mode_id, pts4, sigma_only=True, tangent=True)
-                    tan.append((net, params, act_t, out_t.view(n_pad, 4)))
-                quads_ready = torch.cuda.Event()
-                quads_ready.record(self._side)
-                d_quads = [torch.empty_like(tan[0][3]), torch.empty_like(tan[1][3])]
-                args_n = self._loss_args({"quads": tan[0][3], "quads_fine": tan[1][3]}, consts_n)
-                g_n = _lib.AnrLossGrads()
-                g_n.quads, g_n.quads_fine = d_quads[0].data_ptr(), d_quads[1].data_ptr()
-                _lib.check(lib.anr_train_loss_backward(C.byref(args_n), ops._ptr(one), C.byref(g_n), ops._stream(one)), "anr_train_loss_backward")
-                enc4 = None
-                for (net, params, act_t, _), dq in zip(tan, d_quads):
-                    named = dict(zip(PARAM_KEYS, params))
-                    pack_b = ops.mlp_pack(named, mode_id, backward=True)
-                    g4 = ops.mlp_head_grad(dq.reshape(-1), None, None, pts4, pts4.shape[0], True)
-                    dact = ops.mlp_backward(pack_b, mode_id, g4, act_t, sigma_only=True, tangent=True)
-                    if enc4 is None:                                 # (the same rows for both networks)
-                        enc4 = ops.encode64(pts4, act_t.dtype, tangent=True)
-                    tan_grads.append((net, ops.mlp_wgrad(mode_id, act_t, dact, enc4, g4, sigma_only=True, tangent=True)))
-                    keep.append((pack_b, g4, dact))
-                keep.append((pts4, enc4, d_quads))
+            box = {}
+
+            # The branch is ISSUED in two pieces, each right after the step's stream has issued a long launch (the two neighbour
+            # searches): a replayed graph's nodes reach the GPU in capture order at ~12 us apiece, so twenty nodes of this branch
+            # issued first held the render passes' first launch back by 0.25 ms.
+            def normals_forward_and_first_network():
+                with torch.cuda.stream(self._side):
+                    pts4 = box["pts4"] = ops.tangent_quads(pair, n_pad)
+                    for net, params, pack in nets:
+                        out_t, act_t = ops.mlp_forward_save(pack, mode_id, pts4, sigma_only=True, tangent=True)
+                        tan.append((net, params, act_t, out_t.view(n_pad, 4)))
+                    box["quads_ready"] = torch.cuda.Event()
+                    box["quads_ready"].record(self._side)
+                    d_quads = box["d_quads"] = [torch.empty_like(tan[0][3]), torch.empty_like(tan[1][3])]
+                    args_n = self._loss_args({"quads": tan[0][3], "quads_fine": tan[1][3]}, consts_n)
+                    g_n = _lib.AnrLossGrads()
+                    g_n.quads, g_n.quads_fine = d_quads[0].data_ptr(), d_quads[1].data_ptr()
+                    _lib.check(lib.anr_train_loss_backward(C.byref(args_n), ops._ptr(one), C.byref(g_n), ops._stream(one)), "anr_train_loss_backward")
+                    box["enc4"] = ops.encode64(pts4, tan[0][2].dtype, tangent=True)      # (the same rows for both networks)
+                    normals_backward(0)
+                    keep.append((pts4, box["enc4"], d_quads))
+
+            def normals_backward(i):
+                net, params, act_t, _ = tan[i]
+                pts4 = box["pts4"]
+                named = dict(zip(PARAM_KEYS, params))
+                pack_b = ops.mlp_pack(named, mode_id, backward=True)
+                g4 = ops.mlp_head_grad(box["d_quads"][i].reshape(-1), None, None, pts4, pts4.shape[0], True)
+                dact = ops.mlp_backward(pack_b, mode_id, g4, act_t, sigma_only=True, tangent=True)
+                tan_grads.append((net, ops.mlp_wgrad(mode_id, act_t, dact, box["enc4"], g4, sigma_only=True, tangent=True)))
+                keep.append((pack_b, g4, dact))
+
+            def normals_second_network():
+                with torch.cuda.stream(self._side):
+                    normals_backward(1)
 
         # ---- per-frame state (models/anim_nerf.py:108-151) from the parameter tables
         if table is not None:
@@ -257,6 +268,8 @@ class ExplicitTrainStep:
         steps = vr._table(dev, "steps", Kc)
         zc = ops.sample_coarse(rays_b, steps, draws["t_rand"].view(bs * R, Kc) if jitter else None).view(bs, R, Kc)
         pts_c, nidx_c, nw_c = ops.warp_points(index, o2c, lbs, thr, rays=rays_b, z=zc, skip_far=True, neighbours=True)
+        if want_normals:
+            normals_forward_and_first_network()
         n_r = bs * ((fg_points.shape[1] if fg_points is not None else 0) + (bg_points.shape[1] if bg_points is not None else 0))
         st_c, out_c = self._mlp_pass(m.nerf, mode_id, pts_c.view(-1, 4), fg_points, bg_points)
         flat_rays = rays_b.view(bs * R, 8)
@@ -269,13 +282,15 @@ class ExplicitTrainStep:
         zs = zs.view(bs, R, K)
         pts_f, nidx_f, nw_f = ops.warp_points(index, o2c, lbs, thr, rays=rays_b, z=zs, skip_far=True, neighbours=True,
                                               reuse=(pts_c, None, perm, nidx_c, nw_c))
+        if want_normals:
+            normals_second_network()
         st_f, out_f = self._mlp_pass(m.nerf_fine, mode_id, pts_f.view(-1, 4), fg_points, bg_points)
         noise_f = draws["noise_f"].view(bs * R, K) if noisy else None
         _, rgb_f, dep_f, acc_f = ops.composite(out_f[:n_f].view(bs * R, K, 4), zs.view(bs * R, K), flat_rays, vr.white_bkgd,
                                                noise=noise_f, want_weights=False)
 
         if want_normals:
-            main.wait_event(quads_ready)                             # the loss values read the quads
+            main.wait_event(box["quads_ready"])                      # the loss values read the quads
         self.last_quads = [x[3] for x in tan]
         # ---- losses (train.py:228-322) and their gradients: two launches
         consts = {"R": bs * R, "k": -2.0 / hp.n_samples, "lambda_alphas": hp.lambda_alphas, "lambda_foreground": hp.lambda_foreground,
