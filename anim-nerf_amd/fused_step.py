@@ -23,7 +23,7 @@ the total's upstream gradient is 1), backward, weight gradients into buffers of 
 `anr_add_inplace` per network — next to the frame set-up and the render passes' forward, whose searches and small launches leave
 most of the GPU idle; and the render passes' weight gradients, behind the activation gradients, while the backward chain goes on
 towards the points and the poses.  The forward weight packs both branches read are made on the step's stream before the fork
-(the normals branch packs its own backward weights).  4.27 -> 3.85 ms per step at 16 frames, 2.14 -> 1.74 at 2
+(the normals branch packs its own backward weights).  4.27 -> 3.77 ms per step at 16 frames, 2.14 -> 1.73 at 2
 (`tools/exp/step_timeline.py`: 1.7 ms of the step with one launch running, 1.5 with two, 0.7 with three; launches that share the
 GPU slow each other down — the sum of the kernel times goes from 4.3 to 6.9 ms — which is why a third branch, the coarse pass's
 backward chain next to the fine pass's, bought nothing at 16 frames).  `ANR_STEP_BRANCHES=0` puts every launch back on the
