@@ -68,7 +68,8 @@ class ExplicitTrainStep:
         self.draw_state[0] = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
         self.last_draws = None         # the random tensors of the last step (t_rand, noise_c, u_fine, noise_f, n0, n1): for tests
         self.last_quads = None         # ... and its tangent quads (coarse, fine)
-        self._side = None              # the normals branch's stream (see run())
+        self._streams = None           # (the normals branch's stream, the render passes' weight gradients'): see run()
+        self._side = None
         self.parallel = os.environ.get("ANR_STEP_BRANCHES", "1") != "0"
         self._wgrad_stream = None      # ... and the render passes' weight gradients'
 
@@ -186,16 +187,16 @@ class ExplicitTrainStep:
         # most of the GPU idle (a parallel branch of the step's HIP graph).  The forward weight packs are made on the step's
         # stream BEFORE the fork (both branches read them); the branch packs its own backward weights.
         main = torch.cuda.current_stream(dev)
-        if not self.parallel:                                        # (debugging: every launch on the step's own stream)
+        if self.parallel:
+            if self._streams is None:
+                self._streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            self._side, self._wgrad_stream = self._streams
+        else:                                                        # (debugging, per-kernel timing: every launch on the step's stream)
             self._side = self._wgrad_stream = main
-        elif self._wgrad_stream is None:
-            self._wgrad_stream = torch.cuda.Stream(device=dev)
         keep = []
         tan, tan_grads = [], []
         one = self._one()
         if want_normals:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=dev)
             nets = []
             for net in (m.nerf, m.nerf_fine):
                 params = [dict(net.named_parameters())[k] for k in PARAM_KEYS]

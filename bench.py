@@ -517,8 +517,15 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False, scaling="weak", fra
         if graphed:
             # a replay launches nothing from Python, so the per-kernel HIP events come from a few EAGER steps of the same batch
             # right after the timed region (same kernels, same shapes; their host-side pace does not enter any number below)
+            # ... with every launch on ONE stream: the replayed step runs its normals branch and its weight gradients next to the
+            # render passes (fused_step.py), and a kernel's time next to another kernel says nothing about the kernel
             eager_steps = min(steps, 5)
+            branches = getattr(trainer.explicit, "parallel", None)
+            if branches:
+                trainer.explicit.parallel = False
             eager_elapsed, per_kernel, _ = ctx.timed(eager_step, eager_steps, 0)
+            if branches:
+                trainer.explicit.parallel = True
     n_rays = F * 1024
     return {
         "metric": "rays/sec, training step (64+32 samples, 256-wide MLP x2, fwd+bwd+Adam)",
@@ -536,8 +543,8 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False, scaling="weak", fra
                    "rays_per_step_per_gpu": n_rays, "grad_floats": sum(p.numel() for p in trainer.params),
                    "kernel_launches_timed_per_step": sum(v["launches"] for v in per_kernel.values()) // max(eager_steps, 1),
                    "step_launch": (("one HIP graph replay per step" if world == 1 else "forward + backward as one HIP graph replay per step")
-                                   + " (captured after %d eager steps, untimed); per-kernel times from "
-                                   "%d eager steps after the timed region, %.2f ms per step there"
+                                   + " (captured after %d eager steps, untimed; three parallel branches); per-kernel times from "
+                                   "%d eager single-stream steps after the timed region, %.2f ms per step there"
                                    % (trainer.GRAPH_WARM_STEPS, eager_steps, eager_elapsed / eager_steps * 1e3)) if graphed
                    else "eager: one launch per kernel"},
         "roofline": mlp_roofline(per_kernel, "mlp_forward_save", mode, MLP_FLOP_PER_POINT,
