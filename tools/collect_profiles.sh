@@ -61,3 +61,6 @@ for b in 2 16; do echo "bodies $b: $(python3 tools/bench_warp_small.py 30 groups
 python3 tools/step_ops.py 16 2>/dev/null | tail -4 > $DST/train_step_framework_ops.txt
 python3 -m pytest tests -m gpu -q --durations=15 2>&1 | tail -22 > $DST/gpu_test_durations.txt
 ls $DST
+# round 4, second half: the replayed step's parallel branches (which launches run next to which)
+python3 tools/exp/step_timeline.py $OUT/cfg4_trace > $DST/train_step_timeline.txt
+python3 tools/exp/step_timeline.py $OUT/cfg4_f2_trace > $DST/train_step_timeline_f2.txt
