@@ -121,17 +121,25 @@ class ExplicitTrainStep:
         dact = ops.mlp_backward(_cached_pack(params, mode_id, True), mode_id, g4, act, count=rows)
         main = torch.cuda.current_stream(self.dev)
         side = self._wgrad_stream
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            enc = ops.encode64(st["pts_c"], act.dtype, count=rows)
-            ops.mlp_wgrad(mode_id, act, dact, enc, g4, accumulate_into=st["net"].grad_sink.flat, count=rows)
-        keep.append((g4, dact, enc))
-        if not want_pts:
-            return None
-        d_enc = ops.mlp_denc(mode_id, dact, params[PARAM_KEYS.index("xyz_encoding_1.0.weight")],
-                             params[PARAM_KEYS.index("xyz_encoding_5.0.weight")], count=rows)
-        d_pts_c = ops.encode_backward(st["pts_c"], d_enc, count=rows)
-        return ops.expand_rows(d_pts_c, st["pos"], 0.0)
+        side.wait_stream(main)                                       # (the fork is HERE: the weight gradients wait for dact only)
+
+        def weight_gradients():
+            with torch.cuda.stream(side):
+                enc = ops.encode64(st["pts_c"], act.dtype, count=rows)
+                ops.mlp_wgrad(mode_id, act, dact, enc, g4, accumulate_into=st["net"].grad_sink.flat, count=rows)
+            keep.append((g4, dact, enc))
+
+        # (issued AFTER the chain's next launches: the graph executor keeps the successor captured first on the queue of the
+        # activation gradients and moves the other one to a queue that may be busy with the normals branch's tail — with the
+        # weight gradients first, the chain towards the points waited there: 1.64 against 1.7-1.9 ms per step at 2 frames)
+        out = None
+        if want_pts:
+            d_enc = ops.mlp_denc(mode_id, dact, params[PARAM_KEYS.index("xyz_encoding_1.0.weight")],
+                                 params[PARAM_KEYS.index("xyz_encoding_5.0.weight")], count=rows)
+            d_pts_c = ops.encode_backward(st["pts_c"], d_enc, count=rows)
+            out = ops.expand_rows(d_pts_c, st["pos"], 0.0)
+        weight_gradients()
+        return out
 
     def _loss_args(self, t, consts):
         a = _lib.AnrLossArgs()
