@@ -20,6 +20,7 @@ ANR_MLP_FLAG_SIGMA_ONLY = 0x400
 ANR_MLP_FLAG_TANGENT = 0x800
 ANR_MLP_FLAG_ACCUMULATE = 0x1000
 ANR_MLP_FLAG_VIEW = 0x2000
+ANR_MLP_FLAG_BACKGROUND = 0x4000
 ANR_MAX_SAMPLES = 256
 
 

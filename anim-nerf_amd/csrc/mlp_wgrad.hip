@@ -396,11 +396,16 @@ struct Layout {
 };
 const Layout& layout() { static Layout L; return L; }
 
-int splits_for(int64_t n, int stage_rows, int gemms) {
+int splits_for(int64_t n, int stage_rows, int gemms, int background) {
     // one workgroup per CU (the LDS ring admits one) over the GEMMs of one shape, at least 4 stages per task
     int64_t want = (256 + gemms - 1) / gemms;
     int64_t most = n / (4 * stage_rows);
     int64_t s = want < most ? want : most;
+    // ANR_MLP_FLAG_BACKGROUND: half of them.  256 workgroups of 96 KB LDS and 110 MB of partial products per call leave the
+    // launches this one runs next to nowhere to go: with half, the training step (its weight gradients on a stream of their
+    // own behind the backward chain) goes from 3.80 to 3.67 ms at 16 frames and from 1.85 to 1.56 at 2 frames per rank; a
+    // quarter: 3.91 / 1.58.  (A lone call on 131,072 rows is 22 % slower with half the slices: not the default.)
+    if (background) s /= 2;
     return (int)(s < 1 ? 1 : s);
 }
 }  // namespace
@@ -415,7 +420,7 @@ extern "C" int64_t anr_mlp_wgrad_ws_floats(int64_t n) {
 
 template <bool BF16>
 static int wgrad_launch(const void* act, const void* dact, const void* enc, const float* g4, int64_t n, int sigma_only,
-                        int tangent, int accumulate, float* ws, float* grads, hipStream_t st, const int32_t* count) {
+                        int tangent, int accumulate, float* ws, float* grads, hipStream_t st, const int32_t* count, int background) {
     using C = WgCfg<BF16>;
     const Layout& L = layout();
     WgradSegs segs{};
@@ -437,7 +442,7 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
         a.tangent = tangent;
         a.count = count;
         const int n_g = sigma_only ? 7 : 8;
-        a.splits = splits_for(n, C::SR, n_g);
+        a.splits = splits_for(n, C::SR, n_g, background);
         a.rows_per_split = (int)(((n + a.splits - 1) / a.splits + C::SR - 1) / C::SR * C::SR);
         constexpr int BLK = 65536 + 256;                       // [M][N] + the M column sums
         for (int l = 2; l <= 8; ++l) {
@@ -465,8 +470,8 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
         WgradArgs a{};
         a.tangent = tangent;
         a.count = count;
-        a.splits = splits_for(n, C::SR, 2);
-        if (a.splits > 64) a.splits = 64;
+        a.splits = splits_for(n, C::SR, 2, background);
+        if (a.splits > (background ? 32 : 64)) a.splits = background ? 32 : 64;
         a.rows_per_split = (int)(((n + a.splits - 1) / a.splits + C::SR - 1) / C::SR * C::SR);
         constexpr int BLK = 256 * 64 + 256;
         for (int l : {1, 5}) {
@@ -487,7 +492,7 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
         WgradArgs a{};
         a.tangent = tangent;
         a.count = count;
-        a.splits = splits_for(n, C::SR, 1);
+        a.splits = splits_for(n, C::SR, 1, background);
         a.rows_per_split = (int)(((n + a.splits - 1) / a.splits + C::SR - 1) / C::SR * C::SR);
         constexpr int BLK = 128 * 256 + 128;
         a.g[0] = WgradGemm{2304, 0, 2048, ws_off, 1};
@@ -540,13 +545,14 @@ extern "C" int anr_mlp_wgrad_counted(int mode, const void* act, const void* dact
     ANR_REQUIRE(!tan || so, ANR_E_BADARG, "anr_mlp_wgrad: tangent mode = sigma only");
     hipStream_t st = (hipStream_t)stream;
     const int accumulate = (mode & ANR_MLP_FLAG_ACCUMULATE) ? 1 : 0;
+    const int bg = (mode & ANR_MLP_FLAG_BACKGROUND) ? 1 : 0;
     if (so && !accumulate) {                                         // tensors this call does not produce: zeros
         const Layout& L = layout();
         if (int rc = zero_fill(grads_out + L.fw, sizeof(float) * (L.total - L.fw), st, "anr_mlp_wgrad (zero)")) return rc;
     }
     switch (mode & 0xff) {
-        case ANR_MLP_BF16: return wgrad_launch<true>(act, dact, enc, g4, n, so, tan, accumulate, workspace, grads_out, st, count);
-        case ANR_MLP_F32:  return wgrad_launch<false>(act, dact, enc, g4, n, so, tan, accumulate, workspace, grads_out, st, count);
+        case ANR_MLP_BF16: return wgrad_launch<true>(act, dact, enc, g4, n, so, tan, accumulate, workspace, grads_out, st, count, bg);
+        case ANR_MLP_F32:  return wgrad_launch<false>(act, dact, enc, g4, n, so, tan, accumulate, workspace, grads_out, st, count, bg);
         default: return fail(ANR_E_BADARG, "anr_mlp_wgrad: unknown mode %d", mode);
     }
 }

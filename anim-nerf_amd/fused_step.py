@@ -23,7 +23,7 @@ the total's upstream gradient is 1), backward, weight gradients into buffers of 
 `anr_add_inplace` per network — next to the frame set-up and the render passes' forward, whose searches and small launches leave
 most of the GPU idle; and the render passes' weight gradients, behind the activation gradients, while the backward chain goes on
 towards the points and the poses.  The forward weight packs both branches read are made on the step's stream before the fork
-(the normals branch packs its own backward weights).  4.27 -> 3.77 ms per step at 16 frames, 2.14 -> 1.73 at 2
+(the normals branch packs its own backward weights).  4.27 -> 3.66 ms per step at 16 frames, 2.14 -> 1.57 at 2
 (`tools/exp/step_timeline.py`: 1.7 ms of the step with one launch running, 1.5 with two, 0.7 with three; launches that share the
 GPU slow each other down — the sum of the kernel times goes from 4.3 to 6.9 ms — which is why a third branch, the coarse pass's
 backward chain next to the fine pass's, bought nothing at 16 frames).  `ANR_STEP_BRANCHES=0` puts every launch back on the
@@ -126,7 +126,7 @@ class ExplicitTrainStep:
         def weight_gradients():
             with torch.cuda.stream(side):
                 enc = ops.encode64(st["pts_c"], act.dtype, count=rows)
-                ops.mlp_wgrad(mode_id, act, dact, enc, g4, accumulate_into=st["net"].grad_sink.flat, count=rows)
+                ops.mlp_wgrad(mode_id, act, dact, enc, g4, accumulate_into=st["net"].grad_sink.flat, count=rows, background=self.parallel)
             keep.append((g4, dact, enc))
 
         # (issued AFTER the chain's next launches: the graph executor keeps the successor captured first on the queue of the
@@ -243,7 +243,7 @@ class ExplicitTrainStep:
                 pack_b = ops.mlp_pack(named, mode_id, backward=True)
                 g4 = ops.mlp_head_grad(box["d_quads"][i].reshape(-1), None, None, pts4, pts4.shape[0], True)
                 dact = ops.mlp_backward(pack_b, mode_id, g4, act_t, sigma_only=True, tangent=True)
-                tan_grads.append((net, ops.mlp_wgrad(mode_id, act_t, dact, box["enc4"], g4, sigma_only=True, tangent=True)))
+                tan_grads.append((net, ops.mlp_wgrad(mode_id, act_t, dact, box["enc4"], g4, sigma_only=True, tangent=True, background=self.parallel)))
                 keep.append((pack_b, g4, dact))
 
             def normals_second_network():

@@ -438,7 +438,8 @@ _WGRAD_WS = {}
 
 
 def mlp_wgrad(mode: int, act: torch.Tensor, dact: torch.Tensor, enc: torch.Tensor, g4: torch.Tensor, sigma_only: bool = False,
-              tangent: bool = False, accumulate_into: Optional[torch.Tensor] = None, count: Optional[torch.Tensor] = None):
+              tangent: bool = False, accumulate_into: Optional[torch.Tensor] = None, count: Optional[torch.Tensor] = None,
+              background: bool = False):
     """All 22 parameter gradients of one network from the saved activations, the activation gradients, the encoding matrix
     (encode64) and g4 = (dL/d rgb_pre, dL/d sigma): a flat fp32 tensor in the order of autograd.PARAM_KEYS (PyTorch
     [out][in] layouts).  Hand-written split-K MFMA GEMMs (csrc/mlp_wgrad.hip); n % 64 == 0."""
@@ -446,6 +447,8 @@ def mlp_wgrad(mode: int, act: torch.Tensor, dact: torch.Tensor, enc: torch.Tenso
     act, dact, enc, g4 = _dev(act, "act", act.dtype), _dev(dact, "dact", act.dtype), _dev(enc, "enc", act.dtype), _dev(g4, "g4")
     n = act.shape[0]
     m = (mode & 0xff) | (ANR_MLP_FLAG_SIGMA_ONLY if sigma_only else 0) | (ANR_MLP_FLAG_TANGENT if tangent else 0)
+    if background:                                         # runs next to other launches: half the slices (ANR_MLP_FLAG_BACKGROUND)
+        m |= _lib.ANR_MLP_FLAG_BACKGROUND
     key = (act.device.index, torch.cuda.current_stream(act.device).cuda_stream)
     ws = _WGRAD_WS.get(key)
     need = lib.anr_mlp_wgrad_ws_floats(n)

@@ -58,6 +58,10 @@ extern "C" {
 #define ANR_MLP_FLAG_ACCUMULATE 0x1000
 /* anr_mlp_pack_bytes: the pack of a network with the view-dependent colour head fused (anr_mlp_pack_view / anr_mlp_forward_view) */
 #define ANR_MLP_FLAG_VIEW 0x2000
+/* anr_mlp_wgrad: the call runs NEXT TO other launches (a side stream, a parallel branch of a captured graph): half the
+ * split-K slices — half the workgroups and half the partial products.  A lone call is ~20 % slower that way; next to the
+ * backward chain of a training step it leaves the chain's launches room to run. */
+#define ANR_MLP_FLAG_BACKGROUND 0x4000
 
 int         anr_version(void);
 const char* anr_last_error(void);
