@@ -218,8 +218,9 @@ class ExplicitTrainStep:
 
             # The branch is ISSUED in two pieces, each right after the step's stream has issued a long launch (the two neighbour
             # searches): a replayed graph's nodes reach the GPU in capture order at ~12 us apiece, so twenty nodes of this branch
-            # issued first held the render passes' first launch back by 0.25 ms.
-            def normals_forward_and_first_network():
+            # issued first held the render passes' first launch back by 0.25 ms.  (Its three forward launches issued at the
+            # fork, next to the frame set-up's small ones: 3.66 / 1.58-1.83 ms per step against 3.61 / 1.56.)
+            def normals_forward():
                 with torch.cuda.stream(self._side):
                     pts4 = box["pts4"] = ops.tangent_quads(pair, n_pad)
                     for net, params, pack in nets:
@@ -227,6 +228,10 @@ class ExplicitTrainStep:
                         tan.append((net, params, act_t, out_t.view(n_pad, 4)))
                     box["quads_ready"] = torch.cuda.Event()
                     box["quads_ready"].record(self._side)
+
+            def normals_first_network():
+                with torch.cuda.stream(self._side):
+                    pts4 = box["pts4"]
                     d_quads = box["d_quads"] = [torch.empty_like(tan[0][3]), torch.empty_like(tan[1][3])]
                     args_n = self._loss_args({"quads": tan[0][3], "quads_fine": tan[1][3]}, consts_n)
                     g_n = _lib.AnrLossGrads()
@@ -278,7 +283,8 @@ class ExplicitTrainStep:
         zc = ops.sample_coarse(rays_b, steps, draws["t_rand"].view(bs * R, Kc) if jitter else None).view(bs, R, Kc)
         pts_c, nidx_c, nw_c = ops.warp_points(index, o2c, lbs, thr, rays=rays_b, z=zc, skip_far=True, neighbours=True)
         if want_normals:
-            normals_forward_and_first_network()
+            normals_forward()
+            normals_first_network()
         n_r = bs * ((fg_points.shape[1] if fg_points is not None else 0) + (bg_points.shape[1] if bg_points is not None else 0))
         st_c, out_c = self._mlp_pass(m.nerf, mode_id, pts_c.view(-1, 4), fg_points, bg_points)
         flat_rays = rays_b.view(bs * R, 8)
