@@ -1552,3 +1552,85 @@ def test_explicit_step_equals_the_autograd_step(dev, smpl_table, mode, frames):
     used = torch.zeros(40, dtype=torch.bool)
     used[frame_idx.cpu()] = True
     assert (g_pose[~used].abs().max() == 0) and (g_pose[used].abs().sum(-1) > 0).all()
+
+
+def test_add_inplace_and_background_weight_gradients(dev):
+    """anr_add_inplace (dst += src, any length and alignment) and ANR_MLP_FLAG_BACKGROUND (anr_mlp_wgrad with half the split-K
+    slices: the same sums cut differently — equal to the plain call within fp32 rounding of the partial sums)."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import ops
+    from anim_nerf_amd.autograd import PARAM_KEYS
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 7, 1024, 592388):
+        a, b = torch.randn(n + 1, generator=g).to(dev), torch.randn(n + 1, generator=g).to(dev)
+        for off in (0, 1):                                            # (off = 1: not 16-byte aligned)
+            want = a[off:off + n] + b[off:off + n]
+            dst = a[off:off + n].clone() if off == 0 else a.clone()[off:off + n]
+            ops.add_inplace(dst, b[off:off + n])
+            assert torch.equal(dst, want), (n, off)
+    torch.manual_seed(0)
+    net = ana.NeRF(freqs_dir=0, use_view=False).to(dev)
+    named = dict(net.named_parameters())
+    P = {k: named[k].detach() for k in PARAM_KEYS}
+    for mode_name in ("bf16", "f32"):
+        mode = ops.MLP_MODES[mode_name]
+        n = 40960
+        pts = torch.cat([torch.rand(n, 3, generator=g) * 2 - 1, torch.ones(n, 1)], -1).to(dev)
+        g4 = torch.randn(n, 4, generator=g).to(dev)
+        _, act = ops.mlp_forward_save(ops.mlp_pack(P, mode), mode, pts)
+        dact = ops.mlp_backward(ops.mlp_pack(P, mode, backward=True), mode, g4, act)
+        enc = ops.encode64(pts, act.dtype)
+        plain = ops.mlp_wgrad(mode, act, dact, enc, g4)
+        half = ops.mlp_wgrad(mode, act, dact, enc, g4, background=True)
+        err = (plain - half).norm() / plain.norm()
+        assert err < 2e-6, (mode_name, err.item())
+        count = torch.tensor([20480], dtype=torch.int32, device=dev)
+        a = ops.mlp_wgrad(mode, act, dact, enc, g4, count=count)
+        b = ops.mlp_wgrad(mode, act, dact, enc, g4, count=count, background=True)
+        assert (a - b).norm() / a.norm() < 2e-6 and (a - plain).norm() / plain.norm() > 1e-3        # (half the rows: other sums)
+
+
+def test_explicit_step_branches_on_and_off(dev, smpl_table):
+    """The explicit step with its parallel branches (the normals regulariser and the weight gradients on streams of their own)
+    against the same step with every launch on one stream (ExplicitTrainStep.parallel = False; ANR_STEP_BRANCHES=0): the same
+    draws (the counter is rewound), the same loss terms and gradients up to the order of the atomics' additions."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    frames, H = 2, 16
+    c2w, focal, cen = syn.pinhole_camera(H, H)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), H, H, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(frames, 1, 1, 1).contiguous()
+    gen = torch.Generator().manual_seed(4)
+    rgbs = torch.rand(frames, H, H, 3, generator=gen).to(dev)
+    alphas = (torch.rand(frames, H, H, 1, generator=gen) > 0.5).float().to(dev)
+    fg = (torch.rand(frames, 96, 3, generator=gen) * 0.4 - 0.2).to(dev)
+    bg = (torch.rand(frames, 64, 3, generator=gen) * 2 - 1).to(dev)
+    frame_idx = torch.tensor([5, 17], device=dev)
+    seeded = syn.animated_pose_params(seed=200, bs=40)
+    m = seeded_model(smpl_table, 11, True, 300.0, (2.0, 2.0), device=dev, mlp_mode="bf16")
+    m.train()
+    table = ana.BodyModelParams(40).to(dev)
+    for name in table.param_names:
+        table.init_parameters(name, torch.from_numpy(seeded[name]).to(dev), requires_grad=True)
+    hp = ana.TrainHParams(n_samples=64, n_importance=32, chunk=2048)
+    tr = ana.Trainer(m, ana.VolumeRenderer(n_coarse=64, n_fine=32), hp, body_model_params=table)
+    assert tr.explicit is not None and tr.explicit.parallel
+    args = (rays, rgbs, alphas, None, _templ(dev), fg, bg, 1.0, frame_idx)
+    state0 = tr.explicit.draw_state.clone()
+    out = []
+    for parallel in (True, False, True):
+        tr.explicit.parallel = parallel
+        tr.explicit.draw_state.copy_(state0)
+        loss, det = tr._step_body(*args, apply=False)
+        torch.cuda.synchronize()
+        grads = {k: p.grad.clone() for k, p in list(m.named_parameters()) + list(table.named_parameters())
+                 if p.grad is not None and not k.startswith("body_model.")}
+        out.append((loss.item(), {k: v.item() for k, v in det.items()}, grads))
+    for la, da, ga in out[1:]:
+        lb, db, gb = out[0]
+        assert abs(la - lb) <= 1e-6 * abs(lb), (la, lb)
+        for k in db:
+            assert abs(da[k] - db[k]) <= 1e-6 * abs(db[k]) + 1e-9, (k, da[k], db[k])
+        assert set(ga) == set(gb) and len(gb) >= 2 * 24 + 4
+        for k in gb:
+            err = (ga[k] - gb[k]).norm() / gb[k].norm().clamp_min(1e-20)
+            assert err < 1e-4, (k, err.item())
