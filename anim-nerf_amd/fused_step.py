@@ -22,8 +22,8 @@ the captured graph: the normals regulariser — all of it: forward, the gradient
 the total's upstream gradient is 1), backward, weight gradients into buffers of their own that join the flat gradient with one
 `anr_add_inplace` per network — next to the frame set-up and the render passes' forward, whose searches and small launches leave
 most of the GPU idle; and the render passes' weight gradients, behind the activation gradients, while the backward chain goes on
-towards the points and the poses.  The forward weight packs both branches read are made on the step's stream before the fork
-(the normals branch packs its own backward weights).  4.27 -> 3.66 ms per step at 16 frames, 2.14 -> 1.57 at 2
+towards the points and the poses.  The forward weight packs both branches read are made on the step's stream before the fork,
+the backward ones on the weight gradients' stream meanwhile.  4.27 -> 3.66 ms per step at 16 frames, 2.14 -> 1.57 at 2
 (`tools/exp/step_timeline.py`: 1.7 ms of the step with one launch running, 1.5 with two, 0.7 with three; launches that share the
 GPU slow each other down — the sum of the kernel times goes from 4.3 to 6.9 ms — which is why a third branch, the coarse pass's
 backward chain next to the fine pass's, bought nothing at 16 frames).  `ANR_STEP_BRANCHES=0` puts every launch back on the
@@ -100,25 +100,28 @@ class ExplicitTrainStep:
         return body_model_params is not None and not any(torch.is_tensor(v) and v.requires_grad for v in body_model_params.values())
 
     # ------------------------------------------------------------------------------------------------------------------
-    def _mlp_pass(self, net, mode_id, pts, fg, bg):
+    def _mlp_pass(self, net, mode_id, pts, fg, bg, pack=None):
         """compacted training forward of one network on pts[n,4] (+ the prior points as riders): -> state for the backward,
         out_full[n + n_r, 4]"""
         params = [dict(net.named_parameters())[k] for k in PARAM_KEYS]
-        pack = _cached_pack(params, mode_id, False)
+        if pack is None:
+            pack = _cached_pack(params, mode_id, False)
         index, pos, pts_c, count = ops.compact_ordered_riders(pts, fg, bg)
         rows = count[1:2]
         out_c, act = ops.mlp_forward_save(pack, mode_id, pts_c, False, count=rows)
         out_full = ops.expand_rows(out_c, pos, -1e5)
         return dict(net=net, params=params, index=index, pos=pos, pts_c=pts_c, count=count, rows=rows, out_c=out_c, act=act), out_full
 
-    def _mlp_backward(self, st, mode_id, d_out_full, want_pts, keep):
+    def _mlp_backward(self, st, mode_id, d_out_full, want_pts, keep, pack_b=None):
         """activation, weight (into the network's flat buffer) and — want_pts — point gradients of one compacted pass.
         The weight gradients feed nothing else in the step: they run on a stream of their own (`_wgrad_stream`) behind the
         backward chain, which goes on with the gradient towards the points; `keep` holds what that stream still reads."""
         params, act, rows = st["params"], st["act"], st["rows"]
-        weights_generation(params[0], backward=True)
+        if pack_b is None:
+            weights_generation(params[0], backward=True)
+            pack_b = _cached_pack(params, mode_id, True)
         g4 = ops.mlp_head_grad(d_out_full, st["index"], st["out_c"], st["pts_c"], st["count"], False)
-        dact = ops.mlp_backward(_cached_pack(params, mode_id, True), mode_id, g4, act, count=rows)
+        dact = ops.mlp_backward(pack_b, mode_id, g4, act, count=rows)
         main = torch.cuda.current_stream(self.dev)
         side = self._wgrad_stream
         side.wait_stream(main)                                       # (the fork is HERE: the weight gradients wait for dact only)
@@ -204,11 +207,22 @@ class ExplicitTrainStep:
         keep = []
         tan, tan_grads = [], []
         one = self._one()
+        # The four weight packs of the step, up front: the forward ones on the step's stream (both branches read them), the
+        # backward ones on the weight gradients' stream, which has nothing to do until the backward pass — two launches off the
+        # chain between the losses and the first activation gradients.  (Forward first: a backward pack marks the generation.)
+        nets = []
+        for net in (m.nerf, m.nerf_fine):
+            params = [dict(net.named_parameters())[k] for k in PARAM_KEYS]
+            nets.append((net, params, _cached_pack(params, mode_id, False)))
+        self._wgrad_stream.wait_stream(main)
+        with torch.cuda.stream(self._wgrad_stream):
+            packs_b = []
+            for net, params, _ in nets:
+                weights_generation(params[0], backward=True)
+                packs_b.append(_cached_pack(params, mode_id, True))
+            packs_b_ready = torch.cuda.Event()
+            packs_b_ready.record(self._wgrad_stream)
         if want_normals:
-            nets = []
-            for net in (m.nerf, m.nerf_fine):
-                params = [dict(net.named_parameters())[k] for k in PARAM_KEYS]
-                nets.append((net, params, _cached_pack(params, mode_id, False)))
             pair = draws["pair"]
             n_pad = -(-pair.shape[0] // 16) * 16
             consts_n = {"lambda_normals": hp.lambda_normals, "nv": m.verts_template.shape[1], "normal_sets": m.verts_template.shape[0],
@@ -238,18 +252,17 @@ class ExplicitTrainStep:
                     g_n.quads, g_n.quads_fine = d_quads[0].data_ptr(), d_quads[1].data_ptr()
                     _lib.check(lib.anr_train_loss_backward(C.byref(args_n), ops._ptr(one), C.byref(g_n), ops._stream(one)), "anr_train_loss_backward")
                     box["enc4"] = ops.encode64(pts4, tan[0][2].dtype, tangent=True)      # (the same rows for both networks)
+                    self._side.wait_event(packs_b_ready)
                     normals_backward(0)
                     keep.append((pts4, box["enc4"], d_quads))
 
             def normals_backward(i):
                 net, params, act_t, _ = tan[i]
                 pts4 = box["pts4"]
-                named = dict(zip(PARAM_KEYS, params))
-                pack_b = ops.mlp_pack(named, mode_id, backward=True)
                 g4 = ops.mlp_head_grad(box["d_quads"][i].reshape(-1), None, None, pts4, pts4.shape[0], True)
-                dact = ops.mlp_backward(pack_b, mode_id, g4, act_t, sigma_only=True, tangent=True)
+                dact = ops.mlp_backward(packs_b[i], mode_id, g4, act_t, sigma_only=True, tangent=True)
                 tan_grads.append((net, ops.mlp_wgrad(mode_id, act_t, dact, box["enc4"], g4, sigma_only=True, tangent=True, background=self.parallel)))
-                keep.append((pack_b, g4, dact))
+                keep.append((g4, dact))
 
             def normals_second_network():
                 with torch.cuda.stream(self._side):
@@ -286,7 +299,7 @@ class ExplicitTrainStep:
             normals_forward()
             normals_first_network()
         n_r = bs * ((fg_points.shape[1] if fg_points is not None else 0) + (bg_points.shape[1] if bg_points is not None else 0))
-        st_c, out_c = self._mlp_pass(m.nerf, mode_id, pts_c.view(-1, 4), fg_points, bg_points)
+        st_c, out_c = self._mlp_pass(m.nerf, mode_id, pts_c.view(-1, 4), fg_points, bg_points, nets[0][2])
         flat_rays = rays_b.view(bs * R, 8)
         noise_c = draws["noise_c"].view(bs * R, Kc) if noisy else None
         w_c, rgb_c, dep_c, acc_c = ops.composite(out_c[:n_c].view(bs * R, Kc, 4), zc.view(bs * R, Kc), flat_rays, vr.white_bkgd,
@@ -299,7 +312,7 @@ class ExplicitTrainStep:
                                               reuse=(pts_c, None, perm, nidx_c, nw_c))
         if want_normals:
             normals_second_network()
-        st_f, out_f = self._mlp_pass(m.nerf_fine, mode_id, pts_f.view(-1, 4), fg_points, bg_points)
+        st_f, out_f = self._mlp_pass(m.nerf_fine, mode_id, pts_f.view(-1, 4), fg_points, bg_points, nets[1][2])
         noise_f = draws["noise_f"].view(bs * R, K) if noisy else None
         _, rgb_f, dep_f, acc_f = ops.composite(out_f[:n_f].view(bs * R, K, 4), zs.view(bs * R, K), flat_rays, vr.white_bkgd,
                                                noise=noise_f, want_weights=False)
@@ -347,14 +360,15 @@ class ExplicitTrainStep:
         dz_f = dfar_f = None
         if refine:
             _, dz_f, dfar_f = res
-        d_pts_f = self._mlp_backward(st_f, mode_id, d_out_f, refine, keep)
+        main.wait_event(packs_b_ready)
+        d_pts_f = self._mlp_backward(st_f, mode_id, d_out_f, refine, keep, packs_b[1])
         dz_c_from_fine = None
         if refine:
             dzw_f = ops.warp_backward_acc(d_pts_f[:n_f].view(bs, R * K, 4), rays_b, zs, o2c, nidx_f, nw_f, d_o2c, d_rays)
             dz_c_from_fine = ops.merge_backward2(dzw_f.view(bs * R, K), dz_f, perm, Kc)
         res = ops.composite_backward(out_c[:n_c].view(bs * R, Kc, 4), zc.view(bs * R, Kc), flat_rays, vr.white_bkgd, d_rgb_c, None, d_acc_c,
                                      noise=noise_c, want_dz=refine, out=d_out_c)
-        d_pts_c = self._mlp_backward(st_c, mode_id, d_out_c, refine, keep)
+        d_pts_c = self._mlp_backward(st_c, mode_id, d_out_c, refine, keep, packs_b[0])
         if refine:
             _, dz_c, dfar_c = res
             dzw_c = ops.warp_backward_acc(d_pts_c[:n_c].view(bs, R * Kc, 4), rays_b, zc, o2c, nidx_c, nw_c, d_o2c, d_rays)
