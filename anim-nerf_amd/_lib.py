@@ -21,6 +21,7 @@ ANR_MLP_FLAG_TANGENT = 0x800
 ANR_MLP_FLAG_ACCUMULATE = 0x1000
 ANR_MLP_FLAG_VIEW = 0x2000
 ANR_MLP_FLAG_BACKGROUND = 0x4000
+ANR_MLP_FLAG_BITS_ONLY = ANR_MLP_FLAG_ENC_ONLY = 0x8000
 ANR_MAX_SAMPLES = 256
 
 
@@ -74,6 +75,7 @@ SIGNATURES = {
     "anr_frame_backward": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
     "anr_frame_backward_ws_floats": (_L, [_I, _I]),
     "anr_frame_backward_adjoint": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "anr_frame_backward_adjoint_values": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "anr_to_root_frame": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "anr_rays_to_body": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "anr_ober2cano": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _P]),
@@ -107,6 +109,8 @@ SIGNATURES = {
     "anr_mlp_wgrad_floats": (_L, []),
     "anr_mlp_wgrad_ws_floats": (_L, [_L]),
     "anr_mlp_denc": (_I, [_I, _P, _P, _P, _L, _P, _P]),
+    "anr_mlp_dpoints": (_I, [_P, _I, _P, _P, _L, _P, _P, _P]),
+    "anr_warp_backward_compact": (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P]),
     "anr_mlp_wgrad": (_I, [_I, _P, _P, _P, _P, _L, _P, _P, _P]),
     "anr_encode_backward": (_I, [_P, _I, _P, _L, _P, _P]),
     "anr_mlp_bwd_pack_bytes": (_L, [_I]),
@@ -140,6 +144,8 @@ SIGNATURES = {
     "anr_adam_chunk_bytes": (_I, []),
     "anr_adam_step": (_I, [_P, _I, _P, C.POINTER(_F), _I, C.c_double, C.c_double, C.c_double, _P]),
     "anr_compact_ordered_riders": (_I, [_P, _L, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "anr_compact_state_words": (_L, [_L]),
+    "anr_compact_ordered_single": (_I, [_P, _L, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "anr_train_draws": (_I, [_P, _P, _P]),
     "anr_gather_frame_params": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "anr_scatter_frame_param_grads": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
@@ -148,6 +154,9 @@ SIGNATURES = {
     "anr_to_root_frame_strided": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "anr_zero_fill": (_I, [_P, _L, _P]),
     "anr_add_inplace": (_I, [_P, _P, _L, _P]),
+    "anr_copy_segments": (_I, [_P, _P, _P, _I, _P]),
+    "anr_frame_setup": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I]
+                        + [_P] * 13 + [_P, _P]),
     "anr_knn_within": (_I, [_P, _P, _I, _I, _L, _F, _P, _P]),
     "anr_grid_points_cells": (_I, [_I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, _P, _L, _P, _P, _P]),
     "anr_scatter_relu": (_I, [_P, _P, _L, _L, _L, _P, _P]),

@@ -144,6 +144,47 @@ class AnimNeRF(nn.Module):
         if body_model_params_template is not None and not self._same_template(body_model_params_template):
             self._set_template(body_model_params_template)
 
+    def frame_setup(self, body_model_params, body_model_params_template, rays):
+        """set_body_model + convert_to_body_model_space + clac_ober2cano_transform for a batch of frames, -> the rays in the
+        root-joint frame.  On the GPU, in the kernels' forms, the three are TWO launches (ops.frame_setup, csrc/frame_setup.hip:
+        eight before); anything else (CPU, gradients that must flow through torch's own autograd, another body model) takes the
+        three calls.  Both training steps — the explicit one and the autograd one — set their frames up through the same
+        kernels, so they render the same bits."""
+        p = body_model_params
+        names = ("betas", "global_orient", "body_pose", "transl")
+        bm = self.body_model
+        fast = (rays.is_cuda and bm.v_template.is_cuda and body_model_params_template is not None
+                and all(torch.is_tensor(p.get(k)) and p[k].is_cuda and p[k].dtype == torch.float32 for k in names)
+                and bm.lbs_weights.shape[1] == 24 and bm.shapedirs.shape[-1] == 10 and p["betas"].shape[-1] == 10
+                and p["body_pose"].shape[-1] == 69 and rays.shape[-1] == 8 and rays.dim() == 3
+                and not any(torch.is_tensor(v) and v.requires_grad for v in body_model_params_template.values()))
+        if not fast:
+            self.set_body_model(body_model_params, body_model_params_template)
+            rays = self.convert_to_body_model_space(rays)
+            self.clac_ober2cano_transform()
+            return rays
+        self._refine = None
+        if torch.is_grad_enabled() and any(p[k].requires_grad for k in names):
+            self._refine = dict(p)                              # (pose refinement: the chain's backward is attached below)
+        if not self._same_template(body_model_params_template):
+            with torch.no_grad():
+                self._set_template(body_model_params_template)
+        bs = rays.shape[0]
+        with torch.no_grad():
+            arrays = (p["betas"].detach().expand(bs, -1).contiguous(), p["global_orient"].detach().expand(bs, -1).contiguous(),
+                      p["body_pose"].detach().expand(bs, -1).contiguous(), p["transl"].detach().expand(bs, -1).contiguous())
+            o = ops.frame_setup(arrays, None, self._chain_consts(), bm,
+                                (self.verts_transform_template, self.shape_offsets_template, self.pose_offsets_template), rays.detach())
+        self.shape_offsets, self.pose_offsets, self.joints_transform = o["shape_offsets"], o["pose_offsets"], o["A"]
+        self.global_transform, self.verts, self.joints, self.verts_transform = o["g_root"], o["verts"], o["joints"], o["verts_transform"]
+        self._knn_index = None
+        self._o2c_attached = None
+        new_rays, o2c = o["rays_body"], o["ober2cano"]
+        if self._refine is not None:
+            new_rays, o2c = self._attach_chain(new_rays, rays.detach(), o2c)
+        self.ober2cano_transform = o2c
+        return new_rays
+
     def _set_template(self, body_model_params_template):
         t = self.body_model(**body_model_params_template, return_verts=True)
         self.verts_template = t["vertices"]

@@ -52,14 +52,15 @@ def bump_generation(params):
         torch.autograd.graph.increment_version(params)
 
 
-def _cached_pack(params, mode_id, backward):
+def _cached_pack(params, mode_id, backward, frozen=False):
     """Fragment-ordered weight pack for the forward / activation-gradient kernels, rebuilt only when a parameter changed:
     one pack per network and optimiser step, not one per ray chunk.  Keyed by the parameter OBJECTS (weak references: a
     new tensor that happens to reuse a freed one's address and version counter must not hit), their version counters and
-    the generation above."""
+    the generation above.  frozen: no optimiser touches these tensors (requires_grad False, the `_refine` stage): the
+    version counters alone decide — the packs of a frozen network are made once per run, not once per step."""
     import weakref
     key = (mode_id, backward, tuple(id(p) for p in params))
-    ver = (tuple(p._version for p in params), weights_generation(params[0], backward))
+    ver = (tuple(p._version for p in params), "frozen" if frozen else weights_generation(params[0], backward))
     hit = _PACKS.get(key)
     if hit is None or hit[0] != ver or any(r() is not p for r, p in zip(hit[2], params)):
         if len(_PACKS) > 64:

@@ -315,11 +315,26 @@ __global__ __launch_bounds__(FB_THREADS) void frame_adjoint_kernel(
     const float* __restrict__ J0, const float* __restrict__ JS, const int64_t* __restrict__ parents,
     const float* __restrict__ lbs_w, const float* __restrict__ T_templ, int64_t templ_stride,
     const float* __restrict__ rays_world, int ray_stride, int R, const float* __restrict__ d_o2c,
-    const float* __restrict__ d_rays, int V, int n_vblocks, float* __restrict__ acc, float* __restrict__ goff) {
+    const float* __restrict__ d_rays, int V, int n_vblocks, float* __restrict__ acc, float* __restrict__ goff,
+    const float* __restrict__ A_fwd, const float* __restrict__ Ginv_fwd) {
     __shared__ ChainLds L;
     __shared__ float sAcc[FA_ACC];
     const int b = blockIdx.y;
-    run_chain(L, b, -1, -1, betas, pose, transl, J0, JS, parents);
+    if (A_fwd != nullptr && Ginv_fwd != nullptr) {
+        // the VALUES of the chain as the forward kernels left them (anr_smpl_forward's joints_transform, with transl on its
+        // translation column; anr_to_root_frame's inverse root transform): no 24-step chain per workgroup (25 of this kernel's
+        // 89 us at 2 frames)
+        for (int i = threadIdx.x; i < FB_J * 12; i += FB_THREADS) {
+            const int j = i / 12, e = i % 12;
+            float a = A_fwd[((int64_t)b * FB_J + j) * 16 + e];
+            if ((e & 3) == 3) a -= transl[b * 3 + (e >> 2)];
+            L.A[j][e][0] = a;
+        }
+        if (threadIdx.x < 12) L.G[threadIdx.x][0] = Ginv_fwd[(int64_t)b * 16 + threadIdx.x];
+        if (threadIdx.x < 3) L.Tr[threadIdx.x][0] = transl[b * 3 + threadIdx.x];
+    } else {
+        run_chain(L, b, -1, -1, betas, pose, transl, J0, JS, parents);
+    }
     for (int i = threadIdx.x; i < FA_ACC; i += FB_THREADS) sAcc[i] = 0.0f;
     __syncthreads();
     float Gi[12];
@@ -448,23 +463,31 @@ __global__ __launch_bounds__(FB_THREADS) void frame_adjoint_kernel(
         if (sAcc[i] != 0.0f) atomicAdd(&acc[(int64_t)b * FA_ACC + i], sAcc[i]);
 }
 
-__global__ __launch_bounds__(FB_THREADS) void frame_offsets_kernel(const float* __restrict__ goff, const float* __restrict__ shapedirs,
+// (1,024 threads per dot product of length 3 V = 20,670: 21 loads per thread instead of 81 — the kernel is a latency chain,
+// 42 us at 2 frames with 256; fixed-order tree: the same bits on every run)
+constexpr int FO_THREADS = 1024;
+__global__ __launch_bounds__(FO_THREADS) void frame_offsets_kernel(const float* __restrict__ goff, const float* __restrict__ shapedirs,
                                                                    const float* __restrict__ posedirs, int V, float* __restrict__ H) {
-    __shared__ float sRed[FB_THREADS / 64];
+    __shared__ float sRed[FO_THREADS / 64];
     const int b = blockIdx.y, f = blockIdx.x;
     const float* gb = goff + (int64_t)b * V * 3;
     float s = 0.0f;
     if (f < 207) {
         const float* pd = posedirs + (int64_t)f * 3 * V;
-        for (int i = threadIdx.x; i < 3 * V; i += FB_THREADS) s += gb[i] * pd[i];
+        for (int i = threadIdx.x; i < 3 * V; i += FO_THREADS) s += gb[i] * pd[i];
     } else {
         const int k = f - 207;
-        for (int i = threadIdx.x; i < 3 * V; i += FB_THREADS) s += gb[i] * shapedirs[(int64_t)i * FB_NB + k];
+        for (int i = threadIdx.x; i < 3 * V; i += FO_THREADS) s += gb[i] * shapedirs[(int64_t)i * FB_NB + k];
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) H[(int64_t)b * FA_H + f] = -((sRed[0] + sRed[1]) + (sRed[2] + sRed[3]));
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < FO_THREADS / 64; w += 4) t += (sRed[w] + sRed[w + 1]) + (sRed[w + 2] + sRed[w + 3]);
+        H[(int64_t)b * FA_H + f] = -t;
+    }
 }
 
 __global__ __launch_bounds__(64) void frame_params_kernel(
@@ -518,8 +541,21 @@ extern "C" int anr_frame_backward_adjoint(const float* betas, const float* pose,
                                           const float* posedirs, int V, const float* T_template, int template_bs,
                                           const float* rays_world, int ray_stride, int R, const float* d_ober2cano,
                                           const float* d_rays_body, float* workspace, float* grads_out, void* stream) {
+    return anr_frame_backward_adjoint_values(betas, pose, transl, bs, J0, JS, parents, lbs_weights, shapedirs, posedirs, V, T_template,
+                                             template_bs, rays_world, ray_stride, R, d_ober2cano, d_rays_body, nullptr, nullptr, workspace,
+                                             grads_out, stream);
+}
+
+extern "C" int anr_frame_backward_adjoint_values(const float* betas, const float* pose, const float* transl, int bs, const float* J0,
+                                                 const float* JS, const int64_t* parents, const float* lbs_weights, const float* shapedirs,
+                                                 const float* posedirs, int V, const float* T_template, int template_bs,
+                                                 const float* rays_world, int ray_stride, int R, const float* d_ober2cano,
+                                                 const float* d_rays_body, const float* joints_transform, const float* g_inv,
+                                                 float* workspace, float* grads_out, void* stream) {
     ANR_REQUIRE(betas && pose && transl && J0 && JS && parents && lbs_weights && shapedirs && posedirs && T_template &&
                 (d_ober2cano || d_rays_body) && workspace && grads_out, ANR_E_BADARG, "anr_frame_backward_adjoint: null pointer");
+    ANR_REQUIRE((joints_transform == nullptr) == (g_inv == nullptr), ANR_E_BADARG,
+                "anr_frame_backward_adjoint_values: joints_transform and g_inv come together");
     ANR_REQUIRE(bs > 0 && V > 0 && (template_bs == 1 || template_bs == bs), ANR_E_BADARG,
                 "anr_frame_backward_adjoint: bs=%d V=%d template_bs=%d", bs, V, template_bs);
     ANR_REQUIRE(!d_rays_body || (rays_world && R > 0 && ray_stride >= 8), ANR_E_BADARG, "anr_frame_backward_adjoint: rays R=%d stride=%d", R,
@@ -533,9 +569,9 @@ extern "C" int anr_frame_backward_adjoint(const float* betas, const float* pose,
     const int nrb = d_rays_body ? (R + FB_THREADS - 1) / FB_THREADS : 0;
     hipLaunchKernelGGL(frame_adjoint_kernel, dim3(nvb + nrb, bs), dim3(FB_THREADS), 0, st, betas, pose, transl, J0, JS, parents,
                        lbs_weights, T_template, template_bs == 1 ? (int64_t)0 : (int64_t)V * 16, rays_world, ray_stride, R, d_ober2cano,
-                       d_rays_body, V, nvb, acc, goff);
+                       d_rays_body, V, nvb, acc, goff, joints_transform, g_inv);
     if (d_ober2cano)
-        hipLaunchKernelGGL(frame_offsets_kernel, dim3(FA_H, bs), dim3(FB_THREADS), 0, st, goff, shapedirs, posedirs, V, H);
+        hipLaunchKernelGGL(frame_offsets_kernel, dim3(FA_H, bs), dim3(FO_THREADS), 0, st, goff, shapedirs, posedirs, V, H);
     hipLaunchKernelGGL(frame_params_kernel, dim3(FB_NP, bs), dim3(64), 0, st, betas, pose, transl, J0, JS, parents, acc,
                        d_ober2cano ? H : (const float*)nullptr, grads_out);
     return check_launch("anr_frame_backward_adjoint");

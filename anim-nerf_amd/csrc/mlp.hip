@@ -23,6 +23,9 @@ ANR_PRE(ANR_MLP_F32, false) ANR_PRE(ANR_MLP_F32, true) ANR_PRE(ANR_MLP_BF16_W8, 
 extern template int launch_mlp<ANR_MLP_F32, true, false, true, true>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*, const float*, int, int);
 extern template int launch_mlp<ANR_MLP_BF16_W8, true, false, true, true>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*, const float*, int, int);
 
+extern template int launch_mlp<ANR_MLP_F32, true, false, true, false, false, false, true>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*, const float*, int, int);
+extern template int launch_mlp<ANR_MLP_BF16_W8, true, false, true, false, false, false, true>(const void*, const float*, int64_t, float*, hipStream_t, float*, const int32_t*, const int32_t*, const float*, int, int);
+
 // ---------------------------------------------------------------------------------------------
 // weight packing: one thread per (frag, lane) 16-byte piece; tail threads fill the bias table
 struct PackStage {
@@ -191,6 +194,14 @@ extern "C" int anr_mlp_forward_save_indexed(const void* pack, int mode, const fl
         switch (mode & 0xff) {
             case ANR_MLP_F32:  return launch_mlp<ANR_MLP_F32, true, true, true, false, true>(pack, pts, n, out, st, act);
             case ANR_MLP_BF16: return launch_mlp<ANR_MLP_BF16_W8, true, true, true, false, true>(pack, pts, n, out, st, act);
+            default: return fail(ANR_E_BADARG, "anr_mlp_forward_save: unknown mode %d", mode);
+        }
+    }
+    if (mode & ANR_MLP_FLAG_BITS_ONLY) {
+        ANR_REQUIRE(!so, ANR_E_BADARG, "anr_mlp_forward_save: ANR_MLP_FLAG_BITS_ONLY serves the full network (rgb + sigma)");
+        switch (mode & 0xff) {
+            case ANR_MLP_F32:  return launch_mlp<ANR_MLP_F32, true, false, true, false, false, false, true>(pack, pts, n, out, st, act, index, count);
+            case ANR_MLP_BF16: return launch_mlp<ANR_MLP_BF16_W8, true, false, true, false, false, false, true>(pack, pts, n, out, st, act, index, count);
             default: return fail(ANR_E_BADARG, "anr_mlp_forward_save: unknown mode %d", mode);
         }
     }

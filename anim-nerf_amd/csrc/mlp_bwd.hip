@@ -18,16 +18,6 @@
 
 namespace anr {
 
-constexpr int BWD_TABLE_BYTES = 1024;          // w_sigma, 256 fp32, in accumulator-register order per tile
-constexpr int BWD_TILES = 76;
-
-template <class C> __host__ __device__ constexpr int btile_frags(int t) { return t < 4 ? 4 : t < 12 ? C::DF : C::HF; }
-template <class C> __host__ __device__ constexpr int bfrag_offset(int t) {
-    int n = 0;
-    for (int i = 0; i < t; ++i) n += btile_frags<C>(i);
-    return n;
-}
-template <class C> constexpr int btotal_frags() { return bfrag_offset<C>(BWD_TILES); }
 // column (block = column / 32 of the blocked buffers) of the activation whose sign gates out-tile t, and where its result is stored
 __host__ __device__ constexpr int bcol(int t) {
     return t < 4 ? 2304 + 32 * t : t < 12 ? 2048 + 32 * (t - 4) : 256 * (7 - (t - 12) / 8) + 32 * ((t - 12) % 8);
@@ -37,7 +27,11 @@ __host__ __device__ constexpr bool bmasked(int t) { return !(t >= 4 && t < 12); 
 // START: the first tile of the chain = where the upstream gradient enters: 0 (d rgb' and d sigma), 12 (FEATURE: d
 // xyz_encoding_final[256] and d sigma — the view-dependent colour head, use_view=True, lives outside the kernels and hands
 // over the gradient of its input), 20 (sigma only).
-template <int MODE, int START>
+// ENC_ONLY (ANR_MLP_FLAG_ENC_ONLY): the networks are frozen and only the gradient towards the sample points is wanted —
+// dact is written where anr_mlp_denc reads it (the gradients of layers 1 and 5: tiles 68..75 and 36..43) and nowhere else.
+__host__ __device__ constexpr bool bstored(int t, bool enc_only) { return !enc_only || (t >= 36 && t < 44) || (t >= 68 && t < 76); }
+
+template <int MODE, int START, bool ENC_ONLY = false>
 struct MlpBwd {
     static constexpr bool SIGMA_ONLY = START == 20, FEATURE = START == 12;
     using C = Cfg<MODE>;
@@ -75,8 +69,8 @@ struct MlpBwd {
     BlockWalk dact_blk;          // the block of dact the next epilogue stores into (mlp_core.h)
     unsigned gate_off[NT];       // row * 32 + 16 * half of the row whose sign bits gate this lane's column, and of the next point tile's
     unsigned gate_off_next[NT];
-    unsigned dact_off[NT];       // byte offset of this lane's row (+ 4*half features) inside a block of dact (rows past the end
-                                 // alias the last row: same values, same bytes)
+    unsigned dact_off[NT];       // byte offset of this lane's row inside a piece array of dact + its half-wave's array (row * 16 +
+                                 // half * 16 R; rows past the end alias the last row: same values, same bytes)
     char* lds_bits;              // this wave's [2 buffers][NT][64 lanes x 16 B] of gathered sign bits
     static constexpr int ESZ = sizeof(ActT);
 
@@ -126,7 +120,7 @@ struct MlpBwd {
     static __host__ __device__ constexpr int stores_since_dma(int T) {
         const int first = T == FIRST ? BWD_TILES - TPC : T - TPC, last = T == FIRST ? BWD_TILES - 1 : T - 1;
         int n = 0;
-        for (int U = first; U <= last; ++U) n += (U - 1 >= FIRST) ? (C::IS_BF16 ? 2 : 4) : 0;
+        for (int U = first; U <= last; ++U) n += (U - 1 >= FIRST && bstored(U - 1, ENC_ONLY)) ? (C::IS_BF16 ? 2 : 4) : 0;
         return n * NT;
     }
     template <int T> __device__ __forceinline__ void advance() {
@@ -165,8 +159,14 @@ struct MlpBwd {
         int half;
         template <int Q> __device__ __forceinline__ void part() const {
             parts<Q>();
-            // on to the block of the next tile of the chain (the schedule walks the blocks in a static order)
-            if constexpr (Q == 3 && TG + 1 < BWD_TILES) db.template step<bcol(TG + 1) / 32 - bcol(TG) / 32>();
+            // db walks the piece arrays (mlp_core.h: two per store instruction, UPB steps per block) in the static order of the
+            // schedule: on inside the block after a store, and behind the tile's last one to the block of the next tile of the chain
+            constexpr int UPB = C::IS_BF16 ? 2 : 4;
+            if constexpr (Q == 3) {
+                if constexpr (TG + 1 < BWD_TILES) db.template step<(bcol(TG + 1) / 32 - bcol(TG) / 32) * UPB - (UPB - 1)>();
+            } else if constexpr (!C::IS_BF16 || (Q & 1)) {
+                db.template step<1>();
+            }
         }
         template <int Q> __device__ __forceinline__ void parts() const {
 #pragma unroll
@@ -195,15 +195,15 @@ struct MlpBwd {
                     d4[((4 * Q) % EPF) / 2 + 1] = pk[1];
                     dst = __builtin_bit_cast(Frag, d4);
                     if ((4 * Q + 4) % EPF == 0) pin(dst);
-                    // the two half-waves hold alternate 8-byte pieces of a row; one v_permlane32_swap per dword hands the lower
-                    // half-wave both pieces of the even quarter and the upper one both of the odd quarter: 16-byte stores, 32
-                    // contiguous bytes per row and instruction (8-byte pieces: 16) — half the store instructions
-                    if constexpr (Q & 1) {
+                    // the two half-waves hold alternate 8-byte halves of a 16-byte piece of the row; one v_permlane32_swap per dword
+                    // hands the lower half-wave both halves of the even quarter's piece and the upper one both of the odd
+                    // quarter's: 16-byte stores, a whole piece per lane, 512 contiguous bytes per half-wave (mlp_core.h)
+                    if constexpr ((Q & 1) && bstored(TG, ENC_ONLY)) {
                         const u32x4 prev = __builtin_bit_cast(u32x4, Y[n][TB + (4 * (Q - 1)) / EPF]);
                         constexpr int pd = ((4 * (Q - 1)) % EPF) / 2;
                         const auto s0 = __builtin_amdgcn_permlane32_swap(prev[pd], pk[0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(prev[pd + 1], pk[1], false, false);
-                        *reinterpret_cast<g_uint4*>(db.p + dof[n] + (16 * (Q >> 1) + 4 * half) * ESZ) = u32x4n{s0[0], s1[0], s0[1], s1[1]};
+                        act_store(reinterpret_cast<g_uint4*>(db.p + dof[n]), u32x4n{s0[0], s1[0], s0[1], s1[1]});    // piece 2 (Q >> 1) + half
                     }
                 } else {
                     f32x4 keep;
@@ -215,7 +215,7 @@ struct MlpBwd {
                         keep[i] = v;
                     }
                     if ((4 * Q + 4) % EPF == 0) pin(Y[n][TB + (4 * Q) / EPF]);
-                    *reinterpret_cast<g_f32x4*>(db.p + dof[n] + 8 * Q * ESZ) = keep;
+                    if constexpr (bstored(TG, ENC_ONLY)) act_store(reinterpret_cast<g_f32x4*>(db.p + dof[n]), keep);   // piece 2 Q + half
                 }
             }
         }
@@ -372,7 +372,7 @@ struct MlpBwd {
                 gin[n] = g_next[n];
                 dsig[n] = gin[n].w;
                 gate_off[n] = gate_off_next[n];
-                dact_off[n] = ((unsigned)rows_of(pt, n) * 32 + 4 * half) * ESZ;
+                dact_off[n] = (unsigned)rows_of(pt, n) * 16u + (unsigned)half * (unsigned)(R * 16);
                 if (more) {                                   // the next tile's upstream gradient arrives under this tile's MFMAs
                     const int64_t cl = rows_of(pt + gridDim.x, n);
                     g_next[n] = g[cl];
@@ -387,8 +387,8 @@ struct MlpBwd {
                 first = false;
             }
             // the first epilogue of the chain: tile 0 (rgb^T), 4 (FEATURE: d feature enters through dir^T's), 12 (sigma only)
-            dact_blk.stride = act_block_off(R, ESZ, 1);
-            dact_blk.reset(dact_base, bcol(FEATURE ? 4 : SIGMA_ONLY ? 12 : 0) / 32);
+            dact_blk.stride = 2 * 16 * R;                     // two piece arrays per store instruction
+            dact_blk.reset(dact_base, bcol(FEATURE ? 4 : SIGMA_ONLY ? 12 : 0) / 32 * (C::IS_BF16 ? 2 : 4));
             Frag A[NT][HF], B[NT][HF];
             if constexpr (FEATURE) {
                 // dF comes from outside (fp32 [n][256]): through the epilogue of the stage that would have produced it —
@@ -415,9 +415,12 @@ struct MlpBwd {
                         for (int t = 0; t < 4; ++t)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                char* dst = dact_base + act_block_off(R, ESZ, bcol(t) / 32) + dact_off[n] + 8 * q * ESZ;
-                                if constexpr (C::IS_BF16) *reinterpret_cast<uint2*>(dst) = make_uint2(0u, 0u);
-                                else *reinterpret_cast<f32x4*>(dst) = f32x4{0.f, 0.f, 0.f, 0.f};
+                                // features 8 q + 4 half .. + 3 of the row: bf16 half a piece (piece q), fp32 piece 2 q + half
+                                const int64_t row16 = (int64_t)rows_of(pt, n) * 16;
+                                if constexpr (C::IS_BF16)
+                                    *reinterpret_cast<uint2*>(dact_base + act_piece_off(R, ESZ, bcol(t) / 32, q) + row16 + 8 * half) = make_uint2(0u, 0u);
+                                else
+                                    *reinterpret_cast<f32x4*>(dact_base + act_piece_off(R, ESZ, bcol(t) / 32, 2 * q + half) + row16) = f32x4{0.f, 0.f, 0.f, 0.f};
                             }
                 layer<12, 8, HF, HF, HF>(A, B, NoEpi{}, dsig);                              // final^T: dF -> dh8' (B)
                 layer<20, 8, HF, HF, HF>(B, A, last_of<12, 8, HF>(B), dsig);                // W8^T   : dh8' -> dh7' (A)
@@ -474,23 +477,23 @@ struct MlpBwd {
     }
 };
 
-template <int MODE, int START>
+template <int MODE, int START, bool ENC_ONLY = false>
 __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void mlp_bwd_kernel(
     const char* __restrict__ pack, const float4* __restrict__ g, const void* __restrict__ act, void* __restrict__ dact,
     int64_t n_pts, int tangent, const float* __restrict__ dfeat, const int32_t* __restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    using M = MlpBwd<MODE, START>;
+    using M = MlpBwd<MODE, START, ENC_ONLY>;
     M m;
     m.run(pack, g, reinterpret_cast<const typename M::ActT*>(act), reinterpret_cast<typename M::ActT*>(dact), n_pts, lds, tangent,
           dfeat, count);
 }
 
-template <int MODE, int START>
+template <int MODE, int START, bool ENC_ONLY = false>
 int launch_mlp_bwd(const void* pack, const float* g, const void* act, void* dact, int64_t n, hipStream_t st, int tangent = 0,
                    const float* dfeat = nullptr, const int32_t* count = nullptr) {
     using C = Cfg<MODE>;
-    const int lds = BWD_TABLE_BYTES + 3 * MlpBwd<MODE, START>::SLOT + C::WAVES * 2 * C::NT * 1024;    // + the gathered sign bits
-    auto kern = mlp_bwd_kernel<MODE, START>;
+    const int lds = BWD_TABLE_BYTES + 3 * MlpBwd<MODE, START, ENC_ONLY>::SLOT + C::WAVES * 2 * C::NT * 1024;    // + the gathered sign bits
+    auto kern = mlp_bwd_kernel<MODE, START, ENC_ONLY>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail((int)e, "anr_mlp_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
     const int pts_per_wg = C::WAVES * C::NT * 32;
@@ -508,7 +511,8 @@ int launch_mlp_bwd(const void* pack, const float* g, const void* act, void* dact
 //   row  = input feature 32 t' + i of the forward layer (t' = tile inside its stage)
 //   k    = output feature of the forward layer in the slot order of the gradient fragments (mlp_core.h header)
 struct BwdStage { const float* W; int ld, in_off, in_dim, out_dim, tile0, nf; };
-struct BwdPlan { BwdStage s[10]; const float* w_sigma; };
+struct BwdPlan { BwdStage s[10]; const float* w_sigma; const float* w1; const float* w5; };
+
 
 template <int MODE>
 __global__ void mlp_bwd_pack_kernel(BwdPlan plan, char* __restrict__ pack) {
@@ -540,11 +544,22 @@ __global__ void mlp_bwd_pack_kernel(BwdPlan plan, char* __restrict__ pack) {
         } else {
             *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
         }
-    } else {
+    } else if (gid - n_pieces < BWD_TABLE_BYTES / 4) {
         const int64_t bi = gid - n_pieces;                 // w_sigma table: [tile j][half][reg]
-        if (bi >= BWD_TABLE_BYTES / 4) return;
         const int j = (int)(bi / 32), h = (int)((bi % 32) / 16), reg = (int)(bi % 16);
         reinterpret_cast<float*>(pack)[bi] = plan.w_sigma[32 * j + 8 * (reg >> 2) + 4 * h + (reg & 3)];
+    } else {
+        const int64_t pe = gid - n_pieces - BWD_TABLE_BYTES / 4;      // one element of the encoding panels
+        if (pe >= DENC_PANEL_ELEMS) return;
+        constexpr int EPL = C::IS_BF16 ? 8 : 1, KF = C::IS_BF16 ? 16 : 128;
+        const int e = (int)(pe % EPL), i = (int)(pe / EPL);
+        const int l = i & 63, nt = (i >> 6) & 1, kf = (i >> 7) % KF, layer = (i >> 7) / KF;
+        const int j = (l & 31) + 32 * nt, h = l >> 5;
+        const int k = C::IS_BF16 ? 16 * kf + 8 * (e >> 2) + 4 * h + (e & 3) : 2 * kf + h;
+        const float v = j < 63 ? (layer ? plan.w5[(int64_t)k * 319 + j] : plan.w1[(int64_t)k * 63 + j]) : 0.0f;
+        char* dst = pack + denc_panel_off<C>();
+        if constexpr (C::IS_BF16) reinterpret_cast<__bf16*>(dst)[pe] = (__bf16)v;
+        else reinterpret_cast<float*>(dst)[pe] = v;
     }
 }
 
@@ -554,8 +569,8 @@ using namespace anr;
 
 extern "C" int64_t anr_mlp_bwd_pack_bytes(int mode) {
     switch (mode & 0xff) {
-        case ANR_MLP_F32:  return BWD_TABLE_BYTES + (int64_t)btotal_frags<Cfg<ANR_MLP_F32>>() * FRAG_BYTES;
-        case ANR_MLP_BF16: return BWD_TABLE_BYTES + (int64_t)btotal_frags<Cfg<ANR_MLP_BF16>>() * FRAG_BYTES;
+        case ANR_MLP_F32:  return denc_panel_off<Cfg<ANR_MLP_F32>>() + denc_panel_bytes<Cfg<ANR_MLP_F32>>();
+        case ANR_MLP_BF16: return denc_panel_off<Cfg<ANR_MLP_BF16>>() + denc_panel_bytes<Cfg<ANR_MLP_BF16>>();
         default: return ANR_E_BADARG;
     }
 }
@@ -574,12 +589,15 @@ extern "C" int anr_mlp_bwd_pack(const anr_mlp_params* p, int mode, void* pack_ou
         plan.s[3 + s] = BwdStage{p->w_trunk[l], l == 4 ? 319 : 256, l == 4 ? 63 : 0, 256, 256, 20 + 8 * s, 0};
     }
     plan.w_sigma = p->w_sigma;
+    ANR_REQUIRE(p->w_trunk[0], ANR_E_BADARG, "anr_mlp_bwd_pack: null trunk tensor 0");
+    plan.w1 = p->w_trunk[0];
+    plan.w5 = p->w_trunk[4];
     hipStream_t st = (hipStream_t)stream;
     if ((mode & 0xff) == ANR_MLP_F32) {
-        int64_t n = (int64_t)btotal_frags<Cfg<ANR_MLP_F32>>() * 64 + BWD_TABLE_BYTES / 4;
+        int64_t n = (int64_t)btotal_frags<Cfg<ANR_MLP_F32>>() * 64 + BWD_TABLE_BYTES / 4 + DENC_PANEL_ELEMS;
         hipLaunchKernelGGL(mlp_bwd_pack_kernel<ANR_MLP_F32>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, plan, (char*)pack_out);
     } else if ((mode & 0xff) == ANR_MLP_BF16) {
-        int64_t n = (int64_t)btotal_frags<Cfg<ANR_MLP_BF16>>() * 64 + BWD_TABLE_BYTES / 4;
+        int64_t n = (int64_t)btotal_frags<Cfg<ANR_MLP_BF16>>() * 64 + BWD_TABLE_BYTES / 4 + DENC_PANEL_ELEMS;
         hipLaunchKernelGGL(mlp_bwd_pack_kernel<ANR_MLP_BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, plan, (char*)pack_out);
     } else {
         return fail(ANR_E_BADARG, "anr_mlp_bwd_pack: unknown mode %d", mode);
@@ -604,6 +622,14 @@ extern "C" int anr_mlp_backward_counted(const void* bwd_pack, int mode, const fl
     const bool so = (mode & ANR_MLP_FLAG_SIGMA_ONLY) != 0;
     const int tan = (mode & ANR_MLP_FLAG_TANGENT) ? 1 : 0;
     ANR_REQUIRE(!tan || (so && n % 4 == 0), ANR_E_BADARG, "anr_mlp_backward: tangent mode = sigma only, points in quads");
+    if (mode & ANR_MLP_FLAG_ENC_ONLY) {
+        ANR_REQUIRE(!so && !tan, ANR_E_BADARG, "anr_mlp_backward: ANR_MLP_FLAG_ENC_ONLY serves the full network's render passes");
+        switch (mode & 0xff) {
+            case ANR_MLP_F32:  return launch_mlp_bwd<ANR_MLP_F32, 0, true>(bwd_pack, g, act, dact, n, st, 0, nullptr, count);
+            case ANR_MLP_BF16: return launch_mlp_bwd<ANR_MLP_BF16_W8, 0, true>(bwd_pack, g, act, dact, n, st, 0, nullptr, count);
+            default: return fail(ANR_E_BADARG, "anr_mlp_backward: unknown mode %d", mode);
+        }
+    }
     switch (mode & 0xff) {
         case ANR_MLP_F32:
             return so ? launch_mlp_bwd<ANR_MLP_F32, 20>(bwd_pack, g, act, dact, n, st, tan, nullptr, count)

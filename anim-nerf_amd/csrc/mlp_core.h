@@ -146,6 +146,16 @@ __device__ __forceinline__ void dma16(const char* gsrc_lane, unsigned dst /* LDS
                  : "v"(gsrc_lane), "s"(__builtin_amdgcn_readfirstlane(dst))
                  : "memory");
 }
+// ... nontemporal: for a stream every byte of which is read ONCE by ONE workgroup (the weight-gradient kernel's slabs of saved
+// activations: tools/exp/exp_dma_patterns.hip: 6.06 -> 6.86 TB/s on the bare stream); NOT for the weight chunks above, which
+// every workgroup re-reads from L2
+__device__ __forceinline__ void dma16_nt(const char* gsrc_lane, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc_lane), "s"(__builtin_amdgcn_readfirstlane(dst))
+                 : "memory");
+}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // `slot` = byte offset of the ring slot inside the workgroup's dynamic LDS array `lds`
@@ -170,11 +180,20 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-// ---- saved activations / activation gradients (training): a buffer of R rows (points), BLOCKED by 32-feature tile.
-//   column c of row r  ->  element (c / 32 * R + r) * 32 + c % 32        76 blocks [R][32]: h1..h8 (8 x 8) | final (8) | dir hidden (4)
-// so the 32 rows a wavefront produces for one out-tile are 2 KiB (bf16) of CONTIGUOUS memory per store instruction pair.
-// (Row-major rows of 5 KB took 2.0 ms per 2^20 rows for the same bytes next to the weight stream, this layout 1.1:
-// tools/exp/exp_store_patterns2.hip.)  Behind the blocks, at element ACT_COLS * R, the SIGN BITS of the ReLU'd columns (bit
+// ---- saved activations / activation gradients (training): a buffer of R rows (points), BLOCKED by 32-feature tile and,
+// inside a block, by 16-BYTE PIECE of a row (8 bf16 / 4 fp32 features):
+//   column c of row r  ->  byte ((c / 32 * PPB + (c % 32) / EPP) * R + r) * 16 + (c % EPP) * esz,   EPP = 16 / esz, PPB = 32 / EPP
+//   76 blocks: h1..h8 (8 x 8) | final (8) | dir hidden (4), each PPB piece arrays [R][16 bytes]
+// What a lane holds when it stores is one 16-byte piece of its row (mlp_core.h FragEpi / mlp_bwd.hip MaskEpi), and the 32
+// lanes of a half-wave hold the SAME piece of 32 consecutive rows: with this layout a store instruction writes two spans of
+// 512 contiguous bytes — eight full 128-byte lines, nothing partial — and may therefore be issued nontemporal.  Round 3's
+// layout ([R][32 features] per block: the two 16-byte halves a store wrote of each 64-byte row came from lanes i and i + 32)
+// made every instruction touch 16 lines with 32-byte partial writes: 1.31 ms per 2^20 rows next to the MFMA chain in
+// tools/exp/exp_store_mfma2.hip where this one takes 1.16, and 1.09 nontemporal (round 2's row-major rows of 5 KB: 2.0).
+// The consumers gather: the weight-gradient kernel's LDS-DMA reads 16 rows x 16 B from each of a block's PPB pieces per
+// instruction (per-lane source addresses; the stream runs at the same 5.6-5.8 TB/s as on contiguous KiBs:
+// tools/exp/exp_dma_patterns.hip) into the SAME LDS image as before.
+// Behind the blocks, at element ACT_COLS * R, the SIGN BITS of the ReLU'd columns (bit
 // 4Q+i of the uint16 of (block w, half-wave h) <-> feature 32w + 8Q + 4h + i is > 0), grouped the way the kernels produce
 // and consume them: per trunk layer g a block [R][half-wave][16 B] at byte g * 32 R (the 8 uint16 of the layer's blocks),
 // the colour head's 4 blocks as [R][half-wave][8 B] at byte 288 R.  The activation-gradient kernel gates with these instead
@@ -184,6 +203,25 @@ constexpr int ACT_PITCH = 2592;
 __host__ __device__ constexpr int act_col(int T) { return T < 64 ? 32 * T : T < 73 ? 2048 + 32 * (T - 65) : 2304 + 32 * (T - 73); }
 // byte offsets inside a buffer of R rows of ESZ-byte elements
 __host__ __device__ constexpr int64_t act_block_off(int64_t R, int esz, int blk) { return (int64_t)blk * R * (32 * esz); }
+__host__ __device__ constexpr int act_ppb(int esz) { return 2 * esz; }                       // 16-byte pieces per block row
+// byte offset of piece `sub` (features sub * EPP ..) of block `blk`, row 0; rows are 16 bytes apart
+__host__ __device__ constexpr int64_t act_piece_off(int64_t R, int esz, int blk, int sub) {
+    return ((int64_t)blk * act_ppb(esz) + sub) * R * 16;
+}
+// byte offset of feature `f` (0..31) of block `blk`, row `r`
+__host__ __device__ constexpr int64_t act_elem_off(int64_t R, int esz, int blk, int f, int64_t r) {
+    return act_piece_off(R, esz, blk, f * esz / 16) + r * 16 + (f * esz) % 16;
+}
+#ifndef ANR_ACT_STORE_NT
+#define ANR_ACT_STORE_NT 1          // the saved activations / activation gradients leave as nontemporal stores (full lines)
+#endif
+template <class V, class P> __device__ __forceinline__ void act_store(P* p, const V& v) {
+#if ANR_ACT_STORE_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 __host__ __device__ constexpr int64_t act_bits_off(int64_t R, int esz, int w) {
     return (int64_t)ACT_COLS * R * esz + (w < 72 ? (int64_t)(w / 8) * 32 * R : (int64_t)288 * R);
 }
@@ -201,7 +239,7 @@ typedef __attribute__((address_space(1))) u32x2n g_uint2;
 typedef __attribute__((address_space(1))) f32x4 g_f32x4;
 struct BlockWalk {
     gchar* p;
-    int64_t stride;                                   // bytes per block
+    int64_t stride;                                   // bytes per step: a block (the bits), or the two piece arrays one store instruction of a tile covers (the data)
     __device__ __forceinline__ void reset(char* base, int64_t first_block) {
         p = (gchar*)base + first_block * stride;
         asm volatile("" : "+s"(p));
@@ -223,8 +261,13 @@ __host__ __device__ constexpr int act_sign_bit(int Q, int i) { return ((i & 1) ?
 // sigma of a tangent column is then d sigma / d x_d.
 // VIEW: the colour head takes the view direction (viewdir[n][stride], handed in where the rays-mode kernels take `rays`):
 // its Fourier panel is computed like the position's and multiplied in front of the feature in the dir_encoding tiles.
-template <int MODE, bool DMA, bool SIGMA_ONLY = false, bool SAVE = false, bool PRE = false, bool TAN = false, bool VIEW = false>
+// BITS_ONLY (with SAVE): only the ReLU sign bits are kept — what the activation-gradient kernel gates with — not the
+// activations themselves, which only the WEIGHT gradients read: the `_refine` stage of the shipped configs trains the poses
+// with the networks frozen (train.py:433-437, configs/people_snapshot/*_refine.yaml: pretrained_model_requires_grad False).
+template <int MODE, bool DMA, bool SIGMA_ONLY = false, bool SAVE = false, bool PRE = false, bool TAN = false, bool VIEW = false,
+          bool BITS_ONLY = false>
 struct Mlp {
+    static_assert(!BITS_ONLY || SAVE, "BITS_ONLY is a variant of SAVE");
     static_assert(!VIEW || (!SIGMA_ONLY && !SAVE && !PRE && !TAN), "the fused view-dependent head: inference, full network");
     using C = Cfg<MODE>;
     using Frag = typename C::Frag;
@@ -263,7 +306,7 @@ struct Mlp {
     int64_t act_rows;
     BlockWalk act_blk;       // SAVE: the data block / the layer's bits block the next epilogue stores into
     BlockWalk bits_blk;
-    unsigned act_off[NT];    // SAVE: byte offset of this lane's row (+ 4*half features) inside a block; rows past the end alias the last row
+    unsigned act_off[NT];    // SAVE: byte offset of this lane's row inside a piece array + its half-wave's array (row * 16 + half * 16 R); rows past the end alias the last row
     unsigned bits_off[NT];   // SAVE: ... inside a layer's bits block (row * 32 + 16 * half)
     char* lds_bits[NT];      // SAVE: this lane's 16 bytes of LDS where a layer's sign bits collect (one global store per layer)
     unsigned savebits[NT];   // SAVE: sign flags of the tile whose epilogue is pending
@@ -274,7 +317,7 @@ struct Mlp {
         if (V < 0 || V == 64 || V >= 77) return 0;
         const bool relu = V < 64 || V >= 73;
         const bool layer_end = relu && (V < 64 ? V % 8 == 7 : V == 76);
-        return (C::IS_BF16 ? 2 : 4) + (layer_end ? 1 : 0);
+        return (BITS_ONLY ? 0 : (C::IS_BF16 ? 2 : 4)) + (layer_end ? 1 : 0);
     }
     // ... and between the LDS-DMA of chunk c+1 (issued by the advance() in front of tile T - TPC) and the advance() in
     // front of tile T, which needs that chunk: the epilogues that ran in between.  The vector-memory counter retires in
@@ -373,7 +416,9 @@ struct Mlp {
         }
         template <int Q> __device__ __forceinline__ void part() const {
             parts<Q>();
-            if constexpr (SAVE && Q == 3) ab.template step<1>();         // the tiles that store walk the blocks in order
+            // the tiles that store walk the piece arrays in order: two per store instruction (bf16: after quarters 1 and 3,
+            // fp32: after every quarter)
+            if constexpr (SAVE && !BITS_ONLY && (!C::IS_BF16 || (Q & 1))) ab.template step<1>();
         }
         template <int Q> __device__ __forceinline__ void parts() const {
 #pragma unroll
@@ -412,15 +457,16 @@ struct Mlp {
                     dst = __builtin_bit_cast(Frag, d4);
                     if ((4 * Q + 4) % EPF == 0) pin(dst);
                     // features 32t + 8Q + 4h + (0..3) of this lane's point: 8 contiguous bytes of its row
-                    // (the two half-waves hold alternate 8-byte pieces of the row: one v_permlane32_swap per dword hands the lower
-                    // half-wave both pieces of the even quarter, the upper one both of the odd quarter -> 16-byte stores, 32
-                    // contiguous bytes per row and instruction)
-                    if constexpr (SAVE && (Q & 1)) {
+                    // (the two half-waves hold alternate 8-byte halves of a 16-byte piece: one v_permlane32_swap per dword hands
+                    // the lower half-wave both halves of the even quarter's piece, the upper one both of the odd quarter's ->
+                    // 16-byte stores, a whole piece per lane, 512 contiguous bytes per half-wave)
+                    if constexpr (SAVE && !BITS_ONLY && (Q & 1)) {
                         const u32x4 prev = __builtin_bit_cast(u32x4, Y[n][TB + (4 * (Q - 1)) / EPF]);
                         constexpr int pd = ((4 * (Q - 1)) % EPF) / 2;
                         const auto s0 = __builtin_amdgcn_permlane32_swap(prev[pd], pk[0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(prev[pd + 1], pk[1], false, false);
-                        *reinterpret_cast<g_uint4*>(ab.p + ao[n] + (16 * (Q >> 1) + 4 * half) * ESZ) = u32x4n{s0[0], s1[0], s0[1], s1[1]};
+                        // (piece 2 (Q >> 1) + half of the block: ab walks two piece arrays per store, ao = row * 16 + half * R * 16)
+                        act_store(reinterpret_cast<g_uint4*>(ab.p + ao[n]), u32x4n{s0[0], s1[0], s0[1], s1[1]});
                     }
                     if constexpr (SAVE && RELU) {
                         // after the ReLU a bf16 is > 0 exactly when its bit pattern is non-zero: min(x, 1) per 16-bit half is
@@ -450,7 +496,7 @@ struct Mlp {
                         keep[i] = v;
                     }
                     if ((4 * Q + 4) % EPF == 0) pin(Y[n][TB + (4 * Q) / EPF]);
-                    if constexpr (SAVE) *reinterpret_cast<g_f32x4*>(ab.p + ao[n] + 8 * Q * ESZ) = keep;
+                    if constexpr (SAVE && !BITS_ONLY) act_store(reinterpret_cast<g_f32x4*>(ab.p + ao[n]), keep);      // piece 2 Q + half
                     if constexpr (SAVE && RELU) {
                         unsigned nib = 0;
 #pragma unroll
@@ -704,7 +750,7 @@ struct Mlp {
             // issues the same number of stores whatever n is, which the counted waits of advance() rely on)
             if constexpr (SAVE) {
                 const unsigned row = (unsigned)clamp_row(idx, n_pts);
-                act_off[n] = (row * 32 + 4 * half) * (unsigned)sizeof(ActT);
+                act_off[n] = row * 16u + (unsigned)half * (unsigned)(act_rows * 16);
                 bits_off[n] = row * 32 + 16 * half;
             }
             if constexpr (SAVE) lds_bits[n] = lds + BIAS_BYTES + 3 * SLOT + ((n * WAVES + wave) * 64 + lane) * 16;
@@ -756,7 +802,7 @@ struct Mlp {
             first = false;
         }
         if constexpr (SAVE) {
-            act_blk.stride = act_block_off(act_rows, sizeof(ActT), 1);
+            act_blk.stride = 2 * 16 * act_rows;               // two piece arrays per store instruction
             bits_blk.stride = 32 * act_rows;
             act_blk.reset(act_base, 0);
             bits_blk.reset(act_base + act_bits_off(act_rows, sizeof(ActT), 0), 0);
@@ -833,7 +879,26 @@ struct Mlp {
     }
 };
 
-template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE, bool PRE = false, bool TAN = false, bool VIEW = false>
+// ---- layout of the BACKWARD weight pack (anr_mlp_bwd_pack, csrc/mlp_bwd.hip): [w_sigma table | W^T fragments of the 76
+// out-tiles of the activation-gradient kernel | encoding panels]
+constexpr int BWD_TABLE_BYTES = 1024;          // w_sigma, 256 fp32, in accumulator-register order per tile
+constexpr int BWD_TILES = 76;
+template <class C> __host__ __device__ constexpr int btile_frags(int t) { return t < 4 ? 4 : t < 12 ? C::DF : C::HF; }
+template <class C> __host__ __device__ constexpr int bfrag_offset(int t) {
+    int n = 0;
+    for (int i = 0; i < t; ++i) n += btile_frags<C>(i);
+    return n;
+}
+template <class C> constexpr int btotal_frags() { return bfrag_offset<C>(BWD_TILES); }
+// Behind the W^T fragments: the two 256 x 64 ENCODING panels of layers 1 and 5 (xyz_encoding_1 [256,63], the first 63
+// columns of xyz_encoding_5 [256,319]) as MFMA B fragments [layer][k-fragment][column tile 2][lane 64][EPL elements] — the
+// operand of dL/d enc = dact_1 W1[:, :63] + dact_5 W5[:, :63] (anr_mlp_dpoints, csrc/mlp_wgrad.hip), made once per
+// optimiser step by the pack kernel instead of once per workgroup by its consumer.  32,768 elements in either mode.
+constexpr int DENC_PANEL_ELEMS = 32768;
+template <class C> __host__ __device__ constexpr int64_t denc_panel_off() { return BWD_TABLE_BYTES + (int64_t)btotal_frags<C>() * FRAG_BYTES; }
+template <class C> __host__ __device__ constexpr int64_t denc_panel_bytes() { return (int64_t)DENC_PANEL_ELEMS * (C::IS_BF16 ? 2 : 4); }
+
+template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE, bool PRE = false, bool TAN = false, bool VIEW = false, bool BITS_ONLY = false>
 __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void mlp_kernel(const char* __restrict__ pack,
                                                              const float4* __restrict__ pts, int64_t n_pts,
                                                              void* __restrict__ out, float* __restrict__ act,
@@ -841,17 +906,17 @@ __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void m
                                                              const int32_t* __restrict__ count,
                                                              const float* __restrict__ rays, int ray_stride, int K) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    Mlp<MODE, DMA, SIGMA_ONLY, SAVE, PRE, TAN, VIEW> m;
+    Mlp<MODE, DMA, SIGMA_ONLY, SAVE, PRE, TAN, VIEW, BITS_ONLY> m;
     m.run(pack, pts, n_pts, out, act, lds, index, count, rays, ray_stride, K);
 }
 
-template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE, bool PRE = false, bool TAN = false, bool VIEW = false>
+template <int MODE, bool DMA, bool SIGMA_ONLY, bool SAVE, bool PRE = false, bool TAN = false, bool VIEW = false, bool BITS_ONLY = false>
 int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStream_t st, float* act,
                const int32_t* index = nullptr, const int32_t* count = nullptr, const float* rays = nullptr,
                int ray_stride = 0, int K = 1) {
     using C = Cfg<MODE>;
     const int lds = BIAS_BYTES + 3 * slot_bytes<C>() + (SAVE ? C::NT * C::WAVES * 64 * 16 : 0);     // + the sign-bit slots
-    auto kern = mlp_kernel<MODE, DMA, SIGMA_ONLY, SAVE, PRE, TAN, VIEW>;
+    auto kern = mlp_kernel<MODE, DMA, SIGMA_ONLY, SAVE, PRE, TAN, VIEW, BITS_ONLY>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail((int)e, "anr_mlp_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
     const int pts_per_wg = C::WAVES * C::NT * 32;

@@ -6,8 +6,9 @@
 //
 // The contraction runs over the POINTS, i.e. over the slow index of both operands, so an MFMA fragment (one feature,
 // 8 consecutive points per lane) is a column walk.  gfx950's transposing LDS read does it in hardware: for a slab of
-// rows, each 32-feature block is 2 KiB of contiguous memory and goes L2 -> LDS as it lies there (LDS-DMA, 16 B per lane;
-// rows of a block are 64 bytes apart, so the four rows one ds_read_b64_tr_b16 touches sit in different bank windows), and
+// rows, each 32-feature block goes L2 -> LDS in 1-KiB pieces of 16 rows x its four 16-byte piece arrays (LDS-DMA, 16 B per lane
+// with per-lane source addresses: the blocked buffers of mlp_core.h; inside a piece array a's copy of row r sits at position
+// 16 a + (r + 4 a) mod 16, so the 4 rows x 4 arrays one ds_read_b64_tr_b16 touches per half-wave fill the 64 banks exactly), and
 // each fragment is two ds_read_b64_tr_b16 (lane s of a 16-lane group points at row k0 + s/4, features f0 + 4 (s%4); it
 // receives feature f0 + s of rows k0 .. k0+3).  fp32 (parity mode): v_mfma_f32_32x32x2_f32 takes one point per
 // half-wave and its fragment is a plain row read.
@@ -89,7 +90,13 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
     const int n_stages = r1 > r0 ? (int)((r1 - r0) / SR) : 0;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     // this lane's 16 bytes of a piece: row (inside the piece) and byte inside the block row
-    const int prow = lane / LPR, pseg = (lane % LPR) * 16;
+    // A piece = RPP rows x LPR piece arrays.  Lane l fetches array psub = l / RPP, row (l % RPP - ROT psub) mod RPP: RPP
+    // consecutive lanes read RPP consecutive rows of ONE array — 256 (128) contiguous bytes, whole lines (with the lanes
+    // interleaving the arrays, 64 bytes of four lines per 16 lanes, the kernel lost 17-26 %) — and its 16 bytes land at LDS
+    // position l of the piece = psub RPP + (row + ROT psub) mod RPP: the rotation spreads the LPR arrays' copies of the same
+    // rows over different bank windows for the transposing reads below.
+    constexpr int ROT = BF16 ? 4 : 1;
+    const int psub = lane / RPP, prow = ((lane % RPP) - ROT * psub) & (RPP - 1), pseg = psub * 16;
 
     auto issue = [&](int st) {                                  // slab of stage st -> ring buffer st % NBUF
         const int64_t row0 = r0 + (int64_t)st * SR;
@@ -99,16 +106,17 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
             const int piece = wave + p * WG_WAVES;               // wave-uniform
             const int blk = piece / (BLK / 1024), row = (piece % (BLK / 1024)) * RPP + prow;
             const char* src;
+            // (a lane's 16 bytes = piece `psub` of the block's row: its own array [n][16 B] in the blocked buffers, mlp_core.h)
             if (piece < STAGE_A / 1024) {
-                src = dact + act_block_off(n, ESZ, gm.a_col / 32 + blk) + (row0 + row) * (32 * ESZ) + pseg;
+                src = dact + act_piece_off(n, ESZ, gm.a_col / 32 + blk, psub) + (row0 + row) * 16;
             } else if (piece < PIECES) {
                 const int bb = blk - M / 32;
                 if (gm.b_src) src = enc + (row0 + row) * (64 * ESZ) + bb * (32 * ESZ) + pseg;        // enc[points][64], row-major
-                else          src = act + act_block_off(n, ESZ, gm.b_col / 32 + bb) + (row0 + row) * (32 * ESZ) + pseg;
+                else          src = act + act_piece_off(n, ESZ, gm.b_col / 32 + bb, psub) + (row0 + row) * 16;
             } else {
-                src = dact + (row0 + row) * (32 * ESZ) + pseg;      // padding piece: lands behind the images, never read
+                src = dact + (row0 + row) * 16;                     // padding piece: lands behind the images, never read
             }
-            dma16(src, buf + piece * 1024);
+            dma16_nt(src, buf + piece * 1024);
         }
     };
 
@@ -141,8 +149,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
         const char* B = A + STAGE_A;
         if constexpr (BF16) {
             const int grp = lane >> 4, s = lane & 15, h = lane >> 5;
-            // lane's row / feature offset inside a [16 rows][32 features] fragment source block
-            const int frow = 4 * h + (s >> 2), fcol = 16 * (grp & 1) + 4 * (s & 3);
+            // lane's row / feature inside a [16 rows][32 features] fragment source block (one DMA piece): row frow (and frow + 8
+            // for the second read), features fcol .. fcol + 3 = half (s & 1) of piece array fsub, at the piece's LDS position
+            // fsub 16 + (row + 4 fsub) mod 16 (issue() above)
+            const int frow = 4 * h + (s >> 2), fsub = 2 * (grp & 1) + ((s & 3) >> 1);
+            const unsigned foff0 = (unsigned)((fsub * 16 + ((frow + 4 * fsub) & 15)) * 16 + 8 * (s & 1));
+            const unsigned foff1 = (unsigned)((fsub * 16 + ((frow + 8 + 4 * fsub) & 15)) * 16 + 8 * (s & 1));
 #pragma unroll
             for (int ks = 0; ks < SR / 16; ++ks) {
                 bf16x8 fa[TM], fb[TN];
@@ -150,16 +162,16 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
                     const unsigned ad = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)A +
-                                        (m_base / 32 + a) * BLK + (ks * 16 + frow) * 64 + fcol * 2;
-                    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
-                                 : "=&v"(alo[a]), "=&v"(ahi[a]) : "v"(ad), "n"(8 * 64) : "memory");
+                                        (m_base / 32 + a) * BLK + ks * 1024;
+                    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3"
+                                 : "=&v"(alo[a]), "=&v"(ahi[a]) : "v"(ad + foff0), "v"(ad + foff1) : "memory");
                 }
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
                     const unsigned ad = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)B +
-                                        (n_base / 32 + b) * BLK + (ks * 16 + frow) * 64 + fcol * 2;
-                    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
-                                 : "=&v"(blo[b]), "=&v"(bhi[b]) : "v"(ad), "n"(8 * 64) : "memory");
+                                        (n_base / 32 + b) * BLK + ks * 1024;
+                    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3"
+                                 : "=&v"(blo[b]), "=&v"(bhi[b]) : "v"(ad + foff0), "v"(ad + foff1) : "memory");
                 }
                 // one wait for the whole batch; the operands tie every fragment to it (the reads are opaque to hipcc)
 #pragma unroll
@@ -191,12 +203,16 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
 #pragma unroll
             for (int ks = 0; ks < SR / 2; ++ks) {
                 float fa[TM], fb[TN];
+                // row ks 2 + h of the stage = row r of DMA piece (ks 2 + h) / 8; feature i = element i % 4 of piece array
+                // i / 4, at the piece's LDS position (i / 4) 8 + (r + i / 4) mod 8 (issue() above)
+                const int r = (ks * 2 + h) & 7, pc = (ks * 2 + h) >> 3;
+                const int foff = pc * 1024 + ((i >> 2) * 8 + ((r + (i >> 2)) & 7)) * 16 + (i & 3) * 4;
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
-                    fa[a] = *reinterpret_cast<const float*>(A + (m_base / 32 + a) * BLK + (ks * 2 + h) * 128 + i * 4);
+                    fa[a] = *reinterpret_cast<const float*>(A + (m_base / 32 + a) * BLK + foff);
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    fb[b] = *reinterpret_cast<const float*>(B + (n_base / 32 + b) * BLK + (ks * 2 + h) * 128 + i * 4);
+                    fb[b] = *reinterpret_cast<const float*>(B + (n_base / 32 + b) * BLK + foff);
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -261,8 +277,10 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
         rows_per_slice = (int)((n_rows + gridDim.x - 1) / gridDim.x);
     }
     // four consecutive columns per lane: block (first column / 32 + lane / 8), features 4 (lane % 8) of row r
-    const T* h8 = act + ((int64_t)(1792 / 32 + (lane >> 3)) * n) * 32 + 4 * (lane & 7);
-    const T* gh = act + ((int64_t)(2304 / 32 + ((lane & 31) >> 3)) * n) * 32 + 4 * (lane & 7);
+    // (blocked by 32-feature tile and by 16-byte piece inside it, mlp_core.h: rows of a piece array are EPP elements apart)
+    constexpr int EPP = 16 / (int)sizeof(T);
+    const T* h8 = reinterpret_cast<const T*>(reinterpret_cast<const char*>(act) + act_elem_off(n, sizeof(T), 1792 / 32 + (lane >> 3), 4 * (lane & 7), 0));
+    const T* gh = reinterpret_cast<const T*>(reinterpret_cast<const char*>(act) + act_elem_off(n, sizeof(T), 2304 / 32 + ((lane & 31) >> 3), 4 * (lane & 7), 0));
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_slice;
     int64_t r1 = r0 + rows_per_slice;
     if (r1 > n_rows) r1 = n_rows;
@@ -276,7 +294,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
             float4 g[RIF];
 #pragma unroll
             for (int q = 0; q < RIF; ++q) {
-                load4(h8 + (r + 4 * q) * 32, h[q]);
+                load4(h8 + (r + 4 * q) * EPP, h[q]);
                 g[q] = reinterpret_cast<const float4*>(g4)[r + 4 * q];
             }
 #pragma unroll
@@ -289,7 +307,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
         }
         for (; r < r1; r += 4) {
             float h[4];
-            load4(h8 + r * 32, h);
+            load4(h8 + r * EPP, h);
             const float4 g = reinterpret_cast<const float4*>(g4)[r];
 #pragma unroll
             for (int i = 0; i < 4; ++i) sw[i] += g.w * h[i];
@@ -306,7 +324,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
             float4 g[RIF];
 #pragma unroll
             for (int q = 0; q < RIF; ++q) {
-                load4(gh + (r + 8 * q) * 32, h[q]);
+                load4(gh + (r + 8 * q) * EPP, h[q]);
                 g[q] = reinterpret_cast<const float4*>(g4)[r + 8 * q];
             }
 #pragma unroll
@@ -316,7 +334,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
         }
         for (; r < r1; r += 8) {
             float h[4];
-            load4(gh + r * 32, h);
+            load4(gh + r * EPP, h);
             const float4 g = reinterpret_cast<const float4*>(g4)[r];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { sr[0][i] += g.x * h[i]; sr[1][i] += g.y * h[i]; sr[2][i] += g.z * h[i]; }
@@ -560,8 +578,8 @@ extern "C" int anr_mlp_wgrad_counted(int mode, const void* act, const void* dact
 // =====================================================================================================================
 // dL/d enc: the gradient that leaves the MLP through its two encoding inputs (layers 1 and 5) on its way to the sample
 // positions — pose refinement only (train.py:141-144):  d_enc[p][c] = dact_1[p] . W1[:, c] + dact_5[p] . W5[:, c],  c < 63.
-// Points are the MFMA row dimension here, so the A fragments (8 consecutive out-features of one point) are contiguous in
-// the row-major dact and come straight from global memory; the two 256 x 64 weight panels are converted to B-fragment
+// Points are the MFMA row dimension here, so the A fragments (2 x 4 consecutive out-features of one point: halves of two
+// 16-byte pieces of its row) come straight from global memory; the two 256 x 64 weight panels are converted to B-fragment
 // order in LDS once per workgroup.  One wave per 32 points, persistent workgroups.
 namespace anr {
 
@@ -593,7 +611,7 @@ __global__ __launch_bounds__(256) void denc_kernel(const char* __restrict__ dact
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t p = tile * 32 + (lane & 31);
         const int64_t row = p < n_rows ? p : n_rows - 1;
-        const char* arow = dact + row * (int64_t)(32 * sizeof(T));       // this point's row inside a block of dact
+        const char* arow = dact + row * 16;                              // this point's row inside a piece array of dact
         const int h = lane >> 5;
         f32x16 acc[2];
 #pragma unroll
@@ -606,14 +624,15 @@ __global__ __launch_bounds__(256) void denc_kernel(const char* __restrict__ dact
                 const T* b0 = panel + ((int64_t)((layer * KF + kf) * 2 + 0) * 64 + lane) * EPL;
                 const T* b1 = panel + ((int64_t)((layer * KF + kf) * 2 + 1) * 64 + lane) * EPL;
                 if constexpr (BF16) {
-                    const char* ab = a0 + act_block_off(n, 2, kf >> 1) + (16 * (kf & 1) + 4 * h) * 2;
+                    // features 16 (kf & 1) + 4 h .. + 3 and the same + 8: half h of pieces 2 (kf & 1) and 2 (kf & 1) + 1
+                    const char* ab = a0 + act_piece_off(n, 2, kf >> 1, 2 * (kf & 1)) + 8 * h;
                     const uint2 lo = *reinterpret_cast<const uint2*>(ab);
-                    const uint2 hi = *reinterpret_cast<const uint2*>(ab + 16);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(ab + n * 16);
                     const bf16x8 fa = __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, *reinterpret_cast<const bf16x8*>(b0), acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, *reinterpret_cast<const bf16x8*>(b1), acc[1], 0, 0, 0);
                 } else {
-                    const float fa = *reinterpret_cast<const float*>(a0 + act_block_off(n, 4, kf >> 4) + (2 * (kf & 15) + h) * 4);
+                    const float fa = *reinterpret_cast<const float*>(a0 + act_elem_off(n, 4, kf >> 4, 2 * (kf & 15) + h, 0));
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, *b0, acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, *b1, acc[1], 0, 0, 0);
                 }
@@ -632,6 +651,135 @@ __global__ __launch_bounds__(256) void denc_kernel(const char* __restrict__ dact
 }
 
 }  // namespace anr
+
+// =====================================================================================================================
+// dL/d x of a compacted pass in ONE launch (round 5): anr_mlp_denc + anr_encode_backward — d_enc never travels through HBM
+// (252 B written + read per row), the encoding's derivative runs on whole wavefronts, and the weight panels come pre-packed
+// in B-fragment order from the backward weight pack (mlp_core.h: denc_panel_off) instead of being converted from fp32 by every
+// workgroup.  A wavefront takes TP points (64 bf16 / 32 fp32): MFMA tiles as in denc_kernel, accumulators -> this wave's LDS
+// patch [point][65 floats] (pitch 65: the column walk below is conflict-free), then lane p owns point p: its 63 channel
+// gradients meet the derivative of the Fourier features,
+//   d x_d = g[d] + sum_k 2^k (cos(2^k x_d) g[3 + 6k + d] - sin(2^k x_d) g[6 + 6k + d])        (models/embedding.py:22-39)
+// 86 + 59 us -> one launch at the per-rank batch of the reference's 8-GPU run (~70 k rows).
+namespace anr {
+
+template <bool BF16>
+__global__ __launch_bounds__(BF16 ? 256 : 128) void dpoints_kernel(const char* __restrict__ dact, const char* __restrict__ panel_g,
+                                                                   const float4* __restrict__ pts, int64_t n,
+                                                                   float4* __restrict__ d_pts, const int32_t* __restrict__ count) {
+    using T = typename WgCfg<BF16>::T;
+    constexpr int KF = BF16 ? 16 : 128, EPL = BF16 ? 8 : 1;
+    constexpr int WAVES = BF16 ? 4 : 2, TP = BF16 ? 64 : 32, NTILE = TP / 32;
+    constexpr int PANEL_BYTES = DENC_PANEL_ELEMS * (int)sizeof(T);
+    constexpr int PITCH = 65;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const T* panel = reinterpret_cast<const T*>(lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    float* patch = reinterpret_cast<float*>(lds + PANEL_BYTES) + wave * (TP * PITCH);
+    for (int i = threadIdx.x; i < PANEL_BYTES / 16; i += WAVES * 64)
+        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(panel_g)[i];
+    __syncthreads();
+    int64_t n_rows = n;                                      // (n stays the buffer's row count: the piece arrays' stride)
+    if (count) { const int64_t cnt = *count; n_rows = cnt < n ? cnt : n; }
+    const int64_t n_tiles = (n_rows + TP - 1) / TP;
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WAVES) {
+        f32x16 acc[NTILE][2];
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[t][0][e] = 0.f; acc[t][1][e] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+            const int64_t p = tile * TP + t * 32 + (lane & 31);
+            const int64_t row = p < n_rows ? p : n_rows - 1;
+            const char* arow = dact + row * 16;
+#pragma unroll
+            for (int layer = 0; layer < 2; ++layer) {
+                const char* a0 = arow + act_block_off(n, sizeof(T), layer ? 32 : 0);    // dact_5 (columns 1024..) / dact_1
+#pragma unroll 8
+                for (int kf = 0; kf < KF; ++kf) {
+                    const T* b0 = panel + ((int64_t)((layer * KF + kf) * 2 + 0) * 64 + lane) * EPL;
+                    const T* b1 = panel + ((int64_t)((layer * KF + kf) * 2 + 1) * 64 + lane) * EPL;
+                    if constexpr (BF16) {
+                        const char* ab = a0 + act_piece_off(n, 2, kf >> 1, 2 * (kf & 1)) + 8 * h;
+                        const uint2 lo = *reinterpret_cast<const uint2*>(ab);
+                        const uint2 hi = *reinterpret_cast<const uint2*>(ab + n * 16);
+                        const bf16x8 fa = __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
+                        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, *reinterpret_cast<const bf16x8*>(b0), acc[t][0], 0, 0, 0);
+                        acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, *reinterpret_cast<const bf16x8*>(b1), acc[t][1], 0, 0, 0);
+                    } else {
+                        const float fa = *reinterpret_cast<const float*>(a0 + act_elem_off(n, 4, kf >> 4, 2 * (kf & 15) + h, 0));
+                        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, *b0, acc[t][0], 0, 0, 0);
+                        acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, *b1, acc[t][1], 0, 0, 0);
+                    }
+                }
+            }
+            // D[row = point (e&3) + 8 (e>>2) + 4 h][col = channel lane&31 (+32)] -> patch[point][channel]
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    patch[(t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * PITCH + (lane & 31) + 32 * nt] = acc[t][nt][e];
+        }
+        // (the patch is this wavefront's own: the LDS unit executes a wave's instructions in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int64_t p = tile * TP + lane;
+        if (lane < TP && p < n_rows) {
+            const float4 x4 = pts[p];
+            const float x[3] = {x4.x, x4.y, x4.z};
+            const float* g = patch + lane * PITCH;
+            float dx[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float a = g[d];
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+                    const float f = (float)(1 << k), arg = f * x[d];
+                    a += f * (sin_or_cos(arg, 1) * g[3 + 6 * k + d] - sin_or_cos(arg, 0) * g[6 + 6 * k + d]);
+                }
+                dx[d] = a;
+            }
+            d_pts[p] = make_float4(dx[0], dx[1], dx[2], 0.0f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+}  // namespace anr
+
+extern "C" int anr_mlp_dpoints(const void* bwd_pack, int mode, const void* dact, const float* pts, int64_t n, const int32_t* count,
+                               float* d_pts_out, void* stream) {
+    ANR_REQUIRE(bwd_pack && dact && pts && d_pts_out, ANR_E_BADARG, "anr_mlp_dpoints: null pointer");
+    ANR_REQUIRE(n > 0, ANR_E_BADARG, "anr_mlp_dpoints: n=%lld", (long long)n);
+    ANR_REQUIRE((((uintptr_t)bwd_pack | (uintptr_t)dact | (uintptr_t)pts | (uintptr_t)d_pts_out) & 15) == 0, ANR_E_ALIGN,
+                "anr_mlp_dpoints: bwd_pack/dact/pts/d_pts_out must be 16-B aligned");
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    hipStream_t st = (hipStream_t)stream;
+    const char* pack = reinterpret_cast<const char*>(bwd_pack);
+    const float4* p4 = reinterpret_cast<const float4*>(pts);
+    float4* o4 = reinterpret_cast<float4*>(d_pts_out);
+    if ((mode & 0xff) == ANR_MLP_BF16) {
+        const int lds = DENC_PANEL_ELEMS * 2 + 4 * 64 * 65 * 4;
+        const int64_t wgs = (n + 255) / 256;
+        auto k = dpoints_kernel<true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail((int)e, "anr_mlp_dpoints: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k, dim3((unsigned)(wgs < cus ? wgs : cus)), dim3(256), lds, st, reinterpret_cast<const char*>(dact),
+                           pack + denc_panel_off<Cfg<ANR_MLP_BF16>>(), p4, n, o4, count);
+    } else if ((mode & 0xff) == ANR_MLP_F32) {
+        const int lds = DENC_PANEL_ELEMS * 4 + 2 * 32 * 65 * 4;
+        const int64_t wgs = (n + 63) / 64;
+        auto k = dpoints_kernel<false>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail((int)e, "anr_mlp_dpoints: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k, dim3((unsigned)(wgs < cus ? wgs : cus)), dim3(128), lds, st, reinterpret_cast<const char*>(dact),
+                           pack + denc_panel_off<Cfg<ANR_MLP_F32>>(), p4, n, o4, count);
+    } else {
+        return fail(ANR_E_BADARG, "anr_mlp_dpoints: unknown mode %d", mode);
+    }
+    return check_launch("anr_mlp_dpoints");
+}
 
 extern "C" int anr_mlp_denc(int mode, const void* dact, const float* w1, const float* w5, int64_t n, float* d_enc_out,
                             void* stream) {

@@ -103,6 +103,74 @@ __global__ __launch_bounds__(CB) void compact_gather_kernel(const float4* __rest
     }
 }
 
+// ---- the same list in ONE launch (round 5; the explicit training step calls it twice per step): a chained scan with
+// decoupled look-back (Merrill & Garland 2016) over blocks of CB samples.  state[b] = (flag << 32) | value — flag 1: the
+// block's own count, flag 2: the inclusive prefix up to and including it — is ONE 8-byte granule written by a relaxed
+// agent-scope atomic store and read by relaxed agent-scope atomic loads (a valid cross-workgroup hand-off on gfx950 without
+// fences: MI355X_MICROARCH.md, "8-B agent atomics both sides").  Blocks take their number from a ticket, so every
+// predecessor a block waits for is already running.  The LAST block to finish puts state, tickets and all back to zero: the
+// buffer must be zero before its first use and is left zero by every call (a replayed graph needs no fill launch).
+__global__ __launch_bounds__(CB) void compact_single_kernel(const float4* __restrict__ pts, int64_t n, Riders riders, int64_t n_r,
+                                                            unsigned long long* __restrict__ state, int nb, int32_t* __restrict__ count,
+                                                            int32_t* __restrict__ index, int32_t* __restrict__ pos,
+                                                            float4* __restrict__ pts_out) {
+    __shared__ int wave_cnt[CB / WAVE];
+    __shared__ int sh_bid, sh_excl, sh_total;
+    unsigned* tickets = reinterpret_cast<unsigned*>(state + nb);         // [0]: block numbers, [1]: blocks done
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sh_bid = (int)atomicAdd(&tickets[0], 1u);
+    __syncthreads();
+    const int bid = sh_bid;
+    const int64_t i = (int64_t)bid * CB + threadIdx.x;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) p = pts[i];
+    else if (i < n + n_r) p = riders.point(i - n);
+    const bool keep = (i < n && !(p.w < 1.0f)) || (i >= n && i < n + n_r);
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < CB / WAVE; ++w) tot += wave_cnt[w];
+        int excl = 0;
+        if (bid > 0) {
+            __hip_atomic_store(&state[bid], (1ull << 32) | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int j = bid - 1; j >= 0; --j) {
+                unsigned long long sj;
+                do { sj = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((sj >> 32) == 0);
+                excl += (int)(unsigned)sj;
+                if ((sj >> 32) == 2) break;
+            }
+        }
+        __hip_atomic_store(&state[bid], (2ull << 32) | (unsigned)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_excl = excl;
+        sh_total = excl + tot;
+        if (bid == nb - 1) {
+            count[0] = excl + tot;
+            count[1] = excl + tot > 0 ? (excl + tot + 63) / 64 * 64 : 64;   // the row count the MLP kernels work on (padding rows: valid = 0)
+        }
+    }
+    __syncthreads();
+    int off = sh_excl;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    const int r = off + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep) { index[r] = (int32_t)i; pts_out[r] = p; }
+    if (i < n + n_r) pos[i] = keep ? r : -1;
+    if (bid == nb - 1 && threadIdx.x < 64) {                 // padding rows up to the next multiple of 64: valid = 0
+        const int c = sh_total, pad = (c + 63) / 64 * 64;
+        if (c + (int)threadIdx.x < (pad > 0 ? pad : 64)) pts_out[c + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // every block has finished its look-back once it counts itself done: the last one clears the state for the next call
+    __shared__ bool last;
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&tickets[1], 1u) == (unsigned)nb - 1;
+    __syncthreads();
+    if (last) {
+        for (int j = threadIdx.x; j <= nb; j += CB) __hip_atomic_store(&state[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <int COLS>
 __global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ pos, int64_t n,
                                                           float fill, float* __restrict__ out) {
@@ -148,14 +216,16 @@ __global__ __launch_bounds__(256) void tangent_quads_kernel(const float* __restr
 }
 
 // z_k = near' + (far' - near') e_k with e_k = the (jittered) step: d near' = sum g_k (1 - e_k), d far' = sum g_k e_k
-// (models/volume_rendering.py:29-56; pose refinement moves near'/far' with the root transform).  One thread per ray.
+// (models/volume_rendering.py:29-56; pose refinement moves near'/far' with the root transform).  One wavefront per ray:
+// lane k <-> sample k, k + 64, ... (coalesced loads), the sums meet by shuffles.
 __global__ __launch_bounds__(256) void sample_coarse_backward_kernel(const float* __restrict__ g, const float* __restrict__ steps,
                                                                      const float* __restrict__ t_rand, int64_t R, int K,
                                                                      float* __restrict__ d_rays) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
     float dn = 0.0f, df = 0.0f;
-    for (int k = 0; k < K; ++k) {
+    for (int k = lane; k < K; k += 64) {
         const float s = steps[k];
         float e = s;
         if (t_rand) {
@@ -166,9 +236,13 @@ __global__ __launch_bounds__(256) void sample_coarse_backward_kernel(const float
         dn += gk * (1.0f - e);
         df += gk * e;
     }
-    float4* o = reinterpret_cast<float4*>(d_rays + r * 8);
-    o[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-    o[1] = make_float4(0.f, 0.f, dn, df);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { dn += __shfl_xor(dn, o, 64); df += __shfl_xor(df, o, 64); }
+    if (lane == 0) {
+        float4* o = reinterpret_cast<float4*>(d_rays + r * 8);
+        o[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        o[1] = make_float4(0.f, 0.f, dn, df);
+    }
 }
 
 // z_sorted[j] = cat(z_coarse, z_fine)[perm[j]], z_fine detached (models/volume_rendering.py:199-207): the gradient of the
@@ -240,10 +314,25 @@ __global__ __launch_bounds__(256) void train_loss_kernel(anr_loss_args a, float*
             }
         acc[0 + pass] = s_rgb; acc[2 + pass] = s_al; acc[4 + 2 * pass] = s_fg; acc[5 + 2 * pass] = s_bg; acc[8 + pass] = s_n;
     }
+    // range of the target colours: train/psnr is torchmetrics' peak_signal_noise_ratio WITHOUT data_range (train.py:339-344),
+    // i.e. data_range = target.max() - target.min() of the batch
+    float t_hi = -INFINITY, t_lo = INFINITY;
+    for (int64_t i = tid; i < a.R * 3; i += nth) { const float t = a.target_rgb[i]; t_hi = fmaxf(t_hi, t); t_lo = fminf(t_lo, t); }
 #pragma unroll
     for (int t = 0; t < LOSS_TERMS; ++t) {
         const float v = block_sum(acc[t], sh);
         if (threadIdx.x == 0) partials[blockIdx.x * LOSS_TERMS + t] = v;
+    }
+    {
+        __shared__ float sh_hi[4], sh_lo[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { t_hi = fmaxf(t_hi, __shfl_xor(t_hi, o, 64)); t_lo = fminf(t_lo, __shfl_xor(t_lo, o, 64)); }
+        if ((threadIdx.x & 63) == 0) { sh_hi[threadIdx.x >> 6] = t_hi; sh_lo[threadIdx.x >> 6] = t_lo; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            partials[LOSS_BLOCKS * LOSS_TERMS + 2 * blockIdx.x] = fmaxf(fmaxf(sh_hi[0], sh_hi[1]), fmaxf(sh_hi[2], sh_hi[3]));
+            partials[LOSS_BLOCKS * LOSS_TERMS + 2 * blockIdx.x + 1] = fminf(fminf(sh_lo[0], sh_lo[1]), fminf(sh_lo[2], sh_lo[3]));
+        }
     }
     // the last workgroup to finish adds the partial sums up in workgroup order (same bits on every run) and resets the ticket
     __threadfence();
@@ -251,23 +340,38 @@ __global__ __launch_bounds__(256) void train_loss_kernel(anr_loss_args a, float*
     __syncthreads();
     if (!last) return;
     __threadfence();
-    if (threadIdx.x < LOSS_TERMS) {
-        float v = 0.0f;
-        for (int b = 0; b < LOSS_BLOCKS; ++b) v += __builtin_nontemporal_load(&partials[b * LOSS_TERMS + threadIdx.x]);
-        const int t = threadIdx.x;
-        const float cnt = t < 2 ? (float)(a.R * 3) : t < 4 ? (float)a.R
-                        : t < 8 ? (float)(a.prior_rows * ((t & 1) ? a.n_bg : a.n_fg)) : (float)(a.normal_sets * a.nv * 3);
-        vals[t] = cnt > 0.0f ? v / cnt : 0.0f;
+    // (lane b of a wavefront takes workgroup b's partial — LOSS_BLOCKS = 64 — and the lanes meet in a fixed butterfly: the same
+    // bits on every run; one thread per term walking 64 partials one load behind the other took 40 of this kernel's 46 us)
+    static_assert(LOSS_BLOCKS == 64, "one lane per workgroup's partial");
+    __shared__ float s_val[LOSS_TERMS], s_hi, s_lo;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = wave; t < LOSS_TERMS + 2; t += 4) {
+        if (t < LOSS_TERMS) {
+            float v = __builtin_nontemporal_load(&partials[lane * LOSS_TERMS + t]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const float cnt = t < 2 ? (float)(a.R * 3) : t < 4 ? (float)a.R
+                            : t < 8 ? (float)(a.prior_rows * ((t & 1) ? a.n_bg : a.n_fg)) : (float)(a.normal_sets * a.nv * 3);
+            if (lane == 0) s_val[t] = cnt > 0.0f ? v / cnt : 0.0f;
+        } else {
+            // range of the targets: train/psnr is torchmetrics' peak_signal_noise_ratio without data_range (train.py:339-344)
+            float v = __builtin_nontemporal_load(&partials[LOSS_BLOCKS * LOSS_TERMS + 2 * lane + (t - LOSS_TERMS)]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const float u = __shfl_xor(v, o, 64); v = t == LOSS_TERMS ? fmaxf(v, u) : fminf(v, u); }
+            if (lane == 0) { if (t == LOSS_TERMS) s_hi = v; else s_lo = v; }
+        }
     }
     __syncthreads();
+    if (threadIdx.x < LOSS_TERMS) vals[threadIdx.x] = s_val[threadIdx.x];
     if (threadIdx.x == 0) {
         const float w[LOSS_TERMS] = {1.f, 1.f, a.lambda_alphas, a.lambda_alphas, a.lambda_foreground, a.lambda_background,
                                      a.lambda_foreground, a.lambda_background, a.lambda_normals, a.lambda_normals};
         float tot = 0.0f;
-        for (int t = 0; t < LOSS_TERMS; ++t) tot += w[t] * vals[t];
+        for (int t = 0; t < LOSS_TERMS; ++t) tot += w[t] * s_val[t];
         vals[LOSS_TERMS] = tot;
-        // train.py:339-344: PSNR of the rendered batch (fine pass if there is one), data range 1 (models/evaluator.py:18)
-        vals[LOSS_TERMS + 1] = -10.0f * log10f(a.rgb_fine ? vals[1] : vals[0]);
+        // PSNR of the rendered batch (fine pass if there is one): 10 log10((max(target) - min(target))^2 / mse)
+        const float range = s_hi - s_lo;
+        vals[LOSS_TERMS + 1] = 10.0f * log10f(range * range / (a.rgb_fine ? s_val[1] : s_val[0]));
         *ticket = 0u;
     }
 }
@@ -358,6 +462,25 @@ extern "C" int anr_compact_ordered_riders(const float* pts, int64_t n, const flo
     return check_launch("anr_compact_ordered");
 }
 
+extern "C" int64_t anr_compact_state_words(int64_t n) { return (n + CB - 1) / CB + 1; }
+
+extern "C" int anr_compact_ordered_single(const float* pts, int64_t n, const float* fg, int n_fg, const float* bg, int n_bg, int rows,
+                                          int32_t* index_out, int32_t* pos_out, float* pts_out, int32_t* count_out, int64_t* state,
+                                          void* stream) {
+    ANR_REQUIRE(pts && index_out && pos_out && pts_out && count_out && state, ANR_E_BADARG, "anr_compact_ordered_single: null pointer");
+    ANR_REQUIRE(n_fg >= 0 && n_bg >= 0 && rows >= 0 && (n_fg == 0 || fg) && (n_bg == 0 || bg), ANR_E_BADARG,
+                "anr_compact_ordered_single: rider points without their array");
+    const Riders riders{fg, bg, n_fg, n_bg, rows};
+    const int64_t n_r = riders.count();
+    ANR_REQUIRE(n > 0 && n + n_r < (int64_t)1 << 31, ANR_E_BADARG, "anr_compact_ordered_single: n=%lld riders=%lld", (long long)n, (long long)n_r);
+    ANR_REQUIRE((((uintptr_t)pts | (uintptr_t)pts_out) & 15) == 0 && ((uintptr_t)state & 7) == 0, ANR_E_ALIGN,
+                "anr_compact_ordered_single: pts / pts_out must be 16-B aligned, state 8-B");
+    const int nb = (int)((n + n_r + CB - 1) / CB);
+    hipLaunchKernelGGL(compact_single_kernel, dim3(nb), dim3(CB), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(pts), n, riders, n_r,
+                       reinterpret_cast<unsigned long long*>(state), nb, count_out, index_out, pos_out, reinterpret_cast<float4*>(pts_out));
+    return check_launch("anr_compact_ordered_single");
+}
+
 extern "C" int anr_compact_ordered(const float* pts, int64_t n, int32_t* index_out, int32_t* pos_out, float* pts_out,
                                    int32_t* count_out, int32_t* workspace, void* stream) {
     return anr_compact_ordered_riders(pts, n, nullptr, 0, nullptr, 0, 0, index_out, pos_out, pts_out, count_out, workspace, stream);
@@ -402,7 +525,7 @@ extern "C" int anr_tangent_quads(const float* xyz, int64_t n, int64_t n_pad, flo
     return check_launch("anr_tangent_quads");
 }
 
-extern "C" int64_t anr_train_loss_ws_floats(void) { return LOSS_BLOCKS * LOSS_TERMS + 4; }
+extern "C" int64_t anr_train_loss_ws_floats(void) { return LOSS_BLOCKS * (LOSS_TERMS + 2) + 4; }
 
 static int check_loss_args(const anr_loss_args* a, const char* who) {
     ANR_REQUIRE(a, ANR_E_BADARG, "%s: null args", who);
@@ -438,7 +561,7 @@ extern "C" int anr_sample_coarse_backward(const float* g_z, const float* steps, 
     ANR_REQUIRE(g_z && steps && d_rays_out, ANR_E_BADARG, "anr_sample_coarse_backward: null pointer");
     ANR_REQUIRE(R > 0 && K > 0, ANR_E_BADARG, "anr_sample_coarse_backward: R=%lld K=%d", (long long)R, K);
     ANR_REQUIRE(((uintptr_t)d_rays_out & 15) == 0, ANR_E_ALIGN, "anr_sample_coarse_backward: d_rays_out must be 16-B aligned");
-    hipLaunchKernelGGL(sample_coarse_backward_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_z, steps,
+    hipLaunchKernelGGL(sample_coarse_backward_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g_z, steps,
                        t_rand, R, K, d_rays_out);
     return check_launch("anr_sample_coarse_backward");
 }

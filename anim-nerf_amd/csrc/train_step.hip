@@ -151,16 +151,20 @@ __global__ __launch_bounds__(256) void merge_backward2_kernel(const float* __res
     if (p < Kc) d_zc[(i / K) * Kc + p] = ga[i] + (gb ? gb[i] : 0.0f);
 }
 
-// sample_coarse_backward_kernel (train_glue.hip) on g = ga + gb + gc, added into the accumulated ray gradient
+// sample_coarse_backward_kernel (train_glue.hip) on g = ga + gb + gc, added into the accumulated ray gradient.
+// One WAVEFRONT per ray (round 5): lane k <-> sample k, k + 64, ...: every load instruction reads consecutive floats of one
+// ray, the two sums meet by shuffles.  (One THREAD per ray walked K samples with loads K floats apart from up to four
+// arrays: 72 us at 2,048 rays — as long as a pass of the 8-layer network over the same batch.)
 __global__ __launch_bounds__(256) void sample_coarse_backward_acc_kernel(const float* __restrict__ ga, const float* __restrict__ gb,
                                                                          const float* __restrict__ gc, const float* __restrict__ steps,
                                                                          const float* __restrict__ t_rand, const float* __restrict__ dfar_a,
                                                                          const float* __restrict__ dfar_b, int64_t R, int K,
                                                                          float* __restrict__ d_rays) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
     float dn = 0.0f, df = 0.0f;
-    for (int k = 0; k < K; ++k) {
+    for (int k = lane; k < K; k += 64) {
         const float s = steps[k];
         float e = s;
         if (t_rand) {
@@ -171,10 +175,14 @@ __global__ __launch_bounds__(256) void sample_coarse_backward_acc_kernel(const f
         dn += gk * (1.0f - e);
         df += gk * e;
     }
-    if (dfar_a) df += dfar_a[r];
-    if (dfar_b) df += dfar_b[r];
-    d_rays[r * 8 + 6] += dn;
-    d_rays[r * 8 + 7] += df;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { dn += __shfl_xor(dn, o, 64); df += __shfl_xor(df, o, 64); }
+    if (lane == 0) {
+        if (dfar_a) df += dfar_a[r];
+        if (dfar_b) df += dfar_b[r];
+        d_rays[r * 8 + 6] += dn;
+        d_rays[r * 8 + 7] += df;
+    }
 }
 
 }  // namespace anr
@@ -232,7 +240,7 @@ extern "C" int anr_sample_coarse_backward_acc(const float* g_a, const float* g_b
                                               float* d_rays_acc, void* stream) {
     ANR_REQUIRE(g_a && steps && d_rays_acc, ANR_E_BADARG, "anr_sample_coarse_backward_acc: null pointer");
     ANR_REQUIRE(R > 0 && K > 0, ANR_E_BADARG, "anr_sample_coarse_backward_acc: R=%lld K=%d", (long long)R, K);
-    hipLaunchKernelGGL(sample_coarse_backward_acc_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_a, g_b,
+    hipLaunchKernelGGL(sample_coarse_backward_acc_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g_a, g_b,
                        g_c, steps, t_rand, dfar_a, dfar_b, R, K, d_rays_acc);
     return check_launch("anr_sample_coarse_backward_acc");
 }
@@ -255,6 +263,42 @@ extern "C" int anr_add_inplace(float* dst, const float* src, int64_t n, void* st
     ANR_REQUIRE(dst && src && n > 0, ANR_E_BADARG, "anr_add_inplace: null pointer or n=%lld", (long long)n);
     hipLaunchKernelGGL(anr::add_inplace_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
     return anr::check_launch("anr_add_inplace");
+}
+
+namespace anr {
+constexpr int COPY_MAX_SEGS = 24;
+struct CopySegs { const char* src[COPY_MAX_SEGS]; char* dst[COPY_MAX_SEGS]; int64_t bytes[COPY_MAX_SEGS]; };
+// blockIdx.y = segment; the table rides in the kernel arguments (no upload, nothing for a graph to bake but the node itself)
+__global__ __launch_bounds__(256) void copy_segments_kernel(CopySegs t) {
+    const char* s = t.src[blockIdx.y];
+    char* d = t.dst[blockIdx.y];
+    const int64_t n = t.bytes[blockIdx.y];
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+    if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+        for (int64_t i = tid; i < n / 16; i += nth) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+        for (int64_t i = (n / 16) * 16 + tid; i < n; i += nth) d[i] = s[i];
+    } else {
+        for (int64_t i = tid; i < n; i += nth) d[i] = s[i];
+    }
+}
+}  // namespace anr
+
+extern "C" int anr_copy_segments(const void* const* src, void* const* dst, const int64_t* bytes, int n, void* stream) {
+    ANR_REQUIRE(src && dst && bytes, ANR_E_BADARG, "anr_copy_segments: null pointer");
+    ANR_REQUIRE(n > 0 && n <= anr::COPY_MAX_SEGS, ANR_E_BADARG, "anr_copy_segments: n=%d segments (1..%d)", n, anr::COPY_MAX_SEGS);
+    anr::CopySegs t{};
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        ANR_REQUIRE(src[i] && dst[i] && bytes[i] >= 0, ANR_E_BADARG, "anr_copy_segments: segment %d: null pointer or negative size", i);
+        t.src[i] = reinterpret_cast<const char*>(src[i]);
+        t.dst[i] = reinterpret_cast<char*>(dst[i]);
+        t.bytes[i] = bytes[i];
+        most = bytes[i] > most ? bytes[i] : most;
+    }
+    int64_t blocks = (most / 16 + 255) / 256;
+    blocks = blocks < 1 ? 1 : blocks > 64 ? 64 : blocks;
+    hipLaunchKernelGGL(anr::copy_segments_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, t);
+    return anr::check_launch("anr_copy_segments");
 }
 
 extern "C" int anr_zero_fill(void* ptr, int64_t bytes, void* stream) {

@@ -1577,7 +1577,7 @@ __device__ __forceinline__ int wb_slot(int* keys, int v) {
 __global__ __launch_bounds__(WB_THREADS) void warp_backward_kernel(
     const float4* __restrict__ d_pts, const float* __restrict__ rays, int ray_stride, const float* __restrict__ z, int K,
     const float* __restrict__ ober2cano, const int4* __restrict__ nbr_idx, const float4* __restrict__ nbr_w, int V,
-    int64_t N, float* __restrict__ d_o2c, float* __restrict__ d_rays, float* __restrict__ d_z) {
+    int64_t N, float* __restrict__ d_o2c, float* __restrict__ d_rays, float* __restrict__ d_z, const int32_t* __restrict__ pos) {
     __shared__ int hkey[WB_SLOTS];
     __shared__ float hval[WB_SLOTS][12];
     for (int i = threadIdx.x; i < WB_SLOTS; i += WB_THREADS) {
@@ -1590,7 +1590,12 @@ __global__ __launch_bounds__(WB_THREADS) void warp_backward_kernel(
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = n < N;
     const int64_t o = (int64_t)b * N + (in_range ? n : 0);
-    const float4 g = in_range ? d_pts[o] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // pos (anr_warp_backward_compact): d_pts holds the rows of the COMPACTED list of valid samples; pos[sample] = its row or -1
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in_range) {
+        if (pos) { const int r = pos[o]; if (r >= 0) g = d_pts[r]; }
+        else g = d_pts[o];
+    }
     const float4 w4 = in_range ? nbr_w[o] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float w[4] = {w4.x, w4.y, w4.z, w4.w};
     const bool live = (w[0] != 0.f || w[1] != 0.f || w[2] != 0.f || w[3] != 0.f) && (g.x != 0.f || g.y != 0.f || g.z != 0.f);
@@ -1891,8 +1896,25 @@ extern "C" int anr_warp_backward(const float* d_pts, const float* rays, int ray_
     hipLaunchKernelGGL(warp_backward_kernel, grid, dim3(WB_THREADS), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(d_pts), rays, ray_stride, z, K, ober2cano,
                        reinterpret_cast<const int4*>(nbr_idx), reinterpret_cast<const float4*>(nbr_w), V, N,
-                       d_ober2cano, d_rays, d_z);
+                       d_ober2cano, d_rays, d_z, nullptr);
     return check_launch("anr_warp_backward");
+}
+
+extern "C" int anr_warp_backward_compact(const float* d_pts_rows, const int32_t* pos, const float* rays, int ray_stride, const float* z,
+                                         int K, const float* ober2cano, const int32_t* nbr_idx, const float* nbr_w, int bs, int V,
+                                         int64_t N, float* d_ober2cano, float* d_rays, float* d_z, void* stream) {
+    ANR_REQUIRE(d_pts_rows && pos && rays && z && ober2cano && nbr_idx && nbr_w && d_ober2cano && d_rays && d_z, ANR_E_BADARG,
+                "anr_warp_backward_compact: null pointer");
+    ANR_REQUIRE(bs > 0 && V > 0 && N > 0 && K > 0 && N % K == 0 && ray_stride >= 8, ANR_E_BADARG,
+                "anr_warp_backward_compact: bs=%d V=%d N=%lld K=%d", bs, V, (long long)N, K);
+    ANR_REQUIRE((((uintptr_t)d_pts_rows | (uintptr_t)nbr_idx | (uintptr_t)nbr_w) & 15) == 0, ANR_E_ALIGN,
+                "anr_warp_backward_compact: d_pts_rows / nbr_idx / nbr_w must be 16-B aligned");
+    dim3 grid((unsigned)((N + WB_THREADS - 1) / WB_THREADS), bs);
+    hipLaunchKernelGGL(warp_backward_kernel, grid, dim3(WB_THREADS), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(d_pts_rows), rays, ray_stride, z, K, ober2cano,
+                       reinterpret_cast<const int4*>(nbr_idx), reinterpret_cast<const float4*>(nbr_w), V, N,
+                       d_ober2cano, d_rays, d_z, pos);
+    return check_launch("anr_warp_backward_compact");
 }
 
 extern "C" int anr_knn(const void* knn_index, const float* xyz, int bs, int V, int64_t N, float* dist_out,

@@ -80,6 +80,9 @@ class ExplicitTrainStep:
             return False
         if (torch.rand, torch.randn, torch.randn_like) != _TORCH_DRAWS:
             return False
+        bm = m.body_model
+        if bm.lbs_weights.shape[1] != 24 or bm.shapedirs.shape[-1] != 10:        # (anr_frame_setup: the SMPL body of the shipped configs)
+            return False
         if not (getattr(m, "use_unpose", False) and m.k_neigh == 4 and not m.use_view and hasattr(m, "nerf_fine") and m.nerf_fine is not m.nerf
                 and m.evaluate_valid_only and m.skip_far_samples and m.nerf._hip_supported() and m.nerf_fine._hip_supported()):
             return False
@@ -88,31 +91,55 @@ class ExplicitTrainStep:
             return False
         if rays.dim() != 4 or rays.shape[-1] != 8 or rays.shape[1] * rays.shape[2] > hp.chunk or not rays.is_contiguous():
             return False
-        if m.nerf.grad_sink is None or m.nerf_fine.grad_sink is None:
+        # the networks train (their flat gradient buffers are the weight-gradient kernels' destination), or they are FROZEN
+        # and the poses alone train: the `_refine` stage of the shipped configs (configs/people_snapshot/*_refine.yaml:
+        # pretrained_model_requires_grad False, train.py:433-437)
+        frozen = self.frozen_networks()
+        if not frozen and (m.nerf.grad_sink is None or m.nerf_fine.grad_sink is None):
             return False
+        if frozen and (any(p.requires_grad for net in (m.nerf, m.nerf_fine) for p in net.parameters())
+                       or tr.body_model_params is None or frame_idx is None):
+            return False
+        # the prior points ride along as rows of the MLP passes: one set per frame of the batch, float32 on the rays' device
+        # (any other shape goes through the autograd step, which queries them on their own)
+        for pts in (fg_points, bg_points):
+            if pts is not None and not (torch.is_tensor(pts) and pts.device == rays.device and pts.dtype == torch.float32
+                                        and pts.dim() == 3 and pts.shape[0] == rays.shape[0] and pts.shape[2] == 3):
+                return False
         # pose refinement through a BodyModelParams table (optim_body_params), or constant poses given as a dict
         if tr.body_model_params is not None and frame_idx is not None:
             t = tr.body_model_params
             if not all(getattr(t, n).weight.is_cuda and getattr(t, n).weight.is_contiguous() for n in t.param_names):
                 return False
             ws = [getattr(t, n).weight for n in t.param_names]
+            if frozen:
+                return all(w.requires_grad for w in ws)
             return all(w.requires_grad for w in ws) or not any(w.requires_grad for w in ws)
-        return body_model_params is not None and not any(torch.is_tensor(v) and v.requires_grad for v in body_model_params.values())
+        if body_model_params is None or any(torch.is_tensor(v) and v.requires_grad for v in body_model_params.values()):
+            return False
+        p = body_model_params
+        return all(torch.is_tensor(p.get(k)) and p[k].is_cuda and p[k].dtype == torch.float32 and p[k].dim() == 2 and p[k].shape[-1] == d
+                   for k, d in (("betas", 10), ("global_orient", 3), ("body_pose", 69), ("transl", 3)))
+
+    def frozen_networks(self) -> bool:
+        m = self.tr.model
+        return not any(p.requires_grad for p in m.nerf.parameters()) and not any(p.requires_grad for p in m.nerf_fine.parameters())
 
     # ------------------------------------------------------------------------------------------------------------------
-    def _mlp_pass(self, net, mode_id, pts, fg, bg, pack=None):
+    def _mlp_pass(self, net, mode_id, pts, fg, bg, pack=None, frozen=False):
         """compacted training forward of one network on pts[n,4] (+ the prior points as riders): -> state for the backward,
         out_full[n + n_r, 4]"""
         params = [dict(net.named_parameters())[k] for k in PARAM_KEYS]
         if pack is None:
             pack = _cached_pack(params, mode_id, False)
-        index, pos, pts_c, count = ops.compact_ordered_riders(pts, fg, bg)
+        index, pos, pts_c, count = ops.compact_ordered_riders(pts, fg, bg, single=True)
         rows = count[1:2]
-        out_c, act = ops.mlp_forward_save(pack, mode_id, pts_c, False, count=rows)
+        # (frozen networks: nothing reads the saved activations — the weight gradients' operands — only the sign bits)
+        out_c, act = ops.mlp_forward_save(pack, mode_id, pts_c, False, count=rows, bits_only=frozen)
         out_full = ops.expand_rows(out_c, pos, -1e5)
         return dict(net=net, params=params, index=index, pos=pos, pts_c=pts_c, count=count, rows=rows, out_c=out_c, act=act), out_full
 
-    def _mlp_backward(self, st, mode_id, d_out_full, want_pts, keep, pack_b=None):
+    def _mlp_backward(self, st, mode_id, d_out_full, want_pts, keep, pack_b=None, frozen=False):
         """activation, weight (into the network's flat buffer) and — want_pts — point gradients of one compacted pass.
         The weight gradients feed nothing else in the step: they run on a stream of their own (`_wgrad_stream`) behind the
         backward chain, which goes on with the gradient towards the points; `keep` holds what that stream still reads."""
@@ -121,7 +148,9 @@ class ExplicitTrainStep:
             weights_generation(params[0], backward=True)
             pack_b = _cached_pack(params, mode_id, True)
         g4 = ops.mlp_head_grad(d_out_full, st["index"], st["out_c"], st["pts_c"], st["count"], False)
-        dact = ops.mlp_backward(pack_b, mode_id, g4, act, count=rows)
+        dact = ops.mlp_backward(pack_b, mode_id, g4, act, count=rows, enc_only=frozen)
+        if frozen:                                                   # the gradient towards the points, and nothing else
+            return ops.mlp_dpoints(pack_b, mode_id, dact, st["pts_c"], count=rows)
         main = torch.cuda.current_stream(self.dev)
         side = self._wgrad_stream
         side.wait_stream(main)                                       # (the fork is HERE: the weight gradients wait for dact only)
@@ -135,12 +164,9 @@ class ExplicitTrainStep:
         # (issued AFTER the chain's next launches: the graph executor keeps the successor captured first on the queue of the
         # activation gradients and moves the other one to a queue that may be busy with the normals branch's tail — with the
         # weight gradients first, the chain towards the points waited there: 1.64 against 1.7-1.9 ms per step at 2 frames)
-        out = None
-        if want_pts:
-            d_enc = ops.mlp_denc(mode_id, dact, params[PARAM_KEYS.index("xyz_encoding_1.0.weight")],
-                                 params[PARAM_KEYS.index("xyz_encoding_5.0.weight")], count=rows)
-            d_pts_c = ops.encode_backward(st["pts_c"], d_enc, count=rows)
-            out = ops.expand_rows(d_pts_c, st["pos"], 0.0)
+        # (the gradient towards the points stays COMPACT — one row per valid sample, anr_mlp_dpoints: d-encoding and the
+        # encoding's derivative in one launch — and the warp's backward looks a sample's row up through `pos`)
+        out = ops.mlp_dpoints(pack_b, mode_id, dact, st["pts_c"], count=rows) if want_pts else None
         weight_gradients()
         return out
 
@@ -159,7 +185,12 @@ class ExplicitTrainStep:
 
     # ------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def run(self, rays, rgbs, alphas, body_model_params, template_params, fg_points, bg_points, perturb, frame_idx):
+    def run(self, rays, rgbs, alphas, body_model_params, template_params, fg_points, bg_points, perturb, frame_idx, at_split=None):
+        """at_split (more than one rank, the graphed step): called once, on the step's stream with every side stream joined, at the
+        point where the FINE network's flat gradient is complete (its render pass's and the normals branch's weight gradients
+        are in) and the coarse pass's backward has not begun — the caller ends one graph capture there and begins the next,
+        so that a replayed step can all-reduce the fine network's bucket while the second graph (coarse backward, pose chain)
+        replays (Trainer._step_graphed).  Same launches, same sums."""
         tr, m, vr, hp = self.tr, self.tr.model, self.tr.renderer, self.tr.hp
         lib = _lib.load()
         dev = rays.device
@@ -169,7 +200,8 @@ class ExplicitTrainStep:
         K = Kc + Kf
         n_c, n_f = bs * R * Kc, bs * R * K
         mode_id = ops.MLP_MODES[m.nerf.mlp_mode] & 0xff
-        sinks = (m.nerf.grad_sink, m.nerf_fine.grad_sink)
+        frozen = self.frozen_networks()
+        sinks = () if frozen else (m.nerf.grad_sink, m.nerf_fine.grad_sink)
         refine = False
         table = tr.body_model_params if (tr.body_model_params is not None and frame_idx is not None) else None
 
@@ -213,16 +245,41 @@ class ExplicitTrainStep:
         nets = []
         for net in (m.nerf, m.nerf_fine):
             params = [dict(net.named_parameters())[k] for k in PARAM_KEYS]
-            nets.append((net, params, _cached_pack(params, mode_id, False)))
+            nets.append((net, params, _cached_pack(params, mode_id, False, frozen=frozen)))
         self._wgrad_stream.wait_stream(main)
         with torch.cuda.stream(self._wgrad_stream):
             packs_b = []
             for net, params, _ in nets:
-                weights_generation(params[0], backward=True)
-                packs_b.append(_cached_pack(params, mode_id, True))
+                if not frozen:
+                    weights_generation(params[0], backward=True)
+                packs_b.append(_cached_pack(params, mode_id, True, frozen=frozen))
             packs_b_ready = torch.cuda.Event()
             packs_b_ready.record(self._wgrad_stream)
-        if want_normals:
+        if want_normals and frozen:
+            # frozen networks: the regulariser has no parameter to reach (its points are template vertices + noise, its
+            # function the network) — only its VALUE enters the step's loss (train.py:288-309 computes it regardless), so the
+            # branch is its two forward launches (the inference kernel in tangent mode keeps nothing)
+            pair = draws["pair"]
+            n_pad = -(-pair.shape[0] // 16) * 16
+            self._side.wait_stream(main)
+            box = {}
+
+            def normals_forward():
+                with torch.cuda.stream(self._side):
+                    pts4 = box["pts4"] = ops.tangent_quads(pair, n_pad)
+                    for net, params, pack in nets:
+                        out_t, act_t = ops.mlp_forward_save(pack, mode_id, pts4, sigma_only=True, tangent=True)
+                        tan.append((net, params, act_t, out_t.view(n_pad, 4)))
+                    box["quads_ready"] = torch.cuda.Event()
+                    box["quads_ready"].record(self._side)
+                    keep.append(pts4)
+
+            def normals_first_network():
+                pass
+
+            def normals_second_network():
+                pass
+        elif want_normals:
             pair = draws["pair"]
             n_pad = -(-pair.shape[0] // 16) * 16
             consts_n = {"lambda_normals": hp.lambda_normals, "nv": m.verts_template.shape[1], "normal_sets": m.verts_template.shape[0],
@@ -268,25 +325,26 @@ class ExplicitTrainStep:
                 with torch.cuda.stream(self._side):
                     normals_backward(1)
 
-        # ---- per-frame state (models/anim_nerf.py:108-151) from the parameter tables
+        # ---- per-frame state (models/anim_nerf.py:108-151) from the parameter tables: table rows, SMPL, root frame, rays,
+        # ober2cano in two launches (ops.frame_setup), then the KNN index
+        rays_w = rays.view(bs, R, 8)
         if table is not None:
             w = {n: getattr(table, n).weight for n in table.param_names}
             refine = all(v.requires_grad for v in w.values())
-            betas, pose, transl = ops.gather_frame_params(frame_idx, w["betas"], w["global_orient"], w["body_pose"], w["transl"])
+            tables, fidx = (w["betas"], w["global_orient"], w["body_pose"], w["transl"]), frame_idx
         else:
             p = body_model_params
-            betas = p["betas"].expand(bs, -1).contiguous()
-            pose = torch.cat([p["global_orient"], p["body_pose"]], 1)
-            transl = p["transl"].expand(bs, -1).contiguous()
-        verts, joints, A, T, so, po = ops.smpl_forward(betas, pose, transl, bm.v_template, bm.shapedirs, bm.posedirs, bm.J_regressor,
-                                                       bm.parents, bm.lbs_weights)
-        m.shape_offsets, m.pose_offsets, m.joints_transform = so, po, A
-        g_inv, m.global_transform, m.verts, m.joints, m.verts_transform = ops.to_root_frame_from_chain(A, verts, joints, T)
+            tables, fidx = (p["betas"].expand(bs, -1).contiguous(), p["global_orient"].expand(bs, -1).contiguous(),
+                            p["body_pose"].expand(bs, -1).contiguous(), p["transl"].expand(bs, -1).contiguous()), None
+        fs = ops.frame_setup(tables, fidx, m._chain_consts(), bm,
+                             (m.verts_transform_template, m.shape_offsets_template, m.pose_offsets_template), rays_w)
+        betas, pose, transl, A, g_inv = fs["betas"], fs["pose"], fs["transl"], fs["A"], fs["g_inv"]
+        m.shape_offsets, m.pose_offsets, m.joints_transform = fs["shape_offsets"], fs["pose_offsets"], A
+        m.global_transform, m.verts, m.joints, m.verts_transform = fs["g_root"], fs["verts"], fs["joints"], fs["verts_transform"]
         m._knn_index = None
         m._refine = None
-        rays_w = rays.view(bs, R, 8)
-        rays_b = ops.rays_to_body(g_inv, rays_w)
-        o2c = m._ober2cano_values()
+        rays_b = fs["rays_body"]
+        o2c = fs["ober2cano"]
         m.ober2cano_transform = o2c
         index = m.knn_index()
         lbs, thr = bm.lbs_weights, m.dis_threshold
@@ -299,7 +357,7 @@ class ExplicitTrainStep:
             normals_forward()
             normals_first_network()
         n_r = bs * ((fg_points.shape[1] if fg_points is not None else 0) + (bg_points.shape[1] if bg_points is not None else 0))
-        st_c, out_c = self._mlp_pass(m.nerf, mode_id, pts_c.view(-1, 4), fg_points, bg_points, nets[0][2])
+        st_c, out_c = self._mlp_pass(m.nerf, mode_id, pts_c.view(-1, 4), fg_points, bg_points, nets[0][2], frozen)
         flat_rays = rays_b.view(bs * R, 8)
         noise_c = draws["noise_c"].view(bs * R, Kc) if noisy else None
         w_c, rgb_c, dep_c, acc_c = ops.composite(out_c[:n_c].view(bs * R, Kc, 4), zc.view(bs * R, Kc), flat_rays, vr.white_bkgd,
@@ -312,7 +370,7 @@ class ExplicitTrainStep:
                                               reuse=(pts_c, None, perm, nidx_c, nw_c))
         if want_normals:
             normals_second_network()
-        st_f, out_f = self._mlp_pass(m.nerf_fine, mode_id, pts_f.view(-1, 4), fg_points, bg_points, nets[1][2])
+        st_f, out_f = self._mlp_pass(m.nerf_fine, mode_id, pts_f.view(-1, 4), fg_points, bg_points, nets[1][2], frozen)
         noise_f = draws["noise_f"].view(bs * R, K) if noisy else None
         _, rgb_f, dep_f, acc_f = ops.composite(out_f[:n_f].view(bs * R, K, 4), zs.view(bs * R, K), flat_rays, vr.white_bkgd,
                                                noise=noise_f, want_weights=False)
@@ -361,27 +419,37 @@ class ExplicitTrainStep:
         if refine:
             _, dz_f, dfar_f = res
         main.wait_event(packs_b_ready)
-        d_pts_f = self._mlp_backward(st_f, mode_id, d_out_f, refine, keep, packs_b[1])
+        d_pts_f = self._mlp_backward(st_f, mode_id, d_out_f, refine, keep, packs_b[1], frozen)
         dz_c_from_fine = None
         if refine:
-            dzw_f = ops.warp_backward_acc(d_pts_f[:n_f].view(bs, R * K, 4), rays_b, zs, o2c, nidx_f, nw_f, d_o2c, d_rays)
+            dzw_f = ops.warp_backward_acc(d_pts_f, rays_b, zs, o2c, nidx_f, nw_f, d_o2c, d_rays, pos=st_f["pos"])
             dz_c_from_fine = ops.merge_backward2(dzw_f.view(bs * R, K), dz_f, perm, Kc)
+        normals_joined = False
+        if at_split is not None and not frozen:
+            main.wait_stream(self._wgrad_stream)                     # the fine render pass's weight gradients
+            if want_normals:                                         # (both networks' share of the regulariser: 0 + t + r == 0 + r + t)
+                main.wait_stream(self._side)
+                for net, tg in tan_grads:
+                    ops.add_inplace(net.grad_sink.flat, tg)
+                normals_joined = True
+            at_split()
+            self._wgrad_stream.wait_stream(main)                     # (the side stream starts the second capture behind the first's end)
         res = ops.composite_backward(out_c[:n_c].view(bs * R, Kc, 4), zc.view(bs * R, Kc), flat_rays, vr.white_bkgd, d_rgb_c, None, d_acc_c,
                                      noise=noise_c, want_dz=refine, out=d_out_c)
-        d_pts_c = self._mlp_backward(st_c, mode_id, d_out_c, refine, keep, packs_b[0])
+        d_pts_c = self._mlp_backward(st_c, mode_id, d_out_c, refine, keep, packs_b[0], frozen)
         if refine:
             _, dz_c, dfar_c = res
-            dzw_c = ops.warp_backward_acc(d_pts_c[:n_c].view(bs, R * Kc, 4), rays_b, zc, o2c, nidx_c, nw_c, d_o2c, d_rays)
+            dzw_c = ops.warp_backward_acc(d_pts_c, rays_b, zc, o2c, nidx_c, nw_c, d_o2c, d_rays, pos=st_c["pos"])
             ops.sample_coarse_backward_acc(d_rays.view(bs * R, 8), steps, draws["t_rand"].view(bs * R, Kc) if jitter else None,
                                            dzw_c.view(bs * R, Kc), dz_c, dz_c_from_fine, dfar_c, dfar_f)
             c = m._chain_consts()
             grads = ops.frame_backward(betas, pose, transl, c["J0"], c["JS"], c["parents"], c["lbs_weights"], c["shapedirs"], c["posedirs"],
-                                       c["T_template"], rays_world=rays_w, d_o2c=d_o2c, d_rays=d_rays)
+                                       c["T_template"], rays_world=rays_w, d_o2c=d_o2c, d_rays=d_rays, chain_values=(A, g_inv))
             wt = {n: getattr(table, n).weight for n in table.param_names}
             ops.scatter_frame_param_grads(frame_idx, grads, wt["global_orient"].shape[0], wt["betas"].shape[0], wt["betas"].grad,
                                           wt["global_orient"].grad, wt["body_pose"].grad, wt["transl"].grad)
         main.wait_stream(self._wgrad_stream)
-        if want_normals:                                             # flat = render passes' + normals' (0 + r + t == 0 + t + r bit for bit)
+        if want_normals and not normals_joined:                      # flat = render passes' + normals' (0 + r + t == 0 + t + r bit for bit)
             main.wait_stream(self._side)
             for net, tg in tan_grads:
                 ops.add_inplace(net.grad_sink.flat, tg)

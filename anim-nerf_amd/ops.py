@@ -108,7 +108,7 @@ def smpl_forward(betas, pose, transl, v_template, shapedirs, posedirs, J_regress
 
 
 def frame_backward(betas, pose, transl, J0, JS, parents, lbs_weights, shapedirs, posedirs, T_template, rays_world=None,
-                   d_o2c=None, d_rays=None, vertex_joint_mask=None, forward_mode: bool = False) -> torch.Tensor:
+                   d_o2c=None, d_rays=None, vertex_joint_mask=None, forward_mode: bool = False, chain_values=None) -> torch.Tensor:
     """dL/d(betas | global_orient | body_pose | transl)[bs,85] of the per-frame chain (SMPL/LBS, root frame, ober2cano) from
     dL/d ober2cano[bs,V,4,4] and / or dL/d rays_body[bs,R,8] (csrc/frame_bwd.hip).  forward_mode=True: the one-launch
     forward-mode kernel (one workgroup per frame and parameter), kept as the cross-check of the adjoint kernels."""
@@ -129,12 +129,15 @@ def frame_backward(betas, pose, transl, J0, JS, parents, lbs_weights, shapedirs,
         vertex_joint_mask = _dev(vertex_joint_mask, "vertex_joint_mask", torch.int32)
     if not forward_mode:
         # reverse mode through the per-vertex inverses, forward mode through the 24-joint chain (csrc/frame_bwd.hip)
+        # chain_values = (joints_transform[bs,J,4,4], g_inv[bs,4,4]) of the forward pass: the per-vertex kernel reads them instead
+        # of walking the 24-joint chain again in every workgroup
+        A_fwd, g_inv = (None, None) if chain_values is None else (_dev(chain_values[0], "joints_transform"), _dev(chain_values[1], "g_inv"))
         ws = torch.empty(lib.anr_frame_backward_ws_floats(bs, V), dtype=torch.float32, device=pose.device)
         with _timed("frame_backward", bs):
-            _lib.check(lib.anr_frame_backward_adjoint(
+            _lib.check(lib.anr_frame_backward_adjoint_values(
                 _ptr(betas), _ptr(pose), _ptr(transl), bs, _ptr(J0), _ptr(JS), _ptr(parents), _ptr(lbs_weights), _ptr(shapedirs),
                 _ptr(posedirs), V, _ptr(T_template), T_template.shape[0], _ptr(rays_world), rs, R, _ptr(d_o2c),
-                _ptr(d_rays), _ptr(ws), _ptr(grads), _stream(grads)), "anr_frame_backward_adjoint")
+                _ptr(d_rays), _ptr(A_fwd), _ptr(g_inv), _ptr(ws), _ptr(grads), _stream(grads)), "anr_frame_backward_adjoint")
         return grads
     with _timed("frame_backward", bs):
         _lib.check(lib.anr_frame_backward(_ptr(betas), _ptr(pose), _ptr(transl), bs, _ptr(J0), _ptr(JS), _ptr(parents),
@@ -143,6 +146,46 @@ def frame_backward(betas, pose, transl, J0, JS, parents, lbs_weights, shapedirs,
                                           _ptr(d_rays), _ptr(vertex_joint_mask),
                                           _ptr(grads), _stream(grads)), "anr_frame_backward")
     return grads
+
+
+def frame_setup(tables, frame_idx, consts, bm, template, rays_world=None):
+    """The per-frame set-up of a batch in two launches (anr_frame_setup): `tables` = (betas, global_orient, body_pose, transl)
+    — BodyModelParams' tables with frame_idx[bs] int64, or per-frame arrays with frame_idx None; consts = {"J0", "JS"};
+    bm the SMPL module's buffers; template = (T[bs_t,V,4,4], shape_off[bs_t,V,3], pose_off[bs_t,V,3]); rays_world[bs,R,8].
+    -> dict(betas, pose, transl, A, joints, g_inv, g_root, shape_offsets, pose_offsets, verts, verts_transform (root frame),
+    ober2cano, rays_body)."""
+    lib = _lib.load()
+    bw, gw, pw, tw = (_dev(t, n) for t, n in zip(tables, ("betas", "global_orient", "body_pose", "transl")))
+    if frame_idx is not None:
+        frame_idx = _dev(frame_idx, "frame_idx", torch.int64)
+        bs = frame_idx.numel()
+    else:
+        bs = gw.shape[0]
+        if bw.shape[0] != bs or pw.shape[0] != bs or tw.shape[0] != bs:
+            raise ValueError("frame_setup: per-frame arrays of one batch size")
+    dev = gw.device
+    V, J, NB = bm.lbs_weights.shape[0], bm.lbs_weights.shape[1], bm.shapedirs.shape[-1]
+    Tt, sot, pot = (_dev(t, n) for t, n in zip(template, ("T_template", "shape_offsets_template", "pose_offsets_template")))
+    R, rs = 0, 0
+    if rays_world is not None:
+        rays_world = _dev(rays_world, "rays_world")
+        R, rs = rays_world.shape[1], rays_world.shape[2]
+    f32 = dict(dtype=torch.float32, device=dev)
+    o = dict(betas=torch.empty(bs, NB, **f32), pose=torch.empty(bs, 3 * J, **f32), transl=torch.empty(bs, 3, **f32),
+             A=torch.empty(bs, J, 4, 4, **f32), joints=torch.empty(bs, J, 3, **f32), g_inv=torch.empty(bs, 4, 4, **f32),
+             g_root=torch.empty(bs, 4, 4, **f32), shape_offsets=torch.empty(bs, V, 3, **f32), pose_offsets=torch.empty(bs, V, 3, **f32),
+             verts=torch.empty(bs, V, 3, **f32), verts_transform=torch.empty(bs, V, 4, 4, **f32), ober2cano=torch.empty(bs, V, 4, 4, **f32),
+             rays_body=torch.empty(bs, R, 8, **f32) if R else None)
+    ws = torch.empty(bs, 9 * (J - 1), **f32)
+    J0, JS = _dev(consts["J0"], "J0"), _dev(consts["JS"], "JS")
+    _lib.check(lib.anr_frame_setup(
+        _ptr(frame_idx), _ptr(bw), bw.shape[0], _ptr(gw), _ptr(pw), _ptr(tw), bs, _ptr(J0), _ptr(JS), _ptr(_dev(bm.parents, "parents", torch.int64)),
+        _ptr(_dev(bm.v_template, "v_template")), _ptr(_dev(bm.shapedirs, "shapedirs")), _ptr(_dev(bm.posedirs, "posedirs")),
+        _ptr(_dev(bm.lbs_weights, "lbs_weights")), V, J, NB, _ptr(Tt), _ptr(sot), _ptr(pot), Tt.shape[0], _ptr(rays_world), rs, R,
+        _ptr(o["betas"]), _ptr(o["pose"]), _ptr(o["transl"]), _ptr(o["A"]), _ptr(o["joints"]), _ptr(o["g_inv"]), _ptr(o["g_root"]),
+        _ptr(o["shape_offsets"]), _ptr(o["pose_offsets"]), _ptr(o["verts"]), _ptr(o["verts_transform"]), _ptr(o["ober2cano"]),
+        _ptr(o["rays_body"]), _ptr(ws), _stream(ws)), "anr_frame_setup")
+    return o
 
 
 def to_root_frame(global_transform, verts, joints, T):
@@ -488,6 +531,19 @@ def mlp_denc(mode: int, dact: torch.Tensor, w1: torch.Tensor, w5: torch.Tensor, 
     return d_enc
 
 
+def mlp_dpoints(bwd_pack: torch.Tensor, mode: int, dact: torch.Tensor, pts: torch.Tensor, count: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """d_pts[n,4] = (dL/dxyz, 0) of the rows of a compacted pass: `mlp_denc` + `encode_backward` in one launch, the encoding
+    panels of layers 1 and 5 read from the backward weight pack (anr_mlp_dpoints)."""
+    lib = _lib.load()
+    dact, pts = _dev(dact, "dact", dact.dtype), _dev(pts, "pts")
+    n = dact.shape[0]
+    d_pts = torch.empty(n, 4, dtype=torch.float32, device=dact.device)
+    with _timed("mlp_dpoints", n if count is None else count):
+        _lib.check(lib.anr_mlp_dpoints(_ptr(bwd_pack), mode & 0xff, _ptr(dact), _ptr(pts), n, _ptr(count), _ptr(d_pts), _stream(d_pts)),
+                   "anr_mlp_dpoints")
+    return d_pts
+
+
 def encode_backward(pts: torch.Tensor, d_enc: torch.Tensor, count: Optional[torch.Tensor] = None) -> torch.Tensor:
     """d_pts[n,4] = (dL/dxyz, 0) from d_enc[n,63] (fp32)."""
     lib = _lib.load()
@@ -508,24 +564,27 @@ ACT_COLS = 2432                 # columns of a saved-activation / activation-gra
 
 def act_columns(act: torch.Tensor, c0: int = 0, c1: int = ACT_COLS) -> torch.Tensor:
     """Columns [c0, c1) (multiples of 32) of a saved-activation or activation-gradient buffer as a row-major [n, c1 - c0]
-    tensor (a copy).  The kernels keep these buffers BLOCKED by 32-column tile — 76 blocks of [n][32], then the ReLU sign
-    bits (csrc/mlp_core.h) — inside the n x anr_mlp_act_cols() elements `mlp_forward_save` / `mlp_backward` return."""
+    tensor (a copy).  The kernels keep these buffers BLOCKED by 32-column tile and by 16-byte piece of a row inside it — 76 x
+    (4 bf16 / 8 fp32) arrays of [n][16 bytes], then the ReLU sign bits (csrc/mlp_core.h) — inside the n x anr_mlp_act_cols() elements `mlp_forward_save` / `mlp_backward` return."""
     n = act.shape[0]
     assert c0 % 32 == 0 and c1 % 32 == 0 and 0 <= c0 < c1 <= ACT_COLS
-    blocks = act.reshape(-1)[:ACT_COLS * n].view(ACT_COLS // 32, n, 32)
-    return blocks[c0 // 32:c1 // 32].permute(1, 0, 2).reshape(n, c1 - c0)
+    epp = 16 // act.element_size()                               # inside a block: piece arrays [n][16 bytes] (8 bf16 / 4 fp32)
+    pieces = act.reshape(-1)[:ACT_COLS * n].view(ACT_COLS // epp, n, epp)
+    return pieces[c0 // epp:c1 // epp].permute(1, 0, 2).reshape(n, c1 - c0)
 
 
 def mlp_backward(bwd_pack: torch.Tensor, mode: int, g: torch.Tensor, act: torch.Tensor, sigma_only: bool = False,
-                 tangent: bool = False, count: Optional[torch.Tensor] = None):
+                 tangent: bool = False, count: Optional[torch.Tensor] = None, enc_only: bool = False):
     """g[n,4] = (dL/d rgb_pre, dL/d sigma), act from mlp_forward_save -> dact (same dtype, same blocked layout: see
-    `act_columns`): the pre-activation gradient of every layer (trunk columns only if sigma_only)."""
+    `act_columns`): the pre-activation gradient of every layer (trunk columns only if sigma_only).
+    enc_only: frozen networks — only the gradients of layers 1 and 5 (what mlp_denc reads) are written (ANR_MLP_FLAG_ENC_ONLY)."""
     lib = _lib.load()
     g, act = _dev(g, "g"), _dev(act, "act", act.dtype)
     n = g.shape[0]
     dact = torch.empty_like(act)
-    m = (mode & 0xff) | (ANR_MLP_FLAG_SIGMA_ONLY if sigma_only else 0) | (ANR_MLP_FLAG_TANGENT if tangent else 0)
-    with _timed("mlp_backward", n if count is None else count):
+    m = ((mode & 0xff) | (ANR_MLP_FLAG_SIGMA_ONLY if sigma_only else 0) | (ANR_MLP_FLAG_TANGENT if tangent else 0)
+         | (_lib.ANR_MLP_FLAG_ENC_ONLY if enc_only else 0))
+    with _timed("mlp_backward_enc" if enc_only else "mlp_backward", n if count is None else count):
         if count is not None:
             _lib.check(lib.anr_mlp_backward_counted(_ptr(bwd_pack), m, _ptr(g), _ptr(act), _ptr(dact), n, _ptr(count), _stream(dact)),
                        "anr_mlp_backward")
@@ -726,14 +785,15 @@ def composite_backward(rgbs, z, rays, white_bkgd: bool, g_rgb, g_depth, g_acc, n
 
 
 def mlp_forward_save(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_only: bool = False, tangent: bool = False,
-                     count: Optional[torch.Tensor] = None):
+                     count: Optional[torch.Tensor] = None, bits_only: bool = False):
     """Training forward: (out, act) — act (n x anr_mlp_act_cols() elements, blocked by 32-column tile: `act_columns`) keeps
     every layer's post-activation output and the ReLU sign bits.
-    tangent (with sigma_only): points in quads, rows 4p+1..3 carry d/dx, d/dy, d/dz (ANR_MLP_FLAG_TANGENT)."""
+    tangent (with sigma_only): points in quads, rows 4p+1..3 carry d/dx, d/dy, d/dz (ANR_MLP_FLAG_TANGENT).
+    bits_only: frozen networks (the `_refine` stage) — only the sign bits are written (ANR_MLP_FLAG_BITS_ONLY)."""
     lib = _lib.load()
     pts = _dev(pts, "pts")
     n = pts.numel() // 4
-    mode = mode & 0xff
+    mode = (mode & 0xff) | (_lib.ANR_MLP_FLAG_BITS_ONLY if bits_only else 0)
     if sigma_only:
         mode |= ANR_MLP_FLAG_SIGMA_ONLY | (ANR_MLP_FLAG_TANGENT if tangent else 0)
         out = torch.empty(n, dtype=torch.float32, device=pts.device)
@@ -741,7 +801,7 @@ def mlp_forward_save(pack: torch.Tensor, mode: int, pts: torch.Tensor, sigma_onl
         out = torch.empty(n, 4, dtype=torch.float32, device=pts.device)
     act = torch.empty(n, lib.anr_mlp_act_cols(), device=pts.device,
                       dtype=torch.bfloat16 if (mode & 0xff) == ANR_MLP_BF16 else torch.float32)
-    with _timed("mlp_forward_save", n if count is None else count):
+    with _timed("mlp_forward_bits" if bits_only else "mlp_forward_save", n if count is None else count):
         if count is not None:                              # rows on the device; act is sized (and blocked) for all n
             _lib.check(lib.anr_mlp_forward_save_indexed(_ptr(pack), mode, _ptr(pts), None, _ptr(count), n, _ptr(out), _ptr(act),
                                                         _stream(out)), "anr_mlp_forward_save")
@@ -1009,6 +1069,25 @@ def add_inplace(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     return dst
 
 
+def copy_segments(pairs) -> None:
+    """dst.copy_(src) for every (dst, src) of `pairs` (contiguous tensors of equal byte size on the current device) in ONE launch
+    of the library (anr_copy_segments): the batch of a training step moving into the buffers a captured step replays from."""
+    import ctypes as C
+    lib = _lib.load()
+    pairs = [(d, s) for d, s in pairs if d.numel()]
+    for i in range(0, len(pairs), 24):
+        part = pairs[i:i + 24]
+        for d, s in part:
+            if not (d.is_cuda and s.is_cuda and d.is_contiguous() and s.is_contiguous() and d.device == s.device
+                    and d.numel() * d.element_size() == s.numel() * s.element_size()):
+                raise ValueError("copy_segments: contiguous device tensors of equal byte size")
+        n = len(part)
+        src = (C.c_void_p * n)(*[s.data_ptr() for _, s in part])
+        dst = (C.c_void_p * n)(*[d.data_ptr() for d, _ in part])
+        nb = (C.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in part])
+        _lib.check(lib.anr_copy_segments(src, dst, nb, n, _stream(part[0][0])), "anr_copy_segments")
+
+
 DRAW_STATE_WORDS = 35                                         # include/animnerf_hip.h: ANR_DRAW_STATE_WORDS
 
 
@@ -1080,7 +1159,10 @@ def to_root_frame_from_chain(A, verts, joints, T):
     return g_inv, g_root, v2, j2, T2
 
 
-def compact_ordered_riders(pts: torch.Tensor, fg: Optional[torch.Tensor] = None, bg: Optional[torch.Tensor] = None):
+_COMPACT_STATE = {}             # (device, stream) -> the zeroed look-back state of anr_compact_ordered_single (it leaves it zero)
+
+
+def compact_ordered_riders(pts: torch.Tensor, fg: Optional[torch.Tensor] = None, bg: Optional[torch.Tensor] = None, single: bool = False):
     """`compact_ordered` with the prior points fg[rows,n_fg,3] / bg[rows,n_bg,3] appended as valid samples n .. n + n_r - 1, per
     frame its foreground then its background points (index / pos: n + n_r entries)."""
     lib = _lib.load()
@@ -1097,6 +1179,19 @@ def compact_ordered_riders(pts: torch.Tensor, fg: Optional[torch.Tensor] = None,
     pos = torch.empty(tot, dtype=torch.int32, device=pts.device)
     pts_c = torch.empty(-(-tot // 64) * 64, 4, dtype=torch.float32, device=pts.device)
     count = torch.empty(2, dtype=torch.int32, device=pts.device)
+    if single:
+        # one launch (chained scan); the look-back state lives per (device, stream): calls on one stream follow each other
+        key = (pts.device.index, torch.cuda.current_stream(pts.device).cuda_stream)
+        words = int(lib.anr_compact_state_words(tot))
+        state = _COMPACT_STATE.get(key)
+        if state is None or state.numel() < words:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("compact_ordered_riders(single=True): the look-back state must exist before a capture (run one eager step)")
+            state = _COMPACT_STATE[key] = torch.zeros(max(words, 1024), dtype=torch.int64, device=pts.device)
+        with _timed("compact_ordered", tot, tot * 24):
+            _lib.check(lib.anr_compact_ordered_single(_ptr(pts), n, _ptr(fg), n_fg, _ptr(bg), n_bg, rows, _ptr(index), _ptr(pos), _ptr(pts_c),
+                                                      _ptr(count), _ptr(state), _stream(pts)), "anr_compact_ordered_single")
+        return index, pos, pts_c, count
     ws = torch.empty(lib.anr_compact_ws_ints(tot), dtype=torch.int32, device=pts.device)
     with _timed("compact_ordered", tot, tot * 24):
         _lib.check(lib.anr_compact_ordered_riders(_ptr(pts), n, _ptr(fg), n_fg, _ptr(bg), n_bg, rows, _ptr(index), _ptr(pos), _ptr(pts_c),
@@ -1127,10 +1222,23 @@ def sample_coarse_backward_acc(d_rays_acc, steps, t_rand, g_a, g_b=None, g_c=Non
                                                   R, K, _ptr(d_rays_acc), _stream(d_rays_acc)), "anr_sample_coarse_backward_acc")
 
 
-def warp_backward_acc(d_pts, rays, z, o2c, nbr_idx, nbr_w, d_o2c_acc, d_rays_acc) -> torch.Tensor:
+def warp_backward_acc(d_pts, rays, z, o2c, nbr_idx, nbr_w, d_o2c_acc, d_rays_acc, pos=None) -> torch.Tensor:
     """`warp_backward` adding into caller-owned accumulators d_o2c_acc[bs,V,4,4] / d_rays_acc[bs,R,8] (zeroed once per step:
-    the coarse and the fine pass both add there); -> d_z[bs,R,K]."""
+    the coarse and the fine pass both add there); -> d_z[bs,R,K].
+    pos: d_pts holds the rows of the compacted list of valid samples, pos[bs*R*K] maps a sample to its row or -1."""
     lib = _lib.load()
+    if pos is not None:
+        d_pts, rays, z, o2c = _dev(d_pts, "d_pts"), _dev(rays, "rays"), _dev(z, "z"), _dev(o2c, "ober2cano")
+        nbr_idx, nbr_w, pos = _dev(nbr_idx, "nbr_idx", torch.int32), _dev(nbr_w, "nbr_w"), _dev(pos, "pos", torch.int32)
+        d_o2c_acc, d_rays_acc = _dev(d_o2c_acc, "d_o2c_acc"), _dev(d_rays_acc, "d_rays_acc")
+        bs, R, K = z.shape
+        assert pos.numel() >= bs * R * K
+        d_z = torch.empty_like(z)
+        with _timed("warp_backward", bs * R * K):
+            _lib.check(lib.anr_warp_backward_compact(_ptr(d_pts), _ptr(pos), _ptr(rays), rays.shape[-1], _ptr(z), K, _ptr(o2c), _ptr(nbr_idx),
+                                                     _ptr(nbr_w), bs, o2c.shape[1], R * K, _ptr(d_o2c_acc), _ptr(d_rays_acc), _ptr(d_z),
+                                                     _stream(z)), "anr_warp_backward_compact")
+        return d_z
     d_pts, rays, z, o2c = _dev(d_pts, "d_pts"), _dev(rays, "rays"), _dev(z, "z"), _dev(o2c, "ober2cano")
     nbr_idx, nbr_w = _dev(nbr_idx, "nbr_idx", torch.int32), _dev(nbr_w, "nbr_w")
     d_o2c_acc, d_rays_acc = _dev(d_o2c_acc, "d_o2c_acc"), _dev(d_rays_acc, "d_rays_acc")

@@ -51,9 +51,12 @@ def system_forward(volume_renderer, anim_nerf, rays, body_model_params, body_mod
     """AnimNeRFSystem.forward (train.py:189-215): rays[bs,h,w,8] -> dict of [bs,h,w,C]."""
     bs, h, w = rays.shape[:3]
     flat = rays.view(bs, h * w, -1)
-    anim_nerf.set_body_model(body_model_params, body_model_params_template)
-    flat = anim_nerf.convert_to_body_model_space(flat)
-    anim_nerf.clac_ober2cano_transform()
+    if hasattr(anim_nerf, "frame_setup"):                      # (the three calls below as two launches on the GPU)
+        flat = anim_nerf.frame_setup(body_model_params, body_model_params_template, flat)
+    else:
+        anim_nerf.set_body_model(body_model_params, body_model_params_template)
+        flat = anim_nerf.convert_to_body_model_space(flat)
+        anim_nerf.clac_ober2cano_transform()
     if latent_code is not None:
         anim_nerf.set_latent_code(latent_code)
     out = render_prepared(volume_renderer, anim_nerf, flat, chunk=chunk, perturb=perturb)

@@ -17,6 +17,7 @@ the normalisation and the MSE.
 from __future__ import annotations
 
 import contextlib
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -301,6 +302,23 @@ class GradientReducer:
             flat.div_(self.world)
         return sum(f.numel() for f in self.flat)
 
+    def reduce_flat_async(self, bi):
+        """Issue the all-reduce of bucket `bi` now, asynchronously (the backend orders it behind what the current stream has
+        issued); -> [(handle, flat, needs_division)].  RCCL averages in the collective itself (ReduceOp.AVG); gloo sums."""
+        self._probe()
+        if not self.active:
+            return []
+        flat = self.flat[bi]
+        avg = self.dist.get_backend() == "nccl" and self._world_arg is None
+        h = self.dist.all_reduce(flat, op=self.dist.ReduceOp.AVG if avg else self.dist.ReduceOp.SUM, async_op=True)
+        return [(h, flat, not avg)]
+
+    def finish_async(self, pending):
+        for h, flat, divide in pending:
+            h.wait()                                          # (the current stream waits for the collective)
+            if divide:
+                flat.div_(self.world)
+
     def _issue_ready(self, force=False):
         if self.deferred:
             return
@@ -446,7 +464,7 @@ class Trainer:
     """optimizer + schedule + step; `step(batch)` mirrors AnimNeRFSystem.training_step (train.py:324-348)."""
 
     def __init__(self, anim_nerf, volume_renderer, hp: TrainHParams, body_model_params: Optional[BodyModelParams] = None,
-                 graph: bool = False, explicit_step: bool = True):
+                 graph: bool = False, explicit_step: bool = True, static_inputs: bool = False):
         """graph=True: `step_graphed` may capture the whole step (forward, losses, backward, Adam) into ONE HIP graph and
         replay it — every launch of the step leaves the host as one (the step holds no device -> host read: row counts stay
         on the device; FlatAdam keeps its step counter there too).  Opt-in.  `with trainer.loop():` runs the loop on the
@@ -456,7 +474,12 @@ class Trainer:
         explicit_step=True (default): a step of the shipped configuration runs as one explicit sequence of library launches
         (fused_step.ExplicitTrainStep: forward, losses, backward, every gradient accumulated in place — no autograd graph, no
         framework kernel between the first launch and the last); any other configuration, or a caller that patches torch's
-        random functions to inject draws, goes through the autograd Functions (autograd.py).  False: always autograd."""
+        random functions to inject draws, goes through the autograd Functions (autograd.py).  False: always autograd.
+        static_inputs=True (opt-in): a replayed step does not copy a batch tensor that is the very object, at the very version
+        counter, it copied last time — for a loader that REUSES its batch buffers and writes them through torch (a writer
+        that does not bump the version counter — `x.data.copy_()`, DLPack views, raw-pointer kernels — would train on a stale
+        batch).  Default: every batch tensor is copied every step, all of them in one launch (anr_copy_segments)."""
+        self.static_inputs = bool(static_inputs)
         self.model, self.renderer, self.hp = anim_nerf, volume_renderer, hp
         self.body_model_params = body_model_params
         self.graph_enabled = bool(graph)
@@ -464,6 +487,7 @@ class Trainer:
         self._leaf_seen = []
         self._graph_warm = 0
         self._graph_split = False                             # the graph ends with backward (more than one rank)
+        self._graph_second = None                             # ... and is cut in two at the fine network's completed bucket
         for name, p in anim_nerf.named_parameters():          # SMPL member params are unused by the forward
             if name.startswith("body_model."):
                 p.requires_grad_(False)
@@ -585,7 +609,9 @@ class Trainer:
 
     def _step_graphed(self, args, leaves, perturb, eager):
         dist = torch.distributed
-        split = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # (ANR_GRAPH_FORCE_SPLIT=1: the more-than-one-rank structure — backward cut in two graphs, Adam behind them — on one rank,
+        # to time what the cut costs: tools/time_train_cfg4.py)
+        split = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) or bool(os.environ.get("ANR_GRAPH_FORCE_SPLIT"))
         shapes = (float(perturb), bool(split), tuple((n, tuple(t.shape), t.dtype) for n, t in leaves))
         # host values a capture freezes (none when the optimiser step stays outside the graph)
         baked = () if split else tuple(float(g["lr"]) for g in self.optimizer.param_groups)
@@ -610,24 +636,43 @@ class Trainer:
         if eager:
             return self.step(args["rays"], args["rgbs"], args["alphas"], args["bmp"], args["templ"], args["fg"], args["bg"],
                              perturb=perturb, frame_idx=args["frame_idx"])
-        # inputs -> the graph's own buffers; a tensor that is the very object (and version) copied last time is not copied again
-        # (the template pose of a run, a data loader that reuses its batch buffers)
-        templ_changed = False
+        # inputs -> the graph's own buffers, all in one launch.  The batch is copied every step unless static_inputs=True (then a
+        # tensor that is the very object, at the very version, copied last time is skipped); the TEMPLATE pose — one dict for a
+        # whole run in the reference's loader (datasets/anim_nerf_dataset.py:278), ten scalars' worth of tensors — is always
+        # compared by object + version: when it is new its body state, which lives OUTSIDE the graph (computed once per run,
+        # models/anim_nerf.py:108-126), is recomputed by a few eager launches INTO the tensors the graph reads — no re-capture,
+        # whatever the loader does (it used to re-capture, with a device synchronise, on every fresh template object).
+        from . import ops
+        templ_changed, todo = False, []
         for i, ((name, src), dst) in enumerate(zip(leaves, self._graph[2])):
             seen = self._leaf_seen[i]
-            if dst.data_ptr() == src.data_ptr() or (seen is not None and seen[0] is src and seen[1] == src._version):
+            is_templ = name.startswith("templ")
+            if dst.data_ptr() == src.data_ptr():
                 continue
-            dst.copy_(src, non_blocking=True)
+            if (is_templ or self.static_inputs) and seen is not None and seen[0] is src and seen[1] == src._version:
+                continue
+            if src.is_contiguous() and src.dtype == dst.dtype and src.device == dst.device:
+                todo.append((dst, src))
+            else:
+                dst.copy_(src, non_blocking=True)
             self._leaf_seen[i] = (src, src._version)
-            templ_changed |= name.startswith("templ")
+            templ_changed |= is_templ
+        if todo:
+            ops.copy_segments(todo)
         if templ_changed:
-            # the template pose's body state is computed OUTSIDE the graph (once per run, models/anim_nerf.py:108-126): new
-            # template values mean a new state, and the graph holds the old one's addresses
-            self._capture(sig, args, leaves, perturb)
-        _, graph, static_leaves, outs, _pins = self._graph
+            self._refresh_template_state()
+        _, graph, static_leaves, outs, _pins, _st = self._graph
         graph.replay()
         if self._graph_split:                                  # more than one rank: the graph ends with backward
-            self.reducer.reduce_flat()
+            if self._graph_second is not None:
+                # the fine network's bucket is complete: its all-reduce (the backend's own stream, behind what this stream has
+                # issued so far) runs while the second graph replays
+                pending = self.reducer.reduce_flat_async(0)
+                self._graph_second.replay()
+                pending += self.reducer.reduce_flat_async(1)
+                self.reducer.finish_async(pending)
+            else:
+                self.reducer.reduce_flat()
             self.optimizer.step()
         from .autograd import bump_generation
         bump_generation(self.params)                          # the packs cached under the old generation belong to the graph
@@ -665,24 +710,86 @@ class Trainer:
         split = sig[0][1]
         graph = torch.cuda.CUDAGraph()
         self.reducer.deferred = split
+        # More than one rank and two gradient buckets (the networks train): the step is captured as TWO graphs, cut where the
+        # fine network's flat gradient is complete (ExplicitTrainStep.run's `at_split`): a replayed step issues the all-reduce
+        # of that bucket while the second graph — the coarse pass's backward, the pose chain — replays, instead of both
+        # collectives behind the whole backward pass.  The second capture shares the first one's memory pool (the step's
+        # tensors live across the cut) and the two are always replayed in this order.
+        two = (split and self.explicit is not None and len(self.reducer.flat) == 2 and not os.environ.get("ANR_GRAPH_NO_SPLIT")
+               and self.explicit.supported(st["rays"], st["bmp"], st["frame_idx"], st["fg"], st["bg"]) and not self.explicit.frozen_networks())
+        second = torch.cuda.CUDAGraph() if two else None
+        cut = {"done": False}
+
+        def at_split():
+            graph.capture_end()
+            second.capture_begin(pool=graph.pool())
+            cut["done"] = True
         try:
-            with torch.cuda.graph(graph, stream=self._stream):
-                loss, details = self._step_body(st["rays"], st["rgbs"], st["alphas"], st["bmp"], st["templ"], st["fg"], st["bg"],
-                                                perturb, st["frame_idx"], apply=not split)
+            if two:
+                import gc
+                torch.cuda.synchronize()
+                gc.collect()
+                torch.cuda.empty_cache()
+                with torch.cuda.stream(self._stream):
+                    graph.capture_begin()
+                    try:
+                        loss, details = self._step_body(st["rays"], st["rgbs"], st["alphas"], st["bmp"], st["templ"], st["fg"], st["bg"],
+                                                        perturb, st["frame_idx"], apply=False, at_split=at_split)
+                    finally:
+                        (second if cut["done"] else graph).capture_end()
+                if not cut["done"]:
+                    second = None
+            else:
+                with torch.cuda.graph(graph, stream=self._stream):
+                    loss, details = self._step_body(st["rays"], st["rgbs"], st["alphas"], st["bmp"], st["templ"], st["fg"], st["bg"],
+                                                    perturb, st["frame_idx"], apply=not split)
         finally:
             self.reducer.deferred = False
         self._graph_split = split
+        self._graph_second = second
         # Every address the capture baked in that is NOT in the graph's private pool must outlive the graph: module-level
         # scratch that is REPLACED when a later eager call needs more (ops._WGRAD_WS, ops._LOSS_WS) and FlatAdam's chunk table
         # (rebuilt when a .grad pointer moves).  The graph pins what it saw; a replacement allocates next to it.
-        from . import ops
-        pins = [list(ops._WGRAD_WS.values()), list(ops._LOSS_WS.values()), getattr(self.optimizer, "_table", None),
+        from . import autograd, ops
+        pins = [list(ops._WGRAD_WS.values()), list(ops._LOSS_WS.values()), list(ops._COMPACT_STATE.values()), getattr(self.optimizer, "_table", None),
+                # weight packs the capture found in the cache instead of making them (frozen networks: made once per run)
+                [hit[1] for hit in autograd._PACKS.values()],
                 [p.grad for p in self.params],
                 # the template pose's body state, computed outside the graph (an eager call with another template replaces
                 # the model's attributes, not these tensors)
-                [getattr(self.model, n, None) for n in ("verts_template", "joints_template", "verts_transform_template",
-                                                        "joints_transform_template", "shape_offsets_template", "pose_offsets_template")]]
-        self._graph = (sig, graph, static_leaves, (loss, details), pins)
+                [getattr(self.model, n, None) for n in self._TEMPLATE_STATE]]
+        self._graph = (sig, graph, static_leaves, (loss, details), pins, st)
+
+    _TEMPLATE_STATE = ("verts_template", "joints_template", "verts_transform_template", "joints_transform_template",
+                       "shape_offsets_template", "pose_offsets_template")
+
+    def _refresh_template_state(self):
+        """New template values in the graph's static template leaves: recompute the template pose's body state eagerly and
+        write it INTO the tensors the captured step reads (the graph pins them), instead of capturing again."""
+        st, m = self._graph[5], self.model
+        old = [getattr(m, n) for n in self._TEMPLATE_STATE]
+        with torch.no_grad():
+            m._set_template(st["templ"])
+            for n, o in zip(self._TEMPLATE_STATE, old):
+                o.copy_(getattr(m, n))
+                setattr(m, n, o)
+            m._same_template(st["templ"])                       # (the cache now describes the static leaves at their new version)
+
+    def state_dict(self):
+        """Everything a resumed run needs besides the model's own state_dict: the optimiser (FlatAdam keeps torch.optim.Adam's
+        layout), the schedule, and the explicit step's random stream (seed + step counter on the device: without it a resumed
+        run would replay the jitter / noise / normals draws of steps 0..k)."""
+        out = {"optimizer": self.optimizer.state_dict(), "scheduler": self.scheduler.state_dict()}
+        if self.explicit is not None:
+            out["draw_state"] = self.explicit.draw_state.detach().cpu().clone()
+        return out
+
+    def load_state_dict(self, sd):
+        self.optimizer.load_state_dict(sd["optimizer"])
+        self.scheduler.load_state_dict(sd["scheduler"])
+        if self.explicit is not None and sd.get("draw_state") is not None:
+            # in place: a captured step holds this tensor's address
+            self.explicit.draw_state.copy_(sd["draw_state"].to(self.explicit.draw_state.device))
 
     def step(self, rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points=None, bg_points=None,
              perturb=1.0, frame_idx=None):
@@ -698,12 +805,12 @@ class Trainer:
         return loss, details
 
     def _step_body(self, rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points, bg_points, perturb,
-                   frame_idx, apply=True):
+                   frame_idx, apply=True, at_split=None):
         if self.explicit is not None and self.explicit.supported(rays, body_model_params, frame_idx, fg_points, bg_points):
             # forward, losses and backward as a fixed sequence of the library's launches (fused_step.py): no autograd graph,
             # no framework kernel between the first and the last launch of the step
             loss, details = self.explicit.run(rays, rgbs, alphas, body_model_params, body_model_params_template, fg_points,
-                                              bg_points, perturb, frame_idx)
+                                              bg_points, perturb, frame_idx, at_split=at_split)
             if apply:
                 self._apply_gradients()
             return loss, details
@@ -717,7 +824,9 @@ class Trainer:
         loss.backward()                                       # full buckets are all-reduced while this is still running
         with torch.no_grad():
             key = "rgbs_fine" if "rgbs_fine" in results else "rgbs"
-            details["psnr"] = -10.0 * torch.log10(F.mse_loss(results[key], rgbs))
+            # train.py:339-344 calls torchmetrics' peak_signal_noise_ratio WITHOUT data_range: the range is the targets' own
+            data_range = rgbs.max() - rgbs.min()
+            details["psnr"] = 10.0 * torch.log10(data_range ** 2 / F.mse_loss(results[key], rgbs))
         if apply:
             self._apply_gradients()
         return loss.detach(), details

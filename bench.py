@@ -53,6 +53,8 @@ def parse():
                          "cfg4: weak = frames-per-gpu frames on every rank; strong = ONE batch of 16 frames split over the ranks "
                          "(the reference's DataParallel partitioning)")
     ap.add_argument("--frames-per-gpu", type=int, default=16, help="cfg4: frames (of 1024 rays) per step per GPU")
+    ap.add_argument("--refine", action="store_true",
+                    help="cfg4: the `_refine` stage of the shipped configs — networks frozen, only the poses train (train.py:433-437)")
     ap.add_argument("--mode", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--hw", type=int, default=1024)
     ap.add_argument("--n-coarse", type=int, default=64)
@@ -64,6 +66,8 @@ def parse():
                     help="scale the sigma heads about their median (0 = literal random init, which renders a blank image)")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no modes / workloads objects)")
+    ap.add_argument("--extras-only", action="store_true",
+                    help="(internal) the child job of an N > 1 run: the modes / workloads objects without the headline")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="N > 1 plumbing check without a GPU (tests/test_distributed_cpu.py): launch, rendezvous, verified "
                          "all-reduce, barrier-bracketed timing of a sleep, one JSON line")
@@ -295,9 +299,12 @@ def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling=
         "frac": moved / other_s / (PEAK_HBM_GBS * 1e9) if other_s > 0 else None,
         "bytes_per_ray_by_design": moved / max(n_rays * steps, 1),
         "survey_compulsory_bytes_per_ray": 52 + 36 * evals,
-        "frac_on_survey_compulsory_bytes": comp_bytes / other_s / (PEAK_HBM_GBS * 1e9) if other_s > 0 else None,
         "ms_per_step": other_s / steps * 1e3,
     }
+    # (SURVEY 8(d)'s figure prices bytes some of which no kernel of this design moves — the no-warp path never materialises a
+    # 16-B canonical point: where it exceeds what the launches move it is not a fraction of anything, and is left out)
+    if other_s > 0 and comp_bytes <= moved:
+        result["roofline_hbm_kernels"]["frac_on_survey_compulsory_bytes"] = comp_bytes / other_s / (PEAK_HBM_GBS * 1e9)
     if not use_warp and H == 1024 and args.n_coarse == 64 and args.n_fine == 64:
         # the same kernels by the memory-side counters (FETCH_SIZE x 2 + WRITE_SIZE of the round's PMC passes, per frame):
         # what the launches really moved, rays and partial sectors included, over this run's HIP-event time
@@ -311,6 +318,7 @@ def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling=
                 per_frame = sum(v["read_GB_per_frame"] + v["write_GB_per_frame"] for v in grp.values()) * 1e9
                 result["roofline_hbm_kernels"].update({
                     "traffic": per_frame, "traffic_unit": f"HBM bytes per frame by PMC counters ({os.path.relpath(files[-1], ROOT)}, commit {t.get('commit')})",
+                    "traffic_stale": traffic_is_stale(t),
                     "frac_by_counters": per_frame * (n_rays / n_frame) * steps / other_s / (PEAK_HBM_GBS * 1e9)})
     if checks and rank == 0 and world == 1:
         if not args.no_psnr and check_rays is None:
@@ -452,7 +460,7 @@ def grid_bench(args, ctx, mode, steps, warmup, dense=False):
     }
 
 
-def train_bench(args, ctx, mode, steps, warmup, dense=False, scaling="weak", frames=None):
+def train_bench(args, ctx, mode, steps, warmup, dense=False, scaling="weak", frames=None, refine=False):
     """BASELINE configs[3] shape: one optimisation step = `frames_per_gpu` frames x 32x32 rays, 64 coarse + 32 fine,
     perturb = 1, rgb/alpha/foreground/background/normals losses, backward, gradient all-reduce (RCCL), Adam.
     scaling="strong": the reference's own partitioning (train.py:81-86,451-458, config.py:77 `strategy='dp'`,
@@ -467,6 +475,12 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False, scaling="weak", fra
     model = ana.AnimNeRF(body_model_table=tbl, freqs_dir=0, use_view=False, use_unpose=True, use_knn=True,
                          use_fine=True, mlp_mode=mode).to(dev)
     model.skip_invalid_samples = not dense
+    refine = refine or getattr(args, "refine", False)
+    if refine:
+        # configs/people_snapshot/male-3-casual_refine.yaml:52-53 + train.py:433-437: the trained networks are loaded and
+        # FROZEN (pretrained_model_requires_grad: False); optim_body_params stays on — only the pose rows train
+        for p in model.parameters():
+            p.requires_grad_(False)
     hp = ana.TrainHParams(n_samples=64, n_importance=32, chunk=2048)
     GLOBAL = 16                                                # batch_size of the shipped config
     strong = scaling == "strong"
@@ -507,6 +521,8 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False, scaling="weak", fra
         last["loss"], _ = trainer.step(rays, rgbs, alphas, None, templ, fg, bg, perturb=1.0, frame_idx=frame_idx)
         return last["loss"]
 
+    if dev.type == "cuda":
+        torch.cuda.reset_peak_memory_stats(dev)
     with trainer.loop():                # (the Trainer's own stream for the whole loop: no stream fences per step)
         if graphed:
             # untimed set-up, like a compilation: GRAPH_WARM_STEPS eager steps, then the capture (which executes nothing)
@@ -531,15 +547,20 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False, scaling="weak", fra
         "metric": "rays/sec, training step (64+32 samples, 256-wide MLP x2, fwd+bwd+Adam)",
         "value": n_rays * steps * world / elapsed, "unit": "rays/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "scaling": scaling, "dtype": mode,
+        # (activation buffers are sized for "every sample valid": the row counts stay on the device — INTEGRATION.md)
+        "peak_alloc_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2) if dev.type == "cuda" else None,
         "config": {"global_batch_frames": F * world, "frames_per_gpu": F,
                    "partitioning": ("ONE batch of 16 frames split over the ranks (the reference's DP scatter on dim 0), gradients = mean "
                                     "over ranks of per-rank means" if strong else "frames_per_gpu frames on every rank: the global batch grows with N"),
                    "workload": "BASELINE configs[3] shape: train step, %d frames x 32x32 rays per GPU, 64 coarse + 32 fine, "
                                "perturb=1, rgb + alpha + fg/bg + normals losses (reference defaults), pose refinement on (optim_body_params), "
                                "%s + Adam" % (F, "gradient all-reduce (2 x 2.4 MB flat buffers, after the replayed backward)" if graphed
-                                              else "bucketed gradient all-reduce (2 x 2.4 MB, overlapped with backward)"),
+                                              else "bucketed gradient all-reduce (2 x 2.4 MB, overlapped with backward)")
+                               + ("; the `_refine` stage: both networks FROZEN (pretrained_model_requires_grad False), only the pose "
+                                  "rows train — no weight-gradient launch, sign bits instead of saved activations" if refine else ""),
+                   "networks_frozen": bool(refine),
                    "mlp_on_valid_samples_only": bool(model.evaluate_valid_only),
-                   "mlp_rows_per_step": per_kernel.get("mlp_forward_save", {"units": 0})["units"] // max(eager_steps, 1),
+                   "mlp_rows_per_step": per_kernel.get("mlp_forward_bits" if refine else "mlp_forward_save", {"units": 0})["units"] // max(eager_steps, 1),
                    "rays_per_step_per_gpu": n_rays, "grad_floats": sum(p.numel() for p in trainer.params),
                    "kernel_launches_timed_per_step": sum(v["launches"] for v in per_kernel.values()) // max(eager_steps, 1),
                    "step_launch": (("one HIP graph replay per step" if world == 1 else "forward + backward as one HIP graph replay per step")
@@ -547,14 +568,14 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False, scaling="weak", fra
                                    "%d eager single-stream steps after the timed region, %.2f ms per step there"
                                    % (trainer.GRAPH_WARM_STEPS, eager_steps, eager_elapsed / eager_steps * 1e3)) if graphed
                    else "eager: one launch per kernel"},
-        "roofline": mlp_roofline(per_kernel, "mlp_forward_save", mode, MLP_FLOP_PER_POINT,
-                                 f"mlp_kernel<{mode}, save> (training forward)"),
+        "roofline": mlp_roofline(per_kernel, "mlp_forward_bits" if refine else "mlp_forward_save", mode, MLP_FLOP_PER_POINT,
+                                 f"mlp_kernel<{mode}, {'sign bits only' if refine else 'save'}> (training forward)"),
         "kernel_time_share": {k: round(v["s"] / eager_steps / (elapsed / steps), 4) for k, v in per_kernel.items()},
         "final_loss": float(loss),
     }
 
 
-def train_bench_child(args, ctx, mode, steps, warmup, frames=None):
+def train_bench_child(args, ctx, mode, steps, warmup, frames=None, refine=False):
     """cfg4 as an extra of the default run: the graphed training step in a CHILD process (`bench.py --workload cfg4
     --no-extras`), its line merged into this one.  A HIP-graph replay that goes wrong takes its process down with a GPU memory
     fault (tools/soak_train.py found one such sequence: > 50 replays, then a device synchronisation followed by scalar reads,
@@ -562,9 +583,9 @@ def train_bench_child(args, ctx, mode, steps, warmup, frames=None):
     not deliver, the step is measured eagerly in this process and the entry says so."""
     import subprocess
     if ctx.world != 1 or ctx.dev.type != "cuda" or os.environ.get("ANR_BENCH_NO_GRAPH"):
-        return train_bench(args, ctx, mode, steps, warmup, frames=frames)
+        return train_bench(args, ctx, mode, steps, warmup, frames=frames, refine=refine)
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "cfg4", "--no-extras", "--steps", str(steps), "--warmup", str(warmup),
-           "--mode", mode, "--frames-per-gpu", str(frames or args.frames_per_gpu)]
+           "--mode", mode, "--frames-per-gpu", str(frames or args.frames_per_gpu)] + (["--refine"] if refine else [])
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     note = None
     try:
@@ -579,11 +600,30 @@ def train_bench_child(args, ctx, mode, steps, warmup, frames=None):
         note = f"graphed child failed: {type(exc).__name__}: {exc}"[:300]
     os.environ["ANR_BENCH_NO_GRAPH"] = "1"
     try:
-        got = train_bench(args, ctx, mode, steps, warmup, frames=frames)
+        got = train_bench(args, ctx, mode, steps, warmup, frames=frames, refine=refine)
     finally:
         os.environ.pop("ANR_BENCH_NO_GRAPH", None)
     got["config"]["process"] = "eager step in the parent: " + note
     return got
+
+
+TRAFFIC_SOURCES = ("anim-nerf_amd/csrc/mlp_core.h", "anim-nerf_amd/csrc/mlp.hip", "anim-nerf_amd/csrc/mlp_inst_bf16.hip",
+                   "anim-nerf_amd/csrc/composite.hip")
+
+
+def kernel_sources_sha():
+    """sha256 over the sources of the kernels whose PMC traffic profiles/rNN/mlp_hbm_traffic.json records (tools/traffic_json.py
+    stores it at collection time; there is no .git on the GPU box to ask for ancestry)"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in TRAFFIC_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def traffic_is_stale(t):
+    return t.get("kernel_sources_sha") != kernel_sources_sha()
 
 
 def measured_traffic(mode, variant, points_per_launch):
@@ -601,7 +641,9 @@ def measured_traffic(mode, variant, points_per_launch):
         return None, None
     return t[key] * points_per_launch, (f"HBM bytes per launch = {t[key]:.1f} B per point (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                         f"separate passes; {os.path.relpath(files[-1], ROOT)}, measured at commit "
-                                        f"{t.get('commit', 'of round 1')}) x points per launch")
+                                        f"{t.get('commit', 'of round 1')}) x points per launch"
+                                        + ("; STALE: the kernel sources have changed since" if traffic_is_stale(t) else
+                                           "; the kernel sources are the ones it was measured on"))
 
 
 def collective_fields(ctx):
@@ -635,6 +677,8 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)                             # never returns
+    if args.extras_only:
+        return extras_only(args)                      # never returns
     ctx = Ctx(args)
     if args.plumbing_only:
         return plumbing_only(args, ctx)
@@ -653,49 +697,68 @@ def main():
         r = result["roofline"]
         variant = "rays" if not use_warp else ("indexed" if result["config"]["mlp_on_valid_samples_only"] else "explicit")
         r["traffic"], r["traffic_unit"] = measured_traffic(args.mode, variant, r["points"] / r["launches"] if r["launches"] else 0)
+        r["traffic_stale"] = None if r["traffic"] is None else ("STALE" in r["traffic_unit"])
     result.update({"higher_is_better": True, "vs_baseline": None, "data": "synthetic", **collective_fields(ctx)})
 
-    if not args.no_extras and args.workload == "cfg2" and args.scaling == "weak":
-        # every other line this repository quotes, measured in the same process (own warm-up + timed region each)
-        def brief(r, *keep):
-            keys = ("value", "unit", "ms_per_step", "steps", "warmup", "n_gpus", "scaling", "dtype", "roofline") + keep
-            return {**{k: r[k] for k in keys if k in r}, "config": r["config"]}
-        def extra(fn, *a, keep=(), **kw):
-            # a failing extra must not take the headline line with it.  At N > 1 a failure need not be symmetric (OOM or
-            # a HIP error on ONE GPU): the ranks agree on the outcome after each extra, and if any of them failed the job
-            # stops there with the headline printed — the others would otherwise wait in the next barrier (which, like
-            # every collective here, also carries a timeout)
-            try:
-                # every workload starts with an empty allocator cache: the previous one's blocks (a training graph's private
-                # pool, 2-GB grid chunks) otherwise decide whether this one's first allocations are cache hits or hipMallocs
-                import gc
-                gc.collect()
-                if ctx.dev.type == "cuda":
-                    torch.cuda.empty_cache()
-                got, err = brief(fn(*a, **kw), *keep), None
-            except Exception as exc:                        # noqa: BLE001
-                got, err = None, f"{type(exc).__name__}: {exc}"[:300]
-            if world > 1 and not ctx.all_ok(err is None):
-                # every rank knows: the headline (measured, valid) is printed with the failure recorded, and the job ends
-                # HERE with exit code 0 on all ranks — the scaling measurement reads the line, not the extras
-                if rank == 0:
-                    result["workloads"] = {**w, fn.__name__: {"error": err or "failed on another rank"}}
-                    result["extras_failed"] = True          # top level: a reader of the line need not walk the workloads
-                    print(json.dumps(result), flush=True)
-                sys.stdout.flush()
-                # best-effort teardown (a failed rank may never answer: bounded), then leave.  Exit code 0 by default — the
-                # headline on the line is measured and valid, and the scaling harness reads the line; ANR_BENCH_STRICT=1
-                # (CI) turns a failed extra into exit code 3.
-                import threading
-                import torch.distributed as dist
-                t = threading.Thread(target=lambda: dist.destroy_process_group(), daemon=True)
-                t.start()
-                t.join(10.0)
-                os._exit(3 if os.environ.get("ANR_BENCH_STRICT") else 0)
-            return got if err is None else {"error": err}
-        w = {}
+    extras = not args.no_extras and args.workload == "cfg2" and args.scaling == "weak"
+    if extras and world == 1:
+        result.update(collect_extras(args, ctx))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    if extras and world > 1:
+        # N > 1: every other line this repository quotes is measured by a JOB OF ITS OWN — a fresh `torch.distributed.run` child
+        # with the same rank count, started by rank 0 once the headline's process group is gone (a child process, never an exec
+        # of this one).  Whatever happens in there — a GPU fault in a replayed training graph, a hang in a collective, an OOM on
+        # one GPU — the headline above is already measured and is printed below, once, with the child's outcome beside it.
+        if rank != 0:
+            return
+        del ctx
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        result.update(extras_child_job(args, world))
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if result.get("extras_failed") and (os.environ.get("ANR_BENCH_STRICT") or (world > 1 and not os.environ.get("ANR_BENCH_LENIENT"))):
+        sys.exit(3)                                    # (the line above is complete and valid; the exit code says an extra is missing)
+
+
+def collect_extras(args, ctx):
+    """Every other line this repository quotes, each with its own warm-up and timed region: {"modes", "workloads"[, "extras_failed"]}.
+    One rank: in this process (the graphed training steps in children of their own, train_bench_child).  More ranks: this IS the
+    child job (`--extras-only`, extras_child_job); after each workload the ranks agree on its outcome (one MIN all-reduce, like
+    every collective here with a timeout) and the first failure on any rank ends the job with what has been measured."""
+    rank, world = ctx.rank, ctx.world
+    out, w = {}, {}
+
+    def brief(r, *keep):
+        keys = ("value", "unit", "ms_per_step", "steps", "warmup", "n_gpus", "scaling", "dtype", "roofline", "peak_alloc_GiB") + keep
+        return {**{k: r[k] for k in keys if k in r}, "config": r["config"]}
+
+    class Stop(Exception):
+        pass
+
+    def extra(fn, *a, keep=(), **kw):
+        try:
+            # every workload starts with an empty allocator cache: the previous one's blocks (a training graph's private
+            # pool, 2-GB grid chunks) otherwise decide whether this one's first allocations are cache hits or hipMallocs
+            import gc
+            gc.collect()
+            if ctx.dev.type == "cuda":
+                torch.cuda.empty_cache()
+            got, err = brief(fn(*a, **kw), *keep), None
+        except Exception as exc:                        # noqa: BLE001
+            got, err = None, f"{type(exc).__name__}: {exc}"[:300]
+        if world > 1 and not ctx.all_ok(err is None):
+            # a failure need not be symmetric (OOM or a HIP error on ONE GPU): every rank knows now, and nobody walks into the
+            # next workload's barrier
+            raise Stop(err or "failed on another rank")
+        return got if err is None else {"error": err}
+    name = None
+    try:
         if world == 1:
-            result["modes"] = {"f32": extra(render_bench, args, ctx, False, "f32", 2, 1, keep=("roofline_hbm_kernels",))}
+            out["modes"] = {"f32": extra(render_bench, args, ctx, False, "f32", 2, 1, keep=("roofline_hbm_kernels",))}
             # (with its own oracle check: 1,024 rays through the oracle's brute-force 4-NN warp, ~25 s of host time)
             w["cfg3"] = extra(render_bench, args, ctx, True, args.mode, 3, 1, checks=True, check_rays=1024,
                               keep=("roofline_hbm_kernels", "kernel_time_share", "oracle_check", "cpu_baseline"))
@@ -703,29 +766,84 @@ def main():
             w["cfg4"] = extra(train_bench_child, args, ctx, args.mode, 8, 4, keep=("kernel_time_share", "final_loss"))
             # the per-rank step of configs[3] on 8 GPUs: 2 of the batch's 16 frames (strong scaling's unit of work, on one GPU)
             w["cfg4_f2"] = extra(train_bench_child, args, ctx, args.mode, 16, 4, frames=2, keep=("kernel_time_share", "final_loss"))
+            # the `_refine` stage of the shipped configs (networks loaded and frozen, the poses train: train.py:433-437)
+            w["cfg4_refine"] = extra(train_bench_child, args, ctx, args.mode, 8, 4, refine=True, keep=("kernel_time_share", "final_loss"))
             w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 2, keep=("oracle_check",))
         else:
             # N > 1: the strong-scaling counterpart of the headline (one frame's rays sliced over the ranks), the warp
-            # workload, and the training step with its RCCL gradient buckets
-            w["cfg2_strong"] = extra(render_bench, args, ctx, False, args.mode, 3, 1, scaling="strong")
-            w["cfg3"] = extra(render_bench, args, ctx, True, args.mode, 3, 1)
-            w["cfg3_strong"] = extra(render_bench, args, ctx, True, args.mode, 3, 1, scaling="strong")
-            w["cfg4"] = extra(train_bench, args, ctx, args.mode, 8, 4, keep=("final_loss",))
-            if 16 % world == 0:                             # configs[3] as the reference shards it: 16 frames / N per rank
-                w["cfg4_strong"] = extra(train_bench, args, ctx, args.mode, 16, 4, scaling="strong", keep=("final_loss",))
-            w["cfg5"] = extra(grid_bench, args, ctx, args.mode, 3, 2)
-        result["workloads"] = w
-        failed = [k for k, v in {**w, **result.get("modes", {})}.items() if isinstance(v, dict) and "error" in v]
-        if failed:
-            result["extras_failed"] = True
+            # workload, and the training step with its RCCL gradient all-reduce
+            for name, fn, a, kw in (
+                    ("cfg2_strong", render_bench, (False, args.mode, 3, 1), dict(scaling="strong")),
+                    ("cfg3", render_bench, (True, args.mode, 3, 1), {}),
+                    ("cfg3_strong", render_bench, (True, args.mode, 3, 1), dict(scaling="strong")),
+                    ("cfg5", grid_bench, (args.mode, 3, 2), {}),
+                    ("cfg4", train_bench, (args.mode, 8, 4), dict(keep=("final_loss",))),
+                    # configs[3] as the reference shards it: 16 frames / N per rank
+                    ("cfg4_strong", train_bench, (args.mode, 16, 4), dict(scaling="strong", keep=("final_loss",)))):
+                if name == "cfg4_strong" and 16 % world:
+                    continue
+                w[name] = extra(fn, args, ctx, *a, **kw)
+    except Stop as stop:
+        w[name or "extras"] = {"error": str(stop)}
+    out["workloads"] = w
+    failed = [k for k, v in {**w, **out.get("modes", {})}.items() if isinstance(v, dict) and "error" in v]
+    if failed:
+        out["extras_failed"] = True
+    return out
 
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    if world > 1:
+
+def extras_only(args):
+    """`--extras-only` (the child job of an N > 1 run): the process group of its own, collect_extras, rank 0 prints the object."""
+    ctx = Ctx(args)
+    import anim_nerf_amd as ana
+    ana._lib.load()
+    out = collect_extras(args, ctx)
+    if ctx.rank == 0:
+        print(json.dumps({"metric": "extras", **out}), flush=True)
+    sys.stdout.flush()
+    if ctx.world > 1:
+        # best-effort teardown (after a failure a rank may never answer: bounded), then leave
+        import threading
         import torch.distributed as dist
-        dist.destroy_process_group()
-    if result.get("extras_failed") and os.environ.get("ANR_BENCH_STRICT"):
-        sys.exit(3)
+        t = threading.Thread(target=lambda: dist.destroy_process_group(), daemon=True)
+        t.start()
+        t.join(20.0)
+    os._exit(3 if out.get("extras_failed") else 0)
+
+
+def extras_child_job(args, world):
+    """Rank 0 of an N > 1 run, after its own process group is gone: run `bench.py --gpus N --extras-only` as a child
+    `torch.distributed.run` job and hand back its object — or the reason it did not deliver."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(world), "--extras-only", "--mode", args.mode,
+           "--hw", str(args.hw), "--n-coarse", str(args.n_coarse), "--n-fine", str(args.n_fine), "--chunk", str(args.chunk),
+           "--sigma-gain", str(args.sigma_gain), "--frames-per-gpu", str(args.frames_per_gpu), "--cpu-rays", "0", "--no-psnr"]
+    scrub = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME",
+             "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE")
+    env = {k: v for k, v in os.environ.items() if k not in scrub and not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_ASYNC"))}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    limit = float(os.environ.get("ANR_BENCH_EXTRAS_TIMEOUT", "1500"))
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric": "extras"' in ln]
+        if lines:
+            got = json.loads(lines[-1])
+            got.pop("metric", None)
+            got["extras_process"] = (f"a child torch.distributed.run job of {world} ranks started after the headline's process group was "
+                                     f"destroyed: exit code {r.returncode}, {time.perf_counter() - t0:.0f} s")
+            if r.returncode != 0:
+                got["extras_failed"] = True
+            return got
+        note = f"extras job exited with {r.returncode} and no line: {r.stderr[-300:]!r}"
+    except Exception as exc:                                    # noqa: BLE001
+        note = f"extras job failed: {type(exc).__name__}: {exc}"[:400]
+    return {"workloads": {"error": note}, "extras_failed": True}
 
 
 def cpu_baseline(args, tbl, model, rays, pose_np, use_warp, max_rays=None):

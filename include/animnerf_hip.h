@@ -62,6 +62,14 @@ extern "C" {
  * split-K slices — half the workgroups and half the partial products.  A lone call is ~20 % slower that way; next to the
  * backward chain of a training step it leaves the chain's launches room to run. */
 #define ANR_MLP_FLAG_BACKGROUND 0x4000
+/* The `_refine` stage of the shipped configs (configs/people_snapshot/*_refine.yaml: pretrained_model_requires_grad False,
+ * train.py:433-437): the networks are loaded and FROZEN and only the poses train, so nothing ever reads the saved
+ * activations or most of the activation gradients (they are the weight-gradient GEMMs' operands).
+ * anr_mlp_forward_save[_indexed]: keep only the ReLU sign bits (304 B per row instead of 5.2 KB; the data area of `act` is
+ * left untouched).  anr_mlp_backward[_counted]: write only the pre-activation gradients of layers 1 and 5 (columns 0..255 and
+ * 1024..1279 of `dact`) — what anr_mlp_denc reads on the way to the sample points. */
+#define ANR_MLP_FLAG_BITS_ONLY 0x8000
+#define ANR_MLP_FLAG_ENC_ONLY  0x8000
 
 int         anr_version(void);
 const char* anr_last_error(void);
@@ -216,6 +224,13 @@ int anr_warp_backward(const float* d_pts, const float* rays, int ray_stride, con
                       const float* ober2cano, const int32_t* nbr_idx, const float* nbr_w, int bs, int V, int64_t N,
                       float* d_ober2cano, float* d_rays, float* d_z, void* stream);
 
+/* anr_warp_backward fed from the COMPACTED list of valid samples (the explicit training step): d_pts_rows[rows*4] holds the
+ * gradient of the listed samples only (anr_mlp_dpoints' output), pos[bs*N] maps a sample to its row or to -1 (the inverse
+ * map anr_compact_ordered writes); a sample without a row has no gradient.  Saves the expansion to bs*N dense rows. */
+int anr_warp_backward_compact(const float* d_pts_rows, const int32_t* pos, const float* rays, int ray_stride, const float* z,
+                              int K, const float* ober2cano, const int32_t* nbr_idx, const float* nbr_w, int bs, int V,
+                              int64_t N, float* d_ober2cano, float* d_rays, float* d_z, void* stream);
+
 /* Same output layout without the warp (use_unpose=False, models/anim_nerf.py:296-297):
  * pts_out = (x, y, z, 1). */
 int anr_points_from_rays(const float* rays, int ray_stride, const float* z, int K,
@@ -364,6 +379,16 @@ int anr_frame_backward_adjoint(const float* betas, const float* pose, const floa
                                const float* rays_world, int ray_stride, int R, const float* d_ober2cano,
                                const float* d_rays_body, float* workspace, float* grads_out, void* stream);
 
+/* ... with the VALUES of the chain handed in as the forward kernels left them — joints_transform[bs*J*16] (anr_smpl_forward's A,
+ * transl on its translation column) and g_inv[bs*16] (anr_to_root_frame's inverse root transform) — instead of being
+ * recomputed by every workgroup of the per-vertex kernel (both NULL: anr_frame_backward_adjoint). */
+int anr_frame_backward_adjoint_values(const float* betas, const float* pose, const float* transl, int bs, const float* J0,
+                                      const float* JS, const int64_t* parents, const float* lbs_weights, const float* shapedirs,
+                                      const float* posedirs, int V, const float* T_template, int template_bs,
+                                      const float* rays_world, int ray_stride, int R, const float* d_ober2cano,
+                                      const float* d_rays_body, const float* joints_transform, const float* g_inv,
+                                      float* workspace, float* grads_out, void* stream);
+
 /* ---- a16 (part): weight and bias gradients of the MLP -----------------------------------------------------------
  * What autograd computes for the 22 parameter tensors of models/nerf.py:60-127 once the activation gradients exist:
  *   dW_l = dact_l^T in_l (in_1 = enc, in_5 = [enc, h4], in_l = h_{l-1}; xyz_encoding_final, dir_encoding on h8 / the
@@ -383,6 +408,12 @@ int anr_mlp_wgrad(int mode, const void* act, const void* dact, const void* enc, 
  * d_enc_out[n*63] = dact[:, 0:256] . W1[:, 0:63] + dact[:, 1024:1280] . W5[:, 0:63]  (xyz_encoding_1 / _5 weights, fp32,
  * PyTorch [256][63] / [256][319] layouts); anr_encode_backward turns it into dL/d xyz. */
 int anr_mlp_denc(int mode, const void* dact, const float* w1, const float* w5, int64_t n, float* d_enc_out, void* stream);
+/* anr_mlp_denc + anr_encode_backward in one launch (what the explicit training step calls): d_pts_out[n*4] = (dL/d xyz, 0) of
+ * the rows of a compacted pass from their activation gradients `dact` (layers 1 and 5) and their canonical points pts[n*4];
+ * the two encoding weight panels are read, pre-packed, from the BACKWARD weight pack (anr_mlp_bwd_pack writes them behind
+ * the W^T fragments).  count (optional, device): the number of listed rows.  d_enc[n][63] never exists in memory. */
+int anr_mlp_dpoints(const void* bwd_pack, int mode, const void* dact, const float* pts, int64_t n, const int32_t* count,
+                    float* d_pts_out, void* stream);
 
 /* ---- a16: the same steps on a compacted list whose LENGTH IS KNOWN ON THE DEVICE ONLY ------------------------------------
  * The reference's masked assignment (models/anim_nerf.py:284-289) makes the number of valid samples data dependent; reading it
@@ -446,6 +477,13 @@ int anr_compact_ordered(const float* pts, int64_t n, int32_t* index_out, int32_t
 int anr_compact_ordered_riders(const float* pts, int64_t n, const float* fg, int n_fg, const float* bg, int n_bg, int rows,
                                int32_t* index_out, int32_t* pos_out, float* pts_out, int32_t* count_out, int32_t* workspace,
                                void* stream);
+/* The same list in ONE launch (a chained scan with decoupled look-back instead of count / scan / gather): what the explicit
+ * training step calls.  state[anr_compact_state_words(n + riders)] int64 must be ZERO before its first use and is left zero by
+ * every call (a call in a replayed HIP graph needs no fill in front of it); calls sharing a state buffer must not overlap. */
+int64_t anr_compact_state_words(int64_t n);
+int anr_compact_ordered_single(const float* pts, int64_t n, const float* fg, int n_fg, const float* bg, int n_bg, int rows,
+                               int32_t* index_out, int32_t* pos_out, float* pts_out, int32_t* count_out, int64_t* state,
+                               void* stream);
 int anr_expand_rows(const float* src, const int32_t* pos, int64_t n, int cols, float fill, float* out, void* stream);
 int anr_mlp_head_grad(const float* g_in, const int32_t* index, const float* out, const float* pts, int64_t rows,
                       int64_t n_pad, int sigma_only, float* g_out, void* stream);
@@ -471,7 +509,8 @@ int anr_merge_backward(const float* g_sorted, const int32_t* perm, int64_t R, in
  *     eps 1e-5, MSE between a point's and its neighbour's (train.py:288-309).
  * vals_out[12] = loss_rgb, loss_rgb_fine, loss_alphas, loss_alphas_fine, loss_foreground, loss_background,
  *   loss_foreground_fine, loss_background_fine, loss_normals, loss_normals_fine, total (weighted by the lambdas), and the
- *   batch's PSNR = -10 log10(loss_rgb_fine, or loss_rgb without a fine pass) (train.py:339-344).
+ *   batch's PSNR = 10 log10((max target_rgb - min target_rgb)^2 / loss_rgb_fine, or loss_rgb without a fine pass): what
+ *   train.py:339-344 logs as train/psnr — torchmetrics' peak_signal_noise_ratio called without data_range.
  * workspace[anr_train_loss_ws_floats()], zero before its first use (the kernel leaves it ready for the next call). */
 typedef struct {
     const float *rgb, *acc, *rgb_fine, *acc_fine, *target_rgb, *target_alpha;
@@ -631,6 +670,25 @@ int anr_sample_coarse_backward_acc(const float* g_a, const float* g_b, const flo
 int anr_to_root_frame_strided(const float* global_transform, int64_t g_stride, const float* verts, const float* joints,
                               const float* T, int bs, int V, int J, float* g_inv_out, float* g_root_out, float* verts_out,
                               float* joints_out, float* T_out, void* stream);
+/* The per-frame set-up of a batch of frames in two launches (csrc/frame_setup.hip): what AnimNeRF.set_body_model,
+ * convert_to_body_model_space and clac_ober2cano_transform compute (models/anim_nerf.py:108-151 over smplx/body_models.py:289-387
+ * and smplx/lbs.py:152-404), i.e. anr_gather_frame_params + anr_smpl_forward + anr_to_root_frame + anr_rays_to_body +
+ * anr_ober2cano with the rest joints taken as J0 + JS . betas (J0[24*3] = J_regressor v_template, JS[24*3*10] = J_regressor
+ * shapedirs).  frame_idx != NULL: betas_w / global_orient_w / body_pose_w / transl_w are the BodyModelParams tables
+ * (models/body_model_params.py) and frame b reads row frame_idx[b] (betas: row min(., betas_rows - 1)); NULL: per-frame arrays.
+ * template_*: the template pose's state, one body (template_bs = 1) or one per frame.  R = 0: no rays.
+ * Outputs: the frames' parameters betas[bs*10], pose[bs*72], transl[bs*3]; A = joints_transform[bs*24*16] (transl on the
+ * translation column); joints, verts and vertices_transform IN THE ROOT FRAME; g_inv, g_root[bs*16]; shape / pose offsets;
+ * ober2cano[bs*V*16]; rays_body[bs*R*8].  ws_feat[bs*207] fp32. */
+int anr_frame_setup(const int64_t* frame_idx, const float* betas_w, int betas_rows, const float* global_orient_w,
+                    const float* body_pose_w, const float* transl_w, int bs, const float* J0, const float* JS,
+                    const int64_t* parents, const float* v_template, const float* shapedirs, const float* posedirs,
+                    const float* lbs_weights, int V, int J, int NB, const float* T_template,
+                    const float* shape_off_template, const float* pose_off_template, int template_bs,
+                    const float* rays_world, int ray_stride, int R, float* betas_out, float* pose_out, float* transl_out,
+                    float* A_out, float* joints_root_out, float* g_inv_out, float* g_root_out, float* shape_off_out,
+                    float* pose_off_out, float* verts_root_out, float* T_root_out, float* ober2cano_out,
+                    float* rays_body_out, float* ws_feat, void* stream);
 /* zero `bytes` (a multiple of 4) at a 4-byte aligned device address: a kernel, not a memset (a memset NODE of a captured HIP
  * graph went stale on ROCm 7.2: DESIGN.md section 4.4) */
 int anr_zero_fill(void* ptr, int64_t bytes, void* stream);
@@ -638,6 +696,10 @@ int anr_zero_fill(void* ptr, int64_t bytes, void* stream);
  * on a second stream next to the render passes, joining the network's flat gradient buffer — what autograd's accumulation of
  * models/nerf.py:177-190's and the render passes' contributions into one .grad does (train.py:324-348) */
 int anr_add_inplace(float* dst, const float* src, int64_t n, void* stream);
+/* n (<= 24) device-to-device copies dst[i][0..bytes[i]) = src[i][...] in ONE launch; src / dst / bytes are HOST arrays (the table
+ * travels in the kernel arguments).  The batch of a training step (train.py:324-331: rays, rgbs, alphas, the pose rows, the
+ * prior points) moving into the fixed buffers a captured step replays from — one launch instead of one copy per tensor. */
+int anr_copy_segments(const void* const* src, void* const* dst, const int64_t* bytes, int n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -308,3 +308,67 @@ def neighbour_discontinuity(lbs_weights, dist, idx):
     w_n = lbs_weights[idx]
     conf = torch.exp(-(w_n - w_n[..., 0:1, :]).abs().sum(-1) / (2.0 * orc.WEIGHT_STD ** 2))
     return ((conf - 0.9).abs() < 2e-6).any(-1) | ((dist[..., 1:] - dist[..., :-1]).abs() <= 1e-6).any(-1)
+
+
+def point_triangle_distance(p, a, b, c):
+    """[n] distances of points p[n,3] to triangles (a, b, c)[n,3] (Ericson, Real-Time Collision Detection 5.1.5: the closest
+    point by Voronoi region of the triangle), branch-free over tensors."""
+    ab, ac, ap = b - a, c - a, p - a
+    d1, d2 = (ab * ap).sum(-1), (ac * ap).sum(-1)
+    bp = p - b
+    d3, d4 = (ab * bp).sum(-1), (ac * bp).sum(-1)
+    cp = p - c
+    d5, d6 = (ab * cp).sum(-1), (ac * cp).sum(-1)
+    vc, vb, va = d1 * d4 - d3 * d2, d5 * d2 - d1 * d6, d3 * d6 - d5 * d4
+    tiny = 1e-30
+    denom = (va + vb + vc).clamp_min(tiny)
+    v, w = vb / denom, vc / denom
+    q = a + ab * v[:, None] + ac * w[:, None]                                        # interior
+    t_bc = ((d4 - d3) / ((d4 - d3) + (d5 - d6)).clamp_min(tiny)).clamp(0, 1)
+    q = torch.where(((va <= 0) & (d4 - d3 >= 0) & (d5 - d6 >= 0))[:, None], b + (c - b) * t_bc[:, None], q)
+    t_ac = (d2 / (d2 - d6).clamp_min(tiny)).clamp(0, 1)
+    q = torch.where(((vb <= 0) & (d2 >= 0) & (d6 <= 0))[:, None], a + ac * t_ac[:, None], q)
+    t_ab = (d1 / (d1 - d3).clamp_min(tiny)).clamp(0, 1)
+    q = torch.where(((vc <= 0) & (d1 >= 0) & (d3 <= 0))[:, None], a + ab * t_ab[:, None], q)
+    q = torch.where(((d6 >= 0) & (d5 <= d6))[:, None], c, q)
+    q = torch.where(((d3 >= 0) & (d4 <= d3))[:, None], b, q)
+    q = torch.where(((d1 <= 0) & (d2 <= 0))[:, None], a, q)
+    return (p - q).norm(dim=-1)
+
+
+def vertex_to_surface_distance(verts, other_verts, other_tris, N, reach=1, chunk=1 << 18, cap=None):
+    """[n] distance (in voxels, clamped to `cap` = reach + 1 where nothing is near) from each vertex of one marching-cubes
+    mesh to the SURFACE of another one of the same N^3 grid (vertices in index space, extract_mesh.py:159-165).  A marching-
+    cubes triangle lies inside one grid cube, so the triangles that can be within `reach` voxels of a vertex are those of the
+    (2 reach + 1)^3 cubes around it: triangles are sorted by their cube, each cube holds at most 5 (csrc/mesh.hip: MAX_TRIS 8
+    bounds the table)."""
+    dev = verts.device
+    cap = float(reach + 1) if cap is None else float(cap)
+    tv = other_verts[other_tris.long()]                                              # [T, 3, 3]
+    cube = tv.mean(1).floor().clamp_(0, N - 2).long()
+    key = (cube[:, 0] * N + cube[:, 1]) * N + cube[:, 2]
+    key, order = torch.sort(key)
+    tv = tv[order]
+    per_cube = int(torch.unique_consecutive(key, return_counts=True)[1].max()) if key.numel() else 0
+    out = torch.full((verts.shape[0],), cap, dtype=torch.float32, device=dev)
+    offs = torch.arange(-reach, reach + 1, device=dev)
+    offs = torch.stack(torch.meshgrid(offs, offs, offs, indexing="ij"), -1).reshape(-1, 3)
+    for s in range(0, verts.shape[0], chunk):
+        p = verts[s:s + chunk]
+        base = p.floor().long()
+        best = torch.full((p.shape[0],), cap, dtype=torch.float32, device=dev)
+        for o in offs:
+            cell = base + o
+            inside = ((cell >= 0) & (cell <= N - 2)).all(-1)
+            k = (cell[:, 0] * N + cell[:, 1]) * N + cell[:, 2]
+            lo = torch.searchsorted(key, k)
+            hi = torch.searchsorted(key, k, right=True)
+            for j in range(per_cube):
+                has = inside & (lo + j < hi)
+                if not bool(has.any()):
+                    break
+                t = tv[(lo + j).clamp_max(max(tv.shape[0] - 1, 0))]
+                d = point_triangle_distance(p, t[:, 0], t[:, 1], t[:, 2])
+                best = torch.where(has, torch.minimum(best, d), best)
+        out[s:s + chunk] = best
+    return out

@@ -66,18 +66,25 @@ def main():
     both = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
     assert all(torch.equal(both[0], b) for b in both[1:]), "parameters differ between ranks after the step"
-    # The graphed step with more than one rank: forward + backward replayed from a HIP graph, the all-reduce of the flat buffers
-    # and Adam after each replay.  Same trajectory as the eager step (overlapped bucket all-reduce) on a copy of the model.
+    # The graphed step with more than one rank: forward + backward replayed from TWO HIP graphs, the all-reduce of the fine
+    # network's flat buffer issued between them (it runs while the second replays), the other bucket's and Adam after.  Same trajectory as the eager step (overlapped bucket all-reduce) on a copy of the model.
     import copy
-    hp2 = ana.TrainHParams(n_samples=16, n_importance=8, chunk=64, lambda_normals=0.0, lr=1e-3)
+    # (normals term on: its weight gradients join the flat buffers at the cut between the two graphs; both copies draw the same
+    # numbers — the explicit step's stream is a function of the seed at construction and the step count)
+    hp2 = ana.TrainHParams(n_samples=16, n_importance=8, chunk=64, lambda_normals=0.05, lr=1e-3)
     base = seeded_model(tbl, g["seed"], True, g["gain"], g["shift"], device=dev)
     me, mg = copy.deepcopy(base), copy.deepcopy(base)
-    te, tg = ana.Trainer(me, vr, hp2), ana.Trainer(mg, vr, hp2, graph=True)
+    torch.manual_seed(900)
+    te = ana.Trainer(me, vr, hp2)
+    torch.manual_seed(900)
+    tg = ana.Trainer(mg, vr, hp2, graph=True)
     for it in range(6):
         le, _ = te.step(rays, tgt, alp, pose, templ, fg, bg, perturb=0.0)
         lg, _ = tg.step_graphed(rays, tgt, alp, pose, templ, fg, bg, perturb=0.0)
         assert abs(float(le) - float(lg)) <= 2e-3 * abs(float(le)), (rank, it, float(le), float(lg))
     assert tg._graph is not None and tg._graph_split and te._graph is None
+    # the replayed backward is cut in two graphs at the fine network's completed bucket: its all-reduce overlaps the second
+    assert tg._graph_second is not None
     assert te.explicit is not None and tg.explicit is not None     # (both ran the explicit step: fused_step.py)
     for (k, a), (_, b) in zip(me.named_parameters(), mg.named_parameters()):
         if a.requires_grad:

@@ -623,36 +623,83 @@ def test_training_step_matches_reference_loss_fixture(dev, smpl_table):
         want = float(g["loss/" + k])
         assert abs(v.item() - want) <= 1e-6 + 2e-4 * abs(want), (k, v.item(), want)
     assert abs(loss.item() - float(g["total"])) <= 2e-4 * float(g["total"])
-    # (3) every weight gradient against fp64 autograd of the oracle on the same importance samples and draws
+    # (3) every weight gradient against fp64 autograd of the oracle on the same importance samples and draws.
+    # Twice: (a) the oracle warps the samples itself, in fp64 — the gate of rounds 3-4 (5e-3; measured 2.3e-3 / 1.1e-3); (b) the
+    # oracle is handed the HIP path's fp32 CANONICAL POINTS and differentiates the same function of the weights in fp64 —
+    # 1e-3, the gate of every other whole-gradient comparison of this file.  What separates the two is the conditioning of
+    # the REFERENCE's own function, not a kernel: tools/exp/loss_fixture_terms.py (round 5) finds the whole 2e-3 in the rgb
+    # term alone, in xyz_encoding_1.0.weight (2e-2 of that tensor) — dL/dW1 = sum over samples of dact_1 x encoding(x_c), and
+    # 1e-6 of fp32 rounding in a canonical point is 5e-4 rad of phase in the 2^9 band of the encoding (test_reference_conditioning),
+    # summed with cancelling signs.  The reference's own fp32 gradient sits as far from fp64 as ours does.  (Round 4 blamed
+    # ReLU kinks of the normals term: taking the 574 kink pairs out on both sides moved the figure from 2.28e-3 to 2.28e-3.)
+    from anim_nerf_amd import ops
     Pc = {k: v.double().requires_grad_(True) for k, v in net_params(m.nerf).items()}
     Pf = {k: v.double().requires_grad_(True) for k, v in net_params(m.nerf_fine).items()}
     z_fine = _hip_fine_samples(m, vr, rays, pose, dev)
     tbl64 = _fp64(tbl)
+    st = orc.frame_state(tbl64, _fp64(pose), _fp64(templ))
+    kw = dict(n_samples=Kc, fg_points=fg.double(), bg_points=bg.double(), verts_template=st["verts_template"],
+              draws=tuple(d.double() for d in draws), lambda_alphas=hp.lambda_alphas, lambda_foreground=hp.lambda_foreground,
+              lambda_background=hp.lambda_background, lambda_normals=hp.lambda_normals, epsilon=hp.epsilon, dis_threshold=hp.dis_threshold)
+    t_rgb, t_a = tgt_rgb.view(F_, H * W, 3).double(), tgt_a.view(F_, H * W, 1).double()
+
+    def rel_error():
+        out = {}
+        for tag, net, P in (("coarse", m.nerf, Pc), ("fine", m.nerf_fine, Pf)):
+            num = den = 0.0
+            for k, p in net.named_parameters():
+                num += (p.grad.cpu().double() - P[k].grad).pow(2).sum().item()
+                den += P[k].grad.pow(2).sum().item()
+            assert den > 0
+            out[tag] = (num / den) ** 0.5
+        return out
+    # (a) the oracle's own warp
     out = orc.render_frame(tbl64, Pc, Pf, rays.view(F_, H * W, 8).double(), _fp64(pose), _fp64(templ), n_coarse=Kc, n_fine=Kf,
                            use_unpose=True, chunk=hp.chunk, knn_chunk=512, z_fine=z_fine)
-    st = orc.frame_state(tbl64, _fp64(pose), _fp64(templ))
-    ref, _ = orc.training_loss(Pc, Pf, out, tgt_rgb.view(F_, H * W, 3).double(), tgt_a.view(F_, H * W, 1).double(), n_samples=Kc,
-                               fg_points=fg.double(), bg_points=bg.double(), verts_template=st["verts_template"],
-                               draws=tuple(d.double() for d in draws), lambda_alphas=hp.lambda_alphas,
-                               lambda_foreground=hp.lambda_foreground, lambda_background=hp.lambda_background,
-                               lambda_normals=hp.lambda_normals, epsilon=hp.epsilon, dis_threshold=hp.dis_threshold)
+    ref, _ = orc.training_loss(Pc, Pf, out, t_rgb, t_a, **kw)
     ref.backward()
     assert abs(loss.item() - ref.item()) <= 2e-4 * abs(ref.item()), (loss.item(), ref.item())
-    for tag, net, P in (("coarse", m.nerf, Pc), ("fine", m.nerf_fine, Pf)):
-        num = den = 0.0
-        for k, p in net.named_parameters():
-            num += (p.grad.cpu().double() - P[k].grad).pow(2).sum().item()
-            den += P[k].grad.pow(2).sum().item()
-        print(f"train_loss fixture: relative L2 error of the whole {tag} weight gradient vs fp64: {(num / den) ** 0.5:.2e}")
-        # (1e-3 is the gate of the same comparison without the normals term, test_training_loss_gradients_match_oracle, and of
-        # the normals term alone with the points at a ReLU kink masked, test_normals_regulariser_matches_reference: 2.6e-7
-        # measured.  Here the term's 27,560 points are all in: piecewise constant in their ReLU patterns, a handful sit within
-        # fp32 rounding of a kink and flip a whole unit's contribution against the fp64 oracle — measured 2.3e-3 / 1.1e-3.)
-        assert den > 0 and (num / den) ** 0.5 < 5e-3, (tag, (num / den) ** 0.5)
-        # and against the reference's own fp32 gradient norms
+    own_warp = rel_error()
+    # (b) the HIP path's canonical points (and validity bits) injected: the same function of the weights on both sides
+    with torch.no_grad():
+        m.set_body_model({k: v.to(dev) for k, v in pose.items()}, _templ(dev))
+        rays_b = m.convert_to_body_model_space(rays.view(F_, H * W, 8).to(dev))
+        m.clac_ober2cano_transform()
+        zc = vr.sample_coarse(rays_b)
+        zs = torch.sort(torch.cat([zc, z_fine.float().to(dev)], -1), -1).values
+        pts_c = m.warped_points(rays=rays_b, z=zc).view(F_, -1, 4).cpu().double()
+        pts_f = m.warped_points(rays=rays_b, z=zs).view(F_, -1, 4).cpu().double()
+
+    def field(xyz, use_fine):
+        pts = pts_f if use_fine else pts_c
+        assert xyz.shape[:2] == pts.shape[:2]
+        rgb, sig = orc.mlp_forward(Pf if use_fine else Pc, pts[..., :3])
+        return rgb, torch.where(pts[..., 3:] < 1, torch.full_like(sig, -1e5), sig)
+    for P in (Pc, Pf):
+        for v in P.values():
+            v.grad = None
+    out_inj = orc.render_rays(field, rays_b.cpu().double(), Kc, Kf, True, z_fine)
+    ref_inj, _ = orc.training_loss(Pc, Pf, out_inj, t_rgb, t_a, **kw)
+    ref_inj.backward()
+    assert abs(loss.item() - ref_inj.item()) <= 2e-5 * abs(ref_inj.item()), (loss.item(), ref_inj.item())
+    injected = rel_error()
+    print(f"train_loss fixture: relative L2 error of the whole weight gradient vs fp64: oracle's own warp {own_warp}, the HIP path's "
+          f"canonical points injected {injected}")
+    for tag in ("coarse", "fine"):
+        assert injected[tag] < 1e-3, (tag, injected)
+        assert own_warp[tag] < 5e-3, (tag, own_warp)
+    # and against the reference's own fp32 gradient norms — its fp32 arithmetic is one draw of the rounding of the canonical
+    # points (the conditioning above), ours another: the tensors of the layers the encoding feeds (layer 1, and layer 5's
+    # weight) within 1e-2, every other tensor within 3e-3 (measured: 9e-4 / 2e-3)
+    for tag, net in (("coarse", m.nerf), ("fine", m.nerf_fine)):
+        worst = {}
         for k, want in zip(g[f"grad_keys_{tag}"], g[f"grad_norms_{tag}"]):
             got = dict(net.named_parameters())[str(k)].grad.double().norm().item()
-            assert abs(got - want) <= 1e-2 * want + 1e-12, (tag, str(k), got, want)
+            enc_fed = str(k) in ("xyz_encoding_1.0.weight", "xyz_encoding_1.0.bias", "xyz_encoding_5.0.weight")
+            worst[enc_fed] = max(worst.get(enc_fed, 0.0), abs(got - want) / (want + 1e-300))
+            assert abs(got - want) <= (1e-2 if enc_fed else 3e-3) * want + 1e-12, (tag, str(k), got, want)
+        print(f"train_loss fixture: {tag} gradient norms vs the reference's own fp32 norms: worst {worst.get(False, 0):.1e}, "
+              f"encoding-fed tensors {worst.get(True, 0):.1e}")
 
 
 def _loss_scene(dev, smpl_table, frames=2):
@@ -1187,7 +1234,8 @@ def test_training_tracks_an_oracle_trained_copy(dev, smpl_table):
     finally:
         torch.set_num_threads(threads)
     psnr_h = det["psnr"].item()
-    psnr_o = -10.0 * torch.log10(F.mse_loss(out["rgbs_fine"], t_rgb)).item()
+    # (train/psnr = torchmetrics' peak_signal_noise_ratio without data_range, train.py:339-344: the range is the targets' own)
+    psnr_o = (10.0 * torch.log10((t_rgb.max() - t_rgb.min()) ** 2 / F.mse_loss(out["rgbs_fine"], t_rgb))).item()
     gap = max(abs(a - b) / b for a, b in zip(curve_h, curve_o))
     print(f"\nloss {curve_o[0]:.4f} -> HIP {curve_h[-1]:.4f} / oracle {curve_o[-1]:.4f}; widest gap of the curves {gap:.2%}; "
           f"PSNR (last step's batch) HIP {psnr_h:.2f} dB / oracle {psnr_o:.2f} dB")
@@ -1211,6 +1259,74 @@ def test_training_pass_without_a_single_valid_sample(dev, smpl_table):
         assert all(p.grad is None or (torch.isfinite(p.grad).all() and p.grad.abs().max() == 0) for p in net.parameters())
         assert pts.grad is not None and pts.grad.abs().max() == 0
         pts.grad = None
+
+
+def test_graphed_step_inputs_template_and_checkpointed_draws(dev, smpl_table):
+    """What a replayed step reads from its caller: (a) a batch written IN PLACE through a path that does not bump
+    torch's version counter (`x.data.copy_`) is still seen — the batch is copied every step, in one launch (anr_copy_segments),
+    unless the Trainer was built with static_inputs=True; (b) a template pose with new VALUES (and a fresh object every step,
+    as the reference's loader hands it over, datasets/anim_nerf_dataset.py:278) reaches the replay without a new capture: its
+    body state is recomputed into the tensors the graph reads; (c) Trainer.state_dict() carries the explicit step's random
+    stream: a resumed copy draws what the original draws next, not steps 0..k again."""
+    import copy
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import ops
+    m0, table0, batch = _config3_scene(dev, smpl_table, F=4, H=16)
+    hp = ana.TrainHParams(n_samples=32, n_importance=16, lr=0.0)        # lr 0: the weights stay put, losses are comparable
+    fidx = torch.arange(4, device=dev)
+
+    def trainer(graph, hp=hp, **kw):
+        torch.manual_seed(11)                                            # the explicit step's draws: seed + step counter
+        m, table = copy.deepcopy(m0), copy.deepcopy(table0)
+        m.nerf.mlp_mode = m.nerf_fine.mlp_mode = "bf16"
+        return ana.Trainer(m, ana.VolumeRenderer(n_coarse=32, n_fine=16), hp, body_model_params=table, graph=graph, **kw)
+    te, tg = trainer(False), trainer(True)
+    rgbs = batch["rgbs"].clone()
+    templ_b = {k: v.clone() for k, v in _templ(dev).items()}
+    templ_b["body_pose"] = templ_b["body_pose"] + 0.05 * torch.randn(templ_b["body_pose"].shape, generator=torch.Generator().manual_seed(1)).to(dev)
+    graph_obj, losses = None, []
+    for it in range(10):
+        if it == 6:
+            rgbs.data.copy_(1.0 - rgbs)                                  # in place, version counter untouched
+        templ = {k: v.clone() for k, v in (templ_b if it >= 8 else _templ(dev)).items()}      # a fresh object every step
+        pair = []
+        for tr in (te, tg):
+            loss, det = tr.step_graphed(batch["rays"], rgbs, batch["alphas"], None, templ, batch["fg"], batch["bg"], perturb=1.0,
+                                        frame_idx=fidx)
+            pair.append(float(loss))
+        losses.append(pair)
+        if it == 4:
+            assert tg._graph is not None
+            graph_obj = tg._graph[1]
+    assert tg._graph[1] is graph_obj, "a fresh template object (or new template values) must not cost a new capture"
+    le, lg = np.array(losses).T
+    np.testing.assert_allclose(lg, le, rtol=2e-3)
+    assert abs(le[6] - le[5]) > 5e-3 * le[5], "the in-place batch change must show in the loss"
+    assert abs(le[8] - le[7]) > 1e-4 * le[7], "the new template must show in the loss"
+    # static_inputs=True is the documented opt-out: the same in-place write is NOT seen
+    ts = trainer(True, hp=ana.TrainHParams(n_samples=32, n_importance=16, lr=0.0, lambda_normals=0.0), static_inputs=True)
+    rg = batch["rgbs"].clone()
+    seen = []
+    templ = _templ(dev)
+    for it in range(7):
+        if it == 6:
+            rg.data.copy_(1.0 - rg)
+        seen.append(float(ts.step_graphed(batch["rays"], rg, batch["alphas"], None, templ, batch["fg"], batch["bg"], perturb=0.0, frame_idx=fidx)[0]))
+    assert abs(seen[6] - seen[5]) < 1e-3 * seen[5]
+    # (c) the random stream is part of the checkpoint
+    sd = tg.state_dict()
+    assert "draw_state" in sd and int(sd["draw_state"][1]) == 10, sd["draw_state"][:3]
+    tr = trainer(True)
+    tr.load_state_dict(sd)
+    nxt = [float(t.step_graphed(batch["rays"], rgbs, batch["alphas"], None, templ_b, batch["fg"], batch["bg"], perturb=1.0, frame_idx=fidx)[0])
+           for t in (tg, tr)]
+    assert abs(nxt[0] - nxt[1]) <= 2e-3 * abs(nxt[0]), nxt
+    assert torch.equal(tg.explicit.draw_state[:2], tr.explicit.draw_state[:2])
+    # one launch for the batch: the copy entry point itself
+    a = [torch.randn(n, device=dev) for n in (1, 7, 4096, 100003)] + [torch.arange(5, device=dev)]
+    b = [torch.empty_like(x) for x in a]
+    ops.copy_segments(list(zip(b, a)))
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
 
 
 def test_graphed_training_step_equals_the_eager_step(dev, smpl_table):
@@ -1552,6 +1668,133 @@ def test_explicit_step_equals_the_autograd_step(dev, smpl_table, mode, frames):
     used = torch.zeros(40, dtype=torch.bool)
     used[frame_idx.cpu()] = True
     assert (g_pose[~used].abs().max() == 0) and (g_pose[used].abs().sum(-1) > 0).all()
+
+
+def test_frozen_network_kernel_variants(dev):
+    """ANR_MLP_FLAG_BITS_ONLY / ANR_MLP_FLAG_ENC_ONLY (the `_refine` stage: networks frozen, train.py:433-437): the training
+    forward that keeps only the ReLU sign bits returns the same outputs and the same bits as the one that saves everything,
+    and the activation-gradient kernel that writes only layers 1 and 5 writes there what the full one writes — so the
+    gradient towards the points (anr_mlp_denc) is the same bits — at full, ragged and device-counted row counts."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import ops
+    from anim_nerf_amd.autograd import PARAM_KEYS
+    torch.manual_seed(0)
+    net = ana.NeRF(freqs_dir=0, use_view=False).to(dev)
+    named = dict(net.named_parameters())
+    P = {k: named[k].detach() for k in PARAM_KEYS}
+    g = torch.Generator().manual_seed(2)
+    for mode_name in ("bf16", "f32"):
+        mode = ops.MLP_MODES[mode_name]
+        pack, bpack = ops.mlp_pack(P, mode), ops.mlp_pack(P, mode, backward=True)
+        for n, cnt in ((4096, None), (1000 * 64, 37 * 64), (64, None)):
+            pts = torch.cat([torch.rand(n, 3, generator=g) * 2 - 1, torch.ones(n, 1)], -1).to(dev)
+            g4 = torch.randn(n, 4, generator=g).to(dev)
+            count = None if cnt is None else torch.tensor([cnt], dtype=torch.int32, device=dev)
+            rows = n if cnt is None else cnt
+            out, act = ops.mlp_forward_save(pack, mode, pts, count=count)
+            out_b, act_b = ops.mlp_forward_save(pack, mode, pts, count=count, bits_only=True)
+            assert torch.equal(out[:rows], out_b[:rows])
+            # the sign bits behind the blocks (csrc/mlp_core.h): 8 trunk layers x [n][32 B], then the colour head's [n][16 B]
+            raw = lambda a: a.reshape(-1).view(torch.uint8)[ops.ACT_COLS * n * a.element_size():]
+            trunk = lambda a: raw(a)[:8 * 32 * n].view(8, n, 32)[:, :rows]
+            head = lambda a: raw(a)[288 * n:304 * n].view(n, 16)[:rows]
+            assert torch.equal(trunk(act), trunk(act_b)) and torch.equal(head(act), head(act_b))
+            dact = ops.mlp_backward(bpack, mode, g4, act, count=count)
+            dact_e = ops.mlp_backward(bpack, mode, g4, act_b, count=count, enc_only=True)
+            for c0 in (0, 1024):
+                assert torch.equal(ops.act_columns(dact, c0, c0 + 256)[:rows], ops.act_columns(dact_e, c0, c0 + 256)[:rows]), (mode_name, n, c0)
+            w1, w5 = P["xyz_encoding_1.0.weight"], P["xyz_encoding_5.0.weight"]
+            d_enc = ops.mlp_denc(mode, dact, w1, w5, count=count)
+            assert torch.equal(d_enc[:rows], ops.mlp_denc(mode, dact_e, w1, w5, count=count)[:rows])
+            # anr_mlp_dpoints = anr_mlp_denc + anr_encode_backward in one launch, the panels from the backward pack (same MFMA
+            # sums; the encoding's derivative through the kernels' own sin / cos instead of libm's: ~1 ulp apart)
+            want = ops.encode_backward(pts, d_enc, count=count)[:rows]
+            for d in (dact, dact_e):
+                got = ops.mlp_dpoints(bpack, mode, d, pts, count=count)[:rows]
+                assert (got - want).abs().max() <= 2e-5 * want.abs().max() and (got[:, 3] == 0).all(), (mode_name, n)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_refine_step_with_frozen_networks(dev, smpl_table, mode):
+    """The `_refine` stage of the shipped configs (configs/people_snapshot/male-3-casual_refine.yaml:52-53, train.py:433-437):
+    the networks are loaded and frozen (requires_grad False), only the BodyModelParams rows train.  The explicit step takes it
+    (no weight-gradient launch, sign bits instead of saved activations, activation gradients of layers 1 and 5 only):
+    (a) same loss terms and the same pose-table gradients as the autograd step on the same draws, (b) the pose gradients
+    are those of the step that also trains the networks (the same function of the poses), (c) no network tensor gets a
+    gradient or moves, the table moves, (d) replayed from a HIP graph it gives the same losses."""
+    import copy
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    from helpers import InjectedDraws
+    frames, H = 2, 16
+    c2w, focal, cen = syn.pinhole_camera(H, H)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), H, H, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(frames, 1, 1, 1).contiguous()
+    gen = torch.Generator().manual_seed(4)
+    rgbs = torch.rand(frames, H, H, 3, generator=gen).to(dev)
+    alphas = (torch.rand(frames, H, H, 1, generator=gen) > 0.5).float().to(dev)
+    fg = (torch.rand(frames, 96, 3, generator=gen) * 0.4 - 0.2).to(dev)
+    bg = (torch.rand(frames, 64, 3, generator=gen) * 2 - 1).to(dev)
+    frame_idx = torch.tensor([5, 17], device=dev)
+    seeded = syn.animated_pose_params(seed=200, bs=40)
+    hp = ana.TrainHParams(n_samples=64, n_importance=32, chunk=2048)
+
+    def world(frozen, explicit, graph=False):
+        torch.manual_seed(21)
+        m = seeded_model(smpl_table, 11, True, 300.0, (2.0, 2.0), device=dev, mlp_mode=mode)
+        m.train()
+        if frozen:
+            for p in m.parameters():
+                p.requires_grad_(False)
+        table = ana.BodyModelParams(40).to(dev)
+        for name in table.param_names:
+            table.init_parameters(name, torch.from_numpy(seeded[name]).to(dev), requires_grad=True)
+        return m, table, ana.Trainer(m, ana.VolumeRenderer(n_coarse=64, n_fine=32), hp, body_model_params=table, explicit_step=explicit, graph=graph)
+    args = (rays, rgbs, alphas, None, _templ(dev), fg, bg, 1.0, frame_idx)
+    m, table, tr = world(True, True)
+    assert tr.explicit is not None and tr.explicit.frozen_networks() and tr.explicit.supported(rays, None, frame_idx, fg, bg)
+    assert len(tr.optimizer.param_groups[-1]["params"]) == 4 and all(p.grad is None for p in m.parameters())
+    from anim_nerf_amd import ops
+    ops.KERNEL_TIMING = []
+    loss, det = tr._step_body(*args, apply=False)
+    names = {k[0] for k in ops.KERNEL_TIMING}
+    ops.KERNEL_TIMING = None
+    assert "mlp_wgrad" not in names and "mlp_forward_bits" in names and "mlp_backward_enc" in names, names
+    d = tr.explicit.last_draws
+    R = frames * H * H
+    replay = [d["t_rand"].view(R, 64), d["noise_c"].view(R, 64), d["u_fine"].view(R, 32), d["noise_f"].view(R, 96), d["n0"], d["n1"]]
+    g_frozen = {k: p.grad.clone() for k, p in table.named_parameters()}
+    assert all(p.grad is None for p in m.parameters())
+    # (a) the autograd step of the same frozen world on the same draws
+    m2, table2, tr2 = world(True, False)
+    with InjectedDraws(replay=replay):
+        loss2, det2 = tr2._step_body(*args, apply=False)
+    tol = 2e-6 if mode == "f32" else 2e-5
+    assert set(det) == set(det2)
+    for k in det2:
+        assert abs(det[k].item() - det2[k].item()) <= tol * abs(det2[k].item()) + 1e-7, (k, det[k].item(), det2[k].item())
+    for k, p in table2.named_parameters():
+        err = (g_frozen[k] - p.grad).norm() / p.grad.norm().clamp_min(1e-20)
+        assert p.grad.abs().max() > 0 and err < (2e-5 if mode == "f32" else 2e-3), (k, err.item())
+    # (b) the step that also trains the networks: the same pose gradients (its draws are the same function of seed and step)
+    m3, table3, tr3 = world(False, True)
+    loss3, _ = tr3._step_body(*args, apply=False)
+    assert abs(loss3.item() - loss.item()) <= tol * abs(loss.item())
+    for k, p in table3.named_parameters():
+        err = (g_frozen[k] - p.grad).norm() / p.grad.norm().clamp_min(1e-20)
+        assert err < (2e-5 if mode == "f32" else 2e-3), (k, err.item())
+    # (c) steps move the table and nothing else; (d) the graph replays them
+    m4, table4, tr4 = world(True, True, graph=True)
+    before = {k: v.clone() for k, v in m4.state_dict().items()}
+    t_before = table4.body_pose.weight.detach().clone()
+    m5, table5, tr5 = world(True, True)
+    pairs = []
+    for it in range(6):
+        pairs.append((float(tr4.step_graphed(*args[:7], perturb=1.0, frame_idx=frame_idx)[0]),
+                      float(tr5.step_graphed(*args[:7], perturb=1.0, frame_idx=frame_idx)[0])))
+    assert tr4._graph is not None
+    np.testing.assert_allclose([a for a, _ in pairs], [b for _, b in pairs], rtol=5e-3)
+    assert all(torch.equal(v, before[k]) for k, v in m4.state_dict().items())
+    assert (table4.body_pose.weight.detach() - t_before).abs().max() > 0
 
 
 def test_add_inplace_and_background_weight_gradients(dev):

@@ -24,7 +24,10 @@ def line(wl):
     raise SystemExit(f"no bench line in {wl}_trace.json")
 
 
-out = {"commit": commit,
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                                                    # (for the hash of the kernel sources bench.py compares with)
+
+out = {"commit": commit, "kernel_sources_sha": bench.kernel_sources_sha(), "kernel_sources": list(bench.TRAFFIC_SOURCES),
        "command": "bash tools/collect_profiles.sh (rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace, separate "
                   f"passes, on python3 bench.py --workload cfgN --no-extras --cpu-rays 0 --no-psnr --steps {frames - 1} --warmup 1: {frames} frames)",
        "fetch_correction": 2.0,
