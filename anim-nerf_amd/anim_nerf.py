@@ -153,7 +153,8 @@ class AnimNeRF(nn.Module):
         p = body_model_params
         names = ("betas", "global_orient", "body_pose", "transl")
         bm = self.body_model
-        fast = (rays.is_cuda and bm.v_template.is_cuda and body_model_params_template is not None
+        import os
+        fast = (not os.environ.get("ANR_FRAME_SETUP_OFF") and rays.is_cuda and bm.v_template.is_cuda and body_model_params_template is not None
                 and all(torch.is_tensor(p.get(k)) and p[k].is_cuda and p[k].dtype == torch.float32 for k in names)
                 and bm.lbs_weights.shape[1] == 24 and bm.shapedirs.shape[-1] == 10 and p["betas"].shape[-1] == 10
                 and p["body_pose"].shape[-1] == 69 and rays.shape[-1] == 8 and rays.dim() == 3

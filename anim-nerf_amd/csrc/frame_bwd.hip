@@ -319,6 +319,10 @@ __global__ __launch_bounds__(FB_THREADS) void frame_adjoint_kernel(
     const float* __restrict__ A_fwd, const float* __restrict__ Ginv_fwd) {
     __shared__ ChainLds L;
     __shared__ float sAcc[FA_ACC];
+    // per wavefront: the 64 vertices' skinning weights [64][24] and pulled-back transforms gT [64][12], for the contraction
+    // g_A[j][e] = sum_v w[v][j] gT[v][e] below
+    __shared__ float sW[FB_THREADS / 64][64][FB_J];
+    __shared__ float sGT[FB_THREADS / 64][64][12];
     const int b = blockIdx.y;
     if (A_fwd != nullptr && Ginv_fwd != nullptr) {
         // the VALUES of the chain as the forward kernels left them (anr_smpl_forward's joints_transform, with transl on its
@@ -343,8 +347,12 @@ __global__ __launch_bounds__(FB_THREADS) void frame_adjoint_kernel(
     float gG[12], gTr[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 12; ++e) gG[e] = 0.0f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if ((int)blockIdx.x < n_vblocks) {
         const int v = blockIdx.x * FB_THREADS + threadIdx.x;
+        float gT[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) gT[e] = 0.0f;
         if (v < V) {
             float T[12];
 #pragma unroll
@@ -401,7 +409,6 @@ __global__ __launch_bounds__(FB_THREADS) void frame_adjoint_kernel(
 #pragma unroll
                 for (int n = 0; n < 3; ++n) gXR[i * 3 + n] = -(Y[0 * 3 + i] * P[0 * 3 + n] + Y[1 * 3 + i] * P[1 * 3 + n] + Y[2 * 3 + i] * P[2 * 3 + n]);
             // X_R = G_R T_R, X_t = G_R T_t + G_t
-            float gT[12];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
 #pragma unroll
@@ -416,13 +423,27 @@ __global__ __launch_bounds__(FB_THREADS) void frame_adjoint_kernel(
                     gG[r * 4 + k] = gXR[r * 3 + 0] * T[k * 4 + 0] + gXR[r * 3 + 1] * T[k * 4 + 1] + gXR[r * 3 + 2] * T[k * 4 + 2] + gXt[r] * T[k * 4 + 3];
                 gG[r * 4 + 3] = gXt[r];
             }
-#pragma unroll 1
-            for (int j = 0; j < FB_J; ++j) {
-                const float wj = w[j];
-                if (wj != 0.0f) {
+        }
+        // g_A[j][e] += sum over the wavefront's 64 vertices of w[v][j] gT[v][e]: both operands through this wave's LDS patch,
+        // lane l owns the outputs l, l + 64, ... of the 288 (consecutive lanes: consecutive e of one j — the w reads broadcast,
+        // the gT reads hit 12 consecutive words) and walks the vertices in order.  (Every lane adding its 12 products per joint
+        // with LDS atomics queued up to 64 adds on ONE address 288 times per wavefront: most of this kernel's 89 us at 2 frames.)
+        {
+            const float* wv = lbs_w + (int64_t)(v < V ? v : V - 1) * FB_J;
 #pragma unroll
-                    for (int e = 0; e < 12; ++e) atomicAdd(&sAcc[j * 12 + e], wj * gT[e]);
-                }
+            for (int j = 0; j < FB_J; ++j) sW[wave][lane][j] = v < V ? wv[j] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) sGT[wave][lane][e] = gT[e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int k = 0; k < (FB_J * 12 + 63) / 64; ++k) {
+            const int o = lane + 64 * k;
+            if (o < FB_J * 12) {
+                const int j = o / 12, e = o % 12;
+                float acc_je = 0.0f;
+                for (int u = 0; u < 64; ++u) acc_je += sW[wave][u][j] * sGT[wave][u][e];
+                if (acc_je != 0.0f) atomicAdd(&sAcc[o], acc_je);
             }
         }
     } else {

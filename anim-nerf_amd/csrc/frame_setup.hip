@@ -46,7 +46,10 @@ __global__ __launch_bounds__(64) void frame_chain_kernel(const int64_t* __restri
                                                          float* __restrict__ ginv_out, float* __restrict__ groot_out) {
     const int b = blockIdx.x, j = threadIdx.x;
     __shared__ float sB[FS_NB], sP[3 * FS_J], sT[3];
-    __shared__ float Rm[FS_J][9], Jr[FS_J][3], Wd[FS_J][12], sI[12];
+    // (the narrow part of the chain — 24 joints, 85 scalars per frame — accumulates in DOUBLE: it costs nothing here, and the
+    // pose gradients downstream are cancelling sums over 6,890 vertices that amplify every rounding of A ~500 x)
+    __shared__ float Rm[FS_J][9], sI[12];
+    __shared__ double Jr[FS_J][3], Wd[FS_J][12];
     const int64_t row = frame_idx ? frame_idx[b] : b;
     const int64_t brow = frame_idx ? (row < betas_rows ? row : betas_rows - 1) : b;
     if (j < FS_NB) { sB[j] = betas_w[brow * FS_NB + j]; betas_out[b * FS_NB + j] = sB[j]; }
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(64) void frame_chain_kernel(const int64_t* __restri
     if (j < 3) { sT[j] = tr_w[row * 3 + j]; transl_out[b * 3 + j] = sT[j]; }
     __syncthreads();
     if (j < FS_J) {
+#pragma clang fp contract(fast)                                          // (the SMPL part rounds as csrc/smpl.hip does: fused multiply-adds)
         const float x = sP[3 * j], y = sP[3 * j + 1], z = sP[3 * j + 2];
         const float xe = x + 1e-8f, ye = y + 1e-8f, ze = z + 1e-8f;          // lbs.py:316: angle = |rv + 1e-8|
         const float th = sqrtf(xe * xe + ye * ye + ze * ze);
@@ -73,8 +77,8 @@ __global__ __launch_bounds__(64) void frame_chain_kernel(const int64_t* __restri
             }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float acc = J0[j * 3 + c];
-            for (int k = 0; k < FS_NB; ++k) acc += sB[k] * JS[(j * 3 + c) * FS_NB + k];
+            double acc = J0[j * 3 + c];
+            for (int k = 0; k < FS_NB; ++k) acc += (double)sB[k] * (double)JS[(j * 3 + c) * FS_NB + k];
             Jr[j][c] = acc;
         }
         if (j >= 1) {
@@ -87,24 +91,26 @@ __global__ __launch_bounds__(64) void frame_chain_kernel(const int64_t* __restri
     // world_q = world_parent . [R_q | J_q - J_parent], one element (r, c) per lane, joints in tree order (parents[q] < q)
     for (int q = 0; q < FS_J; ++q) {
         if (j < 12) {
+#pragma clang fp contract(fast)
             const int r = j >> 2, c = j & 3;
             const int p = q == 0 ? -1 : (int)parents[q];
-            auto loc = [&](int k, int cc) { return cc < 3 ? Rm[q][k * 3 + cc] : Jr[q][k] - (p >= 0 ? Jr[p][k] : 0.0f); };
-            float w;
+            auto loc = [&](int k, int cc) { return cc < 3 ? (double)Rm[q][k * 3 + cc] : Jr[q][k] - (p >= 0 ? Jr[p][k] : 0.0); };
+            double w;
             if (p < 0) w = loc(r, c);
-            else w = Wd[p][r * 4 + 0] * loc(0, c) + Wd[p][r * 4 + 1] * loc(1, c) + Wd[p][r * 4 + 2] * loc(2, c) + (c == 3 ? Wd[p][r * 4 + 3] : 0.0f);
+            else w = Wd[p][r * 4 + 0] * loc(0, c) + Wd[p][r * 4 + 1] * loc(1, c) + Wd[p][r * 4 + 2] * loc(2, c) + (c == 3 ? Wd[p][r * 4 + 3] : 0.0);
             Wd[q][j] = w;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     float Aj[12];
     if (j < FS_J) {
+#pragma clang fp contract(fast)
         float* A = A_out + ((int64_t)b * FS_J + j) * 16;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const float shift = Wd[j][r * 4 + 0] * Jr[j][0] + Wd[j][r * 4 + 1] * Jr[j][1] + Wd[j][r * 4 + 2] * Jr[j][2];
-            Aj[r * 4 + 0] = Wd[j][r * 4 + 0]; Aj[r * 4 + 1] = Wd[j][r * 4 + 1]; Aj[r * 4 + 2] = Wd[j][r * 4 + 2];
-            Aj[r * 4 + 3] = (Wd[j][r * 4 + 3] - shift) + sT[r];               // body_models.py:373: transl on the translation column
+            const double shift = Wd[j][r * 4 + 0] * Jr[j][0] + Wd[j][r * 4 + 1] * Jr[j][1] + Wd[j][r * 4 + 2] * Jr[j][2];
+            Aj[r * 4 + 0] = (float)Wd[j][r * 4 + 0]; Aj[r * 4 + 1] = (float)Wd[j][r * 4 + 1]; Aj[r * 4 + 2] = (float)Wd[j][r * 4 + 2];
+            Aj[r * 4 + 3] = (float)((Wd[j][r * 4 + 3] - shift) + (double)sT[r]);   // body_models.py:373: transl on the translation column
 #pragma unroll
             for (int c = 0; c < 4; ++c) A[r * 4 + c] = Aj[r * 4 + c];
         }
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(64) void frame_chain_kernel(const int64_t* __restri
     if (j < FS_J) {                                          // posed joints (+ transl), then into the root frame
         float pj[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) pj[r] = Wd[j][r * 4 + 3] + sT[r];
+        for (int r = 0; r < 3; ++r) pj[r] = (float)(Wd[j][r * 4 + 3] + (double)sT[r]);
 #pragma unroll
         for (int r = 0; r < 3; ++r)
             joints_root_out[((int64_t)b * FS_J + j) * 3 + r] = sI[r * 4 + 0] * pj[0] + sI[r * 4 + 1] * pj[1] + sI[r * 4 + 2] * pj[2] + sI[r * 4 + 3];
@@ -187,6 +193,7 @@ __global__ __launch_bounds__(256) void frame_vertex_kernel(
     // pose blend shapes: slice s takes features s, s + 4, ... (lbs.py:152-251: pose_offsets = feat . posedirs)
     float po[3] = {0.f, 0.f, 0.f};
     if (live) {
+#pragma clang fp contract(fast)                                          // (the SMPL part rounds as csrc/smpl.hip does)
         const int64_t row = (int64_t)3 * V;
         for (int p = slice; p < FS_P; p += 4) {
             const float f = sf[p];
@@ -197,33 +204,34 @@ __global__ __launch_bounds__(256) void frame_vertex_kernel(
     sPo[slice][lane][0] = po[0]; sPo[slice][lane][1] = po[1]; sPo[slice][lane][2] = po[2];
     __syncthreads();
     if (slice != 0 || !live) return;
-    float vs[3], so[3], vp[3];
+    float so[3], T[16], x[3], ws = 0.f;
+    {
+#pragma clang fp contract(fast)
+        float vs[3], vp[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        po[c] = (sPo[0][lane][c] + sPo[1][lane][c]) + (sPo[2][lane][c] + sPo[3][lane][c]);
-        float s = 0.f;
-        for (int l = 0; l < FS_NB; ++l) s += sB[l] * shapedirs[((int64_t)v * 3 + c) * FS_NB + l];
-        so[c] = s;
-        vs[c] = v_template[v * 3 + c] + s;
-        vp[c] = vs[c] + po[c];
-        shape_off[((int64_t)b * V + v) * 3 + c] = s;
-        pose_off[((int64_t)b * V + v) * 3 + c] = po[c];
-    }
-    float T[16];
+        for (int c = 0; c < 3; ++c) {
+            po[c] = (sPo[0][lane][c] + sPo[1][lane][c]) + (sPo[2][lane][c] + sPo[3][lane][c]);
+            float s = 0.f;
+            for (int l = 0; l < FS_NB; ++l) s += sB[l] * shapedirs[((int64_t)v * 3 + c) * FS_NB + l];
+            so[c] = s;
+            vs[c] = v_template[v * 3 + c] + s;
+            vp[c] = vs[c] + po[c];
+            shape_off[((int64_t)b * V + v) * 3 + c] = s;
+            pose_off[((int64_t)b * V + v) * 3 + c] = po[c];
+        }
 #pragma unroll
-    for (int e = 0; e < 12; ++e) T[e] = 0.f;
-    float ws = 0.f;
-    for (int j = 0; j < FS_J; ++j) {
-        const float w = lbs_weights[(int64_t)v * FS_J + j];
-        ws += w;
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int j = 0; j < FS_J; ++j) {
+            const float w = lbs_weights[(int64_t)v * FS_J + j];
+            ws += w;
 #pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] += w * sA[j][e];
-    }
-    float x[3];
+            for (int e = 0; e < 12; ++e) T[e] += w * sA[j][e];
+        }
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        x[r] = (T[r * 4 + 0] * vp[0] + T[r * 4 + 1] * vp[1] + T[r * 4 + 2] * vp[2] + T[r * 4 + 3]) + sT[r];
-        T[r * 4 + 3] += sT[r];
+        for (int r = 0; r < 3; ++r) {
+            x[r] = (T[r * 4 + 0] * vp[0] + T[r * 4 + 1] * vp[1] + T[r * 4 + 2] * vp[2] + T[r * 4 + 3]) + sT[r];
+            T[r * 4 + 3] += sT[r];
+        }
     }
     T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = ws;          // the reference's T row 3 is sum_j w_j [0,0,0,1]
     // into the root frame (models/anim_nerf.py:138-144): verts, and T as the full 4x4 product torch computes

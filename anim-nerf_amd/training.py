@@ -212,8 +212,19 @@ class GradientReducer:
         self._probe()                                         # initialised after the Trainer was built
         self.buckets = [list(b) for b in buckets if len(b)]
         self.flat, self.slot = [], {}                         # slot[p] = (bucket index, p's view into the bucket's buffer)
+        # the buckets lie back to back in ONE buffer (`whole`; each bucket's start 16-byte aligned): the graphed step reduces all
+        # of it with one collective, the eager step's hooks reduce the buckets — views of it — one by one as they complete
+        same = len({(b[0].dtype, b[0].device) for b in self.buckets}) <= 1
+        sizes = [(sum(p.numel() for p in b) + 3) // 4 * 4 for b in self.buckets]
+        self.whole = torch.zeros(sum(sizes), dtype=self.buckets[0][0].dtype, device=self.buckets[0][0].device) if (self.buckets and same) else None
+        start = 0
         for bi, b in enumerate(self.buckets):
-            flat = torch.zeros(sum(p.numel() for p in b), dtype=b[0].dtype, device=b[0].device)
+            n_b = sum(p.numel() for p in b)
+            # (.data: the bucket shares the storage, NOT the version counter — the hooks below tell a write to THIS bucket by its
+            # counter, and views of one tensor share theirs)
+            flat = (self.whole[start:start + n_b].data if self.whole is not None
+                    else torch.zeros(n_b, dtype=b[0].dtype, device=b[0].device))
+            start += sizes[bi]
             o = 0
             for p in b:
                 self.slot[p] = (bi, flat[o:o + p.numel()].view_as(p))
@@ -293,13 +304,17 @@ class GradientReducer:
     deferred = False
 
     def reduce_flat(self):
-        """All-reduce + average the flat buffers now (the deferred mode's counterpart of the hooks + finish())."""
+        """All-reduce + average the flat buffers now (the deferred mode's counterpart of the hooks + finish()): ONE collective
+        over the whole buffer — on xGMI a 2.4 MB ring all-reduce is latency-bound, so one of 4.8 MB costs about what each of two
+        did — averaged by the collective itself on RCCL (ReduceOp.AVG: no division launch); gloo sums, then one division."""
         self._probe()
         if not self.active:
             return 0
-        for flat in self.flat:
-            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM)
-            flat.div_(self.world)
+        avg = self.dist.get_backend() == "nccl" and self._world_arg is None
+        for flat in ([self.whole] if self.whole is not None else self.flat):
+            self.dist.all_reduce(flat, op=self.dist.ReduceOp.AVG if avg else self.dist.ReduceOp.SUM)
+            if not avg:
+                flat.div_(self.world)
         return sum(f.numel() for f in self.flat)
 
     def reduce_flat_async(self, bi):
@@ -710,12 +725,17 @@ class Trainer:
         split = sig[0][1]
         graph = torch.cuda.CUDAGraph()
         self.reducer.deferred = split
-        # More than one rank and two gradient buckets (the networks train): the step is captured as TWO graphs, cut where the
-        # fine network's flat gradient is complete (ExplicitTrainStep.run's `at_split`): a replayed step issues the all-reduce
-        # of that bucket while the second graph — the coarse pass's backward, the pose chain — replays, instead of both
-        # collectives behind the whole backward pass.  The second capture shares the first one's memory pool (the step's
-        # tensors live across the cut) and the two are always replayed in this order.
-        two = (split and self.explicit is not None and len(self.reducer.flat) == 2 and not os.environ.get("ANR_GRAPH_NO_SPLIT")
+        # More than one rank: ONE graph (forward + backward into the flat gradient buffer), then ONE all-reduce of the whole
+        # buffer and Adam.  ANR_GRAPH_SPLIT=1 (opt-in, measured and not the default): the step captured as TWO graphs, cut where
+        # the fine network's flat gradient is complete (ExplicitTrainStep.run's `at_split`), so that a replayed step issues the
+        # all-reduce of that bucket while the second graph — the coarse pass's backward, the pose chain — replays.  A capture
+        # can only end with every branch joined, so the cut makes the fine pass's weight gradients and the whole normals branch
+        # finish before the coarse backward starts: +83 us on the 1.34 ms step of the reference's per-rank batch on one GPU
+        # (gpurun_out/r05/step_timings.txt), more than one 2.4 MB all-reduce over xGMI costs.  (An event-record NODE in the one
+        # graph would let a side stream start the collective mid-replay without a cut: torch refuses external events on ROCm
+        # — tools/exp/graph_external_event.py.)  The second capture shares the first one's memory pool and the two are always
+        # replayed in this order.
+        two = (split and self.explicit is not None and len(self.reducer.flat) == 2 and bool(os.environ.get("ANR_GRAPH_SPLIT"))
                and self.explicit.supported(st["rays"], st["bmp"], st["frame_idx"], st["fg"], st["bg"]) and not self.explicit.frozen_networks())
         second = torch.cuda.CUDAGraph() if two else None
         cut = {"done": False}

@@ -140,6 +140,10 @@ class VolumeRenderer(nn.Module):
         z = z + torch.randn_like(z) * self.depth_std
         return torch.min(torch.max(z, rays[..., 6:7]), rays[..., 7:8])
 
+    # a dict: forward() appends its coarse and sorted depths (lists over calls / chunks) — the importance sampler is discontinuous
+    # (models/volume_rendering.py:92-93), so a gradient check hands the oracle the samples of the very pass it differentiates
+    record = None
+
     # -- inference, deterministic sampling: the lean schedule
     fuse_coarse_pass = True          # composite + importance sampling + merge of the coarse pass in one launch
 
@@ -216,6 +220,9 @@ class VolumeRenderer(nn.Module):
                 z_all = torch.sort(torch.cat(parts, -1), -1).values.contiguous()
             else:
                 z_all = self.sample_fine_sorted(z_coarse, w.detach(), perturb, lean_state)
+            if self.record is not None:                         # (a checker's hook: the sampling decisions of THIS forward pass)
+                self.record.setdefault("z_coarse", []).append(z_coarse.detach())
+                self.record.setdefault("z_sorted", []).append(z_all.detach())
             _, rgbs_f, depths_f, alphas_f = self._shade(model, rays, z_all, False, perturb, False, lean_state, **kwargs)
             if self.share_fine:
                 output = {"rgbs": rgbs_f, "alphas": alphas_f, "depths": depths_f}

@@ -554,7 +554,7 @@ def train_bench(args, ctx, mode, steps, warmup, dense=False, scaling="weak", fra
                                     "over ranks of per-rank means" if strong else "frames_per_gpu frames on every rank: the global batch grows with N"),
                    "workload": "BASELINE configs[3] shape: train step, %d frames x 32x32 rays per GPU, 64 coarse + 32 fine, "
                                "perturb=1, rgb + alpha + fg/bg + normals losses (reference defaults), pose refinement on (optim_body_params), "
-                               "%s + Adam" % (F, "gradient all-reduce (2 x 2.4 MB flat buffers, after the replayed backward)" if graphed
+                               "%s + Adam" % (F, "ONE gradient all-reduce (4.8 MB flat buffer, averaged by the collective) after the replayed backward" if graphed
                                               else "bucketed gradient all-reduce (2 x 2.4 MB, overlapped with backward)")
                                + ("; the `_refine` stage: both networks FROZEN (pretrained_model_requires_grad False), only the pose "
                                   "rows train — no weight-gradient launch, sign bits instead of saved activations" if refine else ""),

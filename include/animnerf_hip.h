@@ -62,7 +62,7 @@ extern "C" {
  * split-K slices — half the workgroups and half the partial products.  A lone call is ~20 % slower that way; next to the
  * backward chain of a training step it leaves the chain's launches room to run. */
 #define ANR_MLP_FLAG_BACKGROUND 0x4000
-/* The `_refine` stage of the shipped configs (configs/people_snapshot/*_refine.yaml: pretrained_model_requires_grad False,
+/* The `_refine` stage of the shipped configs (configs/people_snapshot, the four <subject>_refine.yaml files: pretrained_model_requires_grad False,
  * train.py:433-437): the networks are loaded and FROZEN and only the poses train, so nothing ever reads the saved
  * activations or most of the activation gradients (they are the weight-gradient GEMMs' operands).
  * anr_mlp_forward_save[_indexed]: keep only the ReLU sign bits (304 B per row instead of 5.2 KB; the data area of `act` is

@@ -26,7 +26,7 @@ def outside(a, b, rtol=RTOL, atol=1e-5):
     return ((a - b).abs() > atol + rtol * b.abs()).any(-1)[0]
 
 
-def render_stages(model, vr, rays_w, pose, templ):
+def render_stages(model, vr, rays_w, pose, templ, frame_setup=False):
     """One frame (bs = 1) through the HIP path stage by stage: the rendered tensors plus the sampling decisions behind
     them (coarse depths, sorted depths, validity bits).  Everything on the model's device."""
     import anim_nerf_amd as ana
@@ -34,9 +34,12 @@ def render_stages(model, vr, rays_w, pose, templ):
     warp = bool(model.use_unpose)
     Kc, Kf = vr.n_coarse, vr.n_fine
     with torch.no_grad():
-        model.set_body_model({k: v.to(dev) for k, v in pose.items()}, {k: v.to(dev) for k, v in templ.items()})
-        rays_b = model.convert_to_body_model_space(rays_w.to(dev))
-        model.clac_ober2cano_transform()
+        if frame_setup:                  # the set-up of the training steps (AnimNeRF.frame_setup: two launches, the same values to rounding)
+            rays_b = model.frame_setup({k: v.to(dev) for k, v in pose.items()}, {k: v.to(dev) for k, v in templ.items()}, rays_w.to(dev))
+        else:
+            model.set_body_model({k: v.to(dev) for k, v in pose.items()}, {k: v.to(dev) for k, v in templ.items()})
+            rays_b = model.convert_to_body_model_space(rays_w.to(dev))
+            model.clac_ober2cano_transform()
         zc = vr.sample_coarse(rays_b)
         w_c, rgb_c, dep_c, acc_c = vr._shade(model, rays_b, zc, True, 0.0, True)
         out = dict(rgbs=rgb_c, alphas=acc_c, depths=dep_c)

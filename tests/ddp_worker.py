@@ -66,8 +66,8 @@ def main():
     both = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
     assert all(torch.equal(both[0], b) for b in both[1:]), "parameters differ between ranks after the step"
-    # The graphed step with more than one rank: forward + backward replayed from TWO HIP graphs, the all-reduce of the fine
-    # network's flat buffer issued between them (it runs while the second replays), the other bucket's and Adam after.  Same trajectory as the eager step (overlapped bucket all-reduce) on a copy of the model.
+    # The graphed step with more than one rank: forward + backward replayed from a HIP graph, ONE all-reduce of the whole flat
+    # gradient buffer and Adam after each replay (ANR_GRAPH_SPLIT=1: two graphs, the fine bucket's all-reduce between them).  Same trajectory as the eager step (overlapped bucket all-reduce) on a copy of the model.
     import copy
     # (normals term on: its weight gradients join the flat buffers at the cut between the two graphs; both copies draw the same
     # numbers — the explicit step's stream is a function of the seed at construction and the step count)
@@ -83,8 +83,10 @@ def main():
         lg, _ = tg.step_graphed(rays, tgt, alp, pose, templ, fg, bg, perturb=0.0)
         assert abs(float(le) - float(lg)) <= 2e-3 * abs(float(le)), (rank, it, float(le), float(lg))
     assert tg._graph is not None and tg._graph_split and te._graph is None
-    # the replayed backward is cut in two graphs at the fine network's completed bucket: its all-reduce overlaps the second
-    assert tg._graph_second is not None
+    # ANR_GRAPH_SPLIT=1: the replayed backward cut in two graphs at the fine network's completed bucket (its all-reduce overlaps
+    # the second); default: one graph, one all-reduce of the whole gradient buffer
+    assert (tg._graph_second is not None) == bool(os.environ.get("ANR_GRAPH_SPLIT"))
+    assert tg.reducer.whole is not None and tg.reducer.whole.numel() >= sum(f.numel() for f in tg.reducer.flat)
     assert te.explicit is not None and tg.explicit is not None     # (both ran the explicit step: fused_step.py)
     for (k, a), (_, b) in zip(me.named_parameters(), mg.named_parameters()):
         if a.requires_grad:

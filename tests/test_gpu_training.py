@@ -33,15 +33,36 @@ def _hip_fine_samples(m, vr, rays, pose, dev):
     oracle is handed when a gradient check must differentiate the same function (the sampler has no gradient and is
     discontinuous: models/volume_rendering.py:92-93,200)."""
     from anim_nerf_amd import ops
-    with torch.no_grad():
-        m.set_body_model({k: v.detach().to(dev) for k, v in pose.items()}, _templ(dev))
+    with torch.no_grad():                 # (the set-up of the training steps: AnimNeRF.frame_setup, the same kernels and bits)
         bs = rays.shape[0]
-        rays_b = m.convert_to_body_model_space(rays.to(dev).view(bs, -1, 8))
-        m.clac_ober2cano_transform()
+        rays_b = m.frame_setup({k: v.detach().to(dev) for k, v in pose.items()}, _templ(dev), rays.to(dev).view(bs, -1, 8))
         zc = vr.sample_coarse(rays_b)
         w_c = vr._shade(m, rays_b, zc, True, 0.0, True)[0]
         _, zf = ops.sample_fine_merge(zc.view(-1, vr.n_coarse), w_c, vr._table(dev, "u", vr.n_fine), want_fine=True)
     return zf.view(bs, -1, vr.n_fine).cpu().double()
+
+
+def _oracle_render_on_hip_points(m, vr, rays, pose, Pc, Pf, z_fine, dev):
+    """orc.render_rays in the dtype of Pc / Pf on the HIP path's own frame state: its rays in the body frame, its CANONICAL
+    POINTS and validity bits at its coarse and sorted depths — so that the oracle differentiates the same function of the
+    weights as the kernels do.  (Left to warp the samples itself in fp64, the oracle sits 1e-3..2e-3 of the whole weight
+    gradient away from ANY fp32 evaluation, the reference's included: 1e-6 of rounding in a canonical point is 5e-4 rad of
+    phase in the 2^9 band of the encoding — test_training_step_matches_reference_loss_fixture measures both.)"""
+    bs = rays.shape[0]
+    dt = next(iter(Pc.values())).dtype
+    with torch.no_grad():
+        rays_b = m.frame_setup({k: v.detach().to(dev) for k, v in pose.items()}, _templ(dev), rays.to(dev).view(bs, -1, 8))
+        zc = vr.sample_coarse(rays_b)
+        zs = torch.sort(torch.cat([zc, z_fine.float().to(dev)], -1), -1).values
+        pts_c = m.warped_points(rays=rays_b, z=zc).view(bs, -1, 4).cpu().to(dt)
+        pts_f = m.warped_points(rays=rays_b, z=zs).view(bs, -1, 4).cpu().to(dt)
+
+    def field(xyz, use_fine):
+        pts = pts_f if use_fine else pts_c
+        assert xyz.shape[:2] == pts.shape[:2]
+        rgb, sig = orc.mlp_forward(Pf if use_fine else Pc, pts[..., :3])
+        return rgb, torch.where(pts[..., 3:] < 1, torch.full_like(sig, -1e5), sig)
+    return orc.render_rays(field, rays_b.cpu().to(dt), vr.n_coarse, vr.n_fine, True, z_fine)
 
 
 def test_composite_backward_matches_autograd(dev):
@@ -225,8 +246,7 @@ def test_training_loss_gradients_match_oracle(dev, smpl_table):
     Pc = {k: v.double().requires_grad_(True) for k, v in net_params(m.nerf).items()}
     Pf = {k: v.double().requires_grad_(True) for k, v in net_params(m.nerf_fine).items()}
     z_fine = _hip_fine_samples(m, vr, rays, pose, dev)
-    out = orc.render_frame(tbl, Pc, Pf, rays.view(2, 64, 8).double(), _fp64(pose), _fp64(templ), n_coarse=16, n_fine=8,
-                           use_unpose=True, chunk=40, knn_chunk=512, z_fine=z_fine)
+    out = _oracle_render_on_hip_points(m, vr, rays.view(2, 64, 8), pose, Pc, Pf, z_fine, dev)
     # the reference's compute_loss as the oracle restates it (pinned to train.py:228-322 by tests/golden/train_loss.npz)
     ref, _ = orc.training_loss(Pc, Pf, out, tgt_rgb.view(2, 64, 3).double(), tgt_a.view(2, 64, 1).double(), n_samples=16,
                                fg_points=fg.double(), bg_points=bg.double(), draws=None)
@@ -402,8 +422,10 @@ def test_pose_refinement_gradients_match_fp64_oracle(dev, smpl_table, n_fine, lo
               "depth": 3 + torch.rand(2, 64, 1, generator=gen)}[loss_on]
     key = {"rgb": "rgbs", "alpha": "alphas", "depth": "depths"}[loss_on] + ("_fine" if n_fine else "")
 
+    keep = torch.ones(2, 64, 1)                   # rays the loss looks at (set below: all but those at a discontinuity)
+
     def loss_of(res):
-        d = res[key].reshape(target.shape) - target.to(res[key])
+        d = (res[key].reshape(target.shape) - target.to(res[key])) * keep.to(res[key])
         return d.abs().mean() if loss_on == "alpha" else (d ** 2).mean()
 
     def rel(a, b):
@@ -413,16 +435,53 @@ def test_pose_refinement_gradients_match_fp64_oracle(dev, smpl_table, n_fine, lo
     P = [_fp64(net_params(n)) for n in (m.nerf, m.nerf_fine)]
 
     # ---- (1) leaves at the chain / renderer interface
-    with torch.no_grad():
-        m.set_body_model({k: v.to(dev) for k, v in pose.items()}, _templ(dev))
-        rays_b = m.convert_to_body_model_space(rays.view(2, 64, 8).to(dev))
-        m.clac_ober2cano_transform()
+    with torch.no_grad():                 # (the set-up system_forward runs below: the same kernels, hence the same interface values)
+        rays_b = m.frame_setup({k: v.to(dev) for k, v in pose.items()}, _templ(dev), rays.view(2, 64, 8).to(dev))
+        # The warp is discontinuous (validity threshold, neighbour ties: models/anim_nerf.py:165-183) and a gradient cannot be
+        # compared across a sample that sits on the other side in fp32 than in fp64: rays with such a sample — the oracle's
+        # validity bit or canonical point at the HIP path's own depths, vertices and transforms differs from the HIP path's —
+        # are left out of the loss on BOTH sides, in every part of this test (a handful at most: bounded below).
+        zc = vr.sample_coarse(rays_b)
+        z_all = [zc] + ([torch.sort(torch.cat([zc, z_fine.float().to(dev)], -1), -1).values] if n_fine else [])
+        odd = torch.zeros(2, 64, dtype=torch.bool)
+        for fine_pass, z_ in enumerate(z_all):
+            hip4 = m.warped_points(rays=rays_b, z=z_)
+            # ... and relu(sigma) has a kink at 0 (models/volume_rendering.py:131): a valid sample whose sigma changes sign between
+            # the fp32 kernel and fp64 on the same canonical point (or sits within rounding of 0) contributes on one side only
+            sig32 = (m.nerf_fine if fine_pass else m.nerf).eval_points(hip4, "f32")[:, 3].view(2, 64, -1).cpu().double()
+            sig64 = orc.mlp_forward(P[fine_pass], hip4[:, :3].cpu().double()[None])[1].view(2, 64, -1)
+            at_kink = ((sig32 > 0) != (sig64 > 0)) | (sig64.abs() < 1e-5 * sig64.abs().max())
+            # ... and so has every hidden unit: a trunk pre-activation within fp32 rounding of 0 leaves the VALUE continuous and
+            # switches that unit's share of d sigma / d x on or off (what _near_relu_kink names for the normals term: found here
+            # on one ray of one seed — forward identical sample by sample, neighbour ids and blend weights included, gradient
+            # of that ray 7.5e-3 of the whole tensor's norm off: tools/exp/diag_frame_setup2.py)
+            at_kink |= _near_relu_kink(P[fine_pass], hip4[:, :3].cpu().double()[None], tol=1e-6)[0].view(2, 64, -1)
+            odd |= (at_kink & (hip4[:, 3].view(2, 64, -1).cpu() > 0)).any(-1)
+            hip = hip4.view(2, 64, -1, 4).cpu().double()
+            rbd, zd = rays_b.cpu().double(), z_.cpu().double()
+            xyz = (rbd[..., None, :3] + zd[..., None] * rbd[..., None, 3:6]).reshape(2, -1, 3)
+            xc, valid_o, dbg = orc.warp_to_canonical(xyz, m.verts.cpu().double(), tbl64["lbs_weights"], m.ober2cano_transform.cpu().double(),
+                                                     0.2, chunk=512)
+            valid_o = valid_o.view(2, 64, -1)
+            moved = ((hip[..., :3] - xc.view(2, 64, -1, 3)).abs().max(-1).values > 1e-5) & (valid_o > 0)
+            # (a blend-weight confidence within rounding of its 0.9 threshold, or two neighbours tied, barely moves the canonical
+            # point — neighbouring vertices carry nearly the same transform — but switches a vertex's share of the gradient on or off)
+            from accounting import neighbour_discontinuity
+            tie = neighbour_discontinuity(tbl64["lbs_weights"], dbg["dist"], dbg["idx"]).view(2, 64, -1) & (valid_o > 0)
+            odd |= ((hip[..., 3] != valid_o) | moved | tie).any(-1)
+    print(f"\npose gradients [{loss_on}, {n_fine} fine]: {int(odd.sum())} of 128 rays left out (a sample at a validity / neighbour / ReLU discontinuity)")
+    assert int(odd.sum()) <= 16, int(odd.sum())
+    keep.copy_((~odd).float()[..., None])
     rays_b = rays_b.detach().clone().requires_grad_(True)
     m.ober2cano_transform = m.ober2cano_transform.detach().clone().requires_grad_(True)
     loss_leaf = loss_of(vr(m, rays_b, perturb=0.0))
     loss_leaf.backward()
     st = orc.frame_state(tbl64, _fp64(pose), templ64)
     st, _ = orc.to_root_frame(st, rays.view(2, 64, 8).double())
+    # the renderer's inputs at this interface are the frame state of the HIP path: its rays, its ober2cano AND its posed
+    # vertices (what the neighbour search and the validity threshold look at — the oracle's own fp64 vertices sit 1e-7 away,
+    # which is enough to flip a threshold or a tie on one sample of some seeds; what is under test here is the renderer's gradient)
+    st["verts"] = m.verts.detach().cpu().double()
     st["ober2cano"] = m.ober2cano_transform.detach().cpu().double().requires_grad_(True)
     rb = rays_b.detach().cpu().double().requires_grad_(True)
     field = lambda xyz, fine: orc.field_query(P[1 if fine else 0], xyz, st, tbl64["lbs_weights"], True, 0.2, chunk=512)
@@ -608,7 +667,7 @@ def test_training_step_matches_reference_loss_fixture(dev, smpl_table):
     for b in range(F_):
         ref_b = {k: g["results/" + k].reshape(F_, H * W, -1)[b:b + 1] for k in ("rgbs", "alphas", "depths", "rgbs_fine", "alphas_fine", "depths_fine")}
         with torch.no_grad():
-            stages = render_stages(m, vr, rays[b:b + 1].view(1, -1, 8), {k: v[b:b + 1] for k, v in pose.items()}, templ)
+            stages = render_stages(m, vr, rays[b:b + 1].view(1, -1, 8), {k: v[b:b + 1] for k, v in pose.items()}, templ, frame_setup=True)
         for k, v in stages["out"].items():
             # the training forward (kernels that save activations, compacted rows) renders what the inference kernels render;
             # the accounting below is done on the TRAINING forward's values, with the sampling decisions of the stage-by-stage pass
@@ -662,9 +721,7 @@ def test_training_step_matches_reference_loss_fixture(dev, smpl_table):
     own_warp = rel_error()
     # (b) the HIP path's canonical points (and validity bits) injected: the same function of the weights on both sides
     with torch.no_grad():
-        m.set_body_model({k: v.to(dev) for k, v in pose.items()}, _templ(dev))
-        rays_b = m.convert_to_body_model_space(rays.view(F_, H * W, 8).to(dev))
-        m.clac_ober2cano_transform()
+        rays_b = m.frame_setup({k: v.to(dev) for k, v in pose.items()}, _templ(dev), rays.view(F_, H * W, 8).to(dev))
         zc = vr.sample_coarse(rays_b)
         zs = torch.sort(torch.cat([zc, z_fine.float().to(dev)], -1), -1).values
         pts_c = m.warped_points(rays=rays_b, z=zc).view(F_, -1, 4).cpu().double()
@@ -972,11 +1029,13 @@ def test_two_process_training_step_averages_gradients(dev):
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29533", os.path.join(here, "ddp_worker.py")], env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:]
-    assert "rank 0: ok" in r.stdout and "rank 1: ok" in r.stdout
+    for split in ("", "1"):               # the default (one graph, one collective) and the opt-in two-graph cut
+        env["ANR_GRAPH_SPLIT"] = split
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                            "127.0.0.1", "--master-port", "29533", os.path.join(here, "ddp_worker.py")], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:]
+        assert "rank 0: ok" in r.stdout and "rank 1: ok" in r.stdout
 
 
 def test_bench_self_launch_two_ranks_on_one_device(dev):

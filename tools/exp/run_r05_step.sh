@@ -1,10 +1,12 @@
-# round 5 scratch runner (GPU box): the GPU suite, then the training step's timings in the configurations under study
+# round 5 scratch runner (GPU box): the replayed step under different branch structures
 mkdir -p gpurun_out/r05
-python tools/exp/graph_external_event.py 2>&1 | tail -8
-python -m pytest tests -m gpu -q -x 2>&1 | tail -25 | tee gpurun_out/r05/gpu_tests.txt
-t() { python bench.py --workload cfg4 --no-extras --steps 40 --warmup 5 "$@" 2>/dev/null | grep '^{' | python -c "
-import json,sys;d=json.loads(sys.stdin.read());print(round(d['ms_per_step'],3),'ms', d['config']['kernel_launches_timed_per_step'],'launches, peak', d.get('peak_alloc_GiB'),'GiB', {k:v for k,v in d['kernel_time_share'].items()})"; }
-echo "cfg4 f16: $(t --frames-per-gpu 16)"
-echo "cfg4 f2: $(t --frames-per-gpu 2)"
-echo "cfg4 refine f16: $(t --frames-per-gpu 16 --refine)"
-echo "cfg4 refine f2: $(t --frames-per-gpu 2 --refine)"
+t() { python bench.py --workload cfg4 --no-extras --steps 60 --warmup 5 "$@" 2>/dev/null | grep '^{' | python -c "
+import json,sys;d=json.loads(sys.stdin.read());print(round(d['ms_per_step'],3),'ms')"; }
+for f in 2 16; do
+echo "f$f default: $(t --frames-per-gpu $f)  again: $(t --frames-per-gpu $f)"
+echo "f$f wgrad fork first: $(ANR_STEP_WGRAD_FIRST=1 t --frames-per-gpu $f)"
+echo "f$f one side stream: $(ANR_STEP_ONE_SIDE=1 t --frames-per-gpu $f)"
+echo "f$f one side + wgrad first: $(ANR_STEP_ONE_SIDE=1 ANR_STEP_WGRAD_FIRST=1 t --frames-per-gpu $f)"
+echo "f$f no branches: $(ANR_STEP_BRANCHES=0 t --frames-per-gpu $f)"
+done
+python -m pytest tests/test_gpu_training.py -q 2>&1 | tail -8
