@@ -334,12 +334,19 @@ __global__ __launch_bounds__(256) void train_loss_kernel(anr_loss_args a, float*
             partials[LOSS_BLOCKS * LOSS_TERMS + 2 * blockIdx.x + 1] = fminf(fminf(sh_lo[0], sh_lo[1]), fminf(sh_lo[2], sh_lo[3]));
         }
     }
-    // the last workgroup to finish adds the partial sums up in workgroup order (same bits on every run) and resets the ticket
-    __threadfence();
-    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == LOSS_BLOCKS - 1;
+    // the last workgroup to finish adds the partial sums up (a fixed tree: same bits on every run) and resets the ticket.
+    // Thread 0 wrote every partial of this workgroup: it alone releases them (agent scope, then the drained vmcnt hipcc may drop:
+    // MI355X_MICROARCH.md) before it takes its ticket — 256 threads x 64 workgroups each issuing __threadfence() were a third of
+    // this kernel's 33 us; the last workgroup acquires once, through one lane.
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = atomicAdd(ticket, 1u) == LOSS_BLOCKS - 1;
+    }
     __syncthreads();
     if (!last) return;
-    __threadfence();
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
     // (lane b of a wavefront takes workgroup b's partial — LOSS_BLOCKS = 64 — and the lanes meet in a fixed butterfly: the same
     // bits on every run; one thread per term walking 64 partials one load behind the other took 40 of this kernel's 46 us)
     static_assert(LOSS_BLOCKS == 64, "one lane per workgroup's partial");

@@ -213,25 +213,18 @@ class ExplicitTrainStep:
         for flat in ([tr.reducer.whole] if tr.reducer.whole is not None else tr.reducer.flat):
             ops.zero_fill(flat)
 
-        # ---- random numbers of the step: one launch, counter on the device
         want_normals = hp.lambda_normals != 0
         jitter = perturb > 0
         noisy = vr.noise_std > 0.0 and perturb > 0
         if not m._same_template(template_params):
             m._set_template(template_params)
-        draws = ops.train_draws(self.draw_state, n_t=bs * R * Kc if jitter else 0, t_scale=float(perturb),
-                                n_nc=bs * R * Kc if noisy else 0, n_u=bs * R * Kf if jitter else 0, n_nf=bs * R * K if noisy else 0,
-                                noise_scale=float(vr.noise_std), verts_template=m.verts_template if want_normals else None,
-                                point_scale=hp.dis_threshold * 0.5, neighbour_scale=hp.epsilon)
-        self.last_draws = draws
 
         # ---- normals regulariser (models/nerf.py:177-190, train.py:298-309): both networks on the same quads (forward-mode
         # tangents, autograd.QuadSigmaFunction).  It needs the draws and the weights and NOTHING of the render passes — its loss
         # term's gradient is a function of its own outputs (the total's upstream gradient is 1) — and only the loss values and
         # Adam need it: the whole branch, forward, loss gradient, backward and weight gradients (into buffers of their own), runs
         # on a SECOND STREAM next to the frame set-up and the render passes' forward, whose searches and small launches leave
-        # most of the GPU idle (a parallel branch of the step's HIP graph).  The forward weight packs are made on the step's
-        # stream BEFORE the fork (both branches read them); the branch packs its own backward weights.
+        # most of the GPU idle (a parallel branch of the step's HIP graph).
         main = torch.cuda.current_stream(dev)
         if self.parallel:
             if self._streams is None:
@@ -244,15 +237,22 @@ class ExplicitTrainStep:
         keep = []
         tan, tan_grads = [], []
         one = self._one()
-        # The four weight packs of the step, up front: the forward ones on the step's stream (both branches read them), the
-        # backward ones on the weight gradients' stream, which has nothing to do until the backward pass — two launches off the
-        # chain between the losses and the first activation gradients.  (Forward first: a backward pack marks the generation.)
+        # What the frame set-up does NOT need runs next to it, on the weight gradients' stream (idle until the backward pass): the
+        # step's random numbers (one launch + the counter's; the coarse depths are their first consumer) and the four weight
+        # packs (the first network pass is theirs) — six launches, ~45 us, off the front of the step's chain (round 5).
+        # (Forward packs first: a backward pack marks the generation.)
         nets = []
-        for net in (m.nerf, m.nerf_fine):
-            params = [dict(net.named_parameters())[k] for k in PARAM_KEYS]
-            nets.append((net, params, _cached_pack(params, mode_id, False, frozen=frozen)))
         self._wgrad_stream.wait_stream(main)
         with torch.cuda.stream(self._wgrad_stream):
+            draws = ops.train_draws(self.draw_state, n_t=bs * R * Kc if jitter else 0, t_scale=float(perturb),
+                                    n_nc=bs * R * Kc if noisy else 0, n_u=bs * R * Kf if jitter else 0, n_nf=bs * R * K if noisy else 0,
+                                    noise_scale=float(vr.noise_std), verts_template=m.verts_template if want_normals else None,
+                                    point_scale=hp.dis_threshold * 0.5, neighbour_scale=hp.epsilon)
+            for net in (m.nerf, m.nerf_fine):
+                params = [dict(net.named_parameters())[k] for k in PARAM_KEYS]
+                nets.append((net, params, _cached_pack(params, mode_id, False, frozen=frozen)))
+            front_ready = torch.cuda.Event()                             # the draws and the forward packs
+            front_ready.record(self._wgrad_stream)
             packs_b = []
             for net, params, _ in nets:
                 if not frozen:
@@ -260,6 +260,7 @@ class ExplicitTrainStep:
                 packs_b.append(_cached_pack(params, mode_id, True, frozen=frozen))
             packs_b_ready = torch.cuda.Event()
             packs_b_ready.record(self._wgrad_stream)
+        self.last_draws = draws
         if want_normals and frozen:
             # frozen networks: the regulariser has no parameter to reach (its points are template vertices + noise, its
             # function the network) — only its VALUE enters the step's loss (train.py:288-309 computes it regardless), so the
@@ -267,6 +268,7 @@ class ExplicitTrainStep:
             pair = draws["pair"]
             n_pad = -(-pair.shape[0] // 16) * 16
             self._side.wait_stream(main)
+            self._side.wait_event(front_ready)
             box = {}
 
             def normals_forward():
@@ -290,6 +292,7 @@ class ExplicitTrainStep:
             consts_n = {"lambda_normals": hp.lambda_normals, "nv": m.verts_template.shape[1], "normal_sets": m.verts_template.shape[0],
                         "quad_rows": n_pad, "delta": 0.02}
             self._side.wait_stream(main)
+            self._side.wait_event(front_ready)
             box = {}
 
             # The branch is ISSUED in two pieces, each right after the step's stream has issued a long launch (the two neighbour
@@ -355,6 +358,7 @@ class ExplicitTrainStep:
         lbs, thr = bm.lbs_weights, m.dis_threshold
 
         # ---- coarse pass
+        main.wait_event(front_ready)                                 # the jitter (and, further down, the forward weight packs)
         steps = vr._table(dev, "steps", Kc)
         zc = ops.sample_coarse(rays_b, steps, draws["t_rand"].view(bs * R, Kc) if jitter else None).view(bs, R, Kc)
         pts_c, nidx_c, nw_c = ops.warp_points(index, o2c, lbs, thr, rays=rays_b, z=zc, skip_far=True, neighbours=True)
