@@ -444,6 +444,22 @@ def grid_bench(args, ctx, mode, steps, warmup, dense=False):
             check["f32"] = {"voxels_within_1e-4": ((sig32[sel].cpu() - want).abs() <= 1e-4 * want.abs() + 1e-4 * scale).float().mean().item(),
                             "accounting": _account(lambda acc: acc.account_for_points(model, otbl, points, sig32[sel], use_fine=True, relu=True,
                                                                                       dis_threshold=model.dis_threshold, label="bench cfg5", quiet=True))}
+            if mode != "f32":
+                # the timed mode's LEVEL SET against the parity mode's, as what extract_mesh.py:159-165 makes of the two grids:
+                # vertex-to-surface distances both ways (tests/accounting.py; gated at >= 99.7 % within one voxel by
+                # tests/test_gpu_parity.py::test_timed_mode_mesh_within_one_voxel_of_the_parity_mode_mesh)
+                def _mesh_gap(acc):
+                    va, ta = ana.mesh.marching_cubes((5.0 - sig.view(N, N, N)).contiguous(), 0.0)
+                    vb, tb = ana.mesh.marching_cubes((5.0 - sig32.view(N, N, N)).contiguous(), 0.0)
+                    out = {"occupancy_flips": int(((sig > 5.0) != (sig32 > 5.0)).sum()), "occupied_f32": int((sig32 > 5.0).sum())}
+                    for name, (p_, q_, t_) in ((mode + "_to_f32", (va, vb, tb)), ("f32_to_" + mode, (vb, va, ta))):
+                        dd = acc.vertex_to_surface_distance(p_, q_, t_, N, reach=2)
+                        out[name] = {"vertices": int(dd.numel()), "within_1_voxel": round(float((dd <= 1.0).float().mean()), 5),
+                                     "within_2_voxels": round(float((dd <= 2.0).float().mean()), 5), "mean_voxels": round(float(dd.mean()), 4)}
+                    return out
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import accounting as _acc
+                check["mesh_vs_f32_mesh"] = _mesh_gap(_acc)
             for net in (model.nerf, model.nerf_fine):
                 net.mlp_mode = mode
     return {

@@ -4,7 +4,8 @@
 # --pmc passes are separate from each other and carry no trace domain besides --kernel-trace.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$ROOT/gpurun_out/prof_r04
+R=${ANR_ROUND:-r05}
+OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for wl in cfg2 cfg3 cfg4; do
@@ -22,8 +23,8 @@ for wl in cfg2 cfg3; do
   python3 tools/hbm_table.py $OUT/${wl}_fetch $OUT/${wl}_write $OUT/${wl}_trace >> $OUT/hbm_${wl}.txt
   cat $OUT/hbm_${wl}.txt
 done
-# the files the judge reads, named as in profiles/r03/ and r04/
-DST=$ROOT/gpurun_out/profiles_r04
+# the files the judge reads, named as in profiles/r03/ .. r05/
+DST=$ROOT/gpurun_out/profiles_$R
 mkdir -p $DST
 for wl in cfg2 cfg3 cfg4; do
   cp $OUT/${wl}_trace/*/*kernel_stats.csv $DST/bench_${wl}_bf16_kernel_stats.csv
@@ -41,6 +42,8 @@ timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYC
 cd $ROOT
 python3 tools/pmc_summary.py $OUT/mlp_pmc mlp_kernel > $DST/mlp_pmc_head.txt
 python3 tools/bench_mlp.py 4194304 7 bf16,bf16_w4,f32 >> $DST/mlp_pmc_head.txt
+# round 5: the 8-wave x 32-point and the 4-wave x 64-point shapes A/B on THIS box, alternating (box spread exceeds the recorded deltas)
+{ echo "same-box A/B, alternating runs (tools/bench_mlp.py 4194304 7 <mode>):"; for i in 1 2 3; do python3 tools/bench_mlp.py 4194304 7 bf16,bf16_w4 2>/dev/null | tail -2; done; } > $DST/mlp_shape_ab.txt
 ls $DST
 # second half of round 3: the training step as one graph replay (idle time between its kernels), the small-batch warp search
 python3 tools/step_gaps.py $OUT/cfg4_trace > $DST/train_step_graph_gaps.txt
@@ -64,3 +67,9 @@ ls $DST
 # round 4, second half: the replayed step's parallel branches (which launches run next to which)
 python3 tools/exp/step_timeline.py $OUT/cfg4_trace > $DST/train_step_timeline.txt
 python3 tools/exp/step_timeline.py $OUT/cfg4_f2_trace > $DST/train_step_timeline_f2.txt
+
+# round 5: the frozen-network (_refine) step, the training kernels per row count, the replayed step at HEAD
+python3 bench.py --workload cfg4 --no-extras --steps 40 --warmup 5 --refine 2>/dev/null | grep '^{' > $DST/bench_cfg4_refine_bf16.json
+python3 bench.py --workload cfg4 --no-extras --steps 40 --warmup 5 --refine --frames-per-gpu 2 2>/dev/null | grep '^{' > $DST/bench_cfg4_refine_f2_bf16.json
+cp $ROOT/gpurun_out/r05/*.txt $DST/ 2>/dev/null
+ls $DST
