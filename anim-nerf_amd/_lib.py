@@ -21,6 +21,7 @@ ANR_MLP_FLAG_TANGENT = 0x800
 ANR_MLP_FLAG_ACCUMULATE = 0x1000
 ANR_MLP_FLAG_VIEW = 0x2000
 ANR_MLP_FLAG_BACKGROUND = 0x4000
+ANR_MLP_FLAG_NO_FILL = 0x10000
 ANR_MLP_FLAG_BITS_ONLY = ANR_MLP_FLAG_ENC_ONLY = 0x8000
 ANR_MAX_SAMPLES = 256
 
@@ -53,13 +54,13 @@ class AnrLossArgs(C.Structure):
                 + [(k, _L) for k in ("R", "prior_rows", "nv", "normal_sets", "quad_rows")]
                 + [("n_fg", C.c_int32), ("n_bg", C.c_int32)]
                 + [(k, _F) for k in ("k", "delta", "lambda_alphas", "lambda_foreground", "lambda_background", "lambda_normals")]
-                + [("s_stride", C.c_int32)])
+                + [("s_stride", C.c_int32), ("s_count", _P), ("s_count_fine", _P)])
 
 
 class AnrDrawPlan(C.Structure):
     _fields_ = ([(k, _P) for k in ("t_rand", "noise_c", "u_fine", "noise_f")] + [(k, _L) for k in ("n_t", "n_nc", "n_u", "n_nf")]
                 + [("t_scale", _F), ("noise_scale", _F), ("verts_template", _P), ("n_v3", _L), ("point_scale", _F), ("neighbour_scale", _F)]
-                + [(k, _P) for k in ("n0", "n1", "pair")])
+                + [(k, _P) for k in ("n0", "n1", "pair", "quads")])
 
 
 class AnrLossGrads(C.Structure):
@@ -75,7 +76,8 @@ SIGNATURES = {
     "anr_frame_backward": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
     "anr_frame_backward_ws_floats": (_L, [_I, _I]),
     "anr_frame_backward_adjoint": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
-    "anr_frame_backward_adjoint_values": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "anr_frame_backward_adjoint_values": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "anr_frame_backward_ws_zero_floats": (_L, [_I]),
     "anr_to_root_frame": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "anr_rays_to_body": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "anr_ober2cano": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _P]),
@@ -93,6 +95,8 @@ SIGNATURES = {
     "anr_points_from_rays": (_I, [_P, _I, _P, _I, _L, _P, _P]),
     "anr_mlp_pack_bytes": (_L, [_I]),
     "anr_mlp_pack": (_I, [C.POINTER(AnrMlpParams), _I, _P, _P]),
+    "anr_mlp_pack_pair": (_I, [C.POINTER(AnrMlpParams), C.POINTER(AnrMlpParams), _I, _P, _P, _P]),
+    "anr_mlp_bwd_pack_pair": (_I, [C.POINTER(AnrMlpParams), C.POINTER(AnrMlpParams), _I, _P, _P, _P]),
     "anr_mlp_forward": (_I, [_P, _I, _P, _L, _P, _P]),
     "anr_mlp_forward_rays": (_I, [_P, _I, _P, _I, _P, _I, _L, _P, _P]),
     "anr_mlp_forward_embedded": (_I, [_P, _I, _P, _L, _P, _P, _P]),
@@ -120,6 +124,8 @@ SIGNATURES = {
     "anr_grid_points": (_I, [_I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, _L, _L, _P, _P]),
     "anr_composite_masked": (_I, [_P, _P, _P, _I, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "anr_composite": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
+    "anr_composite_indexed": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
+    "anr_composite_backward_indexed": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "anr_composite_backward": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "anr_sample_fine_merge": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P]),
     "anr_sample_fine_merge_u8": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P]),
@@ -155,6 +161,10 @@ SIGNATURES = {
     "anr_zero_fill": (_I, [_P, _L, _P]),
     "anr_add_inplace": (_I, [_P, _P, _L, _P]),
     "anr_copy_segments": (_I, [_P, _P, _P, _I, _P]),
+    "anr_zero_segments": (_I, [_P, _P, _I, _P]),
+    "anr_add_segments": (_I, [_P, _P, _P, _I, _P]),
+    "anr_mlp_wgrad_sigma_floats": (_L, []),
+    "anr_warp_ws_zero_range": (_I, [_I, _L, C.POINTER(_L), C.POINTER(_L)]),
     "anr_frame_setup": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I]
                         + [_P] * 13 + [_P, _P]),
     "anr_knn_within": (_I, [_P, _P, _I, _I, _L, _F, _P, _P]),

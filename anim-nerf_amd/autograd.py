@@ -73,6 +73,25 @@ def _cached_pack(params, mode_id, backward, frozen=False):
     return hit[1]
 
 
+def _cached_pack_pair(params_a, params_b, mode_id, backward, frozen=False):
+    """_cached_pack of two networks; when both need a new pack, one launch makes both (ops.mlp_pack_pair)."""
+    import weakref
+    todo = []
+    for params in (params_a, params_b):
+        key = (mode_id, backward, tuple(id(p) for p in params))
+        ver = (tuple(p._version for p in params), "frozen" if frozen else weights_generation(params[0], backward))
+        hit = _PACKS.get(key)
+        todo.append((key, ver, hit is None or hit[0] != ver or any(r() is not p for r, p in zip(hit[2], params))))
+    if not (todo[0][2] and todo[1][2]) or any(dict(zip(PARAM_KEYS, ps))["dir_encoding.0.weight"].shape[1] > 256 for ps in (params_a, params_b)):
+        return _cached_pack(params_a, mode_id, backward, frozen), _cached_pack(params_b, mode_id, backward, frozen)
+    if len(_PACKS) > 64:
+        _PACKS.clear()
+    pa, pb = ops.mlp_pack_pair(dict(zip(PARAM_KEYS, params_a)), dict(zip(PARAM_KEYS, params_b)), mode_id, backward=backward)
+    for (key, ver, _), params, pack in zip(todo, (params_a, params_b), (pa, pb)):
+        _PACKS[key] = (ver, pack, [weakref.ref(p) for p in params])
+    return pa, pb
+
+
 PARAM_SHAPES = ([s for i in range(8) for s in ((256, 63 if i == 0 else 319 if i == 4 else 256), (256,))]
                 + [(1, 256), (1,), (256, 256), (256,), (128, 256), (128,), (3, 128), (3,)])
 

@@ -118,12 +118,15 @@ __device__ __forceinline__ void composite_ray(int lane, int K, Col col_of, Depth
 
 // MASKED: validity bytes given; NOISY: sigma noise given (training) — compile-time, so that the S row loads of a lane are
 // issued back to back instead of behind a (uniform) branch each.
-template <int S, int LPR, bool MASKED, bool NOISY>
+// INDEXED (training, the compacted network pass): rgbs = the rows of the VALID samples only, pos[R*K] = a sample's row or -1
+// (a sample the warp found invalid — (0, 0, 0, -1e5) as above): the pass's output is read where the network left it instead
+// of being expanded to one row per sample first (anr_expand_rows: a launch and 2 x 16 B per sample).
+template <int S, int LPR, bool MASKED, bool NOISY, bool INDEXED = false>
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_kernel(
     const float4* __restrict__ rgbs, const float* __restrict__ z, const float* __restrict__ rays, int stride,
     const float* __restrict__ noise, int64_t R, int K, int white_bkgd, float* __restrict__ weights_out,
     float* __restrict__ rgb_out, float* __restrict__ depth_out, float* __restrict__ acc_out,
-    const uint8_t* __restrict__ valid) {
+    const uint8_t* __restrict__ valid, const int32_t* __restrict__ pos = nullptr) {
     constexpr int RPW = WAVE / LPR;
     const int lane = threadIdx.x & 63;
     const int l = lane % LPR;
@@ -134,12 +137,17 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_kernel(
     const float4* c = rgbs + r * K;
     const float* zr = z + r * K;
     const uint8_t* vr = valid + r * K;
+    const int32_t* pr = pos + r * K;
     const float* nr = noise + r * K;
     float w[S], zz[S], wsum, cr, cg, cb, dep;
     // a sample the warp found invalid is (0, 0, 0, -1e5) by definition (models/anim_nerf.py:245-290, :305): its rgb-sigma
     // row was never written and is not read
     composite_ray<S, LPR>(lane, K,
-                          [&](int k) { if (MASKED) return vr[k] == 0 ? make_float4(0.f, 0.f, 0.f, -1e5f) : c[k]; return c[k]; },
+                          [&](int k) {
+                              if (INDEXED) { const int p = pr[k]; return p < 0 ? make_float4(0.f, 0.f, 0.f, -1e5f) : rgbs[p]; }
+                              if (MASKED) return vr[k] == 0 ? make_float4(0.f, 0.f, 0.f, -1e5f) : c[k];
+                              return c[k];
+                          },
                           [&](int k) { return zr[k]; }, [&](int k) { return NOISY ? nr[k] : 0.0f; }, w, zz, wsum, cr, cg, cb, dep);
     if (weights_out != nullptr && active) {
 #pragma unroll
@@ -174,12 +182,14 @@ __device__ __forceinline__ float wave_suffix_incl_sum(float v, int lane) {
 //   dL/dc_i = w_i g_rgb ;  dL/dalpha_i = G_i T_i - (sum_{j>i} G_j w_j) / t_i ;
 //   dL/dsigma_i = dL/dalpha_i * delta_i * exp(-delta_i relu(sigma_i)) * [sigma_i > 0].
 // White background folds -sum(g_rgb) - g_depth * far into g_acc'.
+// pos != NULL: rgbs = the valid samples' rows, looked up through pos as in composite_kernel<INDEXED> (d_rgbs stays one row
+// per sample: anr_mlp_head_grad gathers it)
 template <int S>
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_backward_kernel(
     const float4* __restrict__ rgbs, const float* __restrict__ z, const float* __restrict__ rays, int stride,
     const float* __restrict__ noise, int64_t R, int K, int white_bkgd, const float* __restrict__ g_w,
     const float* __restrict__ g_rgb, const float* __restrict__ g_depth, const float* __restrict__ g_acc,
-    float4* __restrict__ d_rgbs, float* __restrict__ d_z, float* __restrict__ d_far) {
+    float4* __restrict__ d_rgbs, float* __restrict__ d_z, float* __restrict__ d_far, const int32_t* __restrict__ pos) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -199,7 +209,12 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_backward_ker
         int k = lane * S + s;
         alpha[s] = 0.0f; tr[s] = 1.0f; zz[s] = 0.0f; delta[s] = 0.f; sg[s] = 0.f; col[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < K) {
-            col[s] = c[k];
+            if (pos != nullptr) {
+                const int p = pos[r * K + k];
+                col[s] = p < 0 ? make_float4(0.f, 0.f, 0.f, -1e5f) : rgbs[p];
+            } else {
+                col[s] = c[k];
+            }
             zz[s] = zr[k];
             delta[s] = (k + 1 < K) ? (zr[k + 1] - zz[s]) : 1e10f;
             sg[s] = col[s].w;
@@ -377,18 +392,40 @@ __device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int lane, const fl
     }
     sync();
 
-    // Stable sort of the Kc+Kf depths: rank(p) = #(y < x) + #(y == x, q < p).  Both halves are normally ascending
-    // (stratified coarse depths; fine depths from ascending u through a monotone inverse cdf): then a fine sample's rank
-    // is its index + the count above, and a coarse one's is its index + the number of fine samples whose count does not
-    // exceed it — a prefix sum of the histogram.  Anything else (random u, a 1-ulp inversion at a bin edge, coinciding
-    // depths) takes the all-pairs count, which is valid for any input.
+    // Stable sort of the Kc+Kf depths: rank(p) = #(y < x) + #(y == x, q < p).  The coarse half is normally ascending
+    // (stratified depths) and the shortcut above gave every fine sample its number of coarse depths <= it: then a coarse
+    // depth's rank is its index + the number of fine samples whose count does not exceed it — a prefix sum of the
+    // histogram — and a fine sample's is its count + its rank AMONG THE FINE SAMPLES: its index when they ascend too
+    // (ascending u through a monotone inverse cdf: inference), a Kf x Kf count otherwise (random u: training — 1/16 of
+    // the all-pairs count at 64 + 32).  Anything else (a 1-ulp inversion at a bin edge, coinciding coarse depths) takes
+    // the all-pairs count, which is valid for any input.
     const int K = Kc + Kf;
+    bool okf = true;
     for (int p = l; p < K; p += LPR)
-        if (p + 1 < K && p + 1 != Kc) ok &= L.zall[p] <= L.zall[p + 1];
-    // (the vote spans the wavefront: with two rays per wavefront both take the general path if either needs it)
-    const bool fast = __all(ok);
+        if (p + 1 < K && p + 1 != Kc) {
+            const bool asc = L.zall[p] <= L.zall[p + 1];
+            if (p < Kc) ok &= asc; else okf &= asc;
+        }
+    // (the votes span the wavefront: with two rays per wavefront both take the slower path if either needs it)
+    const bool regular = __all(ok);
+    const bool fast = regular && __all(okf);
     PermT* perm = reinterpret_cast<PermT*>(L.cdf);        // the cdf is dead from here on (barrier after the sampling loop)
-    if (fast) {
+    if (regular) {
+        if (!fast) {
+#pragma unroll
+            for (int f = 0; f < MAXS; ++f) {
+                const int j = f * LPR + l;
+                if (j < Kf) {
+                    const float x = zfv[f];
+                    int rank = 0;
+                    for (int q = 0; q < Kf; ++q) {        // (every lane reads the same word: a broadcast)
+                        const float y = L.zall[Kc + q];
+                        rank += (y < x || (y == x && q < j)) ? 1 : 0;
+                    }
+                    fpos[f] = fpos[f] - j + rank;
+                }
+            }
+        }
         const int SC = (Kc + LPR - 1) / LPR;              // coarse entries p = l*SC + s: a run per lane, then a DPP scan
         int h[MAXS], mine = 0;
 #pragma unroll
@@ -413,6 +450,11 @@ __device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int lane, const fl
                 L.wbuf[p + below_me] = L.zall[p];
                 if (want_perm) perm[p + below_me] = (PermT)p;
             }
+        }
+        if (!fast) {                                      // (the sampling loop's stores assumed ascending fine depths)
+#pragma unroll
+            for (int f = 0; f < MAXS; ++f)
+                if (f * LPR + l < Kf) L.wbuf[fpos[f]] = zfv[f];
         }
         if (want_perm) {
 #pragma unroll
@@ -553,9 +595,26 @@ extern "C" int anr_composite(const float* rgbs, const float* z, const float* ray
                                 acc_out, stream);
 }
 
+static int composite_any(const float* rgbs, const float* z, const float* rays, int stride, const float* noise, const uint8_t* valid,
+                         const int32_t* pos, int64_t R, int K, int white_bkgd, float* weights_out, float* rgb_out, float* depth_out,
+                         float* acc_out, void* stream);
+
 extern "C" int anr_composite_masked(const float* rgbs, const float* z, const float* rays, int stride, const float* noise,
                                     const uint8_t* valid, int64_t R, int K, int white_bkgd, float* weights_out,
                                     float* rgb_out, float* depth_out, float* acc_out, void* stream) {
+    return composite_any(rgbs, z, rays, stride, noise, valid, nullptr, R, K, white_bkgd, weights_out, rgb_out, depth_out, acc_out, stream);
+}
+
+extern "C" int anr_composite_indexed(const float* rows, const int32_t* pos, const float* z, const float* rays, int stride,
+                                     const float* noise, int64_t R, int K, int white_bkgd, float* weights_out, float* rgb_out,
+                                     float* depth_out, float* acc_out, void* stream) {
+    ANR_REQUIRE(pos, ANR_E_BADARG, "anr_composite_indexed: null pos");
+    return composite_any(rows, z, rays, stride, noise, nullptr, pos, R, K, white_bkgd, weights_out, rgb_out, depth_out, acc_out, stream);
+}
+
+static int composite_any(const float* rgbs, const float* z, const float* rays, int stride, const float* noise, const uint8_t* valid,
+                         const int32_t* pos, int64_t R, int K, int white_bkgd, float* weights_out, float* rgb_out, float* depth_out,
+                         float* acc_out, void* stream) {
     ANR_REQUIRE(rgbs && z && rays && rgb_out && depth_out && acc_out, ANR_E_BADARG, "anr_composite: null pointer");
     ANR_REQUIRE(R > 0 && K > 0 && stride >= 8, ANR_E_BADARG, "anr_composite: R=%lld K=%d stride=%d", (long long)R, K, stride);
     ANR_REQUIRE(K <= ANR_MAX_SAMPLES, ANR_E_SHAPE, "anr_composite: K=%d > %d", K, ANR_MAX_SAMPLES);
@@ -568,9 +627,16 @@ extern "C" int anr_composite_masked(const float* rgbs, const float* z, const flo
                                                                           (WAVES_PER_BLOCK * (WAVE / LPR)))),        \
                        block, 0, st, c, z, rays, stride, noise, R, K, white_bkgd, weights_out, rgb_out, depth_out,   \
                        acc_out, valid)
+#define ANR_LAUNCH_COMPOSITE_IDX(SS, LPR, N)                                                                         \
+    hipLaunchKernelGGL((composite_kernel<SS, LPR, false, N, true>), dim3((unsigned)((R + WAVES_PER_BLOCK * (WAVE / LPR) - 1) / \
+                                                                                (WAVES_PER_BLOCK * (WAVE / LPR)))),   \
+                       block, 0, st, c, z, rays, stride, noise, R, K, white_bkgd, weights_out, rgb_out, depth_out,    \
+                       acc_out, valid, pos)
 #define ANR_LAUNCH_COMPOSITE(SS, LPR)                                                                              \
     do {                                                                                                           \
-        if (valid && noise) { ANR_LAUNCH_COMPOSITE_(SS, LPR, true, true); }                                        \
+        if (pos && noise)   { ANR_LAUNCH_COMPOSITE_IDX(SS, LPR, true); }                                           \
+        else if (pos)       { ANR_LAUNCH_COMPOSITE_IDX(SS, LPR, false); }                                          \
+        else if (valid && noise) { ANR_LAUNCH_COMPOSITE_(SS, LPR, true, true); }                                   \
         else if (valid)     { ANR_LAUNCH_COMPOSITE_(SS, LPR, true, false); }                                       \
         else if (noise)     { ANR_LAUNCH_COMPOSITE_(SS, LPR, false, true); }                                       \
         else                { ANR_LAUNCH_COMPOSITE_(SS, LPR, false, false); }                                      \
@@ -580,6 +646,7 @@ extern "C" int anr_composite_masked(const float* rgbs, const float* z, const flo
     else if (K <= 192) { ANR_LAUNCH_COMPOSITE(3, 64); }
     else               { ANR_LAUNCH_COMPOSITE(4, 64); }
 #undef ANR_LAUNCH_COMPOSITE_
+#undef ANR_LAUNCH_COMPOSITE_IDX
 #undef ANR_LAUNCH_COMPOSITE
     return check_launch("anr_composite");
 }
@@ -588,6 +655,14 @@ extern "C" int anr_composite_backward(const float* rgbs, const float* z, const f
                                       const float* noise, int64_t R, int K, int white_bkgd, const float* g_weights,
                                       const float* g_rgb, const float* g_depth, const float* g_acc, float* d_rgbs,
                                       float* d_z, float* d_far, void* stream) {
+    return anr_composite_backward_indexed(rgbs, nullptr, z, rays, stride, noise, R, K, white_bkgd, g_weights, g_rgb, g_depth, g_acc,
+                                          d_rgbs, d_z, d_far, stream);
+}
+
+extern "C" int anr_composite_backward_indexed(const float* rgbs, const int32_t* pos, const float* z, const float* rays, int stride,
+                                              const float* noise, int64_t R, int K, int white_bkgd, const float* g_weights,
+                                              const float* g_rgb, const float* g_depth, const float* g_acc, float* d_rgbs,
+                                              float* d_z, float* d_far, void* stream) {
     ANR_REQUIRE(rgbs && z && rays && d_rgbs, ANR_E_BADARG, "anr_composite_backward: null pointer");
     ANR_REQUIRE(R > 0 && K > 0 && stride >= 8, ANR_E_BADARG, "anr_composite_backward: R=%lld K=%d stride=%d", (long long)R, K, stride);
     ANR_REQUIRE(K <= ANR_MAX_SAMPLES, ANR_E_SHAPE, "anr_composite_backward: K=%d > %d", K, ANR_MAX_SAMPLES);
@@ -598,7 +673,7 @@ extern "C" int anr_composite_backward(const float* rgbs, const float* z, const f
     hipStream_t st = (hipStream_t)stream;
 #define ANR_LAUNCH_CB(SS)                                                                                      \
     hipLaunchKernelGGL(composite_backward_kernel<SS>, grid, block, 0, st, c, z, rays, stride, noise, R, K, white_bkgd, \
-                       g_weights, g_rgb, g_depth, g_acc, d, d_z, d_far)
+                       g_weights, g_rgb, g_depth, g_acc, d, d_z, d_far, pos)
     switch ((K + 63) / 64) {
         case 1: ANR_LAUNCH_CB(1); break;
         case 2: ANR_LAUNCH_CB(2); break;

@@ -488,9 +488,14 @@ __global__ __launch_bounds__(FB_THREADS) void frame_adjoint_kernel(
 // 42 us at 2 frames with 256; fixed-order tree: the same bits on every run)
 constexpr int FO_THREADS = 1024;
 __global__ __launch_bounds__(FO_THREADS) void frame_offsets_kernel(const float* __restrict__ goff, const float* __restrict__ shapedirs,
-                                                                   const float* __restrict__ posedirs, int V, float* __restrict__ H) {
+                                                                   const float* __restrict__ posedirs, int V, float* __restrict__ H, int bs) {
     __shared__ float sRed[FO_THREADS / 64];
-    const int b = blockIdx.y, f = blockIdx.x;
+    // (the frames of one blend-shape row on consecutive workgroup ids of one XCD — ids go round the 8 XCDs: the row comes
+    // from HBM once and from that XCD's L2 for the other frames; with (row, frame) as the grid's (x, y) a 16-frame step read
+    // the 17 MB of pose blend shapes sixteen times: 70 us)
+    const int t = (int)blockIdx.x >> 3;
+    const int b = t % bs, f = (t / bs) * 8 + ((int)blockIdx.x & 7);
+    if (f >= FA_H) return;
     const float* gb = goff + (int64_t)b * V * 3;
     float s = 0.0f;
     if (f < 207) {
@@ -556,6 +561,7 @@ extern "C" int anr_frame_backward(const float* betas, const float* pose, const f
 }
 
 extern "C" int64_t anr_frame_backward_ws_floats(int bs, int V) { return (int64_t)bs * (FA_ACC + FA_H + 3 * (int64_t)V); }
+extern "C" int64_t anr_frame_backward_ws_zero_floats(int bs) { return (int64_t)bs * FA_ACC; }
 
 extern "C" int anr_frame_backward_adjoint(const float* betas, const float* pose, const float* transl, int bs, const float* J0,
                                           const float* JS, const int64_t* parents, const float* lbs_weights, const float* shapedirs,
@@ -564,7 +570,7 @@ extern "C" int anr_frame_backward_adjoint(const float* betas, const float* pose,
                                           const float* d_rays_body, float* workspace, float* grads_out, void* stream) {
     return anr_frame_backward_adjoint_values(betas, pose, transl, bs, J0, JS, parents, lbs_weights, shapedirs, posedirs, V, T_template,
                                              template_bs, rays_world, ray_stride, R, d_ober2cano, d_rays_body, nullptr, nullptr, workspace,
-                                             grads_out, stream);
+                                             grads_out, 0, stream);
 }
 
 extern "C" int anr_frame_backward_adjoint_values(const float* betas, const float* pose, const float* transl, int bs, const float* J0,
@@ -572,7 +578,7 @@ extern "C" int anr_frame_backward_adjoint_values(const float* betas, const float
                                                  const float* posedirs, int V, const float* T_template, int template_bs,
                                                  const float* rays_world, int ray_stride, int R, const float* d_ober2cano,
                                                  const float* d_rays_body, const float* joints_transform, const float* g_inv,
-                                                 float* workspace, float* grads_out, void* stream) {
+                                                 float* workspace, float* grads_out, int flags, void* stream) {
     ANR_REQUIRE(betas && pose && transl && J0 && JS && parents && lbs_weights && shapedirs && posedirs && T_template &&
                 (d_ober2cano || d_rays_body) && workspace && grads_out, ANR_E_BADARG, "anr_frame_backward_adjoint: null pointer");
     ANR_REQUIRE((joints_transform == nullptr) == (g_inv == nullptr), ANR_E_BADARG,
@@ -585,14 +591,15 @@ extern "C" int anr_frame_backward_adjoint_values(const float* betas, const float
     float* acc = workspace;
     float* H = acc + (int64_t)bs * FA_ACC;
     float* goff = H + (int64_t)bs * FA_H;
-    if (int rc = zero_fill(acc, sizeof(float) * (size_t)bs * FA_ACC, st, "anr_frame_backward_adjoint (zero)")) return rc;
+    if (!(flags & 1))                                           // (1: the caller zeroed the accumulators with its other fills)
+        if (int rc = zero_fill(acc, sizeof(float) * (size_t)bs * FA_ACC, st, "anr_frame_backward_adjoint (zero)")) return rc;
     const int nvb = d_ober2cano ? (V + FB_THREADS - 1) / FB_THREADS : 0;
     const int nrb = d_rays_body ? (R + FB_THREADS - 1) / FB_THREADS : 0;
     hipLaunchKernelGGL(frame_adjoint_kernel, dim3(nvb + nrb, bs), dim3(FB_THREADS), 0, st, betas, pose, transl, J0, JS, parents,
                        lbs_weights, T_template, template_bs == 1 ? (int64_t)0 : (int64_t)V * 16, rays_world, ray_stride, R, d_ober2cano,
                        d_rays_body, V, nvb, acc, goff, joints_transform, g_inv);
     if (d_ober2cano)
-        hipLaunchKernelGGL(frame_offsets_kernel, dim3(FA_H, bs), dim3(FO_THREADS), 0, st, goff, shapedirs, posedirs, V, H);
+        hipLaunchKernelGGL(frame_offsets_kernel, dim3((unsigned)(((FA_H + 7) & ~7) * bs)), dim3(FO_THREADS), 0, st, goff, shapedirs, posedirs, V, H, bs);
     hipLaunchKernelGGL(frame_params_kernel, dim3(FB_NP, bs), dim3(64), 0, st, betas, pose, transl, J0, JS, parents, acc,
                        d_ober2cano ? H : (const float*)nullptr, grads_out);
     return check_launch("anr_frame_backward_adjoint");

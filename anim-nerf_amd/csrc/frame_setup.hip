@@ -153,12 +153,26 @@ __global__ __launch_bounds__(256) void frame_vertex_kernel(
     const float* __restrict__ so_templ, const float* __restrict__ po_templ, int64_t templ_stride_T, int64_t templ_stride_o,
     const float* __restrict__ rays_world, int ray_stride, int R, int n_vblocks, float* __restrict__ shape_off,
     float* __restrict__ pose_off, float* __restrict__ verts_root, float* __restrict__ T_root, float* __restrict__ o2c,
-    float* __restrict__ rays_body) {
-    const int b = blockIdx.y;
+    float* __restrict__ rays_body, int bs, int n_rblocks) {
+    // Workgroup -> (block, frame): the frames of ONE vertex block on consecutive workgroup ids of the SAME XCD (ids go round
+    // the 8 XCDs), so that its slice of the pose blend shapes (207 rows x 768 B; 17 MB over all blocks) comes from HBM once
+    // and from that XCD's L2 for the other frames — with (block, frame) as the grid's (x, y) every frame read the 17 MB again.
+    const int nvp = (n_vblocks + 7) & ~7;
+    int b, bx;
+    if ((int)blockIdx.x < nvp * bs) {
+        const int t = (int)blockIdx.x >> 3;
+        b = t % bs;
+        bx = (t / bs) * 8 + ((int)blockIdx.x & 7);
+        if (bx >= n_vblocks) return;
+    } else {
+        const int t = (int)blockIdx.x - nvp * bs;
+        b = t / n_rblocks;
+        bx = n_vblocks + t % n_rblocks;
+    }
     __shared__ float sA[FS_J][12], sf[FS_P], sB[FS_NB], sI[12], sT[3];
     __shared__ float sPo[4][64][3];
-    if ((int)blockIdx.x >= n_vblocks) {                      // ---- rays: models/anim_nerf.py:128-137
-        const int r = ((int)blockIdx.x - n_vblocks) * 256 + threadIdx.x;
+    if (bx >= n_vblocks) {                                   // ---- rays: models/anim_nerf.py:128-137
+        const int r = (bx - n_vblocks) * 256 + threadIdx.x;
         if (r >= R) return;
         const float* G = ginv + b * 16;
         const float* s = rays_world + ((int64_t)b * R + r) * ray_stride;
@@ -188,7 +202,7 @@ __global__ __launch_bounds__(256) void frame_vertex_kernel(
     if (threadIdx.x < 3) sT[threadIdx.x] = tr[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int v = blockIdx.x * 64 + lane;
+    const int v = bx * 64 + lane;
     const bool live = v < V;
     // pose blend shapes: slice s takes features s, s + 4, ... (lbs.py:152-251: pose_offsets = feat . posedirs)
     float po[3] = {0.f, 0.f, 0.f};
@@ -299,9 +313,9 @@ extern "C" int anr_frame_setup(const int64_t* frame_idx, const float* betas_w, i
     hipLaunchKernelGGL(frame_chain_kernel, dim3(bs), dim3(64), 0, st, frame_idx, betas_w, betas_rows, global_orient_w, body_pose_w,
                        transl_w, J0, JS, parents, betas_out, pose_out, transl_out, A_out, joints_root_out, ws_feat, g_inv_out, g_root_out);
     const int nvb = (V + 63) / 64, nrb = (R + 255) / 256;
-    hipLaunchKernelGGL(frame_vertex_kernel, dim3(nvb + nrb, bs), dim3(256), 0, st, betas_out, transl_out, A_out, ws_feat, g_inv_out,
+    hipLaunchKernelGGL(frame_vertex_kernel, dim3((unsigned)((((nvb + 7) & ~7) + nrb) * bs)), dim3(256), 0, st, betas_out, transl_out, A_out, ws_feat, g_inv_out,
                        v_template, shapedirs, posedirs, lbs_weights, V, T_template, shape_off_template, pose_off_template,
                        template_bs == 1 ? (int64_t)0 : (int64_t)V * 16, template_bs == 1 ? (int64_t)0 : (int64_t)V * 3, rays_world,
-                       ray_stride, R, nvb, shape_off_out, pose_off_out, verts_root_out, T_root_out, ober2cano_out, rays_body_out);
+                       ray_stride, R, nvb, shape_off_out, pose_off_out, verts_root_out, T_root_out, ober2cano_out, rays_body_out, bs, nrb);
     return check_launch("anr_frame_setup");
 }

@@ -41,9 +41,12 @@ __device__ __forceinline__ int enc_channel(int j, int h) {       // -1 = pad
     return h ? -1 : 1;
 }
 
+// blockIdx.y = which of (up to) two networks: a training step packs the coarse and the fine network in ONE launch
 template <int MODE>
-__global__ void mlp_pack_kernel(PackPlan plan, char* __restrict__ pack) {
+__global__ void mlp_pack_kernel(PackPlan plan_a, char* __restrict__ pack_a, PackPlan plan_b, char* __restrict__ pack_b) {
     using C = Cfg<MODE>;
+    const PackPlan& plan = blockIdx.y ? plan_b : plan_a;
+    char* __restrict__ pack = blockIdx.y ? pack_b : pack_a;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n_pieces = (int64_t)plan.total_frags * 64;
     if (gid < n_pieces) {
@@ -144,28 +147,52 @@ extern "C" int anr_mlp_pack(const anr_mlp_params* p, int mode, void* pack_out, v
     return anr_mlp_pack_view(p, mode, 0, pack_out, stream);
 }
 
-extern "C" int anr_mlp_pack_view(const anr_mlp_params* p, int mode, int dir_channels, void* pack_out, void* stream) {
+static int check_pack_params(const anr_mlp_params* p, const void* pack_out) {
     ANR_REQUIRE(p && pack_out, ANR_E_BADARG, "anr_mlp_pack: null pointer");
-    ANR_REQUIRE(dir_channels >= 0 && dir_channels <= 63 && (dir_channels == 0 || dir_channels % 6 == 3), ANR_E_BADARG,
-                "anr_mlp_pack_view: dir_channels=%d (0, or 3 + 6 freqs_dir <= 63)", dir_channels);
     for (int l = 0; l < 8; ++l)
         ANR_REQUIRE(p->w_trunk[l] && p->b_trunk[l], ANR_E_BADARG, "anr_mlp_pack: null trunk tensor %d", l);
     ANR_REQUIRE(p->w_sigma && p->b_sigma && p->w_final && p->b_final && p->w_dir && p->b_dir && p->w_rgb && p->b_rgb,
                 ANR_E_BADARG, "anr_mlp_pack: null head tensor");
     ANR_REQUIRE(((uintptr_t)pack_out & 15) == 0, ANR_E_ALIGN, "anr_mlp_pack: pack_out must be 16-B aligned");
+    return 0;
+}
+
+// p_b / pack_b NULL: one network
+static int pack_networks(const anr_mlp_params* p, const anr_mlp_params* p_b, int mode, int dir_channels, void* pack_out, void* pack_b,
+                         void* stream) {
+    if (int rc = check_pack_params(p, pack_out)) return rc;
+    if (p_b != nullptr)
+        if (int rc = check_pack_params(p_b, pack_b)) return rc;
+    ANR_REQUIRE(dir_channels >= 0 && dir_channels <= 63 && (dir_channels == 0 || dir_channels % 6 == 3), ANR_E_BADARG,
+                "anr_mlp_pack_view: dir_channels=%d (0, or 3 + 6 freqs_dir <= 63)", dir_channels);
     hipStream_t st = (hipStream_t)stream;
+    const unsigned ny = p_b != nullptr ? 2u : 1u;
     if ((mode & 0xff) == ANR_MLP_F32) {
         PackPlan plan = make_plan<ANR_MLP_F32>(p, dir_channels);
+        PackPlan plan_b = p_b != nullptr ? make_plan<ANR_MLP_F32>(p_b, dir_channels) : plan;
         int64_t n = (int64_t)plan.total_frags * 64 + BIAS_BYTES / 4;
-        hipLaunchKernelGGL(mlp_pack_kernel<ANR_MLP_F32>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, plan, (char*)pack_out);
+        hipLaunchKernelGGL(mlp_pack_kernel<ANR_MLP_F32>, dim3((unsigned)((n + 255) / 256), ny), dim3(256), 0, st, plan, (char*)pack_out, plan_b,
+                           (char*)pack_b);
     } else if ((mode & 0xff) == ANR_MLP_BF16) {
         PackPlan plan = make_plan<ANR_MLP_BF16>(p, dir_channels);
+        PackPlan plan_b = p_b != nullptr ? make_plan<ANR_MLP_BF16>(p_b, dir_channels) : plan;
         int64_t n = (int64_t)plan.total_frags * 64 + BIAS_BYTES / 4;
-        hipLaunchKernelGGL(mlp_pack_kernel<ANR_MLP_BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, plan, (char*)pack_out);
+        hipLaunchKernelGGL(mlp_pack_kernel<ANR_MLP_BF16>, dim3((unsigned)((n + 255) / 256), ny), dim3(256), 0, st, plan, (char*)pack_out, plan_b,
+                           (char*)pack_b);
     } else {
         return fail(ANR_E_BADARG, "anr_mlp_pack: unknown mode %d", mode);
     }
     return check_launch("anr_mlp_pack");
+}
+
+extern "C" int anr_mlp_pack_view(const anr_mlp_params* p, int mode, int dir_channels, void* pack_out, void* stream) {
+    return pack_networks(p, nullptr, mode, dir_channels, pack_out, nullptr, stream);
+}
+
+extern "C" int anr_mlp_pack_pair(const anr_mlp_params* p_a, const anr_mlp_params* p_b, int mode, void* pack_a_out, void* pack_b_out,
+                                 void* stream) {
+    ANR_REQUIRE(p_b && pack_b_out, ANR_E_BADARG, "anr_mlp_pack_pair: null pointer");
+    return pack_networks(p_a, p_b, mode, 0, pack_a_out, pack_b_out, stream);
 }
 
 extern "C" int anr_mlp_act_cols(void) { return ACT_PITCH; }

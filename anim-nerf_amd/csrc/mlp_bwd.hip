@@ -514,9 +514,12 @@ struct BwdStage { const float* W; int ld, in_off, in_dim, out_dim, tile0, nf; };
 struct BwdPlan { BwdStage s[10]; const float* w_sigma; const float* w1; const float* w5; };
 
 
+// blockIdx.y = which of (up to) two networks
 template <int MODE>
-__global__ void mlp_bwd_pack_kernel(BwdPlan plan, char* __restrict__ pack) {
+__global__ void mlp_bwd_pack_kernel(BwdPlan plan_a, char* __restrict__ pack_a, BwdPlan plan_b, char* __restrict__ pack_b) {
     using C = Cfg<MODE>;
+    const BwdPlan& plan = blockIdx.y ? plan_b : plan_a;
+    char* __restrict__ pack = blockIdx.y ? pack_b : pack_a;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n_pieces = (int64_t)btotal_frags<C>() * 64;
     if (gid < n_pieces) {
@@ -575,12 +578,12 @@ extern "C" int64_t anr_mlp_bwd_pack_bytes(int mode) {
     }
 }
 
-extern "C" int anr_mlp_bwd_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream) {
+static int bwd_plan(const anr_mlp_params* p, const void* pack_out, BwdPlan& plan) {
     ANR_REQUIRE(p && pack_out, ANR_E_BADARG, "anr_mlp_bwd_pack: null pointer");
     for (int l = 1; l < 8; ++l) ANR_REQUIRE(p->w_trunk[l], ANR_E_BADARG, "anr_mlp_bwd_pack: null trunk tensor %d", l);
     ANR_REQUIRE(p->w_sigma && p->w_final && p->w_dir && p->w_rgb, ANR_E_BADARG, "anr_mlp_bwd_pack: null head tensor");
     ANR_REQUIRE(((uintptr_t)pack_out & 15) == 0, ANR_E_ALIGN, "anr_mlp_bwd_pack: pack_out must be 16-B aligned");
-    BwdPlan plan{};
+    plan = BwdPlan{};
     plan.s[0] = BwdStage{p->w_rgb, 128, 0, 128, 3, 0, 4};                 // rgb.0.weight [3,128]
     plan.s[1] = BwdStage{p->w_dir, 256, 0, 256, 128, 4, 0};               // dir_encoding.0.weight [128,256]
     plan.s[2] = BwdStage{p->w_final, 256, 0, 256, 256, 12, 0};            // xyz_encoding_final.weight [256,256]
@@ -592,17 +595,39 @@ extern "C" int anr_mlp_bwd_pack(const anr_mlp_params* p, int mode, void* pack_ou
     ANR_REQUIRE(p->w_trunk[0], ANR_E_BADARG, "anr_mlp_bwd_pack: null trunk tensor 0");
     plan.w1 = p->w_trunk[0];
     plan.w5 = p->w_trunk[4];
+    return 0;
+}
+
+static int bwd_pack_networks(const anr_mlp_params* p, const anr_mlp_params* p_b, int mode, void* pack_out, void* pack_b, void* stream) {
+    BwdPlan plan, plan_b;
+    if (int rc = bwd_plan(p, pack_out, plan)) return rc;
+    plan_b = plan;
+    if (p_b != nullptr)
+        if (int rc = bwd_plan(p_b, pack_b, plan_b)) return rc;
+    const unsigned ny = p_b != nullptr ? 2u : 1u;
     hipStream_t st = (hipStream_t)stream;
     if ((mode & 0xff) == ANR_MLP_F32) {
         int64_t n = (int64_t)btotal_frags<Cfg<ANR_MLP_F32>>() * 64 + BWD_TABLE_BYTES / 4 + DENC_PANEL_ELEMS;
-        hipLaunchKernelGGL(mlp_bwd_pack_kernel<ANR_MLP_F32>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, plan, (char*)pack_out);
+        hipLaunchKernelGGL(mlp_bwd_pack_kernel<ANR_MLP_F32>, dim3((unsigned)((n + 255) / 256), ny), dim3(256), 0, st, plan, (char*)pack_out,
+                           plan_b, (char*)pack_b);
     } else if ((mode & 0xff) == ANR_MLP_BF16) {
         int64_t n = (int64_t)btotal_frags<Cfg<ANR_MLP_BF16>>() * 64 + BWD_TABLE_BYTES / 4 + DENC_PANEL_ELEMS;
-        hipLaunchKernelGGL(mlp_bwd_pack_kernel<ANR_MLP_BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, plan, (char*)pack_out);
+        hipLaunchKernelGGL(mlp_bwd_pack_kernel<ANR_MLP_BF16>, dim3((unsigned)((n + 255) / 256), ny), dim3(256), 0, st, plan, (char*)pack_out,
+                           plan_b, (char*)pack_b);
     } else {
         return fail(ANR_E_BADARG, "anr_mlp_bwd_pack: unknown mode %d", mode);
     }
     return check_launch("anr_mlp_bwd_pack");
+}
+
+extern "C" int anr_mlp_bwd_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream) {
+    return bwd_pack_networks(p, nullptr, mode, pack_out, nullptr, stream);
+}
+
+extern "C" int anr_mlp_bwd_pack_pair(const anr_mlp_params* p_a, const anr_mlp_params* p_b, int mode, void* pack_a_out, void* pack_b_out,
+                                     void* stream) {
+    ANR_REQUIRE(p_b && pack_b_out, ANR_E_BADARG, "anr_mlp_bwd_pack_pair: null pointer");
+    return bwd_pack_networks(p_a, p_b, mode, pack_a_out, pack_b_out, stream);
 }
 
 extern "C" int anr_mlp_backward(const void* bwd_pack, int mode, const float* g, const void* act, void* dact, int64_t n,

@@ -429,6 +429,7 @@ int splits_for(int64_t n, int stage_rows, int gemms, int background) {
 }  // namespace
 
 extern "C" int64_t anr_mlp_wgrad_floats(void) { return layout().total; }
+extern "C" int64_t anr_mlp_wgrad_sigma_floats(void) { return layout().fw; }
 
 extern "C" int64_t anr_mlp_wgrad_ws_floats(int64_t n) {
     // upper bound for any n: three GEMM shapes at their maximum split counts + the column-sum slices
@@ -564,7 +565,7 @@ extern "C" int anr_mlp_wgrad_counted(int mode, const void* act, const void* dact
     hipStream_t st = (hipStream_t)stream;
     const int accumulate = (mode & ANR_MLP_FLAG_ACCUMULATE) ? 1 : 0;
     const int bg = (mode & ANR_MLP_FLAG_BACKGROUND) ? 1 : 0;
-    if (so && !accumulate) {                                         // tensors this call does not produce: zeros
+    if (so && !accumulate && !(mode & ANR_MLP_FLAG_NO_FILL)) {       // tensors this call does not produce: zeros
         const Layout& L = layout();
         if (int rc = zero_fill(grads_out + L.fw, sizeof(float) * (L.total - L.fw), st, "anr_mlp_wgrad (zero)")) return rc;
     }

@@ -289,6 +289,10 @@ __global__ __launch_bounds__(256) void train_loss_kernel(anr_loss_args a, float*
         const float* rgb = pass ? a.rgb_fine : a.rgb;
         const float* al = pass ? a.acc_fine : a.acc;
         const float* s = pass ? a.s_fine : a.s;
+        if (s) {                                             // (the prior points' rows at the end of a compacted pass)
+            const int32_t* sc = pass ? a.s_count_fine : a.s_count;
+            if (sc) s += (int64_t)(a.s_stride > 0 ? a.s_stride : 1) * (sc[0] - a.prior_rows * (a.n_fg + a.n_bg));
+        }
         const float4* q = reinterpret_cast<const float4*>(pass ? a.quads_fine : a.quads);
         float s_rgb = 0.f, s_al = 0.f, s_fg = 0.f, s_bg = 0.f, s_n = 0.f;
         if (rgb)
@@ -390,6 +394,10 @@ __global__ __launch_bounds__(256) void train_loss_backward_kernel(anr_loss_args 
         const float* rgb = pass ? a.rgb_fine : a.rgb;
         const float* al = pass ? a.acc_fine : a.acc;
         const float* s = pass ? a.s_fine : a.s;
+        if (s) {
+            const int32_t* sc = pass ? a.s_count_fine : a.s_count;
+            if (sc) s += (int64_t)(a.s_stride > 0 ? a.s_stride : 1) * (sc[0] - a.prior_rows * (a.n_fg + a.n_bg));
+        }
         const float4* q = reinterpret_cast<const float4*>(pass ? a.quads_fine : a.quads);
         float* d_rgb = pass ? d.rgb_fine : d.rgb;
         float* d_al = pass ? d.acc_fine : d.acc;

@@ -16,6 +16,7 @@
 //   anr_sample_coarse_backward_acc  anr_sample_coarse_backward of the sum of up to three upstream gradients, ADDED into the
 //                                 accumulated ray gradient together with the two compositors' dL/d far'
 //   anr_zero_fill                 the library's memset (anr_common.h: zero_fill)
+//   anr_zero_segments             ... of up to 24 buffers in one launch (the step's accumulators and counters, filled up front)
 //   anr_add_inplace               dst += src: the normals branch's weight gradients joining the render passes'
 #include "anr_common.h"
 
@@ -91,10 +92,21 @@ __global__ __launch_bounds__(256) void train_draws_kernel(uint64_t* __restrict__
                     asm volatile("" : "+v"(pa), "+v"(pb));
                     float pt = p.verts_template[e + i] + pa;
                     asm volatile("" : "+v"(pt));
+                    const float nb = pt + pb;
                     p.n0[e + i] = a;
                     p.n1[e + i] = b;
                     p.pair[e + i] = pt;
-                    p.pair[p.n_v3 + e + i] = pt + pb;
+                    p.pair[p.n_v3 + e + i] = nb;
+                    if (p.quads != nullptr) {               // component c of point pi (and of its neighbour): four rows each
+                        const int64_t pi = (e + i) / 3, pj = p.n_v3 / 3 + pi;
+                        const int c = (int)((e + i) - 3 * pi);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            p.quads[(4 * pi + q) * 4 + c] = pt;
+                            p.quads[(4 * pj + q) * 4 + c] = nb;
+                            if (c == 0) { p.quads[(4 * pi + q) * 4 + 3] = 1.0f; p.quads[(4 * pj + q) * 4 + 3] = 1.0f; }
+                        }
+                    }
                 }
         }
     }
@@ -266,6 +278,44 @@ extern "C" int anr_add_inplace(float* dst, const float* src, int64_t n, void* st
 }
 
 namespace anr {
+constexpr int ADD_MAX_SEGS = 24;
+struct AddSegs { float* dst[ADD_MAX_SEGS]; const float* src[ADD_MAX_SEGS]; int64_t n[ADD_MAX_SEGS]; };
+__global__ __launch_bounds__(256) void add_segments_kernel(AddSegs t) {
+    float* dst = t.dst[blockIdx.y];
+    const float* src = t.src[blockIdx.y];
+    const int64_t n = t.n[blockIdx.y];
+    const bool vec = (((uintptr_t)dst | (uintptr_t)src) & 15) == 0;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+        if (vec && i + 4 <= n) {
+            float4 a = *reinterpret_cast<const float4*>(dst + i);
+            const float4 b = *reinterpret_cast<const float4*>(src + i);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            *reinterpret_cast<float4*>(dst + i) = a;
+        } else {
+            for (int64_t k = i; k < n && k < i + 4; ++k) dst[k] += src[k];
+        }
+    }
+}
+}  // namespace anr
+
+extern "C" int anr_add_segments(float* const* dst, const float* const* src, const int64_t* floats, int n_segments, void* stream) {
+    ANR_REQUIRE(dst && src && floats, ANR_E_BADARG, "anr_add_segments: null pointer");
+    ANR_REQUIRE(n_segments > 0 && n_segments <= anr::ADD_MAX_SEGS, ANR_E_BADARG, "anr_add_segments: n=%d segments (1..%d)", n_segments,
+                anr::ADD_MAX_SEGS);
+    anr::AddSegs t{};
+    int64_t most = 0;
+    for (int i = 0; i < n_segments; ++i) {
+        ANR_REQUIRE(dst[i] && src[i] && floats[i] >= 0, ANR_E_BADARG, "anr_add_segments: segment %d: null pointer or negative size", i);
+        t.dst[i] = dst[i]; t.src[i] = src[i]; t.n[i] = floats[i];
+        most = floats[i] > most ? floats[i] : most;
+    }
+    int64_t blocks = (most + 1023) / 1024;
+    blocks = blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks;
+    hipLaunchKernelGGL(anr::add_segments_kernel, dim3((unsigned)blocks, (unsigned)n_segments), dim3(256), 0, (hipStream_t)stream, t);
+    return anr::check_launch("anr_add_segments");
+}
+
+namespace anr {
 constexpr int COPY_MAX_SEGS = 24;
 struct CopySegs { const char* src[COPY_MAX_SEGS]; char* dst[COPY_MAX_SEGS]; int64_t bytes[COPY_MAX_SEGS]; };
 // blockIdx.y = segment; the table rides in the kernel arguments (no upload, nothing for a graph to bake but the node itself)
@@ -299,6 +349,38 @@ extern "C" int anr_copy_segments(const void* const* src, void* const* dst, const
     blocks = blocks < 1 ? 1 : blocks > 64 ? 64 : blocks;
     hipLaunchKernelGGL(anr::copy_segments_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, t);
     return anr::check_launch("anr_copy_segments");
+}
+
+namespace anr {
+struct ZeroSegs { char* dst[COPY_MAX_SEGS]; int64_t bytes[COPY_MAX_SEGS]; };
+__global__ __launch_bounds__(256) void zero_segments_kernel(ZeroSegs t) {
+    char* d = t.dst[blockIdx.y];
+    const int64_t n = t.bytes[blockIdx.y];
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+    if (((uintptr_t)d & 15) == 0) {
+        for (int64_t i = tid; i < n / 16; i += nth) reinterpret_cast<uint4*>(d)[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int64_t i = (n / 16) * 16 + tid; i < n; i += nth) d[i] = 0;
+    } else {
+        for (int64_t i = tid; i < n; i += nth) d[i] = 0;
+    }
+}
+}  // namespace anr
+
+extern "C" int anr_zero_segments(void* const* dst, const int64_t* bytes, int n, void* stream) {
+    ANR_REQUIRE(dst && bytes, ANR_E_BADARG, "anr_zero_segments: null pointer");
+    ANR_REQUIRE(n > 0 && n <= anr::COPY_MAX_SEGS, ANR_E_BADARG, "anr_zero_segments: n=%d segments (1..%d)", n, anr::COPY_MAX_SEGS);
+    anr::ZeroSegs t{};
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        ANR_REQUIRE(dst[i] && bytes[i] >= 0, ANR_E_BADARG, "anr_zero_segments: segment %d: null pointer or negative size", i);
+        t.dst[i] = reinterpret_cast<char*>(dst[i]);
+        t.bytes[i] = bytes[i];
+        most = bytes[i] > most ? bytes[i] : most;
+    }
+    int64_t blocks = (most / 16 + 1023) / 1024;                // four 16-byte stores per thread at the largest segment
+    blocks = blocks < 1 ? 1 : blocks > 256 ? 256 : blocks;
+    hipLaunchKernelGGL(anr::zero_segments_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, t);
+    return anr::check_launch("anr_zero_segments");
 }
 
 extern "C" int anr_zero_fill(void* ptr, int64_t bytes, void* stream) {

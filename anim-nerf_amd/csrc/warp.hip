@@ -657,7 +657,9 @@ struct WarpWs {
     // (DEAL_INTS per body each: ItemDealer) | cell_count | cell_start | cell_cap2 | occ_list | cell_seed (bs NCELL each)
     __host__ static int64_t up32(int64_t v) { return (v + 31) / 32 * 32; }
     __host__ static int64_t ints(int bs, int64_t N) { return up32(3 * (int64_t)bs * N) + up32(3 * bs) + 2 * (int64_t)bs * DEAL_INTS + 5 * (int64_t)bs * NCELL; }
-    __host__ static int64_t zeroed_ints(int bs) { return up32(3 * bs) + 2 * (int64_t)bs * DEAL_INTS + (int64_t)bs * NCELL; }      // from `count` on
+    // from `count` on; a small batch (no cells) needs the counters and the cursors only
+    __host__ static int64_t zeroed_ints(int bs, bool cells = true) { return up32(3 * bs) + 2 * (int64_t)bs * DEAL_INTS + (cells ? (int64_t)bs * NCELL : 0); }
+    __host__ static int64_t count_off(int bs, int64_t N) { return up32(3 * (int64_t)bs * N); }
     __host__ WarpWs(int32_t* ws, int bs, int64_t N) {
         list = ws; cells = list + (int64_t)bs * N; sorted = cells + (int64_t)bs * N; count = list + up32(3 * (int64_t)bs * N);
         live = count + bs; occ_count = live + bs;
@@ -704,7 +706,9 @@ constexpr int CLS_ITERS = 8;                   // samples per classify workgroup
 // VEC4 (rays mode, K % 4 == 0): a thread takes FOUR CONSECUTIVE samples of one ray per step — one 16-byte load of depths, one
 // dword of merge permutation in, one dword of validity bytes out — instead of four byte-wide accesses 1,024 samples apart:
 // the pass is a stream over z / perm / mask (11 B per sample) and ran at 1.4 TB/s on byte traffic.
-template <bool FROM_RAYS, bool VEC4>
+// CELLS = false (a small batch per body — training: the near list goes straight to the per-sample search, nobody reads the
+// cells): no cell of a near sample, no hash table, no per-cell counts.
+template <bool FROM_RAYS, bool VEC4, bool CELLS = true>
 __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
     const float* __restrict__ xyz, int xyz_stride, const float* __restrict__ rays, int ray_stride,
     const float* __restrict__ z, int K, const float* __restrict__ index, IndexDims d, int64_t N, float thr,
@@ -720,8 +724,10 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
     const int b = blockIdx.y;
     const float* gbox = index + (int64_t)b * d.total_floats() + d.body_off();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int s = threadIdx.x; s < HN; s += WARP_THREADS) { hkeys[s] = -1; hcnt[s] = 0; }
-    __syncthreads();
+    if (CELLS) {
+        for (int s = threadIdx.x; s < HN; s += WARP_THREADS) { hkeys[s] = -1; hcnt[s] = 0; }
+        __syncthreads();
+    }
     // each thread classifies CLS_ITERS samples and remembers its near ones; the list is then written with ONE
     // block-wide compaction (one scan, one global atomic, no barrier per iteration)
     constexpr int VS = VEC4 ? 4 : 1, STEPS = CLS_ITERS / VS;
@@ -809,7 +815,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
                         reinterpret_cast<float4*>(nbr_w)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
                         reinterpret_cast<int4*>(nbr_idx)[o] = make_int4(0, 0, 0, 0);
                     }
-                    if (near) {
+                    if (CELLS && near) {
                         cell = cell_of_inv(gbox, thr, G, cell_inv, px, py, pz);
                         const int slot = hash_slot(hkeys, cell);
                         if (slot >= 0) atomicAdd(&hcnt[slot], 1);
@@ -844,11 +850,12 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
         for (int it = 0; it < CLS_ITERS; ++it) {
             if ((near_bits >> it) & 1u) {
                 list[pos] = (int32_t)sample_of(it / VS, it % VS);
-                cells[pos] = my_cell[it];
+                if (CELLS) cells[pos] = my_cell[it];
                 ++pos;
             }
         }
     }
+    if (!CELLS) return;
     __syncthreads();
     for (int s = threadIdx.x; s < HN; s += WARP_THREADS)
         if (hkeys[s] >= 0) atomicAdd(cell_count + (int64_t)b * NCELL + hkeys[s], hcnt[s]);
@@ -1706,6 +1713,13 @@ extern "C" int64_t anr_warp_ws_ints(int bs, int64_t N) {
     return WarpWs::ints(bs, N);
 }
 
+extern "C" int anr_warp_ws_zero_range(int bs, int64_t N, int64_t* first_int_out, int64_t* ints_out) {
+    ANR_REQUIRE(bs > 0 && N > 0 && first_int_out && ints_out, ANR_E_BADARG, "anr_warp_ws_zero_range: bs=%d N=%lld", bs, (long long)N);
+    *first_int_out = WarpWs::count_off(bs, N);
+    *ints_out = WarpWs::zeroed_ints(bs, !(N < (int64_t)1 << 19 && !getenv("ANR_WARP_CELLS_ALWAYS")));
+    return 0;
+}
+
 extern "C" int anr_warp_points(const float* xyz, int xyz_stride, const float* rays, int ray_stride, const float* z,
                                int K, const void* knn_index, const float* ober2cano, const float* lbs_weights, int bs,
                                int V, int J, int64_t N, float dis_threshold, int skip_far, float* pts_out,
@@ -1783,33 +1797,34 @@ extern "C" int anr_warp_points_reuse(const float* xyz, int xyz_stride, const flo
         WarpWs w(ws, bs, N);
         const int G = grid_for(N);
         const int cells = G * G * G;
-        if (int rc = zero_fill(w.count, sizeof(int32_t) * WarpWs::zeroed_ints(bs), st, "anr_warp_points (zero)")) return rc;
+        // a small batch per body (training: 1,024 rays) goes straight to the per-sample search (see warp_search_kernel)
+        const bool small = N < (int64_t)1 << 19 && !getenv("ANR_WARP_CELLS_ALWAYS");
+        // (skip_far & 2: the caller has zeroed the counters — anr_warp_ws_zero_range — e.g. with the other fills of its step)
+        if (!(skip_far & 2))
+            if (int rc = zero_fill(w.count, sizeof(int32_t) * WarpWs::zeroed_ints(bs, !small), st, "anr_warp_points (zero)")) return rc;
         dim3 g1((unsigned)((N + CLS_ITERS * WARP_THREADS - 1) / (CLS_ITERS * WARP_THREADS)), bs);
         // four consecutive samples per thread where the shapes allow dword / 16-byte accesses (every shipped shape)
+        // ... and the pass is a stream over the 4-byte-per-sample arrays: the renderer's lean mode.  With the neighbour outputs
+        // (training) every sample also gets 48 bytes of 16-byte rows (point, neighbour ids, blend weights — zeros, or the coarse
+        // call's rows): there a thread per sample makes a wavefront's store 1 KB of consecutive rows, where four samples per
+        // thread make it 64 rows 64 bytes apart.
         const bool vec4 = xyz == nullptr && K % 4 == 0 && N % 4 == 0 && ((uintptr_t)z & 15) == 0 && ((uintptr_t)valid_mask_out & 3) == 0 &&
-                          ((uintptr_t)reuse_perm & 3) == 0;
-        if (vec4)
-            hipLaunchKernelGGL((warp_classify_kernel<true, true>), g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride, z,
-                               K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                               w.list, w.cells, w.count, w.cell_count, valid_mask_out,
-                               reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K, G,
-                               reinterpret_cast<const int4*>(reuse_nbr_idx), reinterpret_cast<const float4*>(reuse_nbr_w));
-        else if (xyz == nullptr)
-            hipLaunchKernelGGL((warp_classify_kernel<true, false>), g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride, z,
-                               K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                               w.list, w.cells, w.count, w.cell_count, valid_mask_out,
-                               reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K, G,
-                               reinterpret_cast<const int4*>(reuse_nbr_idx), reinterpret_cast<const float4*>(reuse_nbr_w));
-        else
-            hipLaunchKernelGGL((warp_classify_kernel<false, false>), g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride,
-                               z, K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,
-                               w.list, w.cells, w.count, w.cell_count, valid_mask_out, nullptr, nullptr, nullptr, 0, G, nullptr, nullptr);
+                          ((uintptr_t)reuse_perm & 3) == 0 && (nbr_w_out == nullptr || getenv("ANR_WARP_CLASSIFY_VEC4"));
+#define ANR_CLASSIFY(FR, V4, CL)                                                                                              \
+        hipLaunchKernelGGL((warp_classify_kernel<FR, V4, CL>), g1, dim3(WARP_THREADS), 0, st, xyz, xyz_stride, rays, ray_stride, z, \
+                           K, index, d, N, dis_threshold, reinterpret_cast<float4*>(pts_out), nbr_idx_out, nbr_w_out,         \
+                           w.list, w.cells, w.count, w.cell_count, valid_mask_out,                                            \
+                           reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K, G,                    \
+                           reinterpret_cast<const int4*>(reuse_nbr_idx), reinterpret_cast<const float4*>(reuse_nbr_w))
+        if (vec4)                { if (small) ANR_CLASSIFY(true, true, false);   else ANR_CLASSIFY(true, true, true); }
+        else if (xyz == nullptr) { if (small) ANR_CLASSIFY(true, false, false);  else ANR_CLASSIFY(true, false, true); }
+        else                     { if (small) ANR_CLASSIFY(false, false, false); else ANR_CLASSIFY(false, false, true); }
+#undef ANR_CLASSIFY
         if (int rc = check_launch("anr_warp_points (classify)")) return rc;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         int64_t gx = (cus + bs - 1) / bs;                                   // one persistent workgroup per CU in total
-        if (N < (int64_t)1 << 19 && !getenv("ANR_WARP_CELLS_ALWAYS")) {
-            // a small batch per body (training: 1,024 rays): straight to the per-sample search (see warp_search_kernel)
+        if (small) {
             const int64_t max_wg = (N + 64 * (WARP_THREADS / 64) - 1) / (64 * (WARP_THREADS / 64));
             if (gx > max_wg) gx = max_wg;
             const int group_bytes = bytes + (WARP_THREADS / 64) * GQ_BYTES;

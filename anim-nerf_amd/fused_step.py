@@ -46,7 +46,7 @@ from typing import Optional
 import torch
 
 from . import _lib, ops
-from .autograd import PARAM_KEYS, _cached_pack, weights_generation
+from .autograd import PARAM_KEYS, _cached_pack, _cached_pack_pair, weights_generation
 
 
 _TORCH_DRAWS = (torch.rand, torch.randn, torch.randn_like)
@@ -127,8 +127,8 @@ class ExplicitTrainStep:
 
     # ------------------------------------------------------------------------------------------------------------------
     def _mlp_pass(self, net, mode_id, pts, fg, bg, pack=None, frozen=False):
-        """compacted training forward of one network on pts[n,4] (+ the prior points as riders): -> state for the backward,
-        out_full[n + n_r, 4]"""
+        """compacted training forward of one network on pts[n,4] (+ the prior points as riders): -> state for the backward
+        (out_c[rows, 4]: the output of the listed rows, pos[n + n_r]: a sample's or rider's row)"""
         params = [dict(net.named_parameters())[k] for k in PARAM_KEYS]
         if pack is None:
             pack = _cached_pack(params, mode_id, False)
@@ -136,10 +136,11 @@ class ExplicitTrainStep:
         rows = count[1:2]
         # (frozen networks: nothing reads the saved activations — the weight gradients' operands — only the sign bits)
         out_c, act = ops.mlp_forward_save(pack, mode_id, pts_c, False, count=rows, bits_only=frozen)
-        out_full = ops.expand_rows(out_c, pos, -1e5)
-        return dict(net=net, params=params, index=index, pos=pos, pts_c=pts_c, count=count, rows=rows, out_c=out_c, act=act), out_full
+        # (the output stays compact: the compositor, its backward and the loss read a sample's row through `pos` — no expanded
+        # copy, anr_expand_rows, a launch and 32 B per sample in each pass)
+        return dict(net=net, params=params, index=index, pos=pos, pts_c=pts_c, count=count, rows=rows, out_c=out_c, act=act)
 
-    def _mlp_backward(self, st, mode_id, d_out_full, want_pts, keep, pack_b=None, frozen=False):
+    def _mlp_backward(self, st, mode_id, d_out_full, want_pts, keep, pack_b=None, frozen=False, wgrad_stream=None):
         """activation, weight (into the network's flat buffer) and — want_pts — point gradients of one compacted pass.
         The weight gradients feed nothing else in the step: they run on a stream of their own (`_wgrad_stream`) behind the
         backward chain, which goes on with the gradient towards the points; `keep` holds what that stream still reads."""
@@ -152,7 +153,7 @@ class ExplicitTrainStep:
         if frozen:                                                   # the gradient towards the points, and nothing else
             return ops.mlp_dpoints(pack_b, mode_id, dact, st["pts_c"], count=rows)
         main = torch.cuda.current_stream(self.dev)
-        side = self._wgrad_stream
+        side = wgrad_stream if wgrad_stream is not None else self._wgrad_stream
         side.wait_stream(main)                                       # (the fork is HERE: the weight gradients wait for dact only)
 
         def weight_gradients():
@@ -178,8 +179,8 @@ class ExplicitTrainStep:
         for k in ("rgb", "acc", "rgb_fine", "acc_fine", "target_rgb", "target_alpha", "quads", "quads_fine"):
             v = t.get(k)
             setattr(a, k, None if v is None else v.data_ptr())
-        for k in ("s", "s_fine"):
-            setattr(a, k, t.get(k))                              # raw addresses: column 3 of the rider rows
+        for k in ("s", "s_fine", "s_count", "s_count_fine"):
+            setattr(a, k, t.get(k))                              # raw addresses: column 3 of the pass's rows, its row count
         for k in ("R", "prior_rows", "nv", "normal_sets", "quad_rows", "n_fg", "n_bg", "s_stride"):
             setattr(a, k, int(consts.get(k, 0)))
         for k in ("k", "delta", "lambda_alphas", "lambda_foreground", "lambda_background", "lambda_normals"):
@@ -208,10 +209,11 @@ class ExplicitTrainStep:
         refine = False
         table = tr.body_model_params if (tr.body_model_params is not None and frame_idx is not None) else None
 
-        # ---- gradient buffers: the reducer's flat buffers are the destination of everything (zeroed by the library's fill)
+        # ---- gradient buffers: the reducer's flat buffers are the destination of everything (zeroed with the step's other
+        # fills, below)
         tr.reducer.prepare(zero=False)
-        for flat in ([tr.reducer.whole] if tr.reducer.whole is not None else tr.reducer.flat):
-            ops.zero_fill(flat)
+        if table is not None:
+            refine = all(getattr(table, n).weight.requires_grad for n in table.param_names)
 
         want_normals = hp.lambda_normals != 0
         jitter = perturb > 0
@@ -241,23 +243,42 @@ class ExplicitTrainStep:
         # step's random numbers (one launch + the counter's; the coarse depths are their first consumer) and the four weight
         # packs (the first network pass is theirs) — six launches, ~45 us, off the front of the step's chain (round 5).
         # (Forward packs first: a backward pack marks the generation.)
+        # Every accumulator and counter of the step is filled HERE, in one launch (anr_zero_segments): the flat gradient
+        # buffers, the two neighbour searches' counters, the pose chain's accumulators — seven fills, five of them between
+        # launches of the step's chain, before round 5.
         nets = []
+        V = bm.lbs_weights.shape[0]
         self._wgrad_stream.wait_stream(main)
         with torch.cuda.stream(self._wgrad_stream):
+            fills = list([tr.reducer.whole] if tr.reducer.whole is not None else tr.reducer.flat)
+            warp_ws_c, z0 = ops.warp_workspace(bs, R * Kc, dev)
+            warp_ws_f, z1 = ops.warp_workspace(bs, R * K, dev)
+            fills += [z0, z1]
+            acc_buf = frame_ws = None
+            if refine:
+                acc_buf = torch.empty(bs * V * 16 + bs * R * 8, dtype=torch.float32, device=dev)
+                frame_ws, z2 = ops.frame_backward_workspace(bs, V, dev)
+                fills += [acc_buf, z2]
+            quads4 = None
+            if want_normals:                                         # the regulariser's points as tangent-mode quads: the draws write them
+                n_pair = 2 * m.verts_template.numel() // 3
+                n_pad = -(-n_pair // 16) * 16
+                quads4 = torch.empty(4 * n_pad, 4, dtype=torch.float32, device=dev)
+                fills.append(quads4[4 * n_pair:])
+            ops.zero_segments(fills)
             draws = ops.train_draws(self.draw_state, n_t=bs * R * Kc if jitter else 0, t_scale=float(perturb),
                                     n_nc=bs * R * Kc if noisy else 0, n_u=bs * R * Kf if jitter else 0, n_nf=bs * R * K if noisy else 0,
                                     noise_scale=float(vr.noise_std), verts_template=m.verts_template if want_normals else None,
-                                    point_scale=hp.dis_threshold * 0.5, neighbour_scale=hp.epsilon)
-            for net in (m.nerf, m.nerf_fine):
-                params = [dict(net.named_parameters())[k] for k in PARAM_KEYS]
-                nets.append((net, params, _cached_pack(params, mode_id, False, frozen=frozen)))
-            front_ready = torch.cuda.Event()                             # the draws and the forward packs
+                                    point_scale=hp.dis_threshold * 0.5, neighbour_scale=hp.epsilon, quads=quads4)
+            both = [[dict(net.named_parameters())[k] for k in PARAM_KEYS] for net in (m.nerf, m.nerf_fine)]
+            packs_f = _cached_pack_pair(both[0], both[1], mode_id, False, frozen=frozen)        # (one launch for the two networks)
+            nets = [(net, params, pack) for net, params, pack in zip((m.nerf, m.nerf_fine), both, packs_f)]
+            front_ready = torch.cuda.Event()                             # the fills, the draws and the forward packs
             front_ready.record(self._wgrad_stream)
-            packs_b = []
-            for net, params, _ in nets:
-                if not frozen:
+            if not frozen:
+                for params in both:
                     weights_generation(params[0], backward=True)
-                packs_b.append(_cached_pack(params, mode_id, True, frozen=frozen))
+            packs_b = list(_cached_pack_pair(both[0], both[1], mode_id, True, frozen=frozen))
             packs_b_ready = torch.cuda.Event()
             packs_b_ready.record(self._wgrad_stream)
         self.last_draws = draws
@@ -273,7 +294,7 @@ class ExplicitTrainStep:
 
             def normals_forward():
                 with torch.cuda.stream(self._side):
-                    pts4 = box["pts4"] = ops.tangent_quads(pair, n_pad)
+                    pts4 = box["pts4"] = quads4
                     for net, params, pack in nets:
                         out_t, act_t = ops.mlp_forward_save(pack, mode_id, pts4, sigma_only=True, tangent=True)
                         tan.append((net, params, act_t, out_t.view(n_pad, 4)))
@@ -301,7 +322,7 @@ class ExplicitTrainStep:
             # fork, next to the frame set-up's small ones: 3.66 / 1.58-1.83 ms per step against 3.61 / 1.56.)
             def normals_forward():
                 with torch.cuda.stream(self._side):
-                    pts4 = box["pts4"] = ops.tangent_quads(pair, n_pad)
+                    pts4 = box["pts4"] = quads4
                     for net, params, pack in nets:
                         out_t, act_t = ops.mlp_forward_save(pack, mode_id, pts4, sigma_only=True, tangent=True)
                         tan.append((net, params, act_t, out_t.view(n_pad, 4)))
@@ -326,7 +347,9 @@ class ExplicitTrainStep:
                 pts4 = box["pts4"]
                 g4 = ops.mlp_head_grad(box["d_quads"][i].reshape(-1), None, None, pts4, pts4.shape[0], True)
                 dact = ops.mlp_backward(packs_b[i], mode_id, g4, act_t, sigma_only=True, tangent=True)
-                tan_grads.append((net, ops.mlp_wgrad(mode_id, act_t, dact, box["enc4"], g4, sigma_only=True, tangent=True, background=self.parallel)))
+                # (sigma only: the tensors behind sigma.bias get nothing from this branch — neither written nor added below)
+                tan_grads.append((net, ops.mlp_wgrad(mode_id, act_t, dact, box["enc4"], g4, sigma_only=True, tangent=True, background=self.parallel,
+                                                     no_fill=True)))
                 keep.append((g4, dact))
 
             def normals_second_network():
@@ -338,7 +361,6 @@ class ExplicitTrainStep:
         rays_w = rays.view(bs, R, 8)
         if table is not None:
             w = {n: getattr(table, n).weight for n in table.param_names}
-            refine = all(v.requires_grad for v in w.values())
             tables, fidx = (w["betas"], w["global_orient"], w["body_pose"], w["transl"]), frame_idx
         else:
             p = body_model_params
@@ -361,28 +383,28 @@ class ExplicitTrainStep:
         main.wait_event(front_ready)                                 # the jitter (and, further down, the forward weight packs)
         steps = vr._table(dev, "steps", Kc)
         zc = ops.sample_coarse(rays_b, steps, draws["t_rand"].view(bs * R, Kc) if jitter else None).view(bs, R, Kc)
-        pts_c, nidx_c, nw_c = ops.warp_points(index, o2c, lbs, thr, rays=rays_b, z=zc, skip_far=True, neighbours=True)
+        pts_c, nidx_c, nw_c = ops.warp_points(index, o2c, lbs, thr, rays=rays_b, z=zc, skip_far=True, neighbours=True, workspace=warp_ws_c)
         if want_normals:
             normals_forward()
             normals_first_network()
         n_r = bs * ((fg_points.shape[1] if fg_points is not None else 0) + (bg_points.shape[1] if bg_points is not None else 0))
-        st_c, out_c = self._mlp_pass(m.nerf, mode_id, pts_c.view(-1, 4), fg_points, bg_points, nets[0][2], frozen)
+        st_c = self._mlp_pass(m.nerf, mode_id, pts_c.view(-1, 4), fg_points, bg_points, nets[0][2], frozen)
         flat_rays = rays_b.view(bs * R, 8)
         noise_c = draws["noise_c"].view(bs * R, Kc) if noisy else None
-        w_c, rgb_c, dep_c, acc_c = ops.composite(out_c[:n_c].view(bs * R, Kc, 4), zc.view(bs * R, Kc), flat_rays, vr.white_bkgd,
-                                                 noise=noise_c, want_weights=True)
+        w_c, rgb_c, dep_c, acc_c = ops.composite(st_c["out_c"], zc.view(bs * R, Kc), flat_rays, vr.white_bkgd, noise=noise_c,
+                                                 want_weights=True, pos=st_c["pos"])
         # ---- fine pass: importance samples + merge, the coarse samples' warp rows copied by the merge's permutation
         u = draws["u_fine"].view(bs * R, Kf) if jitter else vr._table(dev, "u", Kf)
         zs, perm = ops.sample_fine_merge(zc.view(bs * R, Kc), w_c, u, want_perm=True, perm_u8=True)
         zs = zs.view(bs, R, K)
         pts_f, nidx_f, nw_f = ops.warp_points(index, o2c, lbs, thr, rays=rays_b, z=zs, skip_far=True, neighbours=True,
-                                              reuse=(pts_c, None, perm, nidx_c, nw_c))
+                                              reuse=(pts_c, None, perm, nidx_c, nw_c), workspace=warp_ws_f)
         if want_normals:
             normals_second_network()
-        st_f, out_f = self._mlp_pass(m.nerf_fine, mode_id, pts_f.view(-1, 4), fg_points, bg_points, nets[1][2], frozen)
+        st_f = self._mlp_pass(m.nerf_fine, mode_id, pts_f.view(-1, 4), fg_points, bg_points, nets[1][2], frozen)
         noise_f = draws["noise_f"].view(bs * R, K) if noisy else None
-        _, rgb_f, dep_f, acc_f = ops.composite(out_f[:n_f].view(bs * R, K, 4), zs.view(bs * R, K), flat_rays, vr.white_bkgd,
-                                               noise=noise_f, want_weights=False)
+        _, rgb_f, dep_f, acc_f = ops.composite(st_f["out_c"], zs.view(bs * R, K), flat_rays, vr.white_bkgd, noise=noise_f,
+                                               want_weights=False, pos=st_f["pos"])
 
         if want_normals:
             main.wait_event(box["quads_ready"])                      # the loss values read the quads
@@ -395,7 +417,9 @@ class ExplicitTrainStep:
         d_out_c = torch.empty(n_c + n_r, 4, dtype=torch.float32, device=dev)
         d_out_f = torch.empty(n_f + n_r, 4, dtype=torch.float32, device=dev)
         if n_r:
-            t["s"], t["s_fine"] = out_c.data_ptr() + (4 * n_c + 3) * 4, out_f.data_ptr() + (4 * n_f + 3) * 4
+            # the prior points' sigmas: the last n_r of the listed rows of each pass (count[0] of them, on the device)
+            t["s"], t["s_fine"] = st_c["out_c"].data_ptr() + 12, st_f["out_c"].data_ptr() + 12
+            t["s_count"], t["s_count_fine"] = st_c["count"].data_ptr(), st_f["count"].data_ptr()
             consts.update(prior_rows=bs, n_fg=fg_points.shape[1] if fg_points is not None else 0,
                           n_bg=bg_points.shape[1] if bg_points is not None else 0, s_stride=4)
         if want_normals:
@@ -416,14 +440,11 @@ class ExplicitTrainStep:
         _lib.check(lib.anr_train_loss_backward(C.byref(args), ops._ptr(one), C.byref(g), ops._stream(vals)), "anr_train_loss_backward")
 
         # ---- backward: fine pass, the merge, coarse pass, coarse depths, frame chain (the normals' went with their forward)
-        acc_buf = None
         d_o2c = d_rays = None
         if refine:
-            V = o2c.shape[1]
-            acc_buf = ops.zero_fill(torch.empty(bs * V * 16 + bs * R * 8, dtype=torch.float32, device=dev))
             d_o2c, d_rays = acc_buf[:bs * V * 16].view(bs, V, 4, 4), acc_buf[bs * V * 16:].view(bs, R, 8)
-        res = ops.composite_backward(out_f[:n_f].view(bs * R, K, 4), zs.view(bs * R, K), flat_rays, vr.white_bkgd, d_rgb_f, None, d_acc_f,
-                                     noise=noise_f, want_dz=refine, out=d_out_f)
+        res = ops.composite_backward(st_f["out_c"], zs.view(bs * R, K), flat_rays, vr.white_bkgd, d_rgb_f, None, d_acc_f,
+                                     noise=noise_f, want_dz=refine, out=d_out_f, pos=st_f["pos"])
         dz_f = dfar_f = None
         if refine:
             _, dz_f, dfar_f = res
@@ -434,18 +455,26 @@ class ExplicitTrainStep:
             dzw_f = ops.warp_backward_acc(d_pts_f, rays_b, zs, o2c, nidx_f, nw_f, d_o2c, d_rays, pos=st_f["pos"])
             dz_c_from_fine = ops.merge_backward2(dzw_f.view(bs * R, K), dz_f, perm, Kc)
         normals_joined = False
+        n_sigma = lib.anr_mlp_wgrad_sigma_floats()
+
+        def add_normals():                                           # both networks' share of the regulariser: one launch
+            ops.add_segments([(net.grad_sink.flat[:n_sigma], tg[:n_sigma]) for net, tg in tan_grads])
+
         if at_split is not None and not frozen:
             main.wait_stream(self._wgrad_stream)                     # the fine render pass's weight gradients
             if want_normals:                                         # (both networks' share of the regulariser: 0 + t + r == 0 + r + t)
                 main.wait_stream(self._side)
-                for net, tg in tan_grads:
-                    ops.add_inplace(net.grad_sink.flat, tg)
+                add_normals()
                 normals_joined = True
             at_split()
             self._wgrad_stream.wait_stream(main)                     # (the side stream starts the second capture behind the first's end)
-        res = ops.composite_backward(out_c[:n_c].view(bs * R, Kc, 4), zc.view(bs * R, Kc), flat_rays, vr.white_bkgd, d_rgb_c, None, d_acc_c,
-                                     noise=noise_c, want_dz=refine, out=d_out_c)
-        d_pts_c = self._mlp_backward(st_c, mode_id, d_out_c, refine, keep, packs_b[0], frozen)
+        res = ops.composite_backward(st_c["out_c"], zc.view(bs * R, Kc), flat_rays, vr.white_bkgd, d_rgb_c, None, d_acc_c,
+                                     noise=noise_c, want_dz=refine, out=d_out_c, pos=st_c["pos"])
+        # (the coarse pass's weight gradients on the normals branch's stream, long idle by now, instead of behind the fine
+        # pass's on theirs — the weight gradients' stream is what a 16-frame step ends on: 3.24 -> 3.08 ms, same box;
+        # all split-K slices for either pass instead of half: 3.10-3.15, gpurun_out/r05/ab_wgrad_streams.txt)
+        coarse_wgrad_stream = self._side if (self.parallel and at_split is None and not os.environ.get("ANR_STEP_COARSE_WGRAD_QUEUED")) else None
+        d_pts_c = self._mlp_backward(st_c, mode_id, d_out_c, refine, keep, packs_b[0], frozen, wgrad_stream=coarse_wgrad_stream)
         if refine:
             _, dz_c, dfar_c = res
             dzw_c = ops.warp_backward_acc(d_pts_c, rays_b, zc, o2c, nidx_c, nw_c, d_o2c, d_rays, pos=st_c["pos"])
@@ -453,15 +482,16 @@ class ExplicitTrainStep:
                                            dzw_c.view(bs * R, Kc), dz_c, dz_c_from_fine, dfar_c, dfar_f)
             c = m._chain_consts()
             grads = ops.frame_backward(betas, pose, transl, c["J0"], c["JS"], c["parents"], c["lbs_weights"], c["shapedirs"], c["posedirs"],
-                                       c["T_template"], rays_world=rays_w, d_o2c=d_o2c, d_rays=d_rays, chain_values=(A, g_inv))
+                                       c["T_template"], rays_world=rays_w, d_o2c=d_o2c, d_rays=d_rays, chain_values=(A, g_inv), workspace=frame_ws)
             wt = {n: getattr(table, n).weight for n in table.param_names}
             ops.scatter_frame_param_grads(frame_idx, grads, wt["global_orient"].shape[0], wt["betas"].shape[0], wt["betas"].grad,
                                           wt["global_orient"].grad, wt["body_pose"].grad, wt["transl"].grad)
         main.wait_stream(self._wgrad_stream)
+        if coarse_wgrad_stream is not None:
+            main.wait_stream(coarse_wgrad_stream)
         if want_normals and not normals_joined:                      # flat = render passes' + normals' (0 + r + t == 0 + t + r bit for bit)
             main.wait_stream(self._side)
-            for net, tg in tan_grads:
-                ops.add_inplace(net.grad_sink.flat, tg)
+            add_normals()
         keep.clear()
         for s in sinks:                                              # (three passes each went straight into the flat buffers)
             s.expected = s.done = 0

@@ -108,7 +108,8 @@ def smpl_forward(betas, pose, transl, v_template, shapedirs, posedirs, J_regress
 
 
 def frame_backward(betas, pose, transl, J0, JS, parents, lbs_weights, shapedirs, posedirs, T_template, rays_world=None,
-                   d_o2c=None, d_rays=None, vertex_joint_mask=None, forward_mode: bool = False, chain_values=None) -> torch.Tensor:
+                   d_o2c=None, d_rays=None, vertex_joint_mask=None, forward_mode: bool = False, chain_values=None,
+                   workspace=None) -> torch.Tensor:
     """dL/d(betas | global_orient | body_pose | transl)[bs,85] of the per-frame chain (SMPL/LBS, root frame, ober2cano) from
     dL/d ober2cano[bs,V,4,4] and / or dL/d rays_body[bs,R,8] (csrc/frame_bwd.hip).  forward_mode=True: the one-launch
     forward-mode kernel (one workgroup per frame and parameter), kept as the cross-check of the adjoint kernels."""
@@ -132,12 +133,14 @@ def frame_backward(betas, pose, transl, J0, JS, parents, lbs_weights, shapedirs,
         # chain_values = (joints_transform[bs,J,4,4], g_inv[bs,4,4]) of the forward pass: the per-vertex kernel reads them instead
         # of walking the 24-joint chain again in every workgroup
         A_fwd, g_inv = (None, None) if chain_values is None else (_dev(chain_values[0], "joints_transform"), _dev(chain_values[1], "g_inv"))
-        ws = torch.empty(lib.anr_frame_backward_ws_floats(bs, V), dtype=torch.float32, device=pose.device)
+        # workspace = frame_backward_workspace(bs, V) whose accumulators the caller has zeroed (zero_segments): no fill here
+        ws = workspace if workspace is not None else torch.empty(lib.anr_frame_backward_ws_floats(bs, V), dtype=torch.float32, device=pose.device)
         with _timed("frame_backward", bs):
             _lib.check(lib.anr_frame_backward_adjoint_values(
                 _ptr(betas), _ptr(pose), _ptr(transl), bs, _ptr(J0), _ptr(JS), _ptr(parents), _ptr(lbs_weights), _ptr(shapedirs),
                 _ptr(posedirs), V, _ptr(T_template), T_template.shape[0], _ptr(rays_world), rs, R, _ptr(d_o2c),
-                _ptr(d_rays), _ptr(A_fwd), _ptr(g_inv), _ptr(ws), _ptr(grads), _stream(grads)), "anr_frame_backward_adjoint")
+                _ptr(d_rays), _ptr(A_fwd), _ptr(g_inv), _ptr(ws), _ptr(grads), 1 if workspace is not None else 0, _stream(grads)),
+                "anr_frame_backward_adjoint")
         return grads
     with _timed("frame_backward", bs):
         _lib.check(lib.anr_frame_backward(_ptr(betas), _ptr(pose), _ptr(transl), bs, _ptr(J0), _ptr(JS), _ptr(parents),
@@ -309,8 +312,25 @@ def sample_coarse(rays: torch.Tensor, steps: torch.Tensor, t_rand: Optional[torc
     return z
 
 
+def frame_backward_workspace(bs: int, V: int, device):
+    """-> (workspace for frame_backward(workspace=), its leading slice the caller must zero before the call)"""
+    lib = _lib.load()
+    ws = torch.empty(lib.anr_frame_backward_ws_floats(bs, V), dtype=torch.float32, device=device)
+    return ws, ws[:lib.anr_frame_backward_ws_zero_floats(bs)]
+
+
+def warp_workspace(bs: int, N: int, device):
+    """-> (workspace for warp_points(workspace=), the slice of it the caller must zero before the call)"""
+    import ctypes as C
+    lib = _lib.load()
+    ws = torch.empty(lib.anr_warp_ws_ints(bs, N), dtype=torch.int32, device=device)
+    first, n = C.c_int64(0), C.c_int64(0)
+    _lib.check(lib.anr_warp_ws_zero_range(bs, N, C.byref(first), C.byref(n)), "anr_warp_ws_zero_range")
+    return ws, ws[first.value:first.value + n.value]
+
+
 def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays=None, z=None, debug=False,
-                skip_far=False, neighbours=False, two_pass=True, lean=False, reuse=None):
+                skip_far=False, neighbours=False, two_pass=True, lean=False, reuse=None, workspace=None):
     """models/anim_nerf.py:153-192.  Either xyz[bs,N,3|4] or (rays[bs,R,>=8], z[bs,R,K]).
     `index` = knn_index_build(posed verts).  Returns pts[bs,N,4] = (x_c, y_c, z_c, valid)
     (+ dist[bs,N,4], idx[bs,N,4] i32, blended[bs,N] if debug)."""
@@ -342,7 +362,8 @@ def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
         nidx = torch.empty(bs, N, 4, dtype=torch.int32, device=dev)
         nw = torch.empty(bs, N, 4, dtype=torch.float32, device=dev)
     # renderer mode: classify + compact the samples near the body, then search the compacted list
-    ws = (torch.empty(lib.anr_warp_ws_ints(bs, N), dtype=torch.int32, device=dev)
+    # (workspace = warp_workspace(bs, N)[0] with its counters zeroed by the caller: the call launches no fill of its own)
+    ws = ((workspace if workspace is not None else torch.empty(lib.anr_warp_ws_ints(bs, N), dtype=torch.int32, device=dev))
           if (skip_far and two_pass) else None)
     vmask = vindex = vcount = None
     if lean:
@@ -368,7 +389,8 @@ def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
             r_nidx, r_nw = _dev(reuse[3], "reuse nbr_idx", torch.int32), _dev(reuse[4], "reuse nbr_w")
     with _timed("warp_points", bs * N):
         _lib.check(lib.anr_warp_points_reuse(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(index), _ptr(o2c),
-                                             _ptr(lbs_weights), bs, V, J, N, float(dis_threshold), 1 if skip_far else 0,
+                                             _ptr(lbs_weights), bs, V, J, N, float(dis_threshold),
+                                             (3 if (workspace is not None and ws is not None) else 1) if skip_far else 0,
                                              _ptr(pts), _ptr(dist), _ptr(idx), _ptr(blended), _ptr(nidx), _ptr(nw), _ptr(ws),
                                              _ptr(vmask), _ptr(vindex), _ptr(vcount), _ptr(r_pts), _ptr(r_mask), _ptr(r_perm),
                                              r_k, _ptr(r_nidx), _ptr(r_nw), _stream(pts)),
@@ -408,6 +430,38 @@ def points_from_rays(rays: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
         _lib.check(lib.anr_points_from_rays(_ptr(rays), rays.shape[-1], _ptr(z), K, n, _ptr(pts), _stream(pts)),
                    "anr_points_from_rays")
     return pts
+
+
+def mlp_pack_pair(params_a: dict, params_b: dict, mode: int, backward: bool = False):
+    """mlp_pack of two networks of the plain architecture in ONE launch (anr_mlp_pack_pair / anr_mlp_bwd_pack_pair)."""
+    lib = _lib.load()
+    keep, sts = [], []
+    for params in (params_a, params_b):
+        st = AnrMlpParams()
+
+        def g(key):
+            t = _dev(params[key].detach(), key)
+            keep.append(t)
+            return t.data_ptr()
+        for i in range(8):
+            st.w_trunk[i] = g(f"xyz_encoding_{i+1}.0.weight")
+            st.b_trunk[i] = g(f"xyz_encoding_{i+1}.0.bias")
+        st.w_sigma, st.b_sigma = g("sigma.weight"), g("sigma.bias")
+        st.w_final, st.b_final = g("xyz_encoding_final.weight"), g("xyz_encoding_final.bias")
+        st.w_dir, st.b_dir = g("dir_encoding.0.weight"), g("dir_encoding.0.bias")
+        st.w_rgb, st.b_rgb = g("rgb.0.weight"), g("rgb.0.bias")
+        shapes = [(256, 63)] + [(256, 256)] * 3 + [(256, 319)] + [(256, 256)] * 3
+        for i, shp in enumerate(shapes):
+            if tuple(params[f"xyz_encoding_{i+1}.0.weight"].shape) != shp:
+                raise ValueError(f"xyz_encoding_{i+1}.0.weight: expected {shp}")
+        if tuple(params["dir_encoding.0.weight"].shape) != (128, 256) or tuple(params["rgb.0.weight"].shape) != (3, 128):
+            raise ValueError("head shapes must be dir_encoding [128,256], rgb [3,128] (no latent codes)")
+        sts.append(st)
+    nbytes = lib.anr_mlp_bwd_pack_bytes(mode & 0xff) if backward else lib.anr_mlp_pack_bytes(mode & 0xff)
+    pa, pb = (torch.empty(nbytes, dtype=torch.uint8, device=keep[0].device) for _ in range(2))
+    fn = lib.anr_mlp_bwd_pack_pair if backward else lib.anr_mlp_pack_pair
+    _lib.check(fn(C.byref(sts[0]), C.byref(sts[1]), mode & 0xff, _ptr(pa), _ptr(pb), _stream(pa)), "anr_mlp_pack_pair")
+    return pa, pb
 
 
 def mlp_pack(params: dict, mode: int, backward: bool = False, view_channels: int = 0) -> torch.Tensor:
@@ -482,7 +536,7 @@ _WGRAD_WS = {}
 
 def mlp_wgrad(mode: int, act: torch.Tensor, dact: torch.Tensor, enc: torch.Tensor, g4: torch.Tensor, sigma_only: bool = False,
               tangent: bool = False, accumulate_into: Optional[torch.Tensor] = None, count: Optional[torch.Tensor] = None,
-              background: bool = False):
+              background: bool = False, out: Optional[torch.Tensor] = None, no_fill: bool = False):
     """All 22 parameter gradients of one network from the saved activations, the activation gradients, the encoding matrix
     (encode64) and g4 = (dL/d rgb_pre, dL/d sigma): a flat fp32 tensor in the order of autograd.PARAM_KEYS (PyTorch
     [out][in] layouts).  Hand-written split-K MFMA GEMMs (csrc/mlp_wgrad.hip); n % 64 == 0."""
@@ -503,7 +557,11 @@ def mlp_wgrad(mode: int, act: torch.Tensor, dact: torch.Tensor, enc: torch.Tenso
             raise ValueError("accumulate_into must hold anr_mlp_wgrad_floats() floats")
         m |= _lib.ANR_MLP_FLAG_ACCUMULATE
     else:
-        grads = torch.empty(lib.anr_mlp_wgrad_floats(), dtype=torch.float32, device=act.device)
+        grads = out if out is not None else torch.empty(lib.anr_mlp_wgrad_floats(), dtype=torch.float32, device=act.device)
+        if grads.numel() != lib.anr_mlp_wgrad_floats() or not grads.is_contiguous():
+            raise ValueError("out must hold anr_mlp_wgrad_floats() floats")
+        if no_fill:                                        # sigma_only: floats behind anr_mlp_wgrad_sigma_floats() are left alone
+            m |= _lib.ANR_MLP_FLAG_NO_FILL
     with _timed("mlp_wgrad", n if count is None else count):
         if count is not None:                              # rows on the device (a multiple of 64 <= n); n = the buffers' rows
             _lib.check(lib.anr_mlp_wgrad_counted(m, _ptr(act), _ptr(dact), _ptr(enc), _ptr(g4), n, _ptr(count), _ptr(ws), _ptr(grads),
@@ -732,12 +790,19 @@ def grid_points(N: int, x_range, y_range, z_range, center: torch.Tensor, first: 
     return pts
 
 
-def composite(rgbs, z, rays, white_bkgd: bool, noise=None, want_weights: bool = True, valid=None):
+def composite(rgbs, z, rays, white_bkgd: bool, noise=None, want_weights: bool = True, valid=None, pos=None):
     """models/volume_rendering.py:131-160.  rgbs[R,K,4], z[R,K], rays[R,>=8].
-    valid[R,K] uint8 (from warp_points(lean=True)): samples with 0 count as (0,0,0,-1e5) and their rows are not read."""
+    valid[R,K] uint8 (from warp_points(lean=True)): samples with 0 count as (0,0,0,-1e5) and their rows are not read.
+    pos[R*K] int32 (training): rgbs = the rows of a compacted pass, looked up through pos (-1: an invalid sample, as above)."""
     lib = _lib.load()
     rgbs, z, rays = _dev(rgbs, "rgbs"), _dev(z, "z"), _dev(rays, "rays")
     R, K = z.shape
+    if pos is not None:
+        if valid is not None:
+            raise ValueError("composite: pos or valid, not both")
+        pos = _dev(pos, "pos", torch.int32)
+        if pos.numel() < R * K:
+            raise ValueError("composite: pos holds fewer than R K entries")
     dev = z.device
     w = torch.empty(R, K, dtype=torch.float32, device=dev) if want_weights else None
     rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
@@ -750,6 +815,12 @@ def composite(rgbs, z, rays, white_bkgd: bool, noise=None, want_weights: bool = 
     moved = R * (K * (20 if valid is None else 5) + 8 + 20 + (4 * K if want_weights else 0))
     if valid is not None:
         moved = None                  # rows of invalid samples are skipped: data-dependent, counted by the PMC passes only
+    if pos is not None:
+        with _timed("composite", R * K, None):
+            _lib.check(lib.anr_composite_indexed(_ptr(rgbs), _ptr(pos), _ptr(z), _ptr(rays), rays.shape[-1], _ptr(noise), R, K,
+                                                 1 if white_bkgd else 0, _ptr(w), _ptr(rgb), _ptr(depth), _ptr(acc), _stream(z)),
+                       "anr_composite_indexed")
+        return w, rgb, depth, acc
     with _timed("composite", R * K, moved):
         _lib.check(lib.anr_composite_masked(_ptr(rgbs), _ptr(z), _ptr(rays), rays.shape[-1], _ptr(noise), _ptr(valid), R, K,
                                             1 if white_bkgd else 0, _ptr(w), _ptr(rgb), _ptr(depth), _ptr(acc), _stream(z)),
@@ -758,9 +829,9 @@ def composite(rgbs, z, rays, white_bkgd: bool, noise=None, want_weights: bool = 
 
 
 def composite_backward(rgbs, z, rays, white_bkgd: bool, g_rgb, g_depth, g_acc, noise=None, g_weights=None,
-                       want_dz: bool = False, out: Optional[torch.Tensor] = None):
+                       want_dz: bool = False, out: Optional[torch.Tensor] = None, pos=None):
     """Backward of `composite`: -> d_rgbs[R,K,4] (and d_z[R,K], d_far[R] if want_dz).  out: a caller-owned buffer whose first
-    R K rows receive d_rgbs (the explicit training step keeps rider rows behind them)."""
+    R K rows receive d_rgbs (the explicit training step keeps rider rows behind them).  pos: as in `composite`."""
     lib = _lib.load()
     rgbs, z, rays = _dev(rgbs, "rgbs"), _dev(z, "z"), _dev(rays, "rays")
     g_rgb, g_depth, g_acc = (None if g is None else _dev(g, nm) for g, nm in ((g_rgb, "g_rgb"), (g_depth, "g_depth"), (g_acc, "g_acc")))
@@ -777,9 +848,10 @@ def composite_backward(rgbs, z, rays, white_bkgd: bool, g_rgb, g_depth, g_acc, n
     dz = torch.empty(R, K, dtype=torch.float32, device=z.device) if want_dz else None
     dfar = torch.empty(R, dtype=torch.float32, device=z.device) if want_dz else None
     with _timed("composite_backward", R * K):
-        _lib.check(lib.anr_composite_backward(_ptr(rgbs), _ptr(z), _ptr(rays), rays.shape[-1], _ptr(noise), R, K,
-                                              1 if white_bkgd else 0, _ptr(g_weights), _ptr(g_rgb), _ptr(g_depth),
-                                              _ptr(g_acc), _ptr(d), _ptr(dz), _ptr(dfar), _stream(d)),
+        _lib.check(lib.anr_composite_backward_indexed(_ptr(rgbs), None if pos is None else _ptr(_dev(pos, "pos", torch.int32)), _ptr(z),
+                                                      _ptr(rays), rays.shape[-1], _ptr(noise), R, K,
+                                                      1 if white_bkgd else 0, _ptr(g_weights), _ptr(g_rgb), _ptr(g_depth),
+                                                      _ptr(g_acc), _ptr(d), _ptr(dz), _ptr(dfar), _stream(d)),
                    "anr_composite_backward")
     return (d, dz, dfar) if want_dz else d
 
@@ -1069,6 +1141,40 @@ def add_inplace(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     return dst
 
 
+def add_segments(pairs) -> None:
+    """dst += src (fp32, equal sizes) for every (dst, src) of `pairs` in ONE launch (anr_add_segments)."""
+    import ctypes as C
+    lib = _lib.load()
+    pairs = [(d, s) for d, s in pairs if d.numel()]
+    for d, s in pairs:
+        if not (d.is_cuda and s.is_cuda and d.is_contiguous() and s.is_contiguous() and d.dtype == s.dtype == torch.float32
+                and d.numel() == s.numel() and d.device == s.device):
+            raise ValueError("add_segments: contiguous fp32 device tensors of equal size")
+    for i in range(0, len(pairs), 24):
+        part = pairs[i:i + 24]
+        n = len(part)
+        dst = (C.c_void_p * n)(*[d.data_ptr() for d, _ in part])
+        src = (C.c_void_p * n)(*[s_.data_ptr() for _, s_ in part])
+        nf = (C.c_int64 * n)(*[d.numel() for d, _ in part])
+        _lib.check(lib.anr_add_segments(dst, src, nf, n, _stream(part[0][0])), "anr_add_segments")
+
+
+def zero_segments(tensors) -> None:
+    """t.zero_() for every tensor of `tensors` (contiguous, on the current device) in ONE launch (anr_zero_segments)."""
+    import ctypes as C
+    lib = _lib.load()
+    ts = [t for t in tensors if t is not None and t.numel()]
+    for i in range(0, len(ts), 24):
+        part = ts[i:i + 24]
+        for t in part:
+            if not (t.is_cuda and t.is_contiguous() and t.device == part[0].device):
+                raise ValueError("zero_segments: contiguous tensors on one device")
+        n = len(part)
+        dst = (C.c_void_p * n)(*[t.data_ptr() for t in part])
+        nb = (C.c_int64 * n)(*[t.numel() * t.element_size() for t in part])
+        _lib.check(lib.anr_zero_segments(dst, nb, n, _stream(part[0])), "anr_zero_segments")
+
+
 def copy_segments(pairs) -> None:
     """dst.copy_(src) for every (dst, src) of `pairs` (contiguous tensors of equal byte size on the current device) in ONE launch
     of the library (anr_copy_segments): the batch of a training step moving into the buffers a captured step replays from."""
@@ -1092,7 +1198,7 @@ DRAW_STATE_WORDS = 35                                         # include/animnerf
 
 
 def train_draws(state: torch.Tensor, *, n_t=0, t_scale=1.0, n_nc=0, n_u=0, n_nf=0, noise_scale=1.0, verts_template=None,
-                point_scale=0.0, neighbour_scale=0.0):
+                point_scale=0.0, neighbour_scale=0.0, quads: Optional[torch.Tensor] = None):
     """Every random number of one training step in one launch (anr_train_draws): -> dict(t_rand[n_t], noise_c[n_nc],
     u_fine[n_u], noise_f[n_nf], n0, n1 [like verts_template], pair[2 x verts_template rows, 3]); absent ones None.
     state: int64[DRAW_STATE_WORDS] on the device = (seed, step counter, tickets: zero); the kernel advances the counter."""
@@ -1116,6 +1222,11 @@ def train_draws(state: torch.Tensor, *, n_t=0, t_scale=1.0, n_nc=0, n_u=0, n_nf=
         p.verts_template, p.n_v3 = vt.data_ptr(), vt.numel()
         p.point_scale, p.neighbour_scale = float(point_scale), float(neighbour_scale)
         p.n0, p.n1, p.pair = o["n0"].data_ptr(), o["n1"].data_ptr(), o["pair"].data_ptr()
+        if quads is not None:                                   # [>= 4 * pair rows, 4]: `pair` as tangent-mode quads (tangent_quads)
+            quads = _dev(quads, "quads")
+            if quads.numel() < 16 * o["pair"].shape[0]:
+                raise ValueError("train_draws: quads holds fewer than four rows per point of the pair")
+            p.quads = quads.data_ptr()
     if n_t + n_nc + n_u + n_nf + int(p.n_v3) == 0:               # perturb = 0 and no normals term: nothing random in the step
         return o
     _lib.check(lib.anr_train_draws(_ptr(state), C.byref(p), _stream(state)), "anr_train_draws")

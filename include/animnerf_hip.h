@@ -68,6 +68,10 @@ extern "C" {
  * anr_mlp_forward_save[_indexed]: keep only the ReLU sign bits (304 B per row instead of 5.2 KB; the data area of `act` is
  * left untouched).  anr_mlp_backward[_counted]: write only the pre-activation gradients of layers 1 and 5 (columns 0..255 and
  * 1024..1279 of `dact`) — what anr_mlp_denc reads on the way to the sample points. */
+/* anr_mlp_wgrad with ANR_MLP_FLAG_SIGMA_ONLY: the tensors behind sigma.bias — floats [anr_mlp_wgrad_sigma_floats(),
+ * anr_mlp_wgrad_floats()) of grads_out — are left alone instead of zero-filled (a caller that adds only the leading
+ * floats to its gradient buffer: one launch fewer) */
+#define ANR_MLP_FLAG_NO_FILL 0x10000
 #define ANR_MLP_FLAG_BITS_ONLY 0x8000
 #define ANR_MLP_FLAG_ENC_ONLY  0x8000
 
@@ -175,6 +179,10 @@ int anr_sample_coarse(const float* rays, int stride, const float* steps, const f
  *   two neighbouring cells) — instead of one pass in which a wavefront of 64 neighbouring rays searches for its few
  *   near samples.  Same results bit for bit. */
 int64_t anr_warp_ws_ints(int bs, int64_t N);
+/* skip_far & 2 (with ws): the caller has ALREADY zeroed the workspace's counters — ints [first, first + count) of ws, from
+ * anr_warp_ws_zero_range — e.g. together with the other fills of a training step (anr_zero_segments); the call then
+ * launches no fill of its own.  The range depends on (bs, N) only. */
+int anr_warp_ws_zero_range(int bs, int64_t N, int64_t* first_int_out, int64_t* ints_out);
 int anr_warp_points(const float* xyz, int xyz_stride,
                     const float* rays, int ray_stride, const float* z, int K,
                     const void* knn_index, const float* ober2cano, const float* lbs_weights,
@@ -253,6 +261,8 @@ typedef struct anr_mlp_params {
 } anr_mlp_params;
 
 int anr_mlp_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream);
+/* two networks (models/anim_nerf.py: nerf and nerf_fine, repacked after every optimiser step) in ONE launch */
+int anr_mlp_pack_pair(const anr_mlp_params* p_a, const anr_mlp_params* p_b, int mode, void* pack_a_out, void* pack_b_out, void* stream);
 /* use_view=True (the reference's class default, models/nerf.py:60-153; no shipped config selects it): the colour head reads
  * [xyz_encoding_final (256), Embedding(viewdir) (dir_channels = 3 + 6 freqs_dir)] -> 128 -> 3.  anr_mlp_pack_view takes
  * p->w_dir as [128][256 + dir_channels] (pack_out: anr_mlp_pack_bytes(mode | ANR_MLP_FLAG_VIEW) bytes) and
@@ -340,6 +350,8 @@ int anr_encode_backward(const float* pts, int pts_stride, const float* d_enc, in
 int anr_encode64(const float* pts, int pts_stride, int64_t n, int flags, void* enc_out, void* stream);
 int64_t anr_mlp_bwd_pack_bytes(int mode);
 int anr_mlp_bwd_pack(const anr_mlp_params* p, int mode, void* pack_out, void* stream);
+int anr_mlp_bwd_pack_pair(const anr_mlp_params* p_a, const anr_mlp_params* p_b, int mode, void* pack_a_out, void* pack_b_out,
+                          void* stream);
 int anr_mlp_backward(const void* bwd_pack, int mode, const float* g, const void* act, void* dact, int64_t n,
                      void* stream);
 /* ... entered at xyz_encoding_final instead of at the colour head: use_view=True (models/nerf.py:141-153) evaluates
@@ -387,7 +399,10 @@ int anr_frame_backward_adjoint_values(const float* betas, const float* pose, con
                                       const float* posedirs, int V, const float* T_template, int template_bs,
                                       const float* rays_world, int ray_stride, int R, const float* d_ober2cano,
                                       const float* d_rays_body, const float* joints_transform, const float* g_inv,
-                                      float* workspace, float* grads_out, void* stream);
+                                      float* workspace, float* grads_out, int flags, void* stream);
+/* flags & 1: the first anr_frame_backward_ws_zero_floats(bs) floats of workspace (the accumulators) are zero already — filled by
+ * the caller with the other fills of its step (anr_zero_segments) — and the call launches no fill of its own. */
+int64_t anr_frame_backward_ws_zero_floats(int bs);
 
 /* ---- a16 (part): weight and bias gradients of the MLP -----------------------------------------------------------
  * What autograd computes for the 22 parameter tensors of models/nerf.py:60-127 once the activation gradients exist:
@@ -400,6 +415,7 @@ int anr_frame_backward_adjoint_values(const float* betas, const float* pose, con
  *   xyz_encoding_1..8 {weight, bias}, sigma {w, b}, xyz_encoding_final {w, b}, dir_encoding {w, b}, rgb {w, b};
  * with ANR_MLP_FLAG_SIGMA_ONLY the tensors behind sigma.bias are zero-filled.  workspace[anr_mlp_wgrad_ws_floats(n)] fp32. */
 int64_t anr_mlp_wgrad_floats(void);
+int64_t anr_mlp_wgrad_sigma_floats(void);
 int64_t anr_mlp_wgrad_ws_floats(int64_t n);
 int anr_mlp_wgrad(int mode, const void* act, const void* dact, const void* enc, const float* g, int64_t n,
                   float* workspace, float* grads_out, void* stream);
@@ -522,6 +538,10 @@ typedef struct {
     int32_t s_stride;   /* floats between consecutive prior sigmas in s / s_fine: 0 or 1 = packed; 4 = column 3 of (r, g, b, sigma)
                            rows (s points at row 0's sigma), and then the gradient d.s / d.s_fine (pointing at row 0's r) is written
                            as whole rows (0, 0, 0, d sigma) */
+    const int32_t *s_count, *s_count_fine;   /* may be NULL.  Otherwise DEVICE counts: s / s_fine point at row 0 of a compacted pass's
+                           output (its sigma with s_stride 4) and the prior points are the LAST prior_rows (n_fg + n_bg) of its first
+                           s_count[0] rows (anr_compact_ordered_riders) — read where the network left them; the gradient rows d.s /
+                           d.s_fine are NOT offset (they belong to the expanded layout anr_mlp_head_grad gathers from) */
 } anr_loss_args;
 /* gradient destinations, same shapes as the inputs (NULL: not wanted); quads: all quad_rows rows are written */
 typedef struct {
@@ -563,6 +583,14 @@ int anr_composite_masked(const float* rgbs, const float* z, const float* rays, i
                          float* weights_out, float* rgb_out, float* depth_out, float* acc_out,
                          void* stream);
 
+/* ... on the COMPACTED output of a training pass: rows[n_valid*4] = the (r, g, b, sigma) rows of the valid samples only, as
+ * the network pass over anr_compact_ordered's list left them; pos[R*K] = a sample's row, or -1 for a sample the warp found
+ * invalid — which counts as (0, 0, 0, -1e5), models/anim_nerf.py:245-290.  Same values as anr_composite on the expanded rows
+ * (anr_expand_rows), without that launch. */
+int anr_composite_indexed(const float* rows, const int32_t* pos, const float* z, const float* rays, int stride, const float* noise,
+                          int64_t R, int K, int white_bkgd, float* weights_out, float* rgb_out, float* depth_out, float* acc_out,
+                          void* stream);
+
 /* ---- a16 (part): backward of anr_composite -------------------------------------------------------------
  * What autograd differentiates in models/volume_rendering.py:131-160: upstream gradients of the per-ray outputs
  * g_rgb[R*3], g_depth[R], g_acc[R] (each may be NULL = zero; and optionally of the weights, g_weights[R*K] or NULL) ->
@@ -573,6 +601,10 @@ int anr_composite_backward(const float* rgbs, const float* z, const float* rays,
                            int64_t R, int K, int white_bkgd, const float* g_weights, const float* g_rgb,
                            const float* g_depth, const float* g_acc, float* d_rgbs,
                            float* d_z /* [R*K] or NULL */, float* d_far /* [R] or NULL */, void* stream);
+/* ... with the inputs of anr_composite_indexed (pos may be NULL: anr_composite_backward); d_rgbs stays one row per sample */
+int anr_composite_backward_indexed(const float* rows, const int32_t* pos, const float* z, const float* rays, int stride,
+                                   const float* noise, int64_t R, int K, int white_bkgd, const float* g_weights, const float* g_rgb,
+                                   const float* g_depth, const float* g_acc, float* d_rgbs, float* d_z, float* d_far, void* stream);
 
 /* ---- a14: importance sampling + merge ---------------------------------------------------------------
  * models/volume_rendering.py:59-97 and :199-207: inverse-CDF samples over the Kc-1 mid-points
@@ -642,6 +674,9 @@ typedef struct {
     int64_t n_v3;
     float point_scale, neighbour_scale;
     float *n0, *n1, *pair;
+    float* quads;   /* may be NULL.  Otherwise [>= 4 (2 n_v3 / 3)][4]: the `pair` points as the tangent-mode operand of the network pass
+                       — four rows (x, y, z, 1) per point, what anr_tangent_quads makes of `pair` — written by the same launch (rows
+                       behind the last point are the caller's to zero) */
 } anr_draw_plan;
 #define ANR_DRAW_STATE_WORDS 35
 int anr_train_draws(int64_t* state, const anr_draw_plan* plan, void* stream);
@@ -696,10 +731,14 @@ int anr_zero_fill(void* ptr, int64_t bytes, void* stream);
  * on a second stream next to the render passes, joining the network's flat gradient buffer — what autograd's accumulation of
  * models/nerf.py:177-190's and the render passes' contributions into one .grad does (train.py:324-348) */
 int anr_add_inplace(float* dst, const float* src, int64_t n, void* stream);
+/* ... for n_segments <= 24 (dst, src, floats) triples in one launch (both networks' share of the regulariser) */
+int anr_add_segments(float* const* dst, const float* const* src, const int64_t* floats, int n_segments, void* stream);
 /* n (<= 24) device-to-device copies dst[i][0..bytes[i]) = src[i][...] in ONE launch; src / dst / bytes are HOST arrays (the table
  * travels in the kernel arguments).  The batch of a training step (train.py:324-331: rays, rgbs, alphas, the pose rows, the
  * prior points) moving into the fixed buffers a captured step replays from — one launch instead of one copy per tensor. */
 int anr_copy_segments(const void* const* src, void* const* dst, const int64_t* bytes, int n, void* stream);
+/* memset(dst[i], 0, bytes[i]) for n <= 24 device buffers in ONE launch (a step's accumulators and counters, all filled up front). */
+int anr_zero_segments(void* const* dst, const int64_t* bytes, int n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -864,6 +864,35 @@ def test_ordered_compaction_and_row_expansion(dev):
         assert torch.equal(ops.expand_rows(src[:, 0].contiguous(), pos, -1e5), ref[:, 3].where(pos < 0, src[:, 0][pos.clamp(min=0).long()]))
 
 
+def test_compositor_reads_compacted_rows_through_pos(dev):
+    """anr_composite_indexed / anr_composite_backward_indexed (the explicit step: the network pass's output stays compact) ==
+    anr_composite / anr_composite_backward on the rows expanded by anr_expand_rows, bit for bit (64 and 96 samples per ray: both
+    lane layouts; with and without sigma noise)."""
+    from anim_nerf_amd import ops
+    gen = torch.Generator().manual_seed(21)
+    for R, K, frac in ((37, 64, 0.3), (130, 96, 0.6), (5, 96, 0.0)):
+        n = R * K
+        pts = torch.rand(n, 4, generator=gen)
+        pts[:, 3] = (torch.rand(n, generator=gen) < frac).float()
+        index, pos, pts_c, count = ops.compact_ordered(pts.to(dev))
+        rows = torch.cat([torch.rand(pts_c.shape[0], 3, generator=gen), torch.randn(pts_c.shape[0], 1, generator=gen) * 20], -1).to(dev)
+        full = ops.expand_rows(rows, pos, -1e5)
+        z = torch.sort(1.5 + 2 * torch.rand(R, K, generator=gen), -1)[0].to(dev)
+        rays = torch.randn(R, 8, generator=gen).to(dev)
+        rays[:, 6], rays[:, 7] = 1.5, 3.5
+        for noise in (None, torch.randn(R, K, generator=gen).to(dev)):
+            for white in (True, False):
+                a = ops.composite(full.view(R, K, 4), z, rays, white, noise=noise, want_weights=True)
+                b = ops.composite(rows, z, rays, white, noise=noise, want_weights=True, pos=pos)
+                for x, y in zip(a, b):
+                    assert torch.equal(x, y)
+                g_rgb, g_acc = torch.randn(R, 3, generator=gen).to(dev), torch.randn(R, 1, generator=gen).to(dev)
+                da = ops.composite_backward(full.view(R, K, 4), z, rays, white, g_rgb, None, g_acc, noise=noise, want_dz=True)
+                db = ops.composite_backward(rows, z, rays, white, g_rgb, None, g_acc, noise=noise, want_dz=True, pos=pos)
+                for x, y in zip(da, db):
+                    assert torch.equal(x, y)
+
+
 def test_depth_sampling_backward_kernels(dev):
     """CoarseDepthFunction / FineMergeFunction (anr_sample_coarse_backward, anr_merge_backward) against autograd over the
     tensor-op forms of models/volume_rendering.py:29-56 and :199-207."""
