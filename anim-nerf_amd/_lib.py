@@ -83,6 +83,7 @@ SIGNATURES = {
     "anr_ober2cano": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _P]),
     "anr_knn_index_bytes": (_L, [_I]),
     "anr_knn_index_build": (_I, [_P, _P, _I, _I, _P, _P]),
+    "anr_knn_index_build_reach": (_I, [_P, _P, _I, _I, _F, _P, _P]),
     "anr_knn": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),
     "anr_knn_k": (_I, [_P, _P, _I, _I, _I, _L, _I, _P, _P, _P]),
     "anr_sample_coarse": (_I, [_P, _I, _P, _P, _L, _I, _P, _P]),

@@ -6,6 +6,7 @@ Per point  (HIP kernels):  forward(xyz) = warp (exact 4-NN + blend) -> fused enc
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -302,7 +303,9 @@ class AnimNeRF(nn.Module):
         """Spatial index over the current posed vertices (rebuilt when set_body_model /
         convert_to_body_model_space replace them)."""
         if self._knn_index is None or self._knn_index[0] is not self.verts:
-            self._knn_index = (self.verts, ops.knn_index_build(self.verts.detach(), self.knn_order))
+            # (with the reach mask for this model's validity radius: ANR_WARP_NO_REACH_MASK=1 builds the plain index — A/B, tests)
+            reach = 0.0 if os.environ.get("ANR_WARP_NO_REACH_MASK") else float(self.dis_threshold)
+            self._knn_index = (self.verts, ops.knn_index_build(self.verts.detach(), self.knn_order, reach=reach))
         return self._knn_index[1]
 
     def _warp_generic(self, xyz, want_transform=False, chunk=1 << 19):

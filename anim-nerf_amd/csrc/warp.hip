@@ -15,7 +15,8 @@
 // ober2cano 12 floats) stay in L2.
 //
 // Index layout per body (floats): x[Vp] y[Vp] z[Vp] | cluster boxes NC x 8 | super boxes NS x 8 | top boxes NT x 8 |
-// body box 8 | order[Vp] (int32: slot -> original vertex id).  Vp = 8 NC, NC = ceil(V/8), NS = ceil(NC/8), NT = ceil(NS/8).
+// body box 8 | order[Vp] (int32: slot -> original vertex id) | reach mask (1,024 words).  Vp = 8 NC, NC = ceil(V/8),
+// NS = ceil(NC/8), NT = ceil(NS/8).
 #include "anr_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -38,7 +39,8 @@ struct IndexDims {
     __host__ __device__ int body_off() const { return 3 * Vp + 8 * NC + 8 * NS + 8 * NT; }
     __host__ __device__ int order_off() const { return body_off() + 8; }
     __host__ __device__ int lds_floats() const { return order_off(); }
-    __host__ __device__ int total_floats() const { return order_off() + Vp; }
+    __host__ __device__ int reach_off() const { return order_off() + Vp; }           // the reach mask (RG^3 bits), see below
+    __host__ __device__ int total_floats() const { return reach_off() + 1024; }
 };
 inline IndexDims index_dims(int V) {
     IndexDims d;
@@ -51,30 +53,146 @@ inline IndexDims index_dims(int V) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-frame index build: one workgroup per body
-__global__ __launch_bounds__(256) void knn_index_build_kernel(const float* __restrict__ verts,
+// The reach mask: a 32^3 grid over the body's box padded by the validity radius `thr` the index was built for (stored in the
+// body box's 4th float; 0 = no mask); bit (ix, iy, iz) is set iff some vertex lies within thr of the CELL (box distance).  A
+// sample can only be valid if a vertex lies within dis_threshold of it (its blended distance is a convex combination of its
+// four neighbours' distances, models/anim_nerf.py:169-183) — i.e. only in a cell whose bit is set, for any dis_threshold <=
+// thr: the classify pass drops the others without a search.  60 % of a training batch's samples fall into the padded box, 6.5 %
+// are valid (profiles/r04/warp_small_batch_by_bodies.txt): the searches that only prove a sample invalid were most of the
+// per-sample search's work.
+constexpr int RG = 32;
+__device__ __forceinline__ float reach_cell_size(const float* gbox, float thr) {
+    const float ex = gbox[4] - gbox[0], ey = gbox[5] - gbox[1], ez = gbox[6] - gbox[2];
+    return (fmaxf(fmaxf(ex, ey), ez) + 2.0f * thr) * (1.0f / (float)RG);
+}
+// (ix, iy, iz) of a point, or -1 outside the padded cube the grid covers (such a point is farther than thr from the box)
+__device__ __forceinline__ int reach_cell(const float* gbox, float thr, float inv, float px, float py, float pz) {
+    const float fx = (px - gbox[0] + thr) * inv, fy = (py - gbox[1] + thr) * inv, fz = (pz - gbox[2] + thr) * inv;
+    if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)RG && fy < (float)RG && fz < (float)RG)) return -1;
+    return ((int)fx * RG + (int)fy) * RG + (int)fz;
+}
+
+// per-frame index build: one workgroup per body (blockIdx.x = 0), + one per body for the reach mask (blockIdx.x = 1, reach_thr
+// > 0), next to it on another CU.  The mask in two steps, both in LDS: the occupancy of the grid (a bit per cell that holds a
+// vertex), then its dilation by every cell offset whose BOX-TO-BOX distance is within thr — a superset of the cells within thr
+// of a vertex by at most one cell width, at the price of ~600 word operations per (x, y) row of 32 cells instead of a
+// distance test per (vertex, cell) pair (2.4 M of them: 0.2 ms per body as a first cut).
+constexpr int REACH_MAX_HW = 8;                // widest stencil (cells): beyond it the grid is too fine for the radius -> no mask
+constexpr int IB_THREADS = 1024;               // one cluster (8 vertices) / one row of the reach grid per thread
+__global__ __launch_bounds__(IB_THREADS) void knn_index_build_kernel(const float* __restrict__ verts,
                                                               const int32_t* __restrict__ order, IndexDims d,
-                                                              float* __restrict__ index) {
-    const int b = blockIdx.x;
+                                                              float* __restrict__ index, float reach_thr) {
+    const int b = blockIdx.y;
+    if (blockIdx.x > 0) {
+        static_assert(RG == 32, "a word of the mask = the 32 z-cells of one (x, y)");
+        const float* v = verts + (int64_t)b * d.V * 3;
+        __shared__ float red[6][IB_THREADS / 64];
+        __shared__ unsigned occ[RG * RG];
+        // a thread's vertices stay in registers between the two passes (V <= 16,384: MAX_NC clusters): every load of the pass in
+        // flight at once, not one trip to L2 per vertex
+        constexpr int PT = MAX_NC * CS / IB_THREADS;
+        float px[PT], py[PT], pz[PT];
+        float lo[3] = {FAR, FAR, FAR}, hi[3] = {-FAR, -FAR, -FAR};
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            const int i = k * IB_THREADS + threadIdx.x;
+            px[k] = py[k] = pz[k] = 0.0f;
+            if (i < d.V) { px[k] = v[i * 3 + 0]; py[k] = v[i * 3 + 1]; pz[k] = v[i * 3 + 2]; }
+        }
+#pragma unroll
+        for (int k = 0; k < PT; ++k)
+            if (k * IB_THREADS + (int)threadIdx.x < d.V) {
+                lo[0] = fminf(lo[0], px[k]); lo[1] = fminf(lo[1], py[k]); lo[2] = fminf(lo[2], pz[k]);
+                hi[0] = fmaxf(hi[0], px[k]); hi[1] = fmaxf(hi[1], py[k]); hi[2] = fmaxf(hi[2], pz[k]);
+            }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
+            if ((threadIdx.x & 63) == 0) { red[a][threadIdx.x >> 6] = lo[a]; red[3 + a][threadIdx.x >> 6] = hi[a]; }
+        }
+        for (int i = threadIdx.x; i < RG * RG; i += IB_THREADS) occ[i] = 0u;
+        __syncthreads();
+        float gbox[8];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {                          // (min / max are exact: the bits of the body box the other workgroup stores)
+            float l = red[a][0], h = red[3 + a][0];
+#pragma unroll
+            for (int w = 1; w < IB_THREADS / 64; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+            gbox[a] = l; gbox[4 + a] = h;
+        }
+        const float cs = reach_cell_size(gbox, reach_thr), inv = 1.0f / cs;
+#pragma unroll
+        for (int k = 0; k < PT; ++k)
+            if (k * IB_THREADS + (int)threadIdx.x < d.V) {
+                int c = reach_cell(gbox, reach_thr, inv, px[k], py[k], pz[k]);
+                if (c < 0) c = 0;                               // (cannot happen for a point of the box; a NaN vertex lands here)
+                atomicOr(&occ[c >> 5], 1u << (c & 31));
+            }
+        __syncthreads();
+        // cell offsets (dx, dy, dz) with box-to-box distance cs sqrt(sum max(|d| - 1, 0)^2) <= thr (+ the roundings of
+        // reach_cell on either side)
+        const float rho = (reach_thr * 1.001f + 1e-5f) * inv + 1e-3f, rho2 = rho * rho;
+        const int hw = (int)rho + 1;                           // |d| - 1 <= rho
+        unsigned* mask = reinterpret_cast<unsigned*>(index + (int64_t)b * d.total_floats() + d.reach_off());
+        for (int row = threadIdx.x; row < RG * RG; row += IB_THREADS) {
+            const int ix = row >> 5, iy = row & 31;
+            unsigned out = 0u;
+            if (hw <= REACH_MAX_HW) {
+                for (int dx = -hw; dx <= hw; ++dx) {
+                    const int sx = ix + dx;
+                    if (sx < 0 || sx >= RG) continue;
+                    const float ax = (float)max(abs(dx) - 1, 0);
+                    for (int dy = -hw; dy <= hw; ++dy) {
+                        const int sy = iy + dy;
+                        if (sy < 0 || sy >= RG) continue;
+                        const unsigned w = occ[sx * RG + sy];
+                        if (w == 0u) continue;
+                        const float ay = (float)max(abs(dy) - 1, 0), rest = rho2 - ax * ax - ay * ay;
+                        if (rest < 0.0f) continue;
+                        const int k = (int)sqrtf(rest) + 1;    // |dz| - 1 <= sqrt(rest)
+                        unsigned dil = w;
+                        for (int t = 1; t <= k; ++t) dil |= (w << t) | (w >> t);
+                        out |= dil;
+                    }
+                }
+            } else {
+                out = 0xffffffffu;
+            }
+            mask[row] = out;
+        }
+        return;
+    }
     const float* v = verts + (int64_t)b * d.V * 3;
     float* out = index + (int64_t)b * d.total_floats();
     int32_t* ord_out = reinterpret_cast<int32_t*>(out + d.order_off());
     __shared__ float cbox[MAX_NC][6];
     __shared__ float sbox[MAX_NC / SC][6];
+    __shared__ float tbox[MAX_NC / SC / TC + 1][6];
     for (int c = threadIdx.x; c < d.NC; c += blockDim.x) {
-        float lo[3] = {FAR, FAR, FAR}, hi[3] = {-FAR, -FAR, -FAR};
+        // (the 8 slot -> vertex ids first, then the 24 coordinates: two trips to L2 per cluster, not sixteen)
+        int src[CS];
+        float p[CS][3];
+#pragma unroll
         for (int i = 0; i < CS; ++i) {
             const int slot = c * CS + i;
-            float p[3] = {FAR, FAR, FAR};
-            int src = -1;
-            if (slot < d.V) {
-                src = order ? order[slot] : slot;
-                p[0] = v[src * 3 + 0]; p[1] = v[src * 3 + 1]; p[2] = v[src * 3 + 2];
+            src[i] = slot < d.V ? (order ? order[slot] : slot) : -1;
+        }
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[a]); hi[a] = fmaxf(hi[a], p[a]); }
+        for (int i = 0; i < CS; ++i) {
+            p[i][0] = p[i][1] = p[i][2] = FAR;
+            if (src[i] >= 0) { p[i][0] = v[src[i] * 3 + 0]; p[i][1] = v[src[i] * 3 + 1]; p[i][2] = v[src[i] * 3 + 2]; }
+        }
+        float lo[3] = {FAR, FAR, FAR}, hi[3] = {-FAR, -FAR, -FAR};
+#pragma unroll
+        for (int i = 0; i < CS; ++i) {
+            const int slot = c * CS + i;
+            if (src[i] >= 0) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[i][a]); hi[a] = fmaxf(hi[a], p[i][a]); }
             }
-            out[slot] = p[0]; out[d.Vp + slot] = p[1]; out[2 * d.Vp + slot] = p[2];
-            ord_out[slot] = src < 0 ? 0 : src;
+            out[slot] = p[i][0]; out[d.Vp + slot] = p[i][1]; out[2 * d.Vp + slot] = p[i][2];
+            ord_out[slot] = src[i] < 0 ? 0 : src[i];
         }
         float* bx = out + d.box_off() + c * 8;
 #pragma unroll
@@ -84,9 +202,14 @@ __global__ __launch_bounds__(256) void knn_index_build_kernel(const float* __res
     __syncthreads();
     for (int s = threadIdx.x; s < d.NS; s += blockDim.x) {
         float lo[3] = {FAR, FAR, FAR}, hi[3] = {-FAR, -FAR, -FAR};
-        for (int c = s * SC; c < min((s + 1) * SC, d.NC); ++c)
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], cbox[c][a]); hi[a] = fmaxf(hi[a], cbox[c][3 + a]); }
+        for (int k = 0; k < SC; ++k) {
+            const int c = s * SC + k;
+            if (c < d.NC) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], cbox[c][a]); hi[a] = fmaxf(hi[a], cbox[c][3 + a]); }
+            }
+        }
         float* bx = out + d.sbox_off() + s * 8;
 #pragma unroll
         for (int a = 0; a < 3; ++a) { bx[a] = lo[a]; bx[4 + a] = hi[a]; sbox[s][a] = lo[a]; sbox[s][3 + a] = hi[a]; }
@@ -95,23 +218,30 @@ __global__ __launch_bounds__(256) void knn_index_build_kernel(const float* __res
     __syncthreads();
     for (int t = threadIdx.x; t < d.NT; t += blockDim.x) {
         float lo[3] = {FAR, FAR, FAR}, hi[3] = {-FAR, -FAR, -FAR};
-        for (int q = t * TC; q < min((t + 1) * TC, d.NS); ++q)
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], sbox[q][a]); hi[a] = fmaxf(hi[a], sbox[q][3 + a]); }
+        for (int k = 0; k < TC; ++k) {
+            const int q = t * TC + k;
+            if (q < d.NS) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], sbox[q][a]); hi[a] = fmaxf(hi[a], sbox[q][3 + a]); }
+            }
+        }
         float* bx = out + d.tbox_off() + t * 8;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { bx[a] = lo[a]; bx[4 + a] = hi[a]; }
+        for (int a = 0; a < 3; ++a) { bx[a] = lo[a]; bx[4 + a] = hi[a]; tbox[t][a] = lo[a]; tbox[t][3 + a] = hi[a]; }
         bx[3] = 0.f; bx[7] = 0.f;
     }
-    if (threadIdx.x == 0) {
+    __syncthreads();
+    if (threadIdx.x == 0) {                                   // the body box: the union of the (<= 32) top boxes
         float lo[3] = {FAR, FAR, FAR}, hi[3] = {-FAR, -FAR, -FAR};
-        for (int q = 0; q < d.NS; ++q)
+        for (int t = 0; t < d.NT; ++t)
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], sbox[q][a]); hi[a] = fmaxf(hi[a], sbox[q][3 + a]); }
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], tbox[t][a]); hi[a] = fmaxf(hi[a], tbox[t][3 + a]); }
         float* bx = out + d.body_off();
 #pragma unroll
         for (int a = 0; a < 3; ++a) { bx[a] = lo[a]; bx[4 + a] = hi[a]; }
-        bx[3] = 0.f; bx[7] = 0.f;
+        bx[3] = reach_thr > 0.0f ? reach_thr : 0.f;          // the radius the reach mask holds for (0: none)
+        bx[7] = 0.f;
     }
 }
 
@@ -735,6 +865,11 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
     unsigned near_bits = 0;
     const uint32_t R32 = (uint32_t)(N / (K > 0 ? K : 1));
     const float cell_inv = 1.0f / cell_size(gbox, thr, G);
+    // the reach mask (knn_index_build_kernel), if the index carries one for a radius >= thr
+    const float reach_thr = gbox[3];
+    const bool masked = reach_thr >= thr;
+    const float reach_inv = masked ? 1.0f / reach_cell_size(gbox, reach_thr) : 0.0f;
+    const unsigned* __restrict__ reach = reinterpret_cast<const unsigned*>(index + (int64_t)b * d.total_floats() + d.reach_off());
     // flat index of the thread's sample (step, v)
     auto sample_of = [&](int step, int v) { return (((int64_t)blockIdx.x * STEPS + step) * WARP_THREADS + threadIdx.x) * VS + v; };
 #pragma unroll
@@ -781,6 +916,10 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
                 const int64_t o = (int64_t)b * N + n;
                 // farther than the threshold from the whole body -> cannot be valid (see warp_points_kernel)
                 near = box_d2(gbox, px, py, pz) < thr * thr;
+                if (masked && near) {                       // ... and from every vertex, unless its cell's bit says otherwise
+                    const int rc = reach_cell(gbox, reach_thr, reach_inv, px, py, pz);
+                    near = rc >= 0 && ((reach[rc >> 5] >> (rc & 31)) & 1u) != 0u;
+                }
                 bool reused = false;
                 if (FROM_RAYS && perm != nullptr) {
                     // fine pass: this sorted sample IS coarse sample p of the same ray (z_sorted[j] = cat(z_coarse, z_fine)
@@ -1698,13 +1837,19 @@ extern "C" int64_t anr_knn_index_bytes(int V) {
 
 extern "C" int anr_knn_index_build(const float* verts, const int32_t* order, int bs, int V, void* index_out,
                                    void* stream) {
+    return anr_knn_index_build_reach(verts, order, bs, V, 0.0f, index_out, stream);
+}
+
+extern "C" int anr_knn_index_build_reach(const float* verts, const int32_t* order, int bs, int V, float dis_threshold, void* index_out,
+                                         void* stream) {
     ANR_REQUIRE(verts && index_out, ANR_E_BADARG, "anr_knn_index_build: null pointer");
-    ANR_REQUIRE(bs > 0 && V >= 4, ANR_E_BADARG, "anr_knn_index_build: bs=%d V=%d", bs, V);
+    ANR_REQUIRE(bs > 0 && V >= 4 && dis_threshold >= 0.0f, ANR_E_BADARG, "anr_knn_index_build: bs=%d V=%d dis_threshold=%g", bs, V,
+                dis_threshold);
     ANR_REQUIRE(((uintptr_t)index_out & 15) == 0, ANR_E_ALIGN, "anr_knn_index_build: index_out must be 16-B aligned");
     IndexDims d = index_dims(V);
     ANR_REQUIRE(d.NC <= MAX_NC, ANR_E_SHAPE, "anr_knn_index_build: V=%d too large (max %d)", V, MAX_NC * CS);
-    hipLaunchKernelGGL(knn_index_build_kernel, dim3(bs), dim3(256), 0, (hipStream_t)stream, verts, order, d,
-                       reinterpret_cast<float*>(index_out));
+    hipLaunchKernelGGL(knn_index_build_kernel, dim3(dis_threshold > 0.0f ? 2 : 1, bs), dim3(IB_THREADS), 0, (hipStream_t)stream, verts, order, d,
+                       reinterpret_cast<float*>(index_out), dis_threshold);
     return check_launch("anr_knn_index_build");
 }
 

@@ -246,41 +246,82 @@ class ExplicitTrainStep:
         # Every accumulator and counter of the step is filled HERE, in one launch (anr_zero_segments): the flat gradient
         # buffers, the two neighbour searches' counters, the pose chain's accumulators — seven fills, five of them between
         # launches of the step's chain, before round 5.
-        nets = []
         V = bm.lbs_weights.shape[0]
-        self._wgrad_stream.wait_stream(main)
-        with torch.cuda.stream(self._wgrad_stream):
-            fills = list([tr.reducer.whole] if tr.reducer.whole is not None else tr.reducer.flat)
-            warp_ws_c, z0 = ops.warp_workspace(bs, R * Kc, dev)
-            warp_ws_f, z1 = ops.warp_workspace(bs, R * K, dev)
-            fills += [z0, z1]
-            acc_buf = frame_ws = None
-            if refine:
-                acc_buf = torch.empty(bs * V * 16 + bs * R * 8, dtype=torch.float32, device=dev)
-                frame_ws, z2 = ops.frame_backward_workspace(bs, V, dev)
-                fills += [acc_buf, z2]
-            quads4 = None
-            if want_normals:                                         # the regulariser's points as tangent-mode quads: the draws write them
-                n_pair = 2 * m.verts_template.numel() // 3
-                n_pad = -(-n_pair // 16) * 16
-                quads4 = torch.empty(4 * n_pad, 4, dtype=torch.float32, device=dev)
-                fills.append(quads4[4 * n_pair:])
-            ops.zero_segments(fills)
-            draws = ops.train_draws(self.draw_state, n_t=bs * R * Kc if jitter else 0, t_scale=float(perturb),
-                                    n_nc=bs * R * Kc if noisy else 0, n_u=bs * R * Kf if jitter else 0, n_nf=bs * R * K if noisy else 0,
-                                    noise_scale=float(vr.noise_std), verts_template=m.verts_template if want_normals else None,
-                                    point_scale=hp.dis_threshold * 0.5, neighbour_scale=hp.epsilon, quads=quads4)
-            both = [[dict(net.named_parameters())[k] for k in PARAM_KEYS] for net in (m.nerf, m.nerf_fine)]
-            packs_f = _cached_pack_pair(both[0], both[1], mode_id, False, frozen=frozen)        # (one launch for the two networks)
-            nets = [(net, params, pack) for net, params, pack in zip((m.nerf, m.nerf_fine), both, packs_f)]
-            front_ready = torch.cuda.Event()                             # the fills, the draws and the forward packs
-            front_ready.record(self._wgrad_stream)
-            if not frozen:
-                for params in both:
-                    weights_generation(params[0], backward=True)
-            packs_b = list(_cached_pack_pair(both[0], both[1], mode_id, True, frozen=frozen))
-            packs_b_ready = torch.cuda.Event()
-            packs_b_ready.record(self._wgrad_stream)
+        nets = draws = front_ready = packs_b = packs_b_ready = warp_ws_c = warp_ws_f = acc_buf = frame_ws = quads4 = None
+
+        begin = torch.cuda.Event()                                    # (the side stream forks HERE, whatever is issued first)
+        begin.record(main)
+
+        def front():
+            nonlocal nets, draws, front_ready, packs_b, packs_b_ready, warp_ws_c, warp_ws_f, acc_buf, frame_ws, quads4
+            self._wgrad_stream.wait_event(begin)
+            with torch.cuda.stream(self._wgrad_stream):
+                fills = list([tr.reducer.whole] if tr.reducer.whole is not None else tr.reducer.flat)
+                warp_ws_c, z0 = ops.warp_workspace(bs, R * Kc, dev)
+                warp_ws_f, z1 = ops.warp_workspace(bs, R * K, dev)
+                fills += [z0, z1]
+                acc_buf = frame_ws = None
+                if refine:
+                    acc_buf = torch.empty(bs * V * 16 + bs * R * 8, dtype=torch.float32, device=dev)
+                    frame_ws, z2 = ops.frame_backward_workspace(bs, V, dev)
+                    fills += [acc_buf, z2]
+                quads4 = None
+                if want_normals:                                         # the regulariser's points as tangent-mode quads: the draws write them
+                    n_pair = 2 * m.verts_template.numel() // 3
+                    n_pad = -(-n_pair // 16) * 16
+                    quads4 = torch.empty(4 * n_pad, 4, dtype=torch.float32, device=dev)
+                    fills.append(quads4[4 * n_pair:])
+                ops.zero_segments(fills)
+                draws = ops.train_draws(self.draw_state, n_t=bs * R * Kc if jitter else 0, t_scale=float(perturb),
+                                        n_nc=bs * R * Kc if noisy else 0, n_u=bs * R * Kf if jitter else 0, n_nf=bs * R * K if noisy else 0,
+                                        noise_scale=float(vr.noise_std), verts_template=m.verts_template if want_normals else None,
+                                        point_scale=hp.dis_threshold * 0.5, neighbour_scale=hp.epsilon, quads=quads4)
+                both = [[dict(net.named_parameters())[k] for k in PARAM_KEYS] for net in (m.nerf, m.nerf_fine)]
+                packs_f = _cached_pack_pair(both[0], both[1], mode_id, False, frozen=frozen)        # (one launch for the two networks)
+                nets = [(net, params, pack) for net, params, pack in zip((m.nerf, m.nerf_fine), both, packs_f)]
+                front_ready = torch.cuda.Event()                             # the fills, the draws and the forward packs
+                front_ready.record(self._wgrad_stream)
+                if not frozen:
+                    for params in both:
+                        weights_generation(params[0], backward=True)
+                packs_b = list(_cached_pack_pair(both[0], both[1], mode_id, True, frozen=frozen))
+                packs_b_ready = torch.cuda.Event()
+                packs_b_ready.record(self._wgrad_stream)
+
+        # ---- per-frame state (models/anim_nerf.py:108-151) from the parameter tables: table rows, SMPL, root frame, rays,
+        # ober2cano in two launches (ops.frame_setup), then the KNN index
+        rays_w = rays.view(bs, R, 8)
+        fs = index = None
+
+        def frame_state():
+            nonlocal fs, index
+            if table is not None:
+                w = {n: getattr(table, n).weight for n in table.param_names}
+                tables, fidx = (w["betas"], w["global_orient"], w["body_pose"], w["transl"]), frame_idx
+            else:
+                p = body_model_params
+                tables, fidx = (p["betas"].expand(bs, -1).contiguous(), p["global_orient"].expand(bs, -1).contiguous(),
+                                p["body_pose"].expand(bs, -1).contiguous(), p["transl"].expand(bs, -1).contiguous()), None
+            fs = ops.frame_setup(tables, fidx, m._chain_consts(), bm,
+                                 (m.verts_transform_template, m.shape_offsets_template, m.pose_offsets_template), rays_w)
+            m.shape_offsets, m.pose_offsets, m.joints_transform = fs["shape_offsets"], fs["pose_offsets"], fs["A"]
+            m.global_transform, m.verts, m.joints, m.verts_transform = fs["g_root"], fs["verts"], fs["joints"], fs["verts_transform"]
+            m._knn_index = None
+            m._refine = None
+            m.ober2cano_transform = fs["ober2cano"]
+            index = m.knn_index()
+
+        # (capture order = the order a replayed graph's nodes reach the GPU: ANR_STEP_FRONT_LATE puts the chain's first three
+        # launches ahead of the side stream's five)
+        if os.environ.get("ANR_STEP_FRONT_LATE"):
+            frame_state()
+            front()
+        else:
+            front()
+            frame_state()
+        betas, pose, transl, A, g_inv = fs["betas"], fs["pose"], fs["transl"], fs["A"], fs["g_inv"]
+        rays_b, o2c = fs["rays_body"], fs["ober2cano"]
+        lbs, thr = bm.lbs_weights, m.dis_threshold
         self.last_draws = draws
         if want_normals and frozen:
             # frozen networks: the regulariser has no parameter to reach (its points are template vertices + noise, its
@@ -355,29 +396,6 @@ class ExplicitTrainStep:
             def normals_second_network():
                 with torch.cuda.stream(self._side):
                     normals_backward(1)
-
-        # ---- per-frame state (models/anim_nerf.py:108-151) from the parameter tables: table rows, SMPL, root frame, rays,
-        # ober2cano in two launches (ops.frame_setup), then the KNN index
-        rays_w = rays.view(bs, R, 8)
-        if table is not None:
-            w = {n: getattr(table, n).weight for n in table.param_names}
-            tables, fidx = (w["betas"], w["global_orient"], w["body_pose"], w["transl"]), frame_idx
-        else:
-            p = body_model_params
-            tables, fidx = (p["betas"].expand(bs, -1).contiguous(), p["global_orient"].expand(bs, -1).contiguous(),
-                            p["body_pose"].expand(bs, -1).contiguous(), p["transl"].expand(bs, -1).contiguous()), None
-        fs = ops.frame_setup(tables, fidx, m._chain_consts(), bm,
-                             (m.verts_transform_template, m.shape_offsets_template, m.pose_offsets_template), rays_w)
-        betas, pose, transl, A, g_inv = fs["betas"], fs["pose"], fs["transl"], fs["A"], fs["g_inv"]
-        m.shape_offsets, m.pose_offsets, m.joints_transform = fs["shape_offsets"], fs["pose_offsets"], A
-        m.global_transform, m.verts, m.joints, m.verts_transform = fs["g_root"], fs["verts"], fs["joints"], fs["verts_transform"]
-        m._knn_index = None
-        m._refine = None
-        rays_b = fs["rays_body"]
-        o2c = fs["ober2cano"]
-        m.ober2cano_transform = o2c
-        index = m.knn_index()
-        lbs, thr = bm.lbs_weights, m.dis_threshold
 
         # ---- coarse pass
         main.wait_event(front_ready)                                 # the jitter (and, further down, the forward weight packs)

@@ -251,8 +251,10 @@ def morton_order(points: torch.Tensor) -> torch.Tensor:
     return torch.argsort(code, stable=True).to(torch.int32)
 
 
-def knn_index_build(verts: torch.Tensor, order: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Per-frame spatial index of posed vertices verts[bs,V,3] -> uint8[bs, anr_knn_index_bytes(V)]."""
+def knn_index_build(verts: torch.Tensor, order: Optional[torch.Tensor] = None, reach: float = 0.0) -> torch.Tensor:
+    """Per-frame spatial index of posed vertices verts[bs,V,3] -> uint8[bs, anr_knn_index_bytes(V)].
+    reach > 0: with the reach mask for validity radii <= reach (anr_knn_index_build_reach): warp_points(skip_far) drops the
+    samples no vertex can reach in its classify pass."""
     lib = _lib.load()
     verts = _dev(verts, "verts")
     bs, V, _ = verts.shape
@@ -260,7 +262,7 @@ def knn_index_build(verts: torch.Tensor, order: Optional[torch.Tensor] = None) -
         order = _dev(order, "order", torch.int32)
     nbytes = lib.anr_knn_index_bytes(V)
     index = torch.empty(bs, nbytes, dtype=torch.uint8, device=verts.device)
-    _lib.check(lib.anr_knn_index_build(_ptr(verts), _ptr(order), bs, V, _ptr(index), _stream(index)),
+    _lib.check(lib.anr_knn_index_build_reach(_ptr(verts), _ptr(order), bs, V, float(reach), _ptr(index), _stream(index)),
                "anr_knn_index_build")
     return index
 

@@ -136,6 +136,13 @@ int anr_ober2cano(const float* t_pose, const float* t_template,
  *   anr_knn: xyz[bs*N*3] -> dist[bs*N*4] (Euclidean, ascending), idx[bs*N*4] (int64, 0-based vertex id). */
 int64_t anr_knn_index_bytes(int V);
 int anr_knn_index_build(const float* verts, const int32_t* order, int bs, int V, void* index_out, void* stream);
+/* ... with the reach mask for validity radii up to dis_threshold (> 0): 32^3 bits over the body's box padded by dis_threshold,
+ * set where some vertex lies within dis_threshold of the cell.  anr_warp_points (skip_far with a workspace) called with a
+ * dis_threshold <= this one then drops the samples of unset cells in its classify pass — they cannot be valid
+ * (models/anim_nerf.py:169-183: the blended distance is a convex combination of the four neighbours' distances) — instead of
+ * searching their neighbours to find that out.  Same outputs bit for bit. */
+int anr_knn_index_build_reach(const float* verts, const int32_t* order, int bs, int V, float dis_threshold, void* index_out,
+                              void* stream);
 int anr_knn(const void* knn_index, const float* xyz, int bs, int V, int64_t N,
             float* dist_out, int64_t* idx_out, void* stream);
 /* d1_out[bs*N] = distance of xyz[bs*N*3] to the nearest vertex where that is below `radius`, +inf elsewhere: the same exact

@@ -248,6 +248,55 @@ def test_warp_two_pass_equals_one_pass(dev, smpl_table):
     assert torch.equal(one[..., 3], two[..., 3]) and torch.equal(one[one[..., 3] == 1], two[two[..., 3] == 1])
 
 
+def test_reach_mask_drops_only_samples_no_vertex_can_reach(dev, smpl_table):
+    """The index built with the reach mask (anr_knn_index_build_reach: a 32^3 grid of "some vertex within dis_threshold of this
+    cell") against the plain index: the classify pass of anr_warp_points lists FEWER samples for the search, and every output a
+    consumer reads — validity, canonical points, neighbour ids and blend weights of the valid samples, the lean list — carries
+    the same bits; training-shaped batch and a dense one (the cell-sorted path); a radius above the mask's falls back to the
+    box test."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import ops, synthetic as syn
+    m = seeded_model(smpl_table, 3, True, device=dev)
+    for bs, hw, n_rays, K in ((3, 128, 1024, 64), (1, 256, 256 * 256, 16)):
+        pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=40 + bs, bs=bs, pose_std=0.4).items()}
+        templ = {k: torch.from_numpy(v).to(dev) for k, v in syn.template_pose_params().items()}
+        c2w, focal, cen = syn.pinhole_camera(hw, hw)
+        full = ana.gen_rays(torch.from_numpy(c2w).to(dev), hw, hw, focal.tolist(), 0.1, 10.0, cen.tolist()).view(-1, 8)
+        gen = torch.Generator().manual_seed(5)
+        pick = torch.stack([torch.randperm(hw * hw, generator=gen)[:n_rays] for _ in range(bs)]).to(dev)
+        with torch.no_grad():
+            m.set_body_model(pose, templ)
+            rays = m.convert_to_body_model_space(full[pick].contiguous())
+            m.clac_ober2cano_transform()
+            z = ana.VolumeRenderer(n_coarse=K).sample_coarse(rays)
+            plain = ops.knn_index_build(m.verts, m.knn_order)
+            masked = ops.knn_index_build(m.verts, m.knn_order, reach=0.2)
+            nfl = m.knn_index().shape[1]
+            assert plain.shape == masked.shape and masked.shape[1] == nfl
+            bits = masked[:, -4096:].contiguous().view(torch.int32)
+            set_frac = sum(bin(int(w) & 0xffffffff).count("1") for w in bits.flatten().tolist()) / (bs * 32768)
+            assert 0.02 < set_frac < 0.6, set_frac                 # a body fills a small part of its padded box
+            # the tree itself is the same: everything but the mask (last 4 KB) and the radius in the body box's 4th float
+            Vp = -(-m.verts.shape[1] // 8) * 8
+            box3 = nfl - 4096 - 4 * Vp - 32 + 12
+            assert torch.equal(plain[:, :box3], masked[:, :box3]) and torch.equal(plain[:, box3 + 4:-4096], masked[:, box3 + 4:-4096])
+            assert masked[:, box3:box3 + 4].contiguous().view(torch.float32).eq(0.2).all() and not plain[:, box3:box3 + 4].any()
+            rest = (m.ober2cano_transform, m.body_model.lbs_weights)
+            for thr in (0.2, 0.1, 0.25):                            # 0.25 > the mask's radius: box test only
+                a = ops.warp_points(plain, *rest, thr, rays=rays, z=z, skip_far=True, neighbours=True)
+                b = ops.warp_points(masked, *rest, thr, rays=rays, z=z, skip_far=True, neighbours=True)
+                v = a[0][..., 3] == 1
+                assert torch.equal(a[0][..., 3], b[0][..., 3]) and 0.005 < v.float().mean() < 0.9
+                for x, y in zip(a, b):
+                    assert torch.equal(x[v], y[v])
+                la = ops.warp_points(plain, *rest, thr, rays=rays, z=z, skip_far=True, lean=True)
+                lb = ops.warp_points(masked, *rest, thr, rays=rays, z=z, skip_far=True, lean=True)
+                assert torch.equal(la[1], lb[1]) and torch.equal(la[3], lb[3])
+                n = int(la[3].item())
+                # (the list's order is the order its workgroups reached the counter in: compared as a set)
+                assert torch.equal(torch.sort(la[2][:n])[0], torch.sort(lb[2][:n])[0]) and torch.equal(la[0][la[1] == 1], lb[0][lb[1] == 1])
+
+
 @pytest.mark.parametrize("bs,n_rays,K", [(4, 1024, 64), (1, 77, 20), (3, 300, 33)])
 def test_warp_small_batch_group_search_is_bit_identical(dev, smpl_table, bs, n_rays, K, monkeypatch):
     """A training-shaped batch (random pixels, a few bodies in different poses) goes through warp_search_groups_kernel
