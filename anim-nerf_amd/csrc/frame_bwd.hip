@@ -487,32 +487,51 @@ __global__ __launch_bounds__(FB_THREADS) void frame_adjoint_kernel(
 // (1,024 threads per dot product of length 3 V = 20,670: 21 loads per thread instead of 81 — the kernel is a latency chain,
 // 42 us at 2 frames with 256; fixed-order tree: the same bits on every run)
 constexpr int FO_THREADS = 1024;
+// BT frames per workgroup: a blend-shape row (82 KB; 17 MB in all) is read once for BT frames — a workgroup per (row, frame)
+// read the 17 MB once per frame: 70 us at 16 frames (and the frames of a row placed back to back on one XCD walked the same
+// lines in lockstep, one channel at a time: 300 us).  Per (row, frame) the sum and its order are what they were.
+template <int BT>
 __global__ __launch_bounds__(FO_THREADS) void frame_offsets_kernel(const float* __restrict__ goff, const float* __restrict__ shapedirs,
                                                                    const float* __restrict__ posedirs, int V, float* __restrict__ H, int bs) {
-    __shared__ float sRed[FO_THREADS / 64];
-    // (the frames of one blend-shape row on consecutive workgroup ids of one XCD — ids go round the 8 XCDs: the row comes
-    // from HBM once and from that XCD's L2 for the other frames; with (row, frame) as the grid's (x, y) a 16-frame step read
-    // the 17 MB of pose blend shapes sixteen times: 70 us)
-    const int t = (int)blockIdx.x >> 3;
-    const int b = t % bs, f = (t / bs) * 8 + ((int)blockIdx.x & 7);
-    if (f >= FA_H) return;
-    const float* gb = goff + (int64_t)b * V * 3;
-    float s = 0.0f;
-    if (f < 207) {
-        const float* pd = posedirs + (int64_t)f * 3 * V;
-        for (int i = threadIdx.x; i < 3 * V; i += FO_THREADS) s += gb[i] * pd[i];
-    } else {
-        const int k = f - 207;
-        for (int i = threadIdx.x; i < 3 * V; i += FO_THREADS) s += gb[i] * shapedirs[(int64_t)i * FB_NB + k];
+    __shared__ float sRed[BT][FO_THREADS / 64];
+    const int f = blockIdx.x, b0 = (int)blockIdx.y * BT;
+    float s[BT];
+#pragma unroll
+    for (int t = 0; t < BT; ++t) s[t] = 0.0f;
+    const int n = 3 * V;
+    // (U iterations' loads in flight at a time — a loop of load, load, multiply-add is one trip to L2 per iteration: 21 trips)
+    constexpr int U = 8;
+    const float* row = f < 207 ? posedirs + (int64_t)f * n : shapedirs + (f - 207);
+    const int stride = f < 207 ? 1 : FB_NB;
+    for (int i0 = threadIdx.x; i0 < n; i0 += U * FO_THREADS) {
+        float p[U], g[U][BT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * FO_THREADS;
+            p[u] = i < n ? row[(int64_t)i * stride] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < BT; ++t) g[u][t] = (i < n && b0 + t < bs) ? goff[(int64_t)(b0 + t) * n + i] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i0 + u * FO_THREADS < n) {
+#pragma unroll
+                for (int t = 0; t < BT; ++t)
+                    if (b0 + t < bs) s[t] += g[u][t] * p[u];
+            }
     }
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = s;
+#pragma unroll
+    for (int t = 0; t < BT; ++t) {
+        const float w = wave_sum(s[t]);
+        if ((threadIdx.x & 63) == 0) sRed[t][threadIdx.x >> 6] = w;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < BT && b0 + (int)threadIdx.x < bs) {
+        const float* r = sRed[threadIdx.x];
         float t = 0.0f;
 #pragma unroll
-        for (int w = 0; w < FO_THREADS / 64; w += 4) t += (sRed[w] + sRed[w + 1]) + (sRed[w + 2] + sRed[w + 3]);
-        H[(int64_t)b * FA_H + f] = -t;
+        for (int w = 0; w < FO_THREADS / 64; w += 4) t += (r[w] + r[w + 1]) + (r[w + 2] + r[w + 3]);
+        H[(int64_t)(b0 + threadIdx.x) * FA_H + f] = -t;
     }
 }
 
@@ -599,7 +618,13 @@ extern "C" int anr_frame_backward_adjoint_values(const float* betas, const float
                        lbs_weights, T_template, template_bs == 1 ? (int64_t)0 : (int64_t)V * 16, rays_world, ray_stride, R, d_ober2cano,
                        d_rays_body, V, nvb, acc, goff, joints_transform, g_inv);
     if (d_ober2cano)
-        hipLaunchKernelGGL(frame_offsets_kernel, dim3((unsigned)(((FA_H + 7) & ~7) * bs)), dim3(FO_THREADS), 0, st, goff, shapedirs, posedirs, V, H, bs);
+    {
+        // (frames per workgroup, 16 frames: 1 -> 153 us, 2 -> 49, 4 -> 66 next to the weight gradients' tail; 2 frames: 43 / 29)
+        const int bt = bs >= 3 ? 4 : bs;
+        if (bt >= 4) hipLaunchKernelGGL(frame_offsets_kernel<4>, dim3(FA_H, (bs + 3) / 4), dim3(FO_THREADS), 0, st, goff, shapedirs, posedirs, V, H, bs);
+        else if (bt == 2) hipLaunchKernelGGL(frame_offsets_kernel<2>, dim3(FA_H, (bs + 1) / 2), dim3(FO_THREADS), 0, st, goff, shapedirs, posedirs, V, H, bs);
+        else hipLaunchKernelGGL(frame_offsets_kernel<1>, dim3(FA_H, bs), dim3(FO_THREADS), 0, st, goff, shapedirs, posedirs, V, H, bs);
+    }
     hipLaunchKernelGGL(frame_params_kernel, dim3(FB_NP, bs), dim3(64), 0, st, betas, pose, transl, J0, JS, parents, acc,
                        d_ober2cano ? H : (const float*)nullptr, grads_out);
     return check_launch("anr_frame_backward_adjoint");

@@ -146,6 +146,12 @@ __global__ __launch_bounds__(64) void frame_chain_kernel(const int64_t* __restri
 
 // 256 threads = 64 vertices x 4 slices of the 207 pose features (the pose blend shapes are a 621-load chain per vertex when
 // one thread walks them alone), or 256 rays.
+// BT frames per vertex workgroup: a vertex's 621 blend-shape values (207 rows x 768 B per workgroup; 17 MB over the mesh) are
+// loaded ONCE and applied to the features of BT frames — the pass is that stream, and a workgroup per (block, frame) read it
+// once per frame: 46 us at 16 frames.  (An XCD-aware order of those workgroups — the frames of a block back to back on one
+// XCD, the stream from its L2 — made the frames' workgroups walk the same lines in lockstep, on one channel at a time: 62 us.)
+// Per frame the arithmetic and its order are what they were: the same bits.
+template <int BT>
 __global__ __launch_bounds__(256) void frame_vertex_kernel(
     const float* __restrict__ betas, const float* __restrict__ transl, const float* __restrict__ A, const float* __restrict__ feat,
     const float* __restrict__ ginv, const float* __restrict__ v_template, const float* __restrict__ shapedirs,
@@ -154,25 +160,13 @@ __global__ __launch_bounds__(256) void frame_vertex_kernel(
     const float* __restrict__ rays_world, int ray_stride, int R, int n_vblocks, float* __restrict__ shape_off,
     float* __restrict__ pose_off, float* __restrict__ verts_root, float* __restrict__ T_root, float* __restrict__ o2c,
     float* __restrict__ rays_body, int bs, int n_rblocks) {
-    // Workgroup -> (block, frame): the frames of ONE vertex block on consecutive workgroup ids of the SAME XCD (ids go round
-    // the 8 XCDs), so that its slice of the pose blend shapes (207 rows x 768 B; 17 MB over all blocks) comes from HBM once
-    // and from that XCD's L2 for the other frames — with (block, frame) as the grid's (x, y) every frame read the 17 MB again.
-    const int nvp = (n_vblocks + 7) & ~7;
-    int b, bx;
-    if ((int)blockIdx.x < nvp * bs) {
-        const int t = (int)blockIdx.x >> 3;
-        b = t % bs;
-        bx = (t / bs) * 8 + ((int)blockIdx.x & 7);
-        if (bx >= n_vblocks) return;
-    } else {
-        const int t = (int)blockIdx.x - nvp * bs;
-        b = t / n_rblocks;
-        bx = n_vblocks + t % n_rblocks;
-    }
-    __shared__ float sA[FS_J][12], sf[FS_P], sB[FS_NB], sI[12], sT[3];
-    __shared__ float sPo[4][64][3];
-    if (bx >= n_vblocks) {                                   // ---- rays: models/anim_nerf.py:128-137
-        const int r = (bx - n_vblocks) * 256 + threadIdx.x;
+    const int n_groups = (bs + BT - 1) / BT;
+    __shared__ float sA[BT][FS_J][12], sf[BT][FS_P], sB[BT][FS_NB], sI[BT][12], sT[BT][3];
+    __shared__ float sPo[BT][4][64][3];
+    if ((int)blockIdx.x >= n_vblocks * n_groups) {           // ---- rays: models/anim_nerf.py:128-137
+        const int t = (int)blockIdx.x - n_vblocks * n_groups;
+        const int b = t / n_rblocks;
+        const int r = (t % n_rblocks) * 256 + threadIdx.x;
         if (r >= R) return;
         const float* G = ginv + b * 16;
         const float* s = rays_world + ((int64_t)b * R + r) * ray_stride;
@@ -189,102 +183,120 @@ __global__ __launch_bounds__(256) void frame_vertex_kernel(
         dst[1] = make_float4(dn[1], dn[2], fmaxf(s[6], dist - 1.0f), fminf(s[7], dist + 1.0f));
         return;
     }
-    const float* tr = transl + (int64_t)b * 3;
-    for (int e = threadIdx.x; e < FS_J * 12; e += 256) {
-        const int j = e / 12, k = e % 12;
-        float a = A[((int64_t)b * FS_J + j) * 16 + k];
-        if ((k & 3) == 3) a -= tr[k >> 2];                   // back to the un-translated relative transform
-        sA[j][k] = a;
+    const int bx = (int)blockIdx.x % n_vblocks, b0 = ((int)blockIdx.x / n_vblocks) * BT;
+    const int nb = min(BT, bs - b0);                           // frames of this group
+    for (int e = threadIdx.x; e < nb * FS_J * 12; e += 256) {
+        const int t = e / (FS_J * 12), j = (e / 12) % FS_J, k = e % 12;
+        float a = A[((int64_t)(b0 + t) * FS_J + j) * 16 + k];
+        if ((k & 3) == 3) a -= transl[(int64_t)(b0 + t) * 3 + (k >> 2)];      // back to the un-translated relative transform
+        sA[t][j][k] = a;
     }
-    for (int e = threadIdx.x; e < FS_P; e += 256) sf[e] = feat[(int64_t)b * FS_P + e];
-    if (threadIdx.x < FS_NB) sB[threadIdx.x] = betas[b * FS_NB + threadIdx.x];
-    if (threadIdx.x < 12) sI[threadIdx.x] = ginv[b * 16 + threadIdx.x];
-    if (threadIdx.x < 3) sT[threadIdx.x] = tr[threadIdx.x];
+    for (int e = threadIdx.x; e < BT * FS_P; e += 256) {
+        const int t = e / FS_P, q = e % FS_P;
+        sf[t][q] = t < nb ? feat[(int64_t)(b0 + t) * FS_P + q] : 0.0f;
+    }
+    if (threadIdx.x < nb * FS_NB) sB[threadIdx.x / FS_NB][threadIdx.x % FS_NB] = betas[(b0 + threadIdx.x / FS_NB) * FS_NB + threadIdx.x % FS_NB];
+    if (threadIdx.x < nb * 12) sI[threadIdx.x / 12][threadIdx.x % 12] = ginv[(b0 + threadIdx.x / 12) * 16 + threadIdx.x % 12];
+    if (threadIdx.x < nb * 3) sT[threadIdx.x / 3][threadIdx.x % 3] = transl[(int64_t)(b0 + threadIdx.x / 3) * 3 + threadIdx.x % 3];
     __syncthreads();
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int v = bx * 64 + lane;
     const bool live = v < V;
     // pose blend shapes: slice s takes features s, s + 4, ... (lbs.py:152-251: pose_offsets = feat . posedirs)
-    float po[3] = {0.f, 0.f, 0.f};
+    float pot_[BT][3];
+#pragma unroll
+    for (int t = 0; t < BT; ++t) { pot_[t][0] = 0.f; pot_[t][1] = 0.f; pot_[t][2] = 0.f; }
     if (live) {
 #pragma clang fp contract(fast)                                          // (the SMPL part rounds as csrc/smpl.hip does)
         const int64_t row = (int64_t)3 * V;
         for (int p = slice; p < FS_P; p += 4) {
-            const float f = sf[p];
             const float* pd = posedirs + p * row + (int64_t)v * 3;
-            po[0] += f * pd[0]; po[1] += f * pd[1]; po[2] += f * pd[2];
+            const float d0 = pd[0], d1 = pd[1], d2 = pd[2];
+#pragma unroll
+            for (int t = 0; t < BT; ++t) {
+                const float f = sf[t][p];
+                pot_[t][0] += f * d0; pot_[t][1] += f * d1; pot_[t][2] += f * d2;
+            }
         }
     }
-    sPo[slice][lane][0] = po[0]; sPo[slice][lane][1] = po[1]; sPo[slice][lane][2] = po[2];
+#pragma unroll
+    for (int t = 0; t < BT; ++t) { sPo[t][slice][lane][0] = pot_[t][0]; sPo[t][slice][lane][1] = pot_[t][1]; sPo[t][slice][lane][2] = pot_[t][2]; }
     __syncthreads();
-    if (slice != 0 || !live) return;
-    float so[3], T[16], x[3], ws = 0.f;
+    // wavefront t finishes frame t of the group (BT <= 4 wavefronts): the frames' chains of dependent loads side by side, not
+    // one behind the other in wavefront 0
+    static_assert(BT <= 4, "one wavefront per frame of the group");
+    if (slice >= nb || !live) return;
     {
+        const int t = slice;
+        const int b = b0 + t;
+        float po[3], so[3], T[16], x[3], ws = 0.f;
+        {
 #pragma clang fp contract(fast)
-        float vs[3], vp[3];
+            float vs[3], vp[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            po[c] = (sPo[0][lane][c] + sPo[1][lane][c]) + (sPo[2][lane][c] + sPo[3][lane][c]);
-            float s = 0.f;
-            for (int l = 0; l < FS_NB; ++l) s += sB[l] * shapedirs[((int64_t)v * 3 + c) * FS_NB + l];
-            so[c] = s;
-            vs[c] = v_template[v * 3 + c] + s;
-            vp[c] = vs[c] + po[c];
-            shape_off[((int64_t)b * V + v) * 3 + c] = s;
-            pose_off[((int64_t)b * V + v) * 3 + c] = po[c];
+            for (int c = 0; c < 3; ++c) {
+                po[c] = (sPo[t][0][lane][c] + sPo[t][1][lane][c]) + (sPo[t][2][lane][c] + sPo[t][3][lane][c]);
+                float s = 0.f;
+                for (int l = 0; l < FS_NB; ++l) s += sB[t][l] * shapedirs[((int64_t)v * 3 + c) * FS_NB + l];
+                so[c] = s;
+                vs[c] = v_template[v * 3 + c] + s;
+                vp[c] = vs[c] + po[c];
+                shape_off[((int64_t)b * V + v) * 3 + c] = s;
+                pose_off[((int64_t)b * V + v) * 3 + c] = po[c];
+            }
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = 0.f;
+            for (int j = 0; j < FS_J; ++j) {
+                const float w = lbs_weights[(int64_t)v * FS_J + j];
+                ws += w;
+#pragma unroll
+                for (int e = 0; e < 12; ++e) T[e] += w * sA[t][j][e];
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                x[r] = (T[r * 4 + 0] * vp[0] + T[r * 4 + 1] * vp[1] + T[r * 4 + 2] * vp[2] + T[r * 4 + 3]) + sT[t][r];
+                T[r * 4 + 3] += sT[t][r];
+            }
         }
-#pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = 0.f;
-        for (int j = 0; j < FS_J; ++j) {
-            const float w = lbs_weights[(int64_t)v * FS_J + j];
-            ws += w;
-#pragma unroll
-            for (int e = 0; e < 12; ++e) T[e] += w * sA[j][e];
-        }
+        T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = ws;          // the reference's T row 3 is sum_j w_j [0,0,0,1]
+        // into the root frame (models/anim_nerf.py:138-144): verts, and T as the full 4x4 product torch computes
+        float Xr[12];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            x[r] = (T[r * 4 + 0] * vp[0] + T[r * 4 + 1] * vp[1] + T[r * 4 + 2] * vp[2] + T[r * 4 + 3]) + sT[r];
-            T[r * 4 + 3] += sT[r];
+            verts_root[((int64_t)b * V + v) * 3 + r] = sI[t][r * 4 + 0] * x[0] + sI[t][r * 4 + 1] * x[1] + sI[t][r * 4 + 2] * x[2] + sI[t][r * 4 + 3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                Xr[r * 4 + c] = sI[t][r * 4 + 0] * T[c] + sI[t][r * 4 + 1] * T[4 + c] + sI[t][r * 4 + 2] * T[8 + c] + sI[t][r * 4 + 3] * T[12 + c];
         }
+        float4* t4 = reinterpret_cast<float4*>(T_root + ((int64_t)b * V + v) * 16);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) t4[r] = make_float4(Xr[r * 4 + 0], Xr[r * 4 + 1], Xr[r * 4 + 2], Xr[r * 4 + 3]);
+        t4[3] = make_float4(0.f, 0.f, 0.f, ws);
+        // observation -> canonical (models/anim_nerf.py:147-151): T_template (T_root)^-1, offsets on the translation
+        float I[12];
+        fs_affine_inverse12(Xr, I);
+        const float* sot = so_templ + b * templ_stride_o + (int64_t)v * 3;
+        const float* pot = po_templ + b * templ_stride_o + (int64_t)v * 3;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float tt = I[r * 4 + 3];
+            tt += sot[r] - so[r];
+            tt += pot[r] - po[r];
+            I[r * 4 + 3] = tt;
+        }
+        const float4* pb = reinterpret_cast<const float4*>(T_templ + b * templ_stride_T + (int64_t)v * 16);
+        float4* dst = reinterpret_cast<float4*>(o2c + ((int64_t)b * V + v) * 16);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float4 B = pb[r];
+            const float o0 = B.x * I[0] + B.y * I[4] + B.z * I[8];
+            const float o1 = B.x * I[1] + B.y * I[5] + B.z * I[9];
+            const float o2 = B.x * I[2] + B.y * I[6] + B.z * I[10];
+            const float o3 = B.x * I[3] + B.y * I[7] + B.z * I[11] + B.w;
+            dst[r] = make_float4(o0, o1, o2, o3);
+        }
+        dst[3] = make_float4(0.f, 0.f, 0.f, 1.f);
     }
-    T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = ws;          // the reference's T row 3 is sum_j w_j [0,0,0,1]
-    // into the root frame (models/anim_nerf.py:138-144): verts, and T as the full 4x4 product torch computes
-    float Xr[12];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        verts_root[((int64_t)b * V + v) * 3 + r] = sI[r * 4 + 0] * x[0] + sI[r * 4 + 1] * x[1] + sI[r * 4 + 2] * x[2] + sI[r * 4 + 3];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            Xr[r * 4 + c] = sI[r * 4 + 0] * T[c] + sI[r * 4 + 1] * T[4 + c] + sI[r * 4 + 2] * T[8 + c] + sI[r * 4 + 3] * T[12 + c];
-    }
-    float4* t4 = reinterpret_cast<float4*>(T_root + ((int64_t)b * V + v) * 16);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) t4[r] = make_float4(Xr[r * 4 + 0], Xr[r * 4 + 1], Xr[r * 4 + 2], Xr[r * 4 + 3]);
-    t4[3] = make_float4(0.f, 0.f, 0.f, ws);
-    // observation -> canonical (models/anim_nerf.py:147-151): T_template (T_root)^-1, offsets on the translation
-    float I[12];
-    fs_affine_inverse12(Xr, I);
-    const float* sot = so_templ + b * templ_stride_o + (int64_t)v * 3;
-    const float* pot = po_templ + b * templ_stride_o + (int64_t)v * 3;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        float t = I[r * 4 + 3];
-        t += sot[r] - so[r];
-        t += pot[r] - po[r];
-        I[r * 4 + 3] = t;
-    }
-    const float4* pb = reinterpret_cast<const float4*>(T_templ + b * templ_stride_T + (int64_t)v * 16);
-    float4* dst = reinterpret_cast<float4*>(o2c + ((int64_t)b * V + v) * 16);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const float4 B = pb[r];
-        const float o0 = B.x * I[0] + B.y * I[4] + B.z * I[8];
-        const float o1 = B.x * I[1] + B.y * I[5] + B.z * I[9];
-        const float o2 = B.x * I[2] + B.y * I[6] + B.z * I[10];
-        const float o3 = B.x * I[3] + B.y * I[7] + B.z * I[11] + B.w;
-        dst[r] = make_float4(o0, o1, o2, o3);
-    }
-    dst[3] = make_float4(0.f, 0.f, 0.f, 1.f);
 }
 
 }  // namespace anr
@@ -313,9 +325,17 @@ extern "C" int anr_frame_setup(const int64_t* frame_idx, const float* betas_w, i
     hipLaunchKernelGGL(frame_chain_kernel, dim3(bs), dim3(64), 0, st, frame_idx, betas_w, betas_rows, global_orient_w, body_pose_w,
                        transl_w, J0, JS, parents, betas_out, pose_out, transl_out, A_out, joints_root_out, ws_feat, g_inv_out, g_root_out);
     const int nvb = (V + 63) / 64, nrb = (R + 255) / 256;
-    hipLaunchKernelGGL(frame_vertex_kernel, dim3((unsigned)((((nvb + 7) & ~7) + nrb) * bs)), dim3(256), 0, st, betas_out, transl_out, A_out, ws_feat, g_inv_out,
-                       v_template, shapedirs, posedirs, lbs_weights, V, T_template, shape_off_template, pose_off_template,
-                       template_bs == 1 ? (int64_t)0 : (int64_t)V * 16, template_bs == 1 ? (int64_t)0 : (int64_t)V * 3, rays_world,
-                       ray_stride, R, nvb, shape_off_out, pose_off_out, verts_root_out, T_root_out, ober2cano_out, rays_body_out, bs, nrb);
+#define ANR_FRAME_VERTEX(BT)                                                                                                      \
+    hipLaunchKernelGGL(frame_vertex_kernel<BT>, dim3((unsigned)(nvb * ((bs + BT - 1) / BT) + nrb * bs)), dim3(256), 0, st, betas_out,       \
+                       transl_out, A_out, ws_feat, g_inv_out, v_template, shapedirs, posedirs, lbs_weights, V, T_template,                 \
+                       shape_off_template, pose_off_template, template_bs == 1 ? (int64_t)0 : (int64_t)V * 16,                            \
+                       template_bs == 1 ? (int64_t)0 : (int64_t)V * 3, rays_world, ray_stride, R, nvb, shape_off_out, pose_off_out,      \
+                       verts_root_out, T_root_out, ober2cano_out, rays_body_out, bs, nrb)
+    {
+        // (frames per workgroup, 16 frames: 1 -> 66 us, 2 -> 55, 4 -> 38; 2 frames: 22 / 25)
+        const int bt = bs >= 3 ? 4 : bs;
+        if (bt >= 4) ANR_FRAME_VERTEX(4); else if (bt == 2) ANR_FRAME_VERTEX(2); else ANR_FRAME_VERTEX(1);
+    }
+#undef ANR_FRAME_VERTEX
     return check_launch("anr_frame_setup");
 }
