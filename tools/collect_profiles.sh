@@ -71,5 +71,5 @@ python3 tools/exp/step_timeline.py $OUT/cfg4_f2_trace > $DST/train_step_timeline
 # round 5: the frozen-network (_refine) step, the training kernels per row count, the replayed step at HEAD
 python3 bench.py --workload cfg4 --no-extras --steps 40 --warmup 5 --refine 2>/dev/null | grep '^{' > $DST/bench_cfg4_refine_bf16.json
 python3 bench.py --workload cfg4 --no-extras --steps 40 --warmup 5 --refine --frames-per-gpu 2 2>/dev/null | grep '^{' > $DST/bench_cfg4_refine_f2_bf16.json
-cp $ROOT/gpurun_out/r05/*.txt $DST/ 2>/dev/null
+# (the experiment outputs of the round — gpurun_out/r05/*.txt — are copied into profiles/r05/ on the build host)
 ls $DST
