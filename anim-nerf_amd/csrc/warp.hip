@@ -1000,6 +1000,165 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
         if (hkeys[s] >= 0) atomicAdd(cell_count + (int64_t)b * NCELL + hkeys[s], hcnt[s]);
 }
 
+// The renderer's lean pass (validity bytes out, no neighbour outputs; rays mode, four consecutive samples per thread) written in
+// PHASES, so that every load of a thread's eight samples is in flight before the first one is used.  In the generic kernel
+// above a sample's chain — merge permutation -> validity byte of the coarse sample it copies -> that sample's point -> store —
+// ran once per sample behind the previous sample's (round 4's counters: 70 % of the wave-cycles waiting on memory at 30 % VALU
+// issue, 2 TB/s): here the two 16-byte depth loads, the two permutation dwords and the rays go first, then the eight validity
+// bytes and reach-mask words, then the (up to) eight points, then the stores.  Same outputs.
+template <bool CELLS>
+__global__ __launch_bounds__(WARP_THREADS) void warp_classify_lean_kernel(
+    const float* __restrict__ rays, int ray_stride, const float* __restrict__ z, int K, const float* __restrict__ index, IndexDims d,
+    int64_t N, float thr, float4* __restrict__ pts_out, int32_t* __restrict__ list, int32_t* __restrict__ cells,
+    int32_t* __restrict__ count, int32_t* __restrict__ cell_count, uint8_t* __restrict__ valid_mask,
+    const float4* __restrict__ reuse_pts, const uint8_t* __restrict__ reuse_mask, const uint8_t* __restrict__ perm, int reuse_K,
+    int G) {
+    __shared__ int wave_cnt[WARP_THREADS / 64];
+    __shared__ int block_base;
+    __shared__ int hkeys[HN], hcnt[HN];
+    const int b = blockIdx.y;
+    const float* gbox = index + (int64_t)b * d.total_floats() + d.body_off();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (CELLS) {
+        for (int s = threadIdx.x; s < HN; s += WARP_THREADS) { hkeys[s] = -1; hcnt[s] = 0; }
+        __syncthreads();
+    }
+    constexpr int VS = 4, STEPS = CLS_ITERS / VS;
+    const uint32_t R32 = (uint32_t)(N / K);
+    const float cell_inv = 1.0f / cell_size(gbox, thr, G);
+    const float reach_thr = gbox[3];
+    const bool masked = reach_thr >= thr;
+    const float reach_inv = masked ? 1.0f / reach_cell_size(gbox, reach_thr) : 0.0f;
+    const unsigned* __restrict__ reach = reinterpret_cast<const unsigned*>(index + (int64_t)b * d.total_floats() + d.reach_off());
+    auto sample_of = [&](int step, int v) { return (((int64_t)blockIdx.x * STEPS + step) * WARP_THREADS + threadIdx.x) * VS + v; };
+    // ---- A: depths, permutation bytes, rays
+    float zz[CLS_ITERS];
+    unsigned pm[STEPS];
+    uint32_t ray4[STEPS];
+    bool in[STEPS];
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+        const int64_t n0 = sample_of(step, 0);
+        in[step] = n0 < N;                                  // (N % 4 == 0: the four samples are in range together)
+        float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        pm[step] = 0u;
+        if (in[step]) {
+            z4 = *reinterpret_cast<const float4*>(z + (int64_t)b * N + n0);
+            if (perm != nullptr) pm[step] = *reinterpret_cast<const unsigned*>(perm + (int64_t)b * N + n0);
+        }
+        zz[step * VS + 0] = z4.x; zz[step * VS + 1] = z4.y; zz[step * VS + 2] = z4.z; zz[step * VS + 3] = z4.w;
+        ray4[step] = in[step] ? (uint32_t)n0 / (uint32_t)K : 0u;                      // (N < 2^31 on this path)
+    }
+    float ro[STEPS][3], rd[STEPS][3];
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+        const float* ry = rays + ((int64_t)b * R32 + ray4[step]) * ray_stride;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { ro[step][a] = in[step] ? ry[a] : 0.0f; rd[step][a] = in[step] ? ry[3 + a] : 0.0f; }
+    }
+    // ---- B: positions, the box test, the coarse samples' validity bytes, the reach-mask words
+    float px[CLS_ITERS], py[CLS_ITERS], pz[CLS_ITERS];
+    int64_t src[CLS_ITERS];
+    unsigned m[CLS_ITERS], rw[CLS_ITERS];
+    unsigned near_bits = 0u, reused_bits = 0u;
+    int rbit[CLS_ITERS];
+#pragma unroll
+    for (int it = 0; it < CLS_ITERS; ++it) {
+        const int step = it / VS, v = it % VS;
+        px[it] = __fadd_rn(ro[step][0], __fmul_rn(zz[it], rd[step][0]));
+        py[it] = __fadd_rn(ro[step][1], __fmul_rn(zz[it], rd[step][1]));
+        pz[it] = __fadd_rn(ro[step][2], __fmul_rn(zz[it], rd[step][2]));
+        bool near = in[step] && box_d2(gbox, px[it], py[it], pz[it]) < thr * thr;
+        m[it] = 0u; rw[it] = 0xffffffffu; rbit[it] = 0; src[it] = 0;
+        bool reused = false;
+        if (in[step] && perm != nullptr) {
+            // this sorted sample IS coarse sample pj of the same ray: its canonical point and validity were computed in the
+            // coarse pass
+            const int pj = (int)((pm[step] >> (8 * v)) & 0xffu);
+            if (pj < reuse_K) {
+                src[it] = ((int64_t)b * R32 + ray4[step]) * reuse_K + pj;
+                m[it] = reuse_mask[src[it]];
+                reused = true;
+                near = false;
+            }
+        }
+        if (masked && near) {
+            const int rc = reach_cell(gbox, reach_thr, reach_inv, px[it], py[it], pz[it]);
+            if (rc >= 0) { rw[it] = reach[rc >> 5]; rbit[it] = rc & 31; } else { near = false; }
+        }
+        near_bits |= (near ? 1u : 0u) << it;
+        reused_bits |= (reused ? 1u : 0u) << it;
+    }
+    // ---- C: the points of the valid coarse samples
+    float4 rp[CLS_ITERS];
+#pragma unroll
+    for (int it = 0; it < CLS_ITERS; ++it) {
+        rp[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m[it]) rp[it] = reuse_pts[src[it]];
+    }
+    // ---- D: stores
+    int my_cell[CLS_ITERS];
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+        unsigned mask_out = 0u;
+#pragma unroll
+        for (int v = 0; v < VS; ++v) {
+            const int it = step * VS + v;
+            const int64_t o = (int64_t)b * N + sample_of(step, v);
+            my_cell[it] = 0;
+            if ((reused_bits >> it) & 1u) {
+                mask_out |= m[it] << (8 * v);
+                if (m[it]) pts_out[o] = rp[it];
+            } else if ((near_bits >> it) & 1u) {
+                if (((rw[it] >> rbit[it]) & 1u) == 0u) {     // no vertex can reach this cell
+                    near_bits &= ~(1u << it);
+                } else {
+                    pts_out[o] = make_float4(px[it], py[it], pz[it], 0.0f);
+                    if (CELLS) {
+                        const int cell = cell_of_inv(gbox, thr, G, cell_inv, px[it], py[it], pz[it]);
+                        my_cell[it] = cell;
+                        const int slot = hash_slot(hkeys, cell);
+                        if (slot >= 0) atomicAdd(&hcnt[slot], 1);
+                        else atomicAdd(cell_count + (int64_t)b * NCELL + cell, 1);
+                    }
+                }
+            }
+        }
+        if (in[step]) *reinterpret_cast<unsigned*>(valid_mask + (int64_t)b * N + sample_of(step, 0)) = mask_out;
+    }
+    {
+        const int mine = __popc(near_bits);
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wave_cnt[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+#pragma unroll
+            for (int w = 0; w < WARP_THREADS / 64; ++w) { int c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
+            block_base = tot ? atomicAdd(count + b, tot) : 0;
+        }
+        __syncthreads();
+        int64_t pos = (int64_t)b * N + block_base + wave_cnt[wave] + incl - mine;
+#pragma unroll
+        for (int it = 0; it < CLS_ITERS; ++it) {
+            if ((near_bits >> it) & 1u) {
+                list[pos] = (int32_t)sample_of(it / VS, it % VS);
+                if (CELLS) cells[pos] = my_cell[it];
+                ++pos;
+            }
+        }
+    }
+    if (!CELLS) return;
+    __syncthreads();
+    for (int s = threadIdx.x; s < HN; s += WARP_THREADS)
+        if (hkeys[s] >= 0) atomicAdd(cell_count + (int64_t)b * NCELL + hkeys[s], hcnt[s]);
+}
+
 // Per occupied cell, one exact search from the cell's centre c (r = half diagonal):
 //   * nearest vertex farther than dis_threshold + r  ->  every point of the cell is farther than dis_threshold from
 //     every vertex, its blended distance (a convex combination of neighbour distances) too: the cell is dead, its
@@ -1961,7 +2120,17 @@ extern "C" int anr_warp_points_reuse(const float* xyz, int xyz_stride, const flo
                            w.list, w.cells, w.count, w.cell_count, valid_mask_out,                                            \
                            reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K, G,                    \
                            reinterpret_cast<const int4*>(reuse_nbr_idx), reinterpret_cast<const float4*>(reuse_nbr_w))
-        if (vec4)                { if (small) ANR_CLASSIFY(true, true, false);   else ANR_CLASSIFY(true, true, true); }
+        if (vec4 && valid_mask_out != nullptr && nbr_w_out == nullptr && (reuse_pts == nullptr || reuse_mask != nullptr) &&
+            !getenv("ANR_WARP_CLASSIFY_GENERIC")) {
+            // the renderer's lean pass: its own kernel, loads in phases (warp_classify_lean_kernel)
+#define ANR_CLASSIFY_LEAN(CL)                                                                                                  \
+            hipLaunchKernelGGL((warp_classify_lean_kernel<CL>), g1, dim3(WARP_THREADS), 0, st, rays, ray_stride, z, K, index, d, N,  \
+                               dis_threshold, reinterpret_cast<float4*>(pts_out), w.list, w.cells, w.count, w.cell_count,          \
+                               valid_mask_out, reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K, G)
+            if (small) ANR_CLASSIFY_LEAN(false); else ANR_CLASSIFY_LEAN(true);
+#undef ANR_CLASSIFY_LEAN
+        }
+        else if (vec4)           { if (small) ANR_CLASSIFY(true, true, false);   else ANR_CLASSIFY(true, true, true); }
         else if (xyz == nullptr) { if (small) ANR_CLASSIFY(true, false, false);  else ANR_CLASSIFY(true, false, true); }
         else                     { if (small) ANR_CLASSIFY(false, false, false); else ANR_CLASSIFY(false, false, true); }
 #undef ANR_CLASSIFY
