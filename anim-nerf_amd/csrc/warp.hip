@@ -1511,6 +1511,11 @@ __device__ __forceinline__ unsigned group8_min(unsigned v) {
 __device__ __forceinline__ unsigned pick_key(float dist, float bound, unsigned tag, unsigned tag_mask) {
     return dist <= bound ? ((__float_as_uint(dist) & ~tag_mask) | tag) : PICK_NONE;
 }
+#ifndef ANR_GROUP_SCAN
+#define ANR_GROUP_SCAN 2
+#endif
+constexpr int GROUP_SCAN = ANR_GROUP_SCAN;     // clusters a group scans per step (see the scan below): 1 -> 2: 0.147 -> 0.126-0.130 ms
+                                               // per call at 2 bodies; 3: the same; 4: 0.132 (profiles/r05/ab_group_scan.txt)
 constexpr int GQ_ENTRIES = 64;                 // blend queue per wavefront: {sample, slots 0|1, slots 2|3}
 constexpr int GQ_BYTES = GQ_ENTRIES * 12;
 
@@ -1701,18 +1706,52 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_search_groups_kernel(
                 const int k = (int)(cm & 7u);
                 if (j == k) cd = INF;
                 const int slot0 = (c_base + k) * CS;
-                const float d2 = dist2(px, py, pz, lds[slot0 + j], lds[d.Vp + slot0 + j], lds[2 * d.Vp + slot0 + j]);
-                bool pend = d2 <= best.d[3];                     // (<=: a tie with the current 4th may carry a lower slot)
-                while (__any(pend)) {
-                    const unsigned m = group8_min(pend ? __float_as_uint(d2) : PICK_NONE);
-                    const unsigned long long bal = __ballot(pend && __float_as_uint(d2) == m);
-                    const unsigned mine = (unsigned)(bal >> gbase) & 0xffu;
-                    if (mine) {
-                        const int k2 = __builtin_ctz(mine);
-                        best_insert(best, __uint_as_float(m), slot0 + k2);
-                        if (j == k2) pend = false;
+                // ... and the next pending one of the same super-cluster with it (round 5): a launch lasts as long as its longest
+                // sample chain — 100-180 steps for a sample whose 4th-neighbour sphere grazes that many clusters — and a step's
+                // fixed part (the picks, the hand-out and finish votes) is most of a step that inserts nothing.  The second
+                // clusters are picked against the bound BEFORE the first one's scan: at worst eight distances each for nothing.
+                // The (distance, slot) order of best_insert makes the result independent of the order of the candidates.
+                int slots[GROUP_SCAN];
+                float d2s[GROUP_SCAN];
+                unsigned pend = 0u;                               // bit c: this lane's vertex of cluster c still beats the 4th
+                slots[0] = slot0;
+#pragma unroll
+                for (int c = 1; c < GROUP_SCAN; ++c) {
+                    const unsigned cmx = group8_min(pick_key(cd, best.d[3], j, 7));
+                    const bool more = cmx != PICK_NONE;
+                    const int kx = (int)(cmx & 7u);
+                    if (more && j == kx) cd = INF;
+                    slots[c] = more ? (c_base + kx) * CS : -1;
+                }
+#pragma unroll
+                for (int c = 0; c < GROUP_SCAN; ++c) {
+                    const int sl = slots[c] < 0 ? slot0 : slots[c];
+                    d2s[c] = dist2(px, py, pz, lds[sl + j], lds[d.Vp + sl + j], lds[2 * d.Vp + sl + j]);
+                    // (<=: a tie with the current 4th may carry a lower slot)
+                    pend |= (slots[c] >= 0 && d2s[c] <= best.d[3]) ? 1u << c : 0u;
+                }
+                while (__any(pend != 0u)) {
+                    unsigned u = PICK_NONE;
+#pragma unroll
+                    for (int c = 0; c < GROUP_SCAN; ++c) u = min(u, ((pend >> c) & 1u) ? __float_as_uint(d2s[c]) : PICK_NONE);
+                    const unsigned m = group8_min(u);
+                    int sv = 0x7fffffff, cv = 0;                  // equal distances in several clusters: the lowest slot first
+#pragma unroll
+                    for (int c = 0; c < GROUP_SCAN; ++c) {
+                        const unsigned long long bal = __ballot(((pend >> c) & 1u) && __float_as_uint(d2s[c]) == m);
+                        const unsigned mine = (unsigned)(bal >> gbase) & 0xffu;
+                        const int sc = mine ? slots[c] + __builtin_ctz(mine) : 0x7fffffff;
+                        if (sc < sv) { sv = sc; cv = c; }
                     }
-                    pend = pend && d2 <= best.d[3];
+                    if (sv != 0x7fffffff) {
+                        best_insert(best, __uint_as_float(m), sv);
+#pragma unroll
+                        for (int c = 0; c < GROUP_SCAN; ++c)
+                            if (c == cv && j == sv - slots[c]) pend &= ~(1u << c);
+                    }
+#pragma unroll
+                    for (int c = 0; c < GROUP_SCAN; ++c)
+                        if (!(d2s[c] <= best.d[3])) pend &= ~(1u << c);
                 }
             }
         }
