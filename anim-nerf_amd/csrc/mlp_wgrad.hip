@@ -664,21 +664,31 @@ __global__ __launch_bounds__(256) void denc_kernel(const char* __restrict__ dact
 // 86 + 59 us -> one launch at the per-rank batch of the reference's 8-GPU run (~70 k rows).
 namespace anr {
 
-template <bool BF16>
+// NTILE = 32-point tiles per wavefront and trip: 2 for bf16 where the rows are many; 1 when the buffer is small (a 2-frame
+// training batch: ~20 k listed rows are 300 64-point tiles for 1,024 wavefronts — half the chain per wavefront with 32)
+template <bool BF16, int NTILE>
 __global__ __launch_bounds__(BF16 ? 256 : 128) void dpoints_kernel(const char* __restrict__ dact, const char* __restrict__ panel_g,
                                                                    const float4* __restrict__ pts, int64_t n,
                                                                    float4* __restrict__ d_pts, const int32_t* __restrict__ count) {
     using T = typename WgCfg<BF16>::T;
     constexpr int KF = BF16 ? 16 : 128, EPL = BF16 ? 8 : 1;
-    constexpr int WAVES = BF16 ? 4 : 2, TP = BF16 ? 64 : 32, NTILE = TP / 32;
+    constexpr int WAVES = BF16 ? 4 : 2, TP = 32 * NTILE;
     constexpr int PANEL_BYTES = DENC_PANEL_ELEMS * (int)sizeof(T);
     constexpr int PITCH = 65;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const T* panel = reinterpret_cast<const T*>(lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     float* patch = reinterpret_cast<float*>(lds + PANEL_BYTES) + wave * (TP * PITCH);
-    for (int i = threadIdx.x; i < PANEL_BYTES / 16; i += WAVES * 64)
-        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(panel_g)[i];
+    {   // the panel: every 16-byte piece of a thread in flight before the first LDS store (a copy loop of load, store is one
+        // trip to L2 per iteration: 16 trips, ~30 us of a 40 us launch at a 2-frame batch)
+        constexpr int PIECES = PANEL_BYTES / 16 / (WAVES * 64);
+        static_assert(PANEL_BYTES % (16 * WAVES * 64) == 0, "whole pieces per thread");
+        uint4 tmp[PIECES];
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) tmp[i] = reinterpret_cast<const uint4*>(panel_g)[i * (WAVES * 64) + threadIdx.x];
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) reinterpret_cast<uint4*>(lds)[i * (WAVES * 64) + threadIdx.x] = tmp[i];
+    }
     __syncthreads();
     int64_t n_rows = n;                                      // (n stays the buffer's row count: the piece arrays' stride)
     if (count) { const int64_t cnt = *count; n_rows = cnt < n ? cnt : n; }
@@ -697,7 +707,8 @@ __global__ __launch_bounds__(BF16 ? 256 : 128) void dpoints_kernel(const char* _
 #pragma unroll
             for (int layer = 0; layer < 2; ++layer) {
                 const char* a0 = arow + act_block_off(n, sizeof(T), layer ? 32 : 0);    // dact_5 (columns 1024..) / dact_1
-#pragma unroll 8
+                // (bf16: the 32 eight-byte loads of a layer in flight at once — the pass is a chain of trips to L2)
+#pragma unroll 16
                 for (int kf = 0; kf < KF; ++kf) {
                     const T* b0 = panel + ((int64_t)((layer * KF + kf) * 2 + 0) * 64 + lane) * EPL;
                     const T* b1 = panel + ((int64_t)((layer * KF + kf) * 2 + 1) * 64 + lane) * EPL;
@@ -762,8 +773,9 @@ extern "C" int anr_mlp_dpoints(const void* bwd_pack, int mode, const void* dact,
     float4* o4 = reinterpret_cast<float4*>(d_pts_out);
     if ((mode & 0xff) == ANR_MLP_BF16) {
         const int lds = DENC_PANEL_ELEMS * 2 + 4 * 64 * 65 * 4;
-        const int64_t wgs = (n + 255) / 256;
-        auto k = dpoints_kernel<true>;
+        const bool small = n <= (int64_t)1 << 18;
+        const int64_t wgs = (n + (small ? 127 : 255)) / (small ? 128 : 256);
+        auto k = small ? dpoints_kernel<true, 1> : dpoints_kernel<true, 2>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail((int)e, "anr_mlp_dpoints: hipFuncSetAttribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(k, dim3((unsigned)(wgs < cus ? wgs : cus)), dim3(256), lds, st, reinterpret_cast<const char*>(dact),
@@ -771,7 +783,7 @@ extern "C" int anr_mlp_dpoints(const void* bwd_pack, int mode, const void* dact,
     } else if ((mode & 0xff) == ANR_MLP_F32) {
         const int lds = DENC_PANEL_ELEMS * 4 + 2 * 32 * 65 * 4;
         const int64_t wgs = (n + 63) / 64;
-        auto k = dpoints_kernel<false>;
+        auto k = dpoints_kernel<false, 1>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail((int)e, "anr_mlp_dpoints: hipFuncSetAttribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(k, dim3((unsigned)(wgs < cus ? wgs : cus)), dim3(128), lds, st, reinterpret_cast<const char*>(dact),
