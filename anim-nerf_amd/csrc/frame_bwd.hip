@@ -76,6 +76,10 @@ struct ChainLds {
     float Feat[9];                   // tangent of the 9 pose-feature entries of the parameter's joint
     float Rot[FB_J][9][2], Jr[FB_J][3][2], World[FB_J][12][2];
     int desc;                        // bit j: joint j lies in the subtree of the parameter's joint
+    int lvl_start[FB_J + 1];         // joints by depth in the kinematic tree: level l = lvl_joint[lvl_start[l] .. lvl_start[l + 1])
+    int lvl_joint[FB_J];
+    int n_levels;
+    int par[FB_J], depth[FB_J];
 };
 
 __device__ __forceinline__ void run_chain(ChainLds& L, int b, int pi, int pj, const float* __restrict__ betas,
@@ -87,15 +91,28 @@ __device__ __forceinline__ void run_chain(ChainLds& L, int b, int pi, int pj, co
     auto seed = [&](int idx, float val) { return Dual(val, idx == pi ? 1.0f : 0.0f); };
     if (threadIdx.x < FB_J) {
         const int j = threadIdx.x;
+        // (every input of the lane first — 10 betas, its 30 regressor entries, 3 rest coordinates, 3 pose entries: one trip to
+        // L2 — then the sums: a loop of load, load, multiply-add was thirty trips, most of frame_params_kernel's 28 us)
+        float bet[FB_NB], js[3][FB_NB], j0[3], pv[3];
+#pragma unroll
+        for (int k = 0; k < FB_NB; ++k) bet[k] = betas[b * FB_NB + k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int k = 0; k < FB_NB; ++k) js[c][k] = JS[(j * 3 + c) * FB_NB + k];
+            j0[c] = J0[j * 3 + c];
+            pv[c] = pose[(b * FB_J + j) * 3 + c];
+        }
+#pragma unroll
         for (int c = 0; c < 3; ++c) {                              // rest joints: J_regressor . (v_template + shapedirs . betas)
-            Dual s(J0[j * 3 + c]);
-#pragma unroll 1
-            for (int k = 0; k < FB_NB; ++k) s = s + seed(k, betas[b * FB_NB + k]) * Dual(JS[(j * 3 + c) * FB_NB + k]);
+            Dual s(j0[c]);
+#pragma unroll
+            for (int k = 0; k < FB_NB; ++k) s = s + seed(k, bet[k]) * Dual(js[c][k]);
             L.Jr[j][c][0] = s.v; L.Jr[j][c][1] = s.d;
         }
         // Rodrigues, angle = |rv + 1e-8| (smplx/lbs.py:316)
         Dual rv[3];
-        for (int c = 0; c < 3; ++c) rv[c] = seed(FB_NB + 3 * j + c, pose[(b * FB_J + j) * 3 + c]);
+        for (int c = 0; c < 3; ++c) rv[c] = seed(FB_NB + 3 * j + c, pv[c]);
         const Dual e0 = rv[0] + Dual(1e-8f), e1 = rv[1] + Dual(1e-8f), e2 = rv[2] + Dual(1e-8f);
         const Dual theta = dsqrt(e0 * e0 + e1 * e1 + e2 * e2);
         const Dual kx = rv[0] / theta, ky = rv[1] / theta, kz = rv[2] / theta;
@@ -112,43 +129,70 @@ __device__ __forceinline__ void run_chain(ChainLds& L, int b, int pi, int pj, co
             }
     }
     if (threadIdx.x < 9 && pj < 1) L.Feat[threadIdx.x] = 0.0f;      // the root joint has no pose blend shapes
-    if (threadIdx.x == 0) {
-        int m = 0;
-        if (pj >= 1)
-            for (int j = 0; j < FB_J; ++j) {
-                int k = j;
-                while (k > 0 && k != pj) k = (int)parents[k];
-                if (k == pj) m |= 1 << j;
-            }
-        L.desc = m;
-    }
+    if (threadIdx.x == 0) L.desc = 0;
+    if (threadIdx.x < FB_J) L.par[threadIdx.x] = (int)parents[threadIdx.x];
     if (threadIdx.x < 3) {
         const Dual t = seed(FB_NB + 3 * FB_J + threadIdx.x, transl[b * 3 + threadIdx.x]);
         L.Tr[threadIdx.x][0] = t.v; L.Tr[threadIdx.x][1] = t.d;
     }
     __syncthreads();
-    // world_j = world_parent . [R_j | J_j - J_parent], one element (r, c) per lane, joints in tree order
+    // the joints by depth (a stable sort of 24 entries, every step out of LDS and in parallel): the chain below walks the tree
+    // LEVEL BY LEVEL — 9 levels for SMPL's skeleton, the joints of a level side by side — instead of joint by joint (24 steps
+    // of one dependent LDS round trip each: most of this 64-lane workgroup's time)
+    if (threadIdx.x < FB_J) {
+        int dpt = 0;
+        for (int k = threadIdx.x; k > 0; k = L.par[k]) ++dpt;              // (parents[j] < j: tree order)
+        L.depth[threadIdx.x] = dpt;
+        // the subtree of the parameter's joint, a lane per joint out of LDS (one thread walking all 24 paths through the
+        // parents array in global memory — ~100 dependent loads — was the longest thing in a pose parameter's workgroup)
+        if (pj >= 1) {
+            int k = threadIdx.x;
+            while (k > 0 && k != pj) k = L.par[k];
+            if (k == pj) atomicOr(&L.desc, 1 << threadIdx.x);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < FB_J) {
+        const int mine = L.depth[threadIdx.x];
+        int rank = 0;
+        for (int q = 0; q < FB_J; ++q) rank += (L.depth[q] < mine || (L.depth[q] == mine && q < (int)threadIdx.x)) ? 1 : 0;
+        L.lvl_joint[rank] = threadIdx.x;
+    }
+    if (threadIdx.x <= FB_J) {
+        int c = 0, deepest = 0;
+        for (int q = 0; q < FB_J; ++q) { c += L.depth[q] < (int)threadIdx.x ? 1 : 0; deepest = max(deepest, L.depth[q]); }
+        L.lvl_start[threadIdx.x] = c;
+        if (threadIdx.x == 0) L.n_levels = deepest + 1;
+    }
+    __syncthreads();
+    // world_j = world_parent . [R_j | J_j - J_parent], one element (r, c) per lane, five joints of a level per pass
+    const int n_levels = L.n_levels;
 #pragma unroll 1
-    for (int j = 0; j < FB_J; ++j) {
-        if (threadIdx.x < 12) {
-            const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
-            const int par = (int)parents[j];
-            auto local = [&](int k, int cc) {                     // element (k, cc) of joint j's local transform
-                if (cc < 3) return Dual(L.Rot[j][k * 3 + cc][0], L.Rot[j][k * 3 + cc][1]);
-                Dual t(L.Jr[j][k][0], L.Jr[j][k][1]);
-                if (j > 0) t = t - Dual(L.Jr[par][k][0], L.Jr[par][k][1]);
-                return t;
-            };
-            Dual w;
-            if (j == 0) {
-                w = local(r, c);
-            } else {
-                w = Dual(L.World[par][r * 4 + 0][0], L.World[par][r * 4 + 0][1]) * local(0, c) +
-                    Dual(L.World[par][r * 4 + 1][0], L.World[par][r * 4 + 1][1]) * local(1, c) +
-                    Dual(L.World[par][r * 4 + 2][0], L.World[par][r * 4 + 2][1]) * local(2, c);
-                if (c == 3) w = w + Dual(L.World[par][r * 4 + 3][0], L.World[par][r * 4 + 3][1]);
+    for (int lvl = 0; lvl < n_levels; ++lvl) {
+        const int first = L.lvl_start[lvl], n_here = L.lvl_start[lvl + 1] - first;
+        for (int s0 = 0; s0 < n_here; s0 += 5) {
+            const int slot = (int)threadIdx.x / 12, e = (int)threadIdx.x % 12;
+            if (threadIdx.x < 60 && s0 + slot < n_here) {
+                const int j = L.lvl_joint[first + s0 + slot];
+                const int r = e >> 2, c = e & 3;
+                const int par = j > 0 ? L.par[j] : 0;
+                auto local = [&](int k, int cc) {                     // element (k, cc) of joint j's local transform
+                    if (cc < 3) return Dual(L.Rot[j][k * 3 + cc][0], L.Rot[j][k * 3 + cc][1]);
+                    Dual t(L.Jr[j][k][0], L.Jr[j][k][1]);
+                    if (j > 0) t = t - Dual(L.Jr[par][k][0], L.Jr[par][k][1]);
+                    return t;
+                };
+                Dual w;
+                if (j == 0) {
+                    w = local(r, c);
+                } else {
+                    w = Dual(L.World[par][r * 4 + 0][0], L.World[par][r * 4 + 0][1]) * local(0, c) +
+                        Dual(L.World[par][r * 4 + 1][0], L.World[par][r * 4 + 1][1]) * local(1, c) +
+                        Dual(L.World[par][r * 4 + 2][0], L.World[par][r * 4 + 2][1]) * local(2, c);
+                    if (c == 3) w = w + Dual(L.World[par][r * 4 + 3][0], L.World[par][r * 4 + 3][1]);
+                }
+                L.World[j][e][0] = w.v; L.World[j][e][1] = w.d;
             }
-            L.World[j][threadIdx.x][0] = w.v; L.World[j][threadIdx.x][1] = w.d;
         }
         __syncthreads();
     }

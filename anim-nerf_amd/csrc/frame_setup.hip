@@ -88,17 +88,46 @@ __global__ __launch_bounds__(64) void frame_chain_kernel(const int64_t* __restri
         }
     }
     __syncthreads();
-    // world_q = world_parent . [R_q | J_q - J_parent], one element (r, c) per lane, joints in tree order (parents[q] < q)
-    for (int q = 0; q < FS_J; ++q) {
-        if (j < 12) {
+    // world_q = world_parent . [R_q | J_q - J_parent], one element (r, c) per lane, the tree LEVEL BY LEVEL (9 levels for SMPL's
+    // skeleton, five joints of a level per pass) instead of joint by joint (24 dependent LDS round trips)
+    __shared__ int lvl_start[FS_J + 1], lvl_joint[FS_J], n_levels_s, par_s[FS_J], depth_s[FS_J];
+    if (j < FS_J) par_s[j] = (int)parents[j];
+    __syncthreads();
+    if (j < FS_J) {
+        int dpt = 0;
+        for (int k = j; k > 0; k = par_s[k]) ++dpt;                        // (parents[q] < q: tree order)
+        depth_s[j] = dpt;
+    }
+    __syncthreads();
+    if (j < FS_J) {
+        const int mine = depth_s[j];
+        int rank = 0;
+        for (int q = 0; q < FS_J; ++q) rank += (depth_s[q] < mine || (depth_s[q] == mine && q < j)) ? 1 : 0;
+        lvl_joint[rank] = j;
+    }
+    if (j <= FS_J) {
+        int c = 0, deepest = 0;
+        for (int q = 0; q < FS_J; ++q) { c += depth_s[q] < j ? 1 : 0; deepest = max(deepest, depth_s[q]); }
+        lvl_start[j] = c;
+        if (j == 0) n_levels_s = deepest + 1;
+    }
+    __syncthreads();
+    const int n_levels = n_levels_s;
+    for (int lvl = 0; lvl < n_levels; ++lvl) {
+        const int first = lvl_start[lvl], n_here = lvl_start[lvl + 1] - first;
+        for (int s0 = 0; s0 < n_here; s0 += 5) {
+            const int slot = j / 12, e = j % 12;
+            if (j < 60 && s0 + slot < n_here) {
 #pragma clang fp contract(fast)
-            const int r = j >> 2, c = j & 3;
-            const int p = q == 0 ? -1 : (int)parents[q];
-            auto loc = [&](int k, int cc) { return cc < 3 ? (double)Rm[q][k * 3 + cc] : Jr[q][k] - (p >= 0 ? Jr[p][k] : 0.0); };
-            double w;
-            if (p < 0) w = loc(r, c);
-            else w = Wd[p][r * 4 + 0] * loc(0, c) + Wd[p][r * 4 + 1] * loc(1, c) + Wd[p][r * 4 + 2] * loc(2, c) + (c == 3 ? Wd[p][r * 4 + 3] : 0.0);
-            Wd[q][j] = w;
+                const int q = lvl_joint[first + s0 + slot];
+                const int r = e >> 2, c = e & 3;
+                const int p = q == 0 ? -1 : par_s[q];
+                auto loc = [&](int k, int cc) { return cc < 3 ? (double)Rm[q][k * 3 + cc] : Jr[q][k] - (p >= 0 ? Jr[p][k] : 0.0); };
+                double w;
+                if (p < 0) w = loc(r, c);
+                else w = Wd[p][r * 4 + 0] * loc(0, c) + Wd[p][r * 4 + 1] * loc(1, c) + Wd[p][r * 4 + 2] * loc(2, c) + (c == 3 ? Wd[p][r * 4 + 3] : 0.0);
+                Wd[q][e] = w;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
