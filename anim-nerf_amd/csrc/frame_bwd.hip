@@ -402,9 +402,12 @@ __global__ __launch_bounds__(FB_THREADS) void frame_adjoint_kernel(
 #pragma unroll
             for (int e = 0; e < 12; ++e) T[e] = 0.0f;
             const float* w = lbs_w + (int64_t)v * FB_J;
-#pragma unroll 1
+            float wv[FB_J];                                      // (the 24 weights in one trip, not one trip per joint)
+#pragma unroll
+            for (int j = 0; j < FB_J; ++j) wv[j] = w[j];
+#pragma unroll
             for (int j = 0; j < FB_J; ++j) {
-                const float wj = w[j];
+                const float wj = wv[j];
                 if (wj != 0.0f) {
 #pragma unroll
                     for (int e = 0; e < 12; ++e) T[e] += wj * L.A[j][e][0];
