@@ -1921,6 +1921,95 @@ def test_add_inplace_and_background_weight_gradients(dev):
         assert (a - b).norm() / a.norm() < 2e-6 and (a - plain).norm() / plain.norm() > 1e-3        # (half the rows: other sums)
 
 
+def test_step_plumbing_entry_points_of_round_5(dev, smpl_table):
+    """The launches that took the explicit step from 95 to 70, each against what it replaces, bit for bit: anr_zero_segments /
+    anr_add_segments (fills and adds of several buffers in one launch, any length and alignment), anr_mlp_pack_pair /
+    anr_mlp_bwd_pack_pair (two networks per launch == anr_mlp_pack / anr_mlp_bwd_pack each), the draws' tangent quads ==
+    anr_tangent_quads(pair), anr_warp_points on a workspace zeroed by the caller (skip_far & 2) == the call that fills its own,
+    ANR_MLP_FLAG_NO_FILL (the tensors behind sigma.bias are left alone), anr_frame_backward_adjoint_values on a workspace whose
+    accumulators the caller zeroed == the call that fills them."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import ops, synthetic as syn
+    from anim_nerf_amd.autograd import PARAM_KEYS
+    g = torch.Generator().manual_seed(11)
+    # ---- fills and adds
+    bufs = [torch.randn(n + 1, generator=g).to(dev)[off:off + n] for n, off in ((1, 0), (7, 1), (4096, 0), (100_003, 1), (592_388, 0))]
+    src = [torch.randn(b.numel(), generator=g).to(dev) for b in bufs]
+    want = [b + s_ for b, s_ in zip(bufs, src)]
+    ops.add_segments(list(zip(bufs, src)))
+    assert all(torch.equal(b, w) for b, w in zip(bufs, want))
+    ops.zero_segments(bufs)
+    assert not any(b.any() for b in bufs)
+    # ---- two networks per pack launch
+    torch.manual_seed(0)
+    nets = [ana.NeRF(freqs_dir=0, use_view=False).to(dev) for _ in range(2)]
+    P = [{k: dict(n.named_parameters())[k].detach() for k in PARAM_KEYS} for n in nets]
+    for mode_name in ("bf16", "f32"):
+        mode = ops.MLP_MODES[mode_name]
+        for backward in (False, True):
+            pa, pb = ops.mlp_pack_pair(P[0], P[1], mode, backward=backward)
+            assert torch.equal(pa, ops.mlp_pack(P[0], mode, backward=backward)) and torch.equal(pb, ops.mlp_pack(P[1], mode, backward=backward))
+            assert not torch.equal(pa, pb)
+    # ---- the draws write the tangent quads
+    vt = torch.rand(2, 6890, 3, generator=g).to(dev)
+    n_pair = 2 * vt.numel() // 3
+    n_pad = -(-n_pair // 16) * 16
+    quads = torch.full((4 * n_pad, 4), float("nan"), device=dev)
+    state = torch.zeros(ops.DRAW_STATE_WORDS, dtype=torch.int64, device=dev)
+    state[0] = 1234
+    d = ops.train_draws(state, verts_template=vt, point_scale=0.1, neighbour_scale=0.02, quads=quads)
+    assert torch.equal(quads[:4 * n_pair], ops.tangent_quads(d["pair"], n_pad)[:4 * n_pair]) and torch.isnan(quads[4 * n_pair:]).all()
+    # ---- sigma-only weight gradients without the tail fill
+    mode = ops.MLP_MODES["bf16"]
+    n = 4096
+    pts = torch.cat([torch.rand(n, 3, generator=g) * 2 - 1, torch.ones(n, 1)], -1).to(dev)
+    g4 = torch.randn(n, 4, generator=g).to(dev)
+    _, act = ops.mlp_forward_save(ops.mlp_pack(P[0], mode), mode, pts, sigma_only=True)
+    dact = ops.mlp_backward(ops.mlp_pack(P[0], mode, backward=True), mode, g4, act, sigma_only=True)
+    enc = ops.encode64(pts, act.dtype)
+    filled = ops.mlp_wgrad(mode, act, dact, enc, g4, sigma_only=True)
+    lib = ana._lib.load()
+    n_sigma, n_all = lib.anr_mlp_wgrad_sigma_floats(), lib.anr_mlp_wgrad_floats()
+    out = torch.full((n_all,), 7.0, device=dev)
+    kept = ops.mlp_wgrad(mode, act, dact, enc, g4, sigma_only=True, out=out, no_fill=True)
+    assert kept.data_ptr() == out.data_ptr() and torch.equal(kept[:n_sigma], filled[:n_sigma])
+    assert not filled[n_sigma:].any() and bool((kept[n_sigma:] == 7.0).all()) and 0 < n_sigma < n_all
+    # ---- the warp and the pose chain on workspaces the caller zeroed
+    m = seeded_model(smpl_table, 3, True, device=dev)
+    bs = 2
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=77, bs=bs, pose_std=0.3).items()}
+    c2w, focal, cen = syn.pinhole_camera(32, 32)
+    full = ana.gen_rays(torch.from_numpy(c2w).to(dev), 32, 32, focal.tolist(), 0.1, 10.0, cen.tolist()).view(-1, 8)
+    with torch.no_grad():
+        m.set_body_model(pose, _templ(dev))
+        rays = m.convert_to_body_model_space(full[None].repeat(bs, 1, 1).contiguous())
+        m.clac_ober2cano_transform()
+        z = ana.VolumeRenderer(n_coarse=64).sample_coarse(rays)
+        args = (m.knn_index(), m.ober2cano_transform, m.body_model.lbs_weights, 0.2)
+        own = ops.warp_points(*args, rays=rays, z=z, skip_far=True, neighbours=True)
+        ws, zero_me = ops.warp_workspace(bs, z.shape[1] * z.shape[2], dev)
+        ws.fill_(0x7f7f7f7f)                                           # (everything the call does not zero itself: garbage)
+        ops.zero_segments([zero_me])
+        given = ops.warp_points(*args, rays=rays, z=z, skip_far=True, neighbours=True, workspace=ws)
+        v = own[0][..., 3] == 1
+        assert torch.equal(own[0][..., 3], given[0][..., 3]) and v.any()
+        for a, b in zip(own, given):
+            assert torch.equal(a[v], b[v])
+        c = m._chain_consts()
+        V = m.body_model.lbs_weights.shape[0]
+        d_o2c = torch.randn(bs, V, 4, 4, generator=g).to(dev) * 1e-3
+        d_rays = torch.randn(bs, rays.shape[1], 8, generator=g).to(dev) * 1e-3
+        rw = full[None].repeat(bs, 1, 1).contiguous()
+        common = (pose["betas"].expand(bs, -1).contiguous(), torch.cat([pose["global_orient"], pose["body_pose"]], -1).contiguous(),
+                  pose["transl"].contiguous(), c["J0"], c["JS"], c["parents"], c["lbs_weights"], c["shapedirs"], c["posedirs"], c["T_template"])
+        a = ops.frame_backward(*common, rays_world=rw, d_o2c=d_o2c, d_rays=d_rays)
+        fws, fz = ops.frame_backward_workspace(bs, V, dev)
+        fws.fill_(3.0)
+        ops.zero_segments([fz])
+        b = ops.frame_backward(*common, rays_world=rw, d_o2c=d_o2c, d_rays=d_rays, workspace=fws)
+        assert (a - b).abs().max() <= 1e-5 * a.abs().max()              # (float atomics: the order of the per-block sums)
+
+
 def test_explicit_step_branches_on_and_off(dev, smpl_table):
     """The explicit step with its parallel branches (the normals regulariser and the weight gradients on streams of their own)
     against the same step with every launch on one stream (ExplicitTrainStep.parallel = False; ANR_STEP_BRANCHES=0): the same
