@@ -167,9 +167,6 @@ class ExplicitTrainStep:
         # weight gradients first, the chain towards the points waited there: 1.64 against 1.7-1.9 ms per step at 2 frames)
         # (the gradient towards the points stays COMPACT — one row per valid sample, anr_mlp_dpoints: d-encoding and the
         # encoding's derivative in one launch — and the warp's backward looks a sample's row up through `pos`)
-        if os.environ.get("ANR_STEP_WGRAD_FIRST"):                    # (experiment: the fork captured before the chain's next launch)
-            weight_gradients()
-            return ops.mlp_dpoints(pack_b, mode_id, dact, st["pts_c"], count=rows) if want_pts else None
         out = ops.mlp_dpoints(pack_b, mode_id, dact, st["pts_c"], count=rows) if want_pts else None
         weight_gradients()
         return out
@@ -232,8 +229,6 @@ class ExplicitTrainStep:
             if self._streams is None:
                 self._streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
             self._side, self._wgrad_stream = self._streams
-            if os.environ.get("ANR_STEP_ONE_SIDE"):                  # (experiment: both side branches on one stream)
-                self._wgrad_stream = self._side
         else:                                                        # (debugging, per-kernel timing: every launch on the step's stream)
             self._side = self._wgrad_stream = main
         keep = []
