@@ -12,7 +12,7 @@
 //   2  frame_vertex_kernel  vertex blocks: shape / pose offsets, skinning transform, posed vertex, both into the root frame,
 //                           ober2cano = T_template (G^-1 T)^-1 + offset differences; ray blocks: o', d', near', far'.
 // The values agree with the separate kernels (anr_smpl_forward, anr_to_root_frame, anr_rays_to_body, anr_ober2cano) to fp32
-// rounding (tests/test_gpu_training.py::test_fused_frame_setup_matches_the_separate_kernels); both training steps (explicit
+// rounding (tests/test_gpu_parity.py::test_fused_frame_setup_matches_reference_and_the_separate_kernels); both training steps (explicit
 // and autograd) go through this one, so they see the same bits.
 #include "anr_common.h"
 
