@@ -54,7 +54,7 @@ class AnrLossArgs(C.Structure):
                 + [(k, _L) for k in ("R", "prior_rows", "nv", "normal_sets", "quad_rows")]
                 + [("n_fg", C.c_int32), ("n_bg", C.c_int32)]
                 + [(k, _F) for k in ("k", "delta", "lambda_alphas", "lambda_foreground", "lambda_background", "lambda_normals")]
-                + [("s_stride", C.c_int32), ("s_count", _P), ("s_count_fine", _P)])
+                + [("s_stride", C.c_int32), ("s_count", _P), ("s_count_fine", _P), ("s_grad_rows", C.c_int32)])
 
 
 class AnrDrawPlan(C.Structure):
@@ -127,6 +127,7 @@ SIGNATURES = {
     "anr_composite": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "anr_composite_indexed": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "anr_composite_backward_indexed": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "anr_composite_backward_compact": (_I, [_P, _P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "anr_composite_backward": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "anr_sample_fine_merge": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P]),
     "anr_sample_fine_merge_u8": (_I, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _P]),

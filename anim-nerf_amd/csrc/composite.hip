@@ -189,9 +189,17 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_backward_ker
     const float4* __restrict__ rgbs, const float* __restrict__ z, const float* __restrict__ rays, int stride,
     const float* __restrict__ noise, int64_t R, int K, int white_bkgd, const float* __restrict__ g_w,
     const float* __restrict__ g_rgb, const float* __restrict__ g_depth, const float* __restrict__ g_acc,
-    float4* __restrict__ d_rgbs, float* __restrict__ d_z, float* __restrict__ d_far, const int32_t* __restrict__ pos) {
+    float4* __restrict__ d_rgbs, float* __restrict__ d_z, float* __restrict__ d_far, const int32_t* __restrict__ pos,
+    float4* __restrict__ g4_rows = nullptr, const int32_t* __restrict__ count = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    // g4_rows (with pos): the gradient leaves as the g operand of the network's backward — row pos[sample] of the COMPACTED
+    // pass = (dL/d rgb . sigmoid', dL/d sigma), what anr_mlp_head_grad makes of d_rgbs — and nothing is written per sample;
+    // the (< 64) padding rows behind the count[0] listed ones are zeroed here
+    if (g4_rows != nullptr && count != nullptr && blockIdx.x == 0 && threadIdx.x < 64) {
+        const int lo = count[0], hi = count[1];
+        if (lo + (int)threadIdx.x < hi) g4_rows[lo + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (r >= R) return;
     const float4* c = rgbs + r * K;
     const float* zr = z + r * K;
@@ -203,14 +211,17 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_backward_ker
 
     float alpha[S], tr[S], zz[S], delta[S], sg[S];
     float4 col[S];
+    int prow[S];
     float prod = 1.0f;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         int k = lane * S + s;
         alpha[s] = 0.0f; tr[s] = 1.0f; zz[s] = 0.0f; delta[s] = 0.f; sg[s] = 0.f; col[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        prow[s] = -1;
         if (k < K) {
             if (pos != nullptr) {
                 const int p = pos[r * K + k];
+                prow[s] = p;
                 col[s] = p < 0 ? make_float4(0.f, 0.f, 0.f, -1e5f) : rgbs[p];
             } else {
                 col[s] = c[k];
@@ -251,7 +262,15 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_backward_ker
             const float dalpha = G[s] * tr[s] - after / t;
             const float e = expf(-delta[s] * fmaxf(sg[s], 0.0f));
             const float dsig = (sg[s] > 0.0f) ? dalpha * delta[s] * e : 0.0f;
-            d_rgbs[r * K + k] = make_float4(w[s] * gr, w[s] * gg, w[s] * gb, dsig);
+            if (g4_rows != nullptr) {
+                if (prow[s] >= 0) {
+                    const float4 o = col[s];
+                    const float ux = w[s] * gr, uy = w[s] * gg, uz = w[s] * gb;
+                    g4_rows[prow[s]] = make_float4(ux * o.x * (1.0f - o.x), uy * o.y * (1.0f - o.y), uz * o.z * (1.0f - o.z), dsig);
+                }
+            } else {
+                d_rgbs[r * K + k] = make_float4(w[s] * gr, w[s] * gg, w[s] * gb, dsig);
+            }
             if (k + 1 < K) ddelta[s] = dalpha * fmaxf(sg[s], 0.0f) * e;   // the last delta is the constant 1e10
             after += G[s] * w[s];
             wsum += w[s];
@@ -659,10 +678,34 @@ extern "C" int anr_composite_backward(const float* rgbs, const float* z, const f
                                           d_rgbs, d_z, d_far, stream);
 }
 
+static int composite_backward_any(const float* rgbs, const int32_t* pos, const float* z, const float* rays, int stride,
+                                  const float* noise, int64_t R, int K, int white_bkgd, const float* g_weights,
+                                  const float* g_rgb, const float* g_depth, const float* g_acc, float* d_rgbs,
+                                  float* d_z, float* d_far, float* g4_rows, const int32_t* count, void* stream);
+
 extern "C" int anr_composite_backward_indexed(const float* rgbs, const int32_t* pos, const float* z, const float* rays, int stride,
                                               const float* noise, int64_t R, int K, int white_bkgd, const float* g_weights,
                                               const float* g_rgb, const float* g_depth, const float* g_acc, float* d_rgbs,
                                               float* d_z, float* d_far, void* stream) {
+    ANR_REQUIRE(d_rgbs, ANR_E_BADARG, "anr_composite_backward: null pointer");
+    return composite_backward_any(rgbs, pos, z, rays, stride, noise, R, K, white_bkgd, g_weights, g_rgb, g_depth, g_acc, d_rgbs, d_z, d_far,
+                                  nullptr, nullptr, stream);
+}
+
+extern "C" int anr_composite_backward_compact(const float* rows, const int32_t* pos, const int32_t* count, const float* z, const float* rays,
+                                              int stride, const float* noise, int64_t R, int K, int white_bkgd, const float* g_weights,
+                                              const float* g_rgb, const float* g_depth, const float* g_acc, float* g4_rows_out,
+                                              float* d_z, float* d_far, void* stream) {
+    ANR_REQUIRE(pos && count && g4_rows_out, ANR_E_BADARG, "anr_composite_backward_compact: null pointer");
+    ANR_REQUIRE(((uintptr_t)g4_rows_out & 15) == 0, ANR_E_ALIGN, "anr_composite_backward_compact: g4_rows_out must be 16-B aligned");
+    return composite_backward_any(rows, pos, z, rays, stride, noise, R, K, white_bkgd, g_weights, g_rgb, g_depth, g_acc, g4_rows_out, d_z,
+                                  d_far, g4_rows_out, count, stream);
+}
+
+static int composite_backward_any(const float* rgbs, const int32_t* pos, const float* z, const float* rays, int stride,
+                                  const float* noise, int64_t R, int K, int white_bkgd, const float* g_weights,
+                                  const float* g_rgb, const float* g_depth, const float* g_acc, float* d_rgbs,
+                                  float* d_z, float* d_far, float* g4_rows, const int32_t* count, void* stream) {
     ANR_REQUIRE(rgbs && z && rays && d_rgbs, ANR_E_BADARG, "anr_composite_backward: null pointer");
     ANR_REQUIRE(R > 0 && K > 0 && stride >= 8, ANR_E_BADARG, "anr_composite_backward: R=%lld K=%d stride=%d", (long long)R, K, stride);
     ANR_REQUIRE(K <= ANR_MAX_SAMPLES, ANR_E_SHAPE, "anr_composite_backward: K=%d > %d", K, ANR_MAX_SAMPLES);
@@ -673,7 +716,7 @@ extern "C" int anr_composite_backward_indexed(const float* rgbs, const int32_t* 
     hipStream_t st = (hipStream_t)stream;
 #define ANR_LAUNCH_CB(SS)                                                                                      \
     hipLaunchKernelGGL(composite_backward_kernel<SS>, grid, block, 0, st, c, z, rays, stride, noise, R, K, white_bkgd, \
-                       g_weights, g_rgb, g_depth, g_acc, d, d_z, d_far, pos)
+                       g_weights, g_rgb, g_depth, g_acc, d, d_z, d_far, pos, reinterpret_cast<float4*>(g4_rows), count)
     switch ((K + 63) / 64) {
         case 1: ANR_LAUNCH_CB(1); break;
         case 2: ANR_LAUNCH_CB(2); break;

@@ -419,12 +419,15 @@ __global__ __launch_bounds__(256) void train_loss_backward_kernel(anr_loss_args 
             const float cf = a.n_fg ? g * a.lambda_foreground * a.k / (float)(a.prior_rows * a.n_fg) : 0.0f;
             const float cb = a.n_bg ? -g * a.lambda_background * a.k / (float)(a.prior_rows * a.n_bg) : 0.0f;
             const int ss = a.s_stride > 0 ? a.s_stride : 1;
+            const int32_t* sc = pass ? a.s_count_fine : a.s_count;
+            const int64_t row_shift = (a.s_grad_rows && sc) ? (int64_t)sc[0] - a.prior_rows * per : 0;
             for (int64_t i = tid; i < a.prior_rows * per; i += nth) {
                 const float v = s[i * ss];
                 const float dv = v > 0.0f ? ((int)(i % per) < a.n_fg ? cf : cb) * expf(a.k * v) : 0.0f;
                 // s_stride 4: the sigmas are column 3 of (r, g, b, sigma) rows and so are their gradients (d_s points at row 0's r)
-                if (ss == 4) reinterpret_cast<float4*>(d_s)[i] = make_float4(0.f, 0.f, 0.f, dv);
-                else d_s[i * ss] = dv;
+                // (s_grad_rows: the gradient rows are the prior points' rows of the compacted pass, like the sigmas themselves)
+                if (ss == 4) reinterpret_cast<float4*>(d_s)[i + row_shift] = make_float4(0.f, 0.f, 0.f, dv);
+                else d_s[(i + row_shift) * ss] = dv;
             }
         }
         if (q && d_q) {

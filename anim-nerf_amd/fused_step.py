@@ -140,15 +140,15 @@ class ExplicitTrainStep:
         # copy, anr_expand_rows, a launch and 32 B per sample in each pass)
         return dict(net=net, params=params, index=index, pos=pos, pts_c=pts_c, count=count, rows=rows, out_c=out_c, act=act)
 
-    def _mlp_backward(self, st, mode_id, d_out_full, want_pts, keep, pack_b=None, frozen=False, wgrad_stream=None):
-        """activation, weight (into the network's flat buffer) and — want_pts — point gradients of one compacted pass.
+    def _mlp_backward(self, st, mode_id, g4, want_pts, keep, pack_b=None, frozen=False, wgrad_stream=None):
+        """activation, weight (into the network's flat buffer) and — want_pts — point gradients of one compacted pass; g4 = the
+        upstream gradient as the backward kernels' operand (the compositor's backward and the loss kernel wrote its rows).
         The weight gradients feed nothing else in the step: they run on a stream of their own (`_wgrad_stream`) behind the
         backward chain, which goes on with the gradient towards the points; `keep` holds what that stream still reads."""
         params, act, rows = st["params"], st["act"], st["rows"]
         if pack_b is None:
             weights_generation(params[0], backward=True)
             pack_b = _cached_pack(params, mode_id, True)
-        g4 = ops.mlp_head_grad(d_out_full, st["index"], st["out_c"], st["pts_c"], st["count"], False)
         dact = ops.mlp_backward(pack_b, mode_id, g4, act, count=rows, enc_only=frozen)
         if frozen:                                                   # the gradient towards the points, and nothing else
             return ops.mlp_dpoints(pack_b, mode_id, dact, st["pts_c"], count=rows)
@@ -178,7 +178,7 @@ class ExplicitTrainStep:
             setattr(a, k, None if v is None else v.data_ptr())
         for k in ("s", "s_fine", "s_count", "s_count_fine"):
             setattr(a, k, t.get(k))                              # raw addresses: column 3 of the pass's rows, its row count
-        for k in ("R", "prior_rows", "nv", "normal_sets", "quad_rows", "n_fg", "n_bg", "s_stride"):
+        for k in ("R", "prior_rows", "nv", "normal_sets", "quad_rows", "n_fg", "n_bg", "s_stride", "s_grad_rows"):
             setattr(a, k, int(consts.get(k, 0)))
         for k in ("k", "delta", "lambda_alphas", "lambda_foreground", "lambda_background", "lambda_normals"):
             setattr(a, k, float(consts.get(k, 0.0)))
@@ -427,14 +427,17 @@ class ExplicitTrainStep:
                   "lambda_background": hp.lambda_background, "lambda_normals": hp.lambda_normals}
         t = {"rgb": rgb_c, "acc": acc_c, "rgb_fine": rgb_f, "acc_fine": acc_f, "target_rgb": rgbs.reshape(-1, 3), "target_alpha": alphas.reshape(-1)}
         assert t["target_rgb"].is_contiguous() and t["target_alpha"].is_contiguous()
-        d_out_c = torch.empty(n_c + n_r, 4, dtype=torch.float32, device=dev)
-        d_out_f = torch.empty(n_f + n_r, 4, dtype=torch.float32, device=dev)
+        # the upstream gradient of either pass goes straight to the rows of the network's backward operand (round 5: no row per
+        # sample in between, no anr_mlp_head_grad): the compositor's backward writes the samples' rows, the loss kernel the prior
+        # points'
+        g4_c = torch.empty(st_c["pts_c"].shape[0], 4, dtype=torch.float32, device=dev)
+        g4_f = torch.empty(st_f["pts_c"].shape[0], 4, dtype=torch.float32, device=dev)
         if n_r:
             # the prior points' sigmas: the last n_r of the listed rows of each pass (count[0] of them, on the device)
             t["s"], t["s_fine"] = st_c["out_c"].data_ptr() + 12, st_f["out_c"].data_ptr() + 12
             t["s_count"], t["s_count_fine"] = st_c["count"].data_ptr(), st_f["count"].data_ptr()
             consts.update(prior_rows=bs, n_fg=fg_points.shape[1] if fg_points is not None else 0,
-                          n_bg=bg_points.shape[1] if bg_points is not None else 0, s_stride=4)
+                          n_bg=bg_points.shape[1] if bg_points is not None else 0, s_stride=4, s_grad_rows=1)
         if want_normals:
             t["quads"], t["quads_fine"] = tan[0][3], tan[1][3]
             consts.update(nv=m.verts_template.shape[1], normal_sets=m.verts_template.shape[0], quad_rows=tan[0][3].shape[0], delta=0.02)
@@ -449,7 +452,7 @@ class ExplicitTrainStep:
         d_rgb_c, d_acc_c, d_rgb_f, d_acc_f = (torch.empty_like(x) for x in (rgb_c, acc_c, rgb_f, acc_f))
         g.rgb, g.acc, g.rgb_fine, g.acc_fine = (x.data_ptr() for x in (d_rgb_c, d_acc_c, d_rgb_f, d_acc_f))
         if n_r:
-            g.s, g.s_fine = d_out_c.data_ptr() + 16 * n_c, d_out_f.data_ptr() + 16 * n_f
+            g.s, g.s_fine = g4_c.data_ptr(), g4_f.data_ptr()
         _lib.check(lib.anr_train_loss_backward(C.byref(args), ops._ptr(one), C.byref(g), ops._stream(vals)), "anr_train_loss_backward")
 
         # ---- backward: fine pass, the merge, coarse pass, coarse depths, frame chain (the normals' went with their forward)
@@ -457,12 +460,12 @@ class ExplicitTrainStep:
         if refine:
             d_o2c, d_rays = acc_buf[:bs * V * 16].view(bs, V, 4, 4), acc_buf[bs * V * 16:].view(bs, R, 8)
         res = ops.composite_backward(st_f["out_c"], zs.view(bs * R, K), flat_rays, vr.white_bkgd, d_rgb_f, None, d_acc_f,
-                                     noise=noise_f, want_dz=refine, out=d_out_f, pos=st_f["pos"])
+                                     noise=noise_f, want_dz=refine, pos=st_f["pos"], g4_out=g4_f, count=st_f["count"])
         dz_f = dfar_f = None
         if refine:
             _, dz_f, dfar_f = res
         main.wait_event(packs_b_ready)
-        d_pts_f = self._mlp_backward(st_f, mode_id, d_out_f, refine, keep, packs_b[1], frozen)
+        d_pts_f = self._mlp_backward(st_f, mode_id, g4_f, refine, keep, packs_b[1], frozen)
         dz_c_from_fine = None
         if refine:
             dzw_f = ops.warp_backward_acc(d_pts_f, rays_b, zs, o2c, nidx_f, nw_f, d_o2c, d_rays, pos=st_f["pos"])
@@ -482,12 +485,12 @@ class ExplicitTrainStep:
             at_split()
             self._wgrad_stream.wait_stream(main)                     # (the side stream starts the second capture behind the first's end)
         res = ops.composite_backward(st_c["out_c"], zc.view(bs * R, Kc), flat_rays, vr.white_bkgd, d_rgb_c, None, d_acc_c,
-                                     noise=noise_c, want_dz=refine, out=d_out_c, pos=st_c["pos"])
+                                     noise=noise_c, want_dz=refine, pos=st_c["pos"], g4_out=g4_c, count=st_c["count"])
         # (the coarse pass's weight gradients on the normals branch's stream, long idle by now, instead of behind the fine
         # pass's on theirs — the weight gradients' stream is what a 16-frame step ends on: 3.24 -> 3.08 ms, same box;
         # all split-K slices for either pass instead of half: 3.10-3.15, gpurun_out/r05/ab_wgrad_streams.txt)
         coarse_wgrad_stream = self._side if (self.parallel and at_split is None and not os.environ.get("ANR_STEP_COARSE_WGRAD_QUEUED")) else None
-        d_pts_c = self._mlp_backward(st_c, mode_id, d_out_c, refine, keep, packs_b[0], frozen, wgrad_stream=coarse_wgrad_stream)
+        d_pts_c = self._mlp_backward(st_c, mode_id, g4_c, refine, keep, packs_b[0], frozen, wgrad_stream=coarse_wgrad_stream)
         if refine:
             _, dz_c, dfar_c = res
             dzw_c = ops.warp_backward_acc(d_pts_c, rays_b, zc, o2c, nidx_c, nw_c, d_o2c, d_rays, pos=st_c["pos"])

@@ -831,9 +831,12 @@ def composite(rgbs, z, rays, white_bkgd: bool, noise=None, want_weights: bool = 
 
 
 def composite_backward(rgbs, z, rays, white_bkgd: bool, g_rgb, g_depth, g_acc, noise=None, g_weights=None,
-                       want_dz: bool = False, out: Optional[torch.Tensor] = None, pos=None):
+                       want_dz: bool = False, out: Optional[torch.Tensor] = None, pos=None, g4_out: Optional[torch.Tensor] = None,
+                       count: Optional[torch.Tensor] = None):
     """Backward of `composite`: -> d_rgbs[R,K,4] (and d_z[R,K], d_far[R] if want_dz).  out: a caller-owned buffer whose first
-    R K rows receive d_rgbs (the explicit training step keeps rider rows behind them).  pos: as in `composite`."""
+    R K rows receive d_rgbs (the explicit training step keeps rider rows behind them).  pos: as in `composite`.
+    g4_out[rows,4] + count (with pos; anr_composite_backward_compact): the gradient goes straight to the g operand of the
+    network's backward — row pos[sample] = (dL/d rgb . sigmoid', dL/d sigma) — nothing per sample is written, d_rgbs is None."""
     lib = _lib.load()
     rgbs, z, rays = _dev(rgbs, "rgbs"), _dev(z, "z"), _dev(rays, "rays")
     g_rgb, g_depth, g_acc = (None if g is None else _dev(g, nm) for g, nm in ((g_rgb, "g_rgb"), (g_depth, "g_depth"), (g_acc, "g_acc")))
@@ -846,9 +849,19 @@ def composite_backward(rgbs, z, rays, white_bkgd: bool, g_rgb, g_depth, g_acc, n
         out = _dev(out, "out")
         if out.numel() < R * K * 4:
             raise ValueError("composite_backward: out is smaller than R K rows")
-    d = out if out is not None else torch.empty(R, K, 4, dtype=torch.float32, device=z.device)
     dz = torch.empty(R, K, dtype=torch.float32, device=z.device) if want_dz else None
     dfar = torch.empty(R, dtype=torch.float32, device=z.device) if want_dz else None
+    if g4_out is not None:
+        if pos is None or count is None:
+            raise ValueError("composite_backward: g4_out needs pos and count")
+        g4_out, count = _dev(g4_out, "g4_out"), _dev(count, "count", torch.int32)
+        with _timed("composite_backward", R * K):
+            _lib.check(lib.anr_composite_backward_compact(_ptr(rgbs), _ptr(_dev(pos, "pos", torch.int32)), _ptr(count), _ptr(z), _ptr(rays),
+                                                          rays.shape[-1], _ptr(noise), R, K, 1 if white_bkgd else 0, _ptr(g_weights),
+                                                          _ptr(g_rgb), _ptr(g_depth), _ptr(g_acc), _ptr(g4_out), _ptr(dz), _ptr(dfar),
+                                                          _stream(g4_out)), "anr_composite_backward_compact")
+        return (None, dz, dfar) if want_dz else None
+    d = out if out is not None else torch.empty(R, K, 4, dtype=torch.float32, device=z.device)
     with _timed("composite_backward", R * K):
         _lib.check(lib.anr_composite_backward_indexed(_ptr(rgbs), None if pos is None else _ptr(_dev(pos, "pos", torch.int32)), _ptr(z),
                                                       _ptr(rays), rays.shape[-1], _ptr(noise), R, K,

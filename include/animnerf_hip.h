@@ -548,7 +548,10 @@ typedef struct {
     const int32_t *s_count, *s_count_fine;   /* may be NULL.  Otherwise DEVICE counts: s / s_fine point at row 0 of a compacted pass's
                            output (its sigma with s_stride 4) and the prior points are the LAST prior_rows (n_fg + n_bg) of its first
                            s_count[0] rows (anr_compact_ordered_riders) — read where the network left them; the gradient rows d.s /
-                           d.s_fine are NOT offset (they belong to the expanded layout anr_mlp_head_grad gathers from) */
+                           d.s_fine are NOT offset (they belong to the expanded layout anr_mlp_head_grad gathers from) ... */
+    int32_t s_grad_rows;   /* ... unless this is 1 (with s_count): d.s / d.s_fine point at row 0 of the g operand of the network's
+                           backward (rows of the compacted pass, anr_composite_backward_compact) and the prior points' rows are
+                           written there, (0, 0, 0, d sigma) each */
 } anr_loss_args;
 /* gradient destinations, same shapes as the inputs (NULL: not wanted); quads: all quad_rows rows are written */
 typedef struct {
@@ -609,6 +612,14 @@ int anr_composite_backward(const float* rgbs, const float* z, const float* rays,
                            const float* g_depth, const float* g_acc, float* d_rgbs,
                            float* d_z /* [R*K] or NULL */, float* d_far /* [R] or NULL */, void* stream);
 /* ... with the inputs of anr_composite_indexed (pos may be NULL: anr_composite_backward); d_rgbs stays one row per sample */
+/* ... and straight to the g operand of the network's backward: g4_rows_out[row pos[sample]] = (dL/d rgb . sigmoid'(rgb),
+ * dL/d sigma) for the valid samples — what anr_mlp_head_grad makes of d_rgbs through the list — nothing per sample; the
+ * padding rows [count[0], count[1]) (anr_compact_ordered's device counts) are zeroed.  The prior points' rows are the loss
+ * kernel's (anr_loss_args.s_grad_rows). */
+int anr_composite_backward_compact(const float* rows, const int32_t* pos, const int32_t* count, const float* z, const float* rays,
+                                   int stride, const float* noise, int64_t R, int K, int white_bkgd, const float* g_weights,
+                                   const float* g_rgb, const float* g_depth, const float* g_acc, float* g4_rows_out, float* d_z,
+                                   float* d_far, void* stream);
 int anr_composite_backward_indexed(const float* rows, const int32_t* pos, const float* z, const float* rays, int stride,
                                    const float* noise, int64_t R, int K, int white_bkgd, const float* g_weights, const float* g_rgb,
                                    const float* g_depth, const float* g_acc, float* d_rgbs, float* d_z, float* d_far, void* stream);

@@ -891,6 +891,15 @@ def test_compositor_reads_compacted_rows_through_pos(dev):
                 db = ops.composite_backward(rows, z, rays, white, g_rgb, None, g_acc, noise=noise, want_dz=True, pos=pos)
                 for x, y in zip(da, db):
                     assert torch.equal(x, y)
+                # ... and straight to the rows of the network's backward operand (anr_composite_backward_compact) == the dense
+                # gradient gathered through the list by anr_mlp_head_grad; padding rows zero, nothing else touched
+                want = ops.mlp_head_grad(da[0].view(-1, 4), index, rows, pts_c, count, False)
+                g4 = torch.full((pts_c.shape[0], 4), 9.0, device=dev)
+                _, dz, dfar = ops.composite_backward(rows, z, rays, white, g_rgb, None, g_acc, noise=noise, want_dz=True, pos=pos, g4_out=g4,
+                                                     count=count)
+                c0, c1 = (int(v) for v in count.tolist())
+                assert torch.equal(g4[:c1], want[:c1]) and bool((g4[c1:] == 9.0).all()) and not g4[c0:c1].any()
+                assert torch.equal(dz, da[1]) and torch.equal(dfar, da[2])
 
 
 def test_depth_sampling_backward_kernels(dev):
