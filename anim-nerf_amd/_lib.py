@@ -54,7 +54,7 @@ class AnrLossArgs(C.Structure):
                 + [(k, _L) for k in ("R", "prior_rows", "nv", "normal_sets", "quad_rows")]
                 + [("n_fg", C.c_int32), ("n_bg", C.c_int32)]
                 + [(k, _F) for k in ("k", "delta", "lambda_alphas", "lambda_foreground", "lambda_background", "lambda_normals")]
-                + [("s_stride", C.c_int32), ("s_count", _P), ("s_count_fine", _P), ("s_grad_rows", C.c_int32)])
+                + [("s_stride", C.c_int32), ("s_count", _P), ("s_count_fine", _P), ("s_grad_rows", C.c_int32), ("quad_grad_rows", C.c_int32)])
 
 
 class AnrDrawPlan(C.Structure):

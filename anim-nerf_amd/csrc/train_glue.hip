@@ -447,10 +447,21 @@ __global__ __launch_bounds__(256) void train_loss_backward_kernel(anr_loss_args 
                     // n = scale(sigma) * grad sigma;  d scale / d sigma = -delta * scale
                     return make_float4(-a.delta * scale * (gx * qq.y + gy * qq.z + gz * qq.w), scale * gx, scale * gy, scale * gz);
                 };
-                d_q[ia] = through(u, iu, 1.0f, sa, qa);
-                d_q[ib] = through(v, iv, -1.0f, sb, qb);
+                const float4 ga = through(u, iu, 1.0f, sa, qa), gb = through(v, iv, -1.0f, sb, qb);
+                if (a.quad_grad_rows) {
+                    // ... as the g operand of the tangent-mode backward: row 4 p + q = (0, 0, 0, d (sigma | d/dx | d/dy | d/dz))
+                    // — what anr_mlp_head_grad (sigma only) makes of the quad's gradient, without that launch
+                    d_q[4 * ia + 0] = make_float4(0.f, 0.f, 0.f, ga.x); d_q[4 * ia + 1] = make_float4(0.f, 0.f, 0.f, ga.y);
+                    d_q[4 * ia + 2] = make_float4(0.f, 0.f, 0.f, ga.z); d_q[4 * ia + 3] = make_float4(0.f, 0.f, 0.f, ga.w);
+                    d_q[4 * ib + 0] = make_float4(0.f, 0.f, 0.f, gb.x); d_q[4 * ib + 1] = make_float4(0.f, 0.f, 0.f, gb.y);
+                    d_q[4 * ib + 2] = make_float4(0.f, 0.f, 0.f, gb.z); d_q[4 * ib + 3] = make_float4(0.f, 0.f, 0.f, gb.w);
+                } else {
+                    d_q[ia] = ga;
+                    d_q[ib] = gb;
+                }
             }
-            for (int64_t p = a.normal_sets * 2 * a.nv + tid; p < a.quad_rows; p += nth) d_q[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int64_t per = a.quad_grad_rows ? 4 : 1;
+            for (int64_t p = per * a.normal_sets * 2 * a.nv + tid; p < per * a.quad_rows; p += nth) d_q[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 }

@@ -178,7 +178,7 @@ class ExplicitTrainStep:
             setattr(a, k, None if v is None else v.data_ptr())
         for k in ("s", "s_fine", "s_count", "s_count_fine"):
             setattr(a, k, t.get(k))                              # raw addresses: column 3 of the pass's rows, its row count
-        for k in ("R", "prior_rows", "nv", "normal_sets", "quad_rows", "n_fg", "n_bg", "s_stride", "s_grad_rows"):
+        for k in ("R", "prior_rows", "nv", "normal_sets", "quad_rows", "n_fg", "n_bg", "s_stride", "s_grad_rows", "quad_grad_rows"):
             setattr(a, k, int(consts.get(k, 0)))
         for k in ("k", "delta", "lambda_alphas", "lambda_foreground", "lambda_background", "lambda_normals"):
             setattr(a, k, float(consts.get(k, 0.0)))
@@ -368,8 +368,9 @@ class ExplicitTrainStep:
             def normals_first_network():
                 with torch.cuda.stream(self._side):
                     pts4 = box["pts4"]
-                    d_quads = box["d_quads"] = [torch.empty_like(tan[0][3]), torch.empty_like(tan[1][3])]
-                    args_n = self._loss_args({"quads": tan[0][3], "quads_fine": tan[1][3]}, consts_n)
+                    # (the quads' gradient as the backward kernels' operand, four rows (0, 0, 0, .) per quad: no head-gradient launch)
+                    d_quads = box["d_quads"] = [torch.empty(4 * n_pad, 4, dtype=torch.float32, device=dev) for _ in range(2)]
+                    args_n = self._loss_args({"quads": tan[0][3], "quads_fine": tan[1][3]}, dict(consts_n, quad_grad_rows=1))
                     g_n = _lib.AnrLossGrads()
                     g_n.quads, g_n.quads_fine = d_quads[0].data_ptr(), d_quads[1].data_ptr()
                     _lib.check(lib.anr_train_loss_backward(C.byref(args_n), ops._ptr(one), C.byref(g_n), ops._stream(one)), "anr_train_loss_backward")
@@ -381,7 +382,7 @@ class ExplicitTrainStep:
             def normals_backward(i):
                 net, params, act_t, _ = tan[i]
                 pts4 = box["pts4"]
-                g4 = ops.mlp_head_grad(box["d_quads"][i].reshape(-1), None, None, pts4, pts4.shape[0], True)
+                g4 = box["d_quads"][i]
                 dact = ops.mlp_backward(packs_b[i], mode_id, g4, act_t, sigma_only=True, tangent=True)
                 # (sigma only: the tensors behind sigma.bias get nothing from this branch — neither written nor added below)
                 tan_grads.append((net, ops.mlp_wgrad(mode_id, act_t, dact, box["enc4"], g4, sigma_only=True, tangent=True, background=self.parallel,

@@ -552,6 +552,8 @@ typedef struct {
     int32_t s_grad_rows;   /* ... unless this is 1 (with s_count): d.s / d.s_fine point at row 0 of the g operand of the network's
                            backward (rows of the compacted pass, anr_composite_backward_compact) and the prior points' rows are
                            written there, (0, 0, 0, d sigma) each */
+    int32_t quad_grad_rows;   /* 1: d.quads / d.quads_fine are the g operand of the tangent-mode backward, [4 quad_rows][4]: row 4 p + q
+                           = (0, 0, 0, dL/d quads[p][q]) — what anr_mlp_head_grad (sigma only) makes of the quad gradients */
 } anr_loss_args;
 /* gradient destinations, same shapes as the inputs (NULL: not wanted); quads: all quad_rows rows are written */
 typedef struct {
