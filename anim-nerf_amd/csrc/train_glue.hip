@@ -110,53 +110,87 @@ __global__ __launch_bounds__(CB) void compact_gather_kernel(const float4* __rest
 // fences: MI355X_MICROARCH.md, "8-B agent atomics both sides").  Blocks take their number from a ticket, so every
 // predecessor a block waits for is already running.  The LAST block to finish puts state, tickets and all back to zero: the
 // buffer must be zero before its first use and is left zero by every call (a replayed graph needs no fill launch).
+// CSI samples per thread (block = CSI x CB consecutive samples, thread t takes t, t + CB, ...): the blocks' ticket — one
+// same-address atomic each, ~25-50 ns apiece one behind the other — was the kernel's clock with a block per 1,024 samples
+// (1,536 blocks: 47 us; 128: 12 us; the look-back, by one thread or by a wavefront, did not show).
+constexpr int CSI = 4;
 __global__ __launch_bounds__(CB) void compact_single_kernel(const float4* __restrict__ pts, int64_t n, Riders riders, int64_t n_r,
                                                             unsigned long long* __restrict__ state, int nb, int32_t* __restrict__ count,
                                                             int32_t* __restrict__ index, int32_t* __restrict__ pos,
                                                             float4* __restrict__ pts_out) {
-    __shared__ int wave_cnt[CB / WAVE];
+    __shared__ int wave_cnt[CSI][CB / WAVE];
     __shared__ int sh_bid, sh_excl, sh_total;
     unsigned* tickets = reinterpret_cast<unsigned*>(state + nb);         // [0]: block numbers, [1]: blocks done
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) sh_bid = (int)atomicAdd(&tickets[0], 1u);
     __syncthreads();
     const int bid = sh_bid;
-    const int64_t i = (int64_t)bid * CB + threadIdx.x;
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n) p = pts[i];
-    else if (i < n + n_r) p = riders.point(i - n);
-    const bool keep = (i < n && !(p.w < 1.0f)) || (i >= n && i < n + n_r);
-    const unsigned long long m = __ballot(keep);
-    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    float4 p[CSI];
+    bool keep[CSI];
+    unsigned long long m[CSI];
+#pragma unroll
+    for (int it = 0; it < CSI; ++it) {                       // (every load of the thread first)
+        const int64_t i = ((int64_t)bid * CSI + it) * CB + threadIdx.x;
+        p[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n) p[it] = pts[i];
+        else if (i < n + n_r) p[it] = riders.point(i - n);
+    }
+#pragma unroll
+    for (int it = 0; it < CSI; ++it) {
+        const int64_t i = ((int64_t)bid * CSI + it) * CB + threadIdx.x;
+        keep[it] = (i < n && !(p[it].w < 1.0f)) || (i >= n && i < n + n_r);
+        m[it] = __ballot(keep[it]);
+        if (lane == 0) wave_cnt[it][wave] = __popcll(m[it]);
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (wave == 0) {
+        // the look-back by a wavefront: lane l reads predecessor bid - 1 - l (spinning until it has published), the lanes up to
+        // the first inclusive prefix add up
         int tot = 0;
 #pragma unroll
-        for (int w = 0; w < CB / WAVE; ++w) tot += wave_cnt[w];
-        int excl = 0;
-        if (bid > 0) {
+        for (int it = 0; it < CSI; ++it)
+#pragma unroll
+            for (int w = 0; w < CB / WAVE; ++w) tot += wave_cnt[it][w];
+        if (lane == 0 && bid > 0)
             __hip_atomic_store(&state[bid], (1ull << 32) | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int j = bid - 1; j >= 0; --j) {
-                unsigned long long sj;
+        int excl = 0;
+        for (int base = bid - 1; base >= 0; base -= 64) {
+            const int j = base - lane;
+            unsigned long long sj = 0ull;
+            if (j >= 0) {
                 do { sj = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((sj >> 32) == 0);
-                excl += (int)(unsigned)sj;
-                if ((sj >> 32) == 2) break;
             }
+            const unsigned long long prefixes = __ballot(j >= 0 && (sj >> 32) == 2);
+            const int first = prefixes ? __builtin_ctzll(prefixes) : 64;      // the nearest predecessor that knows its prefix
+            int v = (j >= 0 && lane <= first) ? (int)(unsigned)sj : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            excl += v;
+            if (prefixes) break;
         }
-        __hip_atomic_store(&state[bid], (2ull << 32) | (unsigned)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sh_excl = excl;
-        sh_total = excl + tot;
-        if (bid == nb - 1) {
-            count[0] = excl + tot;
-            count[1] = excl + tot > 0 ? (excl + tot + 63) / 64 * 64 : 64;   // the row count the MLP kernels work on (padding rows: valid = 0)
+        if (lane == 0) {
+            __hip_atomic_store(&state[bid], (2ull << 32) | (unsigned)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_excl = excl;
+            sh_total = excl + tot;
+            if (bid == nb - 1) {
+                count[0] = excl + tot;
+                count[1] = excl + tot > 0 ? (excl + tot + 63) / 64 * 64 : 64;   // the row count the MLP kernels work on (padding rows: valid = 0)
+            }
         }
     }
     __syncthreads();
     int off = sh_excl;
-    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-    const int r = off + __popcll(m & ((1ull << lane) - 1ull));
-    if (keep) { index[r] = (int32_t)i; pts_out[r] = p; }
-    if (i < n + n_r) pos[i] = keep ? r : -1;
+#pragma unroll
+    for (int it = 0; it < CSI; ++it) {                       // sample order = (it, wave, lane) order inside the block
+        const int64_t i = ((int64_t)bid * CSI + it) * CB + threadIdx.x;
+        int mine = off;
+        for (int w = 0; w < wave; ++w) mine += wave_cnt[it][w];
+        const int r = mine + __popcll(m[it] & ((1ull << lane) - 1ull));
+        if (keep[it]) { index[r] = (int32_t)i; pts_out[r] = p[it]; }
+        if (i < n + n_r) pos[i] = keep[it] ? r : -1;
+#pragma unroll
+        for (int w = 0; w < CB / WAVE; ++w) off += wave_cnt[it][w];
+    }
     if (bid == nb - 1 && threadIdx.x < 64) {                 // padding rows up to the next multiple of 64: valid = 0
         const int c = sh_total, pad = (c + 63) / 64 * 64;
         if (c + (int)threadIdx.x < (pad > 0 ? pad : 64)) pts_out[c + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -504,7 +538,7 @@ extern "C" int anr_compact_ordered_single(const float* pts, int64_t n, const flo
     ANR_REQUIRE(n > 0 && n + n_r < (int64_t)1 << 31, ANR_E_BADARG, "anr_compact_ordered_single: n=%lld riders=%lld", (long long)n, (long long)n_r);
     ANR_REQUIRE((((uintptr_t)pts | (uintptr_t)pts_out) & 15) == 0 && ((uintptr_t)state & 7) == 0, ANR_E_ALIGN,
                 "anr_compact_ordered_single: pts / pts_out must be 16-B aligned, state 8-B");
-    const int nb = (int)((n + n_r + CB - 1) / CB);
+    const int nb = (int)((n + n_r + (int64_t)CSI * CB - 1) / ((int64_t)CSI * CB));
     hipLaunchKernelGGL(compact_single_kernel, dim3(nb), dim3(CB), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(pts), n, riders, n_r,
                        reinterpret_cast<unsigned long long*>(state), nb, count_out, index_out, pos_out, reinterpret_cast<float4*>(pts_out));
     return check_launch("anr_compact_ordered_single");
