@@ -17,6 +17,12 @@ HEADERS = ["anr_common.h", "mlp_core.h", os.path.join("..", "..", "include", "an
 # The 4-wave x 64-point bf16 variant needs more than 256 registers per lane: with the accumulators in AGPRs (hipcc's
 # default) its epilogue spends 2,700 v_accvgpr_read per point tile; VGPR-form MFMAs cut that to 500 (51 -> 54 % of peak).
 PER_SOURCE_FLAGS = {"mlp_inst_bf16_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# No SLP vectorisation: the packed fp32 forms it produces (v_pk_add_f32 / v_pk_mul_f32 with op_sel and neg modifiers, one half
+# of the pair swapped) sporadically returned the unmodified operand in one lane when other kernels shared the GPU — the step's
+# parallel branches — 1-2 % of replayed steps with a wrong red channel or a pose gradient off by 1e-3..1e-2 (DESIGN 4.4,
+# tools/exp/race_hunt.py, profiles/r05/race_hunt_*.txt).  Without it: 0 deviations above 1.2e-6 in 8,000 replays, and
+# no kernel is slower (profiles/r05/ab_no_slp.txt).  ANR_BUILD_SLP=1 builds the old way, for the hunting tool.
+NO_SLP = [] if os.environ.get("ANR_BUILD_SLP") else ["-fno-slp-vectorize"]
 
 
 def _hipcc() -> str:
@@ -43,6 +49,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = Non
     objs = []
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              "-Wno-unused-value", "-Wno-pass-failed"] + [f"-D{d}" for d in defines] + list(extra_flags)
+    flags += NO_SLP
     tag = ("." + "_".join(defines)) if defines else ""
     if extra_flags:
         tag += ".x" + hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:8]

@@ -509,6 +509,17 @@ class ExplicitTrainStep:
         if want_normals and not normals_joined:                      # flat = render passes' + normals' (0 + r + t == 0 + t + r bit for bit)
             main.wait_stream(self._side)
             add_normals()
+        if os.environ.get("ANR_STEP_DEBUG_KEEP"):
+            # (tools/exp/race_hunt.py: the step's intermediates by name — their addresses are the graph's, the same at every
+            # replay — to find WHICH buffer differs when two replays of one step disagree)
+            loc = locals()
+            names = ("zc", "pts_c", "nidx_c", "nw_c", "w_c", "rgb_c", "acc_c", "zs", "perm", "pts_f", "nidx_f", "nw_f", "rgb_f", "acc_f",
+                     "vals", "g4_c", "g4_f", "d_pts_f", "d_pts_c", "acc_buf", "frame_ws", "grads", "dzw_f", "dzw_c", "dz_c_from_fine")
+            self.debug_keep = {k: loc[k] for k in names if torch.is_tensor(loc.get(k))}
+            self.debug_keep.update({"out_c": st_c["out_c"], "out_f": st_f["out_c"], "cnt_c": st_c["count"], "cnt_f": st_f["count"],
+                                    "act_c": st_c["act"], "act_f": st_f["act"], "fs_o2c": o2c, "fs_rays": rays_b, "index": index})
+            self.debug_keep.update({f"quads{i}": x[3] for i, x in enumerate(tan)})
+            self.debug_keep.update({f"draw_{k}": v for k, v in draws.items() if torch.is_tensor(v)})
         keep.clear()
         for s in sinks:                                              # (three passes each went straight into the flat buffers)
             s.expected = s.done = 0

@@ -2063,3 +2063,54 @@ def test_explicit_step_branches_on_and_off(dev, smpl_table):
         for k in gb:
             err = (ga[k] - gb[k]).norm() / gb[k].norm().clamp_min(1e-20)
             assert err < 1e-4, (k, err.item())
+
+
+def test_replays_of_one_step_reproduce_its_gradients(dev, smpl_table):
+    """One graphed step replayed 600 times with the learning rates at 0 and the draw counter rewound: every replay must give
+    the first replay's loss and gradients — networks' flat buffers, SMPL rows — up to the order of the float atomics' additions
+    (measured 1.2e-6 of the largest entry; gate 1e-4).  Round 5: with SLP-vectorised packed fp32 adds in the library 1-2 % of
+    such replays had a wrong red channel in the fine compositor or a pose gradient off by 1e-3..1e-2, and only with the step's
+    parallel branches running next to each other (tools/exp/race_hunt.py) — a test on one stream cannot see it."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    frames, H = 2, 32
+    c2w, focal, cen = syn.pinhole_camera(H, H)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), H, H, focal.tolist(), 0.1, 10.0, cen.tolist())[None].repeat(frames, 1, 1, 1).contiguous()
+    gen = torch.Generator().manual_seed(0)
+    rgbs = torch.rand(frames, H, H, 3, generator=gen).to(dev)
+    alphas = (torch.rand(frames, H, H, 1, generator=gen) > 0.5).float().to(dev)
+    fg = (torch.rand(frames, 128, 3, generator=gen) * 0.2 - 0.1).to(dev)
+    bg = (torch.rand(frames, 128, 3, generator=gen) * 2 - 1).to(dev) * 1.2
+    frame_idx = torch.tensor([0, 20], device=dev)
+    seeded = syn.animated_pose_params(seed=200, bs=40)
+    torch.manual_seed(0)
+    m = ana.AnimNeRF(body_model_table=smpl_table, freqs_dir=0, use_view=False, use_unpose=True, use_knn=True, use_fine=True,
+                     mlp_mode="bf16").to(dev)
+    table = ana.BodyModelParams(40).to(dev)
+    for name in table.param_names:
+        table.init_parameters(name, torch.from_numpy(seeded[name]).to(dev), requires_grad=True)
+    tr = ana.Trainer(m, ana.VolumeRenderer(n_coarse=64, n_fine=32), ana.TrainHParams(n_samples=64, n_importance=32, chunk=2048),
+                     body_model_params=table, graph=True)
+    for g in tr.optimizer.param_groups:
+        g["lr"] = 0.0
+    state0, ref, devs = None, None, []
+    with tr.loop():
+        for it in range(600 + 7):
+            if state0 is not None:
+                tr.explicit.draw_state.copy_(state0)
+            loss, det = tr.step_graphed(rays, rgbs, alphas, None, _templ(dev), fg, bg, perturb=1.0, frame_idx=frame_idx)
+            if it == 4:
+                state0 = tr.explicit.draw_state.clone()
+            if it < 6:
+                continue
+            cur = [m.nerf_fine.grad_sink.flat.clone(), m.nerf.grad_sink.flat.clone(), loss.reshape(1).clone()]
+            cur += [getattr(table, n).weight.grad.reshape(-1).clone() for n in table.param_names]
+            if ref is None:
+                ref = cur
+                scale = [v.abs().max().clamp_min(1e-30) for v in ref]
+                continue
+            devs.append(torch.stack([(a - b).abs().max() / s for a, b, s in zip(cur, ref, scale)]))
+    assert tr._graph is not None
+    worst = torch.stack(devs).max(0)[0]
+    assert float(ref[0].abs().max()) > 0 and float(ref[3].abs().max()) > 0
+    assert float(worst.max()) < 1e-4, worst.tolist()
