@@ -424,6 +424,78 @@ __global__ __launch_bounds__(256) void encode_kernel(const float* __restrict__ p
     }
 }
 
+// The 64-column form for anr_mlp_wgrad, one row per thread computed in registers and written as 16-byte pieces: the kernel
+// above stores a row element by element — 64 two-byte stores per thread, each wave-wide store instruction touching 64 rows
+// 128 B apart — and calls sinf / cosf 60 times per row: 76-105 us at the head of the fine pass's weight-gradient chain of a
+// 16-frame step.  bf16: the octaves by the double-angle recurrence from a sincosf at 2^0 and another at 2^5 (the error doubles
+// per octave: ~3e-6 absolute after four, three decimal orders under bf16's resolution; from a single seed it reached 1.5e-4
+// at 2^9), the wavefront's 64 rows transposed through LDS (row pitch
+// 144 B: conflict-free) so that every store instruction writes 1 KB of consecutive bytes.  fp32 (parity mode): sincosf per
+// frequency, 16-byte stores.
+template <typename T>
+__global__ __launch_bounds__(256) void encode64_kernel(const float* __restrict__ pts, int stride, int64_t n, T* __restrict__ enc,
+                                                       int tangent, const int32_t* __restrict__ count) {
+    constexpr bool BF = sizeof(T) == 2;
+    __shared__ __attribute__((aligned(16))) char sh[BF ? 4 * 64 * 144 : 16];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (count && *count < n) n = *count;                    // row limit on the device (training: the compacted list's padded length)
+    const bool live = i < n;
+    float v[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) v[c] = 0.0f;
+    if (live) {
+        const float x[3] = {pts[i * stride], pts[i * stride + 1], pts[i * stride + 2]};
+        const int a = (tangent && (i & 3)) ? (int)(i & 3) - 1 : -1;       // row 4p + t, t = 1..3: d enc / d x_{t-1}
+        float sn[3], cs[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            sincosf(x[d], &sn[d], &cs[d]);
+            v[d] = a < 0 ? x[d] : (d == a ? 1.0f : 0.0f);
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const float f = (float)(1 << k);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if ((!BF && k > 0) || k == 5) sincosf(f * x[d], &sn[d], &cs[d]);
+                if (a < 0) { v[3 + 6 * k + d] = sn[d]; v[6 + 6 * k + d] = cs[d]; }
+                else if (d == a) { v[3 + 6 * k + d] = f * cs[d]; v[6 + 6 * k + d] = -f * sn[d]; }
+                if (BF) { const float s2 = 2.0f * sn[d] * cs[d], c2 = 1.0f - 2.0f * sn[d] * sn[d]; sn[d] = s2; cs[d] = c2; }
+            }
+        }
+    }
+    if constexpr (BF) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        char* mine = sh + wave * (64 * 144);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            unsigned w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const __bf16 lo = (__bf16)v[8 * q + 2 * e], hi = (__bf16)v[8 * q + 2 * e + 1];
+                w[e] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+            }
+            *reinterpret_cast<uint4*>(mine + lane * 144 + q * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        // (the patch is this wavefront's own: the LDS unit executes a wave's instructions in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int64_t row0 = (int64_t)blockIdx.x * 256 + wave * 64;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = q * 8 + (lane >> 3), c = lane & 7;
+            if (row0 + r < n)
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(enc) + (row0 + r) * 128 + c * 16) =
+                    *reinterpret_cast<const uint4*>(mine + r * 144 + c * 16);
+        }
+    } else {
+        if (live) {
+            float4* row = reinterpret_cast<float4*>(enc + i * 64);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) row[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void encode_backward_kernel(const float* __restrict__ pts, int stride, const float* __restrict__ d_enc,
                                                               int64_t n, float4* __restrict__ d_pts, const int32_t* __restrict__ count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -462,10 +534,11 @@ static int encode64(const float* pts, int pts_stride, int64_t n, const int32_t* 
     ANR_REQUIRE(n > 0 && pts_stride >= 3, ANR_E_BADARG, "anr_encode64: n=%lld stride=%d", (long long)n, pts_stride);
     dim3 grid((unsigned)((n + 255) / 256));
     const int tan = (flags & ANR_MLP_FLAG_TANGENT) ? 1 : 0;
+    ANR_REQUIRE(((uintptr_t)enc_out & 15) == 0, ANR_E_ALIGN, "anr_encode64: enc_out must be 16-B aligned");
     if (flags & 1)
-        hipLaunchKernelGGL((anr::encode_kernel<__bf16, 64>), grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (__bf16*)enc_out, tan, count);
+        hipLaunchKernelGGL(anr::encode64_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (__bf16*)enc_out, tan, count);
     else
-        hipLaunchKernelGGL((anr::encode_kernel<float, 64>), grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (float*)enc_out, tan, count);
+        hipLaunchKernelGGL(anr::encode64_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, pts, pts_stride, n, (float*)enc_out, tan, count);
     return anr::check_launch("anr_encode64");
 }
 extern "C" int anr_encode64(const float* pts, int pts_stride, int64_t n, int flags, void* enc_out, void* stream) {

@@ -184,7 +184,12 @@ def test_weight_gradient_kernel(dev, smpl_table, mode, n):
         out, act = ops.mlp_forward_save(ops.mlp_pack(P, mode_id), mode_id, pts, sigma_only)
         dact = ops.mlp_backward(ops.mlp_pack(P, mode_id, backward=True), mode_id, g4, act, sigma_only=sigma_only)
         enc = ops.encode64(pts, act.dtype)
-        assert torch.equal(enc[:, :63], ops.encode(pts, act.dtype)) and (enc[:, 63] == 0).all()
+        e32 = ops.encode(pts, torch.float32)
+        if mode == "f32":
+            assert torch.equal(enc[:, :63], e32)
+        else:       # bf16: octaves by the double-angle recurrence (re-seeded at 2^5: < 1e-5 absolute), then ONE rounding to bf16 (half an ulp: 2^-9)
+            assert (enc[:, :63].float() - e32).abs().max() <= 2.0 ** -9 + 1e-5
+        assert (enc[:, 63] == 0).all()
         flat = ops.mlp_wgrad(mode_id, act, dact, enc, g4, sigma_only=sigma_only)
         assert torch.equal(flat, ops.mlp_wgrad(mode_id, act, dact, enc, g4, sigma_only=sigma_only)), "not deterministic"
         A, D, E, G = ops.act_columns(act).double(), ops.act_columns(dact).double(), enc.double()[:, :63], g4.double()
@@ -2114,3 +2119,44 @@ def test_replays_of_one_step_reproduce_its_gradients(dev, smpl_table):
     worst = torch.stack(devs).max(0)[0]
     assert float(ref[0].abs().max()) > 0 and float(ref[3].abs().max()) > 0
     assert float(worst.max()) < 1e-4, worst.tolist()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_encode64_values_tangent_rows_and_row_limit(dev, dtype):
+    """anr_encode64 (the weight-gradient GEMMs' first operand; models/embedding.py:22-39 plus a zero column) against torch in
+    double: value rows, the tangent layout (row 4p = values of point p, rows 4p+1..3 = d enc / d x, y, z) and the device-side
+    row limit (rows at and behind *count are left alone).  fp32: 2e-6 relative to the frequency; bf16 (octaves by the
+    double-angle recurrence from one sincosf, two seeds, one rounding at the end): half a bf16 ulp + 1e-5, relative to the frequency."""
+    from anim_nerf_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    n = 1000                                                      # not a multiple of 64: the last wavefront's partial patch
+    pts = torch.cat([torch.rand(n, 3, generator=gen) * 2.4 - 1.2, torch.ones(n, 1)], -1).to(dev)
+    x = pts[:, :3].double()
+    f = (2.0 ** torch.arange(10, device=dev, dtype=torch.float64))
+    ang = x[:, None, :] * f[None, :, None]                        # [n, 10, 3]
+    val = torch.cat([x, torch.cat([ang.sin(), ang.cos()], -1).reshape(n, 60)], -1)           # [n, 63]
+    scale = torch.cat([torch.ones(3, device=dev, dtype=torch.float64), f.repeat_interleave(6)])
+    tol = 2e-6 if dtype == torch.float32 else 2.0 ** -8 + 1e-5        # (|x| up to 1.2: half an ulp of [1, 2) is 2^-8)
+    enc = ops.encode64(pts, dtype)
+    assert enc.dtype == dtype and (enc[:, 63] == 0).all()
+    assert (enc[:, :63].double() - val).abs().max() <= tol
+    # tangent rows
+    quads = pts.repeat_interleave(4, 0).contiguous()
+    enc4 = ops.encode64(quads, dtype, tangent=True).double().view(n, 4, 64)
+    assert (enc4[:, 0, :63] - val).abs().max() <= tol and (enc4[..., 63] == 0).all()
+    for a in range(3):
+        d = torch.zeros(n, 10, 6, device=dev, dtype=torch.float64)
+        d[:, :, a] = f[None] * ang[:, :, a].cos()
+        d[:, :, 3 + a] = -f[None] * ang[:, :, a].sin()
+        want = torch.cat([torch.eye(3, device=dev, dtype=torch.float64)[a].expand(n, 3), d.reshape(n, 60)], -1)
+        assert ((enc4[:, 1 + a, :63] - want).abs() / scale).max() <= tol, a
+    # row limit on the device
+    cnt = torch.tensor([333], dtype=torch.int32, device=dev)
+    lim = ops.encode64(pts, dtype, count=cnt)
+    assert torch.equal(lim[:333], enc[:333])
+    lim2 = torch.full_like(enc, 7.0)
+    from anim_nerf_amd import _lib
+    lib = _lib.load()
+    flags = 1 if dtype == torch.bfloat16 else 0
+    _lib.check(lib.anr_encode64_counted(pts.data_ptr(), 4, n, cnt.data_ptr(), flags, lim2.data_ptr(), torch.cuda.current_stream().cuda_stream), "anr_encode64")
+    assert torch.equal(lim2[:333], enc[:333]) and (lim2[333:] == 7.0).all()
