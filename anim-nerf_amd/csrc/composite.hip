@@ -22,14 +22,18 @@ __device__ __forceinline__ float dpp(float old, float v) {     // lanes that rec
                                                                  CTRL, ROW_MASK, 0xf, false));
 }
 // inclusive product / sum over each segment of W lanes (W = 32: two rays per wavefront, W = 64: one)
+// (v_mul_f32_dpp with the accumulator as destination: a lane that receives nothing is left as it is, i.e. multiplied by 1.
+// The compiler fuses `v += dpp(0, v)` into v_add_f32_dpp by itself but turns `v *= dpp(1, v)` into v_mov 1.0 / v_mov_dpp /
+// v_mul — three issue slots per step of a kernel that is bound by them.  s_nop 1: a DPP operand written by the previous VALU
+// instruction needs two wait states, and the compiler does not look into the asm.)
 template <int W>
 __device__ __forceinline__ float seg_incl_prod(float v) {
-    v *= dpp<DPP_ROW_SHR1>(1.0f, v);
-    v *= dpp<DPP_ROW_SHR2>(1.0f, v);
-    v *= dpp<DPP_ROW_SHR4>(1.0f, v);
-    v *= dpp<DPP_ROW_SHR8>(1.0f, v);
-    v *= dpp<DPP_ROW_BCAST15, 0xA>(1.0f, v);
-    if (W == 64) v *= dpp<DPP_ROW_BCAST31, 0xC>(1.0f, v);
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+    if (W == 64) asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
     return v;
 }
 template <int W>
@@ -305,8 +309,10 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_backward_ker
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ double dpp_d(double old, double v) {
     const uint64_t o = __builtin_bit_cast(uint64_t, old), x = __builtin_bit_cast(uint64_t, v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)x, CTRL, ROW_MASK, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(o >> 32), (int)(x >> 32), CTRL, ROW_MASK, 0xf, false);
+    // every caller passes old = 0: with all rows taking part, bound_ctrl writes that zero itself (no v_mov 0 per half)
+    constexpr bool BC = ROW_MASK == 0xf;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)x, CTRL, ROW_MASK, 0xf, BC);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(o >> 32), (int)(x >> 32), CTRL, ROW_MASK, 0xf, BC);
     return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
 }
 template <int W>
@@ -332,10 +338,21 @@ template <int KT> struct RayLds {
 // depths, wbuf[0..Kc) = coarse weights, hist[0..Kc] = 0, all visible.
 // Returns with wbuf[0..K) = sorted depths and (want_perm) ((PermT*)cdf)[0..K) = permutation.
 // KC / KF > 0: the sample counts as compile-time constants (the shipped shapes): every bound check below folds away.
+// The lane's u values (fine sample j = f * LPR + l), loaded by the CALLER before its own first wait on memory: behind the
+// compositing they were a round trip to HBM in the middle of the wavefront's chain, one per sample (round 5).
+template <int LPR, int KT, int KF = 0>
+__device__ __forceinline__ void load_u(const float* __restrict__ u_row, int lane, int Kf_rt, float (&uu)[(KT + LPR - 1) / LPR]) {
+    const int Kf = KF ? KF : Kf_rt, l = lane % LPR;
+#pragma unroll
+    for (int f = 0; f < (KT + LPR - 1) / LPR; ++f) uu[f] = (f * LPR + l < Kf) ? u_row[f * LPR + l] : 0.0f;
+}
+
 template <int LPR, int KT, typename PermT, int KC = 0, int KF = 0, class Sync>
-__device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int lane, const float* __restrict__ u_row, int Kc_rt, int Kf_rt,
+__device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int lane, const float (&uu)[(KT + LPR - 1) / LPR], int Kc_rt, int Kf_rt,
                                                float* __restrict__ z_fine_row, bool want_perm, Sync sync) {
     constexpr int MAXS = (KT + LPR - 1) / LPR;
+    constexpr int NS = KC ? (KC - 2 + LPR - 1) / LPR : MAXS;       // pdf entries per lane (a 0 / total beyond them is not folded away)
+    constexpr int NF = KF ? (KF + LPR - 1) / LPR : MAXS;           // fine samples per lane
     const int Kc = KC ? KC : Kc_rt, Kf = KF ? KF : Kf_rt;
     const int l = lane % LPR;
     const float eps = 1e-5f;
@@ -343,10 +360,10 @@ __device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int lane, const fl
     const int np = Kc - 2;                                // pdf entries
     // pdf over weights[1:-1] + eps; each lane owns a contiguous run of S entries
     const int S = (np + LPR - 1) / LPR;
-    float wl[MAXS];
+    float wl[NS];
     float loc = 0.f;
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s) {
+    for (int s = 0; s < NS; ++s) {
         int i = l * S + s;
         wl[s] = (s < S && i < np) ? (L.wbuf[1 + i] + eps) : 0.f;
         loc += wl[s];
@@ -354,11 +371,11 @@ __device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int lane, const fl
     const float total = seg_sum<LPR>(loc, lane);
     double ploc = 0.0;
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s) { wl[s] = wl[s] / total; ploc += (double)wl[s]; }
+    for (int s = 0; s < NS; ++s) { wl[s] = wl[s] / total; ploc += (double)wl[s]; }
     double run = seg_excl_sum_d<LPR>(ploc, l);
     if (l == 0) L.cdf[0] = 0.f;
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s) {
+    for (int s = 0; s < NS; ++s) {
         int i = l * S + s;
         if (s < S && i < np) { run += (double)wl[s]; L.cdf[i + 1] = (float)run; }
     }
@@ -373,35 +390,58 @@ __device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int lane, const fl
     float zfv[MAXS];
     int fpos[MAXS];
     bool ok = true;
+    // The lane's searches go probe by probe TOGETHER: every probe is a round trip to LDS, and one search after the other
+    // made a wavefront's chain twice as many of them as it needs.
+    int lo[NF];
 #pragma unroll
-    for (int f = 0; f < MAXS; ++f) {
-        const int j = f * LPR + l;
-        zfv[f] = 0.f; fpos[f] = 0;
-        if (j < Kf) {
-            const float uu = u_row[j];
-            int lo = 0;
-            auto probe = [&](int step) {
-                const int idx = lo + step;
-                const float v = L.cdf[min(idx, nb) - 1];
-                lo = (idx <= nb && v <= uu) ? idx : lo;
-            };
-            if (KC) {                                     // constant trip count: unrolled, the lane's searches interleave
+    for (int f = 0; f < NF; ++f) lo[f] = 0;
+    constexpr bool FULL = KC > 1 && (KC & (KC - 1)) == 0;  // nb = 2^m - 1: lo + step never leaves the cdf, nothing to clamp
+    const float* at[NF];                                   // FULL: &cdf[lo] itself is the search state (add, compare, select per probe)
 #pragma unroll
-                for (int step = 128; step > 0; step >>= 1)
-                    if (step <= (KC ? KC - 1 : 1)) probe(step);
-            } else {
-                for (int step = top; step > 0; step >>= 1) probe(step);
+    for (int f = 0; f < NF; ++f) at[f] = L.cdf;
+    auto probe = [&](int f, int step) {
+        const int idx = lo[f] + step;
+        if (FULL) {
+            at[f] = (at[f][step - 1] <= uu[f]) ? at[f] + step : at[f];
+        } else {
+            const float v = L.cdf[min(idx, nb) - 1];
+            lo[f] = (idx <= nb && v <= uu[f]) ? idx : lo[f];
+        }
+    };
+    if (KC) {                                             // constant trip count: unrolled
+#pragma unroll
+        for (int step = 128; step > 0; step >>= 1)
+            if (step <= (KC ? KC - 1 : 1)) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) probe(f, step);
             }
-            const int below = max(lo - 1, 0), above = min(lo, Kc - 2);
+    } else {
+        for (int step = top; step > 0; step >>= 1) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) probe(f, step);
+        }
+    }
+    if (FULL) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) lo[f] = (int)(at[f] - L.cdf);
+    }
+#pragma unroll
+    for (int f = 0; f < MAXS; ++f) { zfv[f] = 0.f; fpos[f] = 0; }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int j = f * LPR + l;
+        if (j < Kf) {
+            const int below = max(lo[f] - 1, 0), above = min(lo[f], Kc - 2);
             const float c0 = L.cdf[below], c1 = L.cdf[above];
             const float zb = L.zall[below], zb1 = L.zall[below + 1];
             const float b0 = 0.5f * (zb + zb1), b1 = 0.5f * (L.zall[above] + L.zall[above + 1]);
             float den = c1 - c0;
             if (den < eps) den = 1.0f;
-            const float zf = b0 + (uu - c0) / den * (b1 - b0);
+            const float zf = b0 + (uu[f] - c0) / den * (b1 - b0);
             const int cnt = below + 1 + (zb1 <= zf ? 1 : 0);
             // (what the shortcut assumes: zall[cnt - 1] <= zf < zall[cnt]; anything else takes the general path below)
-            ok &= (zb <= zf) && (cnt >= Kc || zf < L.zall[min(cnt, Kc - 1)]);
+            const float znext = L.zall[min(cnt, Kc - 1)];
+            ok &= (zb <= zf) & ((cnt >= Kc) | (zf < znext));
             zfv[f] = zf; fpos[f] = j + cnt;
             L.zall[Kc + j] = zf;
             L.wbuf[j + cnt] = zf;                         // its place in the sorted row, if the row is regular
@@ -495,23 +535,26 @@ __device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int lane, const fl
     sync();
 }
 
-// rows of K floats (+ K permutation entries) from LDS to HBM, 16 bytes per lane where the row allows it
+// rows of K floats (+ K permutation entries) from LDS to HBM, 16 bytes per lane where the rows allow it.  `zs` / `perm_out`
+// are wave-uniform bases and `row` the ray's index from there (a 32-bit lane offset on a scalar base: no 64-bit vector
+// address arithmetic per store).
 template <int LPR, int KT, typename PermT>
-__device__ __forceinline__ void store_sorted(const RayLds<KT>& L, int l, int K, float* __restrict__ zs_row,
-                                             PermT* __restrict__ perm_row) {
-    if ((K & 3) == 0 && (((uintptr_t)zs_row) & 15) == 0) {
+__device__ __forceinline__ void store_sorted(const RayLds<KT>& L, int l, int K, float* __restrict__ zs, PermT* __restrict__ perm_out,
+                                             unsigned row) {
+    const unsigned off = row * (unsigned)K;
+    if ((K & 3) == 0 && (((uintptr_t)zs) & 15) == 0) {
         for (int q = l; q < K / 4; q += LPR)
-            reinterpret_cast<float4*>(zs_row)[q] = reinterpret_cast<const float4*>(L.wbuf)[q];
+            reinterpret_cast<float4*>(zs)[off / 4 + (unsigned)q] = reinterpret_cast<const float4*>(L.wbuf)[q];
     } else {
-        for (int q = l; q < K; q += LPR) zs_row[q] = L.wbuf[q];
+        for (int q = l; q < K; q += LPR) zs[off + (unsigned)q] = L.wbuf[q];
     }
-    if (perm_row != nullptr) {
+    if (perm_out != nullptr) {
         const PermT* perm = reinterpret_cast<const PermT*>(L.cdf);
-        if (sizeof(PermT) == 1 && (K & 3) == 0 && (((uintptr_t)perm_row) & 3) == 0) {
+        if (sizeof(PermT) == 1 && (K & 3) == 0 && (((uintptr_t)perm_out) & 3) == 0) {
             for (int q = l; q < K / 4; q += LPR)
-                reinterpret_cast<uint32_t*>(perm_row)[q] = reinterpret_cast<const uint32_t*>(perm)[q];
+                reinterpret_cast<uint32_t*>(perm_out)[off / 4 + (unsigned)q] = reinterpret_cast<const uint32_t*>(perm)[q];
         } else {
-            for (int q = l; q < K; q += LPR) perm_row[q] = perm[q];
+            for (int q = l; q < K; q += LPR) perm_out[off + (unsigned)q] = perm[q];
         }
     }
 }
@@ -530,6 +573,8 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void sample_fine_merge_kern
     const bool active = r_raw < R;                        // tail segments compute ray R-1 again, store nothing
     const int64_t r = active ? r_raw : R - 1;
     RayLds<KT>& L = lds[slot];
+    float uu[(KT + LPR - 1) / LPR];
+    load_u<LPR, KT>(u_per_ray ? u + r * Kf : u, lane, Kf, uu);
     for (int k = l; k < Kc; k += LPR) { L.zall[k] = z_coarse[r * Kc + k]; L.wbuf[k] = weights[r * Kc + k]; }
     for (int k = l; k <= Kc; k += LPR) L.hist[k] = 0;
     // a ray's LDS segment is touched by the lanes of ONE wavefront only (LPR <= 64 lanes of it): the LDS unit executes a
@@ -538,9 +583,10 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void sample_fine_merge_kern
     auto sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
     sync();
     const int K = Kc + Kf;
-    fine_and_merge<LPR, KT, PermT>(L, lane, u_per_ray ? u + r * Kf : u, Kc, Kf,
+    fine_and_merge<LPR, KT, PermT>(L, lane, uu, Kc, Kf,
                                    (active && z_fine_out != nullptr) ? z_fine_out + r * Kf : nullptr, perm_out != nullptr, sync);
-    if (active) store_sorted<LPR, KT, PermT>(L, l, K, z_sorted_out + r * K, perm_out ? perm_out + r * K : nullptr);
+    const int64_t r0 = (int64_t)blockIdx.x * (WAVES_PER_BLOCK * RPW);
+    if (active) store_sorted<LPR, KT, PermT>(L, l, K, z_sorted_out + r0 * K, perm_out ? perm_out + r0 * K : nullptr, (unsigned)slot);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -561,36 +607,54 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_sample_kerne
     __shared__ __attribute__((aligned(16))) RayLds<KT> lds[WAVES_PER_BLOCK * RPW];
     const int lane = threadIdx.x & 63, l = lane % LPR;
     const int slot = (threadIdx.x >> 6) * RPW + lane / LPR;
-    const int64_t r_raw = (int64_t)blockIdx.x * (WAVES_PER_BLOCK * RPW) + slot;
-    const bool active = r_raw < R;
-    const int64_t r = active ? r_raw : R - 1;
+    // The block's first ray r0 is a scalar, a lane's ray is r0 + rs with rs < 8: every array below is addressed as
+    // (wave-uniform base of the block's rays)[32-bit lane offset] — scalar base + vector offset in the load / store itself
+    // instead of a 64-bit vector multiply-add per access (round 5: ~40 of the kernel's 500 VALU instructions per wavefront,
+    // and the kernel is bound by exactly those: 98 % VALU-busy by the counters).
+    const int64_t r0 = (int64_t)blockIdx.x * (WAVES_PER_BLOCK * RPW);
+    const int64_t left = R - 1 - r0;                      // >= 0: the grid is ceil(R / rays per block)
+    const bool active = slot <= left;                     // tail segments compute ray R-1 again, store nothing
+    const unsigned rs = active ? (unsigned)slot : (unsigned)left;
     RayLds<KT>& L = lds[slot];
-    const float4* c = rgbs + r * Kc;
-    const uint8_t* vr = valid + r * Kc;
-    const float near = rays[r * stride + 6], far = rays[r * stride + 7];
+    const float4* c = rgbs + r0 * Kc;
+    const uint8_t* vr = valid + r0 * Kc;
+    const float* zr = z + r0 * Kc;
+    const float* ray0 = rays + r0 * stride;
+    const unsigned ck = rs * (unsigned)Kc;
+    const float near = ray0[rs * (unsigned)stride + 6], far = ray0[rs * (unsigned)stride + 7];
+    float uu[(KT + LPR - 1) / LPR];
+    load_u<LPR, KT, KF>(u_per_ray ? u + r0 * Kf + rs * (unsigned)Kf : u, lane, Kf, uu);
     float w[S], zz[S], wsum, cr, cg, cb, dep;
     composite_ray<S, LPR>(lane, Kc,
-                          [&](int k) { if (MASKED) return vr[k] == 0 ? make_float4(0.f, 0.f, 0.f, -1e5f) : c[k]; return c[k]; },
-                          [&](int k) { if (HAS_Z) return z[r * Kc + k]; const float sk = steps[k]; return near * (1.0f - sk) + far * sk; },
+                          [&](int k) { if (MASKED) return vr[ck + (unsigned)k] == 0 ? make_float4(0.f, 0.f, 0.f, -1e5f) : c[ck + (unsigned)k]; return c[ck + (unsigned)k]; },
+                          [&](int k) { if (HAS_Z) return zr[ck + (unsigned)k]; const float sk = steps[k]; return near * (1.0f - sk) + far * sk; },
                           [](int) { return 0.0f; }, w, zz, wsum, cr, cg, cb, dep);
+    float* wo = weights_out + r0 * Kc;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int k = s * LPR + l;
         if (k < Kc) {
             L.zall[k] = zz[s];
             L.wbuf[k] = w[s];
-            if (weights_out != nullptr && active) weights_out[r * Kc + k] = w[s];
+            if (weights_out != nullptr && active) wo[ck + (unsigned)k] = w[s];
         }
     }
-    for (int k = l; k <= Kc; k += LPR) L.hist[k] = 0;
+    if (KC) {                                             // (static shape: no loop, no exec-mask bookkeeping)
+#pragma unroll
+        for (int k0 = 0; k0 <= KC; k0 += LPR)
+            if (k0 + LPR <= KC + 1 || l <= KC - k0) L.hist[k0 + l] = 0;
+    } else {
+        for (int k = l; k <= Kc; k += LPR) L.hist[k] = 0;
+    }
     if (l == LPR - 1 && active) {
         if (white_bkgd) {
             dep = dep + (1.0f - wsum) * far;
             cr = cr + 1.0f - wsum; cg = cg + 1.0f - wsum; cb = cb + 1.0f - wsum;
         }
-        rgb_out[r * 3 + 0] = cr; rgb_out[r * 3 + 1] = cg; rgb_out[r * 3 + 2] = cb;
-        depth_out[r] = dep;
-        acc_out[r] = wsum;
+        float* ro = rgb_out + r0 * 3;
+        ro[rs * 3u + 0] = cr; ro[rs * 3u + 1] = cg; ro[rs * 3u + 2] = cb;
+        (depth_out + r0)[rs] = dep;
+        (acc_out + r0)[rs] = wsum;
     }
     // a ray's LDS segment is touched by the lanes of ONE wavefront only (LPR <= 64 lanes of it): the LDS unit executes a
     // wave's instructions in order, so the compiler fence is all the "barrier" the segment needs — no workgroup barrier
@@ -598,9 +662,10 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_sample_kerne
     auto sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
     sync();
     const int K = Kc + Kf;
-    fine_and_merge<LPR, KT, PermT>(L, lane, u_per_ray ? u + r * Kf : u, Kc, Kf,
-                                   (active && z_fine_out != nullptr) ? z_fine_out + r * Kf : nullptr, perm_out != nullptr, sync);
-    if (active) store_sorted<LPR, KT, PermT>(L, l, K, z_sorted_out + r * K, perm_out ? perm_out + r * K : nullptr);
+    fine_and_merge<LPR, KT, PermT, KC, KF>(L, lane, uu, Kc, Kf,
+                                           (active && z_fine_out != nullptr) ? z_fine_out + r0 * Kf + rs * (unsigned)Kf : nullptr,
+                                           perm_out != nullptr, sync);
+    if (active) store_sorted<LPR, KT, PermT>(L, l, K, z_sorted_out + r0 * K, perm_out ? perm_out + r0 * K : nullptr, rs);
 }
 
 }  // namespace anr
