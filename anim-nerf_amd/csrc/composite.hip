@@ -85,7 +85,7 @@ __device__ __forceinline__ void composite_ray(int lane, int K, Col col_of, Depth
     for (int s = 0; s < S; ++s) {                          // all loads first: S x LPR x 16 B in flight per ray
         const int k = s * LPR + l;
         col[s] = make_float4(0.f, 0.f, 0.f, 0.f); zz[s] = 0.0f;
-        if (k < K) { col[s] = col_of(k); zz[s] = depth_of(k); }
+        if (k < K) { col[s] = col_of(k, s); zz[s] = depth_of(k); }
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -146,13 +146,29 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_kernel(
     float w[S], zz[S], wsum, cr, cg, cb, dep;
     // a sample the warp found invalid is (0, 0, 0, -1e5) by definition (models/anim_nerf.py:245-290, :305): its rgb-sigma
     // row was never written and is not read
-    composite_ray<S, LPR>(lane, K,
-                          [&](int k) {
-                              if (INDEXED) { const int p = pr[k]; return p < 0 ? make_float4(0.f, 0.f, 0.f, -1e5f) : rgbs[p]; }
-                              if (MASKED) return vr[k] == 0 ? make_float4(0.f, 0.f, 0.f, -1e5f) : c[k];
-                              return c[k];
-                          },
-                          [&](int k) { return zr[k]; }, [&](int k) { return NOISY ? nr[k] : 0.0f; }, w, zz, wsum, cr, cg, cb, dep);
+    uint8_t vb[S];
+    bool empty = false;
+    if (MASKED) {                                          // the validity bytes first: a wavefront whose rays miss the body
+        unsigned seen = 0;                                 // altogether (most of a frame's) has nothing to composite
+#pragma unroll
+        for (int s = 0; s < S; ++s) { vb[s] = (s * LPR + l < K) ? vr[s * LPR + l] : (uint8_t)0; seen |= vb[s]; }
+        empty = !__any(seen != 0);
+    }
+    if (empty) {
+        // all sigma = -1e5: alpha = 1 - exp(-delta * 0) = 0, every weight 0 * T = 0 and every sum 0 — the values the general
+        // path arrives at, without its loads, exponentials and scans
+#pragma unroll
+        for (int s = 0; s < S; ++s) w[s] = 0.0f;
+        wsum = 0.f; cr = 0.f; cg = 0.f; cb = 0.f; dep = 0.f;
+    } else {
+        composite_ray<S, LPR>(lane, K,
+                              [&](int k, int s) {
+                                  if (INDEXED) { const int p = pr[k]; return p < 0 ? make_float4(0.f, 0.f, 0.f, -1e5f) : rgbs[p]; }
+                                  if (MASKED) return vb[s] == 0 ? make_float4(0.f, 0.f, 0.f, -1e5f) : c[k];
+                                  return c[k];
+                              },
+                              [&](int k) { return zr[k]; }, [&](int k) { return NOISY ? nr[k] : 0.0f; }, w, zz, wsum, cr, cg, cb, dep);
+    }
     if (weights_out != nullptr && active) {
 #pragma unroll
         for (int s = 0; s < S; ++s)
@@ -625,10 +641,24 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void composite_sample_kerne
     float uu[(KT + LPR - 1) / LPR];
     load_u<LPR, KT, KF>(u_per_ray ? u + r0 * Kf + rs * (unsigned)Kf : u, lane, Kf, uu);
     float w[S], zz[S], wsum, cr, cg, cb, dep;
-    composite_ray<S, LPR>(lane, Kc,
-                          [&](int k) { if (MASKED) return vr[ck + (unsigned)k] == 0 ? make_float4(0.f, 0.f, 0.f, -1e5f) : c[ck + (unsigned)k]; return c[ck + (unsigned)k]; },
-                          [&](int k) { if (HAS_Z) return zr[ck + (unsigned)k]; const float sk = steps[k]; return near * (1.0f - sk) + far * sk; },
-                          [](int) { return 0.0f; }, w, zz, wsum, cr, cg, cb, dep);
+    auto depth_of = [&](int k) { if (HAS_Z) return zr[ck + (unsigned)k]; const float sk = steps[k]; return near * (1.0f - sk) + far * sk; };
+    uint8_t vb[S];
+    bool empty = false;
+    if (MASKED) {                                          // (see composite_kernel: wavefronts whose rays miss the body)
+        unsigned seen = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) { vb[s] = (s * LPR + l < Kc) ? vr[ck + (unsigned)(s * LPR + l)] : (uint8_t)0; seen |= vb[s]; }
+        empty = !__any(seen != 0);
+    }
+    if (empty) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) { w[s] = 0.0f; zz[s] = (s * LPR + l < Kc) ? depth_of(s * LPR + l) : 0.0f; }
+        wsum = 0.f; cr = 0.f; cg = 0.f; cb = 0.f; dep = 0.f;
+    } else {
+        composite_ray<S, LPR>(lane, Kc,
+                              [&](int k, int s) { if (MASKED) return vb[s] == 0 ? make_float4(0.f, 0.f, 0.f, -1e5f) : c[ck + (unsigned)k]; return c[ck + (unsigned)k]; },
+                              depth_of, [](int) { return 0.0f; }, w, zz, wsum, cr, cg, cb, dep);
+    }
     float* wo = weights_out + r0 * Kc;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
