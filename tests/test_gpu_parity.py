@@ -793,6 +793,39 @@ def test_cell_sorted_search_with_two_bodies_is_bit_identical(dev, smpl_table):
     assert not torch.equal(outs[0]["rgbs_fine"][0], outs[0]["rgbs_fine"][1])
 
 
+def test_repeated_renders_are_bit_identical_next_to_other_work(dev, smpl_table):
+    """One frame (two bodies, the cell-sorted sparse path, bf16) rendered 24 times while a side stream keeps the GPU busy with
+    matrix products: every output of every render equals the first render's bit for bit.  The renderer has no float atomics —
+    list orders are fixed by sorts and ordered compaction — so any difference is a fault; round 5 found one of that kind in the
+    training step (packed fp32 adds of the SLP vectoriser misbehaving next to other kernels), this is the
+    renderer's guard."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    hw = 96
+    m = seeded_model(smpl_table, 17, True, 3000.0, (100.0, 100.0), device=dev, mlp_mode="bf16")
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=57, bs=2, pose_std=0.35, transl_z=-2.6).items()}
+    c2w, focal, cen = syn.pinhole_camera(hw, hw)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), hw, hw, focal.tolist(), 0.1, 10.0, cen.tolist()).view(1, -1, 8).repeat(2, 1, 1)
+    vr = ana.VolumeRenderer(n_coarse=64, n_fine=64)
+    side = torch.cuda.Stream()
+    a = torch.randn(1024, 1024, device=dev)
+    first = None
+    for it in range(24):
+        with torch.cuda.stream(side):
+            for _ in range(8):
+                a = torch.tanh(a @ a) * 0.5
+        with torch.no_grad():
+            out = ana.batched_inference(vr, m, rays, pose, _templ(dev), chunk=1 << 14)
+        out = {k: v.clone() for k, v in out.items()}
+        if first is None:
+            first = out
+            assert first["alphas_fine"].max() > 0.2, "the bodies must be in view"
+            continue
+        for k in first:
+            assert torch.equal(out[k], first[k]), (k, it, float((out[k].float() - first[k].float()).abs().max()))
+    torch.cuda.synchronize()
+
+
 def test_disparity_sampling_and_depth_guided_samples(dev, smpl_table):
     """The two VolumeRenderer options no shipped config selects: lindisp=False (models/volume_rendering.py:45-46) and
     n_fine_depth > 0 (:99-111, :204-207)."""
