@@ -354,30 +354,6 @@ template <int KT> struct RayLds {
 // depths, wbuf[0..Kc) = coarse weights, hist[0..Kc] = 0, all visible.
 // Returns with wbuf[0..K) = sorted depths and (want_perm) ((PermT*)cdf)[0..K) = permutation.
 // KC / KF > 0: the sample counts as compile-time constants (the shipped shapes): every bound check below folds away.
-// #{q in [begin, end) : z[q] < x or (z[q] == x and q < self)} — the stable-sort rank of x among those entries.  Every lane reads
-// the same words (broadcasts), sixteen per trip to LDS: as a loop of one 4-byte read per iteration, each behind the previous
-// one's wait, the 96 x 3 reads of a lane on the all-pairs path were 17 us of a 25-us launch whatever its size (a training
-// batch has a few rays with a 1-ulp inversion at a bin edge in every launch, and a launch lasts as long as its slowest
-// wavefront; round 5).
-__device__ __forceinline__ int count_before(const float* z, float x, int self, int begin, int end) {
-    int rank = 0, q = begin;
-    if ((begin & 3) == 0) {
-#pragma unroll 4
-        for (; q + 4 <= end; q += 4) {
-            const float4 y = *reinterpret_cast<const float4*>(z + q);
-            rank += ((y.x < x) | ((y.x == x) & (q < self))) ? 1 : 0;
-            rank += ((y.y < x) | ((y.y == x) & (q + 1 < self))) ? 1 : 0;
-            rank += ((y.z < x) | ((y.z == x) & (q + 2 < self))) ? 1 : 0;
-            rank += ((y.w < x) | ((y.w == x) & (q + 3 < self))) ? 1 : 0;
-        }
-    }
-    for (; q < end; ++q) {
-        const float y = z[q];
-        rank += ((y < x) | ((y == x) & (q < self))) ? 1 : 0;
-    }
-    return rank;
-}
-
 // The lane's u values (fine sample j = f * LPR + l), loaded by the CALLER before its own first wait on memory: behind the
 // compositing they were a round trip to HBM in the middle of the wavefront's chain, one per sample (round 5).
 template <int LPR, int KT, int KF = 0>
@@ -514,7 +490,15 @@ __device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int lane, const fl
 #pragma unroll
             for (int f = 0; f < MAXS; ++f) {
                 const int j = f * LPR + l;
-                if (j < Kf) fpos[f] = fpos[f] - j + count_before(L.zall, zfv[f], Kc + j, Kc, Kc + Kf);
+                if (j < Kf) {
+                    const float x = zfv[f];
+                    int rank = 0;
+                    for (int q = 0; q < Kf; ++q) {        // (every lane reads the same word: a broadcast)
+                        const float y = L.zall[Kc + q];
+                        rank += (y < x || (y == x && q < j)) ? 1 : 0;
+                    }
+                    fpos[f] = fpos[f] - j + rank;
+                }
             }
         }
         const int SC = (Kc + LPR - 1) / LPR;              // coarse entries p = l*SC + s: a run per lane, then a DPP scan
@@ -555,7 +539,11 @@ __device__ __forceinline__ void fine_and_merge(RayLds<KT>& L, int lane, const fl
     } else {                                              // (every slot of wbuf is rewritten)
         for (int p = l; p < K; p += LPR) {
             const float x = L.zall[p];
-            const int rank = count_before(L.zall, x, p, 0, K);
+            int rank = 0;
+            for (int q = 0; q < K; ++q) {
+                const float y = L.zall[q];
+                rank += (y < x || (y == x && q < p)) ? 1 : 0;
+            }
             L.wbuf[rank] = x;
             if (want_perm) perm[rank] = (PermT)p;           // z_sorted[rank] = cat(z_coarse, z_fine)[p]
         }
