@@ -182,3 +182,20 @@ def test_forward_mode_normals_equal_double_backward():
     assert set(g1) == set(g2) and len(g1) == 18
     for k in g2:
         assert (g1[k] - g2[k]).norm() <= 1e-12 * g2[k].norm(), k
+
+
+def test_build_keeps_slp_vectoriser_off():
+    """Every source is compiled with -fno-slp-vectorize (anim-nerf_amd/build.py: NO_SLP): the packed fp32 adds the SLP vectoriser
+    emits made 1-2 % of replayed training steps differ from each other on the GPU.  The GPU-side regression test is
+    test_replays_of_one_step_reproduce_its_gradients; this one keeps the flag from being dropped by an edit of the recipe."""
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "anim-nerf_amd", "build.py")
+    src = open(here).read()
+    assert 'NO_SLP = [] if os.environ.get("ANR_BUILD_SLP") else ["-fno-slp-vectorize"]' in src and "flags += NO_SLP" in src
+    if not os.environ.get("ANR_BUILD_SLP"):
+        spec = importlib.util.spec_from_file_location("_anr_build_recipe", here)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        assert mod.NO_SLP == ["-fno-slp-vectorize"]
+
