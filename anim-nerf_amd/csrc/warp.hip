@@ -1006,21 +1006,30 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
 // ran once per sample behind the previous sample's (round 4's counters: 70 % of the wave-cycles waiting on memory at 30 % VALU
 // issue, 2 TB/s): here the two 16-byte depth loads, the two permutation dwords and the rays go first, then the eight validity
 // bytes and reach-mask words, then the (up to) eight points, then the stores.  Same outputs.
+// Threads per workgroup of this pass: 256, not the 1,024 of the other warp kernels.  The kernel needs 108 VGPRs — four waves per
+// SIMD, i.e. ONE 1,024-thread workgroup per CU — and its phases end in two workgroup barriers around a global atomic (the list
+// range): with one workgroup resident the CU idles through every one of those waits; four workgroups of 256 overlap them.
+// configs[2] 25.59 / 25.62 -> 25.41 / 25.41 ms per frame on one box, 25.53 -> 25.30 / 25.35 on another (512: no change, 128:
+// 25.46 / 25.73 — the per-workgroup hash table's flush starts to count); profiles/r05/ab_lean_threads.txt.
+#ifndef ANR_LEAN_THREADS
+#define ANR_LEAN_THREADS 256
+#endif
+constexpr int LEAN_THREADS = ANR_LEAN_THREADS;
 template <bool CELLS>
-__global__ __launch_bounds__(WARP_THREADS) void warp_classify_lean_kernel(
+__global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
     const float* __restrict__ rays, int ray_stride, const float* __restrict__ z, int K, const float* __restrict__ index, IndexDims d,
     int64_t N, float thr, float4* __restrict__ pts_out, int32_t* __restrict__ list, int32_t* __restrict__ cells,
     int32_t* __restrict__ count, int32_t* __restrict__ cell_count, uint8_t* __restrict__ valid_mask,
     const float4* __restrict__ reuse_pts, const uint8_t* __restrict__ reuse_mask, const uint8_t* __restrict__ perm, int reuse_K,
     int G) {
-    __shared__ int wave_cnt[WARP_THREADS / 64];
+    __shared__ int wave_cnt[LEAN_THREADS / 64];
     __shared__ int block_base;
     __shared__ int hkeys[HN], hcnt[HN];
     const int b = blockIdx.y;
     const float* gbox = index + (int64_t)b * d.total_floats() + d.body_off();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (CELLS) {
-        for (int s = threadIdx.x; s < HN; s += WARP_THREADS) { hkeys[s] = -1; hcnt[s] = 0; }
+        for (int s = threadIdx.x; s < HN; s += LEAN_THREADS) { hkeys[s] = -1; hcnt[s] = 0; }
         __syncthreads();
     }
     constexpr int VS = 4, STEPS = CLS_ITERS / VS;
@@ -1030,7 +1039,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_lean_kernel(
     const bool masked = reach_thr >= thr;
     const float reach_inv = masked ? 1.0f / reach_cell_size(gbox, reach_thr) : 0.0f;
     const unsigned* __restrict__ reach = reinterpret_cast<const unsigned*>(index + (int64_t)b * d.total_floats() + d.reach_off());
-    auto sample_of = [&](int step, int v) { return (((int64_t)blockIdx.x * STEPS + step) * WARP_THREADS + threadIdx.x) * VS + v; };
+    auto sample_of = [&](int step, int v) { return (((int64_t)blockIdx.x * STEPS + step) * LEAN_THREADS + threadIdx.x) * VS + v; };
     // ---- A: depths, permutation bytes, rays
     float zz[CLS_ITERS];
     unsigned pm[STEPS];
@@ -1139,7 +1148,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_lean_kernel(
         if (threadIdx.x == 0) {
             int tot = 0;
 #pragma unroll
-            for (int w = 0; w < WARP_THREADS / 64; ++w) { int c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
+            for (int w = 0; w < LEAN_THREADS / 64; ++w) { int c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
             block_base = tot ? atomicAdd(count + b, tot) : 0;
         }
         __syncthreads();
@@ -1155,7 +1164,7 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_lean_kernel(
     }
     if (!CELLS) return;
     __syncthreads();
-    for (int s = threadIdx.x; s < HN; s += WARP_THREADS)
+    for (int s = threadIdx.x; s < HN; s += LEAN_THREADS)
         if (hkeys[s] >= 0) atomicAdd(cell_count + (int64_t)b * NCELL + hkeys[s], hcnt[s]);
 }
 
@@ -2162,8 +2171,9 @@ extern "C" int anr_warp_points_reuse(const float* xyz, int xyz_stride, const flo
         if (vec4 && valid_mask_out != nullptr && nbr_w_out == nullptr && (reuse_pts == nullptr || reuse_mask != nullptr) &&
             !getenv("ANR_WARP_CLASSIFY_GENERIC")) {
             // the renderer's lean pass: its own kernel, loads in phases (warp_classify_lean_kernel)
+            dim3 gl((unsigned)((N + CLS_ITERS * LEAN_THREADS - 1) / (CLS_ITERS * LEAN_THREADS)), bs);
 #define ANR_CLASSIFY_LEAN(CL)                                                                                                  \
-            hipLaunchKernelGGL((warp_classify_lean_kernel<CL>), g1, dim3(WARP_THREADS), 0, st, rays, ray_stride, z, K, index, d, N,  \
+            hipLaunchKernelGGL((warp_classify_lean_kernel<CL>), gl, dim3(LEAN_THREADS), 0, st, rays, ray_stride, z, K, index, d, N,  \
                                dis_threshold, reinterpret_cast<float4*>(pts_out), w.list, w.cells, w.count, w.cell_count,          \
                                valid_mask_out, reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K, G)
             if (small) ANR_CLASSIFY_LEAN(false); else ANR_CLASSIFY_LEAN(true);
