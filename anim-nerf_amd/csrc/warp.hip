@@ -1006,15 +1006,19 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_classify_kernel(
 // ran once per sample behind the previous sample's (round 4's counters: 70 % of the wave-cycles waiting on memory at 30 % VALU
 // issue, 2 TB/s): here the two 16-byte depth loads, the two permutation dwords and the rays go first, then the eight validity
 // bytes and reach-mask words, then the (up to) eight points, then the stores.  Same outputs.
-// Threads per workgroup of this pass: 256, not the 1,024 of the other warp kernels.  The kernel needs 108 VGPRs — four waves per
-// SIMD, i.e. ONE 1,024-thread workgroup per CU — and its phases end in two workgroup barriers around a global atomic (the list
-// range): with one workgroup resident the CU idles through every one of those waits; four workgroups of 256 overlap them.
-// configs[2] 25.59 / 25.62 -> 25.41 / 25.41 ms per frame on one box, 25.53 -> 25.30 / 25.35 on another (512: no change, 128:
-// 25.46 / 25.73 — the per-workgroup hash table's flush starts to count); profiles/r05/ab_lean_threads.txt.
+// Shape of this pass: 512 threads x 4 samples, not the 1,024 x 8 of the other classify kernel.  At eight samples per thread the
+// kernel needs 108 VGPRs — four waves per SIMD, i.e. ONE 1,024-thread workgroup per CU — and its phases end in two workgroup
+// barriers around a global atomic (the list range): with one workgroup resident the CU idles through every one of those waits.
+// Per configs[2] frame, by the kernel trace on one box (profiles/r05/ab_lean_threads.txt): 1,024 x 8: 1.17 ms; 256 x 8: 1.00;
+// 256 x 4: 1.00; 1,024 x 4: 1.09; **512 x 4: 0.89**.
 #ifndef ANR_LEAN_THREADS
-#define ANR_LEAN_THREADS 256
+#define ANR_LEAN_THREADS 512
 #endif
 constexpr int LEAN_THREADS = ANR_LEAN_THREADS;
+#ifndef ANR_LEAN_ITERS
+#define ANR_LEAN_ITERS 4
+#endif
+constexpr int LEAN_ITERS = ANR_LEAN_ITERS;       // samples per thread of the lean pass (a multiple of 4)
 template <bool CELLS>
 __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
     const float* __restrict__ rays, int ray_stride, const float* __restrict__ z, int K, const float* __restrict__ index, IndexDims d,
@@ -1032,7 +1036,7 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
         for (int s = threadIdx.x; s < HN; s += LEAN_THREADS) { hkeys[s] = -1; hcnt[s] = 0; }
         __syncthreads();
     }
-    constexpr int VS = 4, STEPS = CLS_ITERS / VS;
+    constexpr int VS = 4, STEPS = LEAN_ITERS / VS;
     const uint32_t R32 = (uint32_t)(N / K);
     const float cell_inv = 1.0f / cell_size(gbox, thr, G);
     const float reach_thr = gbox[3];
@@ -1041,7 +1045,7 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
     const unsigned* __restrict__ reach = reinterpret_cast<const unsigned*>(index + (int64_t)b * d.total_floats() + d.reach_off());
     auto sample_of = [&](int step, int v) { return (((int64_t)blockIdx.x * STEPS + step) * LEAN_THREADS + threadIdx.x) * VS + v; };
     // ---- A: depths, permutation bytes, rays
-    float zz[CLS_ITERS];
+    float zz[LEAN_ITERS];
     unsigned pm[STEPS];
     uint32_t ray4[STEPS];
     bool in[STEPS];
@@ -1066,13 +1070,13 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
         for (int a = 0; a < 3; ++a) { ro[step][a] = in[step] ? ry[a] : 0.0f; rd[step][a] = in[step] ? ry[3 + a] : 0.0f; }
     }
     // ---- B: positions, the box test, the coarse samples' validity bytes, the reach-mask words
-    float px[CLS_ITERS], py[CLS_ITERS], pz[CLS_ITERS];
-    int64_t src[CLS_ITERS];
-    unsigned m[CLS_ITERS], rw[CLS_ITERS];
+    float px[LEAN_ITERS], py[LEAN_ITERS], pz[LEAN_ITERS];
+    int64_t src[LEAN_ITERS];
+    unsigned m[LEAN_ITERS], rw[LEAN_ITERS];
     unsigned near_bits = 0u, reused_bits = 0u;
-    int rbit[CLS_ITERS];
+    int rbit[LEAN_ITERS];
 #pragma unroll
-    for (int it = 0; it < CLS_ITERS; ++it) {
+    for (int it = 0; it < LEAN_ITERS; ++it) {
         const int step = it / VS, v = it % VS;
         px[it] = __fadd_rn(ro[step][0], __fmul_rn(zz[it], rd[step][0]));
         py[it] = __fadd_rn(ro[step][1], __fmul_rn(zz[it], rd[step][1]));
@@ -1099,14 +1103,14 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
         reused_bits |= (reused ? 1u : 0u) << it;
     }
     // ---- C: the points of the valid coarse samples
-    float4 rp[CLS_ITERS];
+    float4 rp[LEAN_ITERS];
 #pragma unroll
-    for (int it = 0; it < CLS_ITERS; ++it) {
+    for (int it = 0; it < LEAN_ITERS; ++it) {
         rp[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (m[it]) rp[it] = reuse_pts[src[it]];
     }
     // ---- D: stores
-    int my_cell[CLS_ITERS];
+    int my_cell[LEAN_ITERS];
 #pragma unroll
     for (int step = 0; step < STEPS; ++step) {
         unsigned mask_out = 0u;
@@ -1154,7 +1158,7 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
         __syncthreads();
         int64_t pos = (int64_t)b * N + block_base + wave_cnt[wave] + incl - mine;
 #pragma unroll
-        for (int it = 0; it < CLS_ITERS; ++it) {
+        for (int it = 0; it < LEAN_ITERS; ++it) {
             if ((near_bits >> it) & 1u) {
                 list[pos] = (int32_t)sample_of(it / VS, it % VS);
                 if (CELLS) cells[pos] = my_cell[it];
@@ -2171,7 +2175,7 @@ extern "C" int anr_warp_points_reuse(const float* xyz, int xyz_stride, const flo
         if (vec4 && valid_mask_out != nullptr && nbr_w_out == nullptr && (reuse_pts == nullptr || reuse_mask != nullptr) &&
             !getenv("ANR_WARP_CLASSIFY_GENERIC")) {
             // the renderer's lean pass: its own kernel, loads in phases (warp_classify_lean_kernel)
-            dim3 gl((unsigned)((N + CLS_ITERS * LEAN_THREADS - 1) / (CLS_ITERS * LEAN_THREADS)), bs);
+            dim3 gl((unsigned)((N + LEAN_ITERS * LEAN_THREADS - 1) / (LEAN_ITERS * LEAN_THREADS)), bs);
 #define ANR_CLASSIFY_LEAN(CL)                                                                                                  \
             hipLaunchKernelGGL((warp_classify_lean_kernel<CL>), gl, dim3(LEAN_THREADS), 0, st, rays, ray_stride, z, K, index, d, N,  \
                                dis_threshold, reinterpret_cast<float4*>(pts_out), w.list, w.cells, w.count, w.cell_count,          \
