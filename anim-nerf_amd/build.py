@@ -40,6 +40,65 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+_LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def packed_fp32_forms(lib_path: str = LIB_PATH):
+    """Disassemble every gfx950 code object inside `lib_path` and list the packed fp32 VALU instructions
+    (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) that carry operand modifiers, as (kernel, instruction text, suspicious).
+    suspicious = the form the library must not contain: an `op_sel` that swaps the halves of an operand, or a
+    negation of ONE half only — what the SLP vectoriser makes of `r += 1 - w; g += 1 - w` and what returned the unmodified
+    operand in one lane next to other kernels.  (The explicit float2 arithmetic of the neighbour search compiles to plain
+    both-halves subtractions, neg_lo == neg_hi with at most an op_sel_hi broadcast; every warp test compares its results bit
+    for bit.)  The flag -fno-slp-vectorize is the means; this scan of the generated ISA is the gate (build() raises)."""
+    import re
+    import tempfile
+    objcopy, bundler, objdump = (os.path.join(_LLVM_BIN, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump"))
+    found = []
+    with tempfile.TemporaryDirectory(prefix="anr_isa_") as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([objcopy, f"--dump-section=.hip_fatbin={fat}", lib_path, os.path.join(tmp, "copy.so")], check=True)
+        data = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), data)]
+        if not starts:
+            raise RuntimeError(f"{lib_path}: no offload bundle in .hip_fatbin")
+        pk = re.compile(r"\bv_pk_(?:add|mul|fma)_f32\b")
+        mod = re.compile(r"(op_sel_hi|op_sel|neg_lo|neg_hi):\[([\d,]+)\]")
+        for i, o in enumerate(starts):
+            piece, co = os.path.join(tmp, f"b{i}.bin"), os.path.join(tmp, f"co{i}.o")
+            open(piece, "wb").write(data[o:starts[i + 1] if i + 1 < len(starts) else len(data)])
+            subprocess.run([bundler, "--unbundle", "--type=o", f"--input={piece}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                            f"--output={co}"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            text = subprocess.run([objdump, "-d", "--mcpu=gfx950", co], check=True, capture_output=True, text=True).stdout
+            kernel = "?"
+            for line in text.splitlines():
+                head = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                if head:
+                    kernel = head.group(1)
+                    continue
+                if not pk.search(line):
+                    continue
+                mods = dict(mod.findall(line))
+                if not mods:
+                    continue
+                swapped = "1" in mods.get("op_sel", "")
+                lopsided = mods.get("neg_lo", "") != mods.get("neg_hi", "")
+                found.append((kernel, line.split("//")[0].strip(), swapped or lopsided))
+    return found
+
+
+def check_isa(lib_path: str = LIB_PATH) -> int:
+    """Raise if the linked library holds a packed fp32 instruction of the suspicious form; returns the number of (benign)
+    modified packed instructions it does hold."""
+    forms = packed_fp32_forms(lib_path)
+    bad = [f for f in forms if f[2]]
+    if bad:
+        lines = "\n".join(f"  {k}: {t}" for k, t, _ in bad[:20])
+        raise RuntimeError(f"{lib_path}: {len(bad)} packed fp32 instruction(s) with swapped / half-negated operands "
+                           f"(DESIGN 4.4: build with -fno-slp-vectorize, write such pairs as scalars):\n{lines}")
+    return len(forms)
+
+
 def build(force: bool = False, verbose: bool = False, defines=(), out: str = None, extra_flags=()) -> str:
     """Compile every HIP source for gfx950 and link the shared library.  Returns its path.
     `defines`/`out` build an experiment variant (e.g. timing ablations) next to the product library."""
@@ -71,6 +130,12 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = Non
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    if not os.environ.get("ANR_BUILD_SLP"):                     # (the hunting tool builds the old way on purpose)
+        try:
+            check_isa(lib_path)
+        except RuntimeError:
+            os.replace(lib_path, lib_path + ".rejected")       # a library that fails the gate is not left where it would load
+            raise
     return lib_path
 
 

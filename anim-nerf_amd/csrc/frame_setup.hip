@@ -43,22 +43,29 @@ __global__ __launch_bounds__(64) void frame_chain_kernel(const int64_t* __restri
                                                          float* __restrict__ betas_out, float* __restrict__ pose_out,
                                                          float* __restrict__ transl_out, float* __restrict__ A_out,
                                                          float* __restrict__ joints_root_out, float* __restrict__ feat_out,
-                                                         float* __restrict__ ginv_out, float* __restrict__ groot_out) {
+                                                         float* __restrict__ ginv_out, float* __restrict__ groot_out,
+                                                         int table_rows) {
     const int b = blockIdx.x, j = threadIdx.x;
     __shared__ float sB[FS_NB], sP[3 * FS_J], sT[3];
     // (the narrow part of the chain — 24 joints, 85 scalars per frame — accumulates in DOUBLE: it costs nothing here, and the
     // pose gradients downstream are cancelling sums over 6,890 vertices that amplify every rounding of A ~500 x)
     __shared__ float Rm[FS_J][9], sI[12];
     __shared__ double Jr[FS_J][3], Wd[FS_J][12];
-    const int64_t row = frame_idx ? frame_idx[b] : b;
+    // A frame index outside the tables (nn.Embedding raises there: models/body_model_params.py:5-68) must neither read out of
+    // bounds nor pass for a pose: row 0 is read instead and the frame's parameters are NaN from here on — the step's loss and
+    // every gradient of that frame say so at the next host read, no synchronisation here (table_rows = 0: rows unknown, no check)
+    int64_t row = frame_idx ? frame_idx[b] : b;
+    const bool bad = frame_idx != nullptr && table_rows > 0 && (row < 0 || row >= table_rows);
+    if (bad) row = 0;
+    const float poison = bad ? __builtin_nanf("") : 0.0f;
     const int64_t brow = frame_idx ? (row < betas_rows ? row : betas_rows - 1) : b;
-    if (j < FS_NB) { sB[j] = betas_w[brow * FS_NB + j]; betas_out[b * FS_NB + j] = sB[j]; }
+    if (j < FS_NB) { sB[j] = betas_w[brow * FS_NB + j] + poison; betas_out[b * FS_NB + j] = sB[j]; }
     for (int e = j; e < 3 * FS_J; e += 64) {
-        const float v = e < 3 ? go_w[row * 3 + e] : bp_w[row * 69 + (e - 3)];
+        const float v = (e < 3 ? go_w[row * 3 + e] : bp_w[row * 69 + (e - 3)]) + poison;
         sP[e] = v;
         pose_out[b * 3 * FS_J + e] = v;
     }
-    if (j < 3) { sT[j] = tr_w[row * 3 + j]; transl_out[b * 3 + j] = sT[j]; }
+    if (j < 3) { sT[j] = tr_w[row * 3 + j] + poison; transl_out[b * 3 + j] = sT[j]; }
     __syncthreads();
     if (j < FS_J) {
 #pragma clang fp contract(fast)                                          // (the SMPL part rounds as csrc/smpl.hip does: fused multiply-adds)
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(256) void frame_vertex_kernel(
 
 using namespace anr;
 
-extern "C" int anr_frame_setup(const int64_t* frame_idx, const float* betas_w, int betas_rows, const float* global_orient_w,
+extern "C" int anr_frame_setup_rows(const int64_t* frame_idx, int table_rows, const float* betas_w, int betas_rows, const float* global_orient_w,
                                const float* body_pose_w, const float* transl_w, int bs, const float* J0, const float* JS,
                                const int64_t* parents, const float* v_template, const float* shapedirs, const float* posedirs,
                                const float* lbs_weights, int V, int J, int NB, const float* T_template,
@@ -341,6 +348,7 @@ extern "C" int anr_frame_setup(const int64_t* frame_idx, const float* betas_w, i
                                float* A_out, float* joints_root_out, float* g_inv_out, float* g_root_out, float* shape_off_out,
                                float* pose_off_out, float* verts_root_out, float* T_root_out, float* ober2cano_out,
                                float* rays_body_out, float* ws_feat, void* stream) {
+    ANR_REQUIRE(table_rows >= 0, ANR_E_BADARG, "anr_frame_setup: table_rows=%d", table_rows);
     ANR_REQUIRE(betas_w && global_orient_w && body_pose_w && transl_w && J0 && JS && parents && v_template && shapedirs && posedirs &&
                 lbs_weights && T_template && shape_off_template && pose_off_template, ANR_E_BADARG, "anr_frame_setup: null input");
     ANR_REQUIRE(betas_out && pose_out && transl_out && A_out && joints_root_out && g_inv_out && g_root_out && shape_off_out &&
@@ -352,7 +360,8 @@ extern "C" int anr_frame_setup(const int64_t* frame_idx, const float* betas_w, i
                 "anr_frame_setup: T_template / T_root / ober2cano / rays_body must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(frame_chain_kernel, dim3(bs), dim3(64), 0, st, frame_idx, betas_w, betas_rows, global_orient_w, body_pose_w,
-                       transl_w, J0, JS, parents, betas_out, pose_out, transl_out, A_out, joints_root_out, ws_feat, g_inv_out, g_root_out);
+                       transl_w, J0, JS, parents, betas_out, pose_out, transl_out, A_out, joints_root_out, ws_feat, g_inv_out, g_root_out,
+                       table_rows);
     const int nvb = (V + 63) / 64, nrb = (R + 255) / 256;
 #define ANR_FRAME_VERTEX(BT)                                                                                                      \
     hipLaunchKernelGGL(frame_vertex_kernel<BT>, dim3((unsigned)(nvb * ((bs + BT - 1) / BT) + nrb * bs)), dim3(256), 0, st, betas_out,       \
@@ -367,4 +376,19 @@ extern "C" int anr_frame_setup(const int64_t* frame_idx, const float* betas_w, i
     }
 #undef ANR_FRAME_VERTEX
     return check_launch("anr_frame_setup");
+}
+
+extern "C" int anr_frame_setup(const int64_t* frame_idx, const float* betas_w, int betas_rows, const float* global_orient_w,
+                               const float* body_pose_w, const float* transl_w, int bs, const float* J0, const float* JS,
+                               const int64_t* parents, const float* v_template, const float* shapedirs, const float* posedirs,
+                               const float* lbs_weights, int V, int J, int NB, const float* T_template,
+                               const float* shape_off_template, const float* pose_off_template, int template_bs,
+                               const float* rays_world, int ray_stride, int R, float* betas_out, float* pose_out, float* transl_out,
+                               float* A_out, float* joints_root_out, float* g_inv_out, float* g_root_out, float* shape_off_out,
+                               float* pose_off_out, float* verts_root_out, float* T_root_out, float* ober2cano_out,
+                               float* rays_body_out, float* ws_feat, void* stream) {
+    return anr_frame_setup_rows(frame_idx, 0, betas_w, betas_rows, global_orient_w, body_pose_w, transl_w, bs, J0, JS, parents, v_template,
+                                shapedirs, posedirs, lbs_weights, V, J, NB, T_template, shape_off_template, pose_off_template, template_bs,
+                                rays_world, ray_stride, R, betas_out, pose_out, transl_out, A_out, joints_root_out, g_inv_out, g_root_out,
+                                shape_off_out, pose_off_out, verts_root_out, T_root_out, ober2cano_out, rays_body_out, ws_feat, stream);
 }

@@ -126,13 +126,13 @@ class ExplicitTrainStep:
         return not any(p.requires_grad for p in m.nerf.parameters()) and not any(p.requires_grad for p in m.nerf_fine.parameters())
 
     # ------------------------------------------------------------------------------------------------------------------
-    def _mlp_pass(self, net, mode_id, pts, fg, bg, pack=None, frozen=False):
+    def _mlp_pass(self, net, mode_id, pts, fg, bg, pack=None, frozen=False, cstate=None):
         """compacted training forward of one network on pts[n,4] (+ the prior points as riders): -> state for the backward
         (out_c[rows, 4]: the output of the listed rows, pos[n + n_r]: a sample's or rider's row)"""
         params = [dict(net.named_parameters())[k] for k in PARAM_KEYS]
         if pack is None:
             pack = _cached_pack(params, mode_id, False)
-        index, pos, pts_c, count = ops.compact_ordered_riders(pts, fg, bg, single=True)
+        index, pos, pts_c, count = ops.compact_ordered_riders(pts, fg, bg, single=True, state=cstate)
         rows = count[1:2]
         # (frozen networks: nothing reads the saved activations — the weight gradients' operands — only the sign bits)
         out_c, act = ops.mlp_forward_save(pack, mode_id, pts_c, False, count=rows, bits_only=frozen)
@@ -243,18 +243,24 @@ class ExplicitTrainStep:
         # launches of the step's chain, before round 5.
         V = bm.lbs_weights.shape[0]
         nets = draws = front_ready = packs_b = packs_b_ready = warp_ws_c = warp_ws_f = acc_buf = frame_ws = quads4 = None
+        cstates = None
+        n_riders = bs * ((fg_points.shape[1] if fg_points is not None else 0) + (bg_points.shape[1] if bg_points is not None else 0))
 
         begin = torch.cuda.Event()                                    # (the side stream forks HERE, whatever is issued first)
         begin.record(main)
 
         def front():
-            nonlocal nets, draws, front_ready, packs_b, packs_b_ready, warp_ws_c, warp_ws_f, acc_buf, frame_ws, quads4
+            nonlocal nets, draws, front_ready, packs_b, packs_b_ready, warp_ws_c, warp_ws_f, acc_buf, frame_ws, quads4, cstates
             self._wgrad_stream.wait_event(begin)
             with torch.cuda.stream(self._wgrad_stream):
                 fills = list([tr.reducer.whole] if tr.reducer.whole is not None else tr.reducer.flat)
                 warp_ws_c, z0 = ops.warp_workspace(bs, R * Kc, dev)
                 warp_ws_f, z1 = ops.warp_workspace(bs, R * K, dev)
                 fills += [z0, z1]
+                # the two compactions' look-back states belong to the step and are zeroed with everything else: neither shared
+                # through a process-global table nor dependent on the previous launch having restored them
+                cstates = (ops.compact_state(bs * R * Kc + n_riders, dev), ops.compact_state(bs * R * K + n_riders, dev))
+                fills += list(cstates)
                 acc_buf = frame_ws = None
                 if refine:
                     acc_buf = torch.empty(bs * V * 16 + bs * R * 8, dtype=torch.float32, device=dev)
@@ -402,7 +408,7 @@ class ExplicitTrainStep:
             normals_forward()
             normals_first_network()
         n_r = bs * ((fg_points.shape[1] if fg_points is not None else 0) + (bg_points.shape[1] if bg_points is not None else 0))
-        st_c = self._mlp_pass(m.nerf, mode_id, pts_c.view(-1, 4), fg_points, bg_points, nets[0][2], frozen)
+        st_c = self._mlp_pass(m.nerf, mode_id, pts_c.view(-1, 4), fg_points, bg_points, nets[0][2], frozen, cstates[0])
         flat_rays = rays_b.view(bs * R, 8)
         noise_c = draws["noise_c"].view(bs * R, Kc) if noisy else None
         w_c, rgb_c, dep_c, acc_c = ops.composite(st_c["out_c"], zc.view(bs * R, Kc), flat_rays, vr.white_bkgd, noise=noise_c,
@@ -415,7 +421,7 @@ class ExplicitTrainStep:
                                               reuse=(pts_c, None, perm, nidx_c, nw_c), workspace=warp_ws_f)
         if want_normals:
             normals_second_network()
-        st_f = self._mlp_pass(m.nerf_fine, mode_id, pts_f.view(-1, 4), fg_points, bg_points, nets[1][2], frozen)
+        st_f = self._mlp_pass(m.nerf_fine, mode_id, pts_f.view(-1, 4), fg_points, bg_points, nets[1][2], frozen, cstates[1])
         noise_f = draws["noise_f"].view(bs * R, K) if noisy else None
         _, rgb_f, dep_f, acc_f = ops.composite(st_f["out_c"], zs.view(bs * R, K), flat_rays, vr.white_bkgd, noise=noise_f,
                                                want_weights=False, pos=st_f["pos"])

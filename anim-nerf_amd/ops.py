@@ -181,8 +181,10 @@ def frame_setup(tables, frame_idx, consts, bm, template, rays_world=None):
              rays_body=torch.empty(bs, R, 8, **f32) if R else None)
     ws = torch.empty(bs, 9 * (J - 1), **f32)
     J0, JS = _dev(consts["J0"], "J0"), _dev(consts["JS"], "JS")
-    _lib.check(lib.anr_frame_setup(
-        _ptr(frame_idx), _ptr(bw), bw.shape[0], _ptr(gw), _ptr(pw), _ptr(tw), bs, _ptr(J0), _ptr(JS), _ptr(_dev(bm.parents, "parents", torch.int64)),
+    # (the pose tables' row count travels along: a frame index outside them reads row 0 and poisons the frame with NaN instead
+    # of reading out of bounds — nn.Embedding raises there, models/body_model_params.py:5-68)
+    _lib.check(lib.anr_frame_setup_rows(
+        _ptr(frame_idx), gw.shape[0] if frame_idx is not None else 0, _ptr(bw), bw.shape[0], _ptr(gw), _ptr(pw), _ptr(tw), bs, _ptr(J0), _ptr(JS), _ptr(_dev(bm.parents, "parents", torch.int64)),
         _ptr(_dev(bm.v_template, "v_template")), _ptr(_dev(bm.shapedirs, "shapedirs")), _ptr(_dev(bm.posedirs, "posedirs")),
         _ptr(_dev(bm.lbs_weights, "lbs_weights")), V, J, NB, _ptr(Tt), _ptr(sot), _ptr(pot), Tt.shape[0], _ptr(rays_world), rs, R,
         _ptr(o["betas"]), _ptr(o["pose"]), _ptr(o["transl"]), _ptr(o["A"]), _ptr(o["joints"]), _ptr(o["g_inv"]), _ptr(o["g_root"]),
@@ -1288,9 +1290,20 @@ def to_root_frame_from_chain(A, verts, joints, T):
 _COMPACT_STATE = {}             # (device, stream) -> the zeroed look-back state of anr_compact_ordered_single (it leaves it zero)
 
 
-def compact_ordered_riders(pts: torch.Tensor, fg: Optional[torch.Tensor] = None, bg: Optional[torch.Tensor] = None, single: bool = False):
+def compact_state(total: int, device) -> torch.Tensor:
+    """Look-back state (int64 words, NOT zeroed) for one anr_compact_ordered_single call over `total` entries: the caller owns
+    it and zeroes it in front of every call (the explicit training step: one more segment of its anr_zero_segments launch)."""
+    words = int(_lib.load().anr_compact_state_words(int(total)))
+    return torch.empty(max(words, 1), dtype=torch.int64, device=device)
+
+
+def compact_ordered_riders(pts: torch.Tensor, fg: Optional[torch.Tensor] = None, bg: Optional[torch.Tensor] = None, single: bool = False,
+                           state: Optional[torch.Tensor] = None):
     """`compact_ordered` with the prior points fg[rows,n_fg,3] / bg[rows,n_bg,3] appended as valid samples n .. n + n_r - 1, per
-    frame its foreground then its background points (index / pos: n + n_r entries)."""
+    frame its foreground then its background points (index / pos: n + n_r entries).
+    single + state: the single-pass kernel's look-back state (`compact_state`), ZEROED BY THE CALLER in front of this call — the
+    kernel needs it zero on entry and restores it only in its last block, so a state that outlives a faulted or aborted
+    launch must not be trusted; without `state` a per-(device, stream) tensor kept here is used on that trust (eager calls)."""
     lib = _lib.load()
     pts = _dev(pts, "pts")
     n = pts.numel() // 4
@@ -1309,11 +1322,16 @@ def compact_ordered_riders(pts: torch.Tensor, fg: Optional[torch.Tensor] = None,
         # one launch (chained scan); the look-back state lives per (device, stream): calls on one stream follow each other
         key = (pts.device.index, torch.cuda.current_stream(pts.device).cuda_stream)
         words = int(lib.anr_compact_state_words(tot))
-        state = _COMPACT_STATE.get(key)
-        if state is None or state.numel() < words:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("compact_ordered_riders(single=True): the look-back state must exist before a capture (run one eager step)")
-            state = _COMPACT_STATE[key] = torch.zeros(max(words, 1024), dtype=torch.int64, device=pts.device)
+        if state is not None:
+            state = _dev(state, "state", torch.int64)
+            if state.numel() < words:
+                raise ValueError(f"compact_ordered_riders: state of {state.numel()} words, {words} needed")
+        else:
+            state = _COMPACT_STATE.get(key)
+            if state is None or state.numel() < words:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("compact_ordered_riders(single=True): the look-back state must exist before a capture (run one eager step, or pass state=)")
+                state = _COMPACT_STATE[key] = torch.zeros(max(words, 1024), dtype=torch.int64, device=pts.device)
         with _timed("compact_ordered", tot, tot * 24):
             _lib.check(lib.anr_compact_ordered_single(_ptr(pts), n, _ptr(fg), n_fg, _ptr(bg), n_bg, rows, _ptr(index), _ptr(pos), _ptr(pts_c),
                                                       _ptr(count), _ptr(state), _stream(pts)), "anr_compact_ordered_single")

@@ -630,7 +630,17 @@ class Trainer:
         shapes = (float(perturb), bool(split), tuple((n, tuple(t.shape), t.dtype) for n, t in leaves))
         # host values a capture freezes (none when the optimiser step stays outside the graph)
         baked = () if split else tuple(float(g["lr"]) for g in self.optimizer.param_groups)
-        sig = (shapes, baked)
+        # Frozen networks (`_refine`): their weight packs are made ONCE, found in the cache by the capture and read by every
+        # replay from the address the graph pinned.  A checkpoint loaded after the first capture (load_state_dict, p.copy_)
+        # bumps the tensors' version counters: the signature carries them, so the step is captured again — with fresh packs —
+        # instead of replaying on the old weights.  (A writer that does not bump the counter — `p.data.copy_()` — is invisible
+        # to every cache keyed by it; torch.autograd.graph.increment_version is the remedy, INTEGRATION.md.)
+        frozen_ver = ()
+        if self.explicit is not None and self.explicit.frozen_networks():
+            m = self.model
+            frozen_ver = tuple((id(p), p._version) for net in (m.nerf, getattr(m, "nerf_fine", None)) if net is not None
+                               for p in net.parameters())
+        sig = (shapes, baked, frozen_ver)
         if not eager and (self._graph is None or self._graph[0] != sig):
             if self._graph is not None and self._graph[0][0] != shapes or (self._graph is None and self._graph_warm < self.GRAPH_WARM_STEPS):
                 # (other shapes — the short last batch of an epoch — are not captured: one graph per Trainer, the step stays

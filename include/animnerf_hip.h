@@ -744,6 +744,18 @@ int anr_frame_setup(const int64_t* frame_idx, const float* betas_w, int betas_ro
                     float* A_out, float* joints_root_out, float* g_inv_out, float* g_root_out, float* shape_off_out,
                     float* pose_off_out, float* verts_root_out, float* T_root_out, float* ober2cano_out,
                     float* rays_body_out, float* ws_feat, void* stream);
+/* ... with the pose tables' row count: frame_idx[b] outside [0, table_rows) — where the reference's nn.Embedding raises
+ * (models/body_model_params.py:5-68) — reads row 0 and makes that frame's parameters, hence its loss and gradients, NaN:
+ * no out-of-bounds read, no host synchronisation.  table_rows = 0: not checked (= anr_frame_setup). */
+int anr_frame_setup_rows(const int64_t* frame_idx, int table_rows, const float* betas_w, int betas_rows,
+                         const float* global_orient_w, const float* body_pose_w, const float* transl_w, int bs, const float* J0,
+                         const float* JS, const int64_t* parents, const float* v_template, const float* shapedirs,
+                         const float* posedirs, const float* lbs_weights, int V, int J, int NB, const float* T_template,
+                         const float* shape_off_template, const float* pose_off_template, int template_bs,
+                         const float* rays_world, int ray_stride, int R, float* betas_out, float* pose_out, float* transl_out,
+                         float* A_out, float* joints_root_out, float* g_inv_out, float* g_root_out, float* shape_off_out,
+                         float* pose_off_out, float* verts_root_out, float* T_root_out, float* ober2cano_out,
+                         float* rays_body_out, float* ws_feat, void* stream);
 /* zero `bytes` (a multiple of 4) at a 4-byte aligned device address: a kernel, not a memset (a memset NODE of a captured HIP
  * graph went stale on ROCm 7.2: DESIGN.md section 4.4) */
 int anr_zero_fill(void* ptr, int64_t bytes, void* stream);

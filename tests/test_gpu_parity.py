@@ -123,6 +123,14 @@ def test_fused_frame_setup_matches_reference_and_the_separate_kernels(dev, smpl_
     for k in o_tab:
         assert torch.equal(o_tab[k], o_arr[k]), k
     assert torch.equal(o_tab["pose"], torch.cat([per["global_orient"], per["body_pose"]], 1)) and torch.equal(o_tab["verts"][0], o_tab["verts"][2])
+    # a frame index outside the tables (nn.Embedding raises there): nothing is read out of bounds, that frame — and only that
+    # frame — comes out NaN, so the step's loss says so at the next host read
+    bad = torch.tensor([3, 9, -1, 0], device=dev)
+    o_bad = ops.frame_setup((w["betas"], w["global_orient"], w["body_pose"], w["transl"]), bad, b._chain_consts(), b.body_model, T, rays[:4])
+    for k in ("pose", "A", "verts", "ober2cano", "rays_body"):
+        assert torch.equal(o_bad[k][0], o_tab[k][0]) and torch.equal(o_bad[k][3], o_tab[k][3]), k
+        assert torch.isnan(o_bad[k][1]).any() and torch.isnan(o_bad[k][2]).any(), k
+    assert torch.isnan(o_bad["pose"][1:3]).all() and torch.isnan(o_bad["verts"][1:3]).all()
 
 
 class _one_body:

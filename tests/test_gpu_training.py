@@ -1897,6 +1897,20 @@ def test_refine_step_with_frozen_networks(dev, smpl_table, mode):
     np.testing.assert_allclose([a for a, _ in pairs], [b for _, b in pairs], rtol=5e-3)
     assert all(torch.equal(v, before[k]) for k, v in m4.state_dict().items())
     assert (table4.body_pose.weight.detach() - t_before).abs().max() > 0
+    # (e) a checkpoint loaded AFTER the first capture: the frozen networks' packs were made once and the graph reads them from
+    # a pinned address, so the capture's signature carries the frozen tensors' version counters — the next step is captured
+    # again on the new weights instead of replaying on the old ones (same pose table, same draw counter on both sides)
+    torch.manual_seed(77)
+    other = seeded_model(smpl_table, 29, True, 300.0, (2.0, 2.0), device=dev, mlp_mode=mode)
+    sd = {k: v for k, v in other.state_dict().items() if k.startswith("nerf")}
+    old_graph = tr4._graph[1]
+    for mm, tt in ((m4, tr4), (m5, tr5)):
+        mm.load_state_dict(sd, strict=False)
+    l4 = float(tr4.step_graphed(*args[:7], perturb=1.0, frame_idx=frame_idx)[0])
+    l5 = float(tr5.step_graphed(*args[:7], perturb=1.0, frame_idx=frame_idx)[0])
+    assert tr4._graph is not None and tr4._graph[1] is not old_graph, "the capture must be retaken after the frozen weights changed"
+    assert abs(l4 - l5) <= 5e-3 * abs(l5), (l4, l5)
+    assert abs(l4 - pairs[-1][0]) > 1e-4 * abs(l4), "the new weights must show in the loss"
 
 
 def test_add_inplace_and_background_weight_gradients(dev):

@@ -199,3 +199,24 @@ def test_build_keeps_slp_vectoriser_off():
         spec.loader.exec_module(mod)
         assert mod.NO_SLP == ["-fno-slp-vectorize"]
 
+
+def test_linked_library_holds_no_swapped_or_half_negated_packed_fp32():
+    """The gate behind the flag: the linked library's gfx950 code objects are disassembled and no
+    v_pk_add/mul/fma_f32 may swap an operand's halves (op_sel) or negate one half only — the forms the SLP vectoriser produced
+    and that returned a wrong lane next to other kernels.  build() runs the same scan after linking and rejects
+    the library; here it is run on the library the tests load, whatever built it.  The packed forms that ARE there are the
+    neighbour search's explicit float2 subtractions (both halves negated alike), listed so that a new kind shows up."""
+    import importlib.util
+    import os
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_anr_build_recipe2", os.path.join(root, "anim-nerf_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not (os.path.exists(mod.LIB_PATH) and os.path.exists(os.path.join(mod._LLVM_BIN, "llvm-objdump"))):
+        pytest.skip("no built library / no llvm-objdump here")
+    forms = mod.packed_fp32_forms()
+    assert not [f for f in forms if f[2]], [f for f in forms if f[2]][:5]
+    kernels = {k for k, _, _ in forms}
+    assert all("warp" in k or "knn" in k for k in kernels), sorted(kernels)
+
