@@ -364,7 +364,7 @@ class AnimNeRF(nn.Module):
             return net.get_normal(xyz)
         return net(xyz, viewdir=viewdir)
 
-    def warped_points(self, *, xyz=None, rays=None, z=None, skip_far=False, lean=False, reuse=None, keep=None):
+    def warped_points(self, *, xyz=None, rays=None, z=None, skip_far=False, lean=False, reuse=None, keep=None, steps=None):
         """pts[bs*N,4] = (canonical xyz, valid) for explicit points or for samples along rays.
         skip_far: provably-invalid samples (farther than dis_threshold from the body's bounding box) skip the
         neighbour search; only legal where sigma = -1e5 is all that is consumed (the renderer).
@@ -386,9 +386,10 @@ class AnimNeRF(nn.Module):
                                           self.body_model.lbs_weights, self.dis_threshold, far, reuse if far else None,
                                           keep if far else None).view(-1, 4)
             if lean:                                            # (pts, valid bytes, valid list, device count)
+                # (steps: the coarse pass's deterministic depths as their step table — no depth array, ops.warp_points)
                 pts, vm, vi, vc = ops.warp_points(self.knn_index(), self.ober2cano_transform.detach(),
                                                   self.body_model.lbs_weights, self.dis_threshold, xyz=xyz, rays=rays,
-                                                  z=z, skip_far=True, lean=True, reuse=reuse)
+                                                  z=z, skip_far=True, lean=True, reuse=reuse, steps=steps)
                 return pts.view(-1, 4), vm, vi, vc
             if far and xyz is None and reuse is not None:        # training without pose refinement: rows only
                 reuse = (reuse[0], None, reuse[3])

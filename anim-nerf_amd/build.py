@@ -99,6 +99,23 @@ def check_isa(lib_path: str = LIB_PATH) -> int:
     return len(forms)
 
 
+def _deps(src: str):
+    """`src` and the project headers it includes, transitively (paths)."""
+    import re
+    seen, todo = [], [os.path.join(CSRC, src)]
+    while todo:
+        f = os.path.normpath(todo.pop())
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.append(f)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(f).read(), re.M):
+            for base in (os.path.dirname(f), CSRC, os.path.join(HERE, "..", "include")):
+                if os.path.exists(os.path.join(base, inc)):
+                    todo.append(os.path.join(base, inc))
+                    break
+    return seen
+
+
 def build(force: bool = False, verbose: bool = False, defines=(), out: str = None, extra_flags=()) -> str:
     """Compile every HIP source for gfx950 and link the shared library.  Returns its path.
     `defines`/`out` build an experiment variant (e.g. timing ablations) next to the product library."""
@@ -115,17 +132,29 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = Non
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", tag + ".o"))
+        objs.append(obj)
         cmd = [_hipcc(), *flags, *PER_SOURCE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        # an object is kept when it is newer than its source, the headers that source includes (by name, one level of nesting
+        # is all there is) and this recipe, and was made by the same command line (recorded next to it)
+        stamp = obj + ".cmd"
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == " ".join(cmd):
+            deps = _deps(src) + [os.path.abspath(__file__)]
+            if all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
+                continue
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
-    for src, p in procs:
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), stamp, " ".join(cmd)))
+    failed = []
+    for src, p, stamp, cmdline in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+            failed.append(f"hipcc failed on {src}:\n{out}")
+            continue
+        open(stamp, "w").write(cmdline)
         if verbose and out.strip():
             print(out)
+    if failed:
+        raise RuntimeError("\n".join(failed))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, *objs]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:

@@ -52,6 +52,10 @@ struct MlpBwd {
         return n;
     }
 
+    // half tiles of 128 rows for small batches (mlp_core.h: Mlp::HALFABLE): wavefronts 0-3 run the chain, 4-7 stream the chunks
+    static constexpr bool HALFABLE = ANR_HALF_TILES && C::WAVES == 8 && C::NT == 1;
+    static constexpr int HALF_WAVES = 4;
+    bool half_mode;
     const char* gnext;
     const char* gbase;
     bool more;
@@ -129,7 +133,9 @@ struct MlpBwd {
         if (c + 2 < NCHUNK || more) {
             if (c + 2 == NCHUNK) gnext = gbase;
             const int nf = chunk_frags((c + 2) % NCHUNK);
-            stage_chunk<true, WAVES>(gnext, lds_base, slot_stage, nf, wave, lane);
+            if constexpr (HALFABLE) {
+                if (!half_mode) stage_chunk<true, WAVES>(gnext, lds_base, slot_stage, nf, wave, lane);     // (half tiles: the helpers')
+            } else stage_chunk<true, WAVES>(gnext, lds_base, slot_stage, nf, wave, lane);
             gnext += nf * FRAG_BYTES;
         }
         static_for<NBITS>([&](auto kc) {
@@ -143,6 +149,24 @@ struct MlpBwd {
     __device__ __forceinline__ void rotate() {
         unsigned t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_stage; slot_stage = t;
         ++c;
+    }
+    // half tiles: wavefronts 4-7 — the chunk sequence of the workgroup's ONE point tile in step with the workers' barriers
+    __device__ __forceinline__ void stream_chunks() {
+        dma_wait();
+        __syncthreads();                                   // (the workers' `first` barrier)
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_base;
+        for (int cc = 0; cc < NCHUNK; ++cc) {
+            dma_wait();
+            __syncthreads();                               // (advance() of the chunk's first tile)
+            if (cc + 2 < NCHUNK) {
+                const int nf = chunk_frags(cc + 2);
+                for (int p = wave - HALF_WAVES; p < nf; p += WAVES - HALF_WAVES)
+                    dma16(gnext + p * FRAG_BYTES + lane * 16, base + slot_stage + p * FRAG_BYTES);
+                gnext += nf * FRAG_BYTES;
+            }
+            const unsigned t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_stage; slot_stage = t;
+        }
+        dma_wait();
     }
 
     struct NoEpi {
@@ -320,7 +344,10 @@ struct MlpBwd {
             const int64_t cnt = *count;
             n_pts = cnt < n_pts ? cnt : n_pts;
         }
-        const int64_t n_tiles = (n_pts + WAVES * NT * 32 - 1) / (WAVES * NT * 32);
+        half_mode = false;
+        if constexpr (HALFABLE) half_mode = !tangent && (n_pts + HALF_WAVES * 32 - 1) / (HALF_WAVES * 32) <= (int64_t)gridDim.x;
+        const int wpt = HALFABLE ? (half_mode ? HALF_WAVES : WAVES) : WAVES;      // wavefronts that hold rows of a point tile
+        const int64_t n_tiles = (n_pts + wpt * NT * 32 - 1) / (wpt * NT * 32);
         if ((int64_t)blockIdx.x >= n_tiles) return;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         lane = threadIdx.x & 63;
@@ -338,11 +365,14 @@ struct MlpBwd {
         gnext += chunk_frags(0) * FRAG_BYTES;
         stage_chunk<true, WAVES>(gnext, lds_base, slot_nxt, chunk_frags(1), wave, lane);
         gnext += chunk_frags(1) * FRAG_BYTES;
+        if constexpr (HALFABLE) {
+            if (half_mode && wave >= HALF_WAVES) { stream_chunks(); return; }
+        }
         bool first = true;
         // rows of point tile `t`: a lane past the end aliases the last row (it recomputes and rewrites that row's values:
         // every wave issues the same stores whatever n is — advance() counts them)
         auto rows_of = [&](int64_t t, int n) {
-            const int64_t idx = (t * WAVES + wave) * (NT * 32) + n * 32 + (lane & 31);
+            const int64_t idx = (t * wpt + wave) * (NT * 32) + n * 32 + (lane & 31);
             return idx < n_pts ? idx : n_pts - 1;
         };
         // tangent mode: the ReLU gates of a quad's four columns are the primal column's (row 4p)
@@ -496,7 +526,8 @@ int launch_mlp_bwd(const void* pack, const float* g, const void* act, void* dact
     auto kern = mlp_bwd_kernel<MODE, START, ENC_ONLY>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail((int)e, "anr_mlp_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    const int pts_per_wg = C::WAVES * C::NT * 32;
+    // (the grid holds HALF tiles of 128 rows when the buffer itself is that small: MlpBwd::HALFABLE)
+    const int pts_per_wg = MlpBwd<MODE, START, ENC_ONLY>::HALFABLE ? 128 : C::WAVES * C::NT * 32;
     const int64_t n_tiles = (n + pts_per_wg - 1) / pts_per_wg;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -34,6 +34,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef ANR_HALF_TILES
+#define ANR_HALF_TILES 1            // 0: an A/B build without the small-batch half tiles (tools/bench_mlp_small.py)
+#endif
 constexpr int N_TILES_TOTAL = 78;              // 8*8 trunk + 1 (sigma) + 8 (final) + 4 (dir) + 1 (rgb)
 constexpr int BIAS_BYTES = 10240;              // 78 tiles x 2 halves x 16 floats, padded
 constexpr int FRAG_BYTES = 1024;
@@ -276,6 +279,17 @@ struct Mlp {
     static constexpr int FPT = 16 / EPF;          // next-layer frags produced per out-tile
     static constexpr int SLOT = slot_bytes<C>();
     using ActT = std::conditional_t<C::IS_BF16, __bf16, float>;    // saved activations: the dtype the next layer consumed
+    // HALF TILES (round 6): a training pass at the per-rank batch of the reference's 8-GPU run (2 frames: 17-25 k listed rows)
+    // is 66-100 point tiles of 256 rows — one per CU on a third of the chip, ~59 us each whatever their number, with two
+    // wavefronts per SIMD taking turns on the matrix pipe.  When the listed rows fit HALF tiles of 128 rows on the launch's
+    // workgroups (count on the device: ceil(n / 128) <= gridDim.x) a workgroup takes 128 rows instead: wavefronts 0-3, one
+    // per SIMD, run the layer chain on 32 rows each, wavefronts 4-7 do nothing but stream the weight chunks (LDS-DMA issue,
+    // barriers) — twice the CUs, half the multiplies per CU, the loads' issue off the multiplying wavefronts.  The rows'
+    // values do not depend on which wavefront holds them: same bits.  Training-forward variants of the 8-wave shape only
+    // (the inference instantiations keep their code).
+    static constexpr bool HALFABLE = ANR_HALF_TILES && SAVE && !PRE && !TAN && !VIEW && DMA && C::WAVES == 8 && C::NT == 1;
+    static constexpr int HALF_WAVES = 4;
+    bool half_mode;          // HALFABLE: this launch runs in half tiles
     static constexpr int LAST_TILE = SIGMA_ONLY ? 64 : 77;         // sigma-only stops after the sigma row (tile 64)
     static constexpr int LAST_CHUNK = LAST_TILE / TPC;
     static constexpr int NCHUNK = LAST_CHUNK + 1;                  // chunks per pass (the slot pointers rotate at run time)
@@ -352,7 +366,9 @@ struct Mlp {
         if (c + 2 < NCHUNK || more) {
             if (c + 2 == NCHUNK) gnext = gbase;
             const int nf = chunk_frags<C, VIEW>((c + 2) % NCHUNK);
-            if constexpr (DMA) stage_chunk<DMA, WAVES>(gnext, lds_base, slot_stage, nf, wave, lane);
+            if constexpr (HALFABLE) {
+                if (!half_mode) stage_chunk<DMA, WAVES>(gnext, lds_base, slot_stage, nf, wave, lane);     // (half tiles: the helpers')
+            } else if constexpr (DMA) stage_chunk<DMA, WAVES>(gnext, lds_base, slot_stage, nf, wave, lane);
             else {
 #pragma unroll
                 for (int i = 0; i < MAXP; ++i)
@@ -642,6 +658,26 @@ struct Mlp {
         }
     }
 
+    // Half tiles: what wavefronts 4-7 do — the chunk sequence of ONE point tile (a half-tile launch has one per workgroup), in
+    // step with the workers' barriers: wait for the own pieces of chunk c+1, barrier, stage chunk c+2 over chunk c-1.
+    __device__ __forceinline__ void stream_chunks() {
+        dma_wait();
+        __syncthreads();                                   // (the workers' `first` barrier)
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_base;
+        for (int cc = 0; cc < NCHUNK; ++cc) {
+            dma_wait();
+            __syncthreads();                               // (advance() of the chunk's first tile)
+            if (cc + 2 < NCHUNK) {
+                const int nf = chunk_frags<C, VIEW>(cc + 2);
+                for (int p = wave - HALF_WAVES; p < nf; p += WAVES - HALF_WAVES)
+                    dma16(gnext + p * FRAG_BYTES + lane * 16, base + slot_stage + p * FRAG_BYTES);
+                gnext += nf * FRAG_BYTES;
+            }
+            const unsigned t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_stage; slot_stage = t;
+        }
+        dma_wait();
+    }
+
     // the row a lane past the end of the list works on instead (tangent mode: the row of the last quad with its own role)
     static __device__ __forceinline__ int64_t clamp_row(int64_t idx, int64_t n) {
         return idx < n ? idx : (TAN ? n - 4 + (idx & 3) : n - 1);
@@ -658,7 +694,11 @@ struct Mlp {
             const int64_t cnt = *count;
             n_pts = cnt < n_pts ? cnt : n_pts;
         }
-        const int64_t n_tiles = (n_pts + WAVES * NT * 32 - 1) / (WAVES * NT * 32);
+        half_mode = false;
+        if constexpr (HALFABLE) half_mode = (n_pts + HALF_WAVES * 32 - 1) / (HALF_WAVES * 32) <= (int64_t)gridDim.x;
+        // wavefronts that hold rows of a point tile
+        const int wpt = HALFABLE ? (half_mode ? HALF_WAVES : WAVES) : WAVES;
+        const int64_t n_tiles = (n_pts + wpt * NT * 32 - 1) / (wpt * NT * 32);
         if ((int64_t)blockIdx.x >= n_tiles) return;       // (before anything is in flight into LDS)
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         lane = threadIdx.x & 63;
@@ -687,7 +727,7 @@ struct Mlp {
         auto fetch_pts = [&](int64_t tile_idx, float4 (&dst)[NT]) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                int64_t idx = (tile_idx * WAVES + wave) * (NT * 32) + n * 32 + (lane & 31);
+                int64_t idx = (tile_idx * wpt + wave) * (NT * 32) + n * 32 + (lane & 31);
                 idx = clamp_row(idx, n_pts);
                 if (index) {
                     // every listed sample is valid: the w lane carries its position in pts/out instead
@@ -723,6 +763,9 @@ struct Mlp {
                 }
             }
         };
+        if constexpr (HALFABLE) {
+            if (half_mode && wave >= HALF_WAVES) { stream_chunks(); return; }
+        }
         float4 p_cur[NT], p_nxt[NT];
         if constexpr (PRE) {
 #pragma unroll
@@ -738,7 +781,7 @@ struct Mlp {
         if constexpr (!PRE)
             if (more) fetch_pts(pt + gridDim.x, p_nxt);      // the next tile's points arrive under this tile's MFMAs
         // this wave's points, Fourier-encoded straight into B fragments
-        const int64_t wave_base = (pt * WAVES + wave) * (NT * 32);
+        const int64_t wave_base = (pt * wpt + wave) * (NT * 32);
         float valid[NT];
         Frag E[NT][EF];
 #pragma unroll
@@ -919,7 +962,10 @@ int launch_mlp(const void* pack, const float* pts, int64_t n, float* out, hipStr
     auto kern = mlp_kernel<MODE, DMA, SIGMA_ONLY, SAVE, PRE, TAN, VIEW, BITS_ONLY>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail((int)e, "anr_mlp_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    const int pts_per_wg = C::WAVES * C::NT * 32;
+    // (the training-forward variants of the 8-wave shape may run in half tiles of 128 rows: Mlp::HALFABLE — the grid must
+    // hold those when the buffer itself is that small; the listed rows are counted on the device)
+    constexpr bool halfable = Mlp<MODE, DMA, SIGMA_ONLY, SAVE, PRE, TAN, VIEW, BITS_ONLY>::HALFABLE;
+    const int pts_per_wg = halfable ? 128 : C::WAVES * C::NT * 32;
     const int64_t n_tiles = (n + pts_per_wg - 1) / pts_per_wg;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -1025,7 +1025,10 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
     int64_t N, float thr, float4* __restrict__ pts_out, int32_t* __restrict__ list, int32_t* __restrict__ cells,
     int32_t* __restrict__ count, int32_t* __restrict__ cell_count, uint8_t* __restrict__ valid_mask,
     const float4* __restrict__ reuse_pts, const uint8_t* __restrict__ reuse_mask, const uint8_t* __restrict__ perm, int reuse_K,
-    int G) {
+    int G, int z_steps) {
+    // z_steps (round 6): `z` is the step table s[K] of the deterministic stratified depths, z_k = near' (1 - s_k) + far' s_k
+    // (models/volume_rendering.py:43-44) with the roundings of anr_sample_coarse — the coarse depth array of an inference
+    // frame (4 B per sample written, then read here and by the fused coarse pass) is not made at all.
     __shared__ int wave_cnt[LEAN_THREADS / 64];
     __shared__ int block_base;
     __shared__ int hkeys[HN], hcnt[HN];
@@ -1055,12 +1058,14 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
         in[step] = n0 < N;                                  // (N % 4 == 0: the four samples are in range together)
         float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         pm[step] = 0u;
+        ray4[step] = in[step] ? (uint32_t)n0 / (uint32_t)K : 0u;                      // (N < 2^31 on this path)
         if (in[step]) {
-            z4 = *reinterpret_cast<const float4*>(z + (int64_t)b * N + n0);
+            // (K % 4 == 0: the four samples are consecutive entries of one ray's step table)
+            z4 = z_steps ? *reinterpret_cast<const float4*>(z + ((uint32_t)n0 - ray4[step] * (uint32_t)K))
+                         : *reinterpret_cast<const float4*>(z + (int64_t)b * N + n0);
             if (perm != nullptr) pm[step] = *reinterpret_cast<const unsigned*>(perm + (int64_t)b * N + n0);
         }
         zz[step * VS + 0] = z4.x; zz[step * VS + 1] = z4.y; zz[step * VS + 2] = z4.z; zz[step * VS + 3] = z4.w;
-        ray4[step] = in[step] ? (uint32_t)n0 / (uint32_t)K : 0u;                      // (N < 2^31 on this path)
     }
     float ro[STEPS][3], rd[STEPS][3];
 #pragma unroll
@@ -1068,6 +1073,17 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
         const float* ry = rays + ((int64_t)b * R32 + ray4[step]) * ray_stride;
 #pragma unroll
         for (int a = 0; a < 3; ++a) { ro[step][a] = in[step] ? ry[a] : 0.0f; rd[step][a] = in[step] ? ry[3 + a] : 0.0f; }
+        if (z_steps) {
+#pragma clang fp contract(off)                                     // (anr_sample_coarse rounds the two products and the sum separately;
+            // HIP's __fmul_rn / __fadd_rn are plain operators, which this file's default would contract into an fma)
+            const float near = in[step] ? ry[6] : 0.0f, far = in[step] ? ry[7] : 0.0f;
+#pragma unroll
+            for (int v = 0; v < VS; ++v) {
+                const float sk = zz[step * VS + v];
+                const float lo = near * (1.0f - sk), hi = far * sk;
+                zz[step * VS + v] = lo + hi;
+            }
+        }
     }
     // ---- B: positions, the box test, the coarse samples' validity bytes, the reach-mask words
     float px[LEAN_ITERS], py[LEAN_ITERS], pz[LEAN_ITERS];
@@ -2146,6 +2162,10 @@ extern "C" int anr_warp_points_reuse(const float* xyz, int xyz_stride, const flo
     ANR_REQUIRE(bytes <= 160 * 1024, ANR_E_SHAPE, "anr_warp_points: V=%d needs %d B of LDS (>160 KiB)", V, bytes);
     hipStream_t st = (hipStream_t)stream;
     const float* index = reinterpret_cast<const float*>(knn_index);
+    // skip_far & 4: `z` is the step table s[K] of the deterministic stratified depths (the lean renderer pass only)
+    const bool z_steps = (skip_far & 4) != 0;
+    ANR_REQUIRE(!z_steps || (lean && xyz == nullptr && ws != nullptr), ANR_E_BADARG,
+                "anr_warp_points: skip_far & 4 (z = step table) needs rays mode, a workspace and the validity outputs");
     if (skip_far && ws != nullptr) {
         // two passes: classify + compact, then search the compacted list (see warp_classify_kernel)
         ANR_REQUIRE(dist_out == nullptr, ANR_E_BADARG, "anr_warp_points: debug outputs need skip_far = 0");
@@ -2179,10 +2199,13 @@ extern "C" int anr_warp_points_reuse(const float* xyz, int xyz_stride, const flo
 #define ANR_CLASSIFY_LEAN(CL)                                                                                                  \
             hipLaunchKernelGGL((warp_classify_lean_kernel<CL>), gl, dim3(LEAN_THREADS), 0, st, rays, ray_stride, z, K, index, d, N,  \
                                dis_threshold, reinterpret_cast<float4*>(pts_out), w.list, w.cells, w.count, w.cell_count,          \
-                               valid_mask_out, reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K, G)
+                               valid_mask_out, reinterpret_cast<const float4*>(reuse_pts), reuse_mask, reuse_perm, reuse_K, G,      \
+                               z_steps ? 1 : 0)
             if (small) ANR_CLASSIFY_LEAN(false); else ANR_CLASSIFY_LEAN(true);
 #undef ANR_CLASSIFY_LEAN
         }
+        else if (z_steps) return fail(ANR_E_BADARG, "anr_warp_points: skip_far & 4 (z = step table) is the lean renderer pass's "
+                                      "(validity outputs, K %% 4 == 0, 16-B aligned table, no neighbour outputs)");
         else if (vec4)           { if (small) ANR_CLASSIFY(true, true, false);   else ANR_CLASSIFY(true, true, true); }
         else if (xyz == nullptr) { if (small) ANR_CLASSIFY(true, false, false);  else ANR_CLASSIFY(true, false, true); }
         else                     { if (small) ANR_CLASSIFY(false, false, false); else ANR_CLASSIFY(false, false, true); }

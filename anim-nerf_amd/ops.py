@@ -334,10 +334,12 @@ def warp_workspace(bs: int, N: int, device):
 
 
 def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays=None, z=None, debug=False,
-                skip_far=False, neighbours=False, two_pass=True, lean=False, reuse=None, workspace=None):
+                skip_far=False, neighbours=False, two_pass=True, lean=False, reuse=None, workspace=None, steps=None):
     """models/anim_nerf.py:153-192.  Either xyz[bs,N,3|4] or (rays[bs,R,>=8], z[bs,R,K]).
     `index` = knn_index_build(posed verts).  Returns pts[bs,N,4] = (x_c, y_c, z_c, valid)
-    (+ dist[bs,N,4], idx[bs,N,4] i32, blended[bs,N] if debug)."""
+    (+ dist[bs,N,4], idx[bs,N,4] i32, blended[bs,N] if debug).
+    steps[K] instead of z (lean renderer pass only): the step table of the deterministic stratified depths,
+    z_k = near' (1 - s_k) + far' s_k computed in the kernel (the bits of sample_coarse) — no depth array."""
     lib = _lib.load()
     index = _dev(index, "knn_index", torch.uint8)
     o2c, lbs_weights = _dev(o2c, "ober2cano"), _dev(lbs_weights, "lbs_weights")
@@ -349,6 +351,13 @@ def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
         xyz = _dev(xyz, "xyz")
         N, xs = xyz.shape[1], xyz.shape[2]
         rs, K = 0, 0
+    elif steps is not None:
+        if z is not None or not (lean and skip_far and two_pass) or reuse is not None or neighbours:
+            raise ValueError("warp_points(steps=): the lean renderer pass of the coarse samples (no z, no reuse, no neighbour outputs)")
+        rays, z = _dev(rays, "rays"), _dev(steps, "steps")
+        K = z.numel()
+        N = rays.shape[1] * K
+        rs, xs = rays.shape[-1], 0
     else:
         rays, z = _dev(rays, "rays"), _dev(z, "z")
         K = z.shape[-1]
@@ -394,7 +403,7 @@ def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
     with _timed("warp_points", bs * N):
         _lib.check(lib.anr_warp_points_reuse(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(index), _ptr(o2c),
                                              _ptr(lbs_weights), bs, V, J, N, float(dis_threshold),
-                                             (3 if (workspace is not None and ws is not None) else 1) if skip_far else 0,
+                                             ((3 if (workspace is not None and ws is not None) else 1) | (4 if steps is not None else 0)) if skip_far else 0,
                                              _ptr(pts), _ptr(dist), _ptr(idx), _ptr(blended), _ptr(nidx), _ptr(nw), _ptr(ws),
                                              _ptr(vmask), _ptr(vindex), _ptr(vcount), _ptr(r_pts), _ptr(r_mask), _ptr(r_perm),
                                              r_k, _ptr(r_nidx), _ptr(r_nw), _stream(pts)),

@@ -146,6 +146,8 @@ class VolumeRenderer(nn.Module):
 
     # -- inference, deterministic sampling: the lean schedule
     fuse_coarse_pass = True          # composite + importance sampling + merge of the coarse pass in one launch
+    # True (or ANR_COARSE_DEPTH_ARRAY=1, the A/B switch): the warp path materialises the coarse depths (anr_sample_coarse), as before round 6
+    coarse_depth_array = bool(__import__("os").environ.get("ANR_COARSE_DEPTH_ARRAY"))
 
     def _lean_inference_ok(self, model, rays, perturb, kwargs):
         if not (self.fuse_coarse_pass and perturb == 0 and self.lindisp and self.n_fine > 0 and self.n_fine_depth == 0
@@ -174,12 +176,19 @@ class VolumeRenderer(nn.Module):
                 out_f = net_f.eval_rays(rays, zs.view(bs, R, K))
                 valid_f = None
             else:
-                zc = ops.sample_coarse(rays, steps)
                 reuse = getattr(self, "reuse_coarse_warp", True)
-                pts, valid, vindex, vcount = model.warped_points(rays=rays, z=zc.view(bs, R, Kc), skip_far=True, lean=True)
+                if self.coarse_depth_array or model.k_neigh != 4 or Kc % 4:
+                    zc = ops.sample_coarse(rays, steps)
+                    pts, valid, vindex, vcount = model.warped_points(rays=rays, z=zc.view(bs, R, Kc), skip_far=True, lean=True)
+                    depths = dict(z=zc)
+                else:
+                    # (round 6) no coarse depth array: the classify pass and the fused coarse pass both compute
+                    # near' (1 - s_k) + far' s_k from the ray and the step table, with anr_sample_coarse's roundings — same bits
+                    pts, valid, vindex, vcount = model.warped_points(rays=rays, steps=steps, skip_far=True, lean=True)
+                    depths = dict(steps=steps)
                 out_c = net_c.eval_points(pts, valid_list=(vindex, vcount))
-                cs = ops.composite_sample(out_c.view(bs * R, Kc, 4), flat, u, self.white_bkgd, z=zc, valid=valid.view(bs * R, Kc),
-                                          want_perm=reuse)
+                cs = ops.composite_sample(out_c.view(bs * R, Kc, 4), flat, u, self.white_bkgd, valid=valid.view(bs * R, Kc),
+                                          want_perm=reuse, **depths)
                 zs = cs["z_sorted"]
                 pts_f, valid_f, vindex, vcount = model.warped_points(
                     rays=rays, z=zs.view(bs, R, K), skip_far=True, lean=True, reuse=(pts, valid, cs["perm"]) if reuse else None)

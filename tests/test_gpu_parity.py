@@ -799,6 +799,13 @@ def test_cell_sorted_search_with_two_bodies_is_bit_identical(dev, smpl_table):
         assert torch.equal(outs[0][k], outs[1][k]), k
     assert outs[0]["alphas_fine"].max() > 0.2, "the bodies must be in view"
     assert not torch.equal(outs[0]["rgbs_fine"][0], outs[0]["rgbs_fine"][1])
+    # round 6: the sparse path computes the coarse depths from the step table inside the classify pass and the fused coarse
+    # pass (no depth array); with the array (anr_sample_coarse, as before): the same bits
+    vr.coarse_depth_array = True
+    with torch.no_grad():
+        with_array = ana.batched_inference(vr, m, rays, pose, _templ(dev), chunk=1 << 14)
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], with_array[k]), k
 
 
 def test_repeated_renders_are_bit_identical_next_to_other_work(dev, smpl_table):
