@@ -267,10 +267,14 @@ __host__ __device__ constexpr int act_sign_bit(int Q, int i) { return ((i & 1) ?
 // BITS_ONLY (with SAVE): only the ReLU sign bits are kept — what the activation-gradient kernel gates with — not the
 // activations themselves, which only the WEIGHT gradients read: the `_refine` stage of the shipped configs trains the poses
 // with the networks frozen (train.py:433-437, configs/people_snapshot/*_refine.yaml: pretrained_model_requires_grad False).
+// FUSED (round 6, csrc/ray_march.hip): the tile machinery driven by the one-pass ray-march kernel — consecutive point-tile
+// passes may belong to DIFFERENT networks (coarse, fine, fine, coarse, ...): the ring wraps to `gbase` = the NEXT pass's pack
+// (set by the caller before each pass) and the last tile of a pass prefetches the next pass's first bias from `lds_bias_next`.
 template <int MODE, bool DMA, bool SIGMA_ONLY = false, bool SAVE = false, bool PRE = false, bool TAN = false, bool VIEW = false,
-          bool BITS_ONLY = false>
+          bool BITS_ONLY = false, bool FUSED = false>
 struct Mlp {
     static_assert(!BITS_ONLY || SAVE, "BITS_ONLY is a variant of SAVE");
+    static_assert(!FUSED || (DMA && !SIGMA_ONLY && !SAVE && !PRE && !TAN && !VIEW), "FUSED: the plain inference network");
     static_assert(!VIEW || (!SIGMA_ONLY && !SAVE && !PRE && !TAN), "the fused view-dependent head: inference, full network");
     using C = Cfg<MODE>;
     using Frag = typename C::Frag;
@@ -304,6 +308,7 @@ struct Mlp {
     bool more;               // persistent loop: another point tile follows this one
     char* lds_base;          // the workgroup's dynamic LDS: [bias table | 3 ring slots]
     char* lds_bias;
+    char* lds_bias_next;     // FUSED: the bias table of the NEXT pass's network
     unsigned slot_cur;       // byte offset (in lds_base) of the slot of chunk c
     unsigned slot_nxt;       // ... of chunk c+1
     unsigned slot_stage;     // ... of the slot chunk c+2 is staged into
@@ -383,8 +388,9 @@ struct Mlp {
         unsigned t = slot_cur; slot_cur = slot_nxt; slot_nxt = slot_stage; slot_stage = t;
         ++c;
     }
-    __device__ __forceinline__ f32x16 read_bias(int tile_idx) {
-        const f32x4* b = reinterpret_cast<const f32x4*>(lds_bias + tile_idx * 128 + half * 64);
+    __device__ __forceinline__ f32x16 read_bias(int tile_idx, bool next_pass = false) {
+        const char* table = (FUSED && next_pass) ? lds_bias_next : lds_bias;
+        const f32x4* b = reinterpret_cast<const f32x4*>(table + tile_idx * 128 + half * 64);
         f32x16 v;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -563,7 +569,7 @@ struct Mlp {
             Frag (&ld)[4] = (j & 1) ? wa : wb;
 #pragma unroll
             for (int q = 0; q < 4; ++q) ld[q] = (j + 1 < NG) ? cur[((j + 1) * 4 + q) * 64] : nxt[q * 64];
-            if constexpr (j + 1 == NG && !BIAS_IN_ACC) bias_n = read_bias(END ? 0 : T + 1);
+            if constexpr (j + 1 == NG && !BIAS_IN_ACC) bias_n = read_bias(END ? 0 : T + 1, END);
             __builtin_amdgcn_sched_barrier(0);          // the loads above are issued before this group's MFMAs
             static_for<4>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;

@@ -964,6 +964,22 @@ def composite_sample(rgbs, rays, u, white_bkgd: bool, *, z=None, steps=None, val
     return o
 
 
+def ray_march(pack_c: torch.Tensor, pack_f: torch.Tensor, mode: int, rays: torch.Tensor, steps: torch.Tensor, u: torch.Tensor,
+              white_bkgd: bool):
+    """The whole coarse -> fine render of rays[R, >=8] without the warp in ONE launch (anr_ray_march: 64 + 64 samples):
+    -> dict(rgb, depth, acc, rgb_fine, depth_fine, acc_fine), the bits of the staged launches."""
+    lib = _lib.load()
+    rays, steps, u = _dev(rays, "rays"), _dev(steps, "steps"), _dev(u, "u")
+    R = rays.shape[0]
+    new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=rays.device)
+    o = dict(rgb=new(R, 3), depth=new(R, 1), acc=new(R, 1), rgb_fine=new(R, 3), depth_fine=new(R, 1), acc_fine=new(R, 1))
+    with _timed("ray_march", R * (2 * steps.numel() + u.numel()), R * (32 + 40)):
+        _lib.check(lib.anr_ray_march(_ptr(pack_c), _ptr(pack_f), mode & 0xff, _ptr(rays), rays.shape[-1], R, _ptr(steps), steps.numel(),
+                                     _ptr(u), u.numel(), 1 if white_bkgd else 0, _ptr(o["rgb"]), _ptr(o["depth"]), _ptr(o["acc"]),
+                                     _ptr(o["rgb_fine"]), _ptr(o["depth_fine"]), _ptr(o["acc_fine"]), _stream(rays)), "anr_ray_march")
+    return o
+
+
 # ---- the steps between the big kernels of a training step (csrc/train_glue.hip)
 def compact_ordered(pts: torch.Tensor):
     """-> (index[n] int32 — first `count` entries: the positions with valid >= 1, ascending —, pos[n] int32 (row in that

@@ -146,6 +146,9 @@ class VolumeRenderer(nn.Module):
 
     # -- inference, deterministic sampling: the lean schedule
     fuse_coarse_pass = True          # composite + importance sampling + merge of the coarse pass in one launch
+    # True (or ANR_ONE_PASS=1): a render without the warp at 64 + 64 samples runs as ONE launch, the one-pass ray-march kernel
+    # (csrc/ray_march.hip) — opt-in: same bits, measured ~ the staged path's speed
+    one_pass = bool(__import__("os").environ.get("ANR_ONE_PASS"))
     # True (or ANR_COARSE_DEPTH_ARRAY=1, the A/B switch): the warp path materialises the coarse depths (anr_sample_coarse), as before round 6
     coarse_depth_array = bool(__import__("os").environ.get("ANR_COARSE_DEPTH_ARRAY"))
 
@@ -168,6 +171,18 @@ class VolumeRenderer(nn.Module):
         flat = rays.view(bs * R, -1)
         net_c, net_f = model._net(False), model._net(True)
         with torch.no_grad():
+            if not model.use_unpose and self.one_pass and Kc == 64 and self.n_fine == 64:
+                # the one-pass ray-march kernel (csrc/ray_march.hip): the whole render in ONE launch, same bits
+                pack, mode = net_c.weight_pack()
+                pack_f, mode_f = net_f.weight_pack()
+                if mode_f != mode:
+                    raise ValueError("one_pass: the two networks run in one arithmetic mode")
+                o = ops.ray_march(pack, pack_f, mode, flat, steps, u, self.white_bkgd)
+                fine = {"rgbs": o["rgb_fine"].view(bs, R, 3), "alphas": o["acc_fine"].view(bs, R, 1), "depths": o["depth_fine"].view(bs, R, 1)}
+                if self.share_fine:
+                    return fine
+                return {"rgbs": o["rgb"].view(bs, R, 3), "alphas": o["acc"].view(bs, R, 1), "depths": o["depth"].view(bs, R, 1),
+                        "rgbs_fine": fine["rgbs"], "alphas_fine": fine["alphas"], "depths_fine": fine["depths"]}
             if not model.use_unpose:
                 pack, mode = net_c.weight_pack()
                 out_c = ops.mlp_forward_rays_steps(pack, mode, rays, steps)

@@ -66,6 +66,8 @@ def parse():
                     help="scale the sigma heads about their median (0 = literal random init, which renders a blank image)")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline workload (no modes / workloads objects)")
+    ap.add_argument("--one-pass", action="store_true",
+                    help="cfg2: render through the one-pass ray-march kernel (anr_ray_march) instead of the staged launches")
     ap.add_argument("--extras-only", action="store_true",
                     help="(internal) the child job of an N > 1 run: the modes / workloads objects without the headline")
     ap.add_argument("--plumbing-only", action="store_true",
@@ -226,8 +228,9 @@ def rescale_sigma(model, gain, mode, dev):
             net.sigma.bias.mul_(gain).add_(-gain * med)
 
 
-def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling="weak", checks=False, check_rays=None):
-    """BASELINE configs[1] / configs[2]: a full frame per step."""
+def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling="weak", checks=False, check_rays=None, one_pass=False):
+    """BASELINE configs[1] / configs[2]: a full frame per step.
+    one_pass (configs[1] only): the frame through the one-pass ray-march kernel (anr_ray_march) instead of the staged launches."""
     import anim_nerf_amd as ana
     from anim_nerf_amd import synthetic as syn
     dev, rank, world = ctx.dev, ctx.rank, ctx.world
@@ -238,6 +241,8 @@ def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling=
     rescale_sigma(model, args.sigma_gain, mode, dev)
     model.skip_invalid_samples = not dense
     vr = ana.VolumeRenderer(n_coarse=args.n_coarse, n_fine=args.n_fine, white_bkgd=True)
+    one_pass = bool(one_pass or getattr(args, "one_pass", False)) and not use_warp and args.n_coarse == 64 and args.n_fine == 64
+    vr.one_pass = one_pass
     H = W = args.hw
     c2w, focal, cen = syn.pinhole_camera(H, W)
     strong = scaling == "strong" and world > 1
@@ -259,7 +264,8 @@ def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling=
     elapsed, per_kernel, out = ctx.timed(step, steps, warmup)
     total_rays = (n_frame if strong else n_frame * world) * steps
     evals = args.n_coarse + (args.n_coarse + args.n_fine if args.n_fine else 0)
-    mlp = per_kernel.get("mlp_forward", {"units": 0})
+    mlp_key = "ray_march" if one_pass else "mlp_forward"
+    mlp = per_kernel.get(mlp_key, {"units": 0})
     result = {
         "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "scaling": "strong" if strong else "weak", "dtype": mode,
@@ -278,16 +284,30 @@ def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling=
             "mlp_on_valid_samples_only": bool(model.evaluate_valid_only),
             "mlp_points_per_step": mlp["units"] // max(steps, 1),
         },
-        "roofline": mlp_roofline(per_kernel, "mlp_forward", mode, MLP_FLOP_PER_POINT,
+        "roofline": mlp_roofline(per_kernel, mlp_key, mode, MLP_FLOP_PER_POINT,
+                                 f"ray_march_kernel<{mode}> (ONE launch per frame: stratified samples, point generation, Fourier encoding, both "
+                                 "networks, compositing, importance sampling + merge; the fraction is the WHOLE kernel's)" if one_pass else
                                  f"mlp_kernel<{mode}> (fused Fourier encoding + 11 GEMMs)"),
         "kernel_time_share": {k: round(v["s"] / elapsed, 4) for k, v in per_kernel.items()},
     }
+    if one_pass:
+        # the same frame through the staged launches: the one-pass kernel must return their bits
+        vr.one_pass = False
+        idx = torch.arange(0, n_rays, max(n_rays // 65536, 1), device=dev)[:65536]
+        sub = rays[:, idx].contiguous()
+        with torch.no_grad():
+            st = ana.batched_inference(vr, model, sub, pose, templ, chunk=args.chunk)
+            vr.one_pass = True
+            op = ana.batched_inference(vr, model, sub, pose, templ, chunk=args.chunk)
+        result["config"]["launches_per_frame"] = "1 (anr_ray_march) + the per-frame set-up"
+        result["equals_staged_launches_bit_for_bit"] = bool(all(torch.equal(st[k], op[k]) for k in st))
+        result["equality_check_rays"] = int(idx.numel())
     # Everything around the MLP (sampling, point generation / warp, compaction, compositing, importance sampling) against
     # the HBM roofline.  `achieved` = the bytes those launches move BY DESIGN (every input read once, every output written
     # once: what each wrapper in ops.py declares) / their summed HIP-event time; SURVEY.md section 8(d)'s compulsory figure
     # (52 B per ray + 36 B per sample, which counts a 16-B canonical point per sample even where no kernel moves one) is
     # kept beside it.  With the warp on the binding resource is VALU issue (exact KNN), not HBM.
-    others = {k: v for k, v in per_kernel.items() if k != "mlp_forward"}
+    others = {k: v for k, v in per_kernel.items() if k not in ("mlp_forward", "ray_march")}
     other_s = sum(v["s"] for v in others.values())
     moved = sum(v["bytes"] for v in others.values())
     comp_bytes = n_rays * steps * (52 + 36 * evals)
@@ -775,6 +795,9 @@ def collect_extras(args, ctx):
     try:
         if world == 1:
             out["modes"] = {"f32": extra(render_bench, args, ctx, False, "f32", 2, 1, keep=("roofline_hbm_kernels",))}
+            # the headline workload through the one-pass ray-march kernel (csrc/ray_march.hip): one launch per frame, same bits
+            out["modes"]["one_pass"] = extra(render_bench, args, ctx, False, args.mode, 4, 1, one_pass=True,
+                                             keep=("equals_staged_launches_bit_for_bit", "equality_check_rays", "kernel_time_share"))
             # (with its own oracle check: 1,024 rays through the oracle's brute-force 4-NN warp, ~25 s of host time)
             w["cfg3"] = extra(render_bench, args, ctx, True, args.mode, 3, 1, checks=True, check_rays=1024,
                               keep=("roofline_hbm_kernels", "kernel_time_share", "oracle_check", "cpu_baseline"))

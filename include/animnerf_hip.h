@@ -756,6 +756,17 @@ int anr_frame_setup_rows(const int64_t* frame_idx, int table_rows, const float* 
                          float* A_out, float* joints_root_out, float* g_inv_out, float* g_root_out, float* shape_off_out,
                          float* pose_off_out, float* verts_root_out, float* T_root_out, float* ober2cano_out,
                          float* rays_body_out, float* ws_feat, void* stream);
+/* The one-pass ray-march kernel (csrc/ray_march.hip; models/volume_rendering.py:163-232 with a model without the warp,
+ * use_unpose=False — BASELINE configs[1]): per ray, in ONE launch: Kc stratified coarse depths (perturb = 0, :29-56), x = o + z d,
+ * Fourier encoding + the coarse network (models/nerf.py:129-175; pack_coarse / pack_fine from anr_mlp_pack, `mode` as there),
+ * compositing (:113-160), Kf importance samples from the coarse weights (u[Kf] = linspace(0, 1, Kf), :59-97) merged in depth
+ * order (:199-207), the fine network on the Kc + Kf sorted samples, compositing.  Nothing per sample goes through HBM: 32 B in
+ * and 2 x 20 B out per ray.  Returns the bits of anr_mlp_forward_rays_steps + anr_composite_sample + anr_mlp_forward_rays +
+ * anr_composite.  Built for Kc = Kf = 64 (ANR_E_SHAPE otherwise).  rays[R*ray_stride], steps[Kc] (the table of
+ * anr_sample_coarse), outputs rgb[R*3], depth[R], acc[R] for the coarse and the fine pass. */
+int anr_ray_march(const void* pack_coarse, const void* pack_fine, int mode, const float* rays, int ray_stride, int64_t R,
+                  const float* steps, int Kc, const float* u, int Kf, int white_bkgd, float* rgb_coarse, float* depth_coarse,
+                  float* acc_coarse, float* rgb_fine, float* depth_fine, float* acc_fine, void* stream);
 /* zero `bytes` (a multiple of 4) at a 4-byte aligned device address: a kernel, not a memset (a memset NODE of a captured HIP
  * graph went stale on ROCm 7.2: DESIGN.md section 4.4) */
 int anr_zero_fill(void* ptr, int64_t bytes, void* stream);

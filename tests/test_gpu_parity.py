@@ -1132,6 +1132,48 @@ def test_full_frame_properties(dev, smpl_table):
     assert psnr > 35.0, psnr
 
 
+def test_one_pass_ray_march_equals_the_staged_path(dev, smpl_table):
+    """The one-pass ray-march kernel (anr_ray_march, csrc/ray_march.hip: stratified samples, point generation, encoding, coarse
+    network, compositing, importance sampling + merge, fine network, compositing in ONE launch) against the staged launches
+    (anr_mlp_forward_rays_steps + anr_composite_sample + anr_mlp_forward_rays + anr_composite) on the no-warp model of the
+    reference fixture: every output tensor BIT FOR BIT, fp32 and bf16, ragged ray counts (1, 3, 4, 5, 259 rays: tail groups,
+    fewer groups than workgroups) and a 300 x 300 image (more groups than workgroups: the persistent loop, the ring wrapping
+    between the two networks' packs), chunked and not.  The staged path's gates against the reference (every ray within 1e-4 or
+    accounted for: test_render_matches_reference, test_every_out_of_tolerance_ray_is_accounted_for) are thereby the one-pass
+    kernel's.  Shapes other than 64 + 64 are refused by the entry point, not mis-rendered."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import ops, synthetic as syn
+    g = golden("render_cfg2_nowarp_gain")
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.static_pose_params().items()}
+    c2w, focal, cen = syn.pinhole_camera(300, 300)
+    big = ana.gen_rays(torch.from_numpy(c2w).to(dev), 300, 300, focal.tolist(), 0.1, 10.0, cen.tolist()).view(1, -1, 8)
+    gen = torch.Generator().manual_seed(5)
+    for mode in ("f32", "bf16"):
+        m = seeded_model(smpl_table, g["seed"], False, g["gain"], g["shift"], device=dev, mlp_mode=mode)
+        staged, fused = ana.VolumeRenderer(n_coarse=64, n_fine=64), ana.VolumeRenderer(n_coarse=64, n_fine=64)
+        staged.one_pass, fused.one_pass = False, True
+        sets = [big[:, torch.randperm(big.shape[1], generator=gen)[:n].to(dev)].contiguous() for n in (1, 3, 4, 5, 259)]
+        sets.append(big if mode == "bf16" else big[:, :20000].contiguous())
+        for rays in sets:
+            with torch.no_grad():
+                ops.KERNEL_TIMING = []
+                a = ana.batched_inference(fused, m, rays, pose, _templ(dev), chunk=1 << 20)
+                names = {k[0] for k in ops.KERNEL_TIMING}
+                ops.KERNEL_TIMING = None
+                assert "ray_march" in names and "mlp_forward" not in names and "composite" not in names, names
+                b = ana.batched_inference(staged, m, rays, pose, _templ(dev), chunk=1 << 20)
+                c = ana.batched_inference(fused, m, rays, pose, _templ(dev), chunk=1001)
+            assert set(a) == set(b) == {"rgbs", "alphas", "depths", "rgbs_fine", "alphas_fine", "depths_fine"}
+            for k in a:
+                assert torch.equal(a[k], b[k]), (k, mode, rays.shape[1])
+                assert torch.equal(a[k], c[k]), (k, mode, rays.shape[1], "chunked")
+        assert b["alphas_fine"].max() > 0.5, "the field must be visible"
+    lib = ana._lib.load()
+    z = torch.zeros(64, device=dev)
+    rc = lib.anr_ray_march(z.data_ptr(), z.data_ptr(), 1, z.data_ptr(), 8, 4, z.data_ptr(), 64, z.data_ptr(), 32, 1, *([z.data_ptr()] * 6), None)
+    assert rc < 0 and b"64 + 64" in lib.anr_last_error()
+
+
 def test_full_frame_properties_with_the_warp(dev, smpl_table):
     """1024 x 1024, 64 + 64, inverse-LBS / 4-NN warp on (BASELINE configs[2]) — the sparse machinery at its real size
     (64^3 cell grid, dead cells, 2^20-ray lists, validity bytes, coarse->fine reuse): determinism, chunk invariance,
