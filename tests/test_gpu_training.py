@@ -1816,6 +1816,60 @@ def test_frozen_network_kernel_variants(dev):
                 assert (got - want).abs().max() <= 2e-5 * want.abs().max() and (got[:, 3] == 0).all(), (mode_name, n)
 
 
+def test_half_tiles_return_the_full_tiles_bits(dev):
+    """Round 6: a bf16 training pass whose listed rows fit HALF tiles of 128 rows on the launch's workgroups (count on the device,
+    <= 128 x 256 = 32,768 rows: the per-rank batch of the reference's 8-GPU run) runs four multiplying wavefronts per workgroup
+    on 32 rows each while the other four only stream the weight chunks (csrc/mlp_core.h: Mlp::HALFABLE, csrc/mlp_bwd.hip).  Which
+    wavefront holds a row does not enter its arithmetic: outputs, saved activations, sign bits and activation gradients of the
+    listed rows equal those of a call that lists 40,000 rows of the same buffer (full tiles) bit for bit — at ragged counts, at
+    the switch-over, for the sign-bits-only / encoding-only variants and the sigma-only pass; small buffers (host-known sizes) too."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import ops
+    from anim_nerf_amd.autograd import PARAM_KEYS
+    torch.manual_seed(1)
+    net = ana.NeRF(freqs_dir=0, use_view=False).to(dev)
+    named = dict(net.named_parameters())
+    P = {k: named[k].detach() for k in PARAM_KEYS}
+    mode = ops.MLP_MODES["bf16"]
+    pack, bpack = ops.mlp_pack(P, mode), ops.mlp_pack(P, mode, backward=True)
+    g = torch.Generator().manual_seed(7)
+    N = 65536
+    pts = torch.cat([torch.rand(N, 3, generator=g) * 2 - 1, torch.ones(N, 1)], -1).to(dev)
+    g4 = torch.randn(N, 4, generator=g).to(dev)
+    cnt = lambda n: torch.tensor([n], dtype=torch.int32, device=dev)
+    raw = lambda a: a.reshape(-1).view(torch.uint8)[ops.ACT_COLS * N * a.element_size():]
+    bits = lambda a, rows: (raw(a)[:8 * 32 * N].view(8, N, 32)[:, :rows], raw(a)[288 * N:304 * N].view(N, 16)[:rows])
+    full = cnt(40000)                                             # 313 half tiles > 256 workgroups: full tiles
+    out_r, act_r = ops.mlp_forward_save(pack, mode, pts, count=full)
+    dact_r = ops.mlp_backward(bpack, mode, g4, act_r, count=full)
+    sig_r, sact_r = ops.mlp_forward_save(pack, mode, pts, sigma_only=True, count=full)
+    sdact_r = ops.mlp_backward(bpack, mode, g4, sact_r, sigma_only=True, count=full)
+    cols_r, dcols_r = ops.act_columns(act_r), ops.act_columns(dact_r)
+    for n in (64, 1000 + 24, 17024, 32768, 32832):               # (counts are padded to 64 by the compaction; 32,832: full tiles again)
+        c = cnt(n)
+        out, act = ops.mlp_forward_save(pack, mode, pts, count=c)
+        assert torch.equal(out[:n], out_r[:n]) and torch.equal(ops.act_columns(act)[:n], cols_r[:n]), n
+        for x, y in zip(bits(act, n), bits(act_r, n)):
+            assert torch.equal(x, y), n
+        dact = ops.mlp_backward(bpack, mode, g4, act, count=c)
+        assert torch.equal(ops.act_columns(dact)[:n], dcols_r[:n]), n
+        out_b, act_b = ops.mlp_forward_save(pack, mode, pts, count=c, bits_only=True)
+        assert torch.equal(out_b[:n], out_r[:n])
+        dact_e = ops.mlp_backward(bpack, mode, g4, act_b, count=c, enc_only=True)
+        for c0 in (0, 1024):
+            assert torch.equal(ops.act_columns(dact_e, c0, c0 + 256)[:n], dcols_r[:n, c0:c0 + 256]), (n, c0)
+        sig, sact = ops.mlp_forward_save(pack, mode, pts, sigma_only=True, count=c)
+        assert torch.equal(sig[:n], sig_r[:n])
+        sdact = ops.mlp_backward(bpack, mode, g4, sact, sigma_only=True, count=c)
+        assert torch.equal(ops.act_columns(sdact, 0, 2048)[:n], ops.act_columns(sdact_r, 0, 2048)[:n]), n
+    # a small buffer, size known to the host: the grid itself is sized in half tiles
+    small = pts[:3000].contiguous()
+    out_s, act_s = ops.mlp_forward_save(pack, mode, small)
+    assert torch.equal(out_s, out_r[:3000]) and torch.equal(ops.act_columns(act_s), cols_r[:3000])
+    dact_s = ops.mlp_backward(bpack, mode, g4[:3000].contiguous(), act_s)
+    assert torch.equal(ops.act_columns(dact_s), dcols_r[:3000])
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_refine_step_with_frozen_networks(dev, smpl_table, mode):
     """The `_refine` stage of the shipped configs (configs/people_snapshot/male-3-casual_refine.yaml:52-53, train.py:433-437):
