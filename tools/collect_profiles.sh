@@ -4,7 +4,7 @@
 # --pmc passes are separate from each other and carry no trace domain besides --kernel-trace.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-R=${ANR_ROUND:-r05}
+R=${ANR_ROUND:-r06}
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -72,4 +72,18 @@ python3 tools/exp/step_timeline.py $OUT/cfg4_f2_trace > $DST/train_step_timeline
 python3 bench.py --workload cfg4 --no-extras --steps 40 --warmup 5 --refine 2>/dev/null | grep '^{' > $DST/bench_cfg4_refine_bf16.json
 python3 bench.py --workload cfg4 --no-extras --steps 40 --warmup 5 --refine --frames-per-gpu 2 2>/dev/null | grep '^{' > $DST/bench_cfg4_refine_f2_bf16.json
 # (the experiment outputs of the round — gpurun_out/r05/*.txt — are copied into profiles/r05/ on the build host)
+ls $DST
+
+# round 6: the one-pass ray-march kernel under the kernel trace (ONE launch per frame) and next to the staged launches on this
+# box; the training MLP passes at small row counts (half tiles); the 2-frame step's timeline comes from the cfg4_f2 trace above
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/cfg2_one_pass_trace --output-format csv -- python3 $ROOT/bench.py --one-pass --no-extras --cpu-rays 0 --no-psnr --steps 3 --warmup 1 > $OUT/cfg2_one_pass_trace.json 2> /dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cfg2_one_pass_fetch --output-format csv -- python3 $ROOT/bench.py --one-pass --no-extras --cpu-rays 0 --no-psnr --steps 3 --warmup 1 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cfg2_one_pass_write --output-format csv -- python3 $ROOT/bench.py --one-pass --no-extras --cpu-rays 0 --no-psnr --steps 3 --warmup 1 > /dev/null 2>&1
+cd $ROOT
+cp $OUT/cfg2_one_pass_trace/*/*kernel_stats.csv $DST/bench_cfg2_one_pass_bf16_kernel_stats.csv
+grep '^{' $OUT/cfg2_one_pass_trace.json > $DST/bench_cfg2_one_pass_bf16_under_rocprof.json
+{ echo "== cfg2 through the one-pass kernel (4 frames: 1 warm-up + 3 timed)"; python3 tools/hbm_table.py $OUT/cfg2_one_pass_fetch $OUT/cfg2_one_pass_write $OUT/cfg2_one_pass_trace; } > $DST/hbm_cfg2_one_pass.txt 2>&1
+bash tools/exp/r06_one_pass_ab.sh > $DST/ab_one_pass_collection_box.txt 2>&1
+python3 tools/bench_mlp_small.py > $DST/mlp_small_half_tiles_collection_box.txt 2>/dev/null
 ls $DST
