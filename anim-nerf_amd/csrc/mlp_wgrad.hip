@@ -55,10 +55,11 @@ template <> struct WgCfg<false> {
     static constexpr int KSTEP = 2;
 };
 
+// `block` = the workgroup's index among this GEMM shape's (gemm, slice) tasks; `lds` = the workgroup's dynamic LDS
 template <bool BF16, int TM, int TN, int WM>
-__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __restrict__ dact, const char* __restrict__ act,
-                                                              const char* __restrict__ enc, int64_t n, WgradArgs args,
-                                                              float* __restrict__ partial) {
+__device__ __forceinline__ void wgrad_body(const char* __restrict__ dact, const char* __restrict__ act,
+                                           const char* __restrict__ enc, int64_t n, const WgradArgs& args,
+                                           float* __restrict__ partial, int block, char* lds) {
     using C = WgCfg<BF16>;
     using T = typename C::T;
     constexpr int WN = WG_WAVES / WM;
@@ -73,10 +74,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
     constexpr int PIECES = (STAGE_A + STAGE_B) / 1024;
     constexpr int PPW = (PIECES + WG_WAVES - 1) / WG_WAVES;           // DMA pieces per wave and stage (padded: uniform waits)
     constexpr int STAGE = PPW * WG_WAVES * 1024;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int gi = blockIdx.x / args.splits, sp = blockIdx.x % args.splits;
+    const int gi = block / args.splits, sp = block % args.splits;
     const WgradGemm gm = args.g[gi];
     int64_t n_rows = n, per = args.rows_per_split;          // n stays the buffers' row count (the block stride)
     if (args.count) {
@@ -242,6 +242,31 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
 #pragma unroll
             for (int e = 0; e < 16; ++e) out[M * N + m_base + a * 32 + (e & 3) + 8 * (e >> 2) + rofs] = bacc[a][e];
     }
+}
+
+template <bool BF16, int TM, int TN, int WM>
+__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __restrict__ dact, const char* __restrict__ act,
+                                                              const char* __restrict__ enc, int64_t n, WgradArgs args,
+                                                              float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    wgrad_body<BF16, TM, TN, WM>(dact, act, enc, n, args, partial, (int)blockIdx.x, lds);
+}
+
+// The three GEMM shapes of one weight-gradient call (256 x 256: trunk + xyz_encoding_final; 256 x 64: the encoding columns of
+// layers 1 and 5; 128 x 256: dir_encoding) in ONE launch (round 6): a workgroup takes its shape from its index.  At the
+// per-rank batch of the reference's 8-GPU run a call's five launches were 110 + 50 + 10 + 15 + 22 us of mostly latency, four
+// calls per step queued on two streams — what the step ended on (profiles/r06/train_step_timeline_f2.txt); together the three
+// shapes' 150-200 workgroups fit the chip at once.  Same tasks, same partial sums, same reduction: same bits.
+template <bool BF16>
+__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_shapes_kernel(const char* __restrict__ dact, const char* __restrict__ act,
+                                                                     const char* __restrict__ enc, int64_t n, WgradArgs a0, WgradArgs a1,
+                                                                     WgradArgs a2, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int n0 = a0.n_gemms * a0.splits, n1 = a1.n_gemms * a1.splits;
+    const int b = (int)blockIdx.x;
+    if (b < n0) wgrad_body<BF16, 2, 4, 4>(dact, act, enc, n, a0, partial, b, lds);
+    else if (b < n0 + n1) wgrad_body<BF16, 1, 2, 8>(dact, act, enc, n, a1, partial, b - n0, lds);
+    else wgrad_body<BF16, 2, 2, 2>(dact, act, enc, n, a2, partial, b - n0 - n1, lds);
 }
 
 // ---- the two skinny heads as weighted column sums (their M side is g, 4 fp32 columns):
@@ -455,9 +480,10 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
         const int pieces = stage / 1024, ppw = (pieces + WG_WAVES - 1) / WG_WAVES;
         return WG_NBUF * ppw * WG_WAVES * 1024;
     };
+    WgradArgs a0{}, a1{}, a2{};
     // ---- 256 x 256: trunk layers 2..8 (hidden part of layer 5) and xyz_encoding_final
     {
-        WgradArgs a{};
+        WgradArgs& a = a0;
         a.tangent = tangent;
         a.count = count;
         const int n_g = sigma_only ? 7 : 8;
@@ -478,15 +504,10 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
             ws_off += a.splits * BLK;
             ++a.n_gemms;
         }
-        auto k = wgrad_kernel<BF16, 2, 4, 4>;
-        const int lds = lds_bytes(256, 256);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k, dim3(a.n_gemms * a.splits), dim3(WG_THREADS), lds, st, D, A, E, n, a, ws);
     }
     // ---- 256 x 64: the encoding columns of layers 1 and 5
     {
-        WgradArgs a{};
+        WgradArgs& a = a1;
         a.tangent = tangent;
         a.count = count;
         a.splits = splits_for(n, C::SR, 2, background);
@@ -500,15 +521,11 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
             ws_off += a.splits * BLK;
             ++a.n_gemms;
         }
-        auto k = wgrad_kernel<BF16, 1, 2, 8>;
-        const int lds = lds_bytes(256, 64);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k, dim3(a.n_gemms * a.splits), dim3(WG_THREADS), lds, st, D, A, E, n, a, ws);
     }
     // ---- 128 x 256: dir_encoding
+    a2.splits = 1;
     if (!sigma_only) {
-        WgradArgs a{};
+        WgradArgs& a = a2;
         a.tangent = tangent;
         a.count = count;
         a.splits = splits_for(n, C::SR, 1, background);
@@ -519,11 +536,38 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
         seg(L.dw, 128, 256, 256, ws_off, 256, BLK, a.splits);
         seg(L.db, 1, 128, 128, ws_off + 128 * 256, BLK, BLK, a.splits);
         ws_off += a.splits * BLK;
-        auto k = wgrad_kernel<BF16, 2, 2, 2>;
-        const int lds = lds_bytes(128, 256);
+    }
+    // (ANR_WGRAD_SEPARATE=1: a launch per shape, as before round 6 — the A/B switch)
+    static const bool separate = getenv("ANR_WGRAD_SEPARATE") != nullptr;
+    if (!separate) {
+        auto k = wgrad_shapes_kernel<BF16>;
+        const int lds = lds_bytes(256, 256);                    // the largest of the three images
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k, dim3(a.n_gemms * a.splits), dim3(WG_THREADS), lds, st, D, A, E, n, a, ws);
+        hipLaunchKernelGGL(k, dim3(a0.n_gemms * a0.splits + a1.n_gemms * a1.splits + a2.n_gemms * a2.splits), dim3(WG_THREADS), lds, st, D, A,
+                           E, n, a0, a1, a2, ws);
+    } else {
+        {
+            auto k = wgrad_kernel<BF16, 2, 4, 4>;
+            const int lds = lds_bytes(256, 256);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL(k, dim3(a0.n_gemms * a0.splits), dim3(WG_THREADS), lds, st, D, A, E, n, a0, ws);
+        }
+        {
+            auto k = wgrad_kernel<BF16, 1, 2, 8>;
+            const int lds = lds_bytes(256, 64);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL(k, dim3(a1.n_gemms * a1.splits), dim3(WG_THREADS), lds, st, D, A, E, n, a1, ws);
+        }
+        if (!sigma_only) {
+            auto k = wgrad_kernel<BF16, 2, 2, 2>;
+            const int lds = lds_bytes(128, 256);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL(k, dim3(a2.n_gemms * a2.splits), dim3(WG_THREADS), lds, st, D, A, E, n, a2, ws);
+        }
     }
     // ---- the skinny heads (sigma, rgb) and their biases
     {

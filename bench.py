@@ -644,7 +644,7 @@ def train_bench_child(args, ctx, mode, steps, warmup, frames=None, refine=False)
 
 
 TRAFFIC_SOURCES = ("anim-nerf_amd/csrc/mlp_core.h", "anim-nerf_amd/csrc/mlp.hip", "anim-nerf_amd/csrc/mlp_inst_bf16.hip",
-                   "anim-nerf_amd/csrc/composite.hip")
+                   "anim-nerf_amd/csrc/composite.hip", "anim-nerf_amd/csrc/composite_core.h")
 
 
 def kernel_sources_sha():

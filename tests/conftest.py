@@ -33,3 +33,25 @@ def _built_library():
     if os.path.exists(mod.LIB_PATH) and not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
         return
     mod.build()
+
+
+@pytest.fixture(autouse=True)
+def _collect_dead_trainers_between_tests():
+    """A Trainer that captured its step holds an instantiated HIP graph (three parallel branches); a test's dead Trainers are
+    reference cycles, so WITHOUT this fixture their graphs stay alive until Python's cyclic collector happens to run — by the
+    end of tests/test_gpu_training.py a dozen of them at once.  On ROCm 7.2 that ends in a segmentation fault inside
+    hipGraphLaunch (hip::Graph::UpdateStreams <- hip::GraphExec::Run) of whichever graph is replayed next: round 6 met it when
+    the file ran as a process of its own (7 of 7 runs; never in isolation, never in the whole-suite run; with four graph
+    deaths logged before the crash and none near it — it is the number of LIVE instantiated graphs, not a destruction, that
+    matters; native backtrace and the bisection in profiles/r06/graph_many_live_segfault.txt).  Collecting between tests
+    keeps one test's graphs from piling onto the next's.  A training process holds one Trainer, i.e. one or two graphs; a
+    caller that builds Trainers in a loop should drop the old one and gc.collect() first."""
+    yield
+    import gc
+    gc.collect()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:                                            # noqa: BLE001
+        pass
