@@ -79,6 +79,9 @@ def test_bad_arguments_are_reported_not_crashed():
         "anr_mc_emit": (None, 8, 8, 8, 0.0) + (None,) * 8,
         "anr_adam_step": (None, 1, None, None, 1, 0.9, 0.999, 1e-8, None),
         "anr_warp_points_reuse": (None, 0, None, 8, None, 4, None, None, None, 1, 6890, 24, 8, 0.2, 1) + (None,) * 13 + (0, None, None, None),
+        # round 6: the one-pass ray-march kernel, the frame set-up with the pose tables' row count
+        "anr_ray_march": (None, None, 1, None, 8, 4, None, 64, None, 64, 1) + (None,) * 7,
+        "anr_frame_setup_rows": (None, 4) + (None, 1) + (None,) * 3 + (1,) + (None,) * 7 + (6890, 24, 10) + (None,) * 3 + (1, None, 8, 0) + (None,) * 15,
     }
     for name, args in calls.items():
         if args is None:
