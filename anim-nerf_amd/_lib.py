@@ -172,6 +172,7 @@ SIGNATURES = {
     "anr_frame_setup_rows": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I]
                              + [_P] * 13 + [_P, _P]),
     "anr_ray_march": (_I, [_P, _P, _I, _P, _I, _L, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "anr_ray_march_warp": (_I, [_P, _P, _I, _P, _I, _I, _L, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
     "anr_knn_within": (_I, [_P, _P, _I, _I, _L, _F, _P, _P]),
     "anr_grid_points_cells": (_I, [_I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, _P, _L, _P, _P, _P]),
     "anr_scatter_relu": (_I, [_P, _P, _L, _L, _L, _P, _P]),

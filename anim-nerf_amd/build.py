@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "libanimnerf_hip.so")
 SOURCES = ["frame_ops.hip", "frame_setup.hip", "frame_bwd.hip", "smpl.hip", "composite.hip", "compact.hip", "warp.hip", "knn_k.hip", "mlp.hip", "mlp_bwd.hip", "mlp_wgrad.hip", "train_glue.hip", "train_step.hip", "mesh.hip", "mlp_inst_f32.hip", "mlp_inst_f32_train.hip",
            "mlp_inst_bf16.hip", "mlp_inst_bf16_train.hip", "mlp_inst_pre.hip", "mlp_inst_tan.hip", "mlp_inst_view.hip", "mlp_inst_refine.hip",
            "ray_march.hip"]
-HEADERS = ["anr_common.h", "mlp_core.h", "composite_core.h", os.path.join("..", "..", "include", "animnerf_hip.h")]
+HEADERS = ["anr_common.h", "mlp_core.h", "composite_core.h", "warp_core.h", os.path.join("..", "..", "include", "animnerf_hip.h")]
 
 
 # The 4-wave x 64-point bf16 variant needs more than 256 registers per lane: with the accumulators in AGPRs (hipcc's

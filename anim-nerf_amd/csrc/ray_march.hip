@@ -23,13 +23,34 @@
 // What it costs and saves against the staged path is in DESIGN.md section 4.5: the exchange through HBM (36 B per sample,
 // ~0.9 ms of a 172 ms frame) against the matrix pipe idling through phases X and Y (two wavefronts busy, six waiting).
 #include "mlp_core.h"
+#undef ANR_SEARCH_PROF                      // (the search's experiment counters belong to warp.hip's builds)
+#include "warp_core.h"                      // (before composite_core.h: that one switches fp contraction off for what follows)
 #include "composite_core.h"
 
 namespace anr {
 
 constexpr int RM_KC = 64, RM_KF = 64, RM_K = RM_KC + RM_KF, RM_KT = 128;
 
-template <int MODE>
+// WARP (anr_ray_march_warp): every sample is inverse-skinned inside the pass — models/anim_nerf.py:153-192: exact 4 nearest
+// posed vertices, blend-weight confidence, blended ober2cano transform, validity by the blended distance — before it is encoded;
+// the network then runs on EVERY sample, as the reference's does, and sigma is -1e5 where the sample is not valid (:305).  The
+// index is read where anr_knn_index_build left it (global memory, L2-resident: this kernel's LDS is the weight ring's), with the
+// routines of warp_core.h — the neighbours, canonical points and validity bits of anr_warp_points, hence the staged path's image
+// bit for bit.  Samples farther than dis_threshold from the body's box, or in a cell no vertex can reach (the reach mask), skip
+// the search as in the staged classify pass.  This is the north star's single pass WITH the warp; it is the dense evaluation
+// (the staged path's compaction of a whole frame's valid samples into full tiles is what a four-ray group cannot do) and is
+// measured next to it in DESIGN.md section 4.5.
+struct RmWarp {
+    const float* index;          // anr_knn_index_build's output, bs bodies
+    IndexDims d;
+    const float* o2c;            // ober2cano[bs][V][16]
+    const float* lbs_w;          // lbs_weights[V][J]
+    int J;
+    float thr;                   // dis_threshold
+    int64_t rays_per_body;       // ray r belongs to body r / rays_per_body
+};
+
+template <int MODE, bool WARP = false>
 struct RayMarch : Mlp<MODE, true, false, false, false, false, false, false, true> {
     using Base = Mlp<MODE, true, false, false, false, false, false, false, true>;
     using C = typename Base::C;
@@ -89,10 +110,48 @@ struct RayMarch : Mlp<MODE, true, false, false, false, false, false, false, true
         return make_float4(ry[0] + m[0], ry[1] + m[1], ry[2] + m[2], 1.0f);
     }
 
+    // (x_canonical, valid) of the sample at depth zz of the ray ry[8] of body (ray / rays_per_body): the staged classify pass's
+    // tests (box within dis_threshold, reach mask), then the exact search and the blend of warp_core.h on the lower half-wave —
+    // the upper one holds the same 32 points for the other half of the encoding and takes the result over
+    __device__ __forceinline__ float4 warped_point(const RmWarp& wp, const float* ry, float zz, int64_t ray) const {
+        const int b = (int)(ray / wp.rays_per_body);
+        const float* my_index = wp.index + (int64_t)b * wp.d.total_floats();
+        const float* gbox = my_index + wp.d.body_off();
+        const float px = __fadd_rn(ry[0], __fmul_rn(zz, ry[3]));
+        const float py = __fadd_rn(ry[1], __fmul_rn(zz, ry[4]));
+        const float pz = __fadd_rn(ry[2], __fmul_rn(zz, ry[5]));
+        bool near = half == 0 && box_d2(gbox, px, py, pz) < wp.thr * wp.thr;
+        const float reach_thr = gbox[3];
+        if (reach_thr >= wp.thr && near) {
+            const float inv = 1.0f / reach_cell_size(gbox, reach_thr);
+            const int rc = reach_cell(gbox, reach_thr, inv, px, py, pz);
+            const unsigned* reach = reinterpret_cast<const unsigned*>(my_index + wp.d.reach_off());
+            near = rc >= 0 && ((reach[rc >> 5] >> (rc & 31)) & 1u);
+        }
+        float4 res = make_float4(px, py, pz, 0.0f);
+        if (__any(near)) {
+            Best4 best;
+            best_init(best);
+            search(my_index, wp.d, px, py, pz, near, best);
+            if (near) {
+                const int32_t* order = reinterpret_cast<const int32_t*>(my_index + wp.d.order_off());
+                blend_and_store(best, order, wp.lbs_w, wp.J, wp.o2c + (int64_t)b * wp.d.V * 16, wp.thr, px, py, pz, 0, &res, nullptr,
+                                nullptr, nullptr, nullptr, nullptr);
+            }
+        }
+        const int src = (lane & 31) * 4;
+        res.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(res.x)));
+        res.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(res.y)));
+        res.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(res.z)));
+        res.w = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(res.w)));
+        return res;
+    }
+
     __device__ __forceinline__ void run(const char* __restrict__ pack_c, const char* __restrict__ pack_f, const float* __restrict__ rays,
                                         int stride, int64_t R, const float* __restrict__ steps_g, const float* __restrict__ u_g,
                                         int white_bkgd, float* __restrict__ rgb_c, float* __restrict__ dep_c, float* __restrict__ acc_c,
-                                        float* __restrict__ rgb_f, float* __restrict__ dep_f, float* __restrict__ acc_f, char* lds) {
+                                        float* __restrict__ rgb_f, float* __restrict__ dep_f, float* __restrict__ acc_f, char* lds,
+                                        const RmWarp& wp) {
         const int64_t n_groups = (R + G - 1) / G;
         if ((int64_t)blockIdx.x >= n_groups) return;          // (before anything is in flight into LDS)
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -170,13 +229,16 @@ struct RayMarch : Mlp<MODE, true, false, false, false, false, false, false, true
                 } else {
                     zz = seg[g].wbuf[k];
                 }
-                const float4 p = point_at(ry, zz);
+                float4 p;
+                if constexpr (WARP) p = warped_point(wp, ry, zz, r0 + g < R ? r0 + g : R - 1);
+                else p = point_at(ry, zz);
                 const bool last_pass = ps == NF_T;
                 lds_bias = ps ? bias_tab_f : bias_tab_c;
                 lds_bias_next = last_pass ? bias_tab_c : bias_tab_f;
                 gbase = last_pass ? first_c : first_f;
                 more = !(last_pass && last_group);
-                const float4 o = pass(p);
+                float4 o = pass(p);
+                if constexpr (WARP) o.w = (p.w < 1.0f) ? -1e5f : o.w;          // models/anim_nerf.py:305
                 if (half == 0) rows[i] = o;
                 if (ps != 0 && ps != NF_T) continue;           // (the fine tiles' rows are read after the second one)
                 __syncthreads();
@@ -245,22 +307,22 @@ struct RayMarch : Mlp<MODE, true, false, false, false, false, false, false, true
     }
 };
 
-template <int MODE>
+template <int MODE, bool WARP>
 __global__ __launch_bounds__(Cfg<MODE>::WAVES * 64, Cfg<MODE>::WAVES / 4) void ray_march_kernel(
     const char* __restrict__ pack_c, const char* __restrict__ pack_f, const float* __restrict__ rays, int stride, int64_t R,
     const float* __restrict__ steps, const float* __restrict__ u, int white_bkgd, float* __restrict__ rgb_c, float* __restrict__ dep_c,
-    float* __restrict__ acc_c, float* __restrict__ rgb_f, float* __restrict__ dep_f, float* __restrict__ acc_f) {
+    float* __restrict__ acc_c, float* __restrict__ rgb_f, float* __restrict__ dep_f, float* __restrict__ acc_f, RmWarp wp) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    RayMarch<MODE> m;
-    m.run(pack_c, pack_f, rays, stride, R, steps, u, white_bkgd, rgb_c, dep_c, acc_c, rgb_f, dep_f, acc_f, lds);
+    RayMarch<MODE, WARP> m;
+    m.run(pack_c, pack_f, rays, stride, R, steps, u, white_bkgd, rgb_c, dep_c, acc_c, rgb_f, dep_f, acc_f, lds, wp);
 }
 
-template <int MODE>
+template <int MODE, bool WARP>
 static int launch_ray_march(const void* pack_c, const void* pack_f, const float* rays, int stride, int64_t R, const float* steps,
                             const float* u, int white_bkgd, float* rgb_c, float* dep_c, float* acc_c, float* rgb_f, float* dep_f,
-                            float* acc_f, hipStream_t st) {
-    using RM = RayMarch<MODE>;
-    auto kern = ray_march_kernel<MODE>;
+                            float* acc_f, hipStream_t st, const RmWarp& wp) {
+    using RM = RayMarch<MODE, WARP>;
+    auto kern = ray_march_kernel<MODE, WARP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RM::LDS_BYTES);
     if (e != hipSuccess) return fail((int)e, "anr_ray_march: hipFuncSetAttribute: %s", hipGetErrorString(e));
     const int64_t n_groups = (R + RM::G - 1) / RM::G;
@@ -269,7 +331,7 @@ static int launch_ray_march(const void* pack_c, const void* pack_f, const float*
     dim3 grid((unsigned)(n_groups < cus ? n_groups : cus));   // one persistent workgroup per CU (LDS-limited)
     hipLaunchKernelGGL(kern, grid, dim3(RM::THREADS), RM::LDS_BYTES, st, reinterpret_cast<const char*>(pack_c),
                        reinterpret_cast<const char*>(pack_f), rays, stride, R, steps, u, white_bkgd, rgb_c, dep_c, acc_c, rgb_f, dep_f,
-                       acc_f);
+                       acc_f, wp);
     return check_launch("anr_ray_march");
 }
 
@@ -277,10 +339,9 @@ static int launch_ray_march(const void* pack_c, const void* pack_f, const float*
 
 using namespace anr;
 
-extern "C" int anr_ray_march(const void* pack_coarse, const void* pack_fine, int mode, const float* rays, int ray_stride, int64_t R,
-                             const float* steps, int Kc, const float* u, int Kf, int white_bkgd, float* rgb_coarse,
-                             float* depth_coarse, float* acc_coarse, float* rgb_fine, float* depth_fine, float* acc_fine,
-                             void* stream) {
+static int ray_march_any(const void* pack_coarse, const void* pack_fine, int mode, const float* rays, int ray_stride, int64_t R,
+                         const float* steps, int Kc, const float* u, int Kf, int white_bkgd, float* rgb_coarse, float* depth_coarse,
+                         float* acc_coarse, float* rgb_fine, float* depth_fine, float* acc_fine, const RmWarp* wp, void* stream) {
     ANR_REQUIRE(pack_coarse && pack_fine && rays && steps && u && rgb_coarse && depth_coarse && acc_coarse && rgb_fine && depth_fine &&
                 acc_fine, ANR_E_BADARG, "anr_ray_march: null pointer");
     ANR_REQUIRE(R > 0 && ray_stride >= 8, ANR_E_BADARG, "anr_ray_march: R=%lld stride=%d", (long long)R, ray_stride);
@@ -288,14 +349,41 @@ extern "C" int anr_ray_march(const void* pack_coarse, const void* pack_fine, int
                 Kc, Kf);
     ANR_REQUIRE((((uintptr_t)pack_coarse | (uintptr_t)pack_fine) & 15) == 0, ANR_E_ALIGN, "anr_ray_march: packs must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;
+    const RmWarp none{};
+#define ANR_RM(M)                                                                                                                    \
+    (wp ? launch_ray_march<M, true>(pack_coarse, pack_fine, rays, ray_stride, R, steps, u, white_bkgd, rgb_coarse, depth_coarse,    \
+                                    acc_coarse, rgb_fine, depth_fine, acc_fine, st, *wp)                                            \
+        : launch_ray_march<M, false>(pack_coarse, pack_fine, rays, ray_stride, R, steps, u, white_bkgd, rgb_coarse, depth_coarse,   \
+                                     acc_coarse, rgb_fine, depth_fine, acc_fine, st, none))
     switch (mode & 0xff) {
-        case ANR_MLP_F32:
-            return launch_ray_march<ANR_MLP_F32>(pack_coarse, pack_fine, rays, ray_stride, R, steps, u, white_bkgd, rgb_coarse, depth_coarse,
-                                                 acc_coarse, rgb_fine, depth_fine, acc_fine, st);
-        case ANR_MLP_BF16:
-            return launch_ray_march<ANR_MLP_BF16_W8>(pack_coarse, pack_fine, rays, ray_stride, R, steps, u, white_bkgd, rgb_coarse,
-                                                     depth_coarse, acc_coarse, rgb_fine, depth_fine, acc_fine, st);
-        default:
-            return fail(ANR_E_BADARG, "anr_ray_march: unknown mode %d", mode);
+        case ANR_MLP_F32:  return ANR_RM(ANR_MLP_F32);
+        case ANR_MLP_BF16: return ANR_RM(ANR_MLP_BF16_W8);
+        default:           return fail(ANR_E_BADARG, "anr_ray_march: unknown mode %d", mode);
     }
+#undef ANR_RM
+}
+
+extern "C" int anr_ray_march(const void* pack_coarse, const void* pack_fine, int mode, const float* rays, int ray_stride, int64_t R,
+                             const float* steps, int Kc, const float* u, int Kf, int white_bkgd, float* rgb_coarse,
+                             float* depth_coarse, float* acc_coarse, float* rgb_fine, float* depth_fine, float* acc_fine,
+                             void* stream) {
+    return ray_march_any(pack_coarse, pack_fine, mode, rays, ray_stride, R, steps, Kc, u, Kf, white_bkgd, rgb_coarse, depth_coarse,
+                         acc_coarse, rgb_fine, depth_fine, acc_fine, nullptr, stream);
+}
+
+extern "C" int anr_ray_march_warp(const void* pack_coarse, const void* pack_fine, int mode, const float* rays, int ray_stride, int bs,
+                                  int64_t rays_per_body, const float* steps, int Kc, const float* u, int Kf, int white_bkgd,
+                                  const void* knn_index, const float* ober2cano, const float* lbs_weights, int V, int J,
+                                  float dis_threshold, float* rgb_coarse, float* depth_coarse, float* acc_coarse, float* rgb_fine,
+                                  float* depth_fine, float* acc_fine, void* stream) {
+    ANR_REQUIRE(knn_index && ober2cano && lbs_weights, ANR_E_BADARG, "anr_ray_march_warp: null pointer");
+    ANR_REQUIRE(bs > 0 && rays_per_body > 0 && V >= 4 && J > 0 && J <= MAX_J && dis_threshold > 0.0f, ANR_E_BADARG,
+                "anr_ray_march_warp: bs=%d rays_per_body=%lld V=%d J=%d dis_threshold=%g", bs, (long long)rays_per_body, V, J, dis_threshold);
+    ANR_REQUIRE((((uintptr_t)knn_index | (uintptr_t)ober2cano) & 15) == 0, ANR_E_ALIGN, "anr_ray_march_warp: knn_index / ober2cano must be 16-B aligned");
+    RmWarp wp;
+    wp.index = reinterpret_cast<const float*>(knn_index);
+    wp.d = index_dims(V);
+    wp.o2c = ober2cano; wp.lbs_w = lbs_weights; wp.J = J; wp.thr = dis_threshold; wp.rays_per_body = rays_per_body;
+    return ray_march_any(pack_coarse, pack_fine, mode, rays, ray_stride, (int64_t)bs * rays_per_body, steps, Kc, u, Kf, white_bkgd,
+                         rgb_coarse, depth_coarse, acc_coarse, rgb_fine, depth_fine, acc_fine, &wp, stream);
 }

@@ -965,18 +965,32 @@ def composite_sample(rgbs, rays, u, white_bkgd: bool, *, z=None, steps=None, val
 
 
 def ray_march(pack_c: torch.Tensor, pack_f: torch.Tensor, mode: int, rays: torch.Tensor, steps: torch.Tensor, u: torch.Tensor,
-              white_bkgd: bool):
-    """The whole coarse -> fine render of rays[R, >=8] without the warp in ONE launch (anr_ray_march: 64 + 64 samples):
-    -> dict(rgb, depth, acc, rgb_fine, depth_fine, acc_fine), the bits of the staged launches."""
+              white_bkgd: bool, warp=None):
+    """The whole coarse -> fine render of rays[R, >=8] in ONE launch (anr_ray_march: 64 + 64 samples)
+    -> dict(rgb, depth, acc, rgb_fine, depth_fine, acc_fine), the bits of the staged launches.
+    warp = (knn_index[bs, bytes], ober2cano[bs,V,4,4], lbs_weights[V,J], dis_threshold, rays_per_body): the inverse-LBS / 4-NN
+    warp inside the pass (anr_ray_march_warp; rays in the bodies' root frames, R = bs * rays_per_body), dense evaluation."""
     lib = _lib.load()
     rays, steps, u = _dev(rays, "rays"), _dev(steps, "steps"), _dev(u, "u")
     R = rays.shape[0]
     new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=rays.device)
     o = dict(rgb=new(R, 3), depth=new(R, 1), acc=new(R, 1), rgb_fine=new(R, 3), depth_fine=new(R, 1), acc_fine=new(R, 1))
+    outs = (_ptr(o["rgb"]), _ptr(o["depth"]), _ptr(o["acc"]), _ptr(o["rgb_fine"]), _ptr(o["depth_fine"]), _ptr(o["acc_fine"]))
+    if warp is not None:
+        index, o2c, lbs_w, thr, per_body = warp
+        index, o2c, lbs_w = _dev(index, "knn_index", torch.uint8), _dev(o2c, "ober2cano"), _dev(lbs_w, "lbs_weights")
+        bs, V = o2c.shape[0], o2c.shape[1]
+        if R != bs * int(per_body):
+            raise ValueError(f"ray_march(warp=): {R} rays for {bs} bodies x {per_body} rays")
+        with _timed("ray_march_warp", R * (2 * steps.numel() + u.numel()), R * (32 + 40)):
+            _lib.check(lib.anr_ray_march_warp(_ptr(pack_c), _ptr(pack_f), mode & 0xff, _ptr(rays), rays.shape[-1], bs, int(per_body),
+                                              _ptr(steps), steps.numel(), _ptr(u), u.numel(), 1 if white_bkgd else 0, _ptr(index),
+                                              _ptr(o2c), _ptr(lbs_w), V, lbs_w.shape[1], float(thr), *outs, _stream(rays)),
+                       "anr_ray_march_warp")
+        return o
     with _timed("ray_march", R * (2 * steps.numel() + u.numel()), R * (32 + 40)):
         _lib.check(lib.anr_ray_march(_ptr(pack_c), _ptr(pack_f), mode & 0xff, _ptr(rays), rays.shape[-1], R, _ptr(steps), steps.numel(),
-                                     _ptr(u), u.numel(), 1 if white_bkgd else 0, _ptr(o["rgb"]), _ptr(o["depth"]), _ptr(o["acc"]),
-                                     _ptr(o["rgb_fine"]), _ptr(o["depth_fine"]), _ptr(o["acc_fine"]), _stream(rays)), "anr_ray_march")
+                                     _ptr(u), u.numel(), 1 if white_bkgd else 0, *outs, _stream(rays)), "anr_ray_march")
     return o
 
 

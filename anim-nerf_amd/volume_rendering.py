@@ -171,13 +171,16 @@ class VolumeRenderer(nn.Module):
         flat = rays.view(bs * R, -1)
         net_c, net_f = model._net(False), model._net(True)
         with torch.no_grad():
-            if not model.use_unpose and self.one_pass and Kc == 64 and self.n_fine == 64:
-                # the one-pass ray-march kernel (csrc/ray_march.hip): the whole render in ONE launch, same bits
+            if self.one_pass and Kc == 64 and self.n_fine == 64 and (not model.use_unpose or model.k_neigh == 4):
+                # the one-pass ray-march kernel (csrc/ray_march.hip): the whole render in ONE launch, same bits — with the warp
+                # inside the pass when the model has one (the dense evaluation: every sample through the networks)
                 pack, mode = net_c.weight_pack()
                 pack_f, mode_f = net_f.weight_pack()
                 if mode_f != mode:
                     raise ValueError("one_pass: the two networks run in one arithmetic mode")
-                o = ops.ray_march(pack, pack_f, mode, flat, steps, u, self.white_bkgd)
+                warp = ((model.knn_index(), model.ober2cano_transform.detach(), model.body_model.lbs_weights, model.dis_threshold, R)
+                        if model.use_unpose else None)
+                o = ops.ray_march(pack, pack_f, mode, flat, steps, u, self.white_bkgd, warp=warp)
                 fine = {"rgbs": o["rgb_fine"].view(bs, R, 3), "alphas": o["acc_fine"].view(bs, R, 1), "depths": o["depth_fine"].view(bs, R, 1)}
                 if self.share_fine:
                     return fine

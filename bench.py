@@ -241,7 +241,7 @@ def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling=
     rescale_sigma(model, args.sigma_gain, mode, dev)
     model.skip_invalid_samples = not dense
     vr = ana.VolumeRenderer(n_coarse=args.n_coarse, n_fine=args.n_fine, white_bkgd=True)
-    one_pass = bool(one_pass or getattr(args, "one_pass", False)) and not use_warp and args.n_coarse == 64 and args.n_fine == 64
+    one_pass = bool(one_pass or getattr(args, "one_pass", False)) and args.n_coarse == 64 and args.n_fine == 64
     vr.one_pass = one_pass
     H = W = args.hw
     c2w, focal, cen = syn.pinhole_camera(H, W)
@@ -264,7 +264,7 @@ def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling=
     elapsed, per_kernel, out = ctx.timed(step, steps, warmup)
     total_rays = (n_frame if strong else n_frame * world) * steps
     evals = args.n_coarse + (args.n_coarse + args.n_fine if args.n_fine else 0)
-    mlp_key = "ray_march" if one_pass else "mlp_forward"
+    mlp_key = ("ray_march_warp" if use_warp else "ray_march") if one_pass else "mlp_forward"
     mlp = per_kernel.get(mlp_key, {"units": 0})
     result = {
         "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -285,7 +285,8 @@ def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling=
             "mlp_points_per_step": mlp["units"] // max(steps, 1),
         },
         "roofline": mlp_roofline(per_kernel, mlp_key, mode, MLP_FLOP_PER_POINT,
-                                 f"ray_march_kernel<{mode}> (ONE launch per frame: stratified samples, point generation, Fourier encoding, both "
+                                 f"ray_march_kernel<{mode}{', warp' if use_warp else ''}> (ONE launch per frame: stratified samples, point generation, "
+                                 + ("inverse-LBS / exact 4-NN warp of EVERY sample, " if use_warp else "") + "Fourier encoding, both "
                                  "networks, compositing, importance sampling + merge; the fraction is the WHOLE kernel's)" if one_pass else
                                  f"mlp_kernel<{mode}> (fused Fourier encoding + 11 GEMMs)"),
         "kernel_time_share": {k: round(v["s"] / elapsed, 4) for k, v in per_kernel.items()},
@@ -299,7 +300,9 @@ def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling=
             st = ana.batched_inference(vr, model, sub, pose, templ, chunk=args.chunk)
             vr.one_pass = True
             op = ana.batched_inference(vr, model, sub, pose, templ, chunk=args.chunk)
-        result["config"]["launches_per_frame"] = "1 (anr_ray_march) + the per-frame set-up"
+        result["config"]["launches_per_frame"] = f"1 ({'anr_ray_march_warp' if use_warp else 'anr_ray_march'}) + the per-frame set-up"
+        if use_warp:
+            result["config"]["mlp_on_valid_samples_only"] = False     # the one-pass kernel evaluates every sample (the reference's way)
         result["equals_staged_launches_bit_for_bit"] = bool(all(torch.equal(st[k], op[k]) for k in st))
         result["equality_check_rays"] = int(idx.numel())
     # Everything around the MLP (sampling, point generation / warp, compaction, compositing, importance sampling) against
@@ -307,7 +310,7 @@ def render_bench(args, ctx, use_warp, mode, steps, warmup, dense=False, scaling=
     # once: what each wrapper in ops.py declares) / their summed HIP-event time; SURVEY.md section 8(d)'s compulsory figure
     # (52 B per ray + 36 B per sample, which counts a 16-B canonical point per sample even where no kernel moves one) is
     # kept beside it.  With the warp on the binding resource is VALU issue (exact KNN), not HBM.
-    others = {k: v for k, v in per_kernel.items() if k not in ("mlp_forward", "ray_march")}
+    others = {k: v for k, v in per_kernel.items() if k not in ("mlp_forward", "ray_march", "ray_march_warp")}
     other_s = sum(v["s"] for v in others.values())
     moved = sum(v["bytes"] for v in others.values())
     comp_bytes = n_rays * steps * (52 + 36 * evals)
@@ -802,6 +805,10 @@ def collect_extras(args, ctx):
             w["cfg3"] = extra(render_bench, args, ctx, True, args.mode, 3, 1, checks=True, check_rays=1024,
                               keep=("roofline_hbm_kernels", "kernel_time_share", "oracle_check", "cpu_baseline"))
             w["cfg3_dense"] = extra(render_bench, args, ctx, True, args.mode, 2, 1, dense=True)
+            # configs[2] as ONE launch per frame: the warp inside the one-pass kernel, every sample through the networks (the dense
+            # evaluation, like cfg3_dense and the reference) — the literal single pass of the north star next to the staged default
+            w["cfg3_one_pass"] = extra(render_bench, args, ctx, True, args.mode, 2, 1, one_pass=True,
+                                       keep=("equals_staged_launches_bit_for_bit", "equality_check_rays", "kernel_time_share"))
             w["cfg4"] = extra(train_bench_child, args, ctx, args.mode, 8, 4, keep=("kernel_time_share", "final_loss"))
             # the per-rank step of configs[3] on 8 GPUs: 2 of the batch's 16 frames (strong scaling's unit of work, on one GPU)
             w["cfg4_f2"] = extra(train_bench_child, args, ctx, args.mode, 16, 4, frames=2, keep=("kernel_time_share", "final_loss"))

@@ -767,6 +767,19 @@ int anr_frame_setup_rows(const int64_t* frame_idx, int table_rows, const float* 
 int anr_ray_march(const void* pack_coarse, const void* pack_fine, int mode, const float* rays, int ray_stride, int64_t R,
                   const float* steps, int Kc, const float* u, int Kf, int white_bkgd, float* rgb_coarse, float* depth_coarse,
                   float* acc_coarse, float* rgb_fine, float* depth_fine, float* acc_fine, void* stream);
+/* ... WITH the inverse-LBS / exact 4-nearest-vertex warp inside the pass (models/anim_nerf.py:153-192; use_unpose=True — BASELINE
+ * configs[2]): every sample is warped where it is generated — the staged classify pass's tests (within dis_threshold of the body's
+ * box, the reach mask), then the exact search and the blend of anr_warp_points on the index read from global memory — encoded, and
+ * the networks run on EVERY sample, sigma = -1e5 where the sample is not valid (:305): the reference's own dense evaluation in one
+ * launch.  rays[bs*rays_per_body*ray_stride] in the bodies' root frames (anr_rays_to_body / anr_frame_setup), knn_index from
+ * anr_knn_index_build[_reach] (bs bodies), ober2cano[bs*V*16], lbs_weights[V*J].  Returns the bits of the staged path (whose
+ * sparse evaluation — the networks on the valid samples of the whole frame, compacted — is several times faster: this entry
+ * point is the single-pass form of the north star, not the renderer's default). */
+int anr_ray_march_warp(const void* pack_coarse, const void* pack_fine, int mode, const float* rays, int ray_stride, int bs,
+                       int64_t rays_per_body, const float* steps, int Kc, const float* u, int Kf, int white_bkgd,
+                       const void* knn_index, const float* ober2cano, const float* lbs_weights, int V, int J, float dis_threshold,
+                       float* rgb_coarse, float* depth_coarse, float* acc_coarse, float* rgb_fine, float* depth_fine,
+                       float* acc_fine, void* stream);
 /* zero `bytes` (a multiple of 4) at a 4-byte aligned device address: a kernel, not a memset (a memset NODE of a captured HIP
  * graph went stale on ROCm 7.2: DESIGN.md section 4.4) */
 int anr_zero_fill(void* ptr, int64_t bytes, void* stream);

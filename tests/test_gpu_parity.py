@@ -1174,6 +1174,42 @@ def test_one_pass_ray_march_equals_the_staged_path(dev, smpl_table):
     assert rc < 0 and b"64 + 64" in lib.anr_last_error()
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_one_pass_ray_march_with_the_warp_equals_the_staged_path(dev, smpl_table, seed):
+    """anr_ray_march_warp: the one-pass kernel with the inverse-LBS / exact 4-NN warp INSIDE the pass (every sample warped where
+    it is generated — index read from global memory with the search and blend routines of warp_core.h —, every sample through
+    the networks, sigma masked where invalid) against the staged renderer (classify / cells / cell-sorted search / valid list /
+    MLP on the valid samples / masked compositors): two bodies with different poses per call, ray counts that are no multiple of
+    the kernel's four-ray groups (a group straddles the two bodies), random camera distance — every output tensor BIT FOR BIT in
+    fp32 and bf16.  The staged path's gates against the reference (accounting, tests above) are thereby this kernel's too."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import ops, synthetic as syn
+    rng = np.random.RandomState(100 + seed)
+    hw = int(rng.choice([17, 23]))
+    m = seeded_model(smpl_table, 30 + seed, True, 3000.0, (100.0, 100.0), device=dev)
+    pose_np = syn.animated_pose_params(seed=70 + seed, bs=2, pose_std=0.35, transl_z=float(rng.uniform(-4.0, -2.2)))
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in pose_np.items()}
+    c2w, focal, cen = syn.pinhole_camera(hw, hw)
+    rays = ana.gen_rays(torch.from_numpy(c2w).to(dev), hw, hw, focal.tolist(), 0.1, 10.0, cen.tolist()).view(1, -1, 8).repeat(2, 1, 1)
+    staged, fused = ana.VolumeRenderer(n_coarse=64, n_fine=64), ana.VolumeRenderer(n_coarse=64, n_fine=64)
+    staged.one_pass, fused.one_pass = False, True
+    for mode in ("f32", "bf16"):
+        m.nerf.mlp_mode = m.nerf_fine.mlp_mode = mode
+        with torch.no_grad():
+            ops.KERNEL_TIMING = []
+            a = ana.batched_inference(fused, m, rays, pose, _templ(dev), chunk=1 << 20)
+            names = {k[0] for k in ops.KERNEL_TIMING}
+            ops.KERNEL_TIMING = None
+            assert "ray_march_warp" in names and "warp_points" not in names and "mlp_forward" not in names, names
+            b = ana.batched_inference(staged, m, rays, pose, _templ(dev), chunk=1 << 20)
+            c = ana.batched_inference(fused, m, rays, pose, _templ(dev), chunk=101)
+        for k in b:
+            assert torch.equal(a[k], b[k]), (k, mode, hw)
+            assert torch.equal(a[k], c[k]), (k, mode, hw, "chunked")
+        assert b["alphas_fine"].max() > 0.2, "the bodies must be in view"
+        assert not torch.equal(b["rgbs_fine"][0], b["rgbs_fine"][1])
+
+
 def test_full_frame_properties_with_the_warp(dev, smpl_table):
     """1024 x 1024, 64 + 64, inverse-LBS / 4-NN warp on (BASELINE configs[2]) — the sparse machinery at its real size
     (64^3 cell grid, dead cells, 2^20-ray lists, validity bytes, coarse->fine reuse): determinism, chunk invariance,

@@ -81,6 +81,7 @@ def test_bad_arguments_are_reported_not_crashed():
         "anr_warp_points_reuse": (None, 0, None, 8, None, 4, None, None, None, 1, 6890, 24, 8, 0.2, 1) + (None,) * 13 + (0, None, None, None),
         # round 6: the one-pass ray-march kernel, the frame set-up with the pose tables' row count
         "anr_ray_march": (None, None, 1, None, 8, 4, None, 64, None, 64, 1) + (None,) * 7,
+        "anr_ray_march_warp": (None, None, 1, None, 8, 1, 4, None, 64, None, 64, 1, None, None, None, 6890, 24, 0.2) + (None,) * 7,
         "anr_frame_setup_rows": (None, 4) + (None, 1) + (None,) * 3 + (1,) + (None,) * 7 + (6890, 24, 10) + (None,) * 3 + (1, None, 8, 0) + (None,) * 15,
     }
     for name, args in calls.items():
@@ -208,7 +209,8 @@ def test_linked_library_holds_no_swapped_or_half_negated_packed_fp32():
     v_pk_add/mul/fma_f32 may swap an operand's halves (op_sel) or negate one half only — the forms the SLP vectoriser produced
     and that returned a wrong lane next to other kernels.  build() runs the same scan after linking and rejects
     the library; here it is run on the library the tests load, whatever built it.  The packed forms that ARE there are the
-    neighbour search's explicit float2 subtractions (both halves negated alike), listed so that a new kind shows up."""
+    neighbour search's explicit float2 subtractions (both halves negated alike, in every kernel that inlines warp_core.h's
+    scan_cluster), listed so that a new kind shows up."""
     import importlib.util
     import os
     import pytest
@@ -221,5 +223,6 @@ def test_linked_library_holds_no_swapped_or_half_negated_packed_fp32():
     forms = mod.packed_fp32_forms()
     assert not [f for f in forms if f[2]], [f for f in forms if f[2]][:5]
     kernels = {k for k, _, _ in forms}
-    assert all("warp" in k or "knn" in k for k in kernels), sorted(kernels)
+    # (the search's scan_cluster, inlined: the warp / KNN kernels and the one-pass kernel with the warp)
+    assert all("warp" in k or "knn" in k or "ray_march_kernelILi0ELb1" in k or "ray_march_kernelILi2ELb1" in k for k in kernels), sorted(kernels)
 
