@@ -1,3 +1,5 @@
+# A/B of the half tiles (same box).  The library without them is built first, on the build host:
+#   python anim-nerf_amd/build.py -DANR_HALF_TILES=0 --out=$PWD/anim-nerf_amd/libanimnerf_hip.nohalf.so
 mkdir -p gpurun_out/r06
 {
 echo "== half tiles"; python tools/bench_mlp_small.py
