@@ -114,7 +114,10 @@ struct RayMarch : Mlp<MODE, true, false, false, false, false, false, false, true
     // tests (box within dis_threshold, reach mask), then the exact search and the blend of warp_core.h on the lower half-wave —
     // the upper one holds the same 32 points for the other half of the encoding and takes the result over
     __device__ __forceinline__ float4 warped_point(const RmWarp& wp, const float* ry, float zz, int64_t ray) const {
-        const int b = (int)(ray / wp.rays_per_body);
+        // (a wavefront's 32 samples belong to ONE ray, hence one body: the index base is a scalar.  The tree walk's box reads —
+        // every lane the same box — still compile to vector loads: hipcc keeps uniform loads of plain global memory off the
+        // scalar unit in a kernel that stores.  A walk written on s_load through the constant cache is the lever section 4.5 names.)
+        const int b = __builtin_amdgcn_readfirstlane((int)(ray / wp.rays_per_body));
         const float* my_index = wp.index + (int64_t)b * wp.d.total_floats();
         const float* gbox = my_index + wp.d.body_off();
         const float px = __fadd_rn(ry[0], __fmul_rn(zz, ry[3]));
