@@ -252,23 +252,6 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(const char* __rest
     wgrad_body<BF16, TM, TN, WM>(dact, act, enc, n, args, partial, (int)blockIdx.x, lds);
 }
 
-// The three GEMM shapes of one weight-gradient call (256 x 256: trunk + xyz_encoding_final; 256 x 64: the encoding columns of
-// layers 1 and 5; 128 x 256: dir_encoding) in ONE launch (round 6): a workgroup takes its shape from its index.  At the
-// per-rank batch of the reference's 8-GPU run a call's five launches were 110 + 50 + 10 + 15 + 22 us of mostly latency, four
-// calls per step queued on two streams — what the step ended on (profiles/r06/train_step_timeline_f2.txt); together the three
-// shapes' 150-200 workgroups fit the chip at once.  Same tasks, same partial sums, same reduction: same bits.
-template <bool BF16>
-__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_shapes_kernel(const char* __restrict__ dact, const char* __restrict__ act,
-                                                                     const char* __restrict__ enc, int64_t n, WgradArgs a0, WgradArgs a1,
-                                                                     WgradArgs a2, float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int n0 = a0.n_gemms * a0.splits, n1 = a1.n_gemms * a1.splits;
-    const int b = (int)blockIdx.x;
-    if (b < n0) wgrad_body<BF16, 2, 4, 4>(dact, act, enc, n, a0, partial, b, lds);
-    else if (b < n0 + n1) wgrad_body<BF16, 1, 2, 8>(dact, act, enc, n, a1, partial, b - n0, lds);
-    else wgrad_body<BF16, 2, 2, 2>(dact, act, enc, n, a2, partial, b - n0 - n1, lds);
-}
-
 // ---- the two skinny heads as weighted column sums (their M side is g, 4 fp32 columns):
 //   d sigma.weight[c] = sum_p g[p][3] h8[p][c]     d rgb.weight[j][c] = sum_p g[p][j] G[p][c]     biases: sum_p g[p][j]
 // One workgroup per slice of rows.  A wave reads a whole row of h8 (256 columns, four per lane: one 8- / 16-byte load) or
@@ -289,24 +272,24 @@ __device__ __forceinline__ void load4(const T* p, float (&v)[4]) {
     }
 }
 
+// `block` of `n_blocks` slices; four wavefronts (threads 0..255) and 4 x CS_COLS floats of LDS
 template <typename T>
-__global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, const float* __restrict__ g4, int64_t n,
-                                                    int rows_per_slice, int sigma_only, int tangent, float* __restrict__ partial,
-                                                    const int32_t* __restrict__ count) {
-    __shared__ float sh[4][CS_COLS];
+__device__ __forceinline__ void heads_body(const T* __restrict__ act, const float* __restrict__ g4, int64_t n, int rows_per_slice,
+                                           int sigma_only, int tangent, float* __restrict__ partial, const int32_t* __restrict__ count,
+                                           int block, int n_blocks, float (*sh)[CS_COLS]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t n_rows = n;                                      // (n stays the buffer's row count: the block stride)
     if (count) {
         const int64_t cnt = *count;
         n_rows = cnt < n ? cnt : n;
-        rows_per_slice = (int)((n_rows + gridDim.x - 1) / gridDim.x);
+        rows_per_slice = (int)((n_rows + n_blocks - 1) / n_blocks);
     }
     // four consecutive columns per lane: block (first column / 32 + lane / 8), features 4 (lane % 8) of row r
     // (blocked by 32-feature tile and by 16-byte piece inside it, mlp_core.h: rows of a piece array are EPP elements apart)
     constexpr int EPP = 16 / (int)sizeof(T);
     const T* h8 = reinterpret_cast<const T*>(reinterpret_cast<const char*>(act) + act_elem_off(n, sizeof(T), 1792 / 32 + (lane >> 3), 4 * (lane & 7), 0));
     const T* gh = reinterpret_cast<const T*>(reinterpret_cast<const char*>(act) + act_elem_off(n, sizeof(T), 2304 / 32 + ((lane & 31) >> 3), 4 * (lane & 7), 0));
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_slice;
+    const int64_t r0 = (int64_t)block * rows_per_slice;
     int64_t r1 = r0 + rows_per_slice;
     if (r1 > n_rows) r1 = n_rows;
     constexpr int RIF = 4;
@@ -379,7 +362,40 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, c
     if (lane == 0) { sh[wave][640] = sb[0]; sh[wave][641] = sb[1]; sh[wave][642] = sb[2]; sh[wave][643] = sb[3]; }
     __syncthreads();
     for (int c = threadIdx.x; c < CS_COLS; c += 256)
-        partial[(int64_t)blockIdx.x * CS_COLS + c] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+        partial[(int64_t)block * CS_COLS + c] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ act, const float* __restrict__ g4, int64_t n,
+                                                    int rows_per_slice, int sigma_only, int tangent, float* __restrict__ partial,
+                                                    const int32_t* __restrict__ count) {
+    __shared__ float sh[4][CS_COLS];
+    heads_body<T>(act, g4, n, rows_per_slice, sigma_only, tangent, partial, count, (int)blockIdx.x, (int)gridDim.x, sh);
+}
+
+// The three GEMM shapes of one weight-gradient call (256 x 256: trunk + xyz_encoding_final; 256 x 64: the encoding columns of
+// layers 1 and 5; 128 x 256: dir_encoding) AND the skinny heads in ONE launch (round 6): a workgroup takes its shape from its
+// index.  At the per-rank batch of the reference's 8-GPU run a call's five launches were 110 + 50 + 10 + 15 + 22 us of mostly
+// latency, four calls per step queued on two streams — what the step ended on (profiles/r06/train_step_timeline_f2_first_box.txt);
+// together the shapes' 150-200 workgroups fit the chip at once.  Same tasks, same partial sums, same reduction: same bits.
+struct HeadsArgs { const float* g4; float* partial; int rows_per_slice, sigma_only, tangent, slices; };
+template <bool BF16>
+__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_shapes_kernel(const char* __restrict__ dact, const char* __restrict__ act,
+                                                                     const char* __restrict__ enc, int64_t n, WgradArgs a0, WgradArgs a1,
+                                                                     WgradArgs a2, float* __restrict__ partial, HeadsArgs hd) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int n0 = a0.n_gemms * a0.splits, n1 = a1.n_gemms * a1.splits, n2 = a2.n_gemms * a2.splits;
+    const int b = (int)blockIdx.x;
+    if (b < n0) wgrad_body<BF16, 2, 4, 4>(dact, act, enc, n, a0, partial, b, lds);
+    else if (b < n0 + n1) wgrad_body<BF16, 1, 2, 8>(dact, act, enc, n, a1, partial, b - n0, lds);
+    else if (b < n0 + n1 + n2) wgrad_body<BF16, 2, 2, 2>(dact, act, enc, n, a2, partial, b - n0 - n1, lds);
+    else {
+        // the heads' slices: the stand-alone kernel's four wavefronts, sums and order (the other four leave)
+        if (threadIdx.x >= 256) return;
+        using T = typename WgCfg<BF16>::T;
+        heads_body<T>(reinterpret_cast<const T*>(act), hd.g4, n, hd.rows_per_slice, hd.sigma_only, hd.tangent, hd.partial, a0.count,
+                      b - n0 - n1 - n2, hd.slices, reinterpret_cast<float (*)[CS_COLS]>(lds));
+    }
 }
 
 // ---- reduction over the slices + scatter into the 22 gradient tensors (flat, in the order of anr_mlp_wgrad_layout)
@@ -537,15 +553,32 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
         seg(L.db, 1, 128, 128, ws_off + 128 * 256, BLK, BLK, a.splits);
         ws_off += a.splits * BLK;
     }
-    // (ANR_WGRAD_SEPARATE=1: a launch per shape, as before round 6 — the A/B switch)
+    // ---- the skinny heads (sigma, rgb) and their biases: slices of rows, summed by the reduction like the GEMMs' partials
+    // (256 slices at most: the reduction below adds a segment's slices one after the other per element, and with 1,024
+    // slices of the heads' column sums it was that chain — not the 32 slices of the big GEMMs — that set its 50-60 us)
+    int slices = (int)((n + 127) / 128);
+    if (slices > 256) slices = 256;
+    const int rps = (int)((n + slices - 1) / slices);
+    slices = (int)((n + rps - 1) / rps);
+    float* heads_ws = ws + ws_off;
+    seg(L.sw, 1, 256, 256, ws_off, CS_COLS, CS_COLS, slices);
+    seg(L.sb, 1, 1, 1, ws_off + 643, CS_COLS, CS_COLS, slices);
+    if (!sigma_only) {
+        seg(L.rw, 1, 384, 384, ws_off + 256, CS_COLS, CS_COLS, slices);
+        seg(L.rb, 1, 3, 3, ws_off + 640, CS_COLS, CS_COLS, slices);
+    }
+    ws_off += slices * CS_COLS;
+    using T = typename C::T;
+    // (ANR_WGRAD_SEPARATE=1: a launch per shape and one for the heads, as before round 6 — the A/B switch)
     static const bool separate = getenv("ANR_WGRAD_SEPARATE") != nullptr;
     if (!separate) {
         auto k = wgrad_shapes_kernel<BF16>;
-        const int lds = lds_bytes(256, 256);                    // the largest of the three images
+        const int lds = lds_bytes(256, 256);                    // the largest of the three images (the heads' 10 KB fit it)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k, dim3(a0.n_gemms * a0.splits + a1.n_gemms * a1.splits + a2.n_gemms * a2.splits), dim3(WG_THREADS), lds, st, D, A,
-                           E, n, a0, a1, a2, ws);
+        const HeadsArgs hd{g4, heads_ws, rps, sigma_only, tangent, slices};
+        hipLaunchKernelGGL(k, dim3(a0.n_gemms * a0.splits + a1.n_gemms * a1.splits + a2.n_gemms * a2.splits + slices), dim3(WG_THREADS), lds,
+                           st, D, A, E, n, a0, a1, a2, ws, hd);
     } else {
         {
             auto k = wgrad_kernel<BF16, 2, 4, 4>;
@@ -568,25 +601,8 @@ static int wgrad_launch(const void* act, const void* dact, const void* enc, cons
             if (e != hipSuccess) return fail((int)e, "anr_mlp_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
             hipLaunchKernelGGL(k, dim3(a2.n_gemms * a2.splits), dim3(WG_THREADS), lds, st, D, A, E, n, a2, ws);
         }
-    }
-    // ---- the skinny heads (sigma, rgb) and their biases
-    {
-        // (256 slices at most: the reduction below adds a segment's slices one after the other per element, and with 1,024
-        // slices of the heads' column sums it was that chain — not the 32 slices of the big GEMMs — that set its 50-60 us)
-        int slices = (int)((n + 127) / 128);
-        if (slices > 256) slices = 256;
-        const int rps = (int)((n + slices - 1) / slices);
-        slices = (int)((n + rps - 1) / rps);
-        using T = typename C::T;
-        hipLaunchKernelGGL(heads_kernel<T>, dim3(slices), dim3(256), 0, st,
-                           reinterpret_cast<const T*>(act), g4, n, rps, sigma_only, tangent, ws + ws_off, count);
-        seg(L.sw, 1, 256, 256, ws_off, CS_COLS, CS_COLS, slices);
-        seg(L.sb, 1, 1, 1, ws_off + 643, CS_COLS, CS_COLS, slices);
-        if (!sigma_only) {
-            seg(L.rw, 1, 384, 384, ws_off + 256, CS_COLS, CS_COLS, slices);
-            seg(L.rb, 1, 3, 3, ws_off + 640, CS_COLS, CS_COLS, slices);
-        }
-        ws_off += slices * CS_COLS;
+        hipLaunchKernelGGL(heads_kernel<T>, dim3(slices), dim3(256), 0, st, reinterpret_cast<const T*>(act), g4, n, rps, sigma_only, tangent,
+                           heads_ws, count);
     }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(256, segs.n), dim3(256), 0, st, segs, ws, grads, accumulate);
     return check_launch("anr_mlp_wgrad");
