@@ -690,7 +690,10 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamChunk* __restrict__
     __shared__ bool last;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
+        // No fence in front of the ticket (round 6): the last workgroup reads nothing the others wrote — it only bumps the step
+        // counters, which every workgroup has read AND consumed (its bias corrections fed the stores above) before its thread 0
+        // gets here.  __threadfence() made each of the ~290 workgroups write the L2 back and invalidate it (buffer_wbl2 /
+        // buffer_inv sc1): most of the launch's 30 us.
         last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     }
     __syncthreads();
