@@ -2,7 +2,8 @@
 // opacity) — stratified coarse samples, point generation, Fourier encoding, the coarse network, alpha compositing, importance
 // sampling + sorted merge, the fine network on the Kc + Kf sorted samples and the final compositing in ONE launch, with nothing
 // per sample ever written to HBM.  This is BASELINE.json's "fused ray-march kernel that samples points, ..., Fourier-encodes, and
-// alpha-composites in one pass" for the configuration without the warp (use_unpose=False: configs[1], the headline workload);
+// alpha-composites in one pass" — anr_ray_march for the configuration without the warp (use_unpose=False: configs[1], the
+// headline workload), anr_ray_march_warp (template flag WARP, below) with every sample inverse-skinned inside the pass (configs[2]);
 // reference: models/volume_rendering.py:29-56 (sample_coarse), :113-160 (composite), :59-97 + :199-207 (sample_fine, merge),
 // :163-232 (forward); models/nerf.py:129-175; models/embedding.py:22-39.
 //
