@@ -226,3 +226,19 @@ def test_linked_library_holds_no_swapped_or_half_negated_packed_fp32():
     # (the search's scan_cluster, inlined: the warp / KNN kernels and the one-pass kernel with the warp)
     assert all("warp" in k or "knn" in k or "ray_march_kernelILi0ELb1" in k or "ray_march_kernelILi2ELb1" in k for k in kernels), sorted(kernels)
 
+
+def test_build_recipe_tracks_each_source_headers():
+    """anim-nerf_amd/build.py recompiles an object when its source, a header it includes (transitively) or its command line
+    changed: the dependency scan must see the headers the shared routines moved into this round (composite_core.h, warp_core.h)
+    behind the sources that include them, and the public header behind everything."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_anr_build_recipe3", os.path.join(ROOT, "anim-nerf_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    names = lambda src: {os.path.basename(p) for p in mod._deps(src)}
+    assert {"ray_march.hip", "mlp_core.h", "warp_core.h", "composite_core.h", "anr_common.h", "animnerf_hip.h"} <= names("ray_march.hip")
+    assert {"warp.hip", "warp_core.h", "anr_common.h", "animnerf_hip.h"} <= names("warp.hip") and "mlp_core.h" not in names("warp.hip")
+    assert {"composite.hip", "composite_core.h"} <= names("composite.hip")
+    assert all(h in mod.HEADERS for h in ("composite_core.h", "warp_core.h", "mlp_core.h"))
+    assert set(mod.SOURCES) == {f for f in os.listdir(mod.CSRC) if f.endswith(".hip")}, "every .hip source is in the recipe"
+
