@@ -91,6 +91,8 @@ SIGNATURES = {
     "anr_warp_points_lean": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _L, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "anr_warp_points_reuse": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _L, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I,
                                    _P, _P, _P]),
+    "anr_warp_points_cells": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _L, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I,
+                                   _P, _P, _P, _L, _P]),
     "anr_warp_points": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _L, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "anr_warp_backward": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P]),
     "anr_points_from_rays": (_I, [_P, _I, _P, _I, _L, _P, _P]),

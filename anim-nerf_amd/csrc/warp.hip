@@ -653,31 +653,70 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
     const int b = blockIdx.y;
     const float* gbox = index + (int64_t)b * d.total_floats() + d.body_off();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int VS = 4, STEPS = LEAN_ITERS / VS;
+    const uint32_t R32 = (uint32_t)(N / K);
+    auto sample_of = [&](int step, int v) { return (((int64_t)blockIdx.x * STEPS + step) * LEAN_THREADS + threadIdx.x) * VS + v; };
+    // ---- A0 (round 6): the rays, and whether a ray's line comes within thr of the body's box AT ALL (three slabs
+    // of the box padded by a little more than thr: a superset of the points with box_d2 < thr^2, margins far above the roundings).
+    // Most rays of a frame pass the body by: their samples are neither near nor copies of a valid coarse sample (those were
+    // classified by the same test), so their depths and permutation bytes — 20 of the pass's ~28 bytes per fine sample — are not
+    // read at all, and a workgroup that holds no other ray writes its zero bytes and ends before the first barrier.
+    uint32_t ray4[STEPS];
+    bool in[STEPS], act[STEPS];
+    float ro[STEPS][3], rd[STEPS][3], nr[STEPS], fr[STEPS];
+    bool any_act = false;
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+        const int64_t n0 = sample_of(step, 0);
+        in[step] = n0 < N;                                  // (N % 4 == 0: the four samples are in range together)
+        ray4[step] = in[step] ? (uint32_t)n0 / (uint32_t)K : 0u;                      // (N < 2^31 on this path)
+        const float* ry = rays + ((int64_t)b * R32 + ray4[step]) * ray_stride;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { ro[step][a] = in[step] ? ry[a] : 0.0f; rd[step][a] = in[step] ? ry[3 + a] : 0.0f; }
+        nr[step] = in[step] ? ry[6] : 0.0f; fr[step] = in[step] ? ry[7] : 0.0f;
+        // (the whole LINE, not the segment: true for any depth a caller passes)
+        const float pad = thr * 1.01f + 1.0e-4f;
+        float t0 = -3.0e38f, t1 = 3.0e38f;
+        bool hit = in[step];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float lo = gbox[a] - pad - ro[step][a], hi = gbox[4 + a] + pad - ro[step][a];
+            if (fabsf(rd[step][a]) > 1.0e-12f) {
+                const float inv = 1.0f / rd[step][a];
+                const float ta = lo * inv, tb = hi * inv;
+                t0 = fmaxf(t0, fminf(ta, tb));
+                t1 = fminf(t1, fmaxf(ta, tb));
+            } else if (lo > 0.0f || hi < 0.0f) {
+                hit = false;
+            }
+        }
+        act[step] = hit && t0 <= t1;
+        any_act |= act[step];
+    }
+    if (!__syncthreads_or(any_act ? 1 : 0)) {
+#pragma unroll
+        for (int step = 0; step < STEPS; ++step)
+            if (in[step]) *reinterpret_cast<unsigned*>(valid_mask + (int64_t)b * N + sample_of(step, 0)) = 0u;
+        return;
+    }
     if (CELLS) {
         for (int s = threadIdx.x; s < HN; s += LEAN_THREADS) { hkeys[s] = -1; hcnt[s] = 0; }
         __syncthreads();
     }
-    constexpr int VS = 4, STEPS = LEAN_ITERS / VS;
-    const uint32_t R32 = (uint32_t)(N / K);
     const float cell_inv = 1.0f / cell_size(gbox, thr, G);
     const float reach_thr = gbox[3];
     const bool masked = reach_thr >= thr;
     const float reach_inv = masked ? 1.0f / reach_cell_size(gbox, reach_thr) : 0.0f;
     const unsigned* __restrict__ reach = reinterpret_cast<const unsigned*>(index + (int64_t)b * d.total_floats() + d.reach_off());
-    auto sample_of = [&](int step, int v) { return (((int64_t)blockIdx.x * STEPS + step) * LEAN_THREADS + threadIdx.x) * VS + v; };
-    // ---- A: depths, permutation bytes, rays
+    // ---- A: depths, permutation bytes
     float zz[LEAN_ITERS];
     unsigned pm[STEPS];
-    uint32_t ray4[STEPS];
-    bool in[STEPS];
 #pragma unroll
     for (int step = 0; step < STEPS; ++step) {
         const int64_t n0 = sample_of(step, 0);
-        in[step] = n0 < N;                                  // (N % 4 == 0: the four samples are in range together)
         float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         pm[step] = 0u;
-        ray4[step] = in[step] ? (uint32_t)n0 / (uint32_t)K : 0u;                      // (N < 2^31 on this path)
-        if (in[step]) {
+        if (act[step]) {
             // (K % 4 == 0: the four samples are consecutive entries of one ray's step table)
             z4 = z_steps ? *reinterpret_cast<const float4*>(z + ((uint32_t)n0 - ray4[step] * (uint32_t)K))
                          : *reinterpret_cast<const float4*>(z + (int64_t)b * N + n0);
@@ -685,16 +724,12 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
         }
         zz[step * VS + 0] = z4.x; zz[step * VS + 1] = z4.y; zz[step * VS + 2] = z4.z; zz[step * VS + 3] = z4.w;
     }
-    float ro[STEPS][3], rd[STEPS][3];
 #pragma unroll
     for (int step = 0; step < STEPS; ++step) {
-        const float* ry = rays + ((int64_t)b * R32 + ray4[step]) * ray_stride;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { ro[step][a] = in[step] ? ry[a] : 0.0f; rd[step][a] = in[step] ? ry[3 + a] : 0.0f; }
         if (z_steps) {
 #pragma clang fp contract(off)                                     // (anr_sample_coarse rounds the two products and the sum separately;
             // HIP's __fmul_rn / __fadd_rn are plain operators, which this file's default would contract into an fma)
-            const float near = in[step] ? ry[6] : 0.0f, far = in[step] ? ry[7] : 0.0f;
+            const float near = nr[step], far = fr[step];
 #pragma unroll
             for (int v = 0; v < VS; ++v) {
                 const float sk = zz[step * VS + v];
@@ -715,10 +750,10 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
         px[it] = __fadd_rn(ro[step][0], __fmul_rn(zz[it], rd[step][0]));
         py[it] = __fadd_rn(ro[step][1], __fmul_rn(zz[it], rd[step][1]));
         pz[it] = __fadd_rn(ro[step][2], __fmul_rn(zz[it], rd[step][2]));
-        bool near = in[step] && box_d2(gbox, px[it], py[it], pz[it]) < thr * thr;
+        bool near = act[step] && box_d2(gbox, px[it], py[it], pz[it]) < thr * thr;
         m[it] = 0u; rw[it] = 0xffffffffu; rbit[it] = 0; src[it] = 0;
         bool reused = false;
-        if (in[step] && perm != nullptr) {
+        if (act[step] && perm != nullptr) {
             // this sorted sample IS coarse sample pj of the same ray: its canonical point and validity were computed in the
             // coarse pass
             const int pj = (int)((pm[step] >> (8 * v)) & 0xffu);
@@ -815,16 +850,37 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
 // cell_cap2[cell] = that squared radius, or -1 for a dead cell; defined for cells with a non-zero count only.
 __global__ __launch_bounds__(WARP_THREADS) void warp_cell_list_kernel(const int32_t* __restrict__ cell_count,
                                                                       int32_t* __restrict__ occ_list,
-                                                                      int32_t* __restrict__ occ_count) {
+                                                                      int32_t* __restrict__ occ_count,
+                                                                      const float* __restrict__ prev_cap2,
+                                                                      const int32_t* __restrict__ prev_seed,
+                                                                      float* __restrict__ cell_cap2,
+                                                                      int32_t* __restrict__ cell_seed) {
     // ids of the occupied cells, compacted (order preserved inside blocks of 4096 cells): the per-cell searches below
-    // then run with full wavefronts instead of one wavefront per 64 consecutive cells of which a few are occupied
+    // then run with full wavefronts instead of one wavefront per 64 consecutive cells of which a few are occupied.
+    // Round 6: a cell's radius and seed depend on the body, the grid and dis_threshold, not on the samples — the fine pass of a
+    // frame occupies the cells its coarse pass occupied (the same rays, sampled more densely where the surface is).  With
+    // prev_cap2 / prev_seed (the arrays of the earlier call's workspace: anr_warp_points_cells) a cell that call searched is
+    // copied and left off the list; every call leaves 0 = "not searched" in the cells it did not occupy, for a later one.
     __shared__ int wave_cnt[WARP_THREADS / 64];
     __shared__ int block_base;
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int first = (blockIdx.x * WARP_THREADS + threadIdx.x) * 4;
     const int4 v = *reinterpret_cast<const int4*>(cell_count + (int64_t)b * NCELL + first);
-    const int mine = (v.x > 0) + (v.y > 0) + (v.z > 0) + (v.w > 0);
+    float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 sd = make_int4(0, 0, 0, 0);
+    if (prev_cap2 != nullptr) {
+        cp = *reinterpret_cast<const float4*>(prev_cap2 + (int64_t)b * NCELL + first);
+        sd = *reinterpret_cast<const int4*>(prev_seed + (int64_t)b * NCELL + first);
+    }
+    if (v.x <= 0) cp.x = 0.f;
+    if (v.y <= 0) cp.y = 0.f;
+    if (v.z <= 0) cp.z = 0.f;
+    if (v.w <= 0) cp.w = 0.f;
+    const bool lx = v.x > 0 && cp.x == 0.f, ly = v.y > 0 && cp.y == 0.f, lz = v.z > 0 && cp.z == 0.f, lw = v.w > 0 && cp.w == 0.f;
+    *reinterpret_cast<float4*>(cell_cap2 + (int64_t)b * NCELL + first) = cp;
+    if (prev_cap2 != nullptr) *reinterpret_cast<int4*>(cell_seed + (int64_t)b * NCELL + first) = sd;
+    const int mine = (int)lx + (int)ly + (int)lz + (int)lw;
     int incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -842,10 +898,10 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cell_list_kernel(const int3
     __syncthreads();
     int pos = block_base + wave_cnt[wave] + incl - mine;
     int32_t* out = occ_list + (int64_t)b * NCELL;
-    if (v.x > 0) out[pos++] = first;
-    if (v.y > 0) out[pos++] = first + 1;
-    if (v.z > 0) out[pos++] = first + 2;
-    if (v.w > 0) out[pos++] = first + 3;
+    if (lx) out[pos++] = first;
+    if (ly) out[pos++] = first + 1;
+    if (lz) out[pos++] = first + 2;
+    if (lw) out[pos++] = first + 3;
 }
 
 // lanes per work item of the two search kernels: 64 when there is plenty of work, down to 8 when there is not
@@ -909,6 +965,8 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cells_kernel(const float* _
     // (cells are handed out by the counter, eight per trip: dead cells cost a few instructions and live ones a search — dealt out
     // statically (ItemDealer) the pass took 0.33 ms instead of 0.25; its ~20,000 trips are not what bounds it)
     constexpr int BATCH = 8;                             // cells per trip (4: 0.25 / 0.19 ms per call, 8: 0.19 / 0.16, 16: 0.21 / 0.19, 32: 0.29 / 0.28)
+    // (round 6: the list split over 4 or 2 counters 128 bytes apart, 8 / 4 / 2 cells per trip — no faster than this, fewer cells
+    // per trip slower: profiles/r06/ab_cells_cursors.txt.  It is the trip's latency a wavefront waits through, not the counter's rate)
     for (;;) {
         int first = 0;
         if (lane == 0) first = atomicAdd(occ_cursor + (int64_t)b * DEAL_INTS, BATCH);
@@ -1458,42 +1516,91 @@ extern "C" int anr_search_events_read(long long* host_out) {
 }
 #endif
 
-// lean mode: validity bytes -> list of the valid samples' flat positions for anr_mlp_forward_indexed, in sample order
-// (the MLP's gather of points and scatter of results then walk memory the way the rays were laid out); 4 bytes per thread
-// (16 bytes per thread and trip — a quarter of the trips to the counter — took 0.136 ms per call instead of 0.105)
-__global__ __launch_bounds__(WARP_THREADS) void warp_valid_list_kernel(const uint8_t* __restrict__ mask, int64_t n,
-                                                                       int32_t* __restrict__ valid_index,
-                                                                       int32_t* __restrict__ valid_count) {
-    __shared__ int wave_cnt[WARP_THREADS / 64];
+// lean mode: validity bytes -> list of the valid samples' flat positions for anr_mlp_forward_indexed, in sample order inside
+// every 64-KB span of the byte array (the MLP's gather of points and scatter of results then walk memory the way the rays
+// were laid out).  ONE TRIP TO THE COUNTER PER 64 KB: a workgroup's four wavefronts each hold 16 one-KB pieces in registers
+// (16 bytes per lane and piece, all sixteen loads in flight together), scan the lanes' counts of the pieces that hold anything
+// (most of a frame's pieces end at the ballot), add up, and thread 0 reserves the workgroup's range with one atomic; then every
+// non-empty piece goes through the wave's own 4 KB of LDS — positions written in order, copied out 64 consecutive dwords per
+// store.  A same-address returning atomic retires in ~10 ns on this part, whoever issues it: round 5's form (a 1,024-thread
+// workgroup, 4 bytes per thread, two barriers around thread 0's atomic per 4 KB) took 63 us per call on a configs[2] frame, a
+// wavefront per 1-KB piece with its own atomic and no barrier at all 175 us, this one 37 us (profiles/r06/ab_valid_list.txt).
+// (the last 16 bytes of an array whose length is not a multiple of 16, or an unaligned array: byte by byte, out of line)
+__device__ __noinline__ uint4 bytes16_guarded(const uint8_t* __restrict__ mask, int64_t i0, int64_t n) {
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+    for (int k = 0; k < 16; ++k)
+        if (i0 + k < n) w[k >> 2] |= (unsigned)mask[i0 + k] << (8 * (k & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+constexpr int VL_THREADS = 256;
+constexpr int VL_PIECES = 16;                                  // 1-KB pieces per wavefront: a workgroup takes 64 KB of the byte array
+constexpr int VL_SPAN = VL_PIECES * 1024 * (VL_THREADS / 64);
+__global__ __launch_bounds__(VL_THREADS) void warp_valid_list_kernel(const uint8_t* __restrict__ mask, int64_t n,
+                                                                     int32_t* __restrict__ valid_index,
+                                                                     int32_t* __restrict__ valid_count) {
+    __shared__ int32_t piece[VL_THREADS / 64][1024];
+    __shared__ int wave_tot[VL_THREADS / 64];
     __shared__ int block_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t n_blocks = (n + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
-    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const int64_t i0 = (blk * WARP_THREADS + threadIdx.x) * 4;
-        unsigned v = 0;
-        if (i0 + 3 < n) v = *reinterpret_cast<const unsigned*>(mask + i0);
-        else for (int k = 0; k < 4; ++k) if (i0 + k < n) v |= (unsigned)mask[i0 + k] << (8 * k);
-        const int mine = __popc(v & 0x01010101u);
-        int incl = mine;
+    int32_t* mine_lds = piece[wave];
+    const bool aligned = (reinterpret_cast<uintptr_t>(mask) & 15) == 0;
+    const int64_t w0 = (int64_t)blockIdx.x * VL_SPAN + (int64_t)wave * (VL_PIECES * 1024);
+    uint4 v[VL_PIECES];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
+    for (int p = 0; p < VL_PIECES; ++p) {
+        const int64_t i0 = w0 + p * 1024 + lane * 16;
+        v[p] = make_uint4(0u, 0u, 0u, 0u);
+        if (aligned && i0 + 15 < n) v[p] = *reinterpret_cast<const uint4*>(mask + i0);
+        else if (i0 < n) v[p] = bytes16_guarded(mask, i0, n);
+    }
+    int before[VL_PIECES];                                     // entries of the piece in front of this lane's 16 bytes
+    int tot[VL_PIECES];                                        // (wave-uniform) entries of the piece
+    int wave_sum = 0;
+#pragma unroll
+    for (int p = 0; p < VL_PIECES; ++p) {
+        v[p].x &= 0x01010101u; v[p].y &= 0x01010101u; v[p].z &= 0x01010101u; v[p].w &= 0x01010101u;
+        const int mine = __popc(v[p].x) + __popc(v[p].y) + __popc(v[p].z) + __popc(v[p].w);
+        before[p] = 0; tot[p] = 0;
+        if (__any(mine != 0)) {
+            int incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            before[p] = incl - mine;
+            tot[p] = __builtin_amdgcn_readlane(incl, 63);
+            wave_sum += tot[p];
         }
-        if (lane == 63) wave_cnt[wave] = incl;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tot = 0;
+    }
+    if (lane == 0) wave_tot[wave] = wave_sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
 #pragma unroll
-            for (int w = 0; w < WARP_THREADS / 64; ++w) { int c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
-            block_base = tot ? atomicAdd(valid_count, tot) : 0;
-        }
-        __syncthreads();
-        int pos = block_base + wave_cnt[wave] + incl - mine;
+        for (int w = 0; w < VL_THREADS / 64; ++w) { const int c = wave_tot[w]; wave_tot[w] = t; t += c; }
+        block_base = t ? atomicAdd(valid_count, t) : 0;
+    }
+    __syncthreads();
+    if (wave_sum == 0) return;
+    int base = block_base + wave_tot[wave];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if ((v >> (8 * k)) & 1u) valid_index[pos++] = (int32_t)(i0 + k);
-        __syncthreads();
+    for (int p = 0; p < VL_PIECES; ++p) {
+        if (tot[p] == 0) continue;
+        const int64_t i0 = w0 + p * 1024 + lane * 16;
+        int pos = before[p];
+        const unsigned w[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if ((w[k >> 2] >> (8 * (k & 3))) & 1u) mine_lds[pos++] = (int32_t)(i0 + k);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int e = lane; e < tot[p]; e += 64) valid_index[base + e] = mine_lds[e];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // (the next piece overwrites what was just read)
+        __builtin_amdgcn_wave_barrier();
+        base += tot[p];
     }
 }
 
@@ -1742,7 +1849,23 @@ extern "C" int anr_warp_points_reuse(const float* xyz, int xyz_stride, const flo
                                      int32_t* valid_count_out, const float* reuse_pts, const uint8_t* reuse_mask,
                                      const uint8_t* reuse_perm, int reuse_K, const int32_t* reuse_nbr_idx, const float* reuse_nbr_w,
                                      void* stream) {
+    return anr_warp_points_cells(xyz, xyz_stride, rays, ray_stride, z, K, knn_index, ober2cano, lbs_weights, bs, V, J, N, dis_threshold,
+                                 skip_far, pts_out, dist_out, idx_out, blended_out, nbr_idx_out, nbr_w_out, ws, valid_mask_out,
+                                 valid_index_out, valid_count_out, reuse_pts, reuse_mask, reuse_perm, reuse_K, reuse_nbr_idx,
+                                 reuse_nbr_w, nullptr, 0, stream);
+}
+
+extern "C" int anr_warp_points_cells(const float* xyz, int xyz_stride, const float* rays, int ray_stride, const float* z,
+                                     int K, const void* knn_index, const float* ober2cano, const float* lbs_weights, int bs,
+                                     int V, int J, int64_t N, float dis_threshold, int skip_far, float* pts_out,
+                                     float* dist_out, int32_t* idx_out, float* blended_out, int32_t* nbr_idx_out,
+                                     float* nbr_w_out, int32_t* ws, uint8_t* valid_mask_out, int32_t* valid_index_out,
+                                     int32_t* valid_count_out, const float* reuse_pts, const uint8_t* reuse_mask,
+                                     const uint8_t* reuse_perm, int reuse_K, const int32_t* reuse_nbr_idx, const float* reuse_nbr_w,
+                                     const int32_t* prev_ws, int64_t prev_N, void* stream) {
     const bool lean = valid_mask_out != nullptr;
+    ANR_REQUIRE(prev_ws == nullptr || (skip_far && ws != nullptr && prev_ws != ws && prev_N > 0), ANR_E_BADARG,
+                "anr_warp_points_cells: prev_ws is ANOTHER call's workspace (its N = prev_N > 0) and needs skip_far with a workspace");
     ANR_REQUIRE((reuse_pts != nullptr) == (reuse_perm != nullptr) && (reuse_mask == nullptr || reuse_pts != nullptr),
                 ANR_E_BADARG, "anr_warp_points: reuse_pts / reuse_perm (/ reuse_mask) go together");
     ANR_REQUIRE(reuse_pts == nullptr || (skip_far && ws != nullptr && xyz == nullptr && reuse_K > 0 && reuse_K <= K &&
@@ -1852,16 +1975,25 @@ extern "C" int anr_warp_points_reuse(const float* xyz, int xyz_stride, const flo
             if (lean) {
                 if (int rc = zero_fill(valid_count_out, sizeof(int32_t), st, "anr_warp_points_lean (zero)")) return rc;
                 const int64_t total = (int64_t)bs * N;
-                const int64_t vb = (total + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
-                hipLaunchKernelGGL(warp_valid_list_kernel, dim3((unsigned)(vb < 4096 ? vb : 4096)), dim3(WARP_THREADS), 0, st,
+                const int64_t vb = (total + VL_SPAN - 1) / VL_SPAN;
+                hipLaunchKernelGGL(warp_valid_list_kernel, dim3((unsigned)vb), dim3(VL_THREADS), 0, st,
                                    valid_mask_out, total, valid_index_out, valid_count_out);
                 return check_launch("anr_warp_points_lean (valid list)");
             }
             return 0;
         }
         if (int rc = allow_big_lds(warp_cells_kernel, bytes, "anr_warp_points")) return rc;
+        // (prev_ws: the cells an earlier call on this body / grid / threshold searched are copied, not searched again)
+        const float* prev_cap2 = nullptr;
+        const int32_t* prev_seed = nullptr;
+        if (prev_ws != nullptr && !(prev_N < (int64_t)1 << 19 && !getenv("ANR_WARP_CELLS_ALWAYS")) && grid_for(prev_N) == G &&
+            !getenv("ANR_WARP_NO_PREV_CELLS")) {
+            const WarpWs pw(const_cast<int32_t*>(prev_ws), bs, prev_N);
+            prev_cap2 = pw.cell_cap2;
+            prev_seed = pw.cell_seed;
+        }
         hipLaunchKernelGGL(warp_cell_list_kernel, dim3(cells / (4 * WARP_THREADS), bs), dim3(WARP_THREADS), 0, st, w.cell_count,
-                           w.occ_list, w.occ_count);
+                           w.occ_list, w.occ_count, prev_cap2, prev_seed, w.cell_cap2, w.cell_seed);
         hipLaunchKernelGGL(warp_cells_kernel, dim3((unsigned)(gx < cells / WARP_THREADS ? gx : cells / WARP_THREADS), bs),
                            dim3(WARP_THREADS), bytes, st, index, d, dis_threshold, w.occ_list, w.occ_count, w.occ_cursor,
                            w.cell_cap2, w.cell_seed, G);
@@ -1882,8 +2014,8 @@ extern "C" int anr_warp_points_reuse(const float* xyz, int xyz_stride, const flo
         if (lean) {
             if (int rc = zero_fill(valid_count_out, sizeof(int32_t), st, "anr_warp_points_lean (zero)")) return rc;
             const int64_t total = (int64_t)bs * N;
-            const int64_t vb = (total + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
-            hipLaunchKernelGGL(warp_valid_list_kernel, dim3((unsigned)(vb < 4096 ? vb : 4096)), dim3(WARP_THREADS), 0, st,
+            const int64_t vb = (total + VL_SPAN - 1) / VL_SPAN;
+            hipLaunchKernelGGL(warp_valid_list_kernel, dim3((unsigned)vb), dim3(VL_THREADS), 0, st,
                                valid_mask_out, total, valid_index_out, valid_count_out);
             return check_launch("anr_warp_points_lean (valid list)");
         }

@@ -400,15 +400,22 @@ def warp_points(index, o2c, lbs_weights, dis_threshold: float, *, xyz=None, rays
         r_k = r_pts.numel() // 4 // (bs * (N // K))
         if neighbours:
             r_nidx, r_nw = _dev(reuse[3], "reuse nbr_idx", torch.int32), _dev(reuse[4], "reuse nbr_w")
+    # (lean renderer: the coarse call's workspace rides on its validity bytes — `warp_cells` below — and the fine call that
+    # reuses those bytes copies the per-cell search results out of it instead of searching the cells again: anr_warp_points_cells)
+    prev_ws, prev_n = None, 0
+    if lean and r_mask is not None and dis_threshold == getattr(reuse[1], "warp_cells", (None, 0, None, None))[2] \
+            and reuse[1].warp_cells[3] == index.data_ptr():
+        prev_ws, prev_n = reuse[1].warp_cells[0], reuse[1].warp_cells[1]
     with _timed("warp_points", bs * N):
-        _lib.check(lib.anr_warp_points_reuse(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(index), _ptr(o2c),
+        _lib.check(lib.anr_warp_points_cells(_ptr(xyz), xs, _ptr(rays), rs, _ptr(z), K, _ptr(index), _ptr(o2c),
                                              _ptr(lbs_weights), bs, V, J, N, float(dis_threshold),
                                              ((3 if (workspace is not None and ws is not None) else 1) | (4 if steps is not None else 0)) if skip_far else 0,
                                              _ptr(pts), _ptr(dist), _ptr(idx), _ptr(blended), _ptr(nidx), _ptr(nw), _ptr(ws),
                                              _ptr(vmask), _ptr(vindex), _ptr(vcount), _ptr(r_pts), _ptr(r_mask), _ptr(r_perm),
-                                             r_k, _ptr(r_nidx), _ptr(r_nw), _stream(pts)),
+                                             r_k, _ptr(r_nidx), _ptr(r_nw), _ptr(prev_ws), prev_n, _stream(pts)),
                    "anr_warp_points")
     if lean:
+        vmask.warp_cells = (ws, N, dis_threshold, index.data_ptr())       # (keeps the workspace alive as long as the bytes)
         return pts, vmask, vindex, vcount
     if neighbours:
         return pts, nidx, nw

@@ -232,6 +232,25 @@ int anr_warp_points_reuse(const float* xyz, int xyz_stride,
                           const float* reuse_pts, const uint8_t* reuse_mask, const uint8_t* reuse_perm, int reuse_K,
                           const int32_t* reuse_nbr_idx, const float* reuse_nbr_w, void* stream);
 
+/* anr_warp_points_reuse + the per-cell results of an EARLIER call (round 6).  The cell-sorted search of a large call first
+ * searches once per occupied cell of a grid over the body (radius that holds every point's four neighbours, first cluster to
+ * scan, or "dead": no point of the cell can be valid); those results depend on the body (knn_index), the grid (64^3 from
+ * 2^19 samples per body on, else 32^3) and dis_threshold — not on the samples.  prev_ws = the workspace of an earlier call with
+ * the same knn_index, bs and dis_threshold (its N = prev_N; still intact: nothing has written to it since), e.g. the coarse
+ * pass of the frame whose fine pass this is: cells that call searched are copied instead of searched again (the fine samples
+ * of a ray fall into the cells its coarse samples fell into).  Ignored (a plain anr_warp_points_reuse) when either call is
+ * too small for the cell pass or their grids differ.  prev_ws = NULL: anr_warp_points_reuse.  Same outputs bit for bit. */
+int anr_warp_points_cells(const float* xyz, int xyz_stride,
+                          const float* rays, int ray_stride, const float* z, int K,
+                          const void* knn_index, const float* ober2cano, const float* lbs_weights,
+                          int bs, int V, int J, int64_t N, float dis_threshold, int skip_far,
+                          float* pts_out, float* dist_out, int32_t* idx_out, float* blended_out,
+                          int32_t* nbr_idx_out, float* nbr_w_out, int32_t* ws,
+                          uint8_t* valid_mask_out, int32_t* valid_index_out, int32_t* valid_count_out,
+                          const float* reuse_pts, const uint8_t* reuse_mask, const uint8_t* reuse_perm, int reuse_K,
+                          const int32_t* reuse_nbr_idx, const float* reuse_nbr_w,
+                          const int32_t* prev_ws, int64_t prev_N, void* stream);
+
 /* Backward of anr_warp_points (rays mode) for pose refinement (a16): d_pts[bs*N*4] (w component ignored) ->
  * d_ober2cano[bs*V*16] and d_rays[bs*R*8] (ACCUMULATED with atomics: zero them first), d_z[bs*N] (written).
  * nbr_idx / nbr_w are the training outputs of the forward. */

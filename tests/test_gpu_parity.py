@@ -345,6 +345,44 @@ def test_warp_small_batch_group_search_is_bit_identical(dev, smpl_table, bs, n_r
         assert n_valid == int(v.sum()) and torch.equal(lean[2][:n_valid].long().sort().values, v.view(-1).nonzero()[:, 0])
 
 
+def test_fine_call_copies_the_coarse_calls_cell_results(dev, smpl_table, monkeypatch):
+    """anr_warp_points_cells (round 6): the lean fine call of a frame takes the per-cell radii / seeds / dead flags out of the
+    coarse call's workspace (it rides on the coarse validity bytes, ops.warp_points) instead of searching those cells again.
+    Same validity bytes, same canonical points on the valid samples, same valid list as the call that searches every cell
+    itself (ANR_WARP_NO_PREV_CELLS) and as the exact search of every sample — with fine depths that reach cells the coarse
+    samples did not touch, and with no sample copied (perm = 255 everywhere: every fine sample is searched)."""
+    import anim_nerf_amd as ana
+    from anim_nerf_amd import synthetic as syn
+    m = seeded_model(smpl_table, 3, True, device=dev)
+    pose = {k: torch.from_numpy(v).to(dev) for k, v in syn.animated_pose_params(seed=17, bs=1, pose_std=0.3).items()}
+    hw = 128
+    c2w, focal, cen = syn.pinhole_camera(hw, hw)
+    full = ana.gen_rays(torch.from_numpy(c2w).to(dev), hw, hw, focal.tolist(), 0.1, 10.0, cen.tolist()).view(1, -1, 8)
+    with torch.no_grad():
+        m.set_body_model(pose, _templ(dev))
+        rays = m.convert_to_body_model_space(full.contiguous())
+        m.clac_ober2cano_transform()
+        zc = ana.VolumeRenderer(n_coarse=64).sample_coarse(rays)                 # 16,384 x 64 = 2^20 samples: the cell pass
+        args = (m.knn_index(), m.ober2cano_transform, m.body_model.lbs_weights, 0.2)
+        coarse = ana.ops.warp_points(*args, rays=rays, z=zc, skip_far=True, lean=True)
+        assert coarse[1].warp_cells[1] == zc.shape[1] * 64
+        # "fine" depths: 128 per ray, between and beyond the coarse ones
+        g = torch.Generator(device="cpu").manual_seed(3)
+        zf = (zc[..., :1] + (zc[..., -1:] - zc[..., :1]) * torch.rand(1, zc.shape[1], 128, generator=g).to(dev) * 1.02).sort(-1).values
+        perm = torch.full((1, zc.shape[1] * 128), 255, dtype=torch.uint8, device=dev)
+        with_prev = ana.ops.warp_points(*args, rays=rays, z=zf, skip_far=True, lean=True, reuse=(coarse[0], coarse[1], perm))
+        monkeypatch.setenv("ANR_WARP_NO_PREV_CELLS", "1")
+        without = ana.ops.warp_points(*args, rays=rays, z=zf, skip_far=True, lean=True, reuse=(coarse[0], coarse[1], perm))
+        monkeypatch.delenv("ANR_WARP_NO_PREV_CELLS")
+        exact = ana.ops.warp_points(*args, rays=rays, z=zf, skip_far=False)
+    v = exact[..., 3] == 1
+    assert 0.01 < v.float().mean() < 0.9
+    for got in (with_prev, without):
+        assert torch.equal(got[1].bool(), v) and torch.equal(got[0][v], exact[v])
+        n_valid = int(got[3].item())
+        assert n_valid == int(v.sum()) and torch.equal(got[2][:n_valid].long().sort().values, v.view(-1).nonzero()[:, 0])
+
+
 # ----------------------------------------------------------------------------- a11-a12
 @pytest.mark.parametrize("flag", [0, 0x100], ids=["lds_dma", "reg_staged"])
 def test_mlp_fp32_matches_reference(dev, smpl_table, flag):

@@ -79,6 +79,7 @@ def test_bad_arguments_are_reported_not_crashed():
         "anr_mc_emit": (None, 8, 8, 8, 0.0) + (None,) * 8,
         "anr_adam_step": (None, 1, None, None, 1, 0.9, 0.999, 1e-8, None),
         "anr_warp_points_reuse": (None, 0, None, 8, None, 4, None, None, None, 1, 6890, 24, 8, 0.2, 1) + (None,) * 13 + (0, None, None, None),
+        "anr_warp_points_cells": (None, 0, None, 8, None, 4, None, None, None, 1, 6890, 24, 8, 0.2, 1) + (None,) * 13 + (0, None, None, None, 0, None),
         # round 6: the one-pass ray-march kernel, the frame set-up with the pose tables' row count
         "anr_ray_march": (None, None, 1, None, 8, 4, None, 64, None, 64, 1) + (None,) * 7,
         "anr_ray_march_warp": (None, None, 1, None, 8, 1, 4, None, 64, None, 64, 1, None, None, None, 6890, 24, 0.2) + (None,) * 7,
