@@ -1074,13 +1074,14 @@ __global__ __launch_bounds__(1024) void warp_cell_scan_kernel(const int32_t* __r
 
 // counting-sort scatter of the near list by cell: a workgroup ranks 4096 consecutive list entries per cell in its
 // LDS hash table, reserves one range per distinct cell with a single global atomic, and places the entries
-__global__ __launch_bounds__(WARP_THREADS) void warp_cell_scatter_kernel(const int32_t* __restrict__ list,
-                                                                         const int32_t* __restrict__ cells,
-                                                                         const int32_t* __restrict__ count, int64_t N,
-                                                                         const int32_t* __restrict__ cell_start,
-                                                                         int32_t* __restrict__ cell_fill,
-                                                                         const float* __restrict__ cell_cap2,
-                                                                         int32_t* __restrict__ sorted) {
+template <int T, int E>
+__global__ __launch_bounds__(T) void warp_cell_scatter_kernel(const int32_t* __restrict__ list,
+                                                              const int32_t* __restrict__ cells,
+                                                              const int32_t* __restrict__ count, int64_t N,
+                                                              const int32_t* __restrict__ cell_start,
+                                                              int32_t* __restrict__ cell_fill,
+                                                              const float* __restrict__ cell_cap2,
+                                                              int32_t* __restrict__ sorted) {
     __shared__ int hkeys[HN], hcnt[HN];
     const int b = blockIdx.y;
     const int cnt = count[b];
@@ -1089,33 +1090,50 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cell_scatter_kernel(const i
     const int32_t* start = cell_start + (int64_t)b * NCELL;
     int32_t* fill = cell_fill + (int64_t)b * NCELL;
     const float* cap = cell_cap2 + (int64_t)b * NCELL;
-    for (int base = blockIdx.x * 4 * WARP_THREADS; base < cnt; base += gridDim.x * 4 * WARP_THREADS) {
-        for (int s = threadIdx.x; s < HN; s += WARP_THREADS) { hkeys[s] = -1; hcnt[s] = 0; }
-        __syncthreads();
-        int cell[4], slot[4], rank[4];
+    for (int base = blockIdx.x * E * T; base < cnt; base += gridDim.x * E * T) {
+        // (every load of a trip first: the entries' cells and the entries themselves, then the cells' dead flags)
+        int cell[E], entry[E], slot[E], rank[E];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = base + j * WARP_THREADS + threadIdx.x;
-            slot[j] = -1; rank[j] = 0; cell[j] = -1;
-            if (i < cnt) {
-                const int cl = my_cells[i];
-                if (!(cap[cl] < 0.f)) {                     // entries of dead cells are dropped here
-                    cell[j] = cl;
-                    slot[j] = hash_slot(hkeys, cl);
-                    if (slot[j] >= 0) rank[j] = atomicAdd(&hcnt[slot[j]], 1);
-                }
+        for (int j = 0; j < E; ++j) {
+            const int i = base + j * T + threadIdx.x;
+            cell[j] = i < cnt ? my_cells[i] : -1;
+            entry[j] = i < cnt ? my_list[i] : 0;
+        }
+        for (int s = threadIdx.x; s < HN; s += T) { hkeys[s] = -1; hcnt[s] = 0; }
+        float cp[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) cp[j] = cell[j] >= 0 ? cap[cell[j]] : -1.0f;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            slot[j] = -1; rank[j] = 0;
+            if (cp[j] < 0.f) cell[j] = -1;                  // entries of dead cells are dropped here
+            if (cell[j] >= 0) {
+                slot[j] = hash_slot(hkeys, cell[j]);
+                if (slot[j] >= 0) rank[j] = atomicAdd(&hcnt[slot[j]], 1);
             }
         }
         __syncthreads();
-        for (int s = threadIdx.x; s < HN; s += WARP_THREADS)
-            if (hkeys[s] >= 0) hcnt[s] = start[hkeys[s]] + atomicAdd(fill + hkeys[s], hcnt[s]);      // count -> base position
+        {
+            // count -> base position, one global atomic per distinct cell of the trip (all of a thread's slots in flight together)
+            constexpr int SL = HN / T;
+            int key[SL], st[SL], got[SL];
+#pragma unroll
+            for (int q = 0; q < SL; ++q) {
+                key[q] = hkeys[q * T + threadIdx.x];
+                st[q] = key[q] >= 0 ? start[key[q]] : 0;
+                got[q] = key[q] >= 0 ? atomicAdd(fill + key[q], hcnt[q * T + threadIdx.x]) : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < SL; ++q)
+                if (key[q] >= 0) hcnt[q * T + threadIdx.x] = st[q] + got[q];
+        }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = base + j * WARP_THREADS + threadIdx.x;
-            if (i < cnt && cell[j] >= 0) {
+        for (int j = 0; j < E; ++j) {
+            if (cell[j] >= 0) {
                 const int pos = slot[j] >= 0 ? hcnt[slot[j]] + rank[j] : start[cell[j]] + atomicAdd(fill + cell[j], 1);
-                sorted[(int64_t)b * N + pos] = my_list[i];
+                sorted[(int64_t)b * N + pos] = entry[j];
             }
         }
         __syncthreads();
@@ -2000,9 +2018,11 @@ extern "C" int anr_warp_points_cells(const float* xyz, int xyz_stride, const flo
         // (occ_list is dead once the cells kernel has run: it becomes the scatter's fill counters)
         hipLaunchKernelGGL(warp_cell_scan_kernel, dim3(cells / 4096, bs), dim3(1024), 0, st, w.cell_count, w.cell_start, w.cell_cap2,
                            w.occ_list, w.live, G);
+        // (threads x entries per trip: 512 x 4, 512 x 8, 1,024 x 8, twice the workgroups — all within 3 % of this by the kernel
+        // trace, profiles/r06/ab_scatter_shapes.txt; issuing a trip's loads first is what took the pass from 77 / 138 to 68 / 120 us)
         const int64_t sc_blocks = (N + 4 * WARP_THREADS - 1) / (4 * WARP_THREADS);
-        hipLaunchKernelGGL(warp_cell_scatter_kernel, dim3((unsigned)(sc_blocks < 1024 ? sc_blocks : 1024), bs), dim3(WARP_THREADS), 0, st,
-                           w.list, w.cells, w.count, N, w.cell_start, w.occ_list, w.cell_cap2, w.sorted);
+        hipLaunchKernelGGL((warp_cell_scatter_kernel<WARP_THREADS, 4>), dim3((unsigned)(sc_blocks < 1024 ? sc_blocks : 1024), bs),
+                           dim3(WARP_THREADS), 0, st, w.list, w.cells, w.count, N, w.cell_start, w.occ_list, w.cell_cap2, w.sorted);
         if (int rc = check_launch("anr_warp_points (bin)")) return rc;
         if (int rc = allow_big_lds(warp_search_kernel, bytes, "anr_warp_points")) return rc;
         const int64_t max_wg = (N + 64 * (WARP_THREADS / 64) - 1) / (64 * (WARP_THREADS / 64));
