@@ -659,10 +659,26 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
     // ---- A0 (round 6): the rays, and whether a ray's line comes within thr of the body's box AT ALL (three slabs
     // of the box padded by a little more than thr: a superset of the points with box_d2 < thr^2, margins far above the roundings).
     // Most rays of a frame pass the body by: their samples are neither near nor copies of a valid coarse sample (those were
-    // classified by the same test), so their depths and permutation bytes — 20 of the pass's ~28 bytes per fine sample — are not
-    // read at all, and a workgroup that holds no other ray writes its zero bytes and ends before the first barrier.
+    // classified by the same test), so a workgroup that holds
+    // no other ray writes its zero bytes and ends before the first barrier, and the other phases skip them.
     uint32_t ray4[STEPS];
     bool in[STEPS], act[STEPS];
+    // (the depths and permutation bytes are issued WITH the rays, not after the test: a ray that misses wastes 20 bytes per
+    // sample of a pass that is not short of bandwidth, a ray that hits saves a memory trip — fine call 0.63 -> 0.60 ms)
+    float4 z4e[STEPS];
+    unsigned pme[STEPS];
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+        const int64_t n0 = sample_of(step, 0);
+        z4e[step] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pme[step] = 0u;
+        if (n0 < N) {
+            // (K % 4 == 0: the four samples are consecutive entries of one ray's step table)
+            z4e[step] = z_steps ? *reinterpret_cast<const float4*>(z + ((uint32_t)n0 % (uint32_t)K))
+                                : *reinterpret_cast<const float4*>(z + (int64_t)b * N + n0);
+            if (perm != nullptr) pme[step] = *reinterpret_cast<const unsigned*>(perm + (int64_t)b * N + n0);
+        }
+    }
     float ro[STEPS][3], rd[STEPS][3], nr[STEPS], fr[STEPS];
     bool any_act = false;
 #pragma unroll
@@ -708,20 +724,13 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
     const bool masked = reach_thr >= thr;
     const float reach_inv = masked ? 1.0f / reach_cell_size(gbox, reach_thr) : 0.0f;
     const unsigned* __restrict__ reach = reinterpret_cast<const unsigned*>(index + (int64_t)b * d.total_floats() + d.reach_off());
-    // ---- A: depths, permutation bytes
+    // ---- A: depths, permutation bytes (loaded above)
     float zz[LEAN_ITERS];
     unsigned pm[STEPS];
 #pragma unroll
     for (int step = 0; step < STEPS; ++step) {
-        const int64_t n0 = sample_of(step, 0);
-        float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        pm[step] = 0u;
-        if (act[step]) {
-            // (K % 4 == 0: the four samples are consecutive entries of one ray's step table)
-            z4 = z_steps ? *reinterpret_cast<const float4*>(z + ((uint32_t)n0 - ray4[step] * (uint32_t)K))
-                         : *reinterpret_cast<const float4*>(z + (int64_t)b * N + n0);
-            if (perm != nullptr) pm[step] = *reinterpret_cast<const unsigned*>(perm + (int64_t)b * N + n0);
-        }
+        const float4 z4 = act[step] ? z4e[step] : make_float4(0.f, 0.f, 0.f, 0.f);
+        pm[step] = act[step] ? pme[step] : 0u;
         zz[step * VS + 0] = z4.x; zz[step * VS + 1] = z4.y; zz[step * VS + 2] = z4.z; zz[step * VS + 3] = z4.w;
     }
 #pragma unroll
@@ -771,6 +780,21 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
         near_bits |= (near ? 1u : 0u) << it;
         reused_bits |= (reused ? 1u : 0u) << it;
     }
+    // ---- B2: the reach bits settle which samples are listed; the workgroup's list range is reserved NOW, and the atomic's trip
+    // runs next to phase C's loads instead of after them (the pass is bound by the length of a thread's chain of dependent memory
+    // trips — rays / depths, validity bytes, points, the counter — times the threads a CU holds, not by bytes or instructions)
+#pragma unroll
+    for (int it = 0; it < LEAN_ITERS; ++it)
+        if (((near_bits >> it) & 1u) && ((rw[it] >> rbit[it]) & 1u) == 0u) near_bits &= ~(1u << it);      // no vertex can reach this cell
+    const int mine = __popc(near_bits);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_cnt[wave] = incl;
+    __syncthreads();
     // ---- C: the points of the valid coarse samples
     float4 rp[LEAN_ITERS];
 #pragma unroll
@@ -778,6 +802,13 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
         rp[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (m[it]) rp[it] = reuse_pts[src[it]];
     }
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < LEAN_THREADS / 64; ++w) { int c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
+        block_base = tot ? atomicAdd(count + b, tot) : 0;
+    }
+    __syncthreads();
     // ---- D: stores
     int my_cell[LEAN_ITERS];
 #pragma unroll
@@ -792,39 +823,19 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
                 mask_out |= m[it] << (8 * v);
                 if (m[it]) pts_out[o] = rp[it];
             } else if ((near_bits >> it) & 1u) {
-                if (((rw[it] >> rbit[it]) & 1u) == 0u) {     // no vertex can reach this cell
-                    near_bits &= ~(1u << it);
-                } else {
-                    pts_out[o] = make_float4(px[it], py[it], pz[it], 0.0f);
-                    if (CELLS) {
-                        const int cell = cell_of_inv(gbox, thr, G, cell_inv, px[it], py[it], pz[it]);
-                        my_cell[it] = cell;
-                        const int slot = hash_slot(hkeys, cell);
-                        if (slot >= 0) atomicAdd(&hcnt[slot], 1);
-                        else atomicAdd(cell_count + (int64_t)b * NCELL + cell, 1);
-                    }
+                pts_out[o] = make_float4(px[it], py[it], pz[it], 0.0f);
+                if (CELLS) {
+                    const int cell = cell_of_inv(gbox, thr, G, cell_inv, px[it], py[it], pz[it]);
+                    my_cell[it] = cell;
+                    const int slot = hash_slot(hkeys, cell);
+                    if (slot >= 0) atomicAdd(&hcnt[slot], 1);
+                    else atomicAdd(cell_count + (int64_t)b * NCELL + cell, 1);
                 }
             }
         }
         if (in[step]) *reinterpret_cast<unsigned*>(valid_mask + (int64_t)b * N + sample_of(step, 0)) = mask_out;
     }
     {
-        const int mine = __popc(near_bits);
-        int incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        if (lane == 63) wave_cnt[wave] = incl;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tot = 0;
-#pragma unroll
-            for (int w = 0; w < LEAN_THREADS / 64; ++w) { int c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
-            block_base = tot ? atomicAdd(count + b, tot) : 0;
-        }
-        __syncthreads();
         int64_t pos = (int64_t)b * N + block_base + wave_cnt[wave] + incl - mine;
 #pragma unroll
         for (int it = 0; it < LEAN_ITERS; ++it) {
