@@ -747,12 +747,14 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
             }
         }
     }
-    // ---- B: positions, the box test, the coarse samples' validity bytes, the reach-mask words
+    // ---- B: positions, the box test, the coarse samples' validity bytes, the reach-mask words.  Addresses first, then the eight
+    // loads UNCONDITIONALLY (a lane without a byte or a word to fetch reads element 0) and together: written as `if (...) load`
+    // per sample the compiler ended every sample's branch in a wait, four trips to L2 one behind the other.
     float px[LEAN_ITERS], py[LEAN_ITERS], pz[LEAN_ITERS];
     int64_t src[LEAN_ITERS];
     unsigned m[LEAN_ITERS], rw[LEAN_ITERS];
     unsigned near_bits = 0u, reused_bits = 0u;
-    int rbit[LEAN_ITERS];
+    int rbit[LEAN_ITERS], rword[LEAN_ITERS];
 #pragma unroll
     for (int it = 0; it < LEAN_ITERS; ++it) {
         const int step = it / VS, v = it % VS;
@@ -760,7 +762,7 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
         py[it] = __fadd_rn(ro[step][1], __fmul_rn(zz[it], rd[step][1]));
         pz[it] = __fadd_rn(ro[step][2], __fmul_rn(zz[it], rd[step][2]));
         bool near = act[step] && box_d2(gbox, px[it], py[it], pz[it]) < thr * thr;
-        m[it] = 0u; rw[it] = 0xffffffffu; rbit[it] = 0; src[it] = 0;
+        rbit[it] = 0; rword[it] = -1; src[it] = 0;
         bool reused = false;
         if (act[step] && perm != nullptr) {
             // this sorted sample IS coarse sample pj of the same ray: its canonical point and validity were computed in the
@@ -768,17 +770,29 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
             const int pj = (int)((pm[step] >> (8 * v)) & 0xffu);
             if (pj < reuse_K) {
                 src[it] = ((int64_t)b * R32 + ray4[step]) * reuse_K + pj;
-                m[it] = reuse_mask[src[it]];
                 reused = true;
                 near = false;
             }
         }
         if (masked && near) {
             const int rc = reach_cell(gbox, reach_thr, reach_inv, px[it], py[it], pz[it]);
-            if (rc >= 0) { rw[it] = reach[rc >> 5]; rbit[it] = rc & 31; } else { near = false; }
+            if (rc >= 0) { rword[it] = rc >> 5; rbit[it] = rc & 31; } else { near = false; }
         }
         near_bits |= (near ? 1u : 0u) << it;
         reused_bits |= (reused ? 1u : 0u) << it;
+    }
+#pragma unroll
+    for (int it = 0; it < LEAN_ITERS; ++it) m[it] = 0u;
+    if (perm != nullptr) {                                   // (uniform: the fine call)
+#pragma unroll
+        for (int it = 0; it < LEAN_ITERS; ++it) m[it] = reuse_mask[src[it]];
+    }
+#pragma unroll
+    for (int it = 0; it < LEAN_ITERS; ++it) rw[it] = reach[max(rword[it], 0)];
+#pragma unroll
+    for (int it = 0; it < LEAN_ITERS; ++it) {
+        if (!((reused_bits >> it) & 1u)) m[it] = 0u;
+        if (rword[it] < 0) rw[it] = 0xffffffffu;
     }
     // ---- B2: the reach bits settle which samples are listed; the workgroup's list range is reserved NOW, and the atomic's trip
     // runs next to phase C's loads instead of after them (the pass is bound by the length of a thread's chain of dependent memory
