@@ -355,7 +355,15 @@ constexpr int NCELL = GRID * GRID * GRID;      // stride of the per-body cell ar
 // One exact search per occupied cell pays off when a cell serves many samples.  A training batch (1,024 rays per body)
 // occupies about as many 64^3 cells as it has near samples; a 32^3 grid has an eighth of the cells to search and scan.
 __host__ inline int grid_for(int64_t samples_per_body) { return samples_per_body >= (int64_t)1 << 19 ? 64 : 32; }
-constexpr float MIN_CELL = 0.04f;
+// (round 6: 4 cm -> 3 cm.  The grid has 64 cells per axis over the body's box + 2 dis_threshold, so the bench's body gets
+// 3.2-cm cells: more cells for the per-cell pass (coarse call 132 -> 176 us) and a tighter reach for every item of the search
+// (fine call 1.84 -> 1.71 ms, coarse 0.80 -> 0.78): warp_points 4.05 -> 3.94 ms per configs[2] frame, profiles/r06/ab_min_cell.txt.
+// Ordering a cell's entries by octant on top — items of one or two octants instead of a random draw from the cell — bought the
+// search 3-5 % and cost more than that as its own pass: ab_suborder.txt, dropped.)
+#ifndef ANR_MIN_CELL_MM
+#define ANR_MIN_CELL_MM 30
+#endif
+constexpr float MIN_CELL = ANR_MIN_CELL_MM * 0.001f;
 
 // Work items of a persistent kernel, handed out WITHOUT A HOT COUNTER.  One atomicAdd per item on one address was the clock of
 // the search kernel: 86,760 items in 1.07 ms and 237,000 in 2.92 ms (the two passes of a cfg3 frame) are both 12.3 ns per
