@@ -673,6 +673,10 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
     bool in[STEPS], act[STEPS];
     // (the depths and permutation bytes are issued WITH the rays, not after the test: a ray that misses wastes 20 bytes per
     // sample of a pass that is not short of bandwidth, a ray that hits saves a memory trip — fine call 0.63 -> 0.60 ms)
+    // (sample -> ray: K is 64 or 128 on every shipped shape — a shift; the general 32-bit division is ~25 instructions of the ~700
+    // a wavefront of this pass executes)
+    const int k_shift = (K & (K - 1)) == 0 ? 31 - __builtin_clz((unsigned)K) : -1;
+    auto ray_of = [&](uint32_t n) { return k_shift >= 0 ? n >> k_shift : n / (uint32_t)K; };
     float4 z4e[STEPS];
     unsigned pme[STEPS];
 #pragma unroll
@@ -682,7 +686,7 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
         pme[step] = 0u;
         if (n0 < N) {
             // (K % 4 == 0: the four samples are consecutive entries of one ray's step table)
-            z4e[step] = z_steps ? *reinterpret_cast<const float4*>(z + ((uint32_t)n0 % (uint32_t)K))
+            z4e[step] = z_steps ? *reinterpret_cast<const float4*>(z + ((uint32_t)n0 - ray_of((uint32_t)n0) * (uint32_t)K))
                                 : *reinterpret_cast<const float4*>(z + (int64_t)b * N + n0);
             if (perm != nullptr) pme[step] = *reinterpret_cast<const unsigned*>(perm + (int64_t)b * N + n0);
         }
@@ -693,7 +697,7 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
     for (int step = 0; step < STEPS; ++step) {
         const int64_t n0 = sample_of(step, 0);
         in[step] = n0 < N;                                  // (N % 4 == 0: the four samples are in range together)
-        ray4[step] = in[step] ? (uint32_t)n0 / (uint32_t)K : 0u;                      // (N < 2^31 on this path)
+        ray4[step] = in[step] ? ray_of((uint32_t)n0) : 0u;                            // (N < 2^31 on this path)
         const float* ry = rays + ((int64_t)b * R32 + ray4[step]) * ray_stride;
 #pragma unroll
         for (int a = 0; a < 3; ++a) { ro[step][a] = in[step] ? ry[a] : 0.0f; rd[step][a] = in[step] ? ry[3 + a] : 0.0f; }
@@ -706,7 +710,7 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
         for (int a = 0; a < 3; ++a) {
             const float lo = gbox[a] - pad - ro[step][a], hi = gbox[4 + a] + pad - ro[step][a];
             if (fabsf(rd[step][a]) > 1.0e-12f) {
-                const float inv = 1.0f / rd[step][a];
+                const float inv = __builtin_amdgcn_rcpf(rd[step][a]);      // (1 ulp: the pad's margin is five orders above it)
                 const float ta = lo * inv, tb = hi * inv;
                 t0 = fmaxf(t0, fminf(ta, tb));
                 t1 = fminf(t1, fmaxf(ta, tb));
