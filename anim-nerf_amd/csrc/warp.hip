@@ -1017,9 +1017,24 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cells_kernel(const float* _
             const float cz = gbox[2] - thr + ((float)iz + 0.5f) * cs;
             int c_near = -1;
             float b_near = 3.0e38f;
-            for (int c = lane; c < d.NC; c += 64) {
-                const float v = box_d2(boxes + c * 8, cx, cy, cz);
-                if (v < b_near) { b_near = v; c_near = c; }
+            // (SMPL's 862 clusters are 14 per lane: the first sweep's box distances stay in registers for the second — a box test is
+            // ~14 instructions, the two sweeps were half of what the pass executes; larger meshes take the loops that test twice)
+            constexpr int BOX_ROUNDS = 14;
+            const bool cached = d.NC <= 64 * BOX_ROUNDS;
+            float bd[BOX_ROUNDS];
+            if (cached) {
+#pragma unroll
+                for (int q = 0; q < BOX_ROUNDS; ++q) {
+                    const int c = q * 64 + lane;
+                    const float v = box_d2(boxes + min(c, d.NC - 1) * 8, cx, cy, cz);
+                    bd[q] = c < d.NC ? v : 3.0e38f;
+                    if (bd[q] < b_near) { b_near = bd[q]; c_near = c; }
+                }
+            } else {
+                for (int c = lane; c < d.NC; c += 64) {
+                    const float v = box_d2(boxes + c * 8, cx, cy, cz);
+                    if (v < b_near) { b_near = v; c_near = c; }
+                }
             }
             if (wave_min(b_near) >= lim2) {
                 if (lane == 0) cap[cell] = -1.0f;
@@ -1032,10 +1047,24 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_cells_kernel(const float* _
             int who;
             wave_smallest4(best.d, sm, who);
             const float bound = sm[3];                   // >= d4^2: the 4th smallest of a subset of the vertices
-            for (int c = lane; c < d.NC; c += 64) {
-                if (c == c_near) continue;
-                const float v = box_d2(boxes + c * 8, cx, cy, cz);
-                if (v <= bound && v <= best.d[3]) scan_cluster(lds, d.Vp, c, cx, cy, cz, best);
+            if (cached) {
+                unsigned cand = 0u;                      // this lane's clusters inside the bound, one bit per round
+#pragma unroll
+                for (int q = 0; q < BOX_ROUNDS; ++q)
+                    if (q * 64 + lane != c_near && bd[q] <= bound) cand |= 1u << q;
+                while (__any(cand != 0u)) {
+                    if (cand != 0u) {
+                        const int c = __builtin_ctz(cand) * 64 + lane;
+                        cand &= cand - 1u;
+                        if (box_d2(boxes + c * 8, cx, cy, cz) <= best.d[3]) scan_cluster(lds, d.Vp, c, cx, cy, cz, best);
+                    }
+                }
+            } else {
+                for (int c = lane; c < d.NC; c += 64) {
+                    if (c == c_near) continue;
+                    const float v = box_d2(boxes + c * 8, cx, cy, cz);
+                    if (v <= bound && v <= best.d[3]) scan_cluster(lds, d.Vp, c, cx, cy, cz, best);
+                }
             }
             wave_smallest4(best.d, sm, who);
             const int nearest = __shfl(best.i[0], who, 64);
