@@ -658,6 +658,7 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
     __shared__ int wave_cnt[LEAN_THREADS / 64];
     __shared__ int block_base;
     __shared__ int hkeys[HN], hcnt[HN];
+    __shared__ float4 near_stage[LEAN_THREADS / 64][64];
     const int b = blockIdx.y;
     const float* gbox = index + (int64_t)b * d.total_floats() + d.body_off();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -835,41 +836,58 @@ __global__ __launch_bounds__(LEAN_THREADS) void warp_classify_lean_kernel(
         block_base = tot ? atomicAdd(count + b, tot) : 0;
     }
     __syncthreads();
-    // ---- D: stores
-    int my_cell[LEAN_ITERS];
+    // ---- D: stores.  The copied samples' bytes and points per thread, as laid out ...
 #pragma unroll
     for (int step = 0; step < STEPS; ++step) {
         unsigned mask_out = 0u;
 #pragma unroll
         for (int v = 0; v < VS; ++v) {
             const int it = step * VS + v;
-            const int64_t o = (int64_t)b * N + sample_of(step, v);
-            my_cell[it] = 0;
             if ((reused_bits >> it) & 1u) {
                 mask_out |= m[it] << (8 * v);
-                if (m[it]) pts_out[o] = rp[it];
-            } else if ((near_bits >> it) & 1u) {
-                pts_out[o] = make_float4(px[it], py[it], pz[it], 0.0f);
+                if (m[it]) pts_out[(int64_t)b * N + sample_of(step, v)] = rp[it];
+            }
+        }
+        if (in[step]) *reinterpret_cast<unsigned*>(valid_mask + (int64_t)b * N + sample_of(step, 0)) = mask_out;
+    }
+    // ... and the NEAR samples (9 % of a frame's, but some in almost every wavefront) on DENSE lanes: a near sample's work — its
+    // cell, the hash table, its point, its list entry and its cell entry: ~60 instructions — ran once per sample slot of the
+    // thread, four times per wavefront with a few lanes active each time.  The wave's near samples already have consecutive list
+    // positions (the scan above), so they are handed over through 1 KB of the wave's LDS, 64 at a time, to the lanes in list
+    // order: one pass of full lanes for most wavefronts, and list / cells stores that are consecutive dwords.
+    {
+        const int wave_first = incl - mine;                                   // this thread's first near sample among the wave's
+        const int wave_total = __builtin_amdgcn_readlane(incl, 63);
+        const int64_t list_base = (int64_t)b * N + block_base + wave_cnt[wave];
+        float4* mine_stage = near_stage[wave];
+        for (int r0 = 0; r0 < wave_total; r0 += 64) {
+            int k = wave_first;
+#pragma unroll
+            for (int it = 0; it < LEAN_ITERS; ++it) {
+                if ((near_bits >> it) & 1u) {
+                    if (k >= r0 && k < r0 + 64)
+                        mine_stage[k - r0] = make_float4(px[it], py[it], pz[it], __int_as_float((int)sample_of(it / VS, it % VS)));
+                    ++k;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (r0 + lane < wave_total) {
+                const float4 e = mine_stage[lane];
+                const int sid = __float_as_int(e.w);
+                pts_out[(int64_t)b * N + sid] = make_float4(e.x, e.y, e.z, 0.0f);
+                list[list_base + r0 + lane] = sid;
                 if (CELLS) {
-                    const int cell = cell_of_inv(gbox, thr, G, cell_inv, px[it], py[it], pz[it]);
-                    my_cell[it] = cell;
+                    const int cell = cell_of_inv(gbox, thr, G, cell_inv, e.x, e.y, e.z);
+                    cells[list_base + r0 + lane] = cell;
                     const int slot = hash_slot(hkeys, cell);
                     if (slot >= 0) atomicAdd(&hcnt[slot], 1);
                     else atomicAdd(cell_count + (int64_t)b * NCELL + cell, 1);
                 }
             }
-        }
-        if (in[step]) *reinterpret_cast<unsigned*>(valid_mask + (int64_t)b * N + sample_of(step, 0)) = mask_out;
-    }
-    {
-        int64_t pos = (int64_t)b * N + block_base + wave_cnt[wave] + incl - mine;
-#pragma unroll
-        for (int it = 0; it < LEAN_ITERS; ++it) {
-            if ((near_bits >> it) & 1u) {
-                list[pos] = (int32_t)sample_of(it / VS, it % VS);
-                if (CELLS) cells[pos] = my_cell[it];
-                ++pos;
-            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // (the next round overwrites what was just read)
+            __builtin_amdgcn_wave_barrier();
         }
     }
     if (!CELLS) return;
